@@ -1,0 +1,1647 @@
+// freddie_seg.hip -- gfx950 (MI355X) kernels and C-ABI of the canonical-segmentation path.
+//
+// What each kernel computes is defined by the reference's py/freddie_segment.py (cited per
+// kernel as file:line); how it computes it is specific to this implementation:
+//   * a batch of independent partitions lives in HBM as flat CSR arrays (include/freddie_seg.h);
+//   * every data-dependent size (candidates, DP problems, final positions, label bytes) is
+//     produced and consumed on the device; the host only reads one small status record at the
+//     end of a run and grows an arena + re-runs when a capacity was exceeded, so the steady
+//     state has no host synchronisation inside the pipeline;
+//   * the interval-scoring stage never materialises the reference's (N+1)xR uint32 coverage
+//     matrix: per DP problem it derives, for 64 reads at a time, the window-local coverage
+//     prefix of each read from its exon list, turns the n*(n-1)/2 pair tests into 1-bit planes
+//     in LDS, and counts out(i,j,k) with AND + popcount into an LDS-resident table.
+//
+// No CPU fallback exists in this library: without a GPU fseg_create() fails.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "freddie_seg.h"
+
+namespace {
+
+typedef long long i64;
+typedef unsigned long long u64;
+
+constexpr int kSmoothTile = 1024;      // positions per smoothing / peak tile
+constexpr int kMaxRadius = 200;        // sigma <= 50, truncate 4.0 (py/freddie_segment.py:106,:755)
+constexpr int kScanBlock = 2048;       // elements per scan workgroup
+constexpr int kNMax = 60;              // largest DP problem handled by the LDS-resident scoring kernel
+constexpr int kLaneChunk = 4096;       // reads ("lanes") per scoring work item (must stay < 65536: u16 counters)
+constexpr int kSub = 64;               // reads per scoring sub-chunk (two 32-bit plane words)
+constexpr i64 kNegInf = (i64)(-0x7fffffffffffffffLL - 1);
+
+// error bits of Status::err
+enum : unsigned {
+    kErrExonInterval = 1u,     // an exon is not inside one tint interval (py/freddie_segment.py:668)
+    kErrBreakAssert = 2u,      // break_large_problems: assert max_c_idx_y_v > 0 / index out of range (:640-643)
+    kErrProblemTooLarge = 4u,  // a DP problem has more than kNMax candidates
+    kErrOverflowPairs = 8u,
+    kErrOverflowTri = 16u,
+    kErrOverflowWork = 32u,
+    kErrOverflowLabels = 64u,
+    kErrOverflowProblems = 128u,
+    kErrOverflowChunks = 256u,
+};
+
+struct Status {
+    unsigned err;
+    unsigned pad;
+    u64 n_vals;        // number of Y > 0 values (all partitions)
+    u64 n_vchunks;     // 8192-element chunks of the threshold reduction
+    u64 n_cand;
+    u64 n_prob;
+    u64 n_work;
+    u64 pair_used;
+    u64 tri_used;
+    u64 n_rseg;
+    u64 n_final;
+    u64 label_bytes;
+    u64 work_queue;    // dynamic work counter of the scoring kernel
+    u64 dp_queue;
+};
+
+// ---------------------------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// index of the last element of a[0..n) that is <= x  (a ascending, a[0] <= x)
+template <typename T, typename X>
+__device__ __forceinline__ i64 last_le(const T *a, i64 n, X x) {
+    i64 lo = 0, hi = n;   // invariant: a[lo] <= x (if any), answer in [lo, hi)
+    while (hi - lo > 1) {
+        i64 mid = (lo + hi) >> 1;
+        if ((X)a[mid] <= x) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ i64 reflect_index(i64 i, i64 n) {
+    if (n == 1) return 0;
+    i64 p = 2 * n;
+    i %= p;
+    if (i < 0) i += p;
+    return i < n ? i : p - 1 - i;
+}
+
+// Integer forms of the reference's floating-point label tests (py/freddie_segment.py:490-495,
+// :816-828): with c = cov/L in IEEE double, `c > h`  <=>  cov >= hi  and  `c < 1-h`  <=>  cov <= lo,
+// where hi = min{v : fl(v/L) > h}, lo = max{v : fl(v/L) < fl(1-h)} (fl(v/L) is monotone in v).
+__device__ __forceinline__ void label_thresholds(i64 L, const double *h_table, int h_len, double tau, int *hi_out,
+                                                 int *lo_out) {
+    double h = L < (i64)h_len ? h_table[L] : tau;   // get_high_threshold :269-274
+    double l = 1.0 - h;
+    double dL = (double)L;
+    i64 v = (i64)floor(h * dL);
+    if (v < 0) v = 0;
+    while (v > 0 && (double)(v - 1) / dL > h) --v;
+    while (!((double)v / dL > h) && v <= L + 1) ++v;
+    *hi_out = (int)v;
+    i64 u = (i64)ceil(l * dL);
+    if (u > L) u = L;
+    while (u >= 0 && !((double)u / dL < l)) --u;
+    while ((double)(u + 1) / dL < l && u < L) ++u;
+    *lo_out = (int)u;
+}
+
+// ---------------------------------------------------------------------------------------------
+// S1  splice histogram   (process_splicing_data, py/freddie_segment.py:648-678)
+// one thread per read rep; integer counts, so atomic adds are order-independent
+// ---------------------------------------------------------------------------------------------
+__global__ void k_hist(int n_part, const i64 *part_rep_off, const i64 *part_iv_off, const int *iv_start,
+                       const int *iv_end, const i64 *pos_off, const int *rep_weight, const i64 *rep_exon_off,
+                       const int *ex_ts, const int *ex_te, int ignore_ends, int *y_raw, Status *st) {
+    i64 n_rep = part_rep_off[n_part];
+    for (i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x; r < n_rep; r += (i64)gridDim.x * blockDim.x) {
+        int p = (int)last_le(part_rep_off, (i64)n_part + 1, r);
+        i64 k0 = part_iv_off[p], k1 = part_iv_off[p + 1];
+        int w = rep_weight[r];
+        i64 e0 = rep_exon_off[r], e1 = rep_exon_off[r + 1];
+        for (i64 e = e0; e < e1; ++e) {
+            int ts = ex_ts[e], te = ex_te[e];
+            bool ok = k1 > k0 && ts >= iv_start[k0];
+            i64 k = k0;
+            if (ok) {
+                k = k0 + last_le(iv_start + k0, k1 - k0, ts);
+                ok = ts <= iv_end[k] && te >= iv_start[k] && te <= iv_end[k];   // :666-668
+            }
+            if (!ok) { atomicOr(&st->err, kErrExonInterval); continue; }
+            i64 base = pos_off[k] - iv_start[k];
+            if (!(ignore_ends && e == e0)) atomicAdd(&y_raw[base + ts], w);          // :670-671
+            if (!(ignore_ends && e == e1 - 1)) atomicAdd(&y_raw[base + te], w);      // :672-673
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// S2  Gaussian smoothing, fp64   (gaussian_filter1d(y, sigma, truncate=4.0), :755)
+// out[l] = x[l]*w[0]; for j = radius..1: out += (x[l-j] + x[l+j]) * w[j]   -- farthest pair first,
+// separate multiply and add (no FMA), 'reflect' boundary.  One workgroup per tile of positions; the
+// tile plus its halo is staged in LDS as int32 (the histogram holds exact small integers).
+// Also writes the flag Y > 0 used by the threshold stage.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_smooth(int n_tiles, const int *tile_iv, const int *tile_y0,
+                                                const i64 *pos_off, const int *y_raw, const double *w_g, int radius,
+                                                double *y_out, unsigned char *flag_pos) {
+    __shared__ int xs[kSmoothTile + 2 * kMaxRadius];
+    __shared__ double ws[kMaxRadius + 1];
+    for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        int k = tile_iv[t];
+        i64 y0 = tile_y0[t];
+        i64 base = pos_off[k];
+        i64 len = pos_off[k + 1] - base;
+        __syncthreads();
+        for (int j = threadIdx.x; j <= radius; j += blockDim.x) ws[j] = w_g[j];
+        int span = kSmoothTile + 2 * radius;
+        for (int idx = threadIdx.x; idx < span; idx += blockDim.x) {
+            i64 y = y0 - radius + idx;
+            xs[idx] = y_raw[base + reflect_index(y, len)];
+        }
+        __syncthreads();
+        for (int o = threadIdx.x; o < kSmoothTile; o += blockDim.x) {
+            i64 y = y0 + o;
+            if (y >= len) break;
+            int c = o + radius;
+            double acc = __dmul_rn((double)xs[c], ws[0]);
+            for (int j = radius; j >= 1; --j) {
+                int s = xs[c - j] + xs[c + j];
+                acc = __dadd_rn(acc, __dmul_rn((double)s, ws[j]));
+            }
+            y_out[base + y] = acc;
+            flag_pos[base + y] = acc > 0.0 ? 1 : 0;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// exclusive prefix sum of byte flags (three small kernels; used for the three compactions)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wg_exclusive_scan(int v, int *lds /* >= 16 ints */, int *total) {
+    int lane = lane_id(), wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    int x = v;
+    for (int d = 1; d < 64; d <<= 1) {
+        int y = __shfl_up(x, d);
+        if (lane >= d) x += y;
+    }
+    __syncthreads();
+    if (lane == 63) lds[wave] = x;
+    __syncthreads();
+    int off = 0, tot = 0;
+    for (int w = 0; w < nw; ++w) {
+        int s = lds[w];
+        if (w < wave) off += s;
+        tot += s;
+    }
+    *total = tot;
+    return off + x - v;
+}
+
+__global__ void __launch_bounds__(256) k_scan1(const unsigned char *flags, i64 n, int *bsum) {
+    __shared__ int lds[16];
+    i64 nb = (n + kScanBlock - 1) / kScanBlock;
+    for (i64 b = blockIdx.x; b < nb; b += gridDim.x) {
+        i64 i0 = b * kScanBlock + (i64)threadIdx.x * 8;
+        int s = 0;
+        for (int q = 0; q < 8; ++q) if (i0 + q < n) s += flags[i0 + q];
+        int tot;
+        wg_exclusive_scan(s, lds, &tot);
+        if (threadIdx.x == 0) bsum[b] = tot;
+        __syncthreads();
+    }
+}
+__global__ void __launch_bounds__(256) k_scan2(int *bsum, i64 nb, u64 *total_out) {
+    __shared__ int lds[16];
+    __shared__ int carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (i64 b0 = 0; b0 < nb; b0 += blockDim.x) {
+        i64 b = b0 + threadIdx.x;
+        int v = b < nb ? bsum[b] : 0;
+        int tot;
+        int ex = wg_exclusive_scan(v, lds, &tot);
+        int carry = carry_s;
+        if (b < nb) bsum[b] = carry + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = carry + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total_out = (u64)carry_s;
+}
+__global__ void __launch_bounds__(256) k_scan3(const unsigned char *flags, i64 n, const int *bsum, int *idx) {
+    __shared__ int lds[16];
+    i64 nb = (n + kScanBlock - 1) / kScanBlock;
+    for (i64 b = blockIdx.x; b < nb; b += gridDim.x) {
+        i64 i0 = b * kScanBlock + (i64)threadIdx.x * 8;
+        int f[8], s = 0;
+        for (int q = 0; q < 8; ++q) { f[q] = (i0 + q < n) ? flags[i0 + q] : 0; s += f[q]; }
+        int tot;
+        int ex = wg_exclusive_scan(s, lds, &tot) + bsum[b];
+        for (int q = 0; q < 8; ++q) { if (i0 + q < n) idx[i0 + q] = ex; ex += f[q]; }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// S3a  variance threshold   (py/freddie_segment.py:757-759)
+// V = the Y > 0 values in (interval, position) order; thr = mean(V) + vf * std(V) with numpy's
+// summation order: consecutive 8192-element chunks, each summed pairwise (8 strided accumulators
+// below 129 elements, halves rounded down to a multiple of 8 above), chunk results added left to
+// right.  Empty V gives NaN, which fixes nothing.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_vgather(i64 n_pos, const unsigned char *flag_pos, const int *idx, const double *y, double *v) {
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n_pos; i += (i64)gridDim.x * blockDim.x)
+        if (flag_pos[i]) v[idx[i]] = y[i];
+}
+// one workgroup: per-partition V ranges and chunk offsets
+__global__ void __launch_bounds__(256) k_vplan(int n_part, const i64 *part_iv_off, const i64 *pos_off, i64 n_pos,
+                                               const int *idx, i64 *voff, i64 *chunk_off, Status *st, i64 chunk_cap) {
+    __shared__ int lds[16];
+    __shared__ i64 carry_s;
+    u64 total = st->n_vals;
+    for (int p = threadIdx.x; p <= n_part; p += blockDim.x) {
+        i64 pos = p < n_part ? pos_off[part_iv_off[p]] : n_pos;
+        voff[p] = pos < n_pos ? (i64)idx[pos] : (i64)total;
+    }
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int p0 = 0; p0 < n_part; p0 += blockDim.x) {
+        int p = p0 + threadIdx.x;
+        int nch = 0;
+        if (p < n_part) nch = (int)((voff[p + 1] - voff[p] + 8191) / 8192);
+        int tot;
+        int ex = wg_exclusive_scan(nch, lds, &tot);
+        i64 carry = carry_s;
+        if (p < n_part) chunk_off[p] = carry + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = carry + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        chunk_off[n_part] = carry_s;
+        st->n_vchunks = (u64)carry_s;
+        if (carry_s > chunk_cap) atomicOr(&st->err, kErrOverflowChunks);
+    }
+}
+// one 64-thread workgroup per chunk; pass 0 sums v, pass 1 sums (v-mean)^2
+__global__ void __launch_bounds__(64) k_vsum_chunks(int n_part, const i64 *voff, const i64 *chunk_off, const double *v,
+                                                    const double *mean, int pass, double *csum, i64 chunk_cap) {
+    __shared__ int leaf_off[256], leaf_len[256], leaf_depth[256];
+    __shared__ double leaf_sum[256];
+    __shared__ int n_leaf_s;
+    i64 n_chunks = chunk_off[n_part];
+    if (n_chunks > chunk_cap) n_chunks = chunk_cap;
+    for (i64 c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+        int p = (int)last_le(chunk_off, (i64)n_part + 1, c);
+        i64 nv = voff[p + 1] - voff[p];
+        i64 o0 = (c - chunk_off[p]) * 8192;
+        int m = (int)((nv - o0) < 8192 ? (nv - o0) : 8192);
+        const double *a = v + voff[p] + o0;
+        double mu = pass ? mean[p] : 0.0;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            // leaves of the pairwise recursion, left to right, with their depth
+            int so[24], sl[24], sd[24], sp = 0, nl = 0;
+            so[0] = 0; sl[0] = m; sd[0] = 0; sp = 1;
+            while (sp > 0) {
+                --sp;
+                int off = so[sp], len = sl[sp], d = sd[sp];
+                if (len <= 128) { leaf_off[nl] = off; leaf_len[nl] = len; leaf_depth[nl] = d; ++nl; }
+                else {
+                    int n2 = len / 2; n2 -= n2 % 8;
+                    so[sp] = off + n2; sl[sp] = len - n2; sd[sp] = d + 1; ++sp;   // right (popped second)
+                    so[sp] = off; sl[sp] = n2; sd[sp] = d + 1; ++sp;              // left
+                }
+            }
+            n_leaf_s = nl;
+        }
+        __syncthreads();
+        int nl = n_leaf_s;
+        for (int t = threadIdx.x; t < nl; t += blockDim.x) {
+            const double *b = a + leaf_off[t];
+            int len = leaf_len[t];
+            double res;
+#define FSEG_VAL(i) (pass ? __dmul_rn(__dsub_rn(b[i], mu), __dsub_rn(b[i], mu)) : b[i])
+            if (len < 8) {
+                res = 0.0;
+                for (int i = 0; i < len; ++i) res = __dadd_rn(res, FSEG_VAL(i));
+            } else {
+                double r[8];
+                for (int q = 0; q < 8; ++q) r[q] = FSEG_VAL(q);
+                int i;
+                for (i = 8; i < len - (len % 8); i += 8)
+                    for (int q = 0; q < 8; ++q) r[q] = __dadd_rn(r[q], FSEG_VAL(i + q));
+                res = __dadd_rn(__dadd_rn(__dadd_rn(r[0], r[1]), __dadd_rn(r[2], r[3])),
+                                __dadd_rn(__dadd_rn(r[4], r[5]), __dadd_rn(r[6], r[7])));
+                for (; i < len; ++i) res = __dadd_rn(res, FSEG_VAL(i));
+            }
+#undef FSEG_VAL
+            leaf_sum[t] = res;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            // combine: two finished subtrees of equal depth are siblings
+            double sv[24]; int sd[24], sp = 0;
+            for (int t = 0; t < nl; ++t) {
+                sv[sp] = leaf_sum[t]; sd[sp] = leaf_depth[t]; ++sp;
+                while (sp >= 2 && sd[sp - 1] == sd[sp - 2]) {
+                    sv[sp - 2] = __dadd_rn(sv[sp - 2], sv[sp - 1]);
+                    sd[sp - 2] -= 1;
+                    --sp;
+                }
+            }
+            csum[c] = sv[0];
+        }
+    }
+}
+__global__ void k_vsum_part(int n_part, const i64 *voff, const i64 *chunk_off, const double *csum, int pass,
+                            double vf, double *mean, double *thr, i64 chunk_cap) {
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n_part; p += gridDim.x * blockDim.x) {
+        i64 c0 = chunk_off[p], c1 = chunk_off[p + 1];
+        if (c1 > chunk_cap) c1 = chunk_cap;
+        double n = (double)(voff[p + 1] - voff[p]);
+        double s = 0.0;
+        for (i64 c = c0; c < c1; ++c) s = (c == c0) ? csum[c] : __dadd_rn(s, csum[c]);
+        if (pass == 0) mean[p] = s / n;                                // empty -> 0/0 = NaN like numpy
+        else thr[p] = __dadd_rn(mean[p], __dmul_rn(vf, __dsqrt_rn(s / n)));   // :758-759
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// S3b  candidates   (candidates_from_peaks :615-621; scipy _local_maxima_1d)
+// strict local maxima with the plateau-midpoint rule, plus the first and last position.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_peaks(int n_tiles, const int *tile_iv, const int *tile_y0, const i64 *pos_off,
+                                               const double *yv, unsigned char *flag) {
+    for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        int k = tile_iv[t];
+        i64 y0 = tile_y0[t];
+        i64 base = pos_off[k];
+        i64 len = pos_off[k + 1] - base;
+        const double *x = yv + base;
+        for (int o = threadIdx.x; o < kSmoothTile; o += blockDim.x) {
+            i64 i = y0 + o;
+            if (i >= len) break;
+            if (i == 0 || i == len - 1) { flag[base + i] = 1; continue; }
+            double xi = x[i];
+            if (x[i - 1] < xi) {
+                i64 ia = i + 1;
+                while (ia < len - 1 && x[ia] == xi) ++ia;
+                if (x[ia] < xi) flag[base + (i + ia - 1) / 2] = 1;
+            }
+        }
+    }
+}
+// compaction of position flags into per-interval sorted y lists (used for candidates and finals)
+__global__ void __launch_bounds__(256) k_pos_gather(int n_tiles, const int *tile_iv, const int *tile_y0,
+                                                    const i64 *pos_off, const unsigned char *flag, const int *idx,
+                                                    const int *iv_start, int *out_y, int *out_pos, i64 *out_off) {
+    for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        int k = tile_iv[t];
+        i64 y0 = tile_y0[t];
+        i64 base = pos_off[k];
+        i64 len = pos_off[k + 1] - base;
+        for (int o = threadIdx.x; o < kSmoothTile; o += blockDim.x) {
+            i64 i = y0 + o;
+            if (i >= len) break;
+            if (flag[base + i]) {
+                int d = idx[base + i];
+                out_y[d] = (int)i;
+                if (out_pos) out_pos[d] = iv_start[k] + (int)i;
+                if (i == 0) out_off[k] = d;     // position 0 of every interval is always flagged
+            }
+        }
+    }
+}
+__global__ void k_set_total(i64 *off, i64 K, const u64 *total) { if (threadIdx.x == 0 && blockIdx.x == 0) off[K] = (i64)*total; }
+
+// ---------------------------------------------------------------------------------------------
+// S4  fixing, problem splitting, problem list
+//   fixed = {0, N-1} U {c : Y[cand_c] > thr}                      py/freddie_segment.py:776-783
+//   break_large_problems                                           :623-645 (pairs taken before insertion)
+//   problems = consecutive fixed pairs                             :581
+// one wave per tint interval.  Problems with n == 2 have no (i,j,k) and can never add a breakpoint,
+// so only n >= 3 are emitted.
+// ---------------------------------------------------------------------------------------------
+struct ProblemArrays {
+    int *iv;        // interval
+    int *start;     // first candidate (index inside the interval)
+    int *n;         // number of candidates
+    i64 *pair_off;  // offset into the pair arenas (thresholds, ambiguity counts)
+    i64 *tri_off;   // offset into the out-count arena
+    int *flags;     // bit0: some pair has lo < 0 (a read with zero coverage is ambiguous there)
+    int *chain;     // number of backtracked triples (debug)
+};
+
+__global__ void __launch_bounds__(64) k_fix(i64 K, const i64 *pos_off, const int *iv_part, const i64 *cand_off,
+                                            const int *cand_y, const double *yv, const double *thr_part, int mps,
+                                            unsigned char *fixed0, unsigned char *added, unsigned char *fixed,
+                                            unsigned char *chosen, ProblemArrays pr, i64 prob_cap,
+                                            const i64 *part_lane_off, int *work_prob, int *work_chunk, i64 work_cap,
+                                            Status *st) {
+    int lane = lane_id();
+    for (i64 k = blockIdx.x; k < K; k += gridDim.x) {
+        i64 c0 = cand_off[k];
+        int N = (int)(cand_off[k + 1] - c0);
+        const double *y = yv + pos_off[k];
+        const int *cy = cand_y + c0;
+        int part = iv_part[k];
+        double thr = thr_part[part];
+        for (int t0 = 0; t0 < N; t0 += 64) {
+            int c = t0 + lane;
+            if (c < N) {
+                fixed0[c0 + c] = (c == 0 || c == N - 1 || y[cy[c]] > thr) ? 1 : 0;
+                added[c0 + c] = 0;
+            }
+        }
+        __syncthreads();
+        // break_large_problems over the original consecutive fixed pairs
+        int prev = -1;
+        for (int t0 = 0; t0 < N; t0 += 64) {
+            int c = t0 + lane;
+            u64 mask = __ballot(c < N && fixed0[c0 + c]);
+            while (mask) {
+                int b = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                int cur = t0 + b;
+                if (prev >= 0) {
+                    int size = cur - prev + 1;
+                    if (size > mps) {
+                        int cnt = (int)ceil((double)size / (double)mps);
+                        double step = (double)size / (double)cnt;
+                        for (int i = 1; i < cnt; ++i) {
+                            int anchor = (int)((double)prev + __dmul_rn((double)i, step));
+                            double best = -INFINITY;
+                            int best_c = -1;
+                            bool bad = false;
+                            for (int cc = anchor - 5; cc < anchor + 5; ++cc) {
+                                int ci = cc < 0 ? cc + N : cc;          // Python negative-index wraparound
+                                if (ci < 0 || ci >= N) { bad = true; continue; }
+                                double val = y[cy[ci]];
+                                if (val > best) { best = val; best_c = cc; }
+                            }
+                            if (bad || !(best > 0.0) || best_c < 0) { if (lane == 0) atomicOr(&st->err, kErrBreakAssert); }
+                            else if (lane == 0) added[c0 + best_c] = 1;
+                        }
+                    }
+                }
+                prev = cur;
+            }
+        }
+        __syncthreads();
+        // final fixed set and problems
+        prev = -1;
+        i64 lanes_p = part_lane_off[part + 1] - part_lane_off[part];
+        int chunks = (int)((lanes_p + kLaneChunk - 1) / kLaneChunk);
+        for (int t0 = 0; t0 < N; t0 += 64) {
+            int c = t0 + lane;
+            bool f = c < N && (fixed0[c0 + c] | added[c0 + c]);
+            if (c < N) { fixed[c0 + c] = f; chosen[c0 + c] = f; }
+            u64 mask = __ballot(f);
+            while (mask) {
+                int b = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                int cur = t0 + b;
+                if (prev >= 0 && cur - prev + 1 >= 3) {
+                    int n = cur - prev + 1;
+                    u64 slot = 0, wbase = 0, poff = 0, toff = 0;
+                    if (lane == 0) {
+                        slot = atomicAdd(&st->n_prob, 1ULL);
+                        poff = atomicAdd(&st->pair_used, (u64)n * (n - 1) / 2);
+                        toff = atomicAdd(&st->tri_used, (u64)n * (n - 1) * (n - 2) / 6);
+                        wbase = atomicAdd(&st->n_work, (u64)chunks);
+                        if (n > kNMax) atomicOr(&st->err, kErrProblemTooLarge);
+                        if ((i64)slot < prob_cap) {
+                            pr.iv[slot] = (int)k; pr.start[slot] = prev; pr.n[slot] = n;
+                            pr.pair_off[slot] = (i64)poff; pr.tri_off[slot] = (i64)toff;
+                            pr.flags[slot] = 0; pr.chain[slot] = 0;
+                        } else atomicOr(&st->err, kErrOverflowProblems);
+                    }
+                    slot = __shfl(slot, 0); wbase = __shfl(wbase, 0);
+                    if ((i64)slot < prob_cap) {
+                        for (int q = lane; q < chunks; q += 64) {
+                            if ((i64)(wbase + q) < work_cap) { work_prob[wbase + q] = (int)slot; work_chunk[wbase + q] = q; }
+                            else atomicOr(&st->err, kErrOverflowWork);
+                        }
+                    }
+                }
+                prev = cur;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// pair index q = j*(j-1)/2 + i (i < j);  triple rank = k*(k-1)*(k-2)/6 + j*(j-1)/2 + i (i < j < k)
+__device__ __forceinline__ void pair_decode(int q, int *i, int *j) {
+    int jj = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)q)) * 0.5f);
+    while (jj * (jj - 1) / 2 > q) --jj;
+    while ((jj + 1) * jj / 2 <= q) ++jj;
+    *j = jj;
+    *i = q - jj * (jj - 1) / 2;
+}
+
+// S5a  integer label thresholds of every candidate pair of every problem (:490-495)
+__global__ void __launch_bounds__(256) k_pair_thresholds(const Status *st, ProblemArrays pr, i64 prob_cap,
+                                                         const i64 *cand_off, const int *cand_y, const double *h_table,
+                                                         int h_len, double tau, int2 *pair_thr, i64 pair_cap) {
+    i64 n_prob = (i64)st->n_prob < prob_cap ? (i64)st->n_prob : prob_cap;
+    for (i64 p = blockIdx.x; p < n_prob; p += gridDim.x) {
+        int n = pr.n[p];
+        i64 poff = pr.pair_off[p];
+        int npairs = n * (n - 1) / 2;
+        if (poff + npairs > pair_cap) continue;
+        const int *cy = cand_y + cand_off[pr.iv[p]] + pr.start[p];
+        int any_neg = 0;
+        for (int q = threadIdx.x; q < npairs; q += blockDim.x) {
+            int i, j;
+            pair_decode(q, &i, &j);
+            i64 L = (i64)cy[j] - cy[i] + 1;
+            int hi, lo;
+            label_thresholds(L, h_table, h_len, tau, &hi, &lo);
+            pair_thr[poff + q] = make_int2(hi, lo);
+            if (lo < 0) any_neg = 1;
+        }
+        if (any_neg) atomicOr(&pr.flags[p], 1);
+    }
+}
+
+__global__ void k_zero_arenas(const Status *st, unsigned *out_g, i64 tri_cap, unsigned *amb_g, i64 pair_cap) {
+    i64 nt = (i64)st->tri_used < tri_cap ? (i64)st->tri_used : tri_cap;
+    i64 np = (i64)st->pair_used < pair_cap ? (i64)st->pair_used : pair_cap;
+    i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < nt; i += stride) out_g[i] = 0;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < np; i += stride) amb_g[i] = 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// S5  interval scoring   (optimize(): pair labels :488-497, inside :500-506, outside :509-528)
+//
+// Work item = (problem, chunk of <= kLaneChunk reads of the problem's partition).  For 64 reads at a
+// time the workgroup
+//   A. walks each read's exon list against the problem's n candidates and stores the coverage
+//      prefix cov[r][j] = #covered positions in [cand_0, cand_j)  (= C[j]-C[start], :188-246) in LDS;
+//   B. evaluates every pair (i,j): yea = cov_j-cov_i >= hi_ij, nay = cov_j-cov_i <= lo_ij, shifting the
+//      64 results into two 32-bit plane words per label, kept in LDS as {yea0,yea1,nay0,nay1};
+//      ambiguous reads (neither) are counted per pair for inside(i,j) = -sum(W*amb);
+//   C. for every triple i<j<k that the DP can use adds
+//      popc(yea_ij & nay_jk) + popc(nay_ij & yea_jk)  (the two conjunctions are disjoint, :515-523)
+//      into a u16 counter table in LDS.
+// At the end of the work item the non-zero counters go to the global table with one atomic each.
+// Reads with multiplicity W are expanded into W lanes on upload, so every lane has weight 1.
+// ---------------------------------------------------------------------------------------------
+struct ScoreShared {
+    int cp[kNMax + 4];   // candidate positions (genomic)
+};
+
+__global__ void __launch_bounds__(256) k_score(Status *st, ProblemArrays pr, i64 prob_cap, const int *work_prob,
+                                               const int *work_chunk, i64 work_cap, const i64 *cand_off,
+                                               const int *cand_y, const int *iv_part, const int *iv_start,
+                                               const i64 *part_lane_off, const i64 *part_rep_off, const int *lane_rep,
+                                               const i64 *rep_exon_off, const int *ex_ts, const int *ex_te,
+                                               const int2 *pair_thr, i64 pair_cap, unsigned *out_g, i64 tri_cap,
+                                               unsigned *amb_g) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ int cp[kNMax + 4];
+    __shared__ u64 work_s;
+    __shared__ int any_active_s;
+    constexpr int kMaxPairs = kNMax * (kNMax - 1) / 2;
+    constexpr int kCovStride = kNMax + 1;   // odd: lane-major rows do not collide on LDS banks
+    // dynamic LDS carve-up
+    uint4 *planes = reinterpret_cast<uint4 *>(smem);                                   // kMaxPairs * 16 B
+    unsigned *cov = reinterpret_cast<unsigned *>(smem + (size_t)kMaxPairs * 16);       // kSub * kCovStride * 4 B
+    unsigned short *pair_ij = reinterpret_cast<unsigned short *>(cov + kSub * kCovStride);   // kMaxPairs * 2 B
+    unsigned short *out16 = pair_ij + ((kMaxPairs + 7) & ~7);                          // C(kNMax,3) * 2 B
+
+    i64 n_work = (i64)st->n_work < work_cap ? (i64)st->n_work : work_cap;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) work_s = atomicAdd(&st->work_queue, 1ULL);
+        __syncthreads();
+        i64 w = (i64)work_s;
+        if (w >= n_work) break;
+        int p = work_prob[w];
+        int chunk = work_chunk[w];
+        int n = pr.n[p];
+        i64 poff = pr.pair_off[p], toff = pr.tri_off[p];
+        int npairs = n * (n - 1) / 2, ntri = n * (n - 1) * (n - 2) / 6;
+        if (n > kNMax || poff + npairs > pair_cap || toff + ntri > tri_cap) continue;
+        int k = pr.iv[p];
+        int part = iv_part[k];
+        const int *cy = cand_y + cand_off[k] + pr.start[p];
+        int g0 = iv_start[k];
+        i64 lane_begin = part_lane_off[part] + (i64)chunk * kLaneChunk;
+        i64 lane_end = part_lane_off[part + 1];
+        if (lane_end > lane_begin + kLaneChunk) lane_end = lane_begin + kLaneChunk;
+        i64 rep_base = part_rep_off[part];
+        bool zero_ambiguous = (pr.flags[p] & 1) != 0;
+        for (int j = threadIdx.x; j < n; j += blockDim.x) cp[j] = g0 + cy[j];
+        for (int q = threadIdx.x; q < npairs; q += blockDim.x) {
+            int i, j;
+            pair_decode(q, &i, &j);
+            pair_ij[q] = (unsigned short)(i | (j << 8));
+        }
+        for (int x = threadIdx.x; x < ntri; x += blockDim.x) out16[x] = 0;
+        unsigned amb_acc[(kMaxPairs + 255) / 256];
+#pragma unroll
+        for (int s = 0; s < (kMaxPairs + 255) / 256; ++s) amb_acc[s] = 0;
+        __syncthreads();
+        const int cp0 = cp[0];
+        for (i64 l0 = lane_begin; l0 < lane_end; l0 += kSub) {
+            int n_valid = (int)((lane_end - l0) < kSub ? (lane_end - l0) : kSub);
+            // ---- A: coverage prefixes -----------------------------------------------------------
+            if (threadIdx.x == 0) any_active_s = 0;
+            __syncthreads();
+            if (threadIdx.x < kSub) {
+                unsigned *row = cov + threadIdx.x * kCovStride;
+                unsigned last = 0;
+                if ((int)threadIdx.x < n_valid) {
+                    i64 l = l0 + threadIdx.x;
+                    i64 r = lane_rep ? (i64)lane_rep[l] : rep_base + (l - part_lane_off[part]);
+                    i64 e = rep_exon_off[r], e1 = rep_exon_off[r + 1];
+                    // first exon whose closed interval reaches cand_0 (exons of a read are ordered, :158)
+                    {
+                        i64 lo = e, hi = e1;
+                        while (lo < hi) { i64 mid = (lo + hi) >> 1; if (ex_te[mid] < cp0) lo = mid + 1; else hi = mid; }
+                        e = lo;
+                    }
+                    unsigned acc = 0;
+                    row[0] = 0;
+                    for (int j = 1; j < n; ++j) {
+                        int cj = cp[j];
+                        while (e < e1 && ex_te[e] < cj) {
+                            int a = ex_ts[e] > cp0 ? ex_ts[e] : cp0;
+                            acc += (unsigned)(ex_te[e] + 1 - a);
+                            ++e;
+                        }
+                        unsigned part_cov = 0;
+                        if (e < e1 && ex_ts[e] < cj) {
+                            int a = ex_ts[e] > cp0 ? ex_ts[e] : cp0;
+                            part_cov = (unsigned)(cj - a);
+                        }
+                        last = acc + part_cov;
+                        row[j] = last;
+                    }
+                } else {
+                    for (int j = 0; j < n; ++j) row[j] = 0;
+                }
+                if (last > 0) any_active_s = 1;
+            }
+            __syncthreads();
+            const int any_active = any_active_s;
+            __syncthreads();
+            if (!any_active && !zero_ambiguous) continue;     // 64 reads without coverage: nay everywhere
+            // ---- B: pair planes ---------------------------------------------------------------------
+            unsigned valid0 = n_valid >= 32 ? 0xffffffffu : ((1u << n_valid) - 1u);
+            unsigned valid1 = n_valid >= 64 ? 0xffffffffu : (n_valid > 32 ? ((1u << (n_valid - 32)) - 1u) : 0u);
+#pragma unroll
+            for (int s = 0; s < (kMaxPairs + 255) / 256; ++s) {
+                int q = s * 256 + threadIdx.x;
+                if (q < npairs) {
+                    int i = pair_ij[q] & 255, j = pair_ij[q] >> 8;
+                    int2 th = pair_thr[poff + q];
+                    unsigned y0 = 0, z0 = 0, y1 = 0, z1 = 0;
+                    for (int b = 0; b < 32; ++b) {
+                        int d = (int)(cov[b * kCovStride + j] - cov[b * kCovStride + i]);
+                        y0 |= (unsigned)(d >= th.x) << b;
+                        z0 |= (unsigned)(d <= th.y) << b;
+                    }
+                    for (int b = 0; b < 32; ++b) {
+                        int d = (int)(cov[(32 + b) * kCovStride + j] - cov[(32 + b) * kCovStride + i]);
+                        y1 |= (unsigned)(d >= th.x) << b;
+                        z1 |= (unsigned)(d <= th.y) << b;
+                    }
+                    planes[q] = make_uint4(y0, y1, z0, z1);
+                    amb_acc[s] += __popc(~(y0 | z0) & valid0) + __popc(~(y1 | z1) & valid1);
+                }
+            }
+            __syncthreads();
+            // ---- C: triples ---------------------------------------------------------------------------
+            for (int q = threadIdx.x; q < npairs; q += blockDim.x) {
+                int j = pair_ij[q] & 255, kk = pair_ij[q] >> 8;       // B pair = (j, k)
+                if (j == 0 || cp[kk] - cp[j] < 5) continue;           // dp(): segment too small (:540)
+                uint4 B = planes[q];
+                if ((B.x | B.y | B.z | B.w) == 0) continue;
+                int tbase = kk * (kk - 1) * (kk - 2) / 6 + j * (j - 1) / 2;
+                int abase = j * (j - 1) / 2;
+                for (int i = 0; i < j; ++i) {
+                    if (cp[j] - cp[i] < 5) break;                     // closer i are too small as well
+                    uint4 A = planes[abase + i];
+                    unsigned cnt = __popc(A.x & B.z) + __popc(A.y & B.w) + __popc(A.z & B.x) + __popc(A.w & B.y);
+                    if (cnt) out16[tbase + i] += (unsigned short)cnt;
+                }
+            }
+            __syncthreads();
+        }
+        // ---- flush ---------------------------------------------------------------------------------
+        for (int x = threadIdx.x; x < ntri; x += blockDim.x) {
+            unsigned v = out16[x];
+            if (v) atomicAdd(&out_g[toff + x], v);
+        }
+#pragma unroll
+        for (int s = 0; s < (kMaxPairs + 255) / 256; ++s) {
+            int q = s * 256 + threadIdx.x;
+            if (q < npairs && amb_acc[s]) atomicAdd(&amb_g[poff + q], amb_acc[s]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// S5b  DP over one problem   (dp() :532-558, top level :560-566, backtrack :592-594)
+// D(i,j,k) = in_ij + out_ijk + M(j,k),  M(j,k) = max_{k'>k} D(j,k,k') (first maximiser, strict >),
+// M(j,end) := in_j,end closes the chain (base case :545-548).  The inner maximum depends only on (j,k), so
+// filling M for j descending is O(n^3) and gives the reference's O(n^4) recursion's result
+// (SURVEY.md App. A.7).  One wave per problem, lane = k.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_dp(Status *st, ProblemArrays pr, i64 prob_cap, const i64 *cand_off,
+                                           const int *cand_y, const unsigned *out_g, i64 tri_cap, const unsigned *amb_g,
+                                           i64 pair_cap, int support, unsigned char *chosen) {
+    __shared__ i64 M[kNMax * kNMax];
+    __shared__ unsigned char A[kNMax * kNMax];
+    __shared__ int cy_s[kNMax];
+    __shared__ u64 work_s;
+    int lane = lane_id();
+    i64 n_prob = (i64)st->n_prob < prob_cap ? (i64)st->n_prob : prob_cap;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) work_s = atomicAdd(&st->dp_queue, 1ULL);
+        __syncthreads();
+        i64 p = (i64)work_s;
+        if (p >= n_prob) break;
+        int n = pr.n[p];
+        i64 poff = pr.pair_off[p], toff = pr.tri_off[p];
+        int npairs = n * (n - 1) / 2, ntri = n * (n - 1) * (n - 2) / 6;
+        if (n > kNMax || poff + npairs > pair_cap || toff + ntri > tri_cap) continue;
+        i64 c0 = cand_off[pr.iv[p]] + pr.start[p];
+        for (int j = lane; j < n; j += 64) cy_s[j] = cand_y[c0 + j];
+        __syncthreads();
+        const unsigned *amb = amb_g + poff;
+        const unsigned *outp = out_g + toff;
+        const int end = n - 1;
+#define FSEG_IN(a, b) (-(i64)amb[(b) * ((b) - 1) / 2 + (a)])
+        // M(j, end) = in(j, end)
+        for (int j = lane; j < end; j += 64) { M[j * kNMax + end] = FSEG_IN(j, end); A[j * kNMax + end] = 255; }
+        __syncthreads();
+        for (int j = end - 2; j >= 1; --j) {
+            // lanes: k in (j, end)
+            for (int k0 = j + 1; k0 < end; k0 += 64) {
+                int kx = k0 + lane;
+                if (kx < end) {
+                    i64 best = kNegInf; int arg = 255;
+                    if (cy_s[kx] - cy_s[j] >= 5) {
+                        i64 in_jk = FSEG_IN(j, kx);
+                        for (int k2 = kx + 1; k2 <= end; ++k2) {
+                            if (cy_s[k2] - cy_s[kx] < 5) continue;
+                            i64 tail = M[kx * kNMax + k2];
+                            if (tail == kNegInf) continue;
+                            unsigned o = outp[k2 * (k2 - 1) * (k2 - 2) / 6 + kx * (kx - 1) / 2 + j];
+                            if ((i64)o < (i64)support) continue;              // :526-527
+                            i64 cur = in_jk + (i64)o + tail;
+                            if (cur > best) { best = cur; arg = k2; }
+                        }
+                    }
+                    M[j * kNMax + kx] = best; A[j * kNMax + kx] = (unsigned char)arg;
+                }
+            }
+            __syncthreads();
+        }
+        // top level: i = start
+        i64 best = FSEG_IN(0, end);
+        int bj = -1, bk = -1;
+        for (int j = 1; j < end; ++j) {
+            if (cy_s[j] - cy_s[0] < 5) continue;
+            i64 in_0j = FSEG_IN(0, j);
+            for (int k0 = j + 1; k0 <= end; k0 += 64) {
+                int kx = k0 + lane;
+                i64 cur = kNegInf;
+                if (kx <= end && cy_s[kx] - cy_s[j] >= 5) {
+                    i64 tail = M[j * kNMax + kx];
+                    unsigned o = outp[kx * (kx - 1) * (kx - 2) / 6 + j * (j - 1) / 2 + 0];
+                    if (tail != kNegInf && (i64)o >= (i64)support) cur = in_0j + (i64)o + tail;
+                }
+                // first lane (smallest k) holding the wave maximum
+                i64 mx = cur;
+                for (int d = 32; d >= 1; d >>= 1) { i64 o2 = __shfl_xor(mx, d); mx = o2 > mx ? o2 : mx; }
+                if (mx > best) {
+                    u64 m = __ballot(cur == mx);
+                    int b = __ffsll((long long)m) - 1;
+                    best = mx; bj = j; bk = k0 + b;
+                }
+            }
+        }
+#undef FSEG_IN
+        if (lane == 0) {
+            int chain = 0;
+            if (bj >= 0) {
+                chosen[c0] = 1;
+                int j = bj, k = bk;
+                for (;;) {
+                    chosen[c0 + j] = 1; chosen[c0 + k] = 1; ++chain;
+                    if (k == end) break;
+                    int k2 = A[j * kNMax + k];
+                    if (k2 == 255) break;
+                    j = k; k = k2;
+                }
+            }
+            pr.chain[p] = chain;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// S6  refinement   (refine_segmentation :249-266) and final positions (:802-807)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_segments(i64 K, const i64 *pos_off, const i64 *cand_off, const int *cand_y,
+                                                 const unsigned char *chosen, unsigned char *final_flag, int *rseg_iv,
+                                                 int *rseg_s, int *rseg_e, Status *st) {
+    int lane = lane_id();
+    for (i64 k = blockIdx.x; k < K; k += gridDim.x) {
+        i64 c0 = cand_off[k];
+        int N = (int)(cand_off[k + 1] - c0);
+        i64 base = pos_off[k];
+        int prev_y = -1;
+        for (int t0 = 0; t0 < N; t0 += 64) {
+            int c = t0 + lane;
+            bool f = c < N && chosen[c0 + c];
+            int y = c < N ? cand_y[c0 + c] : 0;
+            if (f) final_flag[base + y] = 1;
+            u64 mask = __ballot(f);
+            while (mask) {
+                int b = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                int cur_y = __shfl(y, b);
+                if (prev_y >= 0 && cur_y - prev_y > 40 && lane == 0) {     // :252
+                    u64 slot = atomicAdd(&st->n_rseg, 1ULL);
+                    rseg_iv[slot] = (int)k; rseg_s[slot] = prev_y; rseg_e[slot] = cur_y;
+                }
+                prev_y = cur_y;
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(64) k_refine(const Status *st, const int *rseg_iv, const int *rseg_s,
+                                               const int *rseg_e, const i64 *pos_off, const int *y_raw,
+                                               const double *w_g, int radius, double sigma, double *g_scr, int *pk_scr,
+                                               unsigned char *flag_scr, unsigned char *keep_scr,
+                                               unsigned char *final_flag) {
+    __shared__ double ws[kMaxRadius + 1];
+    const int skip = 20;
+    int lane = lane_id();
+    for (int j = lane; j <= radius; j += 64) ws[j] = w_g[j];
+    __syncthreads();
+    i64 n_seg = (i64)st->n_rseg;
+    for (i64 sg = blockIdx.x; sg < n_seg; sg += gridDim.x) {
+        int s = rseg_s[sg], e = rseg_e[sg];
+        int len = e - s;
+        i64 base = pos_off[rseg_iv[sg]] + s;
+        const int *xr = y_raw + base;
+        // sum(i_vals) < 20 -> skip (:258); values are exact integers
+        i64 tot = 0;
+        for (int i = skip + lane; i < len - skip; i += 64) tot += xr[i];
+        for (int d = 32; d >= 1; d >>= 1) tot += __shfl_xor(tot, d);
+        if (tot < 20) continue;
+        double *g = g_scr + base;
+        int *pk = pk_scr + base;
+        unsigned char *pf = flag_scr + base, *kp = keep_scr + base;
+        // gaussian_filter1d(i_vals, sigma, mode='constant', cval=0, truncate=1.0)  (:260-261)
+        for (int i = lane; i < len; i += 64) {
+#define FSEG_V(t) (((t) < skip || (t) >= len - skip) ? 0 : xr[t])
+            double acc = __dmul_rn((double)FSEG_V(i), ws[0]);
+            for (int j = radius; j >= 1; --j) {
+                int a = i - j, b = i + j;
+                int sv = (a >= 0 ? FSEG_V(a) : 0) + (b < len ? FSEG_V(b) : 0);
+                acc = __dadd_rn(acc, __dmul_rn((double)sv, ws[j]));
+            }
+#undef FSEG_V
+            g[i] = acc;
+            pf[i] = 0;
+        }
+        __syncthreads();
+        for (int i = 1 + lane; i < len - 1; i += 64) {
+            double gi = g[i];
+            if (g[i - 1] < gi) {
+                int ia = i + 1;
+                while (ia < len - 1 && g[ia] == gi) ++ia;
+                if (g[ia] < gi) pf[(i + ia - 1) / 2] = 1;
+            }
+        }
+        __syncthreads();
+        int m = 0;
+        for (int t0 = 0; t0 < len; t0 += 64) {
+            int i = t0 + lane;
+            bool f = i < len && pf[i];
+            u64 mask = __ballot(f);
+            if (f) { int rank = __popcll(mask & ((1ULL << lane) - 1ULL)); pk[m + rank] = i; kp[m + rank] = 1; }
+            m += __popcll(mask);
+        }
+        __syncthreads();
+        // find_peaks(distance=20): highest peak first, ties -> later peak first; state 1 = kept and
+        // unprocessed, 2 = kept and processed, 0 = removed
+        for (;;) {
+            double bv = -INFINITY; int bq = -1;
+            for (int q = lane; q < m; q += 64)
+                if (kp[q] == 1) { double v = g[pk[q]]; if (v > bv || (v == bv && q > bq)) { bv = v; bq = q; } }
+            for (int d = 32; d >= 1; d >>= 1) {
+                double ov = __shfl_xor(bv, d); int oq = __shfl_xor(bq, d);
+                if (oq >= 0 && (bq < 0 || ov > bv || (ov == bv && oq > bq))) { bv = ov; bq = oq; }
+            }
+            if (bq < 0) break;
+            if (lane == 0) {
+                kp[bq] = 2;
+                int pj = pk[bq];
+                for (int q = bq - 1; q >= 0 && pj - pk[q] < skip; --q) kp[q] = 0;
+                for (int q = bq + 1; q < m && pk[q] - pj < skip; ++q) kp[q] = 0;
+            }
+            __syncthreads();
+        }
+        for (int q = lane; q < m; q += 64) {
+            if (kp[q] != 2) continue;
+            int i = pk[q];
+            i64 a = (i64)rint((double)i - sigma), b = (i64)rint((double)i + sigma + 1.0);   // Python round(): half even
+            if (a < 0) { a += len; if (a < 0) a = 0; } else if (a > len) a = len;           // slice semantics (:263)
+            if (b < 0) { b += len; if (b < 0) b = 0; } else if (b > len) b = len;
+            double sm = 0.0;
+            for (i64 x = a; x < b; ++x) sm = __dadd_rn(sm, g[x]);
+            if (!(sm < 20.0)) final_flag[base + i] = 1;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// S7  labels   (py/freddie_segment.py:808-830, sentinel :829-830, pop :840)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_label_plan(int n_part, const i64 *part_iv_off, const i64 *part_rep_off,
+                                                    const i64 *final_off, i64 *label_off, Status *st, i64 label_cap) {
+    __shared__ i64 carry_s;
+    __shared__ i64 tmp[256];
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int p0 = 0; p0 < n_part; p0 += blockDim.x) {
+        int p = p0 + threadIdx.x;
+        i64 bytes = 0;
+        if (p < n_part) {
+            i64 F = final_off[part_iv_off[p + 1]] - final_off[part_iv_off[p]];
+            bytes = (part_rep_off[p + 1] - part_rep_off[p]) * (F > 0 ? F - 1 : 0);
+        }
+        tmp[threadIdx.x] = bytes;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            i64 c = carry_s;
+            for (int q = 0; q < (int)blockDim.x && p0 + q < n_part; ++q) { i64 b = tmp[q]; tmp[q] = c; c += b; }
+            carry_s = c;
+        }
+        __syncthreads();
+        if (p < n_part) label_off[p] = tmp[threadIdx.x];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        label_off[n_part] = carry_s;
+        st->label_bytes = (u64)carry_s;
+        if (carry_s > label_cap) atomicOr(&st->err, kErrOverflowLabels);
+    }
+}
+// per final index: genomic segment [g0, g1) and integer thresholds; the last index of an interval is
+// the sentinel column (hi = INT_MAX)
+__global__ void k_label_cols(i64 K, const i64 *final_off, const int *final_y, const int *iv_start,
+                             const double *h_table, int h_len, double tau, int4 *col) {
+    i64 F = final_off[K];
+    for (i64 f = (i64)blockIdx.x * blockDim.x + threadIdx.x; f < F; f += (i64)gridDim.x * blockDim.x) {
+        i64 k = last_le(final_off, K + 1, f);
+        if (f + 1 == final_off[k + 1]) { col[f] = make_int4(0, 0, 0x7fffffff, -1); continue; }
+        int y0 = final_y[f], y1 = final_y[f + 1];
+        int hi, lo;
+        label_thresholds((i64)y1 - y0 + 1, h_table, h_len, tau, &hi, &lo);
+        col[f] = make_int4(iv_start[k] + y0, iv_start[k] + y1, hi, lo);
+    }
+}
+__global__ void __launch_bounds__(256) k_label(int n_part, const i64 *label_off, i64 label_cap, const i64 *part_iv_off,
+                                               const i64 *part_rep_off, const i64 *final_off, const int4 *col,
+                                               const i64 *rep_exon_off, const int *ex_ts, const int *ex_te,
+                                               unsigned char *labels) {
+    i64 total = label_off[n_part];
+    if (total > label_cap) return;
+    for (i64 x = (i64)blockIdx.x * blockDim.x + threadIdx.x; x < total; x += (i64)gridDim.x * blockDim.x) {
+        int p = (int)last_le(label_off, (i64)n_part + 1, x);
+        i64 f0 = final_off[part_iv_off[p]];
+        i64 S = final_off[part_iv_off[p + 1]] - f0 - 1;
+        i64 local = x - label_off[p];
+        i64 r = local / S, c = local - r * S;
+        int4 cl = col[f0 + c];
+        unsigned char out = '0';
+        if (cl.z != 0x7fffffff) {
+            i64 rep = part_rep_off[p] + r;
+            i64 e = rep_exon_off[rep], e1 = rep_exon_off[rep + 1];
+            i64 lo = e, hi = e1;
+            while (lo < hi) { i64 mid = (lo + hi) >> 1; if (ex_te[mid] < cl.x) lo = mid + 1; else hi = mid; }
+            int cov = 0;
+            for (e = lo; e < e1 && ex_ts[e] < cl.y; ++e) {
+                int a = ex_ts[e] > cl.x ? ex_ts[e] : cl.x;
+                int b = ex_te[e] + 1 < cl.y ? ex_te[e] + 1 : cl.y;
+                if (b > a) cov += b - a;
+            }
+            out = cov >= cl.z ? '1' : (cov <= cl.w ? '0' : '2');
+        }
+        labels[x] = out;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+enum Stage { ST_HIST, ST_SMOOTH, ST_THRESHOLD, ST_CANDIDATES, ST_FIX, ST_SCORE, ST_DP, ST_REFINE, ST_FINAL, ST_LABEL, ST_COUNT };
+const char *kStageNames[ST_COUNT] = {"histogram", "smooth", "threshold", "candidates", "fix_split", "interval_scoring",
+                                     "dp", "refine", "final_positions", "labels"};
+
+}  // namespace
+
+struct fseg_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    bool have_params = false, have_batch = false, ran = false, pending = false;
+    fseg_params P{};
+    std::vector<double> w_main, w_refine, h_table;
+    // batch metadata (host)
+    int n_part = 0;
+    i64 K = 0, R = 0, I = 0, NPOS = 0, LANES = 0;
+    int n_tiles = 0;
+    bool expanded = false;
+    std::vector<i64> part_iv_off, part_rep_off, part_lane_off, pos_off;
+    std::vector<int> iv_start_h;
+    // device buffers: inputs
+    DevBuf d_part_iv_off, d_part_rep_off, d_part_lane_off, d_iv_start, d_iv_end, d_pos_off, d_iv_part, d_rep_weight,
+        d_rep_exon_off, d_ex_ts, d_ex_te, d_lane_rep, d_tile_iv, d_tile_y0, d_w_main, d_w_refine, d_h_table;
+    // device buffers: position-sized
+    DevBuf d_y_raw, d_y, d_flag, d_idx, d_v, d_bsum, d_g, d_pk, d_pf, d_kp, d_final_flag;
+    // partition-sized
+    DevBuf d_voff, d_chunk_off, d_csum, d_mean, d_thr, d_label_off;
+    // candidate-sized
+    DevBuf d_cand_off, d_cand_y, d_fixed0, d_added, d_fixed, d_chosen, d_final_off, d_final_y, d_final_pos, d_col;
+    DevBuf d_rseg_iv, d_rseg_s, d_rseg_e;
+    // problems / arenas
+    DevBuf d_prob_iv, d_prob_start, d_prob_n, d_prob_pair_off, d_prob_tri_off, d_prob_flags, d_prob_chain;
+    DevBuf d_work_prob, d_work_chunk, d_pair_thr, d_amb, d_out, d_labels;
+    i64 prob_cap = 0, work_cap = 0, pair_cap = 0, tri_cap = 0, label_cap = 0, chunk_cap = 0;
+    DevBuf d_status;
+    Status *h_status = nullptr;   // pinned
+    bool profiling = false;
+    hipEvent_t ev[ST_COUNT + 1] = {};
+    float stage_ms[ST_COUNT] = {};
+    int score_lds = 0;
+};
+
+namespace {
+
+int fail(fseg_ctx *c, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    return code;
+}
+std::string g_create_error;
+
+#define HIP_TRY(c, expr)                                                                         \
+    do {                                                                                         \
+        hipError_t e__ = (expr);                                                                 \
+        if (e__ != hipSuccess) return fail((c), FSEG_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e__)); \
+    } while (0)
+
+int ensure(fseg_ctx *c, DevBuf &b, size_t bytes) {
+    if (bytes <= b.cap && b.p) return FSEG_OK;
+    if (b.p) HIP_TRY(c, hipFree(b.p));
+    b.p = nullptr; b.cap = 0;
+    size_t want = bytes < 256 ? 256 : bytes;
+    HIP_TRY(c, hipMalloc(&b.p, want));
+    b.cap = want;
+    return FSEG_OK;
+}
+template <typename T>
+int upload_vec(fseg_ctx *c, DevBuf &b, const T *src, size_t n) {
+    int rc = ensure(c, b, n * sizeof(T));
+    if (rc) return rc;
+    if (n) HIP_TRY(c, hipMemcpyAsync(b.p, src, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    return FSEG_OK;
+}
+#define TRY(expr) do { int rc__ = (expr); if (rc__) return rc__; } while (0)
+
+int grid_for(i64 items, int per_block, int max_blocks) {
+    i64 g = (items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > max_blocks) g = max_blocks;
+    return (int)g;
+}
+
+size_t score_lds_bytes() {
+    constexpr int kMaxPairs = kNMax * (kNMax - 1) / 2;
+    size_t b = (size_t)kMaxPairs * 16;
+    b += (size_t)kSub * (kNMax + 1) * 4;
+    b += (size_t)((kMaxPairs + 7) & ~7) * 2;
+    b += (size_t)(kNMax * (kNMax - 1) * (kNMax - 2) / 6) * 2;
+    return (b + 15) & ~(size_t)15;
+}
+
+int alloc_arenas(fseg_ctx *c) {
+    TRY(ensure(c, c->d_prob_iv, (size_t)c->prob_cap * 4));
+    TRY(ensure(c, c->d_prob_start, (size_t)c->prob_cap * 4));
+    TRY(ensure(c, c->d_prob_n, (size_t)c->prob_cap * 4));
+    TRY(ensure(c, c->d_prob_pair_off, (size_t)c->prob_cap * 8));
+    TRY(ensure(c, c->d_prob_tri_off, (size_t)c->prob_cap * 8));
+    TRY(ensure(c, c->d_prob_flags, (size_t)c->prob_cap * 4));
+    TRY(ensure(c, c->d_prob_chain, (size_t)c->prob_cap * 4));
+    TRY(ensure(c, c->d_work_prob, (size_t)c->work_cap * 4));
+    TRY(ensure(c, c->d_work_chunk, (size_t)c->work_cap * 4));
+    TRY(ensure(c, c->d_pair_thr, (size_t)c->pair_cap * 8));
+    TRY(ensure(c, c->d_amb, (size_t)c->pair_cap * 4));
+    TRY(ensure(c, c->d_out, (size_t)c->tri_cap * 4));
+    TRY(ensure(c, c->d_labels, (size_t)c->label_cap));
+    TRY(ensure(c, c->d_csum, (size_t)c->chunk_cap * 8));
+    return FSEG_OK;
+}
+
+int launch_scan(fseg_ctx *c, const unsigned char *flags, i64 n, u64 *total_dev) {
+    i64 nb = (n + kScanBlock - 1) / kScanBlock;
+    int g = grid_for(nb, 1, 4096);
+    hipLaunchKernelGGL(k_scan1, dim3(g), dim3(256), 0, c->stream, flags, n, c->d_bsum.as<int>());
+    hipLaunchKernelGGL(k_scan2, dim3(1), dim3(256), 0, c->stream, c->d_bsum.as<int>(), nb, total_dev);
+    hipLaunchKernelGGL(k_scan3, dim3(g), dim3(256), 0, c->stream, flags, n, c->d_bsum.as<int>(), c->d_idx.as<int>());
+    return FSEG_OK;
+}
+
+int enqueue_run(fseg_ctx *c) {
+    hipStream_t s = c->stream;
+    const int n_part = c->n_part;
+    const i64 K = c->K, NPOS = c->NPOS;
+    Status *st = c->d_status.as<Status>();
+    auto mark = [&](int i) { if (c->profiling) (void)hipEventRecord(c->ev[i], s); };
+    HIP_TRY(c, hipMemsetAsync(st, 0, sizeof(Status), s));
+    HIP_TRY(c, hipMemsetAsync(c->d_y_raw.p, 0, (size_t)NPOS * 4, s));
+    mark(0);
+    // S1
+    hipLaunchKernelGGL(k_hist, dim3(grid_for(c->R, 256, 2048)), dim3(256), 0, s, n_part, c->d_part_rep_off.as<i64>(),
+                       c->d_part_iv_off.as<i64>(), c->d_iv_start.as<int>(), c->d_iv_end.as<int>(), c->d_pos_off.as<i64>(),
+                       c->d_rep_weight.as<int>(), c->d_rep_exon_off.as<i64>(), c->d_ex_ts.as<int>(), c->d_ex_te.as<int>(),
+                       c->P.ignore_ends, c->d_y_raw.as<int>(), st);
+    mark(1);
+    // S2
+    int tile_grid = grid_for(c->n_tiles, 1, 8192);
+    hipLaunchKernelGGL(k_smooth, dim3(tile_grid), dim3(256), 0, s, c->n_tiles, c->d_tile_iv.as<int>(),
+                       c->d_tile_y0.as<int>(), c->d_pos_off.as<i64>(), c->d_y_raw.as<int>(), c->d_w_main.as<double>(),
+                       c->P.radius_main, c->d_y.as<double>(), c->d_flag.as<unsigned char>());
+    mark(2);
+    // S3a threshold
+    TRY(launch_scan(c, c->d_flag.as<unsigned char>(), NPOS, &st->n_vals));
+    hipLaunchKernelGGL(k_vgather, dim3(grid_for(NPOS, 256, 4096)), dim3(256), 0, s, NPOS, c->d_flag.as<unsigned char>(),
+                       c->d_idx.as<int>(), c->d_y.as<double>(), c->d_v.as<double>());
+    hipLaunchKernelGGL(k_vplan, dim3(1), dim3(256), 0, s, n_part, c->d_part_iv_off.as<i64>(), c->d_pos_off.as<i64>(), NPOS,
+                       c->d_idx.as<int>(), c->d_voff.as<i64>(), c->d_chunk_off.as<i64>(), st, c->chunk_cap);
+    int chunk_grid = grid_for(c->chunk_cap, 1, 4096);
+    for (int pass = 0; pass < 2; ++pass) {
+        hipLaunchKernelGGL(k_vsum_chunks, dim3(chunk_grid), dim3(64), 0, s, n_part, c->d_voff.as<i64>(),
+                           c->d_chunk_off.as<i64>(), c->d_v.as<double>(), c->d_mean.as<double>(), pass,
+                           c->d_csum.as<double>(), c->chunk_cap);
+        hipLaunchKernelGGL(k_vsum_part, dim3(grid_for(n_part, 64, 1024)), dim3(64), 0, s, n_part, c->d_voff.as<i64>(),
+                           c->d_chunk_off.as<i64>(), c->d_csum.as<double>(), pass, c->P.variance_factor,
+                           c->d_mean.as<double>(), c->d_thr.as<double>(), c->chunk_cap);
+    }
+    mark(3);
+    // S3b candidates
+    HIP_TRY(c, hipMemsetAsync(c->d_flag.p, 0, (size_t)NPOS, s));
+    hipLaunchKernelGGL(k_peaks, dim3(tile_grid), dim3(256), 0, s, c->n_tiles, c->d_tile_iv.as<int>(), c->d_tile_y0.as<int>(),
+                       c->d_pos_off.as<i64>(), c->d_y.as<double>(), c->d_flag.as<unsigned char>());
+    TRY(launch_scan(c, c->d_flag.as<unsigned char>(), NPOS, &st->n_cand));
+    hipLaunchKernelGGL(k_pos_gather, dim3(tile_grid), dim3(256), 0, s, c->n_tiles, c->d_tile_iv.as<int>(),
+                       c->d_tile_y0.as<int>(), c->d_pos_off.as<i64>(), c->d_flag.as<unsigned char>(), c->d_idx.as<int>(),
+                       c->d_iv_start.as<int>(), c->d_cand_y.as<int>(), (int *)nullptr, c->d_cand_off.as<i64>());
+    hipLaunchKernelGGL(k_set_total, dim3(1), dim3(1), 0, s, c->d_cand_off.as<i64>(), K, &st->n_cand);
+    mark(4);
+    // S4
+    ProblemArrays pr{c->d_prob_iv.as<int>(), c->d_prob_start.as<int>(), c->d_prob_n.as<int>(),
+                     c->d_prob_pair_off.as<i64>(), c->d_prob_tri_off.as<i64>(), c->d_prob_flags.as<int>(),
+                     c->d_prob_chain.as<int>()};
+    hipLaunchKernelGGL(k_fix, dim3(grid_for(K, 1, 8192)), dim3(64), 0, s, K, c->d_pos_off.as<i64>(), c->d_iv_part.as<int>(),
+                       c->d_cand_off.as<i64>(), c->d_cand_y.as<int>(), c->d_y.as<double>(), c->d_thr.as<double>(),
+                       c->P.max_problem_size, c->d_fixed0.as<unsigned char>(), c->d_added.as<unsigned char>(),
+                       c->d_fixed.as<unsigned char>(), c->d_chosen.as<unsigned char>(), pr, c->prob_cap,
+                       c->d_part_lane_off.as<i64>(), c->d_work_prob.as<int>(), c->d_work_chunk.as<int>(), c->work_cap, st);
+    mark(5);
+    // S5
+    if (c->prob_cap > 0) {
+        hipLaunchKernelGGL(k_pair_thresholds, dim3(grid_for(c->prob_cap, 1, 2048)), dim3(256), 0, s, st, pr, c->prob_cap,
+                           c->d_cand_off.as<i64>(), c->d_cand_y.as<int>(), c->d_h_table.as<double>(), c->P.h_len,
+                           c->P.threshold_rate, c->d_pair_thr.as<int2>(), c->pair_cap);
+        hipLaunchKernelGGL(k_zero_arenas, dim3(1024), dim3(256), 0, s, st, c->d_out.as<unsigned>(), c->tri_cap,
+                           c->d_amb.as<unsigned>(), c->pair_cap);
+        hipLaunchKernelGGL(k_score, dim3(grid_for(c->work_cap, 1, 256)), dim3(256), c->score_lds, s, st, pr, c->prob_cap,
+                           c->d_work_prob.as<int>(), c->d_work_chunk.as<int>(), c->work_cap, c->d_cand_off.as<i64>(),
+                           c->d_cand_y.as<int>(), c->d_iv_part.as<int>(), c->d_iv_start.as<int>(),
+                           c->d_part_lane_off.as<i64>(), c->d_part_rep_off.as<i64>(),
+                           c->expanded ? c->d_lane_rep.as<int>() : (const int *)nullptr, c->d_rep_exon_off.as<i64>(),
+                           c->d_ex_ts.as<int>(), c->d_ex_te.as<int>(), c->d_pair_thr.as<int2>(), c->pair_cap,
+                           c->d_out.as<unsigned>(), c->tri_cap, c->d_amb.as<unsigned>());
+    }
+    mark(6);
+    if (c->prob_cap > 0) {
+        hipLaunchKernelGGL(k_dp, dim3(grid_for(c->prob_cap, 1, 1280)), dim3(64), 0, s, st, pr, c->prob_cap,
+                           c->d_cand_off.as<i64>(), c->d_cand_y.as<int>(), c->d_out.as<unsigned>(), c->tri_cap,
+                           c->d_amb.as<unsigned>(), c->pair_cap, c->P.min_read_support_outside,
+                           c->d_chosen.as<unsigned char>());
+    }
+    mark(7);
+    // S6
+    HIP_TRY(c, hipMemsetAsync(c->d_final_flag.p, 0, (size_t)NPOS, s));
+    hipLaunchKernelGGL(k_segments, dim3(grid_for(K, 1, 8192)), dim3(64), 0, s, K, c->d_pos_off.as<i64>(),
+                       c->d_cand_off.as<i64>(), c->d_cand_y.as<int>(), c->d_chosen.as<unsigned char>(),
+                       c->d_final_flag.as<unsigned char>(), c->d_rseg_iv.as<int>(), c->d_rseg_s.as<int>(),
+                       c->d_rseg_e.as<int>(), st);
+    hipLaunchKernelGGL(k_refine, dim3(2048), dim3(64), 0, s, st, c->d_rseg_iv.as<int>(), c->d_rseg_s.as<int>(),
+                       c->d_rseg_e.as<int>(), c->d_pos_off.as<i64>(), c->d_y_raw.as<int>(), c->d_w_refine.as<double>(),
+                       c->P.radius_refine, c->P.sigma, c->d_g.as<double>(), c->d_pk.as<int>(),
+                       c->d_pf.as<unsigned char>(), c->d_kp.as<unsigned char>(), c->d_final_flag.as<unsigned char>());
+    mark(8);
+    TRY(launch_scan(c, c->d_final_flag.as<unsigned char>(), NPOS, &st->n_final));
+    hipLaunchKernelGGL(k_pos_gather, dim3(tile_grid), dim3(256), 0, s, c->n_tiles, c->d_tile_iv.as<int>(),
+                       c->d_tile_y0.as<int>(), c->d_pos_off.as<i64>(), c->d_final_flag.as<unsigned char>(),
+                       c->d_idx.as<int>(), c->d_iv_start.as<int>(), c->d_final_y.as<int>(), c->d_final_pos.as<int>(),
+                       c->d_final_off.as<i64>());
+    hipLaunchKernelGGL(k_set_total, dim3(1), dim3(1), 0, s, c->d_final_off.as<i64>(), K, &st->n_final);
+    mark(9);
+    // S7
+    hipLaunchKernelGGL(k_label_plan, dim3(1), dim3(256), 0, s, n_part, c->d_part_iv_off.as<i64>(),
+                       c->d_part_rep_off.as<i64>(), c->d_final_off.as<i64>(), c->d_label_off.as<i64>(), st, c->label_cap);
+    hipLaunchKernelGGL(k_label_cols, dim3(grid_for(NPOS / 8 + 1, 256, 2048)), dim3(256), 0, s, K, c->d_final_off.as<i64>(),
+                       c->d_final_y.as<int>(), c->d_iv_start.as<int>(), c->d_h_table.as<double>(), c->P.h_len,
+                       c->P.threshold_rate, c->d_col.as<int4>());
+    if (c->label_cap > 0)
+        hipLaunchKernelGGL(k_label, dim3(grid_for(c->label_cap, 256, 8192)), dim3(256), 0, s, n_part,
+                           c->d_label_off.as<i64>(), c->label_cap, c->d_part_iv_off.as<i64>(), c->d_part_rep_off.as<i64>(),
+                           c->d_final_off.as<i64>(), c->d_col.as<int4>(), c->d_rep_exon_off.as<i64>(), c->d_ex_ts.as<int>(),
+                           c->d_ex_te.as<int>(), c->d_labels.as<unsigned char>());
+    mark(10);
+    HIP_TRY(c, hipMemcpyAsync(c->h_status, st, sizeof(Status), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipGetLastError());
+    return FSEG_OK;
+}
+
+// wait for the run; grow arenas and re-run if a capacity was exceeded
+int finish_run(fseg_ctx *c) {
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        const Status &s = *c->h_status;
+        unsigned ovf = s.err & (kErrOverflowPairs | kErrOverflowTri | kErrOverflowWork | kErrOverflowLabels |
+                                kErrOverflowProblems | kErrOverflowChunks);
+        bool need = ovf != 0 || (i64)s.n_prob > c->prob_cap || (i64)s.n_work > c->work_cap ||
+                    (i64)s.pair_used > c->pair_cap || (i64)s.tri_used > c->tri_cap || (i64)s.label_bytes > c->label_cap ||
+                    (i64)s.n_vchunks > c->chunk_cap;
+        if (!need) {
+            c->pending = false;
+            c->ran = true;
+            if (c->profiling)
+                for (int i = 0; i < ST_COUNT; ++i) (void)hipEventElapsedTime(&c->stage_ms[i], c->ev[i], c->ev[i + 1]);
+            if (s.err & kErrExonInterval) return fail(c, FSEG_ERR_INPUT, "an exon does not lie inside one tint interval (py/freddie_segment.py:668)");
+            if (s.err & kErrBreakAssert) return fail(c, FSEG_ERR_INPUT, "break_large_problems: candidate window out of range or no positive signal (py/freddie_segment.py:640-643)");
+            if (s.err & kErrProblemTooLarge) return fail(c, FSEG_ERR_UNSUPPORTED, "a DP problem has more than %d candidates (max_problem_size too large for this build)", kNMax);
+            return FSEG_OK;
+        }
+        auto grow = [](i64 need_v, i64 cap) { return need_v > cap ? need_v + need_v / 8 + 64 : cap; };
+        c->prob_cap = grow((i64)s.n_prob, c->prob_cap);
+        c->work_cap = grow((i64)s.n_work, c->work_cap);
+        c->pair_cap = grow((i64)s.pair_used, c->pair_cap);
+        c->tri_cap = grow((i64)s.tri_used, c->tri_cap);
+        c->label_cap = grow((i64)s.label_bytes, c->label_cap);
+        c->chunk_cap = grow((i64)s.n_vchunks, c->chunk_cap);
+        TRY(alloc_arenas(c));
+        TRY(enqueue_run(c));
+    }
+    return fail(c, FSEG_ERR_HIP, "arena sizing did not converge");
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// C-ABI
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+int fseg_abi_version(void) { return FSEG_ABI_VERSION; }
+
+const char *fseg_last_error(const fseg_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int fseg_create(int device, fseg_ctx **out) {
+    if (!out) return FSEG_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        g_create_error = std::string("no HIP device available: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0") +
+                         " (this library has no CPU fallback)";
+        return FSEG_ERR_HIP;
+    }
+    if (device < 0 || device >= n) { g_create_error = "device ordinal out of range"; return FSEG_ERR_ARG; }
+    fseg_ctx *c = new fseg_ctx();
+    c->device = device;
+    e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_status, sizeof(Status), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc(&c->d_status.p, sizeof(Status));
+    for (int i = 0; e == hipSuccess && i <= ST_COUNT; ++i) e = hipEventCreate(&c->ev[i]);
+    c->score_lds = (int)score_lds_bytes();
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_score), hipFuncAttributeMaxDynamicSharedMemorySize, c->score_lds);
+    if (e != hipSuccess) {
+        g_create_error = std::string("context creation failed: ") + hipGetErrorString(e);
+        delete c;
+        return FSEG_ERR_HIP;
+    }
+    c->d_status.cap = sizeof(Status);
+    *out = c;
+    return FSEG_OK;
+}
+
+void fseg_destroy(fseg_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    DevBuf *bufs[] = {&c->d_part_iv_off, &c->d_part_rep_off, &c->d_part_lane_off, &c->d_iv_start, &c->d_iv_end, &c->d_pos_off,
+                      &c->d_iv_part, &c->d_rep_weight, &c->d_rep_exon_off, &c->d_ex_ts, &c->d_ex_te, &c->d_lane_rep,
+                      &c->d_tile_iv, &c->d_tile_y0, &c->d_w_main, &c->d_w_refine, &c->d_h_table, &c->d_y_raw, &c->d_y,
+                      &c->d_flag, &c->d_idx, &c->d_v, &c->d_bsum, &c->d_g, &c->d_pk, &c->d_pf, &c->d_kp, &c->d_final_flag,
+                      &c->d_voff, &c->d_chunk_off, &c->d_csum, &c->d_mean, &c->d_thr, &c->d_label_off, &c->d_cand_off,
+                      &c->d_cand_y, &c->d_fixed0, &c->d_added, &c->d_fixed, &c->d_chosen, &c->d_final_off, &c->d_final_y,
+                      &c->d_final_pos, &c->d_col, &c->d_rseg_iv, &c->d_rseg_s, &c->d_rseg_e, &c->d_prob_iv, &c->d_prob_start,
+                      &c->d_prob_n, &c->d_prob_pair_off, &c->d_prob_tri_off, &c->d_prob_flags, &c->d_prob_chain,
+                      &c->d_work_prob, &c->d_work_chunk, &c->d_pair_thr, &c->d_amb, &c->d_out, &c->d_labels, &c->d_status};
+    for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
+    if (c->h_status) (void)hipHostFree(c->h_status);
+    for (int i = 0; i <= ST_COUNT; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int fseg_set_params(fseg_ctx *c, const fseg_params *p) {
+    if (!c || !p) return FSEG_ERR_ARG;
+    // the ranges parse_args() asserts (py/freddie_segment.py:104-109)
+    if (!(p->threshold_rate >= 0.5 && p->threshold_rate <= 1.0)) return fail(c, FSEG_ERR_ARG, "threshold_rate must be in [0.5, 1]");
+    if (!(p->variance_factor > 0 && p->variance_factor < 10)) return fail(c, FSEG_ERR_ARG, "variance_factor must be in (0, 10)");
+    if (!(p->sigma > 0 && p->sigma <= 50)) return fail(c, FSEG_ERR_ARG, "sigma must be in (0, 50]");
+    if (!(p->max_problem_size > 3)) return fail(c, FSEG_ERR_ARG, "max_problem_size must be > 3");
+    if (p->min_read_support_outside < 0) return fail(c, FSEG_ERR_ARG, "min_read_support_outside must be >= 0");
+    if (p->radius_main < 0 || p->radius_main > kMaxRadius || p->radius_refine < 0 || p->radius_refine > kMaxRadius)
+        return fail(c, FSEG_ERR_ARG, "Gaussian radius out of range");
+    if (!p->w_main || !p->w_refine || !p->h_table || p->h_len <= 0) return fail(c, FSEG_ERR_ARG, "missing weight / threshold tables");
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->P = *p;
+    c->w_main.assign(p->w_main, p->w_main + p->radius_main + 1);
+    c->w_refine.assign(p->w_refine, p->w_refine + p->radius_refine + 1);
+    c->h_table.assign(p->h_table, p->h_table + p->h_len);
+    c->P.w_main = c->w_main.data(); c->P.w_refine = c->w_refine.data(); c->P.h_table = c->h_table.data();
+    TRY(upload_vec(c, c->d_w_main, c->w_main.data(), c->w_main.size()));
+    TRY(upload_vec(c, c->d_w_refine, c->w_refine.data(), c->w_refine.size()));
+    TRY(upload_vec(c, c->d_h_table, c->h_table.data(), c->h_table.size()));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->have_params = true;
+    return FSEG_OK;
+}
+
+int fseg_upload(fseg_ctx *c, const fseg_batch *b) {
+    if (!c || !b) return FSEG_ERR_ARG;
+    if (b->n_part <= 0 || !b->part_iv_off || !b->iv_start || !b->iv_end || !b->part_rep_off || !b->rep_weight ||
+        !b->rep_exon_off || !b->ex_ts || !b->ex_te)
+        return fail(c, FSEG_ERR_ARG, "fseg_upload: null array or empty batch");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int np = b->n_part;
+    const i64 K = b->part_iv_off[np], R = b->part_rep_off[np];
+    const i64 I = b->rep_exon_off[R];
+    if (b->part_iv_off[0] != 0 || b->part_rep_off[0] != 0 || b->rep_exon_off[0] != 0)
+        return fail(c, FSEG_ERR_ARG, "fseg_upload: offsets must start at 0");
+    // validation as read_split() asserts it (py/freddie_segment.py:138-140, :158-161)
+    for (int p = 0; p < np; ++p) {
+        i64 k0 = b->part_iv_off[p], k1 = b->part_iv_off[p + 1];
+        if (k1 <= k0) return fail(c, FSEG_ERR_INPUT, "partition %d has no intervals", p);
+        if (b->part_rep_off[p + 1] < b->part_rep_off[p]) return fail(c, FSEG_ERR_ARG, "part_rep_off not monotone");
+        for (i64 k = k0; k < k1; ++k) {
+            if (!(b->iv_start[k] < b->iv_end[k])) return fail(c, FSEG_ERR_INPUT, "partition %d: interval with start >= end (py/freddie_segment.py:140)", p);
+            if (k > k0 && !(b->iv_end[k - 1] < b->iv_start[k])) return fail(c, FSEG_ERR_INPUT, "partition %d: intervals overlap or are unordered (py/freddie_segment.py:138)", p);
+        }
+    }
+    std::vector<i64> pos_off(K + 1);
+    std::vector<int> iv_part(K);
+    pos_off[0] = 0;
+    for (int p = 0; p < np; ++p)
+        for (i64 k = b->part_iv_off[p]; k < b->part_iv_off[p + 1]; ++k) {
+            iv_part[k] = p;
+            pos_off[k + 1] = pos_off[k] + ((i64)b->iv_end[k] - b->iv_start[k] + 1);
+        }
+    const i64 NPOS = pos_off[K];
+    if (NPOS >= 0x7fffffffLL) return fail(c, FSEG_ERR_UNSUPPORTED, "batch has %lld positions; split it (limit 2^31-1 per upload)", (long long)NPOS);
+    bool expanded = false;
+    i64 lanes = 0;
+    std::vector<i64> part_lane_off(np + 1);
+    part_lane_off[0] = 0;
+    for (int p = 0; p < np; ++p) {
+        for (i64 r = b->part_rep_off[p]; r < b->part_rep_off[p + 1]; ++r) {
+            int w = b->rep_weight[r];
+            if (w < 1) return fail(c, FSEG_ERR_INPUT, "rep %lld has weight %d (< 1)", (long long)r, w);
+            if (w != 1) expanded = true;
+            lanes += w;
+            i64 e0 = b->rep_exon_off[r], e1 = b->rep_exon_off[r + 1];
+            if (e1 < e0) return fail(c, FSEG_ERR_ARG, "rep_exon_off not monotone");
+            for (i64 e = e0; e < e1; ++e) {
+                if (!(b->ex_ts[e] < b->ex_te[e])) return fail(c, FSEG_ERR_INPUT, "rep %lld: exon with start >= end (py/freddie_segment.py:160)", (long long)r);
+                if (e > e0 && !(b->ex_te[e - 1] <= b->ex_ts[e])) return fail(c, FSEG_ERR_INPUT, "rep %lld: exons out of order (py/freddie_segment.py:158)", (long long)r);
+            }
+        }
+        part_lane_off[p + 1] = lanes;
+    }
+    if (lanes >= 0x7fffffffLL) return fail(c, FSEG_ERR_UNSUPPORTED, "too many reads in one upload");
+    std::vector<int> lane_rep;
+    if (expanded) {
+        lane_rep.reserve((size_t)lanes);
+        for (i64 r = 0; r < R; ++r) for (int q = 0; q < b->rep_weight[r]; ++q) lane_rep.push_back((int)r);
+    }
+    std::vector<int> tile_iv, tile_y0;
+    for (i64 k = 0; k < K; ++k) {
+        i64 len = pos_off[k + 1] - pos_off[k];
+        for (i64 y = 0; y < len; y += kSmoothTile) { tile_iv.push_back((int)k); tile_y0.push_back((int)y); }
+    }
+    c->n_part = np; c->K = K; c->R = R; c->I = I; c->NPOS = NPOS; c->LANES = lanes; c->expanded = expanded;
+    c->n_tiles = (int)tile_iv.size();
+    c->part_iv_off.assign(b->part_iv_off, b->part_iv_off + np + 1);
+    c->part_rep_off.assign(b->part_rep_off, b->part_rep_off + np + 1);
+    c->part_lane_off = part_lane_off;
+    c->pos_off = pos_off;
+    c->iv_start_h.assign(b->iv_start, b->iv_start + K);
+    TRY(upload_vec(c, c->d_part_iv_off, b->part_iv_off, (size_t)np + 1));
+    TRY(upload_vec(c, c->d_part_rep_off, b->part_rep_off, (size_t)np + 1));
+    TRY(upload_vec(c, c->d_part_lane_off, part_lane_off.data(), (size_t)np + 1));
+    TRY(upload_vec(c, c->d_iv_start, b->iv_start, (size_t)K));
+    TRY(upload_vec(c, c->d_iv_end, b->iv_end, (size_t)K));
+    TRY(upload_vec(c, c->d_pos_off, pos_off.data(), (size_t)K + 1));
+    TRY(upload_vec(c, c->d_iv_part, iv_part.data(), (size_t)K));
+    TRY(upload_vec(c, c->d_rep_weight, b->rep_weight, (size_t)R));
+    TRY(upload_vec(c, c->d_rep_exon_off, b->rep_exon_off, (size_t)R + 1));
+    TRY(upload_vec(c, c->d_ex_ts, b->ex_ts, (size_t)I));
+    TRY(upload_vec(c, c->d_ex_te, b->ex_te, (size_t)I));
+    if (expanded) TRY(upload_vec(c, c->d_lane_rep, lane_rep.data(), lane_rep.size()));
+    TRY(upload_vec(c, c->d_tile_iv, tile_iv.data(), tile_iv.size()));
+    TRY(upload_vec(c, c->d_tile_y0, tile_y0.data(), tile_y0.size()));
+    // position-sized work buffers
+    size_t np8 = (size_t)NPOS + 16;
+    TRY(ensure(c, c->d_y_raw, np8 * 4)); TRY(ensure(c, c->d_y, np8 * 8)); TRY(ensure(c, c->d_flag, np8));
+    TRY(ensure(c, c->d_idx, np8 * 4)); TRY(ensure(c, c->d_v, np8 * 8));
+    TRY(ensure(c, c->d_bsum, ((size_t)(NPOS / kScanBlock) + 2) * 4));
+    TRY(ensure(c, c->d_g, np8 * 8)); TRY(ensure(c, c->d_pk, np8 * 4)); TRY(ensure(c, c->d_pf, np8)); TRY(ensure(c, c->d_kp, np8));
+    TRY(ensure(c, c->d_final_flag, np8));
+    TRY(ensure(c, c->d_voff, ((size_t)np + 2) * 8)); TRY(ensure(c, c->d_chunk_off, ((size_t)np + 2) * 8));
+    TRY(ensure(c, c->d_mean, ((size_t)np + 1) * 8)); TRY(ensure(c, c->d_thr, ((size_t)np + 1) * 8));
+    TRY(ensure(c, c->d_label_off, ((size_t)np + 2) * 8));
+    // candidate-sized: candidates and finals are distinct positions, so NPOS bounds them
+    TRY(ensure(c, c->d_cand_off, ((size_t)K + 2) * 8)); TRY(ensure(c, c->d_final_off, ((size_t)K + 2) * 8));
+    TRY(ensure(c, c->d_cand_y, np8 * 4)); TRY(ensure(c, c->d_fixed0, np8)); TRY(ensure(c, c->d_added, np8));
+    TRY(ensure(c, c->d_fixed, np8)); TRY(ensure(c, c->d_chosen, np8));
+    TRY(ensure(c, c->d_final_y, np8 * 4)); TRY(ensure(c, c->d_final_pos, np8 * 4)); TRY(ensure(c, c->d_col, np8 * 16));
+    TRY(ensure(c, c->d_rseg_iv, np8 * 4)); TRY(ensure(c, c->d_rseg_s, np8 * 4)); TRY(ensure(c, c->d_rseg_e, np8 * 4));
+    // first-guess arena capacities; fseg_sync() grows them if the run reports an overflow
+    auto atleast = [](i64 &cap, i64 v) { if (cap < v) cap = v; };
+    atleast(c->chunk_cap, NPOS / 8192 + np + 8);
+    atleast(c->prob_cap, 1024); atleast(c->work_cap, 1024); atleast(c->pair_cap, 1 << 16); atleast(c->tri_cap, 1 << 18);
+    atleast(c->label_cap, 1 << 16);
+    TRY(alloc_arenas(c));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->have_batch = true; c->ran = false; c->pending = false;
+    return FSEG_OK;
+}
+
+int fseg_run(fseg_ctx *c) {
+    if (!c) return FSEG_ERR_ARG;
+    if (!c->have_params || !c->have_batch) return fail(c, FSEG_ERR_ARG, "fseg_run: set parameters and upload a batch first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->pending) TRY(finish_run(c));
+    TRY(enqueue_run(c));
+    c->pending = true;
+    return FSEG_OK;
+}
+
+int fseg_sync(fseg_ctx *c) {
+    if (!c) return FSEG_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->pending) return finish_run(c);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return FSEG_OK;
+}
+
+int fseg_get_sizes(fseg_ctx *c, fseg_sizes *out) {
+    if (!c || !out) return FSEG_ERR_ARG;
+    TRY(fseg_sync(c));
+    if (!c->ran) return fail(c, FSEG_ERR_ARG, "no completed run");
+    out->n_final = (int64_t)c->h_status->n_final;
+    out->label_bytes = (int64_t)c->h_status->label_bytes;
+    out->n_cand = (int64_t)c->h_status->n_cand;
+    out->n_problems = (int64_t)c->h_status->n_prob;
+    out->n_positions = c->NPOS;
+    return FSEG_OK;
+}
+
+int fseg_download(fseg_ctx *c, int64_t *part_final_off, int32_t *final_pos, int64_t *label_off, uint8_t *labels) {
+    if (!c) return FSEG_ERR_ARG;
+    TRY(fseg_sync(c));
+    if (!c->ran) return fail(c, FSEG_ERR_ARG, "no completed run");
+    hipStream_t s = c->stream;
+    if (part_final_off) {
+        std::vector<i64> fo((size_t)c->K + 1);
+        HIP_TRY(c, hipMemcpyAsync(fo.data(), c->d_final_off.p, fo.size() * 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        for (int p = 0; p <= c->n_part; ++p) part_final_off[p] = fo[(size_t)c->part_iv_off[p]];
+    }
+    if (final_pos) HIP_TRY(c, hipMemcpyAsync(final_pos, c->d_final_pos.p, (size_t)c->h_status->n_final * 4, hipMemcpyDeviceToHost, s));
+    if (label_off) HIP_TRY(c, hipMemcpyAsync(label_off, c->d_label_off.p, ((size_t)c->n_part + 1) * 8, hipMemcpyDeviceToHost, s));
+    if (labels && c->h_status->label_bytes) HIP_TRY(c, hipMemcpyAsync(labels, c->d_labels.p, (size_t)c->h_status->label_bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    return FSEG_OK;
+}
+
+int fseg_tap(fseg_ctx *c, int what, void *dst, int64_t cap_bytes, int64_t *n_bytes) {
+    if (!c || !n_bytes) return FSEG_ERR_ARG;
+    TRY(fseg_sync(c));
+    if (!c->ran) return fail(c, FSEG_ERR_ARG, "no completed run");
+    const Status &st = *c->h_status;
+    const void *src = nullptr;
+    i64 bytes = 0;
+    std::vector<int> packed;
+    switch (what) {
+        case FSEG_TAP_POS_OFF: src = c->d_pos_off.p; bytes = (c->K + 1) * 8; break;
+        case FSEG_TAP_Y_RAW: src = c->d_y_raw.p; bytes = c->NPOS * 4; break;
+        case FSEG_TAP_Y: src = c->d_y.p; bytes = c->NPOS * 8; break;
+        case FSEG_TAP_THRESHOLD: src = c->d_thr.p; bytes = (i64)c->n_part * 8; break;
+        case FSEG_TAP_CAND_OFF: src = c->d_cand_off.p; bytes = (c->K + 1) * 8; break;
+        case FSEG_TAP_CAND_Y: src = c->d_cand_y.p; bytes = (i64)st.n_cand * 4; break;
+        case FSEG_TAP_FIXED: src = c->d_fixed.p; bytes = (i64)st.n_cand; break;
+        case FSEG_TAP_CHOSEN: src = c->d_chosen.p; bytes = (i64)st.n_cand; break;
+        case FSEG_TAP_FINAL_OFF: src = c->d_final_off.p; bytes = (c->K + 1) * 8; break;
+        case FSEG_TAP_FINAL_Y: src = c->d_final_y.p; bytes = (i64)st.n_final * 4; break;
+        case FSEG_TAP_PROBLEMS: {
+            size_t n = (size_t)st.n_prob;
+            std::vector<int> iv(n), sa(n), nn(n), ch(n);
+            if (n) {
+                HIP_TRY(c, hipMemcpy(iv.data(), c->d_prob_iv.p, n * 4, hipMemcpyDeviceToHost));
+                HIP_TRY(c, hipMemcpy(sa.data(), c->d_prob_start.p, n * 4, hipMemcpyDeviceToHost));
+                HIP_TRY(c, hipMemcpy(nn.data(), c->d_prob_n.p, n * 4, hipMemcpyDeviceToHost));
+                HIP_TRY(c, hipMemcpy(ch.data(), c->d_prob_chain.p, n * 4, hipMemcpyDeviceToHost));
+            }
+            packed.resize(n * 4);
+            for (size_t i = 0; i < n; ++i) { packed[4 * i] = iv[i]; packed[4 * i + 1] = sa[i]; packed[4 * i + 2] = nn[i]; packed[4 * i + 3] = ch[i]; }
+            bytes = (i64)n * 16;
+            *n_bytes = bytes;
+            if (dst && cap_bytes > 0) memcpy(dst, packed.data(), (size_t)(bytes < cap_bytes ? bytes : cap_bytes));
+            return FSEG_OK;
+        }
+        default: return fail(c, FSEG_ERR_ARG, "unknown tap %d", what);
+    }
+    *n_bytes = bytes;
+    if (dst && cap_bytes > 0 && bytes > 0)
+        HIP_TRY(c, hipMemcpy(dst, src, (size_t)(bytes < cap_bytes ? bytes : cap_bytes), hipMemcpyDeviceToHost));
+    return FSEG_OK;
+}
+
+int fseg_set_profiling(fseg_ctx *c, int on) { if (!c) return FSEG_ERR_ARG; c->profiling = on != 0; return FSEG_OK; }
+int fseg_n_stages(void) { return ST_COUNT; }
+const char *fseg_stage_name(int i) { return (i >= 0 && i < ST_COUNT) ? kStageNames[i] : ""; }
+int fseg_stage_ms(fseg_ctx *c, float *ms) {
+    if (!c || !ms) return FSEG_ERR_ARG;
+    TRY(fseg_sync(c));
+    for (int i = 0; i < ST_COUNT; ++i) ms[i] = c->stage_ms[i];
+    return FSEG_OK;
+}
+
+int64_t fseg_scoring_algorithmic_bytes(fseg_ctx *c) {
+    if (!c || !c->ran) return -1;
+    // per partition 4*(N_p + K_p)*R_p + 4*R_p, R_p = read reps
+    std::vector<i64> co((size_t)c->K + 1);
+    if (hipMemcpy(co.data(), c->d_cand_off.p, co.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    i64 total = 0;
+    for (int p = 0; p < c->n_part; ++p) {
+        i64 Np = co[(size_t)c->part_iv_off[p + 1]] - co[(size_t)c->part_iv_off[p]];
+        i64 Kp = c->part_iv_off[p + 1] - c->part_iv_off[p];
+        i64 Rp = c->part_rep_off[p + 1] - c->part_rep_off[p];
+        total += 4 * (Np + Kp) * Rp + 4 * Rp;
+    }
+    return total;
+}
+
+}  // extern "C"

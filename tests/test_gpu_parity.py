@@ -1,0 +1,44 @@
+"""GPU parity: the HIP path (through the C-ABI) against the CPU oracle on the same seeded inputs."""
+import numpy as np
+import pytest
+
+import util
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    ("retention", dict(n_reads=200, n_exons=150, rp=0.05), {}),
+    ("dense", dict(n_reads=200, n_exons=150, rp=0.0), {}),
+    ("long_reads", dict(n_reads=200, n_exons=150, rp=0.05, max_span=0), {}),
+    ("r1000", dict(n_reads=1000, n_exons=150, rp=0.05), {}),
+    ("ont_sigma3", dict(n_reads=1000, n_exons=150, rp=0.08, jp=0.8, jsd=6.0), dict(sigma=3.0, threshold_rate=0.8)),
+    ("refine", dict(n_reads=600, n_exons=60, rp=0.2, max_span=0), dict(min_read_support_outside=1000)),
+    ("weights_ends", dict(n_reads=400, n_exons=80, rp=0.1, jp=0.0), dict(ignore_ends=False, max_problem_size=10, variance_factor=1.0)),
+    ("sigma12", dict(n_reads=400, n_exons=80, rp=0.3, jp=0.5, jsd=4, max_span=0), dict(sigma=12.0, min_read_support_outside=0)),
+]
+
+
+@pytest.mark.parametrize("name,gen,params", CASES, ids=[c[0] for c in CASES])
+def test_single_partition(gpu_ctx, name, gen, params):
+    part = util.make_partition(3, **gen)
+    o = util.run_oracle(part, params)
+    util.run_gpu(gpu_ctx, [part], params)
+    rep = util.compare_partitions(gpu_ctx, [part], [o])
+    assert rep["y_identical"], "smoothed signal differs from the oracle by %g" % rep["max_y_err"]
+
+
+def test_batch_of_partitions(gpu_ctx):
+    parts = [util.make_partition(i, n_reads=150 + 37 * i, n_exons=40 + 11 * i, rp=0.05 * (i % 3)) for i in range(12)]
+    oracles = [util.run_oracle(p) for p in parts]
+    util.run_gpu(gpu_ctx, parts)
+    util.compare_partitions(gpu_ctx, parts, oracles)
+
+
+def test_rerun_is_idempotent(gpu_ctx):
+    part = util.make_partition(5, n_reads=300, n_exons=100, rp=0.1)
+    util.run_gpu(gpu_ctx, [part])
+    a = gpu_ctx.download()
+    gpu_ctx.run(); gpu_ctx.sync()
+    b = gpu_ctx.download()
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)

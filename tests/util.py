@@ -1,0 +1,81 @@
+"""Shared helpers of the test-suite: synthetic partitions -> flat arrays, oracle runs, GPU runs."""
+import numpy as np
+
+from freddie_amd import pack, synth, tables
+from oracle import oracle
+
+DEFAULTS = dict(sigma=5.0, threshold_rate=0.9, variance_factor=3.0, max_problem_size=50,
+                min_read_support_outside=3, ignore_ends=True)
+
+
+def make_partition(index, dedupe=True, **gen_kw):
+    gen_kw.setdefault("with_seq", False)
+    g = synth.generate(index, **gen_kw)
+    return pack.pack_partition(g.iv_start, g.iv_end, g.read_exon_off, g.ex_ts, g.ex_te, dedupe=dedupe)
+
+
+def param_tables(params):
+    return dict(w_main=tables.gaussian_half_kernel(params["sigma"], 4.0),
+                w_refine=tables.gaussian_half_kernel(params["sigma"], 1.0),
+                h_table=np.asarray(tables.smooth_threshold(params["threshold_rate"]), np.float64))
+
+
+def run_oracle(part, params=None, tabs=None, stop_after=0):
+    params = dict(DEFAULTS, **(params or {}))
+    tabs = tabs or param_tables(params)
+    return oracle.segment(part.iv_start, part.iv_end, part.rep_weight, part.rep_exon_off, part.ex_ts, part.ex_te,
+                          stop_after=stop_after, **params, **tabs)
+
+
+def run_gpu(ctx, parts, params=None, tabs=None):
+    params = dict(DEFAULTS, **(params or {}))
+    tabs = tabs or param_tables(params)
+    ctx.set_params(**params, **tabs)
+    ctx.upload(**pack.concat_batch(parts))
+    ctx.run()
+    ctx.sync()
+    return ctx
+
+
+def compare_partitions(ctx, parts, oracles, y_tol=1e-6):
+    """Assert every tap of the GPU run equals the per-partition oracle results (bit-exact for
+    integers; the smoothed signal within y_tol (north_star: 1e-6) and, as built, identical)."""
+    pos_off = ctx.tap("pos_off"); y_raw = ctx.tap("y_raw"); y = ctx.tap("y"); thr = ctx.tap("threshold")
+    cand_off = ctx.tap("cand_off"); cand_y = ctx.tap("cand_y"); fixed = ctx.tap("fixed"); chosen = ctx.tap("chosen")
+    final_off = ctx.tap("final_off"); final_y = ctx.tap("final_y")
+    pfo, final_pos, label_off, labels = ctx.download()
+    k0 = 0
+    report = dict(max_y_err=0.0, y_identical=True)
+    for p, (part, o) in enumerate(zip(parts, oracles)):
+        assert o["error"] == 0, o["errmsg"]
+        K = len(part.iv_start)
+        P0, P1 = pos_off[k0], pos_off[k0 + K]
+        assert np.array_equal(pos_off[k0:k0 + K + 1] - P0, o["pos_off"]), "pos_off p%d" % p
+        assert np.array_equal(y_raw[P0:P1].astype(np.float64), o["Y_raw"]), "Y_raw p%d" % p
+        err = np.abs(y[P0:P1] - o["Y"]).max() if P1 > P0 else 0.0
+        report["max_y_err"] = max(report["max_y_err"], float(err))
+        report["y_identical"] &= bool(np.array_equal(y[P0:P1], o["Y"]))
+        assert err <= y_tol, "Y p%d err %g" % (p, err)
+        assert (thr[p] == o["threshold"]) or (np.isnan(thr[p]) and np.isnan(o["threshold"])), \
+            "threshold p%d: %r vs %r" % (p, thr[p], o["threshold"])
+        c0, c1 = cand_off[k0], cand_off[k0 + K]
+        assert np.array_equal(cand_off[k0:k0 + K + 1] - c0, o["cand_off"]), "cand_off p%d" % p
+        assert np.array_equal(cand_y[c0:c1], o["cands"]), "cands p%d" % p
+        fx = np.zeros(c1 - c0, np.uint8)
+        for k in range(K):
+            fx[o["cand_off"][k] + o["fixed"][o["fixed_off"][k]:o["fixed_off"][k + 1]]] = 1
+        assert np.array_equal(fixed[c0:c1], fx), "fixed p%d" % p
+        ch = np.zeros(c1 - c0, np.uint8)
+        for k in range(K):
+            ch[o["cand_off"][k] + o["finalc"][o["finalc_off"][k]:o["finalc_off"][k + 1]]] = 1
+        assert np.array_equal(chosen[c0:c1], ch), "chosen (run_optimize) p%d: %d vs %d set" % (p, chosen[c0:c1].sum(), ch.sum())
+        f0, f1 = final_off[k0], final_off[k0 + K]
+        assert np.array_equal(final_off[k0:k0 + K + 1] - f0, o["final_off"]), "final_off p%d" % p
+        assert np.array_equal(final_y[f0:f1], o["final_y"]), "final_y p%d" % p
+        assert pfo[p] == f0 and pfo[p + 1] == f1
+        assert np.array_equal(final_pos[f0:f1], o["final_pos"]), "final_pos p%d" % p
+        S = (f1 - f0) - 1
+        lab = labels[label_off[p]:label_off[p + 1]].reshape(part.n_reps, S)
+        assert np.array_equal(lab, o["labels"] + ord("0")), "labels p%d" % p
+        k0 += K
+    return report
