@@ -1062,8 +1062,8 @@ struct DevBuf {
     template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
-enum Stage { ST_HIST, ST_SMOOTH, ST_THRESHOLD, ST_CANDIDATES, ST_FIX, ST_SCORE, ST_DP, ST_REFINE, ST_FINAL, ST_LABEL, ST_COUNT };
-const char *kStageNames[ST_COUNT] = {"histogram", "smooth", "threshold", "candidates", "fix_split", "interval_scoring",
+enum Stage { ST_HIST, ST_SMOOTH, ST_THRESHOLD, ST_CANDIDATES, ST_FIX, ST_SCORE_PREP, ST_SCORE, ST_DP, ST_REFINE, ST_FINAL, ST_LABEL, ST_COUNT };
+const char *kStageNames[ST_COUNT] = {"histogram", "smooth", "threshold", "candidates", "fix_split", "scoring_prep", "interval_scoring",
                                      "dp", "refine", "final_positions", "labels"};
 
 }  // namespace
@@ -1248,6 +1248,9 @@ int enqueue_run(fseg_ctx *c) {
                            c->P.threshold_rate, c->d_pair_thr.as<int2>(), c->pair_cap);
         hipLaunchKernelGGL(k_zero_arenas, dim3(1024), dim3(256), 0, s, st, c->d_out.as<unsigned>(), c->tri_cap,
                            c->d_amb.as<unsigned>(), c->pair_cap);
+    }
+    mark(6);
+    if (c->prob_cap > 0) {
         hipLaunchKernelGGL(k_score, dim3(grid_for(c->work_cap, 1, 256)), dim3(256), c->score_lds, s, st, pr, c->prob_cap,
                            c->d_work_prob.as<int>(), c->d_work_chunk.as<int>(), c->work_cap, c->d_cand_off.as<i64>(),
                            c->d_cand_y.as<int>(), c->d_iv_part.as<int>(), c->d_iv_start.as<int>(),
@@ -1256,14 +1259,14 @@ int enqueue_run(fseg_ctx *c) {
                            c->d_ex_ts.as<int>(), c->d_ex_te.as<int>(), c->d_pair_thr.as<int2>(), c->pair_cap,
                            c->d_out.as<unsigned>(), c->tri_cap, c->d_amb.as<unsigned>());
     }
-    mark(6);
+    mark(7);
     if (c->prob_cap > 0) {
         hipLaunchKernelGGL(k_dp, dim3(grid_for(c->prob_cap, 1, 1280)), dim3(64), 0, s, st, pr, c->prob_cap,
                            c->d_cand_off.as<i64>(), c->d_cand_y.as<int>(), c->d_out.as<unsigned>(), c->tri_cap,
                            c->d_amb.as<unsigned>(), c->pair_cap, c->P.min_read_support_outside,
                            c->d_chosen.as<unsigned char>());
     }
-    mark(7);
+    mark(8);
     // S6
     HIP_TRY(c, hipMemsetAsync(c->d_final_flag.p, 0, (size_t)NPOS, s));
     hipLaunchKernelGGL(k_segments, dim3(grid_for(K, 1, 8192)), dim3(64), 0, s, K, c->d_pos_off.as<i64>(),
@@ -1274,14 +1277,14 @@ int enqueue_run(fseg_ctx *c) {
                        c->d_rseg_e.as<int>(), c->d_pos_off.as<i64>(), c->d_y_raw.as<int>(), c->d_w_refine.as<double>(),
                        c->P.radius_refine, c->P.sigma, c->d_g.as<double>(), c->d_pk.as<int>(),
                        c->d_pf.as<unsigned char>(), c->d_kp.as<unsigned char>(), c->d_final_flag.as<unsigned char>());
-    mark(8);
+    mark(9);
     TRY(launch_scan(c, c->d_final_flag.as<unsigned char>(), NPOS, &st->n_final));
     hipLaunchKernelGGL(k_pos_gather, dim3(tile_grid), dim3(256), 0, s, c->n_tiles, c->d_tile_iv.as<int>(),
                        c->d_tile_y0.as<int>(), c->d_pos_off.as<i64>(), c->d_final_flag.as<unsigned char>(),
                        c->d_idx.as<int>(), c->d_iv_start.as<int>(), c->d_final_y.as<int>(), c->d_final_pos.as<int>(),
                        c->d_final_off.as<i64>());
     hipLaunchKernelGGL(k_set_total, dim3(1), dim3(1), 0, s, c->d_final_off.as<i64>(), K, &st->n_final);
-    mark(9);
+    mark(10);
     // S7
     hipLaunchKernelGGL(k_label_plan, dim3(1), dim3(256), 0, s, n_part, c->d_part_iv_off.as<i64>(),
                        c->d_part_rep_off.as<i64>(), c->d_final_off.as<i64>(), c->d_label_off.as<i64>(), st, c->label_cap);
@@ -1293,7 +1296,7 @@ int enqueue_run(fseg_ctx *c) {
                            c->d_label_off.as<i64>(), c->label_cap, c->d_part_iv_off.as<i64>(), c->d_part_rep_off.as<i64>(),
                            c->d_final_off.as<i64>(), c->d_col.as<int4>(), c->d_rep_exon_off.as<i64>(), c->d_ex_ts.as<int>(),
                            c->d_ex_te.as<int>(), c->d_labels.as<unsigned char>());
-    mark(10);
+    mark(11);
     HIP_TRY(c, hipMemcpyAsync(c->h_status, st, sizeof(Status), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipGetLastError());
     return FSEG_OK;
