@@ -95,6 +95,8 @@ fsynth *fsynth_generate(const fsynth_params *pp, int32_t with_seq) {
     g->p = *pp;
     const fsynth_params p = *pp;
     uint64_t st = p.seed;
+    uint64_t sq_st = p.seed ^ 0xA5A5A5A5C3C3C3C3ULL;   /* sequence letters: own stream, so that the
+                                                           partition structure does not depend on with_seq */
     const int E = p.n_exons, NI = p.n_isoforms > 0 ? p.n_isoforms : 8;
     int32_t *gs = (int32_t *)malloc(sizeof(int32_t) * E), *ge = (int32_t *)malloc(sizeof(int32_t) * E);
     int32_t pos = p.origin;
@@ -205,14 +207,14 @@ fsynth *fsynth_generate(const fsynth_params *pp, int32_t with_seq) {
         if (with_seq) {
             GROW(g->seq, seq_cap, n_seq + total, char);
             char *sq = g->seq + n_seq;
-            for (int32_t x = 0; x < total; ++x) sq[x] = ACGT[sm64(&st) & 3];
+            for (int32_t x = 0; x < total; ++x) sq[x] = ACGT[sm64(&sq_st) & 3];
             /* poly tails with ~4% impurities */
             if (tail_kind == 0)
                 for (int32_t x = 0; x < poly_len; ++x)
-                    if (urange(&st, 0, 24) != 0) sq[q + x] = 'A';
+                    if (urange(&sq_st, 0, 24) != 0) sq[q + x] = 'A';
             if (tail_kind == 1)
                 for (int32_t x = 0; x < poly_len; ++x)
-                    if (urange(&st, 0, 24) != 0) sq[lead + x] = 'T';
+                    if (urange(&sq_st, 0, 24) != 0) sq[lead + x] = 'T';
             n_seq += total;
         }
     }

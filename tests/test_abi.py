@@ -1,0 +1,42 @@
+"""The C-ABI library loads and exports every symbol include/freddie_seg.h declares (no compute)."""
+import os
+import re
+
+import pytest
+
+from freddie_amd import _lib, build
+
+
+def header_functions():
+    text = open(os.path.join(build.INCLUDE, "freddie_seg.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(fseg_[a-z_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported():
+    L = _lib.load()
+    declared = header_functions()
+    assert len(declared) >= 14
+    for name in declared:
+        assert hasattr(L, name), "libfreddie_seg.so does not export %s" % name
+    assert sorted(_lib.EXPORTS) == declared
+    assert L.fseg_abi_version() == 1
+    assert L.fseg_n_stages() >= 8
+
+
+def test_fails_loudly_without_a_gpu():
+    import torch
+    if torch.cuda.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(_lib.SegError, match="no CPU fallback"):
+        _lib.Context(0)
+
+
+def test_product_does_not_import_the_oracle():
+    root = os.path.dirname(build.INCLUDE)
+    for dirpath, _, files in os.walk(os.path.join(root, "freddie_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h", ".c")):
+                src = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), os.path.join(dirpath, f)
+                assert "libfreddie_oracle" not in src

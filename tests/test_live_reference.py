@@ -1,0 +1,34 @@
+"""Differential test of the oracle against the live reference; only where /root/reference exists
+(the build container).  Skipped on the GPU box, where the reference is absent."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+import refrun  # noqa: E402
+import util  # noqa: E402
+from freddie_amd import pack, synth  # noqa: E402
+
+pytestmark = pytest.mark.skipif(not refrun.available(), reason="reference not present")
+
+
+@pytest.mark.parametrize("seed", [101, 102, 103])
+def test_oracle_vs_live_reference(tmp_path, seed):
+    rng = np.random.default_rng(seed)
+    gen = dict(n_reads=int(rng.integers(50, 400)), n_exons=int(rng.integers(5, 120)), rp=float(rng.choice([0, .05, .3])),
+               jp=float(rng.choice([0, .3, .8])), jsd=float(rng.choice([2, 6])), max_span=int(rng.choice([0, 6, 14])))
+    run = dict(sigma=float(rng.choice([3.0, 5.0, 8.0])), threshold_rate=float(rng.choice([.8, .9, .95])),
+               min_read_support_outside=int(rng.choice([0, 3, 10])), max_problem_size=int(rng.choice([20, 50])))
+    synth.generate(seed, write_dir=str(tmp_path / "in"), **gen)
+    tint, rec = refrun.run_recorded(str(tmp_path / "in"), str(tmp_path / "out"), "chrS", seed, **run)
+    g = synth.generate(seed, with_seq=False, **gen)
+    part = pack.pack_partition(g.iv_start, g.iv_end, g.read_exon_off, g.ex_ts, g.ex_te)
+    assert part.n_reps == len(tint["read_reps"])
+    o = util.run_oracle(part, dict(run, ignore_ends=True))
+    assert o["error"] == 0, o["errmsg"]
+    assert np.array_equal(np.concatenate(rec["Y"]), o["Y"])
+    assert np.array_equal(np.array(tint["final_positions"], np.int32), o["final_pos"])
+    for ri, (_, ridxs) in enumerate(tint["read_reps"]):
+        assert list(o["labels"][ri]) == tint["reads"][ridxs[0]]["data"]
