@@ -15,6 +15,7 @@
 // No CPU fallback exists in this library: without a GPU fseg_create() fails.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -33,7 +34,7 @@ constexpr int kSmoothTile = 1024;      // positions per smoothing / peak tile
 constexpr int kMaxRadius = 200;        // sigma <= 50, truncate 4.0 (py/freddie_segment.py:106,:755)
 constexpr int kScanBlock = 2048;       // elements per scan workgroup
 constexpr int kNMax = 60;              // largest DP problem handled by the LDS-resident scoring kernel
-constexpr int kLaneChunk = 4096;       // reads ("lanes") per scoring work item (must stay < 65536: u16 counters)
+constexpr int kLaneChunk = 256;        // reads ("lanes") per scoring work item (u16 counters: must stay < 65536)
 constexpr int kSub = 64;               // reads per scoring sub-chunk (two 32-bit plane words)
 constexpr i64 kNegInf = (i64)(-0x7fffffffffffffffLL - 1);
 
@@ -48,6 +49,7 @@ enum : unsigned {
     kErrOverflowLabels = 64u,
     kErrOverflowProblems = 128u,
     kErrOverflowChunks = 256u,
+    kErrOverflowCov = 512u,
 };
 
 struct Status {
@@ -63,8 +65,10 @@ struct Status {
     u64 n_rseg;
     u64 n_final;
     u64 label_bytes;
+    u64 cov_used;      // elements of the coverage arena
     u64 work_queue;    // dynamic work counter of the scoring kernel
     u64 dp_queue;
+    u64 cov_queue;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -426,8 +430,11 @@ __global__ void k_set_total(i64 *off, i64 K, const u64 *total) { if (threadIdx.x
 //   fixed = {0, N-1} U {c : Y[cand_c] > thr}                      py/freddie_segment.py:776-783
 //   break_large_problems                                           :623-645 (pairs taken before insertion)
 //   problems = consecutive fixed pairs                             :581
-// one wave per tint interval.  Problems with n == 2 have no (i,j,k) and can never add a breakpoint,
-// so only n >= 3 are emitted.
+// One wave per tint interval, lane = candidate inside a 64-candidate tile; the "previous fixed
+// candidate" of a lane comes from the tile's ballot mask or from the carry of earlier tiles.
+// Problems with n == 2 have no (i,j,k) and can never add a breakpoint, so only n >= 3 are emitted.
+// For each problem the kernel also finds the range of position-sorted reads that can overlap its
+// window and carves its share of the arenas (one wave-aggregated atomic per arena and tile).
 // ---------------------------------------------------------------------------------------------
 struct ProblemArrays {
     int *iv;        // interval
@@ -437,15 +444,32 @@ struct ProblemArrays {
     i64 *tri_off;   // offset into the out-count arena
     int *flags;     // bit0: some pair has lo < 0 (a read with zero coverage is ambiguous there)
     int *chain;     // number of backtracked triples (debug)
+    i64 *cov_off;   // offset into the coverage arena
+    int *lane_lo;   // first lane (position-sorted read) that can overlap the problem's window
+    int *lane_n;    // number of lanes examined: [lane_lo, lane_lo + lane_n)
+    i64 *work_base; // first work item of the problem
 };
 
-__global__ void __launch_bounds__(64) k_fix(i64 K, const i64 *pos_off, const int *iv_part, const i64 *cand_off,
-                                            const int *cand_y, const double *yv, const double *thr_part, int mps,
-                                            unsigned char *fixed0, unsigned char *added, unsigned char *fixed,
-                                            unsigned char *chosen, ProblemArrays pr, i64 prob_cap,
-                                            const i64 *part_lane_off, int *work_prob, int *work_chunk, i64 work_cap,
-                                            Status *st) {
+__device__ __forceinline__ i64 wave_excl_scan(i64 v, i64 *total) {
     int lane = lane_id();
+    i64 x = v;
+    for (int d = 1; d < 64; d <<= 1) {
+        i64 y = __shfl_up(x, d);
+        if (lane >= d) x += y;
+    }
+    *total = __shfl(x, 63);
+    return x - v;
+}
+
+__global__ void __launch_bounds__(64) k_fix(i64 K, const i64 *pos_off, const int *iv_part, const int *iv_start,
+                                            const i64 *cand_off, const int *cand_y, const double *yv,
+                                            const double *thr_part, int mps, unsigned char *fixed0,
+                                            unsigned char *added, unsigned char *fixed, unsigned char *chosen,
+                                            ProblemArrays pr, i64 prob_cap, const i64 *part_lane_off,
+                                            const int *lane_start, const int *lane_pmax, int *work_prob,
+                                            int *work_chunk, i64 work_cap, Status *st) {
+    int lane = lane_id();
+    const u64 lt_mask = (1ULL << lane) - 1ULL;
     for (i64 k = blockIdx.x; k < K; k += gridDim.x) {
         i64 c0 = cand_off[k];
         int N = (int)(cand_off[k + 1] - c0);
@@ -461,78 +485,100 @@ __global__ void __launch_bounds__(64) k_fix(i64 K, const i64 *pos_off, const int
             }
         }
         __syncthreads();
-        // break_large_problems over the original consecutive fixed pairs
-        int prev = -1;
+        // break_large_problems over the original consecutive fixed pairs; the lane that owns the
+        // right end of an oversized gap places its anchors
+        int carry = -1;
         for (int t0 = 0; t0 < N; t0 += 64) {
             int c = t0 + lane;
-            u64 mask = __ballot(c < N && fixed0[c0 + c]);
-            while (mask) {
-                int b = __ffsll((long long)mask) - 1;
-                mask &= mask - 1;
-                int cur = t0 + b;
-                if (prev >= 0) {
-                    int size = cur - prev + 1;
-                    if (size > mps) {
-                        int cnt = (int)ceil((double)size / (double)mps);
-                        double step = (double)size / (double)cnt;
-                        for (int i = 1; i < cnt; ++i) {
-                            int anchor = (int)((double)prev + __dmul_rn((double)i, step));
-                            double best = -INFINITY;
-                            int best_c = -1;
-                            bool bad = false;
-                            for (int cc = anchor - 5; cc < anchor + 5; ++cc) {
-                                int ci = cc < 0 ? cc + N : cc;          // Python negative-index wraparound
-                                if (ci < 0 || ci >= N) { bad = true; continue; }
-                                double val = y[cy[ci]];
-                                if (val > best) { best = val; best_c = cc; }
-                            }
-                            if (bad || !(best > 0.0) || best_c < 0) { if (lane == 0) atomicOr(&st->err, kErrBreakAssert); }
-                            else if (lane == 0) added[c0 + best_c] = 1;
+            bool f = c < N && fixed0[c0 + c];
+            u64 mask = __ballot(f);
+            if (f) {
+                u64 below = mask & lt_mask;
+                int prev = below ? t0 + 63 - __clzll((long long)below) : carry;
+                int size = c - prev + 1;
+                if (prev >= 0 && size > mps) {
+                    int cnt = (int)ceil((double)size / (double)mps);
+                    double step = (double)size / (double)cnt;
+                    for (int i = 1; i < cnt; ++i) {
+                        int anchor = (int)((double)prev + __dmul_rn((double)i, step));
+                        double best = -INFINITY;
+                        int best_c = -1;
+                        bool bad = false;
+                        for (int cc = anchor - 5; cc < anchor + 5; ++cc) {
+                            int ci = cc < 0 ? cc + N : cc;          // Python negative-index wraparound
+                            if (ci < 0 || ci >= N) { bad = true; continue; }
+                            double val = y[cy[ci]];
+                            if (val > best) { best = val; best_c = cc; }
                         }
+                        if (bad || !(best > 0.0) || best_c < 0) atomicOr(&st->err, kErrBreakAssert);
+                        else added[c0 + best_c] = 1;
                     }
                 }
-                prev = cur;
             }
+            if (mask) carry = t0 + 63 - __clzll((long long)mask);
         }
         __syncthreads();
-        // final fixed set and problems
-        prev = -1;
-        i64 lanes_p = part_lane_off[part + 1] - part_lane_off[part];
-        int chunks = (int)((lanes_p + kLaneChunk - 1) / kLaneChunk);
+        // final fixed set, problems, arena carving
+        carry = -1;
+        const int g_base = iv_start[k];
+        const i64 L0 = part_lane_off[part], L1 = part_lane_off[part + 1];
         for (int t0 = 0; t0 < N; t0 += 64) {
             int c = t0 + lane;
             bool f = c < N && (fixed0[c0 + c] | added[c0 + c]);
             if (c < N) { fixed[c0 + c] = f; chosen[c0 + c] = f; }
             u64 mask = __ballot(f);
-            while (mask) {
-                int b = __ffsll((long long)mask) - 1;
-                mask &= mask - 1;
-                int cur = t0 + b;
-                if (prev >= 0 && cur - prev + 1 >= 3) {
-                    int n = cur - prev + 1;
-                    u64 slot = 0, wbase = 0, poff = 0, toff = 0;
-                    if (lane == 0) {
-                        slot = atomicAdd(&st->n_prob, 1ULL);
-                        poff = atomicAdd(&st->pair_used, (u64)n * (n - 1) / 2);
-                        toff = atomicAdd(&st->tri_used, (u64)n * (n - 1) * (n - 2) / 6);
-                        wbase = atomicAdd(&st->n_work, (u64)chunks);
-                        if (n > kNMax) atomicOr(&st->err, kErrProblemTooLarge);
-                        if ((i64)slot < prob_cap) {
-                            pr.iv[slot] = (int)k; pr.start[slot] = prev; pr.n[slot] = n;
-                            pr.pair_off[slot] = (i64)poff; pr.tri_off[slot] = (i64)toff;
-                            pr.flags[slot] = 0; pr.chain[slot] = 0;
-                        } else atomicOr(&st->err, kErrOverflowProblems);
-                    }
-                    slot = __shfl(slot, 0); wbase = __shfl(wbase, 0);
-                    if ((i64)slot < prob_cap) {
-                        for (int q = lane; q < chunks; q += 64) {
-                            if ((i64)(wbase + q) < work_cap) { work_prob[wbase + q] = (int)slot; work_chunk[wbase + q] = q; }
+            int prev = -1;
+            if (f) { u64 below = mask & lt_mask; prev = below ? t0 + 63 - __clzll((long long)below) : carry; }
+            bool is_prob = f && prev >= 0 && (c - prev + 1) >= 3;
+            u64 pmask = __ballot(is_prob);
+            if (pmask) {
+                int n = is_prob ? c - prev + 1 : 0;
+                int lo_lane = 0, n_lanes = 0;
+                if (is_prob) {
+                    // reads are sorted by their first position; lane_pmax = running max of their last position
+                    int g0 = g_base + cy[prev], g1 = g_base + cy[c];
+                    i64 a = L0, b = L1;
+                    while (a < b) { i64 m = (a + b) >> 1; if (lane_pmax[m] < g0) a = m + 1; else b = m; }
+                    i64 lo = a;
+                    a = lo; b = L1;
+                    while (a < b) { i64 m = (a + b) >> 1; if (lane_start[m] < g1) a = m + 1; else b = m; }
+                    lo_lane = (int)lo; n_lanes = (int)(a - lo);
+                }
+                int chunks = (n_lanes + kLaneChunk - 1) / kLaneChunk;
+                i64 t_slot, t_pair, t_tri, t_work, t_cov;
+                i64 e_slot = wave_excl_scan(is_prob ? 1 : 0, &t_slot);
+                i64 e_pair = wave_excl_scan((i64)n * (n - 1) / 2, &t_pair);
+                i64 e_tri = wave_excl_scan((i64)n * (n - 1) * (n - 2) / 6, &t_tri);
+                i64 e_work = wave_excl_scan(chunks, &t_work);
+                i64 e_cov = wave_excl_scan((i64)chunks * kLaneChunk * n, &t_cov);
+                u64 b_slot = 0, b_pair = 0, b_tri = 0, b_work = 0, b_cov = 0;
+                if (lane == 0) {
+                    b_slot = atomicAdd(&st->n_prob, (u64)t_slot);
+                    b_pair = atomicAdd(&st->pair_used, (u64)t_pair);
+                    b_tri = atomicAdd(&st->tri_used, (u64)t_tri);
+                    b_work = atomicAdd(&st->n_work, (u64)t_work);
+                    b_cov = atomicAdd(&st->cov_used, (u64)t_cov);
+                }
+                b_slot = __shfl(b_slot, 0); b_pair = __shfl(b_pair, 0); b_tri = __shfl(b_tri, 0);
+                b_work = __shfl(b_work, 0); b_cov = __shfl(b_cov, 0);
+                if (is_prob) {
+                    i64 slot = (i64)b_slot + e_slot;
+                    if (n > kNMax) atomicOr(&st->err, kErrProblemTooLarge);
+                    if (slot < prob_cap) {
+                        pr.iv[slot] = (int)k; pr.start[slot] = prev; pr.n[slot] = n;
+                        pr.pair_off[slot] = (i64)b_pair + e_pair; pr.tri_off[slot] = (i64)b_tri + e_tri;
+                        pr.cov_off[slot] = (i64)b_cov + e_cov; pr.work_base[slot] = (i64)b_work + e_work;
+                        pr.flags[slot] = 0; pr.chain[slot] = 0;
+                        pr.lane_lo[slot] = lo_lane; pr.lane_n[slot] = n_lanes;
+                        i64 wb = (i64)b_work + e_work;
+                        for (int q = 0; q < chunks; ++q) {
+                            if (wb + q < work_cap) { work_prob[wb + q] = (int)slot; work_chunk[wb + q] = q; }
                             else atomicOr(&st->err, kErrOverflowWork);
                         }
-                    }
+                    } else atomicOr(&st->err, kErrOverflowProblems);
                 }
-                prev = cur;
             }
+            if (mask) carry = t0 + 63 - __clzll((long long)mask);
         }
         __syncthreads();
     }
@@ -581,12 +627,83 @@ __global__ void k_zero_arenas(const Status *st, unsigned *out_g, i64 tri_cap, un
 }
 
 // ---------------------------------------------------------------------------------------------
+// S5b  window coverage of every (problem, read)      get_cumulative_coverage (:188-246)
+// cov[j] = #positions of the read's closed exons in [cand_0, cand_j) = C[start+j] - C[start].
+// One thread per read of the problem's read range; the read's (ordered) exon list is merged
+// against the problem's n candidates.  Layout of a work item's block: [j][kLaneChunk reads], so
+// both this kernel's stores and the scoring kernel's loads are coalesced.  Also records, per work
+// item, which 64-read sub-chunks contain a read with any coverage in the window.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kLaneChunk) k_cov(Status *st, ProblemArrays pr, i64 prob_cap, const int *work_prob,
+                                                    const int *work_chunk, i64 work_cap, const i64 *cand_off,
+                                                    const int *cand_y, const int *iv_start, const int *lane_rep,
+                                                    const i64 *rep_exon_off, const int *ex_ts, const int *ex_te,
+                                                    unsigned *cov_g, i64 cov_cap, unsigned char *work_active) {
+    __shared__ int cp[kNMax + 4];
+    __shared__ u64 work_s;
+    __shared__ unsigned active_s;
+    i64 n_work = (i64)st->n_work < work_cap ? (i64)st->n_work : work_cap;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) { work_s = atomicAdd(&st->cov_queue, 1ULL); active_s = 0; }
+        __syncthreads();
+        i64 w = (i64)work_s;
+        if (w >= n_work) break;
+        int p = work_prob[w];
+        int chunk = work_chunk[w];
+        int n = pr.n[p];
+        i64 coff = pr.cov_off[p] + (i64)chunk * kLaneChunk * n;
+        if (n > kNMax || coff + (i64)kLaneChunk * n > cov_cap) { if (threadIdx.x == 0) work_active[w] = 0; continue; }
+        int k = pr.iv[p];
+        const int *cy = cand_y + cand_off[k] + pr.start[p];
+        int g0 = iv_start[k];
+        for (int j = threadIdx.x; j < n; j += blockDim.x) cp[j] = g0 + cy[j];
+        __syncthreads();
+        const int cp0 = cp[0];
+        int t = threadIdx.x;
+        int li = chunk * kLaneChunk + t;
+        unsigned *dst = cov_g + coff + t;
+        unsigned last = 0;
+        if (li < pr.lane_n[p]) {
+            i64 r = lane_rep[pr.lane_lo[p] + li];
+            i64 e = rep_exon_off[r], e1 = rep_exon_off[r + 1];
+            {   // first exon whose closed interval reaches cand_0 (exons of a read are ordered, :158)
+                i64 lo = e, hi = e1;
+                while (lo < hi) { i64 mid = (lo + hi) >> 1; if (ex_te[mid] < cp0) lo = mid + 1; else hi = mid; }
+                e = lo;
+            }
+            unsigned acc = 0;
+            int ts = 0, te = -1;
+            if (e < e1) { ts = ex_ts[e]; te = ex_te[e]; }
+            dst[0] = 0;
+            for (int j = 1; j < n; ++j) {
+                int cj = cp[j];
+                while (e < e1 && te < cj) {
+                    acc += (unsigned)(te + 1 - (ts > cp0 ? ts : cp0));
+                    ++e;
+                    if (e < e1) { ts = ex_ts[e]; te = ex_te[e]; }
+                }
+                unsigned part_cov = 0;
+                if (e < e1 && ts < cj) part_cov = (unsigned)(cj - (ts > cp0 ? ts : cp0));
+                last = acc + part_cov;
+                dst[(i64)j * kLaneChunk] = last;
+            }
+        } else {
+            for (int j = 0; j < n; ++j) dst[(i64)j * kLaneChunk] = 0;
+        }
+        u64 any = __ballot(last > 0);
+        if (lane_id() == 0 && any) atomicOr(&active_s, 1u << (threadIdx.x >> 6));
+        __syncthreads();
+        if (threadIdx.x == 0) work_active[w] = (unsigned char)active_s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // S5  interval scoring   (optimize(): pair labels :488-497, inside :500-506, outside :509-528)
 //
-// Work item = (problem, chunk of <= kLaneChunk reads of the problem's partition).  For 64 reads at a
+// Work item = (problem, chunk of <= kLaneChunk reads of the problem's read range).  For 64 reads at a
 // time the workgroup
-//   A. walks each read's exon list against the problem's n candidates and stores the coverage
-//      prefix cov[r][j] = #covered positions in [cand_0, cand_j)  (= C[j]-C[start], :188-246) in LDS;
+//   A. stages the coverage prefixes cov[r][j] of the 64 reads in LDS;
 //   B. evaluates every pair (i,j): yea = cov_j-cov_i >= hi_ij, nay = cov_j-cov_i <= lo_ij, shifting the
 //      64 results into two 32-bit plane words per label, kept in LDS as {yea0,yea1,nay0,nay1};
 //      ambiguous reads (neither) are counted per pair for inside(i,j) = -sum(W*amb);
@@ -596,23 +713,20 @@ __global__ void k_zero_arenas(const Status *st, unsigned *out_g, i64 tri_cap, un
 // At the end of the work item the non-zero counters go to the global table with one atomic each.
 // Reads with multiplicity W are expanded into W lanes on upload, so every lane has weight 1.
 // ---------------------------------------------------------------------------------------------
-struct ScoreShared {
-    int cp[kNMax + 4];   // candidate positions (genomic)
-};
+constexpr int kScoreThreads = 512;
+constexpr int kMaxPairs = kNMax * (kNMax - 1) / 2;
+constexpr int kPairSlots = (kMaxPairs + kScoreThreads - 1) / kScoreThreads;
+constexpr int kCovStride = kNMax + 1;   // odd: read-major rows do not collide on LDS banks
 
-__global__ void __launch_bounds__(256) k_score(Status *st, ProblemArrays pr, i64 prob_cap, const int *work_prob,
-                                               const int *work_chunk, i64 work_cap, const i64 *cand_off,
-                                               const int *cand_y, const int *iv_part, const int *iv_start,
-                                               const i64 *part_lane_off, const i64 *part_rep_off, const int *lane_rep,
-                                               const i64 *rep_exon_off, const int *ex_ts, const int *ex_te,
-                                               const int2 *pair_thr, i64 pair_cap, unsigned *out_g, i64 tri_cap,
-                                               unsigned *amb_g) {
+__global__ void __launch_bounds__(kScoreThreads) k_score(Status *st, ProblemArrays pr, i64 prob_cap,
+                                                         const int *work_prob, const int *work_chunk, i64 work_cap,
+                                                         const i64 *cand_off, const int *cand_y,
+                                                         const unsigned char *work_active, const unsigned *cov_g,
+                                                         i64 cov_cap, const int2 *pair_thr, i64 pair_cap,
+                                                         unsigned *out_g, i64 tri_cap, unsigned *amb_g) {
     extern __shared__ __align__(16) unsigned char smem[];
-    __shared__ int cp[kNMax + 4];
+    __shared__ int cy_s[kNMax + 4];
     __shared__ u64 work_s;
-    __shared__ int any_active_s;
-    constexpr int kMaxPairs = kNMax * (kNMax - 1) / 2;
-    constexpr int kCovStride = kNMax + 1;   // odd: lane-major rows do not collide on LDS banks
     // dynamic LDS carve-up
     uint4 *planes = reinterpret_cast<uint4 *>(smem);                                   // kMaxPairs * 16 B
     unsigned *cov = reinterpret_cast<unsigned *>(smem + (size_t)kMaxPairs * 16);       // kSub * kCovStride * 4 B
@@ -630,79 +744,43 @@ __global__ void __launch_bounds__(256) k_score(Status *st, ProblemArrays pr, i64
         int chunk = work_chunk[w];
         int n = pr.n[p];
         i64 poff = pr.pair_off[p], toff = pr.tri_off[p];
+        i64 coff = pr.cov_off[p] + (i64)chunk * kLaneChunk * n;
         int npairs = n * (n - 1) / 2, ntri = n * (n - 1) * (n - 2) / 6;
-        if (n > kNMax || poff + npairs > pair_cap || toff + ntri > tri_cap) continue;
-        int k = pr.iv[p];
-        int part = iv_part[k];
-        const int *cy = cand_y + cand_off[k] + pr.start[p];
-        int g0 = iv_start[k];
-        i64 lane_begin = part_lane_off[part] + (i64)chunk * kLaneChunk;
-        i64 lane_end = part_lane_off[part + 1];
-        if (lane_end > lane_begin + kLaneChunk) lane_end = lane_begin + kLaneChunk;
-        i64 rep_base = part_rep_off[part];
+        if (n > kNMax || poff + npairs > pair_cap || toff + ntri > tri_cap || coff + (i64)kLaneChunk * n > cov_cap) continue;
         bool zero_ambiguous = (pr.flags[p] & 1) != 0;
-        for (int j = threadIdx.x; j < n; j += blockDim.x) cp[j] = g0 + cy[j];
+        unsigned active = zero_ambiguous ? 0xfu : work_active[w];
+        int lanes_here = pr.lane_n[p] - chunk * kLaneChunk;
+        if (lanes_here > kLaneChunk) lanes_here = kLaneChunk;
+        if (active == 0) continue;                       // no read of this chunk touches the window
+        const int *cy = cand_y + cand_off[pr.iv[p]] + pr.start[p];
+        for (int j = threadIdx.x; j < n; j += blockDim.x) cy_s[j] = cy[j];
         for (int q = threadIdx.x; q < npairs; q += blockDim.x) {
             int i, j;
             pair_decode(q, &i, &j);
             pair_ij[q] = (unsigned short)(i | (j << 8));
         }
         for (int x = threadIdx.x; x < ntri; x += blockDim.x) out16[x] = 0;
-        unsigned amb_acc[(kMaxPairs + 255) / 256];
+        unsigned amb_acc[kPairSlots];
 #pragma unroll
-        for (int s = 0; s < (kMaxPairs + 255) / 256; ++s) amb_acc[s] = 0;
+        for (int s = 0; s < kPairSlots; ++s) amb_acc[s] = 0;
         __syncthreads();
-        const int cp0 = cp[0];
-        for (i64 l0 = lane_begin; l0 < lane_end; l0 += kSub) {
-            int n_valid = (int)((lane_end - l0) < kSub ? (lane_end - l0) : kSub);
-            // ---- A: coverage prefixes -----------------------------------------------------------
-            if (threadIdx.x == 0) any_active_s = 0;
-            __syncthreads();
-            if (threadIdx.x < kSub) {
-                unsigned *row = cov + threadIdx.x * kCovStride;
-                unsigned last = 0;
-                if ((int)threadIdx.x < n_valid) {
-                    i64 l = l0 + threadIdx.x;
-                    i64 r = lane_rep ? (i64)lane_rep[l] : rep_base + (l - part_lane_off[part]);
-                    i64 e = rep_exon_off[r], e1 = rep_exon_off[r + 1];
-                    // first exon whose closed interval reaches cand_0 (exons of a read are ordered, :158)
-                    {
-                        i64 lo = e, hi = e1;
-                        while (lo < hi) { i64 mid = (lo + hi) >> 1; if (ex_te[mid] < cp0) lo = mid + 1; else hi = mid; }
-                        e = lo;
-                    }
-                    unsigned acc = 0;
-                    row[0] = 0;
-                    for (int j = 1; j < n; ++j) {
-                        int cj = cp[j];
-                        while (e < e1 && ex_te[e] < cj) {
-                            int a = ex_ts[e] > cp0 ? ex_ts[e] : cp0;
-                            acc += (unsigned)(ex_te[e] + 1 - a);
-                            ++e;
-                        }
-                        unsigned part_cov = 0;
-                        if (e < e1 && ex_ts[e] < cj) {
-                            int a = ex_ts[e] > cp0 ? ex_ts[e] : cp0;
-                            part_cov = (unsigned)(cj - a);
-                        }
-                        last = acc + part_cov;
-                        row[j] = last;
-                    }
-                } else {
-                    for (int j = 0; j < n; ++j) row[j] = 0;
-                }
-                if (last > 0) any_active_s = 1;
+        for (int sub = 0; sub < kLaneChunk / kSub; ++sub) {
+            if (!((active >> sub) & 1u)) continue;
+            int n_valid = lanes_here - sub * kSub;
+            if (n_valid <= 0) break;
+            if (n_valid > kSub) n_valid = kSub;
+            // ---- A: stage cov[r][j] for the 64 reads (global layout is [j][reads]) ------------------
+            for (int x = threadIdx.x; x < n * kSub; x += blockDim.x) {
+                int j = x >> 6, r = x & 63;
+                cov[r * kCovStride + j] = cov_g[coff + (i64)j * kLaneChunk + sub * kSub + r];
             }
             __syncthreads();
-            const int any_active = any_active_s;
-            __syncthreads();
-            if (!any_active && !zero_ambiguous) continue;     // 64 reads without coverage: nay everywhere
             // ---- B: pair planes ---------------------------------------------------------------------
             unsigned valid0 = n_valid >= 32 ? 0xffffffffu : ((1u << n_valid) - 1u);
             unsigned valid1 = n_valid >= 64 ? 0xffffffffu : (n_valid > 32 ? ((1u << (n_valid - 32)) - 1u) : 0u);
 #pragma unroll
-            for (int s = 0; s < (kMaxPairs + 255) / 256; ++s) {
-                int q = s * 256 + threadIdx.x;
+            for (int s = 0; s < kPairSlots; ++s) {
+                int q = s * kScoreThreads + threadIdx.x;
                 if (q < npairs) {
                     int i = pair_ij[q] & 255, j = pair_ij[q] >> 8;
                     int2 th = pair_thr[poff + q];
@@ -725,13 +803,13 @@ __global__ void __launch_bounds__(256) k_score(Status *st, ProblemArrays pr, i64
             // ---- C: triples ---------------------------------------------------------------------------
             for (int q = threadIdx.x; q < npairs; q += blockDim.x) {
                 int j = pair_ij[q] & 255, kk = pair_ij[q] >> 8;       // B pair = (j, k)
-                if (j == 0 || cp[kk] - cp[j] < 5) continue;           // dp(): segment too small (:540)
+                if (j == 0 || cy_s[kk] - cy_s[j] < 5) continue;       // dp(): segment too small (:540)
                 uint4 B = planes[q];
                 if ((B.x | B.y | B.z | B.w) == 0) continue;
                 int tbase = kk * (kk - 1) * (kk - 2) / 6 + j * (j - 1) / 2;
                 int abase = j * (j - 1) / 2;
                 for (int i = 0; i < j; ++i) {
-                    if (cp[j] - cp[i] < 5) break;                     // closer i are too small as well
+                    if (cy_s[j] - cy_s[i] < 5) break;                 // closer i are too small as well
                     uint4 A = planes[abase + i];
                     unsigned cnt = __popc(A.x & B.z) + __popc(A.y & B.w) + __popc(A.z & B.x) + __popc(A.w & B.y);
                     if (cnt) out16[tbase + i] += (unsigned short)cnt;
@@ -745,23 +823,27 @@ __global__ void __launch_bounds__(256) k_score(Status *st, ProblemArrays pr, i64
             if (v) atomicAdd(&out_g[toff + x], v);
         }
 #pragma unroll
-        for (int s = 0; s < (kMaxPairs + 255) / 256; ++s) {
-            int q = s * 256 + threadIdx.x;
+        for (int s = 0; s < kPairSlots; ++s) {
+            int q = s * kScoreThreads + threadIdx.x;
             if (q < npairs && amb_acc[s]) atomicAdd(&amb_g[poff + q], amb_acc[s]);
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// S5b  DP over one problem   (dp() :532-558, top level :560-566, backtrack :592-594)
-// D(i,j,k) = in_ij + out_ijk + M(j,k),  M(j,k) = max_{k'>k} D(j,k,k') (first maximiser, strict >),
-// M(j,end) := in_j,end closes the chain (base case :545-548).  The inner maximum depends only on (j,k), so
-// filling M for j descending is O(n^3) and gives the reference's O(n^4) recursion's result
-// (SURVEY.md App. A.7).  One wave per problem, lane = k.
+// S5c  DP over one problem   (dp() :532-558, top level :560-566, backtrack :592-594)
+// D(a,b,c) = in_ab + out_abc + M(b,c),  M(b,c) = max_{c2>c} D(b,c,c2) (first maximiser, strict >),
+// M(b,end) := in_b,end closes the chain (base case :545-548).  The inner maximum depends only on (b,c), so
+// filling M for c descending is O(n^3) and gives the reference's O(n^4) recursion's result
+// (SURVEY.md App. A.7).  One wave per problem; for a fixed c the lanes are the b < c, so the
+// out(b,c,c2) reads of a wave are contiguous.
+// in_ab = -(ambiguous reads of pair (a,b)); reads outside the problem's read range have no coverage
+// in the window and are ambiguous only for pairs whose lo threshold is negative.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) k_dp(Status *st, ProblemArrays pr, i64 prob_cap, const i64 *cand_off,
-                                           const int *cand_y, const unsigned *out_g, i64 tri_cap, const unsigned *amb_g,
-                                           i64 pair_cap, int support, unsigned char *chosen) {
+                                           const int *cand_y, const int *iv_part, const i64 *part_lane_off,
+                                           const unsigned *out_g, i64 tri_cap, const unsigned *amb_g,
+                                           const int2 *pair_thr, i64 pair_cap, int support, unsigned char *chosen) {
     __shared__ i64 M[kNMax * kNMax];
     __shared__ unsigned char A[kNMax * kNMax];
     __shared__ int cy_s[kNMax];
@@ -778,40 +860,43 @@ __global__ void __launch_bounds__(64) k_dp(Status *st, ProblemArrays pr, i64 pro
         i64 poff = pr.pair_off[p], toff = pr.tri_off[p];
         int npairs = n * (n - 1) / 2, ntri = n * (n - 1) * (n - 2) / 6;
         if (n > kNMax || poff + npairs > pair_cap || toff + ntri > tri_cap) continue;
-        i64 c0 = cand_off[pr.iv[p]] + pr.start[p];
+        int k_iv = pr.iv[p];
+        i64 c0 = cand_off[k_iv] + pr.start[p];
         for (int j = lane; j < n; j += 64) cy_s[j] = cand_y[c0 + j];
         __syncthreads();
         const unsigned *amb = amb_g + poff;
+        const int2 *thr = pair_thr + poff;
         const unsigned *outp = out_g + toff;
         const int end = n - 1;
-#define FSEG_IN(a, b) (-(i64)amb[(b) * ((b) - 1) / 2 + (a)])
-        // M(j, end) = in(j, end)
-        for (int j = lane; j < end; j += 64) { M[j * kNMax + end] = FSEG_IN(j, end); A[j * kNMax + end] = 255; }
+        int part = iv_part[k_iv];
+        const i64 outside = (part_lane_off[part + 1] - part_lane_off[part]) - pr.lane_n[p];
+        const bool zamb = (pr.flags[p] & 1) != 0;
+#define FSEG_IN(a, b) (-((i64)amb[(b) * ((b) - 1) / 2 + (a)] + ((zamb && thr[(b) * ((b) - 1) / 2 + (a)].y < 0) ? outside : 0)))
+        // M(b, end) = in(b, end)
+        for (int b = lane; b < end; b += 64) { M[b * kNMax + end] = FSEG_IN(b, end); A[b * kNMax + end] = 255; }
         __syncthreads();
-        for (int j = end - 2; j >= 1; --j) {
-            // lanes: k in (j, end)
-            for (int k0 = j + 1; k0 < end; k0 += 64) {
-                int kx = k0 + lane;
-                if (kx < end) {
-                    i64 best = kNegInf; int arg = 255;
-                    if (cy_s[kx] - cy_s[j] >= 5) {
-                        i64 in_jk = FSEG_IN(j, kx);
-                        for (int k2 = kx + 1; k2 <= end; ++k2) {
-                            if (cy_s[k2] - cy_s[kx] < 5) continue;
-                            i64 tail = M[kx * kNMax + k2];
-                            if (tail == kNegInf) continue;
-                            unsigned o = outp[k2 * (k2 - 1) * (k2 - 2) / 6 + kx * (kx - 1) / 2 + j];
-                            if ((i64)o < (i64)support) continue;              // :526-527
-                            i64 cur = in_jk + (i64)o + tail;
-                            if (cur > best) { best = cur; arg = k2; }
-                        }
+        for (int c = end - 1; c >= 2; --c) {
+            int b = 1 + lane;                          // lanes: b in [1, c)
+            if (b < c) {
+                i64 best = kNegInf; int arg = 255;
+                if (cy_s[c] - cy_s[b] >= 5) {
+                    i64 in_bc = FSEG_IN(b, c);
+                    int base = c * (c - 1) / 2 + b;
+                    for (int c2 = c + 1; c2 <= end; ++c2) {
+                        if (cy_s[c2] - cy_s[c] < 5) continue;
+                        i64 tail = M[c * kNMax + c2];
+                        if (tail == kNegInf) continue;
+                        unsigned o = outp[c2 * (c2 - 1) * (c2 - 2) / 6 + base];
+                        if ((i64)o < (i64)support) continue;              // :526-527
+                        i64 cur = in_bc + (i64)o + tail;
+                        if (cur > best) { best = cur; arg = c2; }
                     }
-                    M[j * kNMax + kx] = best; A[j * kNMax + kx] = (unsigned char)arg;
                 }
+                M[b * kNMax + c] = best; A[b * kNMax + c] = (unsigned char)arg;
             }
             __syncthreads();
         }
-        // top level: i = start
+        // top level: a = start
         i64 best = FSEG_IN(0, end);
         int bj = -1, bk = -1;
         for (int j = 1; j < end; ++j) {
@@ -856,38 +941,45 @@ __global__ void __launch_bounds__(64) k_dp(Status *st, ProblemArrays pr, i64 pro
 
 // ---------------------------------------------------------------------------------------------
 // S6  refinement   (refine_segmentation :249-266) and final positions (:802-807)
+// k_segments marks the chosen candidates as final positions and, for every chosen candidate whose
+// previous chosen candidate is more than 40 positions away, records that segment; k_refine then
+// visits the recorded segments (one wave each).
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) k_segments(i64 K, const i64 *pos_off, const i64 *cand_off, const int *cand_y,
-                                                 const unsigned char *chosen, unsigned char *final_flag, int *rseg_iv,
-                                                 int *rseg_s, int *rseg_e, Status *st) {
+                                                 const unsigned char *chosen, unsigned char *final_flag, int *seg_iv,
+                                                 int *seg_prev_y) {
     int lane = lane_id();
+    const u64 lt_mask = (1ULL << lane) - 1ULL;
     for (i64 k = blockIdx.x; k < K; k += gridDim.x) {
         i64 c0 = cand_off[k];
         int N = (int)(cand_off[k + 1] - c0);
         i64 base = pos_off[k];
-        int prev_y = -1;
+        int carry_y = -1;
         for (int t0 = 0; t0 < N; t0 += 64) {
             int c = t0 + lane;
             bool f = c < N && chosen[c0 + c];
             int y = c < N ? cand_y[c0 + c] : 0;
-            if (f) final_flag[base + y] = 1;
             u64 mask = __ballot(f);
-            while (mask) {
-                int b = __ffsll((long long)mask) - 1;
-                mask &= mask - 1;
-                int cur_y = __shfl(y, b);
-                if (prev_y >= 0 && cur_y - prev_y > 40 && lane == 0) {     // :252
-                    u64 slot = atomicAdd(&st->n_rseg, 1ULL);
-                    rseg_iv[slot] = (int)k; rseg_s[slot] = prev_y; rseg_e[slot] = cur_y;
+            int prev_lane = -1;
+            if (f) { u64 below = mask & lt_mask; if (below) prev_lane = 63 - __clzll((long long)below); }
+            int py = __shfl(y, prev_lane < 0 ? 0 : prev_lane);
+            if (prev_lane < 0) py = carry_y;
+            if (c < N) {
+                int rec = -1;
+                if (f) {
+                    final_flag[base + y] = 1;
+                    if (py >= 0 && y - py > 40) rec = py;             // :252
                 }
-                prev_y = cur_y;
+                seg_prev_y[c0 + c] = rec;
+                seg_iv[c0 + c] = (int)k;
             }
+            if (mask) carry_y = __shfl(y, 63 - __clzll((long long)mask));
         }
     }
 }
 
-__global__ void __launch_bounds__(64) k_refine(const Status *st, const int *rseg_iv, const int *rseg_s,
-                                               const int *rseg_e, const i64 *pos_off, const int *y_raw,
+__global__ void __launch_bounds__(64) k_refine(const Status *st, const int *seg_iv, const int *seg_prev_y,
+                                               const int *cand_y, const i64 *pos_off, const int *y_raw,
                                                const double *w_g, int radius, double sigma, double *g_scr, int *pk_scr,
                                                unsigned char *flag_scr, unsigned char *keep_scr,
                                                unsigned char *final_flag) {
@@ -896,11 +988,13 @@ __global__ void __launch_bounds__(64) k_refine(const Status *st, const int *rseg
     int lane = lane_id();
     for (int j = lane; j <= radius; j += 64) ws[j] = w_g[j];
     __syncthreads();
-    i64 n_seg = (i64)st->n_rseg;
-    for (i64 sg = blockIdx.x; sg < n_seg; sg += gridDim.x) {
-        int s = rseg_s[sg], e = rseg_e[sg];
+    i64 n_cand = (i64)st->n_cand;
+    for (i64 sg = blockIdx.x; sg < n_cand; sg += gridDim.x) {
+        int s = seg_prev_y[sg];
+        if (s < 0) continue;
+        int e = cand_y[sg];
         int len = e - s;
-        i64 base = pos_off[rseg_iv[sg]] + s;
+        i64 base = pos_off[seg_iv[sg]] + s;
         const int *xr = y_raw + base;
         // sum(i_vals) < 20 -> skip (:258); values are exact integers
         i64 tot = 0;
@@ -977,6 +1071,10 @@ __global__ void __launch_bounds__(64) k_refine(const Status *st, const int *rseg
 
 // ---------------------------------------------------------------------------------------------
 // S7  labels   (py/freddie_segment.py:808-830, sentinel :829-830, pop :840)
+// The label matrix of a partition is R x (F-1) bytes ('0','1','2').  A read overlaps only a few of
+// the F-1 segments, so the matrix is first filled with each column's zero-coverage label (k_label_fill,
+// a pure streaming store) and then every read rewrites just the columns its exons can reach
+// (k_label_reads).
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_label_plan(int n_part, const i64 *part_iv_off, const i64 *part_rep_off,
                                                     const i64 *final_off, i64 *label_off, Status *st, i64 label_cap) {
@@ -1008,48 +1106,86 @@ __global__ void __launch_bounds__(256) k_label_plan(int n_part, const i64 *part_
         if (carry_s > label_cap) atomicOr(&st->err, kErrOverflowLabels);
     }
 }
-// per final index: genomic segment [g0, g1) and integer thresholds; the last index of an interval is
-// the sentinel column (hi = INT_MAX)
-__global__ void k_label_cols(i64 K, const i64 *final_off, const int *final_y, const int *iv_start,
-                             const double *h_table, int h_len, double tau, int4 *col) {
+// per final index f (= column): integer thresholds of the segment [final_f, final_f+1) and the label of
+// a read without coverage there; the last index of an interval is the sentinel column (hi = INT_MAX)
+__global__ void k_label_cols(i64 K, const i64 *final_off, const int *final_y, const double *h_table, int h_len,
+                             double tau, int2 *col_thr, unsigned char *col_zero) {
     i64 F = final_off[K];
     for (i64 f = (i64)blockIdx.x * blockDim.x + threadIdx.x; f < F; f += (i64)gridDim.x * blockDim.x) {
         i64 k = last_le(final_off, K + 1, f);
-        if (f + 1 == final_off[k + 1]) { col[f] = make_int4(0, 0, 0x7fffffff, -1); continue; }
-        int y0 = final_y[f], y1 = final_y[f + 1];
+        if (f + 1 == final_off[k + 1]) { col_thr[f] = make_int2(0x7fffffff, 0x7fffffff); col_zero[f] = '0'; continue; }
         int hi, lo;
-        label_thresholds((i64)y1 - y0 + 1, h_table, h_len, tau, &hi, &lo);
-        col[f] = make_int4(iv_start[k] + y0, iv_start[k] + y1, hi, lo);
+        label_thresholds((i64)final_y[f + 1] - final_y[f] + 1, h_table, h_len, tau, &hi, &lo);
+        col_thr[f] = make_int2(hi, lo);
+        col_zero[f] = lo >= 0 ? '0' : '2';
     }
 }
-__global__ void __launch_bounds__(256) k_label(int n_part, const i64 *label_off, i64 label_cap, const i64 *part_iv_off,
-                                               const i64 *part_rep_off, const i64 *final_off, const int4 *col,
-                                               const i64 *rep_exon_off, const int *ex_ts, const int *ex_te,
-                                               unsigned char *labels) {
+__global__ void __launch_bounds__(256) k_label_fill(int n_part, const i64 *label_off, i64 label_cap,
+                                                    const i64 *part_iv_off, const i64 *final_off,
+                                                    const unsigned char *col_zero, unsigned char *labels) {
     i64 total = label_off[n_part];
     if (total > label_cap) return;
-    for (i64 x = (i64)blockIdx.x * blockDim.x + threadIdx.x; x < total; x += (i64)gridDim.x * blockDim.x) {
+    i64 n16 = (total + 15) / 16;
+    for (i64 x16 = (i64)blockIdx.x * blockDim.x + threadIdx.x; x16 < n16; x16 += (i64)gridDim.x * blockDim.x) {
+        i64 x = x16 * 16;
         int p = (int)last_le(label_off, (i64)n_part + 1, x);
+        while (label_off[p + 1] <= x) ++p;                  // skip partitions without label bytes
         i64 f0 = final_off[part_iv_off[p]];
         i64 S = final_off[part_iv_off[p + 1]] - f0 - 1;
-        i64 local = x - label_off[p];
-        i64 r = local / S, c = local - r * S;
-        int4 cl = col[f0 + c];
-        unsigned char out = '0';
-        if (cl.z != 0x7fffffff) {
-            i64 rep = part_rep_off[p] + r;
-            i64 e = rep_exon_off[rep], e1 = rep_exon_off[rep + 1];
-            i64 lo = e, hi = e1;
-            while (lo < hi) { i64 mid = (lo + hi) >> 1; if (ex_te[mid] < cl.x) lo = mid + 1; else hi = mid; }
+        i64 c = (x - label_off[p]) % S;
+        i64 pend = label_off[p + 1];
+        unsigned char buf[16];
+        int nb = (int)(total - x < 16 ? total - x : 16);
+        for (int q = 0; q < nb; ++q) {
+            if (x + q >= pend) {                              // next partition with label bytes
+                ++p;
+                while (label_off[p + 1] <= x + q) ++p;
+                f0 = final_off[part_iv_off[p]];
+                S = final_off[part_iv_off[p + 1]] - f0 - 1;
+                pend = label_off[p + 1];
+                c = 0;
+            }
+            buf[q] = col_zero[f0 + c];
+            if (++c == S) c = 0;
+        }
+        if (nb == 16) *reinterpret_cast<uint4 *>(labels + x) = *reinterpret_cast<uint4 *>(buf);
+        else for (int q = 0; q < nb; ++q) labels[x + q] = buf[q];
+    }
+}
+__global__ void __launch_bounds__(256) k_label_reads(int n_part, const i64 *label_off, i64 label_cap,
+                                                     const i64 *part_iv_off, const i64 *part_rep_off,
+                                                     const i64 *final_off, const int *final_pos, const int2 *col_thr,
+                                                     const i64 *rep_exon_off, const int *ex_ts, const int *ex_te,
+                                                     unsigned char *labels) {
+    if (label_off[n_part] > label_cap) return;
+    i64 n_rep = part_rep_off[n_part];
+    for (i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x; r < n_rep; r += (i64)gridDim.x * blockDim.x) {
+        int p = (int)last_le(part_rep_off, (i64)n_part + 1, r);
+        i64 f0 = final_off[part_iv_off[p]];
+        i64 F = final_off[part_iv_off[p + 1]] - f0;
+        i64 S = F - 1;
+        if (S <= 0) continue;
+        const int *fp = final_pos + f0;                      // ascending over the whole partition
+        unsigned char *row = labels + label_off[p] + (r - part_rep_off[p]) * S;
+        i64 e = rep_exon_off[r], e1 = rep_exon_off[r + 1];
+        if (e >= e1) continue;
+        int first_ts = ex_ts[e], last_te = ex_te[e1 - 1];
+        // first column whose segment [fp[c], fp[c+1]) ends after first_ts
+        i64 lo = 0, hi = S;
+        while (lo < hi) { i64 mid = (lo + hi) >> 1; if (fp[mid + 1] <= first_ts) lo = mid + 1; else hi = mid; }
+        for (i64 c = lo; c < S && fp[c] <= last_te; ++c) {
+            int2 th = col_thr[f0 + c];
+            if (th.x == 0x7fffffff) continue;                 // sentinel column between two intervals
+            int g0 = fp[c], g1 = fp[c + 1];
+            while (e < e1 && ex_te[e] < g0) ++e;              // exons entirely before this segment
             int cov = 0;
-            for (e = lo; e < e1 && ex_ts[e] < cl.y; ++e) {
-                int a = ex_ts[e] > cl.x ? ex_ts[e] : cl.x;
-                int b = ex_te[e] + 1 < cl.y ? ex_te[e] + 1 : cl.y;
+            for (i64 x = e; x < e1 && ex_ts[x] < g1; ++x) {
+                int a = ex_ts[x] > g0 ? ex_ts[x] : g0;
+                int b = ex_te[x] + 1 < g1 ? ex_te[x] + 1 : g1;
                 if (b > a) cov += b - a;
             }
-            out = cov >= cl.z ? '1' : (cov <= cl.w ? '0' : '2');
+            row[c] = cov >= th.x ? '1' : (cov <= th.y ? '0' : '2');
         }
-        labels[x] = out;
     }
 }
 
@@ -1084,18 +1220,21 @@ struct fseg_ctx {
     std::vector<int> iv_start_h;
     // device buffers: inputs
     DevBuf d_part_iv_off, d_part_rep_off, d_part_lane_off, d_iv_start, d_iv_end, d_pos_off, d_iv_part, d_rep_weight,
-        d_rep_exon_off, d_ex_ts, d_ex_te, d_lane_rep, d_tile_iv, d_tile_y0, d_w_main, d_w_refine, d_h_table;
+        d_rep_exon_off, d_ex_ts, d_ex_te, d_lane_rep, d_lane_start, d_lane_pmax, d_tile_iv, d_tile_y0, d_w_main,
+        d_w_refine, d_h_table;
     // device buffers: position-sized
     DevBuf d_y_raw, d_y, d_flag, d_idx, d_v, d_bsum, d_g, d_pk, d_pf, d_kp, d_final_flag;
     // partition-sized
     DevBuf d_voff, d_chunk_off, d_csum, d_mean, d_thr, d_label_off;
     // candidate-sized
-    DevBuf d_cand_off, d_cand_y, d_fixed0, d_added, d_fixed, d_chosen, d_final_off, d_final_y, d_final_pos, d_col;
-    DevBuf d_rseg_iv, d_rseg_s, d_rseg_e;
+    DevBuf d_cand_off, d_cand_y, d_fixed0, d_added, d_fixed, d_chosen, d_final_off, d_final_y, d_final_pos, d_col_thr,
+        d_col_zero;
+    DevBuf d_seg_iv, d_seg_prev;
     // problems / arenas
-    DevBuf d_prob_iv, d_prob_start, d_prob_n, d_prob_pair_off, d_prob_tri_off, d_prob_flags, d_prob_chain;
-    DevBuf d_work_prob, d_work_chunk, d_pair_thr, d_amb, d_out, d_labels;
-    i64 prob_cap = 0, work_cap = 0, pair_cap = 0, tri_cap = 0, label_cap = 0, chunk_cap = 0;
+    DevBuf d_prob_iv, d_prob_start, d_prob_n, d_prob_pair_off, d_prob_tri_off, d_prob_flags, d_prob_chain,
+        d_prob_cov_off, d_prob_lane_lo, d_prob_lane_n, d_prob_work_base;
+    DevBuf d_work_prob, d_work_chunk, d_work_active, d_pair_thr, d_amb, d_out, d_cov, d_labels;
+    i64 prob_cap = 0, work_cap = 0, pair_cap = 0, tri_cap = 0, label_cap = 0, chunk_cap = 0, cov_cap = 0;
     DevBuf d_status;
     Status *h_status = nullptr;   // pinned
     bool profiling = false;
@@ -1165,8 +1304,14 @@ int alloc_arenas(fseg_ctx *c) {
     TRY(ensure(c, c->d_prob_tri_off, (size_t)c->prob_cap * 8));
     TRY(ensure(c, c->d_prob_flags, (size_t)c->prob_cap * 4));
     TRY(ensure(c, c->d_prob_chain, (size_t)c->prob_cap * 4));
+    TRY(ensure(c, c->d_prob_cov_off, (size_t)c->prob_cap * 8));
+    TRY(ensure(c, c->d_prob_lane_lo, (size_t)c->prob_cap * 4));
+    TRY(ensure(c, c->d_prob_lane_n, (size_t)c->prob_cap * 4));
+    TRY(ensure(c, c->d_prob_work_base, (size_t)c->prob_cap * 8));
     TRY(ensure(c, c->d_work_prob, (size_t)c->work_cap * 4));
     TRY(ensure(c, c->d_work_chunk, (size_t)c->work_cap * 4));
+    TRY(ensure(c, c->d_work_active, (size_t)c->work_cap));
+    TRY(ensure(c, c->d_cov, (size_t)c->cov_cap * 4));
     TRY(ensure(c, c->d_pair_thr, (size_t)c->pair_cap * 8));
     TRY(ensure(c, c->d_amb, (size_t)c->pair_cap * 4));
     TRY(ensure(c, c->d_out, (size_t)c->tri_cap * 4));
@@ -1234,36 +1379,43 @@ int enqueue_run(fseg_ctx *c) {
     // S4
     ProblemArrays pr{c->d_prob_iv.as<int>(), c->d_prob_start.as<int>(), c->d_prob_n.as<int>(),
                      c->d_prob_pair_off.as<i64>(), c->d_prob_tri_off.as<i64>(), c->d_prob_flags.as<int>(),
-                     c->d_prob_chain.as<int>()};
+                     c->d_prob_chain.as<int>(), c->d_prob_cov_off.as<i64>(), c->d_prob_lane_lo.as<int>(),
+                     c->d_prob_lane_n.as<int>(), c->d_prob_work_base.as<i64>()};
     hipLaunchKernelGGL(k_fix, dim3(grid_for(K, 1, 8192)), dim3(64), 0, s, K, c->d_pos_off.as<i64>(), c->d_iv_part.as<int>(),
-                       c->d_cand_off.as<i64>(), c->d_cand_y.as<int>(), c->d_y.as<double>(), c->d_thr.as<double>(),
-                       c->P.max_problem_size, c->d_fixed0.as<unsigned char>(), c->d_added.as<unsigned char>(),
-                       c->d_fixed.as<unsigned char>(), c->d_chosen.as<unsigned char>(), pr, c->prob_cap,
-                       c->d_part_lane_off.as<i64>(), c->d_work_prob.as<int>(), c->d_work_chunk.as<int>(), c->work_cap, st);
+                       c->d_iv_start.as<int>(), c->d_cand_off.as<i64>(), c->d_cand_y.as<int>(), c->d_y.as<double>(),
+                       c->d_thr.as<double>(), c->P.max_problem_size, c->d_fixed0.as<unsigned char>(),
+                       c->d_added.as<unsigned char>(), c->d_fixed.as<unsigned char>(), c->d_chosen.as<unsigned char>(), pr,
+                       c->prob_cap, c->d_part_lane_off.as<i64>(), c->d_lane_start.as<int>(), c->d_lane_pmax.as<int>(),
+                       c->d_work_prob.as<int>(), c->d_work_chunk.as<int>(), c->work_cap, st);
     mark(5);
     // S5
+    int work_grid = grid_for(c->work_cap, 1, 4096);
     if (c->prob_cap > 0) {
         hipLaunchKernelGGL(k_pair_thresholds, dim3(grid_for(c->prob_cap, 1, 2048)), dim3(256), 0, s, st, pr, c->prob_cap,
                            c->d_cand_off.as<i64>(), c->d_cand_y.as<int>(), c->d_h_table.as<double>(), c->P.h_len,
                            c->P.threshold_rate, c->d_pair_thr.as<int2>(), c->pair_cap);
         hipLaunchKernelGGL(k_zero_arenas, dim3(1024), dim3(256), 0, s, st, c->d_out.as<unsigned>(), c->tri_cap,
                            c->d_amb.as<unsigned>(), c->pair_cap);
+        hipLaunchKernelGGL(k_cov, dim3(work_grid < 2048 ? work_grid : 2048), dim3(kLaneChunk), 0, s, st, pr, c->prob_cap,
+                           c->d_work_prob.as<int>(), c->d_work_chunk.as<int>(), c->work_cap, c->d_cand_off.as<i64>(),
+                           c->d_cand_y.as<int>(), c->d_iv_start.as<int>(), c->d_lane_rep.as<int>(),
+                           c->d_rep_exon_off.as<i64>(), c->d_ex_ts.as<int>(), c->d_ex_te.as<int>(),
+                           c->d_cov.as<unsigned>(), c->cov_cap, c->d_work_active.as<unsigned char>());
     }
     mark(6);
     if (c->prob_cap > 0) {
-        hipLaunchKernelGGL(k_score, dim3(grid_for(c->work_cap, 1, 256)), dim3(256), c->score_lds, s, st, pr, c->prob_cap,
-                           c->d_work_prob.as<int>(), c->d_work_chunk.as<int>(), c->work_cap, c->d_cand_off.as<i64>(),
-                           c->d_cand_y.as<int>(), c->d_iv_part.as<int>(), c->d_iv_start.as<int>(),
-                           c->d_part_lane_off.as<i64>(), c->d_part_rep_off.as<i64>(),
-                           c->expanded ? c->d_lane_rep.as<int>() : (const int *)nullptr, c->d_rep_exon_off.as<i64>(),
-                           c->d_ex_ts.as<int>(), c->d_ex_te.as<int>(), c->d_pair_thr.as<int2>(), c->pair_cap,
+        hipLaunchKernelGGL(k_score, dim3(work_grid < 256 ? work_grid : 256), dim3(kScoreThreads), c->score_lds, s, st, pr,
+                           c->prob_cap, c->d_work_prob.as<int>(), c->d_work_chunk.as<int>(), c->work_cap,
+                           c->d_cand_off.as<i64>(), c->d_cand_y.as<int>(), c->d_work_active.as<unsigned char>(),
+                           c->d_cov.as<unsigned>(), c->cov_cap, c->d_pair_thr.as<int2>(), c->pair_cap,
                            c->d_out.as<unsigned>(), c->tri_cap, c->d_amb.as<unsigned>());
     }
     mark(7);
     if (c->prob_cap > 0) {
         hipLaunchKernelGGL(k_dp, dim3(grid_for(c->prob_cap, 1, 1280)), dim3(64), 0, s, st, pr, c->prob_cap,
-                           c->d_cand_off.as<i64>(), c->d_cand_y.as<int>(), c->d_out.as<unsigned>(), c->tri_cap,
-                           c->d_amb.as<unsigned>(), c->pair_cap, c->P.min_read_support_outside,
+                           c->d_cand_off.as<i64>(), c->d_cand_y.as<int>(), c->d_iv_part.as<int>(),
+                           c->d_part_lane_off.as<i64>(), c->d_out.as<unsigned>(), c->tri_cap, c->d_amb.as<unsigned>(),
+                           c->d_pair_thr.as<int2>(), c->pair_cap, c->P.min_read_support_outside,
                            c->d_chosen.as<unsigned char>());
     }
     mark(8);
@@ -1271,10 +1423,9 @@ int enqueue_run(fseg_ctx *c) {
     HIP_TRY(c, hipMemsetAsync(c->d_final_flag.p, 0, (size_t)NPOS, s));
     hipLaunchKernelGGL(k_segments, dim3(grid_for(K, 1, 8192)), dim3(64), 0, s, K, c->d_pos_off.as<i64>(),
                        c->d_cand_off.as<i64>(), c->d_cand_y.as<int>(), c->d_chosen.as<unsigned char>(),
-                       c->d_final_flag.as<unsigned char>(), c->d_rseg_iv.as<int>(), c->d_rseg_s.as<int>(),
-                       c->d_rseg_e.as<int>(), st);
-    hipLaunchKernelGGL(k_refine, dim3(2048), dim3(64), 0, s, st, c->d_rseg_iv.as<int>(), c->d_rseg_s.as<int>(),
-                       c->d_rseg_e.as<int>(), c->d_pos_off.as<i64>(), c->d_y_raw.as<int>(), c->d_w_refine.as<double>(),
+                       c->d_final_flag.as<unsigned char>(), c->d_seg_iv.as<int>(), c->d_seg_prev.as<int>());
+    hipLaunchKernelGGL(k_refine, dim3(2048), dim3(64), 0, s, st, c->d_seg_iv.as<int>(), c->d_seg_prev.as<int>(),
+                       c->d_cand_y.as<int>(), c->d_pos_off.as<i64>(), c->d_y_raw.as<int>(), c->d_w_refine.as<double>(),
                        c->P.radius_refine, c->P.sigma, c->d_g.as<double>(), c->d_pk.as<int>(),
                        c->d_pf.as<unsigned char>(), c->d_kp.as<unsigned char>(), c->d_final_flag.as<unsigned char>());
     mark(9);
@@ -1289,13 +1440,18 @@ int enqueue_run(fseg_ctx *c) {
     hipLaunchKernelGGL(k_label_plan, dim3(1), dim3(256), 0, s, n_part, c->d_part_iv_off.as<i64>(),
                        c->d_part_rep_off.as<i64>(), c->d_final_off.as<i64>(), c->d_label_off.as<i64>(), st, c->label_cap);
     hipLaunchKernelGGL(k_label_cols, dim3(grid_for(NPOS / 8 + 1, 256, 2048)), dim3(256), 0, s, K, c->d_final_off.as<i64>(),
-                       c->d_final_y.as<int>(), c->d_iv_start.as<int>(), c->d_h_table.as<double>(), c->P.h_len,
-                       c->P.threshold_rate, c->d_col.as<int4>());
-    if (c->label_cap > 0)
-        hipLaunchKernelGGL(k_label, dim3(grid_for(c->label_cap, 256, 8192)), dim3(256), 0, s, n_part,
+                       c->d_final_y.as<int>(), c->d_h_table.as<double>(), c->P.h_len, c->P.threshold_rate,
+                       c->d_col_thr.as<int2>(), c->d_col_zero.as<unsigned char>());
+    if (c->label_cap > 0) {
+        hipLaunchKernelGGL(k_label_fill, dim3(grid_for(c->label_cap / 16 + 1, 256, 8192)), dim3(256), 0, s, n_part,
+                           c->d_label_off.as<i64>(), c->label_cap, c->d_part_iv_off.as<i64>(), c->d_final_off.as<i64>(),
+                           c->d_col_zero.as<unsigned char>(), c->d_labels.as<unsigned char>());
+        hipLaunchKernelGGL(k_label_reads, dim3(grid_for(c->R, 256, 8192)), dim3(256), 0, s, n_part,
                            c->d_label_off.as<i64>(), c->label_cap, c->d_part_iv_off.as<i64>(), c->d_part_rep_off.as<i64>(),
-                           c->d_final_off.as<i64>(), c->d_col.as<int4>(), c->d_rep_exon_off.as<i64>(), c->d_ex_ts.as<int>(),
-                           c->d_ex_te.as<int>(), c->d_labels.as<unsigned char>());
+                           c->d_final_off.as<i64>(), c->d_final_pos.as<int>(), c->d_col_thr.as<int2>(),
+                           c->d_rep_exon_off.as<i64>(), c->d_ex_ts.as<int>(), c->d_ex_te.as<int>(),
+                           c->d_labels.as<unsigned char>());
+    }
     mark(11);
     HIP_TRY(c, hipMemcpyAsync(c->h_status, st, sizeof(Status), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipGetLastError());
@@ -1308,10 +1464,10 @@ int finish_run(fseg_ctx *c) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         const Status &s = *c->h_status;
         unsigned ovf = s.err & (kErrOverflowPairs | kErrOverflowTri | kErrOverflowWork | kErrOverflowLabels |
-                                kErrOverflowProblems | kErrOverflowChunks);
+                                kErrOverflowProblems | kErrOverflowChunks | kErrOverflowCov);
         bool need = ovf != 0 || (i64)s.n_prob > c->prob_cap || (i64)s.n_work > c->work_cap ||
                     (i64)s.pair_used > c->pair_cap || (i64)s.tri_used > c->tri_cap || (i64)s.label_bytes > c->label_cap ||
-                    (i64)s.n_vchunks > c->chunk_cap;
+                    (i64)s.n_vchunks > c->chunk_cap || (i64)s.cov_used > c->cov_cap;
         if (!need) {
             c->pending = false;
             c->ran = true;
@@ -1329,6 +1485,7 @@ int finish_run(fseg_ctx *c) {
         c->tri_cap = grow((i64)s.tri_used, c->tri_cap);
         c->label_cap = grow((i64)s.label_bytes, c->label_cap);
         c->chunk_cap = grow((i64)s.n_vchunks, c->chunk_cap);
+        c->cov_cap = grow((i64)s.cov_used, c->cov_cap);
         TRY(alloc_arenas(c));
         TRY(enqueue_run(c));
     }
@@ -1382,13 +1539,14 @@ void fseg_destroy(fseg_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->d_part_iv_off, &c->d_part_rep_off, &c->d_part_lane_off, &c->d_iv_start, &c->d_iv_end, &c->d_pos_off,
-                      &c->d_iv_part, &c->d_rep_weight, &c->d_rep_exon_off, &c->d_ex_ts, &c->d_ex_te, &c->d_lane_rep,
+                      &c->d_iv_part, &c->d_rep_weight, &c->d_rep_exon_off, &c->d_ex_ts, &c->d_ex_te, &c->d_lane_rep, &c->d_lane_start, &c->d_lane_pmax,
                       &c->d_tile_iv, &c->d_tile_y0, &c->d_w_main, &c->d_w_refine, &c->d_h_table, &c->d_y_raw, &c->d_y,
                       &c->d_flag, &c->d_idx, &c->d_v, &c->d_bsum, &c->d_g, &c->d_pk, &c->d_pf, &c->d_kp, &c->d_final_flag,
                       &c->d_voff, &c->d_chunk_off, &c->d_csum, &c->d_mean, &c->d_thr, &c->d_label_off, &c->d_cand_off,
                       &c->d_cand_y, &c->d_fixed0, &c->d_added, &c->d_fixed, &c->d_chosen, &c->d_final_off, &c->d_final_y,
-                      &c->d_final_pos, &c->d_col, &c->d_rseg_iv, &c->d_rseg_s, &c->d_rseg_e, &c->d_prob_iv, &c->d_prob_start,
-                      &c->d_prob_n, &c->d_prob_pair_off, &c->d_prob_tri_off, &c->d_prob_flags, &c->d_prob_chain,
+                      &c->d_final_pos, &c->d_col_thr, &c->d_col_zero, &c->d_seg_iv, &c->d_seg_prev, &c->d_prob_iv, &c->d_prob_start,
+                      &c->d_prob_n, &c->d_prob_pair_off, &c->d_prob_tri_off, &c->d_prob_flags, &c->d_prob_chain, &c->d_prob_cov_off,
+                      &c->d_prob_lane_lo, &c->d_prob_lane_n, &c->d_prob_work_base, &c->d_work_active, &c->d_cov,
                       &c->d_work_prob, &c->d_work_chunk, &c->d_pair_thr, &c->d_amb, &c->d_out, &c->d_labels, &c->d_status};
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
     if (c->h_status) (void)hipHostFree(c->h_status);
@@ -1473,10 +1631,29 @@ int fseg_upload(fseg_ctx *c, const fseg_batch *b) {
         part_lane_off[p + 1] = lanes;
     }
     if (lanes >= 0x7fffffffLL) return fail(c, FSEG_ERR_UNSUPPORTED, "too many reads in one upload");
-    std::vector<int> lane_rep;
-    if (expanded) {
-        lane_rep.reserve((size_t)lanes);
-        for (i64 r = 0; r < R; ++r) for (int q = 0; q < b->rep_weight[r]; ++q) lane_rep.push_back((int)r);
+    // "lanes": every read rep repeated rep_weight times (so that every lane has weight 1), ordered inside
+    // each partition by the rep's first position.  lane_pmax = running maximum of the reps' last positions:
+    // the reads that can overlap a window [g0, g1) are exactly a contiguous lane range (k_fix).
+    std::vector<int> lane_rep((size_t)lanes), lane_start((size_t)lanes), lane_pmax((size_t)lanes);
+    {
+        std::vector<std::pair<int, int>> order;   // (first position, rep)
+        for (int p = 0; p < np; ++p) {
+            order.clear();
+            for (i64 r = b->part_rep_off[p]; r < b->part_rep_off[p + 1]; ++r) {
+                if (b->rep_exon_off[r + 1] <= b->rep_exon_off[r]) return fail(c, FSEG_ERR_INPUT, "rep %lld has no exons", (long long)r);
+                order.emplace_back(b->ex_ts[b->rep_exon_off[r]], (int)r);
+            }
+            std::sort(order.begin(), order.end());
+            i64 l = part_lane_off[p];
+            int run_max = -0x7fffffff - 1;
+            for (const auto &o : order) {
+                int last = b->ex_te[b->rep_exon_off[o.second + 1] - 1];
+                if (last > run_max) run_max = last;
+                for (int q = 0; q < b->rep_weight[o.second]; ++q, ++l) {
+                    lane_rep[(size_t)l] = o.second; lane_start[(size_t)l] = o.first; lane_pmax[(size_t)l] = run_max;
+                }
+            }
+        }
     }
     std::vector<int> tile_iv, tile_y0;
     for (i64 k = 0; k < K; ++k) {
@@ -1501,7 +1678,9 @@ int fseg_upload(fseg_ctx *c, const fseg_batch *b) {
     TRY(upload_vec(c, c->d_rep_exon_off, b->rep_exon_off, (size_t)R + 1));
     TRY(upload_vec(c, c->d_ex_ts, b->ex_ts, (size_t)I));
     TRY(upload_vec(c, c->d_ex_te, b->ex_te, (size_t)I));
-    if (expanded) TRY(upload_vec(c, c->d_lane_rep, lane_rep.data(), lane_rep.size()));
+    TRY(upload_vec(c, c->d_lane_rep, lane_rep.data(), lane_rep.size()));
+    TRY(upload_vec(c, c->d_lane_start, lane_start.data(), lane_start.size()));
+    TRY(upload_vec(c, c->d_lane_pmax, lane_pmax.data(), lane_pmax.size()));
     TRY(upload_vec(c, c->d_tile_iv, tile_iv.data(), tile_iv.size()));
     TRY(upload_vec(c, c->d_tile_y0, tile_y0.data(), tile_y0.size()));
     // position-sized work buffers
@@ -1518,13 +1697,13 @@ int fseg_upload(fseg_ctx *c, const fseg_batch *b) {
     TRY(ensure(c, c->d_cand_off, ((size_t)K + 2) * 8)); TRY(ensure(c, c->d_final_off, ((size_t)K + 2) * 8));
     TRY(ensure(c, c->d_cand_y, np8 * 4)); TRY(ensure(c, c->d_fixed0, np8)); TRY(ensure(c, c->d_added, np8));
     TRY(ensure(c, c->d_fixed, np8)); TRY(ensure(c, c->d_chosen, np8));
-    TRY(ensure(c, c->d_final_y, np8 * 4)); TRY(ensure(c, c->d_final_pos, np8 * 4)); TRY(ensure(c, c->d_col, np8 * 16));
-    TRY(ensure(c, c->d_rseg_iv, np8 * 4)); TRY(ensure(c, c->d_rseg_s, np8 * 4)); TRY(ensure(c, c->d_rseg_e, np8 * 4));
+    TRY(ensure(c, c->d_final_y, np8 * 4)); TRY(ensure(c, c->d_final_pos, np8 * 4)); TRY(ensure(c, c->d_col_thr, np8 * 8)); TRY(ensure(c, c->d_col_zero, np8));
+    TRY(ensure(c, c->d_seg_iv, np8 * 4)); TRY(ensure(c, c->d_seg_prev, np8 * 4));
     // first-guess arena capacities; fseg_sync() grows them if the run reports an overflow
     auto atleast = [](i64 &cap, i64 v) { if (cap < v) cap = v; };
     atleast(c->chunk_cap, NPOS / 8192 + np + 8);
     atleast(c->prob_cap, 1024); atleast(c->work_cap, 1024); atleast(c->pair_cap, 1 << 16); atleast(c->tri_cap, 1 << 18);
-    atleast(c->label_cap, 1 << 16);
+    atleast(c->label_cap, 1 << 16); atleast(c->cov_cap, 1 << 18);
     TRY(alloc_arenas(c));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->have_batch = true; c->ran = false; c->pending = false;
