@@ -68,6 +68,7 @@ struct Status {
     u64 cov_used;      // elements of the coverage arena
     u64 work_queue;    // dynamic work counter of the scoring kernel
     u64 dp_queue;
+    u64 dp_queue2;
     u64 cov_queue;
 };
 
@@ -293,12 +294,18 @@ __global__ void __launch_bounds__(256) k_vplan(int n_part, const i64 *part_iv_of
         if (carry_s > chunk_cap) atomicOr(&st->err, kErrOverflowChunks);
     }
 }
-// one 64-thread workgroup per chunk; pass 0 sums v, pass 1 sums (v-mean)^2
-__global__ void __launch_bounds__(64) k_vsum_chunks(int n_part, const i64 *voff, const i64 *chunk_off, const double *v,
-                                                    const double *mean, int pass, double *csum, i64 chunk_cap) {
+// one 512-thread workgroup per chunk; pass 0 sums v, pass 1 sums (v-mean)^2.
+// Thread (leaf, q) owns accumulator q of the 8-lane leaf of the pairwise recursion: r[q] = a[q] + a[8+q] +
+// a[16+q] + ... in that order; the 8 accumulators are combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) by
+// three xor-shuffles (IEEE addition is commutative, so both partners get identical bits), the tail (len%8)
+// is added left to right, and the leaves are combined in recursion order.
+__global__ void __launch_bounds__(512) k_vsum_chunks(int n_part, const i64 *voff, const i64 *chunk_off, const double *v,
+                                                     const double *mean, int pass, double *csum, i64 chunk_cap) {
     __shared__ int leaf_off[256], leaf_len[256], leaf_depth[256];
     __shared__ double leaf_sum[256];
     __shared__ int n_leaf_s;
+    __shared__ int stk_a[32], stk_b[32], stk_c[32];
+    __shared__ double stk_v[32];
     i64 n_chunks = chunk_off[n_part];
     if (n_chunks > chunk_cap) n_chunks = chunk_cap;
     for (i64 c = blockIdx.x; c < n_chunks; c += gridDim.x) {
@@ -309,58 +316,77 @@ __global__ void __launch_bounds__(64) k_vsum_chunks(int n_part, const i64 *voff,
         const double *a = v + voff[p] + o0;
         double mu = pass ? mean[p] : 0.0;
         __syncthreads();
-        if (threadIdx.x == 0) {
-            // leaves of the pairwise recursion, left to right, with their depth
-            int so[24], sl[24], sd[24], sp = 0, nl = 0;
-            so[0] = 0; sl[0] = m; sd[0] = 0; sp = 1;
+        if (m == 8192) {
+            // perfect tree: 64 leaves of 128
+            for (int t = threadIdx.x; t < 64; t += blockDim.x) { leaf_off[t] = t * 128; leaf_len[t] = 128; leaf_depth[t] = 6; }
+            if (threadIdx.x == 0) n_leaf_s = 64;
+        } else if (threadIdx.x == 0) {
+            // leaves of the pairwise recursion, left to right, with their depth (explicit stack in LDS:
+            // runtime-indexed private arrays would live in scratch memory)
+            int sp = 0, nl = 0;
+            stk_a[0] = 0; stk_b[0] = m; stk_c[0] = 0; sp = 1;
             while (sp > 0) {
                 --sp;
-                int off = so[sp], len = sl[sp], d = sd[sp];
+                int off = stk_a[sp], len = stk_b[sp], d = stk_c[sp];
                 if (len <= 128) { leaf_off[nl] = off; leaf_len[nl] = len; leaf_depth[nl] = d; ++nl; }
                 else {
                     int n2 = len / 2; n2 -= n2 % 8;
-                    so[sp] = off + n2; sl[sp] = len - n2; sd[sp] = d + 1; ++sp;   // right (popped second)
-                    so[sp] = off; sl[sp] = n2; sd[sp] = d + 1; ++sp;              // left
+                    stk_a[sp] = off + n2; stk_b[sp] = len - n2; stk_c[sp] = d + 1; ++sp;   // right (popped second)
+                    stk_a[sp] = off; stk_b[sp] = n2; stk_c[sp] = d + 1; ++sp;              // left
                 }
             }
             n_leaf_s = nl;
         }
         __syncthreads();
         int nl = n_leaf_s;
-        for (int t = threadIdx.x; t < nl; t += blockDim.x) {
-            const double *b = a + leaf_off[t];
-            int len = leaf_len[t];
-            double res;
-#define FSEG_VAL(i) (pass ? __dmul_rn(__dsub_rn(b[i], mu), __dsub_rn(b[i], mu)) : b[i])
-            if (len < 8) {
-                res = 0.0;
-                for (int i = 0; i < len; ++i) res = __dadd_rn(res, FSEG_VAL(i));
-            } else {
-                double r[8];
-                for (int q = 0; q < 8; ++q) r[q] = FSEG_VAL(q);
-                int i;
-                for (i = 8; i < len - (len % 8); i += 8)
-                    for (int q = 0; q < 8; ++q) r[q] = __dadd_rn(r[q], FSEG_VAL(i + q));
-                res = __dadd_rn(__dadd_rn(__dadd_rn(r[0], r[1]), __dadd_rn(r[2], r[3])),
-                                __dadd_rn(__dadd_rn(r[4], r[5]), __dadd_rn(r[6], r[7])));
-                for (; i < len; ++i) res = __dadd_rn(res, FSEG_VAL(i));
+        const int q = threadIdx.x & 7;
+#define FSEG_VAL(x) (pass ? __dmul_rn(__dsub_rn((x), mu), __dsub_rn((x), mu)) : (x))
+        for (int t0 = 0; t0 < nl; t0 += 64) {
+            int t = t0 + (threadIdx.x >> 3);
+            double res = 0.0;
+            if (t < nl) {
+                const double *b = a + leaf_off[t];
+                int len = leaf_len[t];
+                if (len < 8) {
+                    for (int i = 0; i < len; ++i) res = __dadd_rn(res, FSEG_VAL(b[i]));      // from 0.0, left to right
+                } else {
+                    int body = len - (len % 8);
+                    double x[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) x[i] = (8 * i + q < body) ? b[8 * i + q] : 0.0;
+                    double r = FSEG_VAL(x[0]);
+#pragma unroll
+                    for (int i = 1; i < 16; ++i) if (8 * i + q < body) r = __dadd_rn(r, FSEG_VAL(x[i]));
+                    r = __dadd_rn(r, __shfl_xor(r, 1));
+                    r = __dadd_rn(r, __shfl_xor(r, 2));
+                    r = __dadd_rn(r, __shfl_xor(r, 4));
+                    res = r;
+                    for (int i = body; i < len; ++i) res = __dadd_rn(res, FSEG_VAL(b[i]));
+                }
             }
-#undef FSEG_VAL
-            leaf_sum[t] = res;
+            if (t < nl && q == 0) leaf_sum[t] = res;
         }
+#undef FSEG_VAL
         __syncthreads();
-        if (threadIdx.x == 0) {
+        if (m == 8192) {
+            // perfect tree over 64 leaves: adjacent pairs level by level = xor butterfly on one wave
+            if (threadIdx.x < 64) {
+                double x = leaf_sum[threadIdx.x];
+                for (int d = 1; d < 64; d <<= 1) x = __dadd_rn(x, __shfl_xor(x, d));
+                if (threadIdx.x == 0) csum[c] = x;
+            }
+        } else if (threadIdx.x == 0) {
             // combine: two finished subtrees of equal depth are siblings
-            double sv[24]; int sd[24], sp = 0;
+            int sp = 0;
             for (int t = 0; t < nl; ++t) {
-                sv[sp] = leaf_sum[t]; sd[sp] = leaf_depth[t]; ++sp;
-                while (sp >= 2 && sd[sp - 1] == sd[sp - 2]) {
-                    sv[sp - 2] = __dadd_rn(sv[sp - 2], sv[sp - 1]);
-                    sd[sp - 2] -= 1;
+                stk_v[sp] = leaf_sum[t]; stk_c[sp] = leaf_depth[t]; ++sp;
+                while (sp >= 2 && stk_c[sp - 1] == stk_c[sp - 2]) {
+                    stk_v[sp - 2] = __dadd_rn(stk_v[sp - 2], stk_v[sp - 1]);
+                    stk_c[sp - 2] -= 1;
                     --sp;
                 }
             }
-            csum[c] = sv[0];
+            csum[c] = stk_v[0];
         }
     }
 }
@@ -461,42 +487,50 @@ __device__ __forceinline__ i64 wave_excl_scan(i64 v, i64 *total) {
     return x - v;
 }
 
-__global__ void __launch_bounds__(64) k_fix(i64 K, const i64 *pos_off, const int *iv_part, const int *iv_start,
-                                            const i64 *cand_off, const int *cand_y, const double *yv,
-                                            const double *thr_part, int mps, unsigned char *fixed0,
-                                            unsigned char *added, unsigned char *fixed, unsigned char *chosen,
-                                            ProblemArrays pr, i64 prob_cap, const i64 *part_lane_off,
-                                            const int *lane_start, const int *lane_pmax, int *work_prob,
-                                            int *work_chunk, i64 work_cap, Status *st) {
-    int lane = lane_id();
-    const u64 lt_mask = (1ULL << lane) - 1ULL;
+// Workgroup-wide "previous flagged element": every thread holds one element (index idx, flag f) of a tile of
+// blockDim.x consecutive elements; returns the index of the nearest flagged element before it (from this tile,
+// else `carry`), and advances carry to the tile's last flagged element.  lds: >= 16 ints.
+__device__ __forceinline__ int wg_prev_flagged(bool f, int idx, int &carry, int *lds) {
+    int lane = lane_id(), wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    u64 mask = __ballot(f);
+    __syncthreads();
+    if (lane == 0) lds[wave] = mask ? idx + 63 - __clzll((long long)mask) : -1;
+    __syncthreads();
+    u64 below = mask & ((1ULL << lane) - 1ULL);
+    int prev = carry;
+    if (below) prev = idx - lane + 63 - __clzll((long long)below);
+    else for (int w = wave - 1; w >= 0; --w) if (lds[w] >= 0) { prev = lds[w]; break; }
+    for (int w = nw - 1; w >= 0; --w) if (lds[w] >= 0) { carry = lds[w]; break; }
+    return prev;
+}
+
+__global__ void k_fix(i64 K, const i64 *pos_off, const int *iv_part, const i64 *cand_off, const int *cand_y,
+                      const double *yv, const double *thr_part, int mps, unsigned char *fixed0, unsigned char *added,
+                      unsigned char *fixed, unsigned char *chosen, int *cand_pn, int *cand_iv, Status *st) {
+    __shared__ int lds[16];
+    const int T = blockDim.x;
     for (i64 k = blockIdx.x; k < K; k += gridDim.x) {
         i64 c0 = cand_off[k];
         int N = (int)(cand_off[k + 1] - c0);
         const double *y = yv + pos_off[k];
         const int *cy = cand_y + c0;
-        int part = iv_part[k];
-        double thr = thr_part[part];
-        for (int t0 = 0; t0 < N; t0 += 64) {
-            int c = t0 + lane;
-            if (c < N) {
-                fixed0[c0 + c] = (c == 0 || c == N - 1 || y[cy[c]] > thr) ? 1 : 0;
-                added[c0 + c] = 0;
-            }
+        double thr = thr_part[iv_part[k]];
+        for (int c = threadIdx.x; c < N; c += T) {
+            fixed0[c0 + c] = (c == 0 || c == N - 1 || y[cy[c]] > thr) ? 1 : 0;
+            added[c0 + c] = 0;
+            cand_iv[c0 + c] = (int)k;
         }
         __syncthreads();
-        // break_large_problems over the original consecutive fixed pairs; the lane that owns the
+        // break_large_problems over the original consecutive fixed pairs; the thread that owns the
         // right end of an oversized gap places its anchors
         int carry = -1;
-        for (int t0 = 0; t0 < N; t0 += 64) {
-            int c = t0 + lane;
+        for (int t0 = 0; t0 < N; t0 += T) {
+            int c = t0 + threadIdx.x;
             bool f = c < N && fixed0[c0 + c];
-            u64 mask = __ballot(f);
-            if (f) {
-                u64 below = mask & lt_mask;
-                int prev = below ? t0 + 63 - __clzll((long long)below) : carry;
+            int prev = wg_prev_flagged(f, c, carry, lds);
+            if (f && prev >= 0) {
                 int size = c - prev + 1;
-                if (prev >= 0 && size > mps) {
+                if (size > mps) {
                     int cnt = (int)ceil((double)size / (double)mps);
                     double step = (double)size / (double)cnt;
                     for (int i = 1; i < cnt; ++i) {
@@ -515,72 +549,156 @@ __global__ void __launch_bounds__(64) k_fix(i64 K, const i64 *pos_off, const int
                     }
                 }
             }
-            if (mask) carry = t0 + 63 - __clzll((long long)mask);
         }
         __syncthreads();
-        // final fixed set, problems, arena carving
+        // final fixed set; the right end of every problem records the problem's size
         carry = -1;
-        const int g_base = iv_start[k];
-        const i64 L0 = part_lane_off[part], L1 = part_lane_off[part + 1];
-        for (int t0 = 0; t0 < N; t0 += 64) {
-            int c = t0 + lane;
+        for (int t0 = 0; t0 < N; t0 += T) {
+            int c = t0 + threadIdx.x;
             bool f = c < N && (fixed0[c0 + c] | added[c0 + c]);
-            if (c < N) { fixed[c0 + c] = f; chosen[c0 + c] = f; }
-            u64 mask = __ballot(f);
-            int prev = -1;
-            if (f) { u64 below = mask & lt_mask; prev = below ? t0 + 63 - __clzll((long long)below) : carry; }
-            bool is_prob = f && prev >= 0 && (c - prev + 1) >= 3;
-            u64 pmask = __ballot(is_prob);
-            if (pmask) {
-                int n = is_prob ? c - prev + 1 : 0;
-                int lo_lane = 0, n_lanes = 0;
-                if (is_prob) {
-                    // reads are sorted by their first position; lane_pmax = running max of their last position
-                    int g0 = g_base + cy[prev], g1 = g_base + cy[c];
-                    i64 a = L0, b = L1;
-                    while (a < b) { i64 m = (a + b) >> 1; if (lane_pmax[m] < g0) a = m + 1; else b = m; }
-                    i64 lo = a;
-                    a = lo; b = L1;
-                    while (a < b) { i64 m = (a + b) >> 1; if (lane_start[m] < g1) a = m + 1; else b = m; }
-                    lo_lane = (int)lo; n_lanes = (int)(a - lo);
-                }
-                int chunks = (n_lanes + kLaneChunk - 1) / kLaneChunk;
-                i64 t_slot, t_pair, t_tri, t_work, t_cov;
-                i64 e_slot = wave_excl_scan(is_prob ? 1 : 0, &t_slot);
-                i64 e_pair = wave_excl_scan((i64)n * (n - 1) / 2, &t_pair);
-                i64 e_tri = wave_excl_scan((i64)n * (n - 1) * (n - 2) / 6, &t_tri);
-                i64 e_work = wave_excl_scan(chunks, &t_work);
-                i64 e_cov = wave_excl_scan((i64)chunks * kLaneChunk * n, &t_cov);
-                u64 b_slot = 0, b_pair = 0, b_tri = 0, b_work = 0, b_cov = 0;
-                if (lane == 0) {
-                    b_slot = atomicAdd(&st->n_prob, (u64)t_slot);
-                    b_pair = atomicAdd(&st->pair_used, (u64)t_pair);
-                    b_tri = atomicAdd(&st->tri_used, (u64)t_tri);
-                    b_work = atomicAdd(&st->n_work, (u64)t_work);
-                    b_cov = atomicAdd(&st->cov_used, (u64)t_cov);
-                }
-                b_slot = __shfl(b_slot, 0); b_pair = __shfl(b_pair, 0); b_tri = __shfl(b_tri, 0);
-                b_work = __shfl(b_work, 0); b_cov = __shfl(b_cov, 0);
-                if (is_prob) {
-                    i64 slot = (i64)b_slot + e_slot;
-                    if (n > kNMax) atomicOr(&st->err, kErrProblemTooLarge);
-                    if (slot < prob_cap) {
-                        pr.iv[slot] = (int)k; pr.start[slot] = prev; pr.n[slot] = n;
-                        pr.pair_off[slot] = (i64)b_pair + e_pair; pr.tri_off[slot] = (i64)b_tri + e_tri;
-                        pr.cov_off[slot] = (i64)b_cov + e_cov; pr.work_base[slot] = (i64)b_work + e_work;
-                        pr.flags[slot] = 0; pr.chain[slot] = 0;
-                        pr.lane_lo[slot] = lo_lane; pr.lane_n[slot] = n_lanes;
-                        i64 wb = (i64)b_work + e_work;
-                        for (int q = 0; q < chunks; ++q) {
-                            if (wb + q < work_cap) { work_prob[wb + q] = (int)slot; work_chunk[wb + q] = q; }
-                            else atomicOr(&st->err, kErrOverflowWork);
-                        }
-                    } else atomicOr(&st->err, kErrOverflowProblems);
-                }
+            int prev = wg_prev_flagged(f, c, carry, lds);
+            if (c < N) {
+                fixed[c0 + c] = f; chosen[c0 + c] = f;
+                int n = (f && prev >= 0 && c - prev + 1 >= 3) ? c - prev + 1 : 0;
+                if (n > kNMax) atomicOr(&st->err, kErrProblemTooLarge);
+                cand_pn[c0 + c] = n;
             }
-            if (mask) carry = t0 + 63 - __clzll((long long)mask);
         }
         __syncthreads();
+    }
+}
+
+// For the right end of every problem: the range of position-sorted reads that can overlap the problem's window
+// [g0, g1): reads are sorted by first position, lane_pmax is the running maximum of their last position.
+__global__ void k_prob_range(const Status *st, const int *cand_pn, const int *cand_iv, const int *cand_y,
+                             const int *iv_part, const int *iv_start, const i64 *part_lane_off, const int *lane_start,
+                             const int *lane_pmax, int *cand_ll, int *cand_ln) {
+    i64 n_cand = (i64)st->n_cand;
+    for (i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x; c < n_cand; c += (i64)gridDim.x * blockDim.x) {
+        int n = cand_pn[c];
+        int lo_lane = 0, n_lanes = 0;
+        if (n > 0) {
+            int k = cand_iv[c];
+            int part = iv_part[k];
+            int g0 = iv_start[k] + cand_y[c - (n - 1)], g1 = iv_start[k] + cand_y[c];
+            i64 a = part_lane_off[part], L1 = part_lane_off[part + 1], b = L1;
+            while (a < b) { i64 m = (a + b) >> 1; if (lane_pmax[m] < g0) a = m + 1; else b = m; }
+            i64 lo = a;
+            b = L1;
+            while (a < b) { i64 m = (a + b) >> 1; if (lane_start[m] < g1) a = m + 1; else b = m; }
+            lo_lane = (int)lo; n_lanes = (int)(a - lo);
+        }
+        cand_ll[c] = lo_lane; cand_ln[c] = n_lanes;
+    }
+}
+
+// Problem list by a prefix sum over the candidates: problem slot, pair / triple / coverage arena offsets and
+// work items come out in candidate order, so the arena layout is deterministic.
+struct ProbSizes { i64 v[5]; };   // slot, pairs, triples, work items, coverage elements
+__device__ __forceinline__ ProbSizes prob_sizes(int n, int n_lanes) {
+    ProbSizes s;
+    if (n <= 0) { for (int q = 0; q < 5; ++q) s.v[q] = 0; return s; }
+    i64 chunks = (n_lanes + kLaneChunk - 1) / kLaneChunk;
+    s.v[0] = 1; s.v[1] = (i64)n * (n - 1) / 2; s.v[2] = (i64)n * (n - 1) * (n - 2) / 6; s.v[3] = chunks;
+    s.v[4] = chunks * kLaneChunk * n;
+    return s;
+}
+__device__ __forceinline__ i64 wg_exclusive_scan64(i64 v, i64 *lds /* >= 16 */, i64 *total) {
+    int lane = lane_id(), wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    i64 x = v;
+    for (int d = 1; d < 64; d <<= 1) {
+        i64 y = __shfl_up(x, d);
+        if (lane >= d) x += y;
+    }
+    __syncthreads();
+    if (lane == 63) lds[wave] = x;
+    __syncthreads();
+    i64 off = 0, tot = 0;
+    for (int w = 0; w < nw; ++w) {
+        i64 sv = lds[w];
+        if (w < wave) off += sv;
+        tot += sv;
+    }
+    *total = tot;
+    return off + x - v;
+}
+constexpr int kProbBlock = 1024;   // candidates per workgroup of the problem scan (256 threads x 4)
+__global__ void __launch_bounds__(256) k_prob_scan1(const Status *st, const int *cand_pn, const int *cand_ln, i64 *bs) {
+    __shared__ i64 lds[16];
+    i64 n = (i64)st->n_cand;
+    i64 nb = (n + kProbBlock - 1) / kProbBlock;
+    for (i64 b = blockIdx.x; b < nb; b += gridDim.x) {
+        i64 i0 = b * kProbBlock + (i64)threadIdx.x * 4;
+        ProbSizes acc; for (int q = 0; q < 5; ++q) acc.v[q] = 0;
+        for (int e = 0; e < 4; ++e) if (i0 + e < n) { ProbSizes s = prob_sizes(cand_pn[i0 + e], cand_ln[i0 + e]); for (int q = 0; q < 5; ++q) acc.v[q] += s.v[q]; }
+        for (int q = 0; q < 5; ++q) {
+            i64 tot;
+            wg_exclusive_scan64(acc.v[q], lds, &tot);
+            if (threadIdx.x == 0) bs[b * 5 + q] = tot;
+            __syncthreads();
+        }
+    }
+}
+__global__ void __launch_bounds__(256) k_prob_scan2(Status *st, i64 *bs) {
+    __shared__ i64 lds[16];
+    __shared__ i64 carry_s[5];
+    i64 n = (i64)st->n_cand;
+    i64 nb = (n + kProbBlock - 1) / kProbBlock;
+    if (threadIdx.x < 5) carry_s[threadIdx.x] = 0;
+    __syncthreads();
+    for (i64 b0 = 0; b0 < nb; b0 += blockDim.x) {
+        i64 b = b0 + threadIdx.x;
+        for (int q = 0; q < 5; ++q) {
+            i64 v = b < nb ? bs[b * 5 + q] : 0;
+            i64 tot;
+            i64 ex = wg_exclusive_scan64(v, lds, &tot);
+            i64 carry = carry_s[q];
+            if (b < nb) bs[b * 5 + q] = carry + ex;
+            __syncthreads();
+            if (threadIdx.x == 0) carry_s[q] = carry + tot;
+            __syncthreads();
+        }
+    }
+    if (threadIdx.x == 0) {
+        st->n_prob = (u64)carry_s[0]; st->pair_used = (u64)carry_s[1]; st->tri_used = (u64)carry_s[2];
+        st->n_work = (u64)carry_s[3]; st->cov_used = (u64)carry_s[4];
+    }
+}
+__global__ void __launch_bounds__(256) k_prob_emit(Status *st, const int *cand_pn, const int *cand_ll, const int *cand_ln,
+                                                   const int *cand_iv, const i64 *cand_off, const i64 *bs,
+                                                   ProblemArrays pr, i64 prob_cap, int *work_prob, int *work_chunk,
+                                                   i64 work_cap) {
+    __shared__ i64 lds[16];
+    i64 n = (i64)st->n_cand;
+    i64 nb = (n + kProbBlock - 1) / kProbBlock;
+    for (i64 b = blockIdx.x; b < nb; b += gridDim.x) {
+        i64 i0 = b * kProbBlock + (i64)threadIdx.x * 4;
+        ProbSizes sz[4], acc; for (int q = 0; q < 5; ++q) acc.v[q] = 0;
+        for (int e = 0; e < 4; ++e) {
+            if (i0 + e < n) sz[e] = prob_sizes(cand_pn[i0 + e], cand_ln[i0 + e]); else sz[e] = prob_sizes(0, 0);
+            for (int q = 0; q < 5; ++q) acc.v[q] += sz[e].v[q];
+        }
+        i64 ex[5];
+        for (int q = 0; q < 5; ++q) { i64 tot; ex[q] = wg_exclusive_scan64(acc.v[q], lds, &tot) + bs[b * 5 + q]; __syncthreads(); }
+        for (int e = 0; e < 4; ++e) {
+            if (sz[e].v[0]) {
+                i64 c = i0 + e;
+                i64 slot = ex[0];
+                int nn = cand_pn[c];
+                if (slot < prob_cap) {
+                    int k = cand_iv[c];
+                    pr.iv[slot] = k; pr.start[slot] = (int)(c - cand_off[k]) - (nn - 1); pr.n[slot] = nn;
+                    pr.pair_off[slot] = ex[1]; pr.tri_off[slot] = ex[2]; pr.work_base[slot] = ex[3]; pr.cov_off[slot] = ex[4];
+                    pr.flags[slot] = 0; pr.chain[slot] = 0;
+                    pr.lane_lo[slot] = cand_ll[c]; pr.lane_n[slot] = cand_ln[c];
+                    for (i64 q = 0; q < sz[e].v[3]; ++q) {
+                        if (ex[3] + q < work_cap) { work_prob[ex[3] + q] = (int)slot; work_chunk[ex[3] + q] = (int)q; }
+                        else atomicOr(&st->err, kErrOverflowWork);
+                    }
+                } else atomicOr(&st->err, kErrOverflowProblems);
+            }
+            for (int q = 0; q < 5; ++q) ex[q] += sz[e].v[q];
+        }
     }
 }
 
@@ -840,101 +958,113 @@ __global__ void __launch_bounds__(kScoreThreads) k_score(Status *st, ProblemArra
 // in_ab = -(ambiguous reads of pair (a,b)); reads outside the problem's read range have no coverage
 // in the window and are ambiguous only for pairs whose lo threshold is negative.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_dp(Status *st, ProblemArrays pr, i64 prob_cap, const i64 *cand_off,
-                                           const int *cand_y, const int *iv_part, const i64 *part_lane_off,
-                                           const unsigned *out_g, i64 tri_cap, const unsigned *amb_g,
-                                           const int2 *pair_thr, i64 pair_cap, int support, unsigned char *chosen) {
-    __shared__ i64 M[kNMax * kNMax];
-    __shared__ unsigned char A[kNMax * kNMax];
-    __shared__ int cy_s[kNMax];
+template <int NM>
+__global__ void __launch_bounds__(256) k_dp(Status *st, int n_lo, u64 *queue, ProblemArrays pr, i64 prob_cap,
+                                            const i64 *cand_off, const int *cand_y, const int *iv_part,
+                                            const i64 *part_lane_off, const unsigned *out_g, i64 tri_cap,
+                                            const unsigned *amb_g, const int2 *pair_thr, i64 pair_cap, int support,
+                                            unsigned char *chosen) {
+    // handles problems with n_lo < n <= NM; the out table of the problem is staged in LDS first
+    constexpr int kTri = NM * (NM - 1) * (NM - 2) / 6, kPairs = NM * (NM - 1) / 2;
+    extern __shared__ __align__(16) unsigned char smem[];
+    i64 *M = reinterpret_cast<i64 *>(smem);                          // M(b,c), b < c, at c*(c-1)/2 + b
+    unsigned *out_s = reinterpret_cast<unsigned *>(M + kPairs);
+    int *in_s = reinterpret_cast<int *>(out_s + kTri);
+    unsigned char *A = reinterpret_cast<unsigned char *>(in_s + kPairs);
+    __shared__ int cy_s[NM];
     __shared__ u64 work_s;
     int lane = lane_id();
     i64 n_prob = (i64)st->n_prob < prob_cap ? (i64)st->n_prob : prob_cap;
     for (;;) {
         __syncthreads();
-        if (threadIdx.x == 0) work_s = atomicAdd(&st->dp_queue, 1ULL);
+        if (threadIdx.x == 0) work_s = atomicAdd(queue, 1ULL);
         __syncthreads();
         i64 p = (i64)work_s;
         if (p >= n_prob) break;
         int n = pr.n[p];
+        if (n <= n_lo || n > NM) continue;
         i64 poff = pr.pair_off[p], toff = pr.tri_off[p];
         int npairs = n * (n - 1) / 2, ntri = n * (n - 1) * (n - 2) / 6;
-        if (n > kNMax || poff + npairs > pair_cap || toff + ntri > tri_cap) continue;
+        if (poff + npairs > pair_cap || toff + ntri > tri_cap) continue;
         int k_iv = pr.iv[p];
         i64 c0 = cand_off[k_iv] + pr.start[p];
-        for (int j = lane; j < n; j += 64) cy_s[j] = cand_y[c0 + j];
-        __syncthreads();
-        const unsigned *amb = amb_g + poff;
-        const int2 *thr = pair_thr + poff;
-        const unsigned *outp = out_g + toff;
-        const int end = n - 1;
         int part = iv_part[k_iv];
         const i64 outside = (part_lane_off[part + 1] - part_lane_off[part]) - pr.lane_n[p];
         const bool zamb = (pr.flags[p] & 1) != 0;
-#define FSEG_IN(a, b) (-((i64)amb[(b) * ((b) - 1) / 2 + (a)] + ((zamb && thr[(b) * ((b) - 1) / 2 + (a)].y < 0) ? outside : 0)))
-        // M(b, end) = in(b, end)
-        for (int b = lane; b < end; b += 64) { M[b * kNMax + end] = FSEG_IN(b, end); A[b * kNMax + end] = 255; }
+        for (int j = threadIdx.x; j < n; j += blockDim.x) cy_s[j] = cand_y[c0 + j];
+        for (int x = threadIdx.x; x < ntri; x += blockDim.x) out_s[x] = out_g[toff + x];
+        for (int q = threadIdx.x; q < npairs; q += blockDim.x)
+            in_s[q] = -(int)((i64)amb_g[poff + q] + ((zamb && pair_thr[poff + q].y < 0) ? outside : 0));
         __syncthreads();
-        for (int c = end - 1; c >= 2; --c) {
-            int b = 1 + lane;                          // lanes: b in [1, c)
-            if (b < c) {
-                i64 best = kNegInf; int arg = 255;
-                if (cy_s[c] - cy_s[b] >= 5) {
-                    i64 in_bc = FSEG_IN(b, c);
-                    int base = c * (c - 1) / 2 + b;
-                    for (int c2 = c + 1; c2 <= end; ++c2) {
-                        if (cy_s[c2] - cy_s[c] < 5) continue;
-                        i64 tail = M[c * kNMax + c2];
-                        if (tail == kNegInf) continue;
-                        unsigned o = outp[c2 * (c2 - 1) * (c2 - 2) / 6 + base];
-                        if ((i64)o < (i64)support) continue;              // :526-527
-                        i64 cur = in_bc + (i64)o + tail;
-                        if (cur > best) { best = cur; arg = c2; }
+        const int end = n - 1;
+        if (threadIdx.x < 64) {          // the recurrence itself runs on one wave
+#define FSEG_IN(a, b) ((i64)in_s[(b) * ((b) - 1) / 2 + (a)])
+#define FSEG_M(a, b) M[(b) * ((b) - 1) / 2 + (a)]
+            for (int b = lane; b < end; b += 64) { FSEG_M(b, end) = FSEG_IN(b, end); A[end * (end - 1) / 2 + b] = 255; }
+            __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): LDS writes of this wave are visible to its later reads
+            for (int c = end - 1; c >= 2; --c) {
+                int b = 1 + lane;                          // lanes: b in [1, c)
+                if (b < c) {
+                    i64 best = kNegInf; int arg = 255;
+                    if (cy_s[c] - cy_s[b] >= 5) {
+                        i64 in_bc = FSEG_IN(b, c);
+                        int base = c * (c - 1) / 2 + b;
+                        const int cyc = cy_s[c];
+#pragma unroll 4
+                        for (int c2 = c + 1; c2 <= end; ++c2) {
+                            i64 tail = FSEG_M(c, c2);
+                            unsigned o = out_s[c2 * (c2 - 1) * (c2 - 2) / 6 + base];
+                            bool ok = (cy_s[c2] - cyc >= 5) & (tail != kNegInf) & ((i64)o >= (i64)support);   // :526-527, :540
+                            i64 cur = ok ? in_bc + (i64)o + tail : kNegInf;
+                            bool take = cur > best;
+                            best = take ? cur : best; arg = take ? c2 : arg;
+                        }
+                    }
+                    FSEG_M(b, c) = best; A[c * (c - 1) / 2 + b] = (unsigned char)arg;
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+            }
+            // top level: a = start
+            i64 best = FSEG_IN(0, end);
+            int bj = -1, bk = -1;
+            for (int j = 1; j < end; ++j) {
+                if (cy_s[j] - cy_s[0] < 5) continue;
+                i64 in_0j = FSEG_IN(0, j);
+                for (int k0 = j + 1; k0 <= end; k0 += 64) {
+                    int kx = k0 + lane;
+                    i64 cur = kNegInf;
+                    if (kx <= end && cy_s[kx] - cy_s[j] >= 5) {
+                        i64 tail = FSEG_M(j, kx);
+                        unsigned o = out_s[kx * (kx - 1) * (kx - 2) / 6 + j * (j - 1) / 2 + 0];
+                        if (tail != kNegInf && (i64)o >= (i64)support) cur = in_0j + (i64)o + tail;
+                    }
+                    // first lane (smallest k) holding the wave maximum
+                    i64 mx = cur;
+                    for (int d = 32; d >= 1; d >>= 1) { i64 o2 = __shfl_xor(mx, d); mx = o2 > mx ? o2 : mx; }
+                    if (mx > best) {
+                        u64 m = __ballot(cur == mx);
+                        int bb = __ffsll((long long)m) - 1;
+                        best = mx; bj = j; bk = k0 + bb;
                     }
                 }
-                M[b * kNMax + c] = best; A[b * kNMax + c] = (unsigned char)arg;
             }
-            __syncthreads();
-        }
-        // top level: a = start
-        i64 best = FSEG_IN(0, end);
-        int bj = -1, bk = -1;
-        for (int j = 1; j < end; ++j) {
-            if (cy_s[j] - cy_s[0] < 5) continue;
-            i64 in_0j = FSEG_IN(0, j);
-            for (int k0 = j + 1; k0 <= end; k0 += 64) {
-                int kx = k0 + lane;
-                i64 cur = kNegInf;
-                if (kx <= end && cy_s[kx] - cy_s[j] >= 5) {
-                    i64 tail = M[j * kNMax + kx];
-                    unsigned o = outp[kx * (kx - 1) * (kx - 2) / 6 + j * (j - 1) / 2 + 0];
-                    if (tail != kNegInf && (i64)o >= (i64)support) cur = in_0j + (i64)o + tail;
+            if (lane == 0) {
+                int chain = 0;
+                if (bj >= 0) {
+                    chosen[c0] = 1;
+                    int j = bj, k = bk;
+                    for (;;) {
+                        chosen[c0 + j] = 1; chosen[c0 + k] = 1; ++chain;
+                        if (k == end) break;
+                        int k2 = A[k * (k - 1) / 2 + j];
+                        if (k2 == 255) break;
+                        j = k; k = k2;
+                    }
                 }
-                // first lane (smallest k) holding the wave maximum
-                i64 mx = cur;
-                for (int d = 32; d >= 1; d >>= 1) { i64 o2 = __shfl_xor(mx, d); mx = o2 > mx ? o2 : mx; }
-                if (mx > best) {
-                    u64 m = __ballot(cur == mx);
-                    int b = __ffsll((long long)m) - 1;
-                    best = mx; bj = j; bk = k0 + b;
-                }
+                pr.chain[p] = chain;
             }
-        }
 #undef FSEG_IN
-        if (lane == 0) {
-            int chain = 0;
-            if (bj >= 0) {
-                chosen[c0] = 1;
-                int j = bj, k = bk;
-                for (;;) {
-                    chosen[c0 + j] = 1; chosen[c0 + k] = 1; ++chain;
-                    if (k == end) break;
-                    int k2 = A[j * kNMax + k];
-                    if (k2 == 255) break;
-                    j = k; k = k2;
-                }
-            }
-            pr.chain[p] = chain;
+#undef FSEG_M
         }
     }
 }
@@ -945,56 +1075,66 @@ __global__ void __launch_bounds__(64) k_dp(Status *st, ProblemArrays pr, i64 pro
 // previous chosen candidate is more than 40 positions away, records that segment; k_refine then
 // visits the recorded segments (one wave each).
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_segments(i64 K, const i64 *pos_off, const i64 *cand_off, const int *cand_y,
-                                                 const unsigned char *chosen, unsigned char *final_flag, int *seg_iv,
-                                                 int *seg_prev_y) {
-    int lane = lane_id();
-    const u64 lt_mask = (1ULL << lane) - 1ULL;
+__global__ void k_segments(i64 K, const i64 *pos_off, const i64 *cand_off, const int *cand_y,
+                           const unsigned char *chosen, unsigned char *final_flag, int *rseg_c, int *rseg_prev,
+                           Status *st) {
+    __shared__ int lds[16];
+    __shared__ int cnt_s[16];
+    __shared__ u64 base_s;
+    const int T = blockDim.x;
+    int lane = lane_id(), wave = threadIdx.x >> 6, nw = (T + 63) >> 6;
     for (i64 k = blockIdx.x; k < K; k += gridDim.x) {
         i64 c0 = cand_off[k];
         int N = (int)(cand_off[k + 1] - c0);
         i64 base = pos_off[k];
-        int carry_y = -1;
-        for (int t0 = 0; t0 < N; t0 += 64) {
-            int c = t0 + lane;
+        int carry = -1;
+        for (int t0 = 0; t0 < N; t0 += T) {
+            int c = t0 + threadIdx.x;
             bool f = c < N && chosen[c0 + c];
-            int y = c < N ? cand_y[c0 + c] : 0;
-            u64 mask = __ballot(f);
-            int prev_lane = -1;
-            if (f) { u64 below = mask & lt_mask; if (below) prev_lane = 63 - __clzll((long long)below); }
-            int py = __shfl(y, prev_lane < 0 ? 0 : prev_lane);
-            if (prev_lane < 0) py = carry_y;
-            if (c < N) {
-                int rec = -1;
-                if (f) {
-                    final_flag[base + y] = 1;
-                    if (py >= 0 && y - py > 40) rec = py;             // :252
-                }
-                seg_prev_y[c0 + c] = rec;
-                seg_iv[c0 + c] = (int)k;
+            int prev = wg_prev_flagged(f, c, carry, lds);
+            int y = 0, py = -1;
+            if (f) {
+                y = cand_y[c0 + c];
+                final_flag[base + y] = 1;
+                if (prev >= 0) py = cand_y[c0 + prev];
             }
-            if (mask) carry_y = __shfl(y, 63 - __clzll((long long)mask));
+            bool need = f && py >= 0 && y - py > 40;                  // :252
+            u64 m = __ballot(need);
+            if (lane == 0) cnt_s[wave] = __popcll(m);
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                int tot = 0;
+                for (int w = 0; w < nw; ++w) { int v = cnt_s[w]; cnt_s[w] = tot; tot += v; }
+                base_s = tot ? atomicAdd(&st->n_rseg, (u64)tot) : 0;
+            }
+            __syncthreads();
+            if (need) {
+                u64 slot = base_s + cnt_s[wave] + __popcll(m & ((1ULL << lane) - 1ULL));
+                rseg_c[slot] = (int)(c0 + c); rseg_prev[slot] = py;
+            }
+            __syncthreads();
         }
     }
 }
 
-__global__ void __launch_bounds__(64) k_refine(const Status *st, const int *seg_iv, const int *seg_prev_y,
-                                               const int *cand_y, const i64 *pos_off, const int *y_raw,
-                                               const double *w_g, int radius, double sigma, double *g_scr, int *pk_scr,
-                                               unsigned char *flag_scr, unsigned char *keep_scr,
-                                               unsigned char *final_flag) {
+__global__ void __launch_bounds__(64) k_refine(const Status *st, const int *cand_iv, const int *rseg_c,
+                                               const int *rseg_prev, const int *cand_y, const i64 *pos_off,
+                                               const int *y_raw, const double *w_g, int radius, double sigma,
+                                               double *g_scr, int *pk_scr, unsigned char *flag_scr,
+                                               unsigned char *keep_scr, unsigned char *final_flag) {
     __shared__ double ws[kMaxRadius + 1];
     const int skip = 20;
     int lane = lane_id();
     for (int j = lane; j <= radius; j += 64) ws[j] = w_g[j];
     __syncthreads();
-    i64 n_cand = (i64)st->n_cand;
-    for (i64 sg = blockIdx.x; sg < n_cand; sg += gridDim.x) {
-        int s = seg_prev_y[sg];
-        if (s < 0) continue;
+    i64 n_seg = (i64)st->n_rseg;
+    for (i64 si = blockIdx.x; si < n_seg; si += gridDim.x) {
+      {
+        i64 sg = rseg_c[si];
+        int s = rseg_prev[si];
         int e = cand_y[sg];
         int len = e - s;
-        i64 base = pos_off[seg_iv[sg]] + s;
+        i64 base = pos_off[cand_iv[sg]] + s;
         const int *xr = y_raw + base;
         // sum(i_vals) < 20 -> skip (:258); values are exact integers
         i64 tot = 0;
@@ -1066,6 +1206,7 @@ __global__ void __launch_bounds__(64) k_refine(const Status *st, const int *seg_
             if (!(sm < 20.0)) final_flag[base + i] = 1;
         }
         __syncthreads();
+      }
     }
 }
 
@@ -1229,7 +1370,7 @@ struct fseg_ctx {
     // candidate-sized
     DevBuf d_cand_off, d_cand_y, d_fixed0, d_added, d_fixed, d_chosen, d_final_off, d_final_y, d_final_pos, d_col_thr,
         d_col_zero;
-    DevBuf d_seg_iv, d_seg_prev;
+    DevBuf d_seg_iv, d_seg_prev, d_rseg_c, d_cand_pn, d_cand_ll, d_cand_ln, d_prob_bs;
     // problems / arenas
     DevBuf d_prob_iv, d_prob_start, d_prob_n, d_prob_pair_off, d_prob_tri_off, d_prob_flags, d_prob_chain,
         d_prob_cov_off, d_prob_lane_lo, d_prob_lane_n, d_prob_work_base;
@@ -1296,6 +1437,11 @@ size_t score_lds_bytes() {
     return (b + 15) & ~(size_t)15;
 }
 
+template <int NM> constexpr size_t dp_lds_bytes() {
+    return (size_t)(NM * (NM - 1) / 2) * (8 + 4 + 1) + (size_t)(NM * (NM - 1) * (NM - 2) / 6) * 4 + 16;
+}
+constexpr int kDpSmall = 32;
+
 int alloc_arenas(fseg_ctx *c) {
     TRY(ensure(c, c->d_prob_iv, (size_t)c->prob_cap * 4));
     TRY(ensure(c, c->d_prob_start, (size_t)c->prob_cap * 4));
@@ -1358,7 +1504,7 @@ int enqueue_run(fseg_ctx *c) {
                        c->d_idx.as<int>(), c->d_voff.as<i64>(), c->d_chunk_off.as<i64>(), st, c->chunk_cap);
     int chunk_grid = grid_for(c->chunk_cap, 1, 4096);
     for (int pass = 0; pass < 2; ++pass) {
-        hipLaunchKernelGGL(k_vsum_chunks, dim3(chunk_grid), dim3(64), 0, s, n_part, c->d_voff.as<i64>(),
+        hipLaunchKernelGGL(k_vsum_chunks, dim3(chunk_grid), dim3(512), 0, s, n_part, c->d_voff.as<i64>(),
                            c->d_chunk_off.as<i64>(), c->d_v.as<double>(), c->d_mean.as<double>(), pass,
                            c->d_csum.as<double>(), c->chunk_cap);
         hipLaunchKernelGGL(k_vsum_part, dim3(grid_for(n_part, 64, 1024)), dim3(64), 0, s, n_part, c->d_voff.as<i64>(),
@@ -1381,12 +1527,27 @@ int enqueue_run(fseg_ctx *c) {
                      c->d_prob_pair_off.as<i64>(), c->d_prob_tri_off.as<i64>(), c->d_prob_flags.as<int>(),
                      c->d_prob_chain.as<int>(), c->d_prob_cov_off.as<i64>(), c->d_prob_lane_lo.as<int>(),
                      c->d_prob_lane_n.as<int>(), c->d_prob_work_base.as<i64>()};
-    hipLaunchKernelGGL(k_fix, dim3(grid_for(K, 1, 8192)), dim3(64), 0, s, K, c->d_pos_off.as<i64>(), c->d_iv_part.as<int>(),
-                       c->d_iv_start.as<int>(), c->d_cand_off.as<i64>(), c->d_cand_y.as<int>(), c->d_y.as<double>(),
+    // threads per interval for the per-interval kernels: long intervals carry many candidates
+    const i64 avg_len = NPOS / (K > 0 ? K : 1);
+    const int iv_threads = avg_len > 65536 ? 1024 : (avg_len > 16384 ? 256 : 64);
+    hipLaunchKernelGGL(k_fix, dim3(grid_for(K, 1, 8192)), dim3(iv_threads), 0, s, K, c->d_pos_off.as<i64>(),
+                       c->d_iv_part.as<int>(), c->d_cand_off.as<i64>(), c->d_cand_y.as<int>(), c->d_y.as<double>(),
                        c->d_thr.as<double>(), c->P.max_problem_size, c->d_fixed0.as<unsigned char>(),
-                       c->d_added.as<unsigned char>(), c->d_fixed.as<unsigned char>(), c->d_chosen.as<unsigned char>(), pr,
-                       c->prob_cap, c->d_part_lane_off.as<i64>(), c->d_lane_start.as<int>(), c->d_lane_pmax.as<int>(),
-                       c->d_work_prob.as<int>(), c->d_work_chunk.as<int>(), c->work_cap, st);
+                       c->d_added.as<unsigned char>(), c->d_fixed.as<unsigned char>(), c->d_chosen.as<unsigned char>(),
+                       c->d_cand_pn.as<int>(), c->d_seg_iv.as<int>(), st);
+    hipLaunchKernelGGL(k_prob_range, dim3(grid_for(NPOS / 64 + 1, 256, 1024)), dim3(256), 0, s, st, c->d_cand_pn.as<int>(),
+                       c->d_seg_iv.as<int>(), c->d_cand_y.as<int>(), c->d_iv_part.as<int>(), c->d_iv_start.as<int>(),
+                       c->d_part_lane_off.as<i64>(), c->d_lane_start.as<int>(), c->d_lane_pmax.as<int>(),
+                       c->d_cand_ll.as<int>(), c->d_cand_ln.as<int>());
+    {
+        int pg = grid_for(NPOS / 8 / kProbBlock + 1, 1, 1024);
+        hipLaunchKernelGGL(k_prob_scan1, dim3(pg), dim3(256), 0, s, st, c->d_cand_pn.as<int>(), c->d_cand_ln.as<int>(),
+                           c->d_prob_bs.as<i64>());
+        hipLaunchKernelGGL(k_prob_scan2, dim3(1), dim3(256), 0, s, st, c->d_prob_bs.as<i64>());
+        hipLaunchKernelGGL(k_prob_emit, dim3(pg), dim3(256), 0, s, st, c->d_cand_pn.as<int>(), c->d_cand_ll.as<int>(),
+                           c->d_cand_ln.as<int>(), c->d_seg_iv.as<int>(), c->d_cand_off.as<i64>(), c->d_prob_bs.as<i64>(),
+                           pr, c->prob_cap, c->d_work_prob.as<int>(), c->d_work_chunk.as<int>(), c->work_cap);
+    }
     mark(5);
     // S5
     int work_grid = grid_for(c->work_cap, 1, 4096);
@@ -1412,21 +1573,27 @@ int enqueue_run(fseg_ctx *c) {
     }
     mark(7);
     if (c->prob_cap > 0) {
-        hipLaunchKernelGGL(k_dp, dim3(grid_for(c->prob_cap, 1, 1280)), dim3(64), 0, s, st, pr, c->prob_cap,
-                           c->d_cand_off.as<i64>(), c->d_cand_y.as<int>(), c->d_iv_part.as<int>(),
+        int dp_grid = grid_for(c->prob_cap, 1, 1024);
+        hipLaunchKernelGGL(k_dp<kDpSmall>, dim3(dp_grid), dim3(256), dp_lds_bytes<kDpSmall>(), s, st, 0, &st->dp_queue, pr,
+                           c->prob_cap, c->d_cand_off.as<i64>(), c->d_cand_y.as<int>(), c->d_iv_part.as<int>(),
                            c->d_part_lane_off.as<i64>(), c->d_out.as<unsigned>(), c->tri_cap, c->d_amb.as<unsigned>(),
                            c->d_pair_thr.as<int2>(), c->pair_cap, c->P.min_read_support_outside,
+                           c->d_chosen.as<unsigned char>());
+        hipLaunchKernelGGL(k_dp<kNMax>, dim3(dp_grid < 256 ? dp_grid : 256), dim3(256), dp_lds_bytes<kNMax>(), s, st, kDpSmall,
+                           &st->dp_queue2, pr, c->prob_cap, c->d_cand_off.as<i64>(), c->d_cand_y.as<int>(),
+                           c->d_iv_part.as<int>(), c->d_part_lane_off.as<i64>(), c->d_out.as<unsigned>(), c->tri_cap,
+                           c->d_amb.as<unsigned>(), c->d_pair_thr.as<int2>(), c->pair_cap, c->P.min_read_support_outside,
                            c->d_chosen.as<unsigned char>());
     }
     mark(8);
     // S6
     HIP_TRY(c, hipMemsetAsync(c->d_final_flag.p, 0, (size_t)NPOS, s));
-    hipLaunchKernelGGL(k_segments, dim3(grid_for(K, 1, 8192)), dim3(64), 0, s, K, c->d_pos_off.as<i64>(),
+    hipLaunchKernelGGL(k_segments, dim3(grid_for(K, 1, 8192)), dim3(iv_threads), 0, s, K, c->d_pos_off.as<i64>(),
                        c->d_cand_off.as<i64>(), c->d_cand_y.as<int>(), c->d_chosen.as<unsigned char>(),
-                       c->d_final_flag.as<unsigned char>(), c->d_seg_iv.as<int>(), c->d_seg_prev.as<int>());
-    hipLaunchKernelGGL(k_refine, dim3(2048), dim3(64), 0, s, st, c->d_seg_iv.as<int>(), c->d_seg_prev.as<int>(),
-                       c->d_cand_y.as<int>(), c->d_pos_off.as<i64>(), c->d_y_raw.as<int>(), c->d_w_refine.as<double>(),
-                       c->P.radius_refine, c->P.sigma, c->d_g.as<double>(), c->d_pk.as<int>(),
+                       c->d_final_flag.as<unsigned char>(), c->d_rseg_c.as<int>(), c->d_seg_prev.as<int>(), st);
+    hipLaunchKernelGGL(k_refine, dim3(2048), dim3(64), 0, s, st, c->d_seg_iv.as<int>(), c->d_rseg_c.as<int>(),
+                       c->d_seg_prev.as<int>(), c->d_cand_y.as<int>(), c->d_pos_off.as<i64>(), c->d_y_raw.as<int>(),
+                       c->d_w_refine.as<double>(), c->P.radius_refine, c->P.sigma, c->d_g.as<double>(), c->d_pk.as<int>(),
                        c->d_pf.as<unsigned char>(), c->d_kp.as<unsigned char>(), c->d_final_flag.as<unsigned char>());
     mark(9);
     TRY(launch_scan(c, c->d_final_flag.as<unsigned char>(), NPOS, &st->n_final));
@@ -1524,6 +1691,9 @@ int fseg_create(int device, fseg_ctx **out) {
     c->score_lds = (int)score_lds_bytes();
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_score), hipFuncAttributeMaxDynamicSharedMemorySize, c->score_lds);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_dp<kNMax>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)dp_lds_bytes<kNMax>());
     if (e != hipSuccess) {
         g_create_error = std::string("context creation failed: ") + hipGetErrorString(e);
         delete c;
@@ -1544,7 +1714,7 @@ void fseg_destroy(fseg_ctx *c) {
                       &c->d_flag, &c->d_idx, &c->d_v, &c->d_bsum, &c->d_g, &c->d_pk, &c->d_pf, &c->d_kp, &c->d_final_flag,
                       &c->d_voff, &c->d_chunk_off, &c->d_csum, &c->d_mean, &c->d_thr, &c->d_label_off, &c->d_cand_off,
                       &c->d_cand_y, &c->d_fixed0, &c->d_added, &c->d_fixed, &c->d_chosen, &c->d_final_off, &c->d_final_y,
-                      &c->d_final_pos, &c->d_col_thr, &c->d_col_zero, &c->d_seg_iv, &c->d_seg_prev, &c->d_prob_iv, &c->d_prob_start,
+                      &c->d_final_pos, &c->d_col_thr, &c->d_col_zero, &c->d_seg_iv, &c->d_seg_prev, &c->d_rseg_c, &c->d_cand_pn, &c->d_cand_ll, &c->d_cand_ln, &c->d_prob_bs, &c->d_prob_iv, &c->d_prob_start,
                       &c->d_prob_n, &c->d_prob_pair_off, &c->d_prob_tri_off, &c->d_prob_flags, &c->d_prob_chain, &c->d_prob_cov_off,
                       &c->d_prob_lane_lo, &c->d_prob_lane_n, &c->d_prob_work_base, &c->d_work_active, &c->d_cov,
                       &c->d_work_prob, &c->d_work_chunk, &c->d_pair_thr, &c->d_amb, &c->d_out, &c->d_labels, &c->d_status};
@@ -1698,7 +1868,9 @@ int fseg_upload(fseg_ctx *c, const fseg_batch *b) {
     TRY(ensure(c, c->d_cand_y, np8 * 4)); TRY(ensure(c, c->d_fixed0, np8)); TRY(ensure(c, c->d_added, np8));
     TRY(ensure(c, c->d_fixed, np8)); TRY(ensure(c, c->d_chosen, np8));
     TRY(ensure(c, c->d_final_y, np8 * 4)); TRY(ensure(c, c->d_final_pos, np8 * 4)); TRY(ensure(c, c->d_col_thr, np8 * 8)); TRY(ensure(c, c->d_col_zero, np8));
-    TRY(ensure(c, c->d_seg_iv, np8 * 4)); TRY(ensure(c, c->d_seg_prev, np8 * 4));
+    TRY(ensure(c, c->d_seg_iv, np8 * 4)); TRY(ensure(c, c->d_seg_prev, np8 * 4)); TRY(ensure(c, c->d_rseg_c, np8 * 4));
+    TRY(ensure(c, c->d_cand_pn, np8 * 4)); TRY(ensure(c, c->d_cand_ll, np8 * 4)); TRY(ensure(c, c->d_cand_ln, np8 * 4));
+    TRY(ensure(c, c->d_prob_bs, ((size_t)NPOS / kProbBlock + 2) * 5 * 8));
     // first-guess arena capacities; fseg_sync() grows them if the run reports an overflow
     auto atleast = [](i64 &cap, i64 v) { if (cap < v) cap = v; };
     atleast(c->chunk_cap, NPOS / 8192 + np + 8);
