@@ -973,6 +973,9 @@ __global__ void __launch_bounds__(256) k_dp(Status *st, int n_lo, u64 *queue, Pr
     unsigned char *A = reinterpret_cast<unsigned char *>(in_s + kPairs);
     __shared__ int cy_s[NM];
     __shared__ u64 work_s;
+    __shared__ i64 part_v[256];
+    __shared__ unsigned char part_a[256];
+    __shared__ int top_key[4];
     int lane = lane_id();
     i64 n_prob = (i64)st->n_prob < prob_cap ? (i64)st->n_prob : prob_cap;
     for (;;) {
@@ -997,62 +1000,70 @@ __global__ void __launch_bounds__(256) k_dp(Status *st, int n_lo, u64 *queue, Pr
             in_s[q] = -(int)((i64)amb_g[poff + q] + ((zamb && pair_thr[poff + q].y < 0) ? outside : 0));
         __syncthreads();
         const int end = n - 1;
-        if (threadIdx.x < 64) {          // the recurrence itself runs on one wave
+        const int wave = threadIdx.x >> 6;
 #define FSEG_IN(a, b) ((i64)in_s[(b) * ((b) - 1) / 2 + (a)])
 #define FSEG_M(a, b) M[(b) * ((b) - 1) / 2 + (a)]
-            for (int b = lane; b < end; b += 64) { FSEG_M(b, end) = FSEG_IN(b, end); A[end * (end - 1) / 2 + b] = 255; }
-            __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): LDS writes of this wave are visible to its later reads
-            for (int c = end - 1; c >= 2; --c) {
-                int b = 1 + lane;                          // lanes: b in [1, c)
-                if (b < c) {
-                    i64 best = kNegInf; int arg = 255;
-                    if (cy_s[c] - cy_s[b] >= 5) {
-                        i64 in_bc = FSEG_IN(b, c);
-                        int base = c * (c - 1) / 2 + b;
-                        const int cyc = cy_s[c];
-#pragma unroll 4
-                        for (int c2 = c + 1; c2 <= end; ++c2) {
-                            i64 tail = FSEG_M(c, c2);
-                            unsigned o = out_s[c2 * (c2 - 1) * (c2 - 2) / 6 + base];
-                            bool ok = (cy_s[c2] - cyc >= 5) & (tail != kNegInf) & ((i64)o >= (i64)support);   // :526-527, :540
-                            i64 cur = ok ? in_bc + (i64)o + tail : kNegInf;
-                            bool take = cur > best;
-                            best = take ? cur : best; arg = take ? c2 : arg;
-                        }
-                    }
-                    FSEG_M(b, c) = best; A[c * (c - 1) / 2 + b] = (unsigned char)arg;
-                }
-                __builtin_amdgcn_s_waitcnt(0xc07f);
-            }
-            // top level: a = start
-            i64 best = FSEG_IN(0, end);
-            int bj = -1, bk = -1;
-            for (int j = 1; j < end; ++j) {
-                if (cy_s[j] - cy_s[0] < 5) continue;
-                i64 in_0j = FSEG_IN(0, j);
-                for (int k0 = j + 1; k0 <= end; k0 += 64) {
-                    int kx = k0 + lane;
-                    i64 cur = kNegInf;
-                    if (kx <= end && cy_s[kx] - cy_s[j] >= 5) {
-                        i64 tail = FSEG_M(j, kx);
-                        unsigned o = out_s[kx * (kx - 1) * (kx - 2) / 6 + j * (j - 1) / 2 + 0];
-                        if (tail != kNegInf && (i64)o >= (i64)support) cur = in_0j + (i64)o + tail;
-                    }
-                    // first lane (smallest k) holding the wave maximum
-                    i64 mx = cur;
-                    for (int d = 32; d >= 1; d >>= 1) { i64 o2 = __shfl_xor(mx, d); mx = o2 > mx ? o2 : mx; }
-                    if (mx > best) {
-                        u64 m = __ballot(cur == mx);
-                        int bb = __ffsll((long long)m) - 1;
-                        best = mx; bj = j; bk = k0 + bb;
-                    }
+        for (int b = threadIdx.x; b < end; b += blockDim.x) { FSEG_M(b, end) = FSEG_IN(b, end); A[end * (end - 1) / 2 + b] = 255; }
+        __syncthreads();
+        // c descending; for a fixed c lane = b in [1, c) and the four waves split the c2 > c candidates
+        for (int c = end - 1; c >= 2; --c) {
+            int b = 1 + lane;
+            i64 best = kNegInf; int arg = 255;
+            if (b < c && cy_s[c] - cy_s[b] >= 5) {
+                i64 in_bc = FSEG_IN(b, c);
+                int base = c * (c - 1) / 2 + b;
+                const int cyc = cy_s[c];
+                for (int c2 = c + 1 + wave; c2 <= end; c2 += 4) {
+                    i64 tail = FSEG_M(c, c2);
+                    unsigned o = out_s[c2 * (c2 - 1) * (c2 - 2) / 6 + base];
+                    bool ok = (cy_s[c2] - cyc >= 5) & (tail != kNegInf) & ((i64)o >= (i64)support);   // :526-527, :540
+                    i64 cur = ok ? in_bc + (i64)o + tail : kNegInf;
+                    bool take = cur > best;
+                    best = take ? cur : best; arg = take ? c2 : arg;
                 }
             }
-            if (lane == 0) {
+            part_v[wave * 64 + lane] = best; part_a[wave * 64 + lane] = (unsigned char)arg;
+            __syncthreads();
+            if (wave == 0 && b < c) {
+                // first maximiser over all c2: larger value wins, equal values keep the smaller c2
+                i64 bv = part_v[lane]; int ba = part_a[lane];
+                for (int w = 1; w < 4; ++w) {
+                    i64 v = part_v[w * 64 + lane]; int a2 = part_a[w * 64 + lane];
+                    if (v > bv || (v == bv && v != kNegInf && a2 < ba)) { bv = v; ba = a2; }
+                }
+                FSEG_M(b, c) = bv; A[c * (c - 1) / 2 + b] = (unsigned char)ba;
+            }
+            __syncthreads();
+        }
+        // top level (a = start): max over (j,k) of in_0j + out_0jk + M(j,k), first maximiser in (j, k) order,
+        // taken only if strictly greater than "no cut" = in(0,end)   (:560-566)
+        {
+            i64 bv = kNegInf; int bkey = 0x7fffffff;
+            for (int q = threadIdx.x; q < npairs; q += blockDim.x) {
+                int j, kx;
+                pair_decode(q, &j, &kx);                    // j < kx
+                if (j < 1) continue;
+                if (cy_s[j] - cy_s[0] < 5 || cy_s[kx] - cy_s[j] < 5) continue;
+                i64 tail = FSEG_M(j, kx);
+                unsigned o = out_s[kx * (kx - 1) * (kx - 2) / 6 + j * (j - 1) / 2 + 0];
+                if (tail == kNegInf || (i64)o < (i64)support) continue;
+                i64 cur = FSEG_IN(0, j) + (i64)o + tail;
+                int key = j * 64 + kx;
+                if (cur > bv || (cur == bv && key < bkey)) { bv = cur; bkey = key; }
+            }
+            for (int d = 32; d >= 1; d >>= 1) {
+                i64 ov = __shfl_xor(bv, d); int ok2 = __shfl_xor(bkey, d);
+                if (ov > bv || (ov == bv && ok2 < bkey)) { bv = ov; bkey = ok2; }
+            }
+            if (lane == 0) { part_v[wave] = bv; top_key[wave] = bkey; }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                for (int w = 1; w < 4; ++w)
+                    if (part_v[w] > bv || (part_v[w] == bv && top_key[w] < bkey)) { bv = part_v[w]; bkey = top_key[w]; }
                 int chain = 0;
-                if (bj >= 0) {
+                if (bv != kNegInf && bv > FSEG_IN(0, end)) {
+                    int j = bkey >> 6, k = bkey & 63;
                     chosen[c0] = 1;
-                    int j = bj, k = bk;
                     for (;;) {
                         chosen[c0 + j] = 1; chosen[c0 + k] = 1; ++chain;
                         if (k == end) break;
@@ -1063,9 +1074,9 @@ __global__ void __launch_bounds__(256) k_dp(Status *st, int n_lo, u64 *queue, Pr
                 }
                 pr.chain[p] = chain;
             }
+        }
 #undef FSEG_IN
 #undef FSEG_M
-        }
     }
 }
 
@@ -1249,8 +1260,9 @@ __global__ void __launch_bounds__(256) k_label_plan(int n_part, const i64 *part_
 }
 // per final index f (= column): integer thresholds of the segment [final_f, final_f+1) and the label of
 // a read without coverage there; the last index of an interval is the sentinel column (hi = INT_MAX)
-__global__ void k_label_cols(i64 K, const i64 *final_off, const int *final_y, const double *h_table, int h_len,
-                             double tau, int2 *col_thr, unsigned char *col_zero) {
+__global__ void k_label_cols(i64 K, const i64 *final_off, const int *final_y, const int *iv_part,
+                             const double *h_table, int h_len, double tau, int2 *col_thr, unsigned char *col_zero,
+                             int *part_has2) {
     i64 F = final_off[K];
     for (i64 f = (i64)blockIdx.x * blockDim.x + threadIdx.x; f < F; f += (i64)gridDim.x * blockDim.x) {
         i64 k = last_le(final_off, K + 1, f);
@@ -1259,73 +1271,78 @@ __global__ void k_label_cols(i64 K, const i64 *final_off, const int *final_y, co
         label_thresholds((i64)final_y[f + 1] - final_y[f] + 1, h_table, h_len, tau, &hi, &lo);
         col_thr[f] = make_int2(hi, lo);
         col_zero[f] = lo >= 0 ? '0' : '2';
+        if (lo < 0) atomicOr(&part_has2[iv_part[k]], 1);
     }
 }
+// The label arena is pre-filled with '0' (the label of a read without coverage); only partitions in which a
+// zero-coverage read is ambiguous for some segment (lo < 0, i.e. threshold_rate == 1) need their default rows.
 __global__ void __launch_bounds__(256) k_label_fill(int n_part, const i64 *label_off, i64 label_cap,
                                                     const i64 *part_iv_off, const i64 *final_off,
-                                                    const unsigned char *col_zero, unsigned char *labels) {
-    i64 total = label_off[n_part];
-    if (total > label_cap) return;
-    i64 n16 = (total + 15) / 16;
-    for (i64 x16 = (i64)blockIdx.x * blockDim.x + threadIdx.x; x16 < n16; x16 += (i64)gridDim.x * blockDim.x) {
-        i64 x = x16 * 16;
-        int p = (int)last_le(label_off, (i64)n_part + 1, x);
-        while (label_off[p + 1] <= x) ++p;                  // skip partitions without label bytes
+                                                    const unsigned char *col_zero, const int *part_has2,
+                                                    unsigned char *labels) {
+    if (label_off[n_part] > label_cap) return;
+    for (int p = blockIdx.x; p < n_part; p += gridDim.x) {
+        if (!part_has2[p]) continue;
         i64 f0 = final_off[part_iv_off[p]];
         i64 S = final_off[part_iv_off[p + 1]] - f0 - 1;
-        i64 c = (x - label_off[p]) % S;
-        i64 pend = label_off[p + 1];
-        unsigned char buf[16];
-        int nb = (int)(total - x < 16 ? total - x : 16);
-        for (int q = 0; q < nb; ++q) {
-            if (x + q >= pend) {                              // next partition with label bytes
-                ++p;
-                while (label_off[p + 1] <= x + q) ++p;
-                f0 = final_off[part_iv_off[p]];
-                S = final_off[part_iv_off[p + 1]] - f0 - 1;
-                pend = label_off[p + 1];
-                c = 0;
-            }
-            buf[q] = col_zero[f0 + c];
-            if (++c == S) c = 0;
-        }
-        if (nb == 16) *reinterpret_cast<uint4 *>(labels + x) = *reinterpret_cast<uint4 *>(buf);
-        else for (int q = 0; q < nb; ++q) labels[x + q] = buf[q];
+        i64 x0 = label_off[p], x1 = label_off[p + 1];
+        for (i64 x = x0 + threadIdx.x; x < x1; x += blockDim.x) labels[x] = col_zero[f0 + (x - x0) % S];
     }
 }
-__global__ void __launch_bounds__(256) k_label_reads(int n_part, const i64 *label_off, i64 label_cap,
+// One workgroup per block of 256 read reps of one partition.  The partition's column table (segment
+// boundaries and integer thresholds) is staged in LDS when it fits; every thread then merges its rep's exon
+// list against the columns its exons can reach.
+constexpr int kLabelCols = 4096;
+__global__ void __launch_bounds__(256) k_label_reads(int n_blocks, const int *rb_part, const int *rb_r0,
+                                                     const i64 *label_off, i64 label_cap, int n_part,
                                                      const i64 *part_iv_off, const i64 *part_rep_off,
                                                      const i64 *final_off, const int *final_pos, const int2 *col_thr,
                                                      const i64 *rep_exon_off, const int *ex_ts, const int *ex_te,
                                                      unsigned char *labels) {
+    __shared__ int fp_s[kLabelCols + 1];
+    __shared__ int2 th_s[kLabelCols];
     if (label_off[n_part] > label_cap) return;
-    i64 n_rep = part_rep_off[n_part];
-    for (i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x; r < n_rep; r += (i64)gridDim.x * blockDim.x) {
-        int p = (int)last_le(part_rep_off, (i64)n_part + 1, r);
+    for (int blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+        int p = rb_part[blk];
         i64 f0 = final_off[part_iv_off[p]];
         i64 F = final_off[part_iv_off[p + 1]] - f0;
         i64 S = F - 1;
         if (S <= 0) continue;
         const int *fp = final_pos + f0;                      // ascending over the whole partition
+        const int2 *th = col_thr + f0;
+        __syncthreads();
+        if (S <= kLabelCols) {
+            for (int x = threadIdx.x; x <= S; x += blockDim.x) fp_s[x] = fp[x];
+            for (int x = threadIdx.x; x < S; x += blockDim.x) th_s[x] = th[x];
+            fp = fp_s; th = th_s;
+        }
+        __syncthreads();
+        i64 r = (i64)rb_r0[blk] + threadIdx.x;
+        if (r >= part_rep_off[p + 1]) continue;
         unsigned char *row = labels + label_off[p] + (r - part_rep_off[p]) * S;
         i64 e = rep_exon_off[r], e1 = rep_exon_off[r + 1];
         if (e >= e1) continue;
         int first_ts = ex_ts[e], last_te = ex_te[e1 - 1];
         // first column whose segment [fp[c], fp[c+1]) ends after first_ts
-        i64 lo = 0, hi = S;
-        while (lo < hi) { i64 mid = (lo + hi) >> 1; if (fp[mid + 1] <= first_ts) lo = mid + 1; else hi = mid; }
-        for (i64 c = lo; c < S && fp[c] <= last_te; ++c) {
-            int2 th = col_thr[f0 + c];
-            if (th.x == 0x7fffffff) continue;                 // sentinel column between two intervals
+        int lo = 0, hi = (int)S;
+        while (lo < hi) { int mid = (lo + hi) >> 1; if (fp[mid + 1] <= first_ts) lo = mid + 1; else hi = mid; }
+        int ts = ex_ts[e], te = ex_te[e];
+        for (int c = lo; c < S && fp[c] <= last_te; ++c) {
+            int2 t2 = th[c];
+            if (t2.x == 0x7fffffff) continue;                 // sentinel column between two intervals
             int g0 = fp[c], g1 = fp[c + 1];
-            while (e < e1 && ex_te[e] < g0) ++e;              // exons entirely before this segment
+            while (e < e1 && te < g0) { ++e; if (e < e1) { ts = ex_ts[e]; te = ex_te[e]; } }   // exons before the segment
             int cov = 0;
-            for (i64 x = e; x < e1 && ex_ts[x] < g1; ++x) {
-                int a = ex_ts[x] > g0 ? ex_ts[x] : g0;
-                int b = ex_te[x] + 1 < g1 ? ex_te[x] + 1 : g1;
-                if (b > a) cov += b - a;
+            if (e < e1 && ts < g1) {
+                int a = ts > g0 ? ts : g0, b2 = te + 1 < g1 ? te + 1 : g1;
+                if (b2 > a) cov += b2 - a;
+                for (i64 x = e + 1; x < e1 && ex_ts[x] < g1; ++x) {
+                    int a3 = ex_ts[x] > g0 ? ex_ts[x] : g0;
+                    int b3 = ex_te[x] + 1 < g1 ? ex_te[x] + 1 : g1;
+                    if (b3 > a3) cov += b3 - a3;
+                }
             }
-            row[c] = cov >= th.x ? '1' : (cov <= th.y ? '0' : '2');
+            row[c] = cov >= t2.x ? '1' : (cov <= t2.y ? '0' : '2');
         }
     }
 }
@@ -1366,7 +1383,8 @@ struct fseg_ctx {
     // device buffers: position-sized
     DevBuf d_y_raw, d_y, d_flag, d_idx, d_v, d_bsum, d_g, d_pk, d_pf, d_kp, d_final_flag;
     // partition-sized
-    DevBuf d_voff, d_chunk_off, d_csum, d_mean, d_thr, d_label_off;
+    DevBuf d_voff, d_chunk_off, d_csum, d_mean, d_thr, d_label_off, d_part_has2, d_rb_part, d_rb_r0;
+    int n_rep_blocks = 0;
     // candidate-sized
     DevBuf d_cand_off, d_cand_y, d_fixed0, d_added, d_fixed, d_chosen, d_final_off, d_final_y, d_final_pos, d_col_thr,
         d_col_zero;
@@ -1606,18 +1624,21 @@ int enqueue_run(fseg_ctx *c) {
     // S7
     hipLaunchKernelGGL(k_label_plan, dim3(1), dim3(256), 0, s, n_part, c->d_part_iv_off.as<i64>(),
                        c->d_part_rep_off.as<i64>(), c->d_final_off.as<i64>(), c->d_label_off.as<i64>(), st, c->label_cap);
+    HIP_TRY(c, hipMemsetAsync(c->d_part_has2.p, 0, (size_t)n_part * 4, s));
     hipLaunchKernelGGL(k_label_cols, dim3(grid_for(NPOS / 8 + 1, 256, 2048)), dim3(256), 0, s, K, c->d_final_off.as<i64>(),
-                       c->d_final_y.as<int>(), c->d_h_table.as<double>(), c->P.h_len, c->P.threshold_rate,
-                       c->d_col_thr.as<int2>(), c->d_col_zero.as<unsigned char>());
+                       c->d_final_y.as<int>(), c->d_iv_part.as<int>(), c->d_h_table.as<double>(), c->P.h_len,
+                       c->P.threshold_rate, c->d_col_thr.as<int2>(), c->d_col_zero.as<unsigned char>(),
+                       c->d_part_has2.as<int>());
     if (c->label_cap > 0) {
-        hipLaunchKernelGGL(k_label_fill, dim3(grid_for(c->label_cap / 16 + 1, 256, 8192)), dim3(256), 0, s, n_part,
-                           c->d_label_off.as<i64>(), c->label_cap, c->d_part_iv_off.as<i64>(), c->d_final_off.as<i64>(),
-                           c->d_col_zero.as<unsigned char>(), c->d_labels.as<unsigned char>());
-        hipLaunchKernelGGL(k_label_reads, dim3(grid_for(c->R, 256, 8192)), dim3(256), 0, s, n_part,
-                           c->d_label_off.as<i64>(), c->label_cap, c->d_part_iv_off.as<i64>(), c->d_part_rep_off.as<i64>(),
-                           c->d_final_off.as<i64>(), c->d_final_pos.as<int>(), c->d_col_thr.as<int2>(),
-                           c->d_rep_exon_off.as<i64>(), c->d_ex_ts.as<int>(), c->d_ex_te.as<int>(),
-                           c->d_labels.as<unsigned char>());
+        HIP_TRY(c, hipMemsetAsync(c->d_labels.p, '0', (size_t)c->label_cap, s));
+        hipLaunchKernelGGL(k_label_fill, dim3(grid_for(n_part, 1, 2048)), dim3(256), 0, s, n_part, c->d_label_off.as<i64>(),
+                           c->label_cap, c->d_part_iv_off.as<i64>(), c->d_final_off.as<i64>(),
+                           c->d_col_zero.as<unsigned char>(), c->d_part_has2.as<int>(), c->d_labels.as<unsigned char>());
+        hipLaunchKernelGGL(k_label_reads, dim3(grid_for(c->n_rep_blocks, 1, 16384)), dim3(256), 0, s, c->n_rep_blocks,
+                           c->d_rb_part.as<int>(), c->d_rb_r0.as<int>(), c->d_label_off.as<i64>(), c->label_cap, n_part,
+                           c->d_part_iv_off.as<i64>(), c->d_part_rep_off.as<i64>(), c->d_final_off.as<i64>(),
+                           c->d_final_pos.as<int>(), c->d_col_thr.as<int2>(), c->d_rep_exon_off.as<i64>(),
+                           c->d_ex_ts.as<int>(), c->d_ex_te.as<int>(), c->d_labels.as<unsigned char>());
     }
     mark(11);
     HIP_TRY(c, hipMemcpyAsync(c->h_status, st, sizeof(Status), hipMemcpyDeviceToHost, s));
@@ -1712,7 +1733,7 @@ void fseg_destroy(fseg_ctx *c) {
                       &c->d_iv_part, &c->d_rep_weight, &c->d_rep_exon_off, &c->d_ex_ts, &c->d_ex_te, &c->d_lane_rep, &c->d_lane_start, &c->d_lane_pmax,
                       &c->d_tile_iv, &c->d_tile_y0, &c->d_w_main, &c->d_w_refine, &c->d_h_table, &c->d_y_raw, &c->d_y,
                       &c->d_flag, &c->d_idx, &c->d_v, &c->d_bsum, &c->d_g, &c->d_pk, &c->d_pf, &c->d_kp, &c->d_final_flag,
-                      &c->d_voff, &c->d_chunk_off, &c->d_csum, &c->d_mean, &c->d_thr, &c->d_label_off, &c->d_cand_off,
+                      &c->d_voff, &c->d_chunk_off, &c->d_csum, &c->d_mean, &c->d_thr, &c->d_label_off, &c->d_part_has2, &c->d_rb_part, &c->d_rb_r0, &c->d_cand_off,
                       &c->d_cand_y, &c->d_fixed0, &c->d_added, &c->d_fixed, &c->d_chosen, &c->d_final_off, &c->d_final_y,
                       &c->d_final_pos, &c->d_col_thr, &c->d_col_zero, &c->d_seg_iv, &c->d_seg_prev, &c->d_rseg_c, &c->d_cand_pn, &c->d_cand_ll, &c->d_cand_ln, &c->d_prob_bs, &c->d_prob_iv, &c->d_prob_start,
                       &c->d_prob_n, &c->d_prob_pair_off, &c->d_prob_tri_off, &c->d_prob_flags, &c->d_prob_chain, &c->d_prob_cov_off,
@@ -1851,6 +1872,16 @@ int fseg_upload(fseg_ctx *c, const fseg_batch *b) {
     TRY(upload_vec(c, c->d_lane_rep, lane_rep.data(), lane_rep.size()));
     TRY(upload_vec(c, c->d_lane_start, lane_start.data(), lane_start.size()));
     TRY(upload_vec(c, c->d_lane_pmax, lane_pmax.data(), lane_pmax.size()));
+    {
+        std::vector<int> rb_part, rb_r0;     // blocks of 256 read reps of one partition (label kernel)
+        for (int p = 0; p < np; ++p)
+            for (i64 r = b->part_rep_off[p]; r < b->part_rep_off[p + 1]; r += 256) { rb_part.push_back(p); rb_r0.push_back((int)r); }
+        c->n_rep_blocks = (int)rb_part.size();
+        TRY(upload_vec(c, c->d_rb_part, rb_part.data(), rb_part.size()));
+        TRY(upload_vec(c, c->d_rb_r0, rb_r0.data(), rb_r0.size()));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    TRY(ensure(c, c->d_part_has2, ((size_t)np + 1) * 4));
     TRY(upload_vec(c, c->d_tile_iv, tile_iv.data(), tile_iv.size()));
     TRY(upload_vec(c, c->d_tile_y0, tile_y0.data(), tile_y0.size()));
     // position-sized work buffers
