@@ -1,0 +1,502 @@
+"""Host side of the segmentation stage: the same interface as the reference's ``py/freddie_segment.py``
+(CLI flags, ``split_*.tsv`` / ``reads_*.tsv`` in, ``segment_*.tsv`` out, and the in-process
+``segment(tint, ...)`` seam), with all of the numeric work done by the gfx950 library behind the C-ABI
+(``include/freddie_seg.h``).  There is no CPU implementation of the numeric path in this package.
+
+Reference map (file:line of vpc-ccg/freddie ``py/freddie_segment.py``):
+  parse_args :53-110 / main :847-885      -> parse_args(), main()
+  read_split :121-171, read_sequence :174-185 -> read_split(), read_sequence()
+  segment :738-844                        -> segment(), segment_batch()  (GPU)
+  get_unaligned_gaps_and_polyA :370-472   -> unaligned_gaps_and_polyA()  (host; per-read string work)
+  run_segment :681-735                    -> run_segment(), write_segment_tsv()
+"""
+import argparse
+import glob
+import multiprocessing
+import os
+import sys
+from math import ceil
+
+import numpy as np
+
+from . import pack, tables
+
+CIGAR_OPS = "MIDNSHPX="
+
+
+# --------------------------------------------------------------------------------------------------
+# arguments (same flags, defaults and range checks as the reference; --gpus / --batch-reads are additions)
+# --------------------------------------------------------------------------------------------------
+def str_to_bool(value):
+    if isinstance(value, bool):
+        return value
+    v = value.lower()
+    if v in ("false", "f", "0", "no", "n"):
+        return False
+    if v in ("true", "t", "1", "yes", "y"):
+        return True
+    raise ValueError("{} is not a valid boolean value".format(value))
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser(description="Cluster aligned reads into isoforms")
+    ap.add_argument("-s", "--split-dir", type=str, required=True, help="Path to Freddie split directory of the reads")
+    ap.add_argument("--consider-ends", type=str_to_bool, nargs="?", const=True, default=False,
+                    help="Consider the start and end splice sites in segmentation")
+    ap.add_argument("-o", "--outdir", type=str, default="freddie_segment/",
+                    help="Path to output directory. Default: freddie_segment/")
+    ap.add_argument("-t", "--threads", type=int, default=1,
+                    help="Host worker processes per GPU for parsing / writing. Default: 1")
+    ap.add_argument("-sd", "--sigma", type=float, default=5.0, help="Sigma value for gaussian_filter1d")
+    ap.add_argument("-tp", "--threshold-rate", type=float, default=0.90,
+                    help="Threshold rate above which the read will be considered as covering a segment. Default: 0.9")
+    ap.add_argument("-vf", "--variance-factor", type=float, default=3.0,
+                    help="The stdev factor to fix a candidate peak. Default 3.0")
+    ap.add_argument("-mps", "--max-problem-size", type=int, default=50,
+                    help="Maximum number of candidate breakpoints allowed per segmentation problem")
+    ap.add_argument("-lo", "--min-read-support-outside", type=int, default=3,
+                    help="Minimum reads support for splice site to support a breakpoint")
+    ap.add_argument("--gpus", type=int, default=0, help="Number of GPUs to scatter partitions over (0 = all visible)")
+    ap.add_argument("--batch-reads", type=int, default=250000, help="Reads per device batch")
+    args = ap.parse_args(argv)
+    assert 1 >= args.threshold_rate >= 0.5
+    assert 10 > args.variance_factor > 0
+    assert 50 >= args.sigma > 0
+    assert args.max_problem_size > 3
+    assert args.min_read_support_outside >= 0
+    assert args.threads > 0
+    return args
+
+
+# --------------------------------------------------------------------------------------------------
+# input files
+# --------------------------------------------------------------------------------------------------
+def _parse_cigar(text):
+    ops = []
+    num = 0
+    have = False
+    for ch in text:
+        if "0" <= ch <= "9":
+            num = num * 10 + (ord(ch) - 48)
+            have = True
+        else:
+            if not have or ch not in CIGAR_OPS:
+                raise ValueError("bad CIGAR %r" % text)
+            ops.append((num, ch))
+            num = 0
+            have = False
+    if have or not ops:
+        raise ValueError("bad CIGAR %r" % text)
+    return ops
+
+
+def _parse_read_interval(field):
+    try:
+        t, q, cig = field.split(":")
+        ts, te = t.split("-")
+        qs, qe = q.split("-")
+        return int(ts), int(te), int(qs), int(qe), _parse_cigar(cig)
+    except ValueError as exc:
+        raise ValueError("bad read interval field %r" % field) from exc
+
+
+def read_split(split_tsv):
+    """One ``split_<contig>_<tint>.tsv`` -> list of tint dicts (the reference asserts there is exactly one)."""
+    tints = {}
+    with open(split_tsv) as f:
+        for line in f:
+            if not line.endswith("\n"):
+                raise ValueError("%s: line without newline" % split_tsv)
+            cols = line[:-1].split("\t")
+            if line[0] == "#":
+                if len(cols) != 4:
+                    raise ValueError("%s: bad header line" % split_tsv)
+                intervals = []
+                for piece in cols[2].split(","):
+                    s, e = piece.split("-")
+                    intervals.append((int(s), int(e)))
+                tint = dict(id=int(cols[1]), chr=cols[0][1:], intervals=intervals, read_count=int(cols[3]),
+                            reads=[], read_reps={})
+                assert tint["id"] not in tints, "Transcriptional interval with id {} is repeated!".format(tint["id"])
+                assert all(a[1] < b[0] for a, b in zip(intervals[:-1], intervals[1:])), intervals
+                assert all(s < e for s, e in intervals)
+                tints[tint["id"]] = tint
+            else:
+                if len(cols) < 6 or cols[3] not in ("+", "-"):
+                    raise ValueError("%s: bad read line" % split_tsv)
+                read = dict(id=int(cols[0]), name=cols[1], chr=cols[2], strand=cols[3], tint=int(cols[4]),
+                            intervals=[_parse_read_interval(x) for x in cols[5:]])
+                iv = read["intervals"]
+                assert all(a[1] <= b[0] and a[3] <= b[2] for a, b in zip(iv[:-1], iv[1:]))
+                assert all(x[0] < x[1] and x[2] < x[3] for x in iv)
+                tints[read["tint"]]["reads"].append(read)
+    for tint in tints.values():
+        assert len(tint["reads"]) == tint["read_count"]
+        reps = {}
+        for ridx, read in enumerate(tint["reads"]):
+            reps.setdefault(tuple((x[0], x[1]) for x in read["intervals"]), []).append(ridx)
+        tint["read_reps"] = list(reps.items())
+    return list(tints.values())
+
+
+def read_sequence(tint, reads_tsv):
+    seqs = {}
+    with open(reads_tsv) as f:
+        for line in f:
+            cols = line.rstrip().split("\t")
+            seqs[int(cols[0])] = cols[3]
+    assert len(seqs) == len(tint["reads"]), tint["id"]
+    for read in tint["reads"]:
+        read["seq"] = seqs[read["id"]]
+        read["length"] = len(read["seq"])
+
+
+# --------------------------------------------------------------------------------------------------
+# per-read string work (host): soft clips, poly-A/T tails and unaligned gaps between label-1 runs
+# --------------------------------------------------------------------------------------------------
+_COMPLEMENT = {"A": "T", "C": "G", "G": "C", "T": "A"}
+
+
+def _thread_cigar(cigar, t_goal, t_pos, q_pos):
+    """Query position reached when the target position advances from t_pos to t_goal (:289-304).
+    The step of every op, insertions included, is clipped to the remaining target distance."""
+    assert t_pos <= t_goal
+    idx = 0
+    while t_pos < t_goal:
+        length, op = cigar[idx]
+        step = min(length, t_goal - t_pos)
+        if op in "MX=":
+            t_pos += step
+            q_pos += step
+        elif op == "D":
+            t_pos += step
+        elif op == "I":
+            q_pos += step
+        idx += 1
+    assert t_pos == t_goal
+    return q_pos
+
+
+def _query_at_or_after(start, read):
+    """First query position aligned at or after target ``start`` (+ non-positive slack) (:307-326)."""
+    for t_start, t_end, q_start, q_end, cigar in read["intervals"]:
+        if t_end < start:
+            continue
+        if start < t_start:
+            q_pos, slack = q_start, start - t_start
+        else:
+            q_pos, slack = _thread_cigar(cigar, start, t_start, q_start), 0
+        assert slack <= 0 and q_start <= q_pos <= q_end
+        return q_pos, slack
+    raise AssertionError("no exon at or after %d" % start)
+
+
+def _query_at_or_before(end, read):
+    """Last query position aligned at or before target ``end`` (+ non-positive slack) (:329-349)."""
+    for t_start, t_end, q_start, q_end, cigar in reversed(read["intervals"]):
+        if t_start > end:
+            continue
+        if t_end < end:
+            q_pos, slack = q_end, t_end - end
+        else:
+            q_pos, slack = _thread_cigar(cigar, end, t_start, q_start), 0
+        assert slack <= 0 and 0 <= q_pos <= q_end
+        return q_pos, slack
+    raise AssertionError("no exon at or before %d" % end)
+
+
+def _poly_runs(seq, s, e, step, char):
+    """Local-alignment runs (+1 match, -2 mismatch, floor 0) of ``char`` over seq[s:e:step] (:352-367).
+    Yields (first index, length up to the best score, purity)."""
+    if e - s == 0:
+        return
+    window = seq[s:e:step]
+    score = 1 if seq[s] == char else 0
+    scores = [score]
+    for c in seq[s + step:e:step]:
+        score = max(0, score + (1 if c == char else -2))
+        scores.append(score)
+    i, n = 0, len(scores)
+    while i < n:
+        if scores[i] <= 0:
+            i += 1
+            continue
+        j = i
+        best_s, best_i = scores[i], i
+        while j < n and scores[j] > 0:
+            if scores[j] >= best_s:              # max over (score, index): later index wins ties
+                best_s, best_i = scores[j], j
+            j += 1
+        length = best_i + 1 - i
+        yield i, length, window[i:i + length].count(char) / length
+        i = j
+
+
+def unaligned_gaps_and_polyA(read, segs):
+    """Sets read['gaps'] from read['data'] (labels), the read's alignment and sequence (:370-472)."""
+    read["gaps"] = set()
+    data = read["data"]
+    if 1 not in data:
+        return
+    runs = []
+    i, n = 0, len(data)
+    while i < n:
+        if data[i] != 1:
+            i += 1
+            continue
+        j = i
+        while j + 1 < n and data[j + 1] == 1:
+            j += 1
+        runs.append((i, j))
+        i = j + 1
+    q_ssc, _ = _query_at_or_after(segs[runs[0][0]][0], read)
+    q_esc, _ = _query_at_or_before(segs[runs[-1][1]][1], read)
+    length = read["length"]
+    assert 0 <= q_ssc <= q_esc <= length
+    minus = read["strand"] == "-"
+    gaps = read["gaps"]
+
+    def scan(s, e):
+        found = []
+        for char in ("A", "T"):
+            if minus:
+                runs_ = _poly_runs(read["seq"], -s - 1, -e - 1, -1, _COMPLEMENT[char])
+            else:
+                runs_ = _poly_runs(read["seq"], s, e, 1, char)
+            for first, ln, purity in runs_:
+                if ln >= 20 and purity >= 0.85:
+                    found.append((first, ln, purity, char))
+        best = None
+        for cand in found:                       # max purity, first one wins ties
+            if best is None or cand[2] > best[2]:
+                best = cand
+        return best
+
+    best = scan(0, q_ssc)
+    if best is not None:
+        first, ln, _, char = best
+        assert 0 <= first < q_ssc
+        gap = q_ssc - first - ln
+        assert 0 <= gap < q_ssc
+        gaps.add("S{}_{}:{}".format(char, ln, gap))
+        gaps.add("SSC:{}".format(first))
+    else:
+        gaps.add("SSC:{}".format(q_ssc))
+    best = scan(q_esc, length)
+    if best is not None:
+        first, ln, _, char = best
+        assert 0 <= first < length - q_esc
+        gaps.add("E{}_{}:{}".format(char, ln, first))
+        gaps.add("ESC:{}".format(length - q_esc - first))
+        assert length - q_esc - first > 0
+    else:
+        gaps.add("ESC:{}".format(length - q_esc))
+    for (_, last1), (first2, _) in zip(runs[:-1], runs[1:]):
+        q_a, slack_a = _query_at_or_before(segs[last1][1], read)
+        q_b, slack_b = _query_at_or_after(segs[first2][0], read)
+        assert 0 < q_a <= q_b < length
+        size = max(0, q_b - q_a + slack_a + slack_b)
+        assert 0 <= size < length and last1 < first2
+        gaps.add("{}-{}:{}".format(last1, first2, size))
+    read["gaps"] = sorted(gaps)
+
+
+# --------------------------------------------------------------------------------------------------
+# the numeric path (GPU)
+# --------------------------------------------------------------------------------------------------
+def pack_tint(tint):
+    """tint dict -> flat arrays (pack.PackedPartition) in the reference's read_reps order."""
+    iv = np.asarray(tint["intervals"], dtype=np.int32).reshape(-1, 2)
+    reps = tint["read_reps"]
+    off = np.zeros(len(reps) + 1, np.int64)
+    np.cumsum([len(k) for k, _ in reps], out=off[1:])
+    flat = np.asarray([x for k, _ in reps for x in k], dtype=np.int32).reshape(-1, 2)
+    read_rep = np.empty(len(tint["reads"]), np.int32)
+    for ri, (_, ridxs) in enumerate(reps):
+        read_rep[ridxs] = ri
+    return pack.PackedPartition(np.ascontiguousarray(iv[:, 0]), np.ascontiguousarray(iv[:, 1]),
+                                np.asarray([len(r) for _, r in reps], np.int32), off,
+                                np.ascontiguousarray(flat[:, 0]), np.ascontiguousarray(flat[:, 1]), read_rep)
+
+
+_default_ctx = {}
+
+
+def default_context(device=0):
+    from . import _lib
+    if device not in _default_ctx:
+        _default_ctx[device] = _lib.Context(device)
+    return _default_ctx[device]
+
+
+def segment_batch(tints, sigma, smoothed_threshold, threshold_rate, variance_factor, max_problem_size,
+                  min_read_support_outside, ignore_ends, ctx=None, gaps=True):
+    """segment() over a batch of tints in one device pass.  Mutates every tint like the reference's segment():
+    tint['final_positions'], tint['segs'], read['data'], read['gaps']."""
+    ctx = ctx or default_context()
+    parts = [pack_tint(t) for t in tints]
+    ctx.set_params(sigma, threshold_rate, variance_factor, max_problem_size, min_read_support_outside, ignore_ends,
+                   tables.gaussian_half_kernel(sigma, 4.0), tables.gaussian_half_kernel(sigma, 1.0),
+                   np.asarray(smoothed_threshold, np.float64))
+    ctx.upload(**pack.concat_batch(parts))
+    ctx.run()
+    part_final_off, final_pos, label_off, labels = ctx.download()
+    for p, (tint, part) in enumerate(zip(tints, parts)):
+        fp = final_pos[part_final_off[p]:part_final_off[p + 1]]
+        tint["final_positions"] = fp.tolist()
+        tint["segs"] = list(zip(tint["final_positions"][:-1], tint["final_positions"][1:]))
+        S = len(fp) - 1
+        lab = (labels[label_off[p]:label_off[p + 1]].reshape(part.n_reps, S) - 48).astype(np.uint8)
+        rows = [row.tolist() for row in lab]
+        for ri, (_, ridxs) in enumerate(tint["read_reps"]):
+            for ridx in ridxs:
+                tint["reads"][ridx]["data"] = list(rows[ri])
+        if gaps:
+            for read in tint["reads"]:
+                unaligned_gaps_and_polyA(read, tint["segs"])
+    return [t["id"] for t in tints]
+
+
+def segment(tint, sigma, smoothed_threshold, threshold_rate, variance_factor, max_problem_size,
+            min_read_support_outside, ignore_ends, ctx=None):
+    """Same signature and effects as the reference's segment() (:738-844)."""
+    return segment_batch([tint], sigma, smoothed_threshold, threshold_rate, variance_factor, max_problem_size,
+                         min_read_support_outside, ignore_ends, ctx=ctx)[0]
+
+
+# --------------------------------------------------------------------------------------------------
+# output + driver
+# --------------------------------------------------------------------------------------------------
+def write_segment_tsv(tint, path):
+    with open(path, "w+") as out:
+        out.write("#{}\t{}\t{}\n".format(tint["chr"], tint["id"], ",".join(map(str, tint["final_positions"]))))
+        for read in tint["reads"]:
+            out.write("\t".join((str(read["id"]), read["name"], read["chr"], read["strand"], str(read["tint"]),
+                                 "".join(map(str, read["data"])), "".join(g + "," for g in read["gaps"]))))
+            out.write("\n")
+
+
+def _load_partition(split_dir, contig, tint_id):
+    tints = read_split("{}/{}/split_{}_{}.tsv".format(split_dir, contig, contig, tint_id))
+    assert len(tints) == 1
+    read_sequence(tints[0], "{}/{}/reads_{}_{}.tsv".format(split_dir, contig, contig, tint_id))
+    return tints[0]
+
+
+def run_segment_batch(jobs, params, ctx):
+    """jobs: list of (split_dir, outdir, contig, tint_id).  Parses, segments on the GPU and writes the outputs."""
+    tints = []
+    for split_dir, outdir, contig, tint_id in jobs:
+        open("{}/{}/segment_{}_{}.log".format(outdir, contig, contig, tint_id), "w+").close()   # :695 (empty log)
+        tints.append(_load_partition(split_dir, contig, tint_id))
+    segment_batch(tints, *params, ctx=ctx)
+    for (split_dir, outdir, contig, tint_id), tint in zip(jobs, tints):
+        write_segment_tsv(tint, "{}/{}/segment_{}_{}.tsv".format(outdir, contig, contig, tint_id))
+    return [(j[2], j[3]) for j in jobs]
+
+
+def run_segment(segment_args, ctx=None):
+    """Reference-shaped entry: one 11-tuple as built by the reference's main() (:858-870)."""
+    (split_dir, outdir, contig, tint_id, sigma, smoothed_threshold, threshold_rate, variance_factor,
+     max_problem_size, min_read_support_outside, ignore_ends) = segment_args
+    params = (sigma, smoothed_threshold, threshold_rate, variance_factor, max_problem_size,
+              min_read_support_outside, ignore_ends)
+    return run_segment_batch([(split_dir, outdir, contig, tint_id)], params, ctx or default_context())[0]
+
+
+def discover(split_dir, outdir):
+    """(contig, tint_id, cost) of every partition, creating the output directories (:852-857)."""
+    found = []
+    for contig in os.listdir(split_dir):
+        if not os.path.isdir("{}/{}".format(split_dir, contig)):
+            continue
+        os.makedirs("{}/{}".format(outdir, contig), exist_ok=True)
+        for path in glob.iglob("{}/{}/split_*.tsv".format(split_dir, contig)):
+            tint_id = int(path[:-4].split("/")[-1].split("_")[-1])
+            found.append((contig, tint_id, os.path.getsize(path)))
+    return found
+
+
+def make_batches(jobs_with_cost, bytes_per_batch):
+    batches, cur, size = [], [], 0
+    for job, cost in jobs_with_cost:
+        if cur and size + cost > bytes_per_batch:
+            batches.append(cur)
+            cur, size = [], 0
+        cur.append(job)
+        size += cost
+    if cur:
+        batches.append(cur)
+    return batches
+
+
+def _gpu_worker(device, jobs_with_cost, params, batch_bytes, queue):
+    from . import _lib
+    ctx = _lib.Context(device)
+    try:
+        for batch in make_batches(jobs_with_cost, batch_bytes):
+            for done in run_segment_batch(batch, params, ctx):
+                queue.put(done)
+    finally:
+        ctx.close()
+        queue.put(None)
+
+
+def main(argv=None):
+    from . import scatter
+    args = parse_args(argv)
+    split_dir = args.split_dir.rstrip("/")
+    parts = discover(split_dir, args.outdir)
+    params = (args.sigma, tables.smooth_threshold(args.threshold_rate), args.threshold_rate, args.variance_factor,
+              args.max_problem_size, args.min_read_support_outside, not args.consider_ends)
+    n_gpus = args.gpus
+    if n_gpus <= 0:
+        import torch
+        n_gpus = torch.cuda.device_count()
+    if n_gpus <= 0:
+        raise SystemExit("freddie_segment: no GPU visible (this implementation has no CPU path)")
+    costs = [c for _, _, c in parts]
+    assign = scatter.lpt_scatter(costs, n_gpus)
+    batch_bytes = max(1, args.batch_reads) * 1400          # ~1.4 KB of split TSV per read
+    total = len(parts)
+    step = ceil(total / 100) if total else 1
+    done_count = 0
+
+    def report():
+        nonlocal done_count
+        if done_count % step == 0:
+            print("[freddie_segment] Done with {}/{} tints ({:.1%})".format(done_count, total, done_count / total))
+        done_count += 1
+
+    if n_gpus == 1:
+        from . import _lib
+        ctx = _lib.Context(0)
+        jobs = [((split_dir, args.outdir, parts[i][0], parts[i][1]), parts[i][2]) for i in assign[0]]
+        for batch in make_batches(jobs, batch_bytes):
+            for _ in run_segment_batch(batch, params, ctx):
+                report()
+        ctx.close()
+        return
+    mp = multiprocessing.get_context("spawn")
+    queue = mp.Queue()
+    procs = []
+    for dev in range(n_gpus):
+        jobs = [((split_dir, args.outdir, parts[i][0], parts[i][1]), parts[i][2]) for i in assign[dev]]
+        pr = mp.Process(target=_gpu_worker, args=(dev, jobs, params, batch_bytes, queue))
+        pr.start()
+        procs.append(pr)
+    alive = n_gpus
+    while alive:
+        item = queue.get()
+        if item is None:
+            alive -= 1
+        else:
+            report()
+    for pr in procs:
+        pr.join()
+        if pr.exitcode != 0:
+            raise SystemExit("a GPU worker failed with exit code %s" % pr.exitcode)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,55 @@
+"""End to end on the GPU box: the drop-in CLI on split directories, output bytes vs the reference's own
+segment_*.tsv (golden fixtures)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+import goldens
+from test_host_mirror import NAMES, input_dir
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_cli(split_dir, out_dir, run):
+    cmd = [sys.executable, os.path.join(ROOT, "py", "freddie_segment.py"), "-s", split_dir, "-o", out_dir, "--gpus", "1",
+           "-sd", str(run["sigma"]), "-tp", str(run["threshold_rate"]), "-vf", str(run["variance_factor"]),
+           "-mps", str(run["max_problem_size"]), "-lo", str(run["min_read_support_outside"])]
+    if run["consider_ends"]:
+        cmd.append("--consider-ends")
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr[-2000:]
+    return res.stdout
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_cli_output_is_byte_identical_to_reference(name, tmp_path):
+    g = goldens.load(name)
+    case = goldens.manifest()["cases"][name]
+    d, contig, tid = input_dir(name, tmp_path)
+    out = str(tmp_path / "out")
+    stdout = run_cli(d, out, case["run"])
+    assert "[freddie_segment] Done with 0/1 tints (0.0%)" in stdout
+    got = open(os.path.join(out, contig, "segment_%s_%d.tsv" % (contig, tid)), "rb").read()
+    assert got == g["segment_tsv"].tobytes()
+    assert os.path.exists(os.path.join(out, contig, "segment_%s_%d.log" % (contig, tid)))
+
+
+def test_cli_many_partitions_in_batches(tmp_path):
+    """Several partitions through the batched driver give the same files as one by one."""
+    from freddie_amd import synth
+    d = str(tmp_path / "in")
+    for i in range(6):
+        synth.generate(100 + i, n_reads=120 + 10 * i, n_exons=40, rp=0.1, write_dir=d)
+    run = dict(sigma=5.0, threshold_rate=0.9, variance_factor=3.0, max_problem_size=50, min_read_support_outside=3,
+               consider_ends=False)
+    run_cli(d, str(tmp_path / "all"), run)
+    for i in range(6):
+        one = str(tmp_path / ("in%d" % i))
+        synth.generate(100 + i, n_reads=120 + 10 * i, n_exons=40, rp=0.1, write_dir=one)
+        run_cli(one, str(tmp_path / ("out%d" % i)), run)
+        a = open(os.path.join(str(tmp_path / "all"), "chrS", "segment_chrS_%d.tsv" % (100 + i)), "rb").read()
+        b = open(os.path.join(str(tmp_path / ("out%d" % i)), "chrS", "segment_chrS_%d.tsv" % (100 + i)), "rb").read()
+        assert a == b and len(a) > 0
