@@ -836,12 +836,21 @@ constexpr int kMaxPairs = kNMax * (kNMax - 1) / 2;
 constexpr int kPairSlots = (kMaxPairs + kScoreThreads - 1) / kScoreThreads;
 constexpr int kCovStride = kNMax + 1;   // odd: read-major rows do not collide on LDS banks
 
+#ifdef FSEG_SCORE_TIMING
+#define FSEG_TPARAM , unsigned long long *tacc
+#define FSEG_T0 unsigned long long t_prev = wall_clock64()
+#define FSEG_TICK(i) do { unsigned long long t_now = wall_clock64(); if (threadIdx.x == 0) atomicAdd(&tacc[i], t_now - t_prev); t_prev = t_now; } while (0)
+#else
+#define FSEG_TPARAM
+#define FSEG_T0
+#define FSEG_TICK(i)
+#endif
 __global__ void __launch_bounds__(kScoreThreads) k_score(Status *st, ProblemArrays pr, i64 prob_cap,
                                                          const int *work_prob, const int *work_chunk, i64 work_cap,
                                                          const i64 *cand_off, const int *cand_y,
                                                          const unsigned char *work_active, const unsigned *cov_g,
                                                          i64 cov_cap, const int2 *pair_thr, i64 pair_cap,
-                                                         unsigned *out_g, i64 tri_cap, unsigned *amb_g) {
+                                                         unsigned *out_g, i64 tri_cap, unsigned *amb_g FSEG_TPARAM) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ int cy_s[kNMax + 4];
     __shared__ u64 work_s;
@@ -852,11 +861,13 @@ __global__ void __launch_bounds__(kScoreThreads) k_score(Status *st, ProblemArra
     unsigned short *out16 = pair_ij + ((kMaxPairs + 7) & ~7);                          // C(kNMax,3) * 2 B
 
     i64 n_work = (i64)st->n_work < work_cap ? (i64)st->n_work : work_cap;
+    FSEG_T0;
     for (;;) {
         __syncthreads();
         if (threadIdx.x == 0) work_s = atomicAdd(&st->work_queue, 1ULL);
         __syncthreads();
         i64 w = (i64)work_s;
+        FSEG_TICK(0);
         if (w >= n_work) break;
         int p = work_prob[w];
         int chunk = work_chunk[w];
@@ -882,6 +893,7 @@ __global__ void __launch_bounds__(kScoreThreads) k_score(Status *st, ProblemArra
 #pragma unroll
         for (int s = 0; s < kPairSlots; ++s) amb_acc[s] = 0;
         __syncthreads();
+        FSEG_TICK(1);
         for (int sub = 0; sub < kLaneChunk / kSub; ++sub) {
             if (!((active >> sub) & 1u)) continue;
             int n_valid = lanes_here - sub * kSub;
@@ -893,6 +905,7 @@ __global__ void __launch_bounds__(kScoreThreads) k_score(Status *st, ProblemArra
                 cov[r * kCovStride + j] = cov_g[coff + (i64)j * kLaneChunk + sub * kSub + r];
             }
             __syncthreads();
+            FSEG_TICK(2);
             // ---- B: pair planes ---------------------------------------------------------------------
             unsigned valid0 = n_valid >= 32 ? 0xffffffffu : ((1u << n_valid) - 1u);
             unsigned valid1 = n_valid >= 64 ? 0xffffffffu : (n_valid > 32 ? ((1u << (n_valid - 32)) - 1u) : 0u);
@@ -918,6 +931,7 @@ __global__ void __launch_bounds__(kScoreThreads) k_score(Status *st, ProblemArra
                 }
             }
             __syncthreads();
+            FSEG_TICK(3);
             // ---- C: triples ---------------------------------------------------------------------------
             for (int q = threadIdx.x; q < npairs; q += blockDim.x) {
                 int j = pair_ij[q] & 255, kk = pair_ij[q] >> 8;       // B pair = (j, k)
@@ -934,6 +948,7 @@ __global__ void __launch_bounds__(kScoreThreads) k_score(Status *st, ProblemArra
                 }
             }
             __syncthreads();
+            FSEG_TICK(4);
         }
         // ---- flush ---------------------------------------------------------------------------------
         for (int x = threadIdx.x; x < ntri; x += blockDim.x) {
@@ -945,6 +960,7 @@ __global__ void __launch_bounds__(kScoreThreads) k_score(Status *st, ProblemArra
             int q = s * kScoreThreads + threadIdx.x;
             if (q < npairs && amb_acc[s]) atomicAdd(&amb_g[poff + q], amb_acc[s]);
         }
+        FSEG_TICK(5);
     }
 }
 
@@ -1394,7 +1410,7 @@ struct fseg_ctx {
         d_prob_cov_off, d_prob_lane_lo, d_prob_lane_n, d_prob_work_base;
     DevBuf d_work_prob, d_work_chunk, d_work_active, d_pair_thr, d_amb, d_out, d_cov, d_labels;
     i64 prob_cap = 0, work_cap = 0, pair_cap = 0, tri_cap = 0, label_cap = 0, chunk_cap = 0, cov_cap = 0;
-    DevBuf d_status;
+    DevBuf d_status, d_tacc;
     Status *h_status = nullptr;   // pinned
     bool profiling = false;
     hipEvent_t ev[ST_COUNT + 1] = {};
@@ -1587,7 +1603,11 @@ int enqueue_run(fseg_ctx *c) {
                            c->prob_cap, c->d_work_prob.as<int>(), c->d_work_chunk.as<int>(), c->work_cap,
                            c->d_cand_off.as<i64>(), c->d_cand_y.as<int>(), c->d_work_active.as<unsigned char>(),
                            c->d_cov.as<unsigned>(), c->cov_cap, c->d_pair_thr.as<int2>(), c->pair_cap,
-                           c->d_out.as<unsigned>(), c->tri_cap, c->d_amb.as<unsigned>());
+                           c->d_out.as<unsigned>(), c->tri_cap, c->d_amb.as<unsigned>()
+#ifdef FSEG_SCORE_TIMING
+                           , c->d_tacc.as<unsigned long long>()
+#endif
+                           );
     }
     mark(7);
     if (c->prob_cap > 0) {
@@ -1738,7 +1758,7 @@ void fseg_destroy(fseg_ctx *c) {
                       &c->d_final_pos, &c->d_col_thr, &c->d_col_zero, &c->d_seg_iv, &c->d_seg_prev, &c->d_rseg_c, &c->d_cand_pn, &c->d_cand_ll, &c->d_cand_ln, &c->d_prob_bs, &c->d_prob_iv, &c->d_prob_start,
                       &c->d_prob_n, &c->d_prob_pair_off, &c->d_prob_tri_off, &c->d_prob_flags, &c->d_prob_chain, &c->d_prob_cov_off,
                       &c->d_prob_lane_lo, &c->d_prob_lane_n, &c->d_prob_work_base, &c->d_work_active, &c->d_cov,
-                      &c->d_work_prob, &c->d_work_chunk, &c->d_pair_thr, &c->d_amb, &c->d_out, &c->d_labels, &c->d_status};
+                      &c->d_work_prob, &c->d_work_chunk, &c->d_pair_thr, &c->d_amb, &c->d_out, &c->d_labels, &c->d_status, &c->d_tacc};
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
     if (c->h_status) (void)hipHostFree(c->h_status);
     for (int i = 0; i <= ST_COUNT; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -1908,6 +1928,8 @@ int fseg_upload(fseg_ctx *c, const fseg_batch *b) {
     atleast(c->prob_cap, 1024); atleast(c->work_cap, 1024); atleast(c->pair_cap, 1 << 16); atleast(c->tri_cap, 1 << 18);
     atleast(c->label_cap, 1 << 16); atleast(c->cov_cap, 1 << 18);
     TRY(alloc_arenas(c));
+    TRY(ensure(c, c->d_tacc, 64));
+    HIP_TRY(c, hipMemsetAsync(c->d_tacc.p, 0, 64, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->have_batch = true; c->ran = false; c->pending = false;
     return FSEG_OK;
@@ -2013,6 +2035,15 @@ int fseg_stage_ms(fseg_ctx *c, float *ms) {
     for (int i = 0; i < ST_COUNT; ++i) ms[i] = c->stage_ms[i];
     return FSEG_OK;
 }
+
+#ifdef FSEG_SCORE_TIMING
+int fseg_debug_score_timing(fseg_ctx *c, unsigned long long *out8) {
+    if (!c || !out8 || !c->d_tacc.p) return FSEG_ERR_ARG;
+    if (hipMemcpy(out8, c->d_tacc.p, 64, hipMemcpyDeviceToHost) != hipSuccess) return FSEG_ERR_HIP;
+    (void)hipMemset(c->d_tacc.p, 0, 64);
+    return FSEG_OK;
+}
+#endif
 
 int64_t fseg_scoring_algorithmic_bytes(fseg_ctx *c) {
     if (!c || !c->ran) return -1;
