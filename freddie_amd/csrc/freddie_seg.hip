@@ -66,7 +66,8 @@ struct Status {
     u64 n_final;
     u64 label_bytes;
     u64 cov_used;      // elements of the coverage arena
-    u64 work_queue;    // dynamic work counter of the scoring kernel
+    u64 cls_work[3];   // work items per problem-size class (n <= 16, <= 32, <= kNMax)
+    u64 cls_queue[3];  // dynamic work counters of the scoring kernels
     u64 dp_queue;
     u64 dp_queue2;
     u64 cov_queue;
@@ -594,13 +595,18 @@ __global__ void k_prob_range(const Status *st, const int *cand_pn, const int *ca
 
 // Problem list by a prefix sum over the candidates: problem slot, pair / triple / coverage arena offsets and
 // work items come out in candidate order, so the arena layout is deterministic.
-struct ProbSizes { i64 v[5]; };   // slot, pairs, triples, work items, coverage elements
+constexpr int kProbCols = 8;      // slot, pairs, triples, work items, coverage elements, work items of class 0/1/2
+constexpr int kClsSmall = 16, kClsMid = 32;
+struct ProbSizes { i64 v[kProbCols]; };
+__device__ __forceinline__ int size_class(int n) { return n <= kClsSmall ? 0 : (n <= kClsMid ? 1 : 2); }
 __device__ __forceinline__ ProbSizes prob_sizes(int n, int n_lanes) {
     ProbSizes s;
-    if (n <= 0) { for (int q = 0; q < 5; ++q) s.v[q] = 0; return s; }
+    for (int q = 0; q < kProbCols; ++q) s.v[q] = 0;
+    if (n <= 0) return s;
     i64 chunks = (n_lanes + kLaneChunk - 1) / kLaneChunk;
     s.v[0] = 1; s.v[1] = (i64)n * (n - 1) / 2; s.v[2] = (i64)n * (n - 1) * (n - 2) / 6; s.v[3] = chunks;
     s.v[4] = chunks * kLaneChunk * n;
+    s.v[5 + size_class(n)] = chunks;
     return s;
 }
 __device__ __forceinline__ i64 wg_exclusive_scan64(i64 v, i64 *lds /* >= 16 */, i64 *total) {
@@ -629,31 +635,31 @@ __global__ void __launch_bounds__(256) k_prob_scan1(const Status *st, const int 
     i64 nb = (n + kProbBlock - 1) / kProbBlock;
     for (i64 b = blockIdx.x; b < nb; b += gridDim.x) {
         i64 i0 = b * kProbBlock + (i64)threadIdx.x * 4;
-        ProbSizes acc; for (int q = 0; q < 5; ++q) acc.v[q] = 0;
-        for (int e = 0; e < 4; ++e) if (i0 + e < n) { ProbSizes s = prob_sizes(cand_pn[i0 + e], cand_ln[i0 + e]); for (int q = 0; q < 5; ++q) acc.v[q] += s.v[q]; }
-        for (int q = 0; q < 5; ++q) {
+        ProbSizes acc; for (int q = 0; q < kProbCols; ++q) acc.v[q] = 0;
+        for (int e = 0; e < 4; ++e) if (i0 + e < n) { ProbSizes s = prob_sizes(cand_pn[i0 + e], cand_ln[i0 + e]); for (int q = 0; q < kProbCols; ++q) acc.v[q] += s.v[q]; }
+        for (int q = 0; q < kProbCols; ++q) {
             i64 tot;
             wg_exclusive_scan64(acc.v[q], lds, &tot);
-            if (threadIdx.x == 0) bs[b * 5 + q] = tot;
+            if (threadIdx.x == 0) bs[b * kProbCols + q] = tot;
             __syncthreads();
         }
     }
 }
 __global__ void __launch_bounds__(256) k_prob_scan2(Status *st, i64 *bs) {
     __shared__ i64 lds[16];
-    __shared__ i64 carry_s[5];
+    __shared__ i64 carry_s[kProbCols];
     i64 n = (i64)st->n_cand;
     i64 nb = (n + kProbBlock - 1) / kProbBlock;
-    if (threadIdx.x < 5) carry_s[threadIdx.x] = 0;
+    if (threadIdx.x < kProbCols) carry_s[threadIdx.x] = 0;
     __syncthreads();
     for (i64 b0 = 0; b0 < nb; b0 += blockDim.x) {
         i64 b = b0 + threadIdx.x;
-        for (int q = 0; q < 5; ++q) {
-            i64 v = b < nb ? bs[b * 5 + q] : 0;
+        for (int q = 0; q < kProbCols; ++q) {
+            i64 v = b < nb ? bs[b * kProbCols + q] : 0;
             i64 tot;
             i64 ex = wg_exclusive_scan64(v, lds, &tot);
             i64 carry = carry_s[q];
-            if (b < nb) bs[b * 5 + q] = carry + ex;
+            if (b < nb) bs[b * kProbCols + q] = carry + ex;
             __syncthreads();
             if (threadIdx.x == 0) carry_s[q] = carry + tot;
             __syncthreads();
@@ -662,24 +668,25 @@ __global__ void __launch_bounds__(256) k_prob_scan2(Status *st, i64 *bs) {
     if (threadIdx.x == 0) {
         st->n_prob = (u64)carry_s[0]; st->pair_used = (u64)carry_s[1]; st->tri_used = (u64)carry_s[2];
         st->n_work = (u64)carry_s[3]; st->cov_used = (u64)carry_s[4];
+        st->cls_work[0] = (u64)carry_s[5]; st->cls_work[1] = (u64)carry_s[6]; st->cls_work[2] = (u64)carry_s[7];
     }
 }
 __global__ void __launch_bounds__(256) k_prob_emit(Status *st, const int *cand_pn, const int *cand_ll, const int *cand_ln,
                                                    const int *cand_iv, const i64 *cand_off, const i64 *bs,
                                                    ProblemArrays pr, i64 prob_cap, int *work_prob, int *work_chunk,
-                                                   i64 work_cap) {
+                                                   int *cls_items, i64 work_cap) {
     __shared__ i64 lds[16];
     i64 n = (i64)st->n_cand;
     i64 nb = (n + kProbBlock - 1) / kProbBlock;
     for (i64 b = blockIdx.x; b < nb; b += gridDim.x) {
         i64 i0 = b * kProbBlock + (i64)threadIdx.x * 4;
-        ProbSizes sz[4], acc; for (int q = 0; q < 5; ++q) acc.v[q] = 0;
+        ProbSizes sz[4], acc; for (int q = 0; q < kProbCols; ++q) acc.v[q] = 0;
         for (int e = 0; e < 4; ++e) {
             if (i0 + e < n) sz[e] = prob_sizes(cand_pn[i0 + e], cand_ln[i0 + e]); else sz[e] = prob_sizes(0, 0);
-            for (int q = 0; q < 5; ++q) acc.v[q] += sz[e].v[q];
+            for (int q = 0; q < kProbCols; ++q) acc.v[q] += sz[e].v[q];
         }
-        i64 ex[5];
-        for (int q = 0; q < 5; ++q) { i64 tot; ex[q] = wg_exclusive_scan64(acc.v[q], lds, &tot) + bs[b * 5 + q]; __syncthreads(); }
+        i64 ex[kProbCols];
+        for (int q = 0; q < kProbCols; ++q) { i64 tot; ex[q] = wg_exclusive_scan64(acc.v[q], lds, &tot) + bs[b * kProbCols + q]; __syncthreads(); }
         for (int e = 0; e < 4; ++e) {
             if (sz[e].v[0]) {
                 i64 c = i0 + e;
@@ -691,13 +698,17 @@ __global__ void __launch_bounds__(256) k_prob_emit(Status *st, const int *cand_p
                     pr.pair_off[slot] = ex[1]; pr.tri_off[slot] = ex[2]; pr.work_base[slot] = ex[3]; pr.cov_off[slot] = ex[4];
                     pr.flags[slot] = 0; pr.chain[slot] = 0;
                     pr.lane_lo[slot] = cand_ll[c]; pr.lane_n[slot] = cand_ln[c];
+                    int cls = size_class(nn);
+                    i64 cbase = ex[5 + cls] + (cls >= 1 ? (i64)st->cls_work[0] : 0) + (cls >= 2 ? (i64)st->cls_work[1] : 0);
                     for (i64 q = 0; q < sz[e].v[3]; ++q) {
-                        if (ex[3] + q < work_cap) { work_prob[ex[3] + q] = (int)slot; work_chunk[ex[3] + q] = (int)q; }
-                        else atomicOr(&st->err, kErrOverflowWork);
+                        if (ex[3] + q < work_cap && cbase + q < work_cap) {
+                            work_prob[ex[3] + q] = (int)slot; work_chunk[ex[3] + q] = (int)q;
+                            cls_items[cbase + q] = (int)(ex[3] + q);
+                        } else atomicOr(&st->err, kErrOverflowWork);
                     }
                 } else atomicOr(&st->err, kErrOverflowProblems);
             }
-            for (int q = 0; q < 5; ++q) ex[q] += sz[e].v[q];
+            for (int q = 0; q < kProbCols; ++q) ex[q] += sz[e].v[q];
         }
     }
 }
@@ -760,7 +771,8 @@ __global__ void __launch_bounds__(kLaneChunk) k_cov(Status *st, ProblemArrays pr
     __shared__ int cp[kNMax + 4];
     __shared__ u64 work_s;
     __shared__ unsigned active_s;
-    i64 n_work = (i64)st->n_work < work_cap ? (i64)st->n_work : work_cap;
+    i64 n_work = (i64)st->n_work;
+    if (n_work > work_cap || (i64)st->n_prob > prob_cap) return;   // lists incomplete: this run only sizes the arenas
     for (;;) {
         __syncthreads();
         if (threadIdx.x == 0) { work_s = atomicAdd(&st->cov_queue, 1ULL); active_s = 0; }
@@ -831,10 +843,26 @@ __global__ void __launch_bounds__(kLaneChunk) k_cov(Status *st, ProblemArrays pr
 // At the end of the work item the non-zero counters go to the global table with one atomic each.
 // Reads with multiplicity W are expanded into W lanes on upload, so every lane has weight 1.
 // ---------------------------------------------------------------------------------------------
-constexpr int kScoreThreads = 512;
-constexpr int kMaxPairs = kNMax * (kNMax - 1) / 2;
-constexpr int kPairSlots = (kMaxPairs + kScoreThreads - 1) / kScoreThreads;
-constexpr int kCovStride = kNMax + 1;   // odd: read-major rows do not collide on LDS banks
+// pair q = j*(j-1)/2 + i  <->  (i, j); independent of the problem size, built once per context
+__device__ unsigned short g_pair_ij[kNMax * (kNMax - 1) / 2];
+__global__ void k_init_pair_table() {
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < kNMax * (kNMax - 1) / 2; q += gridDim.x * blockDim.x) {
+        int i, j;
+        pair_decode(q, &i, &j);
+        g_pair_ij[q] = (unsigned short)(i | (j << 8));
+    }
+}
+
+template <int NM> struct ScoreCfg {
+    static constexpr int kPairs = NM * (NM - 1) / 2;
+    static constexpr int kTri = NM * (NM - 1) * (NM - 2) / 6;
+    static constexpr int kThreads = NM <= 16 ? 128 : (NM <= 32 ? 256 : 512);
+    static constexpr int kSlots = (kPairs + kThreads - 1) / kThreads;
+    static constexpr int kCovStride = NM + 1;      // odd: read-major rows do not collide on LDS banks
+    static constexpr int kStage = (NM * kSub + kThreads - 1) / kThreads;   // coverage words per thread and tile
+    static constexpr size_t kLds = (size_t)kPairs * 16 + (size_t)kSub * kCovStride * 4 + (size_t)((kPairs + 7) & ~7) * 2 +
+                                   (size_t)((kTri + 7) & ~7) * 2;
+};
 
 #ifdef FSEG_SCORE_TIMING
 #define FSEG_TPARAM , unsigned long long *tacc
@@ -845,64 +873,83 @@ constexpr int kCovStride = kNMax + 1;   // odd: read-major rows do not collide o
 #define FSEG_T0
 #define FSEG_TICK(i)
 #endif
-__global__ void __launch_bounds__(kScoreThreads) k_score(Status *st, ProblemArrays pr, i64 prob_cap,
-                                                         const int *work_prob, const int *work_chunk, i64 work_cap,
-                                                         const i64 *cand_off, const int *cand_y,
-                                                         const unsigned char *work_active, const unsigned *cov_g,
-                                                         i64 cov_cap, const int2 *pair_thr, i64 pair_cap,
-                                                         unsigned *out_g, i64 tri_cap, unsigned *amb_g FSEG_TPARAM) {
+template <int NM>
+__global__ void __launch_bounds__(ScoreCfg<NM>::kThreads) k_score(Status *st, int cls, ProblemArrays pr, i64 prob_cap,
+                                                                  const int *cls_items, const int *work_prob,
+                                                                  const int *work_chunk, i64 work_cap, const i64 *cand_off,
+                                                                  const int *cand_y, const unsigned char *work_active,
+                                                                  const unsigned *cov_g, i64 cov_cap, const int2 *pair_thr,
+                                                                  i64 pair_cap, unsigned *out_g, i64 tri_cap,
+                                                                  unsigned *amb_g FSEG_TPARAM) {
+    using C = ScoreCfg<NM>;
+    constexpr int T = C::kThreads;
     extern __shared__ __align__(16) unsigned char smem[];
-    __shared__ int cy_s[kNMax + 4];
+    __shared__ int cy_s[NM + 4];
     __shared__ u64 work_s;
-    // dynamic LDS carve-up
-    uint4 *planes = reinterpret_cast<uint4 *>(smem);                                   // kMaxPairs * 16 B
-    unsigned *cov = reinterpret_cast<unsigned *>(smem + (size_t)kMaxPairs * 16);       // kSub * kCovStride * 4 B
-    unsigned short *pair_ij = reinterpret_cast<unsigned short *>(cov + kSub * kCovStride);   // kMaxPairs * 2 B
-    unsigned short *out16 = pair_ij + ((kMaxPairs + 7) & ~7);                          // C(kNMax,3) * 2 B
-
-    i64 n_work = (i64)st->n_work < work_cap ? (i64)st->n_work : work_cap;
+    uint4 *planes = reinterpret_cast<uint4 *>(smem);                                         // kPairs * 16 B
+    unsigned *cov = reinterpret_cast<unsigned *>(smem + (size_t)C::kPairs * 16);             // kSub * kCovStride * 4 B
+    unsigned short *pair_ij = reinterpret_cast<unsigned short *>(cov + kSub * C::kCovStride);   // kPairs * 2 B
+    unsigned short *out16 = pair_ij + ((C::kPairs + 7) & ~7);                                // kTri * 2 B
+    for (int q = threadIdx.x; q < C::kPairs; q += T) pair_ij[q] = g_pair_ij[q];
+    i64 cls_base = (cls >= 1 ? (i64)st->cls_work[0] : 0) + (cls >= 2 ? (i64)st->cls_work[1] : 0);
+    i64 n_items = (i64)st->cls_work[cls];
+    if ((i64)st->n_work > work_cap || (i64)st->n_prob > prob_cap) n_items = 0;   // lists incomplete: sizing run
     FSEG_T0;
     for (;;) {
         __syncthreads();
-        if (threadIdx.x == 0) work_s = atomicAdd(&st->work_queue, 1ULL);
+        if (threadIdx.x == 0) work_s = atomicAdd(&st->cls_queue[cls], 1ULL);
         __syncthreads();
-        i64 w = (i64)work_s;
+        i64 wi = (i64)work_s;
         FSEG_TICK(0);
-        if (w >= n_work) break;
+        if (wi >= n_items) break;
+        i64 w = cls_items[cls_base + wi];
         int p = work_prob[w];
         int chunk = work_chunk[w];
         int n = pr.n[p];
         i64 poff = pr.pair_off[p], toff = pr.tri_off[p];
         i64 coff = pr.cov_off[p] + (i64)chunk * kLaneChunk * n;
         int npairs = n * (n - 1) / 2, ntri = n * (n - 1) * (n - 2) / 6;
-        if (n > kNMax || poff + npairs > pair_cap || toff + ntri > tri_cap || coff + (i64)kLaneChunk * n > cov_cap) continue;
+        if (n > NM || poff + npairs > pair_cap || toff + ntri > tri_cap || coff + (i64)kLaneChunk * n > cov_cap) continue;
         bool zero_ambiguous = (pr.flags[p] & 1) != 0;
         unsigned active = zero_ambiguous ? 0xfu : work_active[w];
         int lanes_here = pr.lane_n[p] - chunk * kLaneChunk;
         if (lanes_here > kLaneChunk) lanes_here = kLaneChunk;
+        if (lanes_here < kLaneChunk) active &= (1u << ((lanes_here + kSub - 1) / kSub)) - 1u;
         if (active == 0) continue;                       // no read of this chunk touches the window
         const int *cy = cand_y + cand_off[pr.iv[p]] + pr.start[p];
-        for (int j = threadIdx.x; j < n; j += blockDim.x) cy_s[j] = cy[j];
-        for (int q = threadIdx.x; q < npairs; q += blockDim.x) {
-            int i, j;
-            pair_decode(q, &i, &j);
-            pair_ij[q] = (unsigned short)(i | (j << 8));
-        }
-        for (int x = threadIdx.x; x < ntri; x += blockDim.x) out16[x] = 0;
-        unsigned amb_acc[kPairSlots];
+        for (int j = threadIdx.x; j < n; j += T) cy_s[j] = cy[j];
+        for (int x = threadIdx.x; x < ntri; x += T) out16[x] = 0;
+        unsigned amb_acc[C::kSlots];
 #pragma unroll
-        for (int s = 0; s < kPairSlots; ++s) amb_acc[s] = 0;
+        for (int s = 0; s < C::kSlots; ++s) amb_acc[s] = 0;
+        // coverage tile of the first active sub-chunk into registers (global layout is [j][reads])
+        unsigned stage[C::kStage];
+        int sub = __ffs(active) - 1;
+        const int tile_words = n * kSub;
+#pragma unroll
+        for (int e = 0; e < C::kStage; ++e) {
+            int x = e * T + threadIdx.x;
+            stage[e] = x < tile_words ? cov_g[coff + (i64)(x >> 6) * kLaneChunk + sub * kSub + (x & 63)] : 0;
+        }
         __syncthreads();
         FSEG_TICK(1);
-        for (int sub = 0; sub < kLaneChunk / kSub; ++sub) {
-            if (!((active >> sub) & 1u)) continue;
+        while (sub >= 0) {
             int n_valid = lanes_here - sub * kSub;
-            if (n_valid <= 0) break;
             if (n_valid > kSub) n_valid = kSub;
-            // ---- A: stage cov[r][j] for the 64 reads (global layout is [j][reads]) ------------------
-            for (int x = threadIdx.x; x < n * kSub; x += blockDim.x) {
-                int j = x >> 6, r = x & 63;
-                cov[r * kCovStride + j] = cov_g[coff + (i64)j * kLaneChunk + sub * kSub + r];
+            // ---- A: registers -> LDS cov[r][j]; start fetching the next active tile ---------------------
+#pragma unroll
+            for (int e = 0; e < C::kStage; ++e) {
+                int x = e * T + threadIdx.x;
+                if (x < tile_words) cov[(x & 63) * C::kCovStride + (x >> 6)] = stage[e];
+            }
+            unsigned rest = active & ~((2u << sub) - 1u);
+            int next_sub = rest ? __ffs(rest) - 1 : -1;
+            if (next_sub >= 0) {
+#pragma unroll
+                for (int e = 0; e < C::kStage; ++e) {
+                    int x = e * T + threadIdx.x;
+                    stage[e] = x < tile_words ? cov_g[coff + (i64)(x >> 6) * kLaneChunk + next_sub * kSub + (x & 63)] : 0;
+                }
             }
             __syncthreads();
             FSEG_TICK(2);
@@ -910,19 +957,19 @@ __global__ void __launch_bounds__(kScoreThreads) k_score(Status *st, ProblemArra
             unsigned valid0 = n_valid >= 32 ? 0xffffffffu : ((1u << n_valid) - 1u);
             unsigned valid1 = n_valid >= 64 ? 0xffffffffu : (n_valid > 32 ? ((1u << (n_valid - 32)) - 1u) : 0u);
 #pragma unroll
-            for (int s = 0; s < kPairSlots; ++s) {
-                int q = s * kScoreThreads + threadIdx.x;
+            for (int s = 0; s < C::kSlots; ++s) {
+                int q = s * T + threadIdx.x;
                 if (q < npairs) {
                     int i = pair_ij[q] & 255, j = pair_ij[q] >> 8;
                     int2 th = pair_thr[poff + q];
                     unsigned y0 = 0, z0 = 0, y1 = 0, z1 = 0;
                     for (int b = 0; b < 32; ++b) {
-                        int d = (int)(cov[b * kCovStride + j] - cov[b * kCovStride + i]);
+                        int d = (int)(cov[b * C::kCovStride + j] - cov[b * C::kCovStride + i]);
                         y0 |= (unsigned)(d >= th.x) << b;
                         z0 |= (unsigned)(d <= th.y) << b;
                     }
                     for (int b = 0; b < 32; ++b) {
-                        int d = (int)(cov[(32 + b) * kCovStride + j] - cov[(32 + b) * kCovStride + i]);
+                        int d = (int)(cov[(32 + b) * C::kCovStride + j] - cov[(32 + b) * C::kCovStride + i]);
                         y1 |= (unsigned)(d >= th.x) << b;
                         z1 |= (unsigned)(d <= th.y) << b;
                     }
@@ -932,11 +979,13 @@ __global__ void __launch_bounds__(kScoreThreads) k_score(Status *st, ProblemArra
             }
             __syncthreads();
             FSEG_TICK(3);
-            // ---- C: triples ---------------------------------------------------------------------------
-            for (int q = threadIdx.x; q < npairs; q += blockDim.x) {
-                int j = pair_ij[q] & 255, kk = pair_ij[q] >> 8;       // B pair = (j, k)
+            // ---- C: triples.  B pairs (j,k) are enumerated with j descending so that the 64 lanes of a wave
+            // have (nearly) the same trip count j and mostly share the (i,j) plane they read --------------
+            for (int r = threadIdx.x; r < npairs; r += T) {
+                int m = pair_ij[r] >> 8, x = pair_ij[r] & 255;        // m = n-1-j in [1, n-1], x = k-j-1 in [0, m)
+                int j = n - 1 - m, kk = j + 1 + x;
                 if (j == 0 || cy_s[kk] - cy_s[j] < 5) continue;       // dp(): segment too small (:540)
-                uint4 B = planes[q];
+                uint4 B = planes[kk * (kk - 1) / 2 + j];
                 if ((B.x | B.y | B.z | B.w) == 0) continue;
                 int tbase = kk * (kk - 1) * (kk - 2) / 6 + j * (j - 1) / 2;
                 int abase = j * (j - 1) / 2;
@@ -949,15 +998,16 @@ __global__ void __launch_bounds__(kScoreThreads) k_score(Status *st, ProblemArra
             }
             __syncthreads();
             FSEG_TICK(4);
+            sub = next_sub;
         }
         // ---- flush ---------------------------------------------------------------------------------
-        for (int x = threadIdx.x; x < ntri; x += blockDim.x) {
+        for (int x = threadIdx.x; x < ntri; x += T) {
             unsigned v = out16[x];
             if (v) atomicAdd(&out_g[toff + x], v);
         }
 #pragma unroll
-        for (int s = 0; s < kPairSlots; ++s) {
-            int q = s * kScoreThreads + threadIdx.x;
+        for (int s = 0; s < C::kSlots; ++s) {
+            int q = s * T + threadIdx.x;
             if (q < npairs && amb_acc[s]) atomicAdd(&amb_g[poff + q], amb_acc[s]);
         }
         FSEG_TICK(5);
@@ -993,7 +1043,8 @@ __global__ void __launch_bounds__(256) k_dp(Status *st, int n_lo, u64 *queue, Pr
     __shared__ unsigned char part_a[256];
     __shared__ int top_key[4];
     int lane = lane_id();
-    i64 n_prob = (i64)st->n_prob < prob_cap ? (i64)st->n_prob : prob_cap;
+    i64 n_prob = (i64)st->n_prob;
+    if (n_prob > prob_cap) return;                                  // sizing run
     for (;;) {
         __syncthreads();
         if (threadIdx.x == 0) work_s = atomicAdd(queue, 1ULL);
@@ -1408,7 +1459,7 @@ struct fseg_ctx {
     // problems / arenas
     DevBuf d_prob_iv, d_prob_start, d_prob_n, d_prob_pair_off, d_prob_tri_off, d_prob_flags, d_prob_chain,
         d_prob_cov_off, d_prob_lane_lo, d_prob_lane_n, d_prob_work_base;
-    DevBuf d_work_prob, d_work_chunk, d_work_active, d_pair_thr, d_amb, d_out, d_cov, d_labels;
+    DevBuf d_work_prob, d_work_chunk, d_cls_items, d_work_active, d_pair_thr, d_amb, d_out, d_cov, d_labels;
     i64 prob_cap = 0, work_cap = 0, pair_cap = 0, tri_cap = 0, label_cap = 0, chunk_cap = 0, cov_cap = 0;
     DevBuf d_status, d_tacc;
     Status *h_status = nullptr;   // pinned
@@ -1490,6 +1541,7 @@ int alloc_arenas(fseg_ctx *c) {
     TRY(ensure(c, c->d_prob_work_base, (size_t)c->prob_cap * 8));
     TRY(ensure(c, c->d_work_prob, (size_t)c->work_cap * 4));
     TRY(ensure(c, c->d_work_chunk, (size_t)c->work_cap * 4));
+    TRY(ensure(c, c->d_cls_items, (size_t)c->work_cap * 4));
     TRY(ensure(c, c->d_work_active, (size_t)c->work_cap));
     TRY(ensure(c, c->d_cov, (size_t)c->cov_cap * 4));
     TRY(ensure(c, c->d_pair_thr, (size_t)c->pair_cap * 8));
@@ -1580,7 +1632,8 @@ int enqueue_run(fseg_ctx *c) {
         hipLaunchKernelGGL(k_prob_scan2, dim3(1), dim3(256), 0, s, st, c->d_prob_bs.as<i64>());
         hipLaunchKernelGGL(k_prob_emit, dim3(pg), dim3(256), 0, s, st, c->d_cand_pn.as<int>(), c->d_cand_ll.as<int>(),
                            c->d_cand_ln.as<int>(), c->d_seg_iv.as<int>(), c->d_cand_off.as<i64>(), c->d_prob_bs.as<i64>(),
-                           pr, c->prob_cap, c->d_work_prob.as<int>(), c->d_work_chunk.as<int>(), c->work_cap);
+                           pr, c->prob_cap, c->d_work_prob.as<int>(), c->d_work_chunk.as<int>(), c->d_cls_items.as<int>(),
+                           c->work_cap);
     }
     mark(5);
     // S5
@@ -1599,15 +1652,22 @@ int enqueue_run(fseg_ctx *c) {
     }
     mark(6);
     if (c->prob_cap > 0) {
-        hipLaunchKernelGGL(k_score, dim3(work_grid < 256 ? work_grid : 256), dim3(kScoreThreads), c->score_lds, s, st, pr,
-                           c->prob_cap, c->d_work_prob.as<int>(), c->d_work_chunk.as<int>(), c->work_cap,
-                           c->d_cand_off.as<i64>(), c->d_cand_y.as<int>(), c->d_work_active.as<unsigned char>(),
-                           c->d_cov.as<unsigned>(), c->cov_cap, c->d_pair_thr.as<int2>(), c->pair_cap,
-                           c->d_out.as<unsigned>(), c->tri_cap, c->d_amb.as<unsigned>()
 #ifdef FSEG_SCORE_TIMING
-                           , c->d_tacc.as<unsigned long long>()
+#define FSEG_TARG , c->d_tacc.as<unsigned long long>()
+#else
+#define FSEG_TARG
 #endif
-                           );
+#define FSEG_LAUNCH_SCORE(NMV, CLS, MAXWG)                                                                              \
+        hipLaunchKernelGGL(k_score<NMV>, dim3(work_grid < (MAXWG) ? work_grid : (MAXWG)), dim3(ScoreCfg<NMV>::kThreads),  \
+                           ScoreCfg<NMV>::kLds, s, st, CLS, pr, c->prob_cap, c->d_cls_items.as<int>(),                    \
+                           c->d_work_prob.as<int>(), c->d_work_chunk.as<int>(), c->work_cap, c->d_cand_off.as<i64>(),   \
+                           c->d_cand_y.as<int>(), c->d_work_active.as<unsigned char>(), c->d_cov.as<unsigned>(),        \
+                           c->cov_cap, c->d_pair_thr.as<int2>(), c->pair_cap, c->d_out.as<unsigned>(), c->tri_cap,      \
+                           c->d_amb.as<unsigned>() FSEG_TARG)
+        FSEG_LAUNCH_SCORE(kNMax, 2, 256);        // big problems first: they are the long poles
+        FSEG_LAUNCH_SCORE(kClsMid, 1, 1280);
+        FSEG_LAUNCH_SCORE(kClsSmall, 0, 2048);
+#undef FSEG_LAUNCH_SCORE
     }
     mark(7);
     if (c->prob_cap > 0) {
@@ -1729,9 +1789,13 @@ int fseg_create(int device, fseg_ctx **out) {
     if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_status, sizeof(Status), hipHostMallocDefault);
     if (e == hipSuccess) e = hipMalloc(&c->d_status.p, sizeof(Status));
     for (int i = 0; e == hipSuccess && i <= ST_COUNT; ++i) e = hipEventCreate(&c->ev[i]);
-    c->score_lds = (int)score_lds_bytes();
     if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_score), hipFuncAttributeMaxDynamicSharedMemorySize, c->score_lds);
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_score<kNMax>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)ScoreCfg<kNMax>::kLds);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_init_pair_table, dim3(8), dim3(256), 0, c->stream);
+        e = hipStreamSynchronize(c->stream);
+    }
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_dp<kNMax>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)dp_lds_bytes<kNMax>());
@@ -1758,7 +1822,7 @@ void fseg_destroy(fseg_ctx *c) {
                       &c->d_final_pos, &c->d_col_thr, &c->d_col_zero, &c->d_seg_iv, &c->d_seg_prev, &c->d_rseg_c, &c->d_cand_pn, &c->d_cand_ll, &c->d_cand_ln, &c->d_prob_bs, &c->d_prob_iv, &c->d_prob_start,
                       &c->d_prob_n, &c->d_prob_pair_off, &c->d_prob_tri_off, &c->d_prob_flags, &c->d_prob_chain, &c->d_prob_cov_off,
                       &c->d_prob_lane_lo, &c->d_prob_lane_n, &c->d_prob_work_base, &c->d_work_active, &c->d_cov,
-                      &c->d_work_prob, &c->d_work_chunk, &c->d_pair_thr, &c->d_amb, &c->d_out, &c->d_labels, &c->d_status, &c->d_tacc};
+                      &c->d_work_prob, &c->d_work_chunk, &c->d_cls_items, &c->d_pair_thr, &c->d_amb, &c->d_out, &c->d_labels, &c->d_status, &c->d_tacc};
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
     if (c->h_status) (void)hipHostFree(c->h_status);
     for (int i = 0; i <= ST_COUNT; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -1921,7 +1985,7 @@ int fseg_upload(fseg_ctx *c, const fseg_batch *b) {
     TRY(ensure(c, c->d_final_y, np8 * 4)); TRY(ensure(c, c->d_final_pos, np8 * 4)); TRY(ensure(c, c->d_col_thr, np8 * 8)); TRY(ensure(c, c->d_col_zero, np8));
     TRY(ensure(c, c->d_seg_iv, np8 * 4)); TRY(ensure(c, c->d_seg_prev, np8 * 4)); TRY(ensure(c, c->d_rseg_c, np8 * 4));
     TRY(ensure(c, c->d_cand_pn, np8 * 4)); TRY(ensure(c, c->d_cand_ll, np8 * 4)); TRY(ensure(c, c->d_cand_ln, np8 * 4));
-    TRY(ensure(c, c->d_prob_bs, ((size_t)NPOS / kProbBlock + 2) * 5 * 8));
+    TRY(ensure(c, c->d_prob_bs, ((size_t)NPOS / kProbBlock + 2) * kProbCols * 8));
     // first-guess arena capacities; fseg_sync() grows them if the run reports an overflow
     auto atleast = [](i64 &cap, i64 v) { if (cap < v) cap = v; };
     atleast(c->chunk_cap, NPOS / 8192 + np + 8);
