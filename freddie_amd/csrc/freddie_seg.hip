@@ -30,9 +30,9 @@ namespace {
 typedef long long i64;
 typedef unsigned long long u64;
 
-constexpr int kSmoothTile = 1024;      // positions per smoothing / peak tile
+constexpr int kSmoothTile = 1024;      // positions per smoothing / peak tile (k_segments shifts by 10)
 constexpr int kMaxRadius = 200;        // sigma <= 50, truncate 4.0 (py/freddie_segment.py:106,:755)
-constexpr int kScanBlock = 2048;       // elements per scan workgroup
+constexpr int kScanBlock = 8192;       // elements per scan workgroup (256 threads x 32 flag bytes)
 constexpr int kNMax = 60;              // largest DP problem handled by the LDS-resident scoring kernel
 constexpr int kLaneChunk = 256;        // reads ("lanes") per scoring work item (u16 counters: must stay < 65536)
 constexpr int kSub = 64;               // reads per scoring sub-chunk (two 32-bit plane words)
@@ -153,10 +153,13 @@ __global__ void k_hist(int n_part, const i64 *part_rep_off, const i64 *part_iv_o
 // tile plus its halo is staged in LDS as int32 (the histogram holds exact small integers).
 // Also writes the flag Y > 0 used by the threshold stage.
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wg_exclusive_scan(int v, int *lds, int *total);
+
 __global__ void __launch_bounds__(256) k_smooth(int n_tiles, const int *tile_iv, const int *tile_y0,
                                                 const i64 *pos_off, const int *y_raw, const double *w_g, int radius,
-                                                double *y_out, unsigned char *flag_pos) {
+                                                double *y_out, unsigned char *flag_pos, int *cum, int *tile_tot) {
     __shared__ int xs[kSmoothTile + 2 * kMaxRadius];
+    __shared__ int scan_lds[16];
     __shared__ double ws[kMaxRadius + 1];
     for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         int k = tile_iv[t];
@@ -171,6 +174,15 @@ __global__ void __launch_bounds__(256) k_smooth(int n_tiles, const int *tile_iv,
             xs[idx] = y_raw[base + reflect_index(y, len)];
         }
         __syncthreads();
+        {   // inclusive prefix sums of the histogram inside the tile + the tile total: lets k_segments evaluate
+            // refine_segmentation's `sum(i_vals) < 20` test (:258) exactly in O(1) per segment
+            int o4 = threadIdx.x * 4, v4[4], run = 0;
+            for (int e = 0; e < 4; ++e) { run += (y0 + o4 + e < len) ? xs[radius + o4 + e] : 0; v4[e] = run; }
+            int tot;
+            int ex = wg_exclusive_scan(run, scan_lds, &tot);
+            for (int e = 0; e < 4; ++e) if (y0 + o4 + e < len) cum[base + y0 + o4 + e] = ex + v4[e];
+            if (threadIdx.x == 0) tile_tot[t] = tot;
+        }
         for (int o = threadIdx.x; o < kSmoothTile; o += blockDim.x) {
             i64 y = y0 + o;
             if (y >= len) break;
@@ -209,13 +221,36 @@ __device__ __forceinline__ int wg_exclusive_scan(int v, int *lds /* >= 16 ints *
     return off + x - v;
 }
 
+// each thread owns 32 consecutive flag bytes (two 16-byte loads)
+struct Flags32 { unsigned w[8]; };
+__device__ __forceinline__ Flags32 load_flags32(const unsigned char *flags, i64 i0, i64 n) {
+    Flags32 f;
+    if (i0 + 32 <= n) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(flags + i0);
+        uint4 a = src[0], b = src[1];
+        f.w[0] = a.x; f.w[1] = a.y; f.w[2] = a.z; f.w[3] = a.w; f.w[4] = b.x; f.w[5] = b.y; f.w[6] = b.z; f.w[7] = b.w;
+    } else {
+        for (int q = 0; q < 8; ++q) {
+            unsigned w = 0;
+            for (int e = 0; e < 4; ++e) { i64 i = i0 + q * 4 + e; if (i < n) w |= (unsigned)(flags[i] & 1) << (8 * e); }
+            f.w[q] = w;
+        }
+    }
+    for (int q = 0; q < 8; ++q) f.w[q] &= 0x01010101u;
+    return f;
+}
+__device__ __forceinline__ int count_flags32(const Flags32 &f) {
+    int s = 0;
+    for (int q = 0; q < 8; ++q) s += __popc(f.w[q]);
+    return s;
+}
+
 __global__ void __launch_bounds__(256) k_scan1(const unsigned char *flags, i64 n, int *bsum) {
     __shared__ int lds[16];
     i64 nb = (n + kScanBlock - 1) / kScanBlock;
     for (i64 b = blockIdx.x; b < nb; b += gridDim.x) {
-        i64 i0 = b * kScanBlock + (i64)threadIdx.x * 8;
-        int s = 0;
-        for (int q = 0; q < 8; ++q) if (i0 + q < n) s += flags[i0 + q];
+        i64 i0 = b * kScanBlock + (i64)threadIdx.x * 32;
+        int s = i0 < n ? count_flags32(load_flags32(flags, i0, n)) : 0;
         int tot;
         wg_exclusive_scan(s, lds, &tot);
         if (threadIdx.x == 0) bsum[b] = tot;
@@ -240,17 +275,61 @@ __global__ void __launch_bounds__(256) k_scan2(int *bsum, i64 nb, u64 *total_out
     }
     if (threadIdx.x == 0) *total_out = (u64)carry_s;
 }
-__global__ void __launch_bounds__(256) k_scan3(const unsigned char *flags, i64 n, const int *bsum, int *idx) {
+// third pass fused with the consumer of the compaction:
+//   kEmitValues:    v[rank] = y[i]                                   (threshold stage)
+//   kEmitPositions: out_y[rank] = y index inside its interval, out_pos[rank] = genomic position,
+//                   out_off[k] = rank of the interval's first position (always flagged)
+enum { kEmitValues = 0, kEmitPositions = 1 };
+template <int MODE>
+__global__ void __launch_bounds__(256) k_scan_emit(const unsigned char *flags, i64 n, const int *bsum, const double *y,
+                                                   double *v, i64 K, const i64 *pos_off, const int *iv_start, int *out_y,
+                                                   int *out_pos, i64 *out_off) {
     __shared__ int lds[16];
     i64 nb = (n + kScanBlock - 1) / kScanBlock;
     for (i64 b = blockIdx.x; b < nb; b += gridDim.x) {
-        i64 i0 = b * kScanBlock + (i64)threadIdx.x * 8;
-        int f[8], s = 0;
-        for (int q = 0; q < 8; ++q) { f[q] = (i0 + q < n) ? flags[i0 + q] : 0; s += f[q]; }
+        i64 i0 = b * kScanBlock + (i64)threadIdx.x * 32;
+        Flags32 f;
+        int s = 0;
+        if (i0 < n) { f = load_flags32(flags, i0, n); s = count_flags32(f); }
         int tot;
         int ex = wg_exclusive_scan(s, lds, &tot) + bsum[b];
-        for (int q = 0; q < 8; ++q) { if (i0 + q < n) idx[i0 + q] = ex; ex += f[q]; }
+        if (s) {
+            i64 k = -1, k_end = 0, k_base = 0;
+            for (int q = 0; q < 8; ++q) {
+                unsigned w = f.w[q];
+                while (w) {
+                    int e = (__ffs(w) - 1) >> 3;
+                    w &= w - 1;
+                    i64 i = i0 + q * 4 + e;
+                    if (MODE == kEmitValues) v[ex] = y[i];
+                    else {
+                        if (k < 0 || i >= k_end) { k = last_le(pos_off, K + 1, i); k_base = pos_off[k]; k_end = pos_off[k + 1]; }
+                        int yy = (int)(i - k_base);
+                        out_y[ex] = yy;
+                        if (out_pos) out_pos[ex] = iv_start[k] + yy;
+                        if (yy == 0) out_off[k] = ex;
+                    }
+                    ++ex;
+                }
+            }
+        }
         __syncthreads();
+    }
+}
+// rank of the first position of every partition in the compaction of the Y > 0 flags
+__global__ void __launch_bounds__(64) k_voff(int n_part, const i64 *part_iv_off, const i64 *pos_off, i64 n_pos,
+                                             const unsigned char *flags, const int *bsum, const u64 *total, i64 *voff) {
+    for (int p = blockIdx.x; p <= n_part; p += gridDim.x) {
+        if (p == n_part) { if (threadIdx.x == 0) voff[p] = (i64)*total; continue; }
+        i64 pos = pos_off[part_iv_off[p]];
+        i64 b = pos / kScanBlock, start = b * kScanBlock;
+        int cnt = 0;
+        for (i64 i0 = start + (i64)threadIdx.x * 32; i0 < pos; i0 += 64 * 32) {
+            Flags32 f = load_flags32(flags, i0, pos);      // bytes at or after pos are masked out by the bound
+            cnt += count_flags32(f);
+        }
+        for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
+        if (threadIdx.x == 0) voff[p] = (i64)bsum[b] + cnt;
     }
 }
 
@@ -261,20 +340,11 @@ __global__ void __launch_bounds__(256) k_scan3(const unsigned char *flags, i64 n
 // below 129 elements, halves rounded down to a multiple of 8 above), chunk results added left to
 // right.  Empty V gives NaN, which fixes nothing.
 // ---------------------------------------------------------------------------------------------
-__global__ void k_vgather(i64 n_pos, const unsigned char *flag_pos, const int *idx, const double *y, double *v) {
-    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n_pos; i += (i64)gridDim.x * blockDim.x)
-        if (flag_pos[i]) v[idx[i]] = y[i];
-}
 // one workgroup: per-partition V ranges and chunk offsets
 __global__ void __launch_bounds__(256) k_vplan(int n_part, const i64 *part_iv_off, const i64 *pos_off, i64 n_pos,
                                                const int *idx, i64 *voff, i64 *chunk_off, Status *st, i64 chunk_cap) {
     __shared__ int lds[16];
     __shared__ i64 carry_s;
-    u64 total = st->n_vals;
-    for (int p = threadIdx.x; p <= n_part; p += blockDim.x) {
-        i64 pos = p < n_part ? pos_off[part_iv_off[p]] : n_pos;
-        voff[p] = pos < n_pos ? (i64)idx[pos] : (i64)total;
-    }
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
     for (int p0 = 0; p0 < n_part; p0 += blockDim.x) {
@@ -425,27 +495,6 @@ __global__ void __launch_bounds__(256) k_peaks(int n_tiles, const int *tile_iv, 
                 i64 ia = i + 1;
                 while (ia < len - 1 && x[ia] == xi) ++ia;
                 if (x[ia] < xi) flag[base + (i + ia - 1) / 2] = 1;
-            }
-        }
-    }
-}
-// compaction of position flags into per-interval sorted y lists (used for candidates and finals)
-__global__ void __launch_bounds__(256) k_pos_gather(int n_tiles, const int *tile_iv, const int *tile_y0,
-                                                    const i64 *pos_off, const unsigned char *flag, const int *idx,
-                                                    const int *iv_start, int *out_y, int *out_pos, i64 *out_off) {
-    for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-        int k = tile_iv[t];
-        i64 y0 = tile_y0[t];
-        i64 base = pos_off[k];
-        i64 len = pos_off[k + 1] - base;
-        for (int o = threadIdx.x; o < kSmoothTile; o += blockDim.x) {
-            i64 i = y0 + o;
-            if (i >= len) break;
-            if (flag[base + i]) {
-                int d = idx[base + i];
-                out_y[d] = (int)i;
-                if (out_pos) out_pos[d] = iv_start[k] + (int)i;
-                if (i == 0) out_off[k] = d;     // position 0 of every interval is always flagged
             }
         }
     }
@@ -1153,8 +1202,8 @@ __global__ void __launch_bounds__(256) k_dp(Status *st, int n_lo, u64 *queue, Pr
 // previous chosen candidate is more than 40 positions away, records that segment; k_refine then
 // visits the recorded segments (one wave each).
 // ---------------------------------------------------------------------------------------------
-__global__ void k_segments(i64 K, const i64 *pos_off, const i64 *cand_off, const int *cand_y,
-                           const unsigned char *chosen, unsigned char *final_flag, int *rseg_c, int *rseg_prev,
+__global__ void k_segments(i64 K, const i64 *pos_off, const i64 *cand_off, const int *cand_y, const int *cum,
+                           const int *tile_tot, const int *iv_tile0, const unsigned char *chosen, unsigned char *final_flag, int *rseg_c, int *rseg_prev,
                            Status *st) {
     __shared__ int lds[16];
     __shared__ int cnt_s[16];
@@ -1177,6 +1226,17 @@ __global__ void k_segments(i64 K, const i64 *pos_off, const i64 *cand_off, const
                 if (prev >= 0) py = cand_y[c0 + prev];
             }
             bool need = f && py >= 0 && y - py > 40;                  // :252
+            if (need) {
+                // refine_segmentation's `sum(i_vals) < 20 -> continue` (:258), exactly, from the per-tile prefix sums
+                // of the histogram: inner positions [py+20, y-21]
+                int a = py + 20, b = y - 21;
+                int ta = a >> 10, tb = b >> 10;                       // kSmoothTile == 1024
+                const int *cm = cum + base;
+                const int *tt = tile_tot + iv_tile0[k];
+                i64 tot = (i64)cm[b] - ((a & 1023) ? cm[a - 1] : 0);
+                if (tb > ta && tb - ta <= 64) { for (int q = ta; q < tb; ++q) tot += tt[q]; }
+                if (tb - ta <= 64) need = tot >= 20;                  // very long segments: k_refine sums them itself
+            }
             u64 m = __ballot(need);
             if (lane == 0) cnt_s[wave] = __popcll(m);
             __syncthreads();
@@ -1455,7 +1515,7 @@ struct fseg_ctx {
     // candidate-sized
     DevBuf d_cand_off, d_cand_y, d_fixed0, d_added, d_fixed, d_chosen, d_final_off, d_final_y, d_final_pos, d_col_thr,
         d_col_zero;
-    DevBuf d_seg_iv, d_seg_prev, d_rseg_c, d_cand_pn, d_cand_ll, d_cand_ln, d_prob_bs;
+    DevBuf d_cum, d_tile_tot, d_iv_tile0, d_seg_iv, d_seg_prev, d_rseg_c, d_cand_pn, d_cand_ll, d_cand_ln, d_prob_bs;
     // problems / arenas
     DevBuf d_prob_iv, d_prob_start, d_prob_n, d_prob_pair_off, d_prob_tri_off, d_prob_flags, d_prob_chain,
         d_prob_cov_off, d_prob_lane_lo, d_prob_lane_n, d_prob_work_base;
@@ -1552,12 +1612,13 @@ int alloc_arenas(fseg_ctx *c) {
     return FSEG_OK;
 }
 
-int launch_scan(fseg_ctx *c, const unsigned char *flags, i64 n, u64 *total_dev) {
+// prefix sums of a flag array: block sums + their exclusive scan; the third pass is fused with the consumer
+int launch_scan_counts(fseg_ctx *c, const unsigned char *flags, i64 n, u64 *total_dev, int *grid_out) {
     i64 nb = (n + kScanBlock - 1) / kScanBlock;
     int g = grid_for(nb, 1, 4096);
     hipLaunchKernelGGL(k_scan1, dim3(g), dim3(256), 0, c->stream, flags, n, c->d_bsum.as<int>());
     hipLaunchKernelGGL(k_scan2, dim3(1), dim3(256), 0, c->stream, c->d_bsum.as<int>(), nb, total_dev);
-    hipLaunchKernelGGL(k_scan3, dim3(g), dim3(256), 0, c->stream, flags, n, c->d_bsum.as<int>(), c->d_idx.as<int>());
+    *grid_out = g;
     return FSEG_OK;
 }
 
@@ -1580,12 +1641,17 @@ int enqueue_run(fseg_ctx *c) {
     int tile_grid = grid_for(c->n_tiles, 1, 8192);
     hipLaunchKernelGGL(k_smooth, dim3(tile_grid), dim3(256), 0, s, c->n_tiles, c->d_tile_iv.as<int>(),
                        c->d_tile_y0.as<int>(), c->d_pos_off.as<i64>(), c->d_y_raw.as<int>(), c->d_w_main.as<double>(),
-                       c->P.radius_main, c->d_y.as<double>(), c->d_flag.as<unsigned char>());
+                       c->P.radius_main, c->d_y.as<double>(), c->d_flag.as<unsigned char>(), c->d_cum.as<int>(), c->d_tile_tot.as<int>());
     mark(2);
     // S3a threshold
-    TRY(launch_scan(c, c->d_flag.as<unsigned char>(), NPOS, &st->n_vals));
-    hipLaunchKernelGGL(k_vgather, dim3(grid_for(NPOS, 256, 4096)), dim3(256), 0, s, NPOS, c->d_flag.as<unsigned char>(),
-                       c->d_idx.as<int>(), c->d_y.as<double>(), c->d_v.as<double>());
+    int scan_grid = 1;
+    TRY(launch_scan_counts(c, c->d_flag.as<unsigned char>(), NPOS, &st->n_vals, &scan_grid));
+    hipLaunchKernelGGL(k_scan_emit<kEmitValues>, dim3(scan_grid), dim3(256), 0, s, c->d_flag.as<unsigned char>(), NPOS,
+                       c->d_bsum.as<int>(), c->d_y.as<double>(), c->d_v.as<double>(), K, c->d_pos_off.as<i64>(),
+                       c->d_iv_start.as<int>(), (int *)nullptr, (int *)nullptr, (i64 *)nullptr);
+    hipLaunchKernelGGL(k_voff, dim3(grid_for(n_part + 1, 1, 2048)), dim3(64), 0, s, n_part, c->d_part_iv_off.as<i64>(),
+                       c->d_pos_off.as<i64>(), NPOS, c->d_flag.as<unsigned char>(), c->d_bsum.as<int>(), &st->n_vals,
+                       c->d_voff.as<i64>());
     hipLaunchKernelGGL(k_vplan, dim3(1), dim3(256), 0, s, n_part, c->d_part_iv_off.as<i64>(), c->d_pos_off.as<i64>(), NPOS,
                        c->d_idx.as<int>(), c->d_voff.as<i64>(), c->d_chunk_off.as<i64>(), st, c->chunk_cap);
     int chunk_grid = grid_for(c->chunk_cap, 1, 4096);
@@ -1602,9 +1668,9 @@ int enqueue_run(fseg_ctx *c) {
     HIP_TRY(c, hipMemsetAsync(c->d_flag.p, 0, (size_t)NPOS, s));
     hipLaunchKernelGGL(k_peaks, dim3(tile_grid), dim3(256), 0, s, c->n_tiles, c->d_tile_iv.as<int>(), c->d_tile_y0.as<int>(),
                        c->d_pos_off.as<i64>(), c->d_y.as<double>(), c->d_flag.as<unsigned char>());
-    TRY(launch_scan(c, c->d_flag.as<unsigned char>(), NPOS, &st->n_cand));
-    hipLaunchKernelGGL(k_pos_gather, dim3(tile_grid), dim3(256), 0, s, c->n_tiles, c->d_tile_iv.as<int>(),
-                       c->d_tile_y0.as<int>(), c->d_pos_off.as<i64>(), c->d_flag.as<unsigned char>(), c->d_idx.as<int>(),
+    TRY(launch_scan_counts(c, c->d_flag.as<unsigned char>(), NPOS, &st->n_cand, &scan_grid));
+    hipLaunchKernelGGL(k_scan_emit<kEmitPositions>, dim3(scan_grid), dim3(256), 0, s, c->d_flag.as<unsigned char>(), NPOS,
+                       c->d_bsum.as<int>(), (const double *)nullptr, (double *)nullptr, K, c->d_pos_off.as<i64>(),
                        c->d_iv_start.as<int>(), c->d_cand_y.as<int>(), (int *)nullptr, c->d_cand_off.as<i64>());
     hipLaunchKernelGGL(k_set_total, dim3(1), dim3(1), 0, s, c->d_cand_off.as<i64>(), K, &st->n_cand);
     mark(4);
@@ -1687,18 +1753,18 @@ int enqueue_run(fseg_ctx *c) {
     // S6
     HIP_TRY(c, hipMemsetAsync(c->d_final_flag.p, 0, (size_t)NPOS, s));
     hipLaunchKernelGGL(k_segments, dim3(grid_for(K, 1, 8192)), dim3(iv_threads), 0, s, K, c->d_pos_off.as<i64>(),
-                       c->d_cand_off.as<i64>(), c->d_cand_y.as<int>(), c->d_chosen.as<unsigned char>(),
-                       c->d_final_flag.as<unsigned char>(), c->d_rseg_c.as<int>(), c->d_seg_prev.as<int>(), st);
+                       c->d_cand_off.as<i64>(), c->d_cand_y.as<int>(), c->d_cum.as<int>(), c->d_tile_tot.as<int>(), c->d_iv_tile0.as<int>(),
+                       c->d_chosen.as<unsigned char>(), c->d_final_flag.as<unsigned char>(), c->d_rseg_c.as<int>(),
+                       c->d_seg_prev.as<int>(), st);
     hipLaunchKernelGGL(k_refine, dim3(2048), dim3(64), 0, s, st, c->d_seg_iv.as<int>(), c->d_rseg_c.as<int>(),
                        c->d_seg_prev.as<int>(), c->d_cand_y.as<int>(), c->d_pos_off.as<i64>(), c->d_y_raw.as<int>(),
                        c->d_w_refine.as<double>(), c->P.radius_refine, c->P.sigma, c->d_g.as<double>(), c->d_pk.as<int>(),
                        c->d_pf.as<unsigned char>(), c->d_kp.as<unsigned char>(), c->d_final_flag.as<unsigned char>());
     mark(9);
-    TRY(launch_scan(c, c->d_final_flag.as<unsigned char>(), NPOS, &st->n_final));
-    hipLaunchKernelGGL(k_pos_gather, dim3(tile_grid), dim3(256), 0, s, c->n_tiles, c->d_tile_iv.as<int>(),
-                       c->d_tile_y0.as<int>(), c->d_pos_off.as<i64>(), c->d_final_flag.as<unsigned char>(),
-                       c->d_idx.as<int>(), c->d_iv_start.as<int>(), c->d_final_y.as<int>(), c->d_final_pos.as<int>(),
-                       c->d_final_off.as<i64>());
+    TRY(launch_scan_counts(c, c->d_final_flag.as<unsigned char>(), NPOS, &st->n_final, &scan_grid));
+    hipLaunchKernelGGL(k_scan_emit<kEmitPositions>, dim3(scan_grid), dim3(256), 0, s, c->d_final_flag.as<unsigned char>(),
+                       NPOS, c->d_bsum.as<int>(), (const double *)nullptr, (double *)nullptr, K, c->d_pos_off.as<i64>(),
+                       c->d_iv_start.as<int>(), c->d_final_y.as<int>(), c->d_final_pos.as<int>(), c->d_final_off.as<i64>());
     hipLaunchKernelGGL(k_set_total, dim3(1), dim3(1), 0, s, c->d_final_off.as<i64>(), K, &st->n_final);
     mark(10);
     // S7
@@ -1819,7 +1885,7 @@ void fseg_destroy(fseg_ctx *c) {
                       &c->d_flag, &c->d_idx, &c->d_v, &c->d_bsum, &c->d_g, &c->d_pk, &c->d_pf, &c->d_kp, &c->d_final_flag,
                       &c->d_voff, &c->d_chunk_off, &c->d_csum, &c->d_mean, &c->d_thr, &c->d_label_off, &c->d_part_has2, &c->d_rb_part, &c->d_rb_r0, &c->d_cand_off,
                       &c->d_cand_y, &c->d_fixed0, &c->d_added, &c->d_fixed, &c->d_chosen, &c->d_final_off, &c->d_final_y,
-                      &c->d_final_pos, &c->d_col_thr, &c->d_col_zero, &c->d_seg_iv, &c->d_seg_prev, &c->d_rseg_c, &c->d_cand_pn, &c->d_cand_ll, &c->d_cand_ln, &c->d_prob_bs, &c->d_prob_iv, &c->d_prob_start,
+                      &c->d_final_pos, &c->d_col_thr, &c->d_col_zero, &c->d_cum, &c->d_tile_tot, &c->d_iv_tile0, &c->d_seg_iv, &c->d_seg_prev, &c->d_rseg_c, &c->d_cand_pn, &c->d_cand_ll, &c->d_cand_ln, &c->d_prob_bs, &c->d_prob_iv, &c->d_prob_start,
                       &c->d_prob_n, &c->d_prob_pair_off, &c->d_prob_tri_off, &c->d_prob_flags, &c->d_prob_chain, &c->d_prob_cov_off,
                       &c->d_prob_lane_lo, &c->d_prob_lane_n, &c->d_prob_work_base, &c->d_work_active, &c->d_cov,
                       &c->d_work_prob, &c->d_work_chunk, &c->d_cls_items, &c->d_pair_thr, &c->d_amb, &c->d_out, &c->d_labels, &c->d_status, &c->d_tacc};
@@ -1930,9 +1996,10 @@ int fseg_upload(fseg_ctx *c, const fseg_batch *b) {
             }
         }
     }
-    std::vector<int> tile_iv, tile_y0;
+    std::vector<int> tile_iv, tile_y0, iv_tile0((size_t)K);
     for (i64 k = 0; k < K; ++k) {
         i64 len = pos_off[k + 1] - pos_off[k];
+        iv_tile0[(size_t)k] = (int)tile_iv.size();
         for (i64 y = 0; y < len; y += kSmoothTile) { tile_iv.push_back((int)k); tile_y0.push_back((int)y); }
     }
     c->n_part = np; c->K = K; c->R = R; c->I = I; c->NPOS = NPOS; c->LANES = lanes; c->expanded = expanded;
@@ -1966,11 +2033,13 @@ int fseg_upload(fseg_ctx *c, const fseg_batch *b) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     TRY(ensure(c, c->d_part_has2, ((size_t)np + 1) * 4));
+    TRY(upload_vec(c, c->d_iv_tile0, iv_tile0.data(), iv_tile0.size()));
+    TRY(ensure(c, c->d_tile_tot, (tile_iv.size() + 1) * 4));
     TRY(upload_vec(c, c->d_tile_iv, tile_iv.data(), tile_iv.size()));
     TRY(upload_vec(c, c->d_tile_y0, tile_y0.data(), tile_y0.size()));
     // position-sized work buffers
-    size_t np8 = (size_t)NPOS + 16;
-    TRY(ensure(c, c->d_y_raw, np8 * 4)); TRY(ensure(c, c->d_y, np8 * 8)); TRY(ensure(c, c->d_flag, np8));
+    size_t np8 = (size_t)NPOS + 64;
+    TRY(ensure(c, c->d_y_raw, np8 * 4)); TRY(ensure(c, c->d_cum, np8 * 4)); TRY(ensure(c, c->d_y, np8 * 8)); TRY(ensure(c, c->d_flag, np8));
     TRY(ensure(c, c->d_idx, np8 * 4)); TRY(ensure(c, c->d_v, np8 * 8));
     TRY(ensure(c, c->d_bsum, ((size_t)(NPOS / kScanBlock) + 2) * 4));
     TRY(ensure(c, c->d_g, np8 * 8)); TRY(ensure(c, c->d_pk, np8 * 4)); TRY(ensure(c, c->d_pf, np8)); TRY(ensure(c, c->d_kp, np8));
