@@ -892,6 +892,101 @@ __global__ void __launch_bounds__(kLaneChunk) k_cov(Status *st, ProblemArrays pr
 // At the end of the work item the non-zero counters go to the global table with one atomic each.
 // Reads with multiplicity W are expanded into W lanes on upload, so every lane has weight 1.
 // ---------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------
+// S5c  DP over one problem   (dp() :532-558, top level :560-566, backtrack :592-594)
+// D(a,b,c) = in_ab + out_abc + M(b,c),  M(b,c) = max_{c2>c} D(b,c,c2) (first maximiser, strict >),
+// M(b,end) := in_b,end closes the chain (base case :545-548).  The inner maximum depends only on (b,c), so
+// filling M for c descending is O(n^3) and gives the reference's O(n^4) recursion's result
+// (SURVEY.md App. A.7).  For a fixed c the lanes are the b < c (so the out(b,c,c2) reads of a wave are
+// contiguous) and the waves of the workgroup split the c2 > c.  All tables live in LDS:
+//   out_s[rank(a,b,c)] counts, in_s[pair] = -(ambiguous reads), M / A (argmax) per pair, cy_s = candidate y.
+// Every thread of the workgroup must call it; returns the number of backtracked triples (valid on thread 0)
+// and marks the chosen candidates.
+// ---------------------------------------------------------------------------------------------
+template <int T, typename OutT>
+__device__ int dp_solve(int n, const OutT *out_s, const int *in_s, i64 *M, unsigned char *A, const int *cy_s, int support,
+                        i64 *part_v /* T */, unsigned char *part_a /* T */, int *top_key /* T/64 */,
+                        unsigned char *chosen /* + first candidate of the problem */) {
+    constexpr int NW = T / 64;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int end = n - 1;
+    const int npairs = n * (n - 1) / 2;
+#define FSEG_IN(a, b) ((i64)in_s[(b) * ((b) - 1) / 2 + (a)])
+#define FSEG_M(a, b) M[(b) * ((b) - 1) / 2 + (a)]
+    for (int b = threadIdx.x; b < end; b += T) { FSEG_M(b, end) = FSEG_IN(b, end); A[end * (end - 1) / 2 + b] = 255; }
+    __syncthreads();
+    for (int c = end - 1; c >= 2; --c) {
+        int b = 1 + lane;
+        i64 best = kNegInf; int arg = 255;
+        if (b < c && cy_s[c] - cy_s[b] >= 5) {
+            i64 in_bc = FSEG_IN(b, c);
+            int base = c * (c - 1) / 2 + b;
+            const int cyc = cy_s[c];
+            for (int c2 = c + 1 + wave; c2 <= end; c2 += NW) {
+                i64 tail = FSEG_M(c, c2);
+                unsigned o = out_s[c2 * (c2 - 1) * (c2 - 2) / 6 + base];
+                bool ok = (cy_s[c2] - cyc >= 5) & (tail != kNegInf) & ((i64)o >= (i64)support);   // :526-527, :540
+                i64 cur = ok ? in_bc + (i64)o + tail : kNegInf;
+                bool take = cur > best;
+                best = take ? cur : best; arg = take ? c2 : arg;
+            }
+        }
+        part_v[wave * 64 + lane] = best; part_a[wave * 64 + lane] = (unsigned char)arg;
+        __syncthreads();
+        if (wave == 0 && b < c) {
+            // first maximiser over all c2: larger value wins, equal values keep the smaller c2
+            i64 bv = part_v[lane]; int ba = part_a[lane];
+            for (int w = 1; w < NW; ++w) {
+                i64 v = part_v[w * 64 + lane]; int a2 = part_a[w * 64 + lane];
+                if (v > bv || (v == bv && v != kNegInf && a2 < ba)) { bv = v; ba = a2; }
+            }
+            FSEG_M(b, c) = bv; A[c * (c - 1) / 2 + b] = (unsigned char)ba;
+        }
+        __syncthreads();
+    }
+    // top level (a = start): max over (j,k) of in_0j + out_0jk + M(j,k), first maximiser in (j, k) order,
+    // taken only if strictly greater than "no cut" = in(0,end)   (:560-566)
+    i64 bv = kNegInf; int bkey = 0x7fffffff;
+    for (int q = threadIdx.x; q < npairs; q += T) {
+        int j, kx;
+        pair_decode(q, &j, &kx);                    // j < kx
+        if (j < 1) continue;
+        if (cy_s[j] - cy_s[0] < 5 || cy_s[kx] - cy_s[j] < 5) continue;
+        i64 tail = FSEG_M(j, kx);
+        unsigned o = out_s[kx * (kx - 1) * (kx - 2) / 6 + j * (j - 1) / 2 + 0];
+        if (tail == kNegInf || (i64)o < (i64)support) continue;
+        i64 cur = FSEG_IN(0, j) + (i64)o + tail;
+        int key = j * 64 + kx;
+        if (cur > bv || (cur == bv && key < bkey)) { bv = cur; bkey = key; }
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        i64 ov = __shfl_xor(bv, d); int ok2 = __shfl_xor(bkey, d);
+        if (ov > bv || (ov == bv && ok2 < bkey)) { bv = ov; bkey = ok2; }
+    }
+    __syncthreads();
+    if (lane == 0) { part_v[wave] = bv; top_key[wave] = bkey; }
+    __syncthreads();
+    int chain = 0;
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < NW; ++w)
+            if (part_v[w] > bv || (part_v[w] == bv && top_key[w] < bkey)) { bv = part_v[w]; bkey = top_key[w]; }
+        if (bv != kNegInf && bv > FSEG_IN(0, end)) {
+            int j = bkey >> 6, k = bkey & 63;
+            chosen[0] = 1;
+            for (;;) {
+                chosen[j] = 1; chosen[k] = 1; ++chain;
+                if (k == end) break;
+                int k2 = A[k * (k - 1) / 2 + j];
+                if (k2 == 255) break;
+                j = k; k = k2;
+            }
+        }
+    }
+#undef FSEG_IN
+#undef FSEG_M
+    return chain;
+}
+
 // pair q = j*(j-1)/2 + i  <->  (i, j); independent of the problem size, built once per context
 __device__ unsigned short g_pair_ij[kNMax * (kNMax - 1) / 2];
 __global__ void k_init_pair_table() {
@@ -902,6 +997,7 @@ __global__ void k_init_pair_table() {
     }
 }
 
+constexpr bool kFuseDp = false;
 template <int NM> struct ScoreCfg {
     static constexpr int kPairs = NM * (NM - 1) / 2;
     static constexpr int kTri = NM * (NM - 1) * (NM - 2) / 6;
@@ -929,24 +1025,29 @@ __global__ void __launch_bounds__(ScoreCfg<NM>::kThreads) k_score(Status *st, in
                                                                   const int *cand_y, const unsigned char *work_active,
                                                                   const unsigned *cov_g, i64 cov_cap, const int2 *pair_thr,
                                                                   i64 pair_cap, unsigned *out_g, i64 tri_cap,
-                                                                  unsigned *amb_g FSEG_TPARAM) {
+                                                                  unsigned *amb_g, const int *iv_part,
+                                                                  const i64 *part_lane_off, int support,
+                                                                  unsigned char *chosen FSEG_TPARAM) {
     using C = ScoreCfg<NM>;
     constexpr int T = C::kThreads;
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ int cy_s[NM + 4];
     __shared__ u64 work_s;
+    __shared__ int top_key[8];
     uint4 *planes = reinterpret_cast<uint4 *>(smem);                                         // kPairs * 16 B
     unsigned *cov = reinterpret_cast<unsigned *>(smem + (size_t)C::kPairs * 16);             // kSub * kCovStride * 4 B
     unsigned short *pair_ij = reinterpret_cast<unsigned short *>(cov + kSub * C::kCovStride);   // kPairs * 2 B
     unsigned short *out16 = pair_ij + ((C::kPairs + 7) & ~7);                                // kTri * 2 B
     for (int q = threadIdx.x; q < C::kPairs; q += T) pair_ij[q] = g_pair_ij[q];
-    i64 cls_base = (cls >= 1 ? (i64)st->cls_work[0] : 0) + (cls >= 2 ? (i64)st->cls_work[1] : 0);
-    i64 n_items = (i64)st->cls_work[cls];
+    // cls < 0: this launch takes the work items of every size class (small batches: one launch instead of three)
+    i64 cls_base = cls < 0 ? 0 : (cls >= 1 ? (i64)st->cls_work[0] : 0) + (cls >= 2 ? (i64)st->cls_work[1] : 0);
+    i64 n_items = cls < 0 ? (i64)st->n_work : (i64)st->cls_work[cls];
+    u64 *queue = &st->cls_queue[cls < 0 ? 0 : cls];
     if ((i64)st->n_work > work_cap || (i64)st->n_prob > prob_cap) n_items = 0;   // lists incomplete: sizing run
     FSEG_T0;
     for (;;) {
         __syncthreads();
-        if (threadIdx.x == 0) work_s = atomicAdd(&st->cls_queue[cls], 1ULL);
+        if (threadIdx.x == 0) work_s = atomicAdd(queue, 1ULL);
         __syncthreads();
         i64 wi = (i64)work_s;
         FSEG_TICK(0);
@@ -964,7 +1065,13 @@ __global__ void __launch_bounds__(ScoreCfg<NM>::kThreads) k_score(Status *st, in
         int lanes_here = pr.lane_n[p] - chunk * kLaneChunk;
         if (lanes_here > kLaneChunk) lanes_here = kLaneChunk;
         if (lanes_here < kLaneChunk) active &= (1u << ((lanes_here + kSub - 1) / kSub)) - 1u;
-        if (active == 0) continue;                       // no read of this chunk touches the window
+        // (a problem whose reads fit one work item could run its DP right here from the LDS counters; measured
+        // slower than the separate DP kernel on MI355X, so it is kept behind a compile-time switch)
+        const bool single = kFuseDp && pr.lane_n[p] <= kLaneChunk;
+        if (active == 0) {                               // no read of this chunk touches the window: nothing to count,
+            if (single && threadIdx.x == 0) atomicOr(&pr.flags[p], 2);   // and a problem without evidence makes no cut
+            continue;
+        }
         const int *cy = cand_y + cand_off[pr.iv[p]] + pr.start[p];
         for (int j = threadIdx.x; j < n; j += T) cy_s[j] = cy[j];
         for (int x = threadIdx.x; x < ntri; x += T) out16[x] = 0;
@@ -1049,6 +1156,31 @@ __global__ void __launch_bounds__(ScoreCfg<NM>::kThreads) k_score(Status *st, in
             FSEG_TICK(4);
             sub = next_sub;
         }
+        if (single) {
+            // ---- fused DP: the counters of the whole problem are in LDS; the plane / coverage region is free now
+            i64 *M = reinterpret_cast<i64 *>(smem);
+            int *in_s = reinterpret_cast<int *>(M + C::kPairs);
+            unsigned char *A = reinterpret_cast<unsigned char *>(in_s + C::kPairs);
+            i64 *part_v = reinterpret_cast<i64 *>(smem + (((size_t)C::kPairs * 13 + 7) & ~(size_t)7));
+            unsigned char *part_a = reinterpret_cast<unsigned char *>(part_v + T);
+            static_assert((((size_t)C::kPairs * 13 + 7) & ~(size_t)7) + (size_t)T * 9 <=
+                          (size_t)C::kPairs * 16 + (size_t)kSub * C::kCovStride * 4, "DP tables must fit the plane region");
+            int k_iv = pr.iv[p];
+            int part = iv_part[k_iv];
+            const i64 outside = (part_lane_off[part + 1] - part_lane_off[part]) - pr.lane_n[p];
+#pragma unroll
+            for (int s = 0; s < C::kSlots; ++s) {
+                int q = s * T + threadIdx.x;
+                if (q < npairs)
+                    in_s[q] = -(int)((i64)amb_acc[s] + ((zero_ambiguous && pair_thr[poff + q].y < 0) ? outside : 0));
+            }
+            __syncthreads();
+            int chain = dp_solve<T>(n, out16, in_s, M, A, cy_s, support, part_v, part_a, top_key,
+                                    chosen + cand_off[k_iv] + pr.start[p]);
+            if (threadIdx.x == 0) { pr.chain[p] = chain; atomicOr(&pr.flags[p], 2); }
+            FSEG_TICK(5);
+            continue;
+        }
         // ---- flush ---------------------------------------------------------------------------------
         for (int x = threadIdx.x; x < ntri; x += T) {
             unsigned v = out16[x];
@@ -1063,23 +1195,14 @@ __global__ void __launch_bounds__(ScoreCfg<NM>::kThreads) k_score(Status *st, in
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// S5c  DP over one problem   (dp() :532-558, top level :560-566, backtrack :592-594)
-// D(a,b,c) = in_ab + out_abc + M(b,c),  M(b,c) = max_{c2>c} D(b,c,c2) (first maximiser, strict >),
-// M(b,end) := in_b,end closes the chain (base case :545-548).  The inner maximum depends only on (b,c), so
-// filling M for c descending is O(n^3) and gives the reference's O(n^4) recursion's result
-// (SURVEY.md App. A.7).  One wave per problem; for a fixed c the lanes are the b < c, so the
-// out(b,c,c2) reads of a wave are contiguous.
-// in_ab = -(ambiguous reads of pair (a,b)); reads outside the problem's read range have no coverage
-// in the window and are ambiguous only for pairs whose lo threshold is negative.
-// ---------------------------------------------------------------------------------------------
 template <int NM>
 __global__ void __launch_bounds__(256) k_dp(Status *st, int n_lo, u64 *queue, ProblemArrays pr, i64 prob_cap,
                                             const i64 *cand_off, const int *cand_y, const int *iv_part,
                                             const i64 *part_lane_off, const unsigned *out_g, i64 tri_cap,
                                             const unsigned *amb_g, const int2 *pair_thr, i64 pair_cap, int support,
                                             unsigned char *chosen) {
-    // handles problems with n_lo < n <= NM; the out table of the problem is staged in LDS first
+    // handles problems with n_lo < n <= NM that the scoring kernel did not finish itself (more than one
+    // work item); the out table of the problem is staged in LDS first
     constexpr int kTri = NM * (NM - 1) * (NM - 2) / 6, kPairs = NM * (NM - 1) / 2;
     extern __shared__ __align__(16) unsigned char smem[];
     i64 *M = reinterpret_cast<i64 *>(smem);                          // M(b,c), b < c, at c*(c-1)/2 + b
@@ -1091,7 +1214,6 @@ __global__ void __launch_bounds__(256) k_dp(Status *st, int n_lo, u64 *queue, Pr
     __shared__ i64 part_v[256];
     __shared__ unsigned char part_a[256];
     __shared__ int top_key[4];
-    int lane = lane_id();
     i64 n_prob = (i64)st->n_prob;
     if (n_prob > prob_cap) return;                                  // sizing run
     for (;;) {
@@ -1101,7 +1223,7 @@ __global__ void __launch_bounds__(256) k_dp(Status *st, int n_lo, u64 *queue, Pr
         i64 p = (i64)work_s;
         if (p >= n_prob) break;
         int n = pr.n[p];
-        if (n <= n_lo || n > NM) continue;
+        if (n <= n_lo || n > NM || (pr.flags[p] & 2)) continue;
         i64 poff = pr.pair_off[p], toff = pr.tri_off[p];
         int npairs = n * (n - 1) / 2, ntri = n * (n - 1) * (n - 2) / 6;
         if (poff + npairs > pair_cap || toff + ntri > tri_cap) continue;
@@ -1115,84 +1237,8 @@ __global__ void __launch_bounds__(256) k_dp(Status *st, int n_lo, u64 *queue, Pr
         for (int q = threadIdx.x; q < npairs; q += blockDim.x)
             in_s[q] = -(int)((i64)amb_g[poff + q] + ((zamb && pair_thr[poff + q].y < 0) ? outside : 0));
         __syncthreads();
-        const int end = n - 1;
-        const int wave = threadIdx.x >> 6;
-#define FSEG_IN(a, b) ((i64)in_s[(b) * ((b) - 1) / 2 + (a)])
-#define FSEG_M(a, b) M[(b) * ((b) - 1) / 2 + (a)]
-        for (int b = threadIdx.x; b < end; b += blockDim.x) { FSEG_M(b, end) = FSEG_IN(b, end); A[end * (end - 1) / 2 + b] = 255; }
-        __syncthreads();
-        // c descending; for a fixed c lane = b in [1, c) and the four waves split the c2 > c candidates
-        for (int c = end - 1; c >= 2; --c) {
-            int b = 1 + lane;
-            i64 best = kNegInf; int arg = 255;
-            if (b < c && cy_s[c] - cy_s[b] >= 5) {
-                i64 in_bc = FSEG_IN(b, c);
-                int base = c * (c - 1) / 2 + b;
-                const int cyc = cy_s[c];
-                for (int c2 = c + 1 + wave; c2 <= end; c2 += 4) {
-                    i64 tail = FSEG_M(c, c2);
-                    unsigned o = out_s[c2 * (c2 - 1) * (c2 - 2) / 6 + base];
-                    bool ok = (cy_s[c2] - cyc >= 5) & (tail != kNegInf) & ((i64)o >= (i64)support);   // :526-527, :540
-                    i64 cur = ok ? in_bc + (i64)o + tail : kNegInf;
-                    bool take = cur > best;
-                    best = take ? cur : best; arg = take ? c2 : arg;
-                }
-            }
-            part_v[wave * 64 + lane] = best; part_a[wave * 64 + lane] = (unsigned char)arg;
-            __syncthreads();
-            if (wave == 0 && b < c) {
-                // first maximiser over all c2: larger value wins, equal values keep the smaller c2
-                i64 bv = part_v[lane]; int ba = part_a[lane];
-                for (int w = 1; w < 4; ++w) {
-                    i64 v = part_v[w * 64 + lane]; int a2 = part_a[w * 64 + lane];
-                    if (v > bv || (v == bv && v != kNegInf && a2 < ba)) { bv = v; ba = a2; }
-                }
-                FSEG_M(b, c) = bv; A[c * (c - 1) / 2 + b] = (unsigned char)ba;
-            }
-            __syncthreads();
-        }
-        // top level (a = start): max over (j,k) of in_0j + out_0jk + M(j,k), first maximiser in (j, k) order,
-        // taken only if strictly greater than "no cut" = in(0,end)   (:560-566)
-        {
-            i64 bv = kNegInf; int bkey = 0x7fffffff;
-            for (int q = threadIdx.x; q < npairs; q += blockDim.x) {
-                int j, kx;
-                pair_decode(q, &j, &kx);                    // j < kx
-                if (j < 1) continue;
-                if (cy_s[j] - cy_s[0] < 5 || cy_s[kx] - cy_s[j] < 5) continue;
-                i64 tail = FSEG_M(j, kx);
-                unsigned o = out_s[kx * (kx - 1) * (kx - 2) / 6 + j * (j - 1) / 2 + 0];
-                if (tail == kNegInf || (i64)o < (i64)support) continue;
-                i64 cur = FSEG_IN(0, j) + (i64)o + tail;
-                int key = j * 64 + kx;
-                if (cur > bv || (cur == bv && key < bkey)) { bv = cur; bkey = key; }
-            }
-            for (int d = 32; d >= 1; d >>= 1) {
-                i64 ov = __shfl_xor(bv, d); int ok2 = __shfl_xor(bkey, d);
-                if (ov > bv || (ov == bv && ok2 < bkey)) { bv = ov; bkey = ok2; }
-            }
-            if (lane == 0) { part_v[wave] = bv; top_key[wave] = bkey; }
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                for (int w = 1; w < 4; ++w)
-                    if (part_v[w] > bv || (part_v[w] == bv && top_key[w] < bkey)) { bv = part_v[w]; bkey = top_key[w]; }
-                int chain = 0;
-                if (bv != kNegInf && bv > FSEG_IN(0, end)) {
-                    int j = bkey >> 6, k = bkey & 63;
-                    chosen[c0] = 1;
-                    for (;;) {
-                        chosen[c0 + j] = 1; chosen[c0 + k] = 1; ++chain;
-                        if (k == end) break;
-                        int k2 = A[k * (k - 1) / 2 + j];
-                        if (k2 == 255) break;
-                        j = k; k = k2;
-                    }
-                }
-                pr.chain[p] = chain;
-            }
-        }
-#undef FSEG_IN
-#undef FSEG_M
+        int chain = dp_solve<256>(n, out_s, in_s, M, A, cy_s, support, part_v, part_a, top_key, chosen + c0);
+        if (threadIdx.x == 0) pr.chain[p] = chain;
     }
 }
 
@@ -1524,6 +1570,7 @@ struct fseg_ctx {
     DevBuf d_status, d_tacc;
     Status *h_status = nullptr;   // pinned
     bool profiling = false;
+    bool small_batch = false;   // few DP problems in the previous run: merge the per-size-class launches
     hipEvent_t ev[ST_COUNT + 1] = {};
     float stage_ms[ST_COUNT] = {};
     int score_lds = 0;
@@ -1729,25 +1776,33 @@ int enqueue_run(fseg_ctx *c) {
                            c->d_work_prob.as<int>(), c->d_work_chunk.as<int>(), c->work_cap, c->d_cand_off.as<i64>(),   \
                            c->d_cand_y.as<int>(), c->d_work_active.as<unsigned char>(), c->d_cov.as<unsigned>(),        \
                            c->cov_cap, c->d_pair_thr.as<int2>(), c->pair_cap, c->d_out.as<unsigned>(), c->tri_cap,      \
-                           c->d_amb.as<unsigned>() FSEG_TARG)
-        FSEG_LAUNCH_SCORE(kNMax, 2, 256);        // big problems first: they are the long poles
-        FSEG_LAUNCH_SCORE(kClsMid, 1, 1280);
-        FSEG_LAUNCH_SCORE(kClsSmall, 0, 2048);
+                           c->d_amb.as<unsigned>(), c->d_iv_part.as<int>(), c->d_part_lane_off.as<i64>(),                \
+                           c->P.min_read_support_outside, c->d_chosen.as<unsigned char>() FSEG_TARG)
+        if (c->small_batch) {
+            FSEG_LAUNCH_SCORE(kNMax, -1, 256);       // few work items: one launch for every size class
+        } else {
+            FSEG_LAUNCH_SCORE(kNMax, 2, 256);        // big problems first: they are the long poles
+            FSEG_LAUNCH_SCORE(kClsMid, 1, 1280);
+            FSEG_LAUNCH_SCORE(kClsSmall, 0, 2048);
+        }
 #undef FSEG_LAUNCH_SCORE
     }
     mark(7);
     if (c->prob_cap > 0) {
         int dp_grid = grid_for(c->prob_cap, 1, 1024);
-        hipLaunchKernelGGL(k_dp<kDpSmall>, dim3(dp_grid), dim3(256), dp_lds_bytes<kDpSmall>(), s, st, 0, &st->dp_queue, pr,
-                           c->prob_cap, c->d_cand_off.as<i64>(), c->d_cand_y.as<int>(), c->d_iv_part.as<int>(),
-                           c->d_part_lane_off.as<i64>(), c->d_out.as<unsigned>(), c->tri_cap, c->d_amb.as<unsigned>(),
-                           c->d_pair_thr.as<int2>(), c->pair_cap, c->P.min_read_support_outside,
-                           c->d_chosen.as<unsigned char>());
-        hipLaunchKernelGGL(k_dp<kNMax>, dim3(dp_grid < 256 ? dp_grid : 256), dim3(256), dp_lds_bytes<kNMax>(), s, st, kDpSmall,
-                           &st->dp_queue2, pr, c->prob_cap, c->d_cand_off.as<i64>(), c->d_cand_y.as<int>(),
-                           c->d_iv_part.as<int>(), c->d_part_lane_off.as<i64>(), c->d_out.as<unsigned>(), c->tri_cap,
-                           c->d_amb.as<unsigned>(), c->d_pair_thr.as<int2>(), c->pair_cap, c->P.min_read_support_outside,
-                           c->d_chosen.as<unsigned char>());
+#define FSEG_LAUNCH_DP(NMV, NLO, QUEUE, MAXWG)                                                                           \
+        hipLaunchKernelGGL(k_dp<NMV>, dim3(dp_grid < (MAXWG) ? dp_grid : (MAXWG)), dim3(256), dp_lds_bytes<NMV>(), s, st, NLO,   \
+                           QUEUE, pr, c->prob_cap, c->d_cand_off.as<i64>(), c->d_cand_y.as<int>(), c->d_iv_part.as<int>(),     \
+                           c->d_part_lane_off.as<i64>(), c->d_out.as<unsigned>(), c->tri_cap, c->d_amb.as<unsigned>(),         \
+                           c->d_pair_thr.as<int2>(), c->pair_cap, c->P.min_read_support_outside,                              \
+                           c->d_chosen.as<unsigned char>())
+        if (c->small_batch) {
+            FSEG_LAUNCH_DP(kNMax, 0, &st->dp_queue2, 256);
+        } else {
+            FSEG_LAUNCH_DP(kDpSmall, 0, &st->dp_queue, 1024);
+            FSEG_LAUNCH_DP(kNMax, kDpSmall, &st->dp_queue2, 256);
+        }
+#undef FSEG_LAUNCH_DP
     }
     mark(8);
     // S6
@@ -1805,6 +1860,7 @@ int finish_run(fseg_ctx *c) {
         if (!need) {
             c->pending = false;
             c->ran = true;
+            c->small_batch = (i64)s.n_prob <= 256 && (i64)s.n_work <= 1024;
             if (c->profiling)
                 for (int i = 0; i < ST_COUNT; ++i) (void)hipEventElapsedTime(&c->stage_ms[i], c->ev[i], c->ev[i + 1]);
             if (s.err & kErrExonInterval) return fail(c, FSEG_ERR_INPUT, "an exon does not lie inside one tint interval (py/freddie_segment.py:668)");
