@@ -50,6 +50,7 @@ enum : unsigned {
     kErrOverflowProblems = 128u,
     kErrOverflowChunks = 256u,
     kErrOverflowCov = 512u,
+    kErrOverflowNm = 1024u,    // a problem is larger than the LDS carve-up this launch was sized for
 };
 
 struct Status {
@@ -66,6 +67,8 @@ struct Status {
     u64 n_final;
     u64 label_bytes;
     u64 cov_used;      // elements of the coverage arena
+    unsigned max_n;    // largest DP problem of this run
+    unsigned pad2;
     u64 cls_work[3];   // work items per problem-size class (n <= 16, <= 32, <= kNMax)
     u64 cls_queue[3];  // dynamic work counters of the scoring kernels
     u64 dp_queue;
@@ -611,6 +614,7 @@ __global__ void k_fix(i64 K, const i64 *pos_off, const int *iv_part, const i64 *
                 fixed[c0 + c] = f; chosen[c0 + c] = f;
                 int n = (f && prev >= 0 && c - prev + 1 >= 3) ? c - prev + 1 : 0;
                 if (n > kNMax) atomicOr(&st->err, kErrProblemTooLarge);
+                if (n > 0) atomicMax(&st->max_n, (unsigned)n);
                 cand_pn[c0 + c] = n;
             }
         }
@@ -1008,6 +1012,10 @@ template <int NM> struct ScoreCfg {
     static constexpr size_t kLds = (size_t)kPairs * 16 + (size_t)kSub * kCovStride * 4 + (size_t)((kPairs + 7) & ~7) * 2 +
                                    (size_t)((kTri + 7) & ~7) * 2;
 };
+inline size_t score_lds_for(int nm, int cov_stride) {
+    size_t pairs = (size_t)nm * (nm - 1) / 2, tri = (size_t)nm * (nm - 1) * (nm - 2) / 6;
+    return ((pairs * 16 + (size_t)kSub * cov_stride * 4 + ((pairs + 7) & ~(size_t)7) * 2 + ((tri + 7) & ~(size_t)7) * 2) + 15) & ~(size_t)15;
+}
 
 #ifdef FSEG_SCORE_TIMING
 #define FSEG_TPARAM , unsigned long long *tacc
@@ -1019,7 +1027,7 @@ template <int NM> struct ScoreCfg {
 #define FSEG_TICK(i)
 #endif
 template <int NM>
-__global__ void __launch_bounds__(ScoreCfg<NM>::kThreads) k_score(Status *st, int cls, ProblemArrays pr, i64 prob_cap,
+__global__ void __launch_bounds__(ScoreCfg<NM>::kThreads) k_score(Status *st, int cls, int nm, ProblemArrays pr, i64 prob_cap,
                                                                   const int *cls_items, const int *work_prob,
                                                                   const int *work_chunk, i64 work_cap, const i64 *cand_off,
                                                                   const int *cand_y, const unsigned char *work_active,
@@ -1034,11 +1042,15 @@ __global__ void __launch_bounds__(ScoreCfg<NM>::kThreads) k_score(Status *st, in
     __shared__ int cy_s[NM + 4];
     __shared__ u64 work_s;
     __shared__ int top_key[8];
-    uint4 *planes = reinterpret_cast<uint4 *>(smem);                                         // kPairs * 16 B
-    unsigned *cov = reinterpret_cast<unsigned *>(smem + (size_t)C::kPairs * 16);             // kSub * kCovStride * 4 B
-    unsigned short *pair_ij = reinterpret_cast<unsigned short *>(cov + kSub * C::kCovStride);   // kPairs * 2 B
-    unsigned short *out16 = pair_ij + ((C::kPairs + 7) & ~7);                                // kTri * 2 B
-    for (int q = threadIdx.x; q < C::kPairs; q += T) pair_ij[q] = g_pair_ij[q];
+    // LDS carve-up for problems of at most nm candidates (nm <= NM is chosen by the host from the previous run's
+    // largest problem, so that a batch of moderately sized problems gets more workgroups per CU)
+    const int rt_pairs = nm * (nm - 1) / 2;
+    constexpr int rt_stride = C::kCovStride;      // compile-time row stride: LDS addresses fold into instruction offsets
+    uint4 *planes = reinterpret_cast<uint4 *>(smem);                                         // rt_pairs * 16 B
+    unsigned *cov = reinterpret_cast<unsigned *>(smem + (size_t)rt_pairs * 16);              // kSub * rt_stride * 4 B
+    unsigned short *pair_ij = reinterpret_cast<unsigned short *>(cov + kSub * rt_stride);    // rt_pairs * 2 B
+    unsigned short *out16 = pair_ij + ((rt_pairs + 7) & ~7);                                 // C(nm,3) * 2 B
+    for (int q = threadIdx.x; q < rt_pairs; q += T) pair_ij[q] = g_pair_ij[q];
     // cls < 0: this launch takes the work items of every size class (small batches: one launch instead of three)
     i64 cls_base = cls < 0 ? 0 : (cls >= 1 ? (i64)st->cls_work[0] : 0) + (cls >= 2 ? (i64)st->cls_work[1] : 0);
     i64 n_items = cls < 0 ? (i64)st->n_work : (i64)st->cls_work[cls];
@@ -1059,7 +1071,8 @@ __global__ void __launch_bounds__(ScoreCfg<NM>::kThreads) k_score(Status *st, in
         i64 poff = pr.pair_off[p], toff = pr.tri_off[p];
         i64 coff = pr.cov_off[p] + (i64)chunk * kLaneChunk * n;
         int npairs = n * (n - 1) / 2, ntri = n * (n - 1) * (n - 2) / 6;
-        if (n > NM || poff + npairs > pair_cap || toff + ntri > tri_cap || coff + (i64)kLaneChunk * n > cov_cap) continue;
+        if (n > nm) { if (threadIdx.x == 0) atomicOr(&st->err, kErrOverflowNm); continue; }
+        if (poff + npairs > pair_cap || toff + ntri > tri_cap || coff + (i64)kLaneChunk * n > cov_cap) continue;
         bool zero_ambiguous = (pr.flags[p] & 1) != 0;
         unsigned active = zero_ambiguous ? 0xfu : work_active[w];
         int lanes_here = pr.lane_n[p] - chunk * kLaneChunk;
@@ -1096,7 +1109,7 @@ __global__ void __launch_bounds__(ScoreCfg<NM>::kThreads) k_score(Status *st, in
 #pragma unroll
             for (int e = 0; e < C::kStage; ++e) {
                 int x = e * T + threadIdx.x;
-                if (x < tile_words) cov[(x & 63) * C::kCovStride + (x >> 6)] = stage[e];
+                if (x < tile_words) cov[(x & 63) * rt_stride + (x >> 6)] = stage[e];
             }
             unsigned rest = active & ~((2u << sub) - 1u);
             int next_sub = rest ? __ffs(rest) - 1 : -1;
@@ -1120,12 +1133,12 @@ __global__ void __launch_bounds__(ScoreCfg<NM>::kThreads) k_score(Status *st, in
                     int2 th = pair_thr[poff + q];
                     unsigned y0 = 0, z0 = 0, y1 = 0, z1 = 0;
                     for (int b = 0; b < 32; ++b) {
-                        int d = (int)(cov[b * C::kCovStride + j] - cov[b * C::kCovStride + i]);
+                        int d = (int)(cov[b * rt_stride + j] - cov[b * rt_stride + i]);
                         y0 |= (unsigned)(d >= th.x) << b;
                         z0 |= (unsigned)(d <= th.y) << b;
                     }
                     for (int b = 0; b < 32; ++b) {
-                        int d = (int)(cov[(32 + b) * C::kCovStride + j] - cov[(32 + b) * C::kCovStride + i]);
+                        int d = (int)(cov[(32 + b) * rt_stride + j] - cov[(32 + b) * rt_stride + i]);
                         y1 |= (unsigned)(d >= th.x) << b;
                         z1 |= (unsigned)(d <= th.y) << b;
                     }
@@ -1163,8 +1176,6 @@ __global__ void __launch_bounds__(ScoreCfg<NM>::kThreads) k_score(Status *st, in
             unsigned char *A = reinterpret_cast<unsigned char *>(in_s + C::kPairs);
             i64 *part_v = reinterpret_cast<i64 *>(smem + (((size_t)C::kPairs * 13 + 7) & ~(size_t)7));
             unsigned char *part_a = reinterpret_cast<unsigned char *>(part_v + T);
-            static_assert((((size_t)C::kPairs * 13 + 7) & ~(size_t)7) + (size_t)T * 9 <=
-                          (size_t)C::kPairs * 16 + (size_t)kSub * C::kCovStride * 4, "DP tables must fit the plane region");
             int k_iv = pr.iv[p];
             int part = iv_part[k_iv];
             const i64 outside = (part_lane_off[part + 1] - part_lane_off[part]) - pr.lane_n[p];
@@ -1570,6 +1581,7 @@ struct fseg_ctx {
     DevBuf d_status, d_tacc;
     Status *h_status = nullptr;   // pinned
     bool profiling = false;
+    int nm_big = kNMax;         // LDS carve-up of the big-problem kernels: largest problem of the previous run, rounded up
     bool small_batch = false;   // few DP problems in the previous run: merge the per-size-class launches
     hipEvent_t ev[ST_COUNT + 1] = {};
     float stage_ms[ST_COUNT] = {};
@@ -1772,16 +1784,17 @@ int enqueue_run(fseg_ctx *c) {
 #endif
 #define FSEG_LAUNCH_SCORE(NMV, CLS, MAXWG)                                                                              \
         hipLaunchKernelGGL(k_score<NMV>, dim3(work_grid < (MAXWG) ? work_grid : (MAXWG)), dim3(ScoreCfg<NMV>::kThreads),  \
-                           ScoreCfg<NMV>::kLds, s, st, CLS, pr, c->prob_cap, c->d_cls_items.as<int>(),                    \
+                           score_lds_for((NMV) == kNMax ? c->nm_big : (NMV), (NMV) + 1), s, st, CLS,                                 \
+                           ((NMV) == kNMax ? c->nm_big : (NMV)), pr, c->prob_cap, c->d_cls_items.as<int>(),               \
                            c->d_work_prob.as<int>(), c->d_work_chunk.as<int>(), c->work_cap, c->d_cand_off.as<i64>(),   \
                            c->d_cand_y.as<int>(), c->d_work_active.as<unsigned char>(), c->d_cov.as<unsigned>(),        \
                            c->cov_cap, c->d_pair_thr.as<int2>(), c->pair_cap, c->d_out.as<unsigned>(), c->tri_cap,      \
                            c->d_amb.as<unsigned>(), c->d_iv_part.as<int>(), c->d_part_lane_off.as<i64>(),                \
                            c->P.min_read_support_outside, c->d_chosen.as<unsigned char>() FSEG_TARG)
         if (c->small_batch) {
-            FSEG_LAUNCH_SCORE(kNMax, -1, 256);       // few work items: one launch for every size class
+            FSEG_LAUNCH_SCORE(kNMax, -1, 512);       // few work items: one launch for every size class
         } else {
-            FSEG_LAUNCH_SCORE(kNMax, 2, 256);        // big problems first: they are the long poles
+            FSEG_LAUNCH_SCORE(kNMax, 2, 512);        // big problems first: they are the long poles
             FSEG_LAUNCH_SCORE(kClsMid, 1, 1280);
             FSEG_LAUNCH_SCORE(kClsSmall, 0, 2048);
         }
@@ -1854,6 +1867,7 @@ int finish_run(fseg_ctx *c) {
         const Status &s = *c->h_status;
         unsigned ovf = s.err & (kErrOverflowPairs | kErrOverflowTri | kErrOverflowWork | kErrOverflowLabels |
                                 kErrOverflowProblems | kErrOverflowChunks | kErrOverflowCov);
+        if (s.err & kErrOverflowNm) { ovf |= kErrOverflowNm; c->nm_big = kNMax; }
         bool need = ovf != 0 || (i64)s.n_prob > c->prob_cap || (i64)s.n_work > c->work_cap ||
                     (i64)s.pair_used > c->pair_cap || (i64)s.tri_used > c->tri_cap || (i64)s.label_bytes > c->label_cap ||
                     (i64)s.n_vchunks > c->chunk_cap || (i64)s.cov_used > c->cov_cap;
@@ -1861,6 +1875,13 @@ int finish_run(fseg_ctx *c) {
             c->pending = false;
             c->ran = true;
             c->small_batch = (i64)s.n_prob <= 256 && (i64)s.n_work <= 1024;
+            {   // size the next run's big-problem LDS for this run's largest problem (+ headroom, multiple of 4)
+                int want = (int)s.max_n + 3;
+                want = (want + 3) & ~3;
+                if (want < kClsMid + 4) want = kClsMid + 4;
+                if (want > kNMax) want = kNMax;
+                c->nm_big = want;
+            }
             if (c->profiling)
                 for (int i = 0; i < ST_COUNT; ++i) (void)hipEventElapsedTime(&c->stage_ms[i], c->ev[i], c->ev[i + 1]);
             if (s.err & kErrExonInterval) return fail(c, FSEG_ERR_INPUT, "an exon does not lie inside one tint interval (py/freddie_segment.py:668)");
