@@ -19,6 +19,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -1540,9 +1541,14 @@ struct DevBuf {
     template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
-enum Stage { ST_HIST, ST_SMOOTH, ST_THRESHOLD, ST_CANDIDATES, ST_FIX, ST_SCORE_PREP, ST_SCORE, ST_DP, ST_REFINE, ST_FINAL, ST_LABEL, ST_COUNT };
-const char *kStageNames[ST_COUNT] = {"histogram", "smooth", "threshold", "candidates", "fix_split", "scoring_prep", "interval_scoring",
-                                     "dp", "refine", "final_positions", "labels"};
+enum Stage { ST_HIST, ST_SMOOTH, ST_THRESHOLD, ST_CANDIDATES, ST_FIX, ST_SCORE_PREP, ST_SCORE, ST_DP, ST_REFINE, ST_FINAL, ST_LABEL, ST_COUNT,
+             ST_GRAPH_PRE = ST_COUNT, ST_GRAPH_POST, ST_REPORTED };
+// Without graph replay every stage is bracketed by events.  With graph replay and profiling the run is
+// graph(before scoring) | events around plain launches of the scoring kernel | graph(after); the two graphs are
+// reported as graph_pre / graph_post.
+const char *kStageNames[ST_REPORTED] = {"histogram", "smooth", "threshold", "candidates", "fix_split", "scoring_prep",
+                                        "interval_scoring", "dp", "refine", "final_positions", "labels", "graph_pre",
+                                        "graph_post"};
 
 }  // namespace
 
@@ -1582,9 +1588,13 @@ struct fseg_ctx {
     Status *h_status = nullptr;   // pinned
     bool profiling = false;
     int nm_big = kNMax;         // LDS carve-up of the big-problem kernels: largest problem of the previous run, rounded up
-    bool small_batch = false;   // few DP problems in the previous run: merge the per-size-class launches
+    bool small_batch = false;
+    bool use_graph = true;      // replay the launch sequence as hipGraphs (FSEG_NO_GRAPH=1 disables)
+    hipGraph_t graph[2] = {nullptr, nullptr};            // [0] whole pipeline, or before / after scoring when profiling
+    hipGraphExec_t graph_exec[2] = {nullptr, nullptr};
+    int n_graphs = 0;   // few DP problems in the previous run: merge the per-size-class launches
     hipEvent_t ev[ST_COUNT + 1] = {};
-    float stage_ms[ST_COUNT] = {};
+    float stage_ms[ST_REPORTED] = {};
     int score_lds = 0;
 };
 
@@ -1646,7 +1656,16 @@ template <int NM> constexpr size_t dp_lds_bytes() {
 }
 constexpr int kDpSmall = 32;
 
+void drop_graph(fseg_ctx *c) {
+    for (int g = 0; g < 2; ++g) {
+        if (c->graph_exec[g]) { (void)hipGraphExecDestroy(c->graph_exec[g]); c->graph_exec[g] = nullptr; }
+        if (c->graph[g]) { (void)hipGraphDestroy(c->graph[g]); c->graph[g] = nullptr; }
+    }
+    c->n_graphs = 0;
+}
+
 int alloc_arenas(fseg_ctx *c) {
+    drop_graph(c);
     TRY(ensure(c, c->d_prob_iv, (size_t)c->prob_cap * 4));
     TRY(ensure(c, c->d_prob_start, (size_t)c->prob_cap * 4));
     TRY(ensure(c, c->d_prob_n, (size_t)c->prob_cap * 4));
@@ -1681,12 +1700,26 @@ int launch_scan_counts(fseg_ctx *c, const unsigned char *flags, i64 n, u64 *tota
     return FSEG_OK;
 }
 
-int enqueue_run(fseg_ctx *c) {
+// phase: 0 = whole pipeline; 1 = everything before the interval-scoring kernel, 2 = the interval-scoring kernel(s),
+// 3 = everything after.
+int enqueue_run(fseg_ctx *c, int phase = 0) {
     hipStream_t s = c->stream;
+    const bool do_pre = phase == 0 || phase == 1, do_score = phase == 0 || phase == 2, do_post = phase == 0 || phase == 3;
+    const bool in_parts = phase != 0;
     const int n_part = c->n_part;
     const i64 K = c->K, NPOS = c->NPOS;
     Status *st = c->d_status.as<Status>();
-    auto mark = [&](int i) { if (c->profiling) (void)hipEventRecord(c->ev[i], s); };
+    auto mark = [&](int i) { if (c->profiling && !in_parts) (void)hipEventRecord(c->ev[i], s); };
+    const i64 avg_len = NPOS / (K > 0 ? K : 1);
+    const int iv_threads = avg_len > 65536 ? 1024 : (avg_len > 16384 ? 256 : 64);
+    int tile_grid = grid_for(c->n_tiles, 1, 8192);
+    int scan_grid = 1;
+    int work_grid = grid_for(c->work_cap, 1, 4096);
+    ProblemArrays pr{c->d_prob_iv.as<int>(), c->d_prob_start.as<int>(), c->d_prob_n.as<int>(),
+                     c->d_prob_pair_off.as<i64>(), c->d_prob_tri_off.as<i64>(), c->d_prob_flags.as<int>(),
+                     c->d_prob_chain.as<int>(), c->d_prob_cov_off.as<i64>(), c->d_prob_lane_lo.as<int>(),
+                     c->d_prob_lane_n.as<int>(), c->d_prob_work_base.as<i64>()};
+    if (do_pre) {
     HIP_TRY(c, hipMemsetAsync(st, 0, sizeof(Status), s));
     HIP_TRY(c, hipMemsetAsync(c->d_y_raw.p, 0, (size_t)NPOS * 4, s));
     mark(0);
@@ -1697,13 +1730,11 @@ int enqueue_run(fseg_ctx *c) {
                        c->P.ignore_ends, c->d_y_raw.as<int>(), st);
     mark(1);
     // S2
-    int tile_grid = grid_for(c->n_tiles, 1, 8192);
     hipLaunchKernelGGL(k_smooth, dim3(tile_grid), dim3(256), 0, s, c->n_tiles, c->d_tile_iv.as<int>(),
                        c->d_tile_y0.as<int>(), c->d_pos_off.as<i64>(), c->d_y_raw.as<int>(), c->d_w_main.as<double>(),
                        c->P.radius_main, c->d_y.as<double>(), c->d_flag.as<unsigned char>(), c->d_cum.as<int>(), c->d_tile_tot.as<int>());
     mark(2);
     // S3a threshold
-    int scan_grid = 1;
     TRY(launch_scan_counts(c, c->d_flag.as<unsigned char>(), NPOS, &st->n_vals, &scan_grid));
     hipLaunchKernelGGL(k_scan_emit<kEmitValues>, dim3(scan_grid), dim3(256), 0, s, c->d_flag.as<unsigned char>(), NPOS,
                        c->d_bsum.as<int>(), c->d_y.as<double>(), c->d_v.as<double>(), K, c->d_pos_off.as<i64>(),
@@ -1734,13 +1765,6 @@ int enqueue_run(fseg_ctx *c) {
     hipLaunchKernelGGL(k_set_total, dim3(1), dim3(1), 0, s, c->d_cand_off.as<i64>(), K, &st->n_cand);
     mark(4);
     // S4
-    ProblemArrays pr{c->d_prob_iv.as<int>(), c->d_prob_start.as<int>(), c->d_prob_n.as<int>(),
-                     c->d_prob_pair_off.as<i64>(), c->d_prob_tri_off.as<i64>(), c->d_prob_flags.as<int>(),
-                     c->d_prob_chain.as<int>(), c->d_prob_cov_off.as<i64>(), c->d_prob_lane_lo.as<int>(),
-                     c->d_prob_lane_n.as<int>(), c->d_prob_work_base.as<i64>()};
-    // threads per interval for the per-interval kernels: long intervals carry many candidates
-    const i64 avg_len = NPOS / (K > 0 ? K : 1);
-    const int iv_threads = avg_len > 65536 ? 1024 : (avg_len > 16384 ? 256 : 64);
     hipLaunchKernelGGL(k_fix, dim3(grid_for(K, 1, 8192)), dim3(iv_threads), 0, s, K, c->d_pos_off.as<i64>(),
                        c->d_iv_part.as<int>(), c->d_cand_off.as<i64>(), c->d_cand_y.as<int>(), c->d_y.as<double>(),
                        c->d_thr.as<double>(), c->P.max_problem_size, c->d_fixed0.as<unsigned char>(),
@@ -1762,7 +1786,6 @@ int enqueue_run(fseg_ctx *c) {
     }
     mark(5);
     // S5
-    int work_grid = grid_for(c->work_cap, 1, 4096);
     if (c->prob_cap > 0) {
         hipLaunchKernelGGL(k_pair_thresholds, dim3(grid_for(c->prob_cap, 1, 2048)), dim3(256), 0, s, st, pr, c->prob_cap,
                            c->d_cand_off.as<i64>(), c->d_cand_y.as<int>(), c->d_h_table.as<double>(), c->P.h_len,
@@ -1776,7 +1799,8 @@ int enqueue_run(fseg_ctx *c) {
                            c->d_cov.as<unsigned>(), c->cov_cap, c->d_work_active.as<unsigned char>());
     }
     mark(6);
-    if (c->prob_cap > 0) {
+    }   // do_pre
+    if (do_score && c->prob_cap > 0) {
 #ifdef FSEG_SCORE_TIMING
 #define FSEG_TARG , c->d_tacc.as<unsigned long long>()
 #else
@@ -1801,6 +1825,7 @@ int enqueue_run(fseg_ctx *c) {
 #undef FSEG_LAUNCH_SCORE
     }
     mark(7);
+    if (do_post) {
     if (c->prob_cap > 0) {
         int dp_grid = grid_for(c->prob_cap, 1, 1024);
 #define FSEG_LAUNCH_DP(NMV, NLO, QUEUE, MAXWG)                                                                           \
@@ -1856,6 +1881,7 @@ int enqueue_run(fseg_ctx *c) {
     }
     mark(11);
     HIP_TRY(c, hipMemcpyAsync(c->h_status, st, sizeof(Status), hipMemcpyDeviceToHost, s));
+    }   // do_post
     HIP_TRY(c, hipGetLastError());
     return FSEG_OK;
 }
@@ -1874,6 +1900,8 @@ int finish_run(fseg_ctx *c) {
         if (!need) {
             c->pending = false;
             c->ran = true;
+            const bool old_small = c->small_batch;
+            const int old_nm = c->nm_big;
             c->small_batch = (i64)s.n_prob <= 256 && (i64)s.n_work <= 1024;
             {   // size the next run's big-problem LDS for this run's largest problem (+ headroom, multiple of 4)
                 int want = (int)s.max_n + 3;
@@ -1882,8 +1910,18 @@ int finish_run(fseg_ctx *c) {
                 if (want > kNMax) want = kNMax;
                 c->nm_big = want;
             }
-            if (c->profiling)
-                for (int i = 0; i < ST_COUNT; ++i) (void)hipEventElapsedTime(&c->stage_ms[i], c->ev[i], c->ev[i + 1]);
+            const int timed_graphs = c->n_graphs;
+            if (old_small != c->small_batch || old_nm != c->nm_big) drop_graph(c);
+            if (c->profiling) {
+                for (int i = 0; i < ST_REPORTED; ++i) c->stage_ms[i] = 0.f;
+                if (timed_graphs == 2) {
+                    (void)hipEventElapsedTime(&c->stage_ms[ST_GRAPH_PRE], c->ev[0], c->ev[ST_SCORE]);
+                    (void)hipEventElapsedTime(&c->stage_ms[ST_SCORE], c->ev[ST_SCORE], c->ev[ST_SCORE + 1]);
+                    (void)hipEventElapsedTime(&c->stage_ms[ST_GRAPH_POST], c->ev[ST_SCORE + 1], c->ev[ST_COUNT]);
+                } else {
+                    for (int i = 0; i < ST_COUNT; ++i) (void)hipEventElapsedTime(&c->stage_ms[i], c->ev[i], c->ev[i + 1]);
+                }
+            }
             if (s.err & kErrExonInterval) return fail(c, FSEG_ERR_INPUT, "an exon does not lie inside one tint interval (py/freddie_segment.py:668)");
             if (s.err & kErrBreakAssert) return fail(c, FSEG_ERR_INPUT, "break_large_problems: candidate window out of range or no positive signal (py/freddie_segment.py:640-643)");
             if (s.err & kErrProblemTooLarge) return fail(c, FSEG_ERR_UNSUPPORTED, "a DP problem has more than %d candidates (max_problem_size too large for this build)", kNMax);
@@ -1948,6 +1986,7 @@ int fseg_create(int device, fseg_ctx **out) {
         return FSEG_ERR_HIP;
     }
     c->d_status.cap = sizeof(Status);
+    { const char *ng = getenv("FSEG_NO_GRAPH"); if (ng && ng[0] == '1') c->use_graph = false; }
     *out = c;
     return FSEG_OK;
 }
@@ -1956,6 +1995,7 @@ void fseg_destroy(fseg_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    drop_graph(c);
     DevBuf *bufs[] = {&c->d_part_iv_off, &c->d_part_rep_off, &c->d_part_lane_off, &c->d_iv_start, &c->d_iv_end, &c->d_pos_off,
                       &c->d_iv_part, &c->d_rep_weight, &c->d_rep_exon_off, &c->d_ex_ts, &c->d_ex_te, &c->d_lane_rep, &c->d_lane_start, &c->d_lane_pmax,
                       &c->d_tile_iv, &c->d_tile_y0, &c->d_w_main, &c->d_w_refine, &c->d_h_table, &c->d_y_raw, &c->d_y,
@@ -1985,6 +2025,7 @@ int fseg_set_params(fseg_ctx *c, const fseg_params *p) {
         return fail(c, FSEG_ERR_ARG, "Gaussian radius out of range");
     if (!p->w_main || !p->w_refine || !p->h_table || p->h_len <= 0) return fail(c, FSEG_ERR_ARG, "missing weight / threshold tables");
     HIP_TRY(c, hipSetDevice(c->device));
+    drop_graph(c);
     c->P = *p;
     c->w_main.assign(p->w_main, p->w_main + p->radius_main + 1);
     c->w_refine.assign(p->w_refine, p->w_refine + p->radius_refine + 1);
@@ -2141,6 +2182,7 @@ int fseg_upload(fseg_ctx *c, const fseg_batch *b) {
     TRY(ensure(c, c->d_tacc, 64));
     HIP_TRY(c, hipMemsetAsync(c->d_tacc.p, 0, 64, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    drop_graph(c);
     c->have_batch = true; c->ran = false; c->pending = false;
     return FSEG_OK;
 }
@@ -2150,6 +2192,41 @@ int fseg_run(fseg_ctx *c) {
     if (!c->have_params || !c->have_batch) return fail(c, FSEG_ERR_ARG, "fseg_run: set parameters and upload a batch first");
     HIP_TRY(c, hipSetDevice(c->device));
     if (c->pending) TRY(finish_run(c));
+    if (c->use_graph) {
+        if (c->n_graphs == 0) {
+            const int want = c->profiling ? 2 : 1;
+            bool ok = true;
+            for (int g = 0; g < want && ok; ++g) {
+                HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+                int rc = enqueue_run(c, want == 1 ? 0 : (g == 0 ? 1 : 3));
+                hipError_t e = hipStreamEndCapture(c->stream, &c->graph[g]);
+                if (rc == FSEG_OK && e == hipSuccess) e = hipGraphInstantiate(&c->graph_exec[g], c->graph[g], nullptr, nullptr, 0);
+                ok = rc == FSEG_OK && e == hipSuccess;
+            }
+            if (ok) c->n_graphs = want;
+            else {                                         // capture not possible: fall back to plain launches
+                (void)hipGetLastError();
+                drop_graph(c);
+                c->use_graph = false;
+            }
+        }
+        if (c->n_graphs == 1) {
+            HIP_TRY(c, hipGraphLaunch(c->graph_exec[0], c->stream));
+            c->pending = true;
+            return FSEG_OK;
+        }
+        if (c->n_graphs == 2) {
+            HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+            HIP_TRY(c, hipGraphLaunch(c->graph_exec[0], c->stream));
+            HIP_TRY(c, hipEventRecord(c->ev[ST_SCORE], c->stream));
+            TRY(enqueue_run(c, 2));
+            HIP_TRY(c, hipEventRecord(c->ev[ST_SCORE + 1], c->stream));
+            HIP_TRY(c, hipGraphLaunch(c->graph_exec[1], c->stream));
+            HIP_TRY(c, hipEventRecord(c->ev[ST_COUNT], c->stream));
+            c->pending = true;
+            return FSEG_OK;
+        }
+    }
     TRY(enqueue_run(c));
     c->pending = true;
     return FSEG_OK;
@@ -2236,13 +2313,18 @@ int fseg_tap(fseg_ctx *c, int what, void *dst, int64_t cap_bytes, int64_t *n_byt
     return FSEG_OK;
 }
 
-int fseg_set_profiling(fseg_ctx *c, int on) { if (!c) return FSEG_ERR_ARG; c->profiling = on != 0; return FSEG_OK; }
-int fseg_n_stages(void) { return ST_COUNT; }
-const char *fseg_stage_name(int i) { return (i >= 0 && i < ST_COUNT) ? kStageNames[i] : ""; }
+int fseg_set_profiling(fseg_ctx *c, int on) {
+    if (!c) return FSEG_ERR_ARG;
+    if (c->profiling != (on != 0)) drop_graph(c);
+    c->profiling = on != 0;
+    return FSEG_OK;
+}
+int fseg_n_stages(void) { return ST_REPORTED; }
+const char *fseg_stage_name(int i) { return (i >= 0 && i < ST_REPORTED) ? kStageNames[i] : ""; }
 int fseg_stage_ms(fseg_ctx *c, float *ms) {
     if (!c || !ms) return FSEG_ERR_ARG;
     TRY(fseg_sync(c));
-    for (int i = 0; i < ST_COUNT; ++i) ms[i] = c->stage_ms[i];
+    for (int i = 0; i < ST_REPORTED; ++i) ms[i] = c->stage_ms[i];
     return FSEG_OK;
 }
 
