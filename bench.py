@@ -76,6 +76,15 @@ def cpu_baseline(parts, n_reads_of, params, tabs, budget_s=20.0):
                 sample="%d of %d partitions (%d reads), one pass of the C oracle, %.1f s" % (used, len(parts), reads, dt))
 
 
+def measured_traffic(workload):
+    """HBM bytes per launch of the scoring kernel from the committed PMC passes (profiles/traffic.json), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            return json.load(f)[workload]["traffic_bytes"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -165,7 +174,7 @@ def main():
                        "candidates_rank0": sizes["n_cand"], "dp_problems_rank0": sizes["n_problems"],
                        "positions_rank0": sizes["n_positions"], "params": {k: params[k] for k in ("sigma", "threshold_rate")}},
             "roofline": {"kernel": "k_score (interval scoring)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.workload),
                          "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": score_ms},
             "stage_ms": {k: v / args.steps for k, v in stage_acc.items()},
         }
