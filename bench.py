@@ -57,23 +57,30 @@ def build_batch(workload, rank, n_local):
     return parts, n_reads
 
 
-def cpu_baseline(parts, n_reads_of, params, tabs, budget_s=20.0):
-    """Time the CPU oracle on a bounded sample of the same workload (whole partitions, in order)."""
+def cpu_baseline(parts, n_reads_of, params, tabs, min_s=10.0, max_s=25.0):
+    """Time the CPU oracle on a bounded sample of the same workload: whole partitions in order, repeated
+    until at least min_s seconds of CPU work have been measured (never more than max_s)."""
     from oracle import oracle
     t0 = time.perf_counter()
     reads = 0
     used = 0
-    for p, nr in zip(parts, n_reads_of):
-        o = oracle.segment(p.iv_start, p.iv_end, p.rep_weight, p.rep_exon_off, p.ex_ts, p.ex_te, **params, **tabs)
-        if o["error"]:
-            raise RuntimeError("oracle failed: " + o["errmsg"])
-        reads += nr
-        used += 1
-        if time.perf_counter() - t0 > budget_s:
+    passes = 0
+    while True:
+        for p, nr in zip(parts, n_reads_of):
+            o = oracle.segment(p.iv_start, p.iv_end, p.rep_weight, p.rep_exon_off, p.ex_ts, p.ex_te, **params, **tabs)
+            if o["error"]:
+                raise RuntimeError("oracle failed: " + o["errmsg"])
+            reads += nr
+            used += 1
+            if time.perf_counter() - t0 > max_s:
+                break
+        passes += 1
+        if time.perf_counter() - t0 > min_s:
             break
     dt = time.perf_counter() - t0
     return dict(value=reads / dt, unit="reads/s", cores=1, kind="port",
-                sample="%d of %d partitions (%d reads), one pass of the C oracle, %.1f s" % (used, len(parts), reads, dt))
+                sample="%d partition runs (%d reads, %d pass(es) over %d partitions) of the C oracle, %.1f s" % (
+                    used, reads, passes, len(parts), dt))
 
 
 def measured_traffic(workload):
@@ -168,7 +175,8 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u32 bit-planes + int64 DP (f64 smoothing)",
+            "dtype": "u32",
+            "dtype_detail": "u32 bit-planes + popcount for scoring, int64 DP, f64 Gaussian smoothing / threshold",
             "data": "synthetic",
             "config": {"workload": args.workload, "partitions_per_gpu": n_local, "reads_per_gpu": n_reads,
                        "candidates_rank0": sizes["n_cand"], "dp_problems_rank0": sizes["n_problems"],
