@@ -1124,25 +1124,32 @@ __global__ void __launch_bounds__(ScoreCfg<NM>::kThreads) k_score(Status *st, in
             __syncthreads();
             FSEG_TICK(2);
             // ---- B: pair planes ---------------------------------------------------------------------
-            unsigned valid0 = n_valid >= 32 ? 0xffffffffu : ((1u << n_valid) - 1u);
-            unsigned valid1 = n_valid >= 64 ? 0xffffffffu : (n_valid > 32 ? ((1u << (n_valid - 32)) - 1u) : 0u);
+            const int nv1 = n_valid - 32;
+            unsigned valid0 = n_valid >= 32 ? 0xffffffffu : (n_valid > 0 ? ~(0xffffffffu >> n_valid) : 0u);
+            unsigned valid1 = nv1 >= 32 ? 0xffffffffu : (nv1 > 0 ? ~(0xffffffffu >> nv1) : 0u);
 #pragma unroll
             for (int s = 0; s < C::kSlots; ++s) {
                 int q = s * T + threadIdx.x;
                 if (q < npairs) {
                     int i = pair_ij[q] & 255, j = pair_ij[q] >> 8;
                     int2 th = pair_thr[poff + q];
+                    // shift the compare result into the plane word through the carry: acc = 2*acc + (d >= hi).
+                    // Read b of a word therefore lands on bit 31-b (the valid masks below use the same order).
                     unsigned y0 = 0, z0 = 0, y1 = 0, z1 = 0;
+#define FSEG_SHIFT_IN(acc, cmp, a, b) asm("v_cmp_" cmp "_i32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(a), "v"(b) : "vcc")
+#pragma unroll
                     for (int b = 0; b < 32; ++b) {
                         int d = (int)(cov[b * rt_stride + j] - cov[b * rt_stride + i]);
-                        y0 |= (unsigned)(d >= th.x) << b;
-                        z0 |= (unsigned)(d <= th.y) << b;
+                        FSEG_SHIFT_IN(y0, "ge", d, th.x);
+                        FSEG_SHIFT_IN(z0, "le", d, th.y);
                     }
+#pragma unroll
                     for (int b = 0; b < 32; ++b) {
                         int d = (int)(cov[(32 + b) * rt_stride + j] - cov[(32 + b) * rt_stride + i]);
-                        y1 |= (unsigned)(d >= th.x) << b;
-                        z1 |= (unsigned)(d <= th.y) << b;
+                        FSEG_SHIFT_IN(y1, "ge", d, th.x);
+                        FSEG_SHIFT_IN(z1, "le", d, th.y);
                     }
+#undef FSEG_SHIFT_IN
                     planes[q] = make_uint4(y0, y1, z0, z1);
                     amb_acc[s] += __popc(~(y0 | z0) & valid0) + __popc(~(y1 | z1) & valid1);
                 }
