@@ -1041,6 +1041,7 @@ __global__ void __launch_bounds__(ScoreCfg<NM>::kThreads) k_score(Status *st, in
     constexpr int T = C::kThreads;
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ int cy_s[NM + 4];
+    __shared__ int iend_s[NM + 4];
     __shared__ u64 work_s;
     __shared__ int top_key[8];
     // LDS carve-up for problems of at most nm candidates (nm <= NM is chosen by the host from the previous run's
@@ -1087,7 +1088,13 @@ __global__ void __launch_bounds__(ScoreCfg<NM>::kThreads) k_score(Status *st, in
             continue;
         }
         const int *cy = cand_y + cand_off[pr.iv[p]] + pr.start[p];
-        for (int j = threadIdx.x; j < n; j += T) cy_s[j] = cy[j];
+        for (int j = threadIdx.x; j < n; j += T) {
+            int cj = cy[j];
+            cy_s[j] = cj;
+            int e = 0;
+            while (e < j && cj - cy[e] >= 5) ++e;                     // candidates are ascending
+            iend_s[j] = e;
+        }
         for (int x = threadIdx.x; x < ntri; x += T) out16[x] = 0;
         unsigned amb_acc[C::kSlots];
 #pragma unroll
@@ -1166,11 +1173,11 @@ __global__ void __launch_bounds__(ScoreCfg<NM>::kThreads) k_score(Status *st, in
                 if ((B.x | B.y | B.z | B.w) == 0) continue;
                 int tbase = kk * (kk - 1) * (kk - 2) / 6 + j * (j - 1) / 2;
                 int abase = j * (j - 1) / 2;
-                for (int i = 0; i < j; ++i) {
-                    if (cy_s[j] - cy_s[i] < 5) break;                 // closer i are too small as well
+                const int i_end = iend_s[j];                          // i with cand_j - cand_i >= 5 (:540), a prefix
+                for (int i = 0; i < i_end; ++i) {
                     uint4 A = planes[abase + i];
                     unsigned cnt = __popc(A.x & B.z) + __popc(A.y & B.w) + __popc(A.z & B.x) + __popc(A.w & B.y);
-                    if (cnt) out16[tbase + i] += (unsigned short)cnt;
+                    out16[tbase + i] += (unsigned short)cnt;
                 }
             }
             __syncthreads();
