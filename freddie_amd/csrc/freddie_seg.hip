@@ -1174,11 +1174,24 @@ __global__ void __launch_bounds__(ScoreCfg<NM>::kThreads) k_score(Status *st, in
                 int tbase = kk * (kk - 1) * (kk - 2) / 6 + j * (j - 1) / 2;
                 int abase = j * (j - 1) / 2;
                 const int i_end = iend_s[j];                          // i with cand_j - cand_i >= 5 (:540), a prefix
-                for (int i = 0; i < i_end; ++i) {
-                    uint4 A = planes[abase + i];
-                    unsigned cnt = __popc(A.x & B.z) + __popc(A.y & B.w) + __popc(A.z & B.x) + __popc(A.w & B.y);
-                    out16[tbase + i] += (unsigned short)cnt;
+#define FSEG_TRI_CNT(A) (__popc((A).x & B.z) + __popc((A).y & B.w) + __popc((A).z & B.x) + __popc((A).w & B.y))
+                unsigned short *o16 = out16 + tbase;
+                int i = 0;
+                if ((tbase & 1) && i_end > 0) {                       // align to a counter pair
+                    uint4 A = planes[abase];
+                    o16[0] += (unsigned short)FSEG_TRI_CNT(A);
+                    i = 1;
                 }
+                for (; i + 1 < i_end; i += 2) {                       // two u16 counters per 32-bit read-modify-write
+                    uint4 A0 = planes[abase + i], A1 = planes[abase + i + 1];
+                    unsigned add = FSEG_TRI_CNT(A0) | (FSEG_TRI_CNT(A1) << 16);
+                    *reinterpret_cast<unsigned *>(o16 + i) += add;    // a counter never exceeds the reads of a work item (< 65536)
+                }
+                if (i < i_end) {
+                    uint4 A = planes[abase + i];
+                    o16[i] += (unsigned short)FSEG_TRI_CNT(A);
+                }
+#undef FSEG_TRI_CNT
             }
             __syncthreads();
             FSEG_TICK(4);
