@@ -1003,6 +1003,14 @@ __global__ void k_init_pair_table() {
 }
 
 constexpr bool kFuseDp = false;
+// Workgroup barrier that orders LDS traffic only: global loads issued before it (the coverage-tile prefetch)
+// stay in flight, which a full __syncthreads() would wait for.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 template <int NM> struct ScoreCfg {
     static constexpr int kPairs = NM * (NM - 1) / 2;
     static constexpr int kTri = NM * (NM - 1) * (NM - 2) / 6;
@@ -1088,14 +1096,11 @@ __global__ void __launch_bounds__(ScoreCfg<NM>::kThreads) k_score(Status *st, in
             continue;
         }
         const int *cy = cand_y + cand_off[pr.iv[p]] + pr.start[p];
-        for (int j = threadIdx.x; j < n; j += T) {
-            int cj = cy[j];
-            cy_s[j] = cj;
-            int e = 0;
-            while (e < j && cj - cy[e] >= 5) ++e;                     // candidates are ascending
-            iend_s[j] = e;
+        for (int j = threadIdx.x; j < n; j += T) cy_s[j] = cy[j];
+        {
+            uint4 *z = reinterpret_cast<uint4 *>(out16);              // 8 counters per store
+            for (int x = threadIdx.x; x < (ntri + 7) / 8; x += T) z[x] = make_uint4(0, 0, 0, 0);
         }
-        for (int x = threadIdx.x; x < ntri; x += T) out16[x] = 0;
         unsigned amb_acc[C::kSlots];
 #pragma unroll
         for (int s = 0; s < C::kSlots; ++s) amb_acc[s] = 0;
@@ -1107,6 +1112,13 @@ __global__ void __launch_bounds__(ScoreCfg<NM>::kThreads) k_score(Status *st, in
         for (int e = 0; e < C::kStage; ++e) {
             int x = e * T + threadIdx.x;
             stage[e] = x < tile_words ? cov_g[coff + (i64)(x >> 6) * kLaneChunk + sub * kSub + (x & 63)] : 0;
+        }
+        __syncthreads();
+        if (threadIdx.x < n) {
+            // iend_s[j] = number of i < j with cand_j - cand_i >= 5 (candidates ascending): binary search
+            int j = threadIdx.x, lim = cy_s[j] - 5, lo = 0, hi = j;
+            while (lo < hi) { int mid = (lo + hi) >> 1; if (cy_s[mid] <= lim) lo = mid + 1; else hi = mid; }
+            iend_s[j] = lo;
         }
         __syncthreads();
         FSEG_TICK(1);
@@ -1128,7 +1140,7 @@ __global__ void __launch_bounds__(ScoreCfg<NM>::kThreads) k_score(Status *st, in
                     stage[e] = x < tile_words ? cov_g[coff + (i64)(x >> 6) * kLaneChunk + next_sub * kSub + (x & 63)] : 0;
                 }
             }
-            __syncthreads();
+            lds_barrier();
             FSEG_TICK(2);
             // ---- B: pair planes ---------------------------------------------------------------------
             const int nv1 = n_valid - 32;
@@ -1161,7 +1173,7 @@ __global__ void __launch_bounds__(ScoreCfg<NM>::kThreads) k_score(Status *st, in
                     amb_acc[s] += __popc(~(y0 | z0) & valid0) + __popc(~(y1 | z1) & valid1);
                 }
             }
-            __syncthreads();
+            lds_barrier();
             FSEG_TICK(3);
             // ---- C: triples.  B pairs (j,k) are enumerated with j descending so that the 64 lanes of a wave
             // have (nearly) the same trip count j and mostly share the (i,j) plane they read --------------
@@ -1193,7 +1205,7 @@ __global__ void __launch_bounds__(ScoreCfg<NM>::kThreads) k_score(Status *st, in
                 }
 #undef FSEG_TRI_CNT
             }
-            __syncthreads();
+            lds_barrier();
             FSEG_TICK(4);
             sub = next_sub;
         }

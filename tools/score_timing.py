@@ -9,7 +9,7 @@ wl = sys.argv[1]
 parts, n_reads = bench.build_batch(wl, 0, bench.per_gpu_partitions(wl, 1))
 params = bench.PARAMS["default"]
 tabs = dict(w_main=tables.gaussian_half_kernel(5.0, 4.0), w_refine=tables.gaussian_half_kernel(5.0, 1.0), h_table=np.asarray(tables.smooth_threshold(0.9)))
-ctx = _lib.Context(0); ctx.set_params(**params, **tabs); ctx.upload(**pack.concat_batch(parts)); ctx.set_profiling(True)
+ctx = _lib.Context(0); ctx.set_params(**params, **tabs); ctx.upload(**pack.concat_batch(parts)); ctx.set_profiling(True); os.environ["X"]="1"
 L = _lib.load(); L.fseg_debug_score_timing.argtypes=[ctypes.c_void_p, ctypes.c_void_p]
 buf = np.zeros(8, np.uint64)
 for i in range(3): ctx.run(); ctx.sync()
