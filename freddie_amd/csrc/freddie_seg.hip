@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(256) k_scan1(const unsigned char *flags, i64 n
         __syncthreads();
     }
 }
-__global__ void __launch_bounds__(256) k_scan2(int *bsum, i64 nb, u64 *total_out) {
+__global__ void __launch_bounds__(256) k_scan2(int *bsum, i64 nb, u64 *total_out, i64 *off_last /* may be null */) {
     __shared__ int lds[16];
     __shared__ int carry_s;
     if (threadIdx.x == 0) carry_s = 0;
@@ -277,7 +277,7 @@ __global__ void __launch_bounds__(256) k_scan2(int *bsum, i64 nb, u64 *total_out
         if (threadIdx.x == 0) carry_s = carry + tot;
         __syncthreads();
     }
-    if (threadIdx.x == 0) *total_out = (u64)carry_s;
+    if (threadIdx.x == 0) { *total_out = (u64)carry_s; if (off_last) *off_last = (i64)carry_s; }
 }
 // third pass fused with the consumer of the compaction:
 //   kEmitValues:    v[rank] = y[i]                                   (threshold stage)
@@ -779,7 +779,8 @@ __device__ __forceinline__ void pair_decode(int q, int *i, int *j) {
 // S5a  integer label thresholds of every candidate pair of every problem (:490-495)
 __global__ void __launch_bounds__(256) k_pair_thresholds(const Status *st, ProblemArrays pr, i64 prob_cap,
                                                          const i64 *cand_off, const int *cand_y, const double *h_table,
-                                                         int h_len, double tau, int2 *pair_thr, i64 pair_cap) {
+                                                         int h_len, double tau, int2 *pair_thr, i64 pair_cap,
+                                                         unsigned *amb_g, unsigned *out_g, i64 tri_cap) {
     i64 n_prob = (i64)st->n_prob < prob_cap ? (i64)st->n_prob : prob_cap;
     for (i64 p = blockIdx.x; p < n_prob; p += gridDim.x) {
         int n = pr.n[p];
@@ -795,8 +796,12 @@ __global__ void __launch_bounds__(256) k_pair_thresholds(const Status *st, Probl
             int hi, lo;
             label_thresholds(L, h_table, h_len, tau, &hi, &lo);
             pair_thr[poff + q] = make_int2(hi, lo);
+            amb_g[poff + q] = 0;
             if (lo < 0) any_neg = 1;
         }
+        i64 toff = pr.tri_off[p];
+        int ntri = n * (n - 1) * (n - 2) / 6;
+        if (toff + ntri <= tri_cap) for (int x = threadIdx.x; x < ntri; x += blockDim.x) out_g[toff + x] = 0;
         if (any_neg) atomicOr(&pr.flags[p], 1);
     }
 }
@@ -1246,15 +1251,16 @@ __global__ void __launch_bounds__(ScoreCfg<NM>::kThreads) k_score(Status *st, in
     }
 }
 
-template <int NM>
-__global__ void __launch_bounds__(256) k_dp(Status *st, int n_lo, u64 *queue, ProblemArrays pr, i64 prob_cap,
+template <int NM, int T>
+__global__ void __launch_bounds__(T) k_dp(Status *st, int n_lo, int nm, u64 *queue, ProblemArrays pr, i64 prob_cap,
                                             const i64 *cand_off, const int *cand_y, const int *iv_part,
                                             const i64 *part_lane_off, const unsigned *out_g, i64 tri_cap,
                                             const unsigned *amb_g, const int2 *pair_thr, i64 pair_cap, int support,
                                             unsigned char *chosen) {
     // handles problems with n_lo < n <= NM that the scoring kernel did not finish itself (more than one
     // work item); the out table of the problem is staged in LDS first
-    constexpr int kTri = NM * (NM - 1) * (NM - 2) / 6, kPairs = NM * (NM - 1) / 2;
+    // LDS carve-up for problems of at most nm <= NM candidates (nm from the previous run's largest problem)
+    const int kTri = nm * (nm - 1) * (nm - 2) / 6, kPairs = nm * (nm - 1) / 2;
     extern __shared__ __align__(16) unsigned char smem[];
     i64 *M = reinterpret_cast<i64 *>(smem);                          // M(b,c), b < c, at c*(c-1)/2 + b
     unsigned *out_s = reinterpret_cast<unsigned *>(M + kPairs);
@@ -1262,9 +1268,9 @@ __global__ void __launch_bounds__(256) k_dp(Status *st, int n_lo, u64 *queue, Pr
     unsigned char *A = reinterpret_cast<unsigned char *>(in_s + kPairs);
     __shared__ int cy_s[NM];
     __shared__ u64 work_s;
-    __shared__ i64 part_v[256];
-    __shared__ unsigned char part_a[256];
-    __shared__ int top_key[4];
+    __shared__ i64 part_v[T];
+    __shared__ unsigned char part_a[T];
+    __shared__ int top_key[T / 64];
     i64 n_prob = (i64)st->n_prob;
     if (n_prob > prob_cap) return;                                  // sizing run
     for (;;) {
@@ -1275,6 +1281,7 @@ __global__ void __launch_bounds__(256) k_dp(Status *st, int n_lo, u64 *queue, Pr
         if (p >= n_prob) break;
         int n = pr.n[p];
         if (n <= n_lo || n > NM || (pr.flags[p] & 2)) continue;
+        if (n > nm) { if (threadIdx.x == 0) atomicOr(&st->err, kErrOverflowNm); continue; }
         i64 poff = pr.pair_off[p], toff = pr.tri_off[p];
         int npairs = n * (n - 1) / 2, ntri = n * (n - 1) * (n - 2) / 6;
         if (poff + npairs > pair_cap || toff + ntri > tri_cap) continue;
@@ -1288,7 +1295,7 @@ __global__ void __launch_bounds__(256) k_dp(Status *st, int n_lo, u64 *queue, Pr
         for (int q = threadIdx.x; q < npairs; q += blockDim.x)
             in_s[q] = -(int)((i64)amb_g[poff + q] + ((zamb && pair_thr[poff + q].y < 0) ? outside : 0));
         __syncthreads();
-        int chain = dp_solve<256>(n, out_s, in_s, M, A, cy_s, support, part_v, part_a, top_key, chosen + c0);
+        int chain = dp_solve<T>(n, out_s, in_s, M, A, cy_s, support, part_v, part_a, top_key, chosen + c0);
         if (threadIdx.x == 0) pr.chain[p] = chain;
     }
 }
@@ -1690,9 +1697,10 @@ size_t score_lds_bytes() {
     return (b + 15) & ~(size_t)15;
 }
 
-template <int NM> constexpr size_t dp_lds_bytes() {
-    return (size_t)(NM * (NM - 1) / 2) * (8 + 4 + 1) + (size_t)(NM * (NM - 1) * (NM - 2) / 6) * 4 + 16;
+inline size_t dp_lds_for(int nm) {
+    return (size_t)(nm * (nm - 1) / 2) * (8 + 4 + 1) + (size_t)(nm * (nm - 1) * (nm - 2) / 6) * 4 + 16;
 }
+constexpr size_t kLdsPerWg = 160 * 1024;
 constexpr int kDpSmall = 32;
 
 void drop_graph(fseg_ctx *c) {
@@ -1730,11 +1738,11 @@ int alloc_arenas(fseg_ctx *c) {
 }
 
 // prefix sums of a flag array: block sums + their exclusive scan; the third pass is fused with the consumer
-int launch_scan_counts(fseg_ctx *c, const unsigned char *flags, i64 n, u64 *total_dev, int *grid_out) {
+int launch_scan_counts(fseg_ctx *c, const unsigned char *flags, i64 n, u64 *total_dev, int *grid_out, i64 *off_last = nullptr) {
     i64 nb = (n + kScanBlock - 1) / kScanBlock;
     int g = grid_for(nb, 1, 4096);
     hipLaunchKernelGGL(k_scan1, dim3(g), dim3(256), 0, c->stream, flags, n, c->d_bsum.as<int>());
-    hipLaunchKernelGGL(k_scan2, dim3(1), dim3(256), 0, c->stream, c->d_bsum.as<int>(), nb, total_dev);
+    hipLaunchKernelGGL(k_scan2, dim3(1), dim3(256), 0, c->stream, c->d_bsum.as<int>(), nb, total_dev, off_last);
     *grid_out = g;
     return FSEG_OK;
 }
@@ -1797,11 +1805,10 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
     HIP_TRY(c, hipMemsetAsync(c->d_flag.p, 0, (size_t)NPOS, s));
     hipLaunchKernelGGL(k_peaks, dim3(tile_grid), dim3(256), 0, s, c->n_tiles, c->d_tile_iv.as<int>(), c->d_tile_y0.as<int>(),
                        c->d_pos_off.as<i64>(), c->d_y.as<double>(), c->d_flag.as<unsigned char>());
-    TRY(launch_scan_counts(c, c->d_flag.as<unsigned char>(), NPOS, &st->n_cand, &scan_grid));
+    TRY(launch_scan_counts(c, c->d_flag.as<unsigned char>(), NPOS, &st->n_cand, &scan_grid, c->d_cand_off.as<i64>() + K));
     hipLaunchKernelGGL(k_scan_emit<kEmitPositions>, dim3(scan_grid), dim3(256), 0, s, c->d_flag.as<unsigned char>(), NPOS,
                        c->d_bsum.as<int>(), (const double *)nullptr, (double *)nullptr, K, c->d_pos_off.as<i64>(),
                        c->d_iv_start.as<int>(), c->d_cand_y.as<int>(), (int *)nullptr, c->d_cand_off.as<i64>());
-    hipLaunchKernelGGL(k_set_total, dim3(1), dim3(1), 0, s, c->d_cand_off.as<i64>(), K, &st->n_cand);
     mark(4);
     // S4
     hipLaunchKernelGGL(k_fix, dim3(grid_for(K, 1, 8192)), dim3(iv_threads), 0, s, K, c->d_pos_off.as<i64>(),
@@ -1828,9 +1835,8 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
     if (c->prob_cap > 0) {
         hipLaunchKernelGGL(k_pair_thresholds, dim3(grid_for(c->prob_cap, 1, 2048)), dim3(256), 0, s, st, pr, c->prob_cap,
                            c->d_cand_off.as<i64>(), c->d_cand_y.as<int>(), c->d_h_table.as<double>(), c->P.h_len,
-                           c->P.threshold_rate, c->d_pair_thr.as<int2>(), c->pair_cap);
-        hipLaunchKernelGGL(k_zero_arenas, dim3(1024), dim3(256), 0, s, st, c->d_out.as<unsigned>(), c->tri_cap,
-                           c->d_amb.as<unsigned>(), c->pair_cap);
+                           c->P.threshold_rate, c->d_pair_thr.as<int2>(), c->pair_cap, c->d_amb.as<unsigned>(),
+                           c->d_out.as<unsigned>(), c->tri_cap);
         hipLaunchKernelGGL(k_cov, dim3(work_grid < 2048 ? work_grid : 2048), dim3(kLaneChunk), 0, s, st, pr, c->prob_cap,
                            c->d_work_prob.as<int>(), c->d_work_chunk.as<int>(), c->work_cap, c->d_cand_off.as<i64>(),
                            c->d_cand_y.as<int>(), c->d_iv_start.as<int>(), c->d_lane_rep.as<int>(),
@@ -1867,17 +1873,21 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
     if (do_post) {
     if (c->prob_cap > 0) {
         int dp_grid = grid_for(c->prob_cap, 1, 1024);
-#define FSEG_LAUNCH_DP(NMV, NLO, QUEUE, MAXWG)                                                                           \
-        hipLaunchKernelGGL(k_dp<NMV>, dim3(dp_grid < (MAXWG) ? dp_grid : (MAXWG)), dim3(256), dp_lds_bytes<NMV>(), s, st, NLO,   \
-                           QUEUE, pr, c->prob_cap, c->d_cand_off.as<i64>(), c->d_cand_y.as<int>(), c->d_iv_part.as<int>(),     \
-                           c->d_part_lane_off.as<i64>(), c->d_out.as<unsigned>(), c->tri_cap, c->d_amb.as<unsigned>(),         \
-                           c->d_pair_thr.as<int2>(), c->pair_cap, c->P.min_read_support_outside,                              \
+#define FSEG_LAUNCH_DP(NMV, TV, NM_RT, NLO, QUEUE, MAXWG)                                                                \
+        hipLaunchKernelGGL((k_dp<NMV, TV>), dim3(dp_grid < (MAXWG) ? dp_grid : (MAXWG)), dim3(TV), dp_lds_for(NM_RT), s, st,   \
+                           NLO, NM_RT, QUEUE, pr, c->prob_cap, c->d_cand_off.as<i64>(), c->d_cand_y.as<int>(),               \
+                           c->d_iv_part.as<int>(), c->d_part_lane_off.as<i64>(), c->d_out.as<unsigned>(), c->tri_cap,        \
+                           c->d_amb.as<unsigned>(), c->d_pair_thr.as<int2>(), c->pair_cap, c->P.min_read_support_outside,    \
                            c->d_chosen.as<unsigned char>())
+        // 512 threads (8 waves share the c2 loop) when the tables of the largest problem leave room for their scratch
+        const bool dp_wide = dp_lds_for(c->nm_big) + 8 * 1024 <= kLdsPerWg;
         if (c->small_batch) {
-            FSEG_LAUNCH_DP(kNMax, 0, &st->dp_queue2, 256);
+            if (dp_wide) { FSEG_LAUNCH_DP(kNMax, 512, c->nm_big, 0, &st->dp_queue2, 256); }
+            else { FSEG_LAUNCH_DP(kNMax, 256, c->nm_big, 0, &st->dp_queue2, 256); }
         } else {
-            FSEG_LAUNCH_DP(kDpSmall, 0, &st->dp_queue, 1024);
-            FSEG_LAUNCH_DP(kNMax, kDpSmall, &st->dp_queue2, 256);
+            FSEG_LAUNCH_DP(kDpSmall, 256, kDpSmall, 0, &st->dp_queue, 1024);
+            if (dp_wide) { FSEG_LAUNCH_DP(kNMax, 512, c->nm_big, kDpSmall, &st->dp_queue2, 512); }
+            else { FSEG_LAUNCH_DP(kNMax, 256, c->nm_big, kDpSmall, &st->dp_queue2, 256); }
         }
 #undef FSEG_LAUNCH_DP
     }
@@ -1893,11 +1903,10 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
                        c->d_w_refine.as<double>(), c->P.radius_refine, c->P.sigma, c->d_g.as<double>(), c->d_pk.as<int>(),
                        c->d_pf.as<unsigned char>(), c->d_kp.as<unsigned char>(), c->d_final_flag.as<unsigned char>());
     mark(9);
-    TRY(launch_scan_counts(c, c->d_final_flag.as<unsigned char>(), NPOS, &st->n_final, &scan_grid));
+    TRY(launch_scan_counts(c, c->d_final_flag.as<unsigned char>(), NPOS, &st->n_final, &scan_grid, c->d_final_off.as<i64>() + K));
     hipLaunchKernelGGL(k_scan_emit<kEmitPositions>, dim3(scan_grid), dim3(256), 0, s, c->d_final_flag.as<unsigned char>(),
                        NPOS, c->d_bsum.as<int>(), (const double *)nullptr, (double *)nullptr, K, c->d_pos_off.as<i64>(),
                        c->d_iv_start.as<int>(), c->d_final_y.as<int>(), c->d_final_pos.as<int>(), c->d_final_off.as<i64>());
-    hipLaunchKernelGGL(k_set_total, dim3(1), dim3(1), 0, s, c->d_final_off.as<i64>(), K, &st->n_final);
     mark(10);
     // S7
     hipLaunchKernelGGL(k_label_plan, dim3(1), dim3(256), 0, s, n_part, c->d_part_iv_off.as<i64>(),
@@ -2017,8 +2026,11 @@ int fseg_create(int device, fseg_ctx **out) {
         e = hipStreamSynchronize(c->stream);
     }
     if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_dp<kNMax>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)dp_lds_bytes<kNMax>());
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_dp<kNMax, 256>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)dp_lds_for(kNMax));
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_dp<kNMax, 512>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(kLdsPerWg - 8 * 1024));
     if (e != hipSuccess) {
         g_create_error = std::string("context creation failed: ") + hipGetErrorString(e);
         delete c;
