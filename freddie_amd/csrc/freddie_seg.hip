@@ -51,7 +51,8 @@ enum : unsigned {
     kErrOverflowProblems = 128u,
     kErrOverflowChunks = 256u,
     kErrOverflowCov = 512u,
-    kErrOverflowNm = 1024u,    // a problem is larger than the LDS carve-up this launch was sized for
+    kErrOverflowNm = 1024u,
+    kErrNeedWideDp = 2048u,    // a problem sees >= 65536 reads: its DP needs the 32-bit count table    // a problem is larger than the LDS carve-up this launch was sized for
 };
 
 struct Status {
@@ -1251,7 +1252,7 @@ __global__ void __launch_bounds__(ScoreCfg<NM>::kThreads) k_score(Status *st, in
     }
 }
 
-template <int NM, int T>
+template <int NM, int T, typename OutT>
 __global__ void __launch_bounds__(T) k_dp(Status *st, int n_lo, int nm, u64 *queue, ProblemArrays pr, i64 prob_cap,
                                             const i64 *cand_off, const int *cand_y, const int *iv_part,
                                             const i64 *part_lane_off, const unsigned *out_g, i64 tri_cap,
@@ -1263,9 +1264,9 @@ __global__ void __launch_bounds__(T) k_dp(Status *st, int n_lo, int nm, u64 *que
     const int kTri = nm * (nm - 1) * (nm - 2) / 6, kPairs = nm * (nm - 1) / 2;
     extern __shared__ __align__(16) unsigned char smem[];
     i64 *M = reinterpret_cast<i64 *>(smem);                          // M(b,c), b < c, at c*(c-1)/2 + b
-    unsigned *out_s = reinterpret_cast<unsigned *>(M + kPairs);
-    int *in_s = reinterpret_cast<int *>(out_s + kTri);
-    unsigned char *A = reinterpret_cast<unsigned char *>(in_s + kPairs);
+    int *in_s = reinterpret_cast<int *>(M + kPairs);
+    OutT *out_s = reinterpret_cast<OutT *>(in_s + kPairs);            // counts: 16 bit when every problem sees < 65536 reads
+    unsigned char *A = reinterpret_cast<unsigned char *>(out_s + ((kTri + 3) & ~3));
     __shared__ int cy_s[NM];
     __shared__ u64 work_s;
     __shared__ i64 part_v[T];
@@ -1282,6 +1283,7 @@ __global__ void __launch_bounds__(T) k_dp(Status *st, int n_lo, int nm, u64 *que
         int n = pr.n[p];
         if (n <= n_lo || n > NM || (pr.flags[p] & 2)) continue;
         if (n > nm) { if (threadIdx.x == 0) atomicOr(&st->err, kErrOverflowNm); continue; }
+        if (sizeof(OutT) == 2 && pr.lane_n[p] >= 65536) { if (threadIdx.x == 0) atomicOr(&st->err, kErrNeedWideDp); continue; }
         i64 poff = pr.pair_off[p], toff = pr.tri_off[p];
         int npairs = n * (n - 1) / 2, ntri = n * (n - 1) * (n - 2) / 6;
         if (poff + npairs > pair_cap || toff + ntri > tri_cap) continue;
@@ -1291,7 +1293,7 @@ __global__ void __launch_bounds__(T) k_dp(Status *st, int n_lo, int nm, u64 *que
         const i64 outside = (part_lane_off[part + 1] - part_lane_off[part]) - pr.lane_n[p];
         const bool zamb = (pr.flags[p] & 1) != 0;
         for (int j = threadIdx.x; j < n; j += blockDim.x) cy_s[j] = cand_y[c0 + j];
-        for (int x = threadIdx.x; x < ntri; x += blockDim.x) out_s[x] = out_g[toff + x];
+        for (int x = threadIdx.x; x < ntri; x += blockDim.x) out_s[x] = (OutT)out_g[toff + x];
         for (int q = threadIdx.x; q < npairs; q += blockDim.x)
             in_s[q] = -(int)((i64)amb_g[poff + q] + ((zamb && pair_thr[poff + q].y < 0) ? outside : 0));
         __syncthreads();
@@ -1633,6 +1635,7 @@ struct fseg_ctx {
     DevBuf d_status, d_tacc;
     Status *h_status = nullptr;   // pinned
     bool profiling = false;
+    bool dp_wide_counts = false; // some problem of an earlier run saw >= 65536 reads: DP stages 32-bit counts
     int nm_big = kNMax;         // LDS carve-up of the big-problem kernels: largest problem of the previous run, rounded up
     bool small_batch = false;
     bool use_graph = true;      // replay the launch sequence as hipGraphs (FSEG_NO_GRAPH=1 disables)
@@ -1697,8 +1700,8 @@ size_t score_lds_bytes() {
     return (b + 15) & ~(size_t)15;
 }
 
-inline size_t dp_lds_for(int nm) {
-    return (size_t)(nm * (nm - 1) / 2) * (8 + 4 + 1) + (size_t)(nm * (nm - 1) * (nm - 2) / 6) * 4 + 16;
+inline size_t dp_lds_for(int nm, int count_bytes) {
+    return (size_t)(nm * (nm - 1) / 2) * (8 + 4 + 1) + (size_t)(nm * (nm - 1) * (nm - 2) / 6 + 4) * count_bytes + 16;
 }
 constexpr size_t kLdsPerWg = 160 * 1024;
 constexpr int kDpSmall = 32;
@@ -1873,21 +1876,23 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
     if (do_post) {
     if (c->prob_cap > 0) {
         int dp_grid = grid_for(c->prob_cap, 1, 1024);
-#define FSEG_LAUNCH_DP(NMV, TV, NM_RT, NLO, QUEUE, MAXWG)                                                                \
-        hipLaunchKernelGGL((k_dp<NMV, TV>), dim3(dp_grid < (MAXWG) ? dp_grid : (MAXWG)), dim3(TV), dp_lds_for(NM_RT), s, st,   \
-                           NLO, NM_RT, QUEUE, pr, c->prob_cap, c->d_cand_off.as<i64>(), c->d_cand_y.as<int>(),               \
-                           c->d_iv_part.as<int>(), c->d_part_lane_off.as<i64>(), c->d_out.as<unsigned>(), c->tri_cap,        \
-                           c->d_amb.as<unsigned>(), c->d_pair_thr.as<int2>(), c->pair_cap, c->P.min_read_support_outside,    \
+#define FSEG_LAUNCH_DP(NMV, TV, OUTT, NM_RT, NLO, QUEUE, MAXWG)                                                          \
+        hipLaunchKernelGGL((k_dp<NMV, TV, OUTT>), dim3(dp_grid < (MAXWG) ? dp_grid : (MAXWG)), dim3(TV),                     \
+                           dp_lds_for(NM_RT, (int)sizeof(OUTT)), s, st, NLO, NM_RT, QUEUE, pr, c->prob_cap,                   \
+                           c->d_cand_off.as<i64>(), c->d_cand_y.as<int>(), c->d_iv_part.as<int>(),                            \
+                           c->d_part_lane_off.as<i64>(), c->d_out.as<unsigned>(), c->tri_cap, c->d_amb.as<unsigned>(),        \
+                           c->d_pair_thr.as<int2>(), c->pair_cap, c->P.min_read_support_outside,                              \
                            c->d_chosen.as<unsigned char>())
+        // 16-bit count tables unless some problem sees >= 65536 reads (then a previous run asked for the wide tables);
         // 512 threads (8 waves share the c2 loop) when the tables of the largest problem leave room for their scratch
-        const bool dp_wide = dp_lds_for(c->nm_big) + 8 * 1024 <= kLdsPerWg;
-        if (c->small_batch) {
-            if (dp_wide) { FSEG_LAUNCH_DP(kNMax, 512, c->nm_big, 0, &st->dp_queue2, 256); }
-            else { FSEG_LAUNCH_DP(kNMax, 256, c->nm_big, 0, &st->dp_queue2, 256); }
+        if (c->dp_wide_counts) {
+            const bool wide_wg = dp_lds_for(c->nm_big, 4) + 8 * 1024 <= kLdsPerWg;
+            if (!c->small_batch) { FSEG_LAUNCH_DP(kDpSmall, 256, unsigned, kDpSmall, 0, &st->dp_queue, 1024); }
+            if (wide_wg) { FSEG_LAUNCH_DP(kNMax, 512, unsigned, c->nm_big, c->small_batch ? 0 : kDpSmall, &st->dp_queue2, 256); }
+            else { FSEG_LAUNCH_DP(kNMax, 256, unsigned, c->nm_big, c->small_batch ? 0 : kDpSmall, &st->dp_queue2, 256); }
         } else {
-            FSEG_LAUNCH_DP(kDpSmall, 256, kDpSmall, 0, &st->dp_queue, 1024);
-            if (dp_wide) { FSEG_LAUNCH_DP(kNMax, 512, c->nm_big, kDpSmall, &st->dp_queue2, 512); }
-            else { FSEG_LAUNCH_DP(kNMax, 256, c->nm_big, kDpSmall, &st->dp_queue2, 256); }
+            if (!c->small_batch) { FSEG_LAUNCH_DP(kDpSmall, 256, unsigned short, kDpSmall, 0, &st->dp_queue, 1024); }
+            FSEG_LAUNCH_DP(kNMax, 512, unsigned short, c->nm_big, c->small_batch ? 0 : kDpSmall, &st->dp_queue2, 512);
         }
 #undef FSEG_LAUNCH_DP
     }
@@ -1942,6 +1947,7 @@ int finish_run(fseg_ctx *c) {
         unsigned ovf = s.err & (kErrOverflowPairs | kErrOverflowTri | kErrOverflowWork | kErrOverflowLabels |
                                 kErrOverflowProblems | kErrOverflowChunks | kErrOverflowCov);
         if (s.err & kErrOverflowNm) { ovf |= kErrOverflowNm; c->nm_big = kNMax; }
+        if (s.err & kErrNeedWideDp) { ovf |= kErrNeedWideDp; c->dp_wide_counts = true; drop_graph(c); }
         bool need = ovf != 0 || (i64)s.n_prob > c->prob_cap || (i64)s.n_work > c->work_cap ||
                     (i64)s.pair_used > c->pair_cap || (i64)s.tri_used > c->tri_cap || (i64)s.label_bytes > c->label_cap ||
                     (i64)s.n_vchunks > c->chunk_cap || (i64)s.cov_used > c->cov_cap;
@@ -2026,11 +2032,14 @@ int fseg_create(int device, fseg_ctx **out) {
         e = hipStreamSynchronize(c->stream);
     }
     if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_dp<kNMax, 256>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)dp_lds_for(kNMax));
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_dp<kNMax, 256, unsigned>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)dp_lds_for(kNMax, 4));
     if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_dp<kNMax, 512>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(kLdsPerWg - 8 * 1024));
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_dp<kNMax, 512, unsigned>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLdsPerWg - 8 * 1024));
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_dp<kNMax, 512, unsigned short>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)dp_lds_for(kNMax, 2));
     if (e != hipSuccess) {
         g_create_error = std::string("context creation failed: ") + hipGetErrorString(e);
         delete c;
