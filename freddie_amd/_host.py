@@ -1,0 +1,103 @@
+"""ctypes binding of include/freddie_host.h (native host I/O of the segmentation stage)."""
+import ctypes
+import os
+
+import numpy as np
+
+from . import build as _build
+
+_lib = None
+
+
+class HostError(RuntimeError):
+    pass
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_build.HOST_SO):
+        raise HostError("%s not found: build it first (freddie_amd.build.build_host())" % _build.HOST_SO)
+    L = ctypes.CDLL(_build.HOST_SO)
+    vp = ctypes.c_void_p
+    cpp = ctypes.POINTER(ctypes.c_char_p)
+    L.fhost_load.restype = vp
+    L.fhost_load.argtypes = [cpp, cpp, ctypes.c_int32, ctypes.c_int32]
+    L.fhost_free.restype = None
+    L.fhost_free.argtypes = [vp]
+    L.fhost_error.restype = ctypes.c_char_p
+    L.fhost_error.argtypes = [vp]
+    L.fhost_n_part.restype = ctypes.c_int32
+    L.fhost_n_part.argtypes = [vp]
+    L.fhost_n_reads.restype = ctypes.c_int64
+    L.fhost_n_reads.argtypes = [vp]
+    for name in ("fhost_part_iv_off", "fhost_iv_start", "fhost_iv_end", "fhost_part_rep_off", "fhost_rep_weight",
+                 "fhost_rep_exon_off", "fhost_ex_ts", "fhost_ex_te"):
+        getattr(L, name).restype = vp
+        getattr(L, name).argtypes = [vp]
+    L.fhost_write.restype = ctypes.c_int32
+    L.fhost_write.argtypes = [vp, vp, vp, vp, vp, cpp, ctypes.c_int32]
+    _lib = L
+    return L
+
+
+def _c_strings(items):
+    arr = (ctypes.c_char_p * len(items))()
+    arr[:] = [s.encode() for s in items]
+    return arr
+
+
+def _view(ptr, n, dtype):
+    if n == 0 or not ptr:
+        return np.empty(0, dtype)
+    buf = (ctypes.c_char * (int(n) * np.dtype(dtype).itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype)
+
+
+class HostBatch:
+    """Parsed partitions living in native memory; arrays() are views valid until close()."""
+
+    def __init__(self, split_paths, reads_paths, n_threads=1):
+        self._L = load()
+        self._h = self._L.fhost_load(_c_strings(split_paths), _c_strings(reads_paths), len(split_paths), int(n_threads))
+        if not self._h:
+            raise HostError("fhost_load: out of memory")
+        err = self._L.fhost_error(self._h).decode()
+        if err:
+            self.close()
+            raise HostError(err)
+        self.n_part = self._L.fhost_n_part(self._h)
+        self.n_reads = self._L.fhost_n_reads(self._h)
+
+    def arrays(self):
+        L, h = self._L, self._h
+        np_ = self.n_part
+        part_iv_off = _view(L.fhost_part_iv_off(h), np_ + 1, np.int64)
+        part_rep_off = _view(L.fhost_part_rep_off(h), np_ + 1, np.int64)
+        K, R = int(part_iv_off[-1]), int(part_rep_off[-1])
+        rep_exon_off = _view(L.fhost_rep_exon_off(h), R + 1, np.int64)
+        I = int(rep_exon_off[-1])
+        return dict(part_iv_off=part_iv_off, iv_start=_view(L.fhost_iv_start(h), K, np.int32),
+                    iv_end=_view(L.fhost_iv_end(h), K, np.int32), part_rep_off=part_rep_off,
+                    rep_weight=_view(L.fhost_rep_weight(h), R, np.int32), rep_exon_off=rep_exon_off,
+                    ex_ts=_view(L.fhost_ex_ts(h), I, np.int32), ex_te=_view(L.fhost_ex_te(h), I, np.int32))
+
+    def write(self, part_final_off, final_pos, label_off, labels, out_paths, n_threads=1):
+        a = [np.ascontiguousarray(part_final_off, np.int64), np.ascontiguousarray(final_pos, np.int32),
+             np.ascontiguousarray(label_off, np.int64), np.ascontiguousarray(labels, np.uint8)]
+        rc = self._L.fhost_write(self._h, a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data,
+                                 a[3].ctypes.data if a[3].size else None, _c_strings(out_paths), int(n_threads))
+        if rc != 0:
+            raise HostError(self._L.fhost_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.fhost_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,466 @@
+// freddie_host.cpp -- native host side of the segmentation stage (include/freddie_host.h).
+//
+// Multi-threaded replacement of the reference's per-partition Python I/O: the split / reads TSV parser with
+// the read_reps grouping (py/freddie_segment.py:121-185), the per-read soft-clip / poly-A / unaligned-gap
+// annotation (:289-472) and the segment TSV writer (:703-732).  What each function must produce is defined by
+// those reference lines; the implementation (flat arrays, one std::thread per partition slice, one buffered
+// write per file) is this project's own.
+#include "freddie_host.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+typedef long long i64;
+
+struct Read {
+    i64 id = 0, tint = 0;
+    std::string name, chr, seq;
+    char strand = '+';
+    int ex0 = 0, ex1 = 0;     // exon range of this read inside the partition's exon arrays
+    int rep = 0;
+};
+
+struct Partition {
+    std::string chr;
+    i64 id = 0, read_count = 0;
+    std::vector<int> iv_s, iv_e;
+    std::vector<Read> reads;
+    std::vector<int> ts, te, qs, qe;        // per exon of every read
+    std::vector<int> cig_off, cig_len;      // CIGAR ops per exon (CSR)
+    std::vector<char> cig_op;
+    // read reps in first-occurrence order (:165-170)
+    std::vector<int> rep_first_read, rep_weight;
+    std::string err;
+};
+
+struct Error {
+    std::string msg;
+};
+
+bool read_file(const char *path, std::string &out) {
+    FILE *f = fopen(path, "rb");
+    if (!f) return false;
+    fseek(f, 0, SEEK_END);
+    long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    out.resize(n > 0 ? (size_t)n : 0);
+    size_t got = n > 0 ? fread(&out[0], 1, (size_t)n, f) : 0;
+    fclose(f);
+    return got == out.size();
+}
+
+// strict unsigned decimal ([0-9]+), as the reference's regexes require
+bool parse_uint(const char *b, const char *e, i64 &v) {
+    if (b >= e) return false;
+    i64 x = 0;
+    for (const char *p = b; p < e; ++p) {
+        if (*p < '0' || *p > '9') return false;
+        x = x * 10 + (*p - '0');
+        if (x > (i64)4e18) return false;
+    }
+    v = x;
+    return true;
+}
+bool parse_pair(const char *b, const char *e, i64 &a, i64 &c) {   // "<a>-<c>"
+    const char *dash = (const char *)memchr(b, '-', (size_t)(e - b));
+    return dash && parse_uint(b, dash, a) && parse_uint(dash + 1, e, c);
+}
+bool chr_ok(const char *b, const char *e) {      // chr_re of the reference (:23)
+    static const char first[] = "!#$%&+./:;?@^_|~-", rest[] = "!#$%&*+./:;=?@^_|~-";
+    if (b >= e) return false;
+    for (const char *p = b; p < e; ++p) {
+        unsigned char c = (unsigned char)*p;
+        bool alnum = (c >= '0' && c <= '9') || (c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z');
+        if (alnum) continue;
+        if (!strchr(p == b ? first : rest, c) || c == 0) return false;
+    }
+    return true;
+}
+bool name_ok(const char *b, const char *e) {     // [!-?A-~]{1,254} (:30)
+    if (e - b < 1 || e - b > 254) return false;
+    for (const char *p = b; p < e; ++p) {
+        unsigned char c = (unsigned char)*p;
+        if (!((c >= '!' && c <= '?') || (c >= 'A' && c <= '~'))) return false;
+    }
+    return true;
+}
+
+void split_tabs(const char *b, const char *e, std::vector<std::pair<const char *, const char *>> &cols) {
+    cols.clear();
+    const char *s = b;
+    for (const char *p = b; p <= e; ++p) {
+        if (p == e || *p == '\t') { cols.emplace_back(s, p); s = p + 1; }
+    }
+}
+
+void parse_partition(const char *split_path, const char *reads_path, Partition &P) {
+    std::string text;
+    if (!read_file(split_path, text)) { P.err = std::string("cannot read ") + split_path; return; }
+    std::vector<std::pair<const char *, const char *>> cols;
+    const char *p = text.data(), *end = p + text.size();
+    bool have_header = false;
+    std::unordered_map<std::string, int> rep_of;
+    while (p < end) {
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+        if (!nl) { P.err = std::string(split_path) + ": line without newline"; return; }
+        split_tabs(p, nl, cols);
+        if (*p == '#') {
+            if (have_header) { P.err = std::string(split_path) + ": more than one tint in the file (py/freddie_segment.py:699)"; return; }
+            i64 v;
+            if (cols.size() != 4 || !chr_ok(cols[0].first + 1, cols[0].second) || !parse_uint(cols[1].first, cols[1].second, P.id) ||
+                !parse_uint(cols[3].first, cols[3].second, P.read_count)) { P.err = std::string(split_path) + ": malformed header line"; return; }
+            (void)v;
+            P.chr.assign(cols[0].first + 1, cols[0].second);
+            const char *q = cols[2].first;
+            while (q <= cols[2].second) {
+                const char *c = (const char *)memchr(q, ',', (size_t)(cols[2].second - q));
+                if (!c) c = cols[2].second;
+                i64 s, e;
+                if (!parse_pair(q, c, s, e)) { P.err = std::string(split_path) + ": malformed tint intervals"; return; }
+                P.iv_s.push_back((int)s); P.iv_e.push_back((int)e);
+                q = c + 1;
+            }
+            for (size_t k = 0; k < P.iv_s.size(); ++k) {
+                if (!(P.iv_s[k] < P.iv_e[k])) { P.err = std::string(split_path) + ": interval with start >= end (py/freddie_segment.py:140)"; return; }
+                if (k && !(P.iv_e[k - 1] < P.iv_s[k])) { P.err = std::string(split_path) + ": intervals overlap or are unordered (py/freddie_segment.py:138)"; return; }
+            }
+            have_header = true;
+        } else {
+            if (!have_header) { P.err = std::string(split_path) + ": read line before the tint header"; return; }
+            Read r;
+            if (cols.size() < 6 || !parse_uint(cols[0].first, cols[0].second, r.id) || !name_ok(cols[1].first, cols[1].second) ||
+                !chr_ok(cols[2].first, cols[2].second) || cols[3].second - cols[3].first != 1 ||
+                (*cols[3].first != '+' && *cols[3].first != '-') || !parse_uint(cols[4].first, cols[4].second, r.tint)) {
+                P.err = std::string(split_path) + ": malformed read line"; return;
+            }
+            if (r.tint != P.id) { P.err = std::string(split_path) + ": read refers to another tint"; return; }
+            r.name.assign(cols[1].first, cols[1].second);
+            r.chr.assign(cols[2].first, cols[2].second);
+            r.strand = *cols[3].first;
+            r.ex0 = (int)P.ts.size();
+            for (size_t c = 5; c < cols.size(); ++c) {
+                const char *b = cols[c].first, *e = cols[c].second;
+                const char *c1 = (const char *)memchr(b, ':', (size_t)(e - b));
+                const char *c2 = c1 ? (const char *)memchr(c1 + 1, ':', (size_t)(e - c1 - 1)) : nullptr;
+                i64 ts, te, qs, qe;
+                if (!c2 || !parse_pair(b, c1, ts, te) || !parse_pair(c1 + 1, c2, qs, qe) || c2 + 1 >= e) {
+                    P.err = std::string(split_path) + ": malformed read interval"; return;
+                }
+                P.cig_off.push_back((int)P.cig_len.size());
+                const char *q = c2 + 1;
+                while (q < e) {
+                    const char *d = q;
+                    while (d < e && *d >= '0' && *d <= '9') ++d;
+                    i64 len;
+                    if (d == q || d >= e || !strchr("MIDNSHPX=", *d) || !parse_uint(q, d, len)) {
+                        P.err = std::string(split_path) + ": malformed CIGAR"; return;
+                    }
+                    P.cig_len.push_back((int)len); P.cig_op.push_back(*d);
+                    q = d + 1;
+                }
+                P.ts.push_back((int)ts); P.te.push_back((int)te); P.qs.push_back((int)qs); P.qe.push_back((int)qe);
+            }
+            r.ex1 = (int)P.ts.size();
+            for (int x = r.ex0; x < r.ex1; ++x) {       // :158-161
+                if (!(P.ts[x] < P.te[x] && P.qs[x] < P.qe[x])) { P.err = std::string(split_path) + ": exon with start >= end (py/freddie_segment.py:160)"; return; }
+                if (x > r.ex0 && !(P.te[x - 1] <= P.ts[x] && P.qe[x - 1] <= P.qs[x])) { P.err = std::string(split_path) + ": exons out of order (py/freddie_segment.py:158)"; return; }
+            }
+            // read rep = reads with the same tuple of target intervals, first-occurrence order (:165-170)
+            std::string key;
+            key.resize((size_t)(r.ex1 - r.ex0) * 8);
+            for (int x = r.ex0; x < r.ex1; ++x) {
+                memcpy(&key[(size_t)(x - r.ex0) * 8], &P.ts[x], 4);
+                memcpy(&key[(size_t)(x - r.ex0) * 8 + 4], &P.te[x], 4);
+            }
+            auto it = rep_of.find(key);
+            if (it == rep_of.end()) {
+                r.rep = (int)P.rep_first_read.size();
+                rep_of.emplace(std::move(key), r.rep);
+                P.rep_first_read.push_back((int)P.reads.size());
+                P.rep_weight.push_back(1);
+            } else {
+                r.rep = it->second;
+                P.rep_weight[(size_t)r.rep] += 1;
+            }
+            P.reads.push_back(std::move(r));
+        }
+        p = nl + 1;
+    }
+    P.cig_off.push_back((int)P.cig_len.size());
+    if (!have_header) { P.err = std::string(split_path) + ": no tint header"; return; }
+    if ((i64)P.reads.size() != P.read_count) { P.err = std::string(split_path) + ": read_count does not match the number of read lines (py/freddie_segment.py:164)"; return; }
+    // sequences (:174-185): rid \t contig \t tint \t seq
+    if (!read_file(reads_path, text)) { P.err = std::string("cannot read ") + reads_path; return; }
+    std::unordered_map<i64, std::pair<const char *, const char *>> seq_of;
+    p = text.data(); end = p + text.size();
+    while (p < end) {
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+        const char *le = nl ? nl : end;
+        const char *re = le;
+        while (re > p && (re[-1] == '\r' || re[-1] == ' ' || re[-1] == '\t' || re[-1] == '\n')) --re;   // line.rstrip()
+        split_tabs(p, re, cols);
+        i64 rid;
+        if (cols.size() < 4 || !parse_uint(cols[0].first, cols[0].second, rid)) { P.err = std::string(reads_path) + ": malformed line"; return; }
+        seq_of[rid] = std::make_pair(cols[3].first, cols[3].second);
+        p = nl ? nl + 1 : end;
+    }
+    if (seq_of.size() != P.reads.size()) { P.err = std::string(reads_path) + ": number of sequences differs from the number of reads (py/freddie_segment.py:181)"; return; }
+    for (Read &r : P.reads) {
+        auto it = seq_of.find(r.id);
+        if (it == seq_of.end()) { P.err = std::string(reads_path) + ": a read has no sequence"; return; }
+        r.seq.assign(it->second.first, it->second.second);
+    }
+}
+
+// ---- per-read annotation (get_unaligned_gaps_and_polyA :370-472 and helpers) ------------------------------
+struct Fail { const char *what; };
+
+i64 thread_cigar(const Partition &P, int ex, i64 t_goal, i64 t_pos, i64 q_pos) {     // forward_thread_cigar :289-304
+    if (t_pos > t_goal) throw Fail{"forward_thread_cigar: t_pos > t_goal (:290)"};
+    int idx = P.cig_off[(size_t)ex], end = P.cig_off[(size_t)ex + 1];
+    while (t_pos < t_goal) {
+        if (idx >= end) throw Fail{"forward_thread_cigar: CIGAR exhausted before the goal (:293)"};
+        i64 step = std::min<i64>(P.cig_len[(size_t)idx], t_goal - t_pos);       // every op is clipped, insertions too
+        char op = P.cig_op[(size_t)idx];
+        if (op == 'M' || op == 'X' || op == '=') { t_pos += step; q_pos += step; }
+        else if (op == 'D') t_pos += step;
+        else if (op == 'I') q_pos += step;
+        ++idx;
+    }
+    return q_pos;
+}
+void query_at_or_after(const Partition &P, const Read &r, i64 start, i64 &q, i64 &slack) {    // get_interval_start :307-326
+    for (int x = r.ex0; x < r.ex1; ++x) {
+        if (P.te[x] < start) continue;
+        if (start < P.ts[x]) { q = P.qs[x]; slack = start - P.ts[x]; }
+        else { q = thread_cigar(P, x, start, P.ts[x], P.qs[x]); slack = 0; }
+        if (!(slack <= 0 && P.qs[x] <= q && q <= P.qe[x])) throw Fail{"get_interval_start: slack / query position out of range (:323-324)"};
+        return;
+    }
+    throw Fail{"get_interval_start: no exon at or after the position (:326)"};
+}
+void query_at_or_before(const Partition &P, const Read &r, i64 end, i64 &q, i64 &slack) {     // get_interval_end :329-349
+    for (int x = r.ex1 - 1; x >= r.ex0; --x) {
+        if (P.ts[x] > end) continue;
+        if (P.te[x] < end) { q = P.qe[x]; slack = P.te[x] - end; }
+        else { q = thread_cigar(P, x, end, P.ts[x], P.qs[x]); slack = 0; }
+        if (!(slack <= 0 && 0 <= q && q <= P.qe[x])) throw Fail{"get_interval_end: slack / query position out of range (:346-347)"};
+        return;
+    }
+    throw Fail{"get_interval_end: no exon at or before the position (:349)"};
+}
+
+struct PolyRun { i64 first, len; double purity; char ch; };
+
+// find_longest_poly (:352-367) over the window [s0, e0) of the read in alignment orientation: for '-' reads the
+// window is taken from the end of the stored sequence backwards and the complement letter is searched.
+void poly_runs(const std::string &seq, bool minus, i64 s0, i64 e0, char ch, std::vector<PolyRun> &out) {
+    const i64 n = (i64)seq.size();
+    if (e0 - s0 == 0) return;
+    i64 count = e0 - s0;
+    if (count < 0) count = 0;
+    char target = ch;
+    if (minus) target = ch == 'A' ? 'T' : (ch == 'T' ? 'A' : (ch == 'C' ? 'G' : 'C'));
+    auto at = [&](i64 t) -> char {
+        i64 idx = minus ? n - 1 - s0 - t : s0 + t;
+        if (idx < 0 || idx >= n) throw Fail{"find_longest_poly: sequence index out of range (:355)"};
+        return seq[(size_t)idx];
+    };
+    (void)at(0);
+    if (!minus && s0 + count > n) count = n - s0;
+    if (minus && n - 1 - s0 - (count - 1) < 0) count = n - s0;
+    std::vector<int> sc((size_t)count);
+    int prev = at(0) == target ? 1 : 0;
+    sc[0] = prev;
+    for (i64 t = 1; t < count; ++t) {
+        prev = std::max(0, prev + (at(t) == target ? 1 : -2));
+        sc[(size_t)t] = prev;
+    }
+    i64 i = 0;
+    while (i < count) {
+        if (sc[(size_t)i] <= 0) { ++i; continue; }
+        i64 j = i, best_i = i;
+        int best_s = sc[(size_t)i];
+        while (j < count && sc[(size_t)j] > 0) {
+            if (sc[(size_t)j] >= best_s) { best_s = sc[(size_t)j]; best_i = j; }   // max over (score, index)
+            ++j;
+        }
+        i64 len = best_i + 1 - i, hits = 0;
+        for (i64 t = i; t < i + len; ++t) hits += at(t) == target;
+        out.push_back(PolyRun{i, len, (double)hits / (double)len, ch});
+        i = j;
+    }
+}
+bool best_poly(const std::string &seq, bool minus, i64 s0, i64 e0, PolyRun &best) {
+    std::vector<PolyRun> runs;
+    bool have = false;
+    for (char ch : {'A', 'T'}) {
+        runs.clear();
+        poly_runs(seq, minus, s0, e0, ch, runs);
+        for (const PolyRun &r : runs) {
+            if (r.len < 20 || r.purity < 0.85) continue;
+            if (!have || r.purity > best.purity) { best = r; have = true; }   // max purity, first one wins ties
+        }
+    }
+    return have;
+}
+
+void annotate_read(const Partition &P, const Read &r, const unsigned char *data, i64 S, const int *fp,
+                   std::vector<std::string> &gaps) {
+    gaps.clear();
+    std::vector<std::pair<i64, i64>> runs;
+    for (i64 i = 0; i < S;) {
+        if (data[i] != '1') { ++i; continue; }
+        i64 j = i;
+        while (j + 1 < S && data[j + 1] == '1') ++j;
+        runs.emplace_back(i, j);
+        i = j + 1;
+    }
+    if (runs.empty()) return;
+    const i64 length = (i64)r.seq.size();
+    const bool minus = r.strand == '-';
+    i64 q_ssc, q_esc, slack;
+    query_at_or_after(P, r, fp[runs.front().first], q_ssc, slack);          // segs[f][0]
+    query_at_or_before(P, r, fp[runs.back().second + 1], q_esc, slack);     // segs[l][1]
+    if (!(0 <= q_ssc && q_ssc <= q_esc && q_esc <= length)) throw Fail{"soft-clip positions out of order (:389)"};
+    char buf[96];
+    PolyRun b;
+    if (best_poly(r.seq, minus, 0, q_ssc, b)) {
+        i64 gap = q_ssc - b.first - b.len;
+        if (!(0 <= b.first && b.first < q_ssc && 0 <= gap && gap < q_ssc)) throw Fail{"start poly tail out of range (:405,:410)"};
+        snprintf(buf, sizeof buf, "S%c_%lld:%lld", b.ch, b.len, gap); gaps.emplace_back(buf);
+        snprintf(buf, sizeof buf, "SSC:%lld", b.first); gaps.emplace_back(buf);
+    } else { snprintf(buf, sizeof buf, "SSC:%lld", q_ssc); gaps.emplace_back(buf); }
+    if (best_poly(r.seq, minus, q_esc, length, b)) {
+        if (!(0 <= b.first && b.first < length - q_esc && length - q_esc - b.first > 0)) throw Fail{"end poly tail out of range (:435,:441,:450)"};
+        snprintf(buf, sizeof buf, "E%c_%lld:%lld", b.ch, b.len, b.first); gaps.emplace_back(buf);
+        snprintf(buf, sizeof buf, "ESC:%lld", length - q_esc - b.first); gaps.emplace_back(buf);
+    } else { snprintf(buf, sizeof buf, "ESC:%lld", length - q_esc); gaps.emplace_back(buf); }
+    for (size_t k = 0; k + 1 < runs.size(); ++k) {
+        i64 last1 = runs[k].second, first2 = runs[k + 1].first, q_a, slack_a, q_b, slack_b;
+        query_at_or_before(P, r, fp[last1 + 1], q_a, slack_a);
+        query_at_or_after(P, r, fp[first2], q_b, slack_b);
+        if (!(0 < q_a && q_a <= q_b && q_b < length)) throw Fail{"unaligned gap positions out of order (:462)"};
+        i64 size = std::max<i64>(0, q_b - q_a + slack_a + slack_b);
+        if (!(0 <= size && size < length && last1 < first2)) throw Fail{"unaligned gap size out of range (:466-468)"};
+        snprintf(buf, sizeof buf, "%lld-%lld:%lld", last1, first2, size); gaps.emplace_back(buf);
+    }
+    std::sort(gaps.begin(), gaps.end());                                     // sorted(set(...)) on strings (:472)
+    gaps.erase(std::unique(gaps.begin(), gaps.end()), gaps.end());
+}
+
+template <typename F>
+void parallel_for(int n, int n_threads, F fn) {
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > n) n_threads = n;
+    if (n_threads <= 1) { for (int i = 0; i < n; ++i) fn(i); return; }
+    std::atomic<int> next(0);
+    std::vector<std::thread> pool;
+    for (int t = 0; t < n_threads; ++t)
+        pool.emplace_back([&]() { for (int i; (i = next.fetch_add(1)) < n;) fn(i); });
+    for (std::thread &t : pool) t.join();
+}
+
+}  // namespace
+
+struct fhost_batch {
+    std::vector<Partition> parts;
+    std::string err;
+    std::vector<int64_t> part_iv_off, part_rep_off, rep_exon_off;
+    std::vector<int32_t> iv_start, iv_end, rep_weight, ex_ts, ex_te;
+    int64_t n_reads = 0;
+};
+
+extern "C" {
+
+fhost_batch *fhost_load(const char *const *split_paths, const char *const *reads_paths, int32_t n, int32_t n_threads) {
+    fhost_batch *b = new (std::nothrow) fhost_batch();
+    if (!b) return nullptr;
+    if (n <= 0) { b->err = "fhost_load: empty batch"; return b; }
+    b->parts.resize((size_t)n);
+    parallel_for(n, n_threads, [&](int i) { parse_partition(split_paths[i], reads_paths[i], b->parts[(size_t)i]); });
+    for (const Partition &P : b->parts) if (!P.err.empty()) { b->err = P.err; return b; }
+    b->part_iv_off.assign(1, 0); b->part_rep_off.assign(1, 0); b->rep_exon_off.assign(1, 0);
+    for (const Partition &P : b->parts) {
+        b->iv_start.insert(b->iv_start.end(), P.iv_s.begin(), P.iv_s.end());
+        b->iv_end.insert(b->iv_end.end(), P.iv_e.begin(), P.iv_e.end());
+        b->part_iv_off.push_back((int64_t)b->iv_start.size());
+        for (size_t r = 0; r < P.rep_first_read.size(); ++r) {
+            const Read &rd = P.reads[(size_t)P.rep_first_read[r]];
+            for (int x = rd.ex0; x < rd.ex1; ++x) { b->ex_ts.push_back(P.ts[(size_t)x]); b->ex_te.push_back(P.te[(size_t)x]); }
+            b->rep_exon_off.push_back((int64_t)b->ex_ts.size());
+            b->rep_weight.push_back(P.rep_weight[r]);
+        }
+        b->part_rep_off.push_back((int64_t)b->rep_weight.size());
+        b->n_reads += (int64_t)P.reads.size();
+    }
+    return b;
+}
+
+void fhost_free(fhost_batch *b) { delete b; }
+const char *fhost_error(const fhost_batch *b) { return b ? b->err.c_str() : "null batch"; }
+int32_t fhost_n_part(const fhost_batch *b) { return (int32_t)b->parts.size(); }
+int64_t fhost_n_reads(const fhost_batch *b) { return b->n_reads; }
+const int64_t *fhost_part_iv_off(const fhost_batch *b) { return b->part_iv_off.data(); }
+const int32_t *fhost_iv_start(const fhost_batch *b) { return b->iv_start.data(); }
+const int32_t *fhost_iv_end(const fhost_batch *b) { return b->iv_end.data(); }
+const int64_t *fhost_part_rep_off(const fhost_batch *b) { return b->part_rep_off.data(); }
+const int32_t *fhost_rep_weight(const fhost_batch *b) { return b->rep_weight.data(); }
+const int64_t *fhost_rep_exon_off(const fhost_batch *b) { return b->rep_exon_off.data(); }
+const int32_t *fhost_ex_ts(const fhost_batch *b) { return b->ex_ts.data(); }
+const int32_t *fhost_ex_te(const fhost_batch *b) { return b->ex_te.data(); }
+
+int32_t fhost_write(fhost_batch *b, const int64_t *part_final_off, const int32_t *final_pos, const int64_t *label_off,
+                    const uint8_t *labels, const char *const *out_paths, int32_t n_threads) {
+    if (!b || !b->err.empty()) return 1;
+    std::mutex err_mutex;
+    const int n = (int)b->parts.size();
+    parallel_for(n, n_threads, [&](int p) {
+        const Partition &P = b->parts[(size_t)p];
+        const int *fp = final_pos + part_final_off[p];
+        const i64 F = part_final_off[p + 1] - part_final_off[p], S = F - 1;
+        std::string out;
+        out.reserve(P.reads.size() * (size_t)(S + 64) + (size_t)F * 10 + 64);
+        char num[32];
+        out += '#'; out += P.chr; out += '\t';
+        snprintf(num, sizeof num, "%lld", P.id); out += num; out += '\t';
+        for (i64 i = 0; i < F; ++i) { if (i) out += ','; snprintf(num, sizeof num, "%d", fp[i]); out += num; }
+        out += '\n';
+        std::vector<std::string> gaps;
+        try {
+            for (const Read &r : P.reads) {
+                const unsigned char *row = labels + label_off[p] + (i64)r.rep * S;
+                annotate_read(P, r, row, S, fp, gaps);
+                snprintf(num, sizeof num, "%lld", r.id); out += num; out += '\t';
+                out += r.name; out += '\t'; out += r.chr; out += '\t'; out += r.strand; out += '\t';
+                snprintf(num, sizeof num, "%lld", r.tint); out += num; out += '\t';
+                out.append(reinterpret_cast<const char *>(row), (size_t)(S > 0 ? S : 0));
+                out += '\t';
+                for (const std::string &g : gaps) { out += g; out += ','; }
+                out += '\n';
+            }
+        } catch (const Fail &f) {
+            std::lock_guard<std::mutex> lock(err_mutex);
+            if (b->err.empty()) b->err = std::string(out_paths[p]) + ": " + f.what + " (reference: py/freddie_segment.py)";
+            return;
+        }
+        FILE *fo = fopen(out_paths[p], "wb");
+        if (!fo || fwrite(out.data(), 1, out.size(), fo) != out.size()) {
+            std::lock_guard<std::mutex> lock(err_mutex);
+            if (b->err.empty()) b->err = std::string("cannot write ") + out_paths[p];
+        }
+        if (fo) fclose(fo);
+    });
+    return b->err.empty() ? 0 : 2;
+}
+
+}  // extern "C"

@@ -46,7 +46,7 @@ def parse_args(argv=None):
     ap.add_argument("-o", "--outdir", type=str, default="freddie_segment/",
                     help="Path to output directory. Default: freddie_segment/")
     ap.add_argument("-t", "--threads", type=int, default=1,
-                    help="Host worker processes per GPU for parsing / writing. Default: 1")
+                    help="Host threads per GPU for parsing / annotating / writing. Default: 1")
     ap.add_argument("-sd", "--sigma", type=float, default=5.0, help="Sigma value for gaussian_filter1d")
     ap.add_argument("-tp", "--threshold-rate", type=float, default=0.90,
                     help="Threshold rate above which the read will be considered as covering a segment. Default: 0.9")
@@ -383,16 +383,90 @@ def _load_partition(split_dir, contig, tint_id):
     return tints[0]
 
 
-def run_segment_batch(jobs, params, ctx):
-    """jobs: list of (split_dir, outdir, contig, tint_id).  Parses, segments on the GPU and writes the outputs."""
+def _job_paths(job):
+    split_dir, outdir, contig, tint_id = job
+    return ("{}/{}/split_{}_{}.tsv".format(split_dir, contig, contig, tint_id),
+            "{}/{}/reads_{}_{}.tsv".format(split_dir, contig, contig, tint_id),
+            "{}/{}/segment_{}_{}.tsv".format(outdir, contig, contig, tint_id),
+            "{}/{}/segment_{}_{}.log".format(outdir, contig, contig, tint_id))
+
+
+def set_context_params(ctx, params):
+    (sigma, smoothed_threshold, threshold_rate, variance_factor, max_problem_size, min_read_support_outside,
+     ignore_ends) = params
+    ctx.set_params(sigma, threshold_rate, variance_factor, max_problem_size, min_read_support_outside, ignore_ends,
+                   tables.gaussian_half_kernel(sigma, 4.0), tables.gaussian_half_kernel(sigma, 1.0),
+                   np.asarray(smoothed_threshold, np.float64))
+
+
+def load_batch_native(jobs, threads=1):
+    """Parse the partitions of a batch with the native host library (multi-threaded)."""
+    from . import _host
+    paths = [_job_paths(j) for j in jobs]
+    for _, _, _, log in paths:
+        open(log, "w+").close()                      # the reference leaves an empty .log per partition (:695)
+    return _host.HostBatch([p[0] for p in paths], [p[1] for p in paths], n_threads=threads)
+
+
+def run_segment_batch(jobs, params, ctx, threads=1, host_batch=None, params_set=False):
+    """jobs: list of (split_dir, outdir, contig, tint_id).  Parses (natively), segments on the GPU, annotates and
+    writes the outputs (natively).  Returns (host_batch, results) for the caller to write when ``defer_write``."""
+    hb = host_batch or load_batch_native(jobs, threads)
+    try:
+        if not params_set:
+            set_context_params(ctx, params)
+        ctx.upload(**hb.arrays())
+        ctx.run()
+        part_final_off, final_pos, label_off, labels = ctx.download()
+        hb.write(part_final_off, final_pos, label_off, labels, [_job_paths(j)[2] for j in jobs], n_threads=threads)
+    finally:
+        hb.close()
+    return [(j[2], j[3]) for j in jobs]
+
+
+def run_segment_batch_python(jobs, params, ctx):
+    """The same through the Python host code (reference-shaped dicts); kept for the in-process seam and tests."""
     tints = []
     for split_dir, outdir, contig, tint_id in jobs:
-        open("{}/{}/segment_{}_{}.log".format(outdir, contig, contig, tint_id), "w+").close()   # :695 (empty log)
+        open("{}/{}/segment_{}_{}.log".format(outdir, contig, contig, tint_id), "w+").close()
         tints.append(_load_partition(split_dir, contig, tint_id))
     segment_batch(tints, *params, ctx=ctx)
     for (split_dir, outdir, contig, tint_id), tint in zip(jobs, tints):
         write_segment_tsv(tint, "{}/{}/segment_{}_{}.tsv".format(outdir, contig, contig, tint_id))
     return [(j[2], j[3]) for j in jobs]
+
+
+def run_batches(batches, params, ctx, threads, on_done):
+    """Pipelined driver of one GPU: while the GPU works on batch i, batch i+1 is parsed and batch i-1 is
+    annotated and written by host threads (the native calls release the GIL)."""
+    from concurrent.futures import ThreadPoolExecutor
+    if not batches:
+        return
+    set_context_params(ctx, params)
+    with ThreadPoolExecutor(max_workers=2) as pool:
+        nxt = pool.submit(load_batch_native, batches[0], threads)
+        pending_write = None
+
+        def finish(hb, res, jobs):
+            try:
+                hb.write(*res, [_job_paths(j)[2] for j in jobs], n_threads=threads)
+            finally:
+                hb.close()
+            return jobs
+
+        for i, jobs in enumerate(batches):
+            hb = nxt.result()
+            if i + 1 < len(batches):
+                nxt = pool.submit(load_batch_native, batches[i + 1], threads)
+            ctx.upload(**hb.arrays())
+            ctx.run()
+            res = ctx.download()
+            if pending_write is not None:
+                for j in pending_write.result():
+                    on_done((j[2], j[3]))
+            pending_write = pool.submit(finish, hb, res, jobs)
+        for j in pending_write.result():
+            on_done((j[2], j[3]))
 
 
 def run_segment(segment_args, ctx=None):
@@ -430,13 +504,11 @@ def make_batches(jobs_with_cost, bytes_per_batch):
     return batches
 
 
-def _gpu_worker(device, jobs_with_cost, params, batch_bytes, queue):
+def _gpu_worker(device, jobs_with_cost, params, batch_bytes, threads, queue):
     from . import _lib
     ctx = _lib.Context(device)
     try:
-        for batch in make_batches(jobs_with_cost, batch_bytes):
-            for done in run_segment_batch(batch, params, ctx):
-                queue.put(done)
+        run_batches(make_batches(jobs_with_cost, batch_bytes), params, ctx, threads, queue.put)
     finally:
         ctx.close()
         queue.put(None)
@@ -472,17 +544,17 @@ def main(argv=None):
         from . import _lib
         ctx = _lib.Context(0)
         jobs = [((split_dir, args.outdir, parts[i][0], parts[i][1]), parts[i][2]) for i in assign[0]]
-        for batch in make_batches(jobs, batch_bytes):
-            for _ in run_segment_batch(batch, params, ctx):
-                report()
-        ctx.close()
+        try:
+            run_batches(make_batches(jobs, batch_bytes), params, ctx, args.threads, lambda _done: report())
+        finally:
+            ctx.close()
         return
     mp = multiprocessing.get_context("spawn")
     queue = mp.Queue()
     procs = []
     for dev in range(n_gpus):
         jobs = [((split_dir, args.outdir, parts[i][0], parts[i][1]), parts[i][2]) for i in assign[dev]]
-        pr = mp.Process(target=_gpu_worker, args=(dev, jobs, params, batch_bytes, queue))
+        pr = mp.Process(target=_gpu_worker, args=(dev, jobs, params, batch_bytes, args.threads, queue))
         pr.start()
         procs.append(pr)
     alive = n_gpus

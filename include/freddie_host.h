@@ -1,0 +1,54 @@
+/*
+ * freddie_host.h -- C-ABI of the native host side of the segmentation stage:
+ * multi-threaded parsing of split_*.tsv / reads_*.tsv into the flat arrays fseg_upload() takes, and
+ * multi-threaded gaps / poly-A annotation + segment_*.tsv writing from the device results.
+ *
+ * It replaces, for the batched CLI path, the reference's Python
+ *   read_split()      py/freddie_segment.py:121-171  (incl. the read_reps grouping :165-170)
+ *   read_sequence()   py/freddie_segment.py:174-185
+ *   get_unaligned_gaps_and_polyA() and helpers   py/freddie_segment.py:289-472
+ *   the writer part of run_segment()             py/freddie_segment.py:703-732
+ * It does no segmentation arithmetic (that is libfreddie_seg.so's job, on the GPU).
+ */
+#ifndef FREDDIE_HOST_H
+#define FREDDIE_HOST_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fhost_batch fhost_batch;
+
+/* Parse n partitions (split_paths[i], reads_paths[i]) with n_threads worker threads.
+ * Returns NULL on allocation failure; otherwise a batch whose fhost_error() is "" on success. */
+fhost_batch *fhost_load(const char *const *split_paths, const char *const *reads_paths, int32_t n, int32_t n_threads);
+void fhost_free(fhost_batch *b);
+const char *fhost_error(const fhost_batch *b);   /* "" when the batch is usable */
+
+/* Sizes and flat arrays in exactly the layout of fseg_batch (include/freddie_seg.h).  Pointers stay valid
+ * until fhost_free(). */
+int32_t fhost_n_part(const fhost_batch *b);
+int64_t fhost_n_reads(const fhost_batch *b);
+const int64_t *fhost_part_iv_off(const fhost_batch *b);
+const int32_t *fhost_iv_start(const fhost_batch *b);
+const int32_t *fhost_iv_end(const fhost_batch *b);
+const int64_t *fhost_part_rep_off(const fhost_batch *b);
+const int32_t *fhost_rep_weight(const fhost_batch *b);
+const int64_t *fhost_rep_exon_off(const fhost_batch *b);
+const int32_t *fhost_ex_ts(const fhost_batch *b);
+const int32_t *fhost_ex_te(const fhost_batch *b);
+
+/* Annotate and write: for partition p the device results are final positions
+ * final_pos[part_final_off[p] .. part_final_off[p+1]) and the label rows of its read reps at
+ * labels[label_off[p] + rep * (F_p - 1)] (ASCII '0','1','2'; what fseg_download() returns).
+ * out_paths[p] receives segment_<contig>_<tint>.tsv.  Returns 0 on success; on failure fhost_error() says
+ * which reference assertion would have fired. */
+int32_t fhost_write(fhost_batch *b, const int64_t *part_final_off, const int32_t *final_pos, const int64_t *label_off,
+                    const uint8_t *labels, const char *const *out_paths, int32_t n_threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

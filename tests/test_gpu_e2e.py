@@ -53,3 +53,24 @@ def test_cli_many_partitions_in_batches(tmp_path):
         a = open(os.path.join(str(tmp_path / "all"), "chrS", "segment_chrS_%d.tsv" % (100 + i)), "rb").read()
         b = open(os.path.join(str(tmp_path / ("out%d" % i)), "chrS", "segment_chrS_%d.tsv" % (100 + i)), "rb").read()
         assert a == b and len(a) > 0
+
+
+def test_in_process_seam_matches_reference(tmp_path):
+    """segment(tint, ...) -- the reference's in-process seam (py/freddie_segment.py:738-747) -- through the Python
+    host code: same mutations of the tint dict, same TSV bytes."""
+    from freddie_amd import segment, tables
+    name = "g1_retention"
+    g = goldens.load(name)
+    case = goldens.manifest()["cases"][name]
+    d, contig, tid = input_dir(name, tmp_path)
+    tint = segment._load_partition(d, contig, tid)
+    run = case["run"]
+    rid = segment.segment(tint, run["sigma"], tables.smooth_threshold(run["threshold_rate"]), run["threshold_rate"],
+                          run["variance_factor"], run["max_problem_size"], run["min_read_support_outside"],
+                          not run["consider_ends"])
+    assert rid == tint["id"]
+    assert tint["final_positions"] == g["final_positions"].tolist()
+    assert tint["segs"][0] == (tint["final_positions"][0], tint["final_positions"][1])
+    out = tmp_path / "seam.tsv"
+    segment.write_segment_tsv(tint, str(out))
+    assert out.read_bytes() == g["segment_tsv"].tobytes()
