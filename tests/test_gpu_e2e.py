@@ -74,3 +74,26 @@ def test_in_process_seam_matches_reference(tmp_path):
     out = tmp_path / "seam.tsv"
     segment.write_segment_tsv(tint, str(out))
     assert out.read_bytes() == g["segment_tsv"].tobytes()
+
+
+def test_cli_hundred_thousand_reads(tmp_path):
+    """200 partitions x 500 reads through the batched, pipelined CLI; every output file must hash to what the
+    reference CLI wrote for the same (regenerated) inputs (tests/golden/g5_cli_hashes.json)."""
+    import hashlib
+    import json
+    from freddie_amd import synth
+    doc = json.load(open(os.path.join(goldens.GOLDEN_DIR, "g5_cli_hashes.json")))
+    gen = doc["generator"]
+    d = str(tmp_path / "in")
+    for i in range(gen["n_partitions"]):
+        synth.generate(i, n_reads=gen["n_reads"], n_exons=gen["n_exons"], rp=gen["rp"], write_dir=d)
+    for f, want in list(doc["split_inputs"].items())[:5]:
+        assert hashlib.sha256(open(os.path.join(d, "chrS", f), "rb").read()).hexdigest() == want
+    out = str(tmp_path / "out")
+    cmd = [sys.executable, os.path.join(ROOT, "py", "freddie_segment.py"), "-s", d, "-o", out, "--gpus", "1", "-t", "4",
+           "--batch-reads", "20000"]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr[-2000:]
+    bad = [f for f, want in doc["outputs"].items()
+           if hashlib.sha256(open(os.path.join(out, "chrS", f), "rb").read()).hexdigest() != want]
+    assert not bad, "%d of %d outputs differ from the reference, e.g. %s" % (len(bad), len(doc["outputs"]), bad[:3])
