@@ -124,30 +124,58 @@ __device__ __forceinline__ void label_thresholds(i64 L, const double *h_table, i
 
 // ---------------------------------------------------------------------------------------------
 // S1  splice histogram   (process_splicing_data, py/freddie_segment.py:648-678)
-// one thread per read rep; integer counts, so atomic adds are order-independent
+// One workgroup per chunk of kHistChunk consecutive positions of one partition.  The reads that can touch the
+// chunk are a contiguous range of the position-sorted lane list (same two binary searches as k_prob_range); their
+// exon ends falling into the chunk are counted in an LDS histogram (integer counts, so LDS atomics are
+// order-free) which is then written out whole -- no global atomics and no memset of the histogram.
+// A lane is one read (reps are repeated rep_weight times in the lane list), so every hit adds 1.
 // ---------------------------------------------------------------------------------------------
-__global__ void k_hist(int n_part, const i64 *part_rep_off, const i64 *part_iv_off, const int *iv_start,
-                       const int *iv_end, const i64 *pos_off, const int *rep_weight, const i64 *rep_exon_off,
-                       const int *ex_ts, const int *ex_te, int ignore_ends, int *y_raw, Status *st) {
-    i64 n_rep = part_rep_off[n_part];
-    for (i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x; r < n_rep; r += (i64)gridDim.x * blockDim.x) {
-        int p = (int)last_le(part_rep_off, (i64)n_part + 1, r);
-        i64 k0 = part_iv_off[p], k1 = part_iv_off[p + 1];
-        int w = rep_weight[r];
-        i64 e0 = rep_exon_off[r], e1 = rep_exon_off[r + 1];
-        for (i64 e = e0; e < e1; ++e) {
-            int ts = ex_ts[e], te = ex_te[e];
-            bool ok = k1 > k0 && ts >= iv_start[k0];
-            i64 k = k0;
-            if (ok) {
-                k = k0 + last_le(iv_start + k0, k1 - k0, ts);
-                ok = ts <= iv_end[k] && te >= iv_start[k] && te <= iv_end[k];   // :666-668
+constexpr int kHistChunk = 8192;
+__global__ void __launch_bounds__(512) k_hist(int n_chunks, const int *chunk_part, const i64 *chunk_p0, const int *chunk_n,
+                                              const int *chunk_glo, const int *chunk_ghi, const i64 *part_iv_off,
+                                              const int *iv_start, const int *iv_end, const i64 *pos_off,
+                                              const i64 *part_lane_off, const int *lane_rep, const int *lane_start,
+                                              const int *lane_pmax, const i64 *rep_exon_off, const int *ex_ts,
+                                              const int *ex_te, int ignore_ends, int *y_raw, Status *st) {
+    __shared__ int hist[kHistChunk];
+    for (int ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+        const int part = chunk_part[ch];
+        const i64 p0 = chunk_p0[ch];
+        const int np = chunk_n[ch];
+        const int g_lo = chunk_glo[ch], g_hi = chunk_ghi[ch];          // genomic position of the first / last position
+        const i64 k0 = part_iv_off[part], k1 = part_iv_off[part + 1];
+        __syncthreads();
+        for (int i = threadIdx.x; i < np; i += blockDim.x) hist[i] = 0;
+        // lanes whose [first, last] position range meets [g_lo, g_hi]
+        i64 a = part_lane_off[part], L1 = part_lane_off[part + 1], b = L1;
+        while (a < b) { i64 m = (a + b) >> 1; if (lane_pmax[m] < g_lo) a = m + 1; else b = m; }
+        const i64 lo = a;
+        b = L1;
+        while (a < b) { i64 m = (a + b) >> 1; if (lane_start[m] <= g_hi) a = m + 1; else b = m; }
+        const i64 hi = a;
+        __syncthreads();
+        for (i64 l = lo + threadIdx.x; l < hi; l += blockDim.x) {
+            const i64 r = lane_rep[l];
+            const i64 e0 = rep_exon_off[r], e1 = rep_exon_off[r + 1];
+            for (i64 e = e0; e < e1; ++e) {
+                const int ts = ex_ts[e], te = ex_te[e];
+                if (te < g_lo) continue;
+                if (ts > g_hi) break;                                    // exons of a read are ordered (:158)
+                // the interval that holds ts must hold te as well (:666-668)
+                bool ok = ts >= iv_start[k0];
+                i64 k = k0;
+                if (ok) {
+                    k = k0 + last_le(iv_start + k0, k1 - k0, ts);
+                    ok = ts <= iv_end[k] && te <= iv_end[k];
+                }
+                if (!ok) { atomicOr(&st->err, kErrExonInterval); continue; }
+                const i64 base = pos_off[k] - iv_start[k] - p0;
+                if (!(ignore_ends && e == e0) && ts >= g_lo && ts <= g_hi) atomicAdd(&hist[base + ts], 1);       // :670-671
+                if (!(ignore_ends && e == e1 - 1) && te >= g_lo && te <= g_hi) atomicAdd(&hist[base + te], 1);   // :672-673
             }
-            if (!ok) { atomicOr(&st->err, kErrExonInterval); continue; }
-            i64 base = pos_off[k] - iv_start[k];
-            if (!(ignore_ends && e == e0)) atomicAdd(&y_raw[base + ts], w);          // :670-671
-            if (!(ignore_ends && e == e1 - 1)) atomicAdd(&y_raw[base + te], w);      // :672-673
         }
+        __syncthreads();
+        for (int i = threadIdx.x; i < np; i += blockDim.x) y_raw[p0 + i] = hist[i];
     }
 }
 
@@ -1621,6 +1649,8 @@ struct fseg_ctx {
     // device buffers: position-sized
     DevBuf d_y_raw, d_y, d_flag, d_idx, d_v, d_bsum, d_g, d_pk, d_pf, d_kp, d_final_flag;
     // partition-sized
+    DevBuf d_hc_part, d_hc_p0, d_hc_n, d_hc_glo, d_hc_ghi;
+    int n_hist_chunks = 0;
     DevBuf d_voff, d_chunk_off, d_csum, d_mean, d_thr, d_label_off, d_part_has2, d_rb_part, d_rb_r0;
     int n_rep_blocks = 0;
     // candidate-sized
@@ -1771,13 +1801,14 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
                      c->d_prob_lane_n.as<int>(), c->d_prob_work_base.as<i64>()};
     if (do_pre) {
     HIP_TRY(c, hipMemsetAsync(st, 0, sizeof(Status), s));
-    HIP_TRY(c, hipMemsetAsync(c->d_y_raw.p, 0, (size_t)NPOS * 4, s));
     mark(0);
     // S1
-    hipLaunchKernelGGL(k_hist, dim3(grid_for(c->R, 256, 2048)), dim3(256), 0, s, n_part, c->d_part_rep_off.as<i64>(),
-                       c->d_part_iv_off.as<i64>(), c->d_iv_start.as<int>(), c->d_iv_end.as<int>(), c->d_pos_off.as<i64>(),
-                       c->d_rep_weight.as<int>(), c->d_rep_exon_off.as<i64>(), c->d_ex_ts.as<int>(), c->d_ex_te.as<int>(),
-                       c->P.ignore_ends, c->d_y_raw.as<int>(), st);
+    hipLaunchKernelGGL(k_hist, dim3(grid_for(c->n_hist_chunks, 1, 16384)), dim3(512), 0, s, c->n_hist_chunks,
+                       c->d_hc_part.as<int>(), c->d_hc_p0.as<i64>(), c->d_hc_n.as<int>(), c->d_hc_glo.as<int>(),
+                       c->d_hc_ghi.as<int>(), c->d_part_iv_off.as<i64>(), c->d_iv_start.as<int>(), c->d_iv_end.as<int>(),
+                       c->d_pos_off.as<i64>(), c->d_part_lane_off.as<i64>(), c->d_lane_rep.as<int>(),
+                       c->d_lane_start.as<int>(), c->d_lane_pmax.as<int>(), c->d_rep_exon_off.as<i64>(),
+                       c->d_ex_ts.as<int>(), c->d_ex_te.as<int>(), c->P.ignore_ends, c->d_y_raw.as<int>(), st);
     mark(1);
     // S2
     hipLaunchKernelGGL(k_smooth, dim3(tile_grid), dim3(256), 0, s, c->n_tiles, c->d_tile_iv.as<int>(),
@@ -2060,7 +2091,7 @@ void fseg_destroy(fseg_ctx *c) {
                       &c->d_iv_part, &c->d_rep_weight, &c->d_rep_exon_off, &c->d_ex_ts, &c->d_ex_te, &c->d_lane_rep, &c->d_lane_start, &c->d_lane_pmax,
                       &c->d_tile_iv, &c->d_tile_y0, &c->d_w_main, &c->d_w_refine, &c->d_h_table, &c->d_y_raw, &c->d_y,
                       &c->d_flag, &c->d_idx, &c->d_v, &c->d_bsum, &c->d_g, &c->d_pk, &c->d_pf, &c->d_kp, &c->d_final_flag,
-                      &c->d_voff, &c->d_chunk_off, &c->d_csum, &c->d_mean, &c->d_thr, &c->d_label_off, &c->d_part_has2, &c->d_rb_part, &c->d_rb_r0, &c->d_cand_off,
+                      &c->d_hc_part, &c->d_hc_p0, &c->d_hc_n, &c->d_hc_glo, &c->d_hc_ghi, &c->d_voff, &c->d_chunk_off, &c->d_csum, &c->d_mean, &c->d_thr, &c->d_label_off, &c->d_part_has2, &c->d_rb_part, &c->d_rb_r0, &c->d_cand_off,
                       &c->d_cand_y, &c->d_fixed0, &c->d_added, &c->d_fixed, &c->d_chosen, &c->d_final_off, &c->d_final_y,
                       &c->d_final_pos, &c->d_col_thr, &c->d_col_zero, &c->d_cum, &c->d_tile_tot, &c->d_iv_tile0, &c->d_seg_iv, &c->d_seg_prev, &c->d_rseg_c, &c->d_cand_pn, &c->d_cand_ll, &c->d_cand_ln, &c->d_prob_bs, &c->d_prob_iv, &c->d_prob_start,
                       &c->d_prob_n, &c->d_prob_pair_off, &c->d_prob_tri_off, &c->d_prob_flags, &c->d_prob_chain, &c->d_prob_cov_off,
@@ -2142,9 +2173,20 @@ int fseg_upload(fseg_ctx *c, const fseg_batch *b) {
             lanes += w;
             i64 e0 = b->rep_exon_off[r], e1 = b->rep_exon_off[r + 1];
             if (e1 < e0) return fail(c, FSEG_ERR_ARG, "rep_exon_off not monotone");
+            i64 kk = b->part_iv_off[p];
+            const i64 kend = b->part_iv_off[p + 1];
             for (i64 e = e0; e < e1; ++e) {
                 if (!(b->ex_ts[e] < b->ex_te[e])) return fail(c, FSEG_ERR_INPUT, "rep %lld: exon with start >= end (py/freddie_segment.py:160)", (long long)r);
                 if (e > e0 && !(b->ex_te[e - 1] <= b->ex_ts[e])) return fail(c, FSEG_ERR_INPUT, "rep %lld: exons out of order (py/freddie_segment.py:158)", (long long)r);
+                // both ends of an exon must be positions of one tint interval (:666-668); exons and intervals are ordered
+                if (e == e0) {
+                    i64 lo = kk, hi = kend;
+                    while (lo < hi) { i64 mid = (lo + hi) >> 1; if (b->iv_end[mid] < b->ex_ts[e]) lo = mid + 1; else hi = mid; }
+                    kk = lo;
+                }
+                while (kk < kend && b->iv_end[kk] < b->ex_ts[e]) ++kk;
+                if (kk >= kend || b->ex_ts[e] < b->iv_start[kk] || b->ex_te[e] > b->iv_end[kk])
+                    return fail(c, FSEG_ERR_INPUT, "rep %lld: an exon does not lie inside one tint interval (py/freddie_segment.py:668)", (long long)r);
             }
         }
         part_lane_off[p + 1] = lanes;
@@ -2208,6 +2250,36 @@ int fseg_upload(fseg_ctx *c, const fseg_batch *b) {
         c->n_rep_blocks = (int)rb_part.size();
         TRY(upload_vec(c, c->d_rb_part, rb_part.data(), rb_part.size()));
         TRY(upload_vec(c, c->d_rb_r0, rb_r0.data(), rb_r0.size()));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    {   // histogram chunks: kHistChunk consecutive positions of one partition, with the genomic position of the
+        // chunk's first and last position (a chunk may span several intervals of its partition)
+        std::vector<int> hc_part, hc_n, hc_glo, hc_ghi;
+        std::vector<i64> hc_p0;
+        // chunk size: as large as possible (fewer reads are visited twice) while still giving >= 512 workgroups
+        int hist_chunk = kHistChunk;
+        while (hist_chunk > 1024 && NPOS / hist_chunk < 512) hist_chunk >>= 1;
+        for (int p = 0; p < np; ++p) {
+            const i64 k0 = b->part_iv_off[p], k1 = b->part_iv_off[p + 1];
+            const i64 P0 = pos_off[k0], P1 = pos_off[k1];
+            i64 k = k0;
+            for (i64 q0 = P0; q0 < P1; q0 += hist_chunk) {
+                const i64 q1 = std::min<i64>(q0 + hist_chunk, P1) - 1;       // last position of the chunk
+                while (pos_off[k + 1] <= q0) ++k;
+                const int glo = b->iv_start[k] + (int)(q0 - pos_off[k]);
+                i64 kk = k;
+                while (pos_off[kk + 1] <= q1) ++kk;
+                const int ghi = b->iv_start[kk] + (int)(q1 - pos_off[kk]);
+                hc_part.push_back(p); hc_p0.push_back(q0); hc_n.push_back((int)(q1 - q0 + 1));
+                hc_glo.push_back(glo); hc_ghi.push_back(ghi);
+            }
+        }
+        c->n_hist_chunks = (int)hc_part.size();
+        TRY(upload_vec(c, c->d_hc_part, hc_part.data(), hc_part.size()));
+        TRY(upload_vec(c, c->d_hc_p0, hc_p0.data(), hc_p0.size()));
+        TRY(upload_vec(c, c->d_hc_n, hc_n.data(), hc_n.size()));
+        TRY(upload_vec(c, c->d_hc_glo, hc_glo.data(), hc_glo.size()));
+        TRY(upload_vec(c, c->d_hc_ghi, hc_ghi.data(), hc_ghi.size()));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     TRY(ensure(c, c->d_part_has2, ((size_t)np + 1) * 4));
