@@ -131,6 +131,7 @@ __device__ __forceinline__ void label_thresholds(i64 L, const double *h_table, i
 // A lane is one read (reps are repeated rep_weight times in the lane list), so every hit adds 1.
 // ---------------------------------------------------------------------------------------------
 constexpr int kHistChunk = 8192;
+constexpr int kHistIv = 1024;      // intervals of a partition cached in LDS by k_hist
 __global__ void __launch_bounds__(512) k_hist(int n_chunks, const int *chunk_part, const i64 *chunk_p0, const int *chunk_n,
                                               const int *chunk_glo, const int *chunk_ghi, const i64 *part_iv_off,
                                               const int *iv_start, const int *iv_end, const i64 *pos_off,
@@ -138,6 +139,7 @@ __global__ void __launch_bounds__(512) k_hist(int n_chunks, const int *chunk_par
                                               const int *lane_pmax, const i64 *rep_exon_off, const int *ex_ts,
                                               const int *ex_te, int ignore_ends, int *y_raw, Status *st) {
     __shared__ int hist[kHistChunk];
+    __shared__ int ivs_s[kHistIv], ive_s[kHistIv], base_s[kHistIv];
     for (int ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
         const int part = chunk_part[ch];
         const i64 p0 = chunk_p0[ch];
@@ -153,23 +155,40 @@ __global__ void __launch_bounds__(512) k_hist(int n_chunks, const int *chunk_par
         b = L1;
         while (a < b) { i64 m = (a + b) >> 1; if (lane_start[m] <= g_hi) a = m + 1; else b = m; }
         const i64 hi = a;
+        // the partition's interval table in LDS when it fits (the per-exon interval search then stays on chip)
+        const int nk = (int)(k1 - k0);
+        const bool cached = nk <= kHistIv;
+        if (cached)
+            for (int i = threadIdx.x; i < nk; i += blockDim.x) {
+                ivs_s[i] = iv_start[k0 + i]; ive_s[i] = iv_end[k0 + i];
+                base_s[i] = (int)(pos_off[k0 + i] - p0) - iv_start[k0 + i];   // chunk-local index = base + genomic position
+            }
         __syncthreads();
-        for (i64 l = lo + threadIdx.x; l < hi; l += blockDim.x) {
+        // 8 threads share a read: thread q of the group takes the read's exons q, q+8, ...
+        const int sub = threadIdx.x & 7;
+        for (i64 l = lo + (threadIdx.x >> 3); l < hi; l += blockDim.x >> 3) {
             const i64 r = lane_rep[l];
             const i64 e0 = rep_exon_off[r], e1 = rep_exon_off[r + 1];
-            for (i64 e = e0; e < e1; ++e) {
+            for (i64 e = e0 + sub; e < e1; e += 8) {
                 const int ts = ex_ts[e], te = ex_te[e];
-                if (te < g_lo) continue;
-                if (ts > g_hi) break;                                    // exons of a read are ordered (:158)
-                // the interval that holds ts must hold te as well (:666-668)
-                bool ok = ts >= iv_start[k0];
-                i64 k = k0;
-                if (ok) {
-                    k = k0 + last_le(iv_start + k0, k1 - k0, ts);
-                    ok = ts <= iv_end[k] && te <= iv_end[k];
+                if (te < g_lo || ts > g_hi) continue;
+                // the interval that holds ts must hold te as well (:666-668; also validated on upload)
+                int kl = 0;
+                bool ok;
+                int base;
+                if (cached) {
+                    int a2 = 0, b2 = nk;
+                    while (b2 - a2 > 1) { int m = (a2 + b2) >> 1; if (ivs_s[m] <= ts) a2 = m; else b2 = m; }
+                    kl = a2;
+                    ok = ts >= ivs_s[kl] && ts <= ive_s[kl] && te <= ive_s[kl];
+                    base = base_s[kl];
+                } else {
+                    ok = ts >= iv_start[k0];
+                    i64 k = k0;
+                    if (ok) { k = k0 + last_le(iv_start + k0, k1 - k0, ts); ok = ts <= iv_end[k] && te <= iv_end[k]; }
+                    base = (int)(pos_off[k] - p0) - iv_start[k];
                 }
                 if (!ok) { atomicOr(&st->err, kErrExonInterval); continue; }
-                const i64 base = pos_off[k] - iv_start[k] - p0;
                 if (!(ignore_ends && e == e0) && ts >= g_lo && ts <= g_hi) atomicAdd(&hist[base + ts], 1);       // :670-671
                 if (!(ignore_ends && e == e1 - 1) && te >= g_lo && te <= g_hi) atomicAdd(&hist[base + te], 1);   // :672-673
             }
