@@ -394,7 +394,7 @@ __global__ void __launch_bounds__(64) k_voff(int n_part, const i64 *part_iv_off,
 // ---------------------------------------------------------------------------------------------
 // one workgroup: per-partition V ranges and chunk offsets
 __global__ void __launch_bounds__(256) k_vplan(int n_part, const i64 *part_iv_off, const i64 *pos_off, i64 n_pos,
-                                               const int *idx, i64 *voff, i64 *chunk_off, Status *st, i64 chunk_cap) {
+                                               i64 *voff, i64 *chunk_off, Status *st, i64 chunk_cap) {
     __shared__ int lds[16];
     __shared__ i64 carry_s;
     if (threadIdx.x == 0) carry_s = 0;
@@ -551,7 +551,6 @@ __global__ void __launch_bounds__(256) k_peaks(int n_tiles, const int *tile_iv, 
         }
     }
 }
-__global__ void k_set_total(i64 *off, i64 K, const u64 *total) { if (threadIdx.x == 0 && blockIdx.x == 0) off[K] = (i64)*total; }
 
 // ---------------------------------------------------------------------------------------------
 // S4  fixing, problem splitting, problem list
@@ -575,7 +574,6 @@ struct ProblemArrays {
     i64 *cov_off;   // offset into the coverage arena
     int *lane_lo;   // first lane (position-sorted read) that can overlap the problem's window
     int *lane_n;    // number of lanes examined: [lane_lo, lane_lo + lane_n)
-    i64 *work_base; // first work item of the problem
 };
 
 __device__ __forceinline__ i64 wave_excl_scan(i64 v, i64 *total) {
@@ -797,7 +795,7 @@ __global__ void __launch_bounds__(256) k_prob_emit(Status *st, const int *cand_p
                 if (slot < prob_cap) {
                     int k = cand_iv[c];
                     pr.iv[slot] = k; pr.start[slot] = (int)(c - cand_off[k]) - (nn - 1); pr.n[slot] = nn;
-                    pr.pair_off[slot] = ex[1]; pr.tri_off[slot] = ex[2]; pr.work_base[slot] = ex[3]; pr.cov_off[slot] = ex[4];
+                    pr.pair_off[slot] = ex[1]; pr.tri_off[slot] = ex[2]; pr.cov_off[slot] = ex[4];
                     pr.flags[slot] = 0; pr.chain[slot] = 0;
                     pr.lane_lo[slot] = cand_ll[c]; pr.lane_n[slot] = cand_ln[c];
                     int cls = size_class(nn);
@@ -854,13 +852,6 @@ __global__ void __launch_bounds__(256) k_pair_thresholds(const Status *st, Probl
     }
 }
 
-__global__ void k_zero_arenas(const Status *st, unsigned *out_g, i64 tri_cap, unsigned *amb_g, i64 pair_cap) {
-    i64 nt = (i64)st->tri_used < tri_cap ? (i64)st->tri_used : tri_cap;
-    i64 np = (i64)st->pair_used < pair_cap ? (i64)st->pair_used : pair_cap;
-    i64 stride = (i64)gridDim.x * blockDim.x;
-    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < nt; i += stride) out_g[i] = 0;
-    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < np; i += stride) amb_g[i] = 0;
-}
 
 // ---------------------------------------------------------------------------------------------
 // S5b  window coverage of every (problem, read)      get_cumulative_coverage (:188-246)
@@ -1055,7 +1046,6 @@ __global__ void k_init_pair_table() {
     }
 }
 
-constexpr bool kFuseDp = false;
 // Workgroup barrier that orders LDS traffic only: global loads issued before it (the coverage-tile prefetch)
 // stay in flight, which a full __syncthreads() would wait for.
 __device__ __forceinline__ void lds_barrier() {
@@ -1095,16 +1085,13 @@ __global__ void __launch_bounds__(ScoreCfg<NM>::kThreads) k_score(Status *st, in
                                                                   const int *cand_y, const unsigned char *work_active,
                                                                   const unsigned *cov_g, i64 cov_cap, const int2 *pair_thr,
                                                                   i64 pair_cap, unsigned *out_g, i64 tri_cap,
-                                                                  unsigned *amb_g, const int *iv_part,
-                                                                  const i64 *part_lane_off, int support,
-                                                                  unsigned char *chosen FSEG_TPARAM) {
+                                                                  unsigned *amb_g FSEG_TPARAM) {
     using C = ScoreCfg<NM>;
     constexpr int T = C::kThreads;
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ int cy_s[NM + 4];
     __shared__ int iend_s[NM + 4];
     __shared__ u64 work_s;
-    __shared__ int top_key[8];
     // LDS carve-up for problems of at most nm candidates (nm <= NM is chosen by the host from the previous run's
     // largest problem, so that a batch of moderately sized problems gets more workgroups per CU)
     const int rt_pairs = nm * (nm - 1) / 2;
@@ -1141,13 +1128,7 @@ __global__ void __launch_bounds__(ScoreCfg<NM>::kThreads) k_score(Status *st, in
         int lanes_here = pr.lane_n[p] - chunk * kLaneChunk;
         if (lanes_here > kLaneChunk) lanes_here = kLaneChunk;
         if (lanes_here < kLaneChunk) active &= (1u << ((lanes_here + kSub - 1) / kSub)) - 1u;
-        // (a problem whose reads fit one work item could run its DP right here from the LDS counters; measured
-        // slower than the separate DP kernel on MI355X, so it is kept behind a compile-time switch)
-        const bool single = kFuseDp && pr.lane_n[p] <= kLaneChunk;
-        if (active == 0) {                               // no read of this chunk touches the window: nothing to count,
-            if (single && threadIdx.x == 0) atomicOr(&pr.flags[p], 2);   // and a problem without evidence makes no cut
-            continue;
-        }
+        if (active == 0) continue;                       // no read of this chunk touches the window
         const int *cy = cand_y + cand_off[pr.iv[p]] + pr.start[p];
         for (int j = threadIdx.x; j < n; j += T) cy_s[j] = cy[j];
         {
@@ -1262,29 +1243,6 @@ __global__ void __launch_bounds__(ScoreCfg<NM>::kThreads) k_score(Status *st, in
             FSEG_TICK(4);
             sub = next_sub;
         }
-        if (single) {
-            // ---- fused DP: the counters of the whole problem are in LDS; the plane / coverage region is free now
-            i64 *M = reinterpret_cast<i64 *>(smem);
-            int *in_s = reinterpret_cast<int *>(M + C::kPairs);
-            unsigned char *A = reinterpret_cast<unsigned char *>(in_s + C::kPairs);
-            i64 *part_v = reinterpret_cast<i64 *>(smem + (((size_t)C::kPairs * 13 + 7) & ~(size_t)7));
-            unsigned char *part_a = reinterpret_cast<unsigned char *>(part_v + T);
-            int k_iv = pr.iv[p];
-            int part = iv_part[k_iv];
-            const i64 outside = (part_lane_off[part + 1] - part_lane_off[part]) - pr.lane_n[p];
-#pragma unroll
-            for (int s = 0; s < C::kSlots; ++s) {
-                int q = s * T + threadIdx.x;
-                if (q < npairs)
-                    in_s[q] = -(int)((i64)amb_acc[s] + ((zero_ambiguous && pair_thr[poff + q].y < 0) ? outside : 0));
-            }
-            __syncthreads();
-            int chain = dp_solve<T>(n, out16, in_s, M, A, cy_s, support, part_v, part_a, top_key,
-                                    chosen + cand_off[k_iv] + pr.start[p]);
-            if (threadIdx.x == 0) { pr.chain[p] = chain; atomicOr(&pr.flags[p], 2); }
-            FSEG_TICK(5);
-            continue;
-        }
         // ---- flush ---------------------------------------------------------------------------------
         for (int x = threadIdx.x; x < ntri; x += T) {
             unsigned v = out16[x];
@@ -1328,7 +1286,7 @@ __global__ void __launch_bounds__(T) k_dp(Status *st, int n_lo, int nm, u64 *que
         i64 p = (i64)work_s;
         if (p >= n_prob) break;
         int n = pr.n[p];
-        if (n <= n_lo || n > NM || (pr.flags[p] & 2)) continue;
+        if (n <= n_lo || n > NM) continue;
         if (n > nm) { if (threadIdx.x == 0) atomicOr(&st->err, kErrOverflowNm); continue; }
         if (sizeof(OutT) == 2 && pr.lane_n[p] >= 65536) { if (threadIdx.x == 0) atomicOr(&st->err, kErrNeedWideDp); continue; }
         i64 poff = pr.pair_off[p], toff = pr.tri_off[p];
@@ -1666,7 +1624,7 @@ struct fseg_ctx {
         d_rep_exon_off, d_ex_ts, d_ex_te, d_lane_rep, d_lane_start, d_lane_pmax, d_tile_iv, d_tile_y0, d_w_main,
         d_w_refine, d_h_table;
     // device buffers: position-sized
-    DevBuf d_y_raw, d_y, d_flag, d_idx, d_v, d_bsum, d_g, d_pk, d_pf, d_kp, d_final_flag;
+    DevBuf d_y_raw, d_y, d_flag, d_v, d_bsum, d_g, d_pk, d_pf, d_kp, d_final_flag;
     // partition-sized
     DevBuf d_hc_part, d_hc_p0, d_hc_n, d_hc_glo, d_hc_ghi;
     int n_hist_chunks = 0;
@@ -1678,7 +1636,7 @@ struct fseg_ctx {
     DevBuf d_cum, d_tile_tot, d_iv_tile0, d_seg_iv, d_seg_prev, d_rseg_c, d_cand_pn, d_cand_ll, d_cand_ln, d_prob_bs;
     // problems / arenas
     DevBuf d_prob_iv, d_prob_start, d_prob_n, d_prob_pair_off, d_prob_tri_off, d_prob_flags, d_prob_chain,
-        d_prob_cov_off, d_prob_lane_lo, d_prob_lane_n, d_prob_work_base;
+        d_prob_cov_off, d_prob_lane_lo, d_prob_lane_n;
     DevBuf d_work_prob, d_work_chunk, d_cls_items, d_work_active, d_pair_thr, d_amb, d_out, d_cov, d_labels;
     i64 prob_cap = 0, work_cap = 0, pair_cap = 0, tri_cap = 0, label_cap = 0, chunk_cap = 0, cov_cap = 0;
     DevBuf d_status, d_tacc;
@@ -1693,7 +1651,6 @@ struct fseg_ctx {
     int n_graphs = 0;   // few DP problems in the previous run: merge the per-size-class launches
     hipEvent_t ev[ST_COUNT + 1] = {};
     float stage_ms[ST_REPORTED] = {};
-    int score_lds = 0;
 };
 
 namespace {
@@ -1740,14 +1697,6 @@ int grid_for(i64 items, int per_block, int max_blocks) {
     return (int)g;
 }
 
-size_t score_lds_bytes() {
-    constexpr int kMaxPairs = kNMax * (kNMax - 1) / 2;
-    size_t b = (size_t)kMaxPairs * 16;
-    b += (size_t)kSub * (kNMax + 1) * 4;
-    b += (size_t)((kMaxPairs + 7) & ~7) * 2;
-    b += (size_t)(kNMax * (kNMax - 1) * (kNMax - 2) / 6) * 2;
-    return (b + 15) & ~(size_t)15;
-}
 
 inline size_t dp_lds_for(int nm, int count_bytes) {
     return (size_t)(nm * (nm - 1) / 2) * (8 + 4 + 1) + (size_t)(nm * (nm - 1) * (nm - 2) / 6 + 4) * count_bytes + 16;
@@ -1775,7 +1724,6 @@ int alloc_arenas(fseg_ctx *c) {
     TRY(ensure(c, c->d_prob_cov_off, (size_t)c->prob_cap * 8));
     TRY(ensure(c, c->d_prob_lane_lo, (size_t)c->prob_cap * 4));
     TRY(ensure(c, c->d_prob_lane_n, (size_t)c->prob_cap * 4));
-    TRY(ensure(c, c->d_prob_work_base, (size_t)c->prob_cap * 8));
     TRY(ensure(c, c->d_work_prob, (size_t)c->work_cap * 4));
     TRY(ensure(c, c->d_work_chunk, (size_t)c->work_cap * 4));
     TRY(ensure(c, c->d_cls_items, (size_t)c->work_cap * 4));
@@ -1817,7 +1765,7 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
     ProblemArrays pr{c->d_prob_iv.as<int>(), c->d_prob_start.as<int>(), c->d_prob_n.as<int>(),
                      c->d_prob_pair_off.as<i64>(), c->d_prob_tri_off.as<i64>(), c->d_prob_flags.as<int>(),
                      c->d_prob_chain.as<int>(), c->d_prob_cov_off.as<i64>(), c->d_prob_lane_lo.as<int>(),
-                     c->d_prob_lane_n.as<int>(), c->d_prob_work_base.as<i64>()};
+                     c->d_prob_lane_n.as<int>()};
     if (do_pre) {
     HIP_TRY(c, hipMemsetAsync(st, 0, sizeof(Status), s));
     mark(0);
@@ -1843,7 +1791,7 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
                        c->d_pos_off.as<i64>(), NPOS, c->d_flag.as<unsigned char>(), c->d_bsum.as<int>(), &st->n_vals,
                        c->d_voff.as<i64>());
     hipLaunchKernelGGL(k_vplan, dim3(1), dim3(256), 0, s, n_part, c->d_part_iv_off.as<i64>(), c->d_pos_off.as<i64>(), NPOS,
-                       c->d_idx.as<int>(), c->d_voff.as<i64>(), c->d_chunk_off.as<i64>(), st, c->chunk_cap);
+                       c->d_voff.as<i64>(), c->d_chunk_off.as<i64>(), st, c->chunk_cap);
     int chunk_grid = grid_for(c->chunk_cap, 1, 4096);
     for (int pass = 0; pass < 2; ++pass) {
         hipLaunchKernelGGL(k_vsum_chunks, dim3(chunk_grid), dim3(512), 0, s, n_part, c->d_voff.as<i64>(),
@@ -1911,8 +1859,7 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
                            c->d_work_prob.as<int>(), c->d_work_chunk.as<int>(), c->work_cap, c->d_cand_off.as<i64>(),   \
                            c->d_cand_y.as<int>(), c->d_work_active.as<unsigned char>(), c->d_cov.as<unsigned>(),        \
                            c->cov_cap, c->d_pair_thr.as<int2>(), c->pair_cap, c->d_out.as<unsigned>(), c->tri_cap,      \
-                           c->d_amb.as<unsigned>(), c->d_iv_part.as<int>(), c->d_part_lane_off.as<i64>(),                \
-                           c->P.min_read_support_outside, c->d_chosen.as<unsigned char>() FSEG_TARG)
+                           c->d_amb.as<unsigned>() FSEG_TARG)
         if (c->small_batch) {
             FSEG_LAUNCH_SCORE(kNMax, -1, 512);       // few work items: one launch for every size class
         } else {
@@ -2109,12 +2056,12 @@ void fseg_destroy(fseg_ctx *c) {
     DevBuf *bufs[] = {&c->d_part_iv_off, &c->d_part_rep_off, &c->d_part_lane_off, &c->d_iv_start, &c->d_iv_end, &c->d_pos_off,
                       &c->d_iv_part, &c->d_rep_weight, &c->d_rep_exon_off, &c->d_ex_ts, &c->d_ex_te, &c->d_lane_rep, &c->d_lane_start, &c->d_lane_pmax,
                       &c->d_tile_iv, &c->d_tile_y0, &c->d_w_main, &c->d_w_refine, &c->d_h_table, &c->d_y_raw, &c->d_y,
-                      &c->d_flag, &c->d_idx, &c->d_v, &c->d_bsum, &c->d_g, &c->d_pk, &c->d_pf, &c->d_kp, &c->d_final_flag,
+                      &c->d_flag, &c->d_v, &c->d_bsum, &c->d_g, &c->d_pk, &c->d_pf, &c->d_kp, &c->d_final_flag,
                       &c->d_hc_part, &c->d_hc_p0, &c->d_hc_n, &c->d_hc_glo, &c->d_hc_ghi, &c->d_voff, &c->d_chunk_off, &c->d_csum, &c->d_mean, &c->d_thr, &c->d_label_off, &c->d_part_has2, &c->d_rb_part, &c->d_rb_r0, &c->d_cand_off,
                       &c->d_cand_y, &c->d_fixed0, &c->d_added, &c->d_fixed, &c->d_chosen, &c->d_final_off, &c->d_final_y,
                       &c->d_final_pos, &c->d_col_thr, &c->d_col_zero, &c->d_cum, &c->d_tile_tot, &c->d_iv_tile0, &c->d_seg_iv, &c->d_seg_prev, &c->d_rseg_c, &c->d_cand_pn, &c->d_cand_ll, &c->d_cand_ln, &c->d_prob_bs, &c->d_prob_iv, &c->d_prob_start,
                       &c->d_prob_n, &c->d_prob_pair_off, &c->d_prob_tri_off, &c->d_prob_flags, &c->d_prob_chain, &c->d_prob_cov_off,
-                      &c->d_prob_lane_lo, &c->d_prob_lane_n, &c->d_prob_work_base, &c->d_work_active, &c->d_cov,
+                      &c->d_prob_lane_lo, &c->d_prob_lane_n, &c->d_work_active, &c->d_cov,
                       &c->d_work_prob, &c->d_work_chunk, &c->d_cls_items, &c->d_pair_thr, &c->d_amb, &c->d_out, &c->d_labels, &c->d_status, &c->d_tacc};
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
     if (c->h_status) (void)hipHostFree(c->h_status);
@@ -2309,7 +2256,7 @@ int fseg_upload(fseg_ctx *c, const fseg_batch *b) {
     // position-sized work buffers
     size_t np8 = (size_t)NPOS + 64;
     TRY(ensure(c, c->d_y_raw, np8 * 4)); TRY(ensure(c, c->d_cum, np8 * 4)); TRY(ensure(c, c->d_y, np8 * 8)); TRY(ensure(c, c->d_flag, np8));
-    TRY(ensure(c, c->d_idx, np8 * 4)); TRY(ensure(c, c->d_v, np8 * 8));
+    TRY(ensure(c, c->d_v, np8 * 8));
     TRY(ensure(c, c->d_bsum, ((size_t)(NPOS / kScanBlock) + 2) * 4));
     TRY(ensure(c, c->d_g, np8 * 8)); TRY(ensure(c, c->d_pk, np8 * 4)); TRY(ensure(c, c->d_pf, np8)); TRY(ensure(c, c->d_kp, np8));
     TRY(ensure(c, c->d_final_flag, np8));
