@@ -57,6 +57,8 @@ def parse_args(argv=None):
     ap.add_argument("-lo", "--min-read-support-outside", type=int, default=3,
                     help="Minimum reads support for splice site to support a breakpoint")
     ap.add_argument("--gpus", type=int, default=0, help="Number of GPUs to scatter partitions over (0 = all visible)")
+    ap.add_argument("--devices", type=str, default=None,
+                    help="Comma-separated GPU ordinals, one worker per entry (overrides --gpus; e.g. 0,1,2,3)")
     ap.add_argument("--batch-reads", type=int, default=250000, help="Reads per device batch")
     args = ap.parse_args(argv)
     assert 1 >= args.threshold_rate >= 0.5
@@ -521,10 +523,15 @@ def main(argv=None):
     parts = discover(split_dir, args.outdir)
     params = (args.sigma, tables.smooth_threshold(args.threshold_rate), args.threshold_rate, args.variance_factor,
               args.max_problem_size, args.min_read_support_outside, not args.consider_ends)
-    n_gpus = args.gpus
-    if n_gpus <= 0:
-        import torch
-        n_gpus = torch.cuda.device_count()
+    if args.devices:
+        devices = [int(x) for x in args.devices.split(",") if x != ""]
+    else:
+        n_gpus = args.gpus
+        if n_gpus <= 0:
+            import torch
+            n_gpus = torch.cuda.device_count()
+        devices = list(range(n_gpus))
+    n_gpus = len(devices)
     if n_gpus <= 0:
         raise SystemExit("freddie_segment: no GPU visible (this implementation has no CPU path)")
     costs = [c for _, _, c in parts]
@@ -542,7 +549,7 @@ def main(argv=None):
 
     if n_gpus == 1:
         from . import _lib
-        ctx = _lib.Context(0)
+        ctx = _lib.Context(devices[0])
         jobs = [((split_dir, args.outdir, parts[i][0], parts[i][1]), parts[i][2]) for i in assign[0]]
         try:
             run_batches(make_batches(jobs, batch_bytes), params, ctx, args.threads, lambda _done: report())
@@ -552,14 +559,24 @@ def main(argv=None):
     mp = multiprocessing.get_context("spawn")
     queue = mp.Queue()
     procs = []
-    for dev in range(n_gpus):
-        jobs = [((split_dir, args.outdir, parts[i][0], parts[i][1]), parts[i][2]) for i in assign[dev]]
+    for w, dev in enumerate(devices):
+        jobs = [((split_dir, args.outdir, parts[i][0], parts[i][1]), parts[i][2]) for i in assign[w]]
         pr = mp.Process(target=_gpu_worker, args=(dev, jobs, params, batch_bytes, args.threads, queue))
         pr.start()
         procs.append(pr)
+    import queue as queue_mod
     alive = n_gpus
     while alive:
-        item = queue.get()
+        try:
+            item = queue.get(timeout=1.0)
+        except queue_mod.Empty:
+            dead = [pr for pr in procs if pr.exitcode not in (None, 0)]
+            if dead:                                   # a worker died without reporting: stop the others, fail loudly
+                for pr in procs:
+                    if pr.is_alive():
+                        pr.terminate()
+                raise SystemExit("a GPU worker failed with exit code %s" % dead[0].exitcode)
+            continue
         if item is None:
             alive -= 1
         else:
