@@ -223,7 +223,8 @@ __global__ void __launch_bounds__(256) k_smooth(int n_tiles, const int *tile_iv,
         int span = kSmoothTile + 2 * radius;
         for (int idx = threadIdx.x; idx < span; idx += blockDim.x) {
             i64 y = y0 - radius + idx;
-            xs[idx] = y_raw[base + reflect_index(y, len)];
+            if (y < 0 || y >= len) y = reflect_index(y, len);      // only the few halo elements beyond the interval pay the modulo
+            xs[idx] = y_raw[base + y];
         }
         __syncthreads();
         {   // inclusive prefix sums of the histogram inside the tile + the tile total: lets k_segments evaluate
@@ -235,17 +236,34 @@ __global__ void __launch_bounds__(256) k_smooth(int n_tiles, const int *tile_iv,
             for (int e = 0; e < 4; ++e) if (y0 + o4 + e < len) cum[base + y0 + o4 + e] = ex + v4[e];
             if (threadIdx.x == 0) tile_tot[t] = tot;
         }
-        for (int o = threadIdx.x; o < kSmoothTile; o += blockDim.x) {
-            i64 y = y0 + o;
-            if (y >= len) break;
-            int c = o + radius;
-            double acc = __dmul_rn((double)xs[c], ws[0]);
-            for (int j = radius; j >= 1; --j) {
-                int s = xs[c - j] + xs[c + j];
-                acc = __dadd_rn(acc, __dmul_rn((double)s, ws[j]));
+        {   // every thread computes 4 consecutive outputs; the two 4-wide input windows of tap j slide by one
+            // position per tap, so each tap costs two LDS reads for four outputs
+            const int o4 = threadIdx.x * 4;
+            if (y0 + o4 < len) {
+                const int c = o4 + radius;
+                const double w0 = ws[0];
+                double a0 = __dmul_rn((double)xs[c], w0), a1 = __dmul_rn((double)xs[c + 1], w0);
+                double a2 = __dmul_rn((double)xs[c + 2], w0), a3 = __dmul_rn((double)xs[c + 3], w0);
+                int l0 = xs[c - radius], l1 = xs[c - radius + 1], l2 = xs[c - radius + 2], l3 = xs[c - radius + 3];
+                int r0 = xs[c + radius], r1 = xs[c + radius + 1], r2 = xs[c + radius + 2], r3 = xs[c + radius + 3];
+                for (int j = radius; j >= 1; --j) {
+                    const double w = ws[j];
+                    a0 = __dadd_rn(a0, __dmul_rn((double)(l0 + r0), w));
+                    a1 = __dadd_rn(a1, __dmul_rn((double)(l1 + r1), w));
+                    a2 = __dadd_rn(a2, __dmul_rn((double)(l2 + r2), w));
+                    a3 = __dadd_rn(a3, __dmul_rn((double)(l3 + r3), w));
+                    l0 = l1; l1 = l2; l2 = l3; l3 = xs[c - j + 4];          // left window moves right
+                    r3 = r2; r2 = r1; r1 = r0; r0 = xs[c + j - 1];          // right window moves left
+                }
+                const double av[4] = {a0, a1, a2, a3};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (y0 + o4 + e < len) {
+                        y_out[base + y0 + o4 + e] = av[e];
+                        flag_pos[base + y0 + o4 + e] = av[e] > 0.0 ? 1 : 0;
+                    }
+                }
             }
-            y_out[base + y] = acc;
-            flag_pos[base + y] = acc > 0.0 ? 1 : 0;
         }
     }
 }
