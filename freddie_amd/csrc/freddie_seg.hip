@@ -352,8 +352,8 @@ __global__ void __launch_bounds__(256) k_scan2(int *bsum, i64 nb, u64 *total_out
 enum { kEmitValues = 0, kEmitPositions = 1 };
 template <int MODE>
 __global__ void __launch_bounds__(256) k_scan_emit(const unsigned char *flags, i64 n, const int *bsum, const double *y,
-                                                   double *v, i64 K, const i64 *pos_off, const int *iv_start, int *out_y,
-                                                   int *out_pos, i64 *out_off) {
+                                                   double *v, i64 K, const i64 *pos_off, const int *iv_start,
+                                                   const int *blk_iv0, int *out_y, int *out_pos, i64 *out_off) {
     __shared__ int lds[16];
     i64 nb = (n + kScanBlock - 1) / kScanBlock;
     for (i64 b = blockIdx.x; b < nb; b += gridDim.x) {
@@ -373,7 +373,12 @@ __global__ void __launch_bounds__(256) k_scan_emit(const unsigned char *flags, i
                     i64 i = i0 + q * 4 + e;
                     if (MODE == kEmitValues) v[ex] = y[i];
                     else {
-                        if (k < 0 || i >= k_end) { k = last_le(pos_off, K + 1, i); k_base = pos_off[k]; k_end = pos_off[k + 1]; }
+                        if (k < 0 || i >= k_end) {
+                            // the interval of position i lies between the first intervals of this and the next block
+                            const i64 ka = k < 0 ? blk_iv0[b] : k + 1, kb = (i64)blk_iv0[b + 1] + 1;
+                            k = ka + last_le(pos_off + ka, kb - ka, i);
+                            k_base = pos_off[k]; k_end = pos_off[k + 1];
+                        }
                         int yy = (int)(i - k_base);
                         out_y[ex] = yy;
                         if (out_pos) out_pos[ex] = iv_start[k] + yy;
@@ -1644,6 +1649,7 @@ struct fseg_ctx {
     // device buffers: position-sized
     DevBuf d_y_raw, d_y, d_flag, d_v, d_bsum, d_g, d_pk, d_pf, d_kp, d_final_flag;
     // partition-sized
+    DevBuf d_blk_iv0;          // interval of the first position of every scan block (+ a sentinel)
     DevBuf d_hc_part, d_hc_p0, d_hc_n, d_hc_glo, d_hc_ghi;
     int n_hist_chunks = 0;
     DevBuf d_voff, d_chunk_off, d_csum, d_mean, d_thr, d_label_off, d_part_has2, d_rb_part, d_rb_r0;
@@ -1804,7 +1810,7 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
     TRY(launch_scan_counts(c, c->d_flag.as<unsigned char>(), NPOS, &st->n_vals, &scan_grid));
     hipLaunchKernelGGL(k_scan_emit<kEmitValues>, dim3(scan_grid), dim3(256), 0, s, c->d_flag.as<unsigned char>(), NPOS,
                        c->d_bsum.as<int>(), c->d_y.as<double>(), c->d_v.as<double>(), K, c->d_pos_off.as<i64>(),
-                       c->d_iv_start.as<int>(), (int *)nullptr, (int *)nullptr, (i64 *)nullptr);
+                       c->d_iv_start.as<int>(), c->d_blk_iv0.as<int>(), (int *)nullptr, (int *)nullptr, (i64 *)nullptr);
     hipLaunchKernelGGL(k_voff, dim3(grid_for(n_part + 1, 1, 2048)), dim3(64), 0, s, n_part, c->d_part_iv_off.as<i64>(),
                        c->d_pos_off.as<i64>(), NPOS, c->d_flag.as<unsigned char>(), c->d_bsum.as<int>(), &st->n_vals,
                        c->d_voff.as<i64>());
@@ -1827,7 +1833,8 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
     TRY(launch_scan_counts(c, c->d_flag.as<unsigned char>(), NPOS, &st->n_cand, &scan_grid, c->d_cand_off.as<i64>() + K));
     hipLaunchKernelGGL(k_scan_emit<kEmitPositions>, dim3(scan_grid), dim3(256), 0, s, c->d_flag.as<unsigned char>(), NPOS,
                        c->d_bsum.as<int>(), (const double *)nullptr, (double *)nullptr, K, c->d_pos_off.as<i64>(),
-                       c->d_iv_start.as<int>(), c->d_cand_y.as<int>(), (int *)nullptr, c->d_cand_off.as<i64>());
+                       c->d_iv_start.as<int>(), c->d_blk_iv0.as<int>(), c->d_cand_y.as<int>(), (int *)nullptr,
+                       c->d_cand_off.as<i64>());
     mark(4);
     // S4
     hipLaunchKernelGGL(k_fix, dim3(grid_for(K, 1, 8192)), dim3(iv_threads), 0, s, K, c->d_pos_off.as<i64>(),
@@ -1926,7 +1933,8 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
     TRY(launch_scan_counts(c, c->d_final_flag.as<unsigned char>(), NPOS, &st->n_final, &scan_grid, c->d_final_off.as<i64>() + K));
     hipLaunchKernelGGL(k_scan_emit<kEmitPositions>, dim3(scan_grid), dim3(256), 0, s, c->d_final_flag.as<unsigned char>(),
                        NPOS, c->d_bsum.as<int>(), (const double *)nullptr, (double *)nullptr, K, c->d_pos_off.as<i64>(),
-                       c->d_iv_start.as<int>(), c->d_final_y.as<int>(), c->d_final_pos.as<int>(), c->d_final_off.as<i64>());
+                       c->d_iv_start.as<int>(), c->d_blk_iv0.as<int>(), c->d_final_y.as<int>(), c->d_final_pos.as<int>(),
+                       c->d_final_off.as<i64>());
     mark(10);
     // S7
     hipLaunchKernelGGL(k_label_plan, dim3(1), dim3(256), 0, s, n_part, c->d_part_iv_off.as<i64>(),
@@ -2075,7 +2083,7 @@ void fseg_destroy(fseg_ctx *c) {
                       &c->d_iv_part, &c->d_rep_weight, &c->d_rep_exon_off, &c->d_ex_ts, &c->d_ex_te, &c->d_lane_rep, &c->d_lane_start, &c->d_lane_pmax,
                       &c->d_tile_iv, &c->d_tile_y0, &c->d_w_main, &c->d_w_refine, &c->d_h_table, &c->d_y_raw, &c->d_y,
                       &c->d_flag, &c->d_v, &c->d_bsum, &c->d_g, &c->d_pk, &c->d_pf, &c->d_kp, &c->d_final_flag,
-                      &c->d_hc_part, &c->d_hc_p0, &c->d_hc_n, &c->d_hc_glo, &c->d_hc_ghi, &c->d_voff, &c->d_chunk_off, &c->d_csum, &c->d_mean, &c->d_thr, &c->d_label_off, &c->d_part_has2, &c->d_rb_part, &c->d_rb_r0, &c->d_cand_off,
+                      &c->d_blk_iv0, &c->d_hc_part, &c->d_hc_p0, &c->d_hc_n, &c->d_hc_glo, &c->d_hc_ghi, &c->d_voff, &c->d_chunk_off, &c->d_csum, &c->d_mean, &c->d_thr, &c->d_label_off, &c->d_part_has2, &c->d_rb_part, &c->d_rb_r0, &c->d_cand_off,
                       &c->d_cand_y, &c->d_fixed0, &c->d_added, &c->d_fixed, &c->d_chosen, &c->d_final_off, &c->d_final_y,
                       &c->d_final_pos, &c->d_col_thr, &c->d_col_zero, &c->d_cum, &c->d_tile_tot, &c->d_iv_tile0, &c->d_seg_iv, &c->d_seg_prev, &c->d_rseg_c, &c->d_cand_pn, &c->d_cand_ll, &c->d_cand_ln, &c->d_prob_bs, &c->d_prob_iv, &c->d_prob_start,
                       &c->d_prob_n, &c->d_prob_pair_off, &c->d_prob_tri_off, &c->d_prob_flags, &c->d_prob_chain, &c->d_prob_cov_off,
@@ -2264,6 +2272,18 @@ int fseg_upload(fseg_ctx *c, const fseg_batch *b) {
         TRY(upload_vec(c, c->d_hc_n, hc_n.data(), hc_n.size()));
         TRY(upload_vec(c, c->d_hc_glo, hc_glo.data(), hc_glo.size()));
         TRY(upload_vec(c, c->d_hc_ghi, hc_ghi.data(), hc_ghi.size()));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    {
+        const i64 nb = (NPOS + kScanBlock - 1) / kScanBlock;
+        std::vector<int> blk_iv0((size_t)nb + 1);
+        i64 k = 0;
+        for (i64 bq = 0; bq < nb; ++bq) {
+            while (pos_off[k + 1] <= bq * kScanBlock) ++k;
+            blk_iv0[(size_t)bq] = (int)k;
+        }
+        blk_iv0[(size_t)nb] = (int)(K - 1);
+        TRY(upload_vec(c, c->d_blk_iv0, blk_iv0.data(), blk_iv0.size()));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     TRY(ensure(c, c->d_part_has2, ((size_t)np + 1) * 4));
