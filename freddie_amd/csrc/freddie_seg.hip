@@ -354,25 +354,32 @@ template <int MODE>
 __global__ void __launch_bounds__(256) k_scan_emit(const unsigned char *flags, i64 n, const int *bsum, const double *y,
                                                    double *v, i64 K, const i64 *pos_off, const int *iv_start,
                                                    const int *blk_iv0, int *out_y, int *out_pos, i64 *out_off) {
+    // A block is 4 waves x 2048 consecutive positions.  Each wave first counts its flags (16-byte loads), the wave
+    // offsets come from LDS, then the wave walks its positions in rows of 64: ballot -> rank, so the loads of y and
+    // the stores of the compacted output are coalesced.
+    __shared__ int wave_cnt[4];
     __shared__ int lds[16];
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const u64 lt_mask = (1ULL << lane) - 1ULL;
     i64 nb = (n + kScanBlock - 1) / kScanBlock;
-    for (i64 b = blockIdx.x; b < nb; b += gridDim.x) {
-        i64 i0 = b * kScanBlock + (i64)threadIdx.x * 32;
-        Flags32 f;
-        int s = 0;
-        if (i0 < n) { f = load_flags32(flags, i0, n); s = count_flags32(f); }
-        int tot;
-        int ex = wg_exclusive_scan(s, lds, &tot) + bsum[b];
-        if (s) {
-            i64 k = -1, k_end = 0, k_base = 0;
-            for (int q = 0; q < 8; ++q) {
-                unsigned w = f.w[q];
-                while (w) {
-                    int e = (__ffs(w) - 1) >> 3;
-                    w &= w - 1;
-                    i64 i = i0 + q * 4 + e;
-                    if (MODE == kEmitValues) v[ex] = y[i];
-                    else {
+    if (MODE == kEmitPositions) {
+        // sparse flags (about one position in a hundred): every thread owns 32 consecutive positions and only the
+        // threads that hold a flag do any work
+        for (i64 b = blockIdx.x; b < nb; b += gridDim.x) {
+            i64 i0 = b * kScanBlock + (i64)threadIdx.x * 32;
+            Flags32 f;
+            int s = 0;
+            if (i0 < n) { f = load_flags32(flags, i0, n); s = count_flags32(f); }
+            int tot;
+            int ex = wg_exclusive_scan(s, lds, &tot) + bsum[b];
+            if (s) {
+                i64 k = -1, k_end = 0, k_base = 0;
+                for (int q = 0; q < 8; ++q) {
+                    unsigned w = f.w[q];
+                    while (w) {
+                        int e = (__ffs(w) - 1) >> 3;
+                        w &= w - 1;
+                        i64 i = i0 + q * 4 + e;
                         if (k < 0 || i >= k_end) {
                             // the interval of position i lies between the first intervals of this and the next block
                             const i64 ka = k < 0 ? blk_iv0[b] : k + 1, kb = (i64)blk_iv0[b + 1] + 1;
@@ -383,12 +390,53 @@ __global__ void __launch_bounds__(256) k_scan_emit(const unsigned char *flags, i
                         out_y[ex] = yy;
                         if (out_pos) out_pos[ex] = iv_start[k] + yy;
                         if (yy == 0) out_off[k] = ex;
+                        ++ex;
                     }
-                    ++ex;
                 }
             }
+            __syncthreads();
         }
+        return;
+    }
+    for (i64 b = blockIdx.x; b < nb; b += gridDim.x) {
+        const i64 w0 = b * kScanBlock + (i64)wave * 2048;            // first position of this wave
+        int s = 0;
+        {
+            i64 i0 = w0 + (i64)lane * 32;
+            if (i0 < n) s = count_flags32(load_flags32(flags, i0, n));
+        }
+        for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
         __syncthreads();
+        if (lane == 0) wave_cnt[wave] = s;
+        __syncthreads();
+        int ex = bsum[b];
+        for (int w = 0; w < wave; ++w) ex += wave_cnt[w];
+        if (s) {
+            i64 k = -1, k_end = 0, k_base = 0;
+            for (int q = 0; q < 32; ++q) {
+                const i64 i = w0 + q * 64 + lane;
+                const bool f = i < n && (flags[i] & 1);
+                const u64 m = __ballot(f);
+                if (!m) continue;
+                if (f) {
+                    const int d = ex + __popcll(m & lt_mask);
+                    if (MODE == kEmitValues) v[d] = y[i];
+                    else {
+                        if (k < 0 || i >= k_end) {
+                            // the interval of position i lies between the first intervals of this and the next block
+                            const i64 ka = k < 0 ? blk_iv0[b] : k, kb = (i64)blk_iv0[b + 1] + 1;
+                            k = ka + last_le(pos_off + ka, kb - ka, i);
+                            k_base = pos_off[k]; k_end = pos_off[k + 1];
+                        }
+                        int yy = (int)(i - k_base);
+                        out_y[d] = yy;
+                        if (out_pos) out_pos[d] = iv_start[k] + yy;
+                        if (yy == 0) out_off[k] = d;
+                    }
+                }
+                ex += __popcll(m);
+            }
+        }
     }
 }
 // rank of the first position of every partition in the compaction of the Y > 0 flags
