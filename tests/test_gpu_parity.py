@@ -42,3 +42,36 @@ def test_rerun_is_idempotent(gpu_ctx):
     b = gpu_ctx.download()
     for x, y in zip(a, b):
         assert np.array_equal(x, y)
+
+
+def test_config3_slice_against_oracle(gpu_ctx):
+    """40 partitions x 1000 reads generated exactly as the config3 bench workload, every tap against the oracle."""
+    from freddie_amd import synth
+    kw = dict(synth.WORKLOADS["config3"]); kw.pop("n_partitions")
+    parts = [util.make_partition(i, **kw) for i in range(40)]
+    oracles = [util.run_oracle(p) for p in parts]
+    util.run_gpu(gpu_ctx, parts)
+    util.compare_partitions(gpu_ctx, parts, oracles)
+
+
+def test_config5_slice_against_oracle(gpu_ctx):
+    """ONT-like error model with sigma=3.0, threshold_rate=0.80 (BASELINE config 5), 12 partitions x 1000 reads."""
+    from freddie_amd import synth
+    kw = dict(synth.WORKLOADS["config5"]); kw.pop("n_partitions")
+    params = dict(sigma=3.0, threshold_rate=0.8)
+    parts = [util.make_partition(i, **kw) for i in range(12)]
+    oracles = [util.run_oracle(p, params) for p in parts]
+    util.run_gpu(gpu_ctx, parts, params)
+    util.compare_partitions(gpu_ctx, parts, oracles)
+
+
+def test_batch_equals_one_by_one(gpu_ctx):
+    """Batching is transparent: a partition's result does not depend on what else is in the batch."""
+    parts = [util.make_partition(50 + i, n_reads=200 + 50 * i, n_exons=60, rp=0.1) for i in range(8)]
+    util.run_gpu(gpu_ctx, parts)
+    pfo, fp, lo, lab = gpu_ctx.download()
+    for i, p in enumerate(parts):
+        util.run_gpu(gpu_ctx, [p])
+        a, b, c, d = gpu_ctx.download()
+        assert np.array_equal(b, fp[pfo[i]:pfo[i + 1]])
+        assert np.array_equal(d, lab[lo[i]:lo[i + 1]])
