@@ -24,6 +24,17 @@ def test_every_declared_symbol_is_exported():
     assert L.fseg_n_stages() >= 8
 
 
+def test_host_library_exports_every_declared_symbol():
+    from freddie_amd import _host
+    text = open(os.path.join(build.INCLUDE, "freddie_host.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(fhost_[a-z_]+)\s*\(", text)))
+    assert len(declared) >= 14
+    L = _host.load()
+    for name in declared:
+        assert hasattr(L, name), "libfreddie_host.so does not export %s" % name
+
+
 def test_fails_loudly_without_a_gpu():
     import torch
     if torch.cuda.device_count() > 0:
