@@ -73,8 +73,7 @@ struct Status {
     unsigned pad2;
     u64 cls_work[3];   // work items per problem-size class (n <= 16, <= 32, <= kNMax)
     u64 cls_queue[3];  // dynamic work counters of the scoring kernels
-    u64 dp_queue;
-    u64 dp_queue2;
+    u64 dp_cls[2];     // DP problems with n <= kDpSmall / larger
     u64 cov_queue;
 };
 
@@ -766,7 +765,9 @@ __global__ void k_prob_range(const Status *st, const int *cand_pn, const int *ca
 
 // Problem list by a prefix sum over the candidates: problem slot, pair / triple / coverage arena offsets and
 // work items come out in candidate order, so the arena layout is deterministic.
-constexpr int kProbCols = 8;      // slot, pairs, triples, work items, coverage elements, work items of class 0/1/2
+constexpr int kProbCols = 10;     // slot, pairs, triples, work items, coverage elements, work items of class 0/1/2,
+                                  // DP problems of the small / big class
+constexpr int kDpSmall = 32;
 constexpr int kClsSmall = 16, kClsMid = 32;
 struct ProbSizes { i64 v[kProbCols]; };
 __device__ __forceinline__ int size_class(int n) { return n <= kClsSmall ? 0 : (n <= kClsMid ? 1 : 2); }
@@ -778,6 +779,7 @@ __device__ __forceinline__ ProbSizes prob_sizes(int n, int n_lanes) {
     s.v[0] = 1; s.v[1] = (i64)n * (n - 1) / 2; s.v[2] = (i64)n * (n - 1) * (n - 2) / 6; s.v[3] = chunks;
     s.v[4] = chunks * kLaneChunk * n;
     s.v[5 + size_class(n)] = chunks;
+    s.v[n <= kDpSmall ? 8 : 9] = 1;
     return s;
 }
 __device__ __forceinline__ i64 wg_exclusive_scan64(i64 v, i64 *lds /* >= 16 */, i64 *total) {
@@ -840,12 +842,13 @@ __global__ void __launch_bounds__(256) k_prob_scan2(Status *st, i64 *bs) {
         st->n_prob = (u64)carry_s[0]; st->pair_used = (u64)carry_s[1]; st->tri_used = (u64)carry_s[2];
         st->n_work = (u64)carry_s[3]; st->cov_used = (u64)carry_s[4];
         st->cls_work[0] = (u64)carry_s[5]; st->cls_work[1] = (u64)carry_s[6]; st->cls_work[2] = (u64)carry_s[7];
+        st->dp_cls[0] = (u64)carry_s[8]; st->dp_cls[1] = (u64)carry_s[9];
     }
 }
 __global__ void __launch_bounds__(256) k_prob_emit(Status *st, const int *cand_pn, const int *cand_ll, const int *cand_ln,
                                                    const int *cand_iv, const i64 *cand_off, const i64 *bs,
                                                    ProblemArrays pr, i64 prob_cap, int *work_prob, int *work_chunk,
-                                                   int *cls_items, i64 work_cap) {
+                                                   int *cls_items, i64 work_cap, int *dp_items) {
     __shared__ i64 lds[16];
     i64 n = (i64)st->n_cand;
     i64 nb = (n + kProbBlock - 1) / kProbBlock;
@@ -869,6 +872,10 @@ __global__ void __launch_bounds__(256) k_prob_emit(Status *st, const int *cand_p
                     pr.pair_off[slot] = ex[1]; pr.tri_off[slot] = ex[2]; pr.cov_off[slot] = ex[4];
                     pr.flags[slot] = 0; pr.chain[slot] = 0;
                     pr.lane_lo[slot] = cand_ll[c]; pr.lane_n[slot] = cand_ln[c];
+                    {   // DP problem lists: the small problems first, then the big ones
+                        i64 di = nn <= kDpSmall ? ex[8] : (i64)st->dp_cls[0] + ex[9];
+                        if (di < prob_cap) dp_items[di] = (int)slot;
+                    }
                     int cls = size_class(nn);
                     i64 cbase = ex[5 + cls] + (cls >= 1 ? (i64)st->cls_work[0] : 0) + (cls >= 2 ? (i64)st->cls_work[1] : 0);
                     for (i64 q = 0; q < sz[e].v[3]; ++q) {
@@ -942,12 +949,10 @@ __global__ void __launch_bounds__(kLaneChunk) k_cov(Status *st, ProblemArrays pr
     __shared__ unsigned active_s;
     i64 n_work = (i64)st->n_work;
     if (n_work > work_cap || (i64)st->n_prob > prob_cap) return;   // lists incomplete: this run only sizes the arenas
-    for (;;) {
+    for (i64 w = blockIdx.x; w < n_work; w += gridDim.x) {      // static stride: a shared work counter saturates near 90 pops/us
         __syncthreads();
-        if (threadIdx.x == 0) { work_s = atomicAdd(&st->cov_queue, 1ULL); active_s = 0; }
+        if (threadIdx.x == 0) active_s = 0;
         __syncthreads();
-        i64 w = (i64)work_s;
-        if (w >= n_work) break;
         int p = work_prob[w];
         int chunk = work_chunk[w];
         int n = pr.n[p];
@@ -1178,11 +1183,21 @@ __global__ void __launch_bounds__(ScoreCfg<NM>::kThreads) k_score(Status *st, in
     u64 *queue = &st->cls_queue[cls < 0 ? 0 : cls];
     if ((i64)st->n_work > work_cap || (i64)st->n_prob > prob_cap) n_items = 0;   // lists incomplete: sizing run
     FSEG_T0;
+    // a shared work counter saturates near 90 pops/us, so the small classes claim several items per pop
+    constexpr int kPop = NM <= 16 ? 8 : (NM <= 32 ? 4 : 1);
+    i64 wi_base = 0;
+    int wi_left = 0;
     for (;;) {
+        if (wi_left == 0) {
+            __syncthreads();
+            if (threadIdx.x == 0) work_s = atomicAdd(queue, (u64)kPop);
+            __syncthreads();
+            wi_base = (i64)work_s;
+            wi_left = kPop;
+        }
+        const i64 wi = wi_base + (kPop - wi_left);
+        --wi_left;
         __syncthreads();
-        if (threadIdx.x == 0) work_s = atomicAdd(queue, 1ULL);
-        __syncthreads();
-        i64 wi = (i64)work_s;
         FSEG_TICK(0);
         if (wi >= n_items) break;
         i64 w = cls_items[cls_base + wi];
@@ -1329,7 +1344,7 @@ __global__ void __launch_bounds__(ScoreCfg<NM>::kThreads) k_score(Status *st, in
 }
 
 template <int NM, int T, typename OutT>
-__global__ void __launch_bounds__(T) k_dp(Status *st, int n_lo, int nm, u64 *queue, ProblemArrays pr, i64 prob_cap,
+__global__ void __launch_bounds__(T) k_dp(Status *st, int dp_class, int nm, const int *dp_items, ProblemArrays pr, i64 prob_cap,
                                             const i64 *cand_off, const int *cand_y, const int *iv_part,
                                             const i64 *part_lane_off, const unsigned *out_g, i64 tri_cap,
                                             const unsigned *amb_g, const int2 *pair_thr, i64 pair_cap, int support,
@@ -1344,20 +1359,19 @@ __global__ void __launch_bounds__(T) k_dp(Status *st, int n_lo, int nm, u64 *que
     OutT *out_s = reinterpret_cast<OutT *>(in_s + kPairs);            // counts: 16 bit when every problem sees < 65536 reads
     unsigned char *A = reinterpret_cast<unsigned char *>(out_s + ((kTri + 3) & ~3));
     __shared__ int cy_s[NM];
-    __shared__ u64 work_s;
     __shared__ i64 part_v[T];
     __shared__ unsigned char part_a[T];
     __shared__ int top_key[T / 64];
     i64 n_prob = (i64)st->n_prob;
     if (n_prob > prob_cap) return;                                  // sizing run
-    for (;;) {
+    // dp_class 0 / 1: the small / big problems of the per-class list; -1: every problem
+    const i64 list_base = dp_class == 1 ? (i64)st->dp_cls[0] : 0;
+    const i64 list_n = dp_class < 0 ? n_prob : (i64)st->dp_cls[dp_class];
+    for (i64 t = blockIdx.x; t < list_n; t += gridDim.x) {          // static stride (no shared work counter)
         __syncthreads();
-        if (threadIdx.x == 0) work_s = atomicAdd(queue, 1ULL);
-        __syncthreads();
-        i64 p = (i64)work_s;
-        if (p >= n_prob) break;
+        const i64 p = dp_class < 0 ? t : (i64)dp_items[list_base + t];
         int n = pr.n[p];
-        if (n <= n_lo || n > NM) continue;
+        if (n > NM) continue;
         if (n > nm) { if (threadIdx.x == 0) atomicOr(&st->err, kErrOverflowNm); continue; }
         if (sizeof(OutT) == 2 && pr.lane_n[p] >= 65536) { if (threadIdx.x == 0) atomicOr(&st->err, kErrNeedWideDp); continue; }
         i64 poff = pr.pair_off[p], toff = pr.tri_off[p];
@@ -1709,7 +1723,7 @@ struct fseg_ctx {
     // problems / arenas
     DevBuf d_prob_iv, d_prob_start, d_prob_n, d_prob_pair_off, d_prob_tri_off, d_prob_flags, d_prob_chain,
         d_prob_cov_off, d_prob_lane_lo, d_prob_lane_n;
-    DevBuf d_work_prob, d_work_chunk, d_cls_items, d_work_active, d_pair_thr, d_amb, d_out, d_cov, d_labels;
+    DevBuf d_dp_items, d_work_prob, d_work_chunk, d_cls_items, d_work_active, d_pair_thr, d_amb, d_out, d_cov, d_labels;
     i64 prob_cap = 0, work_cap = 0, pair_cap = 0, tri_cap = 0, label_cap = 0, chunk_cap = 0, cov_cap = 0;
     DevBuf d_status, d_tacc;
     Status *h_status = nullptr;   // pinned
@@ -1774,7 +1788,6 @@ inline size_t dp_lds_for(int nm, int count_bytes) {
     return (size_t)(nm * (nm - 1) / 2) * (8 + 4 + 1) + (size_t)(nm * (nm - 1) * (nm - 2) / 6 + 4) * count_bytes + 16;
 }
 constexpr size_t kLdsPerWg = 160 * 1024;
-constexpr int kDpSmall = 32;
 
 void drop_graph(fseg_ctx *c) {
     for (int g = 0; g < 2; ++g) {
@@ -1793,6 +1806,7 @@ int alloc_arenas(fseg_ctx *c) {
     TRY(ensure(c, c->d_prob_tri_off, (size_t)c->prob_cap * 8));
     TRY(ensure(c, c->d_prob_flags, (size_t)c->prob_cap * 4));
     TRY(ensure(c, c->d_prob_chain, (size_t)c->prob_cap * 4));
+    TRY(ensure(c, c->d_dp_items, (size_t)c->prob_cap * 4));
     TRY(ensure(c, c->d_prob_cov_off, (size_t)c->prob_cap * 8));
     TRY(ensure(c, c->d_prob_lane_lo, (size_t)c->prob_cap * 4));
     TRY(ensure(c, c->d_prob_lane_n, (size_t)c->prob_cap * 4));
@@ -1902,7 +1916,7 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
         hipLaunchKernelGGL(k_prob_emit, dim3(pg), dim3(256), 0, s, st, c->d_cand_pn.as<int>(), c->d_cand_ll.as<int>(),
                            c->d_cand_ln.as<int>(), c->d_seg_iv.as<int>(), c->d_cand_off.as<i64>(), c->d_prob_bs.as<i64>(),
                            pr, c->prob_cap, c->d_work_prob.as<int>(), c->d_work_chunk.as<int>(), c->d_cls_items.as<int>(),
-                           c->work_cap);
+                           c->work_cap, c->d_dp_items.as<int>());
     }
     mark(5);
     // S5
@@ -1946,23 +1960,24 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
     if (do_post) {
     if (c->prob_cap > 0) {
         int dp_grid = grid_for(c->prob_cap, 1, 1024);
-#define FSEG_LAUNCH_DP(NMV, TV, OUTT, NM_RT, NLO, QUEUE, MAXWG)                                                          \
+#define FSEG_LAUNCH_DP(NMV, TV, OUTT, NM_RT, DPCLASS, MAXWG)                                                             \
         hipLaunchKernelGGL((k_dp<NMV, TV, OUTT>), dim3(dp_grid < (MAXWG) ? dp_grid : (MAXWG)), dim3(TV),                     \
-                           dp_lds_for(NM_RT, (int)sizeof(OUTT)), s, st, NLO, NM_RT, QUEUE, pr, c->prob_cap,                   \
-                           c->d_cand_off.as<i64>(), c->d_cand_y.as<int>(), c->d_iv_part.as<int>(),                            \
+                           dp_lds_for(NM_RT, (int)sizeof(OUTT)), s, st, DPCLASS, NM_RT, c->d_dp_items.as<int>(), pr,          \
+                           c->prob_cap, c->d_cand_off.as<i64>(), c->d_cand_y.as<int>(), c->d_iv_part.as<int>(),               \
                            c->d_part_lane_off.as<i64>(), c->d_out.as<unsigned>(), c->tri_cap, c->d_amb.as<unsigned>(),        \
                            c->d_pair_thr.as<int2>(), c->pair_cap, c->P.min_read_support_outside,                              \
                            c->d_chosen.as<unsigned char>())
         // 16-bit count tables unless some problem sees >= 65536 reads (then a previous run asked for the wide tables);
-        // 512 threads (8 waves share the c2 loop) when the tables of the largest problem leave room for their scratch
+        // 512 threads (8 waves share the c2 loop) when the tables of the largest problem leave room for their scratch.
+        // small_batch: one launch over every problem; otherwise one launch per DP class list.
         if (c->dp_wide_counts) {
             const bool wide_wg = dp_lds_for(c->nm_big, 4) + 8 * 1024 <= kLdsPerWg;
-            if (!c->small_batch) { FSEG_LAUNCH_DP(kDpSmall, 256, unsigned, kDpSmall, 0, &st->dp_queue, 1024); }
-            if (wide_wg) { FSEG_LAUNCH_DP(kNMax, 512, unsigned, c->nm_big, c->small_batch ? 0 : kDpSmall, &st->dp_queue2, 256); }
-            else { FSEG_LAUNCH_DP(kNMax, 256, unsigned, c->nm_big, c->small_batch ? 0 : kDpSmall, &st->dp_queue2, 256); }
+            if (!c->small_batch) { FSEG_LAUNCH_DP(kDpSmall, 256, unsigned, kDpSmall, 0, 2048); }
+            if (wide_wg) { FSEG_LAUNCH_DP(kNMax, 512, unsigned, c->nm_big, c->small_batch ? -1 : 1, 256); }
+            else { FSEG_LAUNCH_DP(kNMax, 256, unsigned, c->nm_big, c->small_batch ? -1 : 1, 256); }
         } else {
-            if (!c->small_batch) { FSEG_LAUNCH_DP(kDpSmall, 256, unsigned short, kDpSmall, 0, &st->dp_queue, 1024); }
-            FSEG_LAUNCH_DP(kNMax, 512, unsigned short, c->nm_big, c->small_batch ? 0 : kDpSmall, &st->dp_queue2, 512);
+            if (!c->small_batch) { FSEG_LAUNCH_DP(kDpSmall, 256, unsigned short, kDpSmall, 0, 2048); }
+            FSEG_LAUNCH_DP(kNMax, 512, unsigned short, c->nm_big, c->small_batch ? -1 : 1, 512);
         }
 #undef FSEG_LAUNCH_DP
     }
@@ -2136,7 +2151,7 @@ void fseg_destroy(fseg_ctx *c) {
                       &c->d_final_pos, &c->d_col_thr, &c->d_col_zero, &c->d_cum, &c->d_tile_tot, &c->d_iv_tile0, &c->d_seg_iv, &c->d_seg_prev, &c->d_rseg_c, &c->d_cand_pn, &c->d_cand_ll, &c->d_cand_ln, &c->d_prob_bs, &c->d_prob_iv, &c->d_prob_start,
                       &c->d_prob_n, &c->d_prob_pair_off, &c->d_prob_tri_off, &c->d_prob_flags, &c->d_prob_chain, &c->d_prob_cov_off,
                       &c->d_prob_lane_lo, &c->d_prob_lane_n, &c->d_work_active, &c->d_cov,
-                      &c->d_work_prob, &c->d_work_chunk, &c->d_cls_items, &c->d_pair_thr, &c->d_amb, &c->d_out, &c->d_labels, &c->d_status, &c->d_tacc};
+                      &c->d_dp_items, &c->d_work_prob, &c->d_work_chunk, &c->d_cls_items, &c->d_pair_thr, &c->d_amb, &c->d_out, &c->d_labels, &c->d_status, &c->d_tacc};
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
     if (c->h_status) (void)hipHostFree(c->h_status);
     for (int i = 0; i <= ST_COUNT; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
