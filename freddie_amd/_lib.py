@@ -52,7 +52,8 @@ TAPS = dict(pos_off=(1, np.int64), y_raw=(2, np.int32), y=(3, np.float64), thres
 
 
 def lib_path():
-    return _build.SEG_SO
+    # FSEG_LIB: developer override used to compare builds of the same library (tuning experiments)
+    return os.environ.get("FSEG_LIB") or _build.SEG_SO
 
 
 def load():

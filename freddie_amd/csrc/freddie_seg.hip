@@ -314,6 +314,7 @@ __device__ __forceinline__ int count_flags32(const Flags32 &f) {
     return s;
 }
 
+// many blocks: three passes (block sums, their scan by one workgroup, emission)
 __global__ void __launch_bounds__(256) k_scan1(const unsigned char *flags, i64 n, int *bsum) {
     __shared__ int lds[16];
     i64 nb = (n + kScanBlock - 1) / kScanBlock;
@@ -344,13 +345,59 @@ __global__ void __launch_bounds__(256) k_scan2(int *bsum, i64 nb, u64 *total_out
     }
     if (threadIdx.x == 0) { *total_out = (u64)carry_s; if (off_last) *off_last = (i64)carry_s; }
 }
+// few blocks: single-pass chained scan (decoupled look-back): block b publishes its flag count in state[b] as soon as it is
+// known, then adds up its predecessors' words until it meets one that already holds an inclusive prefix.
+// state word = (tag << 62) | value, tag 0 = empty (zeroed at the start of the run), 1 = block aggregate,
+// 2 = inclusive prefix.  One workgroup per block: a block only ever waits for blocks with a smaller index, which
+// the dispatcher started earlier.  Returns the exclusive prefix of the block (all threads); the last block also
+// writes the grand total.
+constexpr u64 kScanValueMask = (1ULL << 62) - 1ULL;
+__device__ __forceinline__ i64 scan_lookback(u64 *state, i64 b, i64 nb, i64 agg, i64 *bcast /* LDS */, u64 *total_out,
+                                             i64 *off_last) {
+    const int lane = lane_id();
+    if (threadIdx.x < 64) {
+        if (lane == 0)
+            __hip_atomic_store(&state[b], ((b == 0 ? 2ULL : 1ULL) << 62) | (u64)agg, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        i64 excl = 0;
+        if (b > 0) {
+            i64 base = b - 1;                                        // lane l looks at block base - l
+            for (;;) {
+                const i64 idx = base - lane;
+                u64 sv = 2ULL << 62;                                 // before block 0: prefix 0
+                if (idx >= 0) sv = __hip_atomic_load(&state[idx], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned tag = (unsigned)(sv >> 62);
+                const u64 m_pref = __ballot(tag == 2), m_empty = __ballot(tag == 0);
+                u64 use;                                             // lanes whose value is added
+                if (m_pref) {
+                    const int first = __ffsll((long long)m_pref) - 1;
+                    use = first == 63 ? ~0ULL : ((2ULL << first) - 1ULL);
+                } else use = ~0ULL;
+                if (m_empty & use) { __builtin_amdgcn_s_sleep(1); continue; }   // a predecessor has not published yet
+                i64 v = ((use >> lane) & 1ULL) ? (i64)(sv & kScanValueMask) : 0;
+                for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+                excl += v;
+                if (m_pref) break;
+                base -= 64;
+            }
+            if (lane == 0)
+                __hip_atomic_store(&state[b], (2ULL << 62) | (u64)(excl + agg), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) {
+            *bcast = excl;
+            if (b == nb - 1) { *total_out = (u64)(excl + agg); if (off_last) *off_last = excl + agg; }
+        }
+    }
+    __syncthreads();
+    return *bcast;
+}
 // third pass fused with the consumer of the compaction:
 //   kEmitValues:    v[rank] = y[i]                                   (threshold stage)
 //   kEmitPositions: out_y[rank] = y index inside its interval, out_pos[rank] = genomic position,
 //                   out_off[k] = rank of the interval's first position (always flagged)
 enum { kEmitValues = 0, kEmitPositions = 1 };
 template <int MODE>
-__global__ void __launch_bounds__(256) k_scan_emit(const unsigned char *flags, i64 n, const int *bsum, const double *y,
+__global__ void __launch_bounds__(256) k_scan_emit(const unsigned char *flags, i64 n, const int *bsum /* or null */,
+                                                   u64 *state, u64 *total_out, i64 *off_last /* may be null */, const double *y,
                                                    double *v, i64 K, const i64 *pos_off, const int *iv_start,
                                                    const int *blk_iv0, int *out_y, int *out_pos, i64 *out_off) {
     // A block is 4 waves x 2048 consecutive positions.  Each wave first counts its flags (16-byte loads), the wave
@@ -358,19 +405,22 @@ __global__ void __launch_bounds__(256) k_scan_emit(const unsigned char *flags, i
     // the stores of the compacted output are coalesced.
     __shared__ int wave_cnt[4];
     __shared__ int lds[16];
+    __shared__ i64 bcast;
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     const u64 lt_mask = (1ULL << lane) - 1ULL;
     i64 nb = (n + kScanBlock - 1) / kScanBlock;
     if (MODE == kEmitPositions) {
         // sparse flags (about one position in a hundred): every thread owns 32 consecutive positions and only the
         // threads that hold a flag do any work
-        for (i64 b = blockIdx.x; b < nb; b += gridDim.x) {
+        {
+            const i64 b = blockIdx.x;                                // grid == nb
             i64 i0 = b * kScanBlock + (i64)threadIdx.x * 32;
             Flags32 f;
             int s = 0;
             if (i0 < n) { f = load_flags32(flags, i0, n); s = count_flags32(f); }
             int tot;
-            int ex = wg_exclusive_scan(s, lds, &tot) + bsum[b];
+            int ex = wg_exclusive_scan(s, lds, &tot);
+            ex += bsum ? bsum[b] : (int)scan_lookback(state, b, nb, tot, &bcast, total_out, off_last);
             if (s) {
                 i64 k = -1, k_end = 0, k_base = 0;
                 for (int q = 0; q < 8; ++q) {
@@ -393,11 +443,11 @@ __global__ void __launch_bounds__(256) k_scan_emit(const unsigned char *flags, i
                     }
                 }
             }
-            __syncthreads();
         }
         return;
     }
-    for (i64 b = blockIdx.x; b < nb; b += gridDim.x) {
+    {
+        const i64 b = blockIdx.x;                                    // grid == nb
         const i64 w0 = b * kScanBlock + (i64)wave * 2048;            // first position of this wave
         int s = 0;
         {
@@ -405,10 +455,10 @@ __global__ void __launch_bounds__(256) k_scan_emit(const unsigned char *flags, i
             if (i0 < n) s = count_flags32(load_flags32(flags, i0, n));
         }
         for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
-        __syncthreads();
         if (lane == 0) wave_cnt[wave] = s;
         __syncthreads();
-        int ex = bsum[b];
+        const int tot = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        int ex = bsum ? bsum[b] : (int)scan_lookback(state, b, nb, tot, &bcast, total_out, off_last);
         for (int w = 0; w < wave; ++w) ex += wave_cnt[w];
         if (s) {
             i64 k = -1, k_end = 0, k_base = 0;
@@ -440,7 +490,7 @@ __global__ void __launch_bounds__(256) k_scan_emit(const unsigned char *flags, i
 }
 // rank of the first position of every partition in the compaction of the Y > 0 flags
 __global__ void __launch_bounds__(64) k_voff(int n_part, const i64 *part_iv_off, const i64 *pos_off, i64 n_pos,
-                                             const unsigned char *flags, const int *bsum, const u64 *total, i64 *voff) {
+                                             const unsigned char *flags, const int *bsum /* or null */, const u64 *state, const u64 *total, i64 *voff) {
     for (int p = blockIdx.x; p <= n_part; p += gridDim.x) {
         if (p == n_part) { if (threadIdx.x == 0) voff[p] = (i64)*total; continue; }
         i64 pos = pos_off[part_iv_off[p]];
@@ -451,7 +501,8 @@ __global__ void __launch_bounds__(64) k_voff(int n_part, const i64 *part_iv_off,
             cnt += count_flags32(f);
         }
         for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
-        if (threadIdx.x == 0) voff[p] = (i64)bsum[b] + cnt;
+        if (threadIdx.x == 0)                                       // look-back state: inclusive prefix of block b-1
+            voff[p] = (bsum ? (i64)bsum[b] : (b ? (i64)(state[b - 1] & kScanValueMask) : 0)) + cnt;
     }
 }
 
@@ -1028,47 +1079,104 @@ __global__ void __launch_bounds__(kLaneChunk) k_cov(Status *st, ProblemArrays pr
 // Every thread of the workgroup must call it; returns the number of backtracked triples (valid on thread 0)
 // and marks the chosen candidates.
 // ---------------------------------------------------------------------------------------------
+#ifdef FSEG_SCORE_TIMING
+#define FSEG_DTICK(i) do { unsigned long long t_now = wall_clock64(); if (threadIdx.x == 0) atomicAdd(&dp_tacc[i], t_now - dt_prev); dt_prev = t_now; } while (0)
+#define FSEG_DPARAM , unsigned long long *dp_tacc, unsigned long long &dt_prev
+#define FSEG_DARG , dp_tacc, dt_prev
+#else
+#define FSEG_DTICK(i)
+#define FSEG_DPARAM
+#define FSEG_DARG
+#endif
+#ifndef FSEG_DP_G
+#define FSEG_DP_G 4                  // candidates per DP block (tuning knob)
+#endif
 template <int T, typename OutT>
 __device__ int dp_solve(int n, const OutT *out_s, const int *in_s, i64 *M, unsigned char *A, const int *cy_s, int support,
                         i64 *part_v /* T */, unsigned char *part_a /* T */, int *top_key /* T/64 */,
-                        unsigned char *chosen /* + first candidate of the problem */) {
+                        unsigned char *chosen /* + first candidate of the problem */ FSEG_DPARAM) {
     constexpr int NW = T / 64;
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     const int end = n - 1;
     const int npairs = n * (n - 1) / 2;
 #define FSEG_IN(a, b) ((i64)in_s[(b) * ((b) - 1) / 2 + (a)])
 #define FSEG_M(a, b) M[(b) * ((b) - 1) / 2 + (a)]
-    for (int b = threadIdx.x; b < end; b += T) { FSEG_M(b, end) = FSEG_IN(b, end); A[end * (end - 1) / 2 + b] = 255; }
+    // M(b,end): the chain closes here; the "segment too small" rule (:540) is folded into the table, so the
+    // inner loops only test tail != -inf
+    for (int b = threadIdx.x; b < end; b += T) {
+        FSEG_M(b, end) = cy_s[end] - cy_s[b] >= 5 ? FSEG_IN(b, end) : kNegInf;
+        A[end * (end - 1) / 2 + b] = 255;
+    }
     __syncthreads();
-    for (int c = end - 1; c >= 2; --c) {
-        int b = 1 + lane;
-        i64 best = kNegInf; int arg = 255;
-        if (b < c && cy_s[c] - cy_s[b] >= 5) {
-            i64 in_bc = FSEG_IN(b, c);
-            int base = c * (c - 1) / 2 + b;
-            const int cyc = cy_s[c];
-            for (int c2 = c + 1 + wave; c2 <= end; c2 += NW) {
-                i64 tail = FSEG_M(c, c2);
-                unsigned o = out_s[c2 * (c2 - 1) * (c2 - 2) / 6 + base];
-                bool ok = (cy_s[c2] - cyc >= 5) & (tail != kNegInf) & ((i64)o >= (i64)support);   // :526-527, :540
-                i64 cur = ok ? in_bc + (i64)o + tail : kNegInf;
-                bool take = cur > best;
-                best = take ? cur : best; arg = take ? c2 : arg;
+    // Blocks of G consecutive c (top, top-1, ..).  M(b,c) needs M(c,c2) for every c2 > c: the c2 above the block
+    // are final, so all G candidates of a block take their maximum over those c2 in parallel (wave = (g, c2 slice),
+    // lanes = b); the G(G-1)/2 terms with c2 inside the block are then added by wave 0 alone, in registers, with
+    // M(c,c2) read from the lane that owns b = c.  Two barriers per block instead of two per candidate.
+    constexpr int G = FSEG_DP_G <= NW ? FSEG_DP_G : NW;
+    constexpr int NWG = NW / G;
+    const int g_w = wave % G, s_w = wave / G;
+    const int b = 1 + lane;
+    for (int top = end - 1; top >= 2; top -= G) {
+        {
+            const int c = top - g_w;
+            i64 best = kNegInf; int arg = 255;
+            if (c >= 2 && b < c && cy_s[c] - cy_s[b] >= 5) {
+                const int base = c * (c - 1) / 2 + b;
+#pragma unroll 4
+                for (int c2 = top + 1 + s_w; c2 <= end; c2 += NWG) {
+                    i64 tail = FSEG_M(c, c2);
+                    unsigned o = out_s[c2 * (c2 - 1) * (c2 - 2) / 6 + base];
+                    bool ok = (tail != kNegInf) & ((i64)o >= (i64)support);                         // :526-527, :540
+                    i64 cur = ok ? (i64)o + tail : kNegInf;     // in(b,c) is the same for every c2: added after the maximum
+                    bool take = cur > best;
+                    best = take ? cur : best; arg = take ? c2 : arg;
+                }
             }
+            part_v[wave * 64 + lane] = best; part_a[wave * 64 + lane] = (unsigned char)arg;
         }
-        part_v[wave * 64 + lane] = best; part_a[wave * 64 + lane] = (unsigned char)arg;
         __syncthreads();
-        if (wave == 0 && b < c) {
-            // first maximiser over all c2: larger value wins, equal values keep the smaller c2
-            i64 bv = part_v[lane]; int ba = part_a[lane];
-            for (int w = 1; w < NW; ++w) {
-                i64 v = part_v[w * 64 + lane]; int a2 = part_a[w * 64 + lane];
-                if (v > bv || (v == bv && v != kNegInf && a2 < ba)) { bv = v; ba = a2; }
+        if (wave == 0) {
+            i64 R[G]; int Ra[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                // first maximiser over the c2 slices: larger value wins, equal values keep the smaller c2
+                i64 bv = part_v[g * 64 + lane]; int ba = part_a[g * 64 + lane];
+#pragma unroll
+                for (int s2 = 1; s2 < NWG; ++s2) {
+                    i64 v = part_v[(s2 * G + g) * 64 + lane]; int a2 = part_a[(s2 * G + g) * 64 + lane];
+                    if (v > bv || (v == bv && v != kNegInf && a2 < ba)) { bv = v; ba = a2; }
+                }
+                R[g] = bv; Ra[g] = ba;
             }
-            FSEG_M(b, c) = bv; A[c * (c - 1) / 2 + b] = (unsigned char)ba;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const int c = top - g;
+                if (c >= 2) {
+                    const bool live = b < c && cy_s[c] - cy_s[b] >= 5;
+                    const int base = c * (c - 1) / 2 + b;
+                    i64 best = kNegInf; int arg = 255;
+#pragma unroll
+                    for (int h = g - 1; h >= 0; --h) {               // c2 = top - h inside the block, ascending
+                        const int c2 = top - h;
+                        // M(c, c2) sits in lane c - 1 (b = c) of R[h]
+                        int lo = __builtin_amdgcn_readlane((int)(unsigned)(u64)R[h], c - 1);
+                        int hi = __builtin_amdgcn_readlane((int)(unsigned)((u64)R[h] >> 32), c - 1);
+                        i64 tail = (i64)(((u64)(unsigned)hi << 32) | (u64)(unsigned)lo);
+                        unsigned o = live ? (unsigned)out_s[c2 * (c2 - 1) * (c2 - 2) / 6 + base] : 0u;
+                        bool ok = live & (tail != kNegInf) & ((i64)o >= (i64)support);
+                        i64 cur = ok ? (i64)o + tail : kNegInf;
+                        bool take = cur > best;
+                        best = take ? cur : best; arg = take ? c2 : arg;
+                    }
+                    if (R[g] > best) { best = R[g]; arg = Ra[g]; }   // the c2 above the block are all larger: strict >
+                    R[g] = (live && best != kNegInf) ? best + FSEG_IN(b, c) : kNegInf;
+                    if (b < c) { FSEG_M(b, c) = R[g]; A[base] = (unsigned char)arg; }
+                }
+            }
         }
         __syncthreads();
     }
+    FSEG_DTICK(10);
     // top level (a = start): max over (j,k) of in_0j + out_0jk + M(j,k), first maximiser in (j, k) order,
     // taken only if strictly greater than "no cut" = in(0,end)   (:560-566)
     i64 bv = kNegInf; int bkey = 0x7fffffff;
@@ -1091,6 +1199,7 @@ __device__ int dp_solve(int n, const OutT *out_s, const int *in_s, i64 *M, unsig
     __syncthreads();
     if (lane == 0) { part_v[wave] = bv; top_key[wave] = bkey; }
     __syncthreads();
+    FSEG_DTICK(11);
     int chain = 0;
     if (threadIdx.x == 0) {
         for (int w = 1; w < NW; ++w)
@@ -1107,6 +1216,7 @@ __device__ int dp_solve(int n, const OutT *out_s, const int *in_s, i64 *M, unsig
             }
         }
     }
+    FSEG_DTICK(12);
 #undef FSEG_IN
 #undef FSEG_M
     return chain;
@@ -1348,7 +1458,7 @@ __global__ void __launch_bounds__(T) k_dp(Status *st, int dp_class, int nm, cons
                                             const i64 *cand_off, const int *cand_y, const int *iv_part,
                                             const i64 *part_lane_off, const unsigned *out_g, i64 tri_cap,
                                             const unsigned *amb_g, const int2 *pair_thr, i64 pair_cap, int support,
-                                            unsigned char *chosen) {
+                                            unsigned char *chosen FSEG_TPARAM) {
     // handles problems with n_lo < n <= NM that the scoring kernel did not finish itself (more than one
     // work item); the out table of the problem is staged in LDS first
     // LDS carve-up for problems of at most nm <= NM candidates (nm from the previous run's largest problem)
@@ -1367,8 +1477,12 @@ __global__ void __launch_bounds__(T) k_dp(Status *st, int dp_class, int nm, cons
     // dp_class 0 / 1: the small / big problems of the per-class list; -1: every problem
     const i64 list_base = dp_class == 1 ? (i64)st->dp_cls[0] : 0;
     const i64 list_n = dp_class < 0 ? n_prob : (i64)st->dp_cls[dp_class];
+#ifdef FSEG_SCORE_TIMING
+    unsigned long long *dp_tacc = tacc; unsigned long long dt_prev = wall_clock64();
+#endif
     for (i64 t = blockIdx.x; t < list_n; t += gridDim.x) {          // static stride (no shared work counter)
         __syncthreads();
+        FSEG_DTICK(8);
         const i64 p = dp_class < 0 ? t : (i64)dp_items[list_base + t];
         int n = pr.n[p];
         if (n > NM) continue;
@@ -1383,11 +1497,18 @@ __global__ void __launch_bounds__(T) k_dp(Status *st, int dp_class, int nm, cons
         const i64 outside = (part_lane_off[part + 1] - part_lane_off[part]) - pr.lane_n[p];
         const bool zamb = (pr.flags[p] & 1) != 0;
         for (int j = threadIdx.x; j < n; j += blockDim.x) cy_s[j] = cand_y[c0 + j];
-        for (int x = threadIdx.x; x < ntri; x += blockDim.x) out_s[x] = (OutT)out_g[toff + x];
+        for (int x0 = threadIdx.x; x0 < ntri; x0 += T * 8) {       // 8 loads in flight per thread
+            unsigned v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { int x = x0 + e * T; v[e] = x < ntri ? out_g[toff + x] : 0u; }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { int x = x0 + e * T; if (x < ntri) out_s[x] = (OutT)v[e]; }
+        }
         for (int q = threadIdx.x; q < npairs; q += blockDim.x)
             in_s[q] = -(int)((i64)amb_g[poff + q] + ((zamb && pair_thr[poff + q].y < 0) ? outside : 0));
         __syncthreads();
-        int chain = dp_solve<T>(n, out_s, in_s, M, A, cy_s, support, part_v, part_a, top_key, chosen + c0);
+        FSEG_DTICK(9);
+        int chain = dp_solve<T>(n, out_s, in_s, M, A, cy_s, support, part_v, part_a, top_key, chosen + c0 FSEG_DARG);
         if (threadIdx.x == 0) pr.chain[p] = chain;
     }
 }
@@ -1709,7 +1830,7 @@ struct fseg_ctx {
         d_rep_exon_off, d_ex_ts, d_ex_te, d_lane_rep, d_lane_start, d_lane_pmax, d_tile_iv, d_tile_y0, d_w_main,
         d_w_refine, d_h_table;
     // device buffers: position-sized
-    DevBuf d_y_raw, d_y, d_flag, d_v, d_bsum, d_g, d_pk, d_pf, d_kp, d_final_flag;
+    DevBuf d_y_raw, d_y, d_flag, d_v, d_scan_state, d_bsum, d_g, d_pk, d_pf, d_kp, d_final_flag;
     // partition-sized
     DevBuf d_blk_iv0;          // interval of the first position of every scan block (+ a sentinel)
     DevBuf d_hc_part, d_hc_p0, d_hc_n, d_hc_glo, d_hc_ghi;
@@ -1732,6 +1853,7 @@ struct fseg_ctx {
     int nm_big = kNMax;         // LDS carve-up of the big-problem kernels: largest problem of the previous run, rounded up
     bool small_batch = false;
     bool use_graph = true;      // replay the launch sequence as hipGraphs (FSEG_NO_GRAPH=1 disables)
+    i64 scan_single_max = 512;  // scan blocks up to which the compactions use the single-pass look-back scan (FSEG_SCAN_SINGLE_MAX)
     hipGraph_t graph[2] = {nullptr, nullptr};            // [0] whole pipeline, or before / after scoring when profiling
     hipGraphExec_t graph_exec[2] = {nullptr, nullptr};
     int n_graphs = 0;   // few DP problems in the previous run: merge the per-size-class launches
@@ -1823,15 +1945,8 @@ int alloc_arenas(fseg_ctx *c) {
     return FSEG_OK;
 }
 
-// prefix sums of a flag array: block sums + their exclusive scan; the third pass is fused with the consumer
-int launch_scan_counts(fseg_ctx *c, const unsigned char *flags, i64 n, u64 *total_dev, int *grid_out, i64 *off_last = nullptr) {
-    i64 nb = (n + kScanBlock - 1) / kScanBlock;
-    int g = grid_for(nb, 1, 4096);
-    hipLaunchKernelGGL(k_scan1, dim3(g), dim3(256), 0, c->stream, flags, n, c->d_bsum.as<int>());
-    hipLaunchKernelGGL(k_scan2, dim3(1), dim3(256), 0, c->stream, c->d_bsum.as<int>(), nb, total_dev, off_last);
-    *grid_out = g;
-    return FSEG_OK;
-}
+// look-back state of the three compactions (values, candidates, final positions): nb words each, zeroed per run
+inline i64 scan_blocks(i64 n) { return (n + kScanBlock - 1) / kScanBlock; }
 
 // phase: 0 = whole pipeline; 1 = everything before the interval-scoring kernel, 2 = the interval-scoring kernel(s),
 // 3 = everything after.
@@ -1846,7 +1961,17 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
     const i64 avg_len = NPOS / (K > 0 ? K : 1);
     const int iv_threads = avg_len > 65536 ? 1024 : (avg_len > 16384 ? 256 : 64);
     int tile_grid = grid_for(c->n_tiles, 1, 8192);
-    int scan_grid = 1;
+    const i64 scan_nb = scan_blocks(NPOS);
+    const int scan_grid = scan_nb > 0 ? (int)scan_nb : 1;       // exactly one workgroup per scan block (look-back)
+    u64 *scan_state = c->d_scan_state.as<u64>();
+    // single-pass look-back scan while the chain of blocks is short; block sums + one scanning workgroup beyond that
+    const bool scan_single = scan_nb <= c->scan_single_max;
+    int *bsum = scan_single ? nullptr : c->d_bsum.as<int>();
+    auto scan_counts = [&](const unsigned char *flags, u64 *total_dev, i64 *off_last) {
+        if (scan_single) return;
+        hipLaunchKernelGGL(k_scan1, dim3(grid_for(scan_nb, 1, 4096)), dim3(256), 0, s, flags, NPOS, bsum);
+        hipLaunchKernelGGL(k_scan2, dim3(1), dim3(256), 0, s, bsum, scan_nb, total_dev, off_last);
+    };
     int work_grid = grid_for(c->work_cap, 1, 4096);
     ProblemArrays pr{c->d_prob_iv.as<int>(), c->d_prob_start.as<int>(), c->d_prob_n.as<int>(),
                      c->d_prob_pair_off.as<i64>(), c->d_prob_tri_off.as<i64>(), c->d_prob_flags.as<int>(),
@@ -1854,6 +1979,7 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
                      c->d_prob_lane_n.as<int>()};
     if (do_pre) {
     HIP_TRY(c, hipMemsetAsync(st, 0, sizeof(Status), s));
+    if (scan_single) HIP_TRY(c, hipMemsetAsync(scan_state, 0, (size_t)scan_nb * 3 * 8, s));
     mark(0);
     // S1
     hipLaunchKernelGGL(k_hist, dim3(grid_for(c->n_hist_chunks, 1, 16384)), dim3(512), 0, s, c->n_hist_chunks,
@@ -1869,12 +1995,12 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
                        c->P.radius_main, c->d_y.as<double>(), c->d_flag.as<unsigned char>(), c->d_cum.as<int>(), c->d_tile_tot.as<int>());
     mark(2);
     // S3a threshold
-    TRY(launch_scan_counts(c, c->d_flag.as<unsigned char>(), NPOS, &st->n_vals, &scan_grid));
+    scan_counts(c->d_flag.as<unsigned char>(), &st->n_vals, nullptr);
     hipLaunchKernelGGL(k_scan_emit<kEmitValues>, dim3(scan_grid), dim3(256), 0, s, c->d_flag.as<unsigned char>(), NPOS,
-                       c->d_bsum.as<int>(), c->d_y.as<double>(), c->d_v.as<double>(), K, c->d_pos_off.as<i64>(),
+                       bsum, scan_state, &st->n_vals, (i64 *)nullptr, c->d_y.as<double>(), c->d_v.as<double>(), K, c->d_pos_off.as<i64>(),
                        c->d_iv_start.as<int>(), c->d_blk_iv0.as<int>(), (int *)nullptr, (int *)nullptr, (i64 *)nullptr);
     hipLaunchKernelGGL(k_voff, dim3(grid_for(n_part + 1, 1, 2048)), dim3(64), 0, s, n_part, c->d_part_iv_off.as<i64>(),
-                       c->d_pos_off.as<i64>(), NPOS, c->d_flag.as<unsigned char>(), c->d_bsum.as<int>(), &st->n_vals,
+                       c->d_pos_off.as<i64>(), NPOS, c->d_flag.as<unsigned char>(), bsum, scan_state, &st->n_vals,
                        c->d_voff.as<i64>());
     hipLaunchKernelGGL(k_vplan, dim3(1), dim3(256), 0, s, n_part, c->d_part_iv_off.as<i64>(), c->d_pos_off.as<i64>(), NPOS,
                        c->d_voff.as<i64>(), c->d_chunk_off.as<i64>(), st, c->chunk_cap);
@@ -1892,9 +2018,9 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
     HIP_TRY(c, hipMemsetAsync(c->d_flag.p, 0, (size_t)NPOS, s));
     hipLaunchKernelGGL(k_peaks, dim3(tile_grid), dim3(256), 0, s, c->n_tiles, c->d_tile_iv.as<int>(), c->d_tile_y0.as<int>(),
                        c->d_pos_off.as<i64>(), c->d_y.as<double>(), c->d_flag.as<unsigned char>());
-    TRY(launch_scan_counts(c, c->d_flag.as<unsigned char>(), NPOS, &st->n_cand, &scan_grid, c->d_cand_off.as<i64>() + K));
+    scan_counts(c->d_flag.as<unsigned char>(), &st->n_cand, c->d_cand_off.as<i64>() + K);
     hipLaunchKernelGGL(k_scan_emit<kEmitPositions>, dim3(scan_grid), dim3(256), 0, s, c->d_flag.as<unsigned char>(), NPOS,
-                       c->d_bsum.as<int>(), (const double *)nullptr, (double *)nullptr, K, c->d_pos_off.as<i64>(),
+                       bsum, scan_state + scan_nb, &st->n_cand, c->d_cand_off.as<i64>() + K, (const double *)nullptr, (double *)nullptr, K, c->d_pos_off.as<i64>(),
                        c->d_iv_start.as<int>(), c->d_blk_iv0.as<int>(), c->d_cand_y.as<int>(), (int *)nullptr,
                        c->d_cand_off.as<i64>());
     mark(4);
@@ -1966,7 +2092,7 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
                            c->prob_cap, c->d_cand_off.as<i64>(), c->d_cand_y.as<int>(), c->d_iv_part.as<int>(),               \
                            c->d_part_lane_off.as<i64>(), c->d_out.as<unsigned>(), c->tri_cap, c->d_amb.as<unsigned>(),        \
                            c->d_pair_thr.as<int2>(), c->pair_cap, c->P.min_read_support_outside,                              \
-                           c->d_chosen.as<unsigned char>())
+                           c->d_chosen.as<unsigned char>() FSEG_TARG)
         // 16-bit count tables unless some problem sees >= 65536 reads (then a previous run asked for the wide tables);
         // 512 threads (8 waves share the c2 loop) when the tables of the largest problem leave room for their scratch.
         // small_batch: one launch over every problem; otherwise one launch per DP class list.
@@ -1993,9 +2119,9 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
                        c->d_w_refine.as<double>(), c->P.radius_refine, c->P.sigma, c->d_g.as<double>(), c->d_pk.as<int>(),
                        c->d_pf.as<unsigned char>(), c->d_kp.as<unsigned char>(), c->d_final_flag.as<unsigned char>());
     mark(9);
-    TRY(launch_scan_counts(c, c->d_final_flag.as<unsigned char>(), NPOS, &st->n_final, &scan_grid, c->d_final_off.as<i64>() + K));
+    scan_counts(c->d_final_flag.as<unsigned char>(), &st->n_final, c->d_final_off.as<i64>() + K);
     hipLaunchKernelGGL(k_scan_emit<kEmitPositions>, dim3(scan_grid), dim3(256), 0, s, c->d_final_flag.as<unsigned char>(),
-                       NPOS, c->d_bsum.as<int>(), (const double *)nullptr, (double *)nullptr, K, c->d_pos_off.as<i64>(),
+                       NPOS, bsum, scan_state + 2 * scan_nb, &st->n_final, c->d_final_off.as<i64>() + K, (const double *)nullptr, (double *)nullptr, K, c->d_pos_off.as<i64>(),
                        c->d_iv_start.as<int>(), c->d_blk_iv0.as<int>(), c->d_final_y.as<int>(), c->d_final_pos.as<int>(),
                        c->d_final_off.as<i64>());
     mark(10);
@@ -2133,6 +2259,7 @@ int fseg_create(int device, fseg_ctx **out) {
     }
     c->d_status.cap = sizeof(Status);
     { const char *ng = getenv("FSEG_NO_GRAPH"); if (ng && ng[0] == '1') c->use_graph = false; }
+    { const char *sm = getenv("FSEG_SCAN_SINGLE_MAX"); if (sm && sm[0]) c->scan_single_max = atoll(sm); }
     *out = c;
     return FSEG_OK;
 }
@@ -2145,7 +2272,7 @@ void fseg_destroy(fseg_ctx *c) {
     DevBuf *bufs[] = {&c->d_part_iv_off, &c->d_part_rep_off, &c->d_part_lane_off, &c->d_iv_start, &c->d_iv_end, &c->d_pos_off,
                       &c->d_iv_part, &c->d_rep_weight, &c->d_rep_exon_off, &c->d_ex_ts, &c->d_ex_te, &c->d_lane_rep, &c->d_lane_start, &c->d_lane_pmax,
                       &c->d_tile_iv, &c->d_tile_y0, &c->d_w_main, &c->d_w_refine, &c->d_h_table, &c->d_y_raw, &c->d_y,
-                      &c->d_flag, &c->d_v, &c->d_bsum, &c->d_g, &c->d_pk, &c->d_pf, &c->d_kp, &c->d_final_flag,
+                      &c->d_flag, &c->d_v, &c->d_scan_state, &c->d_bsum, &c->d_g, &c->d_pk, &c->d_pf, &c->d_kp, &c->d_final_flag,
                       &c->d_blk_iv0, &c->d_hc_part, &c->d_hc_p0, &c->d_hc_n, &c->d_hc_glo, &c->d_hc_ghi, &c->d_voff, &c->d_chunk_off, &c->d_csum, &c->d_mean, &c->d_thr, &c->d_label_off, &c->d_part_has2, &c->d_rb_part, &c->d_rb_r0, &c->d_cand_off,
                       &c->d_cand_y, &c->d_fixed0, &c->d_added, &c->d_fixed, &c->d_chosen, &c->d_final_off, &c->d_final_y,
                       &c->d_final_pos, &c->d_col_thr, &c->d_col_zero, &c->d_cum, &c->d_tile_tot, &c->d_iv_tile0, &c->d_seg_iv, &c->d_seg_prev, &c->d_rseg_c, &c->d_cand_pn, &c->d_cand_ll, &c->d_cand_ln, &c->d_prob_bs, &c->d_prob_iv, &c->d_prob_start,
@@ -2358,7 +2485,8 @@ int fseg_upload(fseg_ctx *c, const fseg_batch *b) {
     size_t np8 = (size_t)NPOS + 64;
     TRY(ensure(c, c->d_y_raw, np8 * 4)); TRY(ensure(c, c->d_cum, np8 * 4)); TRY(ensure(c, c->d_y, np8 * 8)); TRY(ensure(c, c->d_flag, np8));
     TRY(ensure(c, c->d_v, np8 * 8));
-    TRY(ensure(c, c->d_bsum, ((size_t)(NPOS / kScanBlock) + 2) * 4));
+    TRY(ensure(c, c->d_scan_state, ((size_t)scan_blocks(NPOS) * 3 + 1) * 8));
+    TRY(ensure(c, c->d_bsum, ((size_t)scan_blocks(NPOS) + 2) * 4));
     TRY(ensure(c, c->d_g, np8 * 8)); TRY(ensure(c, c->d_pk, np8 * 4)); TRY(ensure(c, c->d_pf, np8)); TRY(ensure(c, c->d_kp, np8));
     TRY(ensure(c, c->d_final_flag, np8));
     TRY(ensure(c, c->d_voff, ((size_t)np + 2) * 8)); TRY(ensure(c, c->d_chunk_off, ((size_t)np + 2) * 8));
@@ -2378,8 +2506,8 @@ int fseg_upload(fseg_ctx *c, const fseg_batch *b) {
     atleast(c->prob_cap, 1024); atleast(c->work_cap, 1024); atleast(c->pair_cap, 1 << 16); atleast(c->tri_cap, 1 << 18);
     atleast(c->label_cap, 1 << 16); atleast(c->cov_cap, 1 << 18);
     TRY(alloc_arenas(c));
-    TRY(ensure(c, c->d_tacc, 64));
-    HIP_TRY(c, hipMemsetAsync(c->d_tacc.p, 0, 64, c->stream));
+    TRY(ensure(c, c->d_tacc, 128));
+    HIP_TRY(c, hipMemsetAsync(c->d_tacc.p, 0, 128, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     drop_graph(c);
     c->have_batch = true; c->ran = false; c->pending = false;
@@ -2530,8 +2658,8 @@ int fseg_stage_ms(fseg_ctx *c, float *ms) {
 #ifdef FSEG_SCORE_TIMING
 int fseg_debug_score_timing(fseg_ctx *c, unsigned long long *out8) {
     if (!c || !out8 || !c->d_tacc.p) return FSEG_ERR_ARG;
-    if (hipMemcpy(out8, c->d_tacc.p, 64, hipMemcpyDeviceToHost) != hipSuccess) return FSEG_ERR_HIP;
-    (void)hipMemset(c->d_tacc.p, 0, 64);
+    if (hipMemcpy(out8, c->d_tacc.p, 128, hipMemcpyDeviceToHost) != hipSuccess) return FSEG_ERR_HIP;   /* 16 slots */
+    (void)hipMemset(c->d_tacc.p, 0, 128);
     return FSEG_OK;
 }
 #endif
