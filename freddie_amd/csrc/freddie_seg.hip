@@ -1733,10 +1733,12 @@ __global__ void __launch_bounds__(256) k_label_fill(int n_part, const i64 *label
         for (i64 x = x0 + threadIdx.x; x < x1; x += blockDim.x) labels[x] = col_zero[f0 + (x - x0) % S];
     }
 }
-// One workgroup per block of 256 read reps of one partition.  The partition's column table (segment
-// boundaries and integer thresholds) is staged in LDS when it fits; every thread then merges its rep's exon
-// list against the columns its exons can reach.
+// One workgroup per 64 read reps of one partition (a quarter of a 256-rep block).  The partition's column table
+// (segment boundaries and integer thresholds) is staged in LDS when it fits; kLabelSplit threads share a rep: each
+// merges the rep's exon list against a quarter of the columns the exons can reach (the walk is a chain of dependent
+// loads, so shorter chains and more of them is what makes it faster).
 constexpr int kLabelCols = 4096;
+constexpr int kLabelSplit = 4;
 __global__ void __launch_bounds__(256) k_label_reads(int n_blocks, const int *rb_part, const int *rb_r0,
                                                      const i64 *label_off, i64 label_cap, int n_part,
                                                      const i64 *part_iv_off, const i64 *part_rep_off,
@@ -1746,12 +1748,14 @@ __global__ void __launch_bounds__(256) k_label_reads(int n_blocks, const int *rb
     __shared__ int fp_s[kLabelCols + 1];
     __shared__ int2 th_s[kLabelCols];
     if (label_off[n_part] > label_cap) return;
-    for (int blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+    for (i64 unit = blockIdx.x; unit < (i64)n_blocks * kLabelSplit; unit += gridDim.x) {
+        const int blk = (int)(unit / kLabelSplit), sub = (int)(unit % kLabelSplit);
         int p = rb_part[blk];
         i64 f0 = final_off[part_iv_off[p]];
         i64 F = final_off[part_iv_off[p + 1]] - f0;
         i64 S = F - 1;
         if (S <= 0) continue;
+        if ((i64)rb_r0[blk] + sub * (256 / kLabelSplit) >= part_rep_off[p + 1]) continue;
         const int *fp = final_pos + f0;                      // ascending over the whole partition
         const int2 *th = col_thr + f0;
         __syncthreads();
@@ -1761,7 +1765,8 @@ __global__ void __launch_bounds__(256) k_label_reads(int n_blocks, const int *rb
             fp = fp_s; th = th_s;
         }
         __syncthreads();
-        i64 r = (i64)rb_r0[blk] + threadIdx.x;
+        i64 r = (i64)rb_r0[blk] + sub * (256 / kLabelSplit) + (threadIdx.x / kLabelSplit);
+        const int q = threadIdx.x % kLabelSplit;
         if (r >= part_rep_off[p + 1]) continue;
         unsigned char *row = labels + label_off[p] + (r - part_rep_off[p]) * S;
         i64 e = rep_exon_off[r], e1 = rep_exon_off[r + 1];
@@ -1770,8 +1775,22 @@ __global__ void __launch_bounds__(256) k_label_reads(int n_blocks, const int *rb
         // first column whose segment [fp[c], fp[c+1]) ends after first_ts
         int lo = 0, hi = (int)S;
         while (lo < hi) { int mid = (lo + hi) >> 1; if (fp[mid + 1] <= first_ts) lo = mid + 1; else hi = mid; }
-        int ts = ex_ts[e], te = ex_te[e];
-        for (int c = lo; c < S && fp[c] <= last_te; ++c) {
+        // first column that starts after last_te
+        int c_hi = lo; hi = (int)S;
+        while (c_hi < hi) { int mid = (c_hi + hi) >> 1; if (fp[mid] <= last_te) c_hi = mid + 1; else hi = mid; }
+        // this thread's share of [lo, c_hi)
+        const int span = c_hi - lo;
+        const int c_a = lo + (int)((i64)span * q / kLabelSplit), c_b = lo + (int)((i64)span * (q + 1) / kLabelSplit);
+        if (c_a >= c_b) continue;
+        if (q) {                                             // first exon that reaches the first column of the share
+            const int g = fp[c_a];
+            i64 a = e, b = e1;
+            while (a < b) { i64 mid = (a + b) >> 1; if (ex_te[mid] < g) a = mid + 1; else b = mid; }
+            e = a;
+        }
+        int ts = 0, te = 0;
+        if (e < e1) { ts = ex_ts[e]; te = ex_te[e]; }
+        for (int c = c_a; c < c_b; ++c) {
             int2 t2 = th[c];
             if (t2.x == 0x7fffffff) continue;                 // sentinel column between two intervals
             int g0 = fp[c], g1 = fp[c + 1];
@@ -1786,7 +1805,9 @@ __global__ void __launch_bounds__(256) k_label_reads(int n_blocks, const int *rb
                     if (b3 > a3) cov += b3 - a3;
                 }
             }
-            row[c] = cov >= t2.x ? '1' : (cov <= t2.y ? '0' : '2');
+            // the arena already holds the zero-coverage label of the column ('0', or '2' when lo < 0): store only what differs
+            const unsigned char lab = cov >= t2.x ? '1' : (cov <= t2.y ? '0' : '2');
+            if (lab != (t2.y < 0 ? '2' : '0')) row[c] = lab;
         }
     }
 }
@@ -2138,7 +2159,7 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
         hipLaunchKernelGGL(k_label_fill, dim3(grid_for(n_part, 1, 2048)), dim3(256), 0, s, n_part, c->d_label_off.as<i64>(),
                            c->label_cap, c->d_part_iv_off.as<i64>(), c->d_final_off.as<i64>(),
                            c->d_col_zero.as<unsigned char>(), c->d_part_has2.as<int>(), c->d_labels.as<unsigned char>());
-        hipLaunchKernelGGL(k_label_reads, dim3(grid_for(c->n_rep_blocks, 1, 16384)), dim3(256), 0, s, c->n_rep_blocks,
+        hipLaunchKernelGGL(k_label_reads, dim3(grid_for((i64)c->n_rep_blocks * kLabelSplit, 1, 65536)), dim3(256), 0, s, c->n_rep_blocks,
                            c->d_rb_part.as<int>(), c->d_rb_r0.as<int>(), c->d_label_off.as<i64>(), c->label_cap, n_part,
                            c->d_part_iv_off.as<i64>(), c->d_part_rep_off.as<i64>(), c->d_final_off.as<i64>(),
                            c->d_final_pos.as<int>(), c->d_col_thr.as<int2>(), c->d_rep_exon_off.as<i64>(),
