@@ -853,92 +853,155 @@ __device__ __forceinline__ i64 wg_exclusive_scan64(i64 v, i64 *lds /* >= 16 */, 
     return off + x - v;
 }
 constexpr int kProbBlock = 1024;   // candidates per workgroup of the problem scan (256 threads x 4)
+// exclusive scan of kProbCols columns over the 256 threads of a workgroup (two barriers for all columns)
+__device__ __forceinline__ void wg_scan_cols(const ProbSizes &v, ProbSizes &ex, ProbSizes &tot, i64 *lds /* 4 * kProbCols */) {
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    for (int q = 0; q < kProbCols; ++q) {
+        i64 x = v.v[q];
+        for (int d = 1; d < 64; d <<= 1) {
+            i64 y = __shfl_up(x, d);
+            if (lane >= d) x += y;
+        }
+        ex.v[q] = x - v.v[q];
+        if (lane == 63) lds[wave * kProbCols + q] = x;
+    }
+    __syncthreads();
+    for (int q = 0; q < kProbCols; ++q) {
+        i64 off = 0, t = 0;
+        for (int w = 0; w < 4; ++w) {
+            i64 sv = lds[w * kProbCols + q];
+            if (w < wave) off += sv;
+            t += sv;
+        }
+        ex.v[q] += off; tot.v[q] = t;
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ ProbSizes prob_block_sizes(const int *cand_pn, const int *cand_ln, i64 b, i64 n, ProbSizes *per_elem /* 4, may be null */) {
+    ProbSizes acc;
+    for (int q = 0; q < kProbCols; ++q) acc.v[q] = 0;
+    const i64 i0 = b * kProbBlock + (i64)threadIdx.x * 4;
+    for (int e = 0; e < 4; ++e) {
+        ProbSizes sz = i0 + e < n ? prob_sizes(cand_pn[i0 + e], cand_ln[i0 + e]) : prob_sizes(0, 0);
+        if (per_elem) per_elem[e] = sz;
+        for (int q = 0; q < kProbCols; ++q) acc.v[q] += sz.v[q];
+    }
+    return acc;
+}
+__device__ __forceinline__ void prob_store_totals(Status *st, const ProbSizes &t) {
+    st->n_prob = (u64)t.v[0]; st->pair_used = (u64)t.v[1]; st->tri_used = (u64)t.v[2];
+    st->n_work = (u64)t.v[3]; st->cov_used = (u64)t.v[4];
+    st->cls_work[0] = (u64)t.v[5]; st->cls_work[1] = (u64)t.v[6]; st->cls_work[2] = (u64)t.v[7];
+    st->dp_cls[0] = (u64)t.v[8]; st->dp_cls[1] = (u64)t.v[9];
+}
 __global__ void __launch_bounds__(256) k_prob_scan1(const Status *st, const int *cand_pn, const int *cand_ln, i64 *bs) {
-    __shared__ i64 lds[16];
+    __shared__ i64 lds[4 * kProbCols];
     i64 n = (i64)st->n_cand;
     i64 nb = (n + kProbBlock - 1) / kProbBlock;
     for (i64 b = blockIdx.x; b < nb; b += gridDim.x) {
-        i64 i0 = b * kProbBlock + (i64)threadIdx.x * 4;
-        ProbSizes acc; for (int q = 0; q < kProbCols; ++q) acc.v[q] = 0;
-        for (int e = 0; e < 4; ++e) if (i0 + e < n) { ProbSizes s = prob_sizes(cand_pn[i0 + e], cand_ln[i0 + e]); for (int q = 0; q < kProbCols; ++q) acc.v[q] += s.v[q]; }
-        for (int q = 0; q < kProbCols; ++q) {
-            i64 tot;
-            wg_exclusive_scan64(acc.v[q], lds, &tot);
-            if (threadIdx.x == 0) bs[b * kProbCols + q] = tot;
-            __syncthreads();
-        }
+        ProbSizes acc = prob_block_sizes(cand_pn, cand_ln, b, n, nullptr), ex, tot;
+        wg_scan_cols(acc, ex, tot, lds);
+        if (threadIdx.x < kProbCols) bs[b * kProbCols + threadIdx.x] = tot.v[threadIdx.x];
     }
 }
 __global__ void __launch_bounds__(256) k_prob_scan2(Status *st, i64 *bs) {
-    __shared__ i64 lds[16];
-    __shared__ i64 carry_s[kProbCols];
+    __shared__ i64 lds[4 * kProbCols];
     i64 n = (i64)st->n_cand;
     i64 nb = (n + kProbBlock - 1) / kProbBlock;
-    if (threadIdx.x < kProbCols) carry_s[threadIdx.x] = 0;
-    __syncthreads();
+    ProbSizes carry;
+    for (int q = 0; q < kProbCols; ++q) carry.v[q] = 0;
     for (i64 b0 = 0; b0 < nb; b0 += blockDim.x) {
         i64 b = b0 + threadIdx.x;
+        ProbSizes v, ex, tot;
+        for (int q = 0; q < kProbCols; ++q) v.v[q] = b < nb ? bs[b * kProbCols + q] : 0;
+        wg_scan_cols(v, ex, tot, lds);
         for (int q = 0; q < kProbCols; ++q) {
-            i64 v = b < nb ? bs[b * kProbCols + q] : 0;
-            i64 tot;
-            i64 ex = wg_exclusive_scan64(v, lds, &tot);
-            i64 carry = carry_s[q];
-            if (b < nb) bs[b * kProbCols + q] = carry + ex;
-            __syncthreads();
-            if (threadIdx.x == 0) carry_s[q] = carry + tot;
-            __syncthreads();
+            if (b < nb) bs[b * kProbCols + q] = carry.v[q] + ex.v[q];
+            carry.v[q] += tot.v[q];
         }
     }
-    if (threadIdx.x == 0) {
-        st->n_prob = (u64)carry_s[0]; st->pair_used = (u64)carry_s[1]; st->tri_used = (u64)carry_s[2];
-        st->n_work = (u64)carry_s[3]; st->cov_used = (u64)carry_s[4];
-        st->cls_work[0] = (u64)carry_s[5]; st->cls_work[1] = (u64)carry_s[6]; st->cls_work[2] = (u64)carry_s[7];
-        st->dp_cls[0] = (u64)carry_s[8]; st->dp_cls[1] = (u64)carry_s[9];
-    }
+    if (threadIdx.x == 0) prob_store_totals(st, carry);
 }
+// bs == nullptr: every workgroup adds up the blocks before it itself (and all of them for the class bases) -- one
+// launch instead of three while the candidate list is a handful of blocks (the host picks the mode from the
+// previous run; either is correct for any size).
+constexpr int kProbDirect = 4;     // work items a problem's own thread writes itself; longer lists are written by the workgroup
 __global__ void __launch_bounds__(256) k_prob_emit(Status *st, const int *cand_pn, const int *cand_ll, const int *cand_ln,
                                                    const int *cand_iv, const i64 *cand_off, const i64 *bs,
                                                    ProblemArrays pr, i64 prob_cap, int *work_prob, int *work_chunk,
                                                    int *cls_items, i64 work_cap, int *dp_items) {
-    __shared__ i64 lds[16];
+    __shared__ i64 lds[4 * kProbCols];
+    __shared__ int l_slot[kProbBlock], l_cnt[kProbBlock];
+    __shared__ i64 l_w0[kProbBlock], l_c0[kProbBlock];
+    __shared__ int l_n;
     i64 n = (i64)st->n_cand;
     i64 nb = (n + kProbBlock - 1) / kProbBlock;
     for (i64 b = blockIdx.x; b < nb; b += gridDim.x) {
-        i64 i0 = b * kProbBlock + (i64)threadIdx.x * 4;
-        ProbSizes sz[4], acc; for (int q = 0; q < kProbCols; ++q) acc.v[q] = 0;
-        for (int e = 0; e < 4; ++e) {
-            if (i0 + e < n) sz[e] = prob_sizes(cand_pn[i0 + e], cand_ln[i0 + e]); else sz[e] = prob_sizes(0, 0);
-            for (int q = 0; q < kProbCols; ++q) acc.v[q] += sz[e].v[q];
+        ProbSizes sz[4], ex, tot, before, grand;
+        if (threadIdx.x == 0) l_n = 0;
+        if (bs) {
+            for (int q = 0; q < kProbCols; ++q) before.v[q] = bs[b * kProbCols + q];
+            grand.v[5] = (i64)st->cls_work[0]; grand.v[6] = (i64)st->cls_work[1]; grand.v[8] = (i64)st->dp_cls[0];
+        } else {
+            for (int q = 0; q < kProbCols; ++q) { before.v[q] = 0; grand.v[q] = 0; }
+            for (i64 bb = 0; bb < nb; ++bb) {
+                if (bb == b) continue;
+                ProbSizes acc = prob_block_sizes(cand_pn, cand_ln, bb, n, nullptr), e2, t2;
+                wg_scan_cols(acc, e2, t2, lds);
+                for (int q = 0; q < kProbCols; ++q) { if (bb < b) before.v[q] += t2.v[q]; grand.v[q] += t2.v[q]; }
+            }
         }
-        i64 ex[kProbCols];
-        for (int q = 0; q < kProbCols; ++q) { i64 tot; ex[q] = wg_exclusive_scan64(acc.v[q], lds, &tot) + bs[b * kProbCols + q]; __syncthreads(); }
+        ProbSizes acc = prob_block_sizes(cand_pn, cand_ln, b, n, sz);
+        wg_scan_cols(acc, ex, tot, lds);
+        for (int q = 0; q < kProbCols; ++q) ex.v[q] += before.v[q];
+        if (!bs) {
+            for (int q = 0; q < kProbCols; ++q) grand.v[q] += tot.v[q];
+            if (b == nb - 1 && threadIdx.x == 0) prob_store_totals(st, grand);
+        }
+        const i64 i0 = b * kProbBlock + (i64)threadIdx.x * 4;
         for (int e = 0; e < 4; ++e) {
             if (sz[e].v[0]) {
                 i64 c = i0 + e;
-                i64 slot = ex[0];
+                i64 slot = ex.v[0];
                 int nn = cand_pn[c];
                 if (slot < prob_cap) {
                     int k = cand_iv[c];
                     pr.iv[slot] = k; pr.start[slot] = (int)(c - cand_off[k]) - (nn - 1); pr.n[slot] = nn;
-                    pr.pair_off[slot] = ex[1]; pr.tri_off[slot] = ex[2]; pr.cov_off[slot] = ex[4];
+                    pr.pair_off[slot] = ex.v[1]; pr.tri_off[slot] = ex.v[2]; pr.cov_off[slot] = ex.v[4];
                     pr.flags[slot] = 0; pr.chain[slot] = 0;
                     pr.lane_lo[slot] = cand_ll[c]; pr.lane_n[slot] = cand_ln[c];
                     {   // DP problem lists: the small problems first, then the big ones
-                        i64 di = nn <= kDpSmall ? ex[8] : (i64)st->dp_cls[0] + ex[9];
+                        i64 di = nn <= kDpSmall ? ex.v[8] : grand.v[8] + ex.v[9];
                         if (di < prob_cap) dp_items[di] = (int)slot;
                     }
                     int cls = size_class(nn);
-                    i64 cbase = ex[5 + cls] + (cls >= 1 ? (i64)st->cls_work[0] : 0) + (cls >= 2 ? (i64)st->cls_work[1] : 0);
-                    for (i64 q = 0; q < sz[e].v[3]; ++q) {
-                        if (ex[3] + q < work_cap && cbase + q < work_cap) {
-                            work_prob[ex[3] + q] = (int)slot; work_chunk[ex[3] + q] = (int)q;
-                            cls_items[cbase + q] = (int)(ex[3] + q);
-                        } else atomicOr(&st->err, kErrOverflowWork);
+                    i64 cbase = ex.v[5 + cls] + (cls >= 1 ? grand.v[5] : 0) + (cls >= 2 ? grand.v[6] : 0);
+                    const i64 cnt = sz[e].v[3];
+                    if (ex.v[3] + cnt > work_cap || cbase + cnt > work_cap) atomicOr(&st->err, kErrOverflowWork);
+                    else if (cnt <= kProbDirect) {
+                        for (i64 q = 0; q < cnt; ++q) {
+                            work_prob[ex.v[3] + q] = (int)slot; work_chunk[ex.v[3] + q] = (int)q;
+                            cls_items[cbase + q] = (int)(ex.v[3] + q);
+                        }
+                    } else {
+                        int li = atomicAdd(&l_n, 1);
+                        l_slot[li] = (int)slot; l_cnt[li] = (int)cnt; l_w0[li] = ex.v[3]; l_c0[li] = cbase;
                     }
                 } else atomicOr(&st->err, kErrOverflowProblems);
             }
-            for (int q = 0; q < kProbCols; ++q) ex[q] += sz[e].v[q];
+            for (int q = 0; q < kProbCols; ++q) ex.v[q] += sz[e].v[q];
         }
+        __syncthreads();
+        const int ln = l_n;
+        for (int li = 0; li < ln; ++li) {
+            const int slot = l_slot[li], cnt = l_cnt[li];
+            const i64 w0 = l_w0[li], c0 = l_c0[li];
+            for (int q = threadIdx.x; q < cnt; q += blockDim.x) {
+                work_prob[w0 + q] = slot; work_chunk[w0 + q] = q;
+                cls_items[c0 + q] = (int)(w0 + q);
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -1874,6 +1937,8 @@ struct fseg_ctx {
     int nm_big = kNMax;         // LDS carve-up of the big-problem kernels: largest problem of the previous run, rounded up
     bool small_batch = false;
     bool use_graph = true;      // replay the launch sequence as hipGraphs (FSEG_NO_GRAPH=1 disables)
+    i64 prob_self_max = 4 * kProbBlock;   // candidates up to which it does (FSEG_PROB_SELF_MAX)
+    bool prob_self_scan = false; // k_prob_emit adds up the candidate blocks itself (few candidates in the previous run)
     i64 scan_single_max = 512;  // scan blocks up to which the compactions use the single-pass look-back scan (FSEG_SCAN_SINGLE_MAX)
     hipGraph_t graph[2] = {nullptr, nullptr};            // [0] whole pipeline, or before / after scoring when profiling
     hipGraphExec_t graph_exec[2] = {nullptr, nullptr};
@@ -2057,11 +2122,14 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
                        c->d_cand_ll.as<int>(), c->d_cand_ln.as<int>());
     {
         int pg = grid_for(NPOS / 8 / kProbBlock + 1, 1, 1024);
-        hipLaunchKernelGGL(k_prob_scan1, dim3(pg), dim3(256), 0, s, st, c->d_cand_pn.as<int>(), c->d_cand_ln.as<int>(),
-                           c->d_prob_bs.as<i64>());
-        hipLaunchKernelGGL(k_prob_scan2, dim3(1), dim3(256), 0, s, st, c->d_prob_bs.as<i64>());
+        // few candidates (previous run): the emit kernel scans by itself, one launch instead of three
+        i64 *bs = c->prob_self_scan ? nullptr : c->d_prob_bs.as<i64>();
+        if (bs) {
+            hipLaunchKernelGGL(k_prob_scan1, dim3(pg), dim3(256), 0, s, st, c->d_cand_pn.as<int>(), c->d_cand_ln.as<int>(), bs);
+            hipLaunchKernelGGL(k_prob_scan2, dim3(1), dim3(256), 0, s, st, bs);
+        }
         hipLaunchKernelGGL(k_prob_emit, dim3(pg), dim3(256), 0, s, st, c->d_cand_pn.as<int>(), c->d_cand_ll.as<int>(),
-                           c->d_cand_ln.as<int>(), c->d_seg_iv.as<int>(), c->d_cand_off.as<i64>(), c->d_prob_bs.as<i64>(),
+                           c->d_cand_ln.as<int>(), c->d_seg_iv.as<int>(), c->d_cand_off.as<i64>(), bs,
                            pr, c->prob_cap, c->d_work_prob.as<int>(), c->d_work_chunk.as<int>(), c->d_cls_items.as<int>(),
                            c->work_cap, c->d_dp_items.as<int>());
     }
@@ -2187,9 +2255,10 @@ int finish_run(fseg_ctx *c) {
         if (!need) {
             c->pending = false;
             c->ran = true;
-            const bool old_small = c->small_batch;
+            const bool old_small = c->small_batch, old_self = c->prob_self_scan;
             const int old_nm = c->nm_big;
             c->small_batch = (i64)s.n_prob <= 256 && (i64)s.n_work <= 1024;
+            c->prob_self_scan = (i64)s.n_cand <= c->prob_self_max;
             {   // size the next run's big-problem LDS for this run's largest problem (+ headroom, multiple of 4)
                 int want = (int)s.max_n + 3;
                 want = (want + 3) & ~3;
@@ -2198,7 +2267,7 @@ int finish_run(fseg_ctx *c) {
                 c->nm_big = want;
             }
             const int timed_graphs = c->n_graphs;
-            if (old_small != c->small_batch || old_nm != c->nm_big) drop_graph(c);
+            if (old_small != c->small_batch || old_nm != c->nm_big || old_self != c->prob_self_scan) drop_graph(c);
             if (c->profiling) {
                 for (int i = 0; i < ST_REPORTED; ++i) c->stage_ms[i] = 0.f;
                 if (timed_graphs == 2) {
@@ -2281,6 +2350,7 @@ int fseg_create(int device, fseg_ctx **out) {
     c->d_status.cap = sizeof(Status);
     { const char *ng = getenv("FSEG_NO_GRAPH"); if (ng && ng[0] == '1') c->use_graph = false; }
     { const char *sm = getenv("FSEG_SCAN_SINGLE_MAX"); if (sm && sm[0]) c->scan_single_max = atoll(sm); }
+    { const char *sm = getenv("FSEG_PROB_SELF_MAX"); if (sm && sm[0]) c->prob_self_max = atoll(sm); }
     *out = c;
     return FSEG_OK;
 }
