@@ -136,9 +136,11 @@ __global__ void __launch_bounds__(512) k_hist(int n_chunks, const int *chunk_par
                                               const int *iv_start, const int *iv_end, const i64 *pos_off,
                                               const i64 *part_lane_off, const int *lane_rep, const int *lane_start,
                                               const int *lane_pmax, const i64 *rep_exon_off, const int *ex_ts,
-                                              const int *ex_te, int ignore_ends, int *y_raw, Status *st) {
+                                              const int *ex_te, int ignore_ends, int *y_raw, Status *st, u64 *zero_ptr, i64 zero_n) {
     __shared__ int hist[kHistChunk];
     __shared__ int ivs_s[kHistIv], ive_s[kHistIv], base_s[kHistIv];
+    // first kernel of the run: also clears the look-back words of the three compactions (saves a memset node)
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < zero_n; i += (i64)gridDim.x * blockDim.x) zero_ptr[i] = 0;
     for (int ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
         const int part = chunk_part[ch];
         const i64 p0 = chunk_p0[ch];
@@ -208,7 +210,7 @@ __device__ __forceinline__ int wg_exclusive_scan(int v, int *lds, int *total);
 
 __global__ void __launch_bounds__(256) k_smooth(int n_tiles, const int *tile_iv, const int *tile_y0,
                                                 const i64 *pos_off, const int *y_raw, const double *w_g, int radius,
-                                                double *y_out, unsigned char *flag_pos, int *cum, int *tile_tot) {
+                                                double *y_out, unsigned char *flag_pos, unsigned char *flag_zero, int *cum, int *tile_tot) {
     __shared__ int xs[kSmoothTile + 2 * kMaxRadius];
     __shared__ int scan_lds[16];
     __shared__ double ws[kMaxRadius + 1];
@@ -260,6 +262,7 @@ __global__ void __launch_bounds__(256) k_smooth(int n_tiles, const int *tile_iv,
                     if (y0 + o4 + e < len) {
                         y_out[base + y0 + o4 + e] = av[e];
                         flag_pos[base + y0 + o4 + e] = av[e] > 0.0 ? 1 : 0;
+                        flag_zero[base + y0 + o4 + e] = 0;          // candidate flags start cleared (k_peaks sets them)
                     }
                 }
             }
@@ -652,7 +655,7 @@ __global__ void k_vsum_part(int n_part, const i64 *voff, const i64 *chunk_off, c
 // strict local maxima with the plateau-midpoint rule, plus the first and last position.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_peaks(int n_tiles, const int *tile_iv, const int *tile_y0, const i64 *pos_off,
-                                               const double *yv, unsigned char *flag) {
+                                               const double *yv, unsigned char *flag, unsigned char *final_zero) {
     for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         int k = tile_iv[t];
         i64 y0 = tile_y0[t];
@@ -662,6 +665,7 @@ __global__ void __launch_bounds__(256) k_peaks(int n_tiles, const int *tile_iv, 
         for (int o = threadIdx.x; o < kSmoothTile; o += blockDim.x) {
             i64 i = y0 + o;
             if (i >= len) break;
+            final_zero[base + i] = 0;                       // final-position flags start cleared (k_segments / k_refine set them)
             if (i == 0 || i == len - 1) { flag[base + i] = 1; continue; }
             double xi = x[i];
             if (x[i - 1] < xi) {
@@ -1736,7 +1740,7 @@ __global__ void __launch_bounds__(64) k_refine(const Status *st, const int *cand
 // (k_label_reads).
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_label_plan(int n_part, const i64 *part_iv_off, const i64 *part_rep_off,
-                                                    const i64 *final_off, i64 *label_off, Status *st, i64 label_cap) {
+                                                    const i64 *final_off, i64 *label_off, Status *st, i64 label_cap, int *part_has2) {
     __shared__ i64 carry_s;
     __shared__ i64 tmp[256];
     if (threadIdx.x == 0) carry_s = 0;
@@ -1756,7 +1760,7 @@ __global__ void __launch_bounds__(256) k_label_plan(int n_part, const i64 *part_
             carry_s = c;
         }
         __syncthreads();
-        if (p < n_part) label_off[p] = tmp[threadIdx.x];
+        if (p < n_part) { label_off[p] = tmp[threadIdx.x]; part_has2[p] = 0; }
         __syncthreads();
     }
     if (threadIdx.x == 0) {
@@ -1914,7 +1918,7 @@ struct fseg_ctx {
         d_rep_exon_off, d_ex_ts, d_ex_te, d_lane_rep, d_lane_start, d_lane_pmax, d_tile_iv, d_tile_y0, d_w_main,
         d_w_refine, d_h_table;
     // device buffers: position-sized
-    DevBuf d_y_raw, d_y, d_flag, d_v, d_scan_state, d_bsum, d_g, d_pk, d_pf, d_kp, d_final_flag;
+    DevBuf d_y_raw, d_y, d_flag, d_cflag, d_v, d_scan_state, d_bsum, d_g, d_pk, d_pf, d_kp, d_final_flag;
     // partition-sized
     DevBuf d_blk_iv0;          // interval of the first position of every scan block (+ a sentinel)
     DevBuf d_hc_part, d_hc_p0, d_hc_n, d_hc_glo, d_hc_ghi;
@@ -2065,7 +2069,6 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
                      c->d_prob_lane_n.as<int>()};
     if (do_pre) {
     HIP_TRY(c, hipMemsetAsync(st, 0, sizeof(Status), s));
-    if (scan_single) HIP_TRY(c, hipMemsetAsync(scan_state, 0, (size_t)scan_nb * 3 * 8, s));
     mark(0);
     // S1
     hipLaunchKernelGGL(k_hist, dim3(grid_for(c->n_hist_chunks, 1, 16384)), dim3(512), 0, s, c->n_hist_chunks,
@@ -2073,12 +2076,14 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
                        c->d_hc_ghi.as<int>(), c->d_part_iv_off.as<i64>(), c->d_iv_start.as<int>(), c->d_iv_end.as<int>(),
                        c->d_pos_off.as<i64>(), c->d_part_lane_off.as<i64>(), c->d_lane_rep.as<int>(),
                        c->d_lane_start.as<int>(), c->d_lane_pmax.as<int>(), c->d_rep_exon_off.as<i64>(),
-                       c->d_ex_ts.as<int>(), c->d_ex_te.as<int>(), c->P.ignore_ends, c->d_y_raw.as<int>(), st);
+                       c->d_ex_ts.as<int>(), c->d_ex_te.as<int>(), c->P.ignore_ends, c->d_y_raw.as<int>(), st,
+                       scan_state, scan_single ? scan_nb * 3 : 0);
     mark(1);
     // S2
     hipLaunchKernelGGL(k_smooth, dim3(tile_grid), dim3(256), 0, s, c->n_tiles, c->d_tile_iv.as<int>(),
                        c->d_tile_y0.as<int>(), c->d_pos_off.as<i64>(), c->d_y_raw.as<int>(), c->d_w_main.as<double>(),
-                       c->P.radius_main, c->d_y.as<double>(), c->d_flag.as<unsigned char>(), c->d_cum.as<int>(), c->d_tile_tot.as<int>());
+                       c->P.radius_main, c->d_y.as<double>(), c->d_flag.as<unsigned char>(), c->d_cflag.as<unsigned char>(),
+                       c->d_cum.as<int>(), c->d_tile_tot.as<int>());
     mark(2);
     // S3a threshold
     scan_counts(c->d_flag.as<unsigned char>(), &st->n_vals, nullptr);
@@ -2101,11 +2106,11 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
     }
     mark(3);
     // S3b candidates
-    HIP_TRY(c, hipMemsetAsync(c->d_flag.p, 0, (size_t)NPOS, s));
     hipLaunchKernelGGL(k_peaks, dim3(tile_grid), dim3(256), 0, s, c->n_tiles, c->d_tile_iv.as<int>(), c->d_tile_y0.as<int>(),
-                       c->d_pos_off.as<i64>(), c->d_y.as<double>(), c->d_flag.as<unsigned char>());
-    scan_counts(c->d_flag.as<unsigned char>(), &st->n_cand, c->d_cand_off.as<i64>() + K);
-    hipLaunchKernelGGL(k_scan_emit<kEmitPositions>, dim3(scan_grid), dim3(256), 0, s, c->d_flag.as<unsigned char>(), NPOS,
+                       c->d_pos_off.as<i64>(), c->d_y.as<double>(), c->d_cflag.as<unsigned char>(),
+                       c->d_final_flag.as<unsigned char>());
+    scan_counts(c->d_cflag.as<unsigned char>(), &st->n_cand, c->d_cand_off.as<i64>() + K);
+    hipLaunchKernelGGL(k_scan_emit<kEmitPositions>, dim3(scan_grid), dim3(256), 0, s, c->d_cflag.as<unsigned char>(), NPOS,
                        bsum, scan_state + scan_nb, &st->n_cand, c->d_cand_off.as<i64>() + K, (const double *)nullptr, (double *)nullptr, K, c->d_pos_off.as<i64>(),
                        c->d_iv_start.as<int>(), c->d_blk_iv0.as<int>(), c->d_cand_y.as<int>(), (int *)nullptr,
                        c->d_cand_off.as<i64>());
@@ -2198,7 +2203,6 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
     }
     mark(8);
     // S6
-    HIP_TRY(c, hipMemsetAsync(c->d_final_flag.p, 0, (size_t)NPOS, s));
     hipLaunchKernelGGL(k_segments, dim3(grid_for(K, 1, 8192)), dim3(iv_threads), 0, s, K, c->d_pos_off.as<i64>(),
                        c->d_cand_off.as<i64>(), c->d_cand_y.as<int>(), c->d_cum.as<int>(), c->d_tile_tot.as<int>(), c->d_iv_tile0.as<int>(),
                        c->d_chosen.as<unsigned char>(), c->d_final_flag.as<unsigned char>(), c->d_rseg_c.as<int>(),
@@ -2216,8 +2220,7 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
     mark(10);
     // S7
     hipLaunchKernelGGL(k_label_plan, dim3(1), dim3(256), 0, s, n_part, c->d_part_iv_off.as<i64>(),
-                       c->d_part_rep_off.as<i64>(), c->d_final_off.as<i64>(), c->d_label_off.as<i64>(), st, c->label_cap);
-    HIP_TRY(c, hipMemsetAsync(c->d_part_has2.p, 0, (size_t)n_part * 4, s));
+                       c->d_part_rep_off.as<i64>(), c->d_final_off.as<i64>(), c->d_label_off.as<i64>(), st, c->label_cap, c->d_part_has2.as<int>());
     hipLaunchKernelGGL(k_label_cols, dim3(grid_for(NPOS / 8 + 1, 256, 2048)), dim3(256), 0, s, K, c->d_final_off.as<i64>(),
                        c->d_final_y.as<int>(), c->d_iv_part.as<int>(), c->d_h_table.as<double>(), c->P.h_len,
                        c->P.threshold_rate, c->d_col_thr.as<int2>(), c->d_col_zero.as<unsigned char>(),
@@ -2363,7 +2366,7 @@ void fseg_destroy(fseg_ctx *c) {
     DevBuf *bufs[] = {&c->d_part_iv_off, &c->d_part_rep_off, &c->d_part_lane_off, &c->d_iv_start, &c->d_iv_end, &c->d_pos_off,
                       &c->d_iv_part, &c->d_rep_weight, &c->d_rep_exon_off, &c->d_ex_ts, &c->d_ex_te, &c->d_lane_rep, &c->d_lane_start, &c->d_lane_pmax,
                       &c->d_tile_iv, &c->d_tile_y0, &c->d_w_main, &c->d_w_refine, &c->d_h_table, &c->d_y_raw, &c->d_y,
-                      &c->d_flag, &c->d_v, &c->d_scan_state, &c->d_bsum, &c->d_g, &c->d_pk, &c->d_pf, &c->d_kp, &c->d_final_flag,
+                      &c->d_flag, &c->d_cflag, &c->d_v, &c->d_scan_state, &c->d_bsum, &c->d_g, &c->d_pk, &c->d_pf, &c->d_kp, &c->d_final_flag,
                       &c->d_blk_iv0, &c->d_hc_part, &c->d_hc_p0, &c->d_hc_n, &c->d_hc_glo, &c->d_hc_ghi, &c->d_voff, &c->d_chunk_off, &c->d_csum, &c->d_mean, &c->d_thr, &c->d_label_off, &c->d_part_has2, &c->d_rb_part, &c->d_rb_r0, &c->d_cand_off,
                       &c->d_cand_y, &c->d_fixed0, &c->d_added, &c->d_fixed, &c->d_chosen, &c->d_final_off, &c->d_final_y,
                       &c->d_final_pos, &c->d_col_thr, &c->d_col_zero, &c->d_cum, &c->d_tile_tot, &c->d_iv_tile0, &c->d_seg_iv, &c->d_seg_prev, &c->d_rseg_c, &c->d_cand_pn, &c->d_cand_ll, &c->d_cand_ln, &c->d_prob_bs, &c->d_prob_iv, &c->d_prob_start,
@@ -2574,7 +2577,7 @@ int fseg_upload(fseg_ctx *c, const fseg_batch *b) {
     TRY(upload_vec(c, c->d_tile_y0, tile_y0.data(), tile_y0.size()));
     // position-sized work buffers
     size_t np8 = (size_t)NPOS + 64;
-    TRY(ensure(c, c->d_y_raw, np8 * 4)); TRY(ensure(c, c->d_cum, np8 * 4)); TRY(ensure(c, c->d_y, np8 * 8)); TRY(ensure(c, c->d_flag, np8));
+    TRY(ensure(c, c->d_y_raw, np8 * 4)); TRY(ensure(c, c->d_cum, np8 * 4)); TRY(ensure(c, c->d_y, np8 * 8)); TRY(ensure(c, c->d_flag, np8)); TRY(ensure(c, c->d_cflag, np8));
     TRY(ensure(c, c->d_v, np8 * 8));
     TRY(ensure(c, c->d_scan_state, ((size_t)scan_blocks(NPOS) * 3 + 1) * 8));
     TRY(ensure(c, c->d_bsum, ((size_t)scan_blocks(NPOS) + 2) * 4));
