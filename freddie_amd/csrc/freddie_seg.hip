@@ -548,11 +548,12 @@ __global__ void __launch_bounds__(256) k_vplan(int n_part, const i64 *part_iv_of
 // is added left to right, and the leaves are combined in recursion order.
 __global__ void __launch_bounds__(512) k_vsum_chunks(int n_part, const i64 *voff, const i64 *chunk_off, const double *v,
                                                      const double *mean, int pass, double *csum, i64 chunk_cap) {
-    __shared__ int leaf_off[256], leaf_len[256], leaf_depth[256];
-    __shared__ double leaf_sum[256];
-    __shared__ int n_leaf_s;
-    __shared__ int stk_a[32], stk_b[32], stk_c[32];
-    __shared__ double stk_v[32];
+    // leaves of the pairwise recursion, left to right; a partial chunk's tree is kept in heap order (root 1,
+    // children 2i / 2i+1; depth <= 7): node_kind 1 = leaf, 2 = inner node
+    __shared__ int leaf_off[128], leaf_len[128], leaf_heap[128];
+    __shared__ double node_val[256];
+    __shared__ unsigned char node_kind[256];
+    __shared__ int n_leaf_s, wave0_leaves;
     i64 n_chunks = chunk_off[n_part];
     if (n_chunks > chunk_cap) n_chunks = chunk_cap;
     for (i64 c = blockIdx.x; c < n_chunks; c += gridDim.x) {
@@ -565,24 +566,35 @@ __global__ void __launch_bounds__(512) k_vsum_chunks(int n_part, const i64 *voff
         __syncthreads();
         if (m == 8192) {
             // perfect tree: 64 leaves of 128
-            for (int t = threadIdx.x; t < 64; t += blockDim.x) { leaf_off[t] = t * 128; leaf_len[t] = 128; leaf_depth[t] = 6; }
+            for (int t = threadIdx.x; t < 64; t += blockDim.x) { leaf_off[t] = t * 128; leaf_len[t] = 128; leaf_heap[t] = 64 + t; }
             if (threadIdx.x == 0) n_leaf_s = 64;
-        } else if (threadIdx.x == 0) {
-            // leaves of the pairwise recursion, left to right, with their depth (explicit stack in LDS:
-            // runtime-indexed private arrays would live in scratch memory)
-            int sp = 0, nl = 0;
-            stk_a[0] = 0; stk_b[0] = m; stk_c[0] = 0; sp = 1;
-            while (sp > 0) {
-                --sp;
-                int off = stk_a[sp], len = stk_b[sp], d = stk_c[sp];
-                if (len <= 128) { leaf_off[nl] = off; leaf_len[nl] = len; leaf_depth[nl] = d; ++nl; }
-                else {
-                    int n2 = len / 2; n2 -= n2 % 8;
-                    stk_a[sp] = off + n2; stk_b[sp] = len - n2; stk_c[sp] = d + 1; ++sp;   // right (popped second)
-                    stk_a[sp] = off; stk_b[sp] = n2; stk_c[sp] = d + 1; ++sp;              // left
+        } else {
+            // every leaf but a lone one has at least 64 elements, so it holds exactly one x = 64 t with x - off < 64:
+            // thread t walks the recursion (n2 = len/2 rounded down to a multiple of 8) down to the leaf of x
+            if (threadIdx.x < 256) node_kind[threadIdx.x] = 0;
+            __syncthreads();
+            if (threadIdx.x < 128) {
+                const int x = threadIdx.x * 64;
+                int off = 0, len = m, h = 1;
+                bool own = false;
+                if (x < m) {
+                    while (len > 128) {
+                        int n2 = len / 2; n2 -= n2 % 8;
+                        if (x < off + n2) { len = n2; h = 2 * h; } else { off += n2; len -= n2; h = 2 * h + 1; }
+                    }
+                    own = x - off < 64;
                 }
-            }
-            n_leaf_s = nl;
+                const u64 mk = __ballot(own);
+                if (threadIdx.x == 0) wave0_leaves = __popcll(mk);
+                __syncthreads();
+                if (own) {
+                    const int rank = __popcll(mk & ((1ULL << lane_id()) - 1ULL)) + (threadIdx.x >= 64 ? wave0_leaves : 0);
+                    leaf_off[rank] = off; leaf_len[rank] = len; leaf_heap[rank] = h;
+                    node_kind[h] = 1;
+                    for (int anc = h >> 1; anc >= 1; anc >>= 1) node_kind[anc] = 2;
+                }
+                if (threadIdx.x == 64) n_leaf_s = wave0_leaves + __popcll(mk);
+            } else __syncthreads();
         }
         __syncthreads();
         int nl = n_leaf_s;
@@ -611,29 +623,25 @@ __global__ void __launch_bounds__(512) k_vsum_chunks(int n_part, const i64 *voff
                     for (int i = body; i < len; ++i) res = __dadd_rn(res, FSEG_VAL(b[i]));
                 }
             }
-            if (t < nl && q == 0) leaf_sum[t] = res;
+            if (t < nl && q == 0) node_val[leaf_heap[t]] = res;
         }
 #undef FSEG_VAL
         __syncthreads();
         if (m == 8192) {
             // perfect tree over 64 leaves: adjacent pairs level by level = xor butterfly on one wave
             if (threadIdx.x < 64) {
-                double x = leaf_sum[threadIdx.x];
+                double x = node_val[64 + threadIdx.x];
                 for (int d = 1; d < 64; d <<= 1) x = __dadd_rn(x, __shfl_xor(x, d));
                 if (threadIdx.x == 0) csum[c] = x;
             }
-        } else if (threadIdx.x == 0) {
-            // combine: two finished subtrees of equal depth are siblings
-            int sp = 0;
-            for (int t = 0; t < nl; ++t) {
-                stk_v[sp] = leaf_sum[t]; stk_c[sp] = leaf_depth[t]; ++sp;
-                while (sp >= 2 && stk_c[sp - 1] == stk_c[sp - 2]) {
-                    stk_v[sp - 2] = __dadd_rn(stk_v[sp - 2], stk_v[sp - 1]);
-                    stk_c[sp - 2] -= 1;
-                    --sp;
-                }
+        } else {
+            // inner nodes bottom-up, one tree level per step: sum(left) + sum(right)
+            for (int lvl = 6; lvl >= 0; --lvl) {
+                const int i = (1 << lvl) + threadIdx.x;
+                if ((int)threadIdx.x < (1 << lvl) && node_kind[i] == 2) node_val[i] = __dadd_rn(node_val[2 * i], node_val[2 * i + 1]);
+                __syncthreads();
             }
-            csum[c] = stk_v[0];
+            if (threadIdx.x == 0) csum[c] = node_val[1];
         }
     }
 }
