@@ -132,7 +132,8 @@ __device__ __forceinline__ void label_thresholds(i64 L, const double *h_table, i
 constexpr int kHistChunk = 8192;
 constexpr int kHistIv = 1024;      // intervals of a partition cached in LDS by k_hist
 __global__ void __launch_bounds__(512) k_hist(int n_chunks, const int *chunk_part, const i64 *chunk_p0, const int *chunk_n,
-                                              const int *chunk_glo, const int *chunk_ghi, const i64 *part_iv_off,
+                                              const int *chunk_glo, const int *chunk_ghi, const i64 *chunk_lane_lo,
+                                              const i64 *chunk_lane_hi, const i64 *part_iv_off,
                                               const int *iv_start, const int *iv_end, const i64 *pos_off,
                                               const i64 *part_lane_off, const int *lane_rep, const int *lane_start,
                                               const int *lane_pmax, const i64 *rep_exon_off, const int *ex_ts,
@@ -149,13 +150,9 @@ __global__ void __launch_bounds__(512) k_hist(int n_chunks, const int *chunk_par
         const i64 k0 = part_iv_off[part], k1 = part_iv_off[part + 1];
         __syncthreads();
         for (int i = threadIdx.x; i < np; i += blockDim.x) hist[i] = 0;
-        // lanes whose [first, last] position range meets [g_lo, g_hi]
-        i64 a = part_lane_off[part], L1 = part_lane_off[part + 1], b = L1;
-        while (a < b) { i64 m = (a + b) >> 1; if (lane_pmax[m] < g_lo) a = m + 1; else b = m; }
-        const i64 lo = a;
-        b = L1;
-        while (a < b) { i64 m = (a + b) >> 1; if (lane_start[m] <= g_hi) a = m + 1; else b = m; }
-        const i64 hi = a;
+        // lanes whose [first, last] position range meets [g_lo, g_hi]: found on upload (the chunks and the sorted
+        // lanes are both fixed then), two dependent 16-step searches less per workgroup
+        const i64 lo = chunk_lane_lo[ch], hi = chunk_lane_hi[ch];
         // the partition's interval table in LDS when it fits (the per-exon interval search then stays on chip)
         const int nk = (int)(k1 - k0);
         const bool cached = nk <= kHistIv;
@@ -1929,7 +1926,7 @@ struct fseg_ctx {
     DevBuf d_y_raw, d_y, d_flag, d_cflag, d_v, d_scan_state, d_bsum, d_g, d_pk, d_pf, d_kp, d_final_flag;
     // partition-sized
     DevBuf d_blk_iv0;          // interval of the first position of every scan block (+ a sentinel)
-    DevBuf d_hc_part, d_hc_p0, d_hc_n, d_hc_glo, d_hc_ghi;
+    DevBuf d_hc_part, d_hc_p0, d_hc_n, d_hc_glo, d_hc_ghi, d_hc_llo, d_hc_lhi;
     int n_hist_chunks = 0;
     DevBuf d_voff, d_chunk_off, d_csum, d_mean, d_thr, d_label_off, d_part_has2, d_rb_part, d_rb_r0;
     int n_rep_blocks = 0;
@@ -2081,7 +2078,7 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
     // S1
     hipLaunchKernelGGL(k_hist, dim3(grid_for(c->n_hist_chunks, 1, 16384)), dim3(512), 0, s, c->n_hist_chunks,
                        c->d_hc_part.as<int>(), c->d_hc_p0.as<i64>(), c->d_hc_n.as<int>(), c->d_hc_glo.as<int>(),
-                       c->d_hc_ghi.as<int>(), c->d_part_iv_off.as<i64>(), c->d_iv_start.as<int>(), c->d_iv_end.as<int>(),
+                       c->d_hc_ghi.as<int>(), c->d_hc_llo.as<i64>(), c->d_hc_lhi.as<i64>(), c->d_part_iv_off.as<i64>(), c->d_iv_start.as<int>(), c->d_iv_end.as<int>(),
                        c->d_pos_off.as<i64>(), c->d_part_lane_off.as<i64>(), c->d_lane_rep.as<int>(),
                        c->d_lane_start.as<int>(), c->d_lane_pmax.as<int>(), c->d_rep_exon_off.as<i64>(),
                        c->d_ex_ts.as<int>(), c->d_ex_te.as<int>(), c->P.ignore_ends, c->d_y_raw.as<int>(), st,
@@ -2375,7 +2372,7 @@ void fseg_destroy(fseg_ctx *c) {
                       &c->d_iv_part, &c->d_rep_weight, &c->d_rep_exon_off, &c->d_ex_ts, &c->d_ex_te, &c->d_lane_rep, &c->d_lane_start, &c->d_lane_pmax,
                       &c->d_tile_iv, &c->d_tile_y0, &c->d_w_main, &c->d_w_refine, &c->d_h_table, &c->d_y_raw, &c->d_y,
                       &c->d_flag, &c->d_cflag, &c->d_v, &c->d_scan_state, &c->d_bsum, &c->d_g, &c->d_pk, &c->d_pf, &c->d_kp, &c->d_final_flag,
-                      &c->d_blk_iv0, &c->d_hc_part, &c->d_hc_p0, &c->d_hc_n, &c->d_hc_glo, &c->d_hc_ghi, &c->d_voff, &c->d_chunk_off, &c->d_csum, &c->d_mean, &c->d_thr, &c->d_label_off, &c->d_part_has2, &c->d_rb_part, &c->d_rb_r0, &c->d_cand_off,
+                      &c->d_blk_iv0, &c->d_hc_part, &c->d_hc_p0, &c->d_hc_n, &c->d_hc_glo, &c->d_hc_ghi, &c->d_hc_llo, &c->d_hc_lhi, &c->d_voff, &c->d_chunk_off, &c->d_csum, &c->d_mean, &c->d_thr, &c->d_label_off, &c->d_part_has2, &c->d_rb_part, &c->d_rb_r0, &c->d_cand_off,
                       &c->d_cand_y, &c->d_fixed0, &c->d_added, &c->d_fixed, &c->d_chosen, &c->d_final_off, &c->d_final_y,
                       &c->d_final_pos, &c->d_col_thr, &c->d_col_zero, &c->d_cum, &c->d_tile_tot, &c->d_iv_tile0, &c->d_seg_iv, &c->d_seg_prev, &c->d_rseg_c, &c->d_cand_pn, &c->d_cand_ll, &c->d_cand_ln, &c->d_prob_bs, &c->d_prob_iv, &c->d_prob_start,
                       &c->d_prob_n, &c->d_prob_pair_off, &c->d_prob_tri_off, &c->d_prob_flags, &c->d_prob_chain, &c->d_prob_cov_off,
@@ -2539,7 +2536,7 @@ int fseg_upload(fseg_ctx *c, const fseg_batch *b) {
     {   // histogram chunks: kHistChunk consecutive positions of one partition, with the genomic position of the
         // chunk's first and last position (a chunk may span several intervals of its partition)
         std::vector<int> hc_part, hc_n, hc_glo, hc_ghi;
-        std::vector<i64> hc_p0;
+        std::vector<i64> hc_p0, hc_llo, hc_lhi;
         // chunk size: as large as possible (fewer reads are visited twice) while still giving >= 512 workgroups
         int hist_chunk = kHistChunk;
         while (hist_chunk > 1024 && NPOS / hist_chunk < 512) hist_chunk >>= 1;
@@ -2556,6 +2553,12 @@ int fseg_upload(fseg_ctx *c, const fseg_batch *b) {
                 const int ghi = b->iv_start[kk] + (int)(q1 - pos_off[kk]);
                 hc_part.push_back(p); hc_p0.push_back(q0); hc_n.push_back((int)(q1 - q0 + 1));
                 hc_glo.push_back(glo); hc_ghi.push_back(ghi);
+                // lanes of the partition whose [first, last] position range meets [glo, ghi]
+                const int *pm = lane_pmax.data(), *ls = lane_start.data();
+                const i64 L0 = part_lane_off[p], L1 = part_lane_off[p + 1];
+                const i64 llo = std::lower_bound(pm + L0, pm + L1, glo) - pm;
+                const i64 lhi = std::upper_bound(ls + llo, ls + L1, ghi) - ls;
+                hc_llo.push_back(llo); hc_lhi.push_back(lhi);
             }
         }
         c->n_hist_chunks = (int)hc_part.size();
@@ -2564,6 +2567,8 @@ int fseg_upload(fseg_ctx *c, const fseg_batch *b) {
         TRY(upload_vec(c, c->d_hc_n, hc_n.data(), hc_n.size()));
         TRY(upload_vec(c, c->d_hc_glo, hc_glo.data(), hc_glo.size()));
         TRY(upload_vec(c, c->d_hc_ghi, hc_ghi.data(), hc_ghi.size()));
+        TRY(upload_vec(c, c->d_hc_llo, hc_llo.data(), hc_llo.size()));
+        TRY(upload_vec(c, c->d_hc_lhi, hc_lhi.data(), hc_lhi.size()));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     {
