@@ -205,12 +205,19 @@ __global__ void __launch_bounds__(512) k_hist(int n_chunks, const int *chunk_par
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int wg_exclusive_scan(int v, int *lds, int *total);
 
+// R > 0: radius known at compile time (the tap loop is fully unrolled: no window moves, no loop control, weights
+// in scalar registers); R == 0: any radius <= kMaxRadius.
+template <int R>
 __global__ void __launch_bounds__(256) k_smooth(int n_tiles, const int *tile_iv, const int *tile_y0,
-                                                const i64 *pos_off, const int *y_raw, const double *w_g, int radius,
+                                                const i64 *pos_off, const int *y_raw, const double *__restrict__ w_g, int radius_rt,
                                                 double *y_out, unsigned char *flag_pos, unsigned char *flag_zero, int *cum, int *tile_tot) {
     __shared__ int xs[kSmoothTile + 2 * kMaxRadius];
     __shared__ int scan_lds[16];
     __shared__ double ws[kMaxRadius + 1];
+    // results go through LDS so that consecutive lanes store consecutive positions (a thread computes 4 in a row)
+    __shared__ double ys[kSmoothTile];
+    __shared__ int cs[kSmoothTile];
+    const int radius = R > 0 ? R : radius_rt;
     for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         int k = tile_iv[t];
         i64 y0 = tile_y0[t];
@@ -231,7 +238,7 @@ __global__ void __launch_bounds__(256) k_smooth(int n_tiles, const int *tile_iv,
             for (int e = 0; e < 4; ++e) { run += (y0 + o4 + e < len) ? xs[radius + o4 + e] : 0; v4[e] = run; }
             int tot;
             int ex = wg_exclusive_scan(run, scan_lds, &tot);
-            for (int e = 0; e < 4; ++e) if (y0 + o4 + e < len) cum[base + y0 + o4 + e] = ex + v4[e];
+            for (int e = 0; e < 4; ++e) cs[o4 + e] = ex + v4[e];
             if (threadIdx.x == 0) tile_tot[t] = tot;
         }
         {   // every thread computes 4 consecutive outputs; the two 4-wide input windows of tap j slide by one
@@ -244,24 +251,31 @@ __global__ void __launch_bounds__(256) k_smooth(int n_tiles, const int *tile_iv,
                 double a2 = __dmul_rn((double)xs[c + 2], w0), a3 = __dmul_rn((double)xs[c + 3], w0);
                 int l0 = xs[c - radius], l1 = xs[c - radius + 1], l2 = xs[c - radius + 2], l3 = xs[c - radius + 3];
                 int r0 = xs[c + radius], r1 = xs[c + radius + 1], r2 = xs[c + radius + 2], r3 = xs[c + radius + 3];
-                for (int j = radius; j >= 1; --j) {
-                    const double w = ws[j];
-                    a0 = __dadd_rn(a0, __dmul_rn((double)(l0 + r0), w));
-                    a1 = __dadd_rn(a1, __dmul_rn((double)(l1 + r1), w));
-                    a2 = __dadd_rn(a2, __dmul_rn((double)(l2 + r2), w));
-                    a3 = __dadd_rn(a3, __dmul_rn((double)(l3 + r3), w));
-                    l0 = l1; l1 = l2; l2 = l3; l3 = xs[c - j + 4];          // left window moves right
-                    r3 = r2; r2 = r1; r1 = r0; r0 = xs[c + j - 1];          // right window moves left
-                }
-                const double av[4] = {a0, a1, a2, a3};
+#define FSEG_TAP(W)                                                                                        \
+                    a0 = __dadd_rn(a0, __dmul_rn((double)(l0 + r0), (W)));                                         \
+                    a1 = __dadd_rn(a1, __dmul_rn((double)(l1 + r1), (W)));                                         \
+                    a2 = __dadd_rn(a2, __dmul_rn((double)(l2 + r2), (W)));                                         \
+                    a3 = __dadd_rn(a3, __dmul_rn((double)(l3 + r3), (W)));                                         \
+                    l0 = l1; l1 = l2; l2 = l3; l3 = xs[c - j + 4];          /* left window moves right */          \
+                    r3 = r2; r2 = r1; r1 = r0; r0 = xs[c + j - 1];          /* right window moves left */
+                if (R > 0) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (y0 + o4 + e < len) {
-                        y_out[base + y0 + o4 + e] = av[e];
-                        flag_pos[base + y0 + o4 + e] = av[e] > 0.0 ? 1 : 0;
-                        flag_zero[base + y0 + o4 + e] = 0;          // candidate flags start cleared (k_peaks sets them)
-                    }
+                    for (int j = R; j >= 1; --j) { FSEG_TAP(w_g[j]) }
+                } else {
+                    for (int j = radius; j >= 1; --j) { FSEG_TAP(ws[j]) }
                 }
+#undef FSEG_TAP
+                ys[o4] = a0; ys[o4 + 1] = a1; ys[o4 + 2] = a2; ys[o4 + 3] = a3;
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < kSmoothTile; i += blockDim.x) {
+            if (y0 + i < len) {
+                const double a = ys[i];
+                y_out[base + y0 + i] = a;
+                flag_pos[base + y0 + i] = a > 0.0 ? 1 : 0;
+                flag_zero[base + y0 + i] = 0;                       // candidate flags start cleared (k_peaks sets them)
+                cum[base + y0 + i] = cs[i];
             }
         }
     }
@@ -2085,10 +2099,16 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
                        scan_state, scan_single ? scan_nb * 3 : 0);
     mark(1);
     // S2
-    hipLaunchKernelGGL(k_smooth, dim3(tile_grid), dim3(256), 0, s, c->n_tiles, c->d_tile_iv.as<int>(),
-                       c->d_tile_y0.as<int>(), c->d_pos_off.as<i64>(), c->d_y_raw.as<int>(), c->d_w_main.as<double>(),
-                       c->P.radius_main, c->d_y.as<double>(), c->d_flag.as<unsigned char>(), c->d_cflag.as<unsigned char>(),
-                       c->d_cum.as<int>(), c->d_tile_tot.as<int>());
+#define FSEG_LAUNCH_SMOOTH(RV)                                                                                         \
+    hipLaunchKernelGGL(k_smooth<RV>, dim3(tile_grid), dim3(256), 0, s, c->n_tiles, c->d_tile_iv.as<int>(),             \
+                       c->d_tile_y0.as<int>(), c->d_pos_off.as<i64>(), c->d_y_raw.as<int>(), c->d_w_main.as<double>(), \
+                       c->P.radius_main, c->d_y.as<double>(), c->d_flag.as<unsigned char>(),                           \
+                       c->d_cflag.as<unsigned char>(), c->d_cum.as<int>(), c->d_tile_tot.as<int>())
+    // sigma = 5 (default) and sigma = 3 (config 5) have their own unrolled instances; any other radius runs the loop
+    if (c->P.radius_main == 20) { FSEG_LAUNCH_SMOOTH(20); }
+    else if (c->P.radius_main == 12) { FSEG_LAUNCH_SMOOTH(12); }
+    else { FSEG_LAUNCH_SMOOTH(0); }
+#undef FSEG_LAUNCH_SMOOTH
     mark(2);
     // S3a threshold
     scan_counts(c->d_flag.as<unsigned char>(), &st->n_vals, nullptr);
