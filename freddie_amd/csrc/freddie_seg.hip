@@ -1823,7 +1823,11 @@ __global__ void __launch_bounds__(256) k_label_fill(int n_part, const i64 *label
 // (segment boundaries and integer thresholds) is staged in LDS when it fits; kLabelSplit threads share a rep: each
 // merges the rep's exon list against a quarter of the columns the exons can reach (the walk is a chain of dependent
 // loads, so shorter chains and more of them is what makes it faster).
-constexpr int kLabelCols = 4096;
+constexpr int kLabelCols = 1024;
+#ifndef FSEG_LABEL_STAGE
+#define FSEG_LABEL_STAGE 1024
+#endif
+constexpr int kLabelStage = FSEG_LABEL_STAGE;
 constexpr int kLabelSplit = 4;
 __global__ void __launch_bounds__(256) k_label_reads(int n_blocks, const int *rb_part, const int *rb_r0,
                                                      const i64 *label_off, i64 label_cap, int n_part,
@@ -1845,7 +1849,9 @@ __global__ void __launch_bounds__(256) k_label_reads(int n_blocks, const int *rb
         const int *fp = final_pos + f0;                      // ascending over the whole partition
         const int2 *th = col_thr + f0;
         __syncthreads();
-        if (S <= kLabelCols) {
+        // short column tables are staged in LDS; a long table stays in global memory (a read only visits the few
+        // columns around its exons, and staging the whole table per workgroup would cost more than it saves)
+        if (S <= kLabelStage) {
             for (int x = threadIdx.x; x <= S; x += blockDim.x) fp_s[x] = fp[x];
             for (int x = threadIdx.x; x < S; x += blockDim.x) th_s[x] = th[x];
             fp = fp_s; th = th_s;
