@@ -14,6 +14,7 @@
 //
 // No CPU fallback exists in this library: without a GPU fseg_create() fails.
 #include <hip/hip_runtime.h>
+#include <chrono>
 
 #include <algorithm>
 #include <cmath>
@@ -2275,9 +2276,22 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
 }
 
 // wait for the run; grow arenas and re-run if a capacity was exceeded
+// wait for the stream: poll for a while (a run is well under a millisecond on a resident batch and the blocking
+// wait's wake-up costs tens of microseconds), then block
+hipError_t wait_stream(fseg_ctx *c) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        hipError_t e = hipStreamQuery(c->stream);
+        if (e != hipErrorNotReady) { (void)hipGetLastError(); return e; }     // NotReady must not linger as the thread's last error
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+    }
+    (void)hipGetLastError();
+    return hipStreamSynchronize(c->stream);
+}
+
 int finish_run(fseg_ctx *c) {
     for (int attempt = 0; attempt < 4; ++attempt) {
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, wait_stream(c));
         const Status &s = *c->h_status;
         unsigned ovf = s.err & (kErrOverflowPairs | kErrOverflowTri | kErrOverflowWork | kErrOverflowLabels |
                                 kErrOverflowProblems | kErrOverflowChunks | kErrOverflowCov);
