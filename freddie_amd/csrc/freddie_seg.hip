@@ -1805,20 +1805,15 @@ __global__ void k_label_cols(i64 K, const i64 *final_off, const int *final_y, co
         if (lo < 0) atomicOr(&part_has2[iv_part[k]], 1);
     }
 }
-// The label arena is pre-filled with '0' (the label of a read without coverage); only partitions in which a
-// zero-coverage read is ambiguous for some segment (lo < 0, i.e. threshold_rate == 1) need their default rows.
-__global__ void __launch_bounds__(256) k_label_fill(int n_part, const i64 *label_off, i64 label_cap,
-                                                    const i64 *part_iv_off, const i64 *final_off,
-                                                    const unsigned char *col_zero, const int *part_has2,
-                                                    unsigned char *labels) {
-    if (label_off[n_part] > label_cap) return;
-    for (int p = blockIdx.x; p < n_part; p += gridDim.x) {
-        if (!part_has2[p]) continue;
-        i64 f0 = final_off[part_iv_off[p]];
-        i64 S = final_off[part_iv_off[p + 1]] - f0 - 1;
-        i64 x0 = label_off[p], x1 = label_off[p + 1];
-        for (i64 x = x0 + threadIdx.x; x < x1; x += blockDim.x) labels[x] = col_zero[f0 + (x - x0) % S];
-    }
+// The label arena is pre-filled with '0' (the label of a read without coverage) by one streaming kernel; in
+// partitions in which a zero-coverage read is ambiguous for some segment (lo < 0, i.e. threshold_rate == 1) every rep
+// first rewrites its row with the columns' defaults (k_label_reads).
+__global__ void __launch_bounds__(256) k_label_zero(const i64 *label_off, int n_part, i64 label_cap, uint4 *labels16) {
+    const i64 total = label_off[n_part];
+    if (total > label_cap) return;
+    const i64 n16 = (total + 15) / 16;                      // the arena is allocated in multiples of 16 bytes
+    const uint4 z = make_uint4(0x30303030u, 0x30303030u, 0x30303030u, 0x30303030u);
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (i64)gridDim.x * blockDim.x) labels16[i] = z;
 }
 // One workgroup per 64 read reps of one partition (a quarter of a 256-rep block).  The partition's column table
 // (segment boundaries and integer thresholds) is staged in LDS when it fits; kLabelSplit threads share a rep: each
@@ -1835,6 +1830,7 @@ __global__ void __launch_bounds__(256) k_label_reads(int n_blocks, const int *rb
                                                      const i64 *part_iv_off, const i64 *part_rep_off,
                                                      const i64 *final_off, const int *final_pos, const int2 *col_thr,
                                                      const i64 *rep_exon_off, const int *ex_ts, const int *ex_te,
+                                                     const unsigned char *col_zero, const int *part_has2,
                                                      unsigned char *labels) {
     __shared__ int fp_s[kLabelCols + 1];
     __shared__ int2 th_s[kLabelCols];
@@ -1860,6 +1856,15 @@ __global__ void __launch_bounds__(256) k_label_reads(int n_blocks, const int *rb
         __syncthreads();
         i64 r = (i64)rb_r0[blk] + sub * (256 / kLabelSplit) + (threadIdx.x / kLabelSplit);
         const int q = threadIdx.x % kLabelSplit;
+        if (part_has2[p]) {                                  // uniform over the workgroup: the rows' defaults are not all '0'
+            if (r < part_rep_off[p + 1]) {
+                unsigned char *row0 = labels + label_off[p] + (r - part_rep_off[p]) * S;
+                const unsigned char *cz = col_zero + f0;
+                for (i64 x = S * q / kLabelSplit; x < S * (q + 1) / kLabelSplit; ++x) row0[x] = cz[x];
+            }
+            __threadfence_block();
+            __syncthreads();                                 // the label stores below may hit bytes another thread just wrote
+        }
         if (r >= part_rep_off[p + 1]) continue;
         unsigned char *row = labels + label_off[p] + (r - part_rep_off[p]) * S;
         i64 e = rep_exon_off[r], e1 = rep_exon_off[r + 1];
@@ -2056,7 +2061,7 @@ int alloc_arenas(fseg_ctx *c) {
     TRY(ensure(c, c->d_pair_thr, (size_t)c->pair_cap * 8));
     TRY(ensure(c, c->d_amb, (size_t)c->pair_cap * 4));
     TRY(ensure(c, c->d_out, (size_t)c->tri_cap * 4));
-    TRY(ensure(c, c->d_labels, (size_t)c->label_cap));
+    TRY(ensure(c, c->d_labels, (size_t)c->label_cap + 16));
     TRY(ensure(c, c->d_csum, (size_t)c->chunk_cap * 8));
     return FSEG_OK;
 }
@@ -2258,15 +2263,14 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
                        c->P.threshold_rate, c->d_col_thr.as<int2>(), c->d_col_zero.as<unsigned char>(),
                        c->d_part_has2.as<int>());
     if (c->label_cap > 0) {
-        HIP_TRY(c, hipMemsetAsync(c->d_labels.p, '0', (size_t)c->label_cap, s));
-        hipLaunchKernelGGL(k_label_fill, dim3(grid_for(n_part, 1, 2048)), dim3(256), 0, s, n_part, c->d_label_off.as<i64>(),
-                           c->label_cap, c->d_part_iv_off.as<i64>(), c->d_final_off.as<i64>(),
-                           c->d_col_zero.as<unsigned char>(), c->d_part_has2.as<int>(), c->d_labels.as<unsigned char>());
+        hipLaunchKernelGGL(k_label_zero, dim3(grid_for(c->label_cap / 16 / 8 + 1, 256, 4096)), dim3(256), 0, s,
+                           c->d_label_off.as<i64>(), n_part, c->label_cap, c->d_labels.as<uint4>());
         hipLaunchKernelGGL(k_label_reads, dim3(grid_for((i64)c->n_rep_blocks * kLabelSplit, 1, 65536)), dim3(256), 0, s, c->n_rep_blocks,
                            c->d_rb_part.as<int>(), c->d_rb_r0.as<int>(), c->d_label_off.as<i64>(), c->label_cap, n_part,
                            c->d_part_iv_off.as<i64>(), c->d_part_rep_off.as<i64>(), c->d_final_off.as<i64>(),
                            c->d_final_pos.as<int>(), c->d_col_thr.as<int2>(), c->d_rep_exon_off.as<i64>(),
-                           c->d_ex_ts.as<int>(), c->d_ex_te.as<int>(), c->d_labels.as<unsigned char>());
+                           c->d_ex_ts.as<int>(), c->d_ex_te.as<int>(), c->d_col_zero.as<unsigned char>(),
+                           c->d_part_has2.as<int>(), c->d_labels.as<unsigned char>());
     }
     mark(11);
     HIP_TRY(c, hipMemcpyAsync(c->h_status, st, sizeof(Status), hipMemcpyDeviceToHost, s));

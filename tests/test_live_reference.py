@@ -32,3 +32,23 @@ def test_oracle_vs_live_reference(tmp_path, seed):
     assert np.array_equal(np.array(tint["final_positions"], np.int32), o["final_pos"])
     for ri, (_, ridxs) in enumerate(tint["read_reps"]):
         assert list(o["labels"][ri]) == tint["reads"][ridxs[0]]["data"]
+
+
+def test_oracle_vs_live_reference_threshold_rate_one(tmp_path):
+    """threshold_rate == 1 (the CLI's upper bound): long segments get h == 1, low == 0, so a read without coverage
+    is ambiguous ('2') there -- the lo < 0 paths of the kernels."""
+    seed = 7
+    gen = dict(n_reads=300, n_exons=60, rp=0.1)
+    run = dict(sigma=5.0, threshold_rate=1.0, min_read_support_outside=3, max_problem_size=50)
+    synth.generate(seed, write_dir=str(tmp_path / "in"), **gen)
+    tint, rec = refrun.run_recorded(str(tmp_path / "in"), str(tmp_path / "out"), "chrS", seed, **run)
+    g = synth.generate(seed, with_seq=False, **gen)
+    part = pack.pack_partition(g.iv_start, g.iv_end, g.read_exon_off, g.ex_ts, g.ex_te)
+    o = util.run_oracle(part, dict(run, ignore_ends=True))
+    assert o["error"] == 0, o["errmsg"]
+    assert np.array_equal(np.array(tint["final_positions"], np.int32), o["final_pos"])
+    n2 = 0
+    for ri, (_, ridxs) in enumerate(tint["read_reps"]):
+        assert list(o["labels"][ri]) == tint["reads"][ridxs[0]]["data"]
+        n2 += list(o["labels"][ri]).count(2)
+    assert n2 > 0
