@@ -840,8 +840,13 @@ __global__ void k_prob_range(const Status *st, const int *cand_pn, const int *ca
 
 // Problem list by a prefix sum over the candidates: problem slot, pair / triple / coverage arena offsets and
 // work items come out in candidate order, so the arena layout is deterministic.
-constexpr int kProbCols = 10;     // slot, pairs, triples, work items, coverage elements, work items of class 0/1/2,
-                                  // DP problems of the small / big class
+// Scanned columns.  Counters that stay below 2^32 over a whole batch share a 64-bit column (low | high << 32):
+//   0: problem slot | DP problems of the small class     1: pairs     2: triples     3: coverage elements
+//   4: work items of class 0 | class 1                   5: work items of class 2 | DP problems of the big class
+// (work items overall = the three class counts)
+constexpr int kProbCols = 6;
+__device__ __forceinline__ i64 col_lo(i64 x) { return x & 0xffffffffLL; }
+__device__ __forceinline__ i64 col_hi(i64 x) { return (i64)((u64)x >> 32); }
 constexpr int kDpSmall = 32;
 constexpr int kClsSmall = 16, kClsMid = 32;
 struct ProbSizes { i64 v[kProbCols]; };
@@ -851,10 +856,12 @@ __device__ __forceinline__ ProbSizes prob_sizes(int n, int n_lanes) {
     for (int q = 0; q < kProbCols; ++q) s.v[q] = 0;
     if (n <= 0) return s;
     i64 chunks = (n_lanes + kLaneChunk - 1) / kLaneChunk;
-    s.v[0] = 1; s.v[1] = (i64)n * (n - 1) / 2; s.v[2] = (i64)n * (n - 1) * (n - 2) / 6; s.v[3] = chunks;
-    s.v[4] = chunks * kLaneChunk * n;
-    s.v[5 + size_class(n)] = chunks;
-    s.v[n <= kDpSmall ? 8 : 9] = 1;
+    const int cls = size_class(n);
+    s.v[0] = 1 + (n <= kDpSmall ? (1LL << 32) : 0);
+    s.v[1] = (i64)n * (n - 1) / 2; s.v[2] = (i64)n * (n - 1) * (n - 2) / 6;
+    s.v[3] = chunks * kLaneChunk * n;
+    s.v[4] = cls == 0 ? chunks : (cls == 1 ? chunks << 32 : 0);
+    s.v[5] = (cls == 2 ? chunks : 0) + (n <= kDpSmall ? 0 : (1LL << 32));
     return s;
 }
 __device__ __forceinline__ i64 wg_exclusive_scan64(i64 v, i64 *lds /* >= 16 */, i64 *total) {
@@ -913,10 +920,10 @@ __device__ __forceinline__ ProbSizes prob_block_sizes(const int *cand_pn, const 
     return acc;
 }
 __device__ __forceinline__ void prob_store_totals(Status *st, const ProbSizes &t) {
-    st->n_prob = (u64)t.v[0]; st->pair_used = (u64)t.v[1]; st->tri_used = (u64)t.v[2];
-    st->n_work = (u64)t.v[3]; st->cov_used = (u64)t.v[4];
-    st->cls_work[0] = (u64)t.v[5]; st->cls_work[1] = (u64)t.v[6]; st->cls_work[2] = (u64)t.v[7];
-    st->dp_cls[0] = (u64)t.v[8]; st->dp_cls[1] = (u64)t.v[9];
+    st->n_prob = (u64)col_lo(t.v[0]); st->pair_used = (u64)t.v[1]; st->tri_used = (u64)t.v[2];
+    st->n_work = (u64)(col_lo(t.v[4]) + col_hi(t.v[4]) + col_lo(t.v[5])); st->cov_used = (u64)t.v[3];
+    st->cls_work[0] = (u64)col_lo(t.v[4]); st->cls_work[1] = (u64)col_hi(t.v[4]); st->cls_work[2] = (u64)col_lo(t.v[5]);
+    st->dp_cls[0] = (u64)col_hi(t.v[0]); st->dp_cls[1] = (u64)col_hi(t.v[5]);
 }
 __global__ void __launch_bounds__(256) k_prob_scan1(const Status *st, const int *cand_pn, const int *cand_ln, i64 *bs) {
     __shared__ i64 lds[4 * kProbCols];
@@ -965,7 +972,7 @@ __global__ void __launch_bounds__(256) k_prob_emit(Status *st, const int *cand_p
         if (threadIdx.x == 0) l_n = 0;
         if (bs) {
             for (int q = 0; q < kProbCols; ++q) before.v[q] = bs[b * kProbCols + q];
-            grand.v[5] = (i64)st->cls_work[0]; grand.v[6] = (i64)st->cls_work[1]; grand.v[8] = (i64)st->dp_cls[0];
+            grand.v[4] = (i64)st->cls_work[0] + ((i64)st->cls_work[1] << 32); grand.v[0] = (i64)st->dp_cls[0] << 32;
         } else {
             for (int q = 0; q < kProbCols; ++q) { before.v[q] = 0; grand.v[q] = 0; }
             for (i64 bb = 0; bb < nb; ++bb) {
@@ -983,33 +990,36 @@ __global__ void __launch_bounds__(256) k_prob_emit(Status *st, const int *cand_p
             if (b == nb - 1 && threadIdx.x == 0) prob_store_totals(st, grand);
         }
         const i64 i0 = b * kProbBlock + (i64)threadIdx.x * 4;
+        const i64 g_cls0 = col_lo(grand.v[4]), g_cls1 = col_hi(grand.v[4]), g_dp0 = col_hi(grand.v[0]);
         for (int e = 0; e < 4; ++e) {
             if (sz[e].v[0]) {
                 i64 c = i0 + e;
-                i64 slot = ex.v[0];
+                i64 slot = col_lo(ex.v[0]);
                 int nn = cand_pn[c];
                 if (slot < prob_cap) {
                     int k = cand_iv[c];
                     pr.iv[slot] = k; pr.start[slot] = (int)(c - cand_off[k]) - (nn - 1); pr.n[slot] = nn;
-                    pr.pair_off[slot] = ex.v[1]; pr.tri_off[slot] = ex.v[2]; pr.cov_off[slot] = ex.v[4];
+                    pr.pair_off[slot] = ex.v[1]; pr.tri_off[slot] = ex.v[2]; pr.cov_off[slot] = ex.v[3];
                     pr.flags[slot] = 0; pr.chain[slot] = 0;
                     pr.lane_lo[slot] = cand_ll[c]; pr.lane_n[slot] = cand_ln[c];
                     {   // DP problem lists: the small problems first, then the big ones
-                        i64 di = nn <= kDpSmall ? ex.v[8] : grand.v[8] + ex.v[9];
+                        i64 di = nn <= kDpSmall ? col_hi(ex.v[0]) : g_dp0 + col_hi(ex.v[5]);
                         if (di < prob_cap) dp_items[di] = (int)slot;
                     }
                     int cls = size_class(nn);
-                    i64 cbase = ex.v[5 + cls] + (cls >= 1 ? grand.v[5] : 0) + (cls >= 2 ? grand.v[6] : 0);
-                    const i64 cnt = sz[e].v[3];
-                    if (ex.v[3] + cnt > work_cap || cbase + cnt > work_cap) atomicOr(&st->err, kErrOverflowWork);
+                    const i64 e_cls0 = col_lo(ex.v[4]), e_cls1 = col_hi(ex.v[4]), e_cls2 = col_lo(ex.v[5]);
+                    const i64 w0 = e_cls0 + e_cls1 + e_cls2;         // work items before this problem
+                    i64 cbase = cls == 0 ? e_cls0 : (cls == 1 ? g_cls0 + e_cls1 : g_cls0 + g_cls1 + e_cls2);
+                    const i64 cnt = col_lo(sz[e].v[4]) + col_hi(sz[e].v[4]) + col_lo(sz[e].v[5]);
+                    if (w0 + cnt > work_cap || cbase + cnt > work_cap) atomicOr(&st->err, kErrOverflowWork);
                     else if (cnt <= kProbDirect) {
                         for (i64 q = 0; q < cnt; ++q) {
-                            work_prob[ex.v[3] + q] = (int)slot; work_chunk[ex.v[3] + q] = (int)q;
-                            cls_items[cbase + q] = (int)(ex.v[3] + q);
+                            work_prob[w0 + q] = (int)slot; work_chunk[w0 + q] = (int)q;
+                            cls_items[cbase + q] = (int)(w0 + q);
                         }
                     } else {
                         int li = atomicAdd(&l_n, 1);
-                        l_slot[li] = (int)slot; l_cnt[li] = (int)cnt; l_w0[li] = ex.v[3]; l_c0[li] = cbase;
+                        l_slot[li] = (int)slot; l_cnt[li] = (int)cnt; l_w0[li] = w0; l_c0[li] = cbase;
                     }
                 } else atomicOr(&st->err, kErrOverflowProblems);
             }
@@ -1017,10 +1027,10 @@ __global__ void __launch_bounds__(256) k_prob_emit(Status *st, const int *cand_p
         }
         __syncthreads();
         const int ln = l_n;
-        for (int li = 0; li < ln; ++li) {
+        for (int li = threadIdx.x >> 6; li < ln; li += 4) {        // one wave per long list
             const int slot = l_slot[li], cnt = l_cnt[li];
             const i64 w0 = l_w0[li], c0 = l_c0[li];
-            for (int q = threadIdx.x; q < cnt; q += blockDim.x) {
+            for (int q = lane_id(); q < cnt; q += 64) {
                 work_prob[w0 + q] = slot; work_chunk[w0 + q] = q;
                 cls_items[c0 + q] = (int)(w0 + q);
             }
