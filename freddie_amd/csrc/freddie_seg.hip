@@ -559,13 +559,14 @@ __global__ void __launch_bounds__(256) k_vplan(int n_part, const i64 *part_iv_of
 // three xor-shuffles (IEEE addition is commutative, so both partners get identical bits), the tail (len%8)
 // is added left to right, and the leaves are combined in recursion order.
 __global__ void __launch_bounds__(512) k_vsum_chunks(int n_part, const i64 *voff, const i64 *chunk_off, const double *v,
-                                                     const double *mean, int pass, double *csum, i64 chunk_cap) {
+                                                     const double *csum0, int pass, double *csum, i64 chunk_cap) {
     // leaves of the pairwise recursion, left to right; a partial chunk's tree is kept in heap order (root 1,
     // children 2i / 2i+1; depth <= 7): node_kind 1 = leaf, 2 = inner node
     __shared__ int leaf_off[128], leaf_len[128], leaf_heap[128];
     __shared__ double node_val[256];
     __shared__ unsigned char node_kind[256];
     __shared__ int n_leaf_s, wave0_leaves;
+    __shared__ double mu_s;
     i64 n_chunks = chunk_off[n_part];
     if (n_chunks > chunk_cap) n_chunks = chunk_cap;
     for (i64 c = blockIdx.x; c < n_chunks; c += gridDim.x) {
@@ -574,8 +575,21 @@ __global__ void __launch_bounds__(512) k_vsum_chunks(int n_part, const i64 *voff
         i64 o0 = (c - chunk_off[p]) * 8192;
         int m = (int)((nv - o0) < 8192 ? (nv - o0) : 8192);
         const double *a = v + voff[p] + o0;
-        double mu = pass ? mean[p] : 0.0;
         __syncthreads();
+        double mu = 0.0;
+        if (pass) {
+            // mean of the partition from the first pass' chunk sums, added left to right (numpy adds its 8192-element
+            // blocks in order); every chunk of the partition repeats these few additions instead of a separate launch
+            if (threadIdx.x == 0) {
+                i64 c0 = chunk_off[p], c1 = chunk_off[p + 1];
+                if (c1 > chunk_cap) c1 = chunk_cap;
+                double sacc = 0.0;
+                for (i64 cc = c0; cc < c1; ++cc) sacc = (cc == c0) ? csum0[cc] : __dadd_rn(sacc, csum0[cc]);
+                mu_s = sacc / (double)nv;
+            }
+            __syncthreads();
+            mu = mu_s;
+        }
         if (m == 8192) {
             // perfect tree: 64 leaves of 128
             for (int t = threadIdx.x; t < 64; t += blockDim.x) { leaf_off[t] = t * 128; leaf_len[t] = 128; leaf_heap[t] = 64 + t; }
@@ -657,16 +671,20 @@ __global__ void __launch_bounds__(512) k_vsum_chunks(int n_part, const i64 *voff
         }
     }
 }
-__global__ void k_vsum_part(int n_part, const i64 *voff, const i64 *chunk_off, const double *csum, int pass,
+__global__ void k_vsum_part(int n_part, const i64 *voff, const i64 *chunk_off, const double *csum0, const double *csum1,
                             double vf, double *mean, double *thr, i64 chunk_cap) {
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n_part; p += gridDim.x * blockDim.x) {
         i64 c0 = chunk_off[p], c1 = chunk_off[p + 1];
         if (c1 > chunk_cap) c1 = chunk_cap;
         double n = (double)(voff[p + 1] - voff[p]);
-        double s = 0.0;
-        for (i64 c = c0; c < c1; ++c) s = (c == c0) ? csum[c] : __dadd_rn(s, csum[c]);
-        if (pass == 0) mean[p] = s / n;                                // empty -> 0/0 = NaN like numpy
-        else thr[p] = __dadd_rn(mean[p], __dmul_rn(vf, __dsqrt_rn(s / n)));   // :758-759
+        double s0 = 0.0, s1 = 0.0;
+        for (i64 c = c0; c < c1; ++c) {
+            s0 = (c == c0) ? csum0[c] : __dadd_rn(s0, csum0[c]);
+            s1 = (c == c0) ? csum1[c] : __dadd_rn(s1, csum1[c]);
+        }
+        const double mu = s0 / n;                                       // empty -> 0/0 = NaN like numpy
+        mean[p] = mu;
+        thr[p] = __dadd_rn(mu, __dmul_rn(vf, __dsqrt_rn(s1 / n)));      // :758-759
     }
 }
 
@@ -675,7 +693,10 @@ __global__ void k_vsum_part(int n_part, const i64 *voff, const i64 *chunk_off, c
 // strict local maxima with the plateau-midpoint rule, plus the first and last position.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_peaks(int n_tiles, const int *tile_iv, const int *tile_y0, const i64 *pos_off,
-                                               const double *yv, unsigned char *flag, unsigned char *final_zero) {
+                                               const double *yv, unsigned char *flag, unsigned char *final_zero,
+                                               int *part_has2, int n_part) {
+    // also clears the per-partition 'some default label is not 0' flags that k_label_cols sets much later
+    if (blockIdx.x == 0) for (int p = threadIdx.x; p < n_part; p += blockDim.x) part_has2[p] = 0;
     for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         int k = tile_iv[t];
         i64 y0 = tile_y0[t];
@@ -1769,8 +1790,9 @@ __global__ void __launch_bounds__(64) k_refine(const Status *st, const int *cand
 // a pure streaming store) and then every read rewrites just the columns its exons can reach
 // (k_label_reads).
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_label_plan(int n_part, const i64 *part_iv_off, const i64 *part_rep_off,
-                                                    const i64 *final_off, i64 *label_off, Status *st, i64 label_cap, int *part_has2) {
+// label arena offsets of the partitions (one workgroup of 256 threads; part of k_label_cols)
+__device__ void label_plan(int n_part, const i64 *part_iv_off, const i64 *part_rep_off,
+                           const i64 *final_off, i64 *label_off, Status *st, i64 label_cap) {
     __shared__ i64 carry_s;
     __shared__ i64 tmp[256];
     if (threadIdx.x == 0) carry_s = 0;
@@ -1790,7 +1812,7 @@ __global__ void __launch_bounds__(256) k_label_plan(int n_part, const i64 *part_
             carry_s = c;
         }
         __syncthreads();
-        if (p < n_part) { label_off[p] = tmp[threadIdx.x]; part_has2[p] = 0; }
+        if (p < n_part) label_off[p] = tmp[threadIdx.x];
         __syncthreads();
     }
     if (threadIdx.x == 0) {
@@ -1801,9 +1823,12 @@ __global__ void __launch_bounds__(256) k_label_plan(int n_part, const i64 *part_
 }
 // per final index f (= column): integer thresholds of the segment [final_f, final_f+1) and the label of
 // a read without coverage there; the last index of an interval is the sentinel column (hi = INT_MAX)
-__global__ void k_label_cols(i64 K, const i64 *final_off, const int *final_y, const int *iv_part,
-                             const double *h_table, int h_len, double tau, int2 *col_thr, unsigned char *col_zero,
-                             int *part_has2) {
+__global__ void __launch_bounds__(256) k_label_cols(i64 K, const i64 *final_off, const int *final_y, const int *iv_part,
+                                                    const double *h_table, int h_len, double tau, int2 *col_thr,
+                                                    unsigned char *col_zero, int *part_has2, int n_part,
+                                                    const i64 *part_iv_off, const i64 *part_rep_off, i64 *label_off,
+                                                    Status *st, i64 label_cap) {
+    if (blockIdx.x == 0) label_plan(n_part, part_iv_off, part_rep_off, final_off, label_off, st, label_cap);
     i64 F = final_off[K];
     for (i64 f = (i64)blockIdx.x * blockDim.x + threadIdx.x; f < F; f += (i64)gridDim.x * blockDim.x) {
         i64 k = last_le(final_off, K + 1, f);
@@ -2072,7 +2097,7 @@ int alloc_arenas(fseg_ctx *c) {
     TRY(ensure(c, c->d_amb, (size_t)c->pair_cap * 4));
     TRY(ensure(c, c->d_out, (size_t)c->tri_cap * 4));
     TRY(ensure(c, c->d_labels, (size_t)c->label_cap + 16));
-    TRY(ensure(c, c->d_csum, (size_t)c->chunk_cap * 8));
+    TRY(ensure(c, c->d_csum, (size_t)c->chunk_cap * 16));     // chunk sums of both passes
     return FSEG_OK;
 }
 
@@ -2143,19 +2168,18 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
     hipLaunchKernelGGL(k_vplan, dim3(1), dim3(256), 0, s, n_part, c->d_part_iv_off.as<i64>(), c->d_pos_off.as<i64>(), NPOS,
                        c->d_voff.as<i64>(), c->d_chunk_off.as<i64>(), st, c->chunk_cap);
     int chunk_grid = grid_for(c->chunk_cap, 1, 4096);
-    for (int pass = 0; pass < 2; ++pass) {
+    double *csum0 = c->d_csum.as<double>(), *csum1 = csum0 + c->chunk_cap;
+    for (int pass = 0; pass < 2; ++pass)
         hipLaunchKernelGGL(k_vsum_chunks, dim3(chunk_grid), dim3(512), 0, s, n_part, c->d_voff.as<i64>(),
-                           c->d_chunk_off.as<i64>(), c->d_v.as<double>(), c->d_mean.as<double>(), pass,
-                           c->d_csum.as<double>(), c->chunk_cap);
-        hipLaunchKernelGGL(k_vsum_part, dim3(grid_for(n_part, 64, 1024)), dim3(64), 0, s, n_part, c->d_voff.as<i64>(),
-                           c->d_chunk_off.as<i64>(), c->d_csum.as<double>(), pass, c->P.variance_factor,
-                           c->d_mean.as<double>(), c->d_thr.as<double>(), c->chunk_cap);
-    }
+                           c->d_chunk_off.as<i64>(), c->d_v.as<double>(), csum0, pass, pass ? csum1 : csum0, c->chunk_cap);
+    hipLaunchKernelGGL(k_vsum_part, dim3(grid_for(n_part, 64, 1024)), dim3(64), 0, s, n_part, c->d_voff.as<i64>(),
+                       c->d_chunk_off.as<i64>(), csum0, csum1, c->P.variance_factor, c->d_mean.as<double>(),
+                       c->d_thr.as<double>(), c->chunk_cap);
     mark(3);
     // S3b candidates
     hipLaunchKernelGGL(k_peaks, dim3(tile_grid), dim3(256), 0, s, c->n_tiles, c->d_tile_iv.as<int>(), c->d_tile_y0.as<int>(),
                        c->d_pos_off.as<i64>(), c->d_y.as<double>(), c->d_cflag.as<unsigned char>(),
-                       c->d_final_flag.as<unsigned char>());
+                       c->d_final_flag.as<unsigned char>(), c->d_part_has2.as<int>(), n_part);
     scan_counts(c->d_cflag.as<unsigned char>(), &st->n_cand, c->d_cand_off.as<i64>() + K);
     hipLaunchKernelGGL(k_scan_emit<kEmitPositions>, dim3(scan_grid), dim3(256), 0, s, c->d_cflag.as<unsigned char>(), NPOS,
                        bsum, scan_state + scan_nb, &st->n_cand, c->d_cand_off.as<i64>() + K, (const double *)nullptr, (double *)nullptr, K, c->d_pos_off.as<i64>(),
@@ -2266,12 +2290,11 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
                        c->d_final_off.as<i64>());
     mark(10);
     // S7
-    hipLaunchKernelGGL(k_label_plan, dim3(1), dim3(256), 0, s, n_part, c->d_part_iv_off.as<i64>(),
-                       c->d_part_rep_off.as<i64>(), c->d_final_off.as<i64>(), c->d_label_off.as<i64>(), st, c->label_cap, c->d_part_has2.as<int>());
     hipLaunchKernelGGL(k_label_cols, dim3(grid_for(NPOS / 8 + 1, 256, 2048)), dim3(256), 0, s, K, c->d_final_off.as<i64>(),
                        c->d_final_y.as<int>(), c->d_iv_part.as<int>(), c->d_h_table.as<double>(), c->P.h_len,
                        c->P.threshold_rate, c->d_col_thr.as<int2>(), c->d_col_zero.as<unsigned char>(),
-                       c->d_part_has2.as<int>());
+                       c->d_part_has2.as<int>(), n_part, c->d_part_iv_off.as<i64>(), c->d_part_rep_off.as<i64>(),
+                       c->d_label_off.as<i64>(), st, c->label_cap);
     if (c->label_cap > 0) {
         hipLaunchKernelGGL(k_label_zero, dim3(grid_for(c->label_cap / 16 / 8 + 1, 256, 4096)), dim3(256), 0, s,
                            c->d_label_off.as<i64>(), n_part, c->label_cap, c->d_labels.as<uint4>());
