@@ -741,6 +741,23 @@ struct ProblemArrays {
     int *lane_lo;   // first lane (position-sorted read) that can overlap the problem's window
     int *lane_n;    // number of lanes examined: [lane_lo, lane_lo + lane_n)
 };
+// Everything the coverage / scoring / DP kernels need to know about a problem, in one 64-byte record: their
+// per-item set-up is a chain of dependent loads, and one record load replaces three levels of it.
+struct __align__(16) ProbDesc {
+    i64 c0;         // global index of the problem's first candidate (cand_off[iv] + start)
+    i64 pair_off, tri_off, cov_off;
+    int n, lane_lo, lane_n;
+    int g0;         // genomic start of the interval (iv_start[iv])
+    int outside;    // lanes of the partition outside [lane_lo, lane_lo + lane_n)
+    int iv, pad0, pad1;
+};
+static_assert(sizeof(ProbDesc) == 64, "ProbDesc is one 64-byte record");
+__device__ __forceinline__ ProbDesc load_desc(const ProbDesc *d) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(d);
+    union { uint4 v[4]; ProbDesc p; } u;
+    u.v[0] = q[0]; u.v[1] = q[1]; u.v[2] = q[2]; u.v[3] = q[3];
+    return u.p;
+}
 
 __device__ __forceinline__ i64 wave_excl_scan(i64 v, i64 *total) {
     int lane = lane_id();
@@ -980,8 +997,9 @@ __global__ void __launch_bounds__(256) k_prob_scan2(Status *st, i64 *bs) {
 constexpr int kProbDirect = 4;     // work items a problem's own thread writes itself; longer lists are written by the workgroup
 __global__ void __launch_bounds__(256) k_prob_emit(Status *st, const int *cand_pn, const int *cand_ll, const int *cand_ln,
                                                    const int *cand_iv, const i64 *cand_off, const i64 *bs,
-                                                   ProblemArrays pr, i64 prob_cap, int *work_prob, int *work_chunk,
-                                                   int *cls_items, i64 work_cap, int *dp_items) {
+                                                   ProblemArrays pr, i64 prob_cap, int2 *work_pc, int4 *cls_items,
+                                                   i64 work_cap, int *dp_items, ProbDesc *desc, const int *iv_start,
+                                                   const int *iv_part, const i64 *part_lane_off) {
     __shared__ i64 lds[4 * kProbCols];
     __shared__ int l_slot[kProbBlock], l_cnt[kProbBlock];
     __shared__ i64 l_w0[kProbBlock], l_c0[kProbBlock];
@@ -1023,6 +1041,15 @@ __global__ void __launch_bounds__(256) k_prob_emit(Status *st, const int *cand_p
                     pr.pair_off[slot] = ex.v[1]; pr.tri_off[slot] = ex.v[2]; pr.cov_off[slot] = ex.v[3];
                     pr.flags[slot] = 0; pr.chain[slot] = 0;
                     pr.lane_lo[slot] = cand_ll[c]; pr.lane_n[slot] = cand_ln[c];
+                    {
+                        ProbDesc d;
+                        d.c0 = c - (nn - 1); d.pair_off = ex.v[1]; d.tri_off = ex.v[2]; d.cov_off = ex.v[3];
+                        d.n = nn; d.lane_lo = cand_ll[c]; d.lane_n = cand_ln[c]; d.g0 = iv_start[k];
+                        const int part = iv_part[k];
+                        d.outside = (int)(part_lane_off[part + 1] - part_lane_off[part]) - d.lane_n;
+                        d.iv = k; d.pad0 = 0; d.pad1 = 0;
+                        desc[slot] = d;
+                    }
                     {   // DP problem lists: the small problems first, then the big ones
                         i64 di = nn <= kDpSmall ? col_hi(ex.v[0]) : g_dp0 + col_hi(ex.v[5]);
                         if (di < prob_cap) dp_items[di] = (int)slot;
@@ -1035,8 +1062,8 @@ __global__ void __launch_bounds__(256) k_prob_emit(Status *st, const int *cand_p
                     if (w0 + cnt > work_cap || cbase + cnt > work_cap) atomicOr(&st->err, kErrOverflowWork);
                     else if (cnt <= kProbDirect) {
                         for (i64 q = 0; q < cnt; ++q) {
-                            work_prob[w0 + q] = (int)slot; work_chunk[w0 + q] = (int)q;
-                            cls_items[cbase + q] = (int)(w0 + q);
+                            work_pc[w0 + q] = make_int2((int)slot, (int)q);
+                            cls_items[cbase + q] = make_int4((int)(w0 + q), (int)slot, (int)q, 0);
                         }
                     } else {
                         int li = atomicAdd(&l_n, 1);
@@ -1052,8 +1079,8 @@ __global__ void __launch_bounds__(256) k_prob_emit(Status *st, const int *cand_p
             const int slot = l_slot[li], cnt = l_cnt[li];
             const i64 w0 = l_w0[li], c0 = l_c0[li];
             for (int q = lane_id(); q < cnt; q += 64) {
-                work_prob[w0 + q] = slot; work_chunk[w0 + q] = q;
-                cls_items[c0 + q] = (int)(w0 + q);
+                work_pc[w0 + q] = make_int2(slot, q);
+                cls_items[c0 + q] = make_int4((int)(w0 + q), slot, q, 0);
             }
         }
         __syncthreads();
@@ -1070,17 +1097,18 @@ __device__ __forceinline__ void pair_decode(int q, int *i, int *j) {
 }
 
 // S5a  integer label thresholds of every candidate pair of every problem (:490-495)
-__global__ void __launch_bounds__(256) k_pair_thresholds(const Status *st, ProblemArrays pr, i64 prob_cap,
+__global__ void __launch_bounds__(256) k_pair_thresholds(const Status *st, ProblemArrays pr, const ProbDesc *desc, i64 prob_cap,
                                                          const i64 *cand_off, const int *cand_y, const double *h_table,
                                                          int h_len, double tau, int2 *pair_thr, i64 pair_cap,
                                                          unsigned *amb_g, unsigned *out_g, i64 tri_cap) {
     i64 n_prob = (i64)st->n_prob < prob_cap ? (i64)st->n_prob : prob_cap;
     for (i64 p = blockIdx.x; p < n_prob; p += gridDim.x) {
-        int n = pr.n[p];
-        i64 poff = pr.pair_off[p];
+        const ProbDesc d = load_desc(desc + p);
+        int n = d.n;
+        i64 poff = d.pair_off;
         int npairs = n * (n - 1) / 2;
         if (poff + npairs > pair_cap) continue;
-        const int *cy = cand_y + cand_off[pr.iv[p]] + pr.start[p];
+        const int *cy = cand_y + d.c0;
         int any_neg = 0;
         for (int q = threadIdx.x; q < npairs; q += blockDim.x) {
             int i, j;
@@ -1092,7 +1120,7 @@ __global__ void __launch_bounds__(256) k_pair_thresholds(const Status *st, Probl
             amb_g[poff + q] = 0;
             if (lo < 0) any_neg = 1;
         }
-        i64 toff = pr.tri_off[p];
+        i64 toff = d.tri_off;
         int ntri = n * (n - 1) * (n - 2) / 6;
         if (toff + ntri <= tri_cap) for (int x = threadIdx.x; x < ntri; x += blockDim.x) out_g[toff + x] = 0;
         if (any_neg) atomicOr(&pr.flags[p], 1);
@@ -1108,8 +1136,8 @@ __global__ void __launch_bounds__(256) k_pair_thresholds(const Status *st, Probl
 // both this kernel's stores and the scoring kernel's loads are coalesced.  Also records, per work
 // item, which 64-read sub-chunks contain a read with any coverage in the window.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kLaneChunk) k_cov(Status *st, ProblemArrays pr, i64 prob_cap, const int *work_prob,
-                                                    const int *work_chunk, i64 work_cap, const i64 *cand_off,
+__global__ void __launch_bounds__(kLaneChunk) k_cov(Status *st, const ProbDesc *desc, i64 prob_cap, const int2 *work_pc,
+                                                    i64 work_cap, const i64 *cand_off,
                                                     const int *cand_y, const int *iv_start, const int *lane_rep,
                                                     const i64 *rep_exon_off, const int *ex_ts, const int *ex_te,
                                                     unsigned *cov_g, i64 cov_cap, unsigned char *work_active) {
@@ -1122,14 +1150,14 @@ __global__ void __launch_bounds__(kLaneChunk) k_cov(Status *st, ProblemArrays pr
         __syncthreads();
         if (threadIdx.x == 0) active_s = 0;
         __syncthreads();
-        int p = work_prob[w];
-        int chunk = work_chunk[w];
-        int n = pr.n[p];
-        i64 coff = pr.cov_off[p] + (i64)chunk * kLaneChunk * n;
+        const int2 pc = work_pc[w];
+        const int chunk = pc.y;
+        const ProbDesc d = load_desc(desc + pc.x);
+        const int n = d.n;
+        i64 coff = d.cov_off + (i64)chunk * kLaneChunk * n;
         if (n > kNMax || coff + (i64)kLaneChunk * n > cov_cap) { if (threadIdx.x == 0) work_active[w] = 0; continue; }
-        int k = pr.iv[p];
-        const int *cy = cand_y + cand_off[k] + pr.start[p];
-        int g0 = iv_start[k];
+        const int *cy = cand_y + d.c0;
+        const int g0 = d.g0;
         for (int j = threadIdx.x; j < n; j += blockDim.x) cp[j] = g0 + cy[j];
         __syncthreads();
         const int cp0 = cp[0];
@@ -1137,8 +1165,8 @@ __global__ void __launch_bounds__(kLaneChunk) k_cov(Status *st, ProblemArrays pr
         int li = chunk * kLaneChunk + t;
         unsigned *dst = cov_g + coff + t;
         unsigned last = 0;
-        if (li < pr.lane_n[p]) {
-            i64 r = lane_rep[pr.lane_lo[p] + li];
+        if (li < d.lane_n) {
+            i64 r = lane_rep[d.lane_lo + li];
             i64 e = rep_exon_off[r], e1 = rep_exon_off[r + 1];
             {   // first exon whose closed interval reaches cand_0 (exons of a read are ordered, :158)
                 i64 lo = e, hi = e1;
@@ -1384,8 +1412,8 @@ inline size_t score_lds_for(int nm, int cov_stride) {
 #endif
 template <int NM>
 __global__ void __launch_bounds__(ScoreCfg<NM>::kThreads) k_score(Status *st, int cls, int nm, ProblemArrays pr, i64 prob_cap,
-                                                                  const int *cls_items, const int *work_prob,
-                                                                  const int *work_chunk, i64 work_cap, const i64 *cand_off,
+                                                                  const int4 *cls_items, const ProbDesc *desc,
+                                                                  i64 work_cap, const i64 *cand_off,
                                                                   const int *cand_y, const unsigned char *work_active,
                                                                   const unsigned *cov_g, i64 cov_cap, const int2 *pair_thr,
                                                                   i64 pair_cap, unsigned *out_g, i64 tri_cap,
@@ -1428,22 +1456,23 @@ __global__ void __launch_bounds__(ScoreCfg<NM>::kThreads) k_score(Status *st, in
         __syncthreads();
         FSEG_TICK(0);
         if (wi >= n_items) break;
-        i64 w = cls_items[cls_base + wi];
-        int p = work_prob[w];
-        int chunk = work_chunk[w];
-        int n = pr.n[p];
-        i64 poff = pr.pair_off[p], toff = pr.tri_off[p];
-        i64 coff = pr.cov_off[p] + (i64)chunk * kLaneChunk * n;
+        const int4 item = cls_items[cls_base + wi];
+        const i64 w = item.x;
+        const int p = item.y, chunk = item.z;
+        const ProbDesc d = load_desc(desc + p);
+        const int n = d.n;
+        i64 poff = d.pair_off, toff = d.tri_off;
+        i64 coff = d.cov_off + (i64)chunk * kLaneChunk * n;
         int npairs = n * (n - 1) / 2, ntri = n * (n - 1) * (n - 2) / 6;
         if (n > nm) { if (threadIdx.x == 0) atomicOr(&st->err, kErrOverflowNm); continue; }
         if (poff + npairs > pair_cap || toff + ntri > tri_cap || coff + (i64)kLaneChunk * n > cov_cap) continue;
         bool zero_ambiguous = (pr.flags[p] & 1) != 0;
         unsigned active = zero_ambiguous ? 0xfu : work_active[w];
-        int lanes_here = pr.lane_n[p] - chunk * kLaneChunk;
+        int lanes_here = d.lane_n - chunk * kLaneChunk;
         if (lanes_here > kLaneChunk) lanes_here = kLaneChunk;
         if (lanes_here < kLaneChunk) active &= (1u << ((lanes_here + kSub - 1) / kSub)) - 1u;
         if (active == 0) continue;                       // no read of this chunk touches the window
-        const int *cy = cand_y + cand_off[pr.iv[p]] + pr.start[p];
+        const int *cy = cand_y + d.c0;
         for (int j = threadIdx.x; j < n; j += T) cy_s[j] = cy[j];
         {
             uint4 *z = reinterpret_cast<uint4 *>(out16);              // 8 counters per store
@@ -1572,7 +1601,7 @@ __global__ void __launch_bounds__(ScoreCfg<NM>::kThreads) k_score(Status *st, in
 }
 
 template <int NM, int T, typename OutT>
-__global__ void __launch_bounds__(T) k_dp(Status *st, int dp_class, int nm, const int *dp_items, ProblemArrays pr, i64 prob_cap,
+__global__ void __launch_bounds__(T) k_dp(Status *st, int dp_class, int nm, const int *dp_items, ProblemArrays pr, const ProbDesc *desc, i64 prob_cap,
                                             const i64 *cand_off, const int *cand_y, const int *iv_part,
                                             const i64 *part_lane_off, const unsigned *out_g, i64 tri_cap,
                                             const unsigned *amb_g, const int2 *pair_thr, i64 pair_cap, int support,
@@ -1602,17 +1631,16 @@ __global__ void __launch_bounds__(T) k_dp(Status *st, int dp_class, int nm, cons
         __syncthreads();
         FSEG_DTICK(8);
         const i64 p = dp_class < 0 ? t : (i64)dp_items[list_base + t];
-        int n = pr.n[p];
+        const ProbDesc d = load_desc(desc + p);
+        int n = d.n;
         if (n > NM) continue;
         if (n > nm) { if (threadIdx.x == 0) atomicOr(&st->err, kErrOverflowNm); continue; }
-        if (sizeof(OutT) == 2 && pr.lane_n[p] >= 65536) { if (threadIdx.x == 0) atomicOr(&st->err, kErrNeedWideDp); continue; }
-        i64 poff = pr.pair_off[p], toff = pr.tri_off[p];
+        if (sizeof(OutT) == 2 && d.lane_n >= 65536) { if (threadIdx.x == 0) atomicOr(&st->err, kErrNeedWideDp); continue; }
+        i64 poff = d.pair_off, toff = d.tri_off;
         int npairs = n * (n - 1) / 2, ntri = n * (n - 1) * (n - 2) / 6;
         if (poff + npairs > pair_cap || toff + ntri > tri_cap) continue;
-        int k_iv = pr.iv[p];
-        i64 c0 = cand_off[k_iv] + pr.start[p];
-        int part = iv_part[k_iv];
-        const i64 outside = (part_lane_off[part + 1] - part_lane_off[part]) - pr.lane_n[p];
+        const i64 c0 = d.c0;
+        const i64 outside = d.outside;
         const bool zamb = (pr.flags[p] & 1) != 0;
         for (int j = threadIdx.x; j < n; j += blockDim.x) cy_s[j] = cand_y[c0 + j];
         for (int x0 = threadIdx.x; x0 < ntri; x0 += T * 8) {       // 8 loads in flight per thread
@@ -1998,7 +2026,7 @@ struct fseg_ctx {
     // problems / arenas
     DevBuf d_prob_iv, d_prob_start, d_prob_n, d_prob_pair_off, d_prob_tri_off, d_prob_flags, d_prob_chain,
         d_prob_cov_off, d_prob_lane_lo, d_prob_lane_n;
-    DevBuf d_dp_items, d_work_prob, d_work_chunk, d_cls_items, d_work_active, d_pair_thr, d_amb, d_out, d_cov, d_labels;
+    DevBuf d_dp_items, d_prob_desc, d_work_pc, d_cls_items, d_work_active, d_pair_thr, d_amb, d_out, d_cov, d_labels;
     i64 prob_cap = 0, work_cap = 0, pair_cap = 0, tri_cap = 0, label_cap = 0, chunk_cap = 0, cov_cap = 0;
     DevBuf d_status, d_tacc;
     Status *h_status = nullptr;   // pinned
@@ -2088,9 +2116,9 @@ int alloc_arenas(fseg_ctx *c) {
     TRY(ensure(c, c->d_prob_cov_off, (size_t)c->prob_cap * 8));
     TRY(ensure(c, c->d_prob_lane_lo, (size_t)c->prob_cap * 4));
     TRY(ensure(c, c->d_prob_lane_n, (size_t)c->prob_cap * 4));
-    TRY(ensure(c, c->d_work_prob, (size_t)c->work_cap * 4));
-    TRY(ensure(c, c->d_work_chunk, (size_t)c->work_cap * 4));
-    TRY(ensure(c, c->d_cls_items, (size_t)c->work_cap * 4));
+    TRY(ensure(c, c->d_prob_desc, (size_t)c->prob_cap * sizeof(ProbDesc)));
+    TRY(ensure(c, c->d_work_pc, (size_t)c->work_cap * 8));
+    TRY(ensure(c, c->d_cls_items, (size_t)c->work_cap * 16));
     TRY(ensure(c, c->d_work_active, (size_t)c->work_cap));
     TRY(ensure(c, c->d_cov, (size_t)c->cov_cap * 4));
     TRY(ensure(c, c->d_pair_thr, (size_t)c->pair_cap * 8));
@@ -2206,18 +2234,20 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
         }
         hipLaunchKernelGGL(k_prob_emit, dim3(pg), dim3(256), 0, s, st, c->d_cand_pn.as<int>(), c->d_cand_ll.as<int>(),
                            c->d_cand_ln.as<int>(), c->d_seg_iv.as<int>(), c->d_cand_off.as<i64>(), bs,
-                           pr, c->prob_cap, c->d_work_prob.as<int>(), c->d_work_chunk.as<int>(), c->d_cls_items.as<int>(),
-                           c->work_cap, c->d_dp_items.as<int>());
+                           pr, c->prob_cap, c->d_work_pc.as<int2>(), c->d_cls_items.as<int4>(),
+                           c->work_cap, c->d_dp_items.as<int>(), c->d_prob_desc.as<ProbDesc>(), c->d_iv_start.as<int>(),
+                           c->d_iv_part.as<int>(), c->d_part_lane_off.as<i64>());
     }
     mark(5);
     // S5
     if (c->prob_cap > 0) {
-        hipLaunchKernelGGL(k_pair_thresholds, dim3(grid_for(c->prob_cap, 1, 2048)), dim3(256), 0, s, st, pr, c->prob_cap,
-                           c->d_cand_off.as<i64>(), c->d_cand_y.as<int>(), c->d_h_table.as<double>(), c->P.h_len,
+        hipLaunchKernelGGL(k_pair_thresholds, dim3(grid_for(c->prob_cap, 1, 2048)), dim3(256), 0, s, st, pr,
+                           c->d_prob_desc.as<ProbDesc>(), c->prob_cap, c->d_cand_off.as<i64>(), c->d_cand_y.as<int>(),
+                           c->d_h_table.as<double>(), c->P.h_len,
                            c->P.threshold_rate, c->d_pair_thr.as<int2>(), c->pair_cap, c->d_amb.as<unsigned>(),
                            c->d_out.as<unsigned>(), c->tri_cap);
-        hipLaunchKernelGGL(k_cov, dim3(work_grid < 2048 ? work_grid : 2048), dim3(kLaneChunk), 0, s, st, pr, c->prob_cap,
-                           c->d_work_prob.as<int>(), c->d_work_chunk.as<int>(), c->work_cap, c->d_cand_off.as<i64>(),
+        hipLaunchKernelGGL(k_cov, dim3(work_grid < 2048 ? work_grid : 2048), dim3(kLaneChunk), 0, s, st,
+                           c->d_prob_desc.as<ProbDesc>(), c->prob_cap, c->d_work_pc.as<int2>(), c->work_cap, c->d_cand_off.as<i64>(),
                            c->d_cand_y.as<int>(), c->d_iv_start.as<int>(), c->d_lane_rep.as<int>(),
                            c->d_rep_exon_off.as<i64>(), c->d_ex_ts.as<int>(), c->d_ex_te.as<int>(),
                            c->d_cov.as<unsigned>(), c->cov_cap, c->d_work_active.as<unsigned char>());
@@ -2233,8 +2263,8 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
 #define FSEG_LAUNCH_SCORE(NMV, CLS, MAXWG)                                                                              \
         hipLaunchKernelGGL(k_score<NMV>, dim3(work_grid < (MAXWG) ? work_grid : (MAXWG)), dim3(ScoreCfg<NMV>::kThreads),  \
                            score_lds_for((NMV) == kNMax ? c->nm_big : (NMV), (NMV) + 1), s, st, CLS,                                 \
-                           ((NMV) == kNMax ? c->nm_big : (NMV)), pr, c->prob_cap, c->d_cls_items.as<int>(),               \
-                           c->d_work_prob.as<int>(), c->d_work_chunk.as<int>(), c->work_cap, c->d_cand_off.as<i64>(),   \
+                           ((NMV) == kNMax ? c->nm_big : (NMV)), pr, c->prob_cap, c->d_cls_items.as<int4>(),              \
+                           c->d_prob_desc.as<ProbDesc>(), c->work_cap, c->d_cand_off.as<i64>(),                         \
                            c->d_cand_y.as<int>(), c->d_work_active.as<unsigned char>(), c->d_cov.as<unsigned>(),        \
                            c->cov_cap, c->d_pair_thr.as<int2>(), c->pair_cap, c->d_out.as<unsigned>(), c->tri_cap,      \
                            c->d_amb.as<unsigned>() FSEG_TARG)
@@ -2254,7 +2284,7 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
 #define FSEG_LAUNCH_DP(NMV, TV, OUTT, NM_RT, DPCLASS, MAXWG)                                                             \
         hipLaunchKernelGGL((k_dp<NMV, TV, OUTT>), dim3(dp_grid < (MAXWG) ? dp_grid : (MAXWG)), dim3(TV),                     \
                            dp_lds_for(NM_RT, (int)sizeof(OUTT)), s, st, DPCLASS, NM_RT, c->d_dp_items.as<int>(), pr,          \
-                           c->prob_cap, c->d_cand_off.as<i64>(), c->d_cand_y.as<int>(), c->d_iv_part.as<int>(),               \
+                           c->d_prob_desc.as<ProbDesc>(), c->prob_cap, c->d_cand_off.as<i64>(), c->d_cand_y.as<int>(), c->d_iv_part.as<int>(),               \
                            c->d_part_lane_off.as<i64>(), c->d_out.as<unsigned>(), c->tri_cap, c->d_amb.as<unsigned>(),        \
                            c->d_pair_thr.as<int2>(), c->pair_cap, c->P.min_read_support_outside,                              \
                            c->d_chosen.as<unsigned char>() FSEG_TARG)
@@ -2454,7 +2484,7 @@ void fseg_destroy(fseg_ctx *c) {
                       &c->d_final_pos, &c->d_col_thr, &c->d_col_zero, &c->d_cum, &c->d_tile_tot, &c->d_iv_tile0, &c->d_seg_iv, &c->d_seg_prev, &c->d_rseg_c, &c->d_cand_pn, &c->d_cand_ll, &c->d_cand_ln, &c->d_prob_bs, &c->d_prob_iv, &c->d_prob_start,
                       &c->d_prob_n, &c->d_prob_pair_off, &c->d_prob_tri_off, &c->d_prob_flags, &c->d_prob_chain, &c->d_prob_cov_off,
                       &c->d_prob_lane_lo, &c->d_prob_lane_n, &c->d_work_active, &c->d_cov,
-                      &c->d_dp_items, &c->d_work_prob, &c->d_work_chunk, &c->d_cls_items, &c->d_pair_thr, &c->d_amb, &c->d_out, &c->d_labels, &c->d_status, &c->d_tacc};
+                      &c->d_dp_items, &c->d_prob_desc, &c->d_work_pc, &c->d_cls_items, &c->d_pair_thr, &c->d_amb, &c->d_out, &c->d_labels, &c->d_status, &c->d_tacc};
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
     if (c->h_status) (void)hipHostFree(c->h_status);
     for (int i = 0; i <= ST_COUNT; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
