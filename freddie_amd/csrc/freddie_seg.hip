@@ -53,6 +53,7 @@ enum : unsigned {
     kErrOverflowChunks = 256u,
     kErrOverflowCov = 512u,
     kErrOverflowNm = 1024u,
+    kErrScanStall = 4096u,     // the look-back scan gave up waiting for a predecessor block: rerun with the three-pass scan
     kErrNeedWideDp = 2048u,    // a problem sees >= 65536 reads: its DP needs the 32-bit count table    // a problem is larger than the LDS carve-up this launch was sized for
 };
 
@@ -368,7 +369,7 @@ __global__ void __launch_bounds__(256) k_scan2(int *bsum, i64 nb, u64 *total_out
 // writes the grand total.
 constexpr u64 kScanValueMask = (1ULL << 62) - 1ULL;
 __device__ __forceinline__ i64 scan_lookback(u64 *state, i64 b, i64 nb, i64 agg, i64 *bcast /* LDS */, u64 *total_out,
-                                             i64 *off_last) {
+                                             i64 *off_last, unsigned *err) {
     const int lane = lane_id();
     if (threadIdx.x < 64) {
         if (lane == 0)
@@ -376,7 +377,10 @@ __device__ __forceinline__ i64 scan_lookback(u64 *state, i64 b, i64 nb, i64 agg,
         i64 excl = 0;
         if (b > 0) {
             i64 base = b - 1;                                        // lane l looks at block base - l
-            for (;;) {
+            // every spin is bounded: the chain is short (the host only picks this scan then) and all its blocks are
+            // resident together, but nothing about dispatch order is guaranteed -- a stall is reported, not waited out
+            for (int spins = 0;; ++spins) {
+                if (spins > (1 << 20)) { if (lane == 0) atomicOr(err, kErrScanStall); break; }
                 const i64 idx = base - lane;
                 u64 sv = 2ULL << 62;                                 // before block 0: prefix 0
                 if (idx >= 0) sv = __hip_atomic_load(&state[idx], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
@@ -412,7 +416,8 @@ __device__ __forceinline__ i64 scan_lookback(u64 *state, i64 b, i64 nb, i64 agg,
 enum { kEmitValues = 0, kEmitPositions = 1 };
 template <int MODE>
 __global__ void __launch_bounds__(256) k_scan_emit(const unsigned char *flags, i64 n, const int *bsum /* or null */,
-                                                   u64 *state, u64 *total_out, i64 *off_last /* may be null */, const double *y,
+                                                   u64 *state, u64 *total_out, i64 *off_last /* may be null */,
+                                                   unsigned *err, const double *y,
                                                    double *v, i64 K, const i64 *pos_off, const int *iv_start,
                                                    const int *blk_iv0, int *out_y, int *out_pos, i64 *out_off) {
     // A block is 4 waves x 2048 consecutive positions.  Each wave first counts its flags (16-byte loads), the wave
@@ -435,7 +440,7 @@ __global__ void __launch_bounds__(256) k_scan_emit(const unsigned char *flags, i
             if (i0 < n) { f = load_flags32(flags, i0, n); s = count_flags32(f); }
             int tot;
             int ex = wg_exclusive_scan(s, lds, &tot);
-            ex += bsum ? bsum[b] : (int)scan_lookback(state, b, nb, tot, &bcast, total_out, off_last);
+            ex += bsum ? bsum[b] : (int)scan_lookback(state, b, nb, tot, &bcast, total_out, off_last, err);
             if (s) {
                 i64 k = -1, k_end = 0, k_base = 0;
                 for (int q = 0; q < 8; ++q) {
@@ -473,7 +478,7 @@ __global__ void __launch_bounds__(256) k_scan_emit(const unsigned char *flags, i
         if (lane == 0) wave_cnt[wave] = s;
         __syncthreads();
         const int tot = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-        int ex = bsum ? bsum[b] : (int)scan_lookback(state, b, nb, tot, &bcast, total_out, off_last);
+        int ex = bsum ? bsum[b] : (int)scan_lookback(state, b, nb, tot, &bcast, total_out, off_last, err);
         for (int w = 0; w < wave; ++w) ex += wave_cnt[w];
         if (s) {
             i64 k = -1, k_end = 0, k_base = 0;
@@ -2188,7 +2193,7 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
     // S3a threshold
     scan_counts(c->d_flag.as<unsigned char>(), &st->n_vals, nullptr);
     hipLaunchKernelGGL(k_scan_emit<kEmitValues>, dim3(scan_grid), dim3(256), 0, s, c->d_flag.as<unsigned char>(), NPOS,
-                       bsum, scan_state, &st->n_vals, (i64 *)nullptr, c->d_y.as<double>(), c->d_v.as<double>(), K, c->d_pos_off.as<i64>(),
+                       bsum, scan_state, &st->n_vals, (i64 *)nullptr, &st->err, c->d_y.as<double>(), c->d_v.as<double>(), K, c->d_pos_off.as<i64>(),
                        c->d_iv_start.as<int>(), c->d_blk_iv0.as<int>(), (int *)nullptr, (int *)nullptr, (i64 *)nullptr);
     hipLaunchKernelGGL(k_voff, dim3(grid_for(n_part + 1, 1, 2048)), dim3(64), 0, s, n_part, c->d_part_iv_off.as<i64>(),
                        c->d_pos_off.as<i64>(), NPOS, c->d_flag.as<unsigned char>(), bsum, scan_state, &st->n_vals,
@@ -2210,7 +2215,7 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
                        c->d_final_flag.as<unsigned char>(), c->d_part_has2.as<int>(), n_part);
     scan_counts(c->d_cflag.as<unsigned char>(), &st->n_cand, c->d_cand_off.as<i64>() + K);
     hipLaunchKernelGGL(k_scan_emit<kEmitPositions>, dim3(scan_grid), dim3(256), 0, s, c->d_cflag.as<unsigned char>(), NPOS,
-                       bsum, scan_state + scan_nb, &st->n_cand, c->d_cand_off.as<i64>() + K, (const double *)nullptr, (double *)nullptr, K, c->d_pos_off.as<i64>(),
+                       bsum, scan_state + scan_nb, &st->n_cand, c->d_cand_off.as<i64>() + K, &st->err, (const double *)nullptr, (double *)nullptr, K, c->d_pos_off.as<i64>(),
                        c->d_iv_start.as<int>(), c->d_blk_iv0.as<int>(), c->d_cand_y.as<int>(), (int *)nullptr,
                        c->d_cand_off.as<i64>());
     mark(4);
@@ -2315,7 +2320,7 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
     mark(9);
     scan_counts(c->d_final_flag.as<unsigned char>(), &st->n_final, c->d_final_off.as<i64>() + K);
     hipLaunchKernelGGL(k_scan_emit<kEmitPositions>, dim3(scan_grid), dim3(256), 0, s, c->d_final_flag.as<unsigned char>(),
-                       NPOS, bsum, scan_state + 2 * scan_nb, &st->n_final, c->d_final_off.as<i64>() + K, (const double *)nullptr, (double *)nullptr, K, c->d_pos_off.as<i64>(),
+                       NPOS, bsum, scan_state + 2 * scan_nb, &st->n_final, c->d_final_off.as<i64>() + K, &st->err, (const double *)nullptr, (double *)nullptr, K, c->d_pos_off.as<i64>(),
                        c->d_iv_start.as<int>(), c->d_blk_iv0.as<int>(), c->d_final_y.as<int>(), c->d_final_pos.as<int>(),
                        c->d_final_off.as<i64>());
     mark(10);
@@ -2364,6 +2369,7 @@ int finish_run(fseg_ctx *c) {
                                 kErrOverflowProblems | kErrOverflowChunks | kErrOverflowCov);
         if (s.err & kErrOverflowNm) { ovf |= kErrOverflowNm; c->nm_big = kNMax; }
         if (s.err & kErrNeedWideDp) { ovf |= kErrNeedWideDp; c->dp_wide_counts = true; drop_graph(c); }
+        if (s.err & kErrScanStall) { ovf |= kErrScanStall; c->scan_single_max = 0; drop_graph(c); }
         bool need = ovf != 0 || (i64)s.n_prob > c->prob_cap || (i64)s.n_work > c->work_cap ||
                     (i64)s.pair_used > c->pair_cap || (i64)s.tri_used > c->tri_cap || (i64)s.label_bytes > c->label_cap ||
                     (i64)s.n_vchunks > c->chunk_cap || (i64)s.cov_used > c->cov_cap;
