@@ -36,6 +36,8 @@ constexpr int kSmoothTile = 1024;      // positions per smoothing / peak tile (k
 constexpr int kMaxRadius = 200;        // sigma <= 50, truncate 4.0 (py/freddie_segment.py:106,:755)
 constexpr int kScanBlock = 8192;       // elements per scan workgroup (256 threads x 32 flag bytes)
 constexpr int kNMax = 60;              // largest DP problem handled by the LDS-resident scoring kernel
+constexpr int kNHuge = 128;            // largest DP problem at all: 60 < n <= 128 (max_problem_size up to ~115) takes the
+                                       // global-table kernels k_score_huge / k_dp_huge
 constexpr int kLaneChunk = 256;        // reads ("lanes") per scoring work item (u16 counters: must stay < 65536)
 constexpr int kSub = 64;               // reads per scoring sub-chunk (two 32-bit plane words)
 constexpr i64 kNegInf = (i64)(-0x7fffffffffffffffLL - 1);
@@ -44,7 +46,7 @@ constexpr i64 kNegInf = (i64)(-0x7fffffffffffffffLL - 1);
 enum : unsigned {
     kErrExonInterval = 1u,     // an exon is not inside one tint interval (py/freddie_segment.py:668)
     kErrBreakAssert = 2u,      // break_large_problems: assert max_c_idx_y_v > 0 / index out of range (:640-643)
-    kErrProblemTooLarge = 4u,  // a DP problem has more than kNMax candidates
+    kErrProblemTooLarge = 4u,  // a DP problem has more than kNHuge candidates
     kErrOverflowPairs = 8u,
     kErrOverflowTri = 16u,
     kErrOverflowWork = 32u,
@@ -73,9 +75,9 @@ struct Status {
     u64 cov_used;      // elements of the coverage arena
     unsigned max_n;    // largest DP problem of this run
     unsigned pad2;
-    u64 cls_work[3];   // work items per problem-size class (n <= 16, <= 32, <= kNMax)
+    u64 cls_work[4];   // work items per problem-size class (n <= 16, <= 32, <= kNMax, <= kNHuge)
     u64 cls_queue[3];  // dynamic work counters of the scoring kernels
-    u64 dp_cls[2];     // DP problems with n <= kDpSmall / larger
+    u64 dp_cls[3];     // DP problems with n <= kDpSmall / <= kNMax / larger
     u64 cov_queue;
 };
 
@@ -754,7 +756,9 @@ struct __align__(16) ProbDesc {
     int n, lane_lo, lane_n;
     int g0;         // genomic start of the interval (iv_start[iv])
     int outside;    // lanes of the partition outside [lane_lo, lane_lo + lane_n)
-    int iv, pad0, pad1;
+    int iv;
+    int w0;         // first work item (= chunk 0) of the problem
+    int pad1;
 };
 static_assert(sizeof(ProbDesc) == 64, "ProbDesc is one 64-byte record");
 __device__ __forceinline__ ProbDesc load_desc(const ProbDesc *d) {
@@ -848,7 +852,7 @@ __global__ void k_fix(i64 K, const i64 *pos_off, const int *iv_part, const i64 *
             if (c < N) {
                 fixed[c0 + c] = f; chosen[c0 + c] = f;
                 int n = (f && prev >= 0 && c - prev + 1 >= 3) ? c - prev + 1 : 0;
-                if (n > kNMax) atomicOr(&st->err, kErrProblemTooLarge);
+                if (n > kNHuge) atomicOr(&st->err, kErrProblemTooLarge);
                 if (n > 0) atomicMax(&st->max_n, (unsigned)n);
                 cand_pn[c0 + c] = n;
             }
@@ -886,14 +890,15 @@ __global__ void k_prob_range(const Status *st, const int *cand_pn, const int *ca
 // Scanned columns.  Counters that stay below 2^32 over a whole batch share a 64-bit column (low | high << 32):
 //   0: problem slot | DP problems of the small class     1: pairs     2: triples     3: coverage elements
 //   4: work items of class 0 | class 1                   5: work items of class 2 | DP problems of the big class
-// (work items overall = the three class counts)
-constexpr int kProbCols = 6;
+//   6: work items of class 3 (huge) | DP problems of the huge class
+// (work items overall = the four class counts)
+constexpr int kProbCols = 7;
 __device__ __forceinline__ i64 col_lo(i64 x) { return x & 0xffffffffLL; }
 __device__ __forceinline__ i64 col_hi(i64 x) { return (i64)((u64)x >> 32); }
 constexpr int kDpSmall = 32;
 constexpr int kClsSmall = 16, kClsMid = 32;
 struct ProbSizes { i64 v[kProbCols]; };
-__device__ __forceinline__ int size_class(int n) { return n <= kClsSmall ? 0 : (n <= kClsMid ? 1 : 2); }
+__device__ __forceinline__ int size_class(int n) { return n <= kClsSmall ? 0 : (n <= kClsMid ? 1 : (n <= kNMax ? 2 : 3)); }
 __device__ __forceinline__ ProbSizes prob_sizes(int n, int n_lanes) {
     ProbSizes s;
     for (int q = 0; q < kProbCols; ++q) s.v[q] = 0;
@@ -904,7 +909,8 @@ __device__ __forceinline__ ProbSizes prob_sizes(int n, int n_lanes) {
     s.v[1] = (i64)n * (n - 1) / 2; s.v[2] = (i64)n * (n - 1) * (n - 2) / 6;
     s.v[3] = chunks * kLaneChunk * n;
     s.v[4] = cls == 0 ? chunks : (cls == 1 ? chunks << 32 : 0);
-    s.v[5] = (cls == 2 ? chunks : 0) + (n <= kDpSmall ? 0 : (1LL << 32));
+    s.v[5] = (cls == 2 ? chunks : 0) + ((n > kDpSmall && n <= kNMax) ? (1LL << 32) : 0);
+    s.v[6] = (cls == 3 ? chunks : 0) + (n > kNMax ? (1LL << 32) : 0);
     return s;
 }
 __device__ __forceinline__ i64 wg_exclusive_scan64(i64 v, i64 *lds /* >= 16 */, i64 *total) {
@@ -964,9 +970,10 @@ __device__ __forceinline__ ProbSizes prob_block_sizes(const int *cand_pn, const 
 }
 __device__ __forceinline__ void prob_store_totals(Status *st, const ProbSizes &t) {
     st->n_prob = (u64)col_lo(t.v[0]); st->pair_used = (u64)t.v[1]; st->tri_used = (u64)t.v[2];
-    st->n_work = (u64)(col_lo(t.v[4]) + col_hi(t.v[4]) + col_lo(t.v[5])); st->cov_used = (u64)t.v[3];
+    st->n_work = (u64)(col_lo(t.v[4]) + col_hi(t.v[4]) + col_lo(t.v[5]) + col_lo(t.v[6])); st->cov_used = (u64)t.v[3];
     st->cls_work[0] = (u64)col_lo(t.v[4]); st->cls_work[1] = (u64)col_hi(t.v[4]); st->cls_work[2] = (u64)col_lo(t.v[5]);
-    st->dp_cls[0] = (u64)col_hi(t.v[0]); st->dp_cls[1] = (u64)col_hi(t.v[5]);
+    st->cls_work[3] = (u64)col_lo(t.v[6]);
+    st->dp_cls[0] = (u64)col_hi(t.v[0]); st->dp_cls[1] = (u64)col_hi(t.v[5]); st->dp_cls[2] = (u64)col_hi(t.v[6]);
 }
 __global__ void __launch_bounds__(256) k_prob_scan1(const Status *st, const int *cand_pn, const int *cand_ln, i64 *bs) {
     __shared__ i64 lds[4 * kProbCols];
@@ -1017,6 +1024,7 @@ __global__ void __launch_bounds__(256) k_prob_emit(Status *st, const int *cand_p
         if (bs) {
             for (int q = 0; q < kProbCols; ++q) before.v[q] = bs[b * kProbCols + q];
             grand.v[4] = (i64)st->cls_work[0] + ((i64)st->cls_work[1] << 32); grand.v[0] = (i64)st->dp_cls[0] << 32;
+            grand.v[5] = (i64)st->cls_work[2] + ((i64)st->dp_cls[1] << 32);
         } else {
             for (int q = 0; q < kProbCols; ++q) { before.v[q] = 0; grand.v[q] = 0; }
             for (i64 bb = 0; bb < nb; ++bb) {
@@ -1034,7 +1042,8 @@ __global__ void __launch_bounds__(256) k_prob_emit(Status *st, const int *cand_p
             if (b == nb - 1 && threadIdx.x == 0) prob_store_totals(st, grand);
         }
         const i64 i0 = b * kProbBlock + (i64)threadIdx.x * 4;
-        const i64 g_cls0 = col_lo(grand.v[4]), g_cls1 = col_hi(grand.v[4]), g_dp0 = col_hi(grand.v[0]);
+        const i64 g_cls0 = col_lo(grand.v[4]), g_cls1 = col_hi(grand.v[4]), g_cls2 = col_lo(grand.v[5]);
+        const i64 g_dp0 = col_hi(grand.v[0]), g_dp1 = col_hi(grand.v[5]);
         for (int e = 0; e < 4; ++e) {
             if (sz[e].v[0]) {
                 i64 c = i0 + e;
@@ -1052,18 +1061,20 @@ __global__ void __launch_bounds__(256) k_prob_emit(Status *st, const int *cand_p
                         d.n = nn; d.lane_lo = cand_ll[c]; d.lane_n = cand_ln[c]; d.g0 = iv_start[k];
                         const int part = iv_part[k];
                         d.outside = (int)(part_lane_off[part + 1] - part_lane_off[part]) - d.lane_n;
-                        d.iv = k; d.pad0 = 0; d.pad1 = 0;
+                        d.iv = k; d.w0 = (int)(col_lo(ex.v[4]) + col_hi(ex.v[4]) + col_lo(ex.v[5]) + col_lo(ex.v[6])); d.pad1 = 0;
                         desc[slot] = d;
                     }
                     {   // DP problem lists: the small problems first, then the big ones
-                        i64 di = nn <= kDpSmall ? col_hi(ex.v[0]) : g_dp0 + col_hi(ex.v[5]);
+                        // (then the huge ones)
+                        i64 di = nn <= kDpSmall ? col_hi(ex.v[0]) : (nn <= kNMax ? g_dp0 + col_hi(ex.v[5]) : g_dp0 + g_dp1 + col_hi(ex.v[6]));
                         if (di < prob_cap) dp_items[di] = (int)slot;
                     }
                     int cls = size_class(nn);
-                    const i64 e_cls0 = col_lo(ex.v[4]), e_cls1 = col_hi(ex.v[4]), e_cls2 = col_lo(ex.v[5]);
-                    const i64 w0 = e_cls0 + e_cls1 + e_cls2;         // work items before this problem
-                    i64 cbase = cls == 0 ? e_cls0 : (cls == 1 ? g_cls0 + e_cls1 : g_cls0 + g_cls1 + e_cls2);
-                    const i64 cnt = col_lo(sz[e].v[4]) + col_hi(sz[e].v[4]) + col_lo(sz[e].v[5]);
+                    const i64 e_cls0 = col_lo(ex.v[4]), e_cls1 = col_hi(ex.v[4]), e_cls2 = col_lo(ex.v[5]), e_cls3 = col_lo(ex.v[6]);
+                    const i64 w0 = e_cls0 + e_cls1 + e_cls2 + e_cls3;   // work items before this problem
+                    i64 cbase = cls == 0 ? e_cls0 : (cls == 1 ? g_cls0 + e_cls1 : (cls == 2 ? g_cls0 + g_cls1 + e_cls2
+                                                                                    : g_cls0 + g_cls1 + g_cls2 + e_cls3));
+                    const i64 cnt = col_lo(sz[e].v[4]) + col_hi(sz[e].v[4]) + col_lo(sz[e].v[5]) + col_lo(sz[e].v[6]);
                     if (w0 + cnt > work_cap || cbase + cnt > work_cap) atomicOr(&st->err, kErrOverflowWork);
                     else if (cnt <= kProbDirect) {
                         for (i64 q = 0; q < cnt; ++q) {
@@ -1146,7 +1157,7 @@ __global__ void __launch_bounds__(kLaneChunk) k_cov(Status *st, const ProbDesc *
                                                     const int *cand_y, const int *iv_start, const int *lane_rep,
                                                     const i64 *rep_exon_off, const int *ex_ts, const int *ex_te,
                                                     unsigned *cov_g, i64 cov_cap, unsigned char *work_active) {
-    __shared__ int cp[kNMax + 4];
+    __shared__ int cp[kNHuge + 4];
     __shared__ u64 work_s;
     __shared__ unsigned active_s;
     i64 n_work = (i64)st->n_work;
@@ -1160,7 +1171,7 @@ __global__ void __launch_bounds__(kLaneChunk) k_cov(Status *st, const ProbDesc *
         const ProbDesc d = load_desc(desc + pc.x);
         const int n = d.n;
         i64 coff = d.cov_off + (i64)chunk * kLaneChunk * n;
-        if (n > kNMax || coff + (i64)kLaneChunk * n > cov_cap) { if (threadIdx.x == 0) work_active[w] = 0; continue; }
+        if (n > kNHuge || coff + (i64)kLaneChunk * n > cov_cap) { if (threadIdx.x == 0) work_active[w] = 0; continue; }
         const int *cy = cand_y + d.c0;
         const int g0 = d.g0;
         for (int j = threadIdx.x; j < n; j += blockDim.x) cp[j] = g0 + cy[j];
@@ -1440,7 +1451,7 @@ __global__ void __launch_bounds__(ScoreCfg<NM>::kThreads) k_score(Status *st, in
     for (int q = threadIdx.x; q < rt_pairs; q += T) pair_ij[q] = g_pair_ij[q];
     // cls < 0: this launch takes the work items of every size class (small batches: one launch instead of three)
     i64 cls_base = cls < 0 ? 0 : (cls >= 1 ? (i64)st->cls_work[0] : 0) + (cls >= 2 ? (i64)st->cls_work[1] : 0);
-    i64 n_items = cls < 0 ? (i64)st->n_work : (i64)st->cls_work[cls];
+    i64 n_items = cls < 0 ? (i64)st->n_work - (i64)st->cls_work[3] : (i64)st->cls_work[cls];   // never the huge class
     u64 *queue = &st->cls_queue[cls < 0 ? 0 : cls];
     if ((i64)st->n_work > work_cap || (i64)st->n_prob > prob_cap) n_items = 0;   // lists incomplete: sizing run
     FSEG_T0;
@@ -1661,6 +1672,203 @@ __global__ void __launch_bounds__(T) k_dp(Status *st, int dp_class, int nm, cons
         FSEG_DTICK(9);
         int chain = dp_solve<T>(n, out_s, in_s, M, A, cy_s, support, part_v, part_a, top_key, chosen + c0 FSEG_DARG);
         if (threadIdx.x == 0) pr.chain[p] = chain;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Problems with kNMax < n <= kNHuge candidates (max_problem_size well above the default 50): the same scoring and
+// DP with the triple counters left in the global arena.  One workgroup owns a problem outright and walks all of its
+// coverage chunks itself, 32 reads at a time, so the counters are plain read-modify-writes (no atomics).  These are
+// the slow-but-complete kernels; they are only launched when a previous run of the batch met such a problem.
+// ---------------------------------------------------------------------------------------------
+constexpr int kHugeSub = 32;           // reads per step of the huge-problem scoring kernel (one plane word per label)
+constexpr size_t kHugeScoreLds = (size_t)(kNHuge * (kNHuge - 1) / 2) * 8 + (size_t)kHugeSub * (kNHuge + 1) * 4;
+__global__ void __launch_bounds__(512) k_score_huge(Status *st, const int *dp_items, ProblemArrays pr, const ProbDesc *desc,
+                                                    i64 prob_cap, i64 work_cap, const int *cand_y, const unsigned *cov_g,
+                                                    i64 cov_cap, const int2 *pair_thr, i64 pair_cap, unsigned *out_g,
+                                                    i64 tri_cap, unsigned *amb_g) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint2 *planes = reinterpret_cast<uint2 *>(smem);                                   // {yea, nay} per pair
+    unsigned *cov = reinterpret_cast<unsigned *>(smem + (size_t)(kNHuge * (kNHuge - 1) / 2) * 8);   // [read][j], stride kNHuge + 1
+    __shared__ int cy_s[kNHuge];
+    __shared__ int iend_s[kNHuge];
+    constexpr int T = 512, stride = kNHuge + 1;
+    if ((i64)st->n_work > work_cap || (i64)st->n_prob > prob_cap) return;              // sizing run
+    const i64 list_base = (i64)st->dp_cls[0] + (i64)st->dp_cls[1], list_n = (i64)st->dp_cls[2];
+    for (i64 t = blockIdx.x; t < list_n; t += gridDim.x) {
+        __syncthreads();
+        const int p = dp_items[list_base + t];
+        const ProbDesc d = load_desc(desc + p);
+        const int n = d.n;
+        if (n > kNHuge) continue;
+        const int npairs = n * (n - 1) / 2, ntri = n * (n - 1) * (n - 2) / 6;
+        const i64 poff = d.pair_off, toff = d.tri_off;
+        const int n_chunks = (d.lane_n + kLaneChunk - 1) / kLaneChunk;
+        if (poff + npairs > pair_cap || toff + ntri > tri_cap || d.cov_off + (i64)n_chunks * kLaneChunk * n > cov_cap) continue;
+        for (int j = threadIdx.x; j < n; j += T) cy_s[j] = cand_y[d.c0 + j];
+        __syncthreads();
+        if (threadIdx.x < n) {
+            int j = threadIdx.x, lim = cy_s[j] - 5, lo = 0, hi = j;
+            while (lo < hi) { int mid = (lo + hi) >> 1; if (cy_s[mid] <= lim) lo = mid + 1; else hi = mid; }
+            iend_s[j] = lo;                                        // number of i < j with cand_j - cand_i >= 5 (:540)
+        }
+        const bool zero_ambiguous = (pr.flags[p] & 1) != 0;
+        for (int r0 = 0; r0 < d.lane_n; r0 += kHugeSub) {
+            const int nr = d.lane_n - r0 < kHugeSub ? d.lane_n - r0 : kHugeSub;
+            const int chunk = r0 / kLaneChunk, in_chunk = r0 % kLaneChunk;
+            const unsigned *src = cov_g + d.cov_off + (i64)chunk * kLaneChunk * n + in_chunk;   // [j][256 reads]
+            __syncthreads();
+            for (int x = threadIdx.x; x < n * kHugeSub; x += T) {
+                const int j = x / kHugeSub, b = x % kHugeSub;
+                cov[b * stride + j] = b < nr ? src[(i64)j * kLaneChunk + b] : 0u;
+            }
+            __syncthreads();
+            const unsigned valid = nr >= 32 ? 0xffffffffu : ((1u << nr) - 1u);
+            for (int q = threadIdx.x; q < npairs; q += T) {
+                int i, j;
+                pair_decode(q, &i, &j);
+                const int2 th = pair_thr[poff + q];
+                unsigned y = 0, z = 0;
+                for (int b = 0; b < kHugeSub; ++b) {
+                    const int dd = (int)(cov[b * stride + j] - cov[b * stride + i]);
+                    y |= (unsigned)(dd >= th.x) << b;              // yea: covered fraction above the high threshold
+                    z |= (unsigned)(dd <= th.y) << b;              // nay: below the low threshold
+                }
+                y &= valid; z &= valid;
+                planes[q] = make_uint2(y, z);
+                const unsigned amb = __popc(~(y | z) & valid);
+                if (amb) amb_g[poff + q] += amb;                    // this workgroup owns the problem: plain update
+            }
+            __syncthreads();
+            // triples: thread = (j,k), loop over the i with cand_j - cand_i >= 5; counters of a (j,k) are contiguous
+            for (int r = threadIdx.x; r < npairs; r += T) {
+                int j, kk;
+                pair_decode(r, &j, &kk);
+                if (j == 0 || cy_s[kk] - cy_s[j] < 5) continue;
+                const uint2 B = planes[r];
+                if ((B.x | B.y) == 0) continue;
+                unsigned *o = out_g + toff + (i64)kk * (kk - 1) * (kk - 2) / 6 + j * (j - 1) / 2;
+                const int abase = j * (j - 1) / 2, i_end = iend_s[j];
+                for (int i = 0; i < i_end; ++i) {
+                    const uint2 A = planes[abase + i];
+                    const unsigned cnt = __popc(A.x & B.y) + __popc(A.y & B.x);
+                    if (cnt) o[i] += cnt;
+                }
+            }
+        }
+        (void)zero_ambiguous;                                       // zero-coverage reads outside the lane range: added in the DP
+    }
+}
+
+constexpr size_t kHugeDpLds = (size_t)(kNHuge * (kNHuge - 1) / 2) * (8 + 4 + 1) + 16;
+__global__ void __launch_bounds__(512) k_dp_huge(Status *st, const int *dp_items, ProblemArrays pr, const ProbDesc *desc,
+                                                 i64 prob_cap, const int *cand_y, const unsigned *out_g, i64 tri_cap,
+                                                 const unsigned *amb_g, const int2 *pair_thr, i64 pair_cap, int support,
+                                                 unsigned char *chosen) {
+    constexpr int T = 512, kSlices = 4, kB = T / kSlices;          // thread = (b, c2 slice); kB == kNHuge
+    constexpr int kPairs = kNHuge * (kNHuge - 1) / 2;
+    extern __shared__ __align__(16) unsigned char smem[];
+    i64 *M = reinterpret_cast<i64 *>(smem);
+    int *in_s = reinterpret_cast<int *>(M + kPairs);
+    unsigned char *A = reinterpret_cast<unsigned char *>(in_s + kPairs);
+    __shared__ int cy_s[kNHuge];
+    __shared__ i64 part_v[T];
+    __shared__ unsigned char part_a[T];
+    __shared__ i64 top_v[T / 64];
+    __shared__ int top_key[T / 64];
+    if ((i64)st->n_prob > prob_cap) return;
+    const i64 list_base = (i64)st->dp_cls[0] + (i64)st->dp_cls[1], list_n = (i64)st->dp_cls[2];
+    const int b = 1 + threadIdx.x % kB, slice = threadIdx.x / kB;
+    for (i64 t = blockIdx.x; t < list_n; t += gridDim.x) {
+        __syncthreads();
+        const int p = dp_items[list_base + t];
+        const ProbDesc d = load_desc(desc + p);
+        const int n = d.n;
+        if (n > kNHuge) continue;
+        const int npairs = n * (n - 1) / 2, ntri = n * (n - 1) * (n - 2) / 6, end = n - 1;
+        const i64 poff = d.pair_off, toff = d.tri_off;
+        if (poff + npairs > pair_cap || toff + ntri > tri_cap) continue;
+        const unsigned *out_p = out_g + toff;
+        const i64 outside = d.outside;
+        const bool zamb = (pr.flags[p] & 1) != 0;
+        for (int j = threadIdx.x; j < n; j += T) cy_s[j] = cand_y[d.c0 + j];
+        for (int q = threadIdx.x; q < npairs; q += T)
+            in_s[q] = -(int)((i64)amb_g[poff + q] + ((zamb && pair_thr[poff + q].y < 0) ? outside : 0));
+        __syncthreads();
+#define FSEG_IN(a, bb) ((i64)in_s[(bb) * ((bb) - 1) / 2 + (a)])
+#define FSEG_M(a, bb) M[(bb) * ((bb) - 1) / 2 + (a)]
+        for (int x = threadIdx.x; x < end; x += T) {
+            FSEG_M(x, end) = cy_s[end] - cy_s[x] >= 5 ? FSEG_IN(x, end) : kNegInf;
+            A[end * (end - 1) / 2 + x] = 255;
+        }
+        __syncthreads();
+        for (int c = end - 1; c >= 2; --c) {
+            i64 best = kNegInf; int arg = 255;
+            const bool live = b < c && cy_s[c] - cy_s[b] >= 5;
+            if (live) {
+                const int base = c * (c - 1) / 2 + b;
+                for (int c2 = c + 1 + slice; c2 <= end; c2 += kSlices) {
+                    const i64 tail = FSEG_M(c, c2);
+                    const unsigned o = out_p[(i64)c2 * (c2 - 1) * (c2 - 2) / 6 + base];
+                    const bool ok = (tail != kNegInf) & ((i64)o >= (i64)support);
+                    const i64 cur = ok ? (i64)o + tail : kNegInf;
+                    const bool take = cur > best;
+                    best = take ? cur : best; arg = take ? c2 : arg;
+                }
+            }
+            part_v[threadIdx.x] = best; part_a[threadIdx.x] = (unsigned char)arg;
+            __syncthreads();
+            if (slice == 0 && b < c) {
+                i64 bv = best; int ba = arg;
+                for (int s2 = 1; s2 < kSlices; ++s2) {
+                    const i64 v = part_v[s2 * kB + b - 1]; const int a2 = part_a[s2 * kB + b - 1];
+                    if (v > bv || (v == bv && v != kNegInf && a2 < ba)) { bv = v; ba = a2; }
+                }
+                FSEG_M(b, c) = (live && bv != kNegInf) ? bv + FSEG_IN(b, c) : kNegInf;
+                A[c * (c - 1) / 2 + b] = (unsigned char)ba;
+            }
+            __syncthreads();
+        }
+        // top level (:560-566): first maximiser in (j, k) order, taken only if strictly better than no cut
+        i64 bv = kNegInf; int bkey = 0x7fffffff;
+        for (int q = threadIdx.x; q < npairs; q += T) {
+            int j, kx;
+            pair_decode(q, &j, &kx);
+            if (j < 1) continue;
+            if (cy_s[j] - cy_s[0] < 5 || cy_s[kx] - cy_s[j] < 5) continue;
+            const i64 tail = FSEG_M(j, kx);
+            const unsigned o = out_p[(i64)kx * (kx - 1) * (kx - 2) / 6 + j * (j - 1) / 2];
+            if (tail == kNegInf || (i64)o < (i64)support) continue;
+            const i64 cur = FSEG_IN(0, j) + (i64)o + tail;
+            const int key = j * 256 + kx;
+            if (cur > bv || (cur == bv && key < bkey)) { bv = cur; bkey = key; }
+        }
+        for (int dd = 32; dd >= 1; dd >>= 1) {
+            i64 ov = __shfl_xor(bv, dd); int ok2 = __shfl_xor(bkey, dd);
+            if (ov > bv || (ov == bv && ok2 < bkey)) { bv = ov; bkey = ok2; }
+        }
+        if (lane_id() == 0) { top_v[threadIdx.x >> 6] = bv; top_key[threadIdx.x >> 6] = bkey; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < T / 64; ++w)
+                if (top_v[w] > bv || (top_v[w] == bv && top_key[w] < bkey)) { bv = top_v[w]; bkey = top_key[w]; }
+            int chain = 0;
+            if (bv != kNegInf && bv > FSEG_IN(0, end)) {
+                int j = bkey >> 8, k = bkey & 255;
+                unsigned char *ch = chosen + d.c0;
+                ch[0] = 1;
+                for (;;) {
+                    ch[j] = 1; ch[k] = 1; ++chain;
+                    if (k == end) break;
+                    int k2 = A[k * (k - 1) / 2 + j];
+                    if (k2 == 255) break;
+                    j = k; k = k2;
+                }
+            }
+            pr.chain[p] = chain;
+        }
+#undef FSEG_IN
+#undef FSEG_M
     }
 }
 
@@ -2036,6 +2244,7 @@ struct fseg_ctx {
     DevBuf d_status, d_tacc;
     Status *h_status = nullptr;   // pinned
     bool profiling = false;
+    bool have_huge = false;      // an earlier run of the batch met a problem with more than kNMax candidates: launch the huge kernels
     bool dp_wide_counts = false; // some problem of an earlier run saw >= 65536 reads: DP stages 32-bit counts
     int nm_big = kNMax;         // LDS carve-up of the big-problem kernels: largest problem of the previous run, rounded up
     bool small_batch = false;
@@ -2281,6 +2490,11 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
             FSEG_LAUNCH_SCORE(kClsSmall, 0, 2048);
         }
 #undef FSEG_LAUNCH_SCORE
+        if (c->have_huge)
+            hipLaunchKernelGGL(k_score_huge, dim3(256), dim3(512), kHugeScoreLds, s, st, c->d_dp_items.as<int>(), pr,
+                               c->d_prob_desc.as<ProbDesc>(), c->prob_cap, c->work_cap, c->d_cand_y.as<int>(),
+                               c->d_cov.as<unsigned>(), c->cov_cap, c->d_pair_thr.as<int2>(), c->pair_cap,
+                               c->d_out.as<unsigned>(), c->tri_cap, c->d_amb.as<unsigned>());
     }
     mark(7);
     if (do_post) {
@@ -2306,6 +2520,11 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
             FSEG_LAUNCH_DP(kNMax, 512, unsigned short, c->nm_big, c->small_batch ? -1 : 1, 512);
         }
 #undef FSEG_LAUNCH_DP
+        if (c->have_huge)
+            hipLaunchKernelGGL(k_dp_huge, dim3(dp_grid < 256 ? dp_grid : 256), dim3(512), kHugeDpLds, s, st, c->d_dp_items.as<int>(),
+                               pr, c->d_prob_desc.as<ProbDesc>(), c->prob_cap, c->d_cand_y.as<int>(), c->d_out.as<unsigned>(),
+                               c->tri_cap, c->d_amb.as<unsigned>(), c->d_pair_thr.as<int2>(), c->pair_cap,
+                               c->P.min_read_support_outside, c->d_chosen.as<unsigned char>());
     }
     mark(8);
     // S6
@@ -2370,6 +2589,7 @@ int finish_run(fseg_ctx *c) {
         if (s.err & kErrOverflowNm) { ovf |= kErrOverflowNm; c->nm_big = kNMax; }
         if (s.err & kErrNeedWideDp) { ovf |= kErrNeedWideDp; c->dp_wide_counts = true; drop_graph(c); }
         if (s.err & kErrScanStall) { ovf |= kErrScanStall; c->scan_single_max = 0; drop_graph(c); }
+        if (s.dp_cls[2] > 0 && !c->have_huge) { ovf |= kErrProblemTooLarge << 16; c->have_huge = true; drop_graph(c); }   // rerun with the huge-problem kernels
         bool need = ovf != 0 || (i64)s.n_prob > c->prob_cap || (i64)s.n_work > c->work_cap ||
                     (i64)s.pair_used > c->pair_cap || (i64)s.tri_used > c->tri_cap || (i64)s.label_bytes > c->label_cap ||
                     (i64)s.n_vchunks > c->chunk_cap || (i64)s.cov_used > c->cov_cap;
@@ -2401,7 +2621,7 @@ int finish_run(fseg_ctx *c) {
             }
             if (s.err & kErrExonInterval) return fail(c, FSEG_ERR_INPUT, "an exon does not lie inside one tint interval (py/freddie_segment.py:668)");
             if (s.err & kErrBreakAssert) return fail(c, FSEG_ERR_INPUT, "break_large_problems: candidate window out of range or no positive signal (py/freddie_segment.py:640-643)");
-            if (s.err & kErrProblemTooLarge) return fail(c, FSEG_ERR_UNSUPPORTED, "a DP problem has more than %d candidates (max_problem_size too large for this build)", kNMax);
+            if (s.err & kErrProblemTooLarge) return fail(c, FSEG_ERR_UNSUPPORTED, "a DP problem has more than %d candidates (max_problem_size too large for this build)", kNHuge);
             return FSEG_OK;
         }
         auto grow = [](i64 need_v, i64 cap) { return need_v > cap ? need_v + need_v / 8 + 64 : cap; };
@@ -2463,6 +2683,12 @@ int fseg_create(int device, fseg_ctx **out) {
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_dp<kNMax, 512, unsigned short>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)dp_lds_for(kNMax, 2));
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_score_huge), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)kHugeScoreLds);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_dp_huge), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)kHugeDpLds);
     if (e != hipSuccess) {
         g_create_error = std::string("context creation failed: ") + hipGetErrorString(e);
         delete c;

@@ -15,6 +15,8 @@ CASES = [
     ("refine", dict(n_reads=600, n_exons=60, rp=0.2, max_span=0), dict(min_read_support_outside=1000)),
     ("weights_ends", dict(n_reads=400, n_exons=80, rp=0.1, jp=0.0), dict(ignore_ends=False, max_problem_size=10, variance_factor=1.0)),
     ("tau_one", dict(n_reads=300, n_exons=60, rp=0.1), dict(threshold_rate=1.0)),
+    ("mps100", dict(n_reads=300, n_exons=150, rp=0.3, max_span=0), dict(max_problem_size=100)),
+    ("mps100_vf9", dict(n_reads=300, n_exons=150, rp=0.3, max_span=0), dict(max_problem_size=100, variance_factor=9.0)),
     ("sigma12", dict(n_reads=400, n_exons=80, rp=0.3, jp=0.5, jsd=4, max_span=0), dict(sigma=12.0, min_read_support_outside=0)),
 ]
 

@@ -52,3 +52,20 @@ def test_oracle_vs_live_reference_threshold_rate_one(tmp_path):
         assert list(o["labels"][ri]) == tint["reads"][ridxs[0]]["data"]
         n2 += list(o["labels"][ri]).count(2)
     assert n2 > 0
+
+
+def test_oracle_vs_live_reference_large_problems(tmp_path):
+    """max_problem_size = 100: DP problems with up to ~110 candidates (the default 50 keeps them <= 60)."""
+    seed = 5
+    gen = dict(n_reads=300, n_exons=150, rp=0.3, max_span=0)
+    run = dict(sigma=5.0, threshold_rate=0.9, min_read_support_outside=3, max_problem_size=100, variance_factor=9.0)
+    synth.generate(seed, write_dir=str(tmp_path / "in"), **gen)
+    tint, rec = refrun.run_recorded(str(tmp_path / "in"), str(tmp_path / "out"), "chrS", seed, **run)
+    g = synth.generate(seed, with_seq=False, **gen)
+    part = pack.pack_partition(g.iv_start, g.iv_end, g.read_exon_off, g.ex_ts, g.ex_te)
+    o = util.run_oracle(part, dict(run, ignore_ends=True))
+    assert o["error"] == 0, o["errmsg"]
+    assert int((np.asarray(o["prob_end"]) - np.asarray(o["prob_start"]) + 1).max()) > 60
+    assert np.array_equal(np.array(tint["final_positions"], np.int32), o["final_pos"])
+    for ri, (_, ridxs) in enumerate(tint["read_reps"]):
+        assert list(o["labels"][ri]) == tint["reads"][ridxs[0]]["data"]
