@@ -36,6 +36,12 @@ def load():
                  "fhost_rep_exon_off", "fhost_ex_ts", "fhost_ex_te"):
         getattr(L, name).restype = vp
         getattr(L, name).argtypes = [vp]
+    L.fhost_load_sidecar.restype = vp
+    L.fhost_load_sidecar.argtypes = [cpp, cpp, cpp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
+    L.fhost_n_from_sidecar.restype = ctypes.c_int32
+    L.fhost_n_from_sidecar.argtypes = [vp]
+    L.fhost_sidecar_write.restype = ctypes.c_int32
+    L.fhost_sidecar_write.argtypes = [vp, cpp, cpp, cpp, ctypes.c_int32]
     L.fhost_write.restype = ctypes.c_int32
     L.fhost_write.argtypes = [vp, vp, vp, vp, vp, cpp, ctypes.c_int32]
     _lib = L
@@ -58,9 +64,18 @@ def _view(ptr, n, dtype):
 class HostBatch:
     """Parsed partitions living in native memory; arrays() are views valid until close()."""
 
-    def __init__(self, split_paths, reads_paths, n_threads=1):
+    def __init__(self, split_paths, reads_paths, n_threads=1, sidecar_paths=None, verify_checksum=True):
+        """sidecar_paths: None (parse the TSVs) or one path-or-None per partition; a side-car that is missing,
+        stale or damaged silently falls back to the TSVs of that partition."""
         self._L = load()
-        self._h = self._L.fhost_load(_c_strings(split_paths), _c_strings(reads_paths), len(split_paths), int(n_threads))
+        self._paths = (list(split_paths), list(reads_paths))
+        if sidecar_paths is None:
+            self._h = self._L.fhost_load(_c_strings(split_paths), _c_strings(reads_paths), len(split_paths), int(n_threads))
+        else:
+            sc = (ctypes.c_char_p * len(sidecar_paths))()
+            sc[:] = [None if s is None else s.encode() for s in sidecar_paths]
+            self._h = self._L.fhost_load_sidecar(_c_strings(split_paths), _c_strings(reads_paths), sc, len(split_paths),
+                                                 int(n_threads), 1 if verify_checksum else 0)
         if not self._h:
             raise HostError("fhost_load: out of memory")
         err = self._L.fhost_error(self._h).decode()
@@ -69,6 +84,13 @@ class HostBatch:
             raise HostError(err)
         self.n_part = self._L.fhost_n_part(self._h)
         self.n_reads = self._L.fhost_n_reads(self._h)
+        self.n_from_sidecar = self._L.fhost_n_from_sidecar(self._h)
+
+    def write_sidecars(self, sidecar_paths, n_threads=1):
+        rc = self._L.fhost_sidecar_write(self._h, _c_strings(self._paths[0]), _c_strings(self._paths[1]),
+                                         _c_strings(sidecar_paths), int(n_threads))
+        if rc != 0:
+            raise HostError(self._L.fhost_error(self._h).decode())
 
     def arrays(self):
         L, h = self._L, self._h

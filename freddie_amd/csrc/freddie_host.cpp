@@ -11,6 +11,7 @@
 #include <atomic>
 #include <cstdio>
 #include <cstring>
+#include <sys/stat.h>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -358,6 +359,193 @@ void annotate_read(const Partition &P, const Read &r, const unsigned char *data,
     gaps.erase(std::unique(gaps.begin(), gaps.end()), gaps.end());
 }
 
+// ---- binary side-car of a partition ------------------------------------------
+// split_<contig>_<tint>.fsc holds what parse_partition() produces from the two TSVs: the flat exon / CIGAR arrays,
+// the read_reps grouping and the sequences packed two bits per base (bytes other than upper-case ACGT are kept in
+// an exception list, so the round trip is exact).  It is bound to its TSVs by their sizes and mtimes and is only an
+// accelerator: the TSVs stay the stage's contract (py/freddie_split.py:445-481 writes them, :121-185 reads them).
+const char FSC_MAGIC[8] = {'F', 'S', 'C', '1', 0, 0, 0, 0};
+
+struct FscHeader {
+    char magic[8];
+    uint64_t split_size; int64_t split_mtime_ns; uint64_t reads_size; int64_t reads_mtime_ns;
+    int64_t id, read_count;
+    uint64_t n_iv, n_reads, n_exons, n_cigar, n_reps, name_bytes, chr_bytes, read_chr_bytes, seq_bases, n_exc;
+    uint64_t payload_bytes, checksum;
+};
+
+bool stat_file(const char *path, uint64_t &size, int64_t &mtime_ns) {
+    struct stat st;
+    if (stat(path, &st) != 0) return false;
+    size = (uint64_t)st.st_size;
+    mtime_ns = (int64_t)st.st_mtim.tv_sec * 1000000000ll + (int64_t)st.st_mtim.tv_nsec;
+    return true;
+}
+
+uint64_t fsc_checksum(const unsigned char *p, size_t n) {       // FNV-1a over 8-byte words (payload is 8-aligned)
+    uint64_t h = 1469598103934665603ull;
+    size_t w = n / 8;
+    for (size_t i = 0; i < w; ++i) { uint64_t v; memcpy(&v, p + i * 8, 8); h = (h ^ v) * 1099511628211ull; }
+    for (size_t i = w * 8; i < n; ++i) h = (h ^ p[i]) * 1099511628211ull;
+    return h;
+}
+
+struct Sink {
+    std::string buf;
+    template <typename T> void put(const T *p, size_t n) {
+        buf.append(reinterpret_cast<const char *>(p), n * sizeof(T));
+        buf.append((8 - buf.size() % 8) % 8, '\0');
+    }
+};
+struct Source {
+    const unsigned char *p, *end;
+    bool ok = true;
+    template <typename T> void get(std::vector<T> &v, size_t n) {
+        size_t bytes = n * sizeof(T), padded = bytes + (8 - bytes % 8) % 8;
+        if (!ok || (size_t)(end - p) < padded) { ok = false; return; }
+        v.resize(n);
+        if (bytes) memcpy(v.data(), p, bytes);
+        p += padded;
+    }
+};
+
+inline int base_code(unsigned char c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : -1; }
+
+bool write_sidecar(const Partition &P, const char *split_path, const char *reads_path, const char *out_path, std::string &err) {
+    FscHeader h;
+    memset(&h, 0, sizeof h);
+    memcpy(h.magic, FSC_MAGIC, 8);
+    if (!stat_file(split_path, h.split_size, h.split_mtime_ns) || !stat_file(reads_path, h.reads_size, h.reads_mtime_ns)) {
+        err = std::string("cannot stat ") + split_path + " / " + reads_path; return false;
+    }
+    const size_t n = P.reads.size();
+    std::vector<int64_t> read_id(n);
+    std::vector<int32_t> read_ex_off(n + 1), read_rep(n);
+    std::vector<uint8_t> strand(n);
+    std::vector<uint32_t> name_off(n + 1), chr_off;
+    std::vector<uint64_t> seq_off(n + 1), exc_pos;
+    std::vector<uint8_t> exc_ch;
+    std::string names, read_chrs;
+    bool chr_differs = false;
+    for (const Read &r : P.reads) chr_differs |= r.chr != P.chr;
+    uint64_t bases = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const Read &r = P.reads[i];
+        read_id[i] = r.id; read_ex_off[i] = r.ex0; read_rep[i] = r.rep; strand[i] = (uint8_t)r.strand;
+        name_off[i] = (uint32_t)names.size(); names += r.name;
+        if (chr_differs) { chr_off.push_back((uint32_t)read_chrs.size()); read_chrs += r.chr; }
+        seq_off[i] = bases; bases += r.seq.size();
+    }
+    read_ex_off[n] = (int32_t)P.ts.size(); name_off[n] = (uint32_t)names.size(); seq_off[n] = bases;
+    if (chr_differs) chr_off.push_back((uint32_t)read_chrs.size());
+    std::vector<uint8_t> packed((size_t)((bases + 3) / 4), 0);
+    for (size_t i = 0; i < n; ++i) {
+        const std::string &q = P.reads[i].seq;
+        uint64_t g = seq_off[i];
+        for (size_t t = 0; t < q.size(); ++t, ++g) {
+            int c = base_code((unsigned char)q[t]);
+            if (c < 0) { exc_pos.push_back(g); exc_ch.push_back((uint8_t)q[t]); c = 0; }
+            packed[(size_t)(g >> 2)] |= (uint8_t)(c << ((g & 3) * 2));
+        }
+    }
+    h.id = P.id; h.read_count = P.read_count;
+    h.n_iv = P.iv_s.size(); h.n_reads = n; h.n_exons = P.ts.size(); h.n_cigar = P.cig_len.size();
+    h.n_reps = P.rep_first_read.size(); h.name_bytes = names.size(); h.chr_bytes = P.chr.size();
+    h.read_chr_bytes = chr_differs ? read_chrs.size() + 1 : 0;       // 0 = every read carries the tint's chr
+    h.seq_bases = bases; h.n_exc = exc_pos.size();
+    Sink s;
+    s.put(P.chr.data(), P.chr.size());
+    s.put(P.iv_s.data(), P.iv_s.size()); s.put(P.iv_e.data(), P.iv_e.size());
+    s.put(read_id.data(), n); s.put(read_ex_off.data(), n + 1); s.put(read_rep.data(), n); s.put(strand.data(), n);
+    s.put(name_off.data(), n + 1); s.put(names.data(), names.size());
+    if (chr_differs) { s.put(chr_off.data(), n + 1); s.put(read_chrs.data(), read_chrs.size()); }
+    s.put(P.ts.data(), P.ts.size()); s.put(P.te.data(), P.te.size()); s.put(P.qs.data(), P.qs.size()); s.put(P.qe.data(), P.qe.size());
+    s.put(P.cig_off.data(), P.cig_off.size()); s.put(P.cig_len.data(), P.cig_len.size()); s.put(P.cig_op.data(), P.cig_op.size());
+    s.put(P.rep_first_read.data(), P.rep_first_read.size()); s.put(P.rep_weight.data(), P.rep_weight.size());
+    s.put(seq_off.data(), n + 1); s.put(packed.data(), packed.size());
+    s.put(exc_pos.data(), exc_pos.size()); s.put(exc_ch.data(), exc_ch.size());
+    h.payload_bytes = s.buf.size();
+    h.checksum = fsc_checksum(reinterpret_cast<const unsigned char *>(s.buf.data()), s.buf.size());
+    std::string tmp = std::string(out_path) + ".tmp";
+    FILE *f = fopen(tmp.c_str(), "wb");
+    bool ok = f && fwrite(&h, sizeof h, 1, f) == 1 && fwrite(s.buf.data(), 1, s.buf.size(), f) == s.buf.size();
+    if (f) ok = fclose(f) == 0 && ok;
+    if (ok) ok = rename(tmp.c_str(), out_path) == 0;                 // readers never see a half-written side-car
+    if (!ok) { remove(tmp.c_str()); err = std::string("cannot write ") + out_path; }
+    return ok;
+}
+
+// Returns true when the side-car exists, belongs to exactly these TSVs and is intact; P is then what
+// parse_partition() would have produced.  Any mismatch returns false (the caller parses the TSVs instead).
+bool load_sidecar(const char *sidecar_path, const char *split_path, const char *reads_path, Partition &P, bool verify) {
+    std::string blob;
+    if (!read_file(sidecar_path, blob) || blob.size() < sizeof(FscHeader)) return false;
+    FscHeader h;
+    memcpy(&h, blob.data(), sizeof h);
+    if (memcmp(h.magic, FSC_MAGIC, 8) != 0 || blob.size() != sizeof h + h.payload_bytes) return false;
+    uint64_t sz; int64_t mt;
+    if (!stat_file(split_path, sz, mt) || sz != h.split_size || mt != h.split_mtime_ns) return false;
+    if (!stat_file(reads_path, sz, mt) || sz != h.reads_size || mt != h.reads_mtime_ns) return false;
+    const unsigned char *pay = reinterpret_cast<const unsigned char *>(blob.data()) + sizeof h;
+    if (verify && fsc_checksum(pay, (size_t)h.payload_bytes) != h.checksum) return false;
+    const size_t n = (size_t)h.n_reads;
+    if (h.n_reads > (1ull << 31) || h.n_exons > (1ull << 31) || h.n_cigar > (1ull << 31) || h.n_reps > h.n_reads ||
+        (int64_t)h.n_reads != h.read_count) return false;
+    Source s{pay, pay + h.payload_bytes};
+    std::vector<char> chr, names, read_chrs;
+    std::vector<int64_t> read_id;
+    std::vector<int32_t> read_ex_off, read_rep;
+    std::vector<uint8_t> strand, packed, exc_ch;
+    std::vector<uint32_t> name_off, chr_off;
+    std::vector<uint64_t> seq_off, exc_pos;
+    s.get(chr, (size_t)h.chr_bytes);
+    s.get(P.iv_s, (size_t)h.n_iv); s.get(P.iv_e, (size_t)h.n_iv);
+    s.get(read_id, n); s.get(read_ex_off, n + 1); s.get(read_rep, n); s.get(strand, n);
+    s.get(name_off, n + 1); s.get(names, (size_t)h.name_bytes);
+    if (h.read_chr_bytes) { s.get(chr_off, n + 1); s.get(read_chrs, (size_t)h.read_chr_bytes - 1); }
+    s.get(P.ts, (size_t)h.n_exons); s.get(P.te, (size_t)h.n_exons); s.get(P.qs, (size_t)h.n_exons); s.get(P.qe, (size_t)h.n_exons);
+    s.get(P.cig_off, (size_t)h.n_exons + 1); s.get(P.cig_len, (size_t)h.n_cigar); s.get(P.cig_op, (size_t)h.n_cigar);
+    s.get(P.rep_first_read, (size_t)h.n_reps); s.get(P.rep_weight, (size_t)h.n_reps);
+    s.get(seq_off, n + 1); s.get(packed, (size_t)((h.seq_bases + 3) / 4));
+    s.get(exc_pos, (size_t)h.n_exc); s.get(exc_ch, (size_t)h.n_exc);
+    if (!s.ok || s.p != s.end) return false;
+    // structural checks: every offset table must be monotone and end at its array's size
+    if (read_ex_off[0] != 0 || read_ex_off[n] != (int32_t)h.n_exons || name_off[n] != h.name_bytes || seq_off[n] != h.seq_bases ||
+        P.cig_off[(size_t)h.n_exons] != (int32_t)h.n_cigar) return false;
+    for (size_t i = 0; i < n; ++i) {
+        if (read_ex_off[i] > read_ex_off[i + 1] || name_off[i] > name_off[i + 1] || seq_off[i] > seq_off[i + 1]) return false;
+        if (read_rep[i] < 0 || (uint64_t)read_rep[i] >= h.n_reps) return false;
+        if (h.read_chr_bytes && (chr_off[i] > chr_off[i + 1] || chr_off[i + 1] > read_chrs.size())) return false;
+    }
+    for (size_t x = 0; x < (size_t)h.n_exons; ++x) if (P.cig_off[x] < 0 || P.cig_off[x] > P.cig_off[x + 1]) return false;
+    for (size_t r = 0; r < (size_t)h.n_reps; ++r) if (P.rep_first_read[r] < 0 || (size_t)P.rep_first_read[r] >= n) return false;
+    for (size_t k = 0; k < exc_pos.size(); ++k) if (exc_pos[k] >= h.seq_bases || (k && exc_pos[k] <= exc_pos[k - 1])) return false;
+    P.chr.assign(chr.begin(), chr.end());
+    P.id = h.id; P.read_count = h.read_count;
+    static const char LUT[4] = {'A', 'C', 'G', 'T'};
+    static char QUAD[256][4];
+    static std::once_flag quad_once;
+    std::call_once(quad_once, []() { for (int b = 0; b < 256; ++b) for (int k = 0; k < 4; ++k) QUAD[b][k] = LUT[(b >> (2 * k)) & 3]; });
+    P.reads.resize(n);
+    size_t e = 0;
+    for (size_t i = 0; i < n; ++i) {
+        Read &r = P.reads[i];
+        r.id = read_id[i]; r.tint = h.id; r.strand = (char)strand[i]; r.ex0 = read_ex_off[i]; r.ex1 = read_ex_off[i + 1]; r.rep = read_rep[i];
+        r.name.assign(names.data() + name_off[i], names.data() + name_off[i + 1]);
+        if (h.read_chr_bytes) r.chr.assign(read_chrs.data() + chr_off[i], read_chrs.data() + chr_off[i + 1]);
+        else r.chr = P.chr;
+        const uint64_t g0 = seq_off[i], len = seq_off[i + 1] - g0;
+        r.seq.resize((size_t)len);
+        char *dst = &r.seq[0];
+        uint64_t t = 0;
+        for (; t < len && ((g0 + t) & 3); ++t) { uint64_t g = g0 + t; dst[t] = LUT[(packed[(size_t)(g >> 2)] >> ((g & 3) * 2)) & 3]; }
+        for (; t + 4 <= len; t += 4) memcpy(dst + t, QUAD[packed[(size_t)((g0 + t) >> 2)]], 4);      // one packed byte = 4 bases
+        for (; t < len; ++t) { uint64_t g = g0 + t; dst[t] = LUT[(packed[(size_t)(g >> 2)] >> ((g & 3) * 2)) & 3]; }
+        while (e < exc_pos.size() && exc_pos[e] < g0 + len) { dst[exc_pos[e] - g0] = (char)exc_ch[e]; ++e; }
+    }
+    return true;
+}
+
 template <typename F>
 void parallel_for(int n, int n_threads, F fn) {
     if (n_threads < 1) n_threads = 1;
@@ -378,17 +566,11 @@ struct fhost_batch {
     std::vector<int64_t> part_iv_off, part_rep_off, rep_exon_off;
     std::vector<int32_t> iv_start, iv_end, rep_weight, ex_ts, ex_te;
     int64_t n_reads = 0;
+    int32_t n_from_sidecar = 0;
 };
 
-extern "C" {
-
-fhost_batch *fhost_load(const char *const *split_paths, const char *const *reads_paths, int32_t n, int32_t n_threads) {
-    fhost_batch *b = new (std::nothrow) fhost_batch();
-    if (!b) return nullptr;
-    if (n <= 0) { b->err = "fhost_load: empty batch"; return b; }
-    b->parts.resize((size_t)n);
-    parallel_for(n, n_threads, [&](int i) { parse_partition(split_paths[i], reads_paths[i], b->parts[(size_t)i]); });
-    for (const Partition &P : b->parts) if (!P.err.empty()) { b->err = P.err; return b; }
+namespace {
+void flatten(fhost_batch *b) {
     b->part_iv_off.assign(1, 0); b->part_rep_off.assign(1, 0); b->rep_exon_off.assign(1, 0);
     for (const Partition &P : b->parts) {
         b->iv_start.insert(b->iv_start.end(), P.iv_s.begin(), P.iv_s.end());
@@ -403,7 +585,58 @@ fhost_batch *fhost_load(const char *const *split_paths, const char *const *reads
         b->part_rep_off.push_back((int64_t)b->rep_weight.size());
         b->n_reads += (int64_t)P.reads.size();
     }
+}
+}  // namespace
+
+extern "C" {
+
+fhost_batch *fhost_load(const char *const *split_paths, const char *const *reads_paths, int32_t n, int32_t n_threads) {
+    fhost_batch *b = new (std::nothrow) fhost_batch();
+    if (!b) return nullptr;
+    if (n <= 0) { b->err = "fhost_load: empty batch"; return b; }
+    b->parts.resize((size_t)n);
+    parallel_for(n, n_threads, [&](int i) { parse_partition(split_paths[i], reads_paths[i], b->parts[(size_t)i]); });
+    for (const Partition &P : b->parts) if (!P.err.empty()) { b->err = P.err; return b; }
+    flatten(b);
     return b;
+}
+
+fhost_batch *fhost_load_sidecar(const char *const *split_paths, const char *const *reads_paths, const char *const *sidecar_paths,
+                                int32_t n, int32_t n_threads, int32_t verify_checksum) {
+    fhost_batch *b = new (std::nothrow) fhost_batch();
+    if (!b) return nullptr;
+    if (n <= 0) { b->err = "fhost_load_sidecar: empty batch"; return b; }
+    b->parts.resize((size_t)n);
+    std::atomic<int> hits(0);
+    parallel_for(n, n_threads, [&](int i) {
+        Partition &P = b->parts[(size_t)i];
+        if (sidecar_paths && sidecar_paths[i] && load_sidecar(sidecar_paths[i], split_paths[i], reads_paths[i], P, verify_checksum != 0)) {
+            hits.fetch_add(1);
+            return;
+        }
+        P = Partition();
+        parse_partition(split_paths[i], reads_paths[i], P);
+    });
+    b->n_from_sidecar = hits.load();
+    for (const Partition &P : b->parts) if (!P.err.empty()) { b->err = P.err; return b; }
+    flatten(b);
+    return b;
+}
+
+int32_t fhost_n_from_sidecar(const fhost_batch *b) { return b->n_from_sidecar; }
+
+int32_t fhost_sidecar_write(fhost_batch *b, const char *const *split_paths, const char *const *reads_paths,
+                            const char *const *sidecar_paths, int32_t n_threads) {
+    if (!b || !b->err.empty()) return 1;
+    std::mutex err_mutex;
+    parallel_for((int)b->parts.size(), n_threads, [&](int p) {
+        std::string err;
+        if (!write_sidecar(b->parts[(size_t)p], split_paths[p], reads_paths[p], sidecar_paths[p], err)) {
+            std::lock_guard<std::mutex> lock(err_mutex);
+            if (b->err.empty()) b->err = err;
+        }
+    });
+    return b->err.empty() ? 0 : 2;
 }
 
 void fhost_free(fhost_batch *b) { delete b; }

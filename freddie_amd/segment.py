@@ -60,6 +60,9 @@ def parse_args(argv=None):
     ap.add_argument("--devices", type=str, default=None,
                     help="Comma-separated GPU ordinals, one worker per entry (overrides --gpus; e.g. 0,1,2,3)")
     ap.add_argument("--batch-reads", type=int, default=250000, help="Reads per device batch")
+    ap.add_argument("--sidecar", choices=("auto", "off", "write"), default="auto",
+                    help="Binary side-cars (split_*.fsc) of the split TSVs: auto = use the fresh ones that exist; "
+                         "write = also emit them for partitions that had to be parsed; off = always parse the TSVs")
     args = ap.parse_args(argv)
     assert 1 >= args.threshold_rate >= 0.5
     assert 10 > args.variance_factor > 0
@@ -401,13 +404,25 @@ def set_context_params(ctx, params):
                    np.asarray(smoothed_threshold, np.float64))
 
 
-def load_batch_native(jobs, threads=1):
-    """Parse the partitions of a batch with the native host library (multi-threaded)."""
+def sidecar_path(split_tsv):
+    """split_<contig>_<tint>.tsv -> split_<contig>_<tint>.fsc (binary side-car, include/freddie_host.h)."""
+    return split_tsv[:-4] + ".fsc"
+
+
+def load_batch_native(jobs, threads=1, sidecar="off"):
+    """Load the partitions of a batch with the native host library (multi-threaded): from their binary side-cars
+    where those are fresh (``sidecar`` auto / write), else by parsing the TSVs."""
     from . import _host
     paths = [_job_paths(j) for j in jobs]
     for _, _, _, log in paths:
         open(log, "w+").close()                      # the reference leaves an empty .log per partition (:695)
-    return _host.HostBatch([p[0] for p in paths], [p[1] for p in paths], n_threads=threads)
+    if sidecar == "off":
+        return _host.HostBatch([p[0] for p in paths], [p[1] for p in paths], n_threads=threads)
+    scs = [sidecar_path(p[0]) for p in paths]
+    hb = _host.HostBatch([p[0] for p in paths], [p[1] for p in paths], n_threads=threads, sidecar_paths=scs)
+    if sidecar == "write" and hb.n_from_sidecar < hb.n_part:
+        hb.write_sidecars(scs, n_threads=threads)
+    return hb
 
 
 def run_segment_batch(jobs, params, ctx, threads=1, host_batch=None, params_set=False):
@@ -438,7 +453,7 @@ def run_segment_batch_python(jobs, params, ctx):
     return [(j[2], j[3]) for j in jobs]
 
 
-def run_batches(batches, params, ctx, threads, on_done):
+def run_batches(batches, params, ctx, threads, on_done, sidecar="off"):
     """Pipelined driver of one GPU: while the GPU works on batch i, batch i+1 is parsed and batch i-1 is
     annotated and written by host threads (the native calls release the GIL)."""
     from concurrent.futures import ThreadPoolExecutor
@@ -446,7 +461,7 @@ def run_batches(batches, params, ctx, threads, on_done):
         return
     set_context_params(ctx, params)
     with ThreadPoolExecutor(max_workers=2) as pool:
-        nxt = pool.submit(load_batch_native, batches[0], threads)
+        nxt = pool.submit(load_batch_native, batches[0], threads, sidecar)
         pending_write = None
 
         def finish(hb, res, jobs):
@@ -459,7 +474,7 @@ def run_batches(batches, params, ctx, threads, on_done):
         for i, jobs in enumerate(batches):
             hb = nxt.result()
             if i + 1 < len(batches):
-                nxt = pool.submit(load_batch_native, batches[i + 1], threads)
+                nxt = pool.submit(load_batch_native, batches[i + 1], threads, sidecar)
             ctx.upload(**hb.arrays())
             ctx.run()
             res = ctx.download()
@@ -506,11 +521,11 @@ def make_batches(jobs_with_cost, bytes_per_batch):
     return batches
 
 
-def _gpu_worker(device, jobs_with_cost, params, batch_bytes, threads, queue):
+def _gpu_worker(device, jobs_with_cost, params, batch_bytes, threads, queue, sidecar="off"):
     from . import _lib
     ctx = _lib.Context(device)
     try:
-        run_batches(make_batches(jobs_with_cost, batch_bytes), params, ctx, threads, queue.put)
+        run_batches(make_batches(jobs_with_cost, batch_bytes), params, ctx, threads, queue.put, sidecar)
     finally:
         ctx.close()
         queue.put(None)
@@ -552,7 +567,7 @@ def main(argv=None):
         ctx = _lib.Context(devices[0])
         jobs = [((split_dir, args.outdir, parts[i][0], parts[i][1]), parts[i][2]) for i in assign[0]]
         try:
-            run_batches(make_batches(jobs, batch_bytes), params, ctx, args.threads, lambda _done: report())
+            run_batches(make_batches(jobs, batch_bytes), params, ctx, args.threads, lambda _done: report(), args.sidecar)
         finally:
             ctx.close()
         return
@@ -561,7 +576,7 @@ def main(argv=None):
     procs = []
     for w, dev in enumerate(devices):
         jobs = [((split_dir, args.outdir, parts[i][0], parts[i][1]), parts[i][2]) for i in assign[w]]
-        pr = mp.Process(target=_gpu_worker, args=(dev, jobs, params, batch_bytes, args.threads, queue))
+        pr = mp.Process(target=_gpu_worker, args=(dev, jobs, params, batch_bytes, args.threads, queue, args.sidecar))
         pr.start()
         procs.append(pr)
     import queue as queue_mod

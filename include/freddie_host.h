@@ -8,6 +8,7 @@
  *   read_sequence()   py/freddie_segment.py:174-185
  *   get_unaligned_gaps_and_polyA() and helpers   py/freddie_segment.py:289-472
  *   the writer part of run_segment()             py/freddie_segment.py:703-732
+ * and (row N2) a binary side-car of a partition's two TSVs that the loader takes instead of parsing them again.
  * It does no segmentation arithmetic (that is libfreddie_seg.so's job, on the GPU).
  */
 #ifndef FREDDIE_HOST_H
@@ -47,6 +48,22 @@ const int32_t *fhost_ex_te(const fhost_batch *b);
  * which reference assertion would have fired. */
 int32_t fhost_write(fhost_batch *b, const int64_t *part_final_off, const int32_t *final_pos, const int64_t *label_off,
                     const uint8_t *labels, const char *const *out_paths, int32_t n_threads);
+
+/* ---- binary side-car ------------------------------------------------------------
+ * split_<contig>_<tint>.fsc, written next to the TSVs that py/freddie_split.py:445-481 produces, holds the parsed
+ * form of both files (flat exon / CIGAR arrays, the read_reps grouping of py/freddie_segment.py:165-170, sequences
+ * at two bits per base with an exception list for bytes other than ACGT).  A side-car is used only when the sizes
+ * and mtimes recorded in it equal those of its two TSVs (and, with verify_checksum, its payload checksum holds);
+ * otherwise the TSVs are parsed, so results never depend on whether side-cars exist. */
+
+/* Like fhost_load(); sidecar_paths may be NULL, and any entry may be NULL. */
+fhost_batch *fhost_load_sidecar(const char *const *split_paths, const char *const *reads_paths,
+                                const char *const *sidecar_paths, int32_t n, int32_t n_threads, int32_t verify_checksum);
+int32_t fhost_n_from_sidecar(const fhost_batch *b);   /* partitions of the batch that came from a side-car */
+
+/* Write the side-car of every partition of a loaded batch (atomically: temp file + rename).  Returns 0 on success. */
+int32_t fhost_sidecar_write(fhost_batch *b, const char *const *split_paths, const char *const *reads_paths,
+                            const char *const *sidecar_paths, int32_t n_threads);
 
 #ifdef __cplusplus
 }

@@ -117,3 +117,31 @@ def test_cli_multi_worker_scatter(tmp_path):
         a = open(os.path.join(str(tmp_path / "one"), "chrS", f), "rb").read()
         b = open(os.path.join(str(tmp_path / "two"), "chrS", f), "rb").read()
         assert a == b and len(a) > 0
+
+
+def test_cli_sidecar_runs_are_byte_identical(tmp_path):
+    """Row N2: `--sidecar write` on the first pass, `auto` on the second (now loading the side-cars, no TSV parsing),
+    `off` as the control -- all three give the reference's bytes for a golden case and identical files for synthetic
+    partitions."""
+    from freddie_amd import synth
+    name = "g1_retention"
+    g = goldens.load(name)
+    d, contig, tid = input_dir(name, tmp_path)
+    for i in range(4):
+        synth.generate(500 + i, n_reads=150, n_exons=40, rp=0.1, write_dir=d, contig=contig)
+    case = goldens.manifest()["cases"][name]["run"]
+    outs = {}
+    for mode in ("write", "auto", "off"):
+        out = str(tmp_path / mode)
+        cmd = [sys.executable, os.path.join(ROOT, "py", "freddie_segment.py"), "-s", d, "-o", out, "--gpus", "1", "-t", "2",
+               "--sidecar", mode, "-sd", str(case["sigma"]), "-tp", str(case["threshold_rate"]),
+               "-vf", str(case["variance_factor"]), "-mps", str(case["max_problem_size"]),
+               "-lo", str(case["min_read_support_outside"])]
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        assert res.returncode == 0, res.stderr[-2000:]
+        outs[mode] = {f: open(os.path.join(out, contig, f), "rb").read() for f in sorted(os.listdir(os.path.join(out, contig)))
+                      if f.endswith(".tsv")}
+        if mode == "write":
+            assert len([f for f in os.listdir(os.path.join(d, contig)) if f.endswith(".fsc")]) == 5
+    assert outs["write"] == outs["auto"] == outs["off"] and len(outs["off"]) == 5
+    assert outs["auto"]["segment_%s_%d.tsv" % (contig, tid)] == g["segment_tsv"].tobytes()

@@ -71,3 +71,120 @@ def test_native_parser_rejects_malformed(tmp_path):
         sp.write_text(bad)
         with pytest.raises(_host.HostError):
             _host.HostBatch([str(sp)], [str(rp)])
+
+
+# ---- binary side-car (row N2): same arrays, same output bytes, never trusted when stale or damaged ----------------
+def _write_with(hb, g, out):
+    F = len(g["final_positions"])
+    hb.write(np.array([0, F]), g["final_positions"], np.array([0, g["labels"].size]),
+             (g["labels"] + ord("0")).astype(np.uint8).ravel(), [out], n_threads=2)
+    return open(out, "rb").read()
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_sidecar_round_trip_matches_reference(name, tmp_path):
+    g = goldens.load(name)
+    d, contig, tid = input_dir(name, tmp_path)
+    sp, rp = paths(d, contig, tid)
+    sc = sp[:-4] + ".fsc"
+    hb = _host.HostBatch([sp], [rp])
+    try:
+        assert hb.n_from_sidecar == 0
+        hb.write_sidecars([sc])
+        a0 = {k: v.copy() for k, v in hb.arrays().items()}
+    finally:
+        hb.close()
+    hb = _host.HostBatch([sp], [rp], sidecar_paths=[sc])
+    try:
+        assert hb.n_from_sidecar == 1 and hb.n_reads == len(g["read_rep"])
+        a1 = hb.arrays()
+        for key in a0:
+            assert np.array_equal(a0[key], a1[key]), key
+        assert _write_with(hb, g, str(tmp_path / "out.tsv")) == g["segment_tsv"].tobytes()
+    finally:
+        hb.close()
+
+
+def test_sidecar_stale_or_damaged_falls_back_to_the_tsvs(tmp_path):
+    name = NAMES[0]
+    g = goldens.load(name)
+    d, contig, tid = input_dir(name, tmp_path)
+    sp, rp = paths(d, contig, tid)
+    sc = sp[:-4] + ".fsc"
+    hb = _host.HostBatch([sp], [rp]); hb.write_sidecars([sc]); hb.close()
+    good = open(sc, "rb").read()
+    # damaged payload: the checksum catches it
+    bad = bytearray(good); bad[len(bad) // 2] ^= 0x40
+    open(sc, "wb").write(bytes(bad))
+    hb = _host.HostBatch([sp], [rp], sidecar_paths=[sc])
+    assert hb.n_from_sidecar == 0
+    assert _write_with(hb, g, str(tmp_path / "o1.tsv")) == g["segment_tsv"].tobytes()
+    hb.close()
+    # truncated file and foreign file
+    for blob in (good[:len(good) - 8], b"not a side-car", b""):
+        open(sc, "wb").write(blob)
+        hb = _host.HostBatch([sp], [rp], sidecar_paths=[sc]); assert hb.n_from_sidecar == 0; hb.close()
+    # intact side-car, but the TSV changed after it was written (mtime differs)
+    open(sc, "wb").write(good)
+    hb = _host.HostBatch([sp], [rp], sidecar_paths=[sc]); assert hb.n_from_sidecar == 1; hb.close()
+    st = os.stat(rp)
+    os.utime(rp, ns=(st.st_atime_ns, st.st_mtime_ns + 1_000_000))
+    hb = _host.HostBatch([sp], [rp], sidecar_paths=[sc]); assert hb.n_from_sidecar == 0; hb.close()
+    # missing side-car and None entries
+    hb = _host.HostBatch([sp, sp], [rp, rp], sidecar_paths=[str(tmp_path / "absent.fsc"), None])
+    assert hb.n_from_sidecar == 0 and hb.n_part == 2
+    hb.close()
+
+
+def test_sidecar_keeps_non_acgt_bytes(tmp_path):
+    """Sequences with N, lower case and IUPAC letters: the exception list makes the round trip exact, so the poly-A
+    search (which compares bytes) sees the same sequence either way."""
+    sp = tmp_path / "split_c_7.tsv"; rp = tmp_path / "reads_c_7.tsv"
+    seqs = ["ACGTNNacgtRYKM" + "A" * 30 + "N" + "A" * 5 + "CCCC" * 30 + "t" * 25,
+            "T" * 26 + "G" * 140 + "N",
+            "n" + "ACGT" * 40]
+    lines = ["#c\t7\t100-300\t3\n"]
+    for i, s in enumerate(seqs):
+        lines.append("%d\tr%d\tc\t%s\t7\t120-180:40-100:60M\t200-260:100-160:60M\n" % (i, i, "+-"[i % 2]))
+    sp.write_text("".join(lines))
+    rp.write_text("".join("%d\tc\t7\t%s\n" % (i, s) for i, s in enumerate(seqs)))
+    sc = str(tmp_path / "split_c_7.fsc")
+    fp = np.array([100, 150, 190, 230, 300], np.int32)
+    labels = np.frombuffer(b"1011", np.uint8)                  # one rep (all reads share their intervals)
+    outs = []
+    for use_sc in (False, True):
+        hb = _host.HostBatch([str(sp)], [str(rp)], sidecar_paths=[sc] if use_sc else None)
+        assert hb.n_from_sidecar == (1 if use_sc else 0)
+        if not use_sc:
+            hb.write_sidecars([sc])
+        out = str(tmp_path / ("o%d.tsv" % use_sc))
+        hb.write(np.array([0, 5]), fp, np.array([0, 4]), labels, [out])
+        hb.close()
+        outs.append(open(out, "rb").read())
+    assert outs[0] == outs[1] and b"SSC" in outs[0]
+
+
+def test_sidecar_tool_covers_a_split_directory(tmp_path):
+    import subprocess
+    import sys
+    from freddie_amd import synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = str(tmp_path / "split")
+    for i in range(5):
+        synth.generate(40 + i, n_reads=60, n_exons=30, rp=0.1, write_dir=d, contig="chr%d" % (i % 2))
+    tool = [sys.executable, os.path.join(root, "py", "freddie_sidecar.py"), "-s", d, "-t", "2", "--chunk", "2"]
+    res = subprocess.run(tool, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr[-1500:]
+    assert "5 partitions" in res.stdout
+    fsc = sorted(os.path.join(dp, f) for dp, _, fs in os.walk(d) for f in fs if f.endswith(".fsc"))
+    assert len(fsc) == 5 and not [f for dp, _, fs in os.walk(d) for f in fs if f.endswith(".tmp")]
+    stamps = [os.stat(f).st_mtime_ns for f in fsc]
+    assert subprocess.run(tool, capture_output=True, text=True).returncode == 0       # second run: nothing to redo
+    assert stamps == [os.stat(f).st_mtime_ns for f in fsc]
+    sp = [f[:-4] + ".tsv" for f in fsc]
+    rp = [os.path.join(os.path.dirname(f), "reads_" + os.path.basename(f)[6:-4] + ".tsv") for f in fsc]
+    a = _host.HostBatch(sp, rp, n_threads=2); b = _host.HostBatch(sp, rp, n_threads=2, sidecar_paths=fsc)
+    assert b.n_from_sidecar == 5
+    for k, v in a.arrays().items():
+        assert np.array_equal(v, b.arrays()[k]), k
+    a.close(); b.close()

@@ -21,6 +21,8 @@ ap.add_argument("--reads", type=int, default=500)
 ap.add_argument("--threads", type=int, default=8)
 ap.add_argument("--keep", default=None)
 ap.add_argument("--generate-only", action="store_true")
+ap.add_argument("--sidecar", default="off", choices=("auto", "off", "write"))
+ap.add_argument("--repeat", type=int, default=1)
 args = ap.parse_args()
 work = args.keep or tempfile.mkdtemp(prefix="e2e_")
 split = os.path.join(work, "split")
@@ -32,14 +34,17 @@ if not os.path.isdir(split):
 if args.generate_only:
     sys.exit(0)
 out = os.path.join(work, "out")
-shutil.rmtree(out, ignore_errors=True)
-t0 = time.time()
-subprocess.check_call([sys.executable, os.path.join(ROOT, "py", "freddie_segment.py"), "-s", split, "-o", out,
-                       "-t", str(args.threads), "--gpus", "1"], stdout=subprocess.DEVNULL)
-dt = time.time() - t0
 n = args.partitions * args.reads
-size = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(split) for f in fs)
-print("e2e: %d reads in %d partitions, %.2f s wall (incl. interpreter + context start-up), %.0f reads/s, input %.1f MB" % (
-    n, args.partitions, dt, n / dt, size / 1e6))
+for rep in range(args.repeat):
+    shutil.rmtree(out, ignore_errors=True)
+    t0 = time.time()
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "py", "freddie_segment.py"), "-s", split, "-o", out,
+                           "-t", str(args.threads), "--gpus", "1", "--sidecar", args.sidecar], stdout=subprocess.DEVNULL)
+    dt = time.time() - t0
+    size = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(split) for f in fs if f.endswith(".tsv"))
+    fsc = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(split) for f in fs if f.endswith(".fsc"))
+    print("e2e[--sidecar %s, run %d]: %d reads in %d partitions, %.2f s wall (incl. interpreter + context start-up), "
+          "%.0f reads/s, TSV input %.1f MB, side-cars %.1f MB" % (args.sidecar, rep, n, args.partitions, dt, n / dt,
+                                                                   size / 1e6, fsc / 1e6))
 if not args.keep:
     shutil.rmtree(work, ignore_errors=True)
