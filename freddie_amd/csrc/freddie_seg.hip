@@ -2225,7 +2225,7 @@ struct fseg_ctx {
         d_rep_exon_off, d_ex_ts, d_ex_te, d_lane_rep, d_lane_start, d_lane_pmax, d_tile_iv, d_tile_y0, d_w_main,
         d_w_refine, d_h_table;
     // device buffers: position-sized
-    DevBuf d_y_raw, d_y, d_flag, d_cflag, d_v, d_scan_state, d_bsum, d_g, d_pk, d_pf, d_kp, d_final_flag;
+    DevBuf d_y_raw, d_y, d_flag, d_cflag, d_v, d_scan_state, d_bsum, d_bsum_side, d_g, d_pk, d_pf, d_kp, d_final_flag;
     // partition-sized
     DevBuf d_blk_iv0;          // interval of the first position of every scan block (+ a sentinel)
     DevBuf d_hc_part, d_hc_p0, d_hc_n, d_hc_glo, d_hc_ghi, d_hc_llo, d_hc_lhi;
@@ -2257,6 +2257,13 @@ struct fseg_ctx {
     int n_graphs = 0;   // few DP problems in the previous run: merge the per-size-class launches
     hipEvent_t ev[ST_COUNT + 1] = {};
     float stage_ms[ST_REPORTED] = {};
+    // Independent kernels of one run (threshold | candidates, pair thresholds | coverage, the scoring size classes,
+    // the DP classes) go to side streams between a fork and a join, so a captured run becomes a graph with parallel
+    // branches (FSEG_NO_FORK=1 keeps everything on the one stream).
+    static constexpr int kSide = 2, kForkEvents = 16;
+    hipStream_t side[kSide] = {};
+    hipEvent_t fj[kForkEvents] = {};
+    bool use_fork = true;
 };
 
 namespace {
@@ -2356,6 +2363,29 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
     const i64 K = c->K, NPOS = c->NPOS;
     Status *st = c->d_status.as<Status>();
     auto mark = [&](int i) { if (c->profiling && !in_parts) (void)hipEventRecord(c->ev[i], s); };
+    // fork(k): side stream k continues from here; join(k): the main stream waits for it.  Every fork is joined before
+    // the function returns, so a capture of the main stream ends with all branches merged.
+    // Small batches (one partition, few problems) are chains of launch-latency-sized kernels: branches only add
+    // cross-stream dependencies there (measured: config2 +4 %), so they stay on the one stream.
+    const bool forking = c->use_fork && !c->small_batch;
+    int fj_next = 0;
+    hipError_t fj_err = hipSuccess;
+    auto fj_event = [&]() { hipEvent_t e = c->fj[fj_next % fseg_ctx::kForkEvents]; ++fj_next; return e; };
+    auto fork = [&](int k) -> hipStream_t {
+        if (!forking) return s;
+        hipEvent_t e = fj_event();
+        hipError_t r = hipEventRecord(e, s);
+        if (r == hipSuccess) r = hipStreamWaitEvent(c->side[k], e, 0);
+        if (r != hipSuccess) fj_err = r;
+        return c->side[k];
+    };
+    auto join = [&](int k) {
+        if (!forking) return;
+        hipEvent_t e = fj_event();
+        hipError_t r = hipEventRecord(e, c->side[k]);
+        if (r == hipSuccess) r = hipStreamWaitEvent(s, e, 0);
+        if (r != hipSuccess) fj_err = r;
+    };
     const i64 avg_len = NPOS / (K > 0 ? K : 1);
     const int iv_threads = avg_len > 65536 ? 1024 : (avg_len > 16384 ? 256 : 64);
     int tile_grid = grid_for(c->n_tiles, 1, 8192);
@@ -2365,10 +2395,11 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
     // single-pass look-back scan while the chain of blocks is short; block sums + one scanning workgroup beyond that
     const bool scan_single = scan_nb <= c->scan_single_max;
     int *bsum = scan_single ? nullptr : c->d_bsum.as<int>();
-    auto scan_counts = [&](const unsigned char *flags, u64 *total_dev, i64 *off_last) {
+    int *bsum_side = scan_single ? nullptr : c->d_bsum_side.as<int>();     // block sums of the scan that runs on a side stream
+    auto scan_counts = [&](hipStream_t q, int *bs, const unsigned char *flags, u64 *total_dev, i64 *off_last) {
         if (scan_single) return;
-        hipLaunchKernelGGL(k_scan1, dim3(grid_for(scan_nb, 1, 4096)), dim3(256), 0, s, flags, NPOS, bsum);
-        hipLaunchKernelGGL(k_scan2, dim3(1), dim3(256), 0, s, bsum, scan_nb, total_dev, off_last);
+        hipLaunchKernelGGL(k_scan1, dim3(grid_for(scan_nb, 1, 4096)), dim3(256), 0, q, flags, NPOS, bs);
+        hipLaunchKernelGGL(k_scan2, dim3(1), dim3(256), 0, q, bs, scan_nb, total_dev, off_last);
     };
     int work_grid = grid_for(c->work_cap, 1, 4096);
     ProblemArrays pr{c->d_prob_iv.as<int>(), c->d_prob_start.as<int>(), c->d_prob_n.as<int>(),
@@ -2399,34 +2430,38 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
     else { FSEG_LAUNCH_SMOOTH(0); }
 #undef FSEG_LAUNCH_SMOOTH
     mark(2);
-    // S3a threshold
-    scan_counts(c->d_flag.as<unsigned char>(), &st->n_vals, nullptr);
-    hipLaunchKernelGGL(k_scan_emit<kEmitValues>, dim3(scan_grid), dim3(256), 0, s, c->d_flag.as<unsigned char>(), NPOS,
-                       bsum, scan_state, &st->n_vals, (i64 *)nullptr, &st->err, c->d_y.as<double>(), c->d_v.as<double>(), K, c->d_pos_off.as<i64>(),
+    // S3a threshold: needs only the smoothed signal, like the candidates (S3b) -- the two chains run side by side
+    {
+    hipStream_t q = fork(0);
+    scan_counts(q, bsum_side, c->d_flag.as<unsigned char>(), &st->n_vals, nullptr);
+    hipLaunchKernelGGL(k_scan_emit<kEmitValues>, dim3(scan_grid), dim3(256), 0, q, c->d_flag.as<unsigned char>(), NPOS,
+                       bsum_side, scan_state, &st->n_vals, (i64 *)nullptr, &st->err, c->d_y.as<double>(), c->d_v.as<double>(), K, c->d_pos_off.as<i64>(),
                        c->d_iv_start.as<int>(), c->d_blk_iv0.as<int>(), (int *)nullptr, (int *)nullptr, (i64 *)nullptr);
-    hipLaunchKernelGGL(k_voff, dim3(grid_for(n_part + 1, 1, 2048)), dim3(64), 0, s, n_part, c->d_part_iv_off.as<i64>(),
-                       c->d_pos_off.as<i64>(), NPOS, c->d_flag.as<unsigned char>(), bsum, scan_state, &st->n_vals,
+    hipLaunchKernelGGL(k_voff, dim3(grid_for(n_part + 1, 1, 2048)), dim3(64), 0, q, n_part, c->d_part_iv_off.as<i64>(),
+                       c->d_pos_off.as<i64>(), NPOS, c->d_flag.as<unsigned char>(), bsum_side, scan_state, &st->n_vals,
                        c->d_voff.as<i64>());
-    hipLaunchKernelGGL(k_vplan, dim3(1), dim3(256), 0, s, n_part, c->d_part_iv_off.as<i64>(), c->d_pos_off.as<i64>(), NPOS,
+    hipLaunchKernelGGL(k_vplan, dim3(1), dim3(256), 0, q, n_part, c->d_part_iv_off.as<i64>(), c->d_pos_off.as<i64>(), NPOS,
                        c->d_voff.as<i64>(), c->d_chunk_off.as<i64>(), st, c->chunk_cap);
     int chunk_grid = grid_for(c->chunk_cap, 1, 4096);
     double *csum0 = c->d_csum.as<double>(), *csum1 = csum0 + c->chunk_cap;
     for (int pass = 0; pass < 2; ++pass)
-        hipLaunchKernelGGL(k_vsum_chunks, dim3(chunk_grid), dim3(512), 0, s, n_part, c->d_voff.as<i64>(),
+        hipLaunchKernelGGL(k_vsum_chunks, dim3(chunk_grid), dim3(512), 0, q, n_part, c->d_voff.as<i64>(),
                            c->d_chunk_off.as<i64>(), c->d_v.as<double>(), csum0, pass, pass ? csum1 : csum0, c->chunk_cap);
-    hipLaunchKernelGGL(k_vsum_part, dim3(grid_for(n_part, 64, 1024)), dim3(64), 0, s, n_part, c->d_voff.as<i64>(),
+    hipLaunchKernelGGL(k_vsum_part, dim3(grid_for(n_part, 64, 1024)), dim3(64), 0, q, n_part, c->d_voff.as<i64>(),
                        c->d_chunk_off.as<i64>(), csum0, csum1, c->P.variance_factor, c->d_mean.as<double>(),
                        c->d_thr.as<double>(), c->chunk_cap);
+    }
     mark(3);
     // S3b candidates
     hipLaunchKernelGGL(k_peaks, dim3(tile_grid), dim3(256), 0, s, c->n_tiles, c->d_tile_iv.as<int>(), c->d_tile_y0.as<int>(),
                        c->d_pos_off.as<i64>(), c->d_y.as<double>(), c->d_cflag.as<unsigned char>(),
                        c->d_final_flag.as<unsigned char>(), c->d_part_has2.as<int>(), n_part);
-    scan_counts(c->d_cflag.as<unsigned char>(), &st->n_cand, c->d_cand_off.as<i64>() + K);
+    scan_counts(s, bsum, c->d_cflag.as<unsigned char>(), &st->n_cand, c->d_cand_off.as<i64>() + K);
     hipLaunchKernelGGL(k_scan_emit<kEmitPositions>, dim3(scan_grid), dim3(256), 0, s, c->d_cflag.as<unsigned char>(), NPOS,
                        bsum, scan_state + scan_nb, &st->n_cand, c->d_cand_off.as<i64>() + K, &st->err, (const double *)nullptr, (double *)nullptr, K, c->d_pos_off.as<i64>(),
                        c->d_iv_start.as<int>(), c->d_blk_iv0.as<int>(), c->d_cand_y.as<int>(), (int *)nullptr,
                        c->d_cand_off.as<i64>());
+    join(0);
     mark(4);
     // S4
     hipLaunchKernelGGL(k_fix, dim3(grid_for(K, 1, 8192)), dim3(iv_threads), 0, s, K, c->d_pos_off.as<i64>(),
@@ -2455,7 +2490,8 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
     mark(5);
     // S5
     if (c->prob_cap > 0) {
-        hipLaunchKernelGGL(k_pair_thresholds, dim3(grid_for(c->prob_cap, 1, 2048)), dim3(256), 0, s, st, pr,
+        hipStream_t q_thr = fork(0);
+        hipLaunchKernelGGL(k_pair_thresholds, dim3(grid_for(c->prob_cap, 1, 2048)), dim3(256), 0, q_thr, st, pr,
                            c->d_prob_desc.as<ProbDesc>(), c->prob_cap, c->d_cand_off.as<i64>(), c->d_cand_y.as<int>(),
                            c->d_h_table.as<double>(), c->P.h_len,
                            c->P.threshold_rate, c->d_pair_thr.as<int2>(), c->pair_cap, c->d_amb.as<unsigned>(),
@@ -2465,6 +2501,7 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
                            c->d_cand_y.as<int>(), c->d_iv_start.as<int>(), c->d_lane_rep.as<int>(),
                            c->d_rep_exon_off.as<i64>(), c->d_ex_ts.as<int>(), c->d_ex_te.as<int>(),
                            c->d_cov.as<unsigned>(), c->cov_cap, c->d_work_active.as<unsigned char>());
+        join(0);
     }
     mark(6);
     }   // do_pre
@@ -2474,20 +2511,22 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
 #else
 #define FSEG_TARG
 #endif
-#define FSEG_LAUNCH_SCORE(NMV, CLS, MAXWG)                                                                              \
+#define FSEG_LAUNCH_SCORE(Q, NMV, CLS, MAXWG)                                                                           \
         hipLaunchKernelGGL(k_score<NMV>, dim3(work_grid < (MAXWG) ? work_grid : (MAXWG)), dim3(ScoreCfg<NMV>::kThreads),  \
-                           score_lds_for((NMV) == kNMax ? c->nm_big : (NMV), (NMV) + 1), s, st, CLS,                                 \
+                           score_lds_for((NMV) == kNMax ? c->nm_big : (NMV), (NMV) + 1), Q, st, CLS,                                 \
                            ((NMV) == kNMax ? c->nm_big : (NMV)), pr, c->prob_cap, c->d_cls_items.as<int4>(),              \
                            c->d_prob_desc.as<ProbDesc>(), c->work_cap, c->d_cand_off.as<i64>(),                         \
                            c->d_cand_y.as<int>(), c->d_work_active.as<unsigned char>(), c->d_cov.as<unsigned>(),        \
                            c->cov_cap, c->d_pair_thr.as<int2>(), c->pair_cap, c->d_out.as<unsigned>(), c->tri_cap,      \
                            c->d_amb.as<unsigned>() FSEG_TARG)
         if (c->small_batch) {
-            FSEG_LAUNCH_SCORE(kNMax, -1, 512);       // few work items: one launch for every size class
-        } else {
-            FSEG_LAUNCH_SCORE(kNMax, 2, 512);        // big problems first: they are the long poles
-            FSEG_LAUNCH_SCORE(kClsMid, 1, 1280);
-            FSEG_LAUNCH_SCORE(kClsSmall, 0, 2048);
+            FSEG_LAUNCH_SCORE(s, kNMax, -1, 512);    // few work items: one launch for every size class
+        } else {                                     // the size classes own disjoint problems: three concurrent launches
+            hipStream_t q1 = fork(0), q0 = fork(1);
+            FSEG_LAUNCH_SCORE(s, kNMax, 2, 512);     // big problems: they are the long poles
+            FSEG_LAUNCH_SCORE(q1, kClsMid, 1, 1280);
+            FSEG_LAUNCH_SCORE(q0, kClsSmall, 0, 2048);
+            join(0); join(1);
         }
 #undef FSEG_LAUNCH_SCORE
         if (c->have_huge)
@@ -2502,7 +2541,7 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
         int dp_grid = grid_for(c->prob_cap, 1, 1024);
 #define FSEG_LAUNCH_DP(NMV, TV, OUTT, NM_RT, DPCLASS, MAXWG)                                                             \
         hipLaunchKernelGGL((k_dp<NMV, TV, OUTT>), dim3(dp_grid < (MAXWG) ? dp_grid : (MAXWG)), dim3(TV),                     \
-                           dp_lds_for(NM_RT, (int)sizeof(OUTT)), s, st, DPCLASS, NM_RT, c->d_dp_items.as<int>(), pr,          \
+                           dp_lds_for(NM_RT, (int)sizeof(OUTT)), ((NMV) == kDpSmall ? q_small : s), st, DPCLASS, NM_RT, c->d_dp_items.as<int>(), pr,          \
                            c->d_prob_desc.as<ProbDesc>(), c->prob_cap, c->d_cand_off.as<i64>(), c->d_cand_y.as<int>(), c->d_iv_part.as<int>(),               \
                            c->d_part_lane_off.as<i64>(), c->d_out.as<unsigned>(), c->tri_cap, c->d_amb.as<unsigned>(),        \
                            c->d_pair_thr.as<int2>(), c->pair_cap, c->P.min_read_support_outside,                              \
@@ -2510,6 +2549,7 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
         // 16-bit count tables unless some problem sees >= 65536 reads (then a previous run asked for the wide tables);
         // 512 threads (8 waves share the c2 loop) when the tables of the largest problem leave room for their scratch.
         // small_batch: one launch over every problem; otherwise one launch per DP class list.
+        hipStream_t q_small = c->small_batch ? s : fork(0);      // the two DP classes own disjoint problems
         if (c->dp_wide_counts) {
             const bool wide_wg = dp_lds_for(c->nm_big, 4) + 8 * 1024 <= kLdsPerWg;
             if (!c->small_batch) { FSEG_LAUNCH_DP(kDpSmall, 256, unsigned, kDpSmall, 0, 2048); }
@@ -2520,6 +2560,7 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
             FSEG_LAUNCH_DP(kNMax, 512, unsigned short, c->nm_big, c->small_batch ? -1 : 1, 512);
         }
 #undef FSEG_LAUNCH_DP
+        if (!c->small_batch) join(0);
         if (c->have_huge)
             hipLaunchKernelGGL(k_dp_huge, dim3(dp_grid < 256 ? dp_grid : 256), dim3(512), kHugeDpLds, s, st, c->d_dp_items.as<int>(),
                                pr, c->d_prob_desc.as<ProbDesc>(), c->prob_cap, c->d_cand_y.as<int>(), c->d_out.as<unsigned>(),
@@ -2537,7 +2578,7 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
                        c->d_w_refine.as<double>(), c->P.radius_refine, c->P.sigma, c->d_g.as<double>(), c->d_pk.as<int>(),
                        c->d_pf.as<unsigned char>(), c->d_kp.as<unsigned char>(), c->d_final_flag.as<unsigned char>());
     mark(9);
-    scan_counts(c->d_final_flag.as<unsigned char>(), &st->n_final, c->d_final_off.as<i64>() + K);
+    scan_counts(s, bsum, c->d_final_flag.as<unsigned char>(), &st->n_final, c->d_final_off.as<i64>() + K);
     hipLaunchKernelGGL(k_scan_emit<kEmitPositions>, dim3(scan_grid), dim3(256), 0, s, c->d_final_flag.as<unsigned char>(),
                        NPOS, bsum, scan_state + 2 * scan_nb, &st->n_final, c->d_final_off.as<i64>() + K, &st->err, (const double *)nullptr, (double *)nullptr, K, c->d_pos_off.as<i64>(),
                        c->d_iv_start.as<int>(), c->d_blk_iv0.as<int>(), c->d_final_y.as<int>(), c->d_final_pos.as<int>(),
@@ -2562,6 +2603,7 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
     mark(11);
     HIP_TRY(c, hipMemcpyAsync(c->h_status, st, sizeof(Status), hipMemcpyDeviceToHost, s));
     }   // do_post
+    HIP_TRY(c, fj_err);
     HIP_TRY(c, hipGetLastError());
     return FSEG_OK;
 }
@@ -2667,6 +2709,8 @@ int fseg_create(int device, fseg_ctx **out) {
     if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_status, sizeof(Status), hipHostMallocDefault);
     if (e == hipSuccess) e = hipMalloc(&c->d_status.p, sizeof(Status));
     for (int i = 0; e == hipSuccess && i <= ST_COUNT; ++i) e = hipEventCreate(&c->ev[i]);
+    for (int i = 0; e == hipSuccess && i < fseg_ctx::kSide; ++i) e = hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking);
+    for (int i = 0; e == hipSuccess && i < fseg_ctx::kForkEvents; ++i) e = hipEventCreateWithFlags(&c->fj[i], hipEventDisableTiming);
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_score<kNMax>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)ScoreCfg<kNMax>::kLds);
@@ -2696,6 +2740,7 @@ int fseg_create(int device, fseg_ctx **out) {
     }
     c->d_status.cap = sizeof(Status);
     { const char *ng = getenv("FSEG_NO_GRAPH"); if (ng && ng[0] == '1') c->use_graph = false; }
+    { const char *nf = getenv("FSEG_NO_FORK"); if (nf && nf[0] == '1') c->use_fork = false; }
     { const char *sm = getenv("FSEG_SCAN_SINGLE_MAX"); if (sm && sm[0]) c->scan_single_max = atoll(sm); }
     { const char *sm = getenv("FSEG_PROB_SELF_MAX"); if (sm && sm[0]) c->prob_self_max = atoll(sm); }
     *out = c;
@@ -2710,7 +2755,7 @@ void fseg_destroy(fseg_ctx *c) {
     DevBuf *bufs[] = {&c->d_part_iv_off, &c->d_part_rep_off, &c->d_part_lane_off, &c->d_iv_start, &c->d_iv_end, &c->d_pos_off,
                       &c->d_iv_part, &c->d_rep_weight, &c->d_rep_exon_off, &c->d_ex_ts, &c->d_ex_te, &c->d_lane_rep, &c->d_lane_start, &c->d_lane_pmax,
                       &c->d_tile_iv, &c->d_tile_y0, &c->d_w_main, &c->d_w_refine, &c->d_h_table, &c->d_y_raw, &c->d_y,
-                      &c->d_flag, &c->d_cflag, &c->d_v, &c->d_scan_state, &c->d_bsum, &c->d_g, &c->d_pk, &c->d_pf, &c->d_kp, &c->d_final_flag,
+                      &c->d_flag, &c->d_cflag, &c->d_v, &c->d_scan_state, &c->d_bsum, &c->d_bsum_side, &c->d_g, &c->d_pk, &c->d_pf, &c->d_kp, &c->d_final_flag,
                       &c->d_blk_iv0, &c->d_hc_part, &c->d_hc_p0, &c->d_hc_n, &c->d_hc_glo, &c->d_hc_ghi, &c->d_hc_llo, &c->d_hc_lhi, &c->d_voff, &c->d_chunk_off, &c->d_csum, &c->d_mean, &c->d_thr, &c->d_label_off, &c->d_part_has2, &c->d_rb_part, &c->d_rb_r0, &c->d_cand_off,
                       &c->d_cand_y, &c->d_fixed0, &c->d_added, &c->d_fixed, &c->d_chosen, &c->d_final_off, &c->d_final_y,
                       &c->d_final_pos, &c->d_col_thr, &c->d_col_zero, &c->d_cum, &c->d_tile_tot, &c->d_iv_tile0, &c->d_seg_iv, &c->d_seg_prev, &c->d_rseg_c, &c->d_cand_pn, &c->d_cand_ll, &c->d_cand_ln, &c->d_prob_bs, &c->d_prob_iv, &c->d_prob_start,
@@ -2720,6 +2765,8 @@ void fseg_destroy(fseg_ctx *c) {
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
     if (c->h_status) (void)hipHostFree(c->h_status);
     for (int i = 0; i <= ST_COUNT; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    for (int i = 0; i < fseg_ctx::kSide; ++i) if (c->side[i]) { (void)hipStreamSynchronize(c->side[i]); (void)hipStreamDestroy(c->side[i]); }
+    for (int i = 0; i < fseg_ctx::kForkEvents; ++i) if (c->fj[i]) (void)hipEventDestroy(c->fj[i]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -2933,6 +2980,7 @@ int fseg_upload(fseg_ctx *c, const fseg_batch *b) {
     TRY(ensure(c, c->d_v, np8 * 8));
     TRY(ensure(c, c->d_scan_state, ((size_t)scan_blocks(NPOS) * 3 + 1) * 8));
     TRY(ensure(c, c->d_bsum, ((size_t)scan_blocks(NPOS) + 2) * 4));
+    TRY(ensure(c, c->d_bsum_side, ((size_t)scan_blocks(NPOS) + 2) * 4));
     TRY(ensure(c, c->d_g, np8 * 8)); TRY(ensure(c, c->d_pk, np8 * 4)); TRY(ensure(c, c->d_pf, np8)); TRY(ensure(c, c->d_kp, np8));
     TRY(ensure(c, c->d_final_flag, np8));
     TRY(ensure(c, c->d_voff, ((size_t)np + 2) * 8)); TRY(ensure(c, c->d_chunk_off, ((size_t)np + 2) * 8));
