@@ -807,6 +807,30 @@ __global__ void k_fix(i64 K, const i64 *pos_off, const int *iv_part, const i64 *
         const double *y = yv + pos_off[k];
         const int *cy = cand_y + c0;
         double thr = thr_part[iv_part[k]];
+        if (T == 64 && N <= 64 && N <= mps) {
+            // short interval, one wave: no gap can exceed max_problem_size, so the fixed set is final at once and the
+            // previous fixed candidate comes from the ballot -- three dependent load rounds, no barrier
+            const int c = threadIdx.x;
+            const bool in = c < N;
+            const bool f = in && (c == 0 || c == N - 1 || y[cy[c]] > thr);
+            const u64 mask = __ballot(f);
+            int n = 0;
+            if (in) {
+                const u64 below = mask & ((1ULL << c) - 1ULL);
+                const int prev = below ? 63 - __clzll((long long)below) : -1;
+                n = (f && prev >= 0 && c - prev + 1 >= 3) ? c - prev + 1 : 0;
+                fixed0[c0 + c] = f; added[c0 + c] = 0; cand_iv[c0 + c] = (int)k;
+                fixed[c0 + c] = f; chosen[c0 + c] = f;
+                cand_pn[c0 + c] = n;
+            }
+            int mx = n;
+            for (int d = 32; d >= 1; d >>= 1) mx = max(mx, __shfl_xor(mx, d));
+            // one address for the whole batch: atomics on it serialise (~90 per us), so skip those that cannot raise it
+            // (a stale read only means an unnecessary atomic, never a missed one: the maximum only grows)
+            if (threadIdx.x == 0 && mx > 0 && (unsigned)mx > __hip_atomic_load(&st->max_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                atomicMax(&st->max_n, (unsigned)mx);
+            continue;
+        }
         for (int c = threadIdx.x; c < N; c += T) {
             fixed0[c0 + c] = (c == 0 || c == N - 1 || y[cy[c]] > thr) ? 1 : 0;
             added[c0 + c] = 0;
@@ -853,7 +877,8 @@ __global__ void k_fix(i64 K, const i64 *pos_off, const int *iv_part, const i64 *
                 fixed[c0 + c] = f; chosen[c0 + c] = f;
                 int n = (f && prev >= 0 && c - prev + 1 >= 3) ? c - prev + 1 : 0;
                 if (n > kNHuge) atomicOr(&st->err, kErrProblemTooLarge);
-                if (n > 0) atomicMax(&st->max_n, (unsigned)n);
+                if (n > 0 && (unsigned)n > __hip_atomic_load(&st->max_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                    atomicMax(&st->max_n, (unsigned)n);
                 cand_pn[c0 + c] = n;
             }
         }
@@ -1253,23 +1278,35 @@ __global__ void __launch_bounds__(kLaneChunk) k_cov(Status *st, const ProbDesc *
 #ifndef FSEG_DP_G
 #define FSEG_DP_G 4                  // candidates per DP block (tuning knob)
 #endif
+// T == 64: the caller is ONE WAVE working on its own problem with wave-private tables (other waves of the workgroup
+// may be inside their own dp_solve<64>), so synchronisation is wave-level and thread indices are lane indices.
+template <int T>
+__device__ __forceinline__ void dp_sync() {
+    if (T == 64) {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        __syncthreads();
+    }
+}
 template <int T, typename OutT>
 __device__ int dp_solve(int n, const OutT *out_s, const int *in_s, i64 *M, unsigned char *A, const int *cy_s, int support,
                         i64 *part_v /* T */, unsigned char *part_a /* T */, int *top_key /* T/64 */,
                         unsigned char *chosen /* + first candidate of the problem */ FSEG_DPARAM) {
     constexpr int NW = T / 64;
-    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int lane = lane_id(), wave = T == 64 ? 0 : (int)(threadIdx.x >> 6);
+    const int tid = T == 64 ? lane : (int)threadIdx.x;
     const int end = n - 1;
     const int npairs = n * (n - 1) / 2;
 #define FSEG_IN(a, b) ((i64)in_s[(b) * ((b) - 1) / 2 + (a)])
 #define FSEG_M(a, b) M[(b) * ((b) - 1) / 2 + (a)]
     // M(b,end): the chain closes here; the "segment too small" rule (:540) is folded into the table, so the
     // inner loops only test tail != -inf
-    for (int b = threadIdx.x; b < end; b += T) {
+    for (int b = tid; b < end; b += T) {
         FSEG_M(b, end) = cy_s[end] - cy_s[b] >= 5 ? FSEG_IN(b, end) : kNegInf;
         A[end * (end - 1) / 2 + b] = 255;
     }
-    __syncthreads();
+    dp_sync<T>();
     // Blocks of G consecutive c (top, top-1, ..).  M(b,c) needs M(c,c2) for every c2 > c: the c2 above the block
     // are final, so all G candidates of a block take their maximum over those c2 in parallel (wave = (g, c2 slice),
     // lanes = b); the G(G-1)/2 terms with c2 inside the block are then added by wave 0 alone, in registers, with
@@ -1296,7 +1333,7 @@ __device__ int dp_solve(int n, const OutT *out_s, const int *in_s, i64 *M, unsig
             }
             part_v[wave * 64 + lane] = best; part_a[wave * 64 + lane] = (unsigned char)arg;
         }
-        __syncthreads();
+        dp_sync<T>();
         if (wave == 0) {
             i64 R[G]; int Ra[G];
 #pragma unroll
@@ -1336,13 +1373,13 @@ __device__ int dp_solve(int n, const OutT *out_s, const int *in_s, i64 *M, unsig
                 }
             }
         }
-        __syncthreads();
+        dp_sync<T>();
     }
     FSEG_DTICK(10);
     // top level (a = start): max over (j,k) of in_0j + out_0jk + M(j,k), first maximiser in (j, k) order,
     // taken only if strictly greater than "no cut" = in(0,end)   (:560-566)
     i64 bv = kNegInf; int bkey = 0x7fffffff;
-    for (int q = threadIdx.x; q < npairs; q += T) {
+    for (int q = tid; q < npairs; q += T) {
         int j, kx;
         pair_decode(q, &j, &kx);                    // j < kx
         if (j < 1) continue;
@@ -1358,12 +1395,12 @@ __device__ int dp_solve(int n, const OutT *out_s, const int *in_s, i64 *M, unsig
         i64 ov = __shfl_xor(bv, d); int ok2 = __shfl_xor(bkey, d);
         if (ov > bv || (ov == bv && ok2 < bkey)) { bv = ov; bkey = ok2; }
     }
-    __syncthreads();
+    dp_sync<T>();
     if (lane == 0) { part_v[wave] = bv; top_key[wave] = bkey; }
-    __syncthreads();
+    dp_sync<T>();
     FSEG_DTICK(11);
     int chain = 0;
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         for (int w = 1; w < NW; ++w)
             if (part_v[w] > bv || (part_v[w] == bv && top_key[w] < bkey)) { bv = part_v[w]; bkey = top_key[w]; }
         if (bv != kNegInf && bv > FSEG_IN(0, end)) {
@@ -1457,18 +1494,32 @@ __global__ void __launch_bounds__(ScoreCfg<NM>::kThreads) k_score(Status *st, in
     FSEG_T0;
     // a shared work counter saturates near 90 pops/us, so the small classes claim several items per pop
     constexpr int kPop = NM <= 16 ? 8 : (NM <= 32 ? 4 : 1);
+#ifndef FSEG_SCORE_STATIC
+#define FSEG_SCORE_STATIC 1
+#endif
+    // The small classes hold tens of thousands of short items: even batched pops serialise on the one counter, so
+    // they take a static stride (neighbouring items are of similar size); the big class keeps the counter.
+    constexpr bool kStatic = FSEG_SCORE_STATIC && NM <= 32;
     i64 wi_base = 0;
     int wi_left = 0;
+    i64 wi_static = blockIdx.x;
     for (;;) {
-        if (wi_left == 0) {
-            __syncthreads();
-            if (threadIdx.x == 0) work_s = atomicAdd(queue, (u64)kPop);
-            __syncthreads();
-            wi_base = (i64)work_s;
-            wi_left = kPop;
+        i64 wi;
+        if (kStatic) {
+            wi = cls < 0 ? -1 : wi_static;
+            wi_static += gridDim.x;
         }
-        const i64 wi = wi_base + (kPop - wi_left);
-        --wi_left;
+        if (!kStatic || wi < 0) {
+            if (wi_left == 0) {
+                __syncthreads();
+                if (threadIdx.x == 0) work_s = atomicAdd(queue, (u64)kPop);
+                __syncthreads();
+                wi_base = (i64)work_s;
+                wi_left = kPop;
+            }
+            wi = wi_base + (kPop - wi_left);
+            --wi_left;
+        }
         __syncthreads();
         FSEG_TICK(0);
         if (wi >= n_items) break;
@@ -1672,6 +1723,108 @@ __global__ void __launch_bounds__(T) k_dp(Status *st, int dp_class, int nm, cons
         FSEG_DTICK(9);
         int chain = dp_solve<T>(n, out_s, in_s, M, A, cy_s, support, part_v, part_a, top_key, chosen + c0 FSEG_DARG);
         if (threadIdx.x == 0) pr.chain[p] = chain;
+    }
+}
+
+// DP of the small class (n <= kDpSmall) for batches of many partitions, where most problems have a handful of
+// candidates: a workgroup takes four list entries at a time; every wave solves its own entry alone when it has at most
+// kDpWave candidates (wave-private tables, wave-level synchronisation, no workgroup barrier on that path), and the
+// entries above that are then solved one after the other by the whole workgroup as in k_dp.
+constexpr int kDpWave = 16;
+constexpr int kDpWavePairs = kDpWave * (kDpWave - 1) / 2, kDpWaveTri = kDpWave * (kDpWave - 1) * (kDpWave - 2) / 6;
+template <typename OutT>
+__host__ __device__ constexpr size_t dp_wave_bytes() {          // tables of one wave-private problem, 16-byte multiple
+    return (((size_t)kDpWavePairs * (8 + 4 + 1) + (size_t)(kDpWaveTri + 4) * sizeof(OutT)) + 15) & ~(size_t)15;
+}
+template <typename OutT>
+__global__ void __launch_bounds__(256) k_dp_waves(Status *st, const int *dp_items, ProblemArrays pr, const ProbDesc *desc, i64 prob_cap,
+                                                  const int *cand_y, const unsigned *out_g, i64 tri_cap, const unsigned *amb_g,
+                                                  const int2 *pair_thr, i64 pair_cap, int support, unsigned char *chosen) {
+    constexpr int T = 256, NM = kDpSmall;
+    constexpr int kTri = NM * (NM - 1) * (NM - 2) / 6, kPairs = NM * (NM - 1) / 2;
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ int cy_s[NM];
+    __shared__ int cy_w[4][kDpWave];
+    __shared__ i64 part_v[T];
+    __shared__ unsigned char part_a[T];
+    __shared__ int top_key[T / 64];
+    __shared__ int big_s[4];
+    const i64 n_prob = (i64)st->n_prob;
+    if (n_prob > prob_cap) return;                                  // sizing run
+    const i64 list_n = (i64)st->dp_cls[0];
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+#ifdef FSEG_SCORE_TIMING
+    __shared__ unsigned long long tick_sink[16];                    // the diagnostic build's ticks of this kernel are dropped
+    unsigned long long *dp_tacc = tick_sink; unsigned long long dt_prev = 0;
+#endif
+    for (i64 g = (i64)blockIdx.x * 4; g < list_n; g += (i64)gridDim.x * 4) {
+        __syncthreads();
+        {   // ---- every wave: its own entry ------------------------------------------------------------------
+            const i64 t = g + wave;
+            int big = -1;
+            if (t < list_n) {
+                const i64 p = dp_items[t];
+                const ProbDesc d = load_desc(desc + p);
+                const int n = d.n;
+                const i64 poff = d.pair_off, toff = d.tri_off;
+                const int npairs = n * (n - 1) / 2, ntri = n * (n - 1) * (n - 2) / 6;
+                const bool usable = n <= NM && poff + npairs <= pair_cap && toff + ntri <= tri_cap;
+                if (sizeof(OutT) == 2 && d.lane_n >= 65536) { if (lane == 0) atomicOr(&st->err, kErrNeedWideDp); }
+                else if (usable && n > kDpWave) big = (int)p;
+                else if (usable) {
+                    unsigned char *w_mem = smem + (size_t)wave * dp_wave_bytes<OutT>();
+                    i64 *M = reinterpret_cast<i64 *>(w_mem);
+                    int *in_s = reinterpret_cast<int *>(M + kDpWavePairs);
+                    OutT *out_s = reinterpret_cast<OutT *>(in_s + kDpWavePairs);
+                    unsigned char *A = reinterpret_cast<unsigned char *>(out_s + ((kDpWaveTri + 3) & ~3));
+                    const bool zamb = (pr.flags[p] & 1) != 0;
+                    if (lane < n) cy_w[wave][lane] = cand_y[d.c0 + lane];
+                    for (int x0 = lane; x0 < ntri; x0 += 64 * 4) {
+                        unsigned v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { int x = x0 + e * 64; v[e] = x < ntri ? out_g[toff + x] : 0u; }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { int x = x0 + e * 64; if (x < ntri) out_s[x] = (OutT)v[e]; }
+                    }
+                    for (int q = lane; q < npairs; q += 64)
+                        in_s[q] = -(int)((i64)amb_g[poff + q] + ((zamb && pair_thr[poff + q].y < 0) ? (i64)d.outside : 0));
+                    dp_sync<64>();
+                    int chain = dp_solve<64>(n, out_s, in_s, M, A, cy_w[wave], support, part_v + wave * 64, part_a + wave * 64,
+                                             top_key + wave, chosen + d.c0 FSEG_DARG);
+                    if (lane == 0) pr.chain[p] = chain;
+                }
+            }
+            if (lane == 0) big_s[wave] = big;
+        }
+        __syncthreads();
+        // ---- the workgroup: entries with more than kDpWave candidates, one after the other ----------------------
+        for (int w = 0; w < 4; ++w) {
+            const int pb = big_s[w];
+            if (pb < 0) continue;                                       // uniform: big_s is shared
+            i64 *M = reinterpret_cast<i64 *>(smem);
+            int *in_s = reinterpret_cast<int *>(M + kPairs);
+            OutT *out_s = reinterpret_cast<OutT *>(in_s + kPairs);
+            unsigned char *A = reinterpret_cast<unsigned char *>(out_s + ((kTri + 3) & ~3));
+            const ProbDesc d = load_desc(desc + pb);
+            const int n = d.n;
+            const i64 poff = d.pair_off, toff = d.tri_off;
+            const int npairs = n * (n - 1) / 2, ntri = n * (n - 1) * (n - 2) / 6;
+            const bool zamb = (pr.flags[pb] & 1) != 0;
+            __syncthreads();
+            for (int j = threadIdx.x; j < n; j += T) cy_s[j] = cand_y[d.c0 + j];
+            for (int x0 = threadIdx.x; x0 < ntri; x0 += T * 8) {
+                unsigned v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { int x = x0 + e * T; v[e] = x < ntri ? out_g[toff + x] : 0u; }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { int x = x0 + e * T; if (x < ntri) out_s[x] = (OutT)v[e]; }
+            }
+            for (int q = threadIdx.x; q < npairs; q += T)
+                in_s[q] = -(int)((i64)amb_g[poff + q] + ((zamb && pair_thr[poff + q].y < 0) ? (i64)d.outside : 0));
+            __syncthreads();
+            int chain = dp_solve<T>(n, out_s, in_s, M, A, cy_s, support, part_v, part_a, top_key, chosen + d.c0 FSEG_DARG);
+            if (threadIdx.x == 0) pr.chain[pb] = chain;
+        }
     }
 }
 
@@ -2546,20 +2699,27 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
                            c->d_part_lane_off.as<i64>(), c->d_out.as<unsigned>(), c->tri_cap, c->d_amb.as<unsigned>(),        \
                            c->d_pair_thr.as<int2>(), c->pair_cap, c->P.min_read_support_outside,                              \
                            c->d_chosen.as<unsigned char>() FSEG_TARG)
+#define FSEG_LAUNCH_DP_WAVES(OUTT)                                                                                        \
+        hipLaunchKernelGGL((k_dp_waves<OUTT>), dim3(grid_for(c->prob_cap, 4, 2048)), dim3(256),                                \
+                           dp_lds_for(kDpSmall, (int)sizeof(OUTT)) > 4 * dp_wave_bytes<OUTT>() ? dp_lds_for(kDpSmall, (int)sizeof(OUTT)) : 4 * dp_wave_bytes<OUTT>(), \
+                           q_small, st, c->d_dp_items.as<int>(), pr, c->d_prob_desc.as<ProbDesc>(), c->prob_cap,                \
+                           c->d_cand_y.as<int>(), c->d_out.as<unsigned>(), c->tri_cap, c->d_amb.as<unsigned>(),                \
+                           c->d_pair_thr.as<int2>(), c->pair_cap, c->P.min_read_support_outside, c->d_chosen.as<unsigned char>())
         // 16-bit count tables unless some problem sees >= 65536 reads (then a previous run asked for the wide tables);
         // 512 threads (8 waves share the c2 loop) when the tables of the largest problem leave room for their scratch.
         // small_batch: one launch over every problem; otherwise one launch per DP class list.
         hipStream_t q_small = c->small_batch ? s : fork(0);      // the two DP classes own disjoint problems
         if (c->dp_wide_counts) {
             const bool wide_wg = dp_lds_for(c->nm_big, 4) + 8 * 1024 <= kLdsPerWg;
-            if (!c->small_batch) { FSEG_LAUNCH_DP(kDpSmall, 256, unsigned, kDpSmall, 0, 2048); }
+            if (!c->small_batch) { FSEG_LAUNCH_DP_WAVES(unsigned); }
             if (wide_wg) { FSEG_LAUNCH_DP(kNMax, 512, unsigned, c->nm_big, c->small_batch ? -1 : 1, 256); }
             else { FSEG_LAUNCH_DP(kNMax, 256, unsigned, c->nm_big, c->small_batch ? -1 : 1, 256); }
         } else {
-            if (!c->small_batch) { FSEG_LAUNCH_DP(kDpSmall, 256, unsigned short, kDpSmall, 0, 2048); }
+            if (!c->small_batch) { FSEG_LAUNCH_DP_WAVES(unsigned short); }
             FSEG_LAUNCH_DP(kNMax, 512, unsigned short, c->nm_big, c->small_batch ? -1 : 1, 512);
         }
 #undef FSEG_LAUNCH_DP
+#undef FSEG_LAUNCH_DP_WAVES
         if (!c->small_batch) join(0);
         if (c->have_huge)
             hipLaunchKernelGGL(k_dp_huge, dim3(dp_grid < 256 ? dp_grid : 256), dim3(512), kHugeDpLds, s, st, c->d_dp_items.as<int>(),
