@@ -2,6 +2,8 @@
 
 * ``libfreddie_seg.so``  -- the product: gfx950 HIP kernels + C-ABI (hipcc, cross-compiles without a GPU)
 * ``libfreddie_host.so`` -- the product's native host I/O: TSV parser, gaps/poly-A, writer (g++)
+* ``libfreddie_cluster.so`` -- gfx950 kernels + C-ABI of the clustering stage's pre-ILP graph work (hipcc; built by
+  ``freddie_amd.cluster_prep.build``)
 * ``synth/libfreddie_synth.so`` -- synthetic split-partition generator (gcc; test/bench infrastructure)
 
 The oracle (``oracle/``) is test infrastructure and is built by ``oracle/Makefile``; it is never
@@ -49,8 +51,9 @@ def build_host(force=False, verbose=False):
 
 
 def build_all(force=False, verbose=False):
-    from . import synth
+    from . import cluster_prep, synth
     build_seg(force, verbose)
     build_host(force, verbose)
+    cluster_prep.build(force, verbose)
     synth.build(force)
     return SEG_SO

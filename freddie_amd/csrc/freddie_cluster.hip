@@ -1,0 +1,354 @@
+// freddie_cluster.hip -- gfx950 kernels + C-ABI (include/freddie_cluster.h) for the pre-ILP work of the clustering
+// stage: the pairwise read-compatibility graph of partition_reads() (py/freddie_cluster.py:217-234) and its iterated
+// edge pruning (:240-255), for a batch of tints per call.
+//
+// Reads are bit rows (bit s = the read covers segment s), so the reference's two list comprehensions over the
+// overlap [f, l] (:229, :232) become popcounts of (a & b & mask) and ((a ^ b) & mask).  The graph is a symmetric
+// bit matrix; a 64 x 64 tile of it is one workgroup's unit of work, lane = column, so a row's 64 edge bits are one
+// wave ballot and one 8-byte store.  Pruning keeps an edge when either end has no other neighbour or the two ends
+// share a neighbour (:247-251): "share a neighbour" is a row-AND over the bit matrix, evaluated tile by tile with
+// both row blocks staged in LDS; every pass reads the previous pass' matrix only (the reference removes the edges
+// of a pass together, :252) and passes repeat until one removes nothing (:254).
+#include "freddie_cluster.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+typedef long long i64;
+typedef unsigned long long u64;
+
+constexpr int kTile = 64;           // rows and columns per tile
+constexpr int kMaxWords = 300;      // uint32 words per read row the LDS staging of k_compat can hold (9600 segments)
+constexpr int kChunk = 64;          // uint64 words of the neighbour rows staged per step of k_prune
+
+struct TintDesc {
+    i64 row0, bits_off, adj_off;
+    int n, n_seg, w, aw;            // rows, segments, uint32 words per read row, uint64 words per adjacency row
+};
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// bits [f, l] of the 32-bit word number w (f <= l, both inside the row)
+__device__ __forceinline__ unsigned range_mask(int f, int l, int w) {
+    const int lo = f - w * 32, hi = l - w * 32;
+    unsigned m = 0xffffffffu;
+    if (lo > 0) m &= 0xffffffffu << lo;
+    if (hi < 31) m &= 0xffffffffu >> (31 - hi);
+    return m;
+}
+
+// ---- pairwise compatibility (py/freddie_cluster.py:217-234) ------------------------------------------------------
+__global__ void __launch_bounds__(256) k_compat(int n_tiles, const int4 *tiles, const TintDesc *tints, const unsigned *bits,
+                                                const int *first, const int *last, const unsigned char *tail, u64 *adj) {
+    extern __shared__ unsigned lds[];
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    for (int ti = blockIdx.x; ti < n_tiles; ti += gridDim.x) {
+        const int4 tile = tiles[ti];
+        const TintDesc d = tints[tile.x];
+        const int W = d.w, Wp = W | 1;                  // odd row stride: lanes reading the same word of 64 rows hit 64 banks
+        unsigned *rows = lds, *cols = lds + kTile * Wp;
+        const unsigned *B = bits + d.bits_off;
+        const int r0 = tile.y * kTile, c0 = tile.z * kTile;
+        __syncthreads();
+        for (int x = threadIdx.x; x < kTile * W; x += blockDim.x) {
+            const int q = x / W, w = x - q * W;
+            rows[q * Wp + w] = r0 + q < d.n ? B[(i64)(r0 + q) * W + w] : 0u;
+            cols[q * Wp + w] = c0 + q < d.n ? B[(i64)(c0 + q) * W + w] : 0u;
+        }
+        __syncthreads();
+        const int col = c0 + lane;
+        const bool col_ok = col < d.n;
+        int f2 = 0, l2 = -1, t2 = 0;
+        if (col_ok) { f2 = first[d.row0 + col]; l2 = last[d.row0 + col]; t2 = tail[d.row0 + col]; }
+        const unsigned *b = cols + lane * Wp;
+        for (int rr = wave; rr < kTile; rr += 4) {
+            const int row = r0 + rr;
+            if (row >= d.n) break;
+            const int f1 = first[d.row0 + row], l1 = last[d.row0 + row], t1 = tail[d.row0 + row];
+            bool edge = false;
+            // poly-A tails on different ends: incompatible (:222-223)
+            if (col_ok && col != row && !(t1 != 0 && t2 != 0 && t1 != t2)) {
+                const int f = f1 > f2 ? f1 : f2, l = l1 < l2 ? l1 : l2;     // overlap of the two reads (:224-226)
+                const int o = l - f + 1;
+                // f < 0 only when neither read covers any segment: then no common segment either (:228-230)
+                if (o >= 1 && f >= 0) {
+                    const unsigned *a = rows + rr * Wp;
+                    int same = 0, diff = 0;
+                    for (int w = f >> 5; w <= (l >> 5); ++w) {
+                        const unsigned m = range_mask(f, l, w), x = a[w], y = b[w];
+                        same += __popc(x & y & m);           // segments both reads cover (:229)
+                        diff += __popc((x ^ y) & m);         // segments where they differ (:232)
+                    }
+                    edge = same >= 1 && ((o > 3 && diff < 3) || (o <= 3 && diff == 0));   // :230, :234
+                }
+            }
+            const u64 word = __ballot(edge);
+            if (lane == 0) adj[d.adj_off + (i64)row * d.aw + tile.z] = word;
+        }
+    }
+}
+
+// ---- degrees ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_degree(i64 n_rows_total, const int *row_tint, const TintDesc *tints, const u64 *adj, int *deg) {
+    const int lane = lane_id();
+    const i64 wave_g = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((i64)gridDim.x * blockDim.x) >> 6;
+    for (i64 r = wave_g; r < n_rows_total; r += n_waves) {
+        const TintDesc d = tints[row_tint[r]];
+        const u64 *a = adj + d.adj_off + (r - d.row0) * d.aw;
+        int c = 0;
+        for (int w = lane; w < d.aw; w += 64) c += __popcll(a[w]);
+        for (int s = 32; s >= 1; s >>= 1) c += __shfl_xor(c, s);
+        if (lane == 0) deg[r] = c;
+    }
+}
+
+// ---- one pruning pass (py/freddie_cluster.py:243-252) ------------------------------------------------------------
+// new(r, c) = old(r, c) and (deg r == 1 or deg c == 1 or rows r and c of `old` intersect)
+__global__ void __launch_bounds__(256) k_prune(int n_tiles, const int4 *tiles, const TintDesc *tints, const u64 *old_adj,
+                                               const int *deg, u64 *new_adj, int *changed /* per tint */) {
+    __shared__ u64 rows[kTile][kChunk + 1];
+    __shared__ u64 cols[kTile][kChunk + 1];
+    __shared__ u64 edge_w[kTile];
+    __shared__ int any_s;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    for (int ti = blockIdx.x; ti < n_tiles; ti += gridDim.x) {
+        const int4 tile = tiles[ti];
+        const TintDesc d = tints[tile.x];
+        const int r0 = tile.y * kTile, c0 = tile.z * kTile;
+        const u64 *A = old_adj + d.adj_off;
+        __syncthreads();
+        if (threadIdx.x == 0) any_s = 0;
+        __syncthreads();
+        if (threadIdx.x < kTile) {
+            const int row = r0 + threadIdx.x;
+            const u64 w = row < d.n ? A[(i64)row * d.aw + tile.z] : 0ull;
+            edge_w[threadIdx.x] = w;
+            if (w) any_s = 1;
+        }
+        __syncthreads();
+        if (!any_s) {                                    // no edge of the graph in this tile
+            if (threadIdx.x < kTile && r0 + (int)threadIdx.x < d.n) new_adj[d.adj_off + (i64)(r0 + threadIdx.x) * d.aw + tile.z] = 0ull;
+            continue;
+        }
+        const int col = c0 + lane;
+        const int deg_c = col < d.n ? deg[d.row0 + col] : 0;
+        // the 16 rows of this wave: bit q of `hit` = rows (r0 + wave + 4q) and `col` share a neighbour
+        unsigned hit = 0;
+        for (int k0 = 0; k0 < d.aw; k0 += kChunk) {
+            const int kn = d.aw - k0 < kChunk ? d.aw - k0 : kChunk;
+            __syncthreads();
+            for (int x = threadIdx.x; x < kTile * kChunk; x += blockDim.x) {
+                const int q = x / kChunk, w = x - q * kChunk;
+                rows[q][w] = (w < kn && r0 + q < d.n) ? A[(i64)(r0 + q) * d.aw + k0 + w] : 0ull;
+                cols[q][w] = (w < kn && c0 + q < d.n) ? A[(i64)(c0 + q) * d.aw + k0 + w] : 0ull;
+            }
+            __syncthreads();
+            for (int q = 0; q < 16; ++q) {
+                const int rr = wave + 4 * q;
+                if (edge_w[rr] == 0) continue;           // uniform: this row has no edge into the tile
+                if (!((edge_w[rr] >> lane) & 1ull) || ((hit >> q) & 1u)) continue;
+                u64 acc = 0;
+                for (int w = 0; w < kn; ++w) acc |= rows[rr][w] & cols[lane][w];
+                if (acc) hit |= 1u << q;
+            }
+        }
+        for (int q = 0; q < 16; ++q) {
+            const int rr = wave + 4 * q, row = r0 + rr;
+            if (row >= d.n) continue;
+            const u64 oldw = edge_w[rr];
+            const int deg_r = deg[d.row0 + row];
+            const bool keep = ((oldw >> lane) & 1ull) && (deg_r == 1 || deg_c == 1 || ((hit >> q) & 1u));
+            const u64 neww = __ballot(keep);
+            if (lane == 0) {
+                new_adj[d.adj_off + (i64)row * d.aw + tile.z] = neww;
+                if (neww != oldw) changed[tile.x] = 1;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+struct fclu_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[3] = {};
+    std::string err;
+    float compat_ms = 0.f, prune_ms = 0.f;
+};
+
+namespace {
+
+std::string g_create_error;
+
+int fail(fclu_ctx *c, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_error = buf;
+    return code;
+}
+
+struct Dev {
+    void *p = nullptr;
+    ~Dev() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+#define HIP_TRY(c, expr)                                                                                     \
+    do {                                                                                                     \
+        hipError_t e__ = (expr);                                                                             \
+        if (e__ != hipSuccess) return fail((c), FCLU_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e__));      \
+    } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int fclu_abi_version(void) { return 1; }
+
+int fclu_create(int device, fclu_ctx **out) {
+    if (!out) return FCLU_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, FCLU_ERR_HIP, "no HIP device available: %s (this library has no CPU fallback)",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    if (device < 0 || device >= n) return fail(nullptr, FCLU_ERR_ARG, "device ordinal out of range");
+    fclu_ctx *c = new fclu_ctx();
+    c->device = device;
+    e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    for (int i = 0; e == hipSuccess && i < 3; ++i) e = hipEventCreate(&c->ev[i]);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_compat), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                2 * kTile * (kMaxWords | 1) * 4);
+    if (e != hipSuccess) {
+        fail(nullptr, FCLU_ERR_HIP, "context creation failed: %s", hipGetErrorString(e));
+        delete c;
+        return FCLU_ERR_HIP;
+    }
+    *out = c;
+    return FCLU_OK;
+}
+
+void fclu_destroy(fclu_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    for (int i = 0; i < 3; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    delete c;
+}
+
+const char *fclu_last_error(const fclu_ctx *c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int fclu_compat_graph(fclu_ctx *c, const fclu_batch *b, int32_t prune, uint64_t *adj_out, int32_t *rounds_out) {
+    if (!c || !b || !adj_out) return FCLU_ERR_ARG;
+    if (b->n_tint <= 0) return fail(c, FCLU_ERR_ARG, "fclu_compat_graph: empty batch");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int T = b->n_tint;
+    const i64 R = b->row_off[T];
+    // host-side shape checks: the kernels index with these and nothing else
+    std::vector<TintDesc> tints((size_t)T);
+    std::vector<int4> tiles;
+    std::vector<int> row_tint((size_t)R);
+    int max_w = 1;
+    for (int t = 0; t < T; ++t) {
+        TintDesc &d = tints[(size_t)t];
+        d.row0 = b->row_off[t];
+        const i64 n = b->row_off[t + 1] - d.row0;
+        if (n < 0 || n > (1 << 30) || b->n_seg[t] < 0) return fail(c, FCLU_ERR_ARG, "tint %d: bad row count or segment count", t);
+        d.n = (int)n; d.n_seg = b->n_seg[t];
+        d.w = (d.n_seg + 31) / 32; if (d.w < 1) d.w = 1;
+        d.aw = (d.n + 63) / 64;
+        d.bits_off = b->bits_off[t]; d.adj_off = b->adj_off[t];
+        if (b->bits_off[t + 1] - d.bits_off != (i64)d.n * d.w) return fail(c, FCLU_ERR_ARG, "tint %d: bits_off does not match rows x words", t);
+        if (b->adj_off[t + 1] - d.adj_off != (i64)d.n * d.aw) return fail(c, FCLU_ERR_ARG, "tint %d: adj_off does not match rows x words", t);
+        if (d.w > kMaxWords) return fail(c, FCLU_ERR_UNSUPPORTED, "tint %d has %d segments; this build stages at most %d", t, d.n_seg, kMaxWords * 32);
+        if (d.w > max_w) max_w = d.w;
+        for (i64 r = 0; r < n; ++r) {
+            row_tint[(size_t)(d.row0 + r)] = t;
+            const int f = b->first[d.row0 + r], l = b->last[d.row0 + r];
+            if (f < -1 || l >= (d.n_seg > 0 ? d.n_seg : 1) || b->tail[d.row0 + r] > 2) return fail(c, FCLU_ERR_ARG, "tint %d read %lld: first/last/tail out of range", t, r);
+        }
+        for (int ti = 0; ti < d.aw; ++ti) for (int tj = 0; tj < d.aw; ++tj) tiles.push_back(make_int4(t, ti, tj, 0));
+    }
+    const i64 n_bits = b->bits_off[T], n_adj = b->adj_off[T];
+    const int n_tiles = (int)tiles.size();
+    if (rounds_out) for (int t = 0; t < T; ++t) rounds_out[t] = 0;
+    c->compat_ms = c->prune_ms = 0.f;
+    if (n_tiles == 0 || R == 0) return FCLU_OK;
+
+    Dev d_tints, d_tiles, d_row_tint, d_bits, d_first, d_last, d_tail, d_adj[2], d_deg, d_changed;
+    HIP_TRY(c, d_tints.alloc(tints.size() * sizeof(TintDesc)));
+    HIP_TRY(c, d_tiles.alloc(tiles.size() * sizeof(int4)));
+    HIP_TRY(c, d_row_tint.alloc((size_t)R * 4));
+    HIP_TRY(c, d_bits.alloc((size_t)n_bits * 4));
+    HIP_TRY(c, d_first.alloc((size_t)R * 4));
+    HIP_TRY(c, d_last.alloc((size_t)R * 4));
+    HIP_TRY(c, d_tail.alloc((size_t)R));
+    HIP_TRY(c, d_adj[0].alloc((size_t)n_adj * 8));
+    HIP_TRY(c, d_adj[1].alloc((size_t)n_adj * 8));
+    HIP_TRY(c, d_deg.alloc((size_t)R * 4));
+    HIP_TRY(c, d_changed.alloc((size_t)T * 4));
+    hipStream_t s = c->stream;
+    HIP_TRY(c, hipMemcpyAsync(d_tints.p, tints.data(), tints.size() * sizeof(TintDesc), hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(d_tiles.p, tiles.data(), tiles.size() * sizeof(int4), hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(d_row_tint.p, row_tint.data(), (size_t)R * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(d_bits.p, b->bits, (size_t)n_bits * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(d_first.p, b->first, (size_t)R * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(d_last.p, b->last, (size_t)R * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(d_tail.p, b->tail, (size_t)R, hipMemcpyHostToDevice, s));
+
+    const int grid = n_tiles < 8192 ? n_tiles : 8192;
+    const size_t lds = (size_t)2 * kTile * (max_w | 1) * 4;
+    HIP_TRY(c, hipEventRecord(c->ev[0], s));
+    hipLaunchKernelGGL(k_compat, dim3(grid), dim3(256), lds, s, n_tiles, d_tiles.as<int4>(), d_tints.as<TintDesc>(),
+                       d_bits.as<unsigned>(), d_first.as<int>(), d_last.as<int>(), d_tail.as<unsigned char>(), d_adj[0].as<u64>());
+    HIP_TRY(c, hipEventRecord(c->ev[1], s));
+    int cur = 0;
+    if (prune) {
+        std::vector<int> changed((size_t)T);
+        const int deg_grid = (int)((R + 3) / 4 < 4096 ? (R + 3) / 4 : 4096);
+        for (int pass = 0; pass < (1 << 20); ++pass) {
+            HIP_TRY(c, hipMemsetAsync(d_changed.p, 0, (size_t)T * 4, s));
+            hipLaunchKernelGGL(k_degree, dim3(deg_grid), dim3(256), 0, s, R, d_row_tint.as<int>(), d_tints.as<TintDesc>(),
+                               d_adj[cur].as<u64>(), d_deg.as<int>());
+            hipLaunchKernelGGL(k_prune, dim3(grid), dim3(256), 0, s, n_tiles, d_tiles.as<int4>(), d_tints.as<TintDesc>(),
+                               d_adj[cur].as<u64>(), d_deg.as<int>(), d_adj[cur ^ 1].as<u64>(), d_changed.as<int>());
+            HIP_TRY(c, hipMemcpyAsync(changed.data(), d_changed.p, (size_t)T * 4, hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipStreamSynchronize(s));
+            cur ^= 1;
+            bool any = false;
+            for (int t = 0; t < T; ++t) if (changed[(size_t)t]) { any = true; if (rounds_out) rounds_out[t] += 1; }
+            if (!any) break;                             // a pass that removed nothing: done (:254)
+        }
+    }
+    HIP_TRY(c, hipEventRecord(c->ev[2], s));
+    HIP_TRY(c, hipMemcpyAsync(adj_out, d_adj[cur].p, (size_t)n_adj * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    HIP_TRY(c, hipGetLastError());
+    (void)hipEventElapsedTime(&c->compat_ms, c->ev[0], c->ev[1]);
+    (void)hipEventElapsedTime(&c->prune_ms, c->ev[1], c->ev[2]);
+    return FCLU_OK;
+}
+
+int fclu_last_timing(fclu_ctx *c, float *compat_ms, float *prune_ms) {
+    if (!c) return FCLU_ERR_ARG;
+    if (compat_ms) *compat_ms = c->compat_ms;
+    if (prune_ms) *prune_ms = c->prune_ms;
+    return FCLU_OK;
+}
+
+}  // extern "C"
