@@ -4,6 +4,8 @@
 * ``libfreddie_host.so`` -- the product's native host I/O: TSV parser, gaps/poly-A, writer (g++)
 * ``libfreddie_cluster.so`` -- gfx950 kernels + C-ABI of the clustering stage's pre-ILP graph work (hipcc; built by
   ``freddie_amd.cluster_prep.build``)
+* ``libfreddie_isoforms.so`` -- gfx950 kernels + C-ABI of the isoform-consensus stage's per-read loops (hipcc; built by
+  ``freddie_amd.isoforms.build``)
 * ``synth/libfreddie_synth.so`` -- synthetic split-partition generator (gcc; test/bench infrastructure)
 
 The oracle (``oracle/``) is test infrastructure and is built by ``oracle/Makefile``; it is never
@@ -51,9 +53,10 @@ def build_host(force=False, verbose=False):
 
 
 def build_all(force=False, verbose=False):
-    from . import cluster_prep, synth
+    from . import cluster_prep, isoforms, synth
     build_seg(force, verbose)
     build_host(force, verbose)
     cluster_prep.build(force, verbose)
+    isoforms.build(force, verbose)
     synth.build(force)
     return SEG_SO

@@ -1,0 +1,300 @@
+// freddie_isoforms.hip -- gfx950 kernels + C-ABI (include/freddie_isoforms.h) of the isoform-consensus stage's per-read
+// loops: the consensus counts of isoforms_cons() (py/freddie_isoforms.py:203-232) and the boundary votes of
+// correct_boundaries() (:129-137).  Integer work only; the layout is read-major label bytes, so the consensus kernel's
+// lanes (= consecutive segments of one read) load consecutive bytes.
+#include "freddie_isoforms.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+namespace {
+
+typedef long long i64;
+typedef unsigned long long u64;
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// One workgroup per isoform, its reads in chunks of kSpanCap.  Phase 1: the four waves split the chunk's reads and
+// find every read's span = first / last segment holding '1' (ballot over 64 label bytes at a time), widened by the
+// tail rule of :217-224, into LDS.  Phase 2: lanes = 64 consecutive segments, the waves split the reads again and count
+// coverage / consensus, partial sums meet in LDS.  The chunk's label bytes (tens of KB) are read from HBM once: the
+// second phase finds them in L2.
+constexpr int kSpanCap = 1024;
+constexpr int kE = 16;              // reads a wave keeps in flight (its label loads are 64 bytes each: latency, not bandwidth, is the limit)
+__global__ void __launch_bounds__(256) k_consensus(int n_iso, const i64 *iso_read_off, const int *n_seg, const i64 *iso_seg_off,
+                                                   const i64 *read_lab_off, const unsigned char *labels, const unsigned char *tail,
+                                                   int *cons, int *cov, int *tails) {
+    __shared__ int t_s[3];
+    __shared__ int2 sp_s[kSpanCap];
+    __shared__ i64 off_s[kSpanCap];
+    __shared__ int part[4][64][2];
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    for (int i = blockIdx.x; i < n_iso; i += gridDim.x) {
+        const i64 r0 = iso_read_off[i], r1 = iso_read_off[i + 1];
+        const int M = n_seg[i];
+        __syncthreads();
+        if (threadIdx.x < 3) t_s[threadIdx.x] = 0;
+        if (r0 == r1) for (int j = threadIdx.x; j < M; j += blockDim.x) { cons[iso_seg_off[i] + j] = 0; cov[iso_seg_off[i] + j] = 0; }
+        for (i64 rb = r0; rb < r1; rb += kSpanCap) {
+            const int n = (int)(r1 - rb < kSpanCap ? r1 - rb : kSpanCap);
+            __syncthreads();
+            for (int q = threadIdx.x; q < n; q += blockDim.x) off_s[q] = read_lab_off[rb + q];   // one coalesced pass
+            __syncthreads();
+            for (int q0 = wave * kE; q0 < n; q0 += 4 * kE) {              // ---- phase 1: spans, kE reads in flight
+                int first[kE], last[kE];
+#pragma unroll
+                for (int e = 0; e < kE; ++e) { first[e] = -1; last[e] = -1; }
+                for (int j0 = 0; j0 < M; j0 += 64) {
+                    const int j = j0 + lane;
+                    unsigned char b[kE];
+#pragma unroll
+                    for (int e = 0; e < kE; ++e) b[e] = (j < M && q0 + e < n) ? labels[off_s[q0 + e < n ? q0 + e : q0] + j] : (unsigned char)0;
+#pragma unroll
+                    for (int e = 0; e < kE; ++e) {
+                        const u64 m = __ballot(b[e] == '1');
+                        if (m) {
+                            if (first[e] < 0) first[e] = j0 + __ffsll((long long)m) - 1;
+                            last[e] = j0 + 63 - __clzll((long long)m);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < kE; ++e) {
+                    if (q0 + e >= n) break;
+                    if (first[e] >= 0 && tail[rb + q0 + e] == 1) { first[e] = 0; last[e] = M - 1; }   // 'S': the whole tint (:217-224)
+                    if (lane == 0) sp_s[q0 + e] = make_int2(first[e], last[e]);
+                }
+            }
+            __syncthreads();
+            for (int q = threadIdx.x; q < n; q += blockDim.x)
+                if (sp_s[q].x >= 0) atomicAdd(&t_s[tail[rb + q]], 1);      // reads without a '1' are not counted (:215-216)
+            for (int j0 = 0; j0 < M; j0 += 64) {                           // ---- phase 2: counts
+                const int j = j0 + lane;
+                int x = 0, c = 0;
+                for (int q0 = wave * kE; q0 < n; q0 += 4 * kE) {          // kE reads in flight, predicated loads
+                    unsigned char b[kE]; bool in[kE];
+#pragma unroll
+                    for (int e = 0; e < kE; ++e) {
+                        const int q = q0 + e < n ? q0 + e : q0;
+                        const int2 sp = sp_s[q];
+                        in[e] = q0 + e < n && j < M && j >= sp.x && j <= sp.y;
+                        b[e] = in[e] ? labels[off_s[q] + j] : (unsigned char)0;
+                    }
+#pragma unroll
+                    for (int e = 0; e < kE; ++e) { c += in[e]; x += b[e] == '1'; }
+                }
+                part[wave][lane][0] = x; part[wave][lane][1] = c;
+                __syncthreads();
+                if (wave == 0 && j < M) {
+                    const int xs = part[0][lane][0] + part[1][lane][0] + part[2][lane][0] + part[3][lane][0];
+                    const int cs = part[0][lane][1] + part[1][lane][1] + part[2][lane][1] + part[3][lane][1];
+                    const i64 o = iso_seg_off[i] + j;
+                    cons[o] = (rb == r0 ? 0 : cons[o]) + xs;               // later chunks add to the first chunk's sums
+                    cov[o] = (rb == r0 ? 0 : cov[o]) + cs;
+                }
+                __syncthreads();
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 3) tails[3 * (i64)i + threadIdx.x] = t_s[threadIdx.x];
+    }
+}
+
+// one workgroup per isoform: threads = the member reads' boundaries; every boundary votes for the isoform boundaries
+// within the window (they are ascending: lower bound, then walk)
+__global__ void __launch_bounds__(256) k_votes(int n_iso, const i64 *iso_read_off, const i64 *iso_b_off, const int *iso_bound,
+                                               const i64 *read_b_off, const int *read_bound, int window, int *votes) {
+    for (int i = blockIdx.x; i < n_iso; i += gridDim.x) {
+        const i64 b0 = iso_b_off[i], nb = iso_b_off[i + 1] - b0;
+        if (nb == 0) continue;
+        const i64 r0 = iso_read_off[i], r1 = iso_read_off[i + 1];
+        const i64 q0 = read_b_off[r0], q1 = read_b_off[r1];                // the member reads' boundaries are contiguous
+        const int *ib = iso_bound + b0;
+        for (i64 q = q0 + threadIdx.x; q < q1; q += blockDim.x) {
+            const int v = read_bound[q];
+            i64 lo = 0, hi = nb;
+            while (lo < hi) { i64 mid = (lo + hi) >> 1; if (ib[mid] < v - window) lo = mid + 1; else hi = mid; }
+            for (i64 k = lo; k < nb && ib[k] <= v + window; ++k)
+                atomicAdd(&votes[(b0 + k) * (2 * window + 1) + (v - ib[k] + window)], 1);
+        }
+    }
+}
+
+}  // namespace
+
+struct fiso_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[2] = {};
+    std::string err;
+    float kernel_ms = 0.f;
+};
+
+namespace {
+
+std::string g_create_error;
+
+int fail(fiso_ctx *c, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_error = buf;
+    return code;
+}
+
+struct Dev {
+    void *p = nullptr;
+    ~Dev() { if (p) (void)hipFree(p); }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+#define HIP_TRY(c, expr)                                                                                     \
+    do {                                                                                                     \
+        hipError_t e__ = (expr);                                                                             \
+        if (e__ != hipSuccess) return fail((c), FISO_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e__));      \
+    } while (0)
+
+template <typename T>
+int to_device(fiso_ctx *c, Dev &d, const T *src, size_t n) {
+    HIP_TRY(c, hipMalloc(&d.p, n * sizeof(T) + 16));
+    if (n) HIP_TRY(c, hipMemcpyAsync(d.p, src, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    return FISO_OK;
+}
+#define TRY(expr) do { int rc__ = (expr); if (rc__) return rc__; } while (0)
+
+int check_offsets(fiso_ctx *c, const char *what, const int64_t *off, i64 n) {
+    if (off[0] != 0) return fail(c, FISO_ERR_ARG, "%s does not start at 0", what);
+    for (i64 i = 0; i < n; ++i) if (off[i + 1] < off[i]) return fail(c, FISO_ERR_ARG, "%s is not monotone at %lld", what, i);
+    return FISO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fiso_abi_version(void) { return 1; }
+
+int fiso_create(int device, fiso_ctx **out) {
+    if (!out) return FISO_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, FISO_ERR_HIP, "no HIP device available: %s (this library has no CPU fallback)",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    if (device < 0 || device >= n) return fail(nullptr, FISO_ERR_ARG, "device ordinal out of range");
+    fiso_ctx *c = new fiso_ctx();
+    c->device = device;
+    e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    for (int i = 0; e == hipSuccess && i < 2; ++i) e = hipEventCreate(&c->ev[i]);
+    if (e != hipSuccess) {
+        fail(nullptr, FISO_ERR_HIP, "context creation failed: %s", hipGetErrorString(e));
+        delete c;
+        return FISO_ERR_HIP;
+    }
+    *out = c;
+    return FISO_OK;
+}
+
+void fiso_destroy(fiso_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    for (int i = 0; i < 2; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    delete c;
+}
+
+const char *fiso_last_error(const fiso_ctx *c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int fiso_consensus(fiso_ctx *c, int32_t n_iso, const int64_t *iso_read_off, const int32_t *n_seg, const int64_t *iso_seg_off,
+                   const int64_t *read_lab_off, const uint8_t *labels, const uint8_t *tail,
+                   int32_t *cons_out, int32_t *cov_out, int32_t *tails_out) {
+    if (!c || n_iso <= 0 || !iso_read_off || !n_seg || !iso_seg_off || !cons_out || !cov_out || !tails_out) return FISO_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    TRY(check_offsets(c, "iso_read_off", iso_read_off, n_iso));
+    TRY(check_offsets(c, "iso_seg_off", iso_seg_off, n_iso));
+    const i64 R = iso_read_off[n_iso], S = iso_seg_off[n_iso];
+    i64 lab_bytes = 0;
+    for (int i = 0; i < n_iso; ++i) {
+        if (n_seg[i] < 0 || iso_seg_off[i + 1] - iso_seg_off[i] != n_seg[i]) return fail(c, FISO_ERR_ARG, "isoform %d: iso_seg_off does not match n_seg", i);
+        for (i64 r = iso_read_off[i]; r < iso_read_off[i + 1]; ++r) {
+            if (read_lab_off[r] < 0 || tail[r] > 2) return fail(c, FISO_ERR_ARG, "read %lld: bad label offset or tail", r);
+            if (read_lab_off[r] + n_seg[i] > lab_bytes) lab_bytes = read_lab_off[r] + n_seg[i];
+        }
+    }
+    c->kernel_ms = 0.f;
+    Dev d_iro, d_ns, d_iso, d_rlo, d_lab, d_tail, d_cons, d_cov, d_tails;
+    TRY(to_device(c, d_iro, iso_read_off, (size_t)n_iso + 1));
+    TRY(to_device(c, d_ns, n_seg, (size_t)n_iso));
+    TRY(to_device(c, d_iso, iso_seg_off, (size_t)n_iso + 1));
+    TRY(to_device(c, d_rlo, read_lab_off, (size_t)R));
+    TRY(to_device(c, d_lab, labels, (size_t)lab_bytes));
+    TRY(to_device(c, d_tail, tail, (size_t)R));
+    HIP_TRY(c, hipMalloc(&d_cons.p, (size_t)S * 4 + 16));
+    HIP_TRY(c, hipMalloc(&d_cov.p, (size_t)S * 4 + 16));
+    HIP_TRY(c, hipMalloc(&d_tails.p, (size_t)n_iso * 12 + 16));
+    hipStream_t s = c->stream;
+    HIP_TRY(c, hipEventRecord(c->ev[0], s));
+    hipLaunchKernelGGL(k_consensus, dim3(n_iso < 8192 ? n_iso : 8192), dim3(256), 0, s, n_iso, d_iro.as<i64>(), d_ns.as<int>(),
+                       d_iso.as<i64>(), d_rlo.as<i64>(), d_lab.as<unsigned char>(), d_tail.as<unsigned char>(),
+                       d_cons.as<int>(), d_cov.as<int>(), d_tails.as<int>());
+    HIP_TRY(c, hipEventRecord(c->ev[1], s));
+    if (S) HIP_TRY(c, hipMemcpyAsync(cons_out, d_cons.p, (size_t)S * 4, hipMemcpyDeviceToHost, s));
+    if (S) HIP_TRY(c, hipMemcpyAsync(cov_out, d_cov.p, (size_t)S * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(tails_out, d_tails.p, (size_t)n_iso * 12, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    HIP_TRY(c, hipGetLastError());
+    (void)hipEventElapsedTime(&c->kernel_ms, c->ev[0], c->ev[1]);
+    return FISO_OK;
+}
+
+int fiso_boundary_votes(fiso_ctx *c, int32_t n_iso, const int64_t *iso_read_off, const int64_t *iso_b_off, const int32_t *iso_bound,
+                        const int64_t *read_b_off, const int32_t *read_bound, int32_t window, int32_t *votes_out) {
+    if (!c || n_iso <= 0 || !iso_read_off || !iso_b_off || !read_b_off || !votes_out) return FISO_ERR_ARG;
+    if (window < 1 || window > 20) return fail(c, FISO_ERR_ARG, "window must be in [1, 20] (py/freddie_isoforms.py:45)");
+    HIP_TRY(c, hipSetDevice(c->device));
+    TRY(check_offsets(c, "iso_read_off", iso_read_off, n_iso));
+    TRY(check_offsets(c, "iso_b_off", iso_b_off, n_iso));
+    const i64 R = iso_read_off[n_iso], B = iso_b_off[n_iso];
+    TRY(check_offsets(c, "read_b_off", read_b_off, R));
+    const i64 Q = read_b_off[R];
+    for (int i = 0; i < n_iso; ++i)
+        for (i64 k = iso_b_off[i] + 1; k < iso_b_off[i + 1]; ++k)
+            if (iso_bound[k] < iso_bound[k - 1]) return fail(c, FISO_ERR_ARG, "isoform %d: boundaries are not ascending", i);
+    c->kernel_ms = 0.f;
+    const size_t n_votes = (size_t)B * (size_t)(2 * window + 1);
+    if (n_votes == 0) return FISO_OK;
+    Dev d_iro, d_ibo, d_ib, d_rbo, d_rb, d_votes;
+    TRY(to_device(c, d_iro, iso_read_off, (size_t)n_iso + 1));
+    TRY(to_device(c, d_ibo, iso_b_off, (size_t)n_iso + 1));
+    TRY(to_device(c, d_ib, iso_bound, (size_t)B));
+    TRY(to_device(c, d_rbo, read_b_off, (size_t)R + 1));
+    TRY(to_device(c, d_rb, read_bound, (size_t)Q));
+    HIP_TRY(c, hipMalloc(&d_votes.p, n_votes * 4 + 16));
+    hipStream_t s = c->stream;
+    HIP_TRY(c, hipEventRecord(c->ev[0], s));
+    HIP_TRY(c, hipMemsetAsync(d_votes.p, 0, n_votes * 4, s));
+    hipLaunchKernelGGL(k_votes, dim3(n_iso < 8192 ? n_iso : 8192), dim3(256), 0, s, n_iso, d_iro.as<i64>(), d_ibo.as<i64>(),
+                       d_ib.as<int>(), d_rbo.as<i64>(), d_rb.as<int>(), window, d_votes.as<int>());
+    HIP_TRY(c, hipEventRecord(c->ev[1], s));
+    HIP_TRY(c, hipMemcpyAsync(votes_out, d_votes.p, n_votes * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    HIP_TRY(c, hipGetLastError());
+    (void)hipEventElapsedTime(&c->kernel_ms, c->ev[0], c->ev[1]);
+    return FISO_OK;
+}
+
+int fiso_last_kernel_ms(fiso_ctx *c, float *ms) {
+    if (!c || !ms) return FISO_ERR_ARG;
+    *ms = c->kernel_ms;
+    return FISO_OK;
+}
+
+}  // extern "C"

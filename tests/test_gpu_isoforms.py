@@ -1,0 +1,119 @@
+"""Isoform-consensus stage (row N4) on the GPU, through include/freddie_isoforms.h: GTF text against what the
+reference itself wrote (fixtures), the CLI on a directory of tints, and the device counts against the CPU oracle on
+random stage inputs that are larger than the fixtures."""
+import copy
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import isoforms_util as iu
+from freddie_amd import isoforms
+from oracle import isoforms_oracle
+from test_host_mirror import input_dir
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = isoforms.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("name", iu.names())
+def test_gtf_matches_reference(ctx, name, tmp_path):
+    doc, ctsv, split_tsv, _, _ = iu.write_case(name, tmp_path, input_dir)
+    for m, w in iu.settings():
+        recs = isoforms.run_consensus_batch([[doc["contig"], doc["tint_id"], ctsv, split_tsv, m, w]], ctx, verbose=False)
+        recs.sort()
+        assert "".join(r + "\n" for _, r in recs) == doc["gtf"]["%g,%d" % (m, w)], (name, m, w)
+
+
+def test_cli_on_a_directory_of_tints(tmp_path):
+    """Several tints, two contigs' worth of files in one cluster dir: the CLI's GTF = the sorted union of the reference's
+    per-tint records."""
+    names = ["g1_retention", "g_refine", "g_sigma12", "e_plateau_touch"]
+    cdir = str(tmp_path / "cluster"); sdir = str(tmp_path / "split")
+    want = []
+    for name in names:
+        doc = iu.load(name)
+        d, contig, tid = input_dir(name, tmp_path)
+        os.makedirs(os.path.join(cdir, contig), exist_ok=True); os.makedirs(os.path.join(sdir, contig), exist_ok=True)
+        open(os.path.join(cdir, contig, "cluster_%s_%d.tsv" % (contig, tid)), "w").write(doc["cluster_tsv"])
+        src = os.path.join(d, contig, "split_%s_%d.tsv" % (contig, tid))
+        open(os.path.join(sdir, contig, "split_%s_%d.tsv" % (contig, tid)), "wb").write(open(src, "rb").read())
+        want.append(doc["gtf"]["0.7,3"])
+    out = str(tmp_path / "out.gtf")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "py", "freddie_isoforms.py"), "-s", sdir, "-c", cdir, "-m", "0.7",
+                          "-w", "3", "-o", out, "--batch-tints", "3"], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert res.stdout.count("Building isoforms for contig") == 4
+    # the reference sorts (key, text) records over all tints: rebuild that order from the per-tint texts
+    recs = []
+    for text in want:
+        cur = None
+        for line in text.splitlines():
+            f = line.split("\t")
+            if f[2] == "transcript":
+                if cur:
+                    recs.append(cur)
+                cur = [(f[0], int(f[3]) - 1), line]
+            else:
+                cur[1] += "\n" + line
+        if cur:
+            recs.append(cur)
+    recs = sorted((k, t) for k, t in recs)
+    assert open(out).read() == "".join(t + "\n" for _, t in recs)
+
+
+def test_random_stage_inputs_match_the_oracle(ctx):
+    jobs = [iu.random_job(1, 40, 60, 50), iu.random_job(2, 5, 700, 300), iu.random_job(3, 300, 4, 9), iu.random_job(4, 2, 3, 1)]
+    want = copy.deepcopy(jobs)
+    for m, w in ((0.5, 8), (0.6, 20), (1.0, 1)):
+        a = copy.deepcopy(jobs); b = copy.deepcopy(want)
+        isoforms.isoforms_cons_batch(a, ctx)
+        for side in ("starts", "ends"):
+            isoforms.correct_boundaries_batch(side, a, m, w, ctx)
+        for isos, segments, reads in b:
+            isoforms_oracle.isoforms_cons(isos, segments, reads)
+            isoforms_oracle.correct_boundaries("starts", isos, reads, m, w)
+            isoforms_oracle.correct_boundaries("ends", isos, reads, m, w)
+        for (ia, _, _), (ib, _, _) in zip(a, b):
+            assert ia == ib
+        assert sum("starts" in i for ia, _, _ in a for i in ia.values()) > 100
+
+
+def test_counts_are_plain_sums(ctx):
+    """Property at a size the Python oracle is too slow for: 200 k reads; cov >= cons, per-isoform tails add up to the reads
+    that cover something, votes add up to the (read boundary, isoform boundary) pairs inside the window (numpy check)."""
+    rng = np.random.default_rng(5)
+    n_iso, per, M = 400, 500, 120
+    R = n_iso * per
+    lab = rng.choice(np.frombuffer(b"0012", np.uint8), size=(R, M), p=[0.3, 0.3, 0.3, 0.1])
+    lab[rng.random(R) < 0.01] = ord("0")
+    tail = rng.integers(0, 3, R).astype(np.uint8)
+    off, cons, cov, tails = ctx.consensus(np.arange(n_iso + 1) * per, np.full(n_iso, M), np.arange(R) * M, lab.reshape(-1), tail)
+    one = lab == ord("1")
+    has = one.any(1)
+    first = np.where(has, one.argmax(1), M); last = np.where(has, M - 1 - one[:, ::-1].argmax(1), -1)
+    first[has & (tail == 1)] = 0; last[has & (tail == 1)] = M - 1
+    j = np.arange(M)[None, :]
+    inside = (j >= first[:, None]) & (j <= last[:, None])
+    assert np.array_equal(cov.reshape(n_iso, M), inside.reshape(n_iso, per, M).sum(1))
+    assert np.array_equal(cons.reshape(n_iso, M), (inside & one).reshape(n_iso, per, M).sum(1))
+    for k in range(3):
+        assert np.array_equal(tails[:, k], (has & (tail == k)).reshape(n_iso, per).sum(1))
+    nb, w = 30, 7
+    iso_b = np.sort(rng.integers(0, 5000, (n_iso, nb)), axis=1).astype(np.int32)
+    rb = rng.integers(0, 5000, (R, 4)).astype(np.int32)
+    votes = ctx.boundary_votes(np.arange(n_iso + 1) * per, np.arange(n_iso + 1) * nb, iso_b.reshape(-1), np.arange(R + 1) * 4,
+                               rb.reshape(-1), w)
+    i = 17
+    d = rb[i * per:(i + 1) * per].reshape(-1)[None, :] - iso_b[i][:, None]
+    want = np.stack([(d == x).sum(1) for x in range(-w, w + 1)], axis=1)
+    assert np.array_equal(votes[i * nb:(i + 1) * nb], want)

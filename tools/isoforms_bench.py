@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Measurement of row N4 (isoform consensus counts + boundary votes) on MI355X through include/freddie_isoforms.h.
+
+    python tools/isoforms_bench.py [--isoforms N] [--reads-per-isoform R] [--segments M] [--steps K] [--no-cpu-baseline]
+
+One JSON line: reads processed per second of kernel time (HIP events on the library's stream; the call's host<->device
+copies are outside the bracket and reported as call_wall_ms), the consensus kernels' roofline with ALGORITHMIC bytes =
+one label byte per (read, segment) + two int32 per (isoform, segment) out -- what isoforms_cons() reads and produces
+once (py/freddie_isoforms.py:203-232) -- and the Python oracle (1 core) on a bounded sample of the same input."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from freddie_amd import isoforms  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--isoforms", type=int, default=4000)
+    ap.add_argument("--reads-per-isoform", type=int, default=500)
+    ap.add_argument("--segments", type=int, default=150)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+    rng = np.random.default_rng(11)
+    n_iso, per, M = a.isoforms, a.reads_per_isoform, a.segments
+    R = n_iso * per
+    lab = rng.choice(np.frombuffer(b"0012", np.uint8), size=(R, M), p=[0.3, 0.3, 0.3, 0.1])
+    tail = rng.integers(0, 3, R).astype(np.uint8)
+    iro = np.arange(n_iso + 1, dtype=np.int64) * per
+    nb, w = 12, 8
+    iso_b = np.sort(rng.integers(0, 50000, (n_iso, nb)), axis=1).astype(np.int32)
+    rb = rng.integers(0, 50000, (R, 8)).astype(np.int32)
+    ctx = isoforms.Context(0)
+    ctx.consensus(iro, np.full(n_iso, M), np.arange(R, dtype=np.int64) * M, lab.reshape(-1), tail)
+    cons_ms, votes_ms, wall = [], [], []
+    for _ in range(a.steps):
+        t0 = time.perf_counter()
+        ctx.kernel_ms = 0.0
+        ctx.consensus(iro, np.full(n_iso, M), np.arange(R, dtype=np.int64) * M, lab.reshape(-1), tail)
+        cons_ms.append(ctx.kernel_ms); ctx.kernel_ms = 0.0
+        ctx.boundary_votes(iro, np.arange(n_iso + 1, dtype=np.int64) * nb, iso_b.reshape(-1), np.arange(R + 1, dtype=np.int64) * 8,
+                           rb.reshape(-1), w)
+        votes_ms.append(ctx.kernel_ms)
+        wall.append(time.perf_counter() - t0)
+    c_ms, v_ms = float(np.mean(cons_ms)), float(np.mean(votes_ms))
+    alg = R * M + 8 * n_iso * M
+    out = {"metric": "reads/sec (isoform consensus counts + boundary votes, kernels)", "value": R / ((c_ms + v_ms) * 1e-3), "unit": "reads/s",
+           "n_gpus": 1, "steps": a.steps, "higher_is_better": True, "dtype": "u8/int32", "data": "synthetic",
+           "config": {"workload": "isoforms", "isoforms": n_iso, "reads": R, "segments": M, "window": w},
+           "kernel_ms": {"consensus": c_ms, "votes": v_ms}, "call_wall_ms": float(np.mean(wall)) * 1e3,
+           "roofline": {"kernel": "k_consensus", "bound": "hbm", "achieved": alg / (c_ms * 1e-3) / 1e9, "peak": 8000.0,
+                        "unit": "GB/s", "frac": alg / (c_ms * 1e-3) / 1e9 / 8000.0, "traffic": None, "algorithmic_bytes_per_launch": alg}}
+    if not a.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import isoforms_util as iu
+        from oracle import isoforms_oracle
+        t0 = time.perf_counter(); done = 0; k = 0
+        while time.perf_counter() - t0 < 10:
+            isos, segments, reads = iu.random_job(100 + k, 8, per, M)
+            t1 = time.perf_counter()
+            isoforms_oracle.isoforms_cons(isos, segments, reads)
+            for side in ("starts", "ends"):
+                isoforms_oracle.correct_boundaries(side, isos, reads, 0.5, w)
+            done += len(reads); k += 1
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": done / dt, "unit": "reads/s", "cores": 1, "kind": "port",
+                               "sample": "%d reads in %d synthetic tints (generation included), Python oracle, %.1f s" % (done, k, dt)}
+    print(json.dumps(out))
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
