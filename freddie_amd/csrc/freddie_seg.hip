@@ -2410,8 +2410,8 @@ struct fseg_ctx {
     int n_graphs = 0;   // few DP problems in the previous run: merge the per-size-class launches
     hipEvent_t ev[ST_COUNT + 1] = {};
     float stage_ms[ST_REPORTED] = {};
-    // Independent kernels of one run (threshold | candidates, pair thresholds | coverage, the scoring size classes,
-    // the DP classes) go to side streams between a fork and a join, so a captured run becomes a graph with parallel
+    // Independent kernels of one run (threshold | candidates, the scoring size classes, the DP classes) go to side
+    // streams (pair thresholds | coverage was tried too: the branch cost more than the overlap gave) between a fork and a join, so a captured run becomes a graph with parallel
     // branches (FSEG_NO_FORK=1 keeps everything on the one stream).
     static constexpr int kSide = 2, kForkEvents = 16;
     hipStream_t side[kSide] = {};
@@ -2643,8 +2643,7 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
     mark(5);
     // S5
     if (c->prob_cap > 0) {
-        hipStream_t q_thr = fork(0);
-        hipLaunchKernelGGL(k_pair_thresholds, dim3(grid_for(c->prob_cap, 1, 2048)), dim3(256), 0, q_thr, st, pr,
+        hipLaunchKernelGGL(k_pair_thresholds, dim3(grid_for(c->prob_cap, 1, 2048)), dim3(256), 0, s, st, pr,
                            c->d_prob_desc.as<ProbDesc>(), c->prob_cap, c->d_cand_off.as<i64>(), c->d_cand_y.as<int>(),
                            c->d_h_table.as<double>(), c->P.h_len,
                            c->P.threshold_rate, c->d_pair_thr.as<int2>(), c->pair_cap, c->d_amb.as<unsigned>(),
@@ -2654,7 +2653,6 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
                            c->d_cand_y.as<int>(), c->d_iv_start.as<int>(), c->d_lane_rep.as<int>(),
                            c->d_rep_exon_off.as<i64>(), c->d_ex_ts.as<int>(), c->d_ex_te.as<int>(),
                            c->d_cov.as<unsigned>(), c->cov_cap, c->d_work_active.as<unsigned char>());
-        join(0);
     }
     mark(6);
     }   // do_pre
