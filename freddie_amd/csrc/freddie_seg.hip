@@ -209,11 +209,47 @@ __global__ void __launch_bounds__(512) k_hist(int n_chunks, const int *chunk_par
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int wg_exclusive_scan(int v, int *lds, int *total);
 
+// Workgroup barrier that orders LDS traffic only: global loads and stores issued before it (prefetches of the next
+// tile, result stores) stay in flight, which a full __syncthreads() would wait for.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+// wg_exclusive_scan() with LDS-only barriers
+__device__ __forceinline__ int wg_exclusive_scan_lds(int v, int *lds /* >= 16 ints */, int *total) {
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    int x = v;
+    for (int d = 1; d < 64; d <<= 1) {
+        int y = __shfl_up(x, d);
+        if (lane >= d) x += y;
+    }
+    lds_barrier();
+    if (lane == 63) lds[wave] = x;
+    lds_barrier();
+    int off = 0, tot = 0;
+    for (int w = 0; w < nw; ++w) {
+        int sv = lds[w];
+        if (w < wave) off += sv;
+        tot += sv;
+    }
+    *total = tot;
+    return off + x - v;
+}
+
 // R > 0: radius known at compile time (the tap loop is fully unrolled: no window moves, no loop control, weights
 // in scalar registers); R == 0: any radius <= kMaxRadius.
+// One 16-byte record per tile (built on upload) instead of tile -> interval -> offsets: the per-tile set-up is one load.
+struct __align__(16) TileDesc {
+    i64 base;       // position of the interval's first element (pos_off[interval])
+    int y0;         // first position of the tile inside the interval
+    int len;        // interval length
+};
+constexpr int kSmoothStage = (kSmoothTile + 2 * kMaxRadius + 255) / 256;   // staged counts per thread, any radius
+
 template <int R>
-__global__ void __launch_bounds__(256) k_smooth(int n_tiles, const int *tile_iv, const int *tile_y0,
-                                                const i64 *pos_off, const int *y_raw, const double *__restrict__ w_g, int radius_rt,
+__global__ void __launch_bounds__(256) k_smooth(int n_tiles, const TileDesc *tiles,
+                                                const int *y_raw, const double *__restrict__ w_g, int radius_rt,
                                                 double *y_out, unsigned char *flag_pos, unsigned char *flag_zero, int *cum, int *tile_tot) {
     __shared__ int xs[kSmoothTile + 2 * kMaxRadius];
     __shared__ int scan_lds[16];
@@ -222,26 +258,42 @@ __global__ void __launch_bounds__(256) k_smooth(int n_tiles, const int *tile_iv,
     __shared__ double ys[kSmoothTile];
     __shared__ int cs[kSmoothTile];
     const int radius = R > 0 ? R : radius_rt;
-    for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-        int k = tile_iv[t];
-        i64 y0 = tile_y0[t];
-        i64 base = pos_off[k];
-        i64 len = pos_off[k + 1] - base;
-        __syncthreads();
-        for (int j = threadIdx.x; j <= radius; j += blockDim.x) ws[j] = w_g[j];
-        int span = kSmoothTile + 2 * radius;
-        for (int idx = threadIdx.x; idx < span; idx += blockDim.x) {
-            i64 y = y0 - radius + idx;
-            if (y < 0 || y >= len) y = reflect_index(y, len);      // only the few halo elements beyond the interval pay the modulo
-            xs[idx] = y_raw[base + y];
+    const int span = kSmoothTile + 2 * radius;
+    constexpr int kStage = R > 0 ? (kSmoothTile + 2 * R + 255) / 256 : kSmoothStage;
+    for (int j = threadIdx.x; j <= radius; j += blockDim.x) ws[j] = w_g[j];
+    // A tile is a short chain of dependent loads (record -> counts) followed by barriers, and a workgroup walks several
+    // tiles: the chain of the NEXT tile is issued before the arithmetic of the current one (counts into registers,
+    // the record one tile further ahead), so its latency hides behind the taps and the stores.
+    const int G = gridDim.x;
+    auto load_counts = [&](const TileDesc &d, int *v) {
+#pragma unroll
+        for (int e = 0; e < kStage; ++e) {
+            const int idx = e * 256 + threadIdx.x;
+            i64 y = (i64)d.y0 - radius + idx;
+            if (y < 0 || y >= d.len) y = reflect_index(y, d.len);      // only the few halo elements beyond the interval pay the modulo
+            v[e] = idx < span ? y_raw[d.base + y] : 0;
         }
-        __syncthreads();
+    };
+    int t = blockIdx.x;
+    TileDesc d_cur = {0, 0, 1}, d_next = {0, 0, 1};
+    int v_cur[kStage];
+    if (t < n_tiles) { d_cur = tiles[t]; load_counts(d_cur, v_cur); }
+    if (t + G < n_tiles) d_next = tiles[t + G];
+    for (; t < n_tiles; t += G) {
+        const i64 y0 = d_cur.y0, base = d_cur.base, len = d_cur.len;
+        lds_barrier();
+#pragma unroll
+        for (int e = 0; e < kStage; ++e) { const int idx = e * 256 + threadIdx.x; if (idx < span) xs[idx] = v_cur[e]; }
+        TileDesc d_n2 = {0, 0, 1};
+        if (t + 2 * G < n_tiles) d_n2 = tiles[t + 2 * G];
+        if (t + G < n_tiles) load_counts(d_next, v_cur);             // in flight during this tile's work
+        lds_barrier();
         {   // inclusive prefix sums of the histogram inside the tile + the tile total: lets k_segments evaluate
             // refine_segmentation's `sum(i_vals) < 20` test (:258) exactly in O(1) per segment
             int o4 = threadIdx.x * 4, v4[4], run = 0;
             for (int e = 0; e < 4; ++e) { run += (y0 + o4 + e < len) ? xs[radius + o4 + e] : 0; v4[e] = run; }
             int tot;
-            int ex = wg_exclusive_scan(run, scan_lds, &tot);
+            int ex = wg_exclusive_scan_lds(run, scan_lds, &tot);
             for (int e = 0; e < 4; ++e) cs[o4 + e] = ex + v4[e];
             if (threadIdx.x == 0) tile_tot[t] = tot;
         }
@@ -272,7 +324,7 @@ __global__ void __launch_bounds__(256) k_smooth(int n_tiles, const int *tile_iv,
                 ys[o4] = a0; ys[o4 + 1] = a1; ys[o4 + 2] = a2; ys[o4 + 3] = a3;
             }
         }
-        __syncthreads();
+        lds_barrier();
         for (int i = threadIdx.x; i < kSmoothTile; i += blockDim.x) {
             if (y0 + i < len) {
                 const double a = ys[i];
@@ -282,6 +334,7 @@ __global__ void __launch_bounds__(256) k_smooth(int n_tiles, const int *tile_iv,
                 cum[base + y0 + i] = cs[i];
             }
         }
+        d_cur = d_next; d_next = d_n2;
     }
 }
 
@@ -699,16 +752,14 @@ __global__ void k_vsum_part(int n_part, const i64 *voff, const i64 *chunk_off, c
 // S3b  candidates   (candidates_from_peaks :615-621; scipy _local_maxima_1d)
 // strict local maxima with the plateau-midpoint rule, plus the first and last position.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_peaks(int n_tiles, const int *tile_iv, const int *tile_y0, const i64 *pos_off,
+__global__ void __launch_bounds__(256) k_peaks(int n_tiles, const TileDesc *tiles,
                                                const double *yv, unsigned char *flag, unsigned char *final_zero,
                                                int *part_has2, int n_part) {
     // also clears the per-partition 'some default label is not 0' flags that k_label_cols sets much later
     if (blockIdx.x == 0) for (int p = threadIdx.x; p < n_part; p += blockDim.x) part_has2[p] = 0;
     for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-        int k = tile_iv[t];
-        i64 y0 = tile_y0[t];
-        i64 base = pos_off[k];
-        i64 len = pos_off[k + 1] - base;
+        const TileDesc d = tiles[t];
+        const i64 y0 = d.y0, base = d.base, len = d.len;
         const double *x = yv + base;
         for (int o = threadIdx.x; o < kSmoothTile; o += blockDim.x) {
             i64 i = y0 + o;
@@ -1431,13 +1482,6 @@ __global__ void k_init_pair_table() {
     }
 }
 
-// Workgroup barrier that orders LDS traffic only: global loads issued before it (the coverage-tile prefetch)
-// stay in flight, which a full __syncthreads() would wait for.
-__device__ __forceinline__ void lds_barrier() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
 
 template <int NM> struct ScoreCfg {
     static constexpr int kPairs = NM * (NM - 1) / 2;
@@ -2375,7 +2419,7 @@ struct fseg_ctx {
     std::vector<int> iv_start_h;
     // device buffers: inputs
     DevBuf d_part_iv_off, d_part_rep_off, d_part_lane_off, d_iv_start, d_iv_end, d_pos_off, d_iv_part, d_rep_weight,
-        d_rep_exon_off, d_ex_ts, d_ex_te, d_lane_rep, d_lane_start, d_lane_pmax, d_tile_iv, d_tile_y0, d_w_main,
+        d_rep_exon_off, d_ex_ts, d_ex_te, d_lane_rep, d_lane_start, d_lane_pmax, d_tile_desc, d_w_main,
         d_w_refine, d_h_table;
     // device buffers: position-sized
     DevBuf d_y_raw, d_y, d_flag, d_cflag, d_v, d_scan_state, d_bsum, d_bsum_side, d_g, d_pk, d_pf, d_kp, d_final_flag;
@@ -2573,8 +2617,8 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
     mark(1);
     // S2
 #define FSEG_LAUNCH_SMOOTH(RV)                                                                                         \
-    hipLaunchKernelGGL(k_smooth<RV>, dim3(tile_grid), dim3(256), 0, s, c->n_tiles, c->d_tile_iv.as<int>(),             \
-                       c->d_tile_y0.as<int>(), c->d_pos_off.as<i64>(), c->d_y_raw.as<int>(), c->d_w_main.as<double>(), \
+    hipLaunchKernelGGL(k_smooth<RV>, dim3(tile_grid), dim3(256), 0, s, c->n_tiles, c->d_tile_desc.as<TileDesc>(),      \
+                       c->d_y_raw.as<int>(), c->d_w_main.as<double>(),                                                 \
                        c->P.radius_main, c->d_y.as<double>(), c->d_flag.as<unsigned char>(),                           \
                        c->d_cflag.as<unsigned char>(), c->d_cum.as<int>(), c->d_tile_tot.as<int>())
     // sigma = 5 (default) and sigma = 3 (config 5) have their own unrolled instances; any other radius runs the loop
@@ -2606,8 +2650,8 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
     }
     mark(3);
     // S3b candidates
-    hipLaunchKernelGGL(k_peaks, dim3(tile_grid), dim3(256), 0, s, c->n_tiles, c->d_tile_iv.as<int>(), c->d_tile_y0.as<int>(),
-                       c->d_pos_off.as<i64>(), c->d_y.as<double>(), c->d_cflag.as<unsigned char>(),
+    hipLaunchKernelGGL(k_peaks, dim3(tile_grid), dim3(256), 0, s, c->n_tiles, c->d_tile_desc.as<TileDesc>(),
+                       c->d_y.as<double>(), c->d_cflag.as<unsigned char>(),
                        c->d_final_flag.as<unsigned char>(), c->d_part_has2.as<int>(), n_part);
     scan_counts(s, bsum, c->d_cflag.as<unsigned char>(), &st->n_cand, c->d_cand_off.as<i64>() + K);
     hipLaunchKernelGGL(k_scan_emit<kEmitPositions>, dim3(scan_grid), dim3(256), 0, s, c->d_cflag.as<unsigned char>(), NPOS,
@@ -2912,7 +2956,7 @@ void fseg_destroy(fseg_ctx *c) {
     drop_graph(c);
     DevBuf *bufs[] = {&c->d_part_iv_off, &c->d_part_rep_off, &c->d_part_lane_off, &c->d_iv_start, &c->d_iv_end, &c->d_pos_off,
                       &c->d_iv_part, &c->d_rep_weight, &c->d_rep_exon_off, &c->d_ex_ts, &c->d_ex_te, &c->d_lane_rep, &c->d_lane_start, &c->d_lane_pmax,
-                      &c->d_tile_iv, &c->d_tile_y0, &c->d_w_main, &c->d_w_refine, &c->d_h_table, &c->d_y_raw, &c->d_y,
+                      &c->d_tile_desc, &c->d_w_main, &c->d_w_refine, &c->d_h_table, &c->d_y_raw, &c->d_y,
                       &c->d_flag, &c->d_cflag, &c->d_v, &c->d_scan_state, &c->d_bsum, &c->d_bsum_side, &c->d_g, &c->d_pk, &c->d_pf, &c->d_kp, &c->d_final_flag,
                       &c->d_blk_iv0, &c->d_hc_part, &c->d_hc_p0, &c->d_hc_n, &c->d_hc_glo, &c->d_hc_ghi, &c->d_hc_llo, &c->d_hc_lhi, &c->d_voff, &c->d_chunk_off, &c->d_csum, &c->d_mean, &c->d_thr, &c->d_label_off, &c->d_part_has2, &c->d_rb_part, &c->d_rb_r0, &c->d_cand_off,
                       &c->d_cand_y, &c->d_fixed0, &c->d_added, &c->d_fixed, &c->d_chosen, &c->d_final_off, &c->d_final_y,
@@ -3041,14 +3085,15 @@ int fseg_upload(fseg_ctx *c, const fseg_batch *b) {
             }
         }
     }
-    std::vector<int> tile_iv, tile_y0, iv_tile0((size_t)K);
+    std::vector<TileDesc> tile_desc;
+    std::vector<int> iv_tile0((size_t)K);
     for (i64 k = 0; k < K; ++k) {
         i64 len = pos_off[k + 1] - pos_off[k];
-        iv_tile0[(size_t)k] = (int)tile_iv.size();
-        for (i64 y = 0; y < len; y += kSmoothTile) { tile_iv.push_back((int)k); tile_y0.push_back((int)y); }
+        iv_tile0[(size_t)k] = (int)tile_desc.size();
+        for (i64 y = 0; y < len; y += kSmoothTile) tile_desc.push_back(TileDesc{pos_off[k], (int)y, (int)len});
     }
     c->n_part = np; c->K = K; c->R = R; c->I = I; c->NPOS = NPOS; c->LANES = lanes; c->expanded = expanded;
-    c->n_tiles = (int)tile_iv.size();
+    c->n_tiles = (int)tile_desc.size();
     c->part_iv_off.assign(b->part_iv_off, b->part_iv_off + np + 1);
     c->part_rep_off.assign(b->part_rep_off, b->part_rep_off + np + 1);
     c->part_lane_off = part_lane_off;
@@ -3129,9 +3174,8 @@ int fseg_upload(fseg_ctx *c, const fseg_batch *b) {
     }
     TRY(ensure(c, c->d_part_has2, ((size_t)np + 1) * 4));
     TRY(upload_vec(c, c->d_iv_tile0, iv_tile0.data(), iv_tile0.size()));
-    TRY(ensure(c, c->d_tile_tot, (tile_iv.size() + 1) * 4));
-    TRY(upload_vec(c, c->d_tile_iv, tile_iv.data(), tile_iv.size()));
-    TRY(upload_vec(c, c->d_tile_y0, tile_y0.data(), tile_y0.size()));
+    TRY(ensure(c, c->d_tile_tot, (tile_desc.size() + 1) * 4));
+    TRY(upload_vec(c, c->d_tile_desc, tile_desc.data(), tile_desc.size()));
     // position-sized work buffers
     size_t np8 = (size_t)NPOS + 64;
     TRY(ensure(c, c->d_y_raw, np8 * 4)); TRY(ensure(c, c->d_cum, np8 * 4)); TRY(ensure(c, c->d_y, np8 * 8)); TRY(ensure(c, c->d_flag, np8)); TRY(ensure(c, c->d_cflag, np8));
