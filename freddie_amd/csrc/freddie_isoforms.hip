@@ -31,6 +31,7 @@ __global__ void __launch_bounds__(256) k_consensus(int n_iso, const i64 *iso_rea
     __shared__ int t_s[3];
     __shared__ int2 sp_s[kSpanCap];
     __shared__ i64 off_s[kSpanCap];
+    __shared__ unsigned char tl_s[kSpanCap];
     __shared__ int part[4][64][2];
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     for (int i = blockIdx.x; i < n_iso; i += gridDim.x) {
@@ -42,7 +43,7 @@ __global__ void __launch_bounds__(256) k_consensus(int n_iso, const i64 *iso_rea
         for (i64 rb = r0; rb < r1; rb += kSpanCap) {
             const int n = (int)(r1 - rb < kSpanCap ? r1 - rb : kSpanCap);
             __syncthreads();
-            for (int q = threadIdx.x; q < n; q += blockDim.x) off_s[q] = read_lab_off[rb + q];   // one coalesced pass
+            for (int q = threadIdx.x; q < n; q += blockDim.x) { off_s[q] = read_lab_off[rb + q]; tl_s[q] = tail[rb + q]; }   // one coalesced pass
             __syncthreads();
             for (int q0 = wave * kE; q0 < n; q0 += 4 * kE) {              // ---- phase 1: spans, kE reads in flight
                 int first[kE], last[kE];
@@ -50,12 +51,15 @@ __global__ void __launch_bounds__(256) k_consensus(int n_iso, const i64 *iso_rea
                 for (int e = 0; e < kE; ++e) { first[e] = -1; last[e] = -1; }
                 for (int j0 = 0; j0 < M; j0 += 64) {
                     const int j = j0 + lane;
+                    // unconditional loads from clamped (always valid) addresses, predicate applied afterwards: a
+                    // conditional load compiles to a branch with its own wait, which serialises the kE loads
+                    const int jc = j < M ? j : M - 1;
                     unsigned char b[kE];
 #pragma unroll
-                    for (int e = 0; e < kE; ++e) b[e] = (j < M && q0 + e < n) ? labels[off_s[q0 + e < n ? q0 + e : q0] + j] : (unsigned char)0;
+                    for (int e = 0; e < kE; ++e) b[e] = labels[off_s[q0 + e < n ? q0 + e : q0] + jc];
 #pragma unroll
                     for (int e = 0; e < kE; ++e) {
-                        const u64 m = __ballot(b[e] == '1');
+                        const u64 m = __ballot(j < M && q0 + e < n && b[e] == '1');
                         if (m) {
                             if (first[e] < 0) first[e] = j0 + __ffsll((long long)m) - 1;
                             last[e] = j0 + 63 - __clzll((long long)m);
@@ -65,27 +69,28 @@ __global__ void __launch_bounds__(256) k_consensus(int n_iso, const i64 *iso_rea
 #pragma unroll
                 for (int e = 0; e < kE; ++e) {
                     if (q0 + e >= n) break;
-                    if (first[e] >= 0 && tail[rb + q0 + e] == 1) { first[e] = 0; last[e] = M - 1; }   // 'S': the whole tint (:217-224)
+                    if (first[e] >= 0 && tl_s[q0 + e] == 1) { first[e] = 0; last[e] = M - 1; }   // 'S': the whole tint (:217-224)
                     if (lane == 0) sp_s[q0 + e] = make_int2(first[e], last[e]);
                 }
             }
             __syncthreads();
             for (int q = threadIdx.x; q < n; q += blockDim.x)
-                if (sp_s[q].x >= 0) atomicAdd(&t_s[tail[rb + q]], 1);      // reads without a '1' are not counted (:215-216)
+                if (sp_s[q].x >= 0) atomicAdd(&t_s[tl_s[q]], 1);      // reads without a '1' are not counted (:215-216)
             for (int j0 = 0; j0 < M; j0 += 64) {                           // ---- phase 2: counts
                 const int j = j0 + lane;
                 int x = 0, c = 0;
                 for (int q0 = wave * kE; q0 < n; q0 += 4 * kE) {          // kE reads in flight, predicated loads
+                    const int jc = j < M ? j : M - 1;
                     unsigned char b[kE]; bool in[kE];
 #pragma unroll
                     for (int e = 0; e < kE; ++e) {
                         const int q = q0 + e < n ? q0 + e : q0;
                         const int2 sp = sp_s[q];
                         in[e] = q0 + e < n && j < M && j >= sp.x && j <= sp.y;
-                        b[e] = in[e] ? labels[off_s[q] + j] : (unsigned char)0;
+                        b[e] = labels[off_s[q] + jc];                         // unconditional (see phase 1)
                     }
 #pragma unroll
-                    for (int e = 0; e < kE; ++e) { c += in[e]; x += b[e] == '1'; }
+                    for (int e = 0; e < kE; ++e) { c += in[e]; x += in[e] && b[e] == '1'; }
                 }
                 part[wave][lane][0] = x; part[wave][lane][1] = c;
                 __syncthreads();
