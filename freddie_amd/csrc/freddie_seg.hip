@@ -525,9 +525,17 @@ __global__ void __launch_bounds__(256) k_scan_emit(const unsigned char *flags, i
         const i64 b = blockIdx.x;                                    // grid == nb
         const i64 w0 = b * kScanBlock + (i64)wave * 2048;            // first position of this wave
         int s = 0;
+        unsigned fm = 0;                                             // bit j = flag of position w0 + lane * 32 + j
         {
             i64 i0 = w0 + (i64)lane * 32;
-            if (i0 < n) s = count_flags32(load_flags32(flags, i0, n));
+            if (i0 < n) {
+                const Flags32 f = load_flags32(flags, i0, n);
+                s = count_flags32(f);
+                for (int q = 0; q < 8; ++q) {
+                    const unsigned w = f.w[q];                       // four 0/1 bytes -> four bits
+                    fm |= ((w & 1u) | ((w >> 7) & 2u) | ((w >> 14) & 4u) | ((w >> 21) & 8u)) << (4 * q);
+                }
+            }
         }
         for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
         if (lane == 0) wave_cnt[wave] = s;
@@ -536,29 +544,45 @@ __global__ void __launch_bounds__(256) k_scan_emit(const unsigned char *flags, i
         int ex = bsum ? bsum[b] : (int)scan_lookback(state, b, nb, tot, &bcast, total_out, off_last, err);
         for (int w = 0; w < wave; ++w) ex += wave_cnt[w];
         if (s) {
+            // The wave walks its 2048 positions in rows of 64 (lane = column), so the loads of y and the compacted
+            // stores are coalesced.  Row q's 64 flags are the masks of lanes 2q and 2q+1 (two readlanes, no memory),
+            // and the values of eight rows are loaded together from clamped addresses before any of them is used: a
+            // load under a condition would be a branch with its own wait, one memory round trip per row.
             i64 k = -1, k_end = 0, k_base = 0;
-            for (int q = 0; q < 32; ++q) {
-                const i64 i = w0 + q * 64 + lane;
-                const bool f = i < n && (flags[i] & 1);
-                const u64 m = __ballot(f);
-                if (!m) continue;
-                if (f) {
-                    const int d = ex + __popcll(m & lt_mask);
-                    if (MODE == kEmitValues) v[d] = y[i];
-                    else {
-                        if (k < 0 || i >= k_end) {
-                            // the interval of position i lies between the first intervals of this and the next block
-                            const i64 ka = k < 0 ? blk_iv0[b] : k, kb = (i64)blk_iv0[b + 1] + 1;
-                            k = ka + last_le(pos_off + ka, kb - ka, i);
-                            k_base = pos_off[k]; k_end = pos_off[k + 1];
-                        }
-                        int yy = (int)(i - k_base);
-                        out_y[d] = yy;
-                        if (out_pos) out_pos[d] = iv_start[k] + yy;
-                        if (yy == 0) out_off[k] = d;
-                    }
+            for (int q0 = 0; q0 < 32; q0 += 8) {
+                u64 m[8];
+                double yv[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int q = q0 + e;
+                    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)fm, 2 * q);
+                    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)fm, 2 * q + 1);
+                    m[e] = (u64)lo | ((u64)hi << 32);
+                    const i64 i = w0 + q * 64 + lane;
+                    if (MODE == kEmitValues) yv[e] = y[i < n ? i : n - 1];
                 }
-                ex += __popcll(m);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    if (!m[e]) continue;
+                    const i64 i = w0 + (q0 + e) * 64 + lane;
+                    if ((m[e] >> lane) & 1ULL) {
+                        const int d = ex + __popcll(m[e] & lt_mask);
+                        if (MODE == kEmitValues) v[d] = yv[e];
+                        else {
+                            if (k < 0 || i >= k_end) {
+                                // the interval of position i lies between the first intervals of this and the next block
+                                const i64 ka = k < 0 ? blk_iv0[b] : k, kb = (i64)blk_iv0[b + 1] + 1;
+                                k = ka + last_le(pos_off + ka, kb - ka, i);
+                                k_base = pos_off[k]; k_end = pos_off[k + 1];
+                            }
+                            int yy = (int)(i - k_base);
+                            out_y[d] = yy;
+                            if (out_pos) out_pos[d] = iv_start[k] + yy;
+                            if (yy == 0) out_off[k] = d;
+                        }
+                    }
+                    ex += __popcll(m[e]);
+                }
             }
         }
     }
@@ -757,22 +781,50 @@ __global__ void __launch_bounds__(256) k_peaks(int n_tiles, const TileDesc *tile
                                                int *part_has2, int n_part) {
     // also clears the per-partition 'some default label is not 0' flags that k_label_cols sets much later
     if (blockIdx.x == 0) for (int p = threadIdx.x; p < n_part; p += blockDim.x) part_has2[p] = 0;
-    for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-        const TileDesc d = tiles[t];
-        const i64 y0 = d.y0, base = d.base, len = d.len;
+    // Like k_smooth, a workgroup walks several tiles and each is a short chain record -> values -> flags: the next
+    // tile's values are loaded (and the record after that) before the current tile's flags are decided.
+    const int G = gridDim.x;
+    auto load3 = [&](const TileDesc &d, double *xm, double *xi, double *xp) {
+        const double *x = yv + d.base;
+        // the three neighbours of this thread's four positions, loaded together from clamped addresses (a load under a
+        // condition is a branch with its own wait); the plateau walk below touches memory only for equal neighbours
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            i64 i = (i64)d.y0 + e * 256 + threadIdx.x;
+            if (i > d.len - 1) i = d.len - 1;
+            xi[e] = x[i]; xm[e] = x[i > 0 ? i - 1 : 0]; xp[e] = x[i < d.len - 1 ? i + 1 : d.len - 1];
+        }
+    };
+    int t = blockIdx.x;
+    TileDesc d_cur = {0, 0, 1}, d_next = {0, 0, 1};
+    double xm[4], xi[4], xp[4];
+    if (t < n_tiles) { d_cur = tiles[t]; load3(d_cur, xm, xi, xp); }
+    if (t + G < n_tiles) d_next = tiles[t + G];
+    for (; t < n_tiles; t += G) {
+        const i64 y0 = d_cur.y0, base = d_cur.base, len = d_cur.len;
         const double *x = yv + base;
-        for (int o = threadIdx.x; o < kSmoothTile; o += blockDim.x) {
-            i64 i = y0 + o;
+        double cm[4], ci[4], cp[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { cm[e] = xm[e]; ci[e] = xi[e]; cp[e] = xp[e]; }
+        TileDesc d_n2 = {0, 0, 1};
+        if (t + 2 * G < n_tiles) d_n2 = tiles[t + 2 * G];
+        if (t + G < n_tiles) load3(d_next, xm, xi, xp);                 // in flight while this tile's flags are written
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const i64 i = y0 + e * 256 + threadIdx.x;
             if (i >= len) break;
             final_zero[base + i] = 0;                       // final-position flags start cleared (k_segments / k_refine set them)
             if (i == 0 || i == len - 1) { flag[base + i] = 1; continue; }
-            double xi = x[i];
-            if (x[i - 1] < xi) {
-                i64 ia = i + 1;
-                while (ia < len - 1 && x[ia] == xi) ++ia;
-                if (x[ia] < xi) flag[base + (i + ia - 1) / 2] = 1;
+            if (cm[e] < ci[e]) {
+                if (cp[e] < ci[e]) flag[base + i] = 1;      // strict peak: plateau of one (ia = i + 1, midpoint i)
+                else if (cp[e] == ci[e]) {
+                    i64 ia = i + 1;
+                    while (ia < len - 1 && x[ia] == ci[e]) ++ia;
+                    if (x[ia] < ci[e]) flag[base + (i + ia - 1) / 2] = 1;
+                }
             }
         }
+        d_cur = d_next; d_next = d_n2;
     }
 }
 
