@@ -2180,12 +2180,16 @@ __global__ void k_segments(i64 K, const i64 *pos_off, const i64 *cand_off, const
     }
 }
 
+constexpr int kRefCap = 1024;       // segment length up to which k_refine works out of LDS
 __global__ void __launch_bounds__(64) k_refine(const Status *st, const int *cand_iv, const int *rseg_c,
                                                const int *rseg_prev, const int *cand_y, const i64 *pos_off,
                                                const int *y_raw, const double *w_g, int radius, double sigma,
                                                double *g_scr, int *pk_scr, unsigned char *flag_scr,
                                                unsigned char *keep_scr, unsigned char *final_flag) {
     __shared__ double ws[kMaxRadius + 1];
+    __shared__ int xl[kRefCap], pkl[kRefCap];
+    __shared__ double gl[kRefCap];
+    __shared__ unsigned char pfl[kRefCap], kpl[kRefCap];
     const int skip = 20;
     int lane = lane_id();
     for (int j = lane; j <= radius; j += 64) ws[j] = w_g[j];
@@ -2199,6 +2203,84 @@ __global__ void __launch_bounds__(64) k_refine(const Status *st, const int *cand
         int len = e - s;
         i64 base = pos_off[cand_iv[sg]] + s;
         const int *xr = y_raw + base;
+        if (len <= kRefCap) {
+            // ---- the segment fits in LDS (nearly all do): its counts are fetched once, four coalesced rows at a time
+            // from clamped addresses (a load under a condition is a branch with its own wait -- and the filter below
+            // would do 2 * radius of them per position), then everything runs out of LDS --------------------------------
+            i64 tot_l = 0;
+            for (int i0 = 0; i0 < len; i0 += 256) {
+                int v[4];
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) { const int t = i0 + e4 * 64 + lane; v[e4] = xr[t < len ? t : len - 1]; }
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) {
+                    const int t = i0 + e4 * 64 + lane;
+                    if (t < len) { const int m = (t < skip || t >= len - skip) ? 0 : v[e4]; xl[t] = m; tot_l += m; }   // zeroed ends (:256-257)
+                }
+            }
+            for (int d = 32; d >= 1; d >>= 1) tot_l += __shfl_xor(tot_l, d);
+            if (tot_l < 20) continue;                                     // sum(i_vals) < 20 -> skip (:258)
+            __syncthreads();
+            for (int i = lane; i < len; i += 64) {                         // gaussian_filter1d(..., mode='constant', truncate=1.0) (:260-261)
+                double acc = __dmul_rn((double)xl[i], ws[0]);
+                for (int j = radius; j >= 1; --j) {
+                    const int a = i - j, b = i + j;
+                    const int sv = (a >= 0 ? xl[a] : 0) + (b < len ? xl[b] : 0);
+                    acc = __dadd_rn(acc, __dmul_rn((double)sv, ws[j]));
+                }
+                gl[i] = acc;
+                pfl[i] = 0;
+            }
+            __syncthreads();
+            for (int i = 1 + lane; i < len - 1; i += 64) {                 // scipy _local_maxima_1d
+                const double gi = gl[i];
+                if (gl[i - 1] < gi) {
+                    int ia = i + 1;
+                    while (ia < len - 1 && gl[ia] == gi) ++ia;
+                    if (gl[ia] < gi) pfl[(i + ia - 1) / 2] = 1;
+                }
+            }
+            __syncthreads();
+            int m = 0;
+            for (int t0 = 0; t0 < len; t0 += 64) {
+                const int i = t0 + lane;
+                const bool f = i < len && pfl[i];
+                const u64 mask = __ballot(f);
+                if (f) { const int rank = __popcll(mask & ((1ULL << lane) - 1ULL)); pkl[m + rank] = i; kpl[m + rank] = 1; }
+                m += __popcll(mask);
+            }
+            __syncthreads();
+            for (;;) {                                                     // find_peaks(distance=20), as in the general path below
+                double bv = -INFINITY; int bq = -1;
+                for (int q = lane; q < m; q += 64)
+                    if (kpl[q] == 1) { const double v = gl[pkl[q]]; if (v > bv || (v == bv && q > bq)) { bv = v; bq = q; } }
+                for (int d = 32; d >= 1; d >>= 1) {
+                    const double ov = __shfl_xor(bv, d); const int oq = __shfl_xor(bq, d);
+                    if (oq >= 0 && (bq < 0 || ov > bv || (ov == bv && oq > bq))) { bv = ov; bq = oq; }
+                }
+                if (bq < 0) break;
+                if (lane == 0) {
+                    kpl[bq] = 2;
+                    const int pj = pkl[bq];
+                    for (int q = bq - 1; q >= 0 && pj - pkl[q] < skip; --q) kpl[q] = 0;
+                    for (int q = bq + 1; q < m && pkl[q] - pj < skip; ++q) kpl[q] = 0;
+                }
+                __syncthreads();
+            }
+            for (int q = lane; q < m; q += 64) {
+                if (kpl[q] != 2) continue;
+                const int i = pkl[q];
+                i64 a = (i64)rint((double)i - sigma), b = (i64)rint((double)i + sigma + 1.0);   // Python round(): half even
+                if (a < 0) { a += len; if (a < 0) a = 0; } else if (a > len) a = len;           // slice semantics (:263)
+                if (b < 0) { b += len; if (b < 0) b = 0; } else if (b > len) b = len;
+                double sm = 0.0;
+                for (i64 x = a; x < b; ++x) sm = __dadd_rn(sm, gl[x]);
+                if (!(sm < 20.0)) final_flag[base + i] = 1;
+            }
+            __syncthreads();
+            continue;
+        }
+        // ---- general path (segments longer than kRefCap): scratch in global memory -------------------------------
         // sum(i_vals) < 20 -> skip (:258); values are exact integers
         i64 tot = 0;
         for (int i = skip + lane; i < len - skip; i += 64) tot += xr[i];
