@@ -776,55 +776,47 @@ __global__ void k_vsum_part(int n_part, const i64 *voff, const i64 *chunk_off, c
 // S3b  candidates   (candidates_from_peaks :615-621; scipy _local_maxima_1d)
 // strict local maxima with the plateau-midpoint rule, plus the first and last position.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_peaks(int n_tiles, const TileDesc *tiles,
-                                               const double *yv, unsigned char *flag, unsigned char *final_zero,
-                                               int *part_has2, int n_part) {
+// edge[p]: bit 0 = p is the first position of its interval, bit 1 = the last one.  Built once per uploaded batch.
+__global__ void __launch_bounds__(256) k_edges(i64 K, const i64 *pos_off, unsigned char *edge) {
+    for (i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x; k < K; k += (i64)gridDim.x * blockDim.x) {
+        const i64 a = pos_off[k], b = pos_off[k + 1] - 1;
+        if (a == b) edge[a] = 3;
+        else { edge[a] = 1; edge[b] = 2; }
+    }
+}
+// Flat over all positions of the batch (intervals are contiguous in the position arrays): a thread owns four consecutive
+// positions, the interval structure comes from the edge bytes, every lane is busy whatever the interval lengths are,
+// and the loads are wide and unconditional.  A position that is neither first nor last has both neighbours in its own
+// interval; the plateau walk to the right stops at the interval's last position.
+__global__ void __launch_bounds__(256) k_peaks(i64 n_pos, const unsigned char *edge, const double *x, unsigned char *flag,
+                                               unsigned char *final_zero, int *part_has2, int n_part) {
     // also clears the per-partition 'some default label is not 0' flags that k_label_cols sets much later
     if (blockIdx.x == 0) for (int p = threadIdx.x; p < n_part; p += blockDim.x) part_has2[p] = 0;
-    // Like k_smooth, a workgroup walks several tiles and each is a short chain record -> values -> flags: the next
-    // tile's values are loaded (and the record after that) before the current tile's flags are decided.
-    const int G = gridDim.x;
-    auto load3 = [&](const TileDesc &d, double *xm, double *xi, double *xp) {
-        const double *x = yv + d.base;
-        // the three neighbours of this thread's four positions, loaded together from clamped addresses (a load under a
-        // condition is a branch with its own wait); the plateau walk below touches memory only for equal neighbours
+    const i64 n4 = (n_pos + 3) >> 2;
+    for (i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x; g < n4; g += (i64)gridDim.x * blockDim.x) {
+        const i64 p0 = g * 4;
+        // the arrays are padded by 64 elements, so the 4-wide loads of the last group stay inside the allocation
+        const double2 v01 = *reinterpret_cast<const double2 *>(x + p0), v23 = *reinterpret_cast<const double2 *>(x + p0 + 2);
+        const double left = x[p0 > 0 ? p0 - 1 : 0], right = x[p0 + 4 < n_pos ? p0 + 4 : n_pos - 1];
+        const unsigned e4 = *reinterpret_cast<const unsigned *>(edge + p0);
+        *reinterpret_cast<unsigned *>(final_zero + p0) = 0u;    // final-position flags start cleared (k_segments / k_refine set them)
+        const double w[6] = {left, v01.x, v01.y, v23.x, v23.y, right};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            i64 i = (i64)d.y0 + e * 256 + threadIdx.x;
-            if (i > d.len - 1) i = d.len - 1;
-            xi[e] = x[i]; xm[e] = x[i > 0 ? i - 1 : 0]; xp[e] = x[i < d.len - 1 ? i + 1 : d.len - 1];
-        }
-    };
-    int t = blockIdx.x;
-    TileDesc d_cur = {0, 0, 1}, d_next = {0, 0, 1};
-    double xm[4], xi[4], xp[4];
-    if (t < n_tiles) { d_cur = tiles[t]; load3(d_cur, xm, xi, xp); }
-    if (t + G < n_tiles) d_next = tiles[t + G];
-    for (; t < n_tiles; t += G) {
-        const i64 y0 = d_cur.y0, base = d_cur.base, len = d_cur.len;
-        const double *x = yv + base;
-        double cm[4], ci[4], cp[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { cm[e] = xm[e]; ci[e] = xi[e]; cp[e] = xp[e]; }
-        TileDesc d_n2 = {0, 0, 1};
-        if (t + 2 * G < n_tiles) d_n2 = tiles[t + 2 * G];
-        if (t + G < n_tiles) load3(d_next, xm, xi, xp);                 // in flight while this tile's flags are written
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const i64 i = y0 + e * 256 + threadIdx.x;
-            if (i >= len) break;
-            final_zero[base + i] = 0;                       // final-position flags start cleared (k_segments / k_refine set them)
-            if (i == 0 || i == len - 1) { flag[base + i] = 1; continue; }
-            if (cm[e] < ci[e]) {
-                if (cp[e] < ci[e]) flag[base + i] = 1;      // strict peak: plateau of one (ia = i + 1, midpoint i)
-                else if (cp[e] == ci[e]) {
-                    i64 ia = i + 1;
-                    while (ia < len - 1 && x[ia] == ci[e]) ++ia;
-                    if (x[ia] < ci[e]) flag[base + (i + ia - 1) / 2] = 1;
+            const i64 p = p0 + e;
+            if (p >= n_pos) break;
+            const unsigned ed = (e4 >> (8 * e)) & 0xffu;
+            if (ed) { flag[p] = 1; continue; }              // first and last position of an interval are candidates (:618-620)
+            const double xi = w[e + 1];
+            if (w[e] < xi) {
+                if (w[e + 2] < xi) flag[p] = 1;             // strict peak: plateau of one
+                else if (w[e + 2] == xi) {
+                    i64 ia = p + 1;
+                    while (!(edge[ia] & 2) && x[ia] == xi) ++ia;
+                    if (x[ia] < xi) flag[(p + ia - 1) / 2] = 1;   // plateau midpoint (positions of one interval are consecutive)
                 }
             }
         }
-        d_cur = d_next; d_next = d_n2;
     }
 }
 
@@ -2559,6 +2551,7 @@ struct fseg_ctx {
     DevBuf d_y_raw, d_y, d_flag, d_cflag, d_v, d_scan_state, d_bsum, d_bsum_side, d_g, d_pk, d_pf, d_kp, d_final_flag;
     // partition-sized
     DevBuf d_blk_iv0;          // interval of the first position of every scan block (+ a sentinel)
+    DevBuf d_edge;             // per position: bit 0 = first of its interval, bit 1 = last (k_edges, once per batch)
     DevBuf d_hc_part, d_hc_p0, d_hc_n, d_hc_glo, d_hc_ghi, d_hc_llo, d_hc_lhi;
     int n_hist_chunks = 0;
     DevBuf d_voff, d_chunk_off, d_csum, d_mean, d_thr, d_label_off, d_part_has2, d_rb_part, d_rb_r0;
@@ -2784,7 +2777,7 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
     }
     mark(3);
     // S3b candidates
-    hipLaunchKernelGGL(k_peaks, dim3(tile_grid), dim3(256), 0, s, c->n_tiles, c->d_tile_desc.as<TileDesc>(),
+    hipLaunchKernelGGL(k_peaks, dim3(grid_for(NPOS / 4 + 1, 256, 16384)), dim3(256), 0, s, NPOS, c->d_edge.as<unsigned char>(),
                        c->d_y.as<double>(), c->d_cflag.as<unsigned char>(),
                        c->d_final_flag.as<unsigned char>(), c->d_part_has2.as<int>(), n_part);
     scan_counts(s, bsum, c->d_cflag.as<unsigned char>(), &st->n_cand, c->d_cand_off.as<i64>() + K);
@@ -3092,7 +3085,7 @@ void fseg_destroy(fseg_ctx *c) {
                       &c->d_iv_part, &c->d_rep_weight, &c->d_rep_exon_off, &c->d_ex_ts, &c->d_ex_te, &c->d_lane_rep, &c->d_lane_start, &c->d_lane_pmax,
                       &c->d_tile_desc, &c->d_w_main, &c->d_w_refine, &c->d_h_table, &c->d_y_raw, &c->d_y,
                       &c->d_flag, &c->d_cflag, &c->d_v, &c->d_scan_state, &c->d_bsum, &c->d_bsum_side, &c->d_g, &c->d_pk, &c->d_pf, &c->d_kp, &c->d_final_flag,
-                      &c->d_blk_iv0, &c->d_hc_part, &c->d_hc_p0, &c->d_hc_n, &c->d_hc_glo, &c->d_hc_ghi, &c->d_hc_llo, &c->d_hc_lhi, &c->d_voff, &c->d_chunk_off, &c->d_csum, &c->d_mean, &c->d_thr, &c->d_label_off, &c->d_part_has2, &c->d_rb_part, &c->d_rb_r0, &c->d_cand_off,
+                      &c->d_blk_iv0, &c->d_edge, &c->d_hc_part, &c->d_hc_p0, &c->d_hc_n, &c->d_hc_glo, &c->d_hc_ghi, &c->d_hc_llo, &c->d_hc_lhi, &c->d_voff, &c->d_chunk_off, &c->d_csum, &c->d_mean, &c->d_thr, &c->d_label_off, &c->d_part_has2, &c->d_rb_part, &c->d_rb_r0, &c->d_cand_off,
                       &c->d_cand_y, &c->d_fixed0, &c->d_added, &c->d_fixed, &c->d_chosen, &c->d_final_off, &c->d_final_y,
                       &c->d_final_pos, &c->d_col_thr, &c->d_col_zero, &c->d_cum, &c->d_tile_tot, &c->d_iv_tile0, &c->d_seg_iv, &c->d_seg_prev, &c->d_rseg_c, &c->d_cand_pn, &c->d_cand_ll, &c->d_cand_ln, &c->d_prob_bs, &c->d_prob_iv, &c->d_prob_start,
                       &c->d_prob_n, &c->d_prob_pair_off, &c->d_prob_tri_off, &c->d_prob_flags, &c->d_prob_chain, &c->d_prob_cov_off,
@@ -3319,6 +3312,9 @@ int fseg_upload(fseg_ctx *c, const fseg_batch *b) {
     TRY(ensure(c, c->d_bsum_side, ((size_t)scan_blocks(NPOS) + 2) * 4));
     TRY(ensure(c, c->d_g, np8 * 8)); TRY(ensure(c, c->d_pk, np8 * 4)); TRY(ensure(c, c->d_pf, np8)); TRY(ensure(c, c->d_kp, np8));
     TRY(ensure(c, c->d_final_flag, np8));
+    TRY(ensure(c, c->d_edge, np8));
+    HIP_TRY(c, hipMemsetAsync(c->d_edge.p, 0, np8, c->stream));
+    hipLaunchKernelGGL(k_edges, dim3(grid_for(K, 256, 4096)), dim3(256), 0, c->stream, K, c->d_pos_off.as<i64>(), c->d_edge.as<unsigned char>());
     TRY(ensure(c, c->d_voff, ((size_t)np + 2) * 8)); TRY(ensure(c, c->d_chunk_off, ((size_t)np + 2) * 8));
     TRY(ensure(c, c->d_mean, ((size_t)np + 1) * 8)); TRY(ensure(c, c->d_thr, ((size_t)np + 1) * 8));
     TRY(ensure(c, c->d_label_off, ((size_t)np + 2) * 8));
