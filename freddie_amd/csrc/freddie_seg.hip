@@ -32,7 +32,10 @@ namespace {
 typedef long long i64;
 typedef unsigned long long u64;
 
-constexpr int kSmoothTile = 1024;      // positions per smoothing / peak tile (k_segments shifts by 10)
+constexpr int kSmoothShift = 9;
+constexpr int kSmoothTile = 1 << kSmoothShift;   // positions per smoothing tile: intervals average ~1.5 K positions in many-partition
+                                                 // batches, and a tile never spans two intervals -- 512 keeps the tiles ~95 % full
+constexpr int kSmoothThreads = kSmoothTile / 4;  // a thread computes 4 consecutive outputs
 constexpr int kMaxRadius = 200;        // sigma <= 50, truncate 4.0 (py/freddie_segment.py:106,:755)
 constexpr int kScanBlock = 8192;       // elements per scan workgroup (256 threads x 32 flag bytes)
 constexpr int kNMax = 60;              // largest DP problem handled by the LDS-resident scoring kernel
@@ -245,10 +248,10 @@ struct __align__(16) TileDesc {
     int y0;         // first position of the tile inside the interval
     int len;        // interval length
 };
-constexpr int kSmoothStage = (kSmoothTile + 2 * kMaxRadius + 255) / 256;   // staged counts per thread, any radius
+constexpr int kSmoothStage = (kSmoothTile + 2 * kMaxRadius + kSmoothThreads - 1) / kSmoothThreads;   // staged counts per thread, any radius
 
 template <int R>
-__global__ void __launch_bounds__(256) k_smooth(int n_tiles, const TileDesc *tiles,
+__global__ void __launch_bounds__(kSmoothThreads) k_smooth(int n_tiles, const TileDesc *tiles,
                                                 const int *y_raw, const double *__restrict__ w_g, int radius_rt,
                                                 double *y_out, unsigned char *flag_pos, unsigned char *flag_zero, int *cum, int *tile_tot) {
     __shared__ int xs[kSmoothTile + 2 * kMaxRadius];
@@ -259,7 +262,7 @@ __global__ void __launch_bounds__(256) k_smooth(int n_tiles, const TileDesc *til
     __shared__ int cs[kSmoothTile];
     const int radius = R > 0 ? R : radius_rt;
     const int span = kSmoothTile + 2 * radius;
-    constexpr int kStage = R > 0 ? (kSmoothTile + 2 * R + 255) / 256 : kSmoothStage;
+    constexpr int kStage = R > 0 ? (kSmoothTile + 2 * R + kSmoothThreads - 1) / kSmoothThreads : kSmoothStage;
     for (int j = threadIdx.x; j <= radius; j += blockDim.x) ws[j] = w_g[j];
     // A tile is a short chain of dependent loads (record -> counts) followed by barriers, and a workgroup walks several
     // tiles: the chain of the NEXT tile is issued before the arithmetic of the current one (counts into registers,
@@ -268,7 +271,7 @@ __global__ void __launch_bounds__(256) k_smooth(int n_tiles, const TileDesc *til
     auto load_counts = [&](const TileDesc &d, int *v) {
 #pragma unroll
         for (int e = 0; e < kStage; ++e) {
-            const int idx = e * 256 + threadIdx.x;
+            const int idx = e * kSmoothThreads + threadIdx.x;
             i64 y = (i64)d.y0 - radius + idx;
             if (y < 0 || y >= d.len) y = reflect_index(y, d.len);      // only the few halo elements beyond the interval pay the modulo
             v[e] = idx < span ? y_raw[d.base + y] : 0;
@@ -283,7 +286,7 @@ __global__ void __launch_bounds__(256) k_smooth(int n_tiles, const TileDesc *til
         const i64 y0 = d_cur.y0, base = d_cur.base, len = d_cur.len;
         lds_barrier();
 #pragma unroll
-        for (int e = 0; e < kStage; ++e) { const int idx = e * 256 + threadIdx.x; if (idx < span) xs[idx] = v_cur[e]; }
+        for (int e = 0; e < kStage; ++e) { const int idx = e * kSmoothThreads + threadIdx.x; if (idx < span) xs[idx] = v_cur[e]; }
         TileDesc d_n2 = {0, 0, 1};
         if (t + 2 * G < n_tiles) d_n2 = tiles[t + 2 * G];
         if (t + G < n_tiles) load_counts(d_next, v_cur);             // in flight during this tile's work
@@ -2147,10 +2150,10 @@ __global__ void k_segments(i64 K, const i64 *pos_off, const i64 *cand_off, const
                 // refine_segmentation's `sum(i_vals) < 20 -> continue` (:258), exactly, from the per-tile prefix sums
                 // of the histogram: inner positions [py+20, y-21]
                 int a = py + 20, b = y - 21;
-                int ta = a >> 10, tb = b >> 10;                       // kSmoothTile == 1024
+                int ta = a >> kSmoothShift, tb = b >> kSmoothShift;
                 const int *cm = cum + base;
                 const int *tt = tile_tot + iv_tile0[k];
-                i64 tot = (i64)cm[b] - ((a & 1023) ? cm[a - 1] : 0);
+                i64 tot = (i64)cm[b] - ((a & (kSmoothTile - 1)) ? cm[a - 1] : 0);
                 if (tb > ta && tb - ta <= 64) { for (int q = ta; q < tb; ++q) tot += tt[q]; }
                 if (tb - ta <= 64) need = tot >= 20;                  // very long segments: k_refine sums them itself
             }
@@ -2712,7 +2715,7 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
     };
     const i64 avg_len = NPOS / (K > 0 ? K : 1);
     const int iv_threads = avg_len > 65536 ? 1024 : (avg_len > 16384 ? 256 : 64);
-    int tile_grid = grid_for(c->n_tiles, 1, 8192);
+    int tile_grid = grid_for(c->n_tiles, 1, 16384);
     const i64 scan_nb = scan_blocks(NPOS);
     const int scan_grid = scan_nb > 0 ? (int)scan_nb : 1;       // exactly one workgroup per scan block (look-back)
     u64 *scan_state = c->d_scan_state.as<u64>();
@@ -2744,7 +2747,7 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
     mark(1);
     // S2
 #define FSEG_LAUNCH_SMOOTH(RV)                                                                                         \
-    hipLaunchKernelGGL(k_smooth<RV>, dim3(tile_grid), dim3(256), 0, s, c->n_tiles, c->d_tile_desc.as<TileDesc>(),      \
+    hipLaunchKernelGGL(k_smooth<RV>, dim3(tile_grid), dim3(kSmoothThreads), 0, s, c->n_tiles, c->d_tile_desc.as<TileDesc>(),      \
                        c->d_y_raw.as<int>(), c->d_w_main.as<double>(),                                                 \
                        c->P.radius_main, c->d_y.as<double>(), c->d_flag.as<unsigned char>(),                           \
                        c->d_cflag.as<unsigned char>(), c->d_cum.as<int>(), c->d_tile_tot.as<int>())
