@@ -1,9 +1,18 @@
+#!/bin/bash
+# Round profile: tools/profile_round.sh <tag>   (run on the GPU box from the repo root; writes under gpurun_out/<tag>/)
+T=${1:-round}
+O=gpurun_out/$T
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-timeout 300 python -m pytest tests -m gpu -x -q 2>&1 | tail -2
-python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err; tail -1 gpurun_out/bench_default.json | python profiles/benchsum.py
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/v12_stats -o p -- python3 bench.py > gpurun_out/v12_bench_under_rocprof.json 2> gpurun_out/v12_stats.err
-grep "^{" gpurun_out/v12_bench_under_rocprof.json | python profiles/benchsum.py
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/v12_fetch -o p -- python3 bench.py --no-cpu-baseline --steps 10 > /dev/null 2> gpurun_out/v12_fetch.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/v12_write -o p -- python3 bench.py --no-cpu-baseline --steps 10 > /dev/null 2> gpurun_out/v12_write.err
-python profiles/pmc_summary.py gpurun_out/v12_fetch/p_counter_collection.csv gpurun_out/v12_write/p_counter_collection.csv | head -12
-for w in config3 config4 config5; do python bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tee gpurun_out/bench_$w.json | python profiles/benchsum.py | head -1; done
+mkdir -p $O
+timeout -k 10 600 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; tail -2 $O/pytest_gpu.log
+python bench.py > $O/config2_bench.json 2> $O/bench.err; python profiles/benchsum.py < $O/config2_bench.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o p -- python3 bench.py > $O/config2_bench_under_rocprof.json 2> $O/stats.err
+python profiles/benchsum.py < $O/config2_bench_under_rocprof.json | head -1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -o p -- python3 bench.py --no-cpu-baseline --steps 10 > /dev/null 2> $O/fetch.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -o p -- python3 bench.py --no-cpu-baseline --steps 10 > /dev/null 2> $O/write.err
+python profiles/pmc_summary.py $O/fetch/p_counter_collection.csv $O/write/p_counter_collection.csv > $O/pmc_summary.txt; head -6 $O/pmc_summary.txt
+for w in config3 config4 config5; do python bench.py --workload $w --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null > $O/${w}_bench.json; python profiles/benchsum.py < $O/${w}_bench.json | head -1; done
+FSEG_NO_GRAPH=1 rocprofv3 --kernel-trace --output-format csv -d $O/trace_config4 -o p -- python3 bench.py --workload config4 --steps 10 --no-cpu-baseline > /dev/null 2> $O/trace4.err
+python profiles/trace_medians.py $O/trace_config4/p_kernel_trace.csv > $O/config4_kernel_medians.txt
+FSEG_NO_GRAPH=1 rocprofv3 --kernel-trace --output-format csv -d $O/trace_config2 -o p -- python3 bench.py --steps 10 --no-cpu-baseline > /dev/null 2> $O/trace2.err
+python profiles/trace_medians.py $O/trace_config2/p_kernel_trace.csv > $O/config2_kernel_medians.txt
