@@ -1022,10 +1022,13 @@ constexpr int kDpSmall = 32;
 constexpr int kClsSmall = 16, kClsMid = 32;
 struct ProbSizes { i64 v[kProbCols]; };
 __device__ __forceinline__ int size_class(int n) { return n <= kClsSmall ? 0 : (n <= kClsMid ? 1 : (n <= kNMax ? 2 : 3)); }
-__device__ __forceinline__ ProbSizes prob_sizes(int n, int n_lanes) {
+// tiny_max > 0: problems with at most tiny_max candidates are solved whole by k_tiny (one wave each, nothing in the
+// arenas): they get a problem slot and nothing else.
+__device__ __forceinline__ ProbSizes prob_sizes(int n, int n_lanes, int tiny_max) {
     ProbSizes s;
     for (int q = 0; q < kProbCols; ++q) s.v[q] = 0;
     if (n <= 0) return s;
+    if (n <= tiny_max) { s.v[0] = 1; return s; }
     i64 chunks = (n_lanes + kLaneChunk - 1) / kLaneChunk;
     const int cls = size_class(n);
     s.v[0] = 1 + (n <= kDpSmall ? (1LL << 32) : 0);
@@ -1080,12 +1083,12 @@ __device__ __forceinline__ void wg_scan_cols(const ProbSizes &v, ProbSizes &ex, 
     }
     __syncthreads();
 }
-__device__ __forceinline__ ProbSizes prob_block_sizes(const int *cand_pn, const int *cand_ln, i64 b, i64 n, ProbSizes *per_elem /* 4, may be null */) {
+__device__ __forceinline__ ProbSizes prob_block_sizes(const int *cand_pn, const int *cand_ln, i64 b, i64 n, ProbSizes *per_elem /* 4, may be null */, int tiny_max) {
     ProbSizes acc;
     for (int q = 0; q < kProbCols; ++q) acc.v[q] = 0;
     const i64 i0 = b * kProbBlock + (i64)threadIdx.x * 4;
     for (int e = 0; e < 4; ++e) {
-        ProbSizes sz = i0 + e < n ? prob_sizes(cand_pn[i0 + e], cand_ln[i0 + e]) : prob_sizes(0, 0);
+        ProbSizes sz = i0 + e < n ? prob_sizes(cand_pn[i0 + e], cand_ln[i0 + e], tiny_max) : prob_sizes(0, 0, 0);
         if (per_elem) per_elem[e] = sz;
         for (int q = 0; q < kProbCols; ++q) acc.v[q] += sz.v[q];
     }
@@ -1098,12 +1101,12 @@ __device__ __forceinline__ void prob_store_totals(Status *st, const ProbSizes &t
     st->cls_work[3] = (u64)col_lo(t.v[6]);
     st->dp_cls[0] = (u64)col_hi(t.v[0]); st->dp_cls[1] = (u64)col_hi(t.v[5]); st->dp_cls[2] = (u64)col_hi(t.v[6]);
 }
-__global__ void __launch_bounds__(256) k_prob_scan1(const Status *st, const int *cand_pn, const int *cand_ln, i64 *bs) {
+__global__ void __launch_bounds__(256) k_prob_scan1(const Status *st, const int *cand_pn, const int *cand_ln, i64 *bs, int tiny_max) {
     __shared__ i64 lds[4 * kProbCols];
     i64 n = (i64)st->n_cand;
     i64 nb = (n + kProbBlock - 1) / kProbBlock;
     for (i64 b = blockIdx.x; b < nb; b += gridDim.x) {
-        ProbSizes acc = prob_block_sizes(cand_pn, cand_ln, b, n, nullptr), ex, tot;
+        ProbSizes acc = prob_block_sizes(cand_pn, cand_ln, b, n, nullptr, tiny_max), ex, tot;
         wg_scan_cols(acc, ex, tot, lds);
         if (threadIdx.x < kProbCols) bs[b * kProbCols + threadIdx.x] = tot.v[threadIdx.x];
     }
@@ -1134,7 +1137,7 @@ __global__ void __launch_bounds__(256) k_prob_emit(Status *st, const int *cand_p
                                                    const int *cand_iv, const i64 *cand_off, const i64 *bs,
                                                    ProblemArrays pr, i64 prob_cap, int2 *work_pc, int4 *cls_items,
                                                    i64 work_cap, int *dp_items, ProbDesc *desc, const int *iv_start,
-                                                   const int *iv_part, const i64 *part_lane_off) {
+                                                   const int *iv_part, const i64 *part_lane_off, int tiny_max) {
     __shared__ i64 lds[4 * kProbCols];
     __shared__ int l_slot[kProbBlock], l_cnt[kProbBlock];
     __shared__ i64 l_w0[kProbBlock], l_c0[kProbBlock];
@@ -1152,12 +1155,12 @@ __global__ void __launch_bounds__(256) k_prob_emit(Status *st, const int *cand_p
             for (int q = 0; q < kProbCols; ++q) { before.v[q] = 0; grand.v[q] = 0; }
             for (i64 bb = 0; bb < nb; ++bb) {
                 if (bb == b) continue;
-                ProbSizes acc = prob_block_sizes(cand_pn, cand_ln, bb, n, nullptr), e2, t2;
+                ProbSizes acc = prob_block_sizes(cand_pn, cand_ln, bb, n, nullptr, tiny_max), e2, t2;
                 wg_scan_cols(acc, e2, t2, lds);
                 for (int q = 0; q < kProbCols; ++q) { if (bb < b) before.v[q] += t2.v[q]; grand.v[q] += t2.v[q]; }
             }
         }
-        ProbSizes acc = prob_block_sizes(cand_pn, cand_ln, b, n, sz);
+        ProbSizes acc = prob_block_sizes(cand_pn, cand_ln, b, n, sz, tiny_max);
         wg_scan_cols(acc, ex, tot, lds);
         for (int q = 0; q < kProbCols; ++q) ex.v[q] += before.v[q];
         if (!bs) {
@@ -1190,7 +1193,7 @@ __global__ void __launch_bounds__(256) k_prob_emit(Status *st, const int *cand_p
                     {   // DP problem lists: the small problems first, then the big ones
                         // (then the huge ones)
                         i64 di = nn <= kDpSmall ? col_hi(ex.v[0]) : (nn <= kNMax ? g_dp0 + col_hi(ex.v[5]) : g_dp0 + g_dp1 + col_hi(ex.v[6]));
-                        if (di < prob_cap) dp_items[di] = (int)slot;
+                        if (di < prob_cap && nn > tiny_max) dp_items[di] = (int)slot;     // k_tiny's problems are in no DP list
                     }
                     int cls = size_class(nn);
                     const i64 e_cls0 = col_lo(ex.v[4]), e_cls1 = col_hi(ex.v[4]), e_cls2 = col_lo(ex.v[5]), e_cls3 = col_lo(ex.v[6]);
@@ -1239,11 +1242,12 @@ __device__ __forceinline__ void pair_decode(int q, int *i, int *j) {
 __global__ void __launch_bounds__(256) k_pair_thresholds(const Status *st, ProblemArrays pr, const ProbDesc *desc, i64 prob_cap,
                                                          const i64 *cand_off, const int *cand_y, const double *h_table,
                                                          int h_len, double tau, int2 *pair_thr, i64 pair_cap,
-                                                         unsigned *amb_g, unsigned *out_g, i64 tri_cap) {
+                                                         unsigned *amb_g, unsigned *out_g, i64 tri_cap, int tiny_max) {
     i64 n_prob = (i64)st->n_prob < prob_cap ? (i64)st->n_prob : prob_cap;
     for (i64 p = blockIdx.x; p < n_prob; p += gridDim.x) {
         const ProbDesc d = load_desc(desc + p);
         int n = d.n;
+        if (n <= tiny_max) continue;                        // solved by k_tiny: owns nothing in the arenas
         i64 poff = d.pair_off;
         int npairs = n * (n - 1) / 2;
         if (poff + npairs > pair_cap) continue;
@@ -1277,8 +1281,8 @@ __global__ void __launch_bounds__(256) k_pair_thresholds(const Status *st, Probl
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kLaneChunk) k_cov(Status *st, const ProbDesc *desc, i64 prob_cap, const int2 *work_pc,
                                                     i64 work_cap, const i64 *cand_off,
-                                                    const int *cand_y, const int *iv_start, const int *lane_rep,
-                                                    const i64 *rep_exon_off, const int *ex_ts, const int *ex_te,
+                                                    const int *cand_y, const int *iv_start, const longlong2 *lane_ex,
+                                                    const int *ex_ts, const int *ex_te,
                                                     unsigned *cov_g, i64 cov_cap, unsigned char *work_active) {
     __shared__ int cp[kNHuge + 4];
     __shared__ u64 work_s;
@@ -1297,16 +1301,17 @@ __global__ void __launch_bounds__(kLaneChunk) k_cov(Status *st, const ProbDesc *
         if (n > kNHuge || coff + (i64)kLaneChunk * n > cov_cap) { if (threadIdx.x == 0) work_active[w] = 0; continue; }
         const int *cy = cand_y + d.c0;
         const int g0 = d.g0;
+        int t = threadIdx.x;
+        int li = chunk * kLaneChunk + t;
+        // the read's exon range needs only the descriptor: in flight together with the candidate positions
+        const longlong2 ex = lane_ex[d.lane_lo + (li < d.lane_n ? li : 0)];
         for (int j = threadIdx.x; j < n; j += blockDim.x) cp[j] = g0 + cy[j];
         __syncthreads();
         const int cp0 = cp[0];
-        int t = threadIdx.x;
-        int li = chunk * kLaneChunk + t;
         unsigned *dst = cov_g + coff + t;
         unsigned last = 0;
         if (li < d.lane_n) {
-            i64 r = lane_rep[d.lane_lo + li];
-            i64 e = rep_exon_off[r], e1 = rep_exon_off[r + 1];
+            i64 e = ex.x, e1 = ex.y;
             {   // first exon whose closed interval reaches cand_0 (exons of a read are ordered, :158)
                 i64 lo = e, hi = e1;
                 while (lo < hi) { i64 mid = (lo + hi) >> 1; if (ex_te[mid] < cp0) lo = mid + 1; else hi = mid; }
@@ -1763,7 +1768,7 @@ __global__ void __launch_bounds__(T) k_dp(Status *st, int dp_class, int nm, cons
                                             const i64 *cand_off, const int *cand_y, const int *iv_part,
                                             const i64 *part_lane_off, const unsigned *out_g, i64 tri_cap,
                                             const unsigned *amb_g, const int2 *pair_thr, i64 pair_cap, int support,
-                                            unsigned char *chosen FSEG_TPARAM) {
+                                            unsigned char *chosen, int tiny_max FSEG_TPARAM) {
     // handles problems with n_lo < n <= NM that the scoring kernel did not finish itself (more than one
     // work item); the out table of the problem is staged in LDS first
     // LDS carve-up for problems of at most nm <= NM candidates (nm from the previous run's largest problem)
@@ -1791,7 +1796,7 @@ __global__ void __launch_bounds__(T) k_dp(Status *st, int dp_class, int nm, cons
         const i64 p = dp_class < 0 ? t : (i64)dp_items[list_base + t];
         const ProbDesc d = load_desc(desc + p);
         int n = d.n;
-        if (n > NM) continue;
+        if (n > NM || n <= tiny_max) continue;              // (the latter only when this launch walks every problem: k_tiny's are not in the lists)
         if (n > nm) { if (threadIdx.x == 0) atomicOr(&st->err, kErrOverflowNm); continue; }
         if (sizeof(OutT) == 2 && d.lane_n >= 65536) { if (threadIdx.x == 0) atomicOr(&st->err, kErrNeedWideDp); continue; }
         i64 poff = d.pair_off, toff = d.tri_off;
@@ -1916,6 +1921,130 @@ __global__ void __launch_bounds__(256) k_dp_waves(Status *st, const int *dp_item
             int chain = dp_solve<T>(n, out_s, in_s, M, A, cy_s, support, part_v, part_a, top_key, chosen + d.c0 FSEG_DARG);
             if (threadIdx.x == 0) pr.chain[pb] = chain;
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Problems with at most kTiny candidates -- in batches of many partitions that is most of them (half have n = 3) -- are
+// solved whole by ONE WAVE each: window coverage (get_cumulative_coverage :188-246), pair labels (:488-497), in / out
+// counts (:500-528) and the DP (:532-566), without a work item, a coverage tile or an arena entry.  Lanes are the reads
+// of the problem's lane range, 64 at a time: a pair's yea / nay plane for those reads is the result of one v_cmp (a
+// ballot), lane q keeps pair q's planes and ambiguity count, lane t the count of triple t; the DP is dp_solve<64> on
+// wave-private tables.  Four waves = four problems per workgroup, no workgroup barrier anywhere.
+// ---------------------------------------------------------------------------------------------
+constexpr int kTiny = 8;
+constexpr int kTinyPairs = kTiny * (kTiny - 1) / 2, kTinyTri = kTiny * (kTiny - 1) * (kTiny - 2) / 6;
+__global__ void __launch_bounds__(256) k_tiny(Status *st, const ProbDesc *desc, i64 prob_cap, int tiny_max, ProblemArrays pr,
+                                              const int *cand_y, const longlong2 *lane_ex, const int *ex_ts,
+                                              const int *ex_te, const double *h_table, int h_len, double tau, int support,
+                                              unsigned char *chosen) {
+    __shared__ u64 planes[4][kTinyPairs][2];            // [wave][pair]{yea, nay} of the current 64 reads
+    __shared__ i64 M_s[4][kTinyPairs];
+    __shared__ int in_s[4][kTinyPairs];
+    __shared__ unsigned out_s[4][kTinyTri + 4];
+    __shared__ unsigned char A_s[4][kTinyPairs + 4];
+    __shared__ int cy_s[4][kTiny];
+    __shared__ i64 part_v[256];
+    __shared__ unsigned char part_a[256];
+    __shared__ int top_key[4];
+    __shared__ unsigned char tri_ijk[kTinyTri][4];
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    if (threadIdx.x < kTinyTri) {                       // rank t = k(k-1)(k-2)/6 + j(j-1)/2 + i  ->  (i, j, k)
+        int t = threadIdx.x, k = 2;
+        while ((k + 1) * k * (k - 1) / 6 <= t) ++k;
+        int i, j;
+        pair_decode(t - k * (k - 1) * (k - 2) / 6, &i, &j);
+        tri_ijk[t][0] = (unsigned char)i; tri_ijk[t][1] = (unsigned char)j; tri_ijk[t][2] = (unsigned char)k;
+    }
+    __syncthreads();
+    const i64 n_prob = (i64)st->n_prob;
+    if (n_prob > prob_cap) return;                      // sizing run: the descriptors are incomplete
+#ifdef FSEG_SCORE_TIMING
+    __shared__ unsigned long long tick_sink[16];
+    unsigned long long *dp_tacc = tick_sink; unsigned long long dt_prev = 0;
+#endif
+    for (i64 p = (i64)blockIdx.x * 4 + wave; p < n_prob; p += (i64)gridDim.x * 4) {
+        const ProbDesc d = load_desc(desc + p);
+        const int n = d.n;
+        if (n > tiny_max) continue;                     // wave-uniform
+        const int npairs = n * (n - 1) / 2, ntri = n * (n - 1) * (n - 2) / 6;
+        dp_sync<64>();                                  // the previous problem's readers of the wave-private tables are done
+        if (lane < n) cy_s[wave][lane] = cand_y[d.c0 + lane];
+        dp_sync<64>();
+        int hi_q = 0x7fffffff, lo_q = -1, pi = 0, pj = 1;
+        if (lane < npairs) {
+            pair_decode(lane, &pi, &pj);
+            label_thresholds((i64)cy_s[wave][pj] - cy_s[wave][pi] + 1, h_table, h_len, tau, &hi_q, &lo_q);   // :490-495 as integer bounds
+        }
+        int ti = 0, tj = 1, tk = 2;
+        if (lane < ntri) { ti = tri_ijk[lane][0]; tj = tri_ijk[lane][1]; tk = tri_ijk[lane][2]; }
+        const int cp0 = d.g0 + cy_s[wave][0];
+        unsigned amb = 0, out = 0;
+        for (int r0 = 0; r0 < d.lane_n; r0 += 64) {
+            const int li = r0 + lane;
+            const bool valid = li < d.lane_n;
+            // window coverage of this lane's read: cov[j] = positions of its closed exons in [cand_0, cand_j)
+            int cov[kTiny];
+#pragma unroll
+            for (int j = 0; j < kTiny; ++j) cov[j] = 0;
+            const longlong2 ex = lane_ex[d.lane_lo + (valid ? li : 0)];      // unconditional: no branch around the load
+            if (valid) {
+                i64 e = ex.x;
+                const i64 e1 = ex.y;
+                {   // first exon whose closed interval reaches cand_0 (exons of a read are ordered, :158)
+                    i64 lo = e, hi = e1;
+                    while (lo < hi) { const i64 mid = (lo + hi) >> 1; if (ex_te[mid] < cp0) lo = mid + 1; else hi = mid; }
+                    e = lo;
+                }
+                int acc = 0, ts = 0, te = -1;
+                if (e < e1) { ts = ex_ts[e]; te = ex_te[e]; }
+#pragma unroll
+                for (int j = 1; j < kTiny; ++j) {
+                    if (j < n) {
+                        const int cj = d.g0 + cy_s[wave][j];
+                        while (e < e1 && te < cj) {
+                            acc += te + 1 - (ts > cp0 ? ts : cp0);
+                            ++e;
+                            if (e < e1) { ts = ex_ts[e]; te = ex_te[e]; }
+                        }
+                        cov[j] = acc + ((e < e1 && ts < cj) ? cj - (ts > cp0 ? ts : cp0) : 0);
+                    }
+                }
+            }
+            const u64 vmask = __ballot(valid);
+            // pair labels: one compare per plane, the 64 reads' bits arrive as the ballot; lane q keeps pair q's planes
+            u64 my_yea = 0, my_nay = 0;
+#pragma unroll
+            for (int j = 1; j < kTiny; ++j) {
+#pragma unroll
+                for (int i = 0; i < j; ++i) {
+                    const int q = j * (j - 1) / 2 + i;
+                    if (q < npairs) {                   // wave-uniform
+                        const int dd = cov[j] - cov[i];
+                        const int hi = __builtin_amdgcn_readlane(hi_q, q), lo = __builtin_amdgcn_readlane(lo_q, q);
+                        const u64 y = __ballot(valid && dd >= hi), z = __ballot(valid && dd <= lo);
+                        if (lane == q) { my_yea = y; my_nay = z; }
+                    }
+                }
+            }
+            if (lane < npairs) {
+                amb += (unsigned)__popcll(~(my_yea | my_nay) & vmask);       // neither label: ambiguous (:500-506)
+                planes[wave][lane][0] = my_yea; planes[wave][lane][1] = my_nay;
+            }
+            dp_sync<64>();
+            if (lane < ntri) {                          // out(i,j,k) (:509-528): the two labels exclude each other
+                const int qa = tj * (tj - 1) / 2 + ti, qb = tk * (tk - 1) / 2 + tj;
+                out += (unsigned)(__popcll(planes[wave][qa][0] & planes[wave][qb][1]) + __popcll(planes[wave][qa][1] & planes[wave][qb][0]));
+            }
+            dp_sync<64>();
+        }
+        // a read outside the lane range has no coverage in the window: ambiguous exactly where lo < 0 (only tau = 1)
+        if (lane < npairs) in_s[wave][lane] = -(int)((i64)amb + (lo_q < 0 ? (i64)d.outside : 0));
+        if (lane < ntri) out_s[wave][lane] = out;
+        dp_sync<64>();
+        const int chain = dp_solve<64>(n, out_s[wave], in_s[wave], M_s[wave], A_s[wave], cy_s[wave], support, part_v + wave * 64,
+                                       part_a + wave * 64, top_key + wave, chosen + d.c0 FSEG_DARG);
+        if (lane == 0) pr.chain[p] = chain;
     }
 }
 
@@ -2548,7 +2677,7 @@ struct fseg_ctx {
     std::vector<int> iv_start_h;
     // device buffers: inputs
     DevBuf d_part_iv_off, d_part_rep_off, d_part_lane_off, d_iv_start, d_iv_end, d_pos_off, d_iv_part, d_rep_weight,
-        d_rep_exon_off, d_ex_ts, d_ex_te, d_lane_rep, d_lane_start, d_lane_pmax, d_tile_desc, d_w_main,
+        d_rep_exon_off, d_ex_ts, d_ex_te, d_lane_rep, d_lane_ex, d_lane_start, d_lane_pmax, d_tile_desc, d_w_main,
         d_w_refine, d_h_table;
     // device buffers: position-sized
     DevBuf d_y_raw, d_y, d_flag, d_cflag, d_v, d_scan_state, d_bsum, d_bsum_side, d_g, d_pk, d_pf, d_kp, d_final_flag;
@@ -2575,6 +2704,7 @@ struct fseg_ctx {
     bool dp_wide_counts = false; // some problem of an earlier run saw >= 65536 reads: DP stages 32-bit counts
     int nm_big = kNMax;         // LDS carve-up of the big-problem kernels: largest problem of the previous run, rounded up
     bool small_batch = false;
+    bool tiny_on = false;       // many problems in the previous run (> 256): problems with <= kTiny candidates go to k_tiny
     bool use_graph = true;      // replay the launch sequence as hipGraphs (FSEG_NO_GRAPH=1 disables)
     i64 prob_self_max = 4 * kProbBlock;   // candidates up to which it does (FSEG_PROB_SELF_MAX)
     bool prob_self_scan = false; // k_prob_emit adds up the candidate blocks itself (few candidates in the previous run)
@@ -2587,10 +2717,12 @@ struct fseg_ctx {
     // Independent kernels of one run (threshold | candidates, the scoring size classes, the DP classes) go to side
     // streams (pair thresholds | coverage was tried too: the branch cost more than the overlap gave) between a fork and a join, so a captured run becomes a graph with parallel
     // branches (FSEG_NO_FORK=1 keeps everything on the one stream).
-    static constexpr int kSide = 2, kForkEvents = 16;
+    static constexpr int kSide = 3, kForkEvents = 16;
     hipStream_t side[kSide] = {};
     hipEvent_t fj[kForkEvents] = {};
     bool use_fork = true;
+    bool use_tiny = true;       // FSEG_NO_TINY=1 keeps every problem on the arena-based path
+    i64 tiny_from = 256;        // problems in the previous run above which k_tiny is used (FSEG_TINY_FROM; tests force 0)
 };
 
 namespace {
@@ -2695,6 +2827,7 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
     // Small batches (one partition, few problems) are chains of launch-latency-sized kernels: branches only add
     // cross-stream dependencies there (measured: config2 +4 %), so they stay on the one stream.
     const bool forking = c->use_fork && !c->small_batch;
+    const int tiny_max = c->tiny_on ? kTiny : 0;
     int fj_next = 0;
     hipError_t fj_err = hipSuccess;
     auto fj_event = [&]() { hipEvent_t e = c->fj[fj_next % fseg_ctx::kForkEvents]; ++fj_next; return e; };
@@ -2805,14 +2938,14 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
         // few candidates (previous run): the emit kernel scans by itself, one launch instead of three
         i64 *bs = c->prob_self_scan ? nullptr : c->d_prob_bs.as<i64>();
         if (bs) {
-            hipLaunchKernelGGL(k_prob_scan1, dim3(pg), dim3(256), 0, s, st, c->d_cand_pn.as<int>(), c->d_cand_ln.as<int>(), bs);
+            hipLaunchKernelGGL(k_prob_scan1, dim3(pg), dim3(256), 0, s, st, c->d_cand_pn.as<int>(), c->d_cand_ln.as<int>(), bs, tiny_max);
             hipLaunchKernelGGL(k_prob_scan2, dim3(1), dim3(256), 0, s, st, bs);
         }
         hipLaunchKernelGGL(k_prob_emit, dim3(pg), dim3(256), 0, s, st, c->d_cand_pn.as<int>(), c->d_cand_ll.as<int>(),
                            c->d_cand_ln.as<int>(), c->d_seg_iv.as<int>(), c->d_cand_off.as<i64>(), bs,
                            pr, c->prob_cap, c->d_work_pc.as<int2>(), c->d_cls_items.as<int4>(),
                            c->work_cap, c->d_dp_items.as<int>(), c->d_prob_desc.as<ProbDesc>(), c->d_iv_start.as<int>(),
-                           c->d_iv_part.as<int>(), c->d_part_lane_off.as<i64>());
+                           c->d_iv_part.as<int>(), c->d_part_lane_off.as<i64>(), tiny_max);
     }
     mark(5);
     // S5
@@ -2821,16 +2954,25 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
                            c->d_prob_desc.as<ProbDesc>(), c->prob_cap, c->d_cand_off.as<i64>(), c->d_cand_y.as<int>(),
                            c->d_h_table.as<double>(), c->P.h_len,
                            c->P.threshold_rate, c->d_pair_thr.as<int2>(), c->pair_cap, c->d_amb.as<unsigned>(),
-                           c->d_out.as<unsigned>(), c->tri_cap);
+                           c->d_out.as<unsigned>(), c->tri_cap, tiny_max);
         hipLaunchKernelGGL(k_cov, dim3(work_grid < 2048 ? work_grid : 2048), dim3(kLaneChunk), 0, s, st,
                            c->d_prob_desc.as<ProbDesc>(), c->prob_cap, c->d_work_pc.as<int2>(), c->work_cap, c->d_cand_off.as<i64>(),
-                           c->d_cand_y.as<int>(), c->d_iv_start.as<int>(), c->d_lane_rep.as<int>(),
-                           c->d_rep_exon_off.as<i64>(), c->d_ex_ts.as<int>(), c->d_ex_te.as<int>(),
+                           c->d_cand_y.as<int>(), c->d_iv_start.as<int>(), c->d_lane_ex.as<longlong2>(),
+                           c->d_ex_ts.as<int>(), c->d_ex_te.as<int>(),
                            c->d_cov.as<unsigned>(), c->cov_cap, c->d_work_active.as<unsigned char>());
     }
     mark(6);
     }   // do_pre
     if (do_score && c->prob_cap > 0) {
+        if (tiny_max > 0) {
+            // the problems with a handful of candidates, whole (coverage, labels, counts, DP), beside the arena-based
+            // path of the others; joined at the end of this stage, so the stage's time bracket covers all scoring work
+            hipStream_t qt = fork(2);
+            hipLaunchKernelGGL(k_tiny, dim3(grid_for(c->prob_cap, 4, 4096)), dim3(256), 0, qt, st, c->d_prob_desc.as<ProbDesc>(),
+                               c->prob_cap, tiny_max, pr, c->d_cand_y.as<int>(), c->d_lane_ex.as<longlong2>(),
+                               c->d_ex_ts.as<int>(), c->d_ex_te.as<int>(), c->d_h_table.as<double>(), c->P.h_len, c->P.threshold_rate,
+                               c->P.min_read_support_outside, c->d_chosen.as<unsigned char>());
+        }
 #ifdef FSEG_SCORE_TIMING
 #define FSEG_TARG , c->d_tacc.as<unsigned long long>()
 #else
@@ -2859,6 +3001,7 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
                                c->d_prob_desc.as<ProbDesc>(), c->prob_cap, c->work_cap, c->d_cand_y.as<int>(),
                                c->d_cov.as<unsigned>(), c->cov_cap, c->d_pair_thr.as<int2>(), c->pair_cap,
                                c->d_out.as<unsigned>(), c->tri_cap, c->d_amb.as<unsigned>());
+        if (tiny_max > 0) join(2);             // k_tiny is interval scoring too: inside the stage's time bracket
     }
     mark(7);
     if (do_post) {
@@ -2870,7 +3013,7 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
                            c->d_prob_desc.as<ProbDesc>(), c->prob_cap, c->d_cand_off.as<i64>(), c->d_cand_y.as<int>(), c->d_iv_part.as<int>(),               \
                            c->d_part_lane_off.as<i64>(), c->d_out.as<unsigned>(), c->tri_cap, c->d_amb.as<unsigned>(),        \
                            c->d_pair_thr.as<int2>(), c->pair_cap, c->P.min_read_support_outside,                              \
-                           c->d_chosen.as<unsigned char>() FSEG_TARG)
+                           c->d_chosen.as<unsigned char>(), tiny_max FSEG_TARG)
 #define FSEG_LAUNCH_DP_WAVES(OUTT)                                                                                        \
         hipLaunchKernelGGL((k_dp_waves<OUTT>), dim3(grid_for(c->prob_cap, 4, 2048)), dim3(256),                                \
                            dp_lds_for(kDpSmall, (int)sizeof(OUTT)) > 4 * dp_wave_bytes<OUTT>() ? dp_lds_for(kDpSmall, (int)sizeof(OUTT)) : 4 * dp_wave_bytes<OUTT>(), \
@@ -2970,9 +3113,10 @@ int finish_run(fseg_ctx *c) {
         if (!need) {
             c->pending = false;
             c->ran = true;
-            const bool old_small = c->small_batch, old_self = c->prob_self_scan;
+            const bool old_small = c->small_batch, old_self = c->prob_self_scan, old_tiny = c->tiny_on;
             const int old_nm = c->nm_big;
             c->small_batch = (i64)s.n_prob <= 256 && (i64)s.n_work <= 1024;
+            c->tiny_on = (i64)s.n_prob > c->tiny_from && c->use_tiny;   // depends on the problem count only, which k_tiny does not change
             c->prob_self_scan = (i64)s.n_cand <= c->prob_self_max;
             {   // size the next run's big-problem LDS for this run's largest problem (+ headroom, multiple of 4)
                 int want = (int)s.max_n + 3;
@@ -2982,7 +3126,7 @@ int finish_run(fseg_ctx *c) {
                 c->nm_big = want;
             }
             const int timed_graphs = c->n_graphs;
-            if (old_small != c->small_batch || old_nm != c->nm_big || old_self != c->prob_self_scan) drop_graph(c);
+            if (old_small != c->small_batch || old_nm != c->nm_big || old_self != c->prob_self_scan || old_tiny != c->tiny_on) drop_graph(c);
             if (c->profiling) {
                 for (int i = 0; i < ST_REPORTED; ++i) c->stage_ms[i] = 0.f;
                 if (timed_graphs == 2) {
@@ -3073,6 +3217,8 @@ int fseg_create(int device, fseg_ctx **out) {
     c->d_status.cap = sizeof(Status);
     { const char *ng = getenv("FSEG_NO_GRAPH"); if (ng && ng[0] == '1') c->use_graph = false; }
     { const char *nf = getenv("FSEG_NO_FORK"); if (nf && nf[0] == '1') c->use_fork = false; }
+    { const char *nt = getenv("FSEG_NO_TINY"); if (nt && nt[0] == '1') c->use_tiny = false; }
+    { const char *tf = getenv("FSEG_TINY_FROM"); if (tf && tf[0]) c->tiny_from = atoll(tf); }
     { const char *sm = getenv("FSEG_SCAN_SINGLE_MAX"); if (sm && sm[0]) c->scan_single_max = atoll(sm); }
     { const char *sm = getenv("FSEG_PROB_SELF_MAX"); if (sm && sm[0]) c->prob_self_max = atoll(sm); }
     *out = c;
@@ -3085,7 +3231,7 @@ void fseg_destroy(fseg_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     drop_graph(c);
     DevBuf *bufs[] = {&c->d_part_iv_off, &c->d_part_rep_off, &c->d_part_lane_off, &c->d_iv_start, &c->d_iv_end, &c->d_pos_off,
-                      &c->d_iv_part, &c->d_rep_weight, &c->d_rep_exon_off, &c->d_ex_ts, &c->d_ex_te, &c->d_lane_rep, &c->d_lane_start, &c->d_lane_pmax,
+                      &c->d_iv_part, &c->d_rep_weight, &c->d_rep_exon_off, &c->d_ex_ts, &c->d_ex_te, &c->d_lane_rep, &c->d_lane_ex, &c->d_lane_start, &c->d_lane_pmax,
                       &c->d_tile_desc, &c->d_w_main, &c->d_w_refine, &c->d_h_table, &c->d_y_raw, &c->d_y,
                       &c->d_flag, &c->d_cflag, &c->d_v, &c->d_scan_state, &c->d_bsum, &c->d_bsum_side, &c->d_g, &c->d_pk, &c->d_pf, &c->d_kp, &c->d_final_flag,
                       &c->d_blk_iv0, &c->d_edge, &c->d_hc_part, &c->d_hc_p0, &c->d_hc_n, &c->d_hc_glo, &c->d_hc_ghi, &c->d_hc_llo, &c->d_hc_lhi, &c->d_voff, &c->d_chunk_off, &c->d_csum, &c->d_mean, &c->d_thr, &c->d_label_off, &c->d_part_has2, &c->d_rb_part, &c->d_rb_r0, &c->d_cand_off,
@@ -3241,6 +3387,14 @@ int fseg_upload(fseg_ctx *c, const fseg_batch *b) {
     TRY(upload_vec(c, c->d_ex_ts, b->ex_ts, (size_t)I));
     TRY(upload_vec(c, c->d_ex_te, b->ex_te, (size_t)I));
     TRY(upload_vec(c, c->d_lane_rep, lane_rep.data(), lane_rep.size()));
+    {   // exon range of every lane's rep, so the per-read walks start with one load instead of lane -> rep -> offsets
+        std::vector<longlong2> lane_ex((size_t)lanes);
+        for (i64 l = 0; l < lanes; ++l) {
+            const int r = lane_rep[(size_t)l];
+            lane_ex[(size_t)l] = make_longlong2(b->rep_exon_off[r], b->rep_exon_off[r + 1]);
+        }
+        TRY(upload_vec(c, c->d_lane_ex, lane_ex.data(), lane_ex.size()));
+    }
     TRY(upload_vec(c, c->d_lane_start, lane_start.data(), lane_start.size()));
     TRY(upload_vec(c, c->d_lane_pmax, lane_pmax.data(), lane_pmax.size()));
     {

@@ -78,3 +78,54 @@ def test_batch_equals_one_by_one(gpu_ctx):
         a, b, c, d = gpu_ctx.download()
         assert np.array_equal(b, fp[pfo[i]:pfo[i + 1]])
         assert np.array_equal(d, lab[lo[i]:lo[i + 1]])
+
+
+def test_tiny_problem_path_forced(monkeypatch):
+    """k_tiny (one wave solves a problem of <= 8 candidates whole) is normally switched on by the problem count of the
+    previous run (> 256); here it is forced for every batch, and the second run of each batch -- the one that uses it --
+    is compared with the oracle on every tap: single partitions of every parameter flavour, and batches."""
+    from freddie_amd import _lib, synth
+    monkeypatch.setenv("FSEG_TINY_FROM", "0")
+    ctx = _lib.Context(0)
+    try:
+        for name, gen, params in CASES:
+            part = util.make_partition(3, **gen)
+            o = util.run_oracle(part, params)
+            util.run_gpu(ctx, [part], params)
+            ctx.run(); ctx.sync()
+            util.compare_partitions(ctx, [part], [o])
+        parts = [util.make_partition(i, n_reads=150 + 37 * i, n_exons=40 + 11 * i, rp=0.05 * (i % 3)) for i in range(12)]
+        oracles = [util.run_oracle(p) for p in parts]
+        util.run_gpu(ctx, parts)
+        ctx.run(); ctx.sync()
+        util.compare_partitions(ctx, parts, oracles)
+        kw = dict(synth.WORKLOADS["config4"]); kw.pop("n_partitions")
+        parts = [util.make_partition(i, **kw) for i in range(30)]
+        oracles = [util.run_oracle(p) for p in parts]
+        util.run_gpu(ctx, parts)
+        ctx.run(); ctx.sync()
+        util.compare_partitions(ctx, parts, oracles)
+    finally:
+        ctx.close()
+
+
+def test_tiny_path_switches_on_by_itself_and_changes_nothing(monkeypatch):
+    """A many-partition batch: the first run sizes the arenas without k_tiny, later runs use it (more than 256 problems);
+    a context with FSEG_NO_TINY=1 must download the same bytes."""
+    from freddie_amd import _lib, synth
+    kw = dict(synth.WORKLOADS["config4"]); kw.pop("n_partitions")
+    parts = [util.make_partition(100 + i, **kw) for i in range(40)]
+    outs = []
+    for no_tiny in ("0", "1"):
+        monkeypatch.setenv("FSEG_NO_TINY", no_tiny)
+        ctx = _lib.Context(0)
+        try:
+            util.run_gpu(ctx, parts)
+            assert ctx.sizes()["n_problems"] > 256
+            for _ in range(2):
+                ctx.run(); ctx.sync()
+            outs.append(ctx.download())
+        finally:
+            ctx.close()
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
