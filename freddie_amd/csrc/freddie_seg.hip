@@ -921,12 +921,6 @@ __global__ void k_fix(i64 K, const i64 *pos_off, const int *iv_part, const i64 *
                 fixed[c0 + c] = f; chosen[c0 + c] = f;
                 cand_pn[c0 + c] = n;
             }
-            int mx = n;
-            for (int d = 32; d >= 1; d >>= 1) mx = max(mx, __shfl_xor(mx, d));
-            // one address for the whole batch: atomics on it serialise (~90 per us), so skip those that cannot raise it
-            // (a stale read only means an unnecessary atomic, never a missed one: the maximum only grows)
-            if (threadIdx.x == 0 && mx > 0 && (unsigned)mx > __hip_atomic_load(&st->max_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                atomicMax(&st->max_n, (unsigned)mx);
             continue;
         }
         for (int c = threadIdx.x; c < N; c += T) {
@@ -975,8 +969,6 @@ __global__ void k_fix(i64 K, const i64 *pos_off, const int *iv_part, const i64 *
                 fixed[c0 + c] = f; chosen[c0 + c] = f;
                 int n = (f && prev >= 0 && c - prev + 1 >= 3) ? c - prev + 1 : 0;
                 if (n > kNHuge) atomicOr(&st->err, kErrProblemTooLarge);
-                if (n > 0 && (unsigned)n > __hip_atomic_load(&st->max_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                    atomicMax(&st->max_n, (unsigned)n);
                 cand_pn[c0 + c] = n;
             }
         }
@@ -1140,6 +1132,7 @@ __global__ void __launch_bounds__(256) k_prob_emit(Status *st, const int *cand_p
                                                    const int *iv_part, const i64 *part_lane_off, int tiny_max) {
     __shared__ i64 lds[4 * kProbCols];
     __shared__ int l_slot[kProbBlock], l_cnt[kProbBlock];
+    __shared__ int l_mx[4];
     __shared__ i64 l_w0[kProbBlock], l_c0[kProbBlock];
     __shared__ int l_n;
     i64 n = (i64)st->n_cand;
@@ -1161,7 +1154,18 @@ __global__ void __launch_bounds__(256) k_prob_emit(Status *st, const int *cand_p
             }
         }
         ProbSizes acc = prob_block_sizes(cand_pn, cand_ln, b, n, sz, tiny_max);
+        {   // largest problem of the run (sizes the big-problem kernels' LDS next time): one atomic per block of 1024
+            // candidates -- per-problem atomics on the one address serialise (~90 per us)
+            int mx = 0;
+            for (int e = 0; e < 4; ++e) { const i64 cc = b * kProbBlock + (i64)threadIdx.x * 4 + e; if (cc < n) mx = max(mx, cand_pn[cc]); }
+            for (int d = 32; d >= 1; d >>= 1) mx = max(mx, __shfl_xor(mx, d));
+            if (lane_id() == 0) l_mx[threadIdx.x >> 6] = mx;          // read after the barriers of the column scan below
+        }
         wg_scan_cols(acc, ex, tot, lds);
+        if (threadIdx.x == 0) {
+            const int mx = max(max(l_mx[0], l_mx[1]), max(l_mx[2], l_mx[3]));
+            if (mx > 0 && (unsigned)mx > __hip_atomic_load(&st->max_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&st->max_n, (unsigned)mx);
+        }
         for (int q = 0; q < kProbCols; ++q) ex.v[q] += before.v[q];
         if (!bs) {
             for (int q = 0; q < kProbCols; ++q) grand.v[q] += tot.v[q];
@@ -1853,10 +1857,13 @@ __global__ void __launch_bounds__(256) k_dp_waves(Status *st, const int *dp_item
     __shared__ unsigned long long tick_sink[16];                    // the diagnostic build's ticks of this kernel are dropped
     unsigned long long *dp_tacc = tick_sink; unsigned long long dt_prev = 0;
 #endif
-    for (i64 g = (i64)blockIdx.x * 4; g < list_n; g += (i64)gridDim.x * 4) {
+    // a workgroup's four entries are a grid apart, not neighbours: the list is in candidate order, neighbouring problems
+    // come from the same gene and are of similar size, and four large ones in one workgroup would be solved one after
+    // the other while the rest of the GPU is already idle
+    for (i64 g = (i64)blockIdx.x; g < list_n; g += (i64)gridDim.x * 4) {
         __syncthreads();
         {   // ---- every wave: its own entry ------------------------------------------------------------------
-            const i64 t = g + wave;
+            const i64 t = g + (i64)wave * gridDim.x;
             int big = -1;
             if (t < list_n) {
                 const i64 p = dp_items[t];
