@@ -83,6 +83,35 @@ def cpu_baseline(parts, n_reads_of, params, tabs, min_s=10.0, max_s=25.0):
                     used, reads, passes, len(parts), dt))
 
 
+def _oracle_one(job):
+    from oracle import oracle
+    p, params, tabs = job
+    o = oracle.segment(p.iv_start, p.iv_end, p.rep_weight, p.rep_exon_off, p.ex_ts, p.ex_te, **params, **tabs)
+    return o["error"]
+
+
+def cpu_baseline_all_cores(parts, n_reads_of, params, tabs, min_s=8.0):
+    """The same oracle over whole partitions on every host core (one process per core, partitions are independent):
+    only meaningful for the many-partition workloads.  The pool is started (and warmed) outside the timed region."""
+    import multiprocessing as mp
+    cores = os.cpu_count() or 1
+    jobs = [(p, params, tabs) for p in parts]
+    with mp.get_context("fork").Pool(cores) as pool:
+        pool.map(_oracle_one, jobs[:cores])                       # start-up, page-in
+        t0 = time.perf_counter()
+        reads = passes = 0
+        while time.perf_counter() - t0 < min_s:
+            errs = pool.map(_oracle_one, jobs, chunksize=max(1, len(jobs) // (cores * 8)))
+            if any(errs):
+                raise RuntimeError("oracle failed in the all-cores baseline")
+            reads += sum(n_reads_of)
+            passes += 1
+        dt = time.perf_counter() - t0
+    return dict(value=reads / dt, unit="reads/s", cores=cores, kind="port",
+                sample="%d pass(es) over %d partitions (%d reads) of the C oracle on %d processes, %.1f s" % (
+                    passes, len(parts), reads, cores, dt))
+
+
 def measured_traffic(workload):
     """HBM bytes per launch of the scoring kernel from the committed PMC passes (profiles/traffic.json), or None."""
     try:
@@ -99,6 +128,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="config2", choices=sorted(synth.WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-all-cores", action="store_true",
+                    help="also time the CPU oracle on every host core (many-partition workloads; adds cpu_baseline_all_cores)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -106,6 +137,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+
+    params = PARAMS["config5" if args.workload == "config5" else "default"]
+    tabs = dict(w_main=tables.gaussian_half_kernel(params["sigma"], 4.0),
+                w_refine=tables.gaussian_half_kernel(params["sigma"], 1.0),
+                h_table=np.asarray(tables.smooth_threshold(params["threshold_rate"]), np.float64))
+    n_local = per_gpu_partitions(args.workload, args.gpus)
+    parts, n_reads = build_batch(args.workload, rank, n_local)
+    n_reads_of = [p.n_reads for p in parts]
+
+    cpu_all = None
+    if args.cpu_all_cores and rank == 0 and len(parts) > 1:
+        cpu_all = cpu_baseline_all_cores(parts, n_reads_of, params, tabs)    # forks: before anything touches the GPU
 
     import torch
     dist = None
@@ -116,14 +159,6 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(local_rank)
-
-    params = PARAMS["config5" if args.workload == "config5" else "default"]
-    tabs = dict(w_main=tables.gaussian_half_kernel(params["sigma"], 4.0),
-                w_refine=tables.gaussian_half_kernel(params["sigma"], 1.0),
-                h_table=np.asarray(tables.smooth_threshold(params["threshold_rate"]), np.float64))
-    n_local = per_gpu_partitions(args.workload, args.gpus)
-    parts, n_reads = build_batch(args.workload, rank, n_local)
-    n_reads_of = [p.n_reads for p in parts]
 
     ctx = _lib.Context(local_rank)
     ctx.set_params(**params, **tabs)
@@ -190,6 +225,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(parts, n_reads_of, params, tabs)
         else:
             out["cpu_baseline"] = None
+        if cpu_all is not None:
+            out["cpu_baseline_all_cores"] = cpu_all
         print(json.dumps(out))
     ctx.close()
     if dist is not None:
