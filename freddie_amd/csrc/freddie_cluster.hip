@@ -6,8 +6,8 @@
 // overlap [f, l] (:229, :232) become popcounts of (a & b & mask) and ((a ^ b) & mask).  The graph is a symmetric
 // bit matrix; a 64 x 64 tile of it is one workgroup's unit of work, lane = column, so a row's 64 edge bits are one
 // wave ballot and one 8-byte store.  Pruning keeps an edge when either end has no other neighbour or the two ends
-// share a neighbour (:247-251): "share a neighbour" is a row-AND over the bit matrix, evaluated tile by tile with
-// both row blocks staged in LDS; every pass reads the previous pass' matrix only (the reference removes the edges
+// share a neighbour (:247-251): the columns that share a neighbour with row r are the OR of the rows of r's
+// neighbours, one wave per row; every pass reads the previous pass' matrix only (the reference removes the edges
 // of a pass together, :252) and passes repeat until one removes nothing (:254).
 #include "freddie_cluster.h"
 
@@ -26,7 +26,6 @@ typedef unsigned long long u64;
 
 constexpr int kTile = 64;           // rows and columns per tile
 constexpr int kMaxWords = 300;      // uint32 words per read row the LDS staging of k_compat can hold (9600 segments)
-constexpr int kChunk = 64;          // uint64 words of the neighbour rows staged per step of k_prune
 
 struct TintDesc {
     i64 row0, bits_off, adj_off;
@@ -110,67 +109,58 @@ __global__ void __launch_bounds__(256) k_degree(i64 n_rows_total, const int *row
 }
 
 // ---- one pruning pass (py/freddie_cluster.py:243-252) ------------------------------------------------------------
-// new(r, c) = old(r, c) and (deg r == 1 or deg c == 1 or rows r and c of `old` intersect)
-__global__ void __launch_bounds__(256) k_prune(int n_tiles, const int4 *tiles, const TintDesc *tints, const u64 *old_adj,
-                                               const int *deg, u64 *new_adj, int *changed /* per tint */) {
-    __shared__ u64 rows[kTile][kChunk + 1];
-    __shared__ u64 cols[kTile][kChunk + 1];
-    __shared__ u64 edge_w[kTile];
-    __shared__ int any_s;
-    const int lane = lane_id(), wave = threadIdx.x >> 6;
-    for (int ti = blockIdx.x; ti < n_tiles; ti += gridDim.x) {
-        const int4 tile = tiles[ti];
-        const TintDesc d = tints[tile.x];
-        const int r0 = tile.y * kTile, c0 = tile.z * kTile;
+// new(r, c) = old(r, c) and (deg r == 1 or deg c == 1 or r and c share a neighbour).
+// "r and c share a neighbour" for all c at once: H(r) = OR of the rows of r's neighbours (the matrix is symmetric, so
+// bit c of neighbour k's row says k ~ c).  One wave per row, lanes = 64 consecutive words of the row, the loop runs over
+// the set bits of row r (wave-uniform) and ORs the neighbour's words (a coalesced read of the neighbour's row): the
+// work is sum(deg) * words instead of one LDS-staged 64 x 64 block pair per tile of the matrix.
+__global__ void __launch_bounds__(256) k_deg1(int n_words_total, const int2 *word_tint, const TintDesc *tints, const int *deg, u64 *deg1) {
+    // deg1[tint word z] bit c = column 64 z + c has exactly one neighbour
+    const int lane = lane_id();
+    const i64 wave_g = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((i64)gridDim.x * blockDim.x) >> 6;
+    for (i64 x = wave_g; x < n_words_total; x += n_waves) {
+        const int2 wt = word_tint[x];                    // (tint, word index inside the tint)
+        const TintDesc d = tints[wt.x];
+        const int col = wt.y * 64 + lane;
+        const u64 m = __ballot(col < d.n && deg[d.row0 + col] == 1);
+        if (lane == 0) deg1[x] = m;
+    }
+}
+__global__ void __launch_bounds__(256) k_prune(i64 n_rows_total, const int *row_tint, const TintDesc *tints, const i64 *tint_word0,
+                                               const u64 *old_adj, const int *deg, const u64 *deg1, u64 *new_adj,
+                                               int *changed /* per tint */) {
+    const int lane = lane_id();
+    const i64 wave_g = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((i64)gridDim.x * blockDim.x) >> 6;
+    for (i64 r = wave_g; r < n_rows_total; r += n_waves) {
+        const int t = row_tint[r];
+        const TintDesc d = tints[t];
         const u64 *A = old_adj + d.adj_off;
-        __syncthreads();
-        if (threadIdx.x == 0) any_s = 0;
-        __syncthreads();
-        if (threadIdx.x < kTile) {
-            const int row = r0 + threadIdx.x;
-            const u64 w = row < d.n ? A[(i64)row * d.aw + tile.z] : 0ull;
-            edge_w[threadIdx.x] = w;
-            if (w) any_s = 1;
-        }
-        __syncthreads();
-        if (!any_s) {                                    // no edge of the graph in this tile
-            if (threadIdx.x < kTile && r0 + (int)threadIdx.x < d.n) new_adj[d.adj_off + (i64)(r0 + threadIdx.x) * d.aw + tile.z] = 0ull;
-            continue;
-        }
-        const int col = c0 + lane;
-        const int deg_c = col < d.n ? deg[d.row0 + col] : 0;
-        // the 16 rows of this wave: bit q of `hit` = rows (r0 + wave + 4q) and `col` share a neighbour
-        unsigned hit = 0;
-        for (int k0 = 0; k0 < d.aw; k0 += kChunk) {
-            const int kn = d.aw - k0 < kChunk ? d.aw - k0 : kChunk;
-            __syncthreads();
-            for (int x = threadIdx.x; x < kTile * kChunk; x += blockDim.x) {
-                const int q = x / kChunk, w = x - q * kChunk;
-                rows[q][w] = (w < kn && r0 + q < d.n) ? A[(i64)(r0 + q) * d.aw + k0 + w] : 0ull;
-                cols[q][w] = (w < kn && c0 + q < d.n) ? A[(i64)(c0 + q) * d.aw + k0 + w] : 0ull;
-            }
-            __syncthreads();
-            for (int q = 0; q < 16; ++q) {
-                const int rr = wave + 4 * q;
-                if (edge_w[rr] == 0) continue;           // uniform: this row has no edge into the tile
-                if (!((edge_w[rr] >> lane) & 1ull) || ((hit >> q) & 1u)) continue;
+        const i64 rl = r - d.row0;
+        const int deg_r = deg[r];
+        const u64 *d1 = deg1 + tint_word0[t];
+        bool any_change = false;
+        for (int z0 = 0; z0 < d.aw; z0 += 64) {
+            const int z = z0 + lane;
+            const bool zin = z < d.aw;
+            const u64 oldw = zin ? A[rl * d.aw + z] : 0ull;
+            u64 keep = ~0ull;
+            if (deg_r != 1) {                            // wave-uniform
                 u64 acc = 0;
-                for (int w = 0; w < kn; ++w) acc |= rows[rr][w] & cols[lane][w];
-                if (acc) hit |= 1u << q;
+                for (int wi = 0; wi < d.aw; ++wi) {
+                    u64 word = A[rl * d.aw + wi];        // the same address in every lane
+                    while (word) {
+                        const int k = wi * 64 + __ffsll((long long)word) - 1;
+                        word &= word - 1;
+                        acc |= A[(i64)k * d.aw + (zin ? z : 0)];
+                    }
+                }
+                keep = acc | (zin ? d1[z] : 0ull);
             }
+            const u64 neww = oldw & keep;
+            if (zin) new_adj[d.adj_off + rl * d.aw + z] = neww;
+            any_change |= neww != oldw;
         }
-        for (int q = 0; q < 16; ++q) {
-            const int rr = wave + 4 * q, row = r0 + rr;
-            if (row >= d.n) continue;
-            const u64 oldw = edge_w[rr];
-            const int deg_r = deg[d.row0 + row];
-            const bool keep = ((oldw >> lane) & 1ull) && (deg_r == 1 || deg_c == 1 || ((hit >> q) & 1u));
-            const u64 neww = __ballot(keep);
-            if (lane == 0) {
-                new_adj[d.adj_off + (i64)row * d.aw + tile.z] = neww;
-                if (neww != oldw) changed[tile.x] = 1;
-            }
-        }
+        if (__ballot(any_change) && lane == 0) changed[t] = 1;
     }
 }
 
@@ -263,6 +253,8 @@ int fclu_compat_graph(fclu_ctx *c, const fclu_batch *b, int32_t prune, uint64_t 
     std::vector<TintDesc> tints((size_t)T);
     std::vector<int4> tiles;
     std::vector<int> row_tint((size_t)R);
+    std::vector<int2> word_tint;                         // every adjacency word column of every tint: (tint, word)
+    std::vector<i64> tint_word0((size_t)T + 1, 0);
     int max_w = 1;
     for (int t = 0; t < T; ++t) {
         TintDesc &d = tints[(size_t)t];
@@ -283,6 +275,8 @@ int fclu_compat_graph(fclu_ctx *c, const fclu_batch *b, int32_t prune, uint64_t 
             if (f < -1 || l >= (d.n_seg > 0 ? d.n_seg : 1) || b->tail[d.row0 + r] > 2) return fail(c, FCLU_ERR_ARG, "tint %d read %lld: first/last/tail out of range", t, r);
         }
         for (int ti = 0; ti < d.aw; ++ti) for (int tj = 0; tj < d.aw; ++tj) tiles.push_back(make_int4(t, ti, tj, 0));
+        for (int z = 0; z < d.aw; ++z) word_tint.push_back(make_int2(t, z));
+        tint_word0[(size_t)t + 1] = (i64)word_tint.size();
     }
     const i64 n_bits = b->bits_off[T], n_adj = b->adj_off[T];
     const int n_tiles = (int)tiles.size();
@@ -290,7 +284,7 @@ int fclu_compat_graph(fclu_ctx *c, const fclu_batch *b, int32_t prune, uint64_t 
     c->compat_ms = c->prune_ms = 0.f;
     if (n_tiles == 0 || R == 0) return FCLU_OK;
 
-    Dev d_tints, d_tiles, d_row_tint, d_bits, d_first, d_last, d_tail, d_adj[2], d_deg, d_changed;
+    Dev d_tints, d_tiles, d_row_tint, d_bits, d_first, d_last, d_tail, d_adj[2], d_deg, d_changed, d_word_tint, d_tint_word0, d_deg1;
     HIP_TRY(c, d_tints.alloc(tints.size() * sizeof(TintDesc)));
     HIP_TRY(c, d_tiles.alloc(tiles.size() * sizeof(int4)));
     HIP_TRY(c, d_row_tint.alloc((size_t)R * 4));
@@ -302,10 +296,15 @@ int fclu_compat_graph(fclu_ctx *c, const fclu_batch *b, int32_t prune, uint64_t 
     HIP_TRY(c, d_adj[1].alloc((size_t)n_adj * 8));
     HIP_TRY(c, d_deg.alloc((size_t)R * 4));
     HIP_TRY(c, d_changed.alloc((size_t)T * 4));
+    HIP_TRY(c, d_word_tint.alloc(word_tint.size() * sizeof(int2)));
+    HIP_TRY(c, d_tint_word0.alloc(tint_word0.size() * 8));
+    HIP_TRY(c, d_deg1.alloc(word_tint.size() * 8));
     hipStream_t s = c->stream;
     HIP_TRY(c, hipMemcpyAsync(d_tints.p, tints.data(), tints.size() * sizeof(TintDesc), hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(d_tiles.p, tiles.data(), tiles.size() * sizeof(int4), hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(d_row_tint.p, row_tint.data(), (size_t)R * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(d_word_tint.p, word_tint.data(), word_tint.size() * sizeof(int2), hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(d_tint_word0.p, tint_word0.data(), tint_word0.size() * 8, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(d_bits.p, b->bits, (size_t)n_bits * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(d_first.p, b->first, (size_t)R * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(d_last.p, b->last, (size_t)R * 4, hipMemcpyHostToDevice, s));
@@ -325,8 +324,12 @@ int fclu_compat_graph(fclu_ctx *c, const fclu_batch *b, int32_t prune, uint64_t 
             HIP_TRY(c, hipMemsetAsync(d_changed.p, 0, (size_t)T * 4, s));
             hipLaunchKernelGGL(k_degree, dim3(deg_grid), dim3(256), 0, s, R, d_row_tint.as<int>(), d_tints.as<TintDesc>(),
                                d_adj[cur].as<u64>(), d_deg.as<int>());
-            hipLaunchKernelGGL(k_prune, dim3(grid), dim3(256), 0, s, n_tiles, d_tiles.as<int4>(), d_tints.as<TintDesc>(),
-                               d_adj[cur].as<u64>(), d_deg.as<int>(), d_adj[cur ^ 1].as<u64>(), d_changed.as<int>());
+            const int n_words = (int)word_tint.size();
+            hipLaunchKernelGGL(k_deg1, dim3((n_words + 3) / 4 < 4096 ? (n_words + 3) / 4 : 4096), dim3(256), 0, s, n_words,
+                               d_word_tint.as<int2>(), d_tints.as<TintDesc>(), d_deg.as<int>(), d_deg1.as<u64>());
+            hipLaunchKernelGGL(k_prune, dim3((int)((R + 3) / 4 < 16384 ? (R + 3) / 4 : 16384)), dim3(256), 0, s, R, d_row_tint.as<int>(),
+                               d_tints.as<TintDesc>(), d_tint_word0.as<i64>(), d_adj[cur].as<u64>(), d_deg.as<int>(),
+                               d_deg1.as<u64>(), d_adj[cur ^ 1].as<u64>(), d_changed.as<int>());
             HIP_TRY(c, hipMemcpyAsync(changed.data(), d_changed.p, (size_t)T * 4, hipMemcpyDeviceToHost, s));
             HIP_TRY(c, hipStreamSynchronize(s));
             cur ^= 1;
