@@ -19,12 +19,12 @@ typedef unsigned long long u64;
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
 // One workgroup per isoform, its reads in chunks of kSpanCap.  Phase 1: the four waves split the chunk's reads and
-// find every read's span = first / last segment holding '1' (ballot over 64 label bytes at a time), widened by the
-// tail rule of :217-224, into LDS.  Phase 2: lanes = 64 consecutive segments, the waves split the reads again and count
+// find every read's span = first / last segment holding '1' (ballot over 256 label bytes at a time), widened by the
+// tail rule of :217-224, into LDS.  Phase 2: lanes = 4 consecutive segments each, the waves split the reads again and count
 // coverage / consensus, partial sums meet in LDS.  The chunk's label bytes (tens of KB) are read from HBM once: the
 // second phase finds them in L2.
 constexpr int kSpanCap = 1024;
-constexpr int kE = 16;              // reads a wave keeps in flight (its label loads are 64 bytes each: latency, not bandwidth, is the limit)
+constexpr int kE = 8;               // reads a wave keeps in flight (16 is slower: registers)
 __global__ void __launch_bounds__(256) k_consensus(int n_iso, const i64 *iso_read_off, const int *n_seg, const i64 *iso_seg_off,
                                                    const i64 *read_lab_off, const unsigned char *labels, const unsigned char *tail,
                                                    int *cons, int *cov, int *tails) {
@@ -32,7 +32,7 @@ __global__ void __launch_bounds__(256) k_consensus(int n_iso, const i64 *iso_rea
     __shared__ int2 sp_s[kSpanCap];
     __shared__ i64 off_s[kSpanCap];
     __shared__ unsigned char tl_s[kSpanCap];
-    __shared__ int part[4][64][2];
+    __shared__ int part[4][256][2];
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     for (int i = blockIdx.x; i < n_iso; i += gridDim.x) {
         const i64 r0 = iso_read_off[i], r1 = iso_read_off[i + 1];
@@ -45,24 +45,32 @@ __global__ void __launch_bounds__(256) k_consensus(int n_iso, const i64 *iso_rea
             __syncthreads();
             for (int q = threadIdx.x; q < n; q += blockDim.x) { off_s[q] = read_lab_off[rb + q]; tl_s[q] = tail[rb + q]; }   // one coalesced pass
             __syncthreads();
-            for (int q0 = wave * kE; q0 < n; q0 += 4 * kE) {              // ---- phase 1: spans, kE reads in flight
+            // A lane owns 4 consecutive segments (one 4-byte load, possibly unaligned: rows are M bytes long), so a wave
+            // covers 256 segments of a read per load instruction; kE reads are in flight per wave.  Loads are
+            // unconditional from clamped (always valid) addresses, the predicate is applied afterwards: a load under a
+            // condition compiles to a branch with its own wait, which would serialise the kE loads.
+            for (int q0 = wave * kE; q0 < n; q0 += 4 * kE) {              // ---- phase 1: spans
                 int first[kE], last[kE];
 #pragma unroll
                 for (int e = 0; e < kE; ++e) { first[e] = -1; last[e] = -1; }
-                for (int j0 = 0; j0 < M; j0 += 64) {
-                    const int j = j0 + lane;
-                    // unconditional loads from clamped (always valid) addresses, predicate applied afterwards: a
-                    // conditional load compiles to a branch with its own wait, which serialises the kE loads
-                    const int jc = j < M ? j : M - 1;
-                    unsigned char b[kE];
+                for (int j0 = 0; j0 < M; j0 += 256) {
+                    const int j = j0 + 4 * lane;
+                    const int jc = j < M ? j : 0;                          // bytes past the row's end are masked below
+                    unsigned w[kE];
 #pragma unroll
-                    for (int e = 0; e < kE; ++e) b[e] = labels[off_s[q0 + e < n ? q0 + e : q0] + jc];
+                    for (int e = 0; e < kE; ++e) __builtin_memcpy(&w[e], labels + off_s[q0 + e < n ? q0 + e : q0] + jc, 4);
 #pragma unroll
                     for (int e = 0; e < kE; ++e) {
-                        const u64 m = __ballot(j < M && q0 + e < n && b[e] == '1');
+                        unsigned ones = 0;                                 // bit s = segment j + s holds '1'
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; ++s4) ones |= (unsigned)(j + s4 < M && ((w[e] >> (8 * s4)) & 0xffu) == '1') << s4;
+                        const u64 m = __ballot(q0 + e < n && ones != 0);
                         if (m) {
-                            if (first[e] < 0) first[e] = j0 + __ffsll((long long)m) - 1;
-                            last[e] = j0 + 63 - __clzll((long long)m);
+                            const int lf = __ffsll((long long)m) - 1, ll = 63 - __clzll((long long)m);
+                            const unsigned of = (unsigned)__builtin_amdgcn_readlane((int)ones, lf);
+                            const unsigned ol = (unsigned)__builtin_amdgcn_readlane((int)ones, ll);
+                            if (first[e] < 0) first[e] = j0 + 4 * lf + __ffs(of) - 1;
+                            last[e] = j0 + 4 * ll + 31 - __clz(ol);
                         }
                     }
                 }
@@ -76,30 +84,42 @@ __global__ void __launch_bounds__(256) k_consensus(int n_iso, const i64 *iso_rea
             __syncthreads();
             for (int q = threadIdx.x; q < n; q += blockDim.x)
                 if (sp_s[q].x >= 0) atomicAdd(&t_s[tl_s[q]], 1);      // reads without a '1' are not counted (:215-216)
-            for (int j0 = 0; j0 < M; j0 += 64) {                           // ---- phase 2: counts
-                const int j = j0 + lane;
-                int x = 0, c = 0;
-                for (int q0 = wave * kE; q0 < n; q0 += 4 * kE) {          // kE reads in flight, predicated loads
-                    const int jc = j < M ? j : M - 1;
-                    unsigned char b[kE]; bool in[kE];
+            for (int j0 = 0; j0 < M; j0 += 256) {                          // ---- phase 2: counts
+                const int j = j0 + 4 * lane;
+                const int jc = j < M ? j : 0;
+                int x[4] = {0, 0, 0, 0}, c[4] = {0, 0, 0, 0};
+                for (int q0 = wave * kE; q0 < n; q0 += 4 * kE) {
+                    unsigned w[kE];
+                    int2 sp[kE];
 #pragma unroll
                     for (int e = 0; e < kE; ++e) {
                         const int q = q0 + e < n ? q0 + e : q0;
-                        const int2 sp = sp_s[q];
-                        in[e] = q0 + e < n && j < M && j >= sp.x && j <= sp.y;
-                        b[e] = labels[off_s[q] + jc];                         // unconditional (see phase 1)
+                        sp[e] = q0 + e < n ? sp_s[q] : make_int2(1, 0);        // an empty span for the padding reads
+                        __builtin_memcpy(&w[e], labels + off_s[q] + jc, 4);
                     }
 #pragma unroll
-                    for (int e = 0; e < kE; ++e) { c += in[e]; x += in[e] && b[e] == '1'; }
+                    for (int e = 0; e < kE; ++e) {
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; ++s4) {
+                            const bool in = j + s4 >= sp[e].x && j + s4 <= sp[e].y;   // spans end below M
+                            c[s4] += in;
+                            x[s4] += in && ((w[e] >> (8 * s4)) & 0xffu) == '1';
+                        }
+                    }
                 }
-                part[wave][lane][0] = x; part[wave][lane][1] = c;
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) { part[wave][4 * lane + s4][0] = x[s4]; part[wave][4 * lane + s4][1] = c[s4]; }
                 __syncthreads();
-                if (wave == 0 && j < M) {
-                    const int xs = part[0][lane][0] + part[1][lane][0] + part[2][lane][0] + part[3][lane][0];
-                    const int cs = part[0][lane][1] + part[1][lane][1] + part[2][lane][1] + part[3][lane][1];
-                    const i64 o = iso_seg_off[i] + j;
-                    cons[o] = (rb == r0 ? 0 : cons[o]) + xs;               // later chunks add to the first chunk's sums
-                    cov[o] = (rb == r0 ? 0 : cov[o]) + cs;
+                {
+                    const int jj = j0 + threadIdx.x;                       // 256 threads = the 256 segments of this step
+                    if (jj < M) {
+                        const int t = threadIdx.x;
+                        const int xs = part[0][t][0] + part[1][t][0] + part[2][t][0] + part[3][t][0];
+                        const int cs = part[0][t][1] + part[1][t][1] + part[2][t][1] + part[3][t][1];
+                        const i64 o = iso_seg_off[i] + jj;
+                        cons[o] = (rb == r0 ? 0 : cons[o]) + xs;           // later chunks add to the first chunk's sums
+                        cov[o] = (rb == r0 ? 0 : cov[o]) + cs;
+                    }
                 }
                 __syncthreads();
             }
