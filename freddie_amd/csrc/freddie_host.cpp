@@ -104,7 +104,7 @@ void split_tabs(const char *b, const char *e, std::vector<std::pair<const char *
 }
 
 void parse_partition(const char *split_path, const char *reads_path, Partition &P) {
-    std::string text;
+    static thread_local std::string text;              // reused across partitions (see load_sidecar)
     if (!read_file(split_path, text)) { P.err = std::string("cannot read ") + split_path; return; }
     std::vector<std::pair<const char *, const char *>> cols;
     const char *p = text.data(), *end = p + text.size();
@@ -400,6 +400,14 @@ struct Sink {
 struct Source {
     const unsigned char *p, *end;
     bool ok = true;
+    // a section that is only read while loading: a pointer into the file image instead of a copy (sections are 8-aligned)
+    template <typename T> const T *view(size_t n) {
+        size_t bytes = n * sizeof(T), padded = bytes + (8 - bytes % 8) % 8;
+        if (!ok || (size_t)(end - p) < padded) { ok = false; return nullptr; }
+        const T *r = reinterpret_cast<const T *>(p);
+        p += padded;
+        return r;
+    }
     template <typename T> void get(std::vector<T> &v, size_t n) {
         size_t bytes = n * sizeof(T), padded = bytes + (8 - bytes % 8) % 8;
         if (!ok || (size_t)(end - p) < padded) { ok = false; return; }
@@ -478,7 +486,9 @@ bool write_sidecar(const Partition &P, const char *split_path, const char *reads
 // Returns true when the side-car exists, belongs to exactly these TSVs and is intact; P is then what
 // parse_partition() would have produced.  Any mismatch returns false (the caller parses the TSVs instead).
 bool load_sidecar(const char *sidecar_path, const char *split_path, const char *reads_path, Partition &P, bool verify) {
-    std::string blob;
+    // one file image per worker thread, reused from partition to partition: a fresh 300 KB buffer per file would be an
+    // mmap + page faults + munmap each time, and those serialise the threads on the process' address-space lock
+    static thread_local std::string blob;
     if (!read_file(sidecar_path, blob) || blob.size() < sizeof(FscHeader)) return false;
     FscHeader h;
     memcpy(&h, blob.data(), sizeof h);
@@ -492,22 +502,24 @@ bool load_sidecar(const char *sidecar_path, const char *split_path, const char *
     if (h.n_reads > (1ull << 31) || h.n_exons > (1ull << 31) || h.n_cigar > (1ull << 31) || h.n_reps > h.n_reads ||
         (int64_t)h.n_reads != h.read_count) return false;
     Source s{pay, pay + h.payload_bytes};
-    std::vector<char> chr, names, read_chrs;
-    std::vector<int64_t> read_id;
-    std::vector<int32_t> read_ex_off, read_rep;
-    std::vector<uint8_t> strand, packed, exc_ch;
-    std::vector<uint32_t> name_off, chr_off;
-    std::vector<uint64_t> seq_off, exc_pos;
-    s.get(chr, (size_t)h.chr_bytes);
+    const char *chr = s.view<char>((size_t)h.chr_bytes);
     s.get(P.iv_s, (size_t)h.n_iv); s.get(P.iv_e, (size_t)h.n_iv);
-    s.get(read_id, n); s.get(read_ex_off, n + 1); s.get(read_rep, n); s.get(strand, n);
-    s.get(name_off, n + 1); s.get(names, (size_t)h.name_bytes);
-    if (h.read_chr_bytes) { s.get(chr_off, n + 1); s.get(read_chrs, (size_t)h.read_chr_bytes - 1); }
+    const int64_t *read_id = s.view<int64_t>(n);
+    const int32_t *read_ex_off = s.view<int32_t>(n + 1), *read_rep = s.view<int32_t>(n);
+    const uint8_t *strand = s.view<uint8_t>(n);
+    const uint32_t *name_off = s.view<uint32_t>(n + 1);
+    const char *names = s.view<char>((size_t)h.name_bytes);
+    const uint32_t *chr_off = nullptr;
+    const char *read_chrs = nullptr;
+    const size_t read_chr_len = h.read_chr_bytes ? (size_t)h.read_chr_bytes - 1 : 0;
+    if (h.read_chr_bytes) { chr_off = s.view<uint32_t>(n + 1); read_chrs = s.view<char>(read_chr_len); }
     s.get(P.ts, (size_t)h.n_exons); s.get(P.te, (size_t)h.n_exons); s.get(P.qs, (size_t)h.n_exons); s.get(P.qe, (size_t)h.n_exons);
     s.get(P.cig_off, (size_t)h.n_exons + 1); s.get(P.cig_len, (size_t)h.n_cigar); s.get(P.cig_op, (size_t)h.n_cigar);
     s.get(P.rep_first_read, (size_t)h.n_reps); s.get(P.rep_weight, (size_t)h.n_reps);
-    s.get(seq_off, n + 1); s.get(packed, (size_t)((h.seq_bases + 3) / 4));
-    s.get(exc_pos, (size_t)h.n_exc); s.get(exc_ch, (size_t)h.n_exc);
+    const uint64_t *seq_off = s.view<uint64_t>(n + 1);
+    const uint8_t *packed = s.view<uint8_t>((size_t)((h.seq_bases + 3) / 4));
+    const uint64_t *exc_pos = s.view<uint64_t>((size_t)h.n_exc);
+    const uint8_t *exc_ch = s.view<uint8_t>((size_t)h.n_exc);
     if (!s.ok || s.p != s.end) return false;
     // structural checks: every offset table must be monotone and end at its array's size
     if (read_ex_off[0] != 0 || read_ex_off[n] != (int32_t)h.n_exons || name_off[n] != h.name_bytes || seq_off[n] != h.seq_bases ||
@@ -515,12 +527,12 @@ bool load_sidecar(const char *sidecar_path, const char *split_path, const char *
     for (size_t i = 0; i < n; ++i) {
         if (read_ex_off[i] > read_ex_off[i + 1] || name_off[i] > name_off[i + 1] || seq_off[i] > seq_off[i + 1]) return false;
         if (read_rep[i] < 0 || (uint64_t)read_rep[i] >= h.n_reps) return false;
-        if (h.read_chr_bytes && (chr_off[i] > chr_off[i + 1] || chr_off[i + 1] > read_chrs.size())) return false;
+        if (h.read_chr_bytes && (chr_off[i] > chr_off[i + 1] || chr_off[i + 1] > read_chr_len)) return false;
     }
     for (size_t x = 0; x < (size_t)h.n_exons; ++x) if (P.cig_off[x] < 0 || P.cig_off[x] > P.cig_off[x + 1]) return false;
     for (size_t r = 0; r < (size_t)h.n_reps; ++r) if (P.rep_first_read[r] < 0 || (size_t)P.rep_first_read[r] >= n) return false;
-    for (size_t k = 0; k < exc_pos.size(); ++k) if (exc_pos[k] >= h.seq_bases || (k && exc_pos[k] <= exc_pos[k - 1])) return false;
-    P.chr.assign(chr.begin(), chr.end());
+    for (size_t k = 0; k < (size_t)h.n_exc; ++k) if (exc_pos[k] >= h.seq_bases || (k && exc_pos[k] <= exc_pos[k - 1])) return false;
+    P.chr.assign(chr, chr + h.chr_bytes);
     P.id = h.id; P.read_count = h.read_count;
     static const char LUT[4] = {'A', 'C', 'G', 'T'};
     static char QUAD[256][4];
@@ -531,8 +543,8 @@ bool load_sidecar(const char *sidecar_path, const char *split_path, const char *
     for (size_t i = 0; i < n; ++i) {
         Read &r = P.reads[i];
         r.id = read_id[i]; r.tint = h.id; r.strand = (char)strand[i]; r.ex0 = read_ex_off[i]; r.ex1 = read_ex_off[i + 1]; r.rep = read_rep[i];
-        r.name.assign(names.data() + name_off[i], names.data() + name_off[i + 1]);
-        if (h.read_chr_bytes) r.chr.assign(read_chrs.data() + chr_off[i], read_chrs.data() + chr_off[i + 1]);
+        r.name.assign(names + name_off[i], names + name_off[i + 1]);
+        if (h.read_chr_bytes) r.chr.assign(read_chrs + chr_off[i], read_chrs + chr_off[i + 1]);
         else r.chr = P.chr;
         const uint64_t g0 = seq_off[i], len = seq_off[i + 1] - g0;
         r.seq.resize((size_t)len);
@@ -541,7 +553,7 @@ bool load_sidecar(const char *sidecar_path, const char *split_path, const char *
         for (; t < len && ((g0 + t) & 3); ++t) { uint64_t g = g0 + t; dst[t] = LUT[(packed[(size_t)(g >> 2)] >> ((g & 3) * 2)) & 3]; }
         for (; t + 4 <= len; t += 4) memcpy(dst + t, QUAD[packed[(size_t)((g0 + t) >> 2)]], 4);      // one packed byte = 4 bases
         for (; t < len; ++t) { uint64_t g = g0 + t; dst[t] = LUT[(packed[(size_t)(g >> 2)] >> ((g & 3) * 2)) & 3]; }
-        while (e < exc_pos.size() && exc_pos[e] < g0 + len) { dst[exc_pos[e] - g0] = (char)exc_ch[e]; ++e; }
+        while (e < (size_t)h.n_exc && exc_pos[e] < g0 + len) { dst[exc_pos[e] - g0] = (char)exc_ch[e]; ++e; }
     }
     return true;
 }

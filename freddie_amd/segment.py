@@ -455,33 +455,49 @@ def run_segment_batch_python(jobs, params, ctx):
 
 def run_batches(batches, params, ctx, threads, on_done, sidecar="off"):
     """Pipelined driver of one GPU: while the GPU works on batch i, batch i+1 is parsed and batch i-1 is
-    annotated and written by host threads (the native calls release the GIL)."""
+    annotated and written by host threads (the native calls release the GIL).  FREDDIE_TIMING=1 prints one line per
+    batch to stderr (load / device / write seconds, partitions taken from side-cars)."""
+    import time
     from concurrent.futures import ThreadPoolExecutor
     if not batches:
         return
+    timing = os.environ.get("FREDDIE_TIMING") == "1"
     set_context_params(ctx, params)
+
+    def load(jobs):
+        t0 = time.perf_counter()
+        hb = load_batch_native(jobs, threads, sidecar)
+        return hb, time.perf_counter() - t0
+
     with ThreadPoolExecutor(max_workers=2) as pool:
-        nxt = pool.submit(load_batch_native, batches[0], threads, sidecar)
+        nxt = pool.submit(load, batches[0])
         pending_write = None
 
-        def finish(hb, res, jobs):
+        def finish(hb, res, jobs, t_load, t_dev, i):
+            t0 = time.perf_counter()
             try:
                 hb.write(*res, [_job_paths(j)[2] for j in jobs], n_threads=threads)
             finally:
+                n_sc, n_reads = hb.n_from_sidecar, hb.n_reads
                 hb.close()
+            if timing:
+                print("[freddie_segment] batch %d: %d partitions (%d from side-cars), %d reads: load %.3f s, device %.3f s, "
+                      "write %.3f s" % (i, len(jobs), n_sc, n_reads, t_load, t_dev, time.perf_counter() - t0), file=sys.stderr)
             return jobs
 
         for i, jobs in enumerate(batches):
-            hb = nxt.result()
+            hb, t_load = nxt.result()
             if i + 1 < len(batches):
-                nxt = pool.submit(load_batch_native, batches[i + 1], threads, sidecar)
+                nxt = pool.submit(load, batches[i + 1])
+            t0 = time.perf_counter()
             ctx.upload(**hb.arrays())
             ctx.run()
             res = ctx.download()
+            t_dev = time.perf_counter() - t0
             if pending_write is not None:
                 for j in pending_write.result():
                     on_done((j[2], j[3]))
-            pending_write = pool.submit(finish, hb, res, jobs)
+            pending_write = pool.submit(finish, hb, res, jobs, t_load, t_dev, i)
         for j in pending_write.result():
             on_done((j[2], j[3]))
 
@@ -509,6 +525,10 @@ def discover(split_dir, outdir):
 
 
 def make_batches(jobs_with_cost, bytes_per_batch):
+    """Consecutive jobs up to bytes_per_batch of split TSV each -- but at least four batches once there is enough input,
+    so that loading, the device and writing overlap (a single batch runs them one after the other)."""
+    total = sum(c for _, c in jobs_with_cost)
+    bytes_per_batch = min(bytes_per_batch, max(total // 4, 8 << 20))
     batches, cur, size = [], [], 0
     for job, cost in jobs_with_cost:
         if cur and size + cost > bytes_per_batch:

@@ -23,6 +23,7 @@ ap.add_argument("--keep", default=None)
 ap.add_argument("--generate-only", action="store_true")
 ap.add_argument("--sidecar", default="off", choices=("auto", "off", "write"))
 ap.add_argument("--repeat", type=int, default=1)
+ap.add_argument("--timing", action="store_true", help="per-batch load / device / write seconds on stderr")
 args = ap.parse_args()
 work = args.keep or tempfile.mkdtemp(prefix="e2e_")
 split = os.path.join(work, "split")
@@ -39,7 +40,8 @@ for rep in range(args.repeat):
     shutil.rmtree(out, ignore_errors=True)
     t0 = time.time()
     subprocess.check_call([sys.executable, os.path.join(ROOT, "py", "freddie_segment.py"), "-s", split, "-o", out,
-                           "-t", str(args.threads), "--gpus", "1", "--sidecar", args.sidecar], stdout=subprocess.DEVNULL)
+                           "-t", str(args.threads), "--gpus", "1", "--sidecar", args.sidecar], stdout=subprocess.DEVNULL,
+                          env=dict(os.environ, FREDDIE_TIMING="1" if args.timing else "0"))
     dt = time.time() - t0
     size = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(split) for f in fs if f.endswith(".tsv"))
     fsc = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(split) for f in fs if f.endswith(".fsc"))
