@@ -94,7 +94,11 @@ def cpu_baseline_all_cores(parts, n_reads_of, params, tabs, min_s=8.0):
     """The same oracle over whole partitions on every host core (one process per core, partitions are independent):
     only meaningful for the many-partition workloads.  The pool is started (and warmed) outside the timed region."""
     import multiprocessing as mp
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))                       # the CPUs this process may use, not the machine's
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 64))
     jobs = [(p, params, tabs) for p in parts]
     with mp.get_context("fork").Pool(cores) as pool:
         pool.map(_oracle_one, jobs[:cores])                       # start-up, page-in
