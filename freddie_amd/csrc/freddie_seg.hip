@@ -1767,12 +1767,24 @@ __global__ void __launch_bounds__(ScoreCfg<NM>::kThreads) k_score(Status *st, in
     }
 }
 
+// The label arena starts every run filled with '0' (the label of a read without coverage, S7).  The fill depends on
+// nothing but the arena's capacity, and the big-problem DP occupies a fraction of the GPU with latency-bound
+// workgroups -- so the fill rides along as extra workgroups of that launch (k_label_zero when there is no DP launch).
+__device__ __forceinline__ void fill_labels(uint4 *labels16, i64 n16, i64 first, i64 stride) {
+    const uint4 z = make_uint4(0x30303030u, 0x30303030u, 0x30303030u, 0x30303030u);
+    for (i64 i = first; i < n16; i += stride) labels16[i] = z;
+}
+
 template <int NM, int T, typename OutT>
 __global__ void __launch_bounds__(T) k_dp(Status *st, int dp_class, int nm, const int *dp_items, ProblemArrays pr, const ProbDesc *desc, i64 prob_cap,
                                             const i64 *cand_off, const int *cand_y, const int *iv_part,
                                             const i64 *part_lane_off, const unsigned *out_g, i64 tri_cap,
                                             const unsigned *amb_g, const int2 *pair_thr, i64 pair_cap, int support,
-                                            unsigned char *chosen, int tiny_max FSEG_TPARAM) {
+                                            unsigned char *chosen, int tiny_max, int dp_blocks, uint4 *labels16, i64 labels_n16 FSEG_TPARAM) {
+    if ((int)blockIdx.x >= dp_blocks) {                 // the workgroups behind the DP ones: label arena fill
+        fill_labels(labels16, labels_n16, (i64)(blockIdx.x - dp_blocks) * T + threadIdx.x, (i64)(gridDim.x - dp_blocks) * T);
+        return;
+    }
     // handles problems with n_lo < n <= NM that the scoring kernel did not finish itself (more than one
     // work item); the out table of the problem is staged in LDS first
     // LDS carve-up for problems of at most nm <= NM candidates (nm from the previous run's largest problem)
@@ -1794,7 +1806,7 @@ __global__ void __launch_bounds__(T) k_dp(Status *st, int dp_class, int nm, cons
 #ifdef FSEG_SCORE_TIMING
     unsigned long long *dp_tacc = tacc; unsigned long long dt_prev = wall_clock64();
 #endif
-    for (i64 t = blockIdx.x; t < list_n; t += gridDim.x) {          // static stride (no shared work counter)
+    for (i64 t = blockIdx.x; t < list_n; t += dp_blocks) {          // static stride (no shared work counter)
         __syncthreads();
         FSEG_DTICK(8);
         const i64 p = dp_class < 0 ? t : (i64)dp_items[list_base + t];
@@ -2546,12 +2558,8 @@ __global__ void __launch_bounds__(256) k_label_cols(i64 K, const i64 *final_off,
 // The label arena is pre-filled with '0' (the label of a read without coverage) by one streaming kernel; in
 // partitions in which a zero-coverage read is ambiguous for some segment (lo < 0, i.e. threshold_rate == 1) every rep
 // first rewrites its row with the columns' defaults (k_label_reads).
-__global__ void __launch_bounds__(256) k_label_zero(const i64 *label_off, int n_part, i64 label_cap, uint4 *labels16) {
-    const i64 total = label_off[n_part];
-    if (total > label_cap) return;
-    const i64 n16 = (total + 15) / 16;                      // the arena is allocated in multiples of 16 bytes
-    const uint4 z = make_uint4(0x30303030u, 0x30303030u, 0x30303030u, 0x30303030u);
-    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (i64)gridDim.x * blockDim.x) labels16[i] = z;
+__global__ void __launch_bounds__(256) k_label_zero(uint4 *labels16, i64 n16) {
+    fill_labels(labels16, n16, (i64)blockIdx.x * blockDim.x + threadIdx.x, (i64)gridDim.x * blockDim.x);
 }
 // One workgroup per 64 read reps of one partition (a quarter of a 256-rep block).  The partition's column table
 // (segment boundaries and integer thresholds) is staged in LDS when it fits; kLabelSplit threads share a rep: each
@@ -3014,13 +3022,16 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
     if (do_post) {
     if (c->prob_cap > 0) {
         int dp_grid = grid_for(c->prob_cap, 1, 1024);
+        const i64 labels_n16 = (c->label_cap + 15) / 16;            // the arena is allocated in multiples of 16 bytes
+        const int fill_blocks = c->label_cap > 0 ? grid_for(labels_n16 / 8 + 1, 512, 512) : 0;
 #define FSEG_LAUNCH_DP(NMV, TV, OUTT, NM_RT, DPCLASS, MAXWG)                                                             \
-        hipLaunchKernelGGL((k_dp<NMV, TV, OUTT>), dim3(dp_grid < (MAXWG) ? dp_grid : (MAXWG)), dim3(TV),                     \
+        hipLaunchKernelGGL((k_dp<NMV, TV, OUTT>), dim3((dp_grid < (MAXWG) ? dp_grid : (MAXWG)) + fill_blocks), dim3(TV),     \
                            dp_lds_for(NM_RT, (int)sizeof(OUTT)), ((NMV) == kDpSmall ? q_small : s), st, DPCLASS, NM_RT, c->d_dp_items.as<int>(), pr,          \
                            c->d_prob_desc.as<ProbDesc>(), c->prob_cap, c->d_cand_off.as<i64>(), c->d_cand_y.as<int>(), c->d_iv_part.as<int>(),               \
                            c->d_part_lane_off.as<i64>(), c->d_out.as<unsigned>(), c->tri_cap, c->d_amb.as<unsigned>(),        \
                            c->d_pair_thr.as<int2>(), c->pair_cap, c->P.min_read_support_outside,                              \
-                           c->d_chosen.as<unsigned char>(), tiny_max FSEG_TARG)
+                           c->d_chosen.as<unsigned char>(), tiny_max, (dp_grid < (MAXWG) ? dp_grid : (MAXWG)),                \
+                           c->d_labels.as<uint4>(), labels_n16 FSEG_TARG)
 #define FSEG_LAUNCH_DP_WAVES(OUTT)                                                                                        \
         hipLaunchKernelGGL((k_dp_waves<OUTT>), dim3(grid_for(c->prob_cap, 4, 2048)), dim3(256),                                \
                            dp_lds_for(kDpSmall, (int)sizeof(OUTT)) > 4 * dp_wave_bytes<OUTT>() ? dp_lds_for(kDpSmall, (int)sizeof(OUTT)) : 4 * dp_wave_bytes<OUTT>(), \
@@ -3073,8 +3084,9 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
                        c->d_part_has2.as<int>(), n_part, c->d_part_iv_off.as<i64>(), c->d_part_rep_off.as<i64>(),
                        c->d_label_off.as<i64>(), st, c->label_cap);
     if (c->label_cap > 0) {
-        hipLaunchKernelGGL(k_label_zero, dim3(grid_for(c->label_cap / 16 / 8 + 1, 256, 4096)), dim3(256), 0, s,
-                           c->d_label_off.as<i64>(), n_part, c->label_cap, c->d_labels.as<uint4>());
+        if (c->prob_cap == 0)                                       // no DP launch carried the fill
+            hipLaunchKernelGGL(k_label_zero, dim3(grid_for(c->label_cap / 16 / 8 + 1, 256, 4096)), dim3(256), 0, s,
+                               c->d_labels.as<uint4>(), (c->label_cap + 15) / 16);
         hipLaunchKernelGGL(k_label_reads, dim3(grid_for((i64)c->n_rep_blocks * kLabelSplit, 1, 65536)), dim3(256), 0, s, c->n_rep_blocks,
                            c->d_rb_part.as<int>(), c->d_rb_r0.as<int>(), c->d_label_off.as<i64>(), c->label_cap, n_part,
                            c->d_part_iv_off.as<i64>(), c->d_part_rep_off.as<i64>(), c->d_final_off.as<i64>(),
