@@ -142,8 +142,8 @@ __global__ void __launch_bounds__(512) k_hist(int n_chunks, const int *chunk_par
                                               const int *chunk_glo, const int *chunk_ghi, const i64 *chunk_lane_lo,
                                               const i64 *chunk_lane_hi, const i64 *part_iv_off,
                                               const int *iv_start, const int *iv_end, const i64 *pos_off,
-                                              const i64 *part_lane_off, const int *lane_rep, const int *lane_start,
-                                              const int *lane_pmax, const i64 *rep_exon_off, const int *ex_ts,
+                                              const i64 *part_lane_off, const longlong2 *lane_ex, const int *lane_start,
+                                              const int *lane_pmax, const int *ex_ts,
                                               const int *ex_te, int ignore_ends, int *y_raw, Status *st, u64 *zero_ptr, i64 zero_n) {
     __shared__ int hist[kHistChunk];
     __shared__ int ivs_s[kHistIv], ive_s[kHistIv], base_s[kHistIv];
@@ -169,33 +169,49 @@ __global__ void __launch_bounds__(512) k_hist(int n_chunks, const int *chunk_par
                 base_s[i] = (int)(pos_off[k0 + i] - p0) - iv_start[k0 + i];   // chunk-local index = base + genomic position
             }
         __syncthreads();
-        // 8 threads share a read: thread q of the group takes the read's exons q, q+8, ...
+        // 8 threads share a read: thread q of the group takes the read's exons q, q+8, ...  The walk is a chain of
+        // dependent loads (lane -> exon range -> exon), so four reads per group are in flight: their exon ranges, then
+        // their first exons, are loaded together from clamped addresses before any of them is used.
         const int sub = threadIdx.x & 7;
-        for (i64 l = lo + (threadIdx.x >> 3); l < hi; l += blockDim.x >> 3) {
-            const i64 r = lane_rep[l];
-            const i64 e0 = rep_exon_off[r], e1 = rep_exon_off[r + 1];
-            for (i64 e = e0 + sub; e < e1; e += 8) {
-                const int ts = ex_ts[e], te = ex_te[e];
-                if (te < g_lo || ts > g_hi) continue;
-                // the interval that holds ts must hold te as well (:666-668; also validated on upload)
-                int kl = 0;
-                bool ok;
-                int base;
-                if (cached) {
-                    int a2 = 0, b2 = nk;
-                    while (b2 - a2 > 1) { int m = (a2 + b2) >> 1; if (ivs_s[m] <= ts) a2 = m; else b2 = m; }
-                    kl = a2;
-                    ok = ts >= ivs_s[kl] && ts <= ive_s[kl] && te <= ive_s[kl];
-                    base = base_s[kl];
-                } else {
-                    ok = ts >= iv_start[k0];
-                    i64 k = k0;
-                    if (ok) { k = k0 + last_le(iv_start + k0, k1 - k0, ts); ok = ts <= iv_end[k] && te <= iv_end[k]; }
-                    base = (int)(pos_off[k] - p0) - iv_start[k];
-                }
-                if (!ok) { atomicOr(&st->err, kErrExonInterval); continue; }
-                if (!(ignore_ends && e == e0) && ts >= g_lo && ts <= g_hi) atomicAdd(&hist[base + ts], 1);       // :670-671
-                if (!(ignore_ends && e == e1 - 1) && te >= g_lo && te <= g_hi) atomicAdd(&hist[base + te], 1);   // :672-673
+        const int G8 = blockDim.x >> 3;
+        auto count_exon = [&](i64 e, i64 e0, i64 e1, int ts, int te) {
+            if (te < g_lo || ts > g_hi) return;
+            // the interval that holds ts must hold te as well (:666-668; also validated on upload)
+            int kl = 0;
+            bool ok;
+            int base;
+            if (cached) {
+                int a2 = 0, b2 = nk;
+                while (b2 - a2 > 1) { int m = (a2 + b2) >> 1; if (ivs_s[m] <= ts) a2 = m; else b2 = m; }
+                kl = a2;
+                ok = ts >= ivs_s[kl] && ts <= ive_s[kl] && te <= ive_s[kl];
+                base = base_s[kl];
+            } else {
+                ok = ts >= iv_start[k0];
+                i64 k = k0;
+                if (ok) { k = k0 + last_le(iv_start + k0, k1 - k0, ts); ok = ts <= iv_end[k] && te <= iv_end[k]; }
+                base = (int)(pos_off[k] - p0) - iv_start[k];
+            }
+            if (!ok) { atomicOr(&st->err, kErrExonInterval); return; }
+            if (!(ignore_ends && e == e0) && ts >= g_lo && ts <= g_hi) atomicAdd(&hist[base + ts], 1);       // :670-671
+            if (!(ignore_ends && e == e1 - 1) && te >= g_lo && te <= g_hi) atomicAdd(&hist[base + te], 1);   // :672-673
+        };
+        for (i64 l0 = lo + (threadIdx.x >> 3); l0 < hi; l0 += 4 * (i64)G8) {
+            longlong2 ex[4];
+            int ts0[4], te0[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const i64 l = l0 + (i64)u * G8; ex[u] = lane_ex[l < hi ? l : l0]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const i64 e = ex[u].x + sub < ex[u].y ? ex[u].x + sub : ex[u].x;       // a valid exon of the read (a read has at least one)
+                ts0[u] = ex_ts[e]; te0[u] = ex_te[e];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (l0 + (i64)u * G8 >= hi) break;
+                const i64 e0 = ex[u].x, e1 = ex[u].y;
+                if (e0 + sub < e1) count_exon(e0 + sub, e0, e1, ts0[u], te0[u]);
+                for (i64 e = e0 + sub + 8; e < e1; e += 8) count_exon(e, e0, e1, ex_ts[e], ex_te[e]);
             }
         }
         __syncthreads();
@@ -2888,8 +2904,8 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
     hipLaunchKernelGGL(k_hist, dim3(grid_for(c->n_hist_chunks, 1, 16384)), dim3(512), 0, s, c->n_hist_chunks,
                        c->d_hc_part.as<int>(), c->d_hc_p0.as<i64>(), c->d_hc_n.as<int>(), c->d_hc_glo.as<int>(),
                        c->d_hc_ghi.as<int>(), c->d_hc_llo.as<i64>(), c->d_hc_lhi.as<i64>(), c->d_part_iv_off.as<i64>(), c->d_iv_start.as<int>(), c->d_iv_end.as<int>(),
-                       c->d_pos_off.as<i64>(), c->d_part_lane_off.as<i64>(), c->d_lane_rep.as<int>(),
-                       c->d_lane_start.as<int>(), c->d_lane_pmax.as<int>(), c->d_rep_exon_off.as<i64>(),
+                       c->d_pos_off.as<i64>(), c->d_part_lane_off.as<i64>(), c->d_lane_ex.as<longlong2>(),
+                       c->d_lane_start.as<int>(), c->d_lane_pmax.as<int>(),
                        c->d_ex_ts.as<int>(), c->d_ex_te.as<int>(), c->P.ignore_ends, c->d_y_raw.as<int>(), st,
                        scan_state, scan_single ? scan_nb * 3 : 0);
     mark(1);
