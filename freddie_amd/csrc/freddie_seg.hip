@@ -1865,7 +1865,7 @@ __host__ __device__ constexpr size_t dp_wave_bytes() {          // tables of one
     return (((size_t)kDpWavePairs * (8 + 4 + 1) + (size_t)(kDpWaveTri + 4) * sizeof(OutT)) + 15) & ~(size_t)15;
 }
 template <typename OutT>
-__global__ void __launch_bounds__(256) k_dp_waves(Status *st, const int *dp_items, ProblemArrays pr, const ProbDesc *desc, i64 prob_cap,
+__global__ void __launch_bounds__(256, 6) k_dp_waves(Status *st, const int *dp_items, ProblemArrays pr, const ProbDesc *desc, i64 prob_cap,
                                                   const int *cand_y, const unsigned *out_g, i64 tri_cap, const unsigned *amb_g,
                                                   const int2 *pair_thr, i64 pair_cap, int support, unsigned char *chosen) {
     constexpr int T = 256, NM = kDpSmall;
@@ -1969,7 +1969,9 @@ __global__ void __launch_bounds__(256) k_dp_waves(Status *st, const int *dp_item
 // ---------------------------------------------------------------------------------------------
 constexpr int kTiny = 8;
 constexpr int kTinyPairs = kTiny * (kTiny - 1) / 2, kTinyTri = kTiny * (kTiny - 1) * (kTiny - 2) / 6;
-__global__ void __launch_bounds__(256) k_tiny(Status *st, const ProbDesc *desc, i64 prob_cap, int tiny_max, ProblemArrays pr,
+// (6 workgroups = 24 waves per CU asked of the register allocator: the kernel is a chain of dependent loads, and at the
+// 120 registers it would otherwise take only 16 waves fit; measured 56 -> 47 us on config4, 8 spills and is slower)
+__global__ void __launch_bounds__(256, 6) k_tiny(Status *st, const ProbDesc *desc, i64 prob_cap, int tiny_max, ProblemArrays pr,
                                               const int *cand_y, const longlong2 *lane_ex, const int *ex_ts,
                                               const int *ex_te, const double *h_table, int h_len, double tau, int support,
                                               unsigned char *chosen) {
