@@ -2709,8 +2709,8 @@ struct fseg_ctx {
     std::vector<i64> part_iv_off, part_rep_off, part_lane_off, pos_off;
     std::vector<int> iv_start_h;
     // device buffers: inputs
-    DevBuf d_part_iv_off, d_part_rep_off, d_part_lane_off, d_iv_start, d_iv_end, d_pos_off, d_iv_part, d_rep_weight,
-        d_rep_exon_off, d_ex_ts, d_ex_te, d_lane_rep, d_lane_ex, d_lane_start, d_lane_pmax, d_tile_desc, d_w_main,
+    DevBuf d_part_iv_off, d_part_rep_off, d_part_lane_off, d_iv_start, d_iv_end, d_pos_off, d_iv_part,
+        d_rep_exon_off, d_ex_ts, d_ex_te, d_lane_ex, d_lane_start, d_lane_pmax, d_tile_desc, d_w_main,
         d_w_refine, d_h_table;
     // device buffers: position-sized
     DevBuf d_y_raw, d_y, d_flag, d_cflag, d_v, d_scan_state, d_bsum, d_bsum_side, d_g, d_pk, d_pf, d_kp, d_final_flag;
@@ -3268,7 +3268,7 @@ void fseg_destroy(fseg_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     drop_graph(c);
     DevBuf *bufs[] = {&c->d_part_iv_off, &c->d_part_rep_off, &c->d_part_lane_off, &c->d_iv_start, &c->d_iv_end, &c->d_pos_off,
-                      &c->d_iv_part, &c->d_rep_weight, &c->d_rep_exon_off, &c->d_ex_ts, &c->d_ex_te, &c->d_lane_rep, &c->d_lane_ex, &c->d_lane_start, &c->d_lane_pmax,
+                      &c->d_iv_part, &c->d_rep_exon_off, &c->d_ex_ts, &c->d_ex_te, &c->d_lane_ex, &c->d_lane_start, &c->d_lane_pmax,
                       &c->d_tile_desc, &c->d_w_main, &c->d_w_refine, &c->d_h_table, &c->d_y_raw, &c->d_y,
                       &c->d_flag, &c->d_cflag, &c->d_v, &c->d_scan_state, &c->d_bsum, &c->d_bsum_side, &c->d_g, &c->d_pk, &c->d_pf, &c->d_kp, &c->d_final_flag,
                       &c->d_blk_iv0, &c->d_edge, &c->d_hc_part, &c->d_hc_p0, &c->d_hc_n, &c->d_hc_glo, &c->d_hc_ghi, &c->d_hc_llo, &c->d_hc_lhi, &c->d_voff, &c->d_chunk_off, &c->d_csum, &c->d_mean, &c->d_thr, &c->d_label_off, &c->d_part_has2, &c->d_rb_part, &c->d_rb_r0, &c->d_cand_off,
@@ -3419,11 +3419,9 @@ int fseg_upload(fseg_ctx *c, const fseg_batch *b) {
     TRY(upload_vec(c, c->d_iv_end, b->iv_end, (size_t)K));
     TRY(upload_vec(c, c->d_pos_off, pos_off.data(), (size_t)K + 1));
     TRY(upload_vec(c, c->d_iv_part, iv_part.data(), (size_t)K));
-    TRY(upload_vec(c, c->d_rep_weight, b->rep_weight, (size_t)R));
     TRY(upload_vec(c, c->d_rep_exon_off, b->rep_exon_off, (size_t)R + 1));
     TRY(upload_vec(c, c->d_ex_ts, b->ex_ts, (size_t)I));
     TRY(upload_vec(c, c->d_ex_te, b->ex_te, (size_t)I));
-    TRY(upload_vec(c, c->d_lane_rep, lane_rep.data(), lane_rep.size()));
     {   // exon range of every lane's rep, so the per-read walks start with one load instead of lane -> rep -> offsets
         std::vector<longlong2> lane_ex((size_t)lanes);
         for (i64 l = 0; l < lanes; ++l) {
