@@ -1867,7 +1867,7 @@ __host__ __device__ constexpr size_t dp_wave_bytes() {          // tables of one
 template <typename OutT>
 __global__ void __launch_bounds__(256, 6) k_dp_waves(Status *st, const int *dp_items, ProblemArrays pr, const ProbDesc *desc, i64 prob_cap,
                                                   const int *cand_y, const unsigned *out_g, i64 tri_cap, const unsigned *amb_g,
-                                                  const int2 *pair_thr, i64 pair_cap, int support, unsigned char *chosen) {
+                                                  const int2 *pair_thr, i64 pair_cap, int support, unsigned char *chosen, int coop) {
     constexpr int T = 256, NM = kDpSmall;
     constexpr int kTri = NM * (NM - 1) * (NM - 2) / 6, kPairs = NM * (NM - 1) / 2;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1901,7 +1901,7 @@ __global__ void __launch_bounds__(256, 6) k_dp_waves(Status *st, const int *dp_i
                 const int npairs = n * (n - 1) / 2, ntri = n * (n - 1) * (n - 2) / 6;
                 const bool usable = n <= NM && poff + npairs <= pair_cap && toff + ntri <= tri_cap;
                 if (sizeof(OutT) == 2 && d.lane_n >= 65536) { if (lane == 0) atomicOr(&st->err, kErrNeedWideDp); }
-                else if (usable && n > kDpWave) big = (int)p;
+                else if (usable && n > kDpWave) big = coop ? (int)p : -1;   // coop == 0: a k_dp launch of its own takes these
                 else if (usable) {
                     unsigned char *w_mem = smem + (size_t)wave * dp_wave_bytes<OutT>();
                     i64 *M = reinterpret_cast<i64 *>(w_mem);
@@ -3055,11 +3055,19 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
                            dp_lds_for(kDpSmall, (int)sizeof(OUTT)) > 4 * dp_wave_bytes<OUTT>() ? dp_lds_for(kDpSmall, (int)sizeof(OUTT)) : 4 * dp_wave_bytes<OUTT>(), \
                            q_small, st, c->d_dp_items.as<int>(), pr, c->d_prob_desc.as<ProbDesc>(), c->prob_cap,                \
                            c->d_cand_y.as<int>(), c->d_out.as<unsigned>(), c->tri_cap, c->d_amb.as<unsigned>(),                \
-                           c->d_pair_thr.as<int2>(), c->pair_cap, c->P.min_read_support_outside, c->d_chosen.as<unsigned char>())
+                           c->d_pair_thr.as<int2>(), c->pair_cap, c->P.min_read_support_outside, c->d_chosen.as<unsigned char>(), 0); \
+        /* the problems of the list with 17 .. 32 candidates: one workgroup each, so that none waits behind another */      \
+        hipLaunchKernelGGL((k_dp<kDpSmall, 256, OUTT>), dim3(grid_for(c->prob_cap, 1, 8192)), dim3(256),                       \
+                           dp_lds_for(kDpSmall, (int)sizeof(OUTT)), q_mid, st, 0, kDpSmall, c->d_dp_items.as<int>(), pr,       \
+                           c->d_prob_desc.as<ProbDesc>(), c->prob_cap, c->d_cand_off.as<i64>(), c->d_cand_y.as<int>(), c->d_iv_part.as<int>(), \
+                           c->d_part_lane_off.as<i64>(), c->d_out.as<unsigned>(), c->tri_cap, c->d_amb.as<unsigned>(),        \
+                           c->d_pair_thr.as<int2>(), c->pair_cap, c->P.min_read_support_outside,                              \
+                           c->d_chosen.as<unsigned char>(), kDpWave, grid_for(c->prob_cap, 1, 8192), (uint4 *)nullptr, (i64)0 FSEG_TARG)
         // 16-bit count tables unless some problem sees >= 65536 reads (then a previous run asked for the wide tables);
         // 512 threads (8 waves share the c2 loop) when the tables of the largest problem leave room for their scratch.
         // small_batch: one launch over every problem; otherwise one launch per DP class list.
-        hipStream_t q_small = c->small_batch ? s : fork(0);      // the two DP classes own disjoint problems
+        hipStream_t q_small = c->small_batch ? s : fork(0);      // the DP classes own disjoint problems
+        hipStream_t q_mid = c->small_batch ? s : fork(1);
         if (c->dp_wide_counts) {
             const bool wide_wg = dp_lds_for(c->nm_big, 4) + 8 * 1024 <= kLdsPerWg;
             if (!c->small_batch) { FSEG_LAUNCH_DP_WAVES(unsigned); }
@@ -3071,7 +3079,7 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
         }
 #undef FSEG_LAUNCH_DP
 #undef FSEG_LAUNCH_DP_WAVES
-        if (!c->small_batch) join(0);
+        if (!c->small_batch) { join(0); join(1); }
         if (c->have_huge)
             hipLaunchKernelGGL(k_dp_huge, dim3(dp_grid < 256 ? dp_grid : 256), dim3(512), kHugeDpLds, s, st, c->d_dp_items.as<int>(),
                                pr, c->d_prob_desc.as<ProbDesc>(), c->prob_cap, c->d_cand_y.as<int>(), c->d_out.as<unsigned>(),
