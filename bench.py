@@ -7,6 +7,7 @@ partitions (static scatter, no collectives: partitions share nothing), so scalin
 `value` = reads segmented by all ranks / max-over-ranks time.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload config2|config3|config4|config5|config1]
+  python bench.py --workload cluster-many|cluster-big|isoforms      (rows N3 / N4 of SURVEY 8f: their own metrics, 1 GPU)
 
 Prints ONE JSON line (rank 0).  `roofline` is for the interval-scoring kernel: algorithmic bytes
 4*(N+K)*R + 4*R per partition over its mean launch duration, measured with HIP events
@@ -116,6 +117,60 @@ def cpu_baseline_all_cores(parts, n_reads_of, params, tabs, min_s=8.0):
                     passes, len(parts), reads, cores, dt))
 
 
+def cpu_baseline_cluster(uniq, budget_s=12.0):
+    """CPU leg of the row-N3 measurement (tools/cluster_bench.py): the oracle's Python restatement of the pairwise
+    compatibility test + pruning on a bounded sample (the first 300 unique reads of successive tints)."""
+    from oracle import cluster_oracle
+    t0 = time.perf_counter()
+    done = 0
+    for u in uniq:
+        sub = u[:300]
+        cluster_oracle.prune(len(sub), cluster_oracle.compat_edges(sub))
+        done += len(sub) * (len(sub) - 1) // 2
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return dict(value=done / dt, unit="pairs/s", cores=1, kind="port",
+                sample="%d pairs (first 300 unique reads of successive tints), Python oracle, %.1f s" % (done, dt))
+
+
+def cpu_baseline_isoforms(per, n_seg, window, budget_s=10.0):
+    """CPU leg of the row-N4 measurement (tools/isoforms_bench.py): the Python oracle's isoforms_cons + correct_boundaries
+    on synthetic tints of the same shape until the budget is spent."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import isoforms_util as iu
+    from oracle import isoforms_oracle
+    t0 = time.perf_counter()
+    done = k = 0
+    while time.perf_counter() - t0 < budget_s:
+        isos, segments, reads = iu.random_job(100 + k, 8, per, n_seg)
+        isoforms_oracle.isoforms_cons(isos, segments, reads)
+        for side in ("starts", "ends"):
+            isoforms_oracle.correct_boundaries(side, isos, reads, 0.5, window)
+        done += len(reads)
+        k += 1
+    dt = time.perf_counter() - t0
+    return dict(value=done / dt, unit="reads/s", cores=1, kind="port",
+                sample="%d reads in %d synthetic tints (generation included), Python oracle, %.1f s" % (done, k, dt))
+
+
+NEXT_ROW_WORKLOADS = ("cluster-many", "cluster-big", "isoforms")     # SURVEY 8(f) rows N3 / N4: their own metrics
+
+
+def run_next_row(args):
+    """The measurements of rows N3 / N4 live in tools/ (GPU side only); the CPU-baseline legs, which use the oracle,
+    are here."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    if args.workload == "isoforms":
+        import isoforms_bench
+        out = isoforms_bench.run(steps=min(args.steps, 10), cpu_baseline=None if args.no_cpu_baseline else cpu_baseline_isoforms)
+    else:
+        import cluster_bench
+        out = cluster_bench.run(args.workload.split("-")[1], steps=min(args.steps, 10),
+                                cpu_baseline=None if args.no_cpu_baseline else cpu_baseline_cluster)
+    print(json.dumps(out))
+
+
 def measured_traffic(workload):
     """HBM bytes per launch of the scoring kernel from the committed PMC passes (profiles/traffic.json), or None."""
     try:
@@ -130,11 +185,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="config2", choices=sorted(synth.WORKLOADS))
+    ap.add_argument("--workload", default="config2", choices=sorted(synth.WORKLOADS) + list(NEXT_ROW_WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-all-cores", action="store_true",
                     help="also time the CPU oracle on every host core (many-partition workloads; adds cpu_baseline_all_cores)")
     args = ap.parse_args()
+    if args.workload in NEXT_ROW_WORKLOADS:
+        return run_next_row(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -1,0 +1,46 @@
+"""Randomized parity sweep on the GPU: random generator settings x random stage parameters, batches of random size,
+every tap against the CPU oracle, with k_tiny forced on for half of the contexts; inputs on which the reference would
+abort (break_large_problems' assertions) must be refused by the library too."""
+import random
+
+import pytest
+
+import util
+from freddie_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed", [7, 11])
+def test_random_inputs_and_parameters(seed, monkeypatch):
+    rng = random.Random(seed)
+    n_part = 0
+    for rd in range(40):
+        monkeypatch.setenv("FSEG_TINY_FROM", "0" if rd % 2 else "256")
+        ctx = _lib.Context(0)
+        try:
+            params = dict(sigma=rng.choice([2.0, 3.0, 5.0, 8.0]), threshold_rate=rng.choice([0.8, 0.9, 0.95, 1.0]),
+                          variance_factor=rng.choice([1.0, 3.0, 6.0]), max_problem_size=rng.choice([6, 10, 30, 50, 90]),
+                          min_read_support_outside=rng.choice([0, 1, 3, 10]), ignore_ends=rng.random() < 0.7)
+            parts = []
+            for _ in range(rng.choice([1, 1, 3, 8, 20])):
+                gen = dict(n_reads=rng.choice([5, 40, 200, 500, 1200]), n_exons=rng.choice([3, 20, 60, 150]),
+                           rp=rng.choice([0.0, 0.05, 0.2, 0.5]), jp=rng.choice([0.0, 0.3, 0.8]), jsd=rng.choice([1.0, 2.0, 6.0]),
+                           max_span=rng.choice([0, 4, 14]))
+                parts.append(util.make_partition(rng.randrange(1 << 20), **gen))
+            oracles = [util.run_oracle(p, params) for p in parts]
+            if any(o["error"] for o in oracles):
+                # the reference would abort on one of its assertions: the library must refuse the batch, not return labels
+                with pytest.raises(_lib.SegError):
+                    util.run_gpu(ctx, parts, params)
+                    ctx.download()
+                continue
+            util.run_gpu(ctx, parts, params)
+            util.compare_partitions(ctx, parts, oracles)
+            ctx.run(); ctx.sync()                               # the steady-state run (k_tiny, sized arenas, graph replay)
+            rep = util.compare_partitions(ctx, parts, oracles)
+            assert rep["y_identical"]
+            n_part += len(parts)
+        finally:
+            ctx.close()
+    assert n_part > 100

@@ -2,13 +2,15 @@
 """Measurement of row N3 (clustering pre-ILP graph work) on MI355X: pairwise compatibility + pruning of a batch of
 synthetic preprocessed tints through include/freddie_cluster.h.
 
-    python tools/cluster_bench.py [--workload many|big] [--steps K] [--no-cpu-baseline]
+    python bench.py --workload cluster-many|cluster-big [--steps K] [--no-cpu-baseline]     (with the CPU baseline)
+    python tools/cluster_bench.py [--workload many|big] [--steps K]                          (GPU side only)
 
-Prints one JSON line: read pairs tested per second (kernel time from HIP events on the library's stream, inputs
-already packed on the host; the call's host->device copies are outside the event bracket), the roofline figure of
-the compatibility kernel with ALGORITHMIC bytes = 2 label cells (1 B each) per segment of every pair's overlap --
-what the reference's two zip() passes over d1[f:l+1], d2[f:l+1] read once (py/freddie_cluster.py:229,232) -- and the
-CPU oracle (Python restatement, 1 core) timed on a bounded sample of the same tints."""
+One JSON line: read pairs tested per second (kernel time from HIP events on the library's stream, inputs already packed
+on the host; the call's host->device copies are outside the event bracket), the roofline figure of the compatibility
+kernel with ALGORITHMIC bytes = 2 label cells (1 B each) per segment of every pair's overlap -- what the reference's two
+zip() passes over d1[f:l+1], d2[f:l+1] read once (py/freddie_cluster.py:229,232).  The CPU baseline (the oracle's Python
+restatement on a bounded sample of the same tints) is bench.py's leg: this file never touches oracle/.
+"""
 import argparse
 import json
 import os
@@ -28,7 +30,7 @@ WORKLOADS = {"many": dict(n_tints=400, n_reps=500, n_segs=300), "big": dict(n_ti
 
 
 def overlap_cells(packed):
-    """sum over unordered pairs of max(0, min(l) - max(f) + 1), per tint, exactly (sorted sweep would do; sizes are small)."""
+    """sum over unordered pairs of max(0, min(l) - max(f) + 1), per tint, exactly."""
     total = 0
     for t in range(packed["n_tint"]):
         a, b = int(packed["row_off"][t]), int(packed["row_off"][t + 1])
@@ -40,13 +42,10 @@ def overlap_cells(packed):
     return total // 2
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", default="many", choices=sorted(WORKLOADS))
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
-    w = WORKLOADS[args.workload]
+def run(workload="many", steps=5, cpu_baseline=None):
+    """Returns the result dict.  cpu_baseline: a callable(unique structures per tint) -> dict supplied by bench.py (the
+    only place besides the tests that may use the oracle), or None."""
+    w = WORKLOADS[workload]
     tints = [cu.random_tint(1000 + t, w["n_reps"], w["n_segs"], n_isoforms=8) for t in range(w["n_tints"])]
     uniq = [cluster_prep.unique_structures(t) for t in tints]
     packed = cluster_prep.pack_structures(uniq)
@@ -55,38 +54,36 @@ def main():
     ctx = cluster_prep.Context(0)
     ctx.compat_graph(packed)                                     # warm-up
     compat, prune, wall = [], [], []
-    for _ in range(args.steps):
+    for _ in range(steps):
         t0 = time.perf_counter()
         adj, rounds = ctx.compat_graph(packed)
         wall.append(time.perf_counter() - t0)
         tm = ctx.last_timing()
         compat.append(tm["compat_ms"]); prune.append(tm["prune_ms"])
+    ctx.close()
     compat_ms, prune_ms = float(np.mean(compat)), float(np.mean(prune))
     alg_bytes = 2 * cells
     out = {
         "metric": "read pairs tested/sec (compatibility graph + pruning, kernels)", "value": n_pairs / ((compat_ms + prune_ms) * 1e-3),
-        "unit": "pairs/s", "n_gpus": 1, "steps": args.steps, "higher_is_better": True, "dtype": "u32", "data": "synthetic",
-        "config": {"workload": "cluster-" + args.workload, **w, "unique_reads": int(packed["row_off"][-1]),
+        "unit": "pairs/s", "n_gpus": 1, "steps": steps, "higher_is_better": True, "dtype": "u32", "data": "synthetic",
+        "config": {"workload": "cluster-" + workload, **w, "unique_reads": int(packed["row_off"][-1]),
                    "pairs": n_pairs, "prune_passes_max": int(rounds.max())},
         "kernel_ms": {"compat": compat_ms, "prune": prune_ms}, "call_wall_ms": float(np.mean(wall)) * 1e3,
         "roofline": {"kernel": "k_compat", "bound": "hbm", "achieved": alg_bytes / (compat_ms * 1e-3) / 1e9, "peak": 8000.0,
                      "unit": "GB/s", "frac": alg_bytes / (compat_ms * 1e-3) / 1e9 / 8000.0, "traffic": None,
                      "algorithmic_bytes_per_launch": alg_bytes},
     }
-    if not args.no_cpu_baseline:
-        from oracle import cluster_oracle
-        t0 = time.perf_counter(); done = 0
-        for u in uniq:
-            sub = u[:300]                                         # bounded sample: the first 300 unique reads of a tint
-            cluster_oracle.prune(len(sub), cluster_oracle.compat_edges(sub))
-            done += len(sub) * (len(sub) - 1) // 2
-            if time.perf_counter() - t0 > 12:
-                break
-        dt = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": done / dt, "unit": "pairs/s", "cores": 1, "kind": "port",
-                               "sample": "%d pairs (first 300 unique reads of successive tints), Python oracle, %.1f s" % (done, dt)}
-    print(json.dumps(out))
-    ctx.close()
+    if cpu_baseline is not None:
+        out["cpu_baseline"] = cpu_baseline(uniq)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="many", choices=sorted(WORKLOADS))
+    ap.add_argument("--steps", type=int, default=5)
+    args = ap.parse_args()
+    print(json.dumps(run(args.workload, args.steps)))
 
 
 if __name__ == "__main__":

@@ -1,12 +1,15 @@
 #!/usr/bin/env python3
 """Measurement of row N4 (isoform consensus counts + boundary votes) on MI355X through include/freddie_isoforms.h.
 
-    python tools/isoforms_bench.py [--isoforms N] [--reads-per-isoform R] [--segments M] [--steps K] [--no-cpu-baseline]
+    python bench.py --workload isoforms [--steps K] [--no-cpu-baseline]                                (with the CPU baseline)
+    python tools/isoforms_bench.py [--isoforms N] [--reads-per-isoform R] [--segments M] [--steps K]     (GPU side only)
 
 One JSON line: reads processed per second of kernel time (HIP events on the library's stream; the call's host<->device
-copies are outside the bracket and reported as call_wall_ms), the consensus kernels' roofline with ALGORITHMIC bytes =
-one label byte per (read, segment) + two int32 per (isoform, segment) out -- what isoforms_cons() reads and produces
-once (py/freddie_isoforms.py:203-232) -- and the Python oracle (1 core) on a bounded sample of the same input."""
+copies are outside the bracket and reported as call_wall_ms) and the consensus kernel's roofline with ALGORITHMIC bytes =
+one label byte per (read, segment) + two int32 per (isoform, segment) out -- what isoforms_cons() reads and produces once
+(py/freddie_isoforms.py:203-232).  The CPU baseline (the Python oracle on a bounded sample) is bench.py's leg: this file
+never touches oracle/.
+"""
 import argparse
 import json
 import os
@@ -20,16 +23,10 @@ sys.path.insert(0, ROOT)
 from freddie_amd import isoforms  # noqa: E402
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--isoforms", type=int, default=4000)
-    ap.add_argument("--reads-per-isoform", type=int, default=500)
-    ap.add_argument("--segments", type=int, default=150)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    a = ap.parse_args()
+def run(n_iso=4000, per=500, M=150, steps=5, cpu_baseline=None):
+    """Returns the result dict.  cpu_baseline: a callable(reads per isoform, segments, window) -> dict supplied by
+    bench.py (the only place besides the tests that may use the oracle), or None."""
     rng = np.random.default_rng(11)
-    n_iso, per, M = a.isoforms, a.reads_per_isoform, a.segments
     R = n_iso * per
     lab = rng.choice(np.frombuffer(b"0012", np.uint8), size=(R, M), p=[0.3, 0.3, 0.3, 0.1])
     tail = rng.integers(0, 3, R).astype(np.uint8)
@@ -40,7 +37,7 @@ def main():
     ctx = isoforms.Context(0)
     ctx.consensus(iro, np.full(n_iso, M), np.arange(R, dtype=np.int64) * M, lab.reshape(-1), tail)
     cons_ms, votes_ms, wall = [], [], []
-    for _ in range(a.steps):
+    for _ in range(steps):
         t0 = time.perf_counter()
         ctx.kernel_ms = 0.0
         ctx.consensus(iro, np.full(n_iso, M), np.arange(R, dtype=np.int64) * M, lab.reshape(-1), tail)
@@ -49,31 +46,28 @@ def main():
                            rb.reshape(-1), w)
         votes_ms.append(ctx.kernel_ms)
         wall.append(time.perf_counter() - t0)
+    ctx.close()
     c_ms, v_ms = float(np.mean(cons_ms)), float(np.mean(votes_ms))
     alg = R * M + 8 * n_iso * M
     out = {"metric": "reads/sec (isoform consensus counts + boundary votes, kernels)", "value": R / ((c_ms + v_ms) * 1e-3), "unit": "reads/s",
-           "n_gpus": 1, "steps": a.steps, "higher_is_better": True, "dtype": "u8/int32", "data": "synthetic",
+           "n_gpus": 1, "steps": steps, "higher_is_better": True, "dtype": "u8/int32", "data": "synthetic",
            "config": {"workload": "isoforms", "isoforms": n_iso, "reads": R, "segments": M, "window": w},
            "kernel_ms": {"consensus": c_ms, "votes": v_ms}, "call_wall_ms": float(np.mean(wall)) * 1e3,
            "roofline": {"kernel": "k_consensus", "bound": "hbm", "achieved": alg / (c_ms * 1e-3) / 1e9, "peak": 8000.0,
                         "unit": "GB/s", "frac": alg / (c_ms * 1e-3) / 1e9 / 8000.0, "traffic": None, "algorithmic_bytes_per_launch": alg}}
-    if not a.no_cpu_baseline:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import isoforms_util as iu
-        from oracle import isoforms_oracle
-        t0 = time.perf_counter(); done = 0; k = 0
-        while time.perf_counter() - t0 < 10:
-            isos, segments, reads = iu.random_job(100 + k, 8, per, M)
-            t1 = time.perf_counter()
-            isoforms_oracle.isoforms_cons(isos, segments, reads)
-            for side in ("starts", "ends"):
-                isoforms_oracle.correct_boundaries(side, isos, reads, 0.5, w)
-            done += len(reads); k += 1
-        dt = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": done / dt, "unit": "reads/s", "cores": 1, "kind": "port",
-                               "sample": "%d reads in %d synthetic tints (generation included), Python oracle, %.1f s" % (done, k, dt)}
-    print(json.dumps(out))
-    ctx.close()
+    if cpu_baseline is not None:
+        out["cpu_baseline"] = cpu_baseline(per, M, w)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--isoforms", type=int, default=4000)
+    ap.add_argument("--reads-per-isoform", type=int, default=500)
+    ap.add_argument("--segments", type=int, default=150)
+    ap.add_argument("--steps", type=int, default=5)
+    a = ap.parse_args()
+    print(json.dumps(run(a.isoforms, a.reads_per_isoform, a.segments, a.steps)))
 
 
 if __name__ == "__main__":

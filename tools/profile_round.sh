@@ -17,9 +17,9 @@ FSEG_NO_GRAPH=1 FSEG_NO_FORK=1 rocprofv3 --kernel-trace --output-format csv -d $
 python profiles/trace_medians.py $O/trace_config4/p_kernel_trace.csv > $O/config4_kernel_medians.txt
 FSEG_NO_GRAPH=1 rocprofv3 --kernel-trace --output-format csv -d $O/trace_config2 -o p -- python3 bench.py --steps 10 --no-cpu-baseline > /dev/null 2> $O/trace2.err
 python profiles/trace_medians.py $O/trace_config2/p_kernel_trace.csv > $O/config2_kernel_medians.txt
-python tools/cluster_bench.py --workload many > $O/n3_cluster_many_bench.json 2>/dev/null
-python tools/cluster_bench.py --workload big --steps 2 --no-cpu-baseline > $O/n3_cluster_big_bench.json 2>/dev/null
-python tools/isoforms_bench.py > $O/n4_isoforms_bench.json 2>/dev/null
+python bench.py --workload cluster-many > $O/n3_cluster_many_bench.json 2>/dev/null
+python bench.py --workload cluster-big --steps 2 --no-cpu-baseline > $O/n3_cluster_big_bench.json 2>/dev/null
+python bench.py --workload isoforms > $O/n4_isoforms_bench.json 2>/dev/null
 python tools/e2e_bench.py --partitions 2000 --reads 500 --threads 8 --sidecar off --repeat 2 > $O/e2e.log 2>&1
 python tools/e2e_bench.py --partitions 2000 --reads 500 --threads 8 --sidecar write --repeat 3 >> $O/e2e.log 2>&1
 tail -5 $O/e2e.log
