@@ -44,10 +44,13 @@ def test_fails_loudly_without_a_gpu():
 
 
 def test_product_does_not_import_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline legs may use oracle/: nothing in the package, the
+    drop-in scripts or the tools does."""
     root = os.path.dirname(build.INCLUDE)
-    for dirpath, _, files in os.walk(os.path.join(root, "freddie_amd")):
-        for f in files:
-            if f.endswith((".py", ".hip", ".cpp", ".h", ".c")):
-                src = open(os.path.join(dirpath, f), errors="ignore").read()
-                assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), os.path.join(dirpath, f)
-                assert "libfreddie_oracle" not in src
+    for sub in ("freddie_amd", "py", "tools"):
+        for dirpath, _, files in os.walk(os.path.join(root, sub)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".cpp", ".h", ".c", ".sh")):
+                    src = open(os.path.join(dirpath, f), errors="ignore").read()
+                    assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), os.path.join(dirpath, f)
+                    assert "libfreddie_oracle" not in src, os.path.join(dirpath, f)
