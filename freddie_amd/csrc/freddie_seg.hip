@@ -1190,23 +1190,32 @@ __global__ void __launch_bounds__(256) k_prob_emit(Status *st, const int *cand_p
         const i64 i0 = b * kProbBlock + (i64)threadIdx.x * 4;
         const i64 g_cls0 = col_lo(grand.v[4]), g_cls1 = col_hi(grand.v[4]), g_cls2 = col_lo(grand.v[5]);
         const i64 g_dp0 = col_hi(grand.v[0]), g_dp1 = col_hi(grand.v[5]);
+        // what a problem's records need, for this thread's four candidates, in three rounds of loads instead of one
+        // chain per candidate (a load under `if (problem)` is a branch with its own wait): candidate -> interval -> partition
+        int pn4[4], iv4[4], ll4[4], ln4[4], is4[4], part4[4], lanes4[4];
+        i64 co4[4];
+        for (int e = 0; e < 4; ++e) {
+            const i64 cc = i0 + e < n ? i0 + e : n - 1;
+            pn4[e] = cand_pn[cc]; iv4[e] = cand_iv[cc]; ll4[e] = cand_ll[cc]; ln4[e] = cand_ln[cc];
+        }
+        for (int e = 0; e < 4; ++e) { co4[e] = cand_off[iv4[e]]; is4[e] = iv_start[iv4[e]]; part4[e] = iv_part[iv4[e]]; }
+        for (int e = 0; e < 4; ++e) lanes4[e] = (int)(part_lane_off[part4[e] + 1] - part_lane_off[part4[e]]);
         for (int e = 0; e < 4; ++e) {
             if (sz[e].v[0]) {
                 i64 c = i0 + e;
                 i64 slot = col_lo(ex.v[0]);
-                int nn = cand_pn[c];
+                int nn = pn4[e];
                 if (slot < prob_cap) {
-                    int k = cand_iv[c];
-                    pr.iv[slot] = k; pr.start[slot] = (int)(c - cand_off[k]) - (nn - 1); pr.n[slot] = nn;
+                    int k = iv4[e];
+                    pr.iv[slot] = k; pr.start[slot] = (int)(c - co4[e]) - (nn - 1); pr.n[slot] = nn;
                     pr.pair_off[slot] = ex.v[1]; pr.tri_off[slot] = ex.v[2]; pr.cov_off[slot] = ex.v[3];
                     pr.flags[slot] = 0; pr.chain[slot] = 0;
-                    pr.lane_lo[slot] = cand_ll[c]; pr.lane_n[slot] = cand_ln[c];
+                    pr.lane_lo[slot] = ll4[e]; pr.lane_n[slot] = ln4[e];
                     {
                         ProbDesc d;
                         d.c0 = c - (nn - 1); d.pair_off = ex.v[1]; d.tri_off = ex.v[2]; d.cov_off = ex.v[3];
-                        d.n = nn; d.lane_lo = cand_ll[c]; d.lane_n = cand_ln[c]; d.g0 = iv_start[k];
-                        const int part = iv_part[k];
-                        d.outside = (int)(part_lane_off[part + 1] - part_lane_off[part]) - d.lane_n;
+                        d.n = nn; d.lane_lo = ll4[e]; d.lane_n = ln4[e]; d.g0 = is4[e];
+                        d.outside = lanes4[e] - d.lane_n;
                         d.iv = k; d.w0 = (int)(col_lo(ex.v[4]) + col_hi(ex.v[4]) + col_lo(ex.v[5]) + col_lo(ex.v[6])); d.pad1 = 0;
                         desc[slot] = d;
                     }
