@@ -1268,12 +1268,12 @@ __device__ __forceinline__ void pair_decode(int q, int *i, int *j) {
 }
 
 // S5a  integer label thresholds of every candidate pair of every problem (:490-495)
-__global__ void __launch_bounds__(256) k_pair_thresholds(const Status *st, ProblemArrays pr, const ProbDesc *desc, i64 prob_cap,
-                                                         const i64 *cand_off, const int *cand_y, const double *h_table,
-                                                         int h_len, double tau, int2 *pair_thr, i64 pair_cap,
-                                                         unsigned *amb_g, unsigned *out_g, i64 tri_cap, int tiny_max) {
+__device__ __forceinline__ void pair_thresholds_blocks(i64 first, i64 stride, const Status *st, ProblemArrays pr, const ProbDesc *desc,
+                                                       i64 prob_cap, const int *cand_y, const double *h_table, int h_len, double tau,
+                                                       int2 *pair_thr, i64 pair_cap, unsigned *amb_g, unsigned *out_g, i64 tri_cap,
+                                                       int tiny_max) {
     i64 n_prob = (i64)st->n_prob < prob_cap ? (i64)st->n_prob : prob_cap;
-    for (i64 p = blockIdx.x; p < n_prob; p += gridDim.x) {
+    for (i64 p = first; p < n_prob; p += stride) {
         const ProbDesc d = load_desc(desc + p);
         int n = d.n;
         if (n <= tiny_max) continue;                        // solved by k_tiny: owns nothing in the arenas
@@ -1298,6 +1298,13 @@ __global__ void __launch_bounds__(256) k_pair_thresholds(const Status *st, Probl
         if (any_neg) atomicOr(&pr.flags[p], 1);
     }
 }
+__global__ void __launch_bounds__(256) k_pair_thresholds(const Status *st, ProblemArrays pr, const ProbDesc *desc, i64 prob_cap,
+                                                         const i64 *cand_off, const int *cand_y, const double *h_table,
+                                                         int h_len, double tau, int2 *pair_thr, i64 pair_cap,
+                                                         unsigned *amb_g, unsigned *out_g, i64 tri_cap, int tiny_max) {
+    pair_thresholds_blocks(blockIdx.x, gridDim.x, st, pr, desc, prob_cap, cand_y, h_table, h_len, tau, pair_thr, pair_cap, amb_g, out_g,
+                           tri_cap, tiny_max);
+}
 
 
 // ---------------------------------------------------------------------------------------------
@@ -1312,13 +1319,24 @@ __global__ void __launch_bounds__(kLaneChunk) k_cov(Status *st, const ProbDesc *
                                                     i64 work_cap, const i64 *cand_off,
                                                     const int *cand_y, const int *iv_start, const longlong2 *lane_ex,
                                                     const int *ex_ts, const int *ex_te,
-                                                    unsigned *cov_g, i64 cov_cap, unsigned char *work_active) {
+                                                    unsigned *cov_g, i64 cov_cap, unsigned char *work_active,
+                                                    int cov_blocks, ProblemArrays pr, const double *h_table, int h_len, double tau,
+                                                    int2 *pair_thr, i64 pair_cap, unsigned *amb_g, unsigned *out_g, i64 tri_cap,
+                                                    int tiny_max) {
+    // One-partition batches are chains of launch-latency-sized kernels: there the pair thresholds (which, like the
+    // coverage, need only the problem list) ride along as the workgroups behind the coverage ones -- one graph node less,
+    // and the two overlap (cov_blocks == gridDim.x: no such workgroups, k_pair_thresholds was launched on its own).
+    if ((int)blockIdx.x >= cov_blocks) {
+        pair_thresholds_blocks(blockIdx.x - cov_blocks, gridDim.x - cov_blocks, st, pr, desc, prob_cap, cand_y, h_table, h_len, tau,
+                               pair_thr, pair_cap, amb_g, out_g, tri_cap, tiny_max);
+        return;
+    }
     __shared__ int cp[kNHuge + 4];
     __shared__ u64 work_s;
     __shared__ unsigned active_s;
     i64 n_work = (i64)st->n_work;
     if (n_work > work_cap || (i64)st->n_prob > prob_cap) return;   // lists incomplete: this run only sizes the arenas
-    for (i64 w = blockIdx.x; w < n_work; w += gridDim.x) {      // static stride: a shared work counter saturates near 90 pops/us
+    for (i64 w = blockIdx.x; w < n_work; w += cov_blocks) {     // static stride: a shared work counter saturates near 90 pops/us
         __syncthreads();
         if (threadIdx.x == 0) active_s = 0;
         __syncthreads();
@@ -2992,16 +3010,21 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
     mark(5);
     // S5
     if (c->prob_cap > 0) {
-        hipLaunchKernelGGL(k_pair_thresholds, dim3(grid_for(c->prob_cap, 1, 2048)), dim3(256), 0, s, st, pr,
-                           c->d_prob_desc.as<ProbDesc>(), c->prob_cap, c->d_cand_off.as<i64>(), c->d_cand_y.as<int>(),
-                           c->d_h_table.as<double>(), c->P.h_len,
-                           c->P.threshold_rate, c->d_pair_thr.as<int2>(), c->pair_cap, c->d_amb.as<unsigned>(),
-                           c->d_out.as<unsigned>(), c->tri_cap, tiny_max);
-        hipLaunchKernelGGL(k_cov, dim3(work_grid < 2048 ? work_grid : 2048), dim3(kLaneChunk), 0, s, st,
+        const int cov_blocks = work_grid < 2048 ? work_grid : 2048;
+        const int pt_blocks = c->small_batch ? grid_for(c->prob_cap, 1, 512) : 0;       // fused only for small batches
+        if (!pt_blocks)
+            hipLaunchKernelGGL(k_pair_thresholds, dim3(grid_for(c->prob_cap, 1, 2048)), dim3(256), 0, s, st, pr,
+                               c->d_prob_desc.as<ProbDesc>(), c->prob_cap, c->d_cand_off.as<i64>(), c->d_cand_y.as<int>(),
+                               c->d_h_table.as<double>(), c->P.h_len,
+                               c->P.threshold_rate, c->d_pair_thr.as<int2>(), c->pair_cap, c->d_amb.as<unsigned>(),
+                               c->d_out.as<unsigned>(), c->tri_cap, tiny_max);
+        hipLaunchKernelGGL(k_cov, dim3(cov_blocks + pt_blocks), dim3(kLaneChunk), 0, s, st,
                            c->d_prob_desc.as<ProbDesc>(), c->prob_cap, c->d_work_pc.as<int2>(), c->work_cap, c->d_cand_off.as<i64>(),
                            c->d_cand_y.as<int>(), c->d_iv_start.as<int>(), c->d_lane_ex.as<longlong2>(),
                            c->d_ex_ts.as<int>(), c->d_ex_te.as<int>(),
-                           c->d_cov.as<unsigned>(), c->cov_cap, c->d_work_active.as<unsigned char>());
+                           c->d_cov.as<unsigned>(), c->cov_cap, c->d_work_active.as<unsigned char>(),
+                           cov_blocks, pr, c->d_h_table.as<double>(), c->P.h_len, c->P.threshold_rate, c->d_pair_thr.as<int2>(),
+                           c->pair_cap, c->d_amb.as<unsigned>(), c->d_out.as<unsigned>(), c->tri_cap, tiny_max);
     }
     mark(6);
     }   // do_pre
