@@ -42,13 +42,14 @@ class _Sizes(ctypes.Structure):
                 ("n_problems", ctypes.c_int64), ("n_positions", ctypes.c_int64)]
 
 
-EXPORTS = ["fseg_abi_version", "fseg_create", "fseg_destroy", "fseg_last_error", "fseg_set_params", "fseg_upload",
+EXPORTS = ["fseg_abi_version", "fseg_source_hash", "fseg_results", "fseg_create", "fseg_destroy", "fseg_last_error", "fseg_set_params", "fseg_upload",
            "fseg_run", "fseg_sync", "fseg_get_sizes", "fseg_download", "fseg_tap", "fseg_set_profiling",
            "fseg_n_stages", "fseg_stage_name", "fseg_stage_ms", "fseg_scoring_algorithmic_bytes"]
 
 TAPS = dict(pos_off=(1, np.int64), y_raw=(2, np.int32), y=(3, np.float64), threshold=(4, np.float64),
             cand_off=(5, np.int64), cand_y=(6, np.int32), fixed=(7, np.uint8), chosen=(8, np.uint8),
-            final_off=(9, np.int64), final_y=(10, np.int32), problems=(11, np.int32))
+            final_off=(9, np.int64), final_y=(10, np.int32), problems=(11, np.int32),
+            lane_start=(12, np.int32), lane_pmax=(13, np.int32), lane_exons=(14, np.int64))
 
 
 def lib_path():
@@ -84,6 +85,9 @@ def load():
     L.fseg_get_sizes.argtypes = [vp, ctypes.POINTER(_Sizes)]
     L.fseg_download.restype = ctypes.c_int
     L.fseg_download.argtypes = [vp, vp, vp, vp, vp]
+    L.fseg_results.restype = ctypes.c_int
+    L.fseg_results.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp)]
+    L.fseg_source_hash.restype = ctypes.c_char_p
     L.fseg_tap.restype = ctypes.c_int
     L.fseg_tap.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]
     L.fseg_set_profiling.restype = ctypes.c_int
@@ -95,7 +99,7 @@ def load():
     L.fseg_stage_ms.argtypes = [vp, vp]
     L.fseg_scoring_algorithmic_bytes.restype = ctypes.c_int64
     L.fseg_scoring_algorithmic_bytes.argtypes = [vp]
-    if L.fseg_abi_version() != 1:
+    if L.fseg_abi_version() != 2:
         raise SegError("libfreddie_seg.so ABI version mismatch")
     _lib = L
     return L
@@ -175,6 +179,21 @@ class Context:
                                           lb.ctypes.data if labels and lb.size else None), "fseg_download")
         return pfo, fp, lo, lb
 
+    def results(self):
+        """Like download(), without the copy: numpy views of the context's pinned result buffers, valid until the next
+        run / upload / results() on this context (what the pipelined CLI hands to the native writer)."""
+        p = [ctypes.c_void_p() for _ in range(4)]
+        self._check(self._L.fseg_results(self._h, *[ctypes.byref(x) for x in p]), "fseg_results")
+        sz = self.sizes()
+
+        def view(ptr, n, dtype):
+            if n == 0 or not ptr.value:
+                return np.empty(0, dtype)
+            buf = (ctypes.c_char * (int(n) * np.dtype(dtype).itemsize)).from_address(ptr.value)
+            return np.frombuffer(buf, dtype=dtype)
+        return (view(p[0], self.n_part + 1, np.int64), view(p[1], sz["n_final"], np.int32),
+                view(p[2], self.n_part + 1, np.int64), view(p[3], sz["label_bytes"], np.uint8))
+
     def tap(self, name):
         what, dtype = TAPS[name]
         n = ctypes.c_int64()
@@ -182,7 +201,7 @@ class Context:
         out = np.empty(n.value // np.dtype(dtype).itemsize, dtype)
         if n.value:
             self._check(self._L.fseg_tap(self._h, what, out.ctypes.data, n.value, ctypes.byref(n)), "fseg_tap")
-        return out.reshape(-1, 4) if name == "problems" else out
+        return out.reshape(-1, 4) if name == "problems" else (out.reshape(-1, 2) if name == "lane_exons" else out)
 
     def set_profiling(self, on):
         self._check(self._L.fseg_set_profiling(self._h, 1 if on else 0), "fseg_set_profiling")

@@ -163,13 +163,8 @@ class _Batch(ctypes.Structure):
 
 def build(force=False, verbose=False):
     """hipcc -> libfreddie_cluster.so (in-tree; cross-compiles without a GPU)."""
-    import subprocess
-    deps = CLUSTER_SRC + [os.path.join(_build.INCLUDE, "freddie_cluster.h")]
-    if force or _build._stale(CLUSTER_SO, deps):
-        cmd = ["hipcc", "-O3", "--offload-arch=gfx950", "-shared", "-fPIC", "-I", _build.INCLUDE, "-o", CLUSTER_SO] + CLUSTER_SRC
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
+    cmd = ["hipcc", "-O3", "--offload-arch=gfx950", "-shared", "-fPIC", "-I", _build.INCLUDE, "-o", CLUSTER_SO] + CLUSTER_SRC
+    _build.build_stamped(CLUSTER_SO, cmd, CLUSTER_SRC + [os.path.join(_build.INCLUDE, "freddie_cluster.h")], force, verbose)
     return CLUSTER_SO
 
 

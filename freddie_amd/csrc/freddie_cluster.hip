@@ -355,3 +355,8 @@ int fclu_last_timing(fclu_ctx *c, float *compat_ms, float *prune_ms) {
 }
 
 }  // extern "C"
+
+#ifdef FREDDIE_SOURCE_HASH
+/* what this binary was built from (freddie_amd/build.py looks for the marker in the file) */
+static const char freddie_source_stamp[] __attribute__((used)) = "FREDDIE_SRC_HASH=" FREDDIE_SOURCE_HASH;
+#endif

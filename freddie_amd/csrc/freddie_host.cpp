@@ -11,6 +11,7 @@
 #include <atomic>
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <sys/stat.h>
 #include <mutex>
 #include <string>
@@ -364,7 +365,7 @@ void annotate_read(const Partition &P, const Read &r, const unsigned char *data,
 // the read_reps grouping and the sequences packed two bits per base (bytes other than upper-case ACGT are kept in
 // an exception list, so the round trip is exact).  It is bound to its TSVs by their sizes and mtimes and is only an
 // accelerator: the TSVs stay the stage's contract (py/freddie_split.py:445-481 writes them, :121-185 reads them).
-const char FSC_MAGIC[8] = {'F', 'S', 'C', '1', 0, 0, 0, 0};
+const char FSC_MAGIC[8] = {'F', 'S', 'C', '2', 0, 0, 0, 0};
 
 struct FscHeader {
     char magic[8];
@@ -382,12 +383,17 @@ bool stat_file(const char *path, uint64_t &size, int64_t &mtime_ns) {
     return true;
 }
 
-uint64_t fsc_checksum(const unsigned char *p, size_t n) {       // FNV-1a over 8-byte words (payload is 8-aligned)
-    uint64_t h = 1469598103934665603ull;
+uint64_t fsc_checksum(const unsigned char *p, size_t n, uint64_t h = 1469598103934665603ull) {   // FNV-1a over 8-byte words (sections are 8-aligned)
     size_t w = n / 8;
     for (size_t i = 0; i < w; ++i) { uint64_t v; memcpy(&v, p + i * 8, 8); h = (h ^ v) * 1099511628211ull; }
     for (size_t i = w * 8; i < n; ++i) h = (h ^ p[i]) * 1099511628211ull;
     return h;
+}
+
+// the header's counts steer the loader, so the checksum covers the header (with its checksum field zeroed) and the payload
+uint64_t fsc_total_checksum(FscHeader h, const unsigned char *payload, size_t n) {
+    h.checksum = 0;
+    return fsc_checksum(payload, n, fsc_checksum(reinterpret_cast<const unsigned char *>(&h), sizeof h));
 }
 
 struct Sink {
@@ -401,16 +407,26 @@ struct Source {
     const unsigned char *p, *end;
     bool ok = true;
     // a section that is only read while loading: a pointer into the file image instead of a copy (sections are 8-aligned)
+    // n comes from the (untrusted) header: a count whose byte size does not fit what is left of the payload --
+    // including one that would wrap around -- fails the load instead of reaching a resize() or a pointer bump
+    template <typename T> bool fits(size_t n, size_t &padded) const {
+        const size_t left = (size_t)(end - p);
+        if (n > left / sizeof(T)) return false;
+        const size_t bytes = n * sizeof(T);
+        padded = bytes + (8 - bytes % 8) % 8;
+        return padded <= left;
+    }
     template <typename T> const T *view(size_t n) {
-        size_t bytes = n * sizeof(T), padded = bytes + (8 - bytes % 8) % 8;
-        if (!ok || (size_t)(end - p) < padded) { ok = false; return nullptr; }
+        size_t padded = 0;
+        if (!ok || !fits<T>(n, padded)) { ok = false; return nullptr; }
         const T *r = reinterpret_cast<const T *>(p);
         p += padded;
         return r;
     }
     template <typename T> void get(std::vector<T> &v, size_t n) {
-        size_t bytes = n * sizeof(T), padded = bytes + (8 - bytes % 8) % 8;
-        if (!ok || (size_t)(end - p) < padded) { ok = false; return; }
+        size_t padded = 0;
+        if (!ok || !fits<T>(n, padded)) { ok = false; return; }
+        const size_t bytes = n * sizeof(T);
         v.resize(n);
         if (bytes) memcpy(v.data(), p, bytes);
         p += padded;
@@ -473,7 +489,7 @@ bool write_sidecar(const Partition &P, const char *split_path, const char *reads
     s.put(seq_off.data(), n + 1); s.put(packed.data(), packed.size());
     s.put(exc_pos.data(), exc_pos.size()); s.put(exc_ch.data(), exc_ch.size());
     h.payload_bytes = s.buf.size();
-    h.checksum = fsc_checksum(reinterpret_cast<const unsigned char *>(s.buf.data()), s.buf.size());
+    h.checksum = fsc_total_checksum(h, reinterpret_cast<const unsigned char *>(s.buf.data()), s.buf.size());
     std::string tmp = std::string(out_path) + ".tmp";
     FILE *f = fopen(tmp.c_str(), "wb");
     bool ok = f && fwrite(&h, sizeof h, 1, f) == 1 && fwrite(s.buf.data(), 1, s.buf.size(), f) == s.buf.size();
@@ -497,7 +513,7 @@ bool load_sidecar(const char *sidecar_path, const char *split_path, const char *
     if (!stat_file(split_path, sz, mt) || sz != h.split_size || mt != h.split_mtime_ns) return false;
     if (!stat_file(reads_path, sz, mt) || sz != h.reads_size || mt != h.reads_mtime_ns) return false;
     const unsigned char *pay = reinterpret_cast<const unsigned char *>(blob.data()) + sizeof h;
-    if (verify && fsc_checksum(pay, (size_t)h.payload_bytes) != h.checksum) return false;
+    if (verify && fsc_total_checksum(h, pay, (size_t)h.payload_bytes) != h.checksum) return false;
     const size_t n = (size_t)h.n_reads;
     if (h.n_reads > (1ull << 31) || h.n_exons > (1ull << 31) || h.n_cigar > (1ull << 31) || h.n_reps > h.n_reads ||
         (int64_t)h.n_reads != h.read_count) return false;
@@ -558,6 +574,13 @@ bool load_sidecar(const char *sidecar_path, const char *split_path, const char *
     return true;
 }
 
+// nothing may leave an extern "C" entry point (or a worker thread) as a C++ exception
+void parse_guarded(const char *split_path, const char *reads_path, Partition &P) {
+    try { parse_partition(split_path, reads_path, P); }
+    catch (const std::exception &e) { P.err = std::string(split_path) + ": " + e.what(); }
+    catch (...) { P.err = std::string(split_path) + ": internal error while parsing"; }
+}
+
 template <typename F>
 void parallel_for(int n, int n_threads, F fn) {
     if (n_threads < 1) n_threads = 1;
@@ -607,7 +630,7 @@ fhost_batch *fhost_load(const char *const *split_paths, const char *const *reads
     if (!b) return nullptr;
     if (n <= 0) { b->err = "fhost_load: empty batch"; return b; }
     b->parts.resize((size_t)n);
-    parallel_for(n, n_threads, [&](int i) { parse_partition(split_paths[i], reads_paths[i], b->parts[(size_t)i]); });
+    parallel_for(n, n_threads, [&](int i) { parse_guarded(split_paths[i], reads_paths[i], b->parts[(size_t)i]); });
     for (const Partition &P : b->parts) if (!P.err.empty()) { b->err = P.err; return b; }
     flatten(b);
     return b;
@@ -622,12 +645,13 @@ fhost_batch *fhost_load_sidecar(const char *const *split_paths, const char *cons
     std::atomic<int> hits(0);
     parallel_for(n, n_threads, [&](int i) {
         Partition &P = b->parts[(size_t)i];
-        if (sidecar_paths && sidecar_paths[i] && load_sidecar(sidecar_paths[i], split_paths[i], reads_paths[i], P, verify_checksum != 0)) {
-            hits.fetch_add(1);
-            return;
-        }
+        bool hit = false;
+        try {        // a damaged side-car must never be worse than a missing one: whatever it throws, the TSVs are parsed instead
+            hit = sidecar_paths && sidecar_paths[i] && load_sidecar(sidecar_paths[i], split_paths[i], reads_paths[i], P, verify_checksum != 0);
+        } catch (...) { hit = false; }
+        if (hit) { hits.fetch_add(1); return; }
         P = Partition();
-        parse_partition(split_paths[i], reads_paths[i], P);
+        parse_guarded(split_paths[i], reads_paths[i], P);
     });
     b->n_from_sidecar = hits.load();
     for (const Partition &P : b->parts) if (!P.err.empty()) { b->err = P.err; return b; }
@@ -643,7 +667,10 @@ int32_t fhost_sidecar_write(fhost_batch *b, const char *const *split_paths, cons
     std::mutex err_mutex;
     parallel_for((int)b->parts.size(), n_threads, [&](int p) {
         std::string err;
-        if (!write_sidecar(b->parts[(size_t)p], split_paths[p], reads_paths[p], sidecar_paths[p], err)) {
+        bool ok = false;
+        try { ok = write_sidecar(b->parts[(size_t)p], split_paths[p], reads_paths[p], sidecar_paths[p], err); }
+        catch (const std::exception &e) { err = std::string(sidecar_paths[p]) + ": " + e.what(); }
+        if (!ok) {
             std::lock_guard<std::mutex> lock(err_mutex);
             if (b->err.empty()) b->err = err;
         }
@@ -697,6 +724,10 @@ int32_t fhost_write(fhost_batch *b, const int64_t *part_final_off, const int32_t
             std::lock_guard<std::mutex> lock(err_mutex);
             if (b->err.empty()) b->err = std::string(out_paths[p]) + ": " + f.what + " (reference: py/freddie_segment.py)";
             return;
+        } catch (const std::exception &e) {
+            std::lock_guard<std::mutex> lock(err_mutex);
+            if (b->err.empty()) b->err = std::string(out_paths[p]) + ": " + e.what();
+            return;
         }
         FILE *fo = fopen(out_paths[p], "wb");
         if (!fo || fwrite(out.data(), 1, out.size(), fo) != out.size()) {
@@ -709,3 +740,8 @@ int32_t fhost_write(fhost_batch *b, const int64_t *part_final_off, const int32_t
 }
 
 }  // extern "C"
+
+#ifdef FREDDIE_SOURCE_HASH
+/* what this binary was built from (freddie_amd/build.py looks for the marker in the file) */
+static const char freddie_source_stamp[] __attribute__((used)) = "FREDDIE_SRC_HASH=" FREDDIE_SOURCE_HASH;
+#endif

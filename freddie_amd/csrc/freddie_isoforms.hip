@@ -323,3 +323,8 @@ int fiso_last_kernel_ms(fiso_ctx *c, float *ms) {
 }
 
 }  // extern "C"
+
+#ifdef FREDDIE_SOURCE_HASH
+/* what this binary was built from (freddie_amd/build.py looks for the marker in the file) */
+static const char freddie_source_stamp[] __attribute__((used)) = "FREDDIE_SRC_HASH=" FREDDIE_SOURCE_HASH;
+#endif

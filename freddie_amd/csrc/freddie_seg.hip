@@ -77,7 +77,7 @@ struct Status {
     u64 label_bytes;
     u64 cov_used;      // elements of the coverage arena
     unsigned max_n;    // largest DP problem of this run
-    unsigned pad2;
+    unsigned max_ln;   // most reads any DP problem of this run examines (>= 65536: the DP needs 32-bit counts)
     u64 cls_work[4];   // work items per problem-size class (n <= 16, <= 32, <= kNMax, <= kNHuge)
     u64 cls_queue[3];  // dynamic work counters of the scoring kernels
     u64 dp_cls[3];     // DP problems with n <= kDpSmall / <= kNMax / larger
@@ -493,7 +493,9 @@ __global__ void __launch_bounds__(256) k_scan_emit(const unsigned char *flags, i
                                                    u64 *state, u64 *total_out, i64 *off_last /* may be null */,
                                                    unsigned *err, const double *y,
                                                    double *v, i64 K, const i64 *pos_off, const int *iv_start,
-                                                   const int *blk_iv0, int *out_y, int *out_pos, i64 *out_off) {
+                                                   const int *blk_iv0, int *out_y, int *out_pos, i64 *out_off,
+                                                   int force_stall /* tests: report a look-back stall */) {
+    if (force_stall && !bsum && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(err, kErrScanStall);
     // A block is 4 waves x 2048 consecutive positions.  Each wave first counts its flags (16-byte loads), the wave
     // offsets come from LDS, then the wave walks its positions in rows of 64: ballot -> rank, so the loads of y and
     // the stores of the compacted output are coalesced.
@@ -1109,14 +1111,35 @@ __device__ __forceinline__ void prob_store_totals(Status *st, const ProbSizes &t
     st->cls_work[3] = (u64)col_lo(t.v[6]);
     st->dp_cls[0] = (u64)col_hi(t.v[0]); st->dp_cls[1] = (u64)col_hi(t.v[5]); st->dp_cls[2] = (u64)col_hi(t.v[6]);
 }
-__global__ void __launch_bounds__(256) k_prob_scan1(const Status *st, const int *cand_pn, const int *cand_ln, i64 *bs, int tiny_max) {
+// Largest problem (candidates) and widest problem (reads examined) of the run: they size the big-problem kernels' LDS
+// and pick the DP's count width.  One atomic per block of 1024 candidates -- per-problem atomics on the one address
+// serialise (~90 per us).  l_mx: 8 ints of LDS; the caller's next barrier orders them.
+__device__ __forceinline__ void prob_block_maxima(Status *st, const int *cand_pn, const int *cand_ln, i64 b, i64 n, int *l_mx) {
+    int mx = 0, ml = 0;
+    for (int e = 0; e < 4; ++e) {
+        const i64 cc = b * kProbBlock + (i64)threadIdx.x * 4 + e;
+        if (cc < n) { const int pn = cand_pn[cc]; mx = max(mx, pn); if (pn > 0) ml = max(ml, cand_ln[cc]); }
+    }
+    for (int d = 32; d >= 1; d >>= 1) { mx = max(mx, __shfl_xor(mx, d)); ml = max(ml, __shfl_xor(ml, d)); }
+    if (lane_id() == 0) { l_mx[threadIdx.x >> 6] = mx; l_mx[4 + (threadIdx.x >> 6)] = ml; }
+}
+__device__ __forceinline__ void prob_publish_maxima(Status *st, const int *l_mx) {
+    const int mx = max(max(l_mx[0], l_mx[1]), max(l_mx[2], l_mx[3])), ml = max(max(l_mx[4], l_mx[5]), max(l_mx[6], l_mx[7]));
+    if (mx > 0 && (unsigned)mx > __hip_atomic_load(&st->max_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&st->max_n, (unsigned)mx);
+    if (ml > 0 && (unsigned)ml > __hip_atomic_load(&st->max_ln, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&st->max_ln, (unsigned)ml);
+}
+__global__ void __launch_bounds__(256) k_prob_scan1(Status *st, const int *cand_pn, const int *cand_ln, i64 *bs, int tiny_max) {
     __shared__ i64 lds[4 * kProbCols];
+    __shared__ int l_mx[8];
     i64 n = (i64)st->n_cand;
     i64 nb = (n + kProbBlock - 1) / kProbBlock;
     for (i64 b = blockIdx.x; b < nb; b += gridDim.x) {
         ProbSizes acc = prob_block_sizes(cand_pn, cand_ln, b, n, nullptr, tiny_max), ex, tot;
+        prob_block_maxima(st, cand_pn, cand_ln, b, n, l_mx);
         wg_scan_cols(acc, ex, tot, lds);
         if (threadIdx.x < kProbCols) bs[b * kProbCols + threadIdx.x] = tot.v[threadIdx.x];
+        if (threadIdx.x == 0) prob_publish_maxima(st, l_mx);
+        __syncthreads();
     }
 }
 __global__ void __launch_bounds__(256) k_prob_scan2(Status *st, i64 *bs) {
@@ -1148,7 +1171,7 @@ __global__ void __launch_bounds__(256) k_prob_emit(Status *st, const int *cand_p
                                                    const int *iv_part, const i64 *part_lane_off, int tiny_max) {
     __shared__ i64 lds[4 * kProbCols];
     __shared__ int l_slot[kProbBlock], l_cnt[kProbBlock];
-    __shared__ int l_mx[4];
+    __shared__ int l_mx[8];
     __shared__ i64 l_w0[kProbBlock], l_c0[kProbBlock];
     __shared__ int l_n;
     i64 n = (i64)st->n_cand;
@@ -1170,18 +1193,9 @@ __global__ void __launch_bounds__(256) k_prob_emit(Status *st, const int *cand_p
             }
         }
         ProbSizes acc = prob_block_sizes(cand_pn, cand_ln, b, n, sz, tiny_max);
-        {   // largest problem of the run (sizes the big-problem kernels' LDS next time): one atomic per block of 1024
-            // candidates -- per-problem atomics on the one address serialise (~90 per us)
-            int mx = 0;
-            for (int e = 0; e < 4; ++e) { const i64 cc = b * kProbBlock + (i64)threadIdx.x * 4 + e; if (cc < n) mx = max(mx, cand_pn[cc]); }
-            for (int d = 32; d >= 1; d >>= 1) mx = max(mx, __shfl_xor(mx, d));
-            if (lane_id() == 0) l_mx[threadIdx.x >> 6] = mx;          // read after the barriers of the column scan below
-        }
+        if (!bs) prob_block_maxima(st, cand_pn, cand_ln, b, n, l_mx);   // (with block sums, k_prob_scan1 has done it; read after the barriers below)
         wg_scan_cols(acc, ex, tot, lds);
-        if (threadIdx.x == 0) {
-            const int mx = max(max(l_mx[0], l_mx[1]), max(l_mx[2], l_mx[3]));
-            if (mx > 0 && (unsigned)mx > __hip_atomic_load(&st->max_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&st->max_n, (unsigned)mx);
-        }
+        if (!bs && threadIdx.x == 0) prob_publish_maxima(st, l_mx);
         for (int q = 0; q < kProbCols; ++q) ex.v[q] += before.v[q];
         if (!bs) {
             for (int q = 0; q < kProbCols; ++q) grand.v[q] += tot.v[q];
@@ -2702,30 +2716,188 @@ __global__ void __launch_bounds__(256) k_label_reads(int n_blocks, const int *rb
 }
 
 // ---------------------------------------------------------------------------------------------
+// upload-time preparation, once per batch, on the device (the inputs arrive in one copy; what used to be a host pass
+// over every exon and a host sort now runs behind that copy on the context's stream)
+//   k_prep_reps   the per-read assertions of read_split() (py/freddie_segment.py:158-161) and of process_splicing_data
+//                 (:666-668: both ends of an exon are positions of one tint interval), and the sort key of every rep
+//   (radix sort)  reps of a partition by first position (freddie_seg_sort.hip)
+//   k_lanes       the lane list: every rep repeated rep_weight times, with the running maximum of the last position
+//   k_hist_ranges the lanes that can reach each histogram chunk
+// ---------------------------------------------------------------------------------------------
+enum : unsigned { kPrepExonEnds = 1u, kPrepExonOrder = 2u, kPrepExonInterval = 4u, kPrepNoExons = 8u };
+struct PrepStatus {
+    unsigned err;
+    unsigned pad;
+    i64 bad_rep[4];    // smallest rep with error bit q
+};
+
+__global__ void __launch_bounds__(256) k_prep_reps(int n_blocks, const int *rb_part, const int *rb_r0, const i64 *part_rep_off,
+                                                   const i64 *part_iv_off, const int *iv_start, const int *iv_end,
+                                                   const i64 *rep_exon_off, const int *ex_ts, const int *ex_te, u64 *key,
+                                                   int *val, int *rep_last, PrepStatus *ps) {
+    for (int blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+        const int p = rb_part[blk];
+        const i64 r = (i64)rb_r0[blk] + threadIdx.x;
+        if (r >= part_rep_off[p + 1]) continue;
+        const i64 e0 = rep_exon_off[r], e1 = rep_exon_off[r + 1];
+        unsigned bad = 0;
+        int first = 0, last = 0;
+        if (e1 <= e0) bad = kPrepNoExons;
+        else {
+            const i64 k0 = part_iv_off[p], k1 = part_iv_off[p + 1];
+            first = ex_ts[e0]; last = ex_te[e1 - 1];
+            i64 kk = k0;
+            {   // first interval that ends at or after the read's first position; exons and intervals are both ordered
+                i64 lo = k0, hi = k1;
+                while (lo < hi) { const i64 mid = (lo + hi) >> 1; if (iv_end[mid] < first) lo = mid + 1; else hi = mid; }
+                kk = lo;
+            }
+            int prev_te = 0;
+            for (i64 e = e0; e < e1; ++e) {
+                const int ts = ex_ts[e], te = ex_te[e];
+                if (!(ts < te)) bad |= kPrepExonEnds;                                   // :160
+                if (e > e0 && !(prev_te <= ts)) bad |= kPrepExonOrder;                  // :158
+                while (kk < k1 && iv_end[kk] < ts) ++kk;
+                if (kk >= k1 || ts < iv_start[kk] || te > iv_end[kk]) bad |= kPrepExonInterval;   // :666-668
+                prev_te = te;
+            }
+        }
+        key[r] = ((u64)(unsigned)p << 32) | (u64)((unsigned)first ^ 0x80000000u);   // signed order of the position
+        val[r] = (int)r;
+        rep_last[r] = last;
+        if (bad) {
+            atomicOr(&ps->err, bad);
+            for (int q = 0; q < 4; ++q) if ((bad >> q) & 1u) atomicMin((unsigned long long *)&ps->bad_rep[q], (unsigned long long)r);
+        }
+    }
+}
+
+// One workgroup per partition walks the partition's reps in sorted order, 256 at a time: exclusive scan of the weights
+// (lane offsets) and inclusive running maximum of the last positions, both with a carry from tile to tile.
+__global__ void __launch_bounds__(256) k_lanes(int n_part, const i64 *part_rep_off, const i64 *part_lane_off, const u64 *key_sorted,
+                                               const int *val_sorted, const int *rep_weight, const int *rep_last,
+                                               const i64 *rep_exon_off, longlong2 *lane_ex, int *lane_start, int *lane_pmax) {
+    __shared__ int lds[16];
+    __shared__ int wmax[4];
+    __shared__ int carry_max_s;
+    __shared__ i64 carry_lane_s;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    for (int p = blockIdx.x; p < n_part; p += gridDim.x) {
+        const i64 r0 = part_rep_off[p], r1 = part_rep_off[p + 1];
+        __syncthreads();
+        if (threadIdx.x == 0) { carry_max_s = -0x7fffffff - 1; carry_lane_s = part_lane_off[p]; }
+        __syncthreads();
+        for (i64 t0 = r0; t0 < r1; t0 += 256) {
+            const i64 i = t0 + threadIdx.x;
+            const bool in = i < r1;
+            const int r = in ? val_sorted[i] : 0;
+            const int w = in ? rep_weight[r] : 0;
+            const int first = in ? (int)((unsigned)(key_sorted[i] & 0xffffffffULL) ^ 0x80000000u) : 0;
+            int m = in ? rep_last[r] : -0x7fffffff - 1;
+            for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(m, d); if (lane >= d) m = max(m, y); }
+            int tot;
+            const int ex = wg_exclusive_scan(w, lds, &tot);
+            if (lane == 63) wmax[wave] = m;
+            __syncthreads();
+            int run = carry_max_s;
+            for (int w2 = 0; w2 < wave; ++w2) run = max(run, wmax[w2]);
+            m = max(m, run);
+            const i64 base = carry_lane_s + ex;
+            __syncthreads();
+            if (threadIdx.x == 255) { carry_max_s = m; carry_lane_s = base + w; }
+            if (in) {
+                const longlong2 exr = make_longlong2(rep_exon_off[r], rep_exon_off[r + 1]);
+                for (int q = 0; q < w; ++q) { lane_ex[base + q] = exr; lane_start[base + q] = first; lane_pmax[base + q] = m; }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// lanes of the chunk's partition whose [first, last] position range meets the chunk's genomic range [glo, ghi]
+__global__ void __launch_bounds__(256) k_hist_ranges(int n_chunks, const int *hc_part, const int *hc_glo, const int *hc_ghi,
+                                                     const i64 *part_lane_off, const int *lane_start, const int *lane_pmax,
+                                                     i64 *hc_llo, i64 *hc_lhi) {
+    for (int ch = blockIdx.x * blockDim.x + threadIdx.x; ch < n_chunks; ch += gridDim.x * blockDim.x) {
+        const int p = hc_part[ch], glo = hc_glo[ch], ghi = hc_ghi[ch];
+        const i64 L0 = part_lane_off[p], L1 = part_lane_off[p + 1];
+        i64 a = L0, b = L1;
+        while (a < b) { const i64 m = (a + b) >> 1; if (lane_pmax[m] < glo) a = m + 1; else b = m; }
+        const i64 llo = a;
+        b = L1;
+        while (a < b) { const i64 m = (a + b) >> 1; if (lane_start[m] <= ghi) a = m + 1; else b = m; }
+        hc_llo[ch] = llo; hc_lhi[ch] = a;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
+// A DevBuf is a view into one of the context's slabs (or, for the few buffers with a life of their own, an allocation):
+// the buffers of a batch are carved out of three device allocations -- inputs (one host-to-device copy fills it),
+// position-sized work arrays, data-dependent arenas -- so a new batch costs no allocator call unless it is larger than
+// every batch before it.
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
     template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
 };
+struct Slab {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+struct HostBuf {     // pinned host memory
+    void *p = nullptr;
+    size_t cap = 0;
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+// offsets of consecutive 256-byte-aligned buffers inside a slab: add() them all, reserve the slab, then bind()
+struct Carve {
+    struct Item { DevBuf *b; size_t off, bytes; };
+    std::vector<Item> items;
+    size_t total = 0;
+    size_t add(DevBuf &b, size_t bytes) {
+        const size_t off = total;
+        items.push_back(Item{&b, off, bytes});
+        total = (off + bytes + 255) & ~(size_t)255;
+        return off;
+    }
+    void bind(const Slab &s) const {
+        for (const Item &it : items) { it.b->p = static_cast<char *>(s.p) + it.off; it.b->cap = it.bytes; }
+    }
+};
 
 enum Stage { ST_HIST, ST_SMOOTH, ST_THRESHOLD, ST_CANDIDATES, ST_FIX, ST_SCORE_PREP, ST_SCORE, ST_DP, ST_REFINE, ST_FINAL, ST_LABEL, ST_COUNT,
              ST_GRAPH_PRE = ST_COUNT, ST_GRAPH_POST, ST_REPORTED };
-// Without graph replay every stage is bracketed by events.  With graph replay and profiling the run is
-// graph(before scoring) | events around plain launches of the scoring kernel | graph(after); the two graphs are
-// reported as graph_pre / graph_post.
+// Plain launches (the first run of a batch, or FSEG_NO_GRAPH=1): every stage is bracketed by its own pair of events.
+// Graph replay with profiling: graph(before scoring) | events around plain launches of the scoring kernel |
+// graph(after); the two graphs are reported as graph_pre / graph_post.
 const char *kStageNames[ST_REPORTED] = {"histogram", "smooth", "threshold", "candidates", "fix_split", "scoring_prep",
                                         "interval_scoring", "dp", "refine", "final_positions", "labels", "graph_pre",
                                         "graph_post"};
 
+// segments of one run (bit mask of enqueue_run)
+enum : unsigned {
+    SEG_PRE1 = 1u,     // status reset, histogram .. problem ranges and the problem scan: every arena size is known after it
+    SEG_PRE2 = 2u,     // problem list, pair thresholds, window coverage
+    SEG_SCORE = 4u,    // the interval-scoring kernels
+    SEG_POST1 = 8u,    // DP, refinement, final positions, label columns: the label arena's size is known after it
+    SEG_POST2 = 16u,   // label arena fill + per-read labels
+    SEG_STATUS = 32u,  // status record to the host
+    SEG_ALL = 63u,
+};
+
 }  // namespace
+
+hipError_t fseg_sort_pairs(void *tmp, size_t *tmp_bytes, const unsigned long long *keys_in, unsigned long long *keys_out,
+                           const int *vals_in, int *vals_out, size_t n, unsigned end_bit, hipStream_t stream);   // freddie_seg_sort.hip
 
 struct fseg_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     std::string err;
     bool have_params = false, have_batch = false, ran = false, pending = false;
+    bool fetched = false;        // the results of the last run are in the pinned result buffers
     fseg_params P{};
     std::vector<double> w_main, w_refine, h_table;
     // batch metadata (host)
@@ -2733,46 +2905,59 @@ struct fseg_ctx {
     i64 K = 0, R = 0, I = 0, NPOS = 0, LANES = 0;
     int n_tiles = 0;
     bool expanded = false;
-    std::vector<i64> part_iv_off, part_rep_off, part_lane_off, pos_off;
-    std::vector<int> iv_start_h;
-    // device buffers: inputs
+    std::vector<i64> part_iv_off, part_rep_off;
+    // the three slabs and the buffers that live outside them
+    Slab slab_in, slab_pos, slab_arena;
+    HostBuf h_stage;             // pinned image of the input slab's uploaded part
+    HostBuf h_res;               // pinned results: final offsets | final positions | label offsets | labels
+    size_t res_off[4] = {0, 0, 0, 0};
+    std::vector<i64> res_pfo;    // part_final_off gathered from the per-interval offsets
+    DevBuf d_labels;             // label arena (sized after the final positions are known)
+    DevBuf d_sort_tmp;
+    // device buffers: inputs (slab_in, uploaded)
     DevBuf d_part_iv_off, d_part_rep_off, d_part_lane_off, d_iv_start, d_iv_end, d_pos_off, d_iv_part,
-        d_rep_exon_off, d_ex_ts, d_ex_te, d_lane_ex, d_lane_start, d_lane_pmax, d_tile_desc, d_w_main,
-        d_w_refine, d_h_table;
-    // device buffers: position-sized
+        d_rep_exon_off, d_rep_weight, d_ex_ts, d_ex_te, d_tile_desc, d_iv_tile0, d_blk_iv0, d_rb_part, d_rb_r0,
+        d_hc_part, d_hc_p0, d_hc_n, d_hc_glo, d_hc_ghi;
+    // slab_in, derived on the device by the upload
+    DevBuf d_lane_ex, d_lane_start, d_lane_pmax, d_hc_llo, d_hc_lhi, d_edge, d_key_a, d_key_b, d_val_a, d_val_b, d_rep_last;
+    DevBuf d_w_main, d_w_refine, d_h_table;     // parameter tables (own allocations)
+    // device buffers: position-sized (slab_pos)
     DevBuf d_y_raw, d_y, d_flag, d_cflag, d_v, d_scan_state, d_bsum, d_bsum_side, d_g, d_pk, d_pf, d_kp, d_final_flag;
-    // partition-sized
-    DevBuf d_blk_iv0;          // interval of the first position of every scan block (+ a sentinel)
-    DevBuf d_edge;             // per position: bit 0 = first of its interval, bit 1 = last (k_edges, once per batch)
-    DevBuf d_hc_part, d_hc_p0, d_hc_n, d_hc_glo, d_hc_ghi, d_hc_llo, d_hc_lhi;
     int n_hist_chunks = 0;
-    DevBuf d_voff, d_chunk_off, d_csum, d_mean, d_thr, d_label_off, d_part_has2, d_rb_part, d_rb_r0;
+    DevBuf d_voff, d_chunk_off, d_csum, d_mean, d_thr, d_label_off, d_part_has2;
     int n_rep_blocks = 0;
-    // candidate-sized
+    // candidate-sized (slab_pos)
     DevBuf d_cand_off, d_cand_y, d_fixed0, d_added, d_fixed, d_chosen, d_final_off, d_final_y, d_final_pos, d_col_thr,
         d_col_zero;
-    DevBuf d_cum, d_tile_tot, d_iv_tile0, d_seg_iv, d_seg_prev, d_rseg_c, d_cand_pn, d_cand_ll, d_cand_ln, d_prob_bs;
-    // problems / arenas
+    DevBuf d_cum, d_tile_tot, d_seg_iv, d_seg_prev, d_rseg_c, d_cand_pn, d_cand_ll, d_cand_ln, d_prob_bs;
+    // problems / arenas (slab_arena)
     DevBuf d_prob_iv, d_prob_start, d_prob_n, d_prob_pair_off, d_prob_tri_off, d_prob_flags, d_prob_chain,
         d_prob_cov_off, d_prob_lane_lo, d_prob_lane_n;
-    DevBuf d_dp_items, d_prob_desc, d_work_pc, d_cls_items, d_work_active, d_pair_thr, d_amb, d_out, d_cov, d_labels;
+    DevBuf d_dp_items, d_prob_desc, d_work_pc, d_cls_items, d_work_active, d_pair_thr, d_amb, d_out, d_cov;
     i64 prob_cap = 0, work_cap = 0, pair_cap = 0, tri_cap = 0, label_cap = 0, chunk_cap = 0, cov_cap = 0;
-    DevBuf d_status, d_tacc;
+    DevBuf d_status, d_prep, d_tacc;
     Status *h_status = nullptr;   // pinned
+    PrepStatus *h_prep = nullptr; // pinned
+    bool prep_checked = false;   // the upload's device-side validation has been read back
     bool profiling = false;
-    bool have_huge = false;      // an earlier run of the batch met a problem with more than kNMax candidates: launch the huge kernels
-    bool dp_wide_counts = false; // some problem of an earlier run saw >= 65536 reads: DP stages 32-bit counts
-    int nm_big = kNMax;         // LDS carve-up of the big-problem kernels: largest problem of the previous run, rounded up
+    bool have_huge = false;      // the batch has a problem with more than kNMax candidates: launch the huge kernels
+    bool dp_wide_counts = false; // some problem sees >= 65536 reads: DP stages 32-bit counts
+    int nm_big = kNMax;         // LDS carve-up of the big-problem kernels: largest problem of the batch, rounded up
     bool small_batch = false;
-    bool tiny_on = false;       // many problems in the previous run (> 256): problems with <= kTiny candidates go to k_tiny
-    bool use_graph = true;      // replay the launch sequence as hipGraphs (FSEG_NO_GRAPH=1 disables)
+    bool tiny_on = false;       // many problems (> tiny_from): problems with <= kTiny candidates go to k_tiny
+    bool use_graph = true;      // replay the launch sequence as hipGraphs from the second run of a batch on (FSEG_NO_GRAPH=1 disables)
+    bool use_sized = true;      // the first run of a batch stops twice to size its arenas exactly (FSEG_NO_SIZED=1: guess, and re-run on overflow)
     i64 prob_self_max = 4 * kProbBlock;   // candidates up to which it does (FSEG_PROB_SELF_MAX)
-    bool prob_self_scan = false; // k_prob_emit adds up the candidate blocks itself (few candidates in the previous run)
+    bool prob_self_scan = false; // k_prob_emit adds up the candidate blocks itself (few candidates)
     i64 scan_single_max = 512;  // scan blocks up to which the compactions use the single-pass look-back scan (FSEG_SCAN_SINGLE_MAX)
+    bool force_scan_stall = false;   // FSEG_FORCE_SCAN_STALL=1 (tests): the first look-back run reports a stall
+    bool force_wide_dp = false;      // FSEG_FORCE_WIDE_DP=1 (tests): 32-bit DP counts whatever the problems need
     hipGraph_t graph[2] = {nullptr, nullptr};            // [0] whole pipeline, or before / after scoring when profiling
     hipGraphExec_t graph_exec[2] = {nullptr, nullptr};
-    int n_graphs = 0;   // few DP problems in the previous run: merge the per-size-class launches
-    hipEvent_t ev[ST_COUNT + 1] = {};
+    int n_graphs = 0;
+    bool last_sized = false;     // the pending run was launched stage by stage (per-stage events valid)
+    hipEvent_t ev_b[ST_COUNT] = {}, ev_e[ST_COUNT] = {};
+    hipEvent_t ev_g[4] = {};
     float stage_ms[ST_REPORTED] = {};
     // Independent kernels of one run (threshold | candidates, the scoring size classes, the DP classes) go to side
     // streams (pair thresholds | coverage was tried too: the branch cost more than the overlap gave) between a fork and a join, so a captured run becomes a graph with parallel
@@ -2782,7 +2967,8 @@ struct fseg_ctx {
     hipEvent_t fj[kForkEvents] = {};
     bool use_fork = true;
     bool use_tiny = true;       // FSEG_NO_TINY=1 keeps every problem on the arena-based path
-    i64 tiny_from = 256;        // problems in the previous run above which k_tiny is used (FSEG_TINY_FROM; tests force 0)
+    i64 tiny_from = 256;        // problems above which k_tiny is used (FSEG_TINY_FROM; tests force 0)
+    bool trace = false;         // FSEG_TRACE=1: phase timers of upload / run on stderr
 };
 
 namespace {
@@ -2803,14 +2989,44 @@ std::string g_create_error;
         hipError_t e__ = (expr);                                                                 \
         if (e__ != hipSuccess) return fail((c), FSEG_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e__)); \
     } while (0)
+#define TRY(expr) do { int rc__ = (expr); if (rc__) return rc__; } while (0)
 
+struct Tick {
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    double ms() { auto n = std::chrono::steady_clock::now(); double d = std::chrono::duration<double, std::milli>(n - t).count(); t = n; return d; }
+};
+
+// own allocation (parameter tables, label arena, sort scratch): grows, never shrinks
 int ensure(fseg_ctx *c, DevBuf &b, size_t bytes) {
     if (bytes <= b.cap && b.p) return FSEG_OK;
     if (b.p) HIP_TRY(c, hipFree(b.p));
     b.p = nullptr; b.cap = 0;
-    size_t want = bytes < 256 ? 256 : bytes;
+    size_t want = bytes < 256 ? 256 : bytes + bytes / 4;          // headroom: batches of a run are of similar, not equal, size
     HIP_TRY(c, hipMalloc(&b.p, want));
     b.cap = want;
+    return FSEG_OK;
+}
+// keep: the slab's contents must survive growing it (device-to-device copy of the old allocation)
+int reserve(fseg_ctx *c, Slab &s, size_t bytes, bool keep = false) {
+    if (bytes <= s.cap && s.p) return FSEG_OK;
+    const size_t want = bytes + bytes / 4 + 4096;
+    void *np = nullptr;
+    HIP_TRY(c, hipMalloc(&np, want));
+    if (s.p) {
+        if (keep) HIP_TRY(c, hipMemcpyAsync(np, s.p, s.cap, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipFree(s.p));
+    }
+    s.p = np; s.cap = want;
+    return FSEG_OK;
+}
+int reserve_host(fseg_ctx *c, HostBuf &h, size_t bytes) {
+    if (bytes <= h.cap && h.p) return FSEG_OK;
+    if (h.p) HIP_TRY(c, hipHostFree(h.p));
+    h.p = nullptr; h.cap = 0;
+    const size_t want = bytes + bytes / 4 + 4096;
+    HIP_TRY(c, hipHostMalloc(&h.p, want, hipHostMallocDefault));
+    h.cap = want;
     return FSEG_OK;
 }
 template <typename T>
@@ -2820,7 +3036,6 @@ int upload_vec(fseg_ctx *c, DevBuf &b, const T *src, size_t n) {
     if (n) HIP_TRY(c, hipMemcpyAsync(b.p, src, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
     return FSEG_OK;
 }
-#define TRY(expr) do { int rc__ = (expr); if (rc__) return rc__; } while (0)
 
 int grid_for(i64 items, int per_block, int max_blocks) {
     i64 g = (items + per_block - 1) / per_block;
@@ -2843,45 +3058,53 @@ void drop_graph(fseg_ctx *c) {
     c->n_graphs = 0;
 }
 
+// (re)bind the data-dependent arenas for the current capacities; the label arena is its own allocation because it is
+// sized after everything else of a run has been written
 int alloc_arenas(fseg_ctx *c) {
     drop_graph(c);
-    TRY(ensure(c, c->d_prob_iv, (size_t)c->prob_cap * 4));
-    TRY(ensure(c, c->d_prob_start, (size_t)c->prob_cap * 4));
-    TRY(ensure(c, c->d_prob_n, (size_t)c->prob_cap * 4));
-    TRY(ensure(c, c->d_prob_pair_off, (size_t)c->prob_cap * 8));
-    TRY(ensure(c, c->d_prob_tri_off, (size_t)c->prob_cap * 8));
-    TRY(ensure(c, c->d_prob_flags, (size_t)c->prob_cap * 4));
-    TRY(ensure(c, c->d_prob_chain, (size_t)c->prob_cap * 4));
-    TRY(ensure(c, c->d_dp_items, (size_t)c->prob_cap * 4));
-    TRY(ensure(c, c->d_prob_cov_off, (size_t)c->prob_cap * 8));
-    TRY(ensure(c, c->d_prob_lane_lo, (size_t)c->prob_cap * 4));
-    TRY(ensure(c, c->d_prob_lane_n, (size_t)c->prob_cap * 4));
-    TRY(ensure(c, c->d_prob_desc, (size_t)c->prob_cap * sizeof(ProbDesc)));
-    TRY(ensure(c, c->d_work_pc, (size_t)c->work_cap * 8));
-    TRY(ensure(c, c->d_cls_items, (size_t)c->work_cap * 16));
-    TRY(ensure(c, c->d_work_active, (size_t)c->work_cap));
-    TRY(ensure(c, c->d_cov, (size_t)c->cov_cap * 4));
-    TRY(ensure(c, c->d_pair_thr, (size_t)c->pair_cap * 8));
-    TRY(ensure(c, c->d_amb, (size_t)c->pair_cap * 4));
-    TRY(ensure(c, c->d_out, (size_t)c->tri_cap * 4));
+    Carve cv;
+    cv.add(c->d_prob_iv, (size_t)c->prob_cap * 4);
+    cv.add(c->d_prob_start, (size_t)c->prob_cap * 4);
+    cv.add(c->d_prob_n, (size_t)c->prob_cap * 4);
+    cv.add(c->d_prob_pair_off, (size_t)c->prob_cap * 8);
+    cv.add(c->d_prob_tri_off, (size_t)c->prob_cap * 8);
+    cv.add(c->d_prob_flags, (size_t)c->prob_cap * 4);
+    cv.add(c->d_prob_chain, (size_t)c->prob_cap * 4);
+    cv.add(c->d_dp_items, (size_t)c->prob_cap * 4);
+    cv.add(c->d_prob_cov_off, (size_t)c->prob_cap * 8);
+    cv.add(c->d_prob_lane_lo, (size_t)c->prob_cap * 4);
+    cv.add(c->d_prob_lane_n, (size_t)c->prob_cap * 4);
+    cv.add(c->d_prob_desc, (size_t)c->prob_cap * sizeof(ProbDesc));
+    cv.add(c->d_work_pc, (size_t)c->work_cap * 8);
+    cv.add(c->d_cls_items, (size_t)c->work_cap * 16);
+    cv.add(c->d_work_active, (size_t)c->work_cap);
+    cv.add(c->d_cov, (size_t)c->cov_cap * 4);
+    cv.add(c->d_pair_thr, (size_t)c->pair_cap * 8);
+    cv.add(c->d_amb, (size_t)c->pair_cap * 4);
+    cv.add(c->d_out, (size_t)c->tri_cap * 4);
+    TRY(reserve(c, c->slab_arena, cv.total));
+    cv.bind(c->slab_arena);
     TRY(ensure(c, c->d_labels, (size_t)c->label_cap + 16));
-    TRY(ensure(c, c->d_csum, (size_t)c->chunk_cap * 16));     // chunk sums of both passes
     return FSEG_OK;
 }
 
 // look-back state of the three compactions (values, candidates, final positions): nb words each, zeroed per run
 inline i64 scan_blocks(i64 n) { return (n + kScanBlock - 1) / kScanBlock; }
 
-// phase: 0 = whole pipeline; 1 = everything before the interval-scoring kernel, 2 = the interval-scoring kernel(s),
-// 3 = everything after.
-int enqueue_run(fseg_ctx *c, int phase = 0) {
+// Enqueue the segments `segs` of one run on the context's stream.
+//   sized: the run is being launched piecewise with the host reading the sizes in between (first run of a batch):
+//          the problem scan always runs as its own kernels (their totals are what the host waits for) and the label
+//          arena is filled by its own kernel over exactly label_fill_bytes.
+int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_bytes = 0) {
     hipStream_t s = c->stream;
-    const bool do_pre = phase == 0 || phase == 1, do_score = phase == 0 || phase == 2, do_post = phase == 0 || phase == 3;
-    const bool in_parts = phase != 0;
+    const bool do_pre1 = segs & SEG_PRE1, do_pre2 = segs & SEG_PRE2, do_score = segs & SEG_SCORE, do_post1 = segs & SEG_POST1,
+               do_post2 = segs & SEG_POST2;
+    const bool stage_events = c->profiling && (sized || !c->use_graph);
     const int n_part = c->n_part;
     const i64 K = c->K, NPOS = c->NPOS;
     Status *st = c->d_status.as<Status>();
-    auto mark = [&](int i) { if (c->profiling && !in_parts) (void)hipEventRecord(c->ev[i], s); };
+    auto begin = [&](int i) { if (stage_events) (void)hipEventRecord(c->ev_b[i], s); };
+    auto end = [&](int i) { if (stage_events) (void)hipEventRecord(c->ev_e[i], s); };
     // fork(k): side stream k continues from here; join(k): the main stream waits for it.  Every fork is joined before
     // the function returns, so a capture of the main stream ends with all branches merged.
     // Small batches (one partition, few problems) are chains of launch-latency-sized kernels: branches only add
@@ -2926,9 +3149,13 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
                      c->d_prob_pair_off.as<i64>(), c->d_prob_tri_off.as<i64>(), c->d_prob_flags.as<int>(),
                      c->d_prob_chain.as<int>(), c->d_prob_cov_off.as<i64>(), c->d_prob_lane_lo.as<int>(),
                      c->d_prob_lane_n.as<int>()};
-    if (do_pre) {
+    const int pg = grid_for(NPOS / 8 / kProbBlock + 1, 1, 1024);
+    // few candidates: the emit kernel scans by itself, one launch instead of three (never in a sized run: there the
+    // host reads the scan's totals before the emit kernel is launched)
+    i64 *prob_bs = (c->prob_self_scan && !sized) ? nullptr : c->d_prob_bs.as<i64>();
+    if (do_pre1) {
     HIP_TRY(c, hipMemsetAsync(st, 0, sizeof(Status), s));
-    mark(0);
+    begin(ST_HIST);
     // S1
     hipLaunchKernelGGL(k_hist, dim3(grid_for(c->n_hist_chunks, 1, 16384)), dim3(512), 0, s, c->n_hist_chunks,
                        c->d_hc_part.as<int>(), c->d_hc_p0.as<i64>(), c->d_hc_n.as<int>(), c->d_hc_glo.as<int>(),
@@ -2937,7 +3164,7 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
                        c->d_lane_start.as<int>(), c->d_lane_pmax.as<int>(),
                        c->d_ex_ts.as<int>(), c->d_ex_te.as<int>(), c->P.ignore_ends, c->d_y_raw.as<int>(), st,
                        scan_state, scan_single ? scan_nb * 3 : 0);
-    mark(1);
+    end(ST_HIST); begin(ST_SMOOTH);
     // S2
 #define FSEG_LAUNCH_SMOOTH(RV)                                                                                         \
     hipLaunchKernelGGL(k_smooth<RV>, dim3(tile_grid), dim3(kSmoothThreads), 0, s, c->n_tiles, c->d_tile_desc.as<TileDesc>(),      \
@@ -2949,14 +3176,16 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
     else if (c->P.radius_main == 12) { FSEG_LAUNCH_SMOOTH(12); }
     else { FSEG_LAUNCH_SMOOTH(0); }
 #undef FSEG_LAUNCH_SMOOTH
-    mark(2);
+    end(ST_SMOOTH);
     // S3a threshold: needs only the smoothed signal, like the candidates (S3b) -- the two chains run side by side
     {
     hipStream_t q = fork(0);
+    if (stage_events) (void)hipEventRecord(c->ev_b[ST_THRESHOLD], q);
     scan_counts(q, bsum_side, c->d_flag.as<unsigned char>(), &st->n_vals, nullptr);
     hipLaunchKernelGGL(k_scan_emit<kEmitValues>, dim3(scan_grid), dim3(256), 0, q, c->d_flag.as<unsigned char>(), NPOS,
                        bsum_side, scan_state, &st->n_vals, (i64 *)nullptr, &st->err, c->d_y.as<double>(), c->d_v.as<double>(), K, c->d_pos_off.as<i64>(),
-                       c->d_iv_start.as<int>(), c->d_blk_iv0.as<int>(), (int *)nullptr, (int *)nullptr, (i64 *)nullptr);
+                       c->d_iv_start.as<int>(), c->d_blk_iv0.as<int>(), (int *)nullptr, (int *)nullptr, (i64 *)nullptr,
+                       c->force_scan_stall ? 1 : 0);
     hipLaunchKernelGGL(k_voff, dim3(grid_for(n_part + 1, 1, 2048)), dim3(64), 0, q, n_part, c->d_part_iv_off.as<i64>(),
                        c->d_pos_off.as<i64>(), NPOS, c->d_flag.as<unsigned char>(), bsum_side, scan_state, &st->n_vals,
                        c->d_voff.as<i64>());
@@ -2970,8 +3199,9 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
     hipLaunchKernelGGL(k_vsum_part, dim3(grid_for(n_part, 64, 1024)), dim3(64), 0, q, n_part, c->d_voff.as<i64>(),
                        c->d_chunk_off.as<i64>(), csum0, csum1, c->P.variance_factor, c->d_mean.as<double>(),
                        c->d_thr.as<double>(), c->chunk_cap);
+    if (stage_events) (void)hipEventRecord(c->ev_e[ST_THRESHOLD], q);
     }
-    mark(3);
+    begin(ST_CANDIDATES);
     // S3b candidates
     hipLaunchKernelGGL(k_peaks, dim3(grid_for(NPOS / 4 + 1, 256, 16384)), dim3(256), 0, s, NPOS, c->d_edge.as<unsigned char>(),
                        c->d_y.as<double>(), c->d_cflag.as<unsigned char>(),
@@ -2980,9 +3210,10 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
     hipLaunchKernelGGL(k_scan_emit<kEmitPositions>, dim3(scan_grid), dim3(256), 0, s, c->d_cflag.as<unsigned char>(), NPOS,
                        bsum, scan_state + scan_nb, &st->n_cand, c->d_cand_off.as<i64>() + K, &st->err, (const double *)nullptr, (double *)nullptr, K, c->d_pos_off.as<i64>(),
                        c->d_iv_start.as<int>(), c->d_blk_iv0.as<int>(), c->d_cand_y.as<int>(), (int *)nullptr,
-                       c->d_cand_off.as<i64>());
+                       c->d_cand_off.as<i64>(), 0);
+    end(ST_CANDIDATES);
     join(0);
-    mark(4);
+    begin(ST_FIX);
     // S4
     hipLaunchKernelGGL(k_fix, dim3(grid_for(K, 1, 8192)), dim3(iv_threads), 0, s, K, c->d_pos_off.as<i64>(),
                        c->d_iv_part.as<int>(), c->d_cand_off.as<i64>(), c->d_cand_y.as<int>(), c->d_y.as<double>(),
@@ -2993,21 +3224,19 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
                        c->d_seg_iv.as<int>(), c->d_cand_y.as<int>(), c->d_iv_part.as<int>(), c->d_iv_start.as<int>(),
                        c->d_part_lane_off.as<i64>(), c->d_lane_start.as<int>(), c->d_lane_pmax.as<int>(),
                        c->d_cand_ll.as<int>(), c->d_cand_ln.as<int>());
-    {
-        int pg = grid_for(NPOS / 8 / kProbBlock + 1, 1, 1024);
-        // few candidates (previous run): the emit kernel scans by itself, one launch instead of three
-        i64 *bs = c->prob_self_scan ? nullptr : c->d_prob_bs.as<i64>();
-        if (bs) {
-            hipLaunchKernelGGL(k_prob_scan1, dim3(pg), dim3(256), 0, s, st, c->d_cand_pn.as<int>(), c->d_cand_ln.as<int>(), bs, tiny_max);
-            hipLaunchKernelGGL(k_prob_scan2, dim3(1), dim3(256), 0, s, st, bs);
-        }
-        hipLaunchKernelGGL(k_prob_emit, dim3(pg), dim3(256), 0, s, st, c->d_cand_pn.as<int>(), c->d_cand_ll.as<int>(),
-                           c->d_cand_ln.as<int>(), c->d_seg_iv.as<int>(), c->d_cand_off.as<i64>(), bs,
-                           pr, c->prob_cap, c->d_work_pc.as<int2>(), c->d_cls_items.as<int4>(),
-                           c->work_cap, c->d_dp_items.as<int>(), c->d_prob_desc.as<ProbDesc>(), c->d_iv_start.as<int>(),
-                           c->d_iv_part.as<int>(), c->d_part_lane_off.as<i64>(), tiny_max);
+    if (prob_bs) {
+        hipLaunchKernelGGL(k_prob_scan1, dim3(pg), dim3(256), 0, s, st, c->d_cand_pn.as<int>(), c->d_cand_ln.as<int>(), prob_bs, tiny_max);
+        hipLaunchKernelGGL(k_prob_scan2, dim3(1), dim3(256), 0, s, st, prob_bs);
     }
-    mark(5);
+    end(ST_FIX);
+    }   // do_pre1
+    if (do_pre2) {
+    begin(ST_SCORE_PREP);
+    hipLaunchKernelGGL(k_prob_emit, dim3(pg), dim3(256), 0, s, st, c->d_cand_pn.as<int>(), c->d_cand_ll.as<int>(),
+                       c->d_cand_ln.as<int>(), c->d_seg_iv.as<int>(), c->d_cand_off.as<i64>(), prob_bs,
+                       pr, c->prob_cap, c->d_work_pc.as<int2>(), c->d_cls_items.as<int4>(),
+                       c->work_cap, c->d_dp_items.as<int>(), c->d_prob_desc.as<ProbDesc>(), c->d_iv_start.as<int>(),
+                       c->d_iv_part.as<int>(), c->d_part_lane_off.as<i64>(), tiny_max);
     // S5
     if (c->prob_cap > 0) {
         const int cov_blocks = work_grid < 2048 ? work_grid : 2048;
@@ -3026,8 +3255,9 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
                            cov_blocks, pr, c->d_h_table.as<double>(), c->P.h_len, c->P.threshold_rate, c->d_pair_thr.as<int2>(),
                            c->pair_cap, c->d_amb.as<unsigned>(), c->d_out.as<unsigned>(), c->tri_cap, tiny_max);
     }
-    mark(6);
-    }   // do_pre
+    end(ST_SCORE_PREP);
+    }   // do_pre2
+    if (do_score) begin(ST_SCORE);
     if (do_score && c->prob_cap > 0) {
         if (tiny_max > 0) {
             // the problems with a handful of candidates, whole (coverage, labels, counts, DP), beside the arena-based
@@ -3068,12 +3298,16 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
                                c->d_out.as<unsigned>(), c->tri_cap, c->d_amb.as<unsigned>());
         if (tiny_max > 0) join(2);             // k_tiny is interval scoring too: inside the stage's time bracket
     }
-    mark(7);
-    if (do_post) {
+    if (do_score) end(ST_SCORE);
+    const i64 labels_n16 = (c->label_cap + 15) / 16;            // the arena is allocated in multiples of 16 bytes
+    // the label arena's '0' fill rides the big-problem DP launch as extra workgroups -- unless the run is being sized
+    // (the arena's size is not known yet) or there is no DP launch
+    const bool ride_fill = !sized && c->prob_cap > 0 && c->label_cap > 0;
+    if (do_post1) {
+    begin(ST_DP);
     if (c->prob_cap > 0) {
         int dp_grid = grid_for(c->prob_cap, 1, 1024);
-        const i64 labels_n16 = (c->label_cap + 15) / 16;            // the arena is allocated in multiples of 16 bytes
-        const int fill_blocks = c->label_cap > 0 ? grid_for(labels_n16 / 8 + 1, 512, 512) : 0;
+        const int fill_blocks = ride_fill ? grid_for(labels_n16 / 8 + 1, 512, 512) : 0;
 #define FSEG_LAUNCH_DP(NMV, TV, OUTT, NM_RT, DPCLASS, MAXWG)                                                             \
         hipLaunchKernelGGL((k_dp<NMV, TV, OUTT>), dim3((dp_grid < (MAXWG) ? dp_grid : (MAXWG)) + fill_blocks), dim3(TV),     \
                            dp_lds_for(NM_RT, (int)sizeof(OUTT)), ((NMV) == kDpSmall ? q_small : s), st, DPCLASS, NM_RT, c->d_dp_items.as<int>(), pr,          \
@@ -3095,7 +3329,7 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
                            c->d_part_lane_off.as<i64>(), c->d_out.as<unsigned>(), c->tri_cap, c->d_amb.as<unsigned>(),        \
                            c->d_pair_thr.as<int2>(), c->pair_cap, c->P.min_read_support_outside,                              \
                            c->d_chosen.as<unsigned char>(), kDpWave, grid_for(c->prob_cap, 1, 8192), (uint4 *)nullptr, (i64)0 FSEG_TARG)
-        // 16-bit count tables unless some problem sees >= 65536 reads (then a previous run asked for the wide tables);
+        // 16-bit count tables unless some problem sees >= 65536 reads;
         // 512 threads (8 waves share the c2 loop) when the tables of the largest problem leave room for their scratch.
         // small_batch: one launch over every problem; otherwise one launch per DP class list.
         hipStream_t q_small = c->small_batch ? s : fork(0);      // the DP classes own disjoint problems
@@ -3118,7 +3352,7 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
                                c->tri_cap, c->d_amb.as<unsigned>(), c->d_pair_thr.as<int2>(), c->pair_cap,
                                c->P.min_read_support_outside, c->d_chosen.as<unsigned char>());
     }
-    mark(8);
+    end(ST_DP); begin(ST_REFINE);
     // S6
     hipLaunchKernelGGL(k_segments, dim3(grid_for(K, 1, 8192)), dim3(iv_threads), 0, s, K, c->d_pos_off.as<i64>(),
                        c->d_cand_off.as<i64>(), c->d_cand_y.as<int>(), c->d_cum.as<int>(), c->d_tile_tot.as<int>(), c->d_iv_tile0.as<int>(),
@@ -3128,23 +3362,28 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
                        c->d_seg_prev.as<int>(), c->d_cand_y.as<int>(), c->d_pos_off.as<i64>(), c->d_y_raw.as<int>(),
                        c->d_w_refine.as<double>(), c->P.radius_refine, c->P.sigma, c->d_g.as<double>(), c->d_pk.as<int>(),
                        c->d_pf.as<unsigned char>(), c->d_kp.as<unsigned char>(), c->d_final_flag.as<unsigned char>());
-    mark(9);
+    end(ST_REFINE); begin(ST_FINAL);
     scan_counts(s, bsum, c->d_final_flag.as<unsigned char>(), &st->n_final, c->d_final_off.as<i64>() + K);
     hipLaunchKernelGGL(k_scan_emit<kEmitPositions>, dim3(scan_grid), dim3(256), 0, s, c->d_final_flag.as<unsigned char>(),
                        NPOS, bsum, scan_state + 2 * scan_nb, &st->n_final, c->d_final_off.as<i64>() + K, &st->err, (const double *)nullptr, (double *)nullptr, K, c->d_pos_off.as<i64>(),
                        c->d_iv_start.as<int>(), c->d_blk_iv0.as<int>(), c->d_final_y.as<int>(), c->d_final_pos.as<int>(),
-                       c->d_final_off.as<i64>());
-    mark(10);
-    // S7
+                       c->d_final_off.as<i64>(), 0);
+    // S7, first half: per-column thresholds and the label arena's plan
     hipLaunchKernelGGL(k_label_cols, dim3(grid_for(NPOS / 8 + 1, 256, 2048)), dim3(256), 0, s, K, c->d_final_off.as<i64>(),
                        c->d_final_y.as<int>(), c->d_iv_part.as<int>(), c->d_h_table.as<double>(), c->P.h_len,
                        c->P.threshold_rate, c->d_col_thr.as<int2>(), c->d_col_zero.as<unsigned char>(),
                        c->d_part_has2.as<int>(), n_part, c->d_part_iv_off.as<i64>(), c->d_part_rep_off.as<i64>(),
                        c->d_label_off.as<i64>(), st, c->label_cap);
+    end(ST_FINAL);
+    }   // do_post1
+    if (do_post2) {
+    begin(ST_LABEL);
     if (c->label_cap > 0) {
-        if (c->prob_cap == 0)                                       // no DP launch carried the fill
-            hipLaunchKernelGGL(k_label_zero, dim3(grid_for(c->label_cap / 16 / 8 + 1, 256, 4096)), dim3(256), 0, s,
-                               c->d_labels.as<uint4>(), (c->label_cap + 15) / 16);
+        if (!ride_fill) {                                           // no DP launch carried the fill
+            const i64 n16 = sized ? (label_fill_bytes + 15) / 16 : labels_n16;
+            if (n16 > 0)
+                hipLaunchKernelGGL(k_label_zero, dim3(grid_for(n16 / 8 + 1, 256, 4096)), dim3(256), 0, s, c->d_labels.as<uint4>(), n16);
+        }
         hipLaunchKernelGGL(k_label_reads, dim3(grid_for((i64)c->n_rep_blocks * kLabelSplit, 1, 65536)), dim3(256), 0, s, c->n_rep_blocks,
                            c->d_rb_part.as<int>(), c->d_rb_r0.as<int>(), c->d_label_off.as<i64>(), c->label_cap, n_part,
                            c->d_part_iv_off.as<i64>(), c->d_part_rep_off.as<i64>(), c->d_final_off.as<i64>(),
@@ -3152,15 +3391,14 @@ int enqueue_run(fseg_ctx *c, int phase = 0) {
                            c->d_ex_ts.as<int>(), c->d_ex_te.as<int>(), c->d_col_zero.as<unsigned char>(),
                            c->d_part_has2.as<int>(), c->d_labels.as<unsigned char>());
     }
-    mark(11);
-    HIP_TRY(c, hipMemcpyAsync(c->h_status, st, sizeof(Status), hipMemcpyDeviceToHost, s));
-    }   // do_post
+    end(ST_LABEL);
+    }   // do_post2
+    if (segs & SEG_STATUS) HIP_TRY(c, hipMemcpyAsync(c->h_status, st, sizeof(Status), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, fj_err);
     HIP_TRY(c, hipGetLastError());
     return FSEG_OK;
 }
 
-// wait for the run; grow arenas and re-run if a capacity was exceeded
 // wait for the stream: poll for a while (a run is well under a millisecond on a resident batch and the blocking
 // wait's wake-up costs tens of microseconds), then block
 hipError_t wait_stream(fseg_ctx *c) {
@@ -3174,15 +3412,74 @@ hipError_t wait_stream(fseg_ctx *c) {
     return hipStreamSynchronize(c->stream);
 }
 
+// the device-side validation of the last upload (read once, with the first status record of the batch)
+int check_prep(fseg_ctx *c) {
+    if (c->prep_checked) return FSEG_OK;
+    c->prep_checked = true;
+    const PrepStatus &ps = *c->h_prep;
+    if (!ps.err) return FSEG_OK;
+    int q = 0;
+    for (int i = 1; i < 4; ++i) if (((ps.err >> i) & 1u) && (!((ps.err >> q) & 1u) || ps.bad_rep[i] < ps.bad_rep[q])) q = i;
+    if (!((ps.err >> q) & 1u)) for (q = 0; q < 4 && !((ps.err >> q) & 1u); ++q) {}
+    const long long r = (long long)ps.bad_rep[q];
+    c->have_batch = false;
+    switch (1u << q) {
+        case kPrepExonEnds: return fail(c, FSEG_ERR_INPUT, "rep %lld: exon with start >= end (py/freddie_segment.py:160)", r);
+        case kPrepExonOrder: return fail(c, FSEG_ERR_INPUT, "rep %lld: exons out of order (py/freddie_segment.py:158)", r);
+        case kPrepExonInterval: return fail(c, FSEG_ERR_INPUT, "rep %lld: an exon does not lie inside one tint interval (py/freddie_segment.py:668)", r);
+        default: return fail(c, FSEG_ERR_INPUT, "rep %lld has no exons", r);
+    }
+}
+
+// what the status record of a finished run says about the run's input (the reference's assertions)
+int run_input_errors(fseg_ctx *c, const Status &s) {
+    if (s.err & kErrExonInterval) return fail(c, FSEG_ERR_INPUT, "an exon does not lie inside one tint interval (py/freddie_segment.py:668)");
+    if (s.err & kErrBreakAssert) return fail(c, FSEG_ERR_INPUT, "break_large_problems: candidate window out of range or no positive signal (py/freddie_segment.py:640-643)");
+    if (s.err & kErrProblemTooLarge) return fail(c, FSEG_ERR_UNSUPPORTED, "a DP problem has more than %d candidates (max_problem_size too large for this build)", kNHuge);
+    return FSEG_OK;
+}
+
+// launch parameters that follow from the sizes of a run (exact in a sized run, last run's otherwise)
+void adapt_to(fseg_ctx *c, const Status &s) {
+    const bool old_small = c->small_batch, old_self = c->prob_self_scan, old_tiny = c->tiny_on;
+    const int old_nm = c->nm_big;
+    c->small_batch = (i64)s.n_prob <= 256 && (i64)s.n_work <= 1024;
+    c->tiny_on = (i64)s.n_prob > c->tiny_from && c->use_tiny;   // depends on the problem count only, which k_tiny does not change
+    c->prob_self_scan = (i64)s.n_cand <= c->prob_self_max;
+    {   // the big-problem LDS carve-up: the largest problem (+ headroom, multiple of 4)
+        int want = (int)s.max_n + 3;
+        want = (want + 3) & ~3;
+        if (want < kClsMid + 4) want = kClsMid + 4;
+        if (want > kNMax) want = kNMax;
+        c->nm_big = want;
+    }
+    if (old_small != c->small_batch || old_nm != c->nm_big || old_self != c->prob_self_scan || old_tiny != c->tiny_on) drop_graph(c);
+}
+
+void collect_stage_times(fseg_ctx *c, int timed_graphs) {
+    if (!c->profiling) return;
+    for (int i = 0; i < ST_REPORTED; ++i) c->stage_ms[i] = 0.f;
+    if (timed_graphs == 2) {
+        (void)hipEventElapsedTime(&c->stage_ms[ST_GRAPH_PRE], c->ev_g[0], c->ev_g[1]);
+        (void)hipEventElapsedTime(&c->stage_ms[ST_SCORE], c->ev_g[1], c->ev_g[2]);
+        (void)hipEventElapsedTime(&c->stage_ms[ST_GRAPH_POST], c->ev_g[2], c->ev_g[3]);
+    } else if (c->last_sized || !c->use_graph) {
+        for (int i = 0; i < ST_COUNT; ++i)
+            if (hipEventElapsedTime(&c->stage_ms[i], c->ev_b[i], c->ev_e[i]) != hipSuccess) { c->stage_ms[i] = 0.f; (void)hipGetLastError(); }
+    }
+}
+
+// wait for the run; grow arenas and re-run if a capacity was exceeded (never after a sized run: its capacities are exact)
 int finish_run(fseg_ctx *c) {
     for (int attempt = 0; attempt < 4; ++attempt) {
         HIP_TRY(c, wait_stream(c));
+        TRY(check_prep(c));
         const Status &s = *c->h_status;
         unsigned ovf = s.err & (kErrOverflowPairs | kErrOverflowTri | kErrOverflowWork | kErrOverflowLabels |
                                 kErrOverflowProblems | kErrOverflowChunks | kErrOverflowCov);
         if (s.err & kErrOverflowNm) { ovf |= kErrOverflowNm; c->nm_big = kNMax; }
-        if (s.err & kErrNeedWideDp) { ovf |= kErrNeedWideDp; c->dp_wide_counts = true; drop_graph(c); }
-        if (s.err & kErrScanStall) { ovf |= kErrScanStall; c->scan_single_max = 0; drop_graph(c); }
+        if (((s.err & kErrNeedWideDp) || (i64)s.max_ln >= 65536) && !c->dp_wide_counts) { ovf |= kErrNeedWideDp; c->dp_wide_counts = true; drop_graph(c); }
+        if (s.err & kErrScanStall) { ovf |= kErrScanStall; c->scan_single_max = 0; c->force_scan_stall = false; drop_graph(c); }
         if (s.dp_cls[2] > 0 && !c->have_huge) { ovf |= kErrProblemTooLarge << 16; c->have_huge = true; drop_graph(c); }   // rerun with the huge-problem kernels
         bool need = ovf != 0 || (i64)s.n_prob > c->prob_cap || (i64)s.n_work > c->work_cap ||
                     (i64)s.pair_used > c->pair_cap || (i64)s.tri_used > c->tri_cap || (i64)s.label_bytes > c->label_cap ||
@@ -3190,34 +3487,10 @@ int finish_run(fseg_ctx *c) {
         if (!need) {
             c->pending = false;
             c->ran = true;
-            const bool old_small = c->small_batch, old_self = c->prob_self_scan, old_tiny = c->tiny_on;
-            const int old_nm = c->nm_big;
-            c->small_batch = (i64)s.n_prob <= 256 && (i64)s.n_work <= 1024;
-            c->tiny_on = (i64)s.n_prob > c->tiny_from && c->use_tiny;   // depends on the problem count only, which k_tiny does not change
-            c->prob_self_scan = (i64)s.n_cand <= c->prob_self_max;
-            {   // size the next run's big-problem LDS for this run's largest problem (+ headroom, multiple of 4)
-                int want = (int)s.max_n + 3;
-                want = (want + 3) & ~3;
-                if (want < kClsMid + 4) want = kClsMid + 4;
-                if (want > kNMax) want = kNMax;
-                c->nm_big = want;
-            }
             const int timed_graphs = c->n_graphs;
-            if (old_small != c->small_batch || old_nm != c->nm_big || old_self != c->prob_self_scan || old_tiny != c->tiny_on) drop_graph(c);
-            if (c->profiling) {
-                for (int i = 0; i < ST_REPORTED; ++i) c->stage_ms[i] = 0.f;
-                if (timed_graphs == 2) {
-                    (void)hipEventElapsedTime(&c->stage_ms[ST_GRAPH_PRE], c->ev[0], c->ev[ST_SCORE]);
-                    (void)hipEventElapsedTime(&c->stage_ms[ST_SCORE], c->ev[ST_SCORE], c->ev[ST_SCORE + 1]);
-                    (void)hipEventElapsedTime(&c->stage_ms[ST_GRAPH_POST], c->ev[ST_SCORE + 1], c->ev[ST_COUNT]);
-                } else {
-                    for (int i = 0; i < ST_COUNT; ++i) (void)hipEventElapsedTime(&c->stage_ms[i], c->ev[i], c->ev[i + 1]);
-                }
-            }
-            if (s.err & kErrExonInterval) return fail(c, FSEG_ERR_INPUT, "an exon does not lie inside one tint interval (py/freddie_segment.py:668)");
-            if (s.err & kErrBreakAssert) return fail(c, FSEG_ERR_INPUT, "break_large_problems: candidate window out of range or no positive signal (py/freddie_segment.py:640-643)");
-            if (s.err & kErrProblemTooLarge) return fail(c, FSEG_ERR_UNSUPPORTED, "a DP problem has more than %d candidates (max_problem_size too large for this build)", kNHuge);
-            return FSEG_OK;
+            collect_stage_times(c, timed_graphs);
+            adapt_to(c, s);
+            return run_input_errors(c, s);
         }
         auto grow = [](i64 need_v, i64 cap) { return need_v > cap ? need_v + need_v / 8 + 64 : cap; };
         c->prob_cap = grow((i64)s.n_prob, c->prob_cap);
@@ -3225,12 +3498,81 @@ int finish_run(fseg_ctx *c) {
         c->pair_cap = grow((i64)s.pair_used, c->pair_cap);
         c->tri_cap = grow((i64)s.tri_used, c->tri_cap);
         c->label_cap = grow((i64)s.label_bytes, c->label_cap);
-        c->chunk_cap = grow((i64)s.n_vchunks, c->chunk_cap);
         c->cov_cap = grow((i64)s.cov_used, c->cov_cap);
         TRY(alloc_arenas(c));
-        TRY(enqueue_run(c));
+        c->last_sized = false;
+        TRY(enqueue_run(c, SEG_ALL));
     }
     return fail(c, FSEG_ERR_HIP, "arena sizing did not converge");
+}
+
+// First run of a batch: launched in three pieces with the host reading the status record in between, so every arena is
+// sized exactly before anything is written into it -- no guessed capacities, no overflow re-run.
+//   A  histogram .. problem scan   -> problems, work items, pairs, triples, coverage elements, largest / widest problem
+//   B  problem list .. label plan  -> final positions, label bytes
+//   C  labels
+// The two waits cost a few tens of microseconds each; with two contexts per GPU (the CLI) another batch's kernels fill them.
+int run_sized(fseg_ctx *c) {
+    Tick tk;
+    double t_a = 0, t_b = 0;
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        // A
+        TRY(enqueue_run(c, SEG_PRE1 | SEG_STATUS, true));
+        HIP_TRY(c, wait_stream(c));
+        TRY(check_prep(c));
+        Status s = *c->h_status;
+        if (s.err & kErrScanStall) { c->scan_single_max = 0; c->force_scan_stall = false; continue; }     // redo with the three-pass scan
+        {   // k_tiny's share of the problems was decided from the previous batch: if this batch decides otherwise, the
+            // arena sizes change with it -- redo the (cheap) problem scan under the right setting
+            const bool tiny = (i64)s.n_prob > c->tiny_from && c->use_tiny;
+            if (tiny != c->tiny_on) {
+                c->tiny_on = tiny;
+                const int pg = grid_for(c->NPOS / 8 / kProbBlock + 1, 1, 1024);
+                Status *st = c->d_status.as<Status>();
+                hipLaunchKernelGGL(k_prob_scan1, dim3(pg), dim3(256), 0, c->stream, st, c->d_cand_pn.as<int>(), c->d_cand_ln.as<int>(),
+                                   c->d_prob_bs.as<i64>(), tiny ? kTiny : 0);
+                hipLaunchKernelGGL(k_prob_scan2, dim3(1), dim3(256), 0, c->stream, st, c->d_prob_bs.as<i64>());
+                HIP_TRY(c, hipMemcpyAsync(c->h_status, st, sizeof(Status), hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(c, wait_stream(c));
+                s = *c->h_status;
+            }
+        }
+        t_a = tk.ms();
+        if ((s.err & (kErrExonInterval | kErrBreakAssert | kErrProblemTooLarge))) {     // the reference would have aborted here
+            c->pending = false; c->ran = false;
+            return run_input_errors(c, s);
+        }
+        auto atleast = [](i64 &cap, i64 v) { if (cap < v) cap = v; };
+        atleast(c->prob_cap, (i64)s.n_prob); atleast(c->work_cap, (i64)s.n_work); atleast(c->pair_cap, (i64)s.pair_used);
+        atleast(c->tri_cap, (i64)s.tri_used); atleast(c->cov_cap, (i64)s.cov_used);
+        c->have_huge = s.dp_cls[2] > 0;
+        c->dp_wide_counts = c->force_wide_dp || (i64)s.max_ln >= 65536;
+        adapt_to(c, s);
+        TRY(alloc_arenas(c));
+        // B
+        TRY(enqueue_run(c, SEG_PRE2 | SEG_SCORE | SEG_POST1 | SEG_STATUS, true));
+        HIP_TRY(c, wait_stream(c));
+        s = *c->h_status;
+        t_b = tk.ms();
+        if (s.err & kErrScanStall) { c->scan_single_max = 0; c->force_scan_stall = false; continue; }
+        const unsigned bad = s.err & (kErrOverflowPairs | kErrOverflowTri | kErrOverflowWork | kErrOverflowProblems | kErrOverflowChunks |
+                                      kErrOverflowCov | kErrOverflowNm | kErrNeedWideDp);
+        if (bad) return fail(c, FSEG_ERR_HIP, "internal: a sized run overflowed an arena (status %#x)", s.err);
+        if ((s.err & (kErrExonInterval | kErrBreakAssert | kErrProblemTooLarge))) {
+            c->pending = false; c->ran = false;
+            return run_input_errors(c, s);
+        }
+        // C
+        if ((i64)s.label_bytes > c->label_cap) { c->label_cap = (i64)s.label_bytes; TRY(ensure(c, c->d_labels, (size_t)c->label_cap + 16)); c->label_cap = (i64)c->d_labels.cap - 16; }
+        TRY(enqueue_run(c, SEG_POST2, true, (i64)s.label_bytes));
+        c->h_status->err &= ~kErrOverflowLabels;       // the plan was made against the old capacity; the arena has been grown since
+        c->pending = true;
+        c->last_sized = true;
+        if (c->trace) fprintf(stderr, "[fseg] run (sized): A %.3f ms, B %.3f ms, C enqueued %.3f ms; %llu problems, %llu work items, %llu label bytes\n",
+                              t_a, t_b, tk.ms(), (unsigned long long)s.n_prob, (unsigned long long)s.n_work, (unsigned long long)s.label_bytes);
+        return FSEG_OK;
+    }
+    return fail(c, FSEG_ERR_HIP, "the compaction scans stalled repeatedly");
 }
 
 }  // namespace
@@ -3241,6 +3583,12 @@ int finish_run(fseg_ctx *c) {
 extern "C" {
 
 int fseg_abi_version(void) { return FSEG_ABI_VERSION; }
+
+#ifndef FREDDIE_SOURCE_HASH
+#define FREDDIE_SOURCE_HASH ""
+#endif
+static const char freddie_source_stamp[] __attribute__((used)) = "FREDDIE_SRC_HASH=" FREDDIE_SOURCE_HASH;
+const char *fseg_source_hash(void) { return freddie_source_stamp + 17; }
 
 const char *fseg_last_error(const fseg_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
@@ -3260,8 +3608,13 @@ int fseg_create(int device, fseg_ctx **out) {
     e = hipSetDevice(device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_status, sizeof(Status), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_prep, sizeof(PrepStatus), hipHostMallocDefault);
     if (e == hipSuccess) e = hipMalloc(&c->d_status.p, sizeof(Status));
-    for (int i = 0; e == hipSuccess && i <= ST_COUNT; ++i) e = hipEventCreate(&c->ev[i]);
+    if (e == hipSuccess) e = hipMalloc(&c->d_prep.p, sizeof(PrepStatus));
+    if (e == hipSuccess) e = hipMalloc(&c->d_tacc.p, 128);
+    if (e == hipSuccess) e = hipMemsetAsync(c->d_tacc.p, 0, 128, c->stream);
+    for (int i = 0; e == hipSuccess && i < ST_COUNT; ++i) { e = hipEventCreate(&c->ev_b[i]); if (e == hipSuccess) e = hipEventCreate(&c->ev_e[i]); }
+    for (int i = 0; e == hipSuccess && i < 4; ++i) e = hipEventCreate(&c->ev_g[i]);
     for (int i = 0; e == hipSuccess && i < fseg_ctx::kSide; ++i) e = hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking);
     for (int i = 0; e == hipSuccess && i < fseg_ctx::kForkEvents; ++i) e = hipEventCreateWithFlags(&c->fj[i], hipEventDisableTiming);
     if (e == hipSuccess)
@@ -3291,10 +3644,15 @@ int fseg_create(int device, fseg_ctx **out) {
         delete c;
         return FSEG_ERR_HIP;
     }
-    c->d_status.cap = sizeof(Status);
-    { const char *ng = getenv("FSEG_NO_GRAPH"); if (ng && ng[0] == '1') c->use_graph = false; }
-    { const char *nf = getenv("FSEG_NO_FORK"); if (nf && nf[0] == '1') c->use_fork = false; }
-    { const char *nt = getenv("FSEG_NO_TINY"); if (nt && nt[0] == '1') c->use_tiny = false; }
+    c->d_status.cap = sizeof(Status); c->d_prep.cap = sizeof(PrepStatus); c->d_tacc.cap = 128;
+    auto flag = [](const char *name) { const char *v = getenv(name); return v && v[0] == '1'; };
+    if (flag("FSEG_NO_GRAPH")) c->use_graph = false;
+    if (flag("FSEG_NO_FORK")) c->use_fork = false;
+    if (flag("FSEG_NO_TINY")) c->use_tiny = false;
+    if (flag("FSEG_NO_SIZED")) c->use_sized = false;
+    if (flag("FSEG_TRACE")) c->trace = true;
+    if (flag("FSEG_FORCE_SCAN_STALL")) c->force_scan_stall = true;
+    if (flag("FSEG_FORCE_WIDE_DP")) { c->force_wide_dp = true; c->dp_wide_counts = true; }
     { const char *tf = getenv("FSEG_TINY_FROM"); if (tf && tf[0]) c->tiny_from = atoll(tf); }
     { const char *sm = getenv("FSEG_SCAN_SINGLE_MAX"); if (sm && sm[0]) c->scan_single_max = atoll(sm); }
     { const char *sm = getenv("FSEG_PROB_SELF_MAX"); if (sm && sm[0]) c->prob_self_max = atoll(sm); }
@@ -3307,19 +3665,16 @@ void fseg_destroy(fseg_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     drop_graph(c);
-    DevBuf *bufs[] = {&c->d_part_iv_off, &c->d_part_rep_off, &c->d_part_lane_off, &c->d_iv_start, &c->d_iv_end, &c->d_pos_off,
-                      &c->d_iv_part, &c->d_rep_exon_off, &c->d_ex_ts, &c->d_ex_te, &c->d_lane_ex, &c->d_lane_start, &c->d_lane_pmax,
-                      &c->d_tile_desc, &c->d_w_main, &c->d_w_refine, &c->d_h_table, &c->d_y_raw, &c->d_y,
-                      &c->d_flag, &c->d_cflag, &c->d_v, &c->d_scan_state, &c->d_bsum, &c->d_bsum_side, &c->d_g, &c->d_pk, &c->d_pf, &c->d_kp, &c->d_final_flag,
-                      &c->d_blk_iv0, &c->d_edge, &c->d_hc_part, &c->d_hc_p0, &c->d_hc_n, &c->d_hc_glo, &c->d_hc_ghi, &c->d_hc_llo, &c->d_hc_lhi, &c->d_voff, &c->d_chunk_off, &c->d_csum, &c->d_mean, &c->d_thr, &c->d_label_off, &c->d_part_has2, &c->d_rb_part, &c->d_rb_r0, &c->d_cand_off,
-                      &c->d_cand_y, &c->d_fixed0, &c->d_added, &c->d_fixed, &c->d_chosen, &c->d_final_off, &c->d_final_y,
-                      &c->d_final_pos, &c->d_col_thr, &c->d_col_zero, &c->d_cum, &c->d_tile_tot, &c->d_iv_tile0, &c->d_seg_iv, &c->d_seg_prev, &c->d_rseg_c, &c->d_cand_pn, &c->d_cand_ll, &c->d_cand_ln, &c->d_prob_bs, &c->d_prob_iv, &c->d_prob_start,
-                      &c->d_prob_n, &c->d_prob_pair_off, &c->d_prob_tri_off, &c->d_prob_flags, &c->d_prob_chain, &c->d_prob_cov_off,
-                      &c->d_prob_lane_lo, &c->d_prob_lane_n, &c->d_work_active, &c->d_cov,
-                      &c->d_dp_items, &c->d_prob_desc, &c->d_work_pc, &c->d_cls_items, &c->d_pair_thr, &c->d_amb, &c->d_out, &c->d_labels, &c->d_status, &c->d_tacc};
+    Slab *slabs[] = {&c->slab_in, &c->slab_pos, &c->slab_arena};
+    for (Slab *s : slabs) if (s->p) (void)hipFree(s->p);
+    DevBuf *bufs[] = {&c->d_labels, &c->d_sort_tmp, &c->d_w_main, &c->d_w_refine, &c->d_h_table, &c->d_status, &c->d_prep, &c->d_tacc};
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
+    if (c->h_stage.p) (void)hipHostFree(c->h_stage.p);
+    if (c->h_res.p) (void)hipHostFree(c->h_res.p);
     if (c->h_status) (void)hipHostFree(c->h_status);
-    for (int i = 0; i <= ST_COUNT; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    if (c->h_prep) (void)hipHostFree(c->h_prep);
+    for (int i = 0; i < ST_COUNT; ++i) { if (c->ev_b[i]) (void)hipEventDestroy(c->ev_b[i]); if (c->ev_e[i]) (void)hipEventDestroy(c->ev_e[i]); }
+    for (int i = 0; i < 4; ++i) if (c->ev_g[i]) (void)hipEventDestroy(c->ev_g[i]);
     for (int i = 0; i < fseg_ctx::kSide; ++i) if (c->side[i]) { (void)hipStreamSynchronize(c->side[i]); (void)hipStreamDestroy(c->side[i]); }
     for (int i = 0; i < fseg_ctx::kForkEvents; ++i) if (c->fj[i]) (void)hipEventDestroy(c->fj[i]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -3338,6 +3693,7 @@ int fseg_set_params(fseg_ctx *c, const fseg_params *p) {
         return fail(c, FSEG_ERR_ARG, "Gaussian radius out of range");
     if (!p->w_main || !p->w_refine || !p->h_table || p->h_len <= 0) return fail(c, FSEG_ERR_ARG, "missing weight / threshold tables");
     HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     drop_graph(c);
     c->P = *p;
     c->w_main.assign(p->w_main, p->w_main + p->radius_main + 1);
@@ -3349,226 +3705,246 @@ int fseg_set_params(fseg_ctx *c, const fseg_params *p) {
     TRY(upload_vec(c, c->d_h_table, c->h_table.data(), c->h_table.size()));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->have_params = true;
+    c->ran = false;          // results of an earlier run belong to other parameters
     return FSEG_OK;
 }
 
+// One pinned staging image, one host-to-device copy, then the device derives what used to be host work (validation
+// of every exon, the per-partition sort of the reps, the lane list, the histogram chunks' lane ranges).  Returns
+// without waiting for the device: what the device-side validation finds is reported by the first call that waits
+// (fseg_run / fseg_sync / fseg_download ...).
 int fseg_upload(fseg_ctx *c, const fseg_batch *b) {
     if (!c || !b) return FSEG_ERR_ARG;
     if (b->n_part <= 0 || !b->part_iv_off || !b->iv_start || !b->iv_end || !b->part_rep_off || !b->rep_weight ||
         !b->rep_exon_off || !b->ex_ts || !b->ex_te)
         return fail(c, FSEG_ERR_ARG, "fseg_upload: null array or empty batch");
     HIP_TRY(c, hipSetDevice(c->device));
+    Tick tk;
+    // the previous batch's work (and its copy out of the staging image) must be over before its buffers are reused
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->pending = false; c->have_batch = false; c->ran = false; c->fetched = false;
     const int np = b->n_part;
     const i64 K = b->part_iv_off[np], R = b->part_rep_off[np];
-    const i64 I = b->rep_exon_off[R];
     if (b->part_iv_off[0] != 0 || b->part_rep_off[0] != 0 || b->rep_exon_off[0] != 0)
         return fail(c, FSEG_ERR_ARG, "fseg_upload: offsets must start at 0");
-    // validation as read_split() asserts it (py/freddie_segment.py:138-140, :158-161)
+    if (K <= 0 || R < 0) return fail(c, FSEG_ERR_ARG, "fseg_upload: bad offsets");
+    const i64 I = b->rep_exon_off[R];
+    if (I < 0) return fail(c, FSEG_ERR_ARG, "rep_exon_off not monotone");
+    // ---- host pass 1: the partition / interval level (validation as read_split() asserts it, :138-140) and the counts
+    i64 NPOS = 0, n_tiles = 0, lanes = 0, n_rep_blocks = 0;
+    bool expanded = false;
     for (int p = 0; p < np; ++p) {
-        i64 k0 = b->part_iv_off[p], k1 = b->part_iv_off[p + 1];
+        const i64 k0 = b->part_iv_off[p], k1 = b->part_iv_off[p + 1];
         if (k1 <= k0) return fail(c, FSEG_ERR_INPUT, "partition %d has no intervals", p);
         if (b->part_rep_off[p + 1] < b->part_rep_off[p]) return fail(c, FSEG_ERR_ARG, "part_rep_off not monotone");
         for (i64 k = k0; k < k1; ++k) {
             if (!(b->iv_start[k] < b->iv_end[k])) return fail(c, FSEG_ERR_INPUT, "partition %d: interval with start >= end (py/freddie_segment.py:140)", p);
             if (k > k0 && !(b->iv_end[k - 1] < b->iv_start[k])) return fail(c, FSEG_ERR_INPUT, "partition %d: intervals overlap or are unordered (py/freddie_segment.py:138)", p);
+            const i64 len = (i64)b->iv_end[k] - b->iv_start[k] + 1;       // an interval owns positions s..e inclusive (:652-659)
+            NPOS += len;
+            n_tiles += (len + kSmoothTile - 1) / kSmoothTile;
         }
+        n_rep_blocks += (b->part_rep_off[p + 1] - b->part_rep_off[p] + 255) / 256;
     }
-    std::vector<i64> pos_off(K + 1);
-    std::vector<int> iv_part(K);
-    pos_off[0] = 0;
-    for (int p = 0; p < np; ++p)
-        for (i64 k = b->part_iv_off[p]; k < b->part_iv_off[p + 1]; ++k) {
-            iv_part[k] = p;
-            pos_off[k + 1] = pos_off[k] + ((i64)b->iv_end[k] - b->iv_start[k] + 1);
-        }
-    const i64 NPOS = pos_off[K];
     if (NPOS >= 0x7fffffffLL) return fail(c, FSEG_ERR_UNSUPPORTED, "batch has %lld positions; split it (limit 2^31-1 per upload)", (long long)NPOS);
-    bool expanded = false;
-    i64 lanes = 0;
-    std::vector<i64> part_lane_off(np + 1);
-    part_lane_off[0] = 0;
-    for (int p = 0; p < np; ++p) {
-        for (i64 r = b->part_rep_off[p]; r < b->part_rep_off[p + 1]; ++r) {
-            int w = b->rep_weight[r];
-            if (w < 1) return fail(c, FSEG_ERR_INPUT, "rep %lld has weight %d (< 1)", (long long)r, w);
-            if (w != 1) expanded = true;
-            lanes += w;
-            i64 e0 = b->rep_exon_off[r], e1 = b->rep_exon_off[r + 1];
-            if (e1 < e0) return fail(c, FSEG_ERR_ARG, "rep_exon_off not monotone");
-            i64 kk = b->part_iv_off[p];
-            const i64 kend = b->part_iv_off[p + 1];
-            for (i64 e = e0; e < e1; ++e) {
-                if (!(b->ex_ts[e] < b->ex_te[e])) return fail(c, FSEG_ERR_INPUT, "rep %lld: exon with start >= end (py/freddie_segment.py:160)", (long long)r);
-                if (e > e0 && !(b->ex_te[e - 1] <= b->ex_ts[e])) return fail(c, FSEG_ERR_INPUT, "rep %lld: exons out of order (py/freddie_segment.py:158)", (long long)r);
-                // both ends of an exon must be positions of one tint interval (:666-668); exons and intervals are ordered
-                if (e == e0) {
-                    i64 lo = kk, hi = kend;
-                    while (lo < hi) { i64 mid = (lo + hi) >> 1; if (b->iv_end[mid] < b->ex_ts[e]) lo = mid + 1; else hi = mid; }
-                    kk = lo;
-                }
-                while (kk < kend && b->iv_end[kk] < b->ex_ts[e]) ++kk;
-                if (kk >= kend || b->ex_ts[e] < b->iv_start[kk] || b->ex_te[e] > b->iv_end[kk])
-                    return fail(c, FSEG_ERR_INPUT, "rep %lld: an exon does not lie inside one tint interval (py/freddie_segment.py:668)", (long long)r);
-            }
-        }
-        part_lane_off[p + 1] = lanes;
+    for (i64 r = 0; r < R; ++r) {
+        const int w = b->rep_weight[r];
+        if (w < 1) return fail(c, FSEG_ERR_INPUT, "rep %lld has weight %d (< 1)", (long long)r, w);
+        if (w != 1) expanded = true;
+        lanes += w;
+        if (b->rep_exon_off[r + 1] < b->rep_exon_off[r]) return fail(c, FSEG_ERR_ARG, "rep_exon_off not monotone");
     }
     if (lanes >= 0x7fffffffLL) return fail(c, FSEG_ERR_UNSUPPORTED, "too many reads in one upload");
-    // "lanes": every read rep repeated rep_weight times (so that every lane has weight 1), ordered inside
-    // each partition by the rep's first position.  lane_pmax = running maximum of the reps' last positions:
-    // the reads that can overlap a window [g0, g1) are exactly a contiguous lane range (k_fix).
-    std::vector<int> lane_rep((size_t)lanes), lane_start((size_t)lanes), lane_pmax((size_t)lanes);
+    // histogram chunks: consecutive positions of one partition; as large as possible (fewer reads are visited twice)
+    // while still giving >= 512 workgroups
+    int hist_chunk = kHistChunk;
+    while (hist_chunk > 1024 && NPOS / hist_chunk < 512) hist_chunk >>= 1;
+    i64 n_chunks = 0;
     {
-        std::vector<std::pair<int, int>> order;   // (first position, rep)
+        i64 k = 0, pos = 0;
         for (int p = 0; p < np; ++p) {
-            order.clear();
-            for (i64 r = b->part_rep_off[p]; r < b->part_rep_off[p + 1]; ++r) {
-                if (b->rep_exon_off[r + 1] <= b->rep_exon_off[r]) return fail(c, FSEG_ERR_INPUT, "rep %lld has no exons", (long long)r);
-                order.emplace_back(b->ex_ts[b->rep_exon_off[r]], (int)r);
-            }
-            std::sort(order.begin(), order.end());
-            i64 l = part_lane_off[p];
-            int run_max = -0x7fffffff - 1;
-            for (const auto &o : order) {
-                int last = b->ex_te[b->rep_exon_off[o.second + 1] - 1];
-                if (last > run_max) run_max = last;
-                for (int q = 0; q < b->rep_weight[o.second]; ++q, ++l) {
-                    lane_rep[(size_t)l] = o.second; lane_start[(size_t)l] = o.first; lane_pmax[(size_t)l] = run_max;
-                }
-            }
+            i64 Pp = 0;
+            for (k = b->part_iv_off[p]; k < b->part_iv_off[p + 1]; ++k) Pp += (i64)b->iv_end[k] - b->iv_start[k] + 1;
+            n_chunks += (Pp + hist_chunk - 1) / hist_chunk;
+            pos += Pp;
         }
+        (void)pos;
     }
-    std::vector<TileDesc> tile_desc;
-    std::vector<int> iv_tile0((size_t)K);
-    for (i64 k = 0; k < K; ++k) {
-        i64 len = pos_off[k + 1] - pos_off[k];
-        iv_tile0[(size_t)k] = (int)tile_desc.size();
-        for (i64 y = 0; y < len; y += kSmoothTile) tile_desc.push_back(TileDesc{pos_off[k], (int)y, (int)len});
-    }
-    c->n_part = np; c->K = K; c->R = R; c->I = I; c->NPOS = NPOS; c->LANES = lanes; c->expanded = expanded;
-    c->n_tiles = (int)tile_desc.size();
-    c->part_iv_off.assign(b->part_iv_off, b->part_iv_off + np + 1);
-    c->part_rep_off.assign(b->part_rep_off, b->part_rep_off + np + 1);
-    c->part_lane_off = part_lane_off;
-    c->pos_off = pos_off;
-    c->iv_start_h.assign(b->iv_start, b->iv_start + K);
-    TRY(upload_vec(c, c->d_part_iv_off, b->part_iv_off, (size_t)np + 1));
-    TRY(upload_vec(c, c->d_part_rep_off, b->part_rep_off, (size_t)np + 1));
-    TRY(upload_vec(c, c->d_part_lane_off, part_lane_off.data(), (size_t)np + 1));
-    TRY(upload_vec(c, c->d_iv_start, b->iv_start, (size_t)K));
-    TRY(upload_vec(c, c->d_iv_end, b->iv_end, (size_t)K));
-    TRY(upload_vec(c, c->d_pos_off, pos_off.data(), (size_t)K + 1));
-    TRY(upload_vec(c, c->d_iv_part, iv_part.data(), (size_t)K));
-    TRY(upload_vec(c, c->d_rep_exon_off, b->rep_exon_off, (size_t)R + 1));
-    TRY(upload_vec(c, c->d_ex_ts, b->ex_ts, (size_t)I));
-    TRY(upload_vec(c, c->d_ex_te, b->ex_te, (size_t)I));
-    {   // exon range of every lane's rep, so the per-read walks start with one load instead of lane -> rep -> offsets
-        std::vector<longlong2> lane_ex((size_t)lanes);
-        for (i64 l = 0; l < lanes; ++l) {
-            const int r = lane_rep[(size_t)l];
-            lane_ex[(size_t)l] = make_longlong2(b->rep_exon_off[r], b->rep_exon_off[r + 1]);
-        }
-        TRY(upload_vec(c, c->d_lane_ex, lane_ex.data(), lane_ex.size()));
-    }
-    TRY(upload_vec(c, c->d_lane_start, lane_start.data(), lane_start.size()));
-    TRY(upload_vec(c, c->d_lane_pmax, lane_pmax.data(), lane_pmax.size()));
+    const i64 nb = scan_blocks(NPOS);
+    if (n_tiles >= 0x7fffffffLL || n_chunks >= 0x7fffffffLL) return fail(c, FSEG_ERR_UNSUPPORTED, "batch too large");
+    // ---- the input slab: [uploaded part, mirrored by the pinned staging image][device-derived part]
+    Carve in;
+    in.add(c->d_part_iv_off, ((size_t)np + 1) * 8);
+    in.add(c->d_part_rep_off, ((size_t)np + 1) * 8);
+    in.add(c->d_part_lane_off, ((size_t)np + 1) * 8);
+    in.add(c->d_iv_start, (size_t)K * 4);
+    in.add(c->d_iv_end, (size_t)K * 4);
+    in.add(c->d_pos_off, ((size_t)K + 1) * 8);
+    in.add(c->d_iv_part, (size_t)K * 4);
+    in.add(c->d_iv_tile0, (size_t)K * 4);
+    in.add(c->d_tile_desc, (size_t)n_tiles * sizeof(TileDesc));
+    in.add(c->d_blk_iv0, ((size_t)nb + 1) * 4);
+    in.add(c->d_rb_part, (size_t)n_rep_blocks * 4);
+    in.add(c->d_rb_r0, (size_t)n_rep_blocks * 4);
+    in.add(c->d_hc_part, (size_t)n_chunks * 4);
+    in.add(c->d_hc_p0, (size_t)n_chunks * 8);
+    in.add(c->d_hc_n, (size_t)n_chunks * 4);
+    in.add(c->d_hc_glo, (size_t)n_chunks * 4);
+    in.add(c->d_hc_ghi, (size_t)n_chunks * 4);
+    in.add(c->d_rep_exon_off, ((size_t)R + 1) * 8);
+    in.add(c->d_rep_weight, (size_t)R * 4);
+    in.add(c->d_ex_ts, (size_t)I * 4);
+    in.add(c->d_ex_te, (size_t)I * 4);
+    const size_t up_bytes = in.total;
+    in.add(c->d_lane_ex, (size_t)lanes * 16);
+    in.add(c->d_lane_start, (size_t)lanes * 4);
+    in.add(c->d_lane_pmax, (size_t)lanes * 4);
+    in.add(c->d_hc_llo, (size_t)n_chunks * 8);
+    in.add(c->d_hc_lhi, (size_t)n_chunks * 8);
+    in.add(c->d_edge, (size_t)NPOS + 64);
+    in.add(c->d_key_a, (size_t)R * 8);
+    in.add(c->d_key_b, (size_t)R * 8);
+    in.add(c->d_val_a, (size_t)R * 4);
+    in.add(c->d_val_b, (size_t)R * 4);
+    in.add(c->d_rep_last, (size_t)R * 4);
+    TRY(reserve(c, c->slab_in, in.total));
+    in.bind(c->slab_in);
+    TRY(reserve_host(c, c->h_stage, up_bytes));
+    char *stage = c->h_stage.as<char>();
+    auto host_of = [&](const DevBuf &d) { return stage + (static_cast<char *>(d.p) - static_cast<char *>(c->slab_in.p)); };
+    const double t_plan = tk.ms();
+    // ---- host pass 2: the small derived tables, written straight into the staging image
     {
-        std::vector<int> rb_part, rb_r0;     // blocks of 256 read reps of one partition (label kernel)
-        for (int p = 0; p < np; ++p)
-            for (i64 r = b->part_rep_off[p]; r < b->part_rep_off[p + 1]; r += 256) { rb_part.push_back(p); rb_r0.push_back((int)r); }
-        c->n_rep_blocks = (int)rb_part.size();
-        TRY(upload_vec(c, c->d_rb_part, rb_part.data(), rb_part.size()));
-        TRY(upload_vec(c, c->d_rb_r0, rb_r0.data(), rb_r0.size()));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-    }
-    {   // histogram chunks: kHistChunk consecutive positions of one partition, with the genomic position of the
-        // chunk's first and last position (a chunk may span several intervals of its partition)
-        std::vector<int> hc_part, hc_n, hc_glo, hc_ghi;
-        std::vector<i64> hc_p0, hc_llo, hc_lhi;
-        // chunk size: as large as possible (fewer reads are visited twice) while still giving >= 512 workgroups
-        int hist_chunk = kHistChunk;
-        while (hist_chunk > 1024 && NPOS / hist_chunk < 512) hist_chunk >>= 1;
+        i64 *h_pos_off = reinterpret_cast<i64 *>(host_of(c->d_pos_off)), *h_lane_off = reinterpret_cast<i64 *>(host_of(c->d_part_lane_off));
+        int *h_iv_part = reinterpret_cast<int *>(host_of(c->d_iv_part)), *h_iv_tile0 = reinterpret_cast<int *>(host_of(c->d_iv_tile0));
+        TileDesc *h_tile = reinterpret_cast<TileDesc *>(host_of(c->d_tile_desc));
+        int *h_blk = reinterpret_cast<int *>(host_of(c->d_blk_iv0));
+        int *h_rb_part = reinterpret_cast<int *>(host_of(c->d_rb_part)), *h_rb_r0 = reinterpret_cast<int *>(host_of(c->d_rb_r0));
+        int *h_hc_part = reinterpret_cast<int *>(host_of(c->d_hc_part)), *h_hc_n = reinterpret_cast<int *>(host_of(c->d_hc_n));
+        int *h_hc_glo = reinterpret_cast<int *>(host_of(c->d_hc_glo)), *h_hc_ghi = reinterpret_cast<int *>(host_of(c->d_hc_ghi));
+        i64 *h_hc_p0 = reinterpret_cast<i64 *>(host_of(c->d_hc_p0));
+        h_pos_off[0] = 0; h_lane_off[0] = 0;
+        i64 t = 0, rb = 0, ch = 0, l = 0, bq = 0;
         for (int p = 0; p < np; ++p) {
             const i64 k0 = b->part_iv_off[p], k1 = b->part_iv_off[p + 1];
-            const i64 P0 = pos_off[k0], P1 = pos_off[k1];
+            for (i64 k = k0; k < k1; ++k) {
+                const i64 len = (i64)b->iv_end[k] - b->iv_start[k] + 1;
+                h_iv_part[k] = p;
+                h_pos_off[k + 1] = h_pos_off[k] + len;
+                h_iv_tile0[k] = (int)t;
+                for (i64 y = 0; y < len; y += kSmoothTile) h_tile[t++] = TileDesc{h_pos_off[k], (int)y, (int)len};
+                // interval of the first position of every scan block
+                for (; bq < nb && bq * kScanBlock < h_pos_off[k + 1]; ++bq) h_blk[bq] = (int)k;
+            }
+            for (i64 r = b->part_rep_off[p]; r < b->part_rep_off[p + 1]; r += 256) { h_rb_part[rb] = p; h_rb_r0[rb] = (int)r; ++rb; }
+            for (i64 r = b->part_rep_off[p]; r < b->part_rep_off[p + 1]; ++r) l += b->rep_weight[r];
+            h_lane_off[p + 1] = l;
+            // histogram chunks of the partition, with the genomic position of the chunk's first and last position (a
+            // chunk may span several intervals of its partition)
+            const i64 P0 = h_pos_off[k0], P1 = h_pos_off[k1];
             i64 k = k0;
             for (i64 q0 = P0; q0 < P1; q0 += hist_chunk) {
-                const i64 q1 = std::min<i64>(q0 + hist_chunk, P1) - 1;       // last position of the chunk
-                while (pos_off[k + 1] <= q0) ++k;
-                const int glo = b->iv_start[k] + (int)(q0 - pos_off[k]);
+                const i64 q1 = std::min<i64>(q0 + hist_chunk, P1) - 1;
+                while (h_pos_off[k + 1] <= q0) ++k;
                 i64 kk = k;
-                while (pos_off[kk + 1] <= q1) ++kk;
-                const int ghi = b->iv_start[kk] + (int)(q1 - pos_off[kk]);
-                hc_part.push_back(p); hc_p0.push_back(q0); hc_n.push_back((int)(q1 - q0 + 1));
-                hc_glo.push_back(glo); hc_ghi.push_back(ghi);
-                // lanes of the partition whose [first, last] position range meets [glo, ghi]
-                const int *pm = lane_pmax.data(), *ls = lane_start.data();
-                const i64 L0 = part_lane_off[p], L1 = part_lane_off[p + 1];
-                const i64 llo = std::lower_bound(pm + L0, pm + L1, glo) - pm;
-                const i64 lhi = std::upper_bound(ls + llo, ls + L1, ghi) - ls;
-                hc_llo.push_back(llo); hc_lhi.push_back(lhi);
+                while (h_pos_off[kk + 1] <= q1) ++kk;
+                h_hc_part[ch] = p; h_hc_p0[ch] = q0; h_hc_n[ch] = (int)(q1 - q0 + 1);
+                h_hc_glo[ch] = b->iv_start[k] + (int)(q0 - h_pos_off[k]);
+                h_hc_ghi[ch] = b->iv_start[kk] + (int)(q1 - h_pos_off[kk]);
+                ++ch;
             }
         }
-        c->n_hist_chunks = (int)hc_part.size();
-        TRY(upload_vec(c, c->d_hc_part, hc_part.data(), hc_part.size()));
-        TRY(upload_vec(c, c->d_hc_p0, hc_p0.data(), hc_p0.size()));
-        TRY(upload_vec(c, c->d_hc_n, hc_n.data(), hc_n.size()));
-        TRY(upload_vec(c, c->d_hc_glo, hc_glo.data(), hc_glo.size()));
-        TRY(upload_vec(c, c->d_hc_ghi, hc_ghi.data(), hc_ghi.size()));
-        TRY(upload_vec(c, c->d_hc_llo, hc_llo.data(), hc_llo.size()));
-        TRY(upload_vec(c, c->d_hc_lhi, hc_lhi.data(), hc_lhi.size()));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        h_blk[nb] = (int)(K - 1);
     }
+    const double t_tables = tk.ms();
+    // ---- the caller's arrays
+    memcpy(host_of(c->d_part_iv_off), b->part_iv_off, ((size_t)np + 1) * 8);
+    memcpy(host_of(c->d_part_rep_off), b->part_rep_off, ((size_t)np + 1) * 8);
+    memcpy(host_of(c->d_iv_start), b->iv_start, (size_t)K * 4);
+    memcpy(host_of(c->d_iv_end), b->iv_end, (size_t)K * 4);
+    memcpy(host_of(c->d_rep_exon_off), b->rep_exon_off, ((size_t)R + 1) * 8);
+    memcpy(host_of(c->d_rep_weight), b->rep_weight, (size_t)R * 4);
+    memcpy(host_of(c->d_ex_ts), b->ex_ts, (size_t)I * 4);
+    memcpy(host_of(c->d_ex_te), b->ex_te, (size_t)I * 4);
+    const double t_copy = tk.ms();
+    c->n_part = np; c->K = K; c->R = R; c->I = I; c->NPOS = NPOS; c->LANES = lanes; c->expanded = expanded;
+    c->n_tiles = (int)n_tiles; c->n_hist_chunks = (int)n_chunks; c->n_rep_blocks = (int)n_rep_blocks;
+    c->part_iv_off.assign(b->part_iv_off, b->part_iv_off + np + 1);
+    c->part_rep_off.assign(b->part_rep_off, b->part_rep_off + np + 1);
+    hipStream_t s = c->stream;
+    HIP_TRY(c, hipMemcpyAsync(c->slab_in.p, stage, up_bytes, hipMemcpyHostToDevice, s));
+    // ---- device-side preparation
     {
-        const i64 nb = (NPOS + kScanBlock - 1) / kScanBlock;
-        std::vector<int> blk_iv0((size_t)nb + 1);
-        i64 k = 0;
-        for (i64 bq = 0; bq < nb; ++bq) {
-            while (pos_off[k + 1] <= bq * kScanBlock) ++k;
-            blk_iv0[(size_t)bq] = (int)k;
-        }
-        blk_iv0[(size_t)nb] = (int)(K - 1);
-        TRY(upload_vec(c, c->d_blk_iv0, blk_iv0.data(), blk_iv0.size()));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        PrepStatus init;
+        init.err = 0; init.pad = 0;
+        for (int q = 0; q < 4; ++q) init.bad_rep[q] = 0x7fffffffffffffffLL;
+        *c->h_prep = init;
+        HIP_TRY(c, hipMemcpyAsync(c->d_prep.p, c->h_prep, sizeof(PrepStatus), hipMemcpyHostToDevice, s));
+        c->prep_checked = false;
     }
-    TRY(ensure(c, c->d_part_has2, ((size_t)np + 1) * 4));
-    TRY(upload_vec(c, c->d_iv_tile0, iv_tile0.data(), iv_tile0.size()));
-    TRY(ensure(c, c->d_tile_tot, (tile_desc.size() + 1) * 4));
-    TRY(upload_vec(c, c->d_tile_desc, tile_desc.data(), tile_desc.size()));
-    // position-sized work buffers
-    size_t np8 = (size_t)NPOS + 64;
-    TRY(ensure(c, c->d_y_raw, np8 * 4)); TRY(ensure(c, c->d_cum, np8 * 4)); TRY(ensure(c, c->d_y, np8 * 8)); TRY(ensure(c, c->d_flag, np8)); TRY(ensure(c, c->d_cflag, np8));
-    TRY(ensure(c, c->d_v, np8 * 8));
-    TRY(ensure(c, c->d_scan_state, ((size_t)scan_blocks(NPOS) * 3 + 1) * 8));
-    TRY(ensure(c, c->d_bsum, ((size_t)scan_blocks(NPOS) + 2) * 4));
-    TRY(ensure(c, c->d_bsum_side, ((size_t)scan_blocks(NPOS) + 2) * 4));
-    TRY(ensure(c, c->d_g, np8 * 8)); TRY(ensure(c, c->d_pk, np8 * 4)); TRY(ensure(c, c->d_pf, np8)); TRY(ensure(c, c->d_kp, np8));
-    TRY(ensure(c, c->d_final_flag, np8));
-    TRY(ensure(c, c->d_edge, np8));
-    HIP_TRY(c, hipMemsetAsync(c->d_edge.p, 0, np8, c->stream));
-    hipLaunchKernelGGL(k_edges, dim3(grid_for(K, 256, 4096)), dim3(256), 0, c->stream, K, c->d_pos_off.as<i64>(), c->d_edge.as<unsigned char>());
-    TRY(ensure(c, c->d_voff, ((size_t)np + 2) * 8)); TRY(ensure(c, c->d_chunk_off, ((size_t)np + 2) * 8));
-    TRY(ensure(c, c->d_mean, ((size_t)np + 1) * 8)); TRY(ensure(c, c->d_thr, ((size_t)np + 1) * 8));
-    TRY(ensure(c, c->d_label_off, ((size_t)np + 2) * 8));
-    // candidate-sized: candidates and finals are distinct positions, so NPOS bounds them
-    TRY(ensure(c, c->d_cand_off, ((size_t)K + 2) * 8)); TRY(ensure(c, c->d_final_off, ((size_t)K + 2) * 8));
-    TRY(ensure(c, c->d_cand_y, np8 * 4)); TRY(ensure(c, c->d_fixed0, np8)); TRY(ensure(c, c->d_added, np8));
-    TRY(ensure(c, c->d_fixed, np8)); TRY(ensure(c, c->d_chosen, np8));
-    TRY(ensure(c, c->d_final_y, np8 * 4)); TRY(ensure(c, c->d_final_pos, np8 * 4)); TRY(ensure(c, c->d_col_thr, np8 * 8)); TRY(ensure(c, c->d_col_zero, np8));
-    TRY(ensure(c, c->d_seg_iv, np8 * 4)); TRY(ensure(c, c->d_seg_prev, np8 * 4)); TRY(ensure(c, c->d_rseg_c, np8 * 4));
-    TRY(ensure(c, c->d_cand_pn, np8 * 4)); TRY(ensure(c, c->d_cand_ll, np8 * 4)); TRY(ensure(c, c->d_cand_ln, np8 * 4));
-    TRY(ensure(c, c->d_prob_bs, ((size_t)NPOS / kProbBlock + 2) * kProbCols * 8));
-    // first-guess arena capacities; fseg_sync() grows them if the run reports an overflow
-    auto atleast = [](i64 &cap, i64 v) { if (cap < v) cap = v; };
-    atleast(c->chunk_cap, NPOS / 8192 + np + 8);
-    atleast(c->prob_cap, 1024); atleast(c->work_cap, 1024); atleast(c->pair_cap, 1 << 16); atleast(c->tri_cap, 1 << 18);
-    atleast(c->label_cap, 1 << 16); atleast(c->cov_cap, 1 << 18);
-    TRY(alloc_arenas(c));
-    TRY(ensure(c, c->d_tacc, 128));
-    HIP_TRY(c, hipMemsetAsync(c->d_tacc.p, 0, 128, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (R > 0) {
+        hipLaunchKernelGGL(k_prep_reps, dim3(grid_for(n_rep_blocks, 1, 65536)), dim3(256), 0, s, (int)n_rep_blocks, c->d_rb_part.as<int>(),
+                           c->d_rb_r0.as<int>(), c->d_part_rep_off.as<i64>(), c->d_part_iv_off.as<i64>(), c->d_iv_start.as<int>(),
+                           c->d_iv_end.as<int>(), c->d_rep_exon_off.as<i64>(), c->d_ex_ts.as<int>(), c->d_ex_te.as<int>(),
+                           c->d_key_a.as<u64>(), c->d_val_a.as<int>(), c->d_rep_last.as<int>(), c->d_prep.as<PrepStatus>());
+        unsigned end_bit = 33;
+        while (end_bit < 64 && ((u64)np >> (end_bit - 32)) != 0) ++end_bit;
+        size_t tmp_bytes = 0;
+        HIP_TRY(c, fseg_sort_pairs(nullptr, &tmp_bytes, c->d_key_a.as<u64>(), c->d_key_b.as<u64>(), c->d_val_a.as<int>(), c->d_val_b.as<int>(),
+                                   (size_t)R, end_bit, s));
+        TRY(ensure(c, c->d_sort_tmp, tmp_bytes));
+        HIP_TRY(c, fseg_sort_pairs(c->d_sort_tmp.p, &tmp_bytes, c->d_key_a.as<u64>(), c->d_key_b.as<u64>(), c->d_val_a.as<int>(),
+                                   c->d_val_b.as<int>(), (size_t)R, end_bit, s));
+        hipLaunchKernelGGL(k_lanes, dim3(grid_for(np, 1, 65536)), dim3(256), 0, s, np, c->d_part_rep_off.as<i64>(), c->d_part_lane_off.as<i64>(),
+                           c->d_key_b.as<u64>(), c->d_val_b.as<int>(), c->d_rep_weight.as<int>(), c->d_rep_last.as<int>(),
+                           c->d_rep_exon_off.as<i64>(), c->d_lane_ex.as<longlong2>(), c->d_lane_start.as<int>(), c->d_lane_pmax.as<int>());
+    }
+    hipLaunchKernelGGL(k_hist_ranges, dim3(grid_for(n_chunks, 256, 4096)), dim3(256), 0, s, (int)n_chunks, c->d_hc_part.as<int>(),
+                       c->d_hc_glo.as<int>(), c->d_hc_ghi.as<int>(), c->d_part_lane_off.as<i64>(), c->d_lane_start.as<int>(),
+                       c->d_lane_pmax.as<int>(), c->d_hc_llo.as<i64>(), c->d_hc_lhi.as<i64>());
+    HIP_TRY(c, hipMemsetAsync(c->d_edge.p, 0, (size_t)NPOS + 64, s));
+    hipLaunchKernelGGL(k_edges, dim3(grid_for(K, 256, 4096)), dim3(256), 0, s, K, c->d_pos_off.as<i64>(), c->d_edge.as<unsigned char>());
+    HIP_TRY(c, hipMemcpyAsync(c->h_prep, c->d_prep.p, sizeof(PrepStatus), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipGetLastError());
+    // ---- position- and candidate-sized work buffers (candidates and finals are distinct positions, so NPOS bounds them)
+    {
+        const size_t np8 = (size_t)NPOS + 64;
+        auto atleast = [](i64 &cap, i64 v) { if (cap < v) cap = v; };
+        atleast(c->chunk_cap, NPOS / 8192 + np + 8);              // an upper bound, not a guess
+        Carve cv;
+        cv.add(c->d_y_raw, np8 * 4); cv.add(c->d_cum, np8 * 4); cv.add(c->d_y, np8 * 8); cv.add(c->d_flag, np8); cv.add(c->d_cflag, np8);
+        cv.add(c->d_v, np8 * 8);
+        cv.add(c->d_scan_state, ((size_t)nb * 3 + 1) * 8);
+        cv.add(c->d_bsum, ((size_t)nb + 2) * 4);
+        cv.add(c->d_bsum_side, ((size_t)nb + 2) * 4);
+        cv.add(c->d_g, np8 * 8); cv.add(c->d_pk, np8 * 4); cv.add(c->d_pf, np8); cv.add(c->d_kp, np8);
+        cv.add(c->d_final_flag, np8);
+        cv.add(c->d_part_has2, ((size_t)np + 1) * 4);
+        cv.add(c->d_tile_tot, ((size_t)n_tiles + 1) * 4);
+        cv.add(c->d_voff, ((size_t)np + 2) * 8); cv.add(c->d_chunk_off, ((size_t)np + 2) * 8);
+        cv.add(c->d_mean, ((size_t)np + 1) * 8); cv.add(c->d_thr, ((size_t)np + 1) * 8);
+        cv.add(c->d_label_off, ((size_t)np + 2) * 8);
+        cv.add(c->d_csum, (size_t)c->chunk_cap * 16);     // chunk sums of both passes
+        cv.add(c->d_cand_off, ((size_t)K + 2) * 8); cv.add(c->d_final_off, ((size_t)K + 2) * 8);
+        cv.add(c->d_cand_y, np8 * 4); cv.add(c->d_fixed0, np8); cv.add(c->d_added, np8);
+        cv.add(c->d_fixed, np8); cv.add(c->d_chosen, np8);
+        cv.add(c->d_final_y, np8 * 4); cv.add(c->d_final_pos, np8 * 4); cv.add(c->d_col_thr, np8 * 8); cv.add(c->d_col_zero, np8);
+        cv.add(c->d_seg_iv, np8 * 4); cv.add(c->d_seg_prev, np8 * 4); cv.add(c->d_rseg_c, np8 * 4);
+        cv.add(c->d_cand_pn, np8 * 4); cv.add(c->d_cand_ll, np8 * 4); cv.add(c->d_cand_ln, np8 * 4);
+        cv.add(c->d_prob_bs, ((size_t)NPOS / kProbBlock + 2) * kProbCols * 8);
+        TRY(reserve(c, c->slab_pos, cv.total));
+        cv.bind(c->slab_pos);
+        // arena capacities: a sized first run makes them exact; without it (FSEG_NO_SIZED) these are first guesses that
+        // finish_run() grows
+        atleast(c->prob_cap, 1024); atleast(c->work_cap, 1024); atleast(c->pair_cap, 1 << 16); atleast(c->tri_cap, 1 << 18);
+        atleast(c->label_cap, 1 << 16); atleast(c->cov_cap, 1 << 18);
+        TRY(alloc_arenas(c));
+    }
     drop_graph(c);
-    c->have_batch = true; c->ran = false; c->pending = false;
+    c->have_batch = true;
+    if (c->trace)
+        fprintf(stderr, "[fseg] upload: plan %.3f ms, tables %.3f ms, copy-in %.3f ms (%.1f MB), enqueue %.3f ms; %lld positions, %lld reps, %lld exons\n",
+                t_plan, t_tables, t_copy, up_bytes / 1e6, tk.ms(), (long long)NPOS, (long long)R, (long long)I);
     return FSEG_OK;
 }
 
@@ -3577,13 +3953,18 @@ int fseg_run(fseg_ctx *c) {
     if (!c->have_params || !c->have_batch) return fail(c, FSEG_ERR_ARG, "fseg_run: set parameters and upload a batch first");
     HIP_TRY(c, hipSetDevice(c->device));
     if (c->pending) TRY(finish_run(c));
+    c->fetched = false;
+    // first run of a batch: piecewise with exact arena sizes; afterwards the sizes are known and the same launch
+    // sequence is replayed (as a hipGraph unless disabled)
+    if (!c->ran && c->use_sized) return run_sized(c);
+    c->last_sized = false;
     if (c->use_graph) {
         if (c->n_graphs == 0) {
             const int want = c->profiling ? 2 : 1;
             bool ok = true;
             for (int g = 0; g < want && ok; ++g) {
                 HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-                int rc = enqueue_run(c, want == 1 ? 0 : (g == 0 ? 1 : 3));
+                int rc = enqueue_run(c, want == 1 ? SEG_ALL : (g == 0 ? (SEG_PRE1 | SEG_PRE2) : (SEG_POST1 | SEG_POST2 | SEG_STATUS)));
                 hipError_t e = hipStreamEndCapture(c->stream, &c->graph[g]);
                 if (rc == FSEG_OK && e == hipSuccess) e = hipGraphInstantiate(&c->graph_exec[g], c->graph[g], nullptr, nullptr, 0);
                 ok = rc == FSEG_OK && e == hipSuccess;
@@ -3601,18 +3982,18 @@ int fseg_run(fseg_ctx *c) {
             return FSEG_OK;
         }
         if (c->n_graphs == 2) {
-            HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+            HIP_TRY(c, hipEventRecord(c->ev_g[0], c->stream));
             HIP_TRY(c, hipGraphLaunch(c->graph_exec[0], c->stream));
-            HIP_TRY(c, hipEventRecord(c->ev[ST_SCORE], c->stream));
-            TRY(enqueue_run(c, 2));
-            HIP_TRY(c, hipEventRecord(c->ev[ST_SCORE + 1], c->stream));
+            HIP_TRY(c, hipEventRecord(c->ev_g[1], c->stream));
+            TRY(enqueue_run(c, SEG_SCORE));
+            HIP_TRY(c, hipEventRecord(c->ev_g[2], c->stream));
             HIP_TRY(c, hipGraphLaunch(c->graph_exec[1], c->stream));
-            HIP_TRY(c, hipEventRecord(c->ev[ST_COUNT], c->stream));
+            HIP_TRY(c, hipEventRecord(c->ev_g[3], c->stream));
             c->pending = true;
             return FSEG_OK;
         }
     }
-    TRY(enqueue_run(c));
+    TRY(enqueue_run(c, SEG_ALL));
     c->pending = true;
     return FSEG_OK;
 }
@@ -3622,6 +4003,7 @@ int fseg_sync(fseg_ctx *c) {
     HIP_TRY(c, hipSetDevice(c->device));
     if (c->pending) return finish_run(c);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->have_batch) TRY(check_prep(c));
     return FSEG_OK;
 }
 
@@ -3634,6 +4016,44 @@ int fseg_get_sizes(fseg_ctx *c, fseg_sizes *out) {
     out->n_cand = (int64_t)c->h_status->n_cand;
     out->n_problems = (int64_t)c->h_status->n_prob;
     out->n_positions = c->NPOS;
+    return FSEG_OK;
+}
+
+// Results of the last run in the context's pinned host buffers (one device-to-host copy each, no pageable staging):
+// valid until the next fseg_run / fseg_upload / fseg_results on this context.
+int fseg_results(fseg_ctx *c, const int64_t **part_final_off, const int32_t **final_pos, const int64_t **label_off,
+                 const uint8_t **labels) {
+    if (!c) return FSEG_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->pending && !c->ran) return fail(c, FSEG_ERR_ARG, "no completed run");
+    hipStream_t s = c->stream;
+    if (!c->fetched) {
+        // a sized run knows its result sizes before its last kernels have finished: the copies queue up right behind them
+        if (!(c->pending && c->last_sized)) TRY(fseg_sync(c));
+        if (!c->pending && !c->ran) return fail(c, FSEG_ERR_ARG, "no completed run");
+        const size_t nf = (size_t)c->h_status->n_final, lb = (size_t)c->h_status->label_bytes;
+        size_t off = 0;
+        auto take = [&](int i, size_t bytes) { c->res_off[i] = off; off = (off + bytes + 255) & ~(size_t)255; };
+        take(0, ((size_t)c->K + 1) * 8); take(1, nf * 4); take(2, ((size_t)c->n_part + 1) * 8); take(3, lb);
+        TRY(reserve_host(c, c->h_res, off));
+        char *h = c->h_res.as<char>();
+        HIP_TRY(c, hipMemcpyAsync(h + c->res_off[0], c->d_final_off.p, ((size_t)c->K + 1) * 8, hipMemcpyDeviceToHost, s));
+        if (nf) HIP_TRY(c, hipMemcpyAsync(h + c->res_off[1], c->d_final_pos.p, nf * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipMemcpyAsync(h + c->res_off[2], c->d_label_off.p, ((size_t)c->n_part + 1) * 8, hipMemcpyDeviceToHost, s));
+        if (lb) HIP_TRY(c, hipMemcpyAsync(h + c->res_off[3], c->d_labels.p, lb, hipMemcpyDeviceToHost, s));
+        if (c->pending) TRY(finish_run(c));
+        else HIP_TRY(c, hipStreamSynchronize(s));
+        if (!c->ran) return fail(c, FSEG_ERR_ARG, "no completed run");
+        const i64 *fo = reinterpret_cast<const i64 *>(h + c->res_off[0]);
+        c->res_pfo.resize((size_t)c->n_part + 1);
+        for (int p = 0; p <= c->n_part; ++p) c->res_pfo[(size_t)p] = fo[(size_t)c->part_iv_off[(size_t)p]];
+        c->fetched = true;
+    }
+    const char *h = c->h_res.as<char>();
+    if (part_final_off) *part_final_off = reinterpret_cast<const int64_t *>(c->res_pfo.data());
+    if (final_pos) *final_pos = reinterpret_cast<const int32_t *>(h + c->res_off[1]);
+    if (label_off) *label_off = reinterpret_cast<const int64_t *>(h + c->res_off[2]);
+    if (labels) *labels = reinterpret_cast<const uint8_t *>(h + c->res_off[3]);
     return FSEG_OK;
 }
 
@@ -3690,6 +4110,9 @@ int fseg_tap(fseg_ctx *c, int what, void *dst, int64_t cap_bytes, int64_t *n_byt
             if (dst && cap_bytes > 0) memcpy(dst, packed.data(), (size_t)(bytes < cap_bytes ? bytes : cap_bytes));
             return FSEG_OK;
         }
+        case FSEG_TAP_LANE_START: src = c->d_lane_start.p; bytes = c->LANES * 4; break;
+        case FSEG_TAP_LANE_PMAX: src = c->d_lane_pmax.p; bytes = c->LANES * 4; break;
+        case FSEG_TAP_LANE_EXONS: src = c->d_lane_ex.p; bytes = c->LANES * 16; break;
         default: return fail(c, FSEG_ERR_ARG, "unknown tap %d", what);
     }
     *n_bytes = bytes;

@@ -35,13 +35,8 @@ class IsoformsError(RuntimeError):
 
 
 def build(force=False, verbose=False):
-    import subprocess
-    deps = ISO_SRC + [os.path.join(_build.INCLUDE, "freddie_isoforms.h")]
-    if force or _build._stale(ISO_SO, deps):
-        cmd = ["hipcc", "-O3", "--offload-arch=gfx950", "-shared", "-fPIC", "-I", _build.INCLUDE, "-o", ISO_SO] + ISO_SRC
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
+    cmd = ["hipcc", "-O3", "--offload-arch=gfx950", "-shared", "-fPIC", "-I", _build.INCLUDE, "-o", ISO_SO] + ISO_SRC
+    _build.build_stamped(ISO_SO, cmd, ISO_SRC + [os.path.join(_build.INCLUDE, "freddie_isoforms.h")], force, verbose)
     return ISO_SO
 
 

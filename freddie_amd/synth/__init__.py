@@ -36,9 +36,9 @@ class _Params(ctypes.Structure):
 
 
 def build(force=False):
+    from .. import build as _build
     src = os.path.join(_HERE, "synth.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
-        subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-o", _SO, src])
+    _build.build_stamped(_SO, ["gcc", "-O2", "-shared", "-fPIC", "-o", _SO, src], [src], force)
     return _SO
 
 

@@ -308,3 +308,8 @@ int fsynth_write_tsv(const fsynth *g, const char *split_path, const char *reads_
     }
     return 0;
 }
+
+#ifdef FREDDIE_SOURCE_HASH
+/* what this binary was built from (freddie_amd/build.py looks for the marker in the file) */
+static const char freddie_source_stamp[] __attribute__((used)) = "FREDDIE_SRC_HASH=" FREDDIE_SOURCE_HASH;
+#endif

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define FSEG_ABI_VERSION 1
+#define FSEG_ABI_VERSION 2
 
 /* status codes */
 #define FSEG_OK 0
@@ -86,6 +86,8 @@ typedef struct {
 } fseg_sizes;
 
 int fseg_abi_version(void);
+/* Hash of the sources this binary was built from (freddie_amd/build.py compares it with the tree's). */
+const char *fseg_source_hash(void);
 
 /* Create / destroy a context bound to HIP device `device`.  Fails (FSEG_ERR_HIP) when no
  * usable GPU is present: there is no CPU fallback. */
@@ -95,19 +97,31 @@ const char *fseg_last_error(const fseg_ctx *ctx);   /* never NULL; ctx may be NU
 
 int fseg_set_params(fseg_ctx *ctx, const fseg_params *params);
 
-/* Copy a batch into HBM (replaces the resident batch).  Arrays are validated the way
- * read_split() asserts them (py/freddie_segment.py:138-140,:158-161). */
+/* Copy a batch into HBM (replaces the resident batch): one pinned staging image, one host-to-device copy; the
+ * per-read preparation (validation, ordering of the reads by first position) runs on the device behind the copy and
+ * the call returns without waiting for it.  Arrays are validated the way read_split() asserts them
+ * (py/freddie_segment.py:138-140,:158-161); what the device-side part of that finds is reported by the next call
+ * that waits for the device (fseg_run, fseg_sync, ...). */
 int fseg_upload(fseg_ctx *ctx, const fseg_batch *batch);
 
 /* Run the whole segmentation path over the resident batch: splice histogram (:648-678),
  * Gaussian smoothing (:755), variance threshold (:757-759), candidates (:615-621), fixing and
  * problem splitting (:776-788,:623-645), interval scoring + DP (:475-596), refinement
- * (:249-266), final positions (:802-807) and labels (:808-830).  Asynchronous with respect to
- * the host until fseg_sync()/fseg_sizes()/fseg_download_*; results stay in HBM. */
+ * (:249-266), final positions (:802-807) and labels (:808-830).  Results stay in HBM until fetched.
+ * The first run of a batch waits twice for the device inside the call (it reads the sizes of the problem list and
+ * of the label matrix to size their arenas exactly); its last stage, and every later run of the same batch (replayed
+ * as a hipGraph), is asynchronous until fseg_sync()/fseg_get_sizes()/fseg_results()/fseg_download(). */
 int fseg_run(fseg_ctx *ctx);
 int fseg_sync(fseg_ctx *ctx);
 
 int fseg_get_sizes(fseg_ctx *ctx, fseg_sizes *out);
+
+/* Results, zero-copy: pointers into the context's own pinned host buffers, filled by one device-to-host copy per
+ * array (layout as for fseg_download below).  They stay valid until the next fseg_run / fseg_upload / fseg_results
+ * on this context.  This is what a host pipeline uses (two contexts per GPU: one batch's results are being written
+ * out while the next batch runs); fseg_download copies into caller memory instead.  Any pointer may be NULL. */
+int fseg_results(fseg_ctx *ctx, const int64_t **part_final_off, const int32_t **final_pos, const int64_t **label_off,
+                 const uint8_t **labels);
 
 /* Results.  part_final_off: n_part+1 offsets into final_pos; final_pos: n_final genomic
  * positions (tint['final_positions'] of each partition, concatenated).  labels: for partition
@@ -129,7 +143,12 @@ enum {
     FSEG_TAP_CHOSEN = 8,      /* uint8[n_cand] 1 = in final_c_idxs after run_optimize                       */
     FSEG_TAP_FINAL_OFF = 9,   /* int64[K+1]                                                                 */
     FSEG_TAP_FINAL_Y = 10,    /* int32[n_final] final y indices per interval                                */
-    FSEG_TAP_PROBLEMS = 11    /* int32[n_problems][4] = (interval, start, n, chain_len)                     */
+    FSEG_TAP_PROBLEMS = 11,   /* int32[n_problems][4] = (interval, start, n, chain_len)                     */
+    /* the upload's device-side preparation: every rep repeated rep_weight times ("lanes"), ordered inside its
+     * partition by first position */
+    FSEG_TAP_LANE_START = 12, /* int32[lanes]  first position of the lane's rep                                      */
+    FSEG_TAP_LANE_PMAX = 13,  /* int32[lanes]  running maximum (inside the partition) of the reps' last positions    */
+    FSEG_TAP_LANE_EXONS = 14  /* int64[lanes][2] exon range (into ex_ts / ex_te) of the lane's rep                   */
 };
 int fseg_tap(fseg_ctx *ctx, int what, void *dst, int64_t cap_bytes, int64_t *n_bytes);
 

@@ -602,3 +602,8 @@ GETTER(const int64_t *, fo_final_off, final_off)
 GETTER(const int32_t *, fo_final_y, final_y)
 GETTER(const int32_t *, fo_final_pos, final_pos)
 GETTER(const uint8_t *, fo_labels, labels)
+
+#ifdef FREDDIE_SOURCE_HASH
+/* what this binary was built from (freddie_amd/build.py looks for the marker in the file) */
+static const char freddie_source_stamp[] __attribute__((used)) = "FREDDIE_SRC_HASH=" FREDDIE_SOURCE_HASH;
+#endif

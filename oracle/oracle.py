@@ -14,9 +14,22 @@ _SO = os.path.join(_HERE, "libfreddie_oracle.so")
 
 
 def build(force=False):
-    src = os.path.join(_HERE, "freddie_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-s", "-C", _HERE, "libfreddie_oracle.so"])
+    # rebuilt when the library does not carry the hash of its source + Makefile (same scheme as freddie_amd/build.py;
+    # restated here because the oracle imports nothing from the product)
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("Makefile", "freddie_oracle.c"):
+        with open(os.path.join(_HERE, name), "rb") as f:
+            h.update(f.read())
+    want = h.hexdigest()[:32]
+    have = None
+    if os.path.exists(_SO):
+        with open(_SO, "rb") as f:
+            blob = f.read()
+        i = blob.find(b"FREDDIE_SRC_HASH=")
+        have = blob[i + 17:i + 49].decode("ascii", "replace") if i >= 0 else None
+    if force or have != want:
+        subprocess.check_call(["make", "-s", "-B", "-C", _HERE, "libfreddie_oracle.so", 'STAMP=-DFREDDIE_SOURCE_HASH=\\"%s\\"' % want])
     return _SO
 
 

@@ -2,6 +2,7 @@
 against the golden fixtures -- no GPU: the labels of the reference are fed to the host code."""
 import hashlib
 import os
+import shutil
 
 import numpy as np
 import pytest
@@ -16,7 +17,10 @@ def input_dir(name, tmp_path):
     """Regenerates (synthetic) or locates (edge) the split directory of a golden case."""
     case = goldens.manifest()["cases"][name]
     if name.startswith("e_"):
-        return os.path.join(EDGE, name), case["contig"], case["tint_id"]
+        d = str(tmp_path / name)                     # a copy: side-car tests write next to the TSVs, never into the tree
+        if not os.path.isdir(d):
+            shutil.copytree(os.path.join(EDGE, name), d)
+        return d, case["contig"], case["tint_id"]
     gen = dict(case["generator"])
     idx = gen.pop("index")
     d = str(tmp_path / name)
