@@ -3,19 +3,29 @@
 // Multi-threaded replacement of the reference's per-partition Python I/O: the split / reads TSV parser with
 // the read_reps grouping (py/freddie_segment.py:121-185), the per-read soft-clip / poly-A / unaligned-gap
 // annotation (:289-472) and the segment TSV writer (:703-732).  What each function must produce is defined by
-// those reference lines; the implementation (flat arrays, one std::thread per partition slice, one buffered
-// write per file) is this project's own.
+// those reference lines; the implementation is this project's own and is built around not allocating per read:
+//   * the two TSVs of a partition are mapped, not copied; read names, contigs and sequences are views into the
+//     mappings for as long as the batch lives (a partition loaded from a side-car keeps them in one arena instead);
+//   * one pass over the bytes of a line, integers parsed in place; the rep grouping is an open-addressing table over
+//     the exon tuples; sequences are matched to reads by position when the two files list the reads in the same
+//     order (the split stage writes them that way), by a hash of the read id otherwise;
+//   * the writer assembles a partition's TSV in one reused buffer with a streaming poly-A scan (no score array) and
+//     fixed-size gap tokens, and hands it to the kernel in one write().
 #include "freddie_host.h"
 
 #include <algorithm>
 #include <atomic>
+#include <cerrno>
 #include <cstdio>
 #include <cstring>
 #include <exception>
-#include <sys/stat.h>
+#include <fcntl.h>
 #include <mutex>
 #include <string>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <thread>
+#include <unistd.h>
 #include <unordered_map>
 #include <vector>
 
@@ -23,12 +33,46 @@ namespace {
 
 typedef long long i64;
 
+struct Str {                   // a view into a mapped file or into the partition's arena
+    const char *p = nullptr;
+    uint32_t n = 0;
+};
+
 struct Read {
     i64 id = 0, tint = 0;
-    std::string name, chr, seq;
-    char strand = '+';
+    Str name, chr, seq;
     int ex0 = 0, ex1 = 0;     // exon range of this read inside the partition's exon arrays
     int rep = 0;
+    char strand = '+';
+};
+
+struct Mapping {              // a whole file, read-only; empty files map to (nullptr, 0)
+    const char *p = nullptr;
+    size_t n = 0;
+    bool open(const char *path, uint64_t *size_out, int64_t *mtime_ns_out) {
+        close();
+        int fd = ::open(path, O_RDONLY | O_CLOEXEC);
+        if (fd < 0) return false;
+        struct stat st;
+        if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) { ::close(fd); return false; }
+        if (size_out) *size_out = (uint64_t)st.st_size;
+        if (mtime_ns_out) *mtime_ns_out = (int64_t)st.st_mtim.tv_sec * 1000000000ll + (int64_t)st.st_mtim.tv_nsec;
+        n = (size_t)st.st_size;
+        if (n) {
+            // no MAP_POPULATE: pages are faulted in by the threads that parse them (populating under the address-space lock
+            // serialised the loader threads: 0.12 s vs 0.02 s per 100 k reads at 8 threads), and the bulk of the sequences --
+            // everything but the soft-clipped ends the poly-A search looks at -- is never touched at all
+            void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m == MAP_FAILED) { ::close(fd); n = 0; return false; }
+            p = static_cast<const char *>(m);
+        }
+        ::close(fd);
+        return true;
+    }
+    void close() {
+        if (p) munmap(const_cast<char *>(p), n);
+        p = nullptr; n = 0;
+    }
 };
 
 struct Partition {
@@ -41,40 +85,51 @@ struct Partition {
     std::vector<char> cig_op;
     // read reps in first-occurrence order (:165-170)
     std::vector<int> rep_first_read, rep_weight;
+    Mapping map_split, map_reads;           // the TSVs stay mapped while the partition lives
+    std::vector<char> arena;                // side-car path: names, contigs and unpacked sequences
+    // the TSVs as they were when this partition was read (what a side-car written from it is bound to)
+    uint64_t split_size = 0, reads_size = 0;
+    int64_t split_mtime_ns = 0, reads_mtime_ns = 0;
+    bool have_stat = false;
     std::string err;
-};
 
-struct Error {
-    std::string msg;
+    Partition() = default;
+    Partition(const Partition &) = delete;
+    Partition &operator=(const Partition &) = delete;
+    ~Partition() { map_split.close(); map_reads.close(); }
+    void reset() {
+        chr.clear(); id = read_count = 0;
+        iv_s.clear(); iv_e.clear(); reads.clear(); ts.clear(); te.clear(); qs.clear(); qe.clear();
+        cig_off.clear(); cig_len.clear(); cig_op.clear(); rep_first_read.clear(); rep_weight.clear();
+        map_split.close(); map_reads.close(); arena.clear(); have_stat = false; err.clear();
+    }
 };
-
-bool read_file(const char *path, std::string &out) {
-    FILE *f = fopen(path, "rb");
-    if (!f) return false;
-    fseek(f, 0, SEEK_END);
-    long n = ftell(f);
-    fseek(f, 0, SEEK_SET);
-    out.resize(n > 0 ? (size_t)n : 0);
-    size_t got = n > 0 ? fread(&out[0], 1, (size_t)n, f) : 0;
-    fclose(f);
-    return got == out.size();
-}
 
 // strict unsigned decimal ([0-9]+), as the reference's regexes require
-bool parse_uint(const char *b, const char *e, i64 &v) {
-    if (b >= e) return false;
+inline bool parse_uint(const char *b, const char *e, i64 &v) {
+    if (b >= e || e - b > 18) return false;
     i64 x = 0;
     for (const char *p = b; p < e; ++p) {
-        if (*p < '0' || *p > '9') return false;
-        x = x * 10 + (*p - '0');
-        if (x > (i64)4e18) return false;
+        const unsigned d = (unsigned)(*p - '0');
+        if (d > 9) return false;
+        x = x * 10 + d;
     }
     v = x;
     return true;
 }
-bool parse_pair(const char *b, const char *e, i64 &a, i64 &c) {   // "<a>-<c>"
-    const char *dash = (const char *)memchr(b, '-', (size_t)(e - b));
-    return dash && parse_uint(b, dash, a) && parse_uint(dash + 1, e, c);
+// digits from p up to (not including) the first non-digit before e; false if there is none (or too many)
+inline bool scan_uint(const char *&p, const char *e, i64 &v) {
+    const char *b = p;
+    i64 x = 0;
+    while (p < e) {
+        const unsigned d = (unsigned)(*p - '0');
+        if (d > 9) break;
+        x = x * 10 + d;
+        ++p;
+    }
+    if (p == b || p - b > 18) return false;
+    v = x;
+    return true;
 }
 bool chr_ok(const char *b, const char *e) {      // chr_re of the reference (:23)
     static const char first[] = "!#$%&+./:;?@^_|~-", rest[] = "!#$%&*+./:;=?@^_|~-";
@@ -87,7 +142,7 @@ bool chr_ok(const char *b, const char *e) {      // chr_re of the reference (:23
     }
     return true;
 }
-bool name_ok(const char *b, const char *e) {     // [!-?A-~]{1,254} (:30)
+inline bool name_ok(const char *b, const char *e) {     // [!-?A-~]{1,254} (:30)
     if (e - b < 1 || e - b > 254) return false;
     for (const char *p = b; p < e; ++p) {
         unsigned char c = (unsigned char)*p;
@@ -95,131 +150,201 @@ bool name_ok(const char *b, const char *e) {     // [!-?A-~]{1,254} (:30)
     }
     return true;
 }
-
-void split_tabs(const char *b, const char *e, std::vector<std::pair<const char *, const char *>> &cols) {
-    cols.clear();
-    const char *s = b;
-    for (const char *p = b; p <= e; ++p) {
-        if (p == e || *p == '\t') { cols.emplace_back(s, p); s = p + 1; }
-    }
+inline const char *find_tab(const char *p, const char *e) {
+    const char *t = (const char *)memchr(p, '\t', (size_t)(e - p));
+    return t ? t : e;
+}
+inline bool is_cigar_op(char c) {
+    switch (c) { case 'M': case 'I': case 'D': case 'N': case 'S': case 'H': case 'P': case 'X': case '=': return true; default: return false; }
 }
 
+// read rep = reads with the same tuple of target intervals, first-occurrence order (:165-170): open addressing over a
+// hash of the tuple, equality checked against the exons of the rep's first read
+struct RepTable {
+    std::vector<int> slot;       // rep + 1, 0 = empty
+    std::vector<uint64_t> hash;  // per rep
+    size_t mask = 0;
+    void init(size_t expect) {
+        size_t n = 1024;
+        while (n < expect * 2 + 16) n <<= 1;
+        slot.assign(n, 0); mask = n - 1; hash.clear();
+    }
+    static uint64_t mix(uint64_t h, uint64_t v) { h ^= v; h *= 0x9E3779B97F4A7C15ull; h ^= h >> 29; return h; }
+    void grow() {
+        std::vector<int> ns((mask + 1) * 2, 0);
+        const size_t nm = ns.size() - 1;
+        for (size_t r = 0; r < hash.size(); ++r) { size_t i = hash[r] & nm; while (ns[i]) i = (i + 1) & nm; ns[i] = (int)r + 1; }
+        slot.swap(ns); mask = nm;
+    }
+};
+
 void parse_partition(const char *split_path, const char *reads_path, Partition &P) {
-    static thread_local std::string text;              // reused across partitions (see load_sidecar)
-    if (!read_file(split_path, text)) { P.err = std::string("cannot read ") + split_path; return; }
-    std::vector<std::pair<const char *, const char *>> cols;
-    const char *p = text.data(), *end = p + text.size();
+    if (!P.map_split.open(split_path, &P.split_size, &P.split_mtime_ns)) { P.err = std::string("cannot read ") + split_path; return; }
+    const char *p = P.map_split.p, *end = p + P.map_split.n;
     bool have_header = false;
-    std::unordered_map<std::string, int> rep_of;
+    RepTable reps;
+    {   // exons are ~30 bytes of text each, CIGAR ops ~4: reserving from the file size avoids regrowth
+        const size_t guess = P.map_split.n / 24 + 16;
+        P.ts.reserve(guess); P.te.reserve(guess); P.qs.reserve(guess); P.qe.reserve(guess); P.cig_off.reserve(guess + 1);
+        P.cig_len.reserve(guess * 2); P.cig_op.reserve(guess * 2);
+    }
+    const std::string sp(split_path);
     while (p < end) {
         const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
-        if (!nl) { P.err = std::string(split_path) + ": line without newline"; return; }
-        split_tabs(p, nl, cols);
+        if (!nl) { P.err = sp + ": line without newline"; return; }
         if (*p == '#') {
-            if (have_header) { P.err = std::string(split_path) + ": more than one tint in the file (py/freddie_segment.py:699)"; return; }
-            i64 v;
-            if (cols.size() != 4 || !chr_ok(cols[0].first + 1, cols[0].second) || !parse_uint(cols[1].first, cols[1].second, P.id) ||
-                !parse_uint(cols[3].first, cols[3].second, P.read_count)) { P.err = std::string(split_path) + ": malformed header line"; return; }
-            (void)v;
-            P.chr.assign(cols[0].first + 1, cols[0].second);
-            const char *q = cols[2].first;
-            while (q <= cols[2].second) {
-                const char *c = (const char *)memchr(q, ',', (size_t)(cols[2].second - q));
-                if (!c) c = cols[2].second;
+            if (have_header) { P.err = sp + ": more than one tint in the file (py/freddie_segment.py:699)"; return; }
+            // #chr \t id \t intervals \t read_count
+            const char *c0e = find_tab(p, nl), *c1 = c0e + 1;
+            const char *c1e = c0e < nl ? find_tab(c1, nl) : nl, *c2 = c1e + 1;
+            const char *c2e = c1e < nl ? find_tab(c2, nl) : nl, *c3 = c2e + 1;
+            const char *c3e = c2e < nl ? find_tab(c3, nl) : nl;
+            if (c2e >= nl || c3e != nl || !chr_ok(p + 1, c0e) || !parse_uint(c1, c1e, P.id) || !parse_uint(c3, c3e, P.read_count)) {
+                P.err = sp + ": malformed header line"; return;
+            }
+            P.chr.assign(p + 1, c0e);
+            const char *q = c2;
+            while (q <= c2e) {
+                const char *c = (const char *)memchr(q, ',', (size_t)(c2e - q));
+                if (!c) c = c2e;
                 i64 s, e;
-                if (!parse_pair(q, c, s, e)) { P.err = std::string(split_path) + ": malformed tint intervals"; return; }
+                const char *t = q;
+                if (!scan_uint(t, c, s) || t >= c || *t != '-' || !parse_uint(t + 1, c, e)) { P.err = sp + ": malformed tint intervals"; return; }
                 P.iv_s.push_back((int)s); P.iv_e.push_back((int)e);
                 q = c + 1;
             }
             for (size_t k = 0; k < P.iv_s.size(); ++k) {
-                if (!(P.iv_s[k] < P.iv_e[k])) { P.err = std::string(split_path) + ": interval with start >= end (py/freddie_segment.py:140)"; return; }
-                if (k && !(P.iv_e[k - 1] < P.iv_s[k])) { P.err = std::string(split_path) + ": intervals overlap or are unordered (py/freddie_segment.py:138)"; return; }
+                if (!(P.iv_s[k] < P.iv_e[k])) { P.err = sp + ": interval with start >= end (py/freddie_segment.py:140)"; return; }
+                if (k && !(P.iv_e[k - 1] < P.iv_s[k])) { P.err = sp + ": intervals overlap or are unordered (py/freddie_segment.py:138)"; return; }
             }
             have_header = true;
+            const size_t expect = (size_t)std::min<i64>(P.read_count, (i64)(P.map_split.n / 16) + 1);
+            P.reads.reserve(expect);
+            reps.init(expect);
         } else {
-            if (!have_header) { P.err = std::string(split_path) + ": read line before the tint header"; return; }
+            if (!have_header) { P.err = sp + ": read line before the tint header"; return; }
+            // rid \t name \t chr \t strand \t tint \t interval(\t interval)*
             Read r;
-            if (cols.size() < 6 || !parse_uint(cols[0].first, cols[0].second, r.id) || !name_ok(cols[1].first, cols[1].second) ||
-                !chr_ok(cols[2].first, cols[2].second) || cols[3].second - cols[3].first != 1 ||
-                (*cols[3].first != '+' && *cols[3].first != '-') || !parse_uint(cols[4].first, cols[4].second, r.tint)) {
-                P.err = std::string(split_path) + ": malformed read line"; return;
+            const char *c0e = find_tab(p, nl);
+            const char *c1 = c0e + 1, *c1e = c0e < nl ? find_tab(c1, nl) : nl;
+            const char *c2 = c1e + 1, *c2e = c1e < nl ? find_tab(c2, nl) : nl;
+            const char *c3 = c2e + 1, *c3e = c2e < nl ? find_tab(c3, nl) : nl;
+            const char *c4 = c3e + 1, *c4e = c3e < nl ? find_tab(c4, nl) : nl;
+            if (c4e >= nl || !parse_uint(p, c0e, r.id) || !name_ok(c1, c1e) || !chr_ok(c2, c2e) || c3e - c3 != 1 ||
+                (*c3 != '+' && *c3 != '-') || !parse_uint(c4, c4e, r.tint)) {
+                P.err = sp + ": malformed read line"; return;
             }
-            if (r.tint != P.id) { P.err = std::string(split_path) + ": read refers to another tint"; return; }
-            r.name.assign(cols[1].first, cols[1].second);
-            r.chr.assign(cols[2].first, cols[2].second);
-            r.strand = *cols[3].first;
+            if (r.tint != P.id) { P.err = sp + ": read refers to another tint"; return; }
+            r.name.p = c1; r.name.n = (uint32_t)(c1e - c1);
+            r.chr.p = c2; r.chr.n = (uint32_t)(c2e - c2);
+            r.strand = *c3;
             r.ex0 = (int)P.ts.size();
-            for (size_t c = 5; c < cols.size(); ++c) {
-                const char *b = cols[c].first, *e = cols[c].second;
-                const char *c1 = (const char *)memchr(b, ':', (size_t)(e - b));
-                const char *c2 = c1 ? (const char *)memchr(c1 + 1, ':', (size_t)(e - c1 - 1)) : nullptr;
+            uint64_t h = 0x243F6A8885A308D3ull;
+            const char *q = c4e + 1;                   // first interval field (c4e < nl)
+            for (;;) {
+                // ts-te:qs-qe:CIGAR up to the next tab / end of line
                 i64 ts, te, qs, qe;
-                if (!c2 || !parse_pair(b, c1, ts, te) || !parse_pair(c1 + 1, c2, qs, qe) || c2 + 1 >= e) {
-                    P.err = std::string(split_path) + ": malformed read interval"; return;
+                if (!scan_uint(q, nl, ts) || q >= nl || *q != '-' || (++q, !scan_uint(q, nl, te)) || q >= nl || *q != ':' ||
+                    (++q, !scan_uint(q, nl, qs)) || q >= nl || *q != '-' || (++q, !scan_uint(q, nl, qe)) || q >= nl || *q != ':') {
+                    P.err = sp + ": malformed read interval"; return;
                 }
+                ++q;
+                if (q >= nl || *q == '\t') { P.err = sp + ": malformed read interval"; return; }
                 P.cig_off.push_back((int)P.cig_len.size());
-                const char *q = c2 + 1;
-                while (q < e) {
-                    const char *d = q;
-                    while (d < e && *d >= '0' && *d <= '9') ++d;
+                while (q < nl && *q != '\t') {
                     i64 len;
-                    if (d == q || d >= e || !strchr("MIDNSHPX=", *d) || !parse_uint(q, d, len)) {
-                        P.err = std::string(split_path) + ": malformed CIGAR"; return;
-                    }
-                    P.cig_len.push_back((int)len); P.cig_op.push_back(*d);
-                    q = d + 1;
+                    if (!scan_uint(q, nl, len) || q >= nl || !is_cigar_op(*q)) { P.err = sp + ": malformed CIGAR"; return; }
+                    P.cig_len.push_back((int)len); P.cig_op.push_back(*q);
+                    ++q;
                 }
                 P.ts.push_back((int)ts); P.te.push_back((int)te); P.qs.push_back((int)qs); P.qe.push_back((int)qe);
+                h = RepTable::mix(h, ((uint64_t)(uint32_t)(int)ts << 32) | (uint32_t)(int)te);
+                if (q >= nl) break;
+                ++q;                                   // the tab: another interval must follow
+                if (q >= nl) { P.err = sp + ": malformed read interval"; return; }
             }
             r.ex1 = (int)P.ts.size();
             for (int x = r.ex0; x < r.ex1; ++x) {       // :158-161
-                if (!(P.ts[x] < P.te[x] && P.qs[x] < P.qe[x])) { P.err = std::string(split_path) + ": exon with start >= end (py/freddie_segment.py:160)"; return; }
-                if (x > r.ex0 && !(P.te[x - 1] <= P.ts[x] && P.qe[x - 1] <= P.qs[x])) { P.err = std::string(split_path) + ": exons out of order (py/freddie_segment.py:158)"; return; }
+                if (!(P.ts[x] < P.te[x] && P.qs[x] < P.qe[x])) { P.err = sp + ": exon with start >= end (py/freddie_segment.py:160)"; return; }
+                if (x > r.ex0 && !(P.te[x - 1] <= P.ts[x] && P.qe[x - 1] <= P.qs[x])) { P.err = sp + ": exons out of order (py/freddie_segment.py:158)"; return; }
             }
-            // read rep = reads with the same tuple of target intervals, first-occurrence order (:165-170)
-            std::string key;
-            key.resize((size_t)(r.ex1 - r.ex0) * 8);
-            for (int x = r.ex0; x < r.ex1; ++x) {
-                memcpy(&key[(size_t)(x - r.ex0) * 8], &P.ts[x], 4);
-                memcpy(&key[(size_t)(x - r.ex0) * 8 + 4], &P.te[x], 4);
+            {
+                const int m = r.ex1 - r.ex0;
+                size_t i = h & reps.mask;
+                int found = -1;
+                while (reps.slot[i]) {
+                    const int cand = reps.slot[i] - 1;
+                    if (reps.hash[(size_t)cand] == h) {
+                        const Read &f = P.reads[(size_t)P.rep_first_read[(size_t)cand]];
+                        if (f.ex1 - f.ex0 == m && memcmp(&P.ts[(size_t)f.ex0], &P.ts[(size_t)r.ex0], (size_t)m * 4) == 0 &&
+                            memcmp(&P.te[(size_t)f.ex0], &P.te[(size_t)r.ex0], (size_t)m * 4) == 0) { found = cand; break; }
+                    }
+                    i = (i + 1) & reps.mask;
+                }
+                if (found < 0) {
+                    r.rep = (int)P.rep_first_read.size();
+                    reps.slot[i] = r.rep + 1;
+                    reps.hash.push_back(h);
+                    P.rep_first_read.push_back((int)P.reads.size());
+                    P.rep_weight.push_back(1);
+                    if (reps.hash.size() * 2 > reps.mask) reps.grow();
+                } else {
+                    r.rep = found;
+                    P.rep_weight[(size_t)found] += 1;
+                }
             }
-            auto it = rep_of.find(key);
-            if (it == rep_of.end()) {
-                r.rep = (int)P.rep_first_read.size();
-                rep_of.emplace(std::move(key), r.rep);
-                P.rep_first_read.push_back((int)P.reads.size());
-                P.rep_weight.push_back(1);
-            } else {
-                r.rep = it->second;
-                P.rep_weight[(size_t)r.rep] += 1;
-            }
-            P.reads.push_back(std::move(r));
+            P.reads.push_back(r);
         }
         p = nl + 1;
     }
     P.cig_off.push_back((int)P.cig_len.size());
-    if (!have_header) { P.err = std::string(split_path) + ": no tint header"; return; }
-    if ((i64)P.reads.size() != P.read_count) { P.err = std::string(split_path) + ": read_count does not match the number of read lines (py/freddie_segment.py:164)"; return; }
-    // sequences (:174-185): rid \t contig \t tint \t seq
-    if (!read_file(reads_path, text)) { P.err = std::string("cannot read ") + reads_path; return; }
-    std::unordered_map<i64, std::pair<const char *, const char *>> seq_of;
-    p = text.data(); end = p + text.size();
+    if (!have_header) { P.err = sp + ": no tint header"; return; }
+    if ((i64)P.reads.size() != P.read_count) { P.err = sp + ": read_count does not match the number of read lines (py/freddie_segment.py:164)"; return; }
+    // sequences (:174-185): rid \t contig \t tint \t seq ; a dict keyed by rid in the reference (a later line replaces an
+    // earlier one with the same rid), whose size must equal the number of reads
+    if (!P.map_reads.open(reads_path, &P.reads_size, &P.reads_mtime_ns)) { P.err = std::string("cannot read ") + reads_path; return; }
+    P.have_stat = true;
+    const std::string rpath(reads_path);
+    p = P.map_reads.p; end = p + P.map_reads.n;
+    const size_t n_reads = P.reads.size();
+    // fast path: line i carries the sequence of read i and the rids are strictly increasing (so the dict has one entry
+    // per line); anything else goes through the dict
+    bool positional = true;
+    size_t line = 0;
+    i64 prev_rid = -1;
+    std::vector<std::pair<i64, Str>> later;      // lines seen after the order broke
     while (p < end) {
         const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
         const char *le = nl ? nl : end;
         const char *re = le;
-        while (re > p && (re[-1] == '\r' || re[-1] == ' ' || re[-1] == '\t' || re[-1] == '\n')) --re;   // line.rstrip()
-        split_tabs(p, re, cols);
+        while (re > p && (re[-1] == '\r' || re[-1] == ' ' || re[-1] == '\t' || re[-1] == '\n' || re[-1] == '\v' || re[-1] == '\f')) --re;   // line.rstrip()
+        const char *c0e = find_tab(p, re);
+        const char *c1e = c0e < re ? find_tab(c0e + 1, re) : re;
+        const char *c2e = c1e < re ? find_tab(c1e + 1, re) : re;
         i64 rid;
-        if (cols.size() < 4 || !parse_uint(cols[0].first, cols[0].second, rid)) { P.err = std::string(reads_path) + ": malformed line"; return; }
-        seq_of[rid] = std::make_pair(cols[3].first, cols[3].second);
+        if (c2e >= re || !parse_uint(p, c0e, rid)) { P.err = rpath + ": malformed line"; return; }
+        const char *c3 = c2e + 1, *c3e = find_tab(c3, re);
+        Str seq; seq.p = c3; seq.n = (uint32_t)(c3e - c3);
+        if (positional && line < n_reads && rid == P.reads[line].id && rid > prev_rid) P.reads[line].seq = seq;
+        else { positional = false; later.emplace_back(rid, seq); }
+        prev_rid = rid;
+        ++line;
         p = nl ? nl + 1 : end;
     }
-    if (seq_of.size() != P.reads.size()) { P.err = std::string(reads_path) + ": number of sequences differs from the number of reads (py/freddie_segment.py:181)"; return; }
+    if (positional) {
+        if (line != n_reads) { P.err = rpath + ": number of sequences differs from the number of reads (py/freddie_segment.py:181)"; return; }
+        return;
+    }
+    std::unordered_map<i64, Str> seq_of;
+    seq_of.reserve(line * 2);
+    const size_t n_pos = line - later.size();          // the lines that matched positionally before the order broke
+    for (size_t i = 0; i < n_pos; ++i) seq_of[P.reads[i].id] = P.reads[i].seq;
+    for (const auto &kv : later) seq_of[kv.first] = kv.second;
+    if (seq_of.size() != n_reads) { P.err = rpath + ": number of sequences differs from the number of reads (py/freddie_segment.py:181)"; return; }
     for (Read &r : P.reads) {
         auto it = seq_of.find(r.id);
-        if (it == seq_of.end()) { P.err = std::string(reads_path) + ": a read has no sequence"; return; }
-        r.seq.assign(it->second.first, it->second.second);
+        if (it == seq_of.end()) { P.err = rpath + ": a read has no sequence"; return; }
+        r.seq = it->second;
     }
 }
 
@@ -263,63 +388,74 @@ void query_at_or_before(const Partition &P, const Read &r, i64 end, i64 &q, i64 
 
 struct PolyRun { i64 first, len; double purity; char ch; };
 
-// find_longest_poly (:352-367) over the window [s0, e0) of the read in alignment orientation: for '-' reads the
-// window is taken from the end of the stored sequence backwards and the complement letter is searched.
-void poly_runs(const std::string &seq, bool minus, i64 s0, i64 e0, char ch, std::vector<PolyRun> &out) {
-    const i64 n = (i64)seq.size();
-    if (e0 - s0 == 0) return;
+// find_longest_poly (:352-367) over the window [s0, e0) of the read in alignment orientation (for '-' reads the window
+// is taken from the end of the stored sequence backwards and the complement letter is searched), fused with the
+// caller's choice (:397-408, :427-439): runs of positive local score (+1 match, -2 mismatch, floored at 0), each cut at
+// its LAST maximum; of those with length >= 20 and purity >= 0.85 the purest wins, the first one on ties, 'A' runs
+// before 'T' runs.  Streaming: no score array.
+bool best_poly(const Str &seq, bool minus, i64 s0, i64 e0, PolyRun &best) {
+    const i64 n = (i64)seq.n;
+    if (e0 - s0 == 0) return false;
     i64 count = e0 - s0;
     if (count < 0) count = 0;
-    char target = ch;
-    if (minus) target = ch == 'A' ? 'T' : (ch == 'T' ? 'A' : (ch == 'C' ? 'G' : 'C'));
-    auto at = [&](i64 t) -> char {
-        i64 idx = minus ? n - 1 - s0 - t : s0 + t;
-        if (idx < 0 || idx >= n) throw Fail{"find_longest_poly: sequence index out of range (:355)"};
-        return seq[(size_t)idx];
-    };
-    (void)at(0);
+    {   // the first element of the window must exist (:355)
+        const i64 idx0 = minus ? n - 1 - s0 : s0;
+        if (idx0 < 0 || idx0 >= n) throw Fail{"find_longest_poly: sequence index out of range (:355)"};
+    }
     if (!minus && s0 + count > n) count = n - s0;
     if (minus && n - 1 - s0 - (count - 1) < 0) count = n - s0;
-    std::vector<int> sc((size_t)count);
-    int prev = at(0) == target ? 1 : 0;
-    sc[0] = prev;
-    for (i64 t = 1; t < count; ++t) {
-        prev = std::max(0, prev + (at(t) == target ? 1 : -2));
-        sc[(size_t)t] = prev;
-    }
-    i64 i = 0;
-    while (i < count) {
-        if (sc[(size_t)i] <= 0) { ++i; continue; }
-        i64 j = i, best_i = i;
-        int best_s = sc[(size_t)i];
-        while (j < count && sc[(size_t)j] > 0) {
-            if (sc[(size_t)j] >= best_s) { best_s = sc[(size_t)j]; best_i = j; }   // max over (score, index)
-            ++j;
-        }
-        i64 len = best_i + 1 - i, hits = 0;
-        for (i64 t = i; t < i + len; ++t) hits += at(t) == target;
-        out.push_back(PolyRun{i, len, (double)hits / (double)len, ch});
-        i = j;
-    }
-}
-bool best_poly(const std::string &seq, bool minus, i64 s0, i64 e0, PolyRun &best) {
-    std::vector<PolyRun> runs;
     bool have = false;
-    for (char ch : {'A', 'T'}) {
-        runs.clear();
-        poly_runs(seq, minus, s0, e0, ch, runs);
-        for (const PolyRun &r : runs) {
-            if (r.len < 20 || r.purity < 0.85) continue;
-            if (!have || r.purity > best.purity) { best = r; have = true; }   // max purity, first one wins ties
+    const char *base = seq.p;
+    for (int pass = 0; pass < 2; ++pass) {
+        const char ch = pass ? 'T' : 'A';
+        const char target = minus ? (ch == 'A' ? 'T' : 'A') : ch;
+        int prev = 0, best_s = 0;
+        bool in_run = false;
+        i64 run_i = 0, best_i = 0, hits_run = 0, hits_best = 0;
+        auto emit = [&]() {
+            const i64 len = best_i + 1 - run_i;
+            if (len < 20) return;
+            const double purity = (double)hits_best / (double)len;
+            if (purity < 0.85) return;
+            if (!have || purity > best.purity) { best = PolyRun{run_i, len, purity, ch}; have = true; }
+        };
+        const char *q = minus ? base + (n - 1 - s0) : base + s0;
+        const i64 step = minus ? -1 : 1;
+        for (i64 t = 0; t < count; ++t, q += step) {
+            const int m = *q == target;
+            const int s = std::max(0, prev + (m ? 1 : -2));
+            if (s > 0) {
+                if (!in_run) { in_run = true; run_i = t; best_s = 0; hits_run = 0; }
+                hits_run += m;
+                if (s >= best_s) { best_s = s; best_i = t; hits_best = hits_run; }     // max over (score, index): the last maximum
+            } else if (in_run) { emit(); in_run = false; }
+            prev = s;
         }
+        if (in_run) emit();
     }
     return have;
 }
 
+struct Tok { char s[48]; };
+
+inline char *put_u(char *p, unsigned long long v) {
+    char tmp[24];
+    int n = 0;
+    do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (n) *p++ = tmp[--n];
+    return p;
+}
+inline char *put_i(char *p, i64 v) {
+    if (v < 0) { *p++ = '-'; return put_u(p, (unsigned long long)(-(v + 1)) + 1ull); }
+    return put_u(p, (unsigned long long)v);
+}
+inline char *put_s(char *p, const char *s) { while (*s) *p++ = *s++; return p; }
+
+// gaps: the tokens of read['gaps'] = sorted(set(...)) (:472), in `toks` (sorted, unique); empty when the read has no '1'
 void annotate_read(const Partition &P, const Read &r, const unsigned char *data, i64 S, const int *fp,
-                   std::vector<std::string> &gaps) {
-    gaps.clear();
-    std::vector<std::pair<i64, i64>> runs;
+                   std::vector<Tok> &toks, std::vector<std::pair<i64, i64>> &runs) {
+    toks.clear();
+    runs.clear();
     for (i64 i = 0; i < S;) {
         if (data[i] != '1') { ++i; continue; }
         i64 j = i;
@@ -328,25 +464,25 @@ void annotate_read(const Partition &P, const Read &r, const unsigned char *data,
         i = j + 1;
     }
     if (runs.empty()) return;
-    const i64 length = (i64)r.seq.size();
+    const i64 length = (i64)r.seq.n;
     const bool minus = r.strand == '-';
     i64 q_ssc, q_esc, slack;
     query_at_or_after(P, r, fp[runs.front().first], q_ssc, slack);          // segs[f][0]
     query_at_or_before(P, r, fp[runs.back().second + 1], q_esc, slack);     // segs[l][1]
     if (!(0 <= q_ssc && q_ssc <= q_esc && q_esc <= length)) throw Fail{"soft-clip positions out of order (:389)"};
-    char buf[96];
+    auto tok = [&]() -> char * { toks.emplace_back(); return toks.back().s; };
     PolyRun b;
     if (best_poly(r.seq, minus, 0, q_ssc, b)) {
         i64 gap = q_ssc - b.first - b.len;
         if (!(0 <= b.first && b.first < q_ssc && 0 <= gap && gap < q_ssc)) throw Fail{"start poly tail out of range (:405,:410)"};
-        snprintf(buf, sizeof buf, "S%c_%lld:%lld", b.ch, b.len, gap); gaps.emplace_back(buf);
-        snprintf(buf, sizeof buf, "SSC:%lld", b.first); gaps.emplace_back(buf);
-    } else { snprintf(buf, sizeof buf, "SSC:%lld", q_ssc); gaps.emplace_back(buf); }
+        char *t = tok(); *t++ = 'S'; *t++ = b.ch; *t++ = '_'; t = put_i(t, b.len); *t++ = ':'; t = put_i(t, gap); *t = 0;
+        t = tok(); t = put_s(t, "SSC:"); t = put_i(t, b.first); *t = 0;
+    } else { char *t = tok(); t = put_s(t, "SSC:"); t = put_i(t, q_ssc); *t = 0; }
     if (best_poly(r.seq, minus, q_esc, length, b)) {
         if (!(0 <= b.first && b.first < length - q_esc && length - q_esc - b.first > 0)) throw Fail{"end poly tail out of range (:435,:441,:450)"};
-        snprintf(buf, sizeof buf, "E%c_%lld:%lld", b.ch, b.len, b.first); gaps.emplace_back(buf);
-        snprintf(buf, sizeof buf, "ESC:%lld", length - q_esc - b.first); gaps.emplace_back(buf);
-    } else { snprintf(buf, sizeof buf, "ESC:%lld", length - q_esc); gaps.emplace_back(buf); }
+        char *t = tok(); *t++ = 'E'; *t++ = b.ch; *t++ = '_'; t = put_i(t, b.len); *t++ = ':'; t = put_i(t, b.first); *t = 0;
+        t = tok(); t = put_s(t, "ESC:"); t = put_i(t, length - q_esc - b.first); *t = 0;
+    } else { char *t = tok(); t = put_s(t, "ESC:"); t = put_i(t, length - q_esc); *t = 0; }
     for (size_t k = 0; k + 1 < runs.size(); ++k) {
         i64 last1 = runs[k].second, first2 = runs[k + 1].first, q_a, slack_a, q_b, slack_b;
         query_at_or_before(P, r, fp[last1 + 1], q_a, slack_a);
@@ -354,10 +490,10 @@ void annotate_read(const Partition &P, const Read &r, const unsigned char *data,
         if (!(0 < q_a && q_a <= q_b && q_b < length)) throw Fail{"unaligned gap positions out of order (:462)"};
         i64 size = std::max<i64>(0, q_b - q_a + slack_a + slack_b);
         if (!(0 <= size && size < length && last1 < first2)) throw Fail{"unaligned gap size out of range (:466-468)"};
-        snprintf(buf, sizeof buf, "%lld-%lld:%lld", last1, first2, size); gaps.emplace_back(buf);
+        char *t = tok(); t = put_i(t, last1); *t++ = '-'; t = put_i(t, first2); *t++ = ':'; t = put_i(t, size); *t = 0;
     }
-    std::sort(gaps.begin(), gaps.end());                                     // sorted(set(...)) on strings (:472)
-    gaps.erase(std::unique(gaps.begin(), gaps.end()), gaps.end());
+    std::sort(toks.begin(), toks.end(), [](const Tok &a, const Tok &b2) { return strcmp(a.s, b2.s) < 0; });   // sorted(set(...)) on strings (:472)
+    toks.erase(std::unique(toks.begin(), toks.end(), [](const Tok &a, const Tok &b2) { return strcmp(a.s, b2.s) == 0; }), toks.end());
 }
 
 // ---- binary side-car of a partition ------------------------------------------
@@ -406,7 +542,6 @@ struct Sink {
 struct Source {
     const unsigned char *p, *end;
     bool ok = true;
-    // a section that is only read while loading: a pointer into the file image instead of a copy (sections are 8-aligned)
     // n comes from the (untrusted) header: a count whose byte size does not fit what is left of the payload --
     // including one that would wrap around -- fails the load instead of reaching a resize() or a pointer bump
     template <typename T> bool fits(size_t n, size_t &padded) const {
@@ -416,6 +551,7 @@ struct Source {
         padded = bytes + (8 - bytes % 8) % 8;
         return padded <= left;
     }
+    // a section that is only read while loading: a pointer into the file image instead of a copy (sections are 8-aligned)
     template <typename T> const T *view(size_t n) {
         size_t padded = 0;
         if (!ok || !fits<T>(n, padded)) { ok = false; return nullptr; }
@@ -439,7 +575,10 @@ bool write_sidecar(const Partition &P, const char *split_path, const char *reads
     FscHeader h;
     memset(&h, 0, sizeof h);
     memcpy(h.magic, FSC_MAGIC, 8);
-    if (!stat_file(split_path, h.split_size, h.split_mtime_ns) || !stat_file(reads_path, h.reads_size, h.reads_mtime_ns)) {
+    // bound to the TSVs as they were when the partition was read, not as they are now: a TSV replaced in between must
+    // make this side-car stale
+    if (P.have_stat) { h.split_size = P.split_size; h.split_mtime_ns = P.split_mtime_ns; h.reads_size = P.reads_size; h.reads_mtime_ns = P.reads_mtime_ns; }
+    else if (!stat_file(split_path, h.split_size, h.split_mtime_ns) || !stat_file(reads_path, h.reads_size, h.reads_mtime_ns)) {
         err = std::string("cannot stat ") + split_path + " / " + reads_path; return false;
     }
     const size_t n = P.reads.size();
@@ -451,24 +590,24 @@ bool write_sidecar(const Partition &P, const char *split_path, const char *reads
     std::vector<uint8_t> exc_ch;
     std::string names, read_chrs;
     bool chr_differs = false;
-    for (const Read &r : P.reads) chr_differs |= r.chr != P.chr;
+    for (const Read &r : P.reads) chr_differs |= !(r.chr.n == P.chr.size() && memcmp(r.chr.p, P.chr.data(), r.chr.n) == 0);
     uint64_t bases = 0;
     for (size_t i = 0; i < n; ++i) {
         const Read &r = P.reads[i];
         read_id[i] = r.id; read_ex_off[i] = r.ex0; read_rep[i] = r.rep; strand[i] = (uint8_t)r.strand;
-        name_off[i] = (uint32_t)names.size(); names += r.name;
-        if (chr_differs) { chr_off.push_back((uint32_t)read_chrs.size()); read_chrs += r.chr; }
-        seq_off[i] = bases; bases += r.seq.size();
+        name_off[i] = (uint32_t)names.size(); names.append(r.name.p, r.name.n);
+        if (chr_differs) { chr_off.push_back((uint32_t)read_chrs.size()); read_chrs.append(r.chr.p, r.chr.n); }
+        seq_off[i] = bases; bases += r.seq.n;
     }
     read_ex_off[n] = (int32_t)P.ts.size(); name_off[n] = (uint32_t)names.size(); seq_off[n] = bases;
     if (chr_differs) chr_off.push_back((uint32_t)read_chrs.size());
     std::vector<uint8_t> packed((size_t)((bases + 3) / 4), 0);
     for (size_t i = 0; i < n; ++i) {
-        const std::string &q = P.reads[i].seq;
+        const Str &q = P.reads[i].seq;
         uint64_t g = seq_off[i];
-        for (size_t t = 0; t < q.size(); ++t, ++g) {
-            int c = base_code((unsigned char)q[t]);
-            if (c < 0) { exc_pos.push_back(g); exc_ch.push_back((uint8_t)q[t]); c = 0; }
+        for (size_t t = 0; t < q.n; ++t, ++g) {
+            int c = base_code((unsigned char)q.p[t]);
+            if (c < 0) { exc_pos.push_back(g); exc_ch.push_back((uint8_t)q.p[t]); c = 0; }
             packed[(size_t)(g >> 2)] |= (uint8_t)(c << ((g & 3) * 2));
         }
     }
@@ -502,21 +641,21 @@ bool write_sidecar(const Partition &P, const char *split_path, const char *reads
 // Returns true when the side-car exists, belongs to exactly these TSVs and is intact; P is then what
 // parse_partition() would have produced.  Any mismatch returns false (the caller parses the TSVs instead).
 bool load_sidecar(const char *sidecar_path, const char *split_path, const char *reads_path, Partition &P, bool verify) {
-    // one file image per worker thread, reused from partition to partition: a fresh 300 KB buffer per file would be an
-    // mmap + page faults + munmap each time, and those serialise the threads on the process' address-space lock
-    static thread_local std::string blob;
-    if (!read_file(sidecar_path, blob) || blob.size() < sizeof(FscHeader)) return false;
+    Mapping blob;                                          // unmapped when the function returns: everything is copied out
+    struct Closer { Mapping &m; ~Closer() { m.close(); } } closer{blob};
+    if (!blob.open(sidecar_path, nullptr, nullptr) || blob.n < sizeof(FscHeader)) return false;
     FscHeader h;
-    memcpy(&h, blob.data(), sizeof h);
-    if (memcmp(h.magic, FSC_MAGIC, 8) != 0 || blob.size() != sizeof h + h.payload_bytes) return false;
+    memcpy(&h, blob.p, sizeof h);
+    if (memcmp(h.magic, FSC_MAGIC, 8) != 0 || blob.n != sizeof h + h.payload_bytes) return false;
     uint64_t sz; int64_t mt;
     if (!stat_file(split_path, sz, mt) || sz != h.split_size || mt != h.split_mtime_ns) return false;
     if (!stat_file(reads_path, sz, mt) || sz != h.reads_size || mt != h.reads_mtime_ns) return false;
-    const unsigned char *pay = reinterpret_cast<const unsigned char *>(blob.data()) + sizeof h;
+    const unsigned char *pay = reinterpret_cast<const unsigned char *>(blob.p) + sizeof h;
     if (verify && fsc_total_checksum(h, pay, (size_t)h.payload_bytes) != h.checksum) return false;
     const size_t n = (size_t)h.n_reads;
     if (h.n_reads > (1ull << 31) || h.n_exons > (1ull << 31) || h.n_cigar > (1ull << 31) || h.n_reps > h.n_reads ||
-        (int64_t)h.n_reads != h.read_count) return false;
+        (int64_t)h.n_reads != h.read_count || h.seq_bases > (1ull << 40) || h.name_bytes > (1ull << 32) ||
+        h.read_chr_bytes > (1ull << 32) || h.chr_bytes > (1ull << 20)) return false;
     Source s{pay, pay + h.payload_bytes};
     const char *chr = s.view<char>((size_t)h.chr_bytes);
     s.get(P.iv_s, (size_t)h.n_iv); s.get(P.iv_e, (size_t)h.n_iv);
@@ -542,6 +681,7 @@ bool load_sidecar(const char *sidecar_path, const char *split_path, const char *
         P.cig_off[(size_t)h.n_exons] != (int32_t)h.n_cigar) return false;
     for (size_t i = 0; i < n; ++i) {
         if (read_ex_off[i] > read_ex_off[i + 1] || name_off[i] > name_off[i + 1] || seq_off[i] > seq_off[i + 1]) return false;
+        if (seq_off[i + 1] - seq_off[i] > 0xffffffffull) return false;
         if (read_rep[i] < 0 || (uint64_t)read_rep[i] >= h.n_reps) return false;
         if (h.read_chr_bytes && (chr_off[i] > chr_off[i + 1] || chr_off[i + 1] > read_chr_len)) return false;
     }
@@ -550,21 +690,28 @@ bool load_sidecar(const char *sidecar_path, const char *split_path, const char *
     for (size_t k = 0; k < (size_t)h.n_exc; ++k) if (exc_pos[k] >= h.seq_bases || (k && exc_pos[k] <= exc_pos[k - 1])) return false;
     P.chr.assign(chr, chr + h.chr_bytes);
     P.id = h.id; P.read_count = h.read_count;
+    P.split_size = h.split_size; P.split_mtime_ns = h.split_mtime_ns; P.reads_size = h.reads_size; P.reads_mtime_ns = h.reads_mtime_ns;
+    P.have_stat = true;
     static const char LUT[4] = {'A', 'C', 'G', 'T'};
     static char QUAD[256][4];
     static std::once_flag quad_once;
     std::call_once(quad_once, []() { for (int b = 0; b < 256; ++b) for (int k = 0; k < 4; ++k) QUAD[b][k] = LUT[(b >> (2 * k)) & 3]; });
+    // one arena for the strings of the partition: names | per-read contigs | sequences
+    P.arena.resize((size_t)h.name_bytes + read_chr_len + (size_t)h.seq_bases);
+    char *a_names = P.arena.data(), *a_chrs = a_names + h.name_bytes, *a_seq = a_chrs + read_chr_len;
+    if (h.name_bytes) memcpy(a_names, names, (size_t)h.name_bytes);
+    if (read_chr_len) memcpy(a_chrs, read_chrs, read_chr_len);
     P.reads.resize(n);
     size_t e = 0;
     for (size_t i = 0; i < n; ++i) {
         Read &r = P.reads[i];
         r.id = read_id[i]; r.tint = h.id; r.strand = (char)strand[i]; r.ex0 = read_ex_off[i]; r.ex1 = read_ex_off[i + 1]; r.rep = read_rep[i];
-        r.name.assign(names + name_off[i], names + name_off[i + 1]);
-        if (h.read_chr_bytes) r.chr.assign(read_chrs + chr_off[i], read_chrs + chr_off[i + 1]);
-        else r.chr = P.chr;
+        r.name.p = a_names + name_off[i]; r.name.n = name_off[i + 1] - name_off[i];
+        if (h.read_chr_bytes) { r.chr.p = a_chrs + chr_off[i]; r.chr.n = chr_off[i + 1] - chr_off[i]; }
+        else { r.chr.p = P.chr.data(); r.chr.n = (uint32_t)P.chr.size(); }
         const uint64_t g0 = seq_off[i], len = seq_off[i + 1] - g0;
-        r.seq.resize((size_t)len);
-        char *dst = &r.seq[0];
+        char *dst = a_seq + g0;
+        r.seq.p = dst; r.seq.n = (uint32_t)len;
         uint64_t t = 0;
         for (; t < len && ((g0 + t) & 3); ++t) { uint64_t g = g0 + t; dst[t] = LUT[(packed[(size_t)(g >> 2)] >> ((g & 3) * 2)) & 3]; }
         for (; t + 4 <= len; t += 4) memcpy(dst + t, QUAD[packed[(size_t)((g0 + t) >> 2)]], 4);      // one packed byte = 4 bases
@@ -605,57 +752,73 @@ struct fhost_batch {
 };
 
 namespace {
-void flatten(fhost_batch *b) {
-    b->part_iv_off.assign(1, 0); b->part_rep_off.assign(1, 0); b->rep_exon_off.assign(1, 0);
-    for (const Partition &P : b->parts) {
-        b->iv_start.insert(b->iv_start.end(), P.iv_s.begin(), P.iv_s.end());
-        b->iv_end.insert(b->iv_end.end(), P.iv_e.begin(), P.iv_e.end());
-        b->part_iv_off.push_back((int64_t)b->iv_start.size());
-        for (size_t r = 0; r < P.rep_first_read.size(); ++r) {
-            const Read &rd = P.reads[(size_t)P.rep_first_read[r]];
-            for (int x = rd.ex0; x < rd.ex1; ++x) { b->ex_ts.push_back(P.ts[(size_t)x]); b->ex_te.push_back(P.te[(size_t)x]); }
-            b->rep_exon_off.push_back((int64_t)b->ex_ts.size());
-            b->rep_weight.push_back(P.rep_weight[r]);
-        }
-        b->part_rep_off.push_back((int64_t)b->rep_weight.size());
+// the flat arrays of fseg_batch: offsets first (serial, cheap), then every partition copies its own slice (parallel)
+void flatten(fhost_batch *b, int n_threads) {
+    const size_t n = b->parts.size();
+    b->part_iv_off.assign(n + 1, 0); b->part_rep_off.assign(n + 1, 0);
+    std::vector<int64_t> part_ex_off(n + 1, 0);
+    for (size_t p = 0; p < n; ++p) {
+        const Partition &P = b->parts[p];
+        int64_t ex = 0;
+        for (int f : P.rep_first_read) { const Read &rd = P.reads[(size_t)f]; ex += rd.ex1 - rd.ex0; }
+        b->part_iv_off[p + 1] = b->part_iv_off[p] + (int64_t)P.iv_s.size();
+        b->part_rep_off[p + 1] = b->part_rep_off[p] + (int64_t)P.rep_first_read.size();
+        part_ex_off[p + 1] = part_ex_off[p] + ex;
         b->n_reads += (int64_t)P.reads.size();
     }
+    b->iv_start.resize((size_t)b->part_iv_off[n]); b->iv_end.resize((size_t)b->part_iv_off[n]);
+    b->rep_weight.resize((size_t)b->part_rep_off[n]); b->rep_exon_off.resize((size_t)b->part_rep_off[n] + 1);
+    b->ex_ts.resize((size_t)part_ex_off[n]); b->ex_te.resize((size_t)part_ex_off[n]);
+    b->rep_exon_off[0] = 0;
+    parallel_for((int)n, n_threads, [&](int pi) {
+        const Partition &P = b->parts[(size_t)pi];
+        const size_t k0 = (size_t)b->part_iv_off[(size_t)pi], r0 = (size_t)b->part_rep_off[(size_t)pi];
+        if (!P.iv_s.empty()) { memcpy(&b->iv_start[k0], P.iv_s.data(), P.iv_s.size() * 4); memcpy(&b->iv_end[k0], P.iv_e.data(), P.iv_e.size() * 4); }
+        int64_t e = part_ex_off[(size_t)pi];
+        for (size_t r = 0; r < P.rep_first_read.size(); ++r) {
+            const Read &rd = P.reads[(size_t)P.rep_first_read[r]];
+            const int m = rd.ex1 - rd.ex0;
+            if (m > 0) { memcpy(&b->ex_ts[(size_t)e], &P.ts[(size_t)rd.ex0], (size_t)m * 4); memcpy(&b->ex_te[(size_t)e], &P.te[(size_t)rd.ex0], (size_t)m * 4); }
+            e += m;
+            b->rep_exon_off[r0 + r + 1] = e;
+            b->rep_weight[r0 + r] = P.rep_weight[r];
+        }
+    });
 }
 }  // namespace
 
 extern "C" {
 
 fhost_batch *fhost_load(const char *const *split_paths, const char *const *reads_paths, int32_t n, int32_t n_threads) {
-    fhost_batch *b = new (std::nothrow) fhost_batch();
-    if (!b) return nullptr;
-    if (n <= 0) { b->err = "fhost_load: empty batch"; return b; }
-    b->parts.resize((size_t)n);
-    parallel_for(n, n_threads, [&](int i) { parse_guarded(split_paths[i], reads_paths[i], b->parts[(size_t)i]); });
-    for (const Partition &P : b->parts) if (!P.err.empty()) { b->err = P.err; return b; }
-    flatten(b);
-    return b;
+    return fhost_load_sidecar(split_paths, reads_paths, nullptr, n, n_threads, 0);
 }
 
 fhost_batch *fhost_load_sidecar(const char *const *split_paths, const char *const *reads_paths, const char *const *sidecar_paths,
                                 int32_t n, int32_t n_threads, int32_t verify_checksum) {
     fhost_batch *b = new (std::nothrow) fhost_batch();
     if (!b) return nullptr;
-    if (n <= 0) { b->err = "fhost_load_sidecar: empty batch"; return b; }
-    b->parts.resize((size_t)n);
-    std::atomic<int> hits(0);
-    parallel_for(n, n_threads, [&](int i) {
-        Partition &P = b->parts[(size_t)i];
-        bool hit = false;
-        try {        // a damaged side-car must never be worse than a missing one: whatever it throws, the TSVs are parsed instead
-            hit = sidecar_paths && sidecar_paths[i] && load_sidecar(sidecar_paths[i], split_paths[i], reads_paths[i], P, verify_checksum != 0);
-        } catch (...) { hit = false; }
-        if (hit) { hits.fetch_add(1); return; }
-        P = Partition();
-        parse_guarded(split_paths[i], reads_paths[i], P);
-    });
-    b->n_from_sidecar = hits.load();
-    for (const Partition &P : b->parts) if (!P.err.empty()) { b->err = P.err; return b; }
-    flatten(b);
+    if (n <= 0) { b->err = "fhost_load: empty batch"; return b; }
+    try {
+        b->parts = std::vector<Partition>((size_t)n);
+        std::atomic<int> hits(0);
+        parallel_for(n, n_threads, [&](int i) {
+            Partition &P = b->parts[(size_t)i];
+            bool hit = false;
+            try {        // a damaged side-car must never be worse than a missing one: whatever it throws, the TSVs are parsed instead
+                hit = sidecar_paths && sidecar_paths[i] && load_sidecar(sidecar_paths[i], split_paths[i], reads_paths[i], P, verify_checksum != 0);
+            } catch (...) { hit = false; }
+            if (hit) { hits.fetch_add(1); return; }
+            P.reset();
+            parse_guarded(split_paths[i], reads_paths[i], P);
+        });
+        b->n_from_sidecar = hits.load();
+        for (const Partition &P : b->parts) if (!P.err.empty()) { b->err = P.err; return b; }
+        flatten(b, n_threads);
+    } catch (const std::exception &e) {
+        b->err = std::string("fhost_load: ") + e.what();
+    } catch (...) {
+        b->err = "fhost_load: internal error";
+    }
     return b;
 }
 
@@ -670,6 +833,7 @@ int32_t fhost_sidecar_write(fhost_batch *b, const char *const *split_paths, cons
         bool ok = false;
         try { ok = write_sidecar(b->parts[(size_t)p], split_paths[p], reads_paths[p], sidecar_paths[p], err); }
         catch (const std::exception &e) { err = std::string(sidecar_paths[p]) + ": " + e.what(); }
+        catch (...) { err = std::string(sidecar_paths[p]) + ": internal error"; }
         if (!ok) {
             std::lock_guard<std::mutex> lock(err_mutex);
             if (b->err.empty()) b->err = err;
@@ -696,45 +860,59 @@ int32_t fhost_write(fhost_batch *b, const int64_t *part_final_off, const int32_t
     if (!b || !b->err.empty()) return 1;
     std::mutex err_mutex;
     const int n = (int)b->parts.size();
+    auto set_err = [&](const std::string &m) { std::lock_guard<std::mutex> lock(err_mutex); if (b->err.empty()) b->err = m; };
     parallel_for(n, n_threads, [&](int p) {
-        const Partition &P = b->parts[(size_t)p];
-        const int *fp = final_pos + part_final_off[p];
-        const i64 F = part_final_off[p + 1] - part_final_off[p], S = F - 1;
-        std::string out;
-        out.reserve(P.reads.size() * (size_t)(S + 64) + (size_t)F * 10 + 64);
-        char num[32];
-        out += '#'; out += P.chr; out += '\t';
-        snprintf(num, sizeof num, "%lld", P.id); out += num; out += '\t';
-        for (i64 i = 0; i < F; ++i) { if (i) out += ','; snprintf(num, sizeof num, "%d", fp[i]); out += num; }
-        out += '\n';
-        std::vector<std::string> gaps;
+        // the output of a partition is assembled in one buffer that the worker thread keeps from partition to partition
+        static thread_local std::vector<char> out;
+        static thread_local std::vector<Tok> toks;
+        static thread_local std::vector<std::pair<i64, i64>> runs;
         try {
+            const Partition &P = b->parts[(size_t)p];
+            const int *fp = final_pos + part_final_off[p];
+            const i64 F = part_final_off[p + 1] - part_final_off[p], S = F - 1;
+            const i64 Sc = S > 0 ? S : 0;
+            size_t need = P.chr.size() + 64 + (size_t)F * 12;
+            for (const Read &r : P.reads) need += (size_t)Sc + r.name.n + r.chr.n + 64 + 48 * 6;
+            if (out.size() < need) out.resize(need + need / 4);
+            char *w = out.data();
+            *w++ = '#'; memcpy(w, P.chr.data(), P.chr.size()); w += P.chr.size(); *w++ = '\t';
+            w = put_i(w, P.id); *w++ = '\t';
+            for (i64 i = 0; i < F; ++i) { if (i) *w++ = ','; w = put_i(w, fp[i]); }
+            *w++ = '\n';
             for (const Read &r : P.reads) {
                 const unsigned char *row = labels + label_off[p] + (i64)r.rep * S;
-                annotate_read(P, r, row, S, fp, gaps);
-                snprintf(num, sizeof num, "%lld", r.id); out += num; out += '\t';
-                out += r.name; out += '\t'; out += r.chr; out += '\t'; out += r.strand; out += '\t';
-                snprintf(num, sizeof num, "%lld", r.tint); out += num; out += '\t';
-                out.append(reinterpret_cast<const char *>(row), (size_t)(S > 0 ? S : 0));
-                out += '\t';
-                for (const std::string &g : gaps) { out += g; out += ','; }
-                out += '\n';
+                annotate_read(P, r, row, S, fp, toks, runs);
+                // a read with many label runs has many gap tokens: make room before writing them
+                const size_t used = (size_t)(w - out.data()), line_max = (size_t)Sc + r.name.n + r.chr.n + 64 + toks.size() * 48;
+                if (used + line_max > out.size()) { out.resize((used + line_max) * 2); w = out.data() + used; }
+                w = put_i(w, r.id); *w++ = '\t';
+                memcpy(w, r.name.p, r.name.n); w += r.name.n; *w++ = '\t';
+                memcpy(w, r.chr.p, r.chr.n); w += r.chr.n; *w++ = '\t';
+                *w++ = r.strand; *w++ = '\t';
+                w = put_i(w, r.tint); *w++ = '\t';
+                if (Sc) { memcpy(w, row, (size_t)Sc); w += Sc; }
+                *w++ = '\t';
+                for (const Tok &g : toks) { w = put_s(w, g.s); *w++ = ','; }
+                *w++ = '\n';
             }
+            const size_t total = (size_t)(w - out.data());
+            int fd = ::open(out_paths[p], O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
+            bool ok = fd >= 0;
+            size_t done = 0;
+            while (ok && done < total) {
+                ssize_t k = ::write(fd, out.data() + done, total - done);
+                if (k < 0) { if (errno == EINTR) continue; ok = false; }
+                else done += (size_t)k;
+            }
+            if (fd >= 0 && ::close(fd) != 0) ok = false;
+            if (!ok) set_err(std::string("cannot write ") + out_paths[p]);
         } catch (const Fail &f) {
-            std::lock_guard<std::mutex> lock(err_mutex);
-            if (b->err.empty()) b->err = std::string(out_paths[p]) + ": " + f.what + " (reference: py/freddie_segment.py)";
-            return;
+            set_err(std::string(out_paths[p]) + ": " + f.what + " (reference: py/freddie_segment.py)");
         } catch (const std::exception &e) {
-            std::lock_guard<std::mutex> lock(err_mutex);
-            if (b->err.empty()) b->err = std::string(out_paths[p]) + ": " + e.what();
-            return;
+            set_err(std::string(out_paths[p]) + ": " + e.what());
+        } catch (...) {
+            set_err(std::string(out_paths[p]) + ": internal error");
         }
-        FILE *fo = fopen(out_paths[p], "wb");
-        if (!fo || fwrite(out.data(), 1, out.size(), fo) != out.size()) {
-            std::lock_guard<std::mutex> lock(err_mutex);
-            if (b->err.empty()) b->err = std::string("cannot write ") + out_paths[p];
-        }
-        if (fo) fclose(fo);
     });
     return b->err.empty() ? 0 : 2;
 }

@@ -453,53 +453,95 @@ def run_segment_batch_python(jobs, params, ctx):
     return [(j[2], j[3]) for j in jobs]
 
 
-def run_batches(batches, params, ctx, threads, on_done, sidecar="off"):
-    """Pipelined driver of one GPU: while the GPU works on batch i, batch i+1 is parsed and batch i-1 is
-    annotated and written by host threads (the native calls release the GIL).  FREDDIE_TIMING=1 prints one line per
-    batch to stderr (load / device / write seconds, partitions taken from side-cars)."""
+def run_batches(batches, params, ctxs, threads, on_done, sidecar="off"):
+    """Pipelined driver of one GPU.  ``ctxs``: one or two contexts on the same device (a single Context is accepted).
+    Batch i+1 (and i+2) are being parsed by the native loader while batch i is on the device and batch i-1 is annotated
+    and written; with two contexts consecutive batches alternate between them, so one batch's upload and the other's
+    download overlap the kernels of the batch in between (each context has its own stream, pinned staging and pinned
+    results, and the writer reads the results in place).  FREDDIE_TIMING=1 prints one line per batch to stderr (load /
+    device / write seconds, partitions taken from side-cars)."""
+    import threading
     import time
+    from collections import deque
     from concurrent.futures import ThreadPoolExecutor
     if not batches:
         return
+    if not isinstance(ctxs, (list, tuple)):
+        ctxs = [ctxs]
     timing = os.environ.get("FREDDIE_TIMING") == "1"
-    set_context_params(ctx, params)
+    for ctx in ctxs:
+        set_context_params(ctx, params)
+    done_lock = threading.Lock()
 
     def load(jobs):
         t0 = time.perf_counter()
         hb = load_batch_native(jobs, threads, sidecar)
         return hb, time.perf_counter() - t0
 
-    with ThreadPoolExecutor(max_workers=2) as pool:
-        nxt = pool.submit(load, batches[0])
-        pending_write = None
+    def write(hb, res, jobs, t_load, t_dev, i):
+        t0 = time.perf_counter()
+        try:
+            hb.write(*res, [_job_paths(j)[2] for j in jobs], n_threads=threads)
+        finally:
+            n_sc, n_reads = hb.n_from_sidecar, hb.n_reads
+            hb.close()
+        if timing:
+            print("[freddie_segment] batch %d: %d partitions (%d from side-cars), %d reads: load %.3f s, device %.3f s, "
+                  "write %.3f s" % (i, len(jobs), n_sc, n_reads, t_load, t_dev, time.perf_counter() - t0), file=sys.stderr)
+        with done_lock:
+            for j in jobs:
+                on_done((j[2], j[3]))
 
-        def finish(hb, res, jobs, t_load, t_dev, i):
+    n_ctx = len(ctxs)
+    with ThreadPoolExecutor(max_workers=2) as load_pool, ThreadPoolExecutor(max_workers=n_ctx) as dev_pool, \
+            ThreadPoolExecutor(max_workers=2) as write_pool:
+        last_write = [None] * n_ctx          # the write that still reads context k's pinned results
+
+        def device(k, i, jobs, hb, t_load):
+            ctx = ctxs[k]
             t0 = time.perf_counter()
             try:
-                hb.write(*res, [_job_paths(j)[2] for j in jobs], n_threads=threads)
-            finally:
-                n_sc, n_reads = hb.n_from_sidecar, hb.n_reads
+                ctx.upload(**hb.arrays())
+                ctx.run()
+                if last_write[k] is not None:
+                    last_write[k].result()   # its results live in this context's pinned buffers until it has finished
+                res = ctx.results()
+            except BaseException:
                 hb.close()
-            if timing:
-                print("[freddie_segment] batch %d: %d partitions (%d from side-cars), %d reads: load %.3f s, device %.3f s, "
-                      "write %.3f s" % (i, len(jobs), n_sc, n_reads, t_load, t_dev, time.perf_counter() - t0), file=sys.stderr)
-            return jobs
+                raise
+            last_write[k] = write_pool.submit(write, hb, res, jobs, t_load, time.perf_counter() - t0, i)
 
-        for i, jobs in enumerate(batches):
-            hb, t_load = nxt.result()
-            if i + 1 < len(batches):
-                nxt = pool.submit(load, batches[i + 1])
-            t0 = time.perf_counter()
-            ctx.upload(**hb.arrays())
-            ctx.run()
-            res = ctx.download()
-            t_dev = time.perf_counter() - t0
-            if pending_write is not None:
-                for j in pending_write.result():
-                    on_done((j[2], j[3]))
-            pending_write = pool.submit(finish, hb, res, jobs, t_load, t_dev, i)
-        for j in pending_write.result():
-            on_done((j[2], j[3]))
+        loads = deque()
+        nxt = 0
+
+        def prefetch():
+            nonlocal nxt
+            while nxt < len(batches) and len(loads) < 2:
+                loads.append(load_pool.submit(load, batches[nxt]))
+                nxt += 1
+
+        prefetch()
+        dev_futs = [None] * n_ctx
+        try:
+            for i, jobs in enumerate(batches):
+                hb, t_load = loads.popleft().result()
+                prefetch()
+                k = i % n_ctx
+                if dev_futs[k] is not None:
+                    dev_futs[k].result()     # the context is free again (and its error, if any, surfaces here)
+                dev_futs[k] = dev_pool.submit(device, k, i, jobs, hb, t_load)
+            for f in dev_futs:
+                if f is not None:
+                    f.result()
+            for f in last_write:
+                if f is not None:
+                    f.result()
+        finally:
+            for f in loads:                  # an error above: do not leak the batches that were already parsed
+                try:
+                    f.result()[0].close()
+                except Exception:
+                    pass
 
 
 def run_segment(segment_args, ctx=None):
@@ -541,32 +583,51 @@ def make_batches(jobs_with_cost, bytes_per_batch):
     return batches
 
 
-def _gpu_worker(device, jobs_with_cost, params, batch_bytes, threads, queue, sidecar="off"):
+def open_contexts(device, n=2):
+    """The contexts one GPU worker drives: two per device, so that copies and kernels of consecutive batches overlap."""
     from . import _lib
-    ctx = _lib.Context(device)
+    ctxs = []
     try:
-        run_batches(make_batches(jobs_with_cost, batch_bytes), params, ctx, threads, queue.put, sidecar)
+        for _ in range(n):
+            ctxs.append(_lib.Context(device))
+    except BaseException:
+        for c in ctxs:
+            c.close()
+        raise
+    return ctxs
+
+
+def _gpu_worker(device, n_workers, jobs_with_cost, params, batch_bytes, threads, queue, sidecar="off"):
+    from . import devices
+    devices.pin_worker(device, n_workers)        # host threads of this worker stay on the cores next to its GPU
+    ctxs = open_contexts(device)
+    try:
+        run_batches(make_batches(jobs_with_cost, batch_bytes), params, ctxs, threads, queue.put, sidecar)
     finally:
-        ctx.close()
+        for ctx in ctxs:
+            ctx.close()
         queue.put(None)
 
 
 def main(argv=None):
-    from . import scatter
+    import time
+    t_start = time.perf_counter()
+    from . import devices, scatter
     args = parse_args(argv)
     split_dir = args.split_dir.rstrip("/")
     parts = discover(split_dir, args.outdir)
     params = (args.sigma, tables.smooth_threshold(args.threshold_rate), args.threshold_rate, args.variance_factor,
               args.max_problem_size, args.min_read_support_outside, not args.consider_ends)
     if args.devices:
-        devices = [int(x) for x in args.devices.split(",") if x != ""]
+        device_list = [int(x) for x in args.devices.split(",") if x != ""]
     else:
         n_gpus = args.gpus
         if n_gpus <= 0:
-            import torch
-            n_gpus = torch.cuda.device_count()
-        devices = list(range(n_gpus))
-    n_gpus = len(devices)
+            # counted from sysfs / the runtime's environment variables, NOT through the HIP runtime: this process may
+            # have to start one worker process per GPU, which a process that has initialised HIP must not do
+            n_gpus = devices.visible_gpu_count()
+        device_list = list(range(n_gpus))
+    n_gpus = len(device_list)
     if n_gpus <= 0:
         raise SystemExit("freddie_segment: no GPU visible (this implementation has no CPU path)")
     costs = [c for _, _, c in parts]
@@ -582,21 +643,28 @@ def main(argv=None):
             print("[freddie_segment] Done with {}/{} tints ({:.1%})".format(done_count, total, done_count / total))
         done_count += 1
 
+    timing = os.environ.get("FREDDIE_TIMING") == "1"
     if n_gpus == 1:
-        from . import _lib
-        ctx = _lib.Context(devices[0])
+        t_disc = time.perf_counter()
+        ctxs = open_contexts(device_list[0])
+        t_ctx = time.perf_counter()
         jobs = [((split_dir, args.outdir, parts[i][0], parts[i][1]), parts[i][2]) for i in assign[0]]
         try:
-            run_batches(make_batches(jobs, batch_bytes), params, ctx, args.threads, lambda _done: report(), args.sidecar)
+            run_batches(make_batches(jobs, batch_bytes), params, ctxs, args.threads, lambda _done: report(), args.sidecar)
         finally:
-            ctx.close()
+            t_run = time.perf_counter()
+            for ctx in ctxs:
+                ctx.close()
+        if timing:
+            print("[freddie_segment] discover %.3f s, contexts %.3f s, batches %.3f s, close %.3f s" % (
+                t_disc - t_start, t_ctx - t_disc, t_run - t_ctx, time.perf_counter() - t_run), file=sys.stderr)
         return
     mp = multiprocessing.get_context("spawn")
     queue = mp.Queue()
     procs = []
-    for w, dev in enumerate(devices):
+    for w, dev in enumerate(device_list):
         jobs = [((split_dir, args.outdir, parts[i][0], parts[i][1]), parts[i][2]) for i in assign[w]]
-        pr = mp.Process(target=_gpu_worker, args=(dev, jobs, params, batch_bytes, args.threads, queue, args.sidecar))
+        pr = mp.Process(target=_gpu_worker, args=(dev, n_gpus, jobs, params, batch_bytes, args.threads, queue, args.sidecar))
         pr.start()
         procs.append(pr)
     import queue as queue_mod
