@@ -466,11 +466,7 @@ def run_batches(batches, params, ctxs, threads, on_done, sidecar="off"):
     from concurrent.futures import ThreadPoolExecutor
     if not batches:
         return
-    if not isinstance(ctxs, (list, tuple)):
-        ctxs = [ctxs]
     timing = os.environ.get("FREDDIE_TIMING") == "1"
-    for ctx in ctxs:
-        set_context_params(ctx, params)
     done_lock = threading.Lock()
 
     def load(jobs):
@@ -492,25 +488,8 @@ def run_batches(batches, params, ctxs, threads, on_done, sidecar="off"):
             for j in jobs:
                 on_done((j[2], j[3]))
 
-    n_ctx = len(ctxs)
-    with ThreadPoolExecutor(max_workers=2) as load_pool, ThreadPoolExecutor(max_workers=n_ctx) as dev_pool, \
+    with ThreadPoolExecutor(max_workers=2) as load_pool, ThreadPoolExecutor(max_workers=2) as dev_pool, \
             ThreadPoolExecutor(max_workers=2) as write_pool:
-        last_write = [None] * n_ctx          # the write that still reads context k's pinned results
-
-        def device(k, i, jobs, hb, t_load):
-            ctx = ctxs[k]
-            t0 = time.perf_counter()
-            try:
-                ctx.upload(**hb.arrays())
-                ctx.run()
-                if last_write[k] is not None:
-                    last_write[k].result()   # its results live in this context's pinned buffers until it has finished
-                res = ctx.results()
-            except BaseException:
-                hb.close()
-                raise
-            last_write[k] = write_pool.submit(write, hb, res, jobs, t_load, time.perf_counter() - t0, i)
-
         loads = deque()
         nxt = 0
 
@@ -520,7 +499,33 @@ def run_batches(batches, params, ctxs, threads, on_done, sidecar="off"):
                 loads.append(load_pool.submit(load, batches[nxt]))
                 nxt += 1
 
-        prefetch()
+        prefetch()                           # the first batches are being parsed while the contexts come up
+        if hasattr(ctxs, "result"):
+            ctxs = ctxs.result()             # a future of open_contexts()
+        if not isinstance(ctxs, (list, tuple)):
+            ctxs = [ctxs]
+        for ctx in ctxs:
+            set_context_params(ctx, params)
+        n_ctx = len(ctxs)
+        last_write = [None] * n_ctx          # the write that still reads context k's pinned results
+
+        def device(k, i, jobs, hb, t_load):
+            ctx = ctxs[k]
+            t0 = time.perf_counter()
+            try:
+                ctx.upload(**hb.arrays())
+                ctx.run()
+                t1 = time.perf_counter()
+                if last_write[k] is not None:
+                    last_write[k].result()   # its results live in this context's pinned buffers until it has finished
+                t2 = time.perf_counter()
+                res = ctx.results()
+            except BaseException:
+                hb.close()
+                raise
+            t_dev = (t1 - t0) + (time.perf_counter() - t2)       # without the wait for the writer
+            last_write[k] = write_pool.submit(write, hb, res, jobs, t_load, t_dev, i)
+
         dev_futs = [None] * n_ctx
         try:
             for i, jobs in enumerate(batches):
@@ -567,10 +572,11 @@ def discover(split_dir, outdir):
 
 
 def make_batches(jobs_with_cost, bytes_per_batch):
-    """Consecutive jobs up to bytes_per_batch of split TSV each -- but at least four batches once there is enough input,
-    so that loading, the device and writing overlap (a single batch runs them one after the other)."""
+    """Consecutive jobs up to bytes_per_batch of split TSV each -- but at least eight batches once there is enough input,
+    so that loading, the device and writing overlap and the pipeline's fill and drain (the first batch's load, the last
+    one's write) stay short; a batch costs the device a few milliseconds, so small batches are cheap."""
     total = sum(c for _, c in jobs_with_cost)
-    bytes_per_batch = min(bytes_per_batch, max(total // 4, 8 << 20))
+    bytes_per_batch = min(bytes_per_batch, max(total // 8, 8 << 20))
     batches, cur, size = [], [], 0
     for job, cost in jobs_with_cost:
         if cur and size + cost > bytes_per_batch:
@@ -599,14 +605,18 @@ def open_contexts(device, n=2):
 
 def _gpu_worker(device, n_workers, jobs_with_cost, params, batch_bytes, threads, queue, sidecar="off"):
     from . import devices
+    from concurrent.futures import ThreadPoolExecutor
     devices.pin_worker(device, n_workers)        # host threads of this worker stay on the cores next to its GPU
-    ctxs = open_contexts(device)
-    try:
-        run_batches(make_batches(jobs_with_cost, batch_bytes), params, ctxs, threads, queue.put, sidecar)
-    finally:
-        for ctx in ctxs:
-            ctx.close()
-        queue.put(None)
+    with ThreadPoolExecutor(max_workers=1) as boot:
+        ctx_future = boot.submit(open_contexts, device)
+        try:
+            run_batches(make_batches(jobs_with_cost, batch_bytes), params, ctx_future, threads, queue.put, sidecar)
+        finally:
+            try:
+                for ctx in ctx_future.result():
+                    ctx.close()
+            finally:
+                queue.put(None)
 
 
 def main(argv=None):
@@ -645,19 +655,20 @@ def main(argv=None):
 
     timing = os.environ.get("FREDDIE_TIMING") == "1"
     if n_gpus == 1:
+        from concurrent.futures import ThreadPoolExecutor
         t_disc = time.perf_counter()
-        ctxs = open_contexts(device_list[0])
-        t_ctx = time.perf_counter()
         jobs = [((split_dir, args.outdir, parts[i][0], parts[i][1]), parts[i][2]) for i in assign[0]]
-        try:
-            run_batches(make_batches(jobs, batch_bytes), params, ctxs, args.threads, lambda _done: report(), args.sidecar)
-        finally:
-            t_run = time.perf_counter()
-            for ctx in ctxs:
-                ctx.close()
+        with ThreadPoolExecutor(max_workers=1) as boot:
+            ctx_future = boot.submit(open_contexts, device_list[0])       # library load + HIP start-up beside the first parse
+            try:
+                run_batches(make_batches(jobs, batch_bytes), params, ctx_future, args.threads, lambda _done: report(), args.sidecar)
+            finally:
+                t_run = time.perf_counter()
+                for ctx in ctx_future.result():
+                    ctx.close()
         if timing:
-            print("[freddie_segment] discover %.3f s, contexts %.3f s, batches %.3f s, close %.3f s" % (
-                t_disc - t_start, t_ctx - t_disc, t_run - t_ctx, time.perf_counter() - t_run), file=sys.stderr)
+            print("[freddie_segment] discover %.3f s, batches (incl. context start-up) %.3f s, close %.3f s" % (
+                t_disc - t_start, t_run - t_disc, time.perf_counter() - t_run), file=sys.stderr)
         return
     mp = multiprocessing.get_context("spawn")
     queue = mp.Queue()
