@@ -17,9 +17,11 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(_build.HOST_SO):
-        raise HostError("%s not found: build it first (freddie_amd.build.build_host())" % _build.HOST_SO)
-    L = ctypes.CDLL(_build.HOST_SO)
+    # FHOST_LIB: another build of the same library (the sanitizer build of tests/test_sanitizers.py)
+    path = os.environ.get("FHOST_LIB") or _build.HOST_SO
+    if not os.path.exists(path):
+        raise HostError("%s not found: build it first (freddie_amd.build.build_host())" % path)
+    L = ctypes.CDLL(path)
     vp = ctypes.c_void_p
     cpp = ctypes.POINTER(ctypes.c_char_p)
     L.fhost_load.restype = vp

@@ -39,7 +39,8 @@ class _Batch(ctypes.Structure):
 
 class _Sizes(ctypes.Structure):
     _fields_ = [("n_final", ctypes.c_int64), ("label_bytes", ctypes.c_int64), ("n_cand", ctypes.c_int64),
-                ("n_problems", ctypes.c_int64), ("n_positions", ctypes.c_int64)]
+                ("n_problems", ctypes.c_int64), ("n_positions", ctypes.c_int64), ("max_problem_size", ctypes.c_int64),
+                ("max_problem_reads", ctypes.c_int64)]
 
 
 EXPORTS = ["fseg_abi_version", "fseg_source_hash", "fseg_results", "fseg_create", "fseg_destroy", "fseg_last_error", "fseg_set_params", "fseg_upload",

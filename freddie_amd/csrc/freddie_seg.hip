@@ -4016,6 +4016,8 @@ int fseg_get_sizes(fseg_ctx *c, fseg_sizes *out) {
     out->n_cand = (int64_t)c->h_status->n_cand;
     out->n_problems = (int64_t)c->h_status->n_prob;
     out->n_positions = c->NPOS;
+    out->max_problem_size = (int64_t)c->h_status->max_n;
+    out->max_problem_reads = (int64_t)c->h_status->max_ln;
     return FSEG_OK;
 }
 

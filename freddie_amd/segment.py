@@ -589,6 +589,12 @@ def make_batches(jobs_with_cost, bytes_per_batch):
     return batches
 
 
+# One worker process per GPU.  "spawn": a worker must not inherit anything of the parent's (the parent never touches
+# the GPU, see devices.py, but a library that did would make fork unsafe).  The CPU test of main() switches to "fork" so
+# that its stand-in for open_contexts() reaches the workers.
+WORKER_START_METHOD = "spawn"
+
+
 def open_contexts(device, n=2):
     """The contexts one GPU worker drives: two per device, so that copies and kernels of consecutive batches overlap."""
     from . import _lib
@@ -670,7 +676,7 @@ def main(argv=None):
             print("[freddie_segment] discover %.3f s, batches (incl. context start-up) %.3f s, close %.3f s" % (
                 t_disc - t_start, t_run - t_disc, time.perf_counter() - t_run), file=sys.stderr)
         return
-    mp = multiprocessing.get_context("spawn")
+    mp = multiprocessing.get_context(WORKER_START_METHOD)
     queue = mp.Queue()
     procs = []
     for w, dev in enumerate(device_list):

@@ -83,6 +83,8 @@ typedef struct {
     int64_t n_cand;        /* total candidates (debug)                                          */
     int64_t n_problems;    /* DP problems with at least 3 candidates (debug)                    */
     int64_t n_positions;   /* sum of interval lengths (debug)                                   */
+    int64_t max_problem_size;   /* candidates of the largest DP problem (debug)                 */
+    int64_t max_problem_reads;  /* reads examined by the widest DP problem (debug; >= 65536 selects 32-bit DP counts) */
 } fseg_sizes;
 
 int fseg_abi_version(void);

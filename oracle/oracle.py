@@ -51,7 +51,7 @@ def lib():
     global _lib
     if _lib is None:
         build()
-        L = ctypes.CDLL(_SO)
+        L = ctypes.CDLL(os.environ.get("FREDDIE_ORACLE_SO") or _SO)      # override: the sanitizer build (tests/test_sanitizers.py)
         vp = ctypes.c_void_p
         L.fo_segment.restype = vp
         L.fo_segment.argtypes = [ctypes.POINTER(_Params), ctypes.c_int32, vp, vp, ctypes.c_int32, vp, vp, vp, vp, ctypes.c_int32]

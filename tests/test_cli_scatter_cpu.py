@@ -1,0 +1,100 @@
+"""The drop-in CLI's multi-GPU path on CPU: main() with two worker processes (--devices 0,1), the LPT scatter, the
+pipelined driver (two contexts per worker, loader / device / writer threads) and the progress protocol -- everything
+but the GPU, whose context is replaced by a stand-in that answers with the CPU oracle's results.  The outputs must be
+byte-identical to a one-worker run and cover every partition exactly once (reference: main() :847-885 maps the
+partitions over a process pool)."""
+import os
+
+import numpy as np
+
+import util
+from freddie_amd import devices, pack, segment, synth
+
+
+class OracleContext:
+    """Stand-in for _lib.Context: same calls the driver makes, results from the CPU oracle."""
+
+    def __init__(self, device):
+        self.device = device
+        self.n_part = 0
+
+    def set_params(self, sigma, threshold_rate, variance_factor, max_problem_size, min_read_support_outside, ignore_ends,
+                   w_main, w_refine, h_table):
+        self.params = dict(sigma=sigma, threshold_rate=threshold_rate, variance_factor=variance_factor,
+                           max_problem_size=max_problem_size, min_read_support_outside=min_read_support_outside,
+                           ignore_ends=ignore_ends)
+
+    def upload(self, **a):
+        self.a = {k: np.array(v) for k, v in a.items()}
+        self.n_part = len(a["part_iv_off"]) - 1
+
+    def run(self):
+        a = self.a
+        pfo, lo, fps, labs = [0], [0], [], []
+        for p in range(self.n_part):
+            k0, k1 = a["part_iv_off"][p], a["part_iv_off"][p + 1]
+            r0, r1 = a["part_rep_off"][p], a["part_rep_off"][p + 1]
+            e0, e1 = a["rep_exon_off"][r0], a["rep_exon_off"][r1]
+            part = pack.PackedPartition(a["iv_start"][k0:k1], a["iv_end"][k0:k1], a["rep_weight"][r0:r1],
+                                        a["rep_exon_off"][r0:r1 + 1] - e0, a["ex_ts"][e0:e1], a["ex_te"][e0:e1], np.zeros(0, np.int32))
+            o = util.run_oracle(part, self.params)
+            assert not o["error"], o["errmsg"]
+            fps.append(o["final_pos"]); labs.append((o["labels"] + 48).astype(np.uint8).ravel())
+            pfo.append(pfo[-1] + len(o["final_pos"])); lo.append(lo[-1] + labs[-1].size)
+        self.res = (np.array(pfo, np.int64), np.concatenate(fps).astype(np.int32), np.array(lo, np.int64), np.concatenate(labs))
+
+    def results(self):
+        return self.res
+
+    def close(self):
+        pass
+
+
+def fake_open_contexts(device, n=2):
+    return [OracleContext(device) for _ in range(n)]
+
+
+def read_tree(root):
+    out = {}
+    for dp, _, fs in os.walk(root):
+        for f in fs:
+            out[os.path.relpath(os.path.join(dp, f), root)] = open(os.path.join(dp, f), "rb").read()
+    return out
+
+
+def test_main_two_workers_equals_one_worker(tmp_path, monkeypatch, capsys):
+    split = str(tmp_path / "split")
+    n = 14
+    for i in range(n):
+        synth.generate(300 + i, n_reads=40 + 25 * (i % 5), n_exons=25, rp=0.1, write_dir=split, contig="chr%d" % (i % 3))
+    monkeypatch.setattr(segment, "open_contexts", fake_open_contexts)
+    monkeypatch.setattr(segment, "WORKER_START_METHOD", "fork")
+    outs = []
+    for devs in ("0", "0,1"):
+        out = str(tmp_path / ("out_" + devs.replace(",", "_")))
+        segment.main(["-s", split, "-o", out, "-t", "2", "--devices", devs, "--batch-reads", "150", "--sidecar", "off"])
+        outs.append(read_tree(out))
+        printed = capsys.readouterr().out
+        assert "Done with 0/%d tints" % n in printed            # the reference's progress line (:877-878)
+    assert outs[0] == outs[1]
+    tsvs = [k for k in outs[0] if k.endswith(".tsv")]
+    assert len(tsvs) == n and len([k for k in outs[0] if k.endswith(".log")]) == n
+    assert all(len(v) > 0 for k, v in outs[0].items() if k.endswith(".tsv"))
+
+
+def test_device_count_without_the_runtime(tmp_path):
+    """devices.visible_gpu_count(): the runtime's own variables first, then the KFD topology (GPU nodes = simd_count > 0)."""
+    root = tmp_path / "nodes"
+    for i, simd in enumerate([0, 0, 1024, 1024, 1024]):
+        d = root / str(i)
+        d.mkdir(parents=True)
+        (d / "properties").write_text("cpu_cores_count %d\nsimd_count %d\ndrm_render_minor %d\n" % (0 if simd else 64, simd, 128 + i))
+    assert devices.visible_gpu_count(env={}, kfd_root=str(root)) == 3
+    assert devices.visible_gpu_count(env={"HIP_VISIBLE_DEVICES": "0,2"}, kfd_root=str(root)) == 2
+    assert devices.visible_gpu_count(env={"ROCR_VISIBLE_DEVICES": "0"}, kfd_root=str(root)) == 1
+    assert devices.visible_gpu_count(env={"HIP_VISIBLE_DEVICES": ""}, kfd_root=str(root)) == 0
+    assert devices.visible_gpu_count(env={"HIP_VISIBLE_DEVICES": "0,-1,1"}, kfd_root=str(root)) == 1
+    cpus = devices.cpus_near_gpu(1, 2, kfd_root=str(root))
+    assert cpus and set(cpus) <= set(os.sched_getaffinity(0))
+    both = [devices.cpus_near_gpu(k, 2, kfd_root=str(root)) for k in (0, 1)]
+    assert not (set(both[0]) & set(both[1])) or len(os.sched_getaffinity(0)) < 2

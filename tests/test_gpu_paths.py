@@ -1,0 +1,162 @@
+"""Code paths that ordinary batches do not reach, each forced and checked against the CPU oracle through the C-ABI:
+the three-pass scan and the look-back scan's stall fallback, plain launches / no side streams / guessed arenas
+(the diagnostic switches every per-kernel profile uses), the 32-bit-count DP (forced, and for real with a problem that
+sees more than 65 535 reads), the huge-problem kernels next to k_tiny in one batch, and the full-size per-GPU batches of
+the bench workloads (reference: optimize :475-568, get_cumulative_coverage's uint32 :189-192)."""
+import numpy as np
+import pytest
+
+import util
+from freddie_amd import _lib, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def mixed_batch():
+    """A dozen partitions of different shapes: big and tiny DP problems, refinement, long intervals."""
+    parts = [util.make_partition(900 + i, n_reads=120 + 90 * i, n_exons=30 + 13 * i, rp=0.04 * (i % 4), max_span=(0 if i % 3 == 0 else 14))
+             for i in range(12)]
+    return parts, [util.run_oracle(p) for p in parts]
+
+
+def check_twice(ctx, parts, oracles, params=None):
+    """First run of the batch (sized, plain launches unless disabled) and the replayed run must both match."""
+    util.run_gpu(ctx, parts, params)
+    rep = util.compare_partitions(ctx, parts, oracles)
+    assert rep["y_identical"]
+    ctx.run(); ctx.sync()
+    rep = util.compare_partitions(ctx, parts, oracles)
+    assert rep["y_identical"]
+    a = ctx.download()
+    b = ctx.results()                                       # pinned zero-copy results == copied results
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+
+
+SWITCHES = [
+    {"FSEG_SCAN_SINGLE_MAX": "0"},                          # three-pass scan (k_scan1 / k_scan2 + block sums)
+    {"FSEG_FORCE_SCAN_STALL": "1"},                         # the look-back scan reports a stall -> rerun with the three-pass scan
+    {"FSEG_NO_GRAPH": "1"},
+    {"FSEG_NO_FORK": "1"},
+    {"FSEG_NO_GRAPH": "1", "FSEG_NO_FORK": "1"},            # how the per-kernel profiles are taken
+    {"FSEG_NO_SIZED": "1"},                                 # guessed arenas, overflow -> grow -> re-run (the fallback path)
+    {"FSEG_NO_SIZED": "1", "FSEG_FORCE_SCAN_STALL": "1"},
+    {"FSEG_FORCE_WIDE_DP": "1"},                            # 32-bit DP count tables on every problem
+    {"FSEG_FORCE_WIDE_DP": "1", "FSEG_TINY_FROM": "0"},
+    {"FSEG_PROB_SELF_MAX": "0"},                            # the problem list always through the block-sum scan
+    {"FSEG_PROB_SELF_MAX": "100000000"},                    # ... and always through the self-scanning emit kernel
+]
+
+
+@pytest.mark.parametrize("env", SWITCHES, ids=["+".join("%s=%s" % kv for kv in e.items()) for e in SWITCHES])
+def test_diagnostic_switches_keep_parity(env, monkeypatch):
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    parts, oracles = mixed_batch()
+    ctx = _lib.Context(0)
+    try:
+        check_twice(ctx, parts, oracles)
+        one = [parts[3]]                                    # a one-partition (small) batch on the same context
+        check_twice(ctx, one, [oracles[3]])
+    finally:
+        ctx.close()
+
+
+def test_wide_count_dp_for_real():
+    """One partition whose DP windows see more than 65 535 reads: the 16-bit count tables cannot hold out(i,j,k), the
+    library must pick the 32-bit DP by itself."""
+    part = util.make_partition(77, n_reads=90000, n_exons=14, rp=0.05, max_span=0)
+    o = util.run_oracle(part)
+    ctx = _lib.Context(0)
+    try:
+        util.run_gpu(ctx, [part])
+        assert ctx.sizes()["max_problem_reads"] >= 65536, ctx.sizes()
+        util.compare_partitions(ctx, [part], [o])
+        ctx.run(); ctx.sync()
+        util.compare_partitions(ctx, [part], [o])
+    finally:
+        ctx.close()
+
+
+def test_huge_problems_and_tiny_problems_in_one_batch(monkeypatch):
+    """max_problem_size 100: problems beyond the LDS-resident kernels (k_score_huge / k_dp_huge) together with many
+    partitions of tiny problems solved by k_tiny."""
+    monkeypatch.setenv("FSEG_TINY_FROM", "0")
+    params = dict(max_problem_size=100)
+    parts = [util.make_partition(3, n_reads=300, n_exons=150, rp=0.3, max_span=0)]
+    parts += [util.make_partition(500 + i, n_reads=200, n_exons=150, rp=0.0) for i in range(6)]      # exon-dense: n <= 4
+    oracles = [util.run_oracle(p, params) for p in parts]
+    ctx = _lib.Context(0)
+    try:
+        util.run_gpu(ctx, parts, params)
+        sz = ctx.sizes()
+        assert sz["max_problem_size"] > 60, sz
+        util.compare_partitions(ctx, parts, oracles)
+        ctx.run(); ctx.sync()
+        util.compare_partitions(ctx, parts, oracles)
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("workload,n_part", [("config4", 500), ("config3", 250)])
+def test_full_size_bench_batches_against_oracle(workload, n_part, gpu_ctx):
+    """The exact batches bench.py times (config4: one GPU's 500 x 500-read share; config3: 250 x 1000 reads), every
+    tap of every partition against the oracle."""
+    kw = dict(synth.WORKLOADS[workload]); kw.pop("n_partitions")
+    parts = [util.make_partition(i, **kw) for i in range(n_part)]
+    oracles = [util.run_oracle(p) for p in parts]
+    util.run_gpu(gpu_ctx, parts)
+    rep = util.compare_partitions(gpu_ctx, parts, oracles)
+    assert rep["y_identical"]
+    gpu_ctx.run(); gpu_ctx.sync()
+    util.compare_partitions(gpu_ctx, parts, oracles)
+
+
+def test_lane_preparation_on_the_device(gpu_ctx):
+    """fseg_upload's device-side ordering of the reads: every rep repeated rep_weight times, sorted inside its partition by
+    first position (ties in rep order), with the running maximum of the last positions."""
+    parts = [util.make_partition(40 + i, n_reads=300 + 50 * i, n_exons=40, rp=0.1, dedupe=True) for i in range(5)]
+    util.run_gpu(gpu_ctx, parts)
+    start, pmax, exons = gpu_ctx.tap("lane_start"), gpu_ctx.tap("lane_pmax"), gpu_ctx.tap("lane_exons")
+    l0 = e0 = 0
+    for p in parts:
+        first = p.ex_ts[p.rep_exon_off[:-1]]
+        last = p.ex_te[p.rep_exon_off[1:] - 1]
+        order = np.lexsort((np.arange(p.n_reps), first))
+        lanes = np.repeat(order, p.rep_weight[order])
+        n = len(lanes)
+        assert n == p.rep_weight.sum()
+        assert np.array_equal(start[l0:l0 + n], first[lanes])
+        assert np.array_equal(pmax[l0:l0 + n], np.maximum.accumulate(last[lanes]))
+        assert np.array_equal(exons[l0:l0 + n, 0], p.rep_exon_off[lanes] + e0)
+        assert np.array_equal(exons[l0:l0 + n, 1], p.rep_exon_off[lanes + 1] + e0)
+        l0 += n; e0 += len(p.ex_ts)
+    assert l0 == len(start)
+
+
+def test_upload_rejects_what_read_split_asserts(gpu_ctx):
+    """The per-read assertions of read_split() / process_splicing_data (:158-161, :666-668) are checked on the device
+    during the upload; the batch must be refused by the first call that waits."""
+    good = util.make_partition(5, n_reads=100, n_exons=20)
+    from freddie_amd import pack
+    cases = []
+    p = pack.PackedPartition(good.iv_start.copy(), good.iv_end.copy(), good.rep_weight.copy(), good.rep_exon_off.copy(),
+                             good.ex_ts.copy(), good.ex_te.copy(), good.read_rep)
+    p.ex_te[3] = p.ex_ts[3]                                       # exon with start >= end
+    cases.append((p, "start >= end"))
+    p = pack.PackedPartition(good.iv_start.copy(), good.iv_end.copy(), good.rep_weight.copy(), good.rep_exon_off.copy(),
+                             good.ex_ts.copy(), good.ex_te.copy(), good.read_rep)
+    e = int(p.rep_exon_off[1])                                    # second exon of rep 0 moved before the first
+    if e >= 2:
+        p.ex_ts[1], p.ex_te[1] = p.ex_ts[0] - 50, p.ex_ts[0] - 10
+        cases.append((p, "out of order|inside one tint interval"))
+    p = pack.PackedPartition(good.iv_start.copy(), good.iv_end.copy(), good.rep_weight.copy(), good.rep_exon_off.copy(),
+                             good.ex_ts.copy(), good.ex_te.copy(), good.read_rep)
+    p.ex_te[int(p.rep_exon_off[-1]) - 1] = int(p.iv_end[-1]) + 5  # runs past the last tint interval
+    cases.append((p, "inside one tint interval"))
+    for bad, msg in cases:
+        with pytest.raises(_lib.SegError, match=msg):
+            util.run_gpu(gpu_ctx, [good, bad])
+            gpu_ctx.download()
+    util.run_gpu(gpu_ctx, [good])                                 # the context is still usable
+    util.compare_partitions(gpu_ctx, [good], [util.run_oracle(good)])
