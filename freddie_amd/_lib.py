@@ -102,6 +102,13 @@ def load():
     L.fseg_scoring_algorithmic_bytes.argtypes = [vp]
     if L.fseg_abi_version() != 2:
         raise SegError("libfreddie_seg.so ABI version mismatch")
+    if not os.environ.get("FSEG_LIB"):
+        # the built library is git-ignored and travels with the tree: refuse one that was built from other sources
+        want = _build.source_hash(_build.SEG_SRC + [os.path.join(_build.INCLUDE, "freddie_seg.h")], _build.seg_command())
+        have = L.fseg_source_hash().decode()
+        if have != want:
+            raise SegError("%s is stale (built from sources %s, the tree is %s): rebuild with "
+                           "python -c 'import __graft_entry__ as g; g.build()'" % (path, have or "?", want))
     _lib = L
     return L
 

@@ -65,7 +65,7 @@ def test_diagnostic_switches_keep_parity(env, monkeypatch):
 def test_wide_count_dp_for_real():
     """One partition whose DP windows see more than 65 535 reads: the 16-bit count tables cannot hold out(i,j,k), the
     library must pick the 32-bit DP by itself."""
-    part = util.make_partition(77, n_reads=90000, n_exons=14, rp=0.05, max_span=0)
+    part = util.make_partition(77, n_reads=90000, n_exons=14, rp=0.5, jp=0.8, jsd=6.0, max_span=0)    # 3 problems, one sees 72 896 reads
     o = util.run_oracle(part)
     ctx = _lib.Context(0)
     try:
