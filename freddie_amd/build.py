@@ -32,7 +32,8 @@ _STAMP = b"FREDDIE_SRC_HASH="
 
 def source_hash(sources, cmd):
     """sha256 over the build command and the contents of every source / header, first 32 hex digits."""
-    h = hashlib.sha256(" ".join(cmd).encode())
+    # the tree may live anywhere (the GPU box unpacks it under another path): paths inside the tree count relative to it
+    h = hashlib.sha256(" ".join(cmd).replace(ROOT + os.sep, "").replace(ROOT, ".").encode())
     for path in sources:
         with open(path, "rb") as f:
             h.update(b"\0" + os.path.basename(path).encode() + b"\0" + f.read())
