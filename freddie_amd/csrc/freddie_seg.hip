@@ -82,6 +82,7 @@ struct Status {
     u64 cls_queue[3];  // dynamic work counters of the scoring kernels
     u64 dp_cls[3];     // DP problems with n <= kDpSmall / <= kNMax / larger
     u64 cov_queue;
+    u64 solve_cls[3];  // problems solved whole by k_solve (n <= 16 / <= 32 / <= kNMax)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -126,6 +127,23 @@ __device__ __forceinline__ void label_thresholds(i64 L, const double *h_table, i
     while (u >= 0 && !((double)u / dL < l)) --u;
     while ((double)(u + 1) / dL < l && u < L) ++u;
     *lo_out = (int)u;
+}
+
+// The bounds depend only on L (and the run's parameters): a table for the short segments, built once per parameter set,
+// replaces the fp64 divisions in the kernels that evaluate them per problem (a DP window's pairs are mostly a few
+// hundred positions apart).
+constexpr int kThrTab = 8192;
+__global__ void __launch_bounds__(256) k_thr_table(const double *h_table, int h_len, double tau, int2 *tab) {
+    for (int L = blockIdx.x * blockDim.x + threadIdx.x; L < kThrTab; L += gridDim.x * blockDim.x) {
+        int hi = 0x7fffffff, lo = -1;
+        if (L >= 1) label_thresholds((i64)L, h_table, h_len, tau, &hi, &lo);
+        tab[L] = make_int2(hi, lo);
+    }
+}
+__device__ __forceinline__ void label_thresholds_tab(i64 L, const int2 *tab, const double *h_table, int h_len, double tau,
+                                                     int *hi_out, int *lo_out) {
+    if (L < (i64)kThrTab) { const int2 t = tab[L]; *hi_out = t.x; *lo_out = t.y; }
+    else label_thresholds(L, h_table, h_len, tau, hi_out, lo_out);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -874,7 +892,7 @@ struct __align__(16) ProbDesc {
     int outside;    // lanes of the partition outside [lane_lo, lane_lo + lane_n)
     int iv;
     int w0;         // first work item (= chunk 0) of the problem
-    int pad1;
+    int kind;       // kKindArena / kKindTiny / kKindFused: which kernels solve it
 };
 static_assert(sizeof(ProbDesc) == 64, "ProbDesc is one 64-byte record");
 __device__ __forceinline__ ProbDesc load_desc(const ProbDesc *d) {
@@ -1024,21 +1042,39 @@ __global__ void k_prob_range(const Status *st, const int *cand_pn, const int *ca
 //   0: problem slot | DP problems of the small class     1: pairs     2: triples     3: coverage elements
 //   4: work items of class 0 | class 1                   5: work items of class 2 | DP problems of the big class
 //   6: work items of class 3 (huge) | DP problems of the huge class
+//   7: fused problems of class 0 | class 1                   8: fused problems of class 2
 // (work items overall = the four class counts)
-constexpr int kProbCols = 7;
+constexpr int kProbCols = 9;
 __device__ __forceinline__ i64 col_lo(i64 x) { return x & 0xffffffffLL; }
 __device__ __forceinline__ i64 col_hi(i64 x) { return (i64)((u64)x >> 32); }
 constexpr int kDpSmall = 32;
 constexpr int kClsSmall = 16, kClsMid = 32;
 struct ProbSizes { i64 v[kProbCols]; };
 __device__ __forceinline__ int size_class(int n) { return n <= kClsSmall ? 0 : (n <= kClsMid ? 1 : (n <= kNMax ? 2 : 3)); }
-// tiny_max > 0: problems with at most tiny_max candidates are solved whole by k_tiny (one wave each, nothing in the
-// arenas): they get a problem slot and nothing else.
-__device__ __forceinline__ ProbSizes prob_sizes(int n, int n_lanes, int tiny_max) {
+// How the problems of a run are divided among the three ways of solving them:
+//   n <= tiny_max (> 0 in batches of many problems): whole by k_tiny, one wave each; a problem slot and nothing else;
+//   otherwise, lanes <= fuse_lanes and n <= kNMax: whole by k_solve, one workgroup each (coverage, pair labels, counts and
+//     DP without leaving LDS); a problem slot and an entry in its size class's solve list;
+//   otherwise: the arena path -- coverage tiles, one scoring work item per 256 reads, global count tables, DP kernels
+//     (problems that see many reads need many workgroups to score them).
+struct ProbSplit { int tiny_max, fuse_lanes; };
+enum { kKindArena = 0, kKindTiny = 1, kKindFused = 2 };
+__device__ __forceinline__ int prob_kind(int n, int n_lanes, ProbSplit sp) {
+    return n <= sp.tiny_max ? kKindTiny : ((n_lanes <= sp.fuse_lanes && n <= kNMax) ? kKindFused : kKindArena);
+}
+__device__ __forceinline__ ProbSizes prob_sizes(int n, int n_lanes, ProbSplit sp) {
     ProbSizes s;
     for (int q = 0; q < kProbCols; ++q) s.v[q] = 0;
     if (n <= 0) return s;
-    if (n <= tiny_max) { s.v[0] = 1; return s; }
+    const int kind = prob_kind(n, n_lanes, sp);
+    if (kind == kKindTiny) { s.v[0] = 1; return s; }
+    if (kind == kKindFused) {
+        const int c = size_class(n);
+        s.v[0] = 1;
+        s.v[7] = c == 0 ? 1 : (c == 1 ? (1LL << 32) : 0);
+        s.v[8] = c == 2 ? 1 : 0;
+        return s;
+    }
     i64 chunks = (n_lanes + kLaneChunk - 1) / kLaneChunk;
     const int cls = size_class(n);
     s.v[0] = 1 + (n <= kDpSmall ? (1LL << 32) : 0);
@@ -1093,12 +1129,12 @@ __device__ __forceinline__ void wg_scan_cols(const ProbSizes &v, ProbSizes &ex, 
     }
     __syncthreads();
 }
-__device__ __forceinline__ ProbSizes prob_block_sizes(const int *cand_pn, const int *cand_ln, i64 b, i64 n, ProbSizes *per_elem /* 4, may be null */, int tiny_max) {
+__device__ __forceinline__ ProbSizes prob_block_sizes(const int *cand_pn, const int *cand_ln, i64 b, i64 n, ProbSizes *per_elem /* 4, may be null */, ProbSplit sp) {
     ProbSizes acc;
     for (int q = 0; q < kProbCols; ++q) acc.v[q] = 0;
     const i64 i0 = b * kProbBlock + (i64)threadIdx.x * 4;
     for (int e = 0; e < 4; ++e) {
-        ProbSizes sz = i0 + e < n ? prob_sizes(cand_pn[i0 + e], cand_ln[i0 + e], tiny_max) : prob_sizes(0, 0, 0);
+        ProbSizes sz = i0 + e < n ? prob_sizes(cand_pn[i0 + e], cand_ln[i0 + e], sp) : prob_sizes(0, 0, sp);
         if (per_elem) per_elem[e] = sz;
         for (int q = 0; q < kProbCols; ++q) acc.v[q] += sz.v[q];
     }
@@ -1110,6 +1146,7 @@ __device__ __forceinline__ void prob_store_totals(Status *st, const ProbSizes &t
     st->cls_work[0] = (u64)col_lo(t.v[4]); st->cls_work[1] = (u64)col_hi(t.v[4]); st->cls_work[2] = (u64)col_lo(t.v[5]);
     st->cls_work[3] = (u64)col_lo(t.v[6]);
     st->dp_cls[0] = (u64)col_hi(t.v[0]); st->dp_cls[1] = (u64)col_hi(t.v[5]); st->dp_cls[2] = (u64)col_hi(t.v[6]);
+    st->solve_cls[0] = (u64)col_lo(t.v[7]); st->solve_cls[1] = (u64)col_hi(t.v[7]); st->solve_cls[2] = (u64)col_lo(t.v[8]);
 }
 // Largest problem (candidates) and widest problem (reads examined) of the run: they size the big-problem kernels' LDS
 // and pick the DP's count width.  One atomic per block of 1024 candidates -- per-problem atomics on the one address
@@ -1128,13 +1165,13 @@ __device__ __forceinline__ void prob_publish_maxima(Status *st, const int *l_mx)
     if (mx > 0 && (unsigned)mx > __hip_atomic_load(&st->max_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&st->max_n, (unsigned)mx);
     if (ml > 0 && (unsigned)ml > __hip_atomic_load(&st->max_ln, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&st->max_ln, (unsigned)ml);
 }
-__global__ void __launch_bounds__(256) k_prob_scan1(Status *st, const int *cand_pn, const int *cand_ln, i64 *bs, int tiny_max) {
+__global__ void __launch_bounds__(256) k_prob_scan1(Status *st, const int *cand_pn, const int *cand_ln, i64 *bs, ProbSplit sp) {
     __shared__ i64 lds[4 * kProbCols];
     __shared__ int l_mx[8];
     i64 n = (i64)st->n_cand;
     i64 nb = (n + kProbBlock - 1) / kProbBlock;
     for (i64 b = blockIdx.x; b < nb; b += gridDim.x) {
-        ProbSizes acc = prob_block_sizes(cand_pn, cand_ln, b, n, nullptr, tiny_max), ex, tot;
+        ProbSizes acc = prob_block_sizes(cand_pn, cand_ln, b, n, nullptr, sp), ex, tot;
         prob_block_maxima(st, cand_pn, cand_ln, b, n, l_mx);
         wg_scan_cols(acc, ex, tot, lds);
         if (threadIdx.x < kProbCols) bs[b * kProbCols + threadIdx.x] = tot.v[threadIdx.x];
@@ -1168,7 +1205,7 @@ __global__ void __launch_bounds__(256) k_prob_emit(Status *st, const int *cand_p
                                                    const int *cand_iv, const i64 *cand_off, const i64 *bs,
                                                    ProblemArrays pr, i64 prob_cap, int2 *work_pc, int4 *cls_items,
                                                    i64 work_cap, int *dp_items, ProbDesc *desc, const int *iv_start,
-                                                   const int *iv_part, const i64 *part_lane_off, int tiny_max) {
+                                                   const int *iv_part, const i64 *part_lane_off, ProbSplit sp, int *solve_items) {
     __shared__ i64 lds[4 * kProbCols];
     __shared__ int l_slot[kProbBlock], l_cnt[kProbBlock];
     __shared__ int l_mx[8];
@@ -1183,16 +1220,17 @@ __global__ void __launch_bounds__(256) k_prob_emit(Status *st, const int *cand_p
             for (int q = 0; q < kProbCols; ++q) before.v[q] = bs[b * kProbCols + q];
             grand.v[4] = (i64)st->cls_work[0] + ((i64)st->cls_work[1] << 32); grand.v[0] = (i64)st->dp_cls[0] << 32;
             grand.v[5] = (i64)st->cls_work[2] + ((i64)st->dp_cls[1] << 32);
+            grand.v[7] = (i64)st->solve_cls[0] + ((i64)st->solve_cls[1] << 32);
         } else {
             for (int q = 0; q < kProbCols; ++q) { before.v[q] = 0; grand.v[q] = 0; }
             for (i64 bb = 0; bb < nb; ++bb) {
                 if (bb == b) continue;
-                ProbSizes acc = prob_block_sizes(cand_pn, cand_ln, bb, n, nullptr, tiny_max), e2, t2;
+                ProbSizes acc = prob_block_sizes(cand_pn, cand_ln, bb, n, nullptr, sp), e2, t2;
                 wg_scan_cols(acc, e2, t2, lds);
                 for (int q = 0; q < kProbCols; ++q) { if (bb < b) before.v[q] += t2.v[q]; grand.v[q] += t2.v[q]; }
             }
         }
-        ProbSizes acc = prob_block_sizes(cand_pn, cand_ln, b, n, sz, tiny_max);
+        ProbSizes acc = prob_block_sizes(cand_pn, cand_ln, b, n, sz, sp);
         if (!bs) prob_block_maxima(st, cand_pn, cand_ln, b, n, l_mx);   // (with block sums, k_prob_scan1 has done it; read after the barriers below)
         wg_scan_cols(acc, ex, tot, lds);
         if (!bs && threadIdx.x == 0) prob_publish_maxima(st, l_mx);
@@ -1204,6 +1242,7 @@ __global__ void __launch_bounds__(256) k_prob_emit(Status *st, const int *cand_p
         const i64 i0 = b * kProbBlock + (i64)threadIdx.x * 4;
         const i64 g_cls0 = col_lo(grand.v[4]), g_cls1 = col_hi(grand.v[4]), g_cls2 = col_lo(grand.v[5]);
         const i64 g_dp0 = col_hi(grand.v[0]), g_dp1 = col_hi(grand.v[5]);
+        const i64 g_sol0 = col_lo(grand.v[7]), g_sol1 = col_hi(grand.v[7]);
         // what a problem's records need, for this thread's four candidates, in three rounds of loads instead of one
         // chain per candidate (a load under `if (problem)` is a branch with its own wait): candidate -> interval -> partition
         int pn4[4], iv4[4], ll4[4], ln4[4], is4[4], part4[4], lanes4[4];
@@ -1230,13 +1269,20 @@ __global__ void __launch_bounds__(256) k_prob_emit(Status *st, const int *cand_p
                         d.c0 = c - (nn - 1); d.pair_off = ex.v[1]; d.tri_off = ex.v[2]; d.cov_off = ex.v[3];
                         d.n = nn; d.lane_lo = ll4[e]; d.lane_n = ln4[e]; d.g0 = is4[e];
                         d.outside = lanes4[e] - d.lane_n;
-                        d.iv = k; d.w0 = (int)(col_lo(ex.v[4]) + col_hi(ex.v[4]) + col_lo(ex.v[5]) + col_lo(ex.v[6])); d.pad1 = 0;
+                        d.iv = k; d.w0 = (int)(col_lo(ex.v[4]) + col_hi(ex.v[4]) + col_lo(ex.v[5]) + col_lo(ex.v[6]));
+                        d.kind = prob_kind(nn, ln4[e], sp);
                         desc[slot] = d;
                     }
-                    {   // DP problem lists: the small problems first, then the big ones
-                        // (then the huge ones)
+                    const int kind = prob_kind(nn, ln4[e], sp);
+                    if (kind == kKindFused) {   // solve lists: class 0, then class 1, then class 2
+                        const int sc = size_class(nn);
+                        const i64 si = sc == 0 ? col_lo(ex.v[7]) : (sc == 1 ? g_sol0 + col_hi(ex.v[7]) : g_sol0 + g_sol1 + col_lo(ex.v[8]));
+                        if (si < prob_cap) solve_items[si] = (int)slot;
+                    }
+                    if (kind == kKindArena) {   // DP problem lists: the small problems first, then the big ones
+                        // (then the huge ones); k_tiny's and k_solve's problems are in no DP list
                         i64 di = nn <= kDpSmall ? col_hi(ex.v[0]) : (nn <= kNMax ? g_dp0 + col_hi(ex.v[5]) : g_dp0 + g_dp1 + col_hi(ex.v[6]));
-                        if (di < prob_cap && nn > tiny_max) dp_items[di] = (int)slot;     // k_tiny's problems are in no DP list
+                        if (di < prob_cap) dp_items[di] = (int)slot;
                     }
                     int cls = size_class(nn);
                     const i64 e_cls0 = col_lo(ex.v[4]), e_cls1 = col_hi(ex.v[4]), e_cls2 = col_lo(ex.v[5]), e_cls3 = col_lo(ex.v[6]);
@@ -1284,13 +1330,12 @@ __device__ __forceinline__ void pair_decode(int q, int *i, int *j) {
 // S5a  integer label thresholds of every candidate pair of every problem (:490-495)
 __device__ __forceinline__ void pair_thresholds_blocks(i64 first, i64 stride, const Status *st, ProblemArrays pr, const ProbDesc *desc,
                                                        i64 prob_cap, const int *cand_y, const double *h_table, int h_len, double tau,
-                                                       int2 *pair_thr, i64 pair_cap, unsigned *amb_g, unsigned *out_g, i64 tri_cap,
-                                                       int tiny_max) {
+                                                       int2 *pair_thr, i64 pair_cap, unsigned *amb_g, unsigned *out_g, i64 tri_cap) {
     i64 n_prob = (i64)st->n_prob < prob_cap ? (i64)st->n_prob : prob_cap;
     for (i64 p = first; p < n_prob; p += stride) {
         const ProbDesc d = load_desc(desc + p);
         int n = d.n;
-        if (n <= tiny_max) continue;                        // solved by k_tiny: owns nothing in the arenas
+        if (d.kind != kKindArena) continue;                 // solved whole by k_tiny / k_solve: owns nothing in the arenas
         i64 poff = d.pair_off;
         int npairs = n * (n - 1) / 2;
         if (poff + npairs > pair_cap) continue;
@@ -1315,9 +1360,9 @@ __device__ __forceinline__ void pair_thresholds_blocks(i64 first, i64 stride, co
 __global__ void __launch_bounds__(256) k_pair_thresholds(const Status *st, ProblemArrays pr, const ProbDesc *desc, i64 prob_cap,
                                                          const i64 *cand_off, const int *cand_y, const double *h_table,
                                                          int h_len, double tau, int2 *pair_thr, i64 pair_cap,
-                                                         unsigned *amb_g, unsigned *out_g, i64 tri_cap, int tiny_max) {
+                                                         unsigned *amb_g, unsigned *out_g, i64 tri_cap) {
     pair_thresholds_blocks(blockIdx.x, gridDim.x, st, pr, desc, prob_cap, cand_y, h_table, h_len, tau, pair_thr, pair_cap, amb_g, out_g,
-                           tri_cap, tiny_max);
+                           tri_cap);
 }
 
 
@@ -1335,14 +1380,13 @@ __global__ void __launch_bounds__(kLaneChunk) k_cov(Status *st, const ProbDesc *
                                                     const int *ex_ts, const int *ex_te,
                                                     unsigned *cov_g, i64 cov_cap, unsigned char *work_active,
                                                     int cov_blocks, ProblemArrays pr, const double *h_table, int h_len, double tau,
-                                                    int2 *pair_thr, i64 pair_cap, unsigned *amb_g, unsigned *out_g, i64 tri_cap,
-                                                    int tiny_max) {
+                                                    int2 *pair_thr, i64 pair_cap, unsigned *amb_g, unsigned *out_g, i64 tri_cap) {
     // One-partition batches are chains of launch-latency-sized kernels: there the pair thresholds (which, like the
     // coverage, need only the problem list) ride along as the workgroups behind the coverage ones -- one graph node less,
     // and the two overlap (cov_blocks == gridDim.x: no such workgroups, k_pair_thresholds was launched on its own).
     if ((int)blockIdx.x >= cov_blocks) {
         pair_thresholds_blocks(blockIdx.x - cov_blocks, gridDim.x - cov_blocks, st, pr, desc, prob_cap, cand_y, h_table, h_len, tau,
-                               pair_thr, pair_cap, amb_g, out_g, tri_cap, tiny_max);
+                               pair_thr, pair_cap, amb_g, out_g, tri_cap);
         return;
     }
     __shared__ int cp[kNHuge + 4];
@@ -1837,7 +1881,7 @@ __global__ void __launch_bounds__(T) k_dp(Status *st, int dp_class, int nm, cons
                                             const i64 *cand_off, const int *cand_y, const int *iv_part,
                                             const i64 *part_lane_off, const unsigned *out_g, i64 tri_cap,
                                             const unsigned *amb_g, const int2 *pair_thr, i64 pair_cap, int support,
-                                            unsigned char *chosen, int tiny_max, int dp_blocks, uint4 *labels16, i64 labels_n16 FSEG_TPARAM) {
+                                            unsigned char *chosen, int n_lo, int dp_blocks, uint4 *labels16, i64 labels_n16 FSEG_TPARAM) {
     if ((int)blockIdx.x >= dp_blocks) {                 // the workgroups behind the DP ones: label arena fill
         fill_labels(labels16, labels_n16, (i64)(blockIdx.x - dp_blocks) * T + threadIdx.x, (i64)(gridDim.x - dp_blocks) * T);
         return;
@@ -1869,7 +1913,7 @@ __global__ void __launch_bounds__(T) k_dp(Status *st, int dp_class, int nm, cons
         const i64 p = dp_class < 0 ? t : (i64)dp_items[list_base + t];
         const ProbDesc d = load_desc(desc + p);
         int n = d.n;
-        if (n > NM || n <= tiny_max) continue;              // (the latter only when this launch walks every problem: k_tiny's are not in the lists)
+        if (n > NM || n <= n_lo || d.kind != kKindArena) continue;   // (when this launch walks every problem: k_tiny's and k_solve's are not its own)
         if (n > nm) { if (threadIdx.x == 0) atomicOr(&st->err, kErrOverflowNm); continue; }
         if (sizeof(OutT) == 2 && d.lane_n >= 65536) { if (threadIdx.x == 0) atomicOr(&st->err, kErrNeedWideDp); continue; }
         i64 poff = d.pair_off, toff = d.tri_off;
@@ -2124,6 +2168,236 @@ __global__ void __launch_bounds__(256, 6) k_tiny(Status *st, const ProbDesc *des
                                        part_a + wave * 64, top_key + wave, chosen + d.c0 FSEG_DARG);
         if (lane == 0) pr.chain[p] = chain;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// S5 whole, for problems that see few reads (at most kFuseLanes -- in batches of many partitions that is every problem: a
+// DP window of a 500-read partition overlaps some 40 .. 130 of them): ONE WORKGROUP takes a problem from its candidates to
+// its chosen breakpoints without leaving LDS --
+//   pair thresholds (:490-495 as integer bounds) into registers, a thread keeps the pairs q = tid, tid + T, ..;
+//   per 64 reads: window coverage (get_cumulative_coverage :188-246) by (read, candidate range) threads -- every read's
+//     exon walk is cut into T/64 pieces that run side by side --, pair planes and ambiguity counts (:488-506), triple
+//     counts (:509-528) into a table of CntT counters (8 bit when no problem of the launch sees more than 255 reads);
+//   then the planes' LDS becomes M / in / A and dp_solve (:532-566, :592-594) runs on the count table where it lies.
+// Nothing of such a problem exists in global memory between its descriptor and its chosen flags: no coverage tiles, no
+// threshold / ambiguity / count arenas, no work items, no DP list entry.  (The arena path remains for problems that see
+// thousands of reads, where one problem has to be spread over many workgroups.)
+// ---------------------------------------------------------------------------------------------
+constexpr int kFuseLanes = 255;   // (four 64-read rounds at most: a problem that sees more is quicker spread over work items;
+                                  //  and 8-bit counters always suffice)
+template <int NM> struct SolveCfg {
+    static constexpr int kThreads = ScoreCfg<NM>::kThreads;
+    static constexpr int kSlots = ScoreCfg<NM>::kSlots;
+    static constexpr int kRanges = kThreads / 64;                 // candidate ranges a read's coverage walk is cut into
+    // waves per SIMD asked of the register allocator (HIP's second launch bound): the kernel is mostly waiting (descriptor
+    // -> candidates -> exon block -> LDS phases -> DP chain), so what it needs is many problems in flight, not many
+    // registers per thread; the big class must fit two 8-wave workgroups per CU
+#ifndef FSEG_SOLVE_OCC
+#define FSEG_SOLVE_OCC 1
+#endif
+    static constexpr int kMinBlocks = !FSEG_SOLVE_OCC ? 1 : (NM <= 16 ? 5 : 4);
+};
+inline size_t solve_lds_for(int nm, int cov_stride, int cnt_bytes) {
+    const size_t pairs = (size_t)nm * (nm - 1) / 2, tri = (size_t)nm * (nm - 1) * (nm - 2) / 6;
+    return ((pairs * 16 + (size_t)kSub * cov_stride * 4 + ((tri + 15) & ~(size_t)15) * cnt_bytes) + 15) & ~(size_t)15;
+}
+template <int NM, typename CntT>
+__global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBlocks) k_solve(Status *st, int cls, int nm, const int *solve_items, ProblemArrays pr,
+                                                                  const ProbDesc *desc, i64 prob_cap, const int *cand_y,
+                                                                  const longlong2 *lane_ex, const int *ex_ts, const int *ex_te,
+                                                                  const double *h_table, int h_len, double tau, const int2 *thr_tab,
+                                                                  int support, unsigned char *chosen FSEG_TPARAM) {
+    using C = SolveCfg<NM>;
+    constexpr int T = C::kThreads, NR = C::kRanges;
+    constexpr int PACK = 4 / (int)sizeof(CntT);                    // counters per 32-bit read-modify-write
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ int cy_s[NM + 4];
+    __shared__ int iend_s[NM + 4];
+    __shared__ i64 part_v[T];
+    __shared__ unsigned char part_a[T];
+    __shared__ int top_key[T / 64];
+    const int rt_pairs = nm * (nm - 1) / 2;
+    constexpr int rt_stride = NM + 1;             // compile-time row stride (odd: rows do not collide on LDS banks)
+    uint4 *planes = reinterpret_cast<uint4 *>(smem);                                         // rt_pairs * 16 B; later M | in | A
+    unsigned *cov = reinterpret_cast<unsigned *>(smem + (size_t)rt_pairs * 16);              // kSub * rt_stride * 4 B
+    CntT *cnt = reinterpret_cast<CntT *>(cov + kSub * rt_stride);                            // C(nm,3) counters
+    i64 *M = reinterpret_cast<i64 *>(smem);
+    int *in_s = reinterpret_cast<int *>(M + rt_pairs);
+    unsigned char *A = reinterpret_cast<unsigned char *>(in_s + rt_pairs);
+    if ((i64)st->n_prob > prob_cap) return;                          // lists incomplete (a run that only sizes the arenas)
+    // cls < 0: every solve list (batches of few problems: one launch instead of three)
+    const i64 list_base = cls <= 0 ? 0 : (cls == 1 ? (i64)st->solve_cls[0] : (i64)st->solve_cls[0] + (i64)st->solve_cls[1]);
+    const i64 list_n = cls < 0 ? (i64)st->solve_cls[0] + (i64)st->solve_cls[1] + (i64)st->solve_cls[2] : (i64)st->solve_cls[cls];
+    const int r_lane = threadIdx.x & 63, w_rng = threadIdx.x >> 6;
+#ifdef FSEG_SCORE_TIMING
+    // diagnostic build: phase clocks of the class given by tacc[15] (slots 0..5 scoring phases, 8..12 the DP's)
+    __shared__ unsigned long long tick_sink[16];
+    const bool timed = (int)tacc[15] == cls;
+    unsigned long long *tk = timed ? tacc : tick_sink;
+    unsigned long long *dp_tacc = tk; unsigned long long dt_prev = wall_clock64();
+#define FSEG_STICK(i) FSEG_DTICK(i)
+#else
+#define FSEG_STICK(i)
+#endif
+    for (i64 t = blockIdx.x; t < list_n; t += gridDim.x) {           // static stride; the lists are in candidate order
+        const int p = solve_items[list_base + t];
+        const ProbDesc d = load_desc(desc + p);
+        const int n = d.n;
+        __syncthreads();                                             // the previous problem's DP is done with LDS
+        FSEG_STICK(0);
+        if (n > nm || n > NM) { if (threadIdx.x == 0) atomicOr(&st->err, kErrOverflowNm); continue; }
+        if (sizeof(CntT) == 1 && d.lane_n > 255) { if (threadIdx.x == 0) atomicOr(&st->err, kErrNeedWideDp); continue; }
+        const int npairs = n * (n - 1) / 2, ntri = n * (n - 1) * (n - 2) / 6;
+        const int *cy = cand_y + d.c0;
+        for (int j = threadIdx.x; j < n; j += T) cy_s[j] = cy[j];
+        {
+            uint4 *z = reinterpret_cast<uint4 *>(cnt);
+            for (int x = threadIdx.x; x < (ntri * (int)sizeof(CntT) + 15) / 16; x += T) z[x] = make_uint4(0, 0, 0, 0);
+        }
+        __syncthreads();
+        // this thread's pairs: (i, j), integer label bounds, ambiguity count -- in registers for the whole problem
+        int pi[C::kSlots], pj[C::kSlots], th_hi[C::kSlots], th_lo[C::kSlots];
+        unsigned amb_acc[C::kSlots];
+#pragma unroll
+        for (int s = 0; s < C::kSlots; ++s) {
+            const int q = s * T + threadIdx.x;
+            amb_acc[s] = 0; pi[s] = 0; pj[s] = 1; th_hi[s] = 0x7fffffff; th_lo[s] = -1;
+            if (q < npairs) {
+                const unsigned short ij = g_pair_ij[q];
+                pi[s] = ij & 255; pj[s] = ij >> 8;
+                label_thresholds_tab((i64)cy_s[pj[s]] - cy_s[pi[s]] + 1, thr_tab, h_table, h_len, tau, &th_hi[s], &th_lo[s]);
+            }
+        }
+        if (threadIdx.x < n) {
+            // iend_s[j] = number of i < j with cand_j - cand_i >= 5 (candidates ascending): binary search
+            int j = threadIdx.x, lim = cy_s[j] - 5, lo = 0, hi = j;
+            while (lo < hi) { int mid = (lo + hi) >> 1; if (cy_s[mid] <= lim) lo = mid + 1; else hi = mid; }
+            iend_s[j] = lo;
+        }
+        FSEG_STICK(1);
+        // this thread's share of a tile's coverage: read r_lane, candidates [ja, jb) of 1 .. n-1 (at most kCovJ of them)
+        constexpr int kCovJ = (NM - 1 + NR - 1) / NR;
+        const int ja = 1 + (int)((i64)(n - 1) * w_rng / NR), jb = 1 + (int)((i64)(n - 1) * (w_rng + 1) / NR);
+        const int cp0 = d.g0 + cy_s[0];
+        int cjv[kCovJ];
+#pragma unroll
+        for (int u = 0; u < kCovJ; ++u) cjv[u] = ja + u < jb ? d.g0 + cy_s[ja + u] : cp0;     // beyond the share: an empty window
+        for (int r0 = 0; r0 < d.lane_n; r0 += kSub) {
+            int n_valid = d.lane_n - r0;
+            if (n_valid > kSub) n_valid = kSub;
+            // ---- A: window coverage cov[r][j] = positions of the read's closed exons in [cand_0, cand_j)
+            //      (get_cumulative_coverage :188-246) = sum over the exons of |[ts, te] n [cand_0, cand_j)|.  Written as that sum
+            //      the walk has no search and no data-dependent loads beyond the exon block itself: eight exons per round from
+            //      clamped addresses (a slot past the read's last exon repeats it as an empty interval), all in flight together.
+            {
+                const bool valid = r_lane < n_valid;
+                const longlong2 ex = lane_ex[d.lane_lo + r0 + (valid ? r_lane : 0)];
+                int acc[kCovJ];
+#pragma unroll
+                for (int u = 0; u < kCovJ; ++u) acc[u] = 0;
+                for (i64 eb = ex.x; eb < ex.y; eb += 8) {
+                    int ts8[8], te8[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const i64 idx = eb + u < ex.y ? eb + u : ex.y - 1;
+                        ts8[u] = ex_ts[idx]; te8[u] = ex_te[idx];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int a0 = max(ts8[u], cp0);
+                        const int b1 = eb + u < ex.y ? te8[u] + 1 : a0;       // closed exon -> half-open end; padding slots are empty
+#pragma unroll
+                        for (int v = 0; v < kCovJ; ++v) acc[v] += max(0, min(b1, cjv[v]) - a0);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < kCovJ; ++u) if (ja + u < jb) cov[r_lane * rt_stride + ja + u] = valid ? (unsigned)acc[u] : 0u;
+                if (w_rng == 0) cov[r_lane * rt_stride] = 0;
+            }
+            lds_barrier();
+            FSEG_STICK(2);
+            // ---- B: pair planes (read b of a plane word lands on bit 31-b, as in k_score) -----------------------------
+            const int nv1 = n_valid - 32;
+            const unsigned valid0 = n_valid >= 32 ? 0xffffffffu : (n_valid > 0 ? ~(0xffffffffu >> n_valid) : 0u);
+            const unsigned valid1 = nv1 >= 32 ? 0xffffffffu : (nv1 > 0 ? ~(0xffffffffu >> nv1) : 0u);
+#pragma unroll
+            for (int s = 0; s < C::kSlots; ++s) {
+                const int q = s * T + threadIdx.x;
+                if (q < npairs) {
+                    const int i = pi[s], j = pj[s], hi = th_hi[s], lo = th_lo[s];
+                    unsigned y0 = 0, z0 = 0, y1 = 0, z1 = 0;
+#define FSEG_SHIFT_IN(acc, cmp, a, b) asm("v_cmp_" cmp "_i32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(a), "v"(b) : "vcc")
+#pragma unroll
+                    for (int b = 0; b < 32; ++b) {
+                        int dd = (int)(cov[b * rt_stride + j] - cov[b * rt_stride + i]);
+                        FSEG_SHIFT_IN(y0, "ge", dd, hi);
+                        FSEG_SHIFT_IN(z0, "le", dd, lo);
+                    }
+                    if (nv1 > 0) {
+#pragma unroll
+                        for (int b = 0; b < 32; ++b) {
+                            int dd = (int)(cov[(32 + b) * rt_stride + j] - cov[(32 + b) * rt_stride + i]);
+                            FSEG_SHIFT_IN(y1, "ge", dd, hi);
+                            FSEG_SHIFT_IN(z1, "le", dd, lo);
+                        }
+                    }
+#undef FSEG_SHIFT_IN
+                    y0 &= valid0; z0 &= valid0; y1 &= valid1; z1 &= valid1;     // rows beyond the problem's reads hold nothing
+                    planes[q] = make_uint4(y0, y1, z0, z1);
+                    amb_acc[s] += __popc(~(y0 | z0) & valid0) + __popc(~(y1 | z1) & valid1);
+                }
+            }
+            lds_barrier();
+            FSEG_STICK(3);
+            // ---- C: triples; the (j,k) pairs are enumerated with j descending (lanes of a wave share the trip count) ---
+#pragma unroll
+            for (int s = 0; s < C::kSlots; ++s) {
+                const int r = s * T + threadIdx.x;
+                if (r >= npairs) continue;
+                const int m = pj[s], x = pi[s];                       // pair r = (x, m): m = n-1-j in [1, n-1], x = k-j-1 in [0, m)
+                const int j = n - 1 - m, kk = j + 1 + x;
+                if (j == 0 || cy_s[kk] - cy_s[j] < 5) continue;       // dp(): segment too small (:540)
+                const uint4 B = planes[kk * (kk - 1) / 2 + j];
+                if ((B.x | B.y | B.z | B.w) == 0) continue;
+                const int tbase = kk * (kk - 1) * (kk - 2) / 6 + j * (j - 1) / 2;
+                const int abase = j * (j - 1) / 2;
+                const int i_end = iend_s[j];                          // i with cand_j - cand_i >= 5 (:540), a prefix
+#define FSEG_TRI_CNT(Av) (__popc((Av).x & B.z) + __popc((Av).y & B.w) + __popc((Av).z & B.x) + __popc((Av).w & B.y))
+                CntT *o = cnt + tbase;
+                int i = 0;
+                for (; i < i_end && ((tbase + i) & (PACK - 1)); ++i) {          // up to a 32-bit boundary of the table
+                    const uint4 Av = planes[abase + i];
+                    o[i] = (CntT)(o[i] + FSEG_TRI_CNT(Av));
+                }
+                for (; i + PACK <= i_end; i += PACK) {                // PACK counters per 32-bit read-modify-write: a counter
+                    unsigned add = 0;                                 // never exceeds the reads of the problem, so no carry
+#pragma unroll
+                    for (int u = 0; u < PACK; ++u) { const uint4 Av = planes[abase + i + u]; add |= (unsigned)FSEG_TRI_CNT(Av) << (8 * (int)sizeof(CntT) * u); }
+                    *reinterpret_cast<unsigned *>(o + i) += add;
+                }
+                for (; i < i_end; ++i) {
+                    const uint4 Av = planes[abase + i];
+                    o[i] = (CntT)(o[i] + FSEG_TRI_CNT(Av));
+                }
+#undef FSEG_TRI_CNT
+            }
+            lds_barrier();
+            FSEG_STICK(4);
+        }
+        // ---- DP on the tables where they lie: the planes' LDS becomes M | in | A ---------------------------------------
+        // a read outside the lane range has no coverage in the window: ambiguous exactly where lo < 0 (only tau = 1)
+        int in_val[C::kSlots];
+#pragma unroll
+        for (int s = 0; s < C::kSlots; ++s) in_val[s] = -(int)((i64)amb_acc[s] + (th_lo[s] < 0 ? (i64)d.outside : 0));
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < C::kSlots; ++s) { const int q = s * T + threadIdx.x; if (q < npairs) in_s[q] = in_val[s]; }
+        __syncthreads();
+        FSEG_STICK(9);
+        const int chain = dp_solve<T>(n, cnt, in_s, M, A, cy_s, support, part_v, part_a, top_key, chosen + d.c0 FSEG_DARG);
+        if (threadIdx.x == 0) pr.chain[p] = chain;
+    }
+#undef FSEG_STICK
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2920,7 +3194,7 @@ struct fseg_ctx {
         d_hc_part, d_hc_p0, d_hc_n, d_hc_glo, d_hc_ghi;
     // slab_in, derived on the device by the upload
     DevBuf d_lane_ex, d_lane_start, d_lane_pmax, d_hc_llo, d_hc_lhi, d_edge, d_key_a, d_key_b, d_val_a, d_val_b, d_rep_last;
-    DevBuf d_w_main, d_w_refine, d_h_table;     // parameter tables (own allocations)
+    DevBuf d_w_main, d_w_refine, d_h_table, d_thr_tab;     // parameter tables (own allocations)
     // device buffers: position-sized (slab_pos)
     DevBuf d_y_raw, d_y, d_flag, d_cflag, d_v, d_scan_state, d_bsum, d_bsum_side, d_g, d_pk, d_pf, d_kp, d_final_flag;
     int n_hist_chunks = 0;
@@ -2933,7 +3207,7 @@ struct fseg_ctx {
     // problems / arenas (slab_arena)
     DevBuf d_prob_iv, d_prob_start, d_prob_n, d_prob_pair_off, d_prob_tri_off, d_prob_flags, d_prob_chain,
         d_prob_cov_off, d_prob_lane_lo, d_prob_lane_n;
-    DevBuf d_dp_items, d_prob_desc, d_work_pc, d_cls_items, d_work_active, d_pair_thr, d_amb, d_out, d_cov;
+    DevBuf d_dp_items, d_solve_items, d_prob_desc, d_work_pc, d_cls_items, d_work_active, d_pair_thr, d_amb, d_out, d_cov;
     i64 prob_cap = 0, work_cap = 0, pair_cap = 0, tri_cap = 0, label_cap = 0, chunk_cap = 0, cov_cap = 0;
     DevBuf d_status, d_prep, d_tacc;
     Status *h_status = nullptr;   // pinned
@@ -2962,11 +3236,21 @@ struct fseg_ctx {
     // Independent kernels of one run (threshold | candidates, the scoring size classes, the DP classes) go to side
     // streams (pair thresholds | coverage was tried too: the branch cost more than the overlap gave) between a fork and a join, so a captured run becomes a graph with parallel
     // branches (FSEG_NO_FORK=1 keeps everything on the one stream).
-    static constexpr int kSide = 3, kForkEvents = 16;
+    // (four streams in all: the runtime multiplexes a process's streams onto four hardware queues, and two streams that
+    // share one run one after the other -- with seven streams the threshold and candidate chains stopped overlapping)
+    static constexpr int kSide = 3, kForkEvents = 32;
     hipStream_t side[kSide] = {};
     hipEvent_t fj[kForkEvents] = {};
     bool use_fork = true;
-    bool use_tiny = true;       // FSEG_NO_TINY=1 keeps every problem on the arena-based path
+    bool use_tiny = true;       // FSEG_NO_TINY=1: no problem goes to k_tiny
+    bool use_fuse = true;       // FSEG_NO_FUSE=1: no problem goes to k_solve (everything that is not tiny takes the arena path)
+    bool fuse_on = true;        // this batch's problems go to k_solve: decided per batch -- when its widest problem sees at most
+                                // kFuseLanes reads, i.e. all of them qualify (measured: a batch of 500-read partitions gains 8 %, while
+                                // batches whose problems straddle the limit run both paths side by side and lose up to 8 %)
+    // what the lists of the resident batch hold (read from the status record; exact once the batch has run or been sized):
+    // launches over an empty list are skipped
+    bool counts_known = false;
+    i64 n_solve[3] = {0, 0, 0}, n_cls_work[4] = {0, 0, 0, 0}, n_dp_cls[3] = {0, 0, 0}, n_arena_prob = 0;
     i64 tiny_from = 256;        // problems above which k_tiny is used (FSEG_TINY_FROM; tests force 0)
     bool trace = false;         // FSEG_TRACE=1: phase timers of upload / run on stderr
 };
@@ -3071,6 +3355,7 @@ int alloc_arenas(fseg_ctx *c) {
     cv.add(c->d_prob_flags, (size_t)c->prob_cap * 4);
     cv.add(c->d_prob_chain, (size_t)c->prob_cap * 4);
     cv.add(c->d_dp_items, (size_t)c->prob_cap * 4);
+    cv.add(c->d_solve_items, (size_t)c->prob_cap * 4);
     cv.add(c->d_prob_cov_off, (size_t)c->prob_cap * 8);
     cv.add(c->d_prob_lane_lo, (size_t)c->prob_cap * 4);
     cv.add(c->d_prob_lane_n, (size_t)c->prob_cap * 4);
@@ -3111,6 +3396,10 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
     // cross-stream dependencies there (measured: config2 +4 %), so they stay on the one stream.
     const bool forking = c->use_fork && !c->small_batch;
     const int tiny_max = c->tiny_on ? kTiny : 0;
+    const ProbSplit split{tiny_max, (c->use_fuse && c->fuse_on) ? kFuseLanes : -1};
+    // list sizes known (the batch has been sized or has run): launches over an empty list are left out
+    const bool known = c->counts_known;
+    const bool any_arena = !known || c->n_arena_prob > 0;
     int fj_next = 0;
     hipError_t fj_err = hipSuccess;
     auto fj_event = [&]() { hipEvent_t e = c->fj[fj_next % fseg_ctx::kForkEvents]; ++fj_next; return e; };
@@ -3225,7 +3514,7 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
                        c->d_part_lane_off.as<i64>(), c->d_lane_start.as<int>(), c->d_lane_pmax.as<int>(),
                        c->d_cand_ll.as<int>(), c->d_cand_ln.as<int>());
     if (prob_bs) {
-        hipLaunchKernelGGL(k_prob_scan1, dim3(pg), dim3(256), 0, s, st, c->d_cand_pn.as<int>(), c->d_cand_ln.as<int>(), prob_bs, tiny_max);
+        hipLaunchKernelGGL(k_prob_scan1, dim3(pg), dim3(256), 0, s, st, c->d_cand_pn.as<int>(), c->d_cand_ln.as<int>(), prob_bs, split);
         hipLaunchKernelGGL(k_prob_scan2, dim3(1), dim3(256), 0, s, st, prob_bs);
     }
     end(ST_FIX);
@@ -3236,9 +3525,9 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
                        c->d_cand_ln.as<int>(), c->d_seg_iv.as<int>(), c->d_cand_off.as<i64>(), prob_bs,
                        pr, c->prob_cap, c->d_work_pc.as<int2>(), c->d_cls_items.as<int4>(),
                        c->work_cap, c->d_dp_items.as<int>(), c->d_prob_desc.as<ProbDesc>(), c->d_iv_start.as<int>(),
-                       c->d_iv_part.as<int>(), c->d_part_lane_off.as<i64>(), tiny_max);
+                       c->d_iv_part.as<int>(), c->d_part_lane_off.as<i64>(), split, c->d_solve_items.as<int>());
     // S5
-    if (c->prob_cap > 0) {
+    if (c->prob_cap > 0 && any_arena) {
         const int cov_blocks = work_grid < 2048 ? work_grid : 2048;
         const int pt_blocks = c->small_batch ? grid_for(c->prob_cap, 1, 512) : 0;       // fused only for small batches
         if (!pt_blocks)
@@ -3246,14 +3535,14 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
                                c->d_prob_desc.as<ProbDesc>(), c->prob_cap, c->d_cand_off.as<i64>(), c->d_cand_y.as<int>(),
                                c->d_h_table.as<double>(), c->P.h_len,
                                c->P.threshold_rate, c->d_pair_thr.as<int2>(), c->pair_cap, c->d_amb.as<unsigned>(),
-                               c->d_out.as<unsigned>(), c->tri_cap, tiny_max);
+                               c->d_out.as<unsigned>(), c->tri_cap);
         hipLaunchKernelGGL(k_cov, dim3(cov_blocks + pt_blocks), dim3(kLaneChunk), 0, s, st,
                            c->d_prob_desc.as<ProbDesc>(), c->prob_cap, c->d_work_pc.as<int2>(), c->work_cap, c->d_cand_off.as<i64>(),
                            c->d_cand_y.as<int>(), c->d_iv_start.as<int>(), c->d_lane_ex.as<longlong2>(),
                            c->d_ex_ts.as<int>(), c->d_ex_te.as<int>(),
                            c->d_cov.as<unsigned>(), c->cov_cap, c->d_work_active.as<unsigned char>(),
                            cov_blocks, pr, c->d_h_table.as<double>(), c->P.h_len, c->P.threshold_rate, c->d_pair_thr.as<int2>(),
-                           c->pair_cap, c->d_amb.as<unsigned>(), c->d_out.as<unsigned>(), c->tri_cap, tiny_max);
+                           c->pair_cap, c->d_amb.as<unsigned>(), c->d_out.as<unsigned>(), c->tri_cap);
     }
     end(ST_SCORE_PREP);
     }   // do_pre2
@@ -3281,17 +3570,36 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
                            c->d_cand_y.as<int>(), c->d_work_active.as<unsigned char>(), c->d_cov.as<unsigned>(),        \
                            c->cov_cap, c->d_pair_thr.as<int2>(), c->pair_cap, c->d_out.as<unsigned>(), c->tri_cap,      \
                            c->d_amb.as<unsigned>() FSEG_TARG)
+#define FSEG_LAUNCH_SOLVE(Q, NMV, CNT, CLS, N_ITEMS, MAXWG)                                                                  \
+            hipLaunchKernelGGL((k_solve<NMV, CNT>), dim3(grid_for((N_ITEMS), 1, (MAXWG))), dim3(SolveCfg<NMV>::kThreads),       \
+                               solve_lds_for((NMV) == kNMax ? c->nm_big : (NMV), (NMV) + 1, (int)sizeof(CNT)), Q, st, CLS,      \
+                               ((NMV) == kNMax ? c->nm_big : (NMV)), c->d_solve_items.as<int>(), pr, c->d_prob_desc.as<ProbDesc>(), \
+                               c->prob_cap, c->d_cand_y.as<int>(), c->d_lane_ex.as<longlong2>(), c->d_ex_ts.as<int>(),         \
+                               c->d_ex_te.as<int>(), c->d_h_table.as<double>(), c->P.h_len, c->P.threshold_rate,               \
+                               c->d_thr_tab.as<int2>(), c->P.min_read_support_outside, c->d_chosen.as<unsigned char>() FSEG_TARG)
+#define FSEG_LAUNCH_SOLVE_W(Q, NMV, CLS, N_ITEMS, MAXWG) FSEG_LAUNCH_SOLVE(Q, NMV, unsigned char, CLS, N_ITEMS, MAXWG)
+        // Two ways a problem is scored (prob_kind): the arena path's work items (k_score per size class) and the problems that
+        // see few reads (at most 255: 8-bit counters), whole, one workgroup each (k_solve per size class).
+        // A batch usually holds only one kind; a class's two launches share a stream.
+        const bool any_solve = c->use_fuse && c->fuse_on && (!known || c->n_solve[0] + c->n_solve[1] + c->n_solve[2] > 0);
+        const i64 cap = c->prob_cap;
         if (c->small_batch) {
-            FSEG_LAUNCH_SCORE(s, kNMax, -1, 512);    // few work items: one launch for every size class
-        } else {                                     // the size classes own disjoint problems: three concurrent launches
+            if (any_arena) FSEG_LAUNCH_SCORE(s, kNMax, -1, 512);    // few work items: one launch for every size class
+            if (any_solve) FSEG_LAUNCH_SOLVE_W(s, kNMax, -1, known ? c->n_solve[0] + c->n_solve[1] + c->n_solve[2] : cap, 512);
+        } else {                                     // the size classes own disjoint problems: three concurrent chains
             hipStream_t q1 = fork(0), q0 = fork(1);
-            FSEG_LAUNCH_SCORE(s, kNMax, 2, 512);     // big problems: they are the long poles
-            FSEG_LAUNCH_SCORE(q1, kClsMid, 1, 1280);
-            FSEG_LAUNCH_SCORE(q0, kClsSmall, 0, 2048);
+            if (any_arena && (!known || c->n_cls_work[2] > 0)) FSEG_LAUNCH_SCORE(s, kNMax, 2, 512);     // big problems: they are the long poles
+            if (any_solve && (!known || c->n_solve[2] > 0)) FSEG_LAUNCH_SOLVE_W(s, kNMax, 2, known ? c->n_solve[2] : cap, 512);
+            if (any_arena && (!known || c->n_cls_work[1] > 0)) FSEG_LAUNCH_SCORE(q1, kClsMid, 1, 1280);
+            if (any_solve && (!known || c->n_solve[1] > 0)) FSEG_LAUNCH_SOLVE_W(q1, kClsMid, 1, known ? c->n_solve[1] : cap, 2048);
+            if (any_arena && (!known || c->n_cls_work[0] > 0)) FSEG_LAUNCH_SCORE(q0, kClsSmall, 0, 2048);
+            if (any_solve && (!known || c->n_solve[0] > 0)) FSEG_LAUNCH_SOLVE_W(q0, kClsSmall, 0, known ? c->n_solve[0] : cap, 4096);
             join(0); join(1);
         }
+#undef FSEG_LAUNCH_SOLVE_W
+#undef FSEG_LAUNCH_SOLVE
 #undef FSEG_LAUNCH_SCORE
-        if (c->have_huge)
+        if (c->have_huge && any_arena)
             hipLaunchKernelGGL(k_score_huge, dim3(256), dim3(512), kHugeScoreLds, s, st, c->d_dp_items.as<int>(), pr,
                                c->d_prob_desc.as<ProbDesc>(), c->prob_cap, c->work_cap, c->d_cand_y.as<int>(),
                                c->d_cov.as<unsigned>(), c->cov_cap, c->d_pair_thr.as<int2>(), c->pair_cap,
@@ -3302,10 +3610,10 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
     const i64 labels_n16 = (c->label_cap + 15) / 16;            // the arena is allocated in multiples of 16 bytes
     // the label arena's '0' fill rides the big-problem DP launch as extra workgroups -- unless the run is being sized
     // (the arena's size is not known yet) or there is no DP launch
-    const bool ride_fill = !sized && c->prob_cap > 0 && c->label_cap > 0;
+    const bool ride_fill = !sized && c->prob_cap > 0 && c->label_cap > 0 && any_arena;
     if (do_post1) {
     begin(ST_DP);
-    if (c->prob_cap > 0) {
+    if (c->prob_cap > 0 && any_arena) {
         int dp_grid = grid_for(c->prob_cap, 1, 1024);
         const int fill_blocks = ride_fill ? grid_for(labels_n16 / 8 + 1, 512, 512) : 0;
 #define FSEG_LAUNCH_DP(NMV, TV, OUTT, NM_RT, DPCLASS, MAXWG)                                                             \
@@ -3439,12 +3747,24 @@ int run_input_errors(fseg_ctx *c, const Status &s) {
     return FSEG_OK;
 }
 
+// what the lists of the batch hold, from the status record of a run (or of the sizing pass)
+void note_counts(fseg_ctx *c, const Status &s) {
+    for (int q = 0; q < 3; ++q) { c->n_solve[q] = (i64)s.solve_cls[q]; c->n_dp_cls[q] = (i64)s.dp_cls[q]; }
+    for (int q = 0; q < 4; ++q) c->n_cls_work[q] = (i64)s.cls_work[q];
+    c->n_arena_prob = (i64)s.dp_cls[0] + (i64)s.dp_cls[1] + (i64)s.dp_cls[2];
+    if (!c->counts_known) drop_graph(c);
+    c->counts_known = true;
+}
+
 // launch parameters that follow from the sizes of a run (exact in a sized run, last run's otherwise)
 void adapt_to(fseg_ctx *c, const Status &s) {
     const bool old_small = c->small_batch, old_self = c->prob_self_scan, old_tiny = c->tiny_on;
     const int old_nm = c->nm_big;
     c->small_batch = (i64)s.n_prob <= 256 && (i64)s.n_work <= 1024;
     c->tiny_on = (i64)s.n_prob > c->tiny_from && c->use_tiny;   // depends on the problem count only, which k_tiny does not change
+    const bool old_fuse = c->fuse_on;
+    c->fuse_on = (i64)s.max_ln <= kFuseLanes;                   // (the widest problem does not depend on the split either)
+    if (old_fuse != c->fuse_on) { c->counts_known = false; drop_graph(c); }
     c->prob_self_scan = (i64)s.n_cand <= c->prob_self_max;
     {   // the big-problem LDS carve-up: the largest problem (+ headroom, multiple of 4)
         int want = (int)s.max_n + 3;
@@ -3478,7 +3798,7 @@ int finish_run(fseg_ctx *c) {
         unsigned ovf = s.err & (kErrOverflowPairs | kErrOverflowTri | kErrOverflowWork | kErrOverflowLabels |
                                 kErrOverflowProblems | kErrOverflowChunks | kErrOverflowCov);
         if (s.err & kErrOverflowNm) { ovf |= kErrOverflowNm; c->nm_big = kNMax; }
-        if (((s.err & kErrNeedWideDp) || (i64)s.max_ln >= 65536) && !c->dp_wide_counts) { ovf |= kErrNeedWideDp; c->dp_wide_counts = true; drop_graph(c); }
+        if ((i64)s.max_ln >= 65536 && !c->dp_wide_counts) { ovf |= kErrNeedWideDp; c->dp_wide_counts = true; drop_graph(c); }
         if (s.err & kErrScanStall) { ovf |= kErrScanStall; c->scan_single_max = 0; c->force_scan_stall = false; drop_graph(c); }
         if (s.dp_cls[2] > 0 && !c->have_huge) { ovf |= kErrProblemTooLarge << 16; c->have_huge = true; drop_graph(c); }   // rerun with the huge-problem kernels
         bool need = ovf != 0 || (i64)s.n_prob > c->prob_cap || (i64)s.n_work > c->work_cap ||
@@ -3489,6 +3809,7 @@ int finish_run(fseg_ctx *c) {
             c->ran = true;
             const int timed_graphs = c->n_graphs;
             collect_stage_times(c, timed_graphs);
+            note_counts(c, s);
             adapt_to(c, s);
             return run_input_errors(c, s);
         }
@@ -3525,12 +3846,13 @@ int run_sized(fseg_ctx *c) {
         {   // k_tiny's share of the problems was decided from the previous batch: if this batch decides otherwise, the
             // arena sizes change with it -- redo the (cheap) problem scan under the right setting
             const bool tiny = (i64)s.n_prob > c->tiny_from && c->use_tiny;
-            if (tiny != c->tiny_on) {
-                c->tiny_on = tiny;
+            const bool fuse = (i64)s.max_ln <= kFuseLanes;
+            if (tiny != c->tiny_on || fuse != c->fuse_on) {
+                c->tiny_on = tiny; c->fuse_on = fuse;
                 const int pg = grid_for(c->NPOS / 8 / kProbBlock + 1, 1, 1024);
                 Status *st = c->d_status.as<Status>();
                 hipLaunchKernelGGL(k_prob_scan1, dim3(pg), dim3(256), 0, c->stream, st, c->d_cand_pn.as<int>(), c->d_cand_ln.as<int>(),
-                                   c->d_prob_bs.as<i64>(), tiny ? kTiny : 0);
+                                   c->d_prob_bs.as<i64>(), ProbSplit{tiny ? kTiny : 0, (c->use_fuse && fuse) ? kFuseLanes : -1});
                 hipLaunchKernelGGL(k_prob_scan2, dim3(1), dim3(256), 0, c->stream, st, c->d_prob_bs.as<i64>());
                 HIP_TRY(c, hipMemcpyAsync(c->h_status, st, sizeof(Status), hipMemcpyDeviceToHost, c->stream));
                 HIP_TRY(c, wait_stream(c));
@@ -3547,6 +3869,7 @@ int run_sized(fseg_ctx *c) {
         atleast(c->tri_cap, (i64)s.tri_used); atleast(c->cov_cap, (i64)s.cov_used);
         c->have_huge = s.dp_cls[2] > 0;
         c->dp_wide_counts = c->force_wide_dp || (i64)s.max_ln >= 65536;
+        note_counts(c, s);
         adapt_to(c, s);
         TRY(alloc_arenas(c));
         // B
@@ -3637,6 +3960,9 @@ int fseg_create(int device, fseg_ctx **out) {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_score_huge), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)kHugeScoreLds);
     if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve<kNMax, unsigned char>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)solve_lds_for(kNMax, kNMax + 1, 1));
+    if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_dp_huge), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)kHugeDpLds);
     if (e != hipSuccess) {
@@ -3649,6 +3975,7 @@ int fseg_create(int device, fseg_ctx **out) {
     if (flag("FSEG_NO_GRAPH")) c->use_graph = false;
     if (flag("FSEG_NO_FORK")) c->use_fork = false;
     if (flag("FSEG_NO_TINY")) c->use_tiny = false;
+    if (flag("FSEG_NO_FUSE")) c->use_fuse = false;
     if (flag("FSEG_NO_SIZED")) c->use_sized = false;
     if (flag("FSEG_TRACE")) c->trace = true;
     if (flag("FSEG_FORCE_SCAN_STALL")) c->force_scan_stall = true;
@@ -3667,7 +3994,7 @@ void fseg_destroy(fseg_ctx *c) {
     drop_graph(c);
     Slab *slabs[] = {&c->slab_in, &c->slab_pos, &c->slab_arena};
     for (Slab *s : slabs) if (s->p) (void)hipFree(s->p);
-    DevBuf *bufs[] = {&c->d_labels, &c->d_sort_tmp, &c->d_w_main, &c->d_w_refine, &c->d_h_table, &c->d_status, &c->d_prep, &c->d_tacc};
+    DevBuf *bufs[] = {&c->d_labels, &c->d_sort_tmp, &c->d_w_main, &c->d_w_refine, &c->d_h_table, &c->d_thr_tab, &c->d_status, &c->d_prep, &c->d_tacc};
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
     if (c->h_stage.p) (void)hipHostFree(c->h_stage.p);
     if (c->h_res.p) (void)hipHostFree(c->h_res.p);
@@ -3703,6 +4030,9 @@ int fseg_set_params(fseg_ctx *c, const fseg_params *p) {
     TRY(upload_vec(c, c->d_w_main, c->w_main.data(), c->w_main.size()));
     TRY(upload_vec(c, c->d_w_refine, c->w_refine.data(), c->w_refine.size()));
     TRY(upload_vec(c, c->d_h_table, c->h_table.data(), c->h_table.size()));
+    TRY(ensure(c, c->d_thr_tab, (size_t)kThrTab * sizeof(int2)));
+    hipLaunchKernelGGL(k_thr_table, dim3(kThrTab / 256), dim3(256), 0, c->stream, c->d_h_table.as<double>(), c->P.h_len,
+                       c->P.threshold_rate, c->d_thr_tab.as<int2>());
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->have_params = true;
     c->ran = false;          // results of an earlier run belong to other parameters
@@ -3722,7 +4052,7 @@ int fseg_upload(fseg_ctx *c, const fseg_batch *b) {
     Tick tk;
     // the previous batch's work (and its copy out of the staging image) must be over before its buffers are reused
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    c->pending = false; c->have_batch = false; c->ran = false; c->fetched = false;
+    c->pending = false; c->have_batch = false; c->ran = false; c->fetched = false; c->counts_known = false;
     const int np = b->n_part;
     const i64 K = b->part_iv_off[np], R = b->part_rep_off[np];
     if (b->part_iv_off[0] != 0 || b->part_rep_off[0] != 0 || b->rep_exon_off[0] != 0)
@@ -4142,7 +4472,12 @@ int fseg_stage_ms(fseg_ctx *c, float *ms) {
 int fseg_debug_score_timing(fseg_ctx *c, unsigned long long *out8) {
     if (!c || !out8 || !c->d_tacc.p) return FSEG_ERR_ARG;
     if (hipMemcpy(out8, c->d_tacc.p, 128, hipMemcpyDeviceToHost) != hipSuccess) return FSEG_ERR_HIP;   /* 16 slots */
-    (void)hipMemset(c->d_tacc.p, 0, 128);
+    (void)hipMemset(c->d_tacc.p, 0, 120);               /* slot 15 = the k_solve class being timed: kept */
+    return FSEG_OK;
+}
+int fseg_debug_timed_class(fseg_ctx *c, int cls) {
+    unsigned long long v = (unsigned long long)(long long)cls;
+    if (!c || hipMemcpy(static_cast<char *>(c->d_tacc.p) + 120, &v, 8, hipMemcpyHostToDevice) != hipSuccess) return FSEG_ERR_HIP;
     return FSEG_OK;
 }
 #endif

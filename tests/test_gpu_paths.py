@@ -43,6 +43,9 @@ SWITCHES = [
     {"FSEG_NO_SIZED": "1", "FSEG_FORCE_SCAN_STALL": "1"},
     {"FSEG_FORCE_WIDE_DP": "1"},                            # 32-bit DP count tables on every problem
     {"FSEG_FORCE_WIDE_DP": "1", "FSEG_TINY_FROM": "0"},
+    {"FSEG_NO_FUSE": "1"},                                  # every non-tiny problem through the arena path (tiles, work items, k_score, k_dp*)
+    {"FSEG_NO_FUSE": "1", "FSEG_NO_TINY": "1", "FSEG_NO_SIZED": "1"},
+    {"FSEG_NO_TINY": "1"},                                  # ... and the tiny ones through k_solve
     {"FSEG_PROB_SELF_MAX": "0"},                            # the problem list always through the block-sum scan
     {"FSEG_PROB_SELF_MAX": "100000000"},                    # ... and always through the self-scanning emit kernel
 ]

@@ -1,11 +1,10 @@
 #!/bin/bash
-# compare builds of libfreddie_seg.so under freddie_amd/variants/ (tuning experiments): tools/variants.sh [workloads...]
-for w in "${@:-config2 config3}"; do
-  for w1 in $w; do
-    for so in default freddie_amd/variants/*.so; do
-      if [ "$so" = default ]; then unset FSEG_LIB; else export FSEG_LIB=$PWD/$so; fi
-      echo "== $so"
-      FSEG_NO_GRAPH=1 python bench.py --workload $w1 --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | python profiles/benchsum.py
-    done
+# compare builds of libfreddie_seg.so under freddie_amd/variants/ (tuning experiments): tools/variants.sh [workload] [reps]
+# (FSEG_LIB skips the stale-library check: variants are built by hand with extra -D flags)
+W=${1:-config4}
+for rep in 1 2; do
+  for so in freddie_amd/variants/*.so; do
+    echo "== $so (run $rep)"
+    FSEG_LIB=$PWD/$so FSEG_NO_GRAPH=1 python tools/replay_probe.py --workload $W 2>&1 | tail -2
   done
 done
