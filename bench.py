@@ -2,7 +2,8 @@
 """Benchmark of the segmentation hot path on MI355X.
 
 A *step* is one pass of the hot path over one batch (about 250 k reads) of synthetic partitions, done the way the
-drop-in CLI does it: ``fseg_upload`` (host arrays -> HBM) -> ``fseg_run`` -> ``fseg_results`` (results in host memory).
+drop-in CLI does it: ``fseg_upload`` (host arrays -> HBM) -> ``fseg_run`` -> ``fseg_results_packed`` (results in host memory:
+final positions, and the label matrix at two bits per label, which is the form the native writer takes).
 Consecutive steps take DISTINCT batches (the default workload, config4, is the whole 2 M-read / 4 000-partition job in 8
 batches) and alternate between two contexts of the GPU, so one batch's copies overlap the other's kernels; no step
 replays a resident batch.  ``value`` = reads segmented by all ranks / max-over-ranks wall time of the timed steps
@@ -279,7 +280,7 @@ def one_shot_steps(ctxs, batches, order, collect=None):
                 b = batches[order[si]]
                 ctx.upload(**b.arrays)
                 ctx.run()
-                res = ctx.results()
+                res = ctx.results(packed=True)
                 if collect is not None:
                     collect(si, order[si], ctx, res)
         except BaseException as exc:                      # noqa: BLE001  (re-raised by the caller)
@@ -427,7 +428,7 @@ def main():
             "dtype": "u32",
             "dtype_detail": "u32 bit-planes + popcount for scoring, int64 DP, f64 Gaussian smoothing / threshold",
             "data": "synthetic",
-            "value_is": "host memory -> host memory: fseg_upload + fseg_run + fseg_results per step, distinct batches, "
+            "value_is": "host memory -> host memory: fseg_upload + fseg_run + fseg_results_packed per step, distinct batches, "
                         "%d contexts per GPU (no resident replay)" % len(ctxs),
             "config": {"workload": args.workload, "partitions": per * n_b * args.gpus, "reads": int(sum(b.n_reads for b in batches)) * args.gpus,
                        "batches_per_gpu": n_b, "partitions_per_batch": per, "reads_per_batch": batches[0].n_reads,

@@ -44,8 +44,9 @@ def load():
     L.fhost_n_from_sidecar.argtypes = [vp]
     L.fhost_sidecar_write.restype = ctypes.c_int32
     L.fhost_sidecar_write.argtypes = [vp, cpp, cpp, cpp, ctypes.c_int32]
-    L.fhost_write.restype = ctypes.c_int32
-    L.fhost_write.argtypes = [vp, vp, vp, vp, vp, cpp, ctypes.c_int32]
+    for name in ("fhost_write", "fhost_write_packed"):
+        getattr(L, name).restype = ctypes.c_int32
+        getattr(L, name).argtypes = [vp, vp, vp, vp, vp, cpp, ctypes.c_int32]
     _lib = L
     return L
 
@@ -107,10 +108,11 @@ class HostBatch:
                     rep_weight=_view(L.fhost_rep_weight(h), R, np.int32), rep_exon_off=rep_exon_off,
                     ex_ts=_view(L.fhost_ex_ts(h), I, np.int32), ex_te=_view(L.fhost_ex_te(h), I, np.int32))
 
-    def write(self, part_final_off, final_pos, label_off, labels, out_paths, n_threads=1):
+    def write(self, part_final_off, final_pos, label_off, labels, out_paths, n_threads=1, packed=False):
+        """packed: ``labels`` holds two bits per label (Context.results(packed=True))."""
         a = [np.ascontiguousarray(part_final_off, np.int64), np.ascontiguousarray(final_pos, np.int32),
              np.ascontiguousarray(label_off, np.int64), np.ascontiguousarray(labels, np.uint8)]
-        rc = self._L.fhost_write(self._h, a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data,
+        rc = (self._L.fhost_write_packed if packed else self._L.fhost_write)(self._h, a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data,
                                  a[3].ctypes.data if a[3].size else None, _c_strings(out_paths), int(n_threads))
         if rc != 0:
             raise HostError(self._L.fhost_error(self._h).decode())

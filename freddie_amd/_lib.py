@@ -43,7 +43,7 @@ class _Sizes(ctypes.Structure):
                 ("max_problem_reads", ctypes.c_int64)]
 
 
-EXPORTS = ["fseg_abi_version", "fseg_source_hash", "fseg_results", "fseg_create", "fseg_destroy", "fseg_last_error", "fseg_set_params", "fseg_upload",
+EXPORTS = ["fseg_abi_version", "fseg_source_hash", "fseg_results", "fseg_results_packed", "fseg_create", "fseg_destroy", "fseg_last_error", "fseg_set_params", "fseg_upload",
            "fseg_run", "fseg_sync", "fseg_get_sizes", "fseg_download", "fseg_tap", "fseg_set_profiling",
            "fseg_n_stages", "fseg_stage_name", "fseg_stage_ms", "fseg_scoring_algorithmic_bytes"]
 
@@ -88,6 +88,8 @@ def load():
     L.fseg_download.argtypes = [vp, vp, vp, vp, vp]
     L.fseg_results.restype = ctypes.c_int
     L.fseg_results.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp)]
+    L.fseg_results_packed.restype = ctypes.c_int
+    L.fseg_results_packed.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp)]
     L.fseg_source_hash.restype = ctypes.c_char_p
     L.fseg_tap.restype = ctypes.c_int
     L.fseg_tap.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]
@@ -187,11 +189,14 @@ class Context:
                                           lb.ctypes.data if labels and lb.size else None), "fseg_download")
         return pfo, fp, lo, lb
 
-    def results(self):
+    def results(self, packed=False):
         """Like download(), without the copy: numpy views of the context's pinned result buffers, valid until the next
-        run / upload / results() on this context (what the pipelined CLI hands to the native writer)."""
+        run / upload / results() on this context (what the pipelined CLI hands to the native writer).
+        packed=True: the labels at two bits each (label g = bits 2(g & 3).. of byte g >> 2), a quarter of the PCIe traffic;
+        HostBatch.write(..., packed=True) takes them."""
         p = [ctypes.c_void_p() for _ in range(4)]
-        self._check(self._L.fseg_results(self._h, *[ctypes.byref(x) for x in p]), "fseg_results")
+        fn = self._L.fseg_results_packed if packed else self._L.fseg_results
+        self._check(fn(self._h, *[ctypes.byref(x) for x in p]), "fseg_results")
         sz = self.sizes()
 
         def view(ptr, n, dtype):
@@ -200,7 +205,7 @@ class Context:
             buf = (ctypes.c_char * (int(n) * np.dtype(dtype).itemsize)).from_address(ptr.value)
             return np.frombuffer(buf, dtype=dtype)
         return (view(p[0], self.n_part + 1, np.int64), view(p[1], sz["n_final"], np.int32),
-                view(p[2], self.n_part + 1, np.int64), view(p[3], sz["label_bytes"], np.uint8))
+                view(p[2], self.n_part + 1, np.int64), view(p[3], (sz["label_bytes"] + 3) // 4 if packed else sz["label_bytes"], np.uint8))
 
     def tap(self, name):
         what, dtype = TAPS[name]

@@ -855,9 +855,14 @@ const int64_t *fhost_rep_exon_off(const fhost_batch *b) { return b->rep_exon_off
 const int32_t *fhost_ex_ts(const fhost_batch *b) { return b->ex_ts.data(); }
 const int32_t *fhost_ex_te(const fhost_batch *b) { return b->ex_te.data(); }
 
-int32_t fhost_write(fhost_batch *b, const int64_t *part_final_off, const int32_t *final_pos, const int64_t *label_off,
-                    const uint8_t *labels, const char *const *out_paths, int32_t n_threads) {
+static int32_t write_impl(fhost_batch *b, const int64_t *part_final_off, const int32_t *final_pos, const int64_t *label_off,
+                          const uint8_t *labels, const char *const *out_paths, int32_t n_threads, bool packed) {
     if (!b || !b->err.empty()) return 1;
+    // packed labels: two bits each, label byte g of the arena at bits 2(g & 3).. of packed byte g >> 2 (fseg_results_packed);
+    // a packed byte becomes four ASCII digits through a table
+    static char DIGITS4[256][4];
+    static std::once_flag digits_once;
+    std::call_once(digits_once, []() { for (int v = 0; v < 256; ++v) for (int k = 0; k < 4; ++k) DIGITS4[v][k] = (char)('0' + ((v >> (2 * k)) & 3)); });
     std::mutex err_mutex;
     const int n = (int)b->parts.size();
     auto set_err = [&](const std::string &m) { std::lock_guard<std::mutex> lock(err_mutex); if (b->err.empty()) b->err = m; };
@@ -880,17 +885,31 @@ int32_t fhost_write(fhost_batch *b, const int64_t *part_final_off, const int32_t
             for (i64 i = 0; i < F; ++i) { if (i) *w++ = ','; w = put_i(w, fp[i]); }
             *w++ = '\n';
             for (const Read &r : P.reads) {
-                const unsigned char *row = labels + label_off[p] + (i64)r.rep * S;
-                annotate_read(P, r, row, S, fp, toks, runs);
-                // a read with many label runs has many gap tokens: make room before writing them
-                const size_t used = (size_t)(w - out.data()), line_max = (size_t)Sc + r.name.n + r.chr.n + 64 + toks.size() * 48;
-                if (used + line_max > out.size()) { out.resize((used + line_max) * 2); w = out.data() + used; }
+                {   // room for the line up to and including its label field (the gap tokens are accounted for below)
+                    const size_t used = (size_t)(w - out.data()), line_max = (size_t)Sc + r.name.n + r.chr.n + 64;
+                    if (used + line_max > out.size()) { out.resize((used + line_max) * 2); w = out.data() + used; }
+                }
                 w = put_i(w, r.id); *w++ = '\t';
                 memcpy(w, r.name.p, r.name.n); w += r.name.n; *w++ = '\t';
                 memcpy(w, r.chr.p, r.chr.n); w += r.chr.n; *w++ = '\t';
                 *w++ = r.strand; *w++ = '\t';
                 w = put_i(w, r.tint); *w++ = '\t';
-                if (Sc) { memcpy(w, row, (size_t)Sc); w += Sc; }
+                // the rep's label row goes straight into the line; the annotation reads it from there
+                const i64 g0 = label_off[p] + (i64)r.rep * S;
+                char *row = w;
+                if (Sc && !packed) memcpy(row, labels + g0, (size_t)Sc);
+                if (Sc && packed) {
+                    i64 g = g0, i = 0;
+                    for (; i < Sc && (g & 3); ++i, ++g) row[i] = (char)('0' + ((labels[g >> 2] >> ((g & 3) * 2)) & 3));
+                    for (; i + 4 <= Sc; i += 4, g += 4) memcpy(row + i, DIGITS4[labels[g >> 2]], 4);
+                    for (; i < Sc; ++i, ++g) row[i] = (char)('0' + ((labels[g >> 2] >> ((g & 3) * 2)) & 3));
+                }
+                w += Sc;
+                annotate_read(P, r, reinterpret_cast<const unsigned char *>(row), S, fp, toks, runs);
+                {   // a read with many label runs has many gap tokens: make room before writing them
+                    const size_t used = (size_t)(w - out.data()), rest_max = 8 + toks.size() * 48;
+                    if (used + rest_max > out.size()) { out.resize((used + rest_max) * 2); w = out.data() + used; }
+                }
                 *w++ = '\t';
                 for (const Tok &g : toks) { w = put_s(w, g.s); *w++ = ','; }
                 *w++ = '\n';
@@ -915,6 +934,16 @@ int32_t fhost_write(fhost_batch *b, const int64_t *part_final_off, const int32_t
         }
     });
     return b->err.empty() ? 0 : 2;
+}
+
+int32_t fhost_write(fhost_batch *b, const int64_t *part_final_off, const int32_t *final_pos, const int64_t *label_off,
+                    const uint8_t *labels, const char *const *out_paths, int32_t n_threads) {
+    return write_impl(b, part_final_off, final_pos, label_off, labels, out_paths, n_threads, false);
+}
+
+int32_t fhost_write_packed(fhost_batch *b, const int64_t *part_final_off, const int32_t *final_pos, const int64_t *label_off,
+                           const uint8_t *labels2, const char *const *out_paths, int32_t n_threads) {
+    return write_impl(b, part_final_off, final_pos, label_off, labels2, out_paths, n_threads, true);
 }
 
 }  // extern "C"

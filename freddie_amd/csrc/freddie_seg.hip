@@ -2990,6 +2990,28 @@ __global__ void __launch_bounds__(256) k_label_reads(int n_blocks, const int *rb
 }
 
 // ---------------------------------------------------------------------------------------------
+// Results to the host.  The label matrix is by far the largest thing that crosses PCIe (about 300 bytes per read, 75 MB per
+// 250 k-read batch, 1.4 ms at 55 GB/s -- more than the whole device pipeline), and a label has three values: the arena is
+// packed to two bits per label before it leaves (k_pack_labels; label byte g of the arena = bits 2(g & 3) .. of packed byte
+// g >> 2) and the host writer unpacks rows straight into the TSV it is assembling (fhost_write_packed).
+// (A copy kernel of our own that streams to pinned memory with a small grid was tried instead of the runtime's copy: it
+// slows kernels of the other context of the pipeline 3x while it runs, the runtime's copy only 1.3x.)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_pack_labels(const uint4 *__restrict__ labels16, unsigned *__restrict__ packed, i64 n16) {
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (i64)gridDim.x * blockDim.x) {
+        const uint4 v = labels16[i];                    // 16 ASCII labels ('0' + 0 .. 2) -> 32 bits
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+        unsigned out = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned x = w[q] & 0x03030303u;      // the two low bits of each byte are the label
+            out |= ((x & 3u) | ((x >> 6) & 0xcu) | ((x >> 12) & 0x30u) | ((x >> 18) & 0xc0u)) << (8 * q);
+        }
+        packed[i] = out;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // upload-time preparation, once per batch, on the device (the inputs arrive in one copy; what used to be a host pass
 // over every exon and a host sort now runs behind that copy on the context's stream)
 //   k_prep_reps   the per-read assertions of read_split() (py/freddie_segment.py:158-161) and of process_splicing_data
@@ -3187,6 +3209,8 @@ struct fseg_ctx {
     size_t res_off[4] = {0, 0, 0, 0};
     std::vector<i64> res_pfo;    // part_final_off gathered from the per-interval offsets
     DevBuf d_labels;             // label arena (sized after the final positions are known)
+    DevBuf d_packed;             // the same at two bits per label, for the trip to the host
+    int fetched_packed = -1;     // what the pinned result buffer holds: -1 nothing, 0 label bytes, 1 packed labels
     DevBuf d_sort_tmp;
     // device buffers: inputs (slab_in, uploaded)
     DevBuf d_part_iv_off, d_part_rep_off, d_part_lane_off, d_iv_start, d_iv_end, d_pos_off, d_iv_part,
@@ -3253,6 +3277,7 @@ struct fseg_ctx {
     i64 n_solve[3] = {0, 0, 0}, n_cls_work[4] = {0, 0, 0, 0}, n_dp_cls[3] = {0, 0, 0}, n_arena_prob = 0;
     i64 tiny_from = 256;        // problems above which k_tiny is used (FSEG_TINY_FROM; tests force 0)
     bool trace = false;         // FSEG_TRACE=1: phase timers of upload / run on stderr
+    bool debug_recopy = false;  // FSEG_DEBUG_RECOPY=1 (probes): fseg_results copies again on every call
 };
 
 namespace {
@@ -3978,6 +4003,7 @@ int fseg_create(int device, fseg_ctx **out) {
     if (flag("FSEG_NO_FUSE")) c->use_fuse = false;
     if (flag("FSEG_NO_SIZED")) c->use_sized = false;
     if (flag("FSEG_TRACE")) c->trace = true;
+    if (flag("FSEG_DEBUG_RECOPY")) c->debug_recopy = true;
     if (flag("FSEG_FORCE_SCAN_STALL")) c->force_scan_stall = true;
     if (flag("FSEG_FORCE_WIDE_DP")) { c->force_wide_dp = true; c->dp_wide_counts = true; }
     { const char *tf = getenv("FSEG_TINY_FROM"); if (tf && tf[0]) c->tiny_from = atoll(tf); }
@@ -3994,7 +4020,7 @@ void fseg_destroy(fseg_ctx *c) {
     drop_graph(c);
     Slab *slabs[] = {&c->slab_in, &c->slab_pos, &c->slab_arena};
     for (Slab *s : slabs) if (s->p) (void)hipFree(s->p);
-    DevBuf *bufs[] = {&c->d_labels, &c->d_sort_tmp, &c->d_w_main, &c->d_w_refine, &c->d_h_table, &c->d_thr_tab, &c->d_status, &c->d_prep, &c->d_tacc};
+    DevBuf *bufs[] = {&c->d_labels, &c->d_packed, &c->d_sort_tmp, &c->d_w_main, &c->d_w_refine, &c->d_h_table, &c->d_thr_tab, &c->d_status, &c->d_prep, &c->d_tacc};
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
     if (c->h_stage.p) (void)hipHostFree(c->h_stage.p);
     if (c->h_res.p) (void)hipHostFree(c->h_res.p);
@@ -4353,26 +4379,34 @@ int fseg_get_sizes(fseg_ctx *c, fseg_sizes *out) {
 
 // Results of the last run in the context's pinned host buffers (one device-to-host copy each, no pageable staging):
 // valid until the next fseg_run / fseg_upload / fseg_results on this context.
-int fseg_results(fseg_ctx *c, const int64_t **part_final_off, const int32_t **final_pos, const int64_t **label_off,
-                 const uint8_t **labels) {
+static int results_impl(fseg_ctx *c, const int64_t **part_final_off, const int32_t **final_pos, const int64_t **label_off,
+                        const uint8_t **labels, bool packed) {
     if (!c) return FSEG_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     if (!c->pending && !c->ran) return fail(c, FSEG_ERR_ARG, "no completed run");
     hipStream_t s = c->stream;
-    if (!c->fetched) {
+    if (!c->fetched || c->debug_recopy || c->fetched_packed != (packed ? 1 : 0)) {
         // a sized run knows its result sizes before its last kernels have finished: the copies queue up right behind them
         if (!(c->pending && c->last_sized)) TRY(fseg_sync(c));
         if (!c->pending && !c->ran) return fail(c, FSEG_ERR_ARG, "no completed run");
         const size_t nf = (size_t)c->h_status->n_final, lb = (size_t)c->h_status->label_bytes;
         size_t off = 0;
         auto take = [&](int i, size_t bytes) { c->res_off[i] = off; off = (off + bytes + 255) & ~(size_t)255; };
-        take(0, ((size_t)c->K + 1) * 8); take(1, nf * 4); take(2, ((size_t)c->n_part + 1) * 8); take(3, lb);
+        take(0, ((size_t)c->K + 1) * 8); take(1, nf * 4); take(2, ((size_t)c->n_part + 1) * 8); take(3, packed ? (lb + 15) / 16 * 4 : lb);
         TRY(reserve_host(c, c->h_res, off));
         char *h = c->h_res.as<char>();
         HIP_TRY(c, hipMemcpyAsync(h + c->res_off[0], c->d_final_off.p, ((size_t)c->K + 1) * 8, hipMemcpyDeviceToHost, s));
         if (nf) HIP_TRY(c, hipMemcpyAsync(h + c->res_off[1], c->d_final_pos.p, nf * 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipMemcpyAsync(h + c->res_off[2], c->d_label_off.p, ((size_t)c->n_part + 1) * 8, hipMemcpyDeviceToHost, s));
-        if (lb) HIP_TRY(c, hipMemcpyAsync(h + c->res_off[3], c->d_labels.p, lb, hipMemcpyDeviceToHost, s));
+        if (lb && !packed) HIP_TRY(c, hipMemcpyAsync(h + c->res_off[3], c->d_labels.p, lb, hipMemcpyDeviceToHost, s));
+        if (lb && packed) {
+            // (the label arena is allocated with 16 spare bytes: the last, partial group of 16 labels is read whole)
+            const i64 n16 = (i64)((lb + 15) / 16);
+            TRY(ensure(c, c->d_packed, (size_t)n16 * 4));
+            hipLaunchKernelGGL(k_pack_labels, dim3(grid_for(n16, 256 * 4, 2048)), dim3(256), 0, s, c->d_labels.as<uint4>(),
+                               c->d_packed.as<unsigned>(), n16);
+            HIP_TRY(c, hipMemcpyAsync(h + c->res_off[3], c->d_packed.p, (size_t)n16 * 4, hipMemcpyDeviceToHost, s));
+        }
         if (c->pending) TRY(finish_run(c));
         else HIP_TRY(c, hipStreamSynchronize(s));
         if (!c->ran) return fail(c, FSEG_ERR_ARG, "no completed run");
@@ -4380,6 +4414,7 @@ int fseg_results(fseg_ctx *c, const int64_t **part_final_off, const int32_t **fi
         c->res_pfo.resize((size_t)c->n_part + 1);
         for (int p = 0; p <= c->n_part; ++p) c->res_pfo[(size_t)p] = fo[(size_t)c->part_iv_off[(size_t)p]];
         c->fetched = true;
+        c->fetched_packed = packed ? 1 : 0;
     }
     const char *h = c->h_res.as<char>();
     if (part_final_off) *part_final_off = reinterpret_cast<const int64_t *>(c->res_pfo.data());
@@ -4387,6 +4422,15 @@ int fseg_results(fseg_ctx *c, const int64_t **part_final_off, const int32_t **fi
     if (label_off) *label_off = reinterpret_cast<const int64_t *>(h + c->res_off[2]);
     if (labels) *labels = reinterpret_cast<const uint8_t *>(h + c->res_off[3]);
     return FSEG_OK;
+}
+
+int fseg_results(fseg_ctx *c, const int64_t **part_final_off, const int32_t **final_pos, const int64_t **label_off,
+                 const uint8_t **labels) {
+    return results_impl(c, part_final_off, final_pos, label_off, labels, false);
+}
+int fseg_results_packed(fseg_ctx *c, const int64_t **part_final_off, const int32_t **final_pos, const int64_t **label_off,
+                        const uint8_t **labels2) {
+    return results_impl(c, part_final_off, final_pos, label_off, labels2, true);
 }
 
 int fseg_download(fseg_ctx *c, int64_t *part_final_off, int32_t *final_pos, int64_t *label_off, uint8_t *labels) {

@@ -477,7 +477,7 @@ def run_batches(batches, params, ctxs, threads, on_done, sidecar="off"):
     def write(hb, res, jobs, t_load, t_dev, i):
         t0 = time.perf_counter()
         try:
-            hb.write(*res, [_job_paths(j)[2] for j in jobs], n_threads=threads)
+            hb.write(*res, [_job_paths(j)[2] for j in jobs], n_threads=threads, packed=True)
         finally:
             n_sc, n_reads = hb.n_from_sidecar, hb.n_reads
             hb.close()
@@ -519,7 +519,7 @@ def run_batches(batches, params, ctxs, threads, on_done, sidecar="off"):
                 if last_write[k] is not None:
                     last_write[k].result()   # its results live in this context's pinned buffers until it has finished
                 t2 = time.perf_counter()
-                res = ctx.results()
+                res = ctx.results(packed=True)    # two bits per label across PCIe; the writer unpacks rows into the TSV
             except BaseException:
                 hb.close()
                 raise

@@ -49,6 +49,11 @@ const int32_t *fhost_ex_te(const fhost_batch *b);
 int32_t fhost_write(fhost_batch *b, const int64_t *part_final_off, const int32_t *final_pos, const int64_t *label_off,
                     const uint8_t *labels, const char *const *out_paths, int32_t n_threads);
 
+/* The same with the labels at two bits each, as fseg_results_packed() hands them over (label byte g of the arena =
+ * bits 2(g & 3).. of labels2[g >> 2]; label_off still counts labels): the rows are unpacked straight into the TSV. */
+int32_t fhost_write_packed(fhost_batch *b, const int64_t *part_final_off, const int32_t *final_pos, const int64_t *label_off,
+                           const uint8_t *labels2, const char *const *out_paths, int32_t n_threads);
+
 /* ---- binary side-car ------------------------------------------------------------
  * split_<contig>_<tint>.fsc, written next to the TSVs that py/freddie_split.py:445-481 produces, holds the parsed
  * form of both files (flat exon / CIGAR arrays, the read_reps grouping of py/freddie_segment.py:165-170, sequences

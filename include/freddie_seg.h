@@ -125,6 +125,12 @@ int fseg_get_sizes(fseg_ctx *ctx, fseg_sizes *out);
 int fseg_results(fseg_ctx *ctx, const int64_t **part_final_off, const int32_t **final_pos, const int64_t **label_off,
                  const uint8_t **labels);
 
+/* The same with the label matrix at two bits per label (it is most of what crosses PCIe: about 300 labels per read):
+ * label byte g of the arena (g as counted by label_off) is bits 2(g & 3) .. 2(g & 3)+1 of labels2[g >> 2], values 0 / 1 / 2.
+ * fhost_write_packed() (include/freddie_host.h) takes this form. */
+int fseg_results_packed(fseg_ctx *ctx, const int64_t **part_final_off, const int32_t **final_pos, const int64_t **label_off,
+                        const uint8_t **labels2);
+
 /* Results.  part_final_off: n_part+1 offsets into final_pos; final_pos: n_final genomic
  * positions (tint['final_positions'] of each partition, concatenated).  labels: for partition
  * p, rep r (local index) the bytes labels[label_off[p] + r*(F_p-1) ..] are the ASCII digits

@@ -43,8 +43,8 @@ class OracleContext:
             pfo.append(pfo[-1] + len(o["final_pos"])); lo.append(lo[-1] + labs[-1].size)
         self.res = (np.array(pfo, np.int64), np.concatenate(fps).astype(np.int32), np.array(lo, np.int64), np.concatenate(labs))
 
-    def results(self):
-        return self.res
+    def results(self, packed=False):
+        return self.res[:3] + (util.pack_labels(self.res[3]),) if packed else self.res
 
     def close(self):
         pass

@@ -31,6 +31,11 @@ def check_twice(ctx, parts, oracles, params=None):
     b = ctx.results()                                       # pinned zero-copy results == copied results
     for x, y in zip(a, b):
         assert np.array_equal(x, y)
+    c = ctx.results(packed=True)                            # ... and the two-bit form of the labels
+    for x, y in zip(a[:3], c[:3]):
+        assert np.array_equal(x, y)
+    assert np.array_equal(c[3], util.pack_labels(a[3]))
+    assert np.array_equal(ctx.results()[3], a[3])           # switching back refetches the byte form
 
 
 SWITCHES = [

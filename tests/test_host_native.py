@@ -61,6 +61,31 @@ def test_native_batch_of_partitions_threads(tmp_path):
         hb.close()
 
 
+def test_native_writer_takes_packed_labels(tmp_path):
+    """Labels at two bits each (what crosses PCIe) give the same TSV bytes as the ASCII form, for rows that start at
+    every alignment inside a packed byte."""
+    import util
+    names = [n for n in NAMES if n.startswith("g1") or n.startswith("e_") or n.startswith("g_")]
+    sps, rps, gs = [], [], []
+    for n in names:
+        d, contig, tid = input_dir(n, tmp_path)
+        sp, rp = paths(d, contig, tid)
+        sps.append(sp); rps.append(rp); gs.append(goldens.load(n))
+    hb = _host.HostBatch(sps, rps, n_threads=3)
+    try:
+        pfo = np.zeros(len(gs) + 1, np.int64); lo = np.zeros(len(gs) + 1, np.int64)
+        np.cumsum([len(g["final_positions"]) for g in gs], out=pfo[1:])
+        np.cumsum([g["labels"].size for g in gs], out=lo[1:])
+        lab = np.concatenate([(g["labels"] + 48).astype(np.uint8).ravel() for g in gs])
+        assert len({int(x) % 4 for x in lo[:-1]}) > 1            # partitions start at different alignments
+        outs = [str(tmp_path / ("p%d.tsv" % i)) for i in range(len(gs))]
+        hb.write(pfo, np.concatenate([g["final_positions"] for g in gs]), lo, util.pack_labels(lab), outs, n_threads=3, packed=True)
+        for o, g in zip(outs, gs):
+            assert open(o, "rb").read() == g["segment_tsv"].tobytes()
+    finally:
+        hb.close()
+
+
 def test_native_parser_rejects_malformed(tmp_path):
     sp = tmp_path / "split_c_1.tsv"; rp = tmp_path / "reads_c_1.tsv"
     rp.write_text("0\tc\t1\tACGT\n")

@@ -79,3 +79,10 @@ def compare_partitions(ctx, parts, oracles, y_tol=1e-6):
         assert np.array_equal(lab, o["labels"] + ord("0")), "labels p%d" % p
         k0 += K
     return report
+
+
+def pack_labels(labels_ascii):
+    """ASCII label bytes -> two bits per label, label g at bits 2(g & 3).. of byte g >> 2 (what fseg_results_packed returns)."""
+    v = (np.asarray(labels_ascii, np.uint8) - 48) & 3
+    v = np.concatenate([v, np.zeros((-len(v)) % 4, np.uint8)]).reshape(-1, 4)
+    return (v[:, 0] | (v[:, 1] << 2) | (v[:, 2] << 4) | (v[:, 3] << 6)).astype(np.uint8)
