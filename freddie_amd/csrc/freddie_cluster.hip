@@ -95,7 +95,12 @@ __global__ void __launch_bounds__(256) k_compat(int n_tiles, const int4 *tiles, 
 }
 
 // ---- degrees ---------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_degree(i64 n_rows_total, const int *row_tint, const TintDesc *tints, const u64 *adj, int *deg) {
+// `gate` (all three kernels of a pass): the "some edge was removed" word of the PREVIOUS pass, or null for the first pass of
+// a burst.  The host enqueues several passes back to back and reads the flags once per burst; the passes after the one that
+// removed nothing find their gate at zero and return at once (py/freddie_cluster.py:240-255 loops until nothing changes).
+__global__ void __launch_bounds__(256) k_degree(i64 n_rows_total, const int *row_tint, const TintDesc *tints, const u64 *adj, int *deg,
+                                                const int *gate) {
+    if (gate && *gate == 0) return;
     const int lane = lane_id();
     const i64 wave_g = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((i64)gridDim.x * blockDim.x) >> 6;
     for (i64 r = wave_g; r < n_rows_total; r += n_waves) {
@@ -114,7 +119,9 @@ __global__ void __launch_bounds__(256) k_degree(i64 n_rows_total, const int *row
 // bit c of neighbour k's row says k ~ c).  One wave per row, lanes = 64 consecutive words of the row, the loop runs over
 // the set bits of row r (wave-uniform) and ORs the neighbour's words (a coalesced read of the neighbour's row): the
 // work is sum(deg) * words instead of one LDS-staged 64 x 64 block pair per tile of the matrix.
-__global__ void __launch_bounds__(256) k_deg1(int n_words_total, const int2 *word_tint, const TintDesc *tints, const int *deg, u64 *deg1) {
+__global__ void __launch_bounds__(256) k_deg1(int n_words_total, const int2 *word_tint, const TintDesc *tints, const int *deg, u64 *deg1,
+                                              const int *gate) {
+    if (gate && *gate == 0) return;
     // deg1[tint word z] bit c = column 64 z + c has exactly one neighbour
     const int lane = lane_id();
     const i64 wave_g = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((i64)gridDim.x * blockDim.x) >> 6;
@@ -128,7 +135,8 @@ __global__ void __launch_bounds__(256) k_deg1(int n_words_total, const int2 *wor
 }
 __global__ void __launch_bounds__(256) k_prune(i64 n_rows_total, const int *row_tint, const TintDesc *tints, const i64 *tint_word0,
                                                const u64 *old_adj, const int *deg, const u64 *deg1, u64 *new_adj,
-                                               int *changed /* per tint */) {
+                                               int *changed /* per tint */, int *pass_any, const int *gate) {
+    if (gate && *gate == 0) return;
     const int lane = lane_id();
     const i64 wave_g = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((i64)gridDim.x * blockDim.x) >> 6;
     for (i64 r = wave_g; r < n_rows_total; r += n_waves) {
@@ -160,18 +168,26 @@ __global__ void __launch_bounds__(256) k_prune(i64 n_rows_total, const int *row_
             if (zin) new_adj[d.adj_off + rl * d.aw + z] = neww;
             any_change |= neww != oldw;
         }
-        if (__ballot(any_change) && lane == 0) changed[t] = 1;
+        if (__ballot(any_change) && lane == 0) { changed[t] = 1; *pass_any = 1; }
     }
 }
 
 }  // namespace
 
+struct GrowBuf {              // device buffer that lives with the context and only ever grows
+    void *p = nullptr;
+    size_t cap = 0;
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
 struct fclu_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev[3] = {};
     std::string err;
     float compat_ms = 0.f, prune_ms = 0.f;
+    GrowBuf tints, tiles, row_tint, bits, first, last, tail, adj[2], deg, changed, word_tint, tint_word0, deg1, pass_any;
+    int *h_flags = nullptr;   // pinned: per-pass flags of a burst + per-tint flags
+    size_t h_flags_cap = 0;
 };
 
 namespace {
@@ -188,12 +204,15 @@ int fail(fclu_ctx *c, int code, const char *fmt, ...) {
     return code;
 }
 
-struct Dev {
-    void *p = nullptr;
-    ~Dev() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
-    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
-};
+hipError_t grow(GrowBuf &b, size_t bytes) {
+    if (b.p && bytes <= b.cap) return hipSuccess;
+    if (b.p) { hipError_t e = hipFree(b.p); b.p = nullptr; b.cap = 0; if (e != hipSuccess) return e; }
+    const size_t want = (bytes ? bytes : 16) + bytes / 4;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e == hipSuccess) b.cap = want;
+    return e;
+}
+constexpr int kBurst = 4;     // pruning passes enqueued per host round trip
 
 #define HIP_TRY(c, expr)                                                                                     \
     do {                                                                                                     \
@@ -238,6 +257,10 @@ void fclu_destroy(fclu_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     for (int i = 0; i < 3; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    GrowBuf *bufs[] = {&c->tints, &c->tiles, &c->row_tint, &c->bits, &c->first, &c->last, &c->tail, &c->adj[0], &c->adj[1], &c->deg,
+                       &c->changed, &c->word_tint, &c->tint_word0, &c->deg1, &c->pass_any};
+    for (GrowBuf *b : bufs) if (b->p) (void)hipFree(b->p);
+    if (c->h_flags) (void)hipHostFree(c->h_flags);
     delete c;
 }
 
@@ -284,21 +307,34 @@ int fclu_compat_graph(fclu_ctx *c, const fclu_batch *b, int32_t prune, uint64_t 
     c->compat_ms = c->prune_ms = 0.f;
     if (n_tiles == 0 || R == 0) return FCLU_OK;
 
-    Dev d_tints, d_tiles, d_row_tint, d_bits, d_first, d_last, d_tail, d_adj[2], d_deg, d_changed, d_word_tint, d_tint_word0, d_deg1;
-    HIP_TRY(c, d_tints.alloc(tints.size() * sizeof(TintDesc)));
-    HIP_TRY(c, d_tiles.alloc(tiles.size() * sizeof(int4)));
-    HIP_TRY(c, d_row_tint.alloc((size_t)R * 4));
-    HIP_TRY(c, d_bits.alloc((size_t)n_bits * 4));
-    HIP_TRY(c, d_first.alloc((size_t)R * 4));
-    HIP_TRY(c, d_last.alloc((size_t)R * 4));
-    HIP_TRY(c, d_tail.alloc((size_t)R));
-    HIP_TRY(c, d_adj[0].alloc((size_t)n_adj * 8));
-    HIP_TRY(c, d_adj[1].alloc((size_t)n_adj * 8));
-    HIP_TRY(c, d_deg.alloc((size_t)R * 4));
-    HIP_TRY(c, d_changed.alloc((size_t)T * 4));
-    HIP_TRY(c, d_word_tint.alloc(word_tint.size() * sizeof(int2)));
-    HIP_TRY(c, d_tint_word0.alloc(tint_word0.size() * 8));
-    HIP_TRY(c, d_deg1.alloc(word_tint.size() * 8));
+    GrowBuf &d_tints = c->tints, &d_tiles = c->tiles, &d_row_tint = c->row_tint, &d_bits = c->bits, &d_first = c->first, &d_last = c->last,
+            &d_tail = c->tail, &d_deg = c->deg, &d_changed = c->changed, &d_word_tint = c->word_tint, &d_tint_word0 = c->tint_word0,
+            &d_deg1 = c->deg1, &d_pass_any = c->pass_any;
+    GrowBuf *d_adj = c->adj;
+    HIP_TRY(c, grow(d_tints, tints.size() * sizeof(TintDesc)));
+    HIP_TRY(c, grow(d_tiles, tiles.size() * sizeof(int4)));
+    HIP_TRY(c, grow(d_row_tint, (size_t)R * 4));
+    HIP_TRY(c, grow(d_bits, (size_t)n_bits * 4));
+    HIP_TRY(c, grow(d_first, (size_t)R * 4));
+    HIP_TRY(c, grow(d_last, (size_t)R * 4));
+    HIP_TRY(c, grow(d_tail, (size_t)R));
+    HIP_TRY(c, grow(d_adj[0], (size_t)n_adj * 8));
+    HIP_TRY(c, grow(d_adj[1], (size_t)n_adj * 8));
+    HIP_TRY(c, grow(d_deg, (size_t)R * 4));
+    HIP_TRY(c, grow(d_changed, (size_t)kBurst * T * 4));
+    HIP_TRY(c, grow(d_word_tint, word_tint.size() * sizeof(int2)));
+    HIP_TRY(c, grow(d_tint_word0, tint_word0.size() * 8));
+    HIP_TRY(c, grow(d_deg1, word_tint.size() * 8));
+    HIP_TRY(c, grow(d_pass_any, (size_t)kBurst * 4));
+    {
+        const size_t need = ((size_t)kBurst * T + kBurst) * 4;
+        if (need > c->h_flags_cap) {
+            if (c->h_flags) HIP_TRY(c, hipHostFree(c->h_flags));
+            c->h_flags = nullptr; c->h_flags_cap = 0;
+            HIP_TRY(c, hipHostMalloc((void **)&c->h_flags, need + need / 4, hipHostMallocDefault));
+            c->h_flags_cap = need + need / 4;
+        }
+    }
     hipStream_t s = c->stream;
     HIP_TRY(c, hipMemcpyAsync(d_tints.p, tints.data(), tints.size() * sizeof(TintDesc), hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync(d_tiles.p, tiles.data(), tiles.size() * sizeof(int4), hipMemcpyHostToDevice, s));
@@ -318,24 +354,35 @@ int fclu_compat_graph(fclu_ctx *c, const fclu_batch *b, int32_t prune, uint64_t 
     HIP_TRY(c, hipEventRecord(c->ev[1], s));
     int cur = 0;
     if (prune) {
-        std::vector<int> changed((size_t)T);
+        // Passes are enqueued kBurst at a time; pass q of a burst is gated on pass q-1's "removed something" word, so the host
+        // reads the flags once per burst instead of once per pass (the loop of :240-255 usually ends after two or three).
         const int deg_grid = (int)((R + 3) / 4 < 4096 ? (R + 3) / 4 : 4096);
-        for (int pass = 0; pass < (1 << 20); ++pass) {
-            HIP_TRY(c, hipMemsetAsync(d_changed.p, 0, (size_t)T * 4, s));
-            hipLaunchKernelGGL(k_degree, dim3(deg_grid), dim3(256), 0, s, R, d_row_tint.as<int>(), d_tints.as<TintDesc>(),
-                               d_adj[cur].as<u64>(), d_deg.as<int>());
-            const int n_words = (int)word_tint.size();
-            hipLaunchKernelGGL(k_deg1, dim3((n_words + 3) / 4 < 4096 ? (n_words + 3) / 4 : 4096), dim3(256), 0, s, n_words,
-                               d_word_tint.as<int2>(), d_tints.as<TintDesc>(), d_deg.as<int>(), d_deg1.as<u64>());
-            hipLaunchKernelGGL(k_prune, dim3((int)((R + 3) / 4 < 16384 ? (R + 3) / 4 : 16384)), dim3(256), 0, s, R, d_row_tint.as<int>(),
-                               d_tints.as<TintDesc>(), d_tint_word0.as<i64>(), d_adj[cur].as<u64>(), d_deg.as<int>(),
-                               d_deg1.as<u64>(), d_adj[cur ^ 1].as<u64>(), d_changed.as<int>());
-            HIP_TRY(c, hipMemcpyAsync(changed.data(), d_changed.p, (size_t)T * 4, hipMemcpyDeviceToHost, s));
+        const int n_words = (int)word_tint.size();
+        int *h_any = c->h_flags, *h_changed = c->h_flags + kBurst;
+        bool done = false;
+        for (int burst = 0; burst < (1 << 18) && !done; ++burst) {
+            HIP_TRY(c, hipMemsetAsync(d_changed.p, 0, (size_t)kBurst * T * 4, s));
+            HIP_TRY(c, hipMemsetAsync(d_pass_any.p, 0, (size_t)kBurst * 4, s));
+            for (int q = 0; q < kBurst; ++q) {
+                const int *gate = q ? d_pass_any.as<int>() + (q - 1) : nullptr;
+                const int from = cur ^ (q & 1), to = from ^ 1;
+                hipLaunchKernelGGL(k_degree, dim3(deg_grid), dim3(256), 0, s, R, d_row_tint.as<int>(), d_tints.as<TintDesc>(),
+                                   d_adj[from].as<u64>(), d_deg.as<int>(), gate);
+                hipLaunchKernelGGL(k_deg1, dim3((n_words + 3) / 4 < 4096 ? (n_words + 3) / 4 : 4096), dim3(256), 0, s, n_words,
+                                   d_word_tint.as<int2>(), d_tints.as<TintDesc>(), d_deg.as<int>(), d_deg1.as<u64>(), gate);
+                hipLaunchKernelGGL(k_prune, dim3((int)((R + 3) / 4 < 16384 ? (R + 3) / 4 : 16384)), dim3(256), 0, s, R, d_row_tint.as<int>(),
+                                   d_tints.as<TintDesc>(), d_tint_word0.as<i64>(), d_adj[from].as<u64>(), d_deg.as<int>(),
+                                   d_deg1.as<u64>(), d_adj[to].as<u64>(), d_changed.as<int>() + (size_t)q * T, d_pass_any.as<int>() + q, gate);
+            }
+            HIP_TRY(c, hipMemcpyAsync(h_any, d_pass_any.p, (size_t)kBurst * 4, hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipMemcpyAsync(h_changed, d_changed.p, (size_t)kBurst * T * 4, hipMemcpyDeviceToHost, s));
             HIP_TRY(c, hipStreamSynchronize(s));
-            cur ^= 1;
-            bool any = false;
-            for (int t = 0; t < T; ++t) if (changed[(size_t)t]) { any = true; if (rounds_out) rounds_out[t] += 1; }
-            if (!any) break;                             // a pass that removed nothing: done (:254)
+            // the passes that ran: 0 .. first pass that removed nothing (inclusive); each of them wrote the other buffer
+            int ran = 0;
+            for (int q = 0; q < kBurst; ++q) { ++ran; if (!h_any[q]) { done = true; break; } }
+            for (int q = 0; q < ran; ++q)
+                if (rounds_out) for (int t = 0; t < T; ++t) if (h_changed[(size_t)q * T + t]) rounds_out[t] += 1;
+            cur ^= ran & 1;
         }
     }
     HIP_TRY(c, hipEventRecord(c->ev[2], s));

@@ -4,8 +4,8 @@
     python bench.py --workload isoforms [--steps K] [--no-cpu-baseline]                                (with the CPU baseline)
     python tools/isoforms_bench.py [--isoforms N] [--reads-per-isoform R] [--segments M] [--steps K]     (GPU side only)
 
-One JSON line: reads processed per second of kernel time (HIP events on the library's stream; the call's host<->device
-copies are outside the bracket and reported as call_wall_ms) and the consensus kernel's roofline with ALGORITHMIC bytes =
+One JSON line: reads processed per second of the two CALLS (host arrays in -> counts / votes in host memory; the 300 MB of
+labels crossing PCIe dominate it), the kernel times as detail, and the consensus kernel's roofline with ALGORITHMIC bytes =
 one label byte per (read, segment) + two int32 per (isoform, segment) out -- what isoforms_cons() reads and produces once
 (py/freddie_isoforms.py:203-232).  The CPU baseline (the Python oracle on a bounded sample) is bench.py's leg: this file
 never touches oracle/.
@@ -49,10 +49,12 @@ def run(n_iso=4000, per=500, M=150, steps=5, cpu_baseline=None):
     ctx.close()
     c_ms, v_ms = float(np.mean(cons_ms)), float(np.mean(votes_ms))
     alg = R * M + 8 * n_iso * M
-    out = {"metric": "reads/sec (isoform consensus counts + boundary votes, kernels)", "value": R / ((c_ms + v_ms) * 1e-3), "unit": "reads/s",
+    wall_ms = float(np.median(wall)) * 1e3
+    out = {"metric": "reads/sec (isoform consensus counts + boundary votes, whole calls: host arrays in, results out)",
+           "value": R / (wall_ms * 1e-3), "unit": "reads/s", "value_kernels_only": R / ((c_ms + v_ms) * 1e-3),
            "n_gpus": 1, "steps": steps, "higher_is_better": True, "dtype": "u8/int32", "data": "synthetic",
            "config": {"workload": "isoforms", "isoforms": n_iso, "reads": R, "segments": M, "window": w},
-           "kernel_ms": {"consensus": c_ms, "votes": v_ms}, "call_wall_ms": float(np.mean(wall)) * 1e3,
+           "kernel_ms": {"consensus": c_ms, "votes": v_ms}, "call_wall_ms": wall_ms,
            "roofline": {"kernel": "k_consensus", "bound": "hbm", "achieved": alg / (c_ms * 1e-3) / 1e9, "peak": 8000.0,
                         "unit": "GB/s", "frac": alg / (c_ms * 1e-3) / 1e9 / 8000.0, "traffic": None, "algorithmic_bytes_per_launch": alg}}
     if cpu_baseline is not None:
