@@ -2213,6 +2213,8 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ int cy_s[NM + 4];
     __shared__ int iend_s[NM + 4];
+    __shared__ int2 act_s[256];                    // reads with coverage in the window: (first exon that meets it, how many do)
+    __shared__ int act_wave[T / 64];
     __shared__ i64 part_v[T];
     __shared__ unsigned char part_a[T];
     __shared__ int top_key[T / 64];
@@ -2274,44 +2276,74 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
             while (lo < hi) { int mid = (lo + hi) >> 1; if (cy_s[mid] <= lim) lo = mid + 1; else hi = mid; }
             iend_s[j] = lo;
         }
+        // ---- the reads that matter.  The lane range is a superset (reads sorted by first position, cut by a running maximum of
+        //      last positions): about a third of its reads have no exon in the window at all.  Such a read is `nay` for every pair
+        //      -- it adds nothing to out(), and to in() only where lo < 0 -- so the scoring rounds run over the others only, packed
+        //      densely (fewer 64-read rounds), and each of those arrives with the exons that meet the window already located:
+        //      exons are ordered, so they are consecutive -- the first with te >= cand_0 up to the last with ts < cand_{n-1}.
+        const int cp0 = d.g0 + cy_s[0], c_last = d.g0 + cy_s[n - 1];
+        int n_act = 0;
+        for (int l0 = 0; l0 < d.lane_n; l0 += T) {
+            const int l = l0 + (int)threadIdx.x;
+            const bool in = l < d.lane_n;
+            const longlong2 ex = lane_ex[d.lane_lo + (in ? l : 0)];
+            i64 first = ex.x;
+            int cnt = 0;
+            for (i64 eb = ex.x; eb < ex.y; eb += 8) {               // eight exons per round from clamped addresses, in flight together
+                int ts8[8], te8[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const i64 idx = eb + u < ex.y ? eb + u : ex.y - 1;
+                    ts8[u] = ex_ts[idx]; te8[u] = ex_te[idx];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const bool hit = eb + u < ex.y && te8[u] >= cp0 && ts8[u] < c_last;
+                    if (hit && cnt == 0) first = eb + u;
+                    cnt += hit;
+                }
+                if (ts8[7] >= c_last) break;                         // the rest of the read lies beyond the window
+            }
+            const bool act = in && cnt > 0;
+            const u64 m = __ballot(act);
+            if ((threadIdx.x & 63) == 0) act_wave[threadIdx.x >> 6] = __popcll(m);
+            __syncthreads();
+            int base = n_act, tot = 0;
+            for (int w2 = 0; w2 < T / 64; ++w2) { const int v = act_wave[w2]; if (w2 < (int)(threadIdx.x >> 6)) base += v; tot += v; }
+            if (act) act_s[base + __popcll(m & ((1ULL << (threadIdx.x & 63)) - 1ULL))] = make_int2((int)first, cnt);
+            n_act += tot;
+            __syncthreads();
+        }
         FSEG_STICK(1);
-        // this thread's share of a tile's coverage: read r_lane, candidates [ja, jb) of 1 .. n-1 (at most kCovJ of them)
+        // this thread's share of a round's coverage: read r_lane, candidates [ja, jb) of 1 .. n-1 (at most kCovJ of them)
         constexpr int kCovJ = (NM - 1 + NR - 1) / NR;
         const int ja = 1 + (int)((i64)(n - 1) * w_rng / NR), jb = 1 + (int)((i64)(n - 1) * (w_rng + 1) / NR);
-        const int cp0 = d.g0 + cy_s[0];
         int cjv[kCovJ];
 #pragma unroll
         for (int u = 0; u < kCovJ; ++u) cjv[u] = ja + u < jb ? d.g0 + cy_s[ja + u] : cp0;     // beyond the share: an empty window
-        for (int r0 = 0; r0 < d.lane_n; r0 += kSub) {
-            int n_valid = d.lane_n - r0;
+        for (int r0 = 0; r0 < n_act; r0 += kSub) {
+            int n_valid = n_act - r0;
             if (n_valid > kSub) n_valid = kSub;
             // ---- A: window coverage cov[r][j] = positions of the read's closed exons in [cand_0, cand_j)
-            //      (get_cumulative_coverage :188-246) = sum over the exons of |[ts, te] n [cand_0, cand_j)|.  Written as that sum
-            //      the walk has no search and no data-dependent loads beyond the exon block itself: eight exons per round from
-            //      clamped addresses (a slot past the read's last exon repeats it as an empty interval), all in flight together.
+            //      (get_cumulative_coverage :188-246) = sum over its exons of |[ts, te] n [cand_0, cand_j)|, over the few exons that
+            //      meet the window (two per step: their loads depend on nothing but the LDS record, so they fly together)
             {
                 const bool valid = r_lane < n_valid;
-                const longlong2 ex = lane_ex[d.lane_lo + r0 + (valid ? r_lane : 0)];
+                const int2 a = act_s[r0 + (valid ? r_lane : 0)];
                 int acc[kCovJ];
 #pragma unroll
                 for (int u = 0; u < kCovJ; ++u) acc[u] = 0;
-                for (i64 eb = ex.x; eb < ex.y; eb += 8) {
-                    int ts8[8], te8[8];
+                const int e_end = valid ? a.y : 0;
+                for (int e = 0; e < e_end; e += 2) {
+                    const int e2 = e + 1 < e_end ? e + 1 : e;
+                    const int tsa = ex_ts[a.x + e], tea = ex_te[a.x + e], tsb = ex_ts[a.x + e2], teb = ex_te[a.x + e2];
+                    const int a0 = max(tsa, cp0), b0 = tea + 1;                     // closed exon -> half-open end
+                    const int a1 = max(tsb, cp0), b1 = e + 1 < e_end ? teb + 1 : a1;  // (an odd count: the second slot is empty)
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const i64 idx = eb + u < ex.y ? eb + u : ex.y - 1;
-                        ts8[u] = ex_ts[idx]; te8[u] = ex_te[idx];
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int a0 = max(ts8[u], cp0);
-                        const int b1 = eb + u < ex.y ? te8[u] + 1 : a0;       // closed exon -> half-open end; padding slots are empty
-#pragma unroll
-                        for (int v = 0; v < kCovJ; ++v) acc[v] += max(0, min(b1, cjv[v]) - a0);
-                    }
+                    for (int v = 0; v < kCovJ; ++v) acc[v] += max(0, min(b0, cjv[v]) - a0) + max(0, min(b1, cjv[v]) - a1);
                 }
 #pragma unroll
-                for (int u = 0; u < kCovJ; ++u) if (ja + u < jb) cov[r_lane * rt_stride + ja + u] = valid ? (unsigned)acc[u] : 0u;
+                for (int u = 0; u < kCovJ; ++u) if (ja + u < jb) cov[r_lane * rt_stride + ja + u] = (unsigned)acc[u];
                 if (w_rng == 0) cov[r_lane * rt_stride] = 0;
             }
             lds_barrier();
@@ -2385,10 +2417,10 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
             FSEG_STICK(4);
         }
         // ---- DP on the tables where they lie: the planes' LDS becomes M | in | A ---------------------------------------
-        // a read outside the lane range has no coverage in the window: ambiguous exactly where lo < 0 (only tau = 1)
+        // a read outside the lane range, or dropped above, has no coverage in the window: ambiguous exactly where lo < 0 (only tau = 1)
         int in_val[C::kSlots];
 #pragma unroll
-        for (int s = 0; s < C::kSlots; ++s) in_val[s] = -(int)((i64)amb_acc[s] + (th_lo[s] < 0 ? (i64)d.outside : 0));
+        for (int s = 0; s < C::kSlots; ++s) in_val[s] = -(int)((i64)amb_acc[s] + (th_lo[s] < 0 ? (i64)d.outside + (d.lane_n - n_act) : 0));
         __syncthreads();
 #pragma unroll
         for (int s = 0; s < C::kSlots; ++s) { const int q = s * T + threadIdx.x; if (q < npairs) in_s[q] = in_val[s]; }
@@ -4086,6 +4118,7 @@ int fseg_upload(fseg_ctx *c, const fseg_batch *b) {
     if (K <= 0 || R < 0) return fail(c, FSEG_ERR_ARG, "fseg_upload: bad offsets");
     const i64 I = b->rep_exon_off[R];
     if (I < 0) return fail(c, FSEG_ERR_ARG, "rep_exon_off not monotone");
+    if (I >= 0x7fffffffLL) return fail(c, FSEG_ERR_UNSUPPORTED, "batch has %lld exons; split it (limit 2^31-1 per upload)", (long long)I);
     // ---- host pass 1: the partition / interval level (validation as read_split() asserts it, :138-140) and the counts
     i64 NPOS = 0, n_tiles = 0, lanes = 0, n_rep_blocks = 0;
     bool expanded = false;
