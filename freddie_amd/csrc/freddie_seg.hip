@@ -1497,21 +1497,26 @@ __device__ __forceinline__ void dp_sync() {
         __syncthreads();
     }
 }
-template <int T, typename OutT>
-__device__ int dp_solve(int n, const OutT *out_s, const int *in_s, i64 *M, unsigned char *A, const int *cy_s, int support,
-                        i64 *part_v /* T */, unsigned char *part_a /* T */, int *top_key /* T/64 */,
+// V: the type the sums are kept in.  i64 in general; int where the caller knows that n * (reads of the partition) stays
+// below 2^30 (k_solve's launches: every sum is a chain of at most n/2 counts and ambiguity terms, each bounded by the
+// partition's reads) -- half the registers, LDS traffic and instructions of the chain.
+template <typename V> __device__ __forceinline__ constexpr V dp_neg_inf() { return sizeof(V) == 8 ? (V)kNegInf : (V)(-0x40000000); }
+template <int T, typename OutT, typename V>
+__device__ int dp_solve(int n, const OutT *out_s, const int *in_s, V *M, unsigned char *A, const int *cy_s, int support,
+                        V *part_v /* T */, unsigned char *part_a /* T */, int *top_key /* T/64 */,
                         unsigned char *chosen /* + first candidate of the problem */ FSEG_DPARAM) {
     constexpr int NW = T / 64;
     const int lane = lane_id(), wave = T == 64 ? 0 : (int)(threadIdx.x >> 6);
     const int tid = T == 64 ? lane : (int)threadIdx.x;
     const int end = n - 1;
     const int npairs = n * (n - 1) / 2;
-#define FSEG_IN(a, b) ((i64)in_s[(b) * ((b) - 1) / 2 + (a)])
+    constexpr V kNeg = dp_neg_inf<V>();
+#define FSEG_IN(a, b) ((V)in_s[(b) * ((b) - 1) / 2 + (a)])
 #define FSEG_M(a, b) M[(b) * ((b) - 1) / 2 + (a)]
     // M(b,end): the chain closes here; the "segment too small" rule (:540) is folded into the table, so the
     // inner loops only test tail != -inf
     for (int b = tid; b < end; b += T) {
-        FSEG_M(b, end) = cy_s[end] - cy_s[b] >= 5 ? FSEG_IN(b, end) : kNegInf;
+        FSEG_M(b, end) = cy_s[end] - cy_s[b] >= 5 ? FSEG_IN(b, end) : kNeg;
         A[end * (end - 1) / 2 + b] = 255;
     }
     dp_sync<T>();
@@ -1526,15 +1531,15 @@ __device__ int dp_solve(int n, const OutT *out_s, const int *in_s, i64 *M, unsig
     for (int top = end - 1; top >= 2; top -= G) {
         {
             const int c = top - g_w;
-            i64 best = kNegInf; int arg = 255;
+            V best = kNeg; int arg = 255;
             if (c >= 2 && b < c && cy_s[c] - cy_s[b] >= 5) {
                 const int base = c * (c - 1) / 2 + b;
 #pragma unroll 4
                 for (int c2 = top + 1 + s_w; c2 <= end; c2 += NWG) {
-                    i64 tail = FSEG_M(c, c2);
+                    V tail = FSEG_M(c, c2);
                     unsigned o = out_s[c2 * (c2 - 1) * (c2 - 2) / 6 + base];
-                    bool ok = (tail != kNegInf) & ((i64)o >= (i64)support);                         // :526-527, :540
-                    i64 cur = ok ? (i64)o + tail : kNegInf;     // in(b,c) is the same for every c2: added after the maximum
+                    bool ok = (tail != kNeg) & ((int)o >= support);                         // :526-527, :540
+                    V cur = ok ? (V)o + tail : kNeg;     // in(b,c) is the same for every c2: added after the maximum
                     bool take = cur > best;
                     best = take ? cur : best; arg = take ? c2 : arg;
                 }
@@ -1543,15 +1548,15 @@ __device__ int dp_solve(int n, const OutT *out_s, const int *in_s, i64 *M, unsig
         }
         dp_sync<T>();
         if (wave == 0) {
-            i64 R[G]; int Ra[G];
+            V R[G]; int Ra[G];
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 // first maximiser over the c2 slices: larger value wins, equal values keep the smaller c2
-                i64 bv = part_v[g * 64 + lane]; int ba = part_a[g * 64 + lane];
+                V bv = part_v[g * 64 + lane]; int ba = part_a[g * 64 + lane];
 #pragma unroll
                 for (int s2 = 1; s2 < NWG; ++s2) {
-                    i64 v = part_v[(s2 * G + g) * 64 + lane]; int a2 = part_a[(s2 * G + g) * 64 + lane];
-                    if (v > bv || (v == bv && v != kNegInf && a2 < ba)) { bv = v; ba = a2; }
+                    V v = part_v[(s2 * G + g) * 64 + lane]; int a2 = part_a[(s2 * G + g) * 64 + lane];
+                    if (v > bv || (v == bv && v != kNeg && a2 < ba)) { bv = v; ba = a2; }
                 }
                 R[g] = bv; Ra[g] = ba;
             }
@@ -1561,22 +1566,25 @@ __device__ int dp_solve(int n, const OutT *out_s, const int *in_s, i64 *M, unsig
                 if (c >= 2) {
                     const bool live = b < c && cy_s[c] - cy_s[b] >= 5;
                     const int base = c * (c - 1) / 2 + b;
-                    i64 best = kNegInf; int arg = 255;
+                    V best = kNeg; int arg = 255;
 #pragma unroll
                     for (int h = g - 1; h >= 0; --h) {               // c2 = top - h inside the block, ascending
                         const int c2 = top - h;
                         // M(c, c2) sits in lane c - 1 (b = c) of R[h]
-                        int lo = __builtin_amdgcn_readlane((int)(unsigned)(u64)R[h], c - 1);
-                        int hi = __builtin_amdgcn_readlane((int)(unsigned)((u64)R[h] >> 32), c - 1);
-                        i64 tail = (i64)(((u64)(unsigned)hi << 32) | (u64)(unsigned)lo);
+                        V tail;
+                        if (sizeof(V) == 8) {
+                            int lo = __builtin_amdgcn_readlane((int)(unsigned)(u64)R[h], c - 1);
+                            int hi = __builtin_amdgcn_readlane((int)(unsigned)((u64)R[h] >> 32), c - 1);
+                            tail = (V)(((u64)(unsigned)hi << 32) | (u64)(unsigned)lo);
+                        } else tail = (V)__builtin_amdgcn_readlane((int)R[h], c - 1);
                         unsigned o = live ? (unsigned)out_s[c2 * (c2 - 1) * (c2 - 2) / 6 + base] : 0u;
-                        bool ok = live & (tail != kNegInf) & ((i64)o >= (i64)support);
-                        i64 cur = ok ? (i64)o + tail : kNegInf;
+                        bool ok = live & (tail != kNeg) & ((int)o >= support);
+                        V cur = ok ? (V)o + tail : kNeg;
                         bool take = cur > best;
                         best = take ? cur : best; arg = take ? c2 : arg;
                     }
                     if (R[g] > best) { best = R[g]; arg = Ra[g]; }   // the c2 above the block are all larger: strict >
-                    R[g] = (live && best != kNegInf) ? best + FSEG_IN(b, c) : kNegInf;
+                    R[g] = (live && best != kNeg) ? best + FSEG_IN(b, c) : kNeg;
                     if (b < c) { FSEG_M(b, c) = R[g]; A[base] = (unsigned char)arg; }
                 }
             }
@@ -1586,21 +1594,21 @@ __device__ int dp_solve(int n, const OutT *out_s, const int *in_s, i64 *M, unsig
     FSEG_DTICK(10);
     // top level (a = start): max over (j,k) of in_0j + out_0jk + M(j,k), first maximiser in (j, k) order,
     // taken only if strictly greater than "no cut" = in(0,end)   (:560-566)
-    i64 bv = kNegInf; int bkey = 0x7fffffff;
+    V bv = kNeg; int bkey = 0x7fffffff;
     for (int q = tid; q < npairs; q += T) {
         int j, kx;
         pair_decode(q, &j, &kx);                    // j < kx
         if (j < 1) continue;
         if (cy_s[j] - cy_s[0] < 5 || cy_s[kx] - cy_s[j] < 5) continue;
-        i64 tail = FSEG_M(j, kx);
+        V tail = FSEG_M(j, kx);
         unsigned o = out_s[kx * (kx - 1) * (kx - 2) / 6 + j * (j - 1) / 2 + 0];
-        if (tail == kNegInf || (i64)o < (i64)support) continue;
-        i64 cur = FSEG_IN(0, j) + (i64)o + tail;
+        if (tail == kNeg || (int)o < support) continue;
+        V cur = FSEG_IN(0, j) + (V)o + tail;
         int key = j * 64 + kx;
         if (cur > bv || (cur == bv && key < bkey)) { bv = cur; bkey = key; }
     }
     for (int d = 32; d >= 1; d >>= 1) {
-        i64 ov = __shfl_xor(bv, d); int ok2 = __shfl_xor(bkey, d);
+        V ov = __shfl_xor(bv, d); int ok2 = __shfl_xor(bkey, d);
         if (ov > bv || (ov == bv && ok2 < bkey)) { bv = ov; bkey = ok2; }
     }
     dp_sync<T>();
@@ -1611,7 +1619,7 @@ __device__ int dp_solve(int n, const OutT *out_s, const int *in_s, i64 *M, unsig
     if (tid == 0) {
         for (int w = 1; w < NW; ++w)
             if (part_v[w] > bv || (part_v[w] == bv && top_key[w] < bkey)) { bv = part_v[w]; bkey = top_key[w]; }
-        if (bv != kNegInf && bv > FSEG_IN(0, end)) {
+        if (bv != kNeg && bv > FSEG_IN(0, end)) {
             int j = bkey >> 6, k = bkey & 63;
             chosen[0] = 1;
             for (;;) {
@@ -2201,7 +2209,7 @@ inline size_t solve_lds_for(int nm, int cov_stride, int cnt_bytes) {
     const size_t pairs = (size_t)nm * (nm - 1) / 2, tri = (size_t)nm * (nm - 1) * (nm - 2) / 6;
     return ((pairs * 16 + (size_t)kSub * cov_stride * 4 + ((tri + 15) & ~(size_t)15) * cnt_bytes) + 15) & ~(size_t)15;
 }
-template <int NM, typename CntT>
+template <int NM, typename CntT, typename V>
 __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBlocks) k_solve(Status *st, int cls, int nm, const int *solve_items, ProblemArrays pr,
                                                                   const ProbDesc *desc, i64 prob_cap, const int *cand_y,
                                                                   const longlong2 *lane_ex, const int *ex_ts, const int *ex_te,
@@ -2215,7 +2223,7 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
     __shared__ int iend_s[NM + 4];
     __shared__ int2 act_s[256];                    // reads with coverage in the window: (first exon that meets it, how many do)
     __shared__ int act_wave[T / 64];
-    __shared__ i64 part_v[T];
+    __shared__ V part_v[T];
     __shared__ unsigned char part_a[T];
     __shared__ int top_key[T / 64];
     const int rt_pairs = nm * (nm - 1) / 2;
@@ -2223,7 +2231,7 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
     uint4 *planes = reinterpret_cast<uint4 *>(smem);                                         // rt_pairs * 16 B; later M | in | A
     unsigned *cov = reinterpret_cast<unsigned *>(smem + (size_t)rt_pairs * 16);              // kSub * rt_stride * 4 B
     CntT *cnt = reinterpret_cast<CntT *>(cov + kSub * rt_stride);                            // C(nm,3) counters
-    i64 *M = reinterpret_cast<i64 *>(smem);
+    V *M = reinterpret_cast<V *>(smem);
     int *in_s = reinterpret_cast<int *>(M + rt_pairs);
     unsigned char *A = reinterpret_cast<unsigned char *>(in_s + rt_pairs);
     if ((i64)st->n_prob > prob_cap) return;                          // lists incomplete (a run that only sizes the arenas)
@@ -3627,14 +3635,17 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
                            c->d_cand_y.as<int>(), c->d_work_active.as<unsigned char>(), c->d_cov.as<unsigned>(),        \
                            c->cov_cap, c->d_pair_thr.as<int2>(), c->pair_cap, c->d_out.as<unsigned>(), c->tri_cap,      \
                            c->d_amb.as<unsigned>() FSEG_TARG)
-#define FSEG_LAUNCH_SOLVE(Q, NMV, CNT, CLS, N_ITEMS, MAXWG)                                                                  \
-            hipLaunchKernelGGL((k_solve<NMV, CNT>), dim3(grid_for((N_ITEMS), 1, (MAXWG))), dim3(SolveCfg<NMV>::kThreads),       \
+#define FSEG_LAUNCH_SOLVE(Q, NMV, CNT, VT, CLS, N_ITEMS, MAXWG)                                                              \
+            hipLaunchKernelGGL((k_solve<NMV, CNT, VT>), dim3(grid_for((N_ITEMS), 1, (MAXWG))), dim3(SolveCfg<NMV>::kThreads),       \
                                solve_lds_for((NMV) == kNMax ? c->nm_big : (NMV), (NMV) + 1, (int)sizeof(CNT)), Q, st, CLS,      \
                                ((NMV) == kNMax ? c->nm_big : (NMV)), c->d_solve_items.as<int>(), pr, c->d_prob_desc.as<ProbDesc>(), \
                                c->prob_cap, c->d_cand_y.as<int>(), c->d_lane_ex.as<longlong2>(), c->d_ex_ts.as<int>(),         \
                                c->d_ex_te.as<int>(), c->d_h_table.as<double>(), c->P.h_len, c->P.threshold_rate,               \
                                c->d_thr_tab.as<int2>(), c->P.min_read_support_outside, c->d_chosen.as<unsigned char>() FSEG_TARG)
-#define FSEG_LAUNCH_SOLVE_W(Q, NMV, CLS, N_ITEMS, MAXWG) FSEG_LAUNCH_SOLVE(Q, NMV, unsigned char, CLS, N_ITEMS, MAXWG)
+        // sums in 32 bits when no chain of a problem can reach 2^30: n <= 64 times the reads of the largest partition
+#define FSEG_LAUNCH_SOLVE_W(Q, NMV, CLS, N_ITEMS, MAXWG)                                                                     \
+            do { if (c->LANES < (1LL << 24)) { FSEG_LAUNCH_SOLVE(Q, NMV, unsigned char, int, CLS, N_ITEMS, MAXWG); }            \
+                 else { FSEG_LAUNCH_SOLVE(Q, NMV, unsigned char, i64, CLS, N_ITEMS, MAXWG); } } while (0)
         // Two ways a problem is scored (prob_kind): the arena path's work items (k_score per size class) and the problems that
         // see few reads (at most 255: 8-bit counters), whole, one workgroup each (k_solve per size class).
         // A batch usually holds only one kind; a class's two launches share a stream.
@@ -4017,7 +4028,10 @@ int fseg_create(int device, fseg_ctx **out) {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_score_huge), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)kHugeScoreLds);
     if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve<kNMax, unsigned char>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve<kNMax, unsigned char, int>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)solve_lds_for(kNMax, kNMax + 1, 1));
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve<kNMax, unsigned char, i64>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)solve_lds_for(kNMax, kNMax + 1, 1));
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_dp_huge), hipFuncAttributeMaxDynamicSharedMemorySize,
