@@ -435,18 +435,27 @@ __global__ void __launch_bounds__(256) k_scan1(const unsigned char *flags, i64 n
         __syncthreads();
     }
 }
-__global__ void __launch_bounds__(256) k_scan2(int *bsum, i64 nb, u64 *total_out, i64 *off_last /* may be null */) {
+// One workgroup of 1024 threads, eight block sums per thread per round (registers), so a batch's few thousand block sums are
+// scanned in one round of one load, one workgroup scan and one store per thread (it was 256 threads x one element: a dozen
+// latency-bound rounds, 12 us three times per run).
+constexpr int kScan2Threads = 1024, kScan2Per = 8;
+__global__ void __launch_bounds__(kScan2Threads) k_scan2(int *bsum, i64 nb, u64 *total_out, i64 *off_last /* may be null */) {
     __shared__ int lds[16];
     __shared__ int carry_s;
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
-    for (i64 b0 = 0; b0 < nb; b0 += blockDim.x) {
-        i64 b = b0 + threadIdx.x;
-        int v = b < nb ? bsum[b] : 0;
+    for (i64 b0 = 0; b0 < nb; b0 += (i64)kScan2Threads * kScan2Per) {
+        const i64 base = b0 + (i64)threadIdx.x * kScan2Per;
+        int v[kScan2Per], run = 0;
+#pragma unroll
+        for (int e = 0; e < kScan2Per; ++e) { v[e] = base + e < nb ? bsum[base + e] : 0; }
+#pragma unroll
+        for (int e = 0; e < kScan2Per; ++e) { const int x = v[e]; v[e] = run; run += x; }      // exclusive inside the thread
         int tot;
-        int ex = wg_exclusive_scan(v, lds, &tot);
-        int carry = carry_s;
-        if (b < nb) bsum[b] = carry + ex;
+        const int ex = wg_exclusive_scan(run, lds, &tot);
+        const int carry = carry_s;
+#pragma unroll
+        for (int e = 0; e < kScan2Per; ++e) if (base + e < nb) bsum[base + e] = carry + ex + v[e];
         __syncthreads();
         if (threadIdx.x == 0) carry_s = carry + tot;
         __syncthreads();
@@ -512,7 +521,7 @@ __global__ void __launch_bounds__(256) k_scan_emit(const unsigned char *flags, i
                                                    unsigned *err, const double *y,
                                                    double *v, i64 K, const i64 *pos_off, const int *iv_start,
                                                    const int *blk_iv0, int *out_y, int *out_pos, i64 *out_off,
-                                                   int force_stall /* tests: report a look-back stall */) {
+                                                   int force_stall /* tests: report a look-back stall */, int *out_iv /* may be null */) {
     if (force_stall && !bsum && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(err, kErrScanStall);
     // A block is 4 waves x 2048 consecutive positions.  Each wave first counts its flags (16-byte loads), the wave
     // offsets come from LDS, then the wave walks its positions in rows of 64: ballot -> rank, so the loads of y and
@@ -552,6 +561,7 @@ __global__ void __launch_bounds__(256) k_scan_emit(const unsigned char *flags, i
                         int yy = (int)(i - k_base);
                         out_y[ex] = yy;
                         if (out_pos) out_pos[ex] = iv_start[k] + yy;
+                        if (out_iv) out_iv[ex] = (int)k;
                         if (yy == 0) out_off[k] = ex;
                         ++ex;
                     }
@@ -617,6 +627,7 @@ __global__ void __launch_bounds__(256) k_scan_emit(const unsigned char *flags, i
                             int yy = (int)(i - k_base);
                             out_y[d] = yy;
                             if (out_pos) out_pos[d] = iv_start[k] + yy;
+                            if (out_iv) out_iv[d] = (int)k;
                             if (yy == 0) out_off[k] = d;
                         }
                     }
@@ -2066,8 +2077,8 @@ constexpr int kTinyPairs = kTiny * (kTiny - 1) / 2, kTinyTri = kTiny * (kTiny - 
 // 120 registers it would otherwise take only 16 waves fit; measured 56 -> 47 us on config4, 8 spills and is slower)
 __global__ void __launch_bounds__(256, 6) k_tiny(Status *st, const ProbDesc *desc, i64 prob_cap, int tiny_max, ProblemArrays pr,
                                               const int *cand_y, const longlong2 *lane_ex, const int *ex_ts,
-                                              const int *ex_te, const double *h_table, int h_len, double tau, int support,
-                                              unsigned char *chosen) {
+                                              const int *ex_te, const double *h_table, int h_len, double tau, const int2 *thr_tab,
+                                              int support, unsigned char *chosen) {
     __shared__ u64 planes[4][kTinyPairs][2];            // [wave][pair]{yea, nay} of the current 64 reads
     __shared__ i64 M_s[4][kTinyPairs];
     __shared__ int in_s[4][kTinyPairs];
@@ -2078,7 +2089,9 @@ __global__ void __launch_bounds__(256, 6) k_tiny(Status *st, const ProbDesc *des
     __shared__ unsigned char part_a[256];
     __shared__ int top_key[4];
     __shared__ unsigned char tri_ijk[kTinyTri][4];
+    __shared__ int2 act_w[4][128];                      // [wave] reads with coverage in the window, waiting for a round: (first exon, count)
     const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const u64 lt_mask = (1ULL << lane) - 1ULL;
     if (threadIdx.x < kTinyTri) {                       // rank t = k(k-1)(k-2)/6 + j(j-1)/2 + i  ->  (i, j, k)
         int t = threadIdx.x, k = 2;
         while ((k + 1) * k * (k - 1) / 6 <= t) ++k;
@@ -2104,41 +2117,64 @@ __global__ void __launch_bounds__(256, 6) k_tiny(Status *st, const ProbDesc *des
         int hi_q = 0x7fffffff, lo_q = -1, pi = 0, pj = 1;
         if (lane < npairs) {
             pair_decode(lane, &pi, &pj);
-            label_thresholds((i64)cy_s[wave][pj] - cy_s[wave][pi] + 1, h_table, h_len, tau, &hi_q, &lo_q);   // :490-495 as integer bounds
+            label_thresholds_tab((i64)cy_s[wave][pj] - cy_s[wave][pi] + 1, thr_tab, h_table, h_len, tau, &hi_q, &lo_q);   // :490-495 as integer bounds
         }
         int ti = 0, tj = 1, tk = 2;
         if (lane < ntri) { ti = tri_ijk[lane][0]; tj = tri_ijk[lane][1]; tk = tri_ijk[lane][2]; }
-        const int cp0 = d.g0 + cy_s[wave][0];
+        const int cp0 = d.g0 + cy_s[wave][0], c_last = d.g0 + cy_s[wave][n - 1];
+        int cj[kTiny];
+#pragma unroll
+        for (int j = 0; j < kTiny; ++j) cj[j] = j < n ? d.g0 + cy_s[wave][j] : cp0;      // beyond the problem: an empty window
         unsigned amb = 0, out = 0;
-        for (int r0 = 0; r0 < d.lane_n; r0 += 64) {
-            const int li = r0 + lane;
-            const bool valid = li < d.lane_n;
+        // As in k_solve: only the reads with an exon in the window are scored (about 60 % of the lane range), packed into
+        // full rounds of 64, each with its window exons located (they are consecutive: first with te >= cand_0 .. last with
+        // ts < cand_{n-1}), so the coverage below is a sum of overlaps over two or three exons instead of a search and a walk.
+        int raw = 0, fill = 0, n_act = 0;               // wave-uniform: lanes examined, records waiting, reads kept
+        while (raw < d.lane_n || fill > 0) {
+            while (fill < 64 && raw < d.lane_n) {
+                const int li = raw + lane;
+                const bool in = li < d.lane_n;
+                const longlong2 ex = lane_ex[d.lane_lo + (in ? li : 0)];      // unconditional: no branch around the load
+                i64 first = ex.x;
+                int cnt = 0;
+                for (i64 eb = ex.x; eb < ex.y; eb += 8) {                 // eight exons per round from clamped addresses
+                    int ts8[8], te8[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const i64 idx = eb + u < ex.y ? eb + u : ex.y - 1;
+                        ts8[u] = ex_ts[idx]; te8[u] = ex_te[idx];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const bool hit = eb + u < ex.y && te8[u] >= cp0 && ts8[u] < c_last;
+                        if (hit && cnt == 0) first = eb + u;
+                        cnt += hit;
+                    }
+                    if (ts8[7] >= c_last) break;
+                }
+                const bool act = in && cnt > 0;
+                const u64 m = __ballot(act);
+                if (act) act_w[wave][fill + __popcll(m & lt_mask)] = make_int2((int)first, cnt);
+                fill += __popcll(m); n_act += __popcll(m);
+                raw += 64;
+            }
+            dp_sync<64>();
+            const int nv = fill < 64 ? fill : 64;
+            const bool valid = lane < nv;
             // window coverage of this lane's read: cov[j] = positions of its closed exons in [cand_0, cand_j)
             int cov[kTiny];
 #pragma unroll
             for (int j = 0; j < kTiny; ++j) cov[j] = 0;
-            const longlong2 ex = lane_ex[d.lane_lo + (valid ? li : 0)];      // unconditional: no branch around the load
-            if (valid) {
-                i64 e = ex.x;
-                const i64 e1 = ex.y;
-                {   // first exon whose closed interval reaches cand_0 (exons of a read are ordered, :158)
-                    i64 lo = e, hi = e1;
-                    while (lo < hi) { const i64 mid = (lo + hi) >> 1; if (ex_te[mid] < cp0) lo = mid + 1; else hi = mid; }
-                    e = lo;
-                }
-                int acc = 0, ts = 0, te = -1;
-                if (e < e1) { ts = ex_ts[e]; te = ex_te[e]; }
+            {
+                const int2 a = act_w[wave][valid ? lane : 0];
+                const int e_end = valid ? a.y : 0;
+                for (int e = 0; e < e_end; e += 2) {
+                    const int e2 = e + 1 < e_end ? e + 1 : e;
+                    const int tsa = ex_ts[a.x + e], tea = ex_te[a.x + e], tsb = ex_ts[a.x + e2], teb = ex_te[a.x + e2];
+                    const int a0 = max(tsa, cp0), b0 = tea + 1;
+                    const int a1 = max(tsb, cp0), b1 = e + 1 < e_end ? teb + 1 : a1;
 #pragma unroll
-                for (int j = 1; j < kTiny; ++j) {
-                    if (j < n) {
-                        const int cj = d.g0 + cy_s[wave][j];
-                        while (e < e1 && te < cj) {
-                            acc += te + 1 - (ts > cp0 ? ts : cp0);
-                            ++e;
-                            if (e < e1) { ts = ex_ts[e]; te = ex_te[e]; }
-                        }
-                        cov[j] = acc + ((e < e1 && ts < cj) ? cj - (ts > cp0 ? ts : cp0) : 0);
-                    }
+                    for (int j = 1; j < kTiny; ++j) cov[j] += max(0, min(b0, cj[j]) - a0) + max(0, min(b1, cj[j]) - a1);
                 }
             }
             const u64 vmask = __ballot(valid);
@@ -2161,15 +2197,21 @@ __global__ void __launch_bounds__(256, 6) k_tiny(Status *st, const ProbDesc *des
                 amb += (unsigned)__popcll(~(my_yea | my_nay) & vmask);       // neither label: ambiguous (:500-506)
                 planes[wave][lane][0] = my_yea; planes[wave][lane][1] = my_nay;
             }
+            // the records beyond this round move to the front of the list
+            int2 keep = make_int2(0, 0);
+            if (lane < fill - nv) keep = act_w[wave][64 + lane];
             dp_sync<64>();
+            if (lane < fill - nv) act_w[wave][lane] = keep;
+            fill -= nv;
             if (lane < ntri) {                          // out(i,j,k) (:509-528): the two labels exclude each other
                 const int qa = tj * (tj - 1) / 2 + ti, qb = tk * (tk - 1) / 2 + tj;
                 out += (unsigned)(__popcll(planes[wave][qa][0] & planes[wave][qb][1]) + __popcll(planes[wave][qa][1] & planes[wave][qb][0]));
             }
             dp_sync<64>();
         }
+        const int dropped = d.lane_n - n_act;           // reads of the lane range without coverage: treated like those outside it
         // a read outside the lane range has no coverage in the window: ambiguous exactly where lo < 0 (only tau = 1)
-        if (lane < npairs) in_s[wave][lane] = -(int)((i64)amb + (lo_q < 0 ? (i64)d.outside : 0));
+        if (lane < npairs) in_s[wave][lane] = -(int)((i64)amb + (lo_q < 0 ? (i64)d.outside + dropped : 0));
         if (lane < ntri) out_s[wave][lane] = out;
         dp_sync<64>();
         const int chain = dp_solve<64>(n, out_s[wave], in_s[wave], M_s[wave], A_s[wave], cy_s[wave], support, part_v + wave * 64,
@@ -2911,18 +2953,18 @@ __device__ void label_plan(int n_part, const i64 *part_iv_off, const i64 *part_r
 }
 // per final index f (= column): integer thresholds of the segment [final_f, final_f+1) and the label of
 // a read without coverage there; the last index of an interval is the sentinel column (hi = INT_MAX)
-__global__ void __launch_bounds__(256) k_label_cols(i64 K, const i64 *final_off, const int *final_y, const int *iv_part,
-                                                    const double *h_table, int h_len, double tau, int2 *col_thr,
+__global__ void __launch_bounds__(256) k_label_cols(i64 K, const i64 *final_off, const int *final_y, const int *final_iv, const int *iv_part,
+                                                    const double *h_table, int h_len, double tau, const int2 *thr_tab, int2 *col_thr,
                                                     unsigned char *col_zero, int *part_has2, int n_part,
                                                     const i64 *part_iv_off, const i64 *part_rep_off, i64 *label_off,
                                                     Status *st, i64 label_cap) {
     if (blockIdx.x == 0) label_plan(n_part, part_iv_off, part_rep_off, final_off, label_off, st, label_cap);
     i64 F = final_off[K];
     for (i64 f = (i64)blockIdx.x * blockDim.x + threadIdx.x; f < F; f += (i64)gridDim.x * blockDim.x) {
-        i64 k = last_le(final_off, K + 1, f);
+        const i64 k = final_iv[f];                           // the interval of every final position, noted by the compaction that emitted it
         if (f + 1 == final_off[k + 1]) { col_thr[f] = make_int2(0x7fffffff, 0x7fffffff); col_zero[f] = '0'; continue; }
         int hi, lo;
-        label_thresholds((i64)final_y[f + 1] - final_y[f] + 1, h_table, h_len, tau, &hi, &lo);
+        label_thresholds_tab((i64)final_y[f + 1] - final_y[f] + 1, thr_tab, h_table, h_len, tau, &hi, &lo);
         col_thr[f] = make_int2(hi, lo);
         col_zero[f] = lo >= 0 ? '0' : '2';
         if (lo < 0) atomicOr(&part_has2[iv_part[k]], 1);
@@ -3265,7 +3307,7 @@ struct fseg_ctx {
     DevBuf d_voff, d_chunk_off, d_csum, d_mean, d_thr, d_label_off, d_part_has2;
     int n_rep_blocks = 0;
     // candidate-sized (slab_pos)
-    DevBuf d_cand_off, d_cand_y, d_fixed0, d_added, d_fixed, d_chosen, d_final_off, d_final_y, d_final_pos, d_col_thr,
+    DevBuf d_cand_off, d_cand_y, d_fixed0, d_added, d_fixed, d_chosen, d_final_off, d_final_y, d_final_pos, d_final_iv, d_col_thr,
         d_col_zero;
     DevBuf d_cum, d_tile_tot, d_seg_iv, d_seg_prev, d_rseg_c, d_cand_pn, d_cand_ll, d_cand_ln, d_prob_bs;
     // problems / arenas (slab_arena)
@@ -3496,7 +3538,7 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
     auto scan_counts = [&](hipStream_t q, int *bs, const unsigned char *flags, u64 *total_dev, i64 *off_last) {
         if (scan_single) return;
         hipLaunchKernelGGL(k_scan1, dim3(grid_for(scan_nb, 1, 4096)), dim3(256), 0, q, flags, NPOS, bs);
-        hipLaunchKernelGGL(k_scan2, dim3(1), dim3(256), 0, q, bs, scan_nb, total_dev, off_last);
+        hipLaunchKernelGGL(k_scan2, dim3(1), dim3(kScan2Threads), 0, q, bs, scan_nb, total_dev, off_last);
     };
     int work_grid = grid_for(c->work_cap, 1, 4096);
     ProblemArrays pr{c->d_prob_iv.as<int>(), c->d_prob_start.as<int>(), c->d_prob_n.as<int>(),
@@ -3539,7 +3581,7 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
     hipLaunchKernelGGL(k_scan_emit<kEmitValues>, dim3(scan_grid), dim3(256), 0, q, c->d_flag.as<unsigned char>(), NPOS,
                        bsum_side, scan_state, &st->n_vals, (i64 *)nullptr, &st->err, c->d_y.as<double>(), c->d_v.as<double>(), K, c->d_pos_off.as<i64>(),
                        c->d_iv_start.as<int>(), c->d_blk_iv0.as<int>(), (int *)nullptr, (int *)nullptr, (i64 *)nullptr,
-                       c->force_scan_stall ? 1 : 0);
+                       c->force_scan_stall ? 1 : 0, (int *)nullptr);
     hipLaunchKernelGGL(k_voff, dim3(grid_for(n_part + 1, 1, 2048)), dim3(64), 0, q, n_part, c->d_part_iv_off.as<i64>(),
                        c->d_pos_off.as<i64>(), NPOS, c->d_flag.as<unsigned char>(), bsum_side, scan_state, &st->n_vals,
                        c->d_voff.as<i64>());
@@ -3564,7 +3606,7 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
     hipLaunchKernelGGL(k_scan_emit<kEmitPositions>, dim3(scan_grid), dim3(256), 0, s, c->d_cflag.as<unsigned char>(), NPOS,
                        bsum, scan_state + scan_nb, &st->n_cand, c->d_cand_off.as<i64>() + K, &st->err, (const double *)nullptr, (double *)nullptr, K, c->d_pos_off.as<i64>(),
                        c->d_iv_start.as<int>(), c->d_blk_iv0.as<int>(), c->d_cand_y.as<int>(), (int *)nullptr,
-                       c->d_cand_off.as<i64>(), 0);
+                       c->d_cand_off.as<i64>(), 0, (int *)nullptr);
     end(ST_CANDIDATES);
     join(0);
     begin(ST_FIX);
@@ -3620,7 +3662,7 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
             hipLaunchKernelGGL(k_tiny, dim3(grid_for(c->prob_cap, 4, 4096)), dim3(256), 0, qt, st, c->d_prob_desc.as<ProbDesc>(),
                                c->prob_cap, tiny_max, pr, c->d_cand_y.as<int>(), c->d_lane_ex.as<longlong2>(),
                                c->d_ex_ts.as<int>(), c->d_ex_te.as<int>(), c->d_h_table.as<double>(), c->P.h_len, c->P.threshold_rate,
-                               c->P.min_read_support_outside, c->d_chosen.as<unsigned char>());
+                               c->d_thr_tab.as<int2>(), c->P.min_read_support_outside, c->d_chosen.as<unsigned char>());
         }
 #ifdef FSEG_SCORE_TIMING
 #define FSEG_TARG , c->d_tacc.as<unsigned long long>()
@@ -3743,11 +3785,11 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
     hipLaunchKernelGGL(k_scan_emit<kEmitPositions>, dim3(scan_grid), dim3(256), 0, s, c->d_final_flag.as<unsigned char>(),
                        NPOS, bsum, scan_state + 2 * scan_nb, &st->n_final, c->d_final_off.as<i64>() + K, &st->err, (const double *)nullptr, (double *)nullptr, K, c->d_pos_off.as<i64>(),
                        c->d_iv_start.as<int>(), c->d_blk_iv0.as<int>(), c->d_final_y.as<int>(), c->d_final_pos.as<int>(),
-                       c->d_final_off.as<i64>(), 0);
+                       c->d_final_off.as<i64>(), 0, c->d_final_iv.as<int>());
     // S7, first half: per-column thresholds and the label arena's plan
     hipLaunchKernelGGL(k_label_cols, dim3(grid_for(NPOS / 8 + 1, 256, 2048)), dim3(256), 0, s, K, c->d_final_off.as<i64>(),
-                       c->d_final_y.as<int>(), c->d_iv_part.as<int>(), c->d_h_table.as<double>(), c->P.h_len,
-                       c->P.threshold_rate, c->d_col_thr.as<int2>(), c->d_col_zero.as<unsigned char>(),
+                       c->d_final_y.as<int>(), c->d_final_iv.as<int>(), c->d_iv_part.as<int>(), c->d_h_table.as<double>(), c->P.h_len,
+                       c->P.threshold_rate, c->d_thr_tab.as<int2>(), c->d_col_thr.as<int2>(), c->d_col_zero.as<unsigned char>(),
                        c->d_part_has2.as<int>(), n_part, c->d_part_iv_off.as<i64>(), c->d_part_rep_off.as<i64>(),
                        c->d_label_off.as<i64>(), st, c->label_cap);
     end(ST_FINAL);
@@ -4331,7 +4373,7 @@ int fseg_upload(fseg_ctx *c, const fseg_batch *b) {
         cv.add(c->d_cand_off, ((size_t)K + 2) * 8); cv.add(c->d_final_off, ((size_t)K + 2) * 8);
         cv.add(c->d_cand_y, np8 * 4); cv.add(c->d_fixed0, np8); cv.add(c->d_added, np8);
         cv.add(c->d_fixed, np8); cv.add(c->d_chosen, np8);
-        cv.add(c->d_final_y, np8 * 4); cv.add(c->d_final_pos, np8 * 4); cv.add(c->d_col_thr, np8 * 8); cv.add(c->d_col_zero, np8);
+        cv.add(c->d_final_y, np8 * 4); cv.add(c->d_final_pos, np8 * 4); cv.add(c->d_final_iv, np8 * 4); cv.add(c->d_col_thr, np8 * 8); cv.add(c->d_col_zero, np8);
         cv.add(c->d_seg_iv, np8 * 4); cv.add(c->d_seg_prev, np8 * 4); cv.add(c->d_rseg_c, np8 * 4);
         cv.add(c->d_cand_pn, np8 * 4); cv.add(c->d_cand_ll, np8 * 4); cv.add(c->d_cand_ln, np8 * 4);
         cv.add(c->d_prob_bs, ((size_t)NPOS / kProbBlock + 2) * kProbCols * 8);
