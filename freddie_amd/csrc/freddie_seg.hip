@@ -3152,25 +3152,52 @@ __global__ void __launch_bounds__(256) k_prep_reps(int n_blocks, const int *rb_p
 
 // One workgroup per partition walks the partition's reps in sorted order, 256 at a time: exclusive scan of the weights
 // (lane offsets) and inclusive running maximum of the last positions, both with a carry from tile to tile.
+// sort_here: no batch-wide sort ran (every partition has at most kLaneSortMax reps, the usual case): the workgroup sorts
+// its partition's (first position, rep) keys itself, bitonic in LDS -- one launch instead of the radix sort's sixteen.
+constexpr int kLaneSortMax = 2048;
 __global__ void __launch_bounds__(256) k_lanes(int n_part, const i64 *part_rep_off, const i64 *part_lane_off, const u64 *key_sorted,
                                                const int *val_sorted, const int *rep_weight, const int *rep_last,
-                                               const i64 *rep_exon_off, longlong2 *lane_ex, int *lane_start, int *lane_pmax) {
+                                               const i64 *rep_exon_off, longlong2 *lane_ex, int *lane_start, int *lane_pmax,
+                                               int sort_here, const u64 *key_unsorted) {
     __shared__ int lds[16];
     __shared__ int wmax[4];
     __shared__ int carry_max_s;
     __shared__ i64 carry_lane_s;
+    __shared__ u64 skey[kLaneSortMax];             // (biased first position << 32 | rep index inside the partition): unique, so
+                                                   // the order is the stable order by position
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     for (int p = blockIdx.x; p < n_part; p += gridDim.x) {
         const i64 r0 = part_rep_off[p], r1 = part_rep_off[p + 1];
         __syncthreads();
         if (threadIdx.x == 0) { carry_max_s = -0x7fffffff - 1; carry_lane_s = part_lane_off[p]; }
+        if (sort_here) {
+            const int nr = (int)(r1 - r0);
+            int N = 1;
+            while (N < nr) N <<= 1;
+            for (int i = threadIdx.x; i < N; i += 256)
+                skey[i] = i < nr ? ((key_unsorted[r0 + i] & 0xffffffffULL) << 32) | (u64)(unsigned)i : ~0ULL;     // padding sorts last
+            __syncthreads();
+            for (int k = 2; k <= N; k <<= 1)
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    for (int t = threadIdx.x; t < N / 2; t += 256) {
+                        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), ixj = i | j;      // the pair (i, i ^ j) with bit j clear in i
+                        const u64 a = skey[i], b = skey[ixj];
+                        const bool up = (i & k) == 0;
+                        if ((a > b) == up) { skey[i] = b; skey[ixj] = a; }
+                    }
+                    __syncthreads();
+                }
+        }
         __syncthreads();
         for (i64 t0 = r0; t0 < r1; t0 += 256) {
             const i64 i = t0 + threadIdx.x;
             const bool in = i < r1;
-            const int r = in ? val_sorted[i] : 0;
+            int r = 0, first = 0;
+            if (in) {
+                if (sort_here) { const u64 k2 = skey[i - r0]; r = (int)(r0 + (i64)(k2 & 0xffffffffULL)); first = (int)((unsigned)(k2 >> 32) ^ 0x80000000u); }
+                else { r = val_sorted[i]; first = (int)((unsigned)(key_sorted[i] & 0xffffffffULL) ^ 0x80000000u); }
+            }
             const int w = in ? rep_weight[r] : 0;
-            const int first = in ? (int)((unsigned)(key_sorted[i] & 0xffffffffULL) ^ 0x80000000u) : 0;
             int m = in ? rep_last[r] : -0x7fffffff - 1;
             for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(m, d); if (lane >= d) m = max(m, y); }
             int tot;
@@ -3359,6 +3386,7 @@ struct fseg_ctx {
     i64 n_solve[3] = {0, 0, 0}, n_cls_work[4] = {0, 0, 0, 0}, n_dp_cls[3] = {0, 0, 0}, n_arena_prob = 0;
     i64 tiny_from = 256;        // problems above which k_tiny is used (FSEG_TINY_FROM; tests force 0)
     bool trace = false;         // FSEG_TRACE=1: phase timers of upload / run on stderr
+    bool force_global_sort = false;   // FSEG_GLOBAL_SORT=1 (tests): the batch-wide radix sort whatever the partition sizes
     bool debug_recopy = false;  // FSEG_DEBUG_RECOPY=1 (probes): fseg_results copies again on every call
 };
 
@@ -4092,6 +4120,7 @@ int fseg_create(int device, fseg_ctx **out) {
     if (flag("FSEG_NO_SIZED")) c->use_sized = false;
     if (flag("FSEG_TRACE")) c->trace = true;
     if (flag("FSEG_DEBUG_RECOPY")) c->debug_recopy = true;
+    if (flag("FSEG_GLOBAL_SORT")) c->force_global_sort = true;
     if (flag("FSEG_FORCE_SCAN_STALL")) c->force_scan_stall = true;
     if (flag("FSEG_FORCE_WIDE_DP")) { c->force_wide_dp = true; c->dp_wide_counts = true; }
     { const char *tf = getenv("FSEG_TINY_FROM"); if (tf && tf[0]) c->tiny_from = atoll(tf); }
@@ -4176,7 +4205,7 @@ int fseg_upload(fseg_ctx *c, const fseg_batch *b) {
     if (I < 0) return fail(c, FSEG_ERR_ARG, "rep_exon_off not monotone");
     if (I >= 0x7fffffffLL) return fail(c, FSEG_ERR_UNSUPPORTED, "batch has %lld exons; split it (limit 2^31-1 per upload)", (long long)I);
     // ---- host pass 1: the partition / interval level (validation as read_split() asserts it, :138-140) and the counts
-    i64 NPOS = 0, n_tiles = 0, lanes = 0, n_rep_blocks = 0;
+    i64 NPOS = 0, n_tiles = 0, lanes = 0, n_rep_blocks = 0, max_part_reps = 0;
     bool expanded = false;
     for (int p = 0; p < np; ++p) {
         const i64 k0 = b->part_iv_off[p], k1 = b->part_iv_off[p + 1];
@@ -4190,6 +4219,7 @@ int fseg_upload(fseg_ctx *c, const fseg_batch *b) {
             n_tiles += (len + kSmoothTile - 1) / kSmoothTile;
         }
         n_rep_blocks += (b->part_rep_off[p + 1] - b->part_rep_off[p] + 255) / 256;
+        if (b->part_rep_off[p + 1] - b->part_rep_off[p] > max_part_reps) max_part_reps = b->part_rep_off[p + 1] - b->part_rep_off[p];
     }
     if (NPOS >= 0x7fffffffLL) return fail(c, FSEG_ERR_UNSUPPORTED, "batch has %lld positions; split it (limit 2^31-1 per upload)", (long long)NPOS);
     for (i64 r = 0; r < R; ++r) {
@@ -4332,17 +4362,23 @@ int fseg_upload(fseg_ctx *c, const fseg_batch *b) {
                            c->d_rb_r0.as<int>(), c->d_part_rep_off.as<i64>(), c->d_part_iv_off.as<i64>(), c->d_iv_start.as<int>(),
                            c->d_iv_end.as<int>(), c->d_rep_exon_off.as<i64>(), c->d_ex_ts.as<int>(), c->d_ex_te.as<int>(),
                            c->d_key_a.as<u64>(), c->d_val_a.as<int>(), c->d_rep_last.as<int>(), c->d_prep.as<PrepStatus>());
-        unsigned end_bit = 33;
-        while (end_bit < 64 && ((u64)np >> (end_bit - 32)) != 0) ++end_bit;
-        size_t tmp_bytes = 0;
-        HIP_TRY(c, fseg_sort_pairs(nullptr, &tmp_bytes, c->d_key_a.as<u64>(), c->d_key_b.as<u64>(), c->d_val_a.as<int>(), c->d_val_b.as<int>(),
-                                   (size_t)R, end_bit, s));
-        TRY(ensure(c, c->d_sort_tmp, tmp_bytes));
-        HIP_TRY(c, fseg_sort_pairs(c->d_sort_tmp.p, &tmp_bytes, c->d_key_a.as<u64>(), c->d_key_b.as<u64>(), c->d_val_a.as<int>(),
-                                   c->d_val_b.as<int>(), (size_t)R, end_bit, s));
+        // small partitions (the usual case) sort themselves inside k_lanes; a batch with a large one goes through the
+        // batch-wide radix sort (FSEG_GLOBAL_SORT=1 forces it: tests)
+        const bool sort_here = max_part_reps <= kLaneSortMax && !c->force_global_sort;
+        if (!sort_here) {
+            unsigned end_bit = 33;
+            while (end_bit < 64 && ((u64)np >> (end_bit - 32)) != 0) ++end_bit;
+            size_t tmp_bytes = 0;
+            HIP_TRY(c, fseg_sort_pairs(nullptr, &tmp_bytes, c->d_key_a.as<u64>(), c->d_key_b.as<u64>(), c->d_val_a.as<int>(), c->d_val_b.as<int>(),
+                                       (size_t)R, end_bit, s));
+            TRY(ensure(c, c->d_sort_tmp, tmp_bytes));
+            HIP_TRY(c, fseg_sort_pairs(c->d_sort_tmp.p, &tmp_bytes, c->d_key_a.as<u64>(), c->d_key_b.as<u64>(), c->d_val_a.as<int>(),
+                                       c->d_val_b.as<int>(), (size_t)R, end_bit, s));
+        }
         hipLaunchKernelGGL(k_lanes, dim3(grid_for(np, 1, 65536)), dim3(256), 0, s, np, c->d_part_rep_off.as<i64>(), c->d_part_lane_off.as<i64>(),
                            c->d_key_b.as<u64>(), c->d_val_b.as<int>(), c->d_rep_weight.as<int>(), c->d_rep_last.as<int>(),
-                           c->d_rep_exon_off.as<i64>(), c->d_lane_ex.as<longlong2>(), c->d_lane_start.as<int>(), c->d_lane_pmax.as<int>());
+                           c->d_rep_exon_off.as<i64>(), c->d_lane_ex.as<longlong2>(), c->d_lane_start.as<int>(), c->d_lane_pmax.as<int>(),
+                           sort_here ? 1 : 0, c->d_key_a.as<u64>());
     }
     hipLaunchKernelGGL(k_hist_ranges, dim3(grid_for(n_chunks, 256, 4096)), dim3(256), 0, s, (int)n_chunks, c->d_hc_part.as<int>(),
                        c->d_hc_glo.as<int>(), c->d_hc_ghi.as<int>(), c->d_part_lane_off.as<i64>(), c->d_lane_start.as<int>(),

@@ -51,6 +51,7 @@ SWITCHES = [
     {"FSEG_NO_FUSE": "1"},                                  # every non-tiny problem through the arena path (tiles, work items, k_score, k_dp*)
     {"FSEG_NO_FUSE": "1", "FSEG_NO_TINY": "1", "FSEG_NO_SIZED": "1"},
     {"FSEG_NO_TINY": "1"},                                  # ... and the tiny ones through k_solve
+    {"FSEG_GLOBAL_SORT": "1"},                              # the batch-wide radix sort of the reps instead of the in-LDS sort per partition
     {"FSEG_PROB_SELF_MAX": "0"},                            # the problem list always through the block-sum scan
     {"FSEG_PROB_SELF_MAX": "100000000"},                    # ... and always through the self-scanning emit kernel
 ]
