@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""profiles/traffic.json from the committed PMC passes of a round: per workload, the scoring stage's HBM bytes per launch
+(FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE; KiB -> bytes) and its VALU utilisation
+(4 * SQ_ACTIVE_INST_VALU / (1024 SIMDs * GRBM_GUI_ACTIVE / 8), weighted by each kernel's share of the stage's time).
+    python profiles/make_traffic.py r02"""
+import csv
+import json
+import os
+import sys
+from collections import defaultdict
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+STAGE = {"config4": ("k_solve<16", "k_solve<32", "k_solve<60", "k_tiny"), "config2": ("k_score<60>",)}
+
+
+def load(path):
+    out = defaultdict(lambda: defaultdict(list))
+    for r in csv.DictReader(open(path)):
+        name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+        out[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return out
+
+
+def mean_last(v, n=5):
+    v = v[-n:]
+    return sum(v) / len(v)
+
+
+doc = {"_comment": "HBM traffic and VALU utilisation of the interval-scoring stage per launch, from rocprofv3 --pmc passes "
+       "(FETCH_SIZE, WRITE_SIZE and the SQ counters each in their own run: tools/profile_round.sh; raw CSVs next to this file). "
+       "bench.py copies these figures into its line labelled 'committed': they are not measured in the benchmark run."}
+for w, kernels in STAGE.items():
+    f = load(os.path.join(HERE, "%s_%s_pmc_fetch_size.csv" % (tag, w)))
+    wr = load(os.path.join(HERE, "%s_%s_pmc_write_size.csv" % (tag, w)))
+    sq = load(os.path.join(HERE, "%s_%s_pmc_sq.csv" % (tag, w)))
+    per = {}
+    traffic = 0.0
+    util_num = util_den = 0.0
+    for k in sorted(f):
+        if not any(k.startswith(p) for p in kernels):
+            continue
+        fetch = mean_last(f[k]["FETCH_SIZE"]); write = mean_last(wr[k]["WRITE_SIZE"]) if k in wr else 0.0
+        gui = mean_last(sq[k]["GRBM_GUI_ACTIVE"]); valu = mean_last(sq[k]["SQ_ACTIVE_INST_VALU"])
+        util = 4.0 * valu / (1024.0 * gui / 8.0)
+        per[k] = {"fetch_size_kib_raw": fetch, "write_size_kib": write, "bytes": int((2 * fetch + write) * 1024), "valu_util": round(util, 3),
+                  "gui_active_cycles_per_xcd": gui / 8.0}
+        traffic += (2 * fetch + write) * 1024
+        util_num += util * gui; util_den += gui
+    doc[w] = {"kernels": per, "traffic_bytes": int(traffic), "valu_util": round(util_num / util_den, 3) if util_den else None,
+              "valu_source": "SQ_ACTIVE_INST_VALU / GRBM_GUI_ACTIVE pass of %s, profiles/%s_%s_pmc_sq.csv (time-weighted over the stage's kernels)" % (tag, tag, w),
+              "build": tag, "csv": ["%s_%s_pmc_%s.csv" % (tag, w, x) for x in ("fetch_size", "write_size", "sq")]}
+json.dump(doc, open(os.path.join(HERE, "traffic.json"), "w"), indent=1)
+print(json.dumps({w: {k: doc[w][k] for k in ("traffic_bytes", "valu_util")} for w in STAGE}, indent=1))
