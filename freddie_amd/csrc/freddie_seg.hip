@@ -340,8 +340,8 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth(int n_tiles, const Ti
             if (y0 + o4 < len) {
                 const int c = o4 + radius;
                 const double w0 = ws[0];
-                double a0 = __dmul_rn((double)xs[c], w0), a1 = __dmul_rn((double)xs[c + 1], w0);
-                double a2 = __dmul_rn((double)xs[c + 2], w0), a3 = __dmul_rn((double)xs[c + 3], w0);
+                double a0 = __dmul_rn((double)(xs[c]), w0), a1 = __dmul_rn((double)(xs[c + 1]), w0);
+                double a2 = __dmul_rn((double)(xs[c + 2]), w0), a3 = __dmul_rn((double)(xs[c + 3]), w0);
                 int l0 = xs[c - radius], l1 = xs[c - radius + 1], l2 = xs[c - radius + 2], l3 = xs[c - radius + 3];
                 int r0 = xs[c + radius], r1 = xs[c + radius + 1], r2 = xs[c + radius + 2], r3 = xs[c + radius + 3];
 #define FSEG_TAP(W)                                                                                        \
@@ -913,6 +913,19 @@ __device__ __forceinline__ ProbDesc load_desc(const ProbDesc *d) {
     return u.p;
 }
 
+// A value every lane of the wave holds identically, moved to a scalar register: what is computed from it (triangular
+// table offsets, loop bounds, LDS base addresses) then runs on the scalar unit instead of costing every lane a multiply.
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int wave_id() { return uni((int)(threadIdx.x >> 6)); }
+__device__ __forceinline__ ProbDesc load_desc_uniform(const ProbDesc *d) {      // the whole wave loads the same record
+    const uint4 *q = reinterpret_cast<const uint4 *>(d);
+    union { uint4 v[4]; int w[16]; ProbDesc p; } u;
+    u.v[0] = q[0]; u.v[1] = q[1]; u.v[2] = q[2]; u.v[3] = q[3];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) u.w[i] = uni(u.w[i]);
+    return u.p;
+}
+
 __device__ __forceinline__ i64 wave_excl_scan(i64 v, i64 *total) {
     int lane = lane_id();
     i64 x = v;
@@ -1479,8 +1492,7 @@ __global__ void __launch_bounds__(kLaneChunk) k_cov(Status *st, const ProbDesc *
 // D(a,b,c) = in_ab + out_abc + M(b,c),  M(b,c) = max_{c2>c} D(b,c,c2) (first maximiser, strict >),
 // M(b,end) := in_b,end closes the chain (base case :545-548).  The inner maximum depends only on (b,c), so
 // filling M for c descending is O(n^3) and gives the reference's O(n^4) recursion's result
-// (SURVEY.md App. A.7).  For a fixed c the lanes are the b < c (so the out(b,c,c2) reads of a wave are
-// contiguous) and the waves of the workgroup split the c2 > c.  All tables live in LDS:
+// (SURVEY.md App. A.7).  All tables live in LDS:
 //   out_s[rank(a,b,c)] counts, in_s[pair] = -(ambiguous reads), M / A (argmax) per pair, cy_s = candidate y.
 // Every thread of the workgroup must call it; returns the number of backtracked triples (valid on thread 0)
 // and marks the chosen candidates.
@@ -1494,11 +1506,8 @@ __global__ void __launch_bounds__(kLaneChunk) k_cov(Status *st, const ProbDesc *
 #define FSEG_DPARAM
 #define FSEG_DARG
 #endif
-#ifndef FSEG_DP_G
-#define FSEG_DP_G 4                  // candidates per DP block (tuning knob)
-#endif
 // T == 64: the caller is ONE WAVE working on its own problem with wave-private tables (other waves of the workgroup
-// may be inside their own dp_solve<64>), so synchronisation is wave-level and thread indices are lane indices.
+// may be inside their own dp_solve_push<64>), so synchronisation is wave-level and thread indices are lane indices.
 template <int T>
 __device__ __forceinline__ void dp_sync() {
     if (T == 64) {
@@ -1512,139 +1521,95 @@ __device__ __forceinline__ void dp_sync() {
 // below 2^30 (k_solve's launches: every sum is a chain of at most n/2 counts and ambiguity terms, each bounded by the
 // partition's reads) -- half the registers, LDS traffic and instructions of the chain.
 template <typename V> __device__ __forceinline__ constexpr V dp_neg_inf() { return sizeof(V) == 8 ? (V)kNegInf : (V)(-0x40000000); }
-template <int T, typename OutT, typename V>
-__device__ int dp_solve(int n, const OutT *out_s, const int *in_s, V *M, unsigned char *A, const int *cy_s, int support,
-                        V *part_v /* T */, unsigned char *part_a /* T */, int *top_key /* T/64 */,
-                        unsigned char *chosen /* + first candidate of the problem */ FSEG_DPARAM) {
-    constexpr int NW = T / 64;
-    const int lane = lane_id(), wave = T == 64 ? 0 : (int)(threadIdx.x >> 6);
+// Pushed, not pulled: every thread OWNS pairs (b,c) -- pair q = s*T + tid, the ownership the scoring phase already uses --
+// and keeps their running maximum in registers:
+//   column c2 final  ->  its owners write M(.,c2)  ->  one barrier  ->  every pair (b,c) with c < c2 takes
+//   out(b,c,c2) + M(c,c2) into its maximum.
+// One barrier per candidate, no reduction over waves, no serial part, and the work of a step is spread over all the
+// threads (out(.,.,c2) is one contiguous run of the count table: lane-consecutive bytes).  Pushes arrive with c2
+// descending, so "first maximiser" (the smallest c2 among equals) is "the later push wins ties".  The row b = 0 is the top
+// level (:560-566): M(0,j) = in(0,j) + max_k(out(0,j,k) + M(j,k)), then the first maximiser over j, taken only if it beats
+// "no cut" = in(0,end).  (A gather formulation -- lanes = b, a loop over c2 per lane, blocks of four candidates with a serial
+// in-block fix-up -- took 36 us for n = 49 against 22 us; tools/probes/dp_probe.hip.)
+template <int T, int NM, typename OutT, typename V>
+__device__ __forceinline__ int dp_solve_push(int n, const OutT *out_s, const int *in_s, V *M, unsigned char *A, const int *cy_s, int support,
+                                             unsigned char *chosen /* + first candidate of the problem */ FSEG_DPARAM) {
+    constexpr int SLOTS = (NM * (NM - 1) / 2 + T - 1) / T;
+    static_assert(NM <= 64, "the top level is one lane per candidate");
+    const int lane = lane_id(), wave = T == 64 ? 0 : wave_id();
     const int tid = T == 64 ? lane : (int)threadIdx.x;
+    n = uni(n); support = uni(support);
     const int end = n - 1;
     const int npairs = n * (n - 1) / 2;
     constexpr V kNeg = dp_neg_inf<V>();
-#define FSEG_IN(a, b) ((V)in_s[(b) * ((b) - 1) / 2 + (a)])
-#define FSEG_M(a, b) M[(b) * ((b) - 1) / 2 + (a)]
-    // M(b,end): the chain closes here; the "segment too small" rule (:540) is folded into the table, so the
-    // inner loops only test tail != -inf
-    for (int b = tid; b < end; b += T) {
-        FSEG_M(b, end) = cy_s[end] - cy_s[b] >= 5 ? FSEG_IN(b, end) : kNeg;
-        A[end * (end - 1) / 2 + b] = 255;
+    int pc[SLOTS], arg[SLOTS];
+    V best[SLOTS], inv[SLOTS];
+    bool live[SLOTS];
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        const int q = s * T + tid;
+        int b, c;
+        pair_decode(q < npairs ? q : 0, &b, &c);
+        pc[s] = c;
+        live[s] = q < npairs && cy_s[c] - cy_s[b] >= 5;            // "segment too small" (:540)
+        inv[s] = (V)in_s[q < npairs ? q : 0];
+        best[s] = kNeg; arg[s] = 255;
     }
-    dp_sync<T>();
-    // Blocks of G consecutive c (top, top-1, ..).  M(b,c) needs M(c,c2) for every c2 > c: the c2 above the block
-    // are final, so all G candidates of a block take their maximum over those c2 in parallel (wave = (g, c2 slice),
-    // lanes = b); the G(G-1)/2 terms with c2 inside the block are then added by wave 0 alone, in registers, with
-    // M(c,c2) read from the lane that owns b = c.  Two barriers per block instead of two per candidate.
-    constexpr int G = FSEG_DP_G <= NW ? FSEG_DP_G : NW;
-    constexpr int NWG = NW / G;
-    const int g_w = wave % G, s_w = wave / G;
-    const int b = 1 + lane;
-    for (int top = end - 1; top >= 2; top -= G) {
-        {
-            const int c = top - g_w;
-            V best = kNeg; int arg = 255;
-            if (c >= 2 && b < c && cy_s[c] - cy_s[b] >= 5) {
-                const int base = c * (c - 1) / 2 + b;
-#pragma unroll 4
-                for (int c2 = top + 1 + s_w; c2 <= end; c2 += NWG) {
-                    V tail = FSEG_M(c, c2);
-                    unsigned o = out_s[c2 * (c2 - 1) * (c2 - 2) / 6 + base];
-                    bool ok = (tail != kNeg) & ((int)o >= support);                         // :526-527, :540
-                    V cur = ok ? (V)o + tail : kNeg;     // in(b,c) is the same for every c2: added after the maximum
-                    bool take = cur > best;
-                    best = take ? cur : best; arg = take ? c2 : arg;
-                }
-            }
-            part_v[wave * 64 + lane] = best; part_a[wave * 64 + lane] = (unsigned char)arg;
-        }
-        dp_sync<T>();
-        if (wave == 0) {
-            V R[G]; int Ra[G];
+    for (int c2 = end; c2 >= 1; --c2) {
+        const int t2 = c2 * (c2 - 1) / 2, t3 = c2 * (c2 - 1) * (c2 - 2) / 6;
+        // column c2 is final: its pairs are q in [t2, t2 + c2)
 #pragma unroll
-            for (int g = 0; g < G; ++g) {
-                // first maximiser over the c2 slices: larger value wins, equal values keep the smaller c2
-                V bv = part_v[g * 64 + lane]; int ba = part_a[g * 64 + lane];
-#pragma unroll
-                for (int s2 = 1; s2 < NWG; ++s2) {
-                    V v = part_v[(s2 * G + g) * 64 + lane]; int a2 = part_a[(s2 * G + g) * 64 + lane];
-                    if (v > bv || (v == bv && v != kNeg && a2 < ba)) { bv = v; ba = a2; }
-                }
-                R[g] = bv; Ra[g] = ba;
-            }
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                const int c = top - g;
-                if (c >= 2) {
-                    const bool live = b < c && cy_s[c] - cy_s[b] >= 5;
-                    const int base = c * (c - 1) / 2 + b;
-                    V best = kNeg; int arg = 255;
-#pragma unroll
-                    for (int h = g - 1; h >= 0; --h) {               // c2 = top - h inside the block, ascending
-                        const int c2 = top - h;
-                        // M(c, c2) sits in lane c - 1 (b = c) of R[h]
-                        V tail;
-                        if (sizeof(V) == 8) {
-                            int lo = __builtin_amdgcn_readlane((int)(unsigned)(u64)R[h], c - 1);
-                            int hi = __builtin_amdgcn_readlane((int)(unsigned)((u64)R[h] >> 32), c - 1);
-                            tail = (V)(((u64)(unsigned)hi << 32) | (u64)(unsigned)lo);
-                        } else tail = (V)__builtin_amdgcn_readlane((int)R[h], c - 1);
-                        unsigned o = live ? (unsigned)out_s[c2 * (c2 - 1) * (c2 - 2) / 6 + base] : 0u;
-                        bool ok = live & (tail != kNeg) & ((int)o >= support);
-                        V cur = ok ? (V)o + tail : kNeg;
-                        bool take = cur > best;
-                        best = take ? cur : best; arg = take ? c2 : arg;
-                    }
-                    if (R[g] > best) { best = R[g]; arg = Ra[g]; }   // the c2 above the block are all larger: strict >
-                    R[g] = (live && best != kNeg) ? best + FSEG_IN(b, c) : kNeg;
-                    if (b < c) { FSEG_M(b, c) = R[g]; A[base] = (unsigned char)arg; }
-                }
+        for (int s = 0; s < SLOTS; ++s) {
+            const int q = s * T + tid;
+            if (q >= t2 && q < t2 + c2) {
+                const V m = c2 == end ? (live[s] ? inv[s] : kNeg) : ((live[s] && best[s] != kNeg) ? best[s] + inv[s] : kNeg);
+                M[q] = m; A[q] = (unsigned char)arg[s];
             }
         }
         dp_sync<T>();
+        if (c2 == 1) break;
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+            const int q = s * T + tid;
+            if (q < t2) {                                            // pairs (b, c) with c < c2
+                const V tail = M[t2 + pc[s]];
+                const unsigned o = (unsigned)out_s[t3 + q];
+                const V cur = (V)o + tail;
+                const bool take = (tail != kNeg) & ((int)o >= support) & (cur >= best[s]);      // :526-527, :540
+                best[s] = take ? cur : best[s]; arg[s] = take ? c2 : arg[s];
+            }
+        }
     }
     FSEG_DTICK(10);
-    // top level (a = start): max over (j,k) of in_0j + out_0jk + M(j,k), first maximiser in (j, k) order,
-    // taken only if strictly greater than "no cut" = in(0,end)   (:560-566)
-    V bv = kNeg; int bkey = 0x7fffffff;
-    for (int q = tid; q < npairs; q += T) {
-        int j, kx;
-        pair_decode(q, &j, &kx);                    // j < kx
-        if (j < 1) continue;
-        if (cy_s[j] - cy_s[0] < 5 || cy_s[kx] - cy_s[j] < 5) continue;
-        V tail = FSEG_M(j, kx);
-        unsigned o = out_s[kx * (kx - 1) * (kx - 2) / 6 + j * (j - 1) / 2 + 0];
-        if (tail == kNeg || (int)o < support) continue;
-        V cur = FSEG_IN(0, j) + (V)o + tail;
-        int key = j * 64 + kx;
-        if (cur > bv || (cur == bv && key < bkey)) { bv = cur; bkey = key; }
-    }
-    for (int d = 32; d >= 1; d >>= 1) {
-        V ov = __shfl_xor(bv, d); int ok2 = __shfl_xor(bkey, d);
-        if (ov > bv || (ov == bv && ok2 < bkey)) { bv = ov; bkey = ok2; }
-    }
-    dp_sync<T>();
-    if (lane == 0) { part_v[wave] = bv; top_key[wave] = bkey; }
-    dp_sync<T>();
-    FSEG_DTICK(11);
     int chain = 0;
-    if (tid == 0) {
-        for (int w = 1; w < NW; ++w)
-            if (part_v[w] > bv || (part_v[w] == bv && top_key[w] < bkey)) { bv = part_v[w]; bkey = top_key[w]; }
-        if (bv != kNeg && bv > FSEG_IN(0, end)) {
-            int j = bkey >> 6, k = bkey & 63;
-            chosen[0] = 1;
+    if (wave == 0) {
+        // first maximiser over j of M(0,j) (larger value, then smaller j), one candidate per lane
+        const int j0 = lane >= 1 && lane < end ? lane : 1;
+        V bv = (lane >= 1 && lane < end) ? M[j0 * (j0 - 1) / 2] : kNeg;
+        int bj = lane;
+        for (int d = 32; d >= 1; d >>= 1) {
+            const V ov = __shfl_xor(bv, d); const int oj = __shfl_xor(bj, d);
+            if (ov > bv || (ov == bv && oj < bj)) { bv = ov; bj = oj; }
+        }
+        FSEG_DTICK(11);
+        // the chain is walked by one lane (dependent LDS loads only: the chosen candidates are collected in a mask) and
+        // stored by the wave, one candidate per lane
+        u64 mask = 0;
+        if (lane == 0 && end >= 2 && bv != kNeg && bv > (V)in_s[end * (end - 1) / 2]) {
+            int j = bj, k = A[bj * (bj - 1) / 2];
+            mask = 1ULL;
             for (;;) {
-                chosen[j] = 1; chosen[k] = 1; ++chain;
+                mask |= (1ULL << j) | (1ULL << k); ++chain;
                 if (k == end) break;
-                int k2 = A[k * (k - 1) / 2 + j];
+                const int k2 = A[k * (k - 1) / 2 + j];
                 if (k2 == 255) break;
                 j = k; k = k2;
             }
         }
+        const unsigned m_lo = (unsigned)uni((int)(unsigned)mask), m_hi = (unsigned)uni((int)(unsigned)(mask >> 32));
+        if (((((u64)m_hi << 32) | m_lo) >> lane) & 1ULL) chosen[lane] = 1;
     }
     FSEG_DTICK(12);
-#undef FSEG_IN
-#undef FSEG_M
     return chain;
 }
 
@@ -1915,9 +1880,6 @@ __global__ void __launch_bounds__(T) k_dp(Status *st, int dp_class, int nm, cons
     OutT *out_s = reinterpret_cast<OutT *>(in_s + kPairs);            // counts: 16 bit when every problem sees < 65536 reads
     unsigned char *A = reinterpret_cast<unsigned char *>(out_s + ((kTri + 3) & ~3));
     __shared__ int cy_s[NM];
-    __shared__ i64 part_v[T];
-    __shared__ unsigned char part_a[T];
-    __shared__ int top_key[T / 64];
     i64 n_prob = (i64)st->n_prob;
     if (n_prob > prob_cap) return;                                  // sizing run
     // dp_class 0 / 1: the small / big problems of the per-class list; -1: every problem
@@ -1953,7 +1915,7 @@ __global__ void __launch_bounds__(T) k_dp(Status *st, int dp_class, int nm, cons
             in_s[q] = -(int)((i64)amb_g[poff + q] + ((zamb && pair_thr[poff + q].y < 0) ? outside : 0));
         __syncthreads();
         FSEG_DTICK(9);
-        int chain = dp_solve<T>(n, out_s, in_s, M, A, cy_s, support, part_v, part_a, top_key, chosen + c0 FSEG_DARG);
+        int chain = dp_solve_push<T, NM>(n, out_s, in_s, M, A, cy_s, support, chosen + c0 FSEG_DARG);
         if (threadIdx.x == 0) pr.chain[p] = chain;
     }
 }
@@ -1977,9 +1939,6 @@ __global__ void __launch_bounds__(256, 6) k_dp_waves(Status *st, const int *dp_i
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ int cy_s[NM];
     __shared__ int cy_w[4][kDpWave];
-    __shared__ i64 part_v[T];
-    __shared__ unsigned char part_a[T];
-    __shared__ int top_key[T / 64];
     __shared__ int big_s[4];
     const i64 n_prob = (i64)st->n_prob;
     if (n_prob > prob_cap) return;                                  // sizing run
@@ -2024,8 +1983,7 @@ __global__ void __launch_bounds__(256, 6) k_dp_waves(Status *st, const int *dp_i
                     for (int q = lane; q < npairs; q += 64)
                         in_s[q] = -(int)((i64)amb_g[poff + q] + ((zamb && pair_thr[poff + q].y < 0) ? (i64)d.outside : 0));
                     dp_sync<64>();
-                    int chain = dp_solve<64>(n, out_s, in_s, M, A, cy_w[wave], support, part_v + wave * 64, part_a + wave * 64,
-                                             top_key + wave, chosen + d.c0 FSEG_DARG);
+                    int chain = dp_solve_push<64, kDpWave>(n, out_s, in_s, M, A, cy_w[wave], support, chosen + d.c0 FSEG_DARG);
                     if (lane == 0) pr.chain[p] = chain;
                 }
             }
@@ -2057,7 +2015,7 @@ __global__ void __launch_bounds__(256, 6) k_dp_waves(Status *st, const int *dp_i
             for (int q = threadIdx.x; q < npairs; q += T)
                 in_s[q] = -(int)((i64)amb_g[poff + q] + ((zamb && pair_thr[poff + q].y < 0) ? (i64)d.outside : 0));
             __syncthreads();
-            int chain = dp_solve<T>(n, out_s, in_s, M, A, cy_s, support, part_v, part_a, top_key, chosen + d.c0 FSEG_DARG);
+            int chain = dp_solve_push<T, NM>(n, out_s, in_s, M, A, cy_s, support, chosen + d.c0 FSEG_DARG);
             if (threadIdx.x == 0) pr.chain[pb] = chain;
         }
     }
@@ -2068,7 +2026,7 @@ __global__ void __launch_bounds__(256, 6) k_dp_waves(Status *st, const int *dp_i
 // solved whole by ONE WAVE each: window coverage (get_cumulative_coverage :188-246), pair labels (:488-497), in / out
 // counts (:500-528) and the DP (:532-566), without a work item, a coverage tile or an arena entry.  Lanes are the reads
 // of the problem's lane range, 64 at a time: a pair's yea / nay plane for those reads is the result of one v_cmp (a
-// ballot), lane q keeps pair q's planes and ambiguity count, lane t the count of triple t; the DP is dp_solve<64> on
+// ballot), lane q keeps pair q's planes and ambiguity count, lane t the count of triple t; the DP is dp_solve_push<64> on
 // wave-private tables.  Four waves = four problems per workgroup, no workgroup barrier anywhere.
 // ---------------------------------------------------------------------------------------------
 constexpr int kTiny = 8;
@@ -2085,9 +2043,6 @@ __global__ void __launch_bounds__(256, 6) k_tiny(Status *st, const ProbDesc *des
     __shared__ unsigned out_s[4][kTinyTri + 4];
     __shared__ unsigned char A_s[4][kTinyPairs + 4];
     __shared__ int cy_s[4][kTiny];
-    __shared__ i64 part_v[256];
-    __shared__ unsigned char part_a[256];
-    __shared__ int top_key[4];
     __shared__ unsigned char tri_ijk[kTinyTri][4];
     __shared__ int2 act_w[4][128];                      // [wave] reads with coverage in the window, waiting for a round: (first exon, count)
     const int lane = lane_id(), wave = threadIdx.x >> 6;
@@ -2214,8 +2169,7 @@ __global__ void __launch_bounds__(256, 6) k_tiny(Status *st, const ProbDesc *des
         if (lane < npairs) in_s[wave][lane] = -(int)((i64)amb + (lo_q < 0 ? (i64)d.outside + dropped : 0));
         if (lane < ntri) out_s[wave][lane] = out;
         dp_sync<64>();
-        const int chain = dp_solve<64>(n, out_s[wave], in_s[wave], M_s[wave], A_s[wave], cy_s[wave], support, part_v + wave * 64,
-                                       part_a + wave * 64, top_key + wave, chosen + d.c0 FSEG_DARG);
+        const int chain = dp_solve_push<64, kTiny>(n, out_s[wave], in_s[wave], M_s[wave], A_s[wave], cy_s[wave], support, chosen + d.c0 FSEG_DARG);
         if (lane == 0) pr.chain[p] = chain;
     }
 }
@@ -2228,7 +2182,7 @@ __global__ void __launch_bounds__(256, 6) k_tiny(Status *st, const ProbDesc *des
 //   per 64 reads: window coverage (get_cumulative_coverage :188-246) by (read, candidate range) threads -- every read's
 //     exon walk is cut into T/64 pieces that run side by side --, pair planes and ambiguity counts (:488-506), triple
 //     counts (:509-528) into a table of CntT counters (8 bit when no problem of the launch sees more than 255 reads);
-//   then the planes' LDS becomes M / in / A and dp_solve (:532-566, :592-594) runs on the count table where it lies.
+//   then the planes' LDS becomes M / in / A and dp_solve_push (:532-566, :592-594) runs on the count table where it lies.
 // Nothing of such a problem exists in global memory between its descriptor and its chosen flags: no coverage tiles, no
 // threshold / ambiguity / count arenas, no work items, no DP list entry.  (The arena path remains for problems that see
 // thousands of reads, where one problem has to be spread over many workgroups.)
@@ -2265,9 +2219,6 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
     __shared__ int iend_s[NM + 4];
     __shared__ int2 act_s[256];                    // reads with coverage in the window: (first exon that meets it, how many do)
     __shared__ int act_wave[T / 64];
-    __shared__ V part_v[T];
-    __shared__ unsigned char part_a[T];
-    __shared__ int top_key[T / 64];
     const int rt_pairs = nm * (nm - 1) / 2;
     constexpr int rt_stride = NM + 1;             // compile-time row stride (odd: rows do not collide on LDS banks)
     uint4 *planes = reinterpret_cast<uint4 *>(smem);                                         // rt_pairs * 16 B; later M | in | A
@@ -2277,6 +2228,9 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
     int *in_s = reinterpret_cast<int *>(M + rt_pairs);
     unsigned char *A = reinterpret_cast<unsigned char *>(in_s + rt_pairs);
     if ((i64)st->n_prob > prob_cap) return;                          // lists incomplete (a run that only sizes the arenas)
+#ifdef FSEG_SOLVE_PRIO
+    __builtin_amdgcn_s_setprio(NM > 32 ? 3 : (NM > 16 ? 2 : 1));
+#endif
     // cls < 0: every solve list (batches of few problems: one launch instead of three)
     const i64 list_base = cls <= 0 ? 0 : (cls == 1 ? (i64)st->solve_cls[0] : (i64)st->solve_cls[0] + (i64)st->solve_cls[1]);
     const i64 list_n = cls < 0 ? (i64)st->solve_cls[0] + (i64)st->solve_cls[1] + (i64)st->solve_cls[2] : (i64)st->solve_cls[cls];
@@ -2476,7 +2430,7 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
         for (int s = 0; s < C::kSlots; ++s) { const int q = s * T + threadIdx.x; if (q < npairs) in_s[q] = in_val[s]; }
         __syncthreads();
         FSEG_STICK(9);
-        const int chain = dp_solve<T>(n, cnt, in_s, M, A, cy_s, support, part_v, part_a, top_key, chosen + d.c0 FSEG_DARG);
+        const int chain = dp_solve_push<T, NM>(n, cnt, in_s, M, A, cy_s, support, chosen + d.c0 FSEG_DARG);
         if (threadIdx.x == 0) pr.chain[p] = chain;
     }
 #undef FSEG_STICK
@@ -3683,15 +3637,7 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
     }   // do_pre2
     if (do_score) begin(ST_SCORE);
     if (do_score && c->prob_cap > 0) {
-        if (tiny_max > 0) {
-            // the problems with a handful of candidates, whole (coverage, labels, counts, DP), beside the arena-based
-            // path of the others; joined at the end of this stage, so the stage's time bracket covers all scoring work
-            hipStream_t qt = fork(2);
-            hipLaunchKernelGGL(k_tiny, dim3(grid_for(c->prob_cap, 4, 4096)), dim3(256), 0, qt, st, c->d_prob_desc.as<ProbDesc>(),
-                               c->prob_cap, tiny_max, pr, c->d_cand_y.as<int>(), c->d_lane_ex.as<longlong2>(),
-                               c->d_ex_ts.as<int>(), c->d_ex_te.as<int>(), c->d_h_table.as<double>(), c->P.h_len, c->P.threshold_rate,
-                               c->d_thr_tab.as<int2>(), c->P.min_read_support_outside, c->d_chosen.as<unsigned char>());
-        }
+        hipStream_t qt = tiny_max > 0 ? fork(2) : s;     // (forked here: a side stream continues from where it was forked)
 #ifdef FSEG_SCORE_TIMING
 #define FSEG_TARG , c->d_tacc.as<unsigned long long>()
 #else
@@ -3732,11 +3678,21 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
             if (any_solve && (!known || c->n_solve[1] > 0)) FSEG_LAUNCH_SOLVE_W(q1, kClsMid, 1, known ? c->n_solve[1] : cap, 2048);
             if (any_arena && (!known || c->n_cls_work[0] > 0)) FSEG_LAUNCH_SCORE(q0, kClsSmall, 0, 2048);
             if (any_solve && (!known || c->n_solve[0] > 0)) FSEG_LAUNCH_SOLVE_W(q0, kClsSmall, 0, known ? c->n_solve[0] : cap, 4096);
-            join(0); join(1);
         }
 #undef FSEG_LAUNCH_SOLVE_W
 #undef FSEG_LAUNCH_SOLVE
 #undef FSEG_LAUNCH_SCORE
+        if (tiny_max > 0) {
+            // the problems with a handful of candidates, whole (coverage, labels, counts, DP), beside the others; launched
+            // last -- the big problems' workgroups need half a CU's LDS each and must be resident before the small
+            // workgroups fill the CUs, or they start late and end the stage alone; joined at the end of this stage, so the
+            // stage's time bracket covers all scoring work
+            hipLaunchKernelGGL(k_tiny, dim3(grid_for(c->prob_cap, 4, 4096)), dim3(256), 0, qt, st, c->d_prob_desc.as<ProbDesc>(),
+                               c->prob_cap, tiny_max, pr, c->d_cand_y.as<int>(), c->d_lane_ex.as<longlong2>(),
+                               c->d_ex_ts.as<int>(), c->d_ex_te.as<int>(), c->d_h_table.as<double>(), c->P.h_len, c->P.threshold_rate,
+                               c->d_thr_tab.as<int2>(), c->P.min_read_support_outside, c->d_chosen.as<unsigned char>());
+        }
+        if (!c->small_batch) { join(0); join(1); }
         if (c->have_huge && any_arena)
             hipLaunchKernelGGL(k_score_huge, dim3(256), dim3(512), kHugeScoreLds, s, st, c->d_dp_items.as<int>(), pr,
                                c->d_prob_desc.as<ProbDesc>(), c->prob_cap, c->work_cap, c->d_cand_y.as<int>(),
@@ -4029,8 +3985,9 @@ int run_sized(fseg_ctx *c) {
         c->h_status->err &= ~kErrOverflowLabels;       // the plan was made against the old capacity; the arena has been grown since
         c->pending = true;
         c->last_sized = true;
-        if (c->trace) fprintf(stderr, "[fseg] run (sized): A %.3f ms, B %.3f ms, C enqueued %.3f ms; %llu problems, %llu work items, %llu label bytes\n",
-                              t_a, t_b, tk.ms(), (unsigned long long)s.n_prob, (unsigned long long)s.n_work, (unsigned long long)s.label_bytes);
+        if (c->trace) fprintf(stderr, "[fseg] run (sized): A %.3f ms, B %.3f ms, C enqueued %.3f ms; %llu problems (fused %llu / %llu / %llu, widest sees %u reads), %llu work items, %llu label bytes\n",
+                              t_a, t_b, tk.ms(), (unsigned long long)s.n_prob, (unsigned long long)s.solve_cls[0], (unsigned long long)s.solve_cls[1],
+                              (unsigned long long)s.solve_cls[2], s.max_ln, (unsigned long long)s.n_work, (unsigned long long)s.label_bytes);
         return FSEG_OK;
     }
     return fail(c, FSEG_ERR_HIP, "the compaction scans stalled repeatedly");

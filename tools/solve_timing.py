@@ -23,9 +23,9 @@ ctx = _lib.Context(0); ctx.set_params(**params, **tabs); ctx.set_profiling(True)
 L = _lib.load()
 L.fseg_debug_score_timing.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 L.fseg_debug_timed_class.argtypes = [ctypes.c_void_p, ctypes.c_int]
-names = {0: "wait/next", 1: "setup+thresholds", 2: "coverage", 3: "pairs", 4: "triples", 9: "in_s", 10: "dp blocks", 11: "dp top level", 12: "dp backtrack"}
+names = {0: "wait/next", 1: "setup+thresholds", 2: "coverage", 3: "pairs", 4: "triples", 5: "dp block: slices", 8: "k_dp: wait/next", 9: "in_s", 10: "dp block: fix-up", 11: "dp top level", 12: "dp backtrack"}
 buf = np.zeros(16, np.uint64)
-for cls in (2, 1, 0):
+for cls in ((2,) if wl == "config2" else (2, 1, 0)):
     L.fseg_debug_timed_class(ctx._h, cls)
     ctx.upload(**b.arrays); ctx.run(); ctx.sync()
     L.fseg_debug_score_timing(ctx._h, buf.ctypes.data)
