@@ -2033,7 +2033,10 @@ constexpr int kTiny = 8;
 constexpr int kTinyPairs = kTiny * (kTiny - 1) / 2, kTinyTri = kTiny * (kTiny - 1) * (kTiny - 2) / 6;
 // (6 workgroups = 24 waves per CU asked of the register allocator: the kernel is a chain of dependent loads, and at the
 // 120 registers it would otherwise take only 16 waves fit; measured 56 -> 47 us on config4, 8 spills and is slower)
-__global__ void __launch_bounds__(256, 6) k_tiny(Status *st, const ProbDesc *desc, i64 prob_cap, int tiny_max, ProblemArrays pr,
+#ifndef FSEG_TINY_OCC
+#define FSEG_TINY_OCC 5
+#endif
+__global__ void __launch_bounds__(256, FSEG_TINY_OCC) k_tiny(Status *st, const ProbDesc *desc, i64 prob_cap, int tiny_max, ProblemArrays pr,
                                               const int *cand_y, const longlong2 *lane_ex, const int *ex_ts,
                                               const int *ex_te, const double *h_table, int h_len, double tau, const int2 *thr_tab,
                                               int support, unsigned char *chosen) {
@@ -3942,6 +3945,8 @@ int run_sized(fseg_ctx *c) {
             const bool tiny = (i64)s.n_prob > c->tiny_from && c->use_tiny;
             const bool fuse = (i64)s.max_ln <= kFuseLanes;
             if (tiny != c->tiny_on || fuse != c->fuse_on) {
+                if (c->trace) fprintf(stderr, "[fseg] problem split changed (tiny %d -> %d, fused %d -> %d; %llu problems, widest sees %u reads): rescan\n",
+                                      (int)c->tiny_on, (int)tiny, (int)c->fuse_on, (int)fuse, (unsigned long long)s.n_prob, s.max_ln);
                 c->tiny_on = tiny; c->fuse_on = fuse;
                 const int pg = grid_for(c->NPOS / 8 / kProbBlock + 1, 1, 1024);
                 Status *st = c->d_status.as<Status>();

@@ -34,6 +34,36 @@ __global__ void __launch_bounds__(T) k_dp_probe(int n, const OutT *out_g, const 
     if (threadIdx.x == 0) { ticks[blockIdx.x] = t1 - t0; chain_g[blockIdx.x] = chain; }
 }
 
+// calibration: what one "write LDS -> barrier -> read LDS -> a little arithmetic" step costs for a workgroup of T threads
+template <int T, int MODE>
+__global__ void __launch_bounds__(T) k_pingpong(int steps, int *out, long long *ticks) {
+    __shared__ int buf[2048];
+    int x = threadIdx.x;
+    buf[threadIdx.x] = x; buf[threadIdx.x + T] = x;
+    __syncthreads();
+    long long t0 = wall_clock64();
+    for (int i = 0; i < steps; ++i) {
+        if (MODE == 0) { __syncthreads(); x += i; }                                                   // barrier only
+        else if (MODE == 1) { buf[threadIdx.x] = x; __syncthreads(); x = buf[(threadIdx.x + 65) % T] + i; }      // write, barrier, read
+        else if (MODE == 2) { x = buf[(x + 65) & (T - 1)] + i; }                                         // dependent LDS reads, no barrier
+        else { buf[threadIdx.x] = x; __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); x = buf[(threadIdx.x + 1) % 64 + (threadIdx.x & ~63)] + i; }
+    }
+    long long t1 = wall_clock64();
+    out[blockIdx.x * T + threadIdx.x] = x;
+    if (threadIdx.x == 0) ticks[blockIdx.x] = t1 - t0;
+}
+#define CK_(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+template <int T, int MODE> static void pingpong(const char *name) {
+    int *o; long long *t; CK_(hipMalloc(&o, 4096 * T * 4)); CK_(hipMalloc(&t, 4096 * 8));
+    for (int grid : {1, 512, 4096}) {
+        const int steps = 2000;
+        for (int w = 0; w < 2; ++w) { hipLaunchKernelGGL((k_pingpong<T, MODE>), dim3(grid), dim3(T), 0, 0, steps, o, t); CK_(hipDeviceSynchronize()); }
+        std::vector<long long> h(grid); CK_(hipMemcpy(h.data(), t, grid * 8, hipMemcpyDeviceToHost));
+        double avg = 0; for (auto v : h) avg += v; avg /= grid;
+        printf("%-40s T=%4d grid=%4d: %.1f ns per step\n", name, T, grid, avg * 10.0 / steps);
+    }
+    (void)hipFree(o); (void)hipFree(t);
+}
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
 struct HostDp { std::vector<unsigned char> chosen; int chain; };
@@ -114,6 +144,9 @@ static void run(const char *name, int n, const std::vector<int> &out, const std:
 }
 
 int main() {
+    pingpong<512, 0>("barrier only"); pingpong<512, 1>("LDS write, barrier, LDS read"); pingpong<512, 2>("dependent LDS reads");
+    pingpong<128, 0>("barrier only"); pingpong<128, 1>("LDS write, barrier, LDS read"); pingpong<64, 3>("LDS write, wave fence, LDS read");
+    pingpong<1024, 1>("LDS write, barrier, LDS read");
     for (int n : {49, 38, 30, 22, 14, 10, 8, 5, 3}) {
         std::mt19937 rng(7 + n);
         const int npairs = n * (n - 1) / 2, ntri = n * (n - 1) * (n - 2) / 6;
