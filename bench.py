@@ -20,10 +20,12 @@ Prints ONE JSON line (rank 0) with, besides the driver's fields:
   value_resident_replay the old headline: hipGraph replay of one resident batch (no copies, no sizing)
   value_hbm_resident    every batch uploaded first, then each run once (first-run path, no copies in the timed part)
   cpu_baseline / cpu_baseline_all_cores   the C oracle on this box's host cores (1 thread / every core)
-  e2e                   the drop-in CLI on a split directory in tmpfs: files in -> files out (N=1 only)
+  e2e                   the drop-in CLI on a split directory of the 2 M-read job in tmpfs: files in -> files out; at --gpus N
+                        the same job through the CLI's N worker processes (strong scaling), run by rank 0 before any rank
+                        touches a GPU
   valu_util             VALU utilisation of the scoring kernels from the committed SQ counter pass (profiles/)
 At N GPUs every rank owns its own partitions (static scatter, no collectives: partitions share nothing) and runs the same
-number of steps, so scaling is weak.
+number of steps, so the headline's scaling is weak; the e2e leg's is strong.
 """
 import argparse
 import json
@@ -163,11 +165,12 @@ def _gen_split(job):
     return idx
 
 
-def e2e_leg(workload, params, n_reads_target, threads):
-    """Files in -> files out through the drop-in CLI (py/freddie_segment.py, one GPU): a split directory of the
-    workload's partitions (with sequences) in tmpfs, the CLI as a child process (it creates its own GPU contexts; this
-    process has not touched the GPU yet), wall time of the whole process including interpreter and context start-up.
-    Two runs: the first pages the libraries in, the second is reported."""
+def e2e_leg(workload, params, n_reads_target, threads, gpus=1):
+    """Files in -> files out through the drop-in CLI (py/freddie_segment.py): a split directory of the workload's
+    partitions (with sequences) in tmpfs, the CLI as a child process (it creates its own GPU contexts -- one worker process
+    per GPU when gpus > 1; this process has not touched the GPU yet), wall time of the whole process including interpreter
+    and context start-up.  The job is the same at every GPU count (strong scaling).  Two runs: the first pages the
+    libraries in, the second is reported."""
     import multiprocessing as mp
     w = dict(synth.WORKLOADS[workload])
     w.pop("n_partitions")
@@ -185,7 +188,7 @@ def e2e_leg(workload, params, n_reads_target, threads):
         t_gen = time.perf_counter() - t0
         size = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(split) for f in fs)
         cmd = [sys.executable, os.path.join(ROOT, "py", "freddie_segment.py"), "-s", split, "-o", out, "-t", str(threads),
-               "--gpus", "1", "--sidecar", "off", "-sd", str(params["sigma"]), "-tp", str(params["threshold_rate"])]
+               "--gpus", str(gpus), "--sidecar", "off", "-sd", str(params["sigma"]), "-tp", str(params["threshold_rate"])]
         walls = []
         for _ in range(2):
             shutil.rmtree(out, ignore_errors=True)
@@ -195,9 +198,10 @@ def e2e_leg(workload, params, n_reads_target, threads):
         n_out = sum(len(fs) for _, _, fs in os.walk(out))
         reads = n_part * w["n_reads"]
         return dict(value=reads / walls[-1], unit="reads/s", reads=reads, partitions=n_part, wall_s=walls, threads=threads,
-                    input_mb=size / 1e6, output_files=n_out, tmp=base or tempfile.gettempdir(), generate_s=t_gen,
-                    what="py/freddie_segment.py -s <split> -o <out> -t %d --gpus 1 --sidecar off: whole process wall time, "
-                         "second of two runs" % threads)
+                    n_gpus=gpus, scaling="strong", input_mb=size / 1e6, output_files=n_out, tmp=base or tempfile.gettempdir(),
+                    generate_s=t_gen,
+                    what="py/freddie_segment.py -s <split> -o <out> -t %d --gpus %d --sidecar off (-t is per GPU worker): whole "
+                         "process wall time, second of two runs" % (threads, gpus))
     finally:
         shutil.rmtree(work, ignore_errors=True)
 
@@ -317,7 +321,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip both CPU-oracle legs")
     ap.add_argument("--no-e2e", action="store_true", help="skip the CLI end-to-end leg")
     ap.add_argument("--no-extras", action="store_true", help="skip config2's roofline, the replay and the HBM-resident legs")
-    ap.add_argument("--e2e-reads", type=int, default=1000000)
+    ap.add_argument("--e2e-reads", type=int, default=2000000, help="reads of the end-to-end job (default: the whole 2 M-read job)")
     ap.add_argument("--contexts", type=int, default=3, help="contexts per GPU the steps alternate between")
     args = ap.parse_args()
     if args.workload in NEXT_ROW_WORKLOADS:
@@ -340,8 +344,24 @@ def main():
     cpu_one = cpu_all = e2e = None
     if rank == 0 and not args.no_cpu_baseline:
         cpu_all = cpu_baseline_all_cores(batches, params, tabs)
-    if rank == 0 and world == 1 and not args.no_e2e and args.workload != "config2":
-        e2e = e2e_leg(args.workload, params, args.e2e_reads, threads=min(16, host_cores()))
+    # The end-to-end leg is a strong-scaling run at every --gpus N: the same split directory through the CLI, which scatters
+    # it over N worker processes (one per GPU).  Rank 0 runs it while no rank has touched a GPU yet; the others wait for it.
+    if not args.no_e2e and args.workload != "config2":
+        done = os.path.join(tempfile.gettempdir(), "freddie_bench_e2e_%s_%d.done" % (os.environ.get("MASTER_PORT", "0"), os.getppid()))     # (the launcher is every rank's parent)
+        if rank == 0:
+            try:
+                if os.path.exists(done):
+                    os.remove(done)
+                e2e = e2e_leg(args.workload, params, args.e2e_reads, threads=max(1, min(16, host_cores() // world)), gpus=world)
+            except Exception as exc:                     # the headline must not depend on this leg (e.g. no room in tmpfs)
+                e2e = dict(error="%s: %s" % (type(exc).__name__, exc))
+            finally:
+                if world > 1:
+                    open(done, "w").close()
+        else:
+            t_wait = time.time()
+            while not os.path.exists(done) and time.time() - t_wait < 900:
+                time.sleep(0.05)
     config2_batch = None
     if rank == 0 and not args.no_extras and args.workload != "config2":
         w2 = dict(synth.WORKLOADS["config2"]); w2.pop("n_partitions")

@@ -62,6 +62,11 @@ enum : unsigned {
     kErrNeedWideDp = 2048u,    // a problem sees >= 65536 reads: its DP needs the 32-bit count table    // a problem is larger than the LDS carve-up this launch was sized for
 };
 
+#ifdef FSEG_SCORE_TIMING
+constexpr size_t kTaccProbs = 1u << 17, kTaccBytes = 128 + kTaccProbs * 32;
+#else
+constexpr size_t kTaccBytes = 128;
+#endif
 struct Status {
     unsigned err;
     unsigned pad;
@@ -926,6 +931,12 @@ __device__ __forceinline__ ProbDesc load_desc_uniform(const ProbDesc *d) {      
     return u.p;
 }
 
+#ifdef FSEG_DESC_VECTOR
+#define FSEG_LOAD_DESC load_desc
+#else
+#define FSEG_LOAD_DESC load_desc_uniform
+#endif
+
 __device__ __forceinline__ i64 wave_excl_scan(i64 v, i64 *total) {
     int lane = lane_id();
     i64 x = v;
@@ -1641,6 +1652,9 @@ inline size_t score_lds_for(int nm, int cov_stride) {
 
 #ifdef FSEG_SCORE_TIMING
 #define FSEG_TPARAM , unsigned long long *tacc
+// diagnostic build: per-problem records behind the 16 phase slots -- (ticks, reads examined, reads with coverage, start tick)
+#define FSEG_PROB_TICK(P, T0, LN, NA) do { if ((P) < kTaccProbs) { unsigned long long *r_ = tacc + 16 + 4 * (size_t)(P); \
+        r_[0] = wall_clock64() - (T0); r_[1] = (unsigned long long)(LN); r_[2] = (unsigned long long)(NA); r_[3] = (T0); } } while (0)
 #define FSEG_T0 unsigned long long t_prev = wall_clock64()
 #define FSEG_TICK(i) do { unsigned long long t_now = wall_clock64(); if (threadIdx.x == 0) atomicAdd(&tacc[i], t_now - t_prev); t_prev = t_now; } while (0)
 #else
@@ -2039,7 +2053,7 @@ constexpr int kTinyPairs = kTiny * (kTiny - 1) / 2, kTinyTri = kTiny * (kTiny - 
 __global__ void __launch_bounds__(256, FSEG_TINY_OCC) k_tiny(Status *st, const ProbDesc *desc, i64 prob_cap, int tiny_max, ProblemArrays pr,
                                               const int *cand_y, const longlong2 *lane_ex, const int *ex_ts,
                                               const int *ex_te, const double *h_table, int h_len, double tau, const int2 *thr_tab,
-                                              int support, unsigned char *chosen) {
+                                              int support, unsigned char *chosen FSEG_TPARAM) {
     __shared__ u64 planes[4][kTinyPairs][2];            // [wave][pair]{yea, nay} of the current 64 reads
     __shared__ i64 M_s[4][kTinyPairs];
     __shared__ int in_s[4][kTinyPairs];
@@ -2048,7 +2062,7 @@ __global__ void __launch_bounds__(256, FSEG_TINY_OCC) k_tiny(Status *st, const P
     __shared__ int cy_s[4][kTiny];
     __shared__ unsigned char tri_ijk[kTinyTri][4];
     __shared__ int2 act_w[4][128];                      // [wave] reads with coverage in the window, waiting for a round: (first exon, count)
-    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int lane = lane_id(), wave = wave_id();
     const u64 lt_mask = (1ULL << lane) - 1ULL;
     if (threadIdx.x < kTinyTri) {                       // rank t = k(k-1)(k-2)/6 + j(j-1)/2 + i  ->  (i, j, k)
         int t = threadIdx.x, k = 2;
@@ -2065,7 +2079,10 @@ __global__ void __launch_bounds__(256, FSEG_TINY_OCC) k_tiny(Status *st, const P
     unsigned long long *dp_tacc = tick_sink; unsigned long long dt_prev = 0;
 #endif
     for (i64 p = (i64)blockIdx.x * 4 + wave; p < n_prob; p += (i64)gridDim.x * 4) {
-        const ProbDesc d = load_desc(desc + p);
+#ifdef FSEG_SCORE_TIMING
+        const unsigned long long t_prob0 = wall_clock64();
+#endif
+        const ProbDesc d = FSEG_LOAD_DESC(desc + p);
         const int n = d.n;
         if (n > tiny_max) continue;                     // wave-uniform
         const int npairs = n * (n - 1) / 2, ntri = n * (n - 1) * (n - 2) / 6;
@@ -2174,6 +2191,9 @@ __global__ void __launch_bounds__(256, FSEG_TINY_OCC) k_tiny(Status *st, const P
         dp_sync<64>();
         const int chain = dp_solve_push<64, kTiny>(n, out_s[wave], in_s[wave], M_s[wave], A_s[wave], cy_s[wave], support, chosen + d.c0 FSEG_DARG);
         if (lane == 0) pr.chain[p] = chain;
+#ifdef FSEG_SCORE_TIMING
+        if (lane == 0) FSEG_PROB_TICK(p, t_prob0, d.lane_n, n_act);
+#endif
     }
 }
 
@@ -2237,7 +2257,7 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
     // cls < 0: every solve list (batches of few problems: one launch instead of three)
     const i64 list_base = cls <= 0 ? 0 : (cls == 1 ? (i64)st->solve_cls[0] : (i64)st->solve_cls[0] + (i64)st->solve_cls[1]);
     const i64 list_n = cls < 0 ? (i64)st->solve_cls[0] + (i64)st->solve_cls[1] + (i64)st->solve_cls[2] : (i64)st->solve_cls[cls];
-    const int r_lane = threadIdx.x & 63, w_rng = threadIdx.x >> 6;
+    const int r_lane = threadIdx.x & 63, w_rng = wave_id();
 #ifdef FSEG_SCORE_TIMING
     // diagnostic build: phase clocks of the class given by tacc[15] (slots 0..5 scoring phases, 8..12 the DP's)
     __shared__ unsigned long long tick_sink[16];
@@ -2249,8 +2269,11 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
 #define FSEG_STICK(i)
 #endif
     for (i64 t = blockIdx.x; t < list_n; t += gridDim.x) {           // static stride; the lists are in candidate order
-        const int p = solve_items[list_base + t];
-        const ProbDesc d = load_desc(desc + p);
+#ifdef FSEG_SCORE_TIMING
+        const unsigned long long t_prob0 = wall_clock64();
+#endif
+        const int p = uni(solve_items[list_base + t]);
+        const ProbDesc d = FSEG_LOAD_DESC(desc + p);
         const int n = d.n;
         __syncthreads();                                             // the previous problem's DP is done with LDS
         FSEG_STICK(0);
@@ -2435,6 +2458,9 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
         FSEG_STICK(9);
         const int chain = dp_solve_push<T, NM>(n, cnt, in_s, M, A, cy_s, support, chosen + d.c0 FSEG_DARG);
         if (threadIdx.x == 0) pr.chain[p] = chain;
+#ifdef FSEG_SCORE_TIMING
+        if (threadIdx.x == 0) FSEG_PROB_TICK(p, t_prob0, d.lane_n, n_act);
+#endif
     }
 #undef FSEG_STICK
 }
@@ -3646,6 +3672,15 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
 #else
 #define FSEG_TARG
 #endif
+#ifndef FSEG_WG_SMALL
+#define FSEG_WG_SMALL 4096
+#endif
+#ifndef FSEG_WG_MID
+#define FSEG_WG_MID 2048
+#endif
+#ifndef FSEG_WG_TINY
+#define FSEG_WG_TINY 4096
+#endif
 #define FSEG_LAUNCH_SCORE(Q, NMV, CLS, MAXWG)                                                                           \
         hipLaunchKernelGGL(k_score<NMV>, dim3(work_grid < (MAXWG) ? work_grid : (MAXWG)), dim3(ScoreCfg<NMV>::kThreads),  \
                            score_lds_for((NMV) == kNMax ? c->nm_big : (NMV), (NMV) + 1), Q, st, CLS,                                 \
@@ -3678,9 +3713,9 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
             if (any_arena && (!known || c->n_cls_work[2] > 0)) FSEG_LAUNCH_SCORE(s, kNMax, 2, 512);     // big problems: they are the long poles
             if (any_solve && (!known || c->n_solve[2] > 0)) FSEG_LAUNCH_SOLVE_W(s, kNMax, 2, known ? c->n_solve[2] : cap, 512);
             if (any_arena && (!known || c->n_cls_work[1] > 0)) FSEG_LAUNCH_SCORE(q1, kClsMid, 1, 1280);
-            if (any_solve && (!known || c->n_solve[1] > 0)) FSEG_LAUNCH_SOLVE_W(q1, kClsMid, 1, known ? c->n_solve[1] : cap, 2048);
+            if (any_solve && (!known || c->n_solve[1] > 0)) FSEG_LAUNCH_SOLVE_W(q1, kClsMid, 1, known ? c->n_solve[1] : cap, FSEG_WG_MID);
             if (any_arena && (!known || c->n_cls_work[0] > 0)) FSEG_LAUNCH_SCORE(q0, kClsSmall, 0, 2048);
-            if (any_solve && (!known || c->n_solve[0] > 0)) FSEG_LAUNCH_SOLVE_W(q0, kClsSmall, 0, known ? c->n_solve[0] : cap, 4096);
+            if (any_solve && (!known || c->n_solve[0] > 0)) FSEG_LAUNCH_SOLVE_W(q0, kClsSmall, 0, known ? c->n_solve[0] : cap, FSEG_WG_SMALL);
         }
 #undef FSEG_LAUNCH_SOLVE_W
 #undef FSEG_LAUNCH_SOLVE
@@ -3690,10 +3725,10 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
             // last -- the big problems' workgroups need half a CU's LDS each and must be resident before the small
             // workgroups fill the CUs, or they start late and end the stage alone; joined at the end of this stage, so the
             // stage's time bracket covers all scoring work
-            hipLaunchKernelGGL(k_tiny, dim3(grid_for(c->prob_cap, 4, 4096)), dim3(256), 0, qt, st, c->d_prob_desc.as<ProbDesc>(),
+            hipLaunchKernelGGL(k_tiny, dim3(grid_for(c->prob_cap, 4, FSEG_WG_TINY)), dim3(256), 0, qt, st, c->d_prob_desc.as<ProbDesc>(),
                                c->prob_cap, tiny_max, pr, c->d_cand_y.as<int>(), c->d_lane_ex.as<longlong2>(),
                                c->d_ex_ts.as<int>(), c->d_ex_te.as<int>(), c->d_h_table.as<double>(), c->P.h_len, c->P.threshold_rate,
-                               c->d_thr_tab.as<int2>(), c->P.min_read_support_outside, c->d_chosen.as<unsigned char>());
+                               c->d_thr_tab.as<int2>(), c->P.min_read_support_outside, c->d_chosen.as<unsigned char>() FSEG_TARG);
         }
         if (!c->small_batch) { join(0); join(1); }
         if (c->have_huge && any_arena)
@@ -4034,8 +4069,8 @@ int fseg_create(int device, fseg_ctx **out) {
     if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_prep, sizeof(PrepStatus), hipHostMallocDefault);
     if (e == hipSuccess) e = hipMalloc(&c->d_status.p, sizeof(Status));
     if (e == hipSuccess) e = hipMalloc(&c->d_prep.p, sizeof(PrepStatus));
-    if (e == hipSuccess) e = hipMalloc(&c->d_tacc.p, 128);
-    if (e == hipSuccess) e = hipMemsetAsync(c->d_tacc.p, 0, 128, c->stream);
+    if (e == hipSuccess) e = hipMalloc(&c->d_tacc.p, kTaccBytes);
+    if (e == hipSuccess) e = hipMemsetAsync(c->d_tacc.p, 0, kTaccBytes, c->stream);
     for (int i = 0; e == hipSuccess && i < ST_COUNT; ++i) { e = hipEventCreate(&c->ev_b[i]); if (e == hipSuccess) e = hipEventCreate(&c->ev_e[i]); }
     for (int i = 0; e == hipSuccess && i < 4; ++i) e = hipEventCreate(&c->ev_g[i]);
     for (int i = 0; e == hipSuccess && i < fseg_ctx::kSide; ++i) e = hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking);
@@ -4073,7 +4108,7 @@ int fseg_create(int device, fseg_ctx **out) {
         delete c;
         return FSEG_ERR_HIP;
     }
-    c->d_status.cap = sizeof(Status); c->d_prep.cap = sizeof(PrepStatus); c->d_tacc.cap = 128;
+    c->d_status.cap = sizeof(Status); c->d_prep.cap = sizeof(PrepStatus); c->d_tacc.cap = kTaccBytes;
     auto flag = [](const char *name) { const char *v = getenv(name); return v && v[0] == '1'; };
     if (flag("FSEG_NO_GRAPH")) c->use_graph = false;
     if (flag("FSEG_NO_FORK")) c->use_fork = false;
@@ -4604,6 +4639,11 @@ int fseg_debug_score_timing(fseg_ctx *c, unsigned long long *out8) {
     if (!c || !out8 || !c->d_tacc.p) return FSEG_ERR_ARG;
     if (hipMemcpy(out8, c->d_tacc.p, 128, hipMemcpyDeviceToHost) != hipSuccess) return FSEG_ERR_HIP;   /* 16 slots */
     (void)hipMemset(c->d_tacc.p, 0, 120);               /* slot 15 = the k_solve class being timed: kept */
+    return FSEG_OK;
+}
+int fseg_debug_prob_ticks(fseg_ctx *c, unsigned long long *out4, long long n_prob) {     /* 4 values per problem */
+    if (!c || !out4 || n_prob < 0 || (size_t)n_prob > kTaccProbs) return FSEG_ERR_ARG;
+    if (hipMemcpy(out4, static_cast<char *>(c->d_tacc.p) + 128, (size_t)n_prob * 32, hipMemcpyDeviceToHost) != hipSuccess) return FSEG_ERR_HIP;
     return FSEG_OK;
 }
 int fseg_debug_timed_class(fseg_ctx *c, int cls) {
