@@ -14,7 +14,14 @@ _lib = None
 
 
 class SegError(RuntimeError):
-    pass
+    """code: the library's FSEG_ERR_* value (include/freddie_seg.h), None when raised by the binding itself."""
+
+    def __init__(self, msg, code=None):
+        super().__init__(msg)
+        self.code = code
+
+
+ERR_ARG, ERR_HIP, ERR_INPUT, ERR_UNSUPPORTED = 1, 2, 3, 4
 
 
 class _Params(ctypes.Structure):
@@ -141,7 +148,7 @@ class Context:
 
     def _check(self, rc, what):
         if rc != 0:
-            raise SegError("%s failed (%d): %s" % (what, rc, self._L.fseg_last_error(self._h).decode()))
+            raise SegError("%s failed (%d): %s" % (what, rc, self._L.fseg_last_error(self._h).decode()), rc)
 
     def set_params(self, sigma, threshold_rate, variance_factor, max_problem_size, min_read_support_outside,
                    ignore_ends, w_main, w_refine, h_table):

@@ -4226,7 +4226,7 @@ int fseg_upload(fseg_ctx *c, const fseg_batch *b) {
         lanes += w;
         if (b->rep_exon_off[r + 1] < b->rep_exon_off[r]) return fail(c, FSEG_ERR_ARG, "rep_exon_off not monotone");
     }
-    if (lanes >= 0x7fffffffLL) return fail(c, FSEG_ERR_UNSUPPORTED, "too many reads in one upload");
+    if (lanes >= 0x7fffffffLL) return fail(c, FSEG_ERR_UNSUPPORTED, "batch has %lld reads; split it (limit 2^31-1 per upload)", (long long)lanes);
     // histogram chunks: consecutive positions of one partition; as large as possible (fewer reads are visited twice)
     // while still giving >= 512 workgroups
     int hist_chunk = kHistChunk;

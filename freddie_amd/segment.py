@@ -453,6 +453,13 @@ def run_segment_batch_python(jobs, params, ctx):
     return [(j[2], j[3]) for j in jobs]
 
 
+def batch_too_large(exc):
+    """True for the errors of Context.upload / run that a smaller batch cures (not for an input the reference rejects too)."""
+    code = getattr(exc, "code", None)
+    msg = str(exc).lower()
+    return (code == 4 and "split it" in msg) or (code == 2 and "memory" in msg)
+
+
 def run_batches(batches, params, ctxs, threads, on_done, sidecar="off"):
     """Pipelined driver of one GPU.  ``ctxs``: one or two contexts on the same device (a single Context is accepted).
     Batch i+1 (and i+2) are being parsed by the native loader while batch i is on the device and batch i-1 is annotated
@@ -520,8 +527,16 @@ def run_batches(batches, params, ctxs, threads, on_done, sidecar="off"):
                     last_write[k].result()   # its results live in this context's pinned buffers until it has finished
                 t2 = time.perf_counter()
                 res = ctx.results(packed=True)    # two bits per label across PCIe; the writer unpacks rows into the TSV
-            except BaseException:
+            except BaseException as exc:
                 hb.close()
+                if len(jobs) > 1 and batch_too_large(exc):
+                    # Batches are cut by split-file bytes; many low-coverage partitions (few bytes, thousands of positions
+                    # each) can exceed what one upload takes (2^31 positions / lanes, or device memory).  The reference works
+                    # partition by partition, so nothing but the batching is at fault: halve and go on.
+                    for half in (jobs[:len(jobs) // 2], jobs[len(jobs) // 2:]):
+                        hb2, t_load2 = load(half)
+                        device(k, i, half, hb2, t_load2)
+                    return
                 raise
             t_dev = (t1 - t0) + (time.perf_counter() - t2)       # without the wait for the writer
             last_write[k] = write_pool.submit(write, hb, res, jobs, t_load, t_dev, i)

@@ -6,9 +6,10 @@ partitions over a process pool)."""
 import os
 
 import numpy as np
+import pytest
 
 import util
-from freddie_amd import devices, pack, segment, synth
+from freddie_amd import _lib, devices, pack, segment, synth
 
 
 class OracleContext:
@@ -80,6 +81,40 @@ def test_main_two_workers_equals_one_worker(tmp_path, monkeypatch, capsys):
     tsvs = [k for k in outs[0] if k.endswith(".tsv")]
     assert len(tsvs) == n and len([k for k in outs[0] if k.endswith(".log")]) == n
     assert all(len(v) > 0 for k, v in outs[0].items() if k.endswith(".tsv"))
+
+
+class SmallContext(OracleContext):
+    """A context that takes at most three partitions per upload, like a device whose limits (2^31 positions per upload,
+    memory) a batch of many low-coverage partitions exceeds."""
+    refused = 0
+
+    def upload(self, **a):
+        if len(a["part_iv_off"]) - 1 > 3:
+            SmallContext.refused += 1
+            raise _lib.SegError("fseg_upload failed (4): batch has 9999999999 positions; split it (limit 2^31-1 per upload)", 4)
+        super().upload(**a)
+
+
+def test_a_batch_the_device_refuses_is_halved_and_retried(tmp_path, monkeypatch):
+    """Batches are cut by split-file bytes; the driver must not die when one of them is more than an upload takes (the
+    reference works partition by partition): same output files as with batches that fit."""
+    split = str(tmp_path / "split")
+    for i in range(11):
+        synth.generate(700 + i, n_reads=30 + 10 * (i % 4), n_exons=20, rp=0.1, write_dir=split, contig="chr%d" % (i % 2))
+    outs = []
+    for cls, batch_reads in ((OracleContext, "60"), (SmallContext, "100000")):
+        monkeypatch.setattr(segment, "open_contexts", lambda device, n=2, cls=cls: [cls(device) for _ in range(n)])
+        out = str(tmp_path / ("out_" + cls.__name__))
+        segment.main(["-s", split, "-o", out, "-t", "2", "--devices", "0", "--batch-reads", batch_reads, "--sidecar", "off"])
+        outs.append(read_tree(out))
+    assert SmallContext.refused >= 2                      # 11 partitions in one batch: halved more than once
+    assert outs[0] == outs[1] and len([k for k in outs[0] if k.endswith(".tsv")]) == 11
+    with pytest.raises(_lib.SegError):                    # an error splitting cannot cure is still an error
+        class Broken(OracleContext):
+            def run(self):
+                raise _lib.SegError("fseg_run failed (4): a problem has 200 candidates", 4)
+        monkeypatch.setattr(segment, "open_contexts", lambda device, n=2: [Broken(device) for _ in range(n)])
+        segment.main(["-s", split, "-o", str(tmp_path / "out_broken"), "-t", "2", "--devices", "0", "--sidecar", "off"])
 
 
 def test_device_count_without_the_runtime(tmp_path):
