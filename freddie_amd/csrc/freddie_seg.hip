@@ -3202,6 +3202,88 @@ __global__ void __launch_bounds__(256) k_lanes(int n_part, const i64 *part_rep_o
     }
 }
 
+// The same for a batch that went through the batch-wide sort (it holds a partition of more than kLaneSortMax reps, e.g. one
+// 50 000-read partition): a workgroup per partition would walk such a partition 256 reps at a time, alone (330 us for 50 k
+// reps).  Instead every block of 256 sorted reps is a workgroup of its own, in three launches: block totals (weights, last
+// positions), an exclusive scan of the totals inside each partition (one wave per partition), and the lanes themselves.
+__global__ void __launch_bounds__(256) k_lane_blocks(int n_blocks, const int *rb_part, const int *rb_r0, const i64 *part_rep_off,
+                                                     const int *val_sorted, const int *rep_weight, const int *rep_last,
+                                                     i64 *rb_sum, int *rb_max) {
+    __shared__ int lds[16];
+    __shared__ int wmax[4];
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    for (int blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+        const i64 i = (i64)rb_r0[blk] + threadIdx.x;
+        const bool in = i < part_rep_off[rb_part[blk] + 1];
+        const int r = in ? val_sorted[i] : 0;
+        const int w = in ? rep_weight[r] : 0;
+        int m = in ? rep_last[r] : -0x7fffffff - 1;
+        for (int d = 32; d >= 1; d >>= 1) m = max(m, __shfl_xor(m, d));
+        __syncthreads();
+        int tot;
+        (void)wg_exclusive_scan(w, lds, &tot);
+        if (lane == 0) wmax[wave] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) { rb_sum[blk] = tot; rb_max[blk] = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3])); }
+    }
+}
+__global__ void __launch_bounds__(256) k_lane_block_scan(int n_part, int n_blocks, const int *rb_part, const i64 *part_lane_off,
+                                                         const i64 *rb_sum, const int *rb_max, i64 *rb_base, int *rb_cmax) {
+    const int lane = lane_id();
+    for (int p = blockIdx.x * 4 + (int)(threadIdx.x >> 6); p < n_part; p += gridDim.x * 4) {
+        // the partition's blocks are consecutive in the block list: [first block of p, first block of p + 1)
+        int b0 = 0, b1 = n_blocks;
+        { int lo = 0, hi = n_blocks; while (lo < hi) { const int mid = (lo + hi) >> 1; if (rb_part[mid] < p) lo = mid + 1; else hi = mid; } b0 = lo; }
+        { int lo = b0, hi = n_blocks; while (lo < hi) { const int mid = (lo + hi) >> 1; if (rb_part[mid] <= p) lo = mid + 1; else hi = mid; } b1 = lo; }
+        i64 carry = part_lane_off[p];
+        int carry_max = -0x7fffffff - 1;
+        for (int c0 = b0; c0 < b1; c0 += 64) {
+            const int b = c0 + lane;
+            const bool in = b < b1;
+            const i64 v = in ? rb_sum[b] : 0;
+            int m = in ? rb_max[b] : -0x7fffffff - 1;
+            i64 tot;
+            const i64 ex = wave_excl_scan(v, &tot);
+            for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(m, d); if (lane >= d) m = max(m, y); }      // inclusive running maximum
+            int before = __shfl_up(m, 1);
+            if (lane == 0) before = -0x7fffffff - 1;
+            if (in) { rb_base[b] = carry + ex; rb_cmax[b] = max(carry_max, before); }
+            carry += tot;
+            carry_max = max(carry_max, __shfl(m, 63));
+        }
+    }
+}
+__global__ void __launch_bounds__(256) k_lane_emit(int n_blocks, const int *rb_part, const int *rb_r0, const i64 *part_rep_off,
+                                                   const u64 *key_sorted, const int *val_sorted, const int *rep_weight, const int *rep_last,
+                                                   const i64 *rep_exon_off, const i64 *rb_base, const int *rb_cmax,
+                                                   longlong2 *lane_ex, int *lane_start, int *lane_pmax) {
+    __shared__ int lds[16];
+    __shared__ int wmax[4];
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    for (int blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+        const i64 i = (i64)rb_r0[blk] + threadIdx.x;
+        const bool in = i < part_rep_off[rb_part[blk] + 1];
+        const int r = in ? val_sorted[i] : 0;
+        const int first = in ? (int)((unsigned)(key_sorted[i] & 0xffffffffULL) ^ 0x80000000u) : 0;
+        const int w = in ? rep_weight[r] : 0;
+        int m = in ? rep_last[r] : -0x7fffffff - 1;
+        for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(m, d); if (lane >= d) m = max(m, y); }
+        __syncthreads();
+        int tot;
+        const int ex = wg_exclusive_scan(w, lds, &tot);
+        if (lane == 63) wmax[wave] = m;
+        __syncthreads();
+        int run = rb_cmax[blk];
+        for (int w2 = 0; w2 < wave; ++w2) run = max(run, wmax[w2]);
+        m = max(m, run);
+        if (in) {
+            const i64 base = rb_base[blk] + ex;
+            const longlong2 exr = make_longlong2(rep_exon_off[r], rep_exon_off[r + 1]);
+            for (int q = 0; q < w; ++q) { lane_ex[base + q] = exr; lane_start[base + q] = first; lane_pmax[base + q] = m; }
+        }
+    }
+}
+
 // lanes of the chunk's partition whose [first, last] position range meets the chunk's genomic range [glo, ghi]
 __global__ void __launch_bounds__(256) k_hist_ranges(int n_chunks, const int *hc_part, const int *hc_glo, const int *hc_ghi,
                                                      const i64 *part_lane_off, const int *lane_start, const int *lane_pmax,
@@ -3306,7 +3388,7 @@ struct fseg_ctx {
     DevBuf d_sort_tmp;
     // device buffers: inputs (slab_in, uploaded)
     DevBuf d_part_iv_off, d_part_rep_off, d_part_lane_off, d_iv_start, d_iv_end, d_pos_off, d_iv_part,
-        d_rep_exon_off, d_rep_weight, d_ex_ts, d_ex_te, d_tile_desc, d_iv_tile0, d_blk_iv0, d_rb_part, d_rb_r0,
+        d_rep_exon_off, d_rep_weight, d_ex_ts, d_ex_te, d_tile_desc, d_iv_tile0, d_blk_iv0, d_rb_part, d_rb_r0, d_rb_sum, d_rb_base, d_rb_max, d_rb_cmax,
         d_hc_part, d_hc_p0, d_hc_n, d_hc_glo, d_hc_ghi;
     // slab_in, derived on the device by the upload
     DevBuf d_lane_ex, d_lane_start, d_lane_pmax, d_hc_llo, d_hc_lhi, d_edge, d_key_a, d_key_b, d_val_a, d_val_b, d_rep_last;
@@ -4279,6 +4361,10 @@ int fseg_upload(fseg_ctx *c, const fseg_batch *b) {
     in.add(c->d_val_a, (size_t)R * 4);
     in.add(c->d_val_b, (size_t)R * 4);
     in.add(c->d_rep_last, (size_t)R * 4);
+    in.add(c->d_rb_sum, (size_t)n_rep_blocks * 8);
+    in.add(c->d_rb_base, (size_t)n_rep_blocks * 8);
+    in.add(c->d_rb_max, (size_t)n_rep_blocks * 4);
+    in.add(c->d_rb_cmax, (size_t)n_rep_blocks * 4);
     TRY(reserve(c, c->slab_in, in.total));
     in.bind(c->slab_in);
     TRY(reserve_host(c, c->h_stage, up_bytes));
@@ -4372,10 +4458,24 @@ int fseg_upload(fseg_ctx *c, const fseg_batch *b) {
             HIP_TRY(c, fseg_sort_pairs(c->d_sort_tmp.p, &tmp_bytes, c->d_key_a.as<u64>(), c->d_key_b.as<u64>(), c->d_val_a.as<int>(),
                                        c->d_val_b.as<int>(), (size_t)R, end_bit, s));
         }
-        hipLaunchKernelGGL(k_lanes, dim3(grid_for(np, 1, 65536)), dim3(256), 0, s, np, c->d_part_rep_off.as<i64>(), c->d_part_lane_off.as<i64>(),
-                           c->d_key_b.as<u64>(), c->d_val_b.as<int>(), c->d_rep_weight.as<int>(), c->d_rep_last.as<int>(),
-                           c->d_rep_exon_off.as<i64>(), c->d_lane_ex.as<longlong2>(), c->d_lane_start.as<int>(), c->d_lane_pmax.as<int>(),
-                           sort_here ? 1 : 0, c->d_key_a.as<u64>());
+        if (sort_here) {
+            hipLaunchKernelGGL(k_lanes, dim3(grid_for(np, 1, 65536)), dim3(256), 0, s, np, c->d_part_rep_off.as<i64>(), c->d_part_lane_off.as<i64>(),
+                               c->d_key_b.as<u64>(), c->d_val_b.as<int>(), c->d_rep_weight.as<int>(), c->d_rep_last.as<int>(),
+                               c->d_rep_exon_off.as<i64>(), c->d_lane_ex.as<longlong2>(), c->d_lane_start.as<int>(), c->d_lane_pmax.as<int>(),
+                               1, c->d_key_a.as<u64>());
+        } else {
+            const int rbg = grid_for(n_rep_blocks, 1, 65536);
+            hipLaunchKernelGGL(k_lane_blocks, dim3(rbg), dim3(256), 0, s, (int)n_rep_blocks, c->d_rb_part.as<int>(), c->d_rb_r0.as<int>(),
+                               c->d_part_rep_off.as<i64>(), c->d_val_b.as<int>(), c->d_rep_weight.as<int>(), c->d_rep_last.as<int>(),
+                               c->d_rb_sum.as<i64>(), c->d_rb_max.as<int>());
+            hipLaunchKernelGGL(k_lane_block_scan, dim3(grid_for(np, 4, 4096)), dim3(256), 0, s, np, (int)n_rep_blocks, c->d_rb_part.as<int>(),
+                               c->d_part_lane_off.as<i64>(), c->d_rb_sum.as<i64>(), c->d_rb_max.as<int>(), c->d_rb_base.as<i64>(),
+                               c->d_rb_cmax.as<int>());
+            hipLaunchKernelGGL(k_lane_emit, dim3(rbg), dim3(256), 0, s, (int)n_rep_blocks, c->d_rb_part.as<int>(), c->d_rb_r0.as<int>(),
+                               c->d_part_rep_off.as<i64>(), c->d_key_b.as<u64>(), c->d_val_b.as<int>(), c->d_rep_weight.as<int>(),
+                               c->d_rep_last.as<int>(), c->d_rep_exon_off.as<i64>(), c->d_rb_base.as<i64>(), c->d_rb_cmax.as<int>(),
+                               c->d_lane_ex.as<longlong2>(), c->d_lane_start.as<int>(), c->d_lane_pmax.as<int>());
+        }
     }
     hipLaunchKernelGGL(k_hist_ranges, dim3(grid_for(n_chunks, 256, 4096)), dim3(256), 0, s, (int)n_chunks, c->d_hc_part.as<int>(),
                        c->d_hc_glo.as<int>(), c->d_hc_ghi.as<int>(), c->d_part_lane_off.as<i64>(), c->d_lane_start.as<int>(),

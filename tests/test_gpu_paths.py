@@ -121,10 +121,15 @@ def test_full_size_bench_batches_against_oracle(workload, n_part, gpu_ctx):
     util.compare_partitions(gpu_ctx, parts, oracles)
 
 
-def test_lane_preparation_on_the_device(gpu_ctx):
+@pytest.mark.parametrize("big", [False, True], ids=["sorted-in-LDS", "batch-wide-sort"])
+def test_lane_preparation_on_the_device(big, gpu_ctx):
     """fseg_upload's device-side ordering of the reads: every rep repeated rep_weight times, sorted inside its partition by
-    first position (ties in rep order), with the running maximum of the last positions."""
+    first position (ties in rep order), with the running maximum of the last positions.  With a partition of more than 2 048
+    reps the batch goes through the radix sort and the block-parallel lane kernels (k_lane_blocks / _block_scan / _emit)."""
     parts = [util.make_partition(40 + i, n_reads=300 + 50 * i, n_exons=40, rp=0.1, dedupe=True) for i in range(5)]
+    if big:
+        parts.insert(2, util.make_partition(46, n_reads=9000, n_exons=60, rp=0.2, dedupe=True))
+        assert parts[2].n_reps > 2048
     util.run_gpu(gpu_ctx, parts)
     start, pmax, exons = gpu_ctx.tap("lane_start"), gpu_ctx.tap("lane_pmax"), gpu_ctx.tap("lane_exons")
     l0 = e0 = 0
