@@ -88,6 +88,7 @@ struct Status {
     u64 dp_cls[3];     // DP problems with n <= kDpSmall / <= kNMax / larger
     u64 cov_queue;
     u64 solve_cls[3];  // problems solved whole by k_solve (n <= 16 / <= 32 / <= kNMax)
+    u64 n_tiny;        // problems solved whole by k_tiny (their list follows the three solve lists)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -918,6 +919,23 @@ __device__ __forceinline__ ProbDesc load_desc(const ProbDesc *d) {
     return u.p;
 }
 
+// Eight (two) consecutive exon coordinates from a dword-aligned address as two 16-byte loads (one 8-byte load).  A lane that
+// walks its own read's exons touches one or two cache lines per block whichever way it loads them, but the texture path works
+// per instruction and lane: eight dword loads of 64 lanes are 512 line accesses, two 16-byte loads 128 -- and that rate, not
+// HBM or the ALUs, is what the small problems' kernels run at.  The exon arrays are padded so that a block which starts at
+// the batch's last exons stays inside them; elements beyond a read's own exons are masked by the callers.
+typedef int int4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef int int2u __attribute__((ext_vector_type(2), aligned(4)));
+__device__ __forceinline__ void load_exons8(const int *p, int (&v)[8]) {
+    const int4u a = *reinterpret_cast<const int4u *>(p), b = *reinterpret_cast<const int4u *>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ int2 load_exons2(const int *p) {
+    const int2u a = *reinterpret_cast<const int2u *>(p);
+    return make_int2(a.x, a.y);
+}
+constexpr size_t kExonPad = 32;        // bytes behind ex_ts / ex_te
+
 // A value every lane of the wave holds identically, moved to a scalar register: what is computed from it (triangular
 // table offsets, loop bounds, LDS base addresses) then runs on the scalar unit instead of costing every lane a multiply.
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -1077,7 +1095,7 @@ __global__ void k_prob_range(const Status *st, const int *cand_pn, const int *ca
 //   0: problem slot | DP problems of the small class     1: pairs     2: triples     3: coverage elements
 //   4: work items of class 0 | class 1                   5: work items of class 2 | DP problems of the big class
 //   6: work items of class 3 (huge) | DP problems of the huge class
-//   7: fused problems of class 0 | class 1                   8: fused problems of class 2
+//   7: fused problems of class 0 | class 1                   8: fused problems of class 2 | k_tiny's problems
 // (work items overall = the four class counts)
 constexpr int kProbCols = 9;
 __device__ __forceinline__ i64 col_lo(i64 x) { return x & 0xffffffffLL; }
@@ -1102,7 +1120,7 @@ __device__ __forceinline__ ProbSizes prob_sizes(int n, int n_lanes, ProbSplit sp
     for (int q = 0; q < kProbCols; ++q) s.v[q] = 0;
     if (n <= 0) return s;
     const int kind = prob_kind(n, n_lanes, sp);
-    if (kind == kKindTiny) { s.v[0] = 1; return s; }
+    if (kind == kKindTiny) { s.v[0] = 1; s.v[8] = 1LL << 32; return s; }
     if (kind == kKindFused) {
         const int c = size_class(n);
         s.v[0] = 1;
@@ -1182,6 +1200,7 @@ __device__ __forceinline__ void prob_store_totals(Status *st, const ProbSizes &t
     st->cls_work[3] = (u64)col_lo(t.v[6]);
     st->dp_cls[0] = (u64)col_hi(t.v[0]); st->dp_cls[1] = (u64)col_hi(t.v[5]); st->dp_cls[2] = (u64)col_hi(t.v[6]);
     st->solve_cls[0] = (u64)col_lo(t.v[7]); st->solve_cls[1] = (u64)col_hi(t.v[7]); st->solve_cls[2] = (u64)col_lo(t.v[8]);
+    st->n_tiny = (u64)col_hi(t.v[8]);
 }
 // Largest problem (candidates) and widest problem (reads examined) of the run: they size the big-problem kernels' LDS
 // and pick the DP's count width.  One atomic per block of 1024 candidates -- per-problem atomics on the one address
@@ -1256,6 +1275,7 @@ __global__ void __launch_bounds__(256) k_prob_emit(Status *st, const int *cand_p
             grand.v[4] = (i64)st->cls_work[0] + ((i64)st->cls_work[1] << 32); grand.v[0] = (i64)st->dp_cls[0] << 32;
             grand.v[5] = (i64)st->cls_work[2] + ((i64)st->dp_cls[1] << 32);
             grand.v[7] = (i64)st->solve_cls[0] + ((i64)st->solve_cls[1] << 32);
+            grand.v[8] = (i64)st->solve_cls[2];
         } else {
             for (int q = 0; q < kProbCols; ++q) { before.v[q] = 0; grand.v[q] = 0; }
             for (i64 bb = 0; bb < nb; ++bb) {
@@ -1277,7 +1297,7 @@ __global__ void __launch_bounds__(256) k_prob_emit(Status *st, const int *cand_p
         const i64 i0 = b * kProbBlock + (i64)threadIdx.x * 4;
         const i64 g_cls0 = col_lo(grand.v[4]), g_cls1 = col_hi(grand.v[4]), g_cls2 = col_lo(grand.v[5]);
         const i64 g_dp0 = col_hi(grand.v[0]), g_dp1 = col_hi(grand.v[5]);
-        const i64 g_sol0 = col_lo(grand.v[7]), g_sol1 = col_hi(grand.v[7]);
+        const i64 g_sol0 = col_lo(grand.v[7]), g_sol1 = col_hi(grand.v[7]), g_sol2 = col_lo(grand.v[8]);
         // what a problem's records need, for this thread's four candidates, in three rounds of loads instead of one
         // chain per candidate (a load under `if (problem)` is a branch with its own wait): candidate -> interval -> partition
         int pn4[4], iv4[4], ll4[4], ln4[4], is4[4], part4[4], lanes4[4];
@@ -1312,6 +1332,10 @@ __global__ void __launch_bounds__(256) k_prob_emit(Status *st, const int *cand_p
                     if (kind == kKindFused) {   // solve lists: class 0, then class 1, then class 2
                         const int sc = size_class(nn);
                         const i64 si = sc == 0 ? col_lo(ex.v[7]) : (sc == 1 ? g_sol0 + col_hi(ex.v[7]) : g_sol0 + g_sol1 + col_lo(ex.v[8]));
+                        if (si < prob_cap) solve_items[si] = (int)slot;
+                    }
+                    if (kind == kKindTiny) {    // ... then k_tiny's problems (every wave of its workgroups gets one)
+                        const i64 si = g_sol0 + g_sol1 + g_sol2 + col_hi(ex.v[8]);
                         if (si < prob_cap) solve_items[si] = (int)slot;
                     }
                     if (kind == kKindArena) {   // DP problem lists: the small problems first, then the big ones
@@ -1519,13 +1543,16 @@ __global__ void __launch_bounds__(kLaneChunk) k_cov(Status *st, const ProbDesc *
 #endif
 // T == 64: the caller is ONE WAVE working on its own problem with wave-private tables (other waves of the workgroup
 // may be inside their own dp_solve_push<64>), so synchronisation is wave-level and thread indices are lane indices.
+// Either way only LDS traffic is ordered (the tables are in LDS): global loads issued before it -- the next phase's
+// prefetches -- stay in flight, which a full fence would wait for.
 template <int T>
 __device__ __forceinline__ void dp_sync() {
     if (T == 64) {
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
         __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
     } else {
-        __syncthreads();
+        lds_barrier();
     }
 }
 // V: the type the sums are kept in.  i64 in general; int where the caller knows that n * (reads of the partition) stays
@@ -2053,7 +2080,7 @@ constexpr int kTinyPairs = kTiny * (kTiny - 1) / 2, kTinyTri = kTiny * (kTiny - 
 __global__ void __launch_bounds__(256, FSEG_TINY_OCC) k_tiny(Status *st, const ProbDesc *desc, i64 prob_cap, int tiny_max, ProblemArrays pr,
                                               const int *cand_y, const longlong2 *lane_ex, const int *ex_ts,
                                               const int *ex_te, const double *h_table, int h_len, double tau, const int2 *thr_tab,
-                                              int support, unsigned char *chosen FSEG_TPARAM) {
+                                              int support, unsigned char *chosen, const int *solve_items FSEG_TPARAM) {
     __shared__ u64 planes[4][kTinyPairs][2];            // [wave][pair]{yea, nay} of the current 64 reads
     __shared__ i64 M_s[4][kTinyPairs];
     __shared__ int in_s[4][kTinyPairs];
@@ -2078,14 +2105,27 @@ __global__ void __launch_bounds__(256, FSEG_TINY_OCC) k_tiny(Status *st, const P
     __shared__ unsigned long long tick_sink[16];
     unsigned long long *dp_tacc = tick_sink; unsigned long long dt_prev = 0;
 #endif
-    for (i64 p = (i64)blockIdx.x * 4 + wave; p < n_prob; p += (i64)gridDim.x * 4) {
+    // k_tiny's problems are a list of their own (behind the three solve lists): every wave of a workgroup has one, and a
+    // workgroup's four are a grid apart (neighbours in the list are neighbours on the genome and of similar size)
+    const i64 list_base = (i64)st->solve_cls[0] + (i64)st->solve_cls[1] + (i64)st->solve_cls[2], list_n = (i64)st->n_tiny;
+    for (i64 t = (i64)blockIdx.x + (i64)wave * gridDim.x; t < list_n; t += (i64)gridDim.x * 4) {
 #ifdef FSEG_SCORE_TIMING
         const unsigned long long t_prob0 = wall_clock64();
 #endif
+        const int p = uni(solve_items[list_base + t]);
         const ProbDesc d = FSEG_LOAD_DESC(desc + p);
         const int n = d.n;
         if (n > tiny_max) continue;                     // wave-uniform
         const int npairs = n * (n - 1) / 2, ntri = n * (n - 1) * (n - 2) / 6;
+        // The problem is a chain of dependent loads (descriptor -> candidates -> thresholds; descriptor -> exon ranges -> exons):
+        // the second branch needs nothing of the first, so the first 64 reads' exon ranges and first exon blocks are requested
+        // now and arrive while the candidates and thresholds are being fetched.
+        longlong2 pf_ex = make_longlong2(0, 0);
+        int pf_ts[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pf_te[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (d.lane_n > 0) {                             // (wave-uniform)
+            pf_ex = lane_ex[d.lane_lo + (lane < d.lane_n ? lane : 0)];
+            load_exons8(ex_ts + pf_ex.x, pf_ts); load_exons8(ex_te + pf_ex.x, pf_te);
+        }
         dp_sync<64>();                                  // the previous problem's readers of the wave-private tables are done
         if (lane < n) cy_s[wave][lane] = cand_y[d.c0 + lane];
         dp_sync<64>();
@@ -2109,16 +2149,19 @@ __global__ void __launch_bounds__(256, FSEG_TINY_OCC) k_tiny(Status *st, const P
             while (fill < 64 && raw < d.lane_n) {
                 const int li = raw + lane;
                 const bool in = li < d.lane_n;
-                const longlong2 ex = lane_ex[d.lane_lo + (in ? li : 0)];      // unconditional: no branch around the load
+                longlong2 ex;
+                int ts8[8], te8[8];
+                if (raw == 0) {                                               // (wave-uniform) the block requested above
+                    ex = pf_ex;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { ts8[u] = pf_ts[u]; te8[u] = pf_te[u]; }
+                } else {
+                    ex = lane_ex[d.lane_lo + (in ? li : 0)];                  // unconditional: no branch around the load
+                    load_exons8(ex_ts + ex.x, ts8); load_exons8(ex_te + ex.x, te8);
+                }
                 i64 first = ex.x;
                 int cnt = 0;
-                for (i64 eb = ex.x; eb < ex.y; eb += 8) {                 // eight exons per round from clamped addresses
-                    int ts8[8], te8[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const i64 idx = eb + u < ex.y ? eb + u : ex.y - 1;
-                        ts8[u] = ex_ts[idx]; te8[u] = ex_te[idx];
-                    }
+                for (i64 eb = ex.x;;) {                                       // eight exons per round from clamped addresses
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         const bool hit = eb + u < ex.y && te8[u] >= cp0 && ts8[u] < c_last;
@@ -2126,6 +2169,9 @@ __global__ void __launch_bounds__(256, FSEG_TINY_OCC) k_tiny(Status *st, const P
                         cnt += hit;
                     }
                     if (ts8[7] >= c_last) break;
+                    eb += 8;
+                    if (eb >= ex.y) break;
+                    load_exons8(ex_ts + eb, ts8); load_exons8(ex_te + eb, te8);
                 }
                 const bool act = in && cnt > 0;
                 const u64 m = __ballot(act);
@@ -2144,8 +2190,8 @@ __global__ void __launch_bounds__(256, FSEG_TINY_OCC) k_tiny(Status *st, const P
                 const int2 a = act_w[wave][valid ? lane : 0];
                 const int e_end = valid ? a.y : 0;
                 for (int e = 0; e < e_end; e += 2) {
-                    const int e2 = e + 1 < e_end ? e + 1 : e;
-                    const int tsa = ex_ts[a.x + e], tea = ex_te[a.x + e], tsb = ex_ts[a.x + e2], teb = ex_te[a.x + e2];
+                    const int2 ts2 = load_exons2(ex_ts + a.x + e), te2 = load_exons2(ex_te + a.x + e);      // (the second may be the next read's: masked below)
+                    const int tsa = ts2.x, tea = te2.x, tsb = ts2.y, teb = te2.y;
                     const int a0 = max(tsa, cp0), b0 = tea + 1;
                     const int a1 = max(tsb, cp0), b1 = e + 1 < e_end ? teb + 1 : a1;
 #pragma unroll
@@ -2321,18 +2367,14 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
             int cnt = 0;
             for (i64 eb = ex.x; eb < ex.y; eb += 8) {               // eight exons per round from clamped addresses, in flight together
                 int ts8[8], te8[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const i64 idx = eb + u < ex.y ? eb + u : ex.y - 1;
-                    ts8[u] = ex_ts[idx]; te8[u] = ex_te[idx];
-                }
+                load_exons8(ex_ts + eb, ts8); load_exons8(ex_te + eb, te8);
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const bool hit = eb + u < ex.y && te8[u] >= cp0 && ts8[u] < c_last;
                     if (hit && cnt == 0) first = eb + u;
                     cnt += hit;
                 }
-                if (ts8[7] >= c_last) break;                         // the rest of the read lies beyond the window
+                if (eb + 7 < ex.y && ts8[7] >= c_last) break;        // the rest of the read lies beyond the window
             }
             const bool act = in && cnt > 0;
             const u64 m = __ballot(act);
@@ -2365,8 +2407,8 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
                 for (int u = 0; u < kCovJ; ++u) acc[u] = 0;
                 const int e_end = valid ? a.y : 0;
                 for (int e = 0; e < e_end; e += 2) {
-                    const int e2 = e + 1 < e_end ? e + 1 : e;
-                    const int tsa = ex_ts[a.x + e], tea = ex_te[a.x + e], tsb = ex_ts[a.x + e2], teb = ex_te[a.x + e2];
+                    const int2 ts2 = load_exons2(ex_ts + a.x + e), te2 = load_exons2(ex_te + a.x + e);      // (the second may be the next read's: masked below)
+                    const int tsa = ts2.x, tea = te2.x, tsb = ts2.y, teb = te2.y;
                     const int a0 = max(tsa, cp0), b0 = tea + 1;                     // closed exon -> half-open end
                     const int a1 = max(tsb, cp0), b1 = e + 1 < e_end ? teb + 1 : a1;  // (an odd count: the second slot is empty)
 #pragma unroll
@@ -3448,7 +3490,7 @@ struct fseg_ctx {
     // what the lists of the resident batch hold (read from the status record; exact once the batch has run or been sized):
     // launches over an empty list are skipped
     bool counts_known = false;
-    i64 n_solve[3] = {0, 0, 0}, n_cls_work[4] = {0, 0, 0, 0}, n_dp_cls[3] = {0, 0, 0}, n_arena_prob = 0;
+    i64 n_solve[3] = {0, 0, 0}, n_cls_work[4] = {0, 0, 0, 0}, n_dp_cls[3] = {0, 0, 0}, n_arena_prob = 0, n_tiny = 0;
     i64 tiny_from = 256;        // problems above which k_tiny is used (FSEG_TINY_FROM; tests force 0)
     bool trace = false;         // FSEG_TRACE=1: phase timers of upload / run on stderr
     bool force_global_sort = false;   // FSEG_GLOBAL_SORT=1 (tests): the batch-wide radix sort whatever the partition sizes
@@ -3803,14 +3845,13 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
 #undef FSEG_LAUNCH_SOLVE
 #undef FSEG_LAUNCH_SCORE
         if (tiny_max > 0) {
-            // the problems with a handful of candidates, whole (coverage, labels, counts, DP), beside the others; launched
-            // last -- the big problems' workgroups need half a CU's LDS each and must be resident before the small
-            // workgroups fill the CUs, or they start late and end the stage alone; joined at the end of this stage, so the
+            // the problems with a handful of candidates, whole (coverage, labels, counts, DP), beside the others (launched
+            // after the classes whose workgroups need half a CU's LDS each); joined at the end of this stage, so the
             // stage's time bracket covers all scoring work
-            hipLaunchKernelGGL(k_tiny, dim3(grid_for(c->prob_cap, 4, FSEG_WG_TINY)), dim3(256), 0, qt, st, c->d_prob_desc.as<ProbDesc>(),
+            hipLaunchKernelGGL(k_tiny, dim3(grid_for(known ? c->n_tiny : c->prob_cap, 4, FSEG_WG_TINY)), dim3(256), 0, qt, st, c->d_prob_desc.as<ProbDesc>(),
                                c->prob_cap, tiny_max, pr, c->d_cand_y.as<int>(), c->d_lane_ex.as<longlong2>(),
                                c->d_ex_ts.as<int>(), c->d_ex_te.as<int>(), c->d_h_table.as<double>(), c->P.h_len, c->P.threshold_rate,
-                               c->d_thr_tab.as<int2>(), c->P.min_read_support_outside, c->d_chosen.as<unsigned char>() FSEG_TARG);
+                               c->d_thr_tab.as<int2>(), c->P.min_read_support_outside, c->d_chosen.as<unsigned char>(), c->d_solve_items.as<int>() FSEG_TARG);
         }
         if (!c->small_batch) { join(0); join(1); }
         if (c->have_huge && any_arena)
@@ -3964,6 +4005,7 @@ int run_input_errors(fseg_ctx *c, const Status &s) {
 // what the lists of the batch hold, from the status record of a run (or of the sizing pass)
 void note_counts(fseg_ctx *c, const Status &s) {
     for (int q = 0; q < 3; ++q) { c->n_solve[q] = (i64)s.solve_cls[q]; c->n_dp_cls[q] = (i64)s.dp_cls[q]; }
+    c->n_tiny = (i64)s.n_tiny;
     for (int q = 0; q < 4; ++q) c->n_cls_work[q] = (i64)s.cls_work[q];
     c->n_arena_prob = (i64)s.dp_cls[0] + (i64)s.dp_cls[1] + (i64)s.dp_cls[2];
     if (!c->counts_known) drop_graph(c);
@@ -4347,8 +4389,8 @@ int fseg_upload(fseg_ctx *c, const fseg_batch *b) {
     in.add(c->d_hc_ghi, (size_t)n_chunks * 4);
     in.add(c->d_rep_exon_off, ((size_t)R + 1) * 8);
     in.add(c->d_rep_weight, (size_t)R * 4);
-    in.add(c->d_ex_ts, (size_t)I * 4);
-    in.add(c->d_ex_te, (size_t)I * 4);
+    in.add(c->d_ex_ts, (size_t)I * 4 + kExonPad);
+    in.add(c->d_ex_te, (size_t)I * 4 + kExonPad);
     const size_t up_bytes = in.total;
     in.add(c->d_lane_ex, (size_t)lanes * 16);
     in.add(c->d_lane_start, (size_t)lanes * 4);
