@@ -224,7 +224,8 @@ class Context:
         return out.reshape(-1, 4) if name == "problems" else (out.reshape(-1, 2) if name == "lane_exons" else out)
 
     def set_profiling(self, on):
-        self._check(self._L.fseg_set_profiling(self._h, 1 if on else 0), "fseg_set_profiling")
+        """True / 1: HIP events around every stage; 2: around the interval-scoring stage only; False: none."""
+        self._check(self._L.fseg_set_profiling(self._h, 2 if on == 2 else (1 if on else 0)), "fseg_set_profiling")
 
     def stage_ms(self):
         n = self._L.fseg_n_stages()

@@ -3454,6 +3454,7 @@ struct fseg_ctx {
     PrepStatus *h_prep = nullptr; // pinned
     bool prep_checked = false;   // the upload's device-side validation has been read back
     bool profiling = false;
+    bool profile_all = true;    // false (fseg_set_profiling(ctx, 2)): only the interval-scoring stage is bracketed by events
     bool have_huge = false;      // the batch has a problem with more than kNMax candidates: launch the huge kernels
     bool dp_wide_counts = false; // some problem sees >= 65536 reads: DP stages 32-bit counts
     int nm_big = kNMax;         // LDS carve-up of the big-problem kernels: largest problem of the batch, rounded up
@@ -3630,8 +3631,8 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
     const int n_part = c->n_part;
     const i64 K = c->K, NPOS = c->NPOS;
     Status *st = c->d_status.as<Status>();
-    auto begin = [&](int i) { if (stage_events) (void)hipEventRecord(c->ev_b[i], s); };
-    auto end = [&](int i) { if (stage_events) (void)hipEventRecord(c->ev_e[i], s); };
+    auto begin = [&](int i) { if (stage_events && (c->profile_all || i == ST_SCORE)) (void)hipEventRecord(c->ev_b[i], s); };
+    auto end = [&](int i) { if (stage_events && (c->profile_all || i == ST_SCORE)) (void)hipEventRecord(c->ev_e[i], s); };
     // fork(k): side stream k continues from here; join(k): the main stream waits for it.  Every fork is joined before
     // the function returns, so a capture of the main stream ends with all branches merged.
     // Small batches (one partition, few problems) are chains of launch-latency-sized kernels: branches only add
@@ -3711,7 +3712,7 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
     // S3a threshold: needs only the smoothed signal, like the candidates (S3b) -- the two chains run side by side
     {
     hipStream_t q = fork(0);
-    if (stage_events) (void)hipEventRecord(c->ev_b[ST_THRESHOLD], q);
+    if (stage_events && c->profile_all) (void)hipEventRecord(c->ev_b[ST_THRESHOLD], q);
     scan_counts(q, bsum_side, c->d_flag.as<unsigned char>(), &st->n_vals, nullptr);
     hipLaunchKernelGGL(k_scan_emit<kEmitValues>, dim3(scan_grid), dim3(256), 0, q, c->d_flag.as<unsigned char>(), NPOS,
                        bsum_side, scan_state, &st->n_vals, (i64 *)nullptr, &st->err, c->d_y.as<double>(), c->d_v.as<double>(), K, c->d_pos_off.as<i64>(),
@@ -3730,7 +3731,7 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
     hipLaunchKernelGGL(k_vsum_part, dim3(grid_for(n_part, 64, 1024)), dim3(64), 0, q, n_part, c->d_voff.as<i64>(),
                        c->d_chunk_off.as<i64>(), csum0, csum1, c->P.variance_factor, c->d_mean.as<double>(),
                        c->d_thr.as<double>(), c->chunk_cap);
-    if (stage_events) (void)hipEventRecord(c->ev_e[ST_THRESHOLD], q);
+    if (stage_events && c->profile_all) (void)hipEventRecord(c->ev_e[ST_THRESHOLD], q);
     }
     begin(ST_CANDIDATES);
     // S3b candidates
@@ -4040,8 +4041,10 @@ void collect_stage_times(fseg_ctx *c, int timed_graphs) {
         (void)hipEventElapsedTime(&c->stage_ms[ST_SCORE], c->ev_g[1], c->ev_g[2]);
         (void)hipEventElapsedTime(&c->stage_ms[ST_GRAPH_POST], c->ev_g[2], c->ev_g[3]);
     } else if (c->last_sized || !c->use_graph) {
-        for (int i = 0; i < ST_COUNT; ++i)
+        for (int i = 0; i < ST_COUNT; ++i) {
+            if (!c->profile_all && i != ST_SCORE) continue;
             if (hipEventElapsedTime(&c->stage_ms[i], c->ev_b[i], c->ev_e[i]) != hipSuccess) { c->stage_ms[i] = 0.f; (void)hipGetLastError(); }
+        }
     }
 }
 
@@ -4763,8 +4766,9 @@ int fseg_tap(fseg_ctx *c, int what, void *dst, int64_t cap_bytes, int64_t *n_byt
 
 int fseg_set_profiling(fseg_ctx *c, int on) {
     if (!c) return FSEG_ERR_ARG;
-    if (c->profiling != (on != 0)) drop_graph(c);
+    if (c->profiling != (on != 0) || c->profile_all != (on != 2)) drop_graph(c);
     c->profiling = on != 0;
+    c->profile_all = on != 2;
     return FSEG_OK;
 }
 int fseg_n_stages(void) { return ST_REPORTED; }

@@ -162,7 +162,8 @@ int fseg_tap(fseg_ctx *ctx, int what, void *dst, int64_t cap_bytes, int64_t *n_b
 
 /* Timing support for benchmarks: HIP-event time of the last run in milliseconds, per stage.
  * Stage names are returned by fseg_stage_name(i); n_stages by fseg_n_stages().  Only filled
- * when profiling was enabled with fseg_set_profiling(ctx, 1) (adds event records). */
+ * when profiling was enabled with fseg_set_profiling(ctx, 1) (adds event records: two per stage); with 2 only the
+ * interval-scoring stage is bracketed (two records per run; the other stages report 0). */
 int fseg_set_profiling(fseg_ctx *ctx, int on);
 int fseg_n_stages(void);
 const char *fseg_stage_name(int i);
