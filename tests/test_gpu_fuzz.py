@@ -1,6 +1,7 @@
 """Randomized parity sweep on the GPU: random generator settings x random stage parameters, batches of random size,
 every tap against the CPU oracle, with k_tiny forced on for half of the contexts; inputs on which the reference would
 abort (break_large_problems' assertions) must be refused by the library too."""
+import os
 import random
 
 import pytest
@@ -11,7 +12,11 @@ from freddie_amd import _lib
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("seed", [7, 11])
+# FREDDIE_FUZZ_SEEDS=20,21,...: a longer sweep by hand after a change to the kernels
+SEEDS = [int(x) for x in os.environ.get("FREDDIE_FUZZ_SEEDS", "7,11").split(",")]
+
+
+@pytest.mark.parametrize("seed", SEEDS)
 def test_random_inputs_and_parameters(seed, monkeypatch):
     rng = random.Random(seed)
     n_part = 0
