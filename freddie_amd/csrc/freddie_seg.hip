@@ -17,6 +17,7 @@
 #include <chrono>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -3453,6 +3454,7 @@ struct fseg_ctx {
     Status *h_status = nullptr;   // pinned
     PrepStatus *h_prep = nullptr; // pinned
     bool prep_checked = false;   // the upload's device-side validation has been read back
+    bool counted_in_flight = false;
     bool profiling = false;
     bool profile_all = true;    // false (fseg_set_profiling(ctx, 2)): only the interval-scoring stage is bracketed by events
     bool have_huge = false;      // the batch has a problem with more than kNMax candidates: launch the huge kernels
@@ -3517,6 +3519,14 @@ std::string g_create_error;
         if (e__ != hipSuccess) return fail((c), FSEG_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e__)); \
     } while (0)
 #define TRY(expr) do { int rc__ = (expr); if (rc__) return rc__; } while (0)
+
+// Contexts of one device that have a batch in flight (uploaded or running, results not yet complete).  A context forks its
+// run over side streams only when it is alone on the device: with several contexts taking turns (the CLI, the benchmark's
+// timed steps) the other contexts' kernels already fill what one stream leaves idle, and the extra streams only crowd the
+// hardware queues (three contexts: 1.44 -> 1.28 ms per 250 k-read batch without them).
+static std::atomic<int> g_in_flight[64];
+static void set_in_flight(fseg_ctx *c, bool on);
+static bool others_in_flight(const fseg_ctx *c);
 
 struct Tick {
     std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
@@ -3637,7 +3647,7 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
     // the function returns, so a capture of the main stream ends with all branches merged.
     // Small batches (one partition, few problems) are chains of launch-latency-sized kernels: branches only add
     // cross-stream dependencies there (measured: config2 +4 %), so they stay on the one stream.
-    const bool forking = c->use_fork && !c->small_batch;
+    const bool forking = c->use_fork && !c->small_batch && !others_in_flight(c);
     const int tiny_max = c->tiny_on ? kTiny : 0;
     const ProbSplit split{tiny_max, (c->use_fuse && c->fuse_on) ? kFuseLanes : -1};
     // list sizes known (the batch has been sized or has run): launches over an empty list are left out
@@ -4049,7 +4059,22 @@ void collect_stage_times(fseg_ctx *c, int timed_graphs) {
 }
 
 // wait for the run; grow arenas and re-run if a capacity was exceeded (never after a sized run: its capacities are exact)
+static void set_in_flight(fseg_ctx *c, bool on) {
+    if (c->counted_in_flight == on || c->device < 0 || c->device >= 64) return;
+    c->counted_in_flight = on;
+    g_in_flight[c->device].fetch_add(on ? 1 : -1, std::memory_order_relaxed);
+}
+static bool others_in_flight(const fseg_ctx *c) {
+    if (c->device < 0 || c->device >= 64) return false;
+    return g_in_flight[c->device].load(std::memory_order_relaxed) - (c->counted_in_flight ? 1 : 0) > 0;
+}
+static int finish_run_impl(fseg_ctx *c);
 int finish_run(fseg_ctx *c) {
+    const int rc = finish_run_impl(c);
+    if (!c->pending) set_in_flight(c, false);
+    return rc;
+}
+static int finish_run_impl(fseg_ctx *c) {
     for (int attempt = 0; attempt < 4; ++attempt) {
         HIP_TRY(c, wait_stream(c));
         TRY(check_prep(c));
@@ -4256,6 +4281,7 @@ int fseg_create(int device, fseg_ctx **out) {
 
 void fseg_destroy(fseg_ctx *c) {
     if (!c) return;
+    set_in_flight(c, false);
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     drop_graph(c);
@@ -4320,6 +4346,7 @@ int fseg_upload(fseg_ctx *c, const fseg_batch *b) {
     // the previous batch's work (and its copy out of the staging image) must be over before its buffers are reused
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->pending = false; c->have_batch = false; c->ran = false; c->fetched = false; c->counts_known = false;
+    set_in_flight(c, true);                              // until the run that follows has completed (finish_run)
     const int np = b->n_part;
     const i64 K = b->part_iv_off[np], R = b->part_rep_off[np];
     if (b->part_iv_off[0] != 0 || b->part_rep_off[0] != 0 || b->rep_exon_off[0] != 0)
@@ -4577,6 +4604,7 @@ int fseg_run(fseg_ctx *c) {
     HIP_TRY(c, hipSetDevice(c->device));
     if (c->pending) TRY(finish_run(c));
     c->fetched = false;
+    set_in_flight(c, true);
     // first run of a batch: piecewise with exact arena sizes; afterwards the sizes are known and the same launch
     // sequence is replayed (as a hipGraph unless disabled)
     if (!c->ran && c->use_sized) return run_sized(c);

@@ -12,8 +12,13 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--contexts", type=int, default=3)
 ap.add_argument("--steps", type=int, default=48)
 ap.add_argument("--workload", default="config4")
+ap.add_argument("--torch", action="store_true", help="import torch and initialise its CUDA context first (what bench.py does)")
 ap.add_argument("--profiling", type=int, default=0, help="0 none, 1 events around every stage, 2 around the scoring stage only")
 args = ap.parse_args()
+if args.torch:
+    import torch
+    torch.cuda.set_device(0)
+    torch.cuda.synchronize()
 params = bench.PARAMS["default"]
 tabs = dict(w_main=tables.gaussian_half_kernel(params["sigma"], 4.0), w_refine=tables.gaussian_half_kernel(params["sigma"], 1.0),
             h_table=np.asarray(tables.smooth_threshold(params["threshold_rate"]), np.float64))
