@@ -406,7 +406,7 @@ def main():
             warm_n[0] += 1
             for k, v in ms.items():
                 warm_acc[k] = warm_acc.get(k, 0.0) + v
-    n_warm = max(args.warmup, n_b)
+    n_warm = max(args.warmup, n_b, 2 * len(ctxs))      # every context has sized its buffers before the timed steps
     one_shot_steps(ctxs, batches, [i % n_b for i in range(n_warm)], note_alg)
     for ctx in ctxs:
         ctx.set_profiling(2)
