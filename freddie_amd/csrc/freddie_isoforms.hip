@@ -25,6 +25,28 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 // second phase finds them in L2.
 constexpr int kSpanCap = 1024;
 constexpr int kE = 8;               // reads a wave keeps in flight (16 is slower: registers)
+// The labels of four consecutive segments of a read, raw: four ASCII bytes -- or, PACKED, the two bytes that hold their
+// 2-bit codes (label index g at bits 2(g & 3).. of byte g >> 2: what fseg_results_packed() delivers), with the shift.
+template <bool PACKED>
+__device__ __forceinline__ unsigned load_labels4(const unsigned char *labels, i64 first_label) {
+    if (!PACKED) { unsigned w; __builtin_memcpy(&w, labels + first_label, 4); return w; }
+    unsigned short h;
+    __builtin_memcpy(&h, labels + (first_label >> 2), 2);
+    return ((unsigned)h >> (2 * (unsigned)(first_label & 3))) & 0xffu;
+}
+// bit s of the result: segment s of the four holds '1'
+template <bool PACKED>
+__device__ __forceinline__ unsigned ones_of4(unsigned w) {
+    if (!PACKED) {
+        unsigned m = 0;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) m |= (unsigned)(((w >> (8 * s4)) & 0xffu) == '1') << s4;
+        return m;
+    }
+    const unsigned one = w & ~(w >> 1) & 0x55u;                  // code 1 = low bit set, high bit clear; at bits 0, 2, 4, 6
+    return (one & 1u) | ((one >> 1) & 2u) | ((one >> 2) & 4u) | ((one >> 3) & 8u);
+}
+template <bool PACKED>
 __global__ void __launch_bounds__(256) k_consensus(int n_iso, const i64 *iso_read_off, const int *n_seg, const i64 *iso_seg_off,
                                                    const i64 *read_lab_off, const unsigned char *labels, const unsigned char *tail,
                                                    int *cons, int *cov, int *tails) {
@@ -58,12 +80,11 @@ __global__ void __launch_bounds__(256) k_consensus(int n_iso, const i64 *iso_rea
                     const int jc = j < M ? j : 0;                          // bytes past the row's end are masked below
                     unsigned w[kE];
 #pragma unroll
-                    for (int e = 0; e < kE; ++e) __builtin_memcpy(&w[e], labels + off_s[q0 + e < n ? q0 + e : q0] + jc, 4);
+                    for (int e = 0; e < kE; ++e) w[e] = load_labels4<PACKED>(labels, off_s[q0 + e < n ? q0 + e : q0] + jc);
+                    const unsigned in_row = j + 3 < M ? 15u : (j < M ? (1u << (M - j)) - 1u : 0u);     // segments of the four inside the row
 #pragma unroll
                     for (int e = 0; e < kE; ++e) {
-                        unsigned ones = 0;                                 // bit s = segment j + s holds '1'
-#pragma unroll
-                        for (int s4 = 0; s4 < 4; ++s4) ones |= (unsigned)(j + s4 < M && ((w[e] >> (8 * s4)) & 0xffu) == '1') << s4;
+                        const unsigned ones = ones_of4<PACKED>(w[e]) & in_row;     // bit s = segment j + s holds '1'
                         const u64 m = __ballot(q0 + e < n && ones != 0);
                         if (m) {
                             const int lf = __ffsll((long long)m) - 1, ll = 63 - __clzll((long long)m);
@@ -95,15 +116,16 @@ __global__ void __launch_bounds__(256) k_consensus(int n_iso, const i64 *iso_rea
                     for (int e = 0; e < kE; ++e) {
                         const int q = q0 + e < n ? q0 + e : q0;
                         sp[e] = q0 + e < n ? sp_s[q] : make_int2(1, 0);        // an empty span for the padding reads
-                        __builtin_memcpy(&w[e], labels + off_s[q] + jc, 4);
+                        w[e] = load_labels4<PACKED>(labels, off_s[q] + jc);
                     }
 #pragma unroll
                     for (int e = 0; e < kE; ++e) {
+                        const unsigned ones = ones_of4<PACKED>(w[e]);
 #pragma unroll
                         for (int s4 = 0; s4 < 4; ++s4) {
                             const bool in = j + s4 >= sp[e].x && j + s4 <= sp[e].y;   // spans end below M
                             c[s4] += in;
-                            x[s4] += in && ((w[e] >> (8 * s4)) & 0xffu) == '1';
+                            x[s4] += in && ((ones >> s4) & 1u);
                         }
                     }
                 }
@@ -238,9 +260,22 @@ void fiso_destroy(fiso_ctx *c) {
 
 const char *fiso_last_error(const fiso_ctx *c) { return c ? c->err.c_str() : g_create_error.c_str(); }
 
+static int consensus_impl(fiso_ctx *c, int32_t n_iso, const int64_t *iso_read_off, const int32_t *n_seg, const int64_t *iso_seg_off,
+                          const int64_t *read_lab_off, const uint8_t *labels, const uint8_t *tail,
+                          int32_t *cons_out, int32_t *cov_out, int32_t *tails_out, bool packed);
 int fiso_consensus(fiso_ctx *c, int32_t n_iso, const int64_t *iso_read_off, const int32_t *n_seg, const int64_t *iso_seg_off,
                    const int64_t *read_lab_off, const uint8_t *labels, const uint8_t *tail,
                    int32_t *cons_out, int32_t *cov_out, int32_t *tails_out) {
+    return consensus_impl(c, n_iso, iso_read_off, n_seg, iso_seg_off, read_lab_off, labels, tail, cons_out, cov_out, tails_out, false);
+}
+int fiso_consensus_packed(fiso_ctx *c, int32_t n_iso, const int64_t *iso_read_off, const int32_t *n_seg, const int64_t *iso_seg_off,
+                          const int64_t *read_lab_off, const uint8_t *labels2, const uint8_t *tail,
+                          int32_t *cons_out, int32_t *cov_out, int32_t *tails_out) {
+    return consensus_impl(c, n_iso, iso_read_off, n_seg, iso_seg_off, read_lab_off, labels2, tail, cons_out, cov_out, tails_out, true);
+}
+static int consensus_impl(fiso_ctx *c, int32_t n_iso, const int64_t *iso_read_off, const int32_t *n_seg, const int64_t *iso_seg_off,
+                          const int64_t *read_lab_off, const uint8_t *labels, const uint8_t *tail,
+                          int32_t *cons_out, int32_t *cov_out, int32_t *tails_out, bool packed) {
     if (!c || n_iso <= 0 || !iso_read_off || !n_seg || !iso_seg_off || !cons_out || !cov_out || !tails_out) return FISO_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     TRY(check_offsets(c, "iso_read_off", iso_read_off, n_iso));
@@ -260,16 +295,21 @@ int fiso_consensus(fiso_ctx *c, int32_t n_iso, const int64_t *iso_read_off, cons
     TRY(to_device(c, d_ns, n_seg, (size_t)n_iso));
     TRY(to_device(c, d_iso, iso_seg_off, (size_t)n_iso + 1));
     TRY(to_device(c, d_rlo, read_lab_off, (size_t)R));
-    TRY(to_device(c, d_lab, labels, (size_t)lab_bytes));
+    TRY(to_device(c, d_lab, labels, packed ? (size_t)(lab_bytes + 3) / 4 : (size_t)lab_bytes));     // (lab_bytes counts labels)
     TRY(to_device(c, d_tail, tail, (size_t)R));
     HIP_TRY(c, hipMalloc(&d_cons.p, (size_t)S * 4 + 16));
     HIP_TRY(c, hipMalloc(&d_cov.p, (size_t)S * 4 + 16));
     HIP_TRY(c, hipMalloc(&d_tails.p, (size_t)n_iso * 12 + 16));
     hipStream_t s = c->stream;
     HIP_TRY(c, hipEventRecord(c->ev[0], s));
-    hipLaunchKernelGGL(k_consensus, dim3(n_iso < 8192 ? n_iso : 8192), dim3(256), 0, s, n_iso, d_iro.as<i64>(), d_ns.as<int>(),
-                       d_iso.as<i64>(), d_rlo.as<i64>(), d_lab.as<unsigned char>(), d_tail.as<unsigned char>(),
-                       d_cons.as<int>(), d_cov.as<int>(), d_tails.as<int>());
+    if (packed)
+        hipLaunchKernelGGL(k_consensus<true>, dim3(n_iso < 8192 ? n_iso : 8192), dim3(256), 0, s, n_iso, d_iro.as<i64>(), d_ns.as<int>(),
+                           d_iso.as<i64>(), d_rlo.as<i64>(), d_lab.as<unsigned char>(), d_tail.as<unsigned char>(),
+                           d_cons.as<int>(), d_cov.as<int>(), d_tails.as<int>());
+    else
+        hipLaunchKernelGGL(k_consensus<false>, dim3(n_iso < 8192 ? n_iso : 8192), dim3(256), 0, s, n_iso, d_iro.as<i64>(), d_ns.as<int>(),
+                           d_iso.as<i64>(), d_rlo.as<i64>(), d_lab.as<unsigned char>(), d_tail.as<unsigned char>(),
+                           d_cons.as<int>(), d_cov.as<int>(), d_tails.as<int>());
     HIP_TRY(c, hipEventRecord(c->ev[1], s));
     if (S) HIP_TRY(c, hipMemcpyAsync(cons_out, d_cons.p, (size_t)S * 4, hipMemcpyDeviceToHost, s));
     if (S) HIP_TRY(c, hipMemcpyAsync(cov_out, d_cov.p, (size_t)S * 4, hipMemcpyDeviceToHost, s));

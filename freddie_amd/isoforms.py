@@ -24,7 +24,7 @@ from . import build as _build
 
 ISO_SO = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libfreddie_isoforms.so")
 ISO_SRC = [os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "freddie_isoforms.hip")]
-EXPORTS = ["fiso_abi_version", "fiso_create", "fiso_destroy", "fiso_last_error", "fiso_consensus", "fiso_boundary_votes",
+EXPORTS = ["fiso_abi_version", "fiso_create", "fiso_destroy", "fiso_last_error", "fiso_consensus", "fiso_consensus_packed", "fiso_boundary_votes",
            "fiso_last_kernel_ms"]
 _lib = None
 _TAIL_CODE = {"N": 0, "S": 1, "E": 2}
@@ -57,12 +57,21 @@ def load():
     L.fiso_last_error.argtypes = [vp]
     L.fiso_consensus.restype = ctypes.c_int
     L.fiso_consensus.argtypes = [vp, ctypes.c_int32] + [vp] * 9
+    L.fiso_consensus_packed.restype = ctypes.c_int
+    L.fiso_consensus_packed.argtypes = L.fiso_consensus.argtypes
     L.fiso_boundary_votes.restype = ctypes.c_int
     L.fiso_boundary_votes.argtypes = [vp, ctypes.c_int32, vp, vp, vp, vp, vp, ctypes.c_int32, vp]
     L.fiso_last_kernel_ms.restype = ctypes.c_int
     L.fiso_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
     _lib = L
     return L
+
+
+def pack_labels(labels):
+    """ASCII labels '0' / '1' / '2' -> two bits each (label g at bits 2(g & 3).. of byte g >> 2)."""
+    v = (np.ascontiguousarray(labels, np.uint8) & 3).astype(np.uint8)
+    v = np.concatenate([v, np.zeros((-len(v)) % 4, np.uint8)]).reshape(-1, 4)
+    return (v[:, 0] | (v[:, 1] << 2) | (v[:, 2] << 4) | (v[:, 3] << 6)).astype(np.uint8)
 
 
 def _ptr(a):
@@ -83,7 +92,9 @@ class Context:
         self._L.fiso_last_kernel_ms(self._h, ctypes.byref(v))
         self.kernel_ms += v.value
 
-    def consensus(self, iso_read_off, n_seg, read_lab_off, labels, tail):
+    def consensus(self, iso_read_off, n_seg, read_lab_off, labels, tail, packed=False):
+        """packed: ``labels`` holds two bits per label (pack_labels() / the segmentation stage's packed results);
+        read_lab_off counts labels either way."""
         n_iso = len(n_seg)
         a = [np.ascontiguousarray(iso_read_off, np.int64), np.ascontiguousarray(n_seg, np.int32), None,
              np.ascontiguousarray(read_lab_off, np.int64), np.ascontiguousarray(labels, np.uint8),
@@ -92,7 +103,7 @@ class Context:
         np.cumsum(a[1], out=a[2][1:])
         S = int(a[2][-1])
         cons = np.zeros(max(S, 1), np.int32); cov = np.zeros(max(S, 1), np.int32); tails = np.zeros(3 * n_iso, np.int32)
-        rc = self._L.fiso_consensus(self._h, n_iso, _ptr(a[0]), _ptr(a[1]), _ptr(a[2]), _ptr(a[3]), _ptr(a[4]), _ptr(a[5]),
+        rc = (self._L.fiso_consensus_packed if packed else self._L.fiso_consensus)(self._h, n_iso, _ptr(a[0]), _ptr(a[1]), _ptr(a[2]), _ptr(a[3]), _ptr(a[4]), _ptr(a[5]),
                                     cons.ctypes.data, cov.ctypes.data, tails.ctypes.data)
         if rc != 0:
             raise IsoformsError("fiso_consensus: " + self._L.fiso_last_error(self._h).decode())

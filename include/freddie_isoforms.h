@@ -39,6 +39,13 @@ int fiso_consensus(fiso_ctx *c, int32_t n_iso, const int64_t *iso_read_off, cons
                    const int64_t *read_lab_off, const uint8_t *labels, const uint8_t *tail,
                    int32_t *cons_out, int32_t *cov_out, int32_t *tails_out);
 
+/* The same with the labels at two bits each, in the layout fseg_results_packed() (include/freddie_seg.h) delivers: label g of
+ * the arena = bits 2(g & 3).. of labels2[g >> 2], code = ASCII & 3; read_lab_off still counts labels.  A quarter of the bytes
+ * across PCIe and out of HBM; for a producer that holds the packed form (the text TSVs the stages exchange hold bytes). */
+int fiso_consensus_packed(fiso_ctx *c, int32_t n_iso, const int64_t *iso_read_off, const int32_t *n_seg, const int64_t *iso_seg_off,
+                          const int64_t *read_lab_off, const uint8_t *labels2, const uint8_t *tail,
+                          int32_t *cons_out, int32_t *cov_out, int32_t *tails_out);
+
 /* correct_boundaries() votes for one side (py/freddie_isoforms.py:129-137).  Isoform i owns the (ascending) boundaries
  * iso_bound[iso_b_off[i] .. iso_b_off[i+1]); read r owns read_bound[read_b_off[r] .. read_b_off[r+1]).
  * votes_out[(iso_b_off[i] + idx) * (2 * window + 1) + (x + window)] = number of (read, boundary) of isoform i with

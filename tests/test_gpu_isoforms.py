@@ -88,6 +88,23 @@ def test_random_stage_inputs_match_the_oracle(ctx):
         assert sum("starts" in i for ia, _, _ in a for i in ia.values()) > 100
 
 
+def test_packed_labels_give_the_same_counts(ctx):
+    """fiso_consensus_packed (labels at two bits each, rows of any length and at any bit offset) == fiso_consensus."""
+    rng = np.random.default_rng(9)
+    n_seg = rng.integers(1, 300, 37)
+    per = rng.integers(0, 40, 37)
+    iro = np.concatenate([[0], np.cumsum(per)])
+    R = int(iro[-1])
+    rows = [rng.choice(np.frombuffer(b"0012", np.uint8), size=int(n_seg[i]), p=[0.3, 0.3, 0.3, 0.1]) for i in range(37) for _ in range(int(per[i]))]
+    lab = np.concatenate(rows)
+    off = np.concatenate([[0], np.cumsum([len(r) for r in rows])])[:-1]
+    tail = rng.integers(0, 3, R).astype(np.uint8)
+    a = ctx.consensus(iro, n_seg, off, lab, tail)
+    b = ctx.consensus(iro, n_seg, off, isoforms.pack_labels(lab), tail, packed=True)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    assert a[1].sum() > 0
+
+
 def test_counts_are_plain_sums(ctx):
     """Property at a size the Python oracle is too slow for: 200 k reads; cov >= cons, per-isoform tails add up to the reads
     that cover something, votes add up to the (read boundary, isoform boundary) pairs inside the window (numpy check)."""
