@@ -174,3 +174,27 @@ def test_upload_rejects_what_read_split_asserts(gpu_ctx):
             gpu_ctx.download()
     util.run_gpu(gpu_ctx, [good])                                 # the context is still usable
     util.compare_partitions(gpu_ctx, [good], [util.run_oracle(good)])
+
+
+@pytest.mark.parametrize("env", [{}, {"FSEG_NO_TINY": "1"}, {"FSEG_TINY_FROM": "0"}], ids=["default", "no-k_tiny", "k_tiny"])
+def test_windows_wider_than_sixteen_bits(env, monkeypatch):
+    """Problems whose window spans more than 65 535 positions (a long unspliced interval): coverage and thresholds beyond
+    16 bits, in every size class, alone and inside a larger batch.  (16-bit coverage rows in the fused solver were tried for
+    their smaller LDS footprint and lost 5 %; this is the case they would have needed a second path for.)"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    wide = [util.wide_window_partition(s, per_cluster=pc) for s, pc in ((0, 4), (1, 8), (2, 16), (3, 28))]
+    oracles = [util.run_oracle(p) for p in wide]
+    spans = []
+    for o in oracles:
+        c = o["cands"]
+        spans.append(max((int(c[e] - c[s]), int(e - s + 1)) for s, e in zip(o["prob_start"], o["prob_end"])))
+    assert all(sp[0] >= 65536 for sp in spans), spans
+    assert max(sp[1] for sp in spans) > 32 and min(sp[1] for sp in spans) <= 8, spans       # every size class has a wide problem
+    ctx = _lib.Context(0)
+    try:
+        check_twice(ctx, [wide[1]], [oracles[1]])                       # a small batch: one launch for every class
+        parts, more = mixed_batch()
+        check_twice(ctx, parts + wide, more + oracles)                  # the per-class launches
+    finally:
+        ctx.close()

@@ -86,3 +86,27 @@ def pack_labels(labels_ascii):
     v = (np.asarray(labels_ascii, np.uint8) - 48) & 3
     v = np.concatenate([v, np.zeros((-len(v)) % 4, np.uint8)]).reshape(-1, 4)
     return (v[:, 0] | (v[:, 1] << 2) | (v[:, 2] << 4) | (v[:, 3] << 6)).astype(np.uint8)
+
+
+def wide_window_partition(seed, n_reads=150, per_cluster=4):
+    """One long (unspliced) interval with three far-apart clusters of exon boundaries: DP problems whose first and last
+    candidate are more than 65 535 positions apart, seen by fewer than 256 reads (so the fused solver takes them)."""
+    rng = np.random.default_rng(seed)
+    step = 600 // max(1, per_cluster // 4)
+    cl = lambda base: [base + step * i for i in range(per_cluster + 1)]      # noqa: E731
+    bounds = np.array(cl(0) + cl(71000) + cl(143000) + [179000])
+    long_k = {per_cluster, 2 * per_cluster + 1}
+    off, ts, te = [0], [], []
+    for _ in range(n_reads):
+        k0 = rng.integers(0, per_cluster); k1 = rng.integers(2 * per_cluster + 2, len(bounds) - 1)
+        ks = [k for k in range(k0, k1) if rng.random() < 0.8]
+        if len(ks) < 2:
+            ks = [k0, k1 - 1]
+        for k in ks:
+            a = bounds[k] + rng.integers(0, 3); b = bounds[k + 1] - 1 - rng.integers(0, 3)
+            if k in long_k:
+                b = a + 300
+            ts.append(a + 1000); te.append(b + 1000)
+        off.append(len(ts))
+    return pack.pack_partition(np.array([1000], np.int32), np.array([180000], np.int32), np.array(off, np.int64),
+                               np.array(ts, np.int32), np.array(te, np.int32), dedupe=True)
