@@ -1,4 +1,4 @@
-// Developer probe: latency of one segmentation DP (dp_solve and candidates for replacing it) on tables already in LDS,
+// Developer probe: latency of one segmentation DP (dp_solve_push, per thread count and table width) on tables already in LDS,
 // alone on the GPU and with every CU busy with the same work; results are checked against a plain host DP.
 // Build: hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -DFSEG_SCORE_TIMING -I include tools/probes/dp_probe.hip freddie_amd/csrc/freddie_seg_sort.hip -o tools/probes/dp_probe.bin
 #include "../../freddie_amd/csrc/freddie_seg.hip"
@@ -15,9 +15,6 @@ __global__ void __launch_bounds__(T) k_dp_probe(int n, const OutT *out_g, const 
     OutT *out_s = reinterpret_cast<OutT *>(in_s + npairs);
     unsigned char *A = reinterpret_cast<unsigned char *>(out_s + ((ntri + 3) & ~3));
     __shared__ int cy_s[64];
-    __shared__ V part_v[T];
-    __shared__ unsigned char part_a[T];
-    __shared__ int top_key[T / 64];
     for (int i = threadIdx.x; i < n; i += T) cy_s[i] = cy_g[i];
     for (int i = threadIdx.x; i < npairs; i += T) in_s[i] = in_g[i];
     for (int i = threadIdx.x; i < ntri; i += T) out_s[i] = out_g[i];
@@ -26,8 +23,7 @@ __global__ void __launch_bounds__(T) k_dp_probe(int n, const OutT *out_g, const 
     unsigned long long dt_prev = t0;
     int chain = 0;
     for (int r = 0; r < reps; ++r) {
-        if (VARIANT == 0) chain = 0;
-        else chain = dp_solve_push<T, NM>(n, out_s, in_s, M, A, cy_s, support, chosen_g + (size_t)blockIdx.x * 64 FSEG_DARG);
+        chain = dp_solve_push<T, NM>(n, out_s, in_s, M, A, cy_s, support, chosen_g + (size_t)blockIdx.x * 64 FSEG_DARG);
         __syncthreads();
     }
     long long t1 = wall_clock64();
@@ -158,22 +154,16 @@ int main() {
         HostDp ref = host_dp(n, out, in, cy, support);
         printf("host: n=%d chain %d\n", n, ref.chain);
         if (n > 32) {
-            run<512, unsigned char, int, 0, 60>("dp_solve<512,u8,int>", n, out, in, cy, support, ref);
             run<512, unsigned char, int, 1, 60>("dp_solve_push<512,60,u8,int>", n, out, in, cy, support, ref);
-            run<512, unsigned short, i64, 0, 60>("dp_solve<512,u16,i64>", n, out, in, cy, support, ref);
             run<512, unsigned short, i64, 1, 60>("dp_solve_push<512,60,u16,i64>", n, out, in, cy, support, ref);
             run<1024, unsigned short, i64, 1, 60>("dp_solve_push<1024,60,u16,i64>", n, out, in, cy, support, ref);
         } else if (n > 16) {
-            run<256, unsigned char, int, 0, 32>("dp_solve<256,u8,int>", n, out, in, cy, support, ref);
             run<256, unsigned char, int, 1, 32>("dp_solve_push<256,32,u8,int>", n, out, in, cy, support, ref);
             run<512, unsigned char, int, 1, 32>("dp_solve_push<512,32,u8,int>", n, out, in, cy, support, ref);
         } else if (n > 8) {
-            run<128, unsigned char, int, 0, 16>("dp_solve<128,u8,int>", n, out, in, cy, support, ref);
             run<128, unsigned char, int, 1, 16>("dp_solve_push<128,16,u8,int>", n, out, in, cy, support, ref);
-            run<64, unsigned char, int, 0, 16>("dp_solve<64,u8,int>", n, out, in, cy, support, ref);
             run<64, unsigned char, int, 1, 16>("dp_solve_push<64,16,u8,int>", n, out, in, cy, support, ref);
         } else {
-            run<64, unsigned char, int, 0, 8>("dp_solve<64,u8,int>", n, out, in, cy, support, ref);
             run<64, unsigned char, int, 1, 8>("dp_solve_push<64,8,u8,int>", n, out, in, cy, support, ref);
         }
     }
