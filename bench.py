@@ -375,8 +375,16 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # FREDDIE_BENCH_BACKEND=gloo: rehearsal of the multi-rank flow on a box with fewer GPUs than ranks (the ranks share
+        # the GPUs there are); the driver's runs use RCCL, one GPU per rank
+        backend = os.environ.get("FREDDIE_BENCH_BACKEND", "nccl")
+        if backend == "gloo":
+            local_rank = local_rank % max(1, torch.cuda.device_count())
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(local_rank)
 
@@ -434,7 +442,8 @@ def main():
     dt = time.perf_counter() - t0
     n_reads = sum(batches[bi].n_reads for bi in order)
 
-    t = torch.tensor([dt, float(n_reads)], dtype=torch.float64, device="cuda")
+    t = torch.tensor([dt, float(n_reads)], dtype=torch.float64,
+                     device="cpu" if dist is not None and dist.get_backend() == "gloo" else "cuda")
     if dist is not None:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
