@@ -315,8 +315,9 @@ def scoring_roofline(alg_bytes, score_ms, committed, extra=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=96, help="timed steps (a step is ~1.4 ms: fewer than ~50 and the six-context "
+                    "pipeline's fill and drain show)")
+    ap.add_argument("--warmup", type=int, default=12)
     ap.add_argument("--workload", default="config4", choices=sorted(synth.WORKLOADS) + list(NEXT_ROW_WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip both CPU-oracle legs")
     ap.add_argument("--no-e2e", action="store_true", help="skip the CLI end-to-end leg")
