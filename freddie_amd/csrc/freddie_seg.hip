@@ -3647,7 +3647,7 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
     // the function returns, so a capture of the main stream ends with all branches merged.
     // Small batches (one partition, few problems) are chains of launch-latency-sized kernels: branches only add
     // cross-stream dependencies there (measured: config2 +4 %), so they stay on the one stream.
-    const bool forking = c->use_fork && !c->small_batch && !others_in_flight(c);
+    const bool forking = c->use_fork && !c->small_batch && !others_in_flight(c) && c->side[0] != nullptr;
     const int tiny_max = c->tiny_on ? kTiny : 0;
     const ProbSplit split{tiny_max, (c->use_fuse && c->fuse_on) ? kFuseLanes : -1};
     // list sizes known (the batch has been sized or has run): launches over an empty list are left out
@@ -4225,7 +4225,9 @@ int fseg_create(int device, fseg_ctx **out) {
     if (e == hipSuccess) e = hipMemsetAsync(c->d_tacc.p, 0, kTaccBytes, c->stream);
     for (int i = 0; e == hipSuccess && i < ST_COUNT; ++i) { e = hipEventCreate(&c->ev_b[i]); if (e == hipSuccess) e = hipEventCreate(&c->ev_e[i]); }
     for (int i = 0; e == hipSuccess && i < 4; ++i) e = hipEventCreate(&c->ev_g[i]);
-    for (int i = 0; e == hipSuccess && i < fseg_ctx::kSide; ++i) e = hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking);
+    // (the side streams are created by the first run that forks: the runtime spreads a process's streams over its few
+    //  hardware queues in creation order, and contexts that take turns on a device use their main streams only -- created
+    //  back to back, those land on different queues)
     for (int i = 0; e == hipSuccess && i < fseg_ctx::kForkEvents; ++i) e = hipEventCreateWithFlags(&c->fj[i], hipEventDisableTiming);
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_score<kNMax>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -4605,6 +4607,16 @@ int fseg_run(fseg_ctx *c) {
     if (c->pending) TRY(finish_run(c));
     c->fetched = false;
     set_in_flight(c, true);
+    if (c->use_fork && !c->side[0] && !others_in_flight(c)) {
+        hipStream_t made[fseg_ctx::kSide] = {};
+        hipError_t e = hipSuccess;
+        for (int i = 0; e == hipSuccess && i < fseg_ctx::kSide; ++i) e = hipStreamCreateWithFlags(&made[i], hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            for (hipStream_t m : made) if (m) (void)hipStreamDestroy(m);
+            return fail(c, FSEG_ERR_HIP, "hipStreamCreateWithFlags: %s", hipGetErrorString(e));
+        }
+        for (int i = 0; i < fseg_ctx::kSide; ++i) c->side[i] = made[i];
+    }
     // first run of a batch: piecewise with exact arena sizes; afterwards the sizes are known and the same launch
     // sequence is replayed (as a hipGraph unless disabled)
     if (!c->ran && c->use_sized) return run_sized(c);
