@@ -541,18 +541,31 @@ __global__ void __launch_bounds__(256) k_scan_emit(const unsigned char *flags, i
     i64 nb = (n + kScanBlock - 1) / kScanBlock;
     if (MODE == kEmitPositions) {
         // sparse flags (about one position in a hundred): every thread owns 32 consecutive positions and only the
-        // threads that hold a flag do any work
+        // threads that hold a flag do any work.  The intervals the block's positions lie in (first interval of this block ..
+        // first interval of the next) are staged in LDS with one coalesced load: a flagged thread's interval search and its
+        // three look-ups would otherwise be a chain of five or six dependent global loads, which is what this kernel ran at.
+        constexpr int kIvStage = 768;
+        __shared__ i64 po_s[kIvStage + 1];
+        __shared__ int is_s[kIvStage];
         {
             const i64 b = blockIdx.x;                                // grid == nb
+            const i64 ka0 = blk_iv0[b], kb0 = (i64)blk_iv0[b + 1] + 1;      // intervals [ka0, kb0) (kb0 <= K)
+            const int niv = (int)(kb0 - ka0);
+            const bool staged = niv <= kIvStage;
+            if (staged) {
+                for (int x = threadIdx.x; x <= niv; x += blockDim.x) po_s[x] = pos_off[ka0 + x];
+                for (int x = threadIdx.x; x < niv; x += blockDim.x) is_s[x] = iv_start[ka0 + x];
+            }
             i64 i0 = b * kScanBlock + (i64)threadIdx.x * 32;
             Flags32 f;
             int s = 0;
             if (i0 < n) { f = load_flags32(flags, i0, n); s = count_flags32(f); }
             int tot;
-            int ex = wg_exclusive_scan(s, lds, &tot);
+            int ex = wg_exclusive_scan(s, lds, &tot);                // (its barriers also publish the staged table)
             ex += bsum ? bsum[b] : (int)scan_lookback(state, b, nb, tot, &bcast, total_out, off_last, err);
             if (s) {
                 i64 k = -1, k_end = 0, k_base = 0;
+                int k_start = 0;
                 for (int q = 0; q < 8; ++q) {
                     unsigned w = f.w[q];
                     while (w) {
@@ -561,13 +574,19 @@ __global__ void __launch_bounds__(256) k_scan_emit(const unsigned char *flags, i
                         i64 i = i0 + q * 4 + e;
                         if (k < 0 || i >= k_end) {
                             // the interval of position i lies between the first intervals of this and the next block
-                            const i64 ka = k < 0 ? blk_iv0[b] : k + 1, kb = (i64)blk_iv0[b + 1] + 1;
-                            k = ka + last_le(pos_off + ka, kb - ka, i);
-                            k_base = pos_off[k]; k_end = pos_off[k + 1];
+                            const i64 ka = k < 0 ? ka0 : k + 1;
+                            if (staged) {
+                                const int a = (int)(ka - ka0);
+                                const int kk = a + (int)last_le(po_s + a, (i64)(niv - a), i);
+                                k = ka0 + kk; k_base = po_s[kk]; k_end = po_s[kk + 1]; k_start = is_s[kk];
+                            } else {
+                                k = ka + last_le(pos_off + ka, kb0 - ka, i);
+                                k_base = pos_off[k]; k_end = pos_off[k + 1]; k_start = iv_start[k];
+                            }
                         }
                         int yy = (int)(i - k_base);
                         out_y[ex] = yy;
-                        if (out_pos) out_pos[ex] = iv_start[k] + yy;
+                        if (out_pos) out_pos[ex] = k_start + yy;
                         if (out_iv) out_iv[ex] = (int)k;
                         if (yy == 0) out_off[k] = ex;
                         ++ex;
