@@ -517,26 +517,28 @@ def main():
             # stretches every kernel's event bracket)
             out["roofline_serial"] = scoring_roofline(batches[0].alg_bytes, sc / reps, committed,
                                                       {"measured": "one context, one resident batch replayed: the stage alone on the GPU"})
-            # (b) inputs resident in HBM before the timed part, every batch run ONCE on the first-run path
-            extra = [_lib.Context(local_rank) for _ in range(n_b)]
-            try:
-                for c2, b in zip(extra, batches):
-                    c2.set_params(**params, **tabs)
-                    c2.upload(**b.arrays)
-                    c2.sync()
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for c2 in extra:
-                    c2.run()
-                for c2 in extra:
-                    c2.sync()
-                dt_h = time.perf_counter() - t0
-            finally:
-                for c2 in extra:
-                    c2.close()
-            out["value_hbm_resident"] = {"value": sum(b.n_reads for b in batches) / dt_h, "unit": "reads/s", "ms_per_step": dt_h / n_b * 1e3,
-                                         "what": "%d distinct batches uploaded first (one context each), then each run once: first-run "
-                                                 "path (sized arenas, plain launches), results left in HBM, no copies in the timed part" % n_b}
+            # (b) inputs resident in HBM before the timed part, every batch run ONCE on the first-run path: one batch per
+            #     context uploaded, then all of them run (one host thread per context, as in the timed steps), results left in HBM
+            n_h = min(len(ctxs), n_b)
+            for c2, b in zip(ctxs[:n_h], batches):
+                c2.upload(**b.arrays)
+                c2.sync()
+            torch.cuda.synchronize()
+
+            def run_one(c2):
+                c2.run()
+                c2.sync()
+            th = [threading.Thread(target=run_one, args=(c2,)) for c2 in ctxs[:n_h]]
+            t0 = time.perf_counter()
+            for t_ in th:
+                t_.start()
+            for t_ in th:
+                t_.join()
+            dt_h = time.perf_counter() - t0
+            out["value_hbm_resident"] = {"value": sum(b.n_reads for b in batches[:n_h]) / dt_h, "unit": "reads/s", "ms_per_step": dt_h / n_h * 1e3,
+                                         "what": "%d distinct batches uploaded first (one per context), then each run once, concurrently: "
+                                                 "first-run path (sized arenas, plain launches), results left in HBM, no copies in the "
+                                                 "timed part" % n_h}
             # (c) BASELINE configs[1]: one 50 k-read partition
             if config2_batch is not None:
                 ctx.upload(**config2_batch.arrays)

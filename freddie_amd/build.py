@@ -71,7 +71,7 @@ def is_current(target, cmd, sources):
 
 def seg_command():
     return ["hipcc", "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-shared", "-fPIC", "-I", INCLUDE,
-            "-o", SEG_SO] + SEG_SRC
+            "-o", SEG_SO] + SEG_SRC + ["-lhsa-runtime64"]
 
 
 def build_seg(force=False, verbose=False):

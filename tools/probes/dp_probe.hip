@@ -1,6 +1,6 @@
 // Developer probe: latency of one segmentation DP (dp_solve_push, per thread count and table width) on tables already in LDS,
 // alone on the GPU and with every CU busy with the same work; results are checked against a plain host DP.
-// Build: hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -DFSEG_SCORE_TIMING -I include tools/probes/dp_probe.hip freddie_amd/csrc/freddie_seg_sort.hip -o tools/probes/dp_probe.bin
+// Build: hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -DFSEG_SCORE_TIMING -I include tools/probes/dp_probe.hip freddie_amd/csrc/freddie_seg_sort.hip -lhsa-runtime64 -o tools/probes/dp_probe.bin
 #include "../../freddie_amd/csrc/freddie_seg.hip"
 #include <vector>
 #include <random>

@@ -1,6 +1,6 @@
 """Diagnostic only: phase shares inside k_solve (and its DP) from a -DFSEG_SCORE_TIMING build.  Never used for reported numbers.
     hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -shared -fPIC -I include -DFSEG_SCORE_TIMING -o freddie_amd/libfreddie_seg_timing.so \
-        freddie_amd/csrc/freddie_seg.hip freddie_amd/csrc/freddie_seg_sort.hip
+        freddie_amd/csrc/freddie_seg.hip freddie_amd/csrc/freddie_seg_sort.hip -lhsa-runtime64
     FSEG_LIB=$PWD/freddie_amd/libfreddie_seg_timing.so python tools/solve_timing.py [workload]"""
 import ctypes, os, sys
 import numpy as np
