@@ -3125,7 +3125,8 @@ __global__ void __launch_bounds__(256) k_label_reads(int n_blocks, const int *rb
 // packed to two bits per label before it leaves (k_pack_labels; label byte g of the arena = bits 2(g & 3) .. of packed byte
 // g >> 2) and the host writer unpacks rows straight into the TSV it is assembling (fhost_write_packed).
 // (A copy kernel of our own that streams to pinned memory with a small grid was tried instead of the runtime's copy: it
-// slows kernels of the other context of the pipeline 3x while it runs, the runtime's copy only 1.3x.)
+// slows kernels of the other contexts of the pipeline 3x while it runs.  The runtime's own large copies are kernels too --
+// see sdma_d2h() for what replaces them.)
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_pack_labels(const uint4 *__restrict__ labels16, unsigned *__restrict__ packed, i64 n16) {
     for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (i64)gridDim.x * blockDim.x) {
