@@ -5,7 +5,7 @@ A *step* is one pass of the hot path over one batch (about 250 k reads) of synth
 drop-in CLI does it: ``fseg_upload`` (host arrays -> HBM) -> ``fseg_run`` -> ``fseg_results_packed`` (results in host memory:
 final positions, and the label matrix at two bits per label, which is the form the native writer takes).
 Consecutive steps take DISTINCT batches (the default workload, config4, is the whole 2 M-read / 4 000-partition job in 8
-batches) and alternate between the contexts of the GPU (six by default), so one batch's copies overlap the others' kernels; no step
+batches) and alternate between the contexts of the GPU (eight by default), so one batch's copies overlap the others' kernels; no step
 replays a resident batch.  ``value`` = reads segmented by all ranks / max-over-ranks wall time of the timed steps
 (host memory to host memory; reference unit of work: run_segment, py/freddie_segment.py:681-735, minus the file I/O
 which the ``e2e`` leg adds).
@@ -323,8 +323,8 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the CLI end-to-end leg")
     ap.add_argument("--no-extras", action="store_true", help="skip config2's roofline, the replay and the HBM-resident legs")
     ap.add_argument("--e2e-reads", type=int, default=2000000, help="reads of the end-to-end job (default: the whole 2 M-read job)")
-    ap.add_argument("--contexts", type=int, default=6, help="contexts per GPU the steps alternate between (each on one stream while "
-                    "the others have work in flight; 3: -10 %, more than 6: no better)")
+    ap.add_argument("--contexts", type=int, default=8, help="contexts per GPU the steps alternate between (each on one stream while "
+                    "the others have work in flight: two per hardware queue; 4: -20 %, 16: -30 %)")
     args = ap.parse_args()
     if args.workload in NEXT_ROW_WORKLOADS:
         return run_next_row(args)
@@ -441,7 +441,9 @@ def main():
             alg_total[0] += batches[bi].alg_bytes
             checksum[0] += int(res[1][-1]) + int(res[3][-1])          # the results are in host memory: touch them
 
-    order = [(n_warm + i) % n_b for i in range(args.steps)]
+    # (step i goes to context i mod C; the extra term keeps a context from meeting the same batch every time when C divides
+    #  the number of distinct batches)
+    order = [(n_warm + i + i // len(ctxs)) % n_b for i in range(args.steps)]
     barrier()
     t0 = time.perf_counter()
     one_shot_steps(ctxs, batches, order, collect)
