@@ -54,6 +54,7 @@ SWITCHES = [
     {"FSEG_GLOBAL_SORT": "1"},                              # the batch-wide radix sort of the reps instead of the in-LDS sort per partition
     {"FSEG_PROB_SELF_MAX": "0"},                            # the problem list always through the block-sum scan
     {"FSEG_PROB_SELF_MAX": "100000000"},                    # ... and always through the self-scanning emit kernel
+    {"FSEG_NO_SDMA_D2H": "1"},                              # results through the runtime's copy instead of the SDMA engine
 ]
 
 
@@ -198,3 +199,42 @@ def test_windows_wider_than_sixteen_bits(env, monkeypatch):
         check_twice(ctx, parts + wide, more + oracles)                  # the per-class launches
     finally:
         ctx.close()
+
+
+def test_contexts_taking_turns_on_one_device():
+    """What the CLI and the benchmark do: several contexts of one device, one host thread each, batches in flight at the same
+    time (a context then keeps to its one stream; the later contexts have no side streams at all; the label matrix leaves
+    through the SDMA engine from several threads).  Every batch must come back as if it had run alone."""
+    import threading
+    n_ctx, rounds = 4, 3
+    batches = []
+    for b in range(n_ctx * rounds):
+        parts = [util.make_partition(3000 + 17 * b + i, n_reads=150 + 40 * ((b + i) % 5), n_exons=40 + 10 * (i % 4), rp=0.05 * (i % 3))
+                 for i in range(6)]
+        batches.append((parts, [util.run_oracle(p) for p in parts]))
+    ctxs = [_lib.Context(0) for _ in range(n_ctx)]
+    errors = []
+
+    def worker(k):
+        try:
+            for r in range(rounds):
+                parts, oracles = batches[r * n_ctx + k]
+                util.run_gpu(ctxs[k], parts)
+                rep = util.compare_partitions(ctxs[k], parts, oracles)
+                assert rep["y_identical"]
+                packed = ctxs[k].results(packed=True)
+                assert np.array_equal(packed[3], util.pack_labels(ctxs[k].download()[3]))
+        except BaseException as exc:                              # noqa: BLE001
+            errors.append(exc)
+
+    try:
+        th = [threading.Thread(target=worker, args=(k,)) for k in range(n_ctx)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        if errors:
+            raise errors[0]
+    finally:
+        for c in ctxs:
+            c.close()
