@@ -480,7 +480,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u32",
-            "dtype_detail": "u32 bit-planes + popcount for scoring, int64 DP, f64 Gaussian smoothing / threshold",
+            "dtype_detail": "u32 bit-planes + popcount for scoring, int32 (int64 for very large partitions) DP sums, f64 Gaussian smoothing / threshold",
             "data": "synthetic",
             "value_is": "host memory -> host memory: fseg_upload + fseg_run + fseg_results_packed per step, distinct batches, "
                         "%d contexts per GPU (no resident replay)" % len(ctxs),
