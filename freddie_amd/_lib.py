@@ -57,7 +57,8 @@ EXPORTS = ["fseg_abi_version", "fseg_source_hash", "fseg_results", "fseg_results
 TAPS = dict(pos_off=(1, np.int64), y_raw=(2, np.int32), y=(3, np.float64), threshold=(4, np.float64),
             cand_off=(5, np.int64), cand_y=(6, np.int32), fixed=(7, np.uint8), chosen=(8, np.uint8),
             final_off=(9, np.int64), final_y=(10, np.int32), problems=(11, np.int32),
-            lane_start=(12, np.int32), lane_pmax=(13, np.int32), lane_exons=(14, np.int64))
+            lane_start=(12, np.int32), lane_pmax=(13, np.int32), lane_exons=(14, np.int64),
+            lane_stream=(15, np.int32), exon_stream=(16, np.int32))
 
 
 def lib_path():
@@ -221,7 +222,7 @@ class Context:
         out = np.empty(n.value // np.dtype(dtype).itemsize, dtype)
         if n.value:
             self._check(self._L.fseg_tap(self._h, what, out.ctypes.data, n.value, ctypes.byref(n)), "fseg_tap")
-        return out.reshape(-1, 4) if name == "problems" else (out.reshape(-1, 2) if name == "lane_exons" else out)
+        return out.reshape(-1, 4) if name == "problems" else (out.reshape(-1, 2) if name in ("lane_exons", "lane_stream", "exon_stream") else out)
 
     def set_profiling(self, on):
         """True / 1: HIP events around every stage; 2: around the interval-scoring stage only; False: none."""

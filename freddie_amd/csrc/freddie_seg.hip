@@ -14,6 +14,7 @@
 //
 // No CPU fallback exists in this library: without a GPU fseg_create() fails.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <hsa/hsa.h>
 #include <hsa/hsa_ext_amd.h>
 #include <chrono>
@@ -958,6 +959,7 @@ __device__ __forceinline__ int2 load_exons2(const int *p) {
     return make_int2(a.x, a.y);
 }
 constexpr size_t kExonPad = 32;        // bytes behind ex_ts / ex_te
+constexpr size_t kLexPad = 64;         // bytes behind the lane-ordered exon stream (it is read in aligned 16-byte units)
 
 // A value every lane of the wave holds identically, moved to a scalar register: what is computed from it (triangular
 // table offsets, loop bounds, LDS base addresses) then runs on the scalar unit instead of costing every lane a multiply.
@@ -1133,10 +1135,14 @@ __device__ __forceinline__ int size_class(int n) { return n <= kClsSmall ? 0 : (
 //     DP without leaving LDS); a problem slot and an entry in its size class's solve list;
 //   otherwise: the arena path -- coverage tiles, one scoring work item per 256 reads, global count tables, DP kernels
 //     (problems that see many reads need many workgroups to score them).
-struct ProbSplit { int tiny_max, fuse_lanes; };
+//   with the wave kernels (k_wave: the batch has its exon stream) the small class -- n <= wave_n -- is solved whole, one wave
+//     per problem, whenever the problem sees at most wave_lanes reads, whatever the rest of the batch looks like.
+struct ProbSplit { int tiny_max, fuse_lanes, wave_n, wave_lanes; };
 enum { kKindArena = 0, kKindTiny = 1, kKindFused = 2 };
 __device__ __forceinline__ int prob_kind(int n, int n_lanes, ProbSplit sp) {
-    return n <= sp.tiny_max ? kKindTiny : ((n_lanes <= sp.fuse_lanes && n <= kNMax) ? kKindFused : kKindArena);
+    if (n <= sp.tiny_max) return kKindTiny;
+    if (n <= sp.wave_n && n_lanes <= sp.wave_lanes) return kKindFused;
+    return (n_lanes <= sp.fuse_lanes && n <= kNMax) ? kKindFused : kKindArena;
 }
 __device__ __forceinline__ ProbSizes prob_sizes(int n, int n_lanes, ProbSplit sp) {
     ProbSizes s;
@@ -2267,6 +2273,224 @@ __global__ void __launch_bounds__(256, FSEG_TINY_OCC) k_tiny(Status *st, const P
 }
 
 // ---------------------------------------------------------------------------------------------
+// S5 whole by ONE WAVE per problem, for problems of at most NM candidates (NM = 8: the tiny list, NM = 16: solve list 0) --
+// k_tiny's plan with the loads made cheap.  k_tiny and k_solve fetch a read's exons with one gather per lane (64 cache lines
+// per load instruction, and the texture path takes them one by one: that rate, not HBM or the ALUs, is what they run at) and
+// every problem is a chain of such gathers.  Here the exons come from the lane-ordered stream `lex` (k_lanes): the reads a
+// round examines -- up to 64 consecutive lanes -- own ONE contiguous piece of it, which the wave copies into LDS with
+// lane-consecutive 16-byte loads; everything after that is LDS and registers:
+//   per round: every lane finds the exons of its read that meet the window (ordered, so they are consecutive) and sums
+//     their overlaps with [cand_0, cand_j) -- window coverage (get_cumulative_coverage :188-246) in registers, lane = read;
+//     pair labels (:488-497): the 64 reads' bits of a pair's plane are one v_cmp, kept by lane q for pair q; in / out counts
+//     (:500-528) with lane t owning triples t, t + 64, ..;
+//   then dp_solve_push<64> (:532-566, :592-594) on wave-private tables.
+// A read of the lane range without coverage in the window is scored like any other (all `nay`; ambiguous where lo < 0).
+// No workgroup barrier anywhere; four waves = four problems per workgroup.
+// ---------------------------------------------------------------------------------------------
+// acc's lane `lane` := the wave-uniform value v (v_writelane_b32; this compiler has no builtin for it)
+// (the lane number has to be an inline constant: a second scalar register would break the one-scalar-operand rule)
+template <int LANE> __device__ __forceinline__ void write_lane(unsigned &acc, unsigned v) {
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(acc) : "s"(v), "n"(LANE));
+}
+template <int B, int E, typename F> __device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (B < E) { f(std::integral_constant<int, B>{}); static_for<B + 1, E>(f); }
+}
+constexpr int kWaveLanes = 1023;               // reads up to which a small problem is one wave's (16 rounds); beyond, the arena path
+constexpr int kStageCap = 512;                 // exons of one round's reads staged in LDS (a round takes fewer reads if they own more)
+constexpr int kWaveRepExons = kStageCap - 2;   // a batch with a rep of more exons than this keeps k_tiny / k_solve
+template <int NM> struct WaveCfg {
+    static constexpr int kPairs = NM * (NM - 1) / 2, kTri = NM * (NM - 1) * (NM - 2) / 6;
+    static constexpr int kPSlots = (kPairs + 63) / 64, kTSlots = (kTri + 63) / 64;
+#ifndef FSEG_WAVE_OCC8
+#define FSEG_WAVE_OCC8 5
+#endif
+#ifndef FSEG_WAVE_OCC16
+#define FSEG_WAVE_OCC16 4
+#endif
+    static constexpr int kOcc = NM <= 8 ? FSEG_WAVE_OCC8 : FSEG_WAVE_OCC16;
+};
+template <int NM, typename V> struct __align__(16) WaveLds {
+    int2 stage[kStageCap + 4];
+    uint4 planes[WaveCfg<NM>::kPairs];             // {yea lo, yea hi, nay lo, nay hi} of the current round's reads
+    V M[WaveCfg<NM>::kPairs];
+    int in[WaveCfg<NM>::kPairs];
+    unsigned out[WaveCfg<NM>::kTri + 4];
+    unsigned char A[WaveCfg<NM>::kPairs + 8];
+    int cy[NM];
+};
+template <int NM, typename V>
+__global__ void __launch_bounds__(256, WaveCfg<NM>::kOcc) k_wave(Status *st, const ProbDesc *desc, i64 prob_cap, int list, ProblemArrays pr,
+                                                                 const int *__restrict__ cand_y, const int2 *__restrict__ lane_lx, const int2 *__restrict__ lex,
+                                                                 const double *h_table, int h_len, double tau, const int2 *__restrict__ thr_tab,
+                                                                 int support, unsigned char *chosen, const int *__restrict__ solve_items FSEG_TPARAM) {
+    using C = WaveCfg<NM>;
+    __shared__ WaveLds<NM, V> lds4[4];
+    __shared__ unsigned short tri_q[C::kTri + 2];      // triple rank t -> (pair (i,j)) | (pair (j,k)) << 8
+    const int lane = lane_id(), wave = wave_id();
+    WaveLds<NM, V> &L = lds4[wave];
+    for (int t = threadIdx.x; t < C::kTri; t += 256) {
+        int k = 2;
+        while ((k + 1) * k * (k - 1) / 6 <= t) ++k;
+        int i, j;
+        pair_decode(t - k * (k - 1) * (k - 2) / 6, &i, &j);
+        tri_q[t] = (unsigned short)((j * (j - 1) / 2 + i) | ((k * (k - 1) / 2 + j) << 8));
+    }
+    __syncthreads();
+    if ((i64)st->n_prob > prob_cap) return;             // sizing run: the descriptors are incomplete
+#ifdef FSEG_SCORE_TIMING
+    __shared__ unsigned long long tick_sink[16];
+    unsigned long long *dp_tacc = tick_sink; unsigned long long dt_prev = 0;
+#endif
+    // list 3: k_tiny's problems (behind the three solve lists); list 0: the small class
+    const i64 list_base = list == 3 ? (i64)st->solve_cls[0] + (i64)st->solve_cls[1] + (i64)st->solve_cls[2] : 0;
+    const i64 list_n = list == 3 ? (i64)st->n_tiny : (i64)st->solve_cls[0];
+    for (i64 t = (i64)blockIdx.x + (i64)wave * gridDim.x; t < list_n; t += (i64)gridDim.x * 4) {
+#ifdef FSEG_SCORE_TIMING
+        const unsigned long long t_prob0 = wall_clock64();
+#endif
+        const int p = uni(solve_items[list_base + t]);
+        const ProbDesc d = FSEG_LOAD_DESC(desc + p);
+        const int n = d.n;
+        if (n > NM || n < 3) { if (lane == 0) atomicOr(&st->err, kErrOverflowNm); continue; }       // (wave-uniform)
+        const int npairs = n * (n - 1) / 2, ntri = n * (n - 1) * (n - 2) / 6;
+        // two independent loads behind the descriptor: the first round's lane ranges and the candidates
+        int2 lx = lane_lx[d.lane_lo + (lane < d.lane_n ? lane : 0)];
+        const int cyv = cand_y[d.c0 + (lane < n ? lane : 0)];
+        dp_sync<64>();                                  // the previous problem's DP is done with the wave's tables
+        if (lane < n) L.cy[lane] = cyv;
+        int hi_q[C::kPSlots], lo_q[C::kPSlots];
+        unsigned amb[C::kPSlots], outc[C::kTSlots];
+#pragma unroll
+        for (int s = 0; s < C::kPSlots; ++s) {
+            const int q = s * 64 + lane;
+            hi_q[s] = 0x7fffffff; lo_q[s] = -1; amb[s] = 0;
+            const unsigned short ij = g_pair_ij[q < npairs ? q : 0];
+            const int ci = __shfl(cyv, ij & 255), cjv = __shfl(cyv, ij >> 8);
+            if (q < npairs) label_thresholds_tab((i64)cjv - ci + 1, thr_tab, h_table, h_len, tau, &hi_q[s], &lo_q[s]);   // :490-495 as integer bounds
+        }
+#pragma unroll
+        for (int s = 0; s < C::kTSlots; ++s) outc[s] = 0;
+        // the candidates' genomic positions, wave-uniform
+        const int cp0 = d.g0 + __builtin_amdgcn_readlane(cyv, 0), c_last = d.g0 + __builtin_amdgcn_readlane(cyv, n - 1);
+        int cj[NM];
+#pragma unroll
+        for (int j = 0; j < NM; ++j) cj[j] = j < n ? d.g0 + __builtin_amdgcn_readlane(cyv, j) : cp0;      // beyond the problem: an empty window
+        for (int l0 = 0; l0 < d.lane_n;) {
+            const bool in = l0 + lane < d.lane_n;
+            if (l0 > 0) lx = lane_lx[d.lane_lo + l0 + (in ? lane : 0)];
+            // ---- the round's reads: as many of the next 64 lanes as own at most kStageCap exons together (all 64, usually);
+            //      their exons are the stream's piece [base, end of the last one's)
+            const int base = uni(lx.x) & ~1;                                     // (16-byte units)
+            const u64 fm = __ballot(in && lx.y - base <= kStageCap);
+            const int m = ~fm == 0 ? 64 : (int)__builtin_ctzll(~fm);            // the ranges ascend: a prefix of the lanes
+            if (m == 0) { if (lane == 0) atomicOr(&st->err, kErrOverflowNm); break; }     // (the host keeps such batches away)
+            const int total = __builtin_amdgcn_readlane(lx.y, m - 1) - base;
+            {
+                const int last2 = total & ~1;
+                int4 sv[kStageCap / 128];
+#pragma unroll
+                for (int u = 0; u < kStageCap / 128; ++u) {
+                    const int i = 2 * lane + 128 * u;
+                    sv[u] = *reinterpret_cast<const int4 *>(lex + base + (i < last2 ? i : last2));
+                }
+#pragma unroll
+                for (int u = 0; u < kStageCap / 128; ++u) {
+                    const int i = 2 * lane + 128 * u;
+                    if (i < total) *reinterpret_cast<int4 *>(&L.stage[i]) = sv[u];
+                }
+            }
+            dp_sync<64>();
+            const bool valid = lane < m;
+            const u64 vmask = m == 64 ? ~0ULL : ((1ULL << m) - 1ULL);
+            // ---- this lane's read: its exons that meet the window (consecutive: the first with te >= cand_0 up to the last with
+            //      ts < cand_{n-1}), then its window coverage cov[j] = positions of its closed exons in [cand_0, cand_j)
+            //      = sum over those exons of |[ts, te] n [cand_0, cand_j)|
+            const int ea = valid ? lx.x - base : 0, eb = valid ? lx.y - base : 0;
+            int first = ea, cnt = 0;
+            for (int e = ea; e < eb; e += 4) {
+                int2 x[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) x[u] = L.stage[e + u];                 // (beyond the read: masked; the array has room)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool hit = e + u < eb && x[u].y >= cp0 && x[u].x < c_last;
+                    if (hit && cnt == 0) first = e + u;
+                    cnt += hit;
+                }
+                if (x[3].x >= c_last) break;                                       // the rest of the read lies beyond the window
+            }
+            int cov[NM];
+#pragma unroll
+            for (int j = 0; j < NM; ++j) cov[j] = 0;
+            for (int e = 0; e < cnt; e += 2) {
+                const int2 xa = L.stage[first + e], xb = L.stage[first + e + 1];
+                const int a0 = max(xa.x, cp0), b0 = xa.y + 1;                      // closed exon -> half-open end
+                const int a1 = max(xb.x, cp0), b1 = e + 1 < cnt ? xb.y + 1 : a1;   // (an odd count: the second slot is empty)
+#pragma unroll
+                for (int j = 1; j < NM; ++j)
+                    if (j < n) cov[j] += max(0, min(b0, cj[j]) - a0) + max(0, min(b1, cj[j]) - a1);
+            }
+            // ---- pair labels: one compare per plane, the reads' bits arrive as the ballot; lane q keeps pair q's planes
+            unsigned yl[C::kPSlots], yh[C::kPSlots], zl[C::kPSlots], zh[C::kPSlots];
+#pragma unroll
+            for (int s = 0; s < C::kPSlots; ++s) { yl[s] = 0; yh[s] = 0; zl[s] = 0; zh[s] = 0; }
+            static_for<1, NM>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                if (j < n) {                                                       // (wave-uniform)
+                    static_for<0, j>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value;
+                        constexpr int q = j * (j - 1) / 2 + i, s = q >> 6, ql = q & 63;
+                        const int dd = cov[j] - cov[i];
+                        const int hi = __builtin_amdgcn_readlane(hi_q[s], ql), lo = __builtin_amdgcn_readlane(lo_q[s], ql);
+                        const u64 y = __ballot(dd >= hi) & vmask, z = __ballot(dd <= lo) & vmask;
+                        write_lane<ql>(yl[s], (unsigned)y); write_lane<ql>(yh[s], (unsigned)(y >> 32));
+                        write_lane<ql>(zl[s], (unsigned)z); write_lane<ql>(zh[s], (unsigned)(z >> 32));
+                    });
+                }
+            });
+#pragma unroll
+            for (int s = 0; s < C::kPSlots; ++s) {
+                const int q = s * 64 + lane;
+                if (q < npairs) {
+                    amb[s] += (unsigned)(__popc(~(yl[s] | zl[s]) & (unsigned)vmask) + __popc(~(yh[s] | zh[s]) & (unsigned)(vmask >> 32)));   // neither label (:500-506)
+                    L.planes[q] = make_uint4(yl[s], yh[s], zl[s], zh[s]);
+                }
+            }
+            dp_sync<64>();
+            // ---- out(i,j,k) (:509-528): the two labels exclude each other
+#pragma unroll
+            for (int s = 0; s < C::kTSlots; ++s) {
+                const int tt = s * 64 + lane;
+                if (tt < ntri) {
+                    const unsigned tq = tri_q[tt];
+                    const uint4 a = L.planes[tq & 255], b = L.planes[tq >> 8];
+                    outc[s] += (unsigned)(__popc(a.x & b.z) + __popc(a.y & b.w) + __popc(a.z & b.x) + __popc(a.w & b.y));
+                }
+            }
+            dp_sync<64>();
+            l0 += m;
+        }
+        // a read outside the lane range has no coverage in the window: ambiguous exactly where lo < 0 (only tau = 1)
+#pragma unroll
+        for (int s = 0; s < C::kPSlots; ++s) {
+            const int q = s * 64 + lane;
+            if (q < npairs) L.in[q] = -(int)((i64)amb[s] + (lo_q[s] < 0 ? (i64)d.outside : 0));
+        }
+#pragma unroll
+        for (int s = 0; s < C::kTSlots; ++s) {
+            const int tt = s * 64 + lane;
+            if (tt < ntri) L.out[tt] = outc[s];
+        }
+        dp_sync<64>();
+        const int chain = dp_solve_push<64, NM>(n, L.out, L.in, L.M, L.A, L.cy, support, chosen + d.c0 FSEG_DARG);
+        if (lane == 0) pr.chain[p] = chain;
+#ifdef FSEG_SCORE_TIMING
+        if (lane == 0) FSEG_PROB_TICK(p, t_prob0, d.lane_n, d.lane_n);
+#endif
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // S5 whole, for problems that see few reads (at most kFuseLanes -- in batches of many partitions that is every problem: a
 // DP window of a 500-read partition overlaps some 40 .. 130 of them): ONE WORKGROUP takes a problem from its candidates to
 // its chosen breakpoints without leaving LDS --
@@ -3207,18 +3431,20 @@ constexpr int kLaneSortMax = 2048;
 __global__ void __launch_bounds__(256) k_lanes(int n_part, const i64 *part_rep_off, const i64 *part_lane_off, const u64 *key_sorted,
                                                const int *val_sorted, const int *rep_weight, const int *rep_last,
                                                const i64 *rep_exon_off, longlong2 *lane_ex, int *lane_start, int *lane_pmax,
-                                               int sort_here, const u64 *key_unsorted) {
+                                               int sort_here, const u64 *key_unsorted, const int *ex_ts, const int *ex_te,
+                                               int2 *lane_lx, int2 *lex) {
     __shared__ int lds[16];
     __shared__ int wmax[4];
     __shared__ int carry_max_s;
     __shared__ i64 carry_lane_s;
+    __shared__ i64 carry_ex_s;
     __shared__ u64 skey[kLaneSortMax];             // (biased first position << 32 | rep index inside the partition): unique, so
                                                    // the order is the stable order by position
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     for (int p = blockIdx.x; p < n_part; p += gridDim.x) {
         const i64 r0 = part_rep_off[p], r1 = part_rep_off[p + 1];
         __syncthreads();
-        if (threadIdx.x == 0) { carry_max_s = -0x7fffffff - 1; carry_lane_s = part_lane_off[p]; }
+        if (threadIdx.x == 0) { carry_max_s = -0x7fffffff - 1; carry_lane_s = part_lane_off[p]; carry_ex_s = rep_exon_off[r0]; }
         if (sort_here) {
             const int nr = (int)(r1 - r0);
             int N = 1;
@@ -3257,11 +3483,19 @@ __global__ void __launch_bounds__(256) k_lanes(int n_part, const i64 *part_rep_o
             for (int w2 = 0; w2 < wave; ++w2) run = max(run, wmax[w2]);
             m = max(m, run);
             const i64 base = carry_lane_s + ex;
+            // the partition's exons again, in lane order (the exon stream `lex`): a rep's exons start where the exons of
+            // the reps sorted before it end, inside the partition's own exon range
+            const longlong2 exr = in ? make_longlong2(rep_exon_off[r], rep_exon_off[r + 1]) : make_longlong2(0, 0);
+            const int ne = (int)(exr.y - exr.x);
+            int tot_e;
+            const int ex_e = wg_exclusive_scan(ne, lds, &tot_e);
+            const i64 ebase = carry_ex_s + ex_e;
             __syncthreads();
-            if (threadIdx.x == 255) { carry_max_s = m; carry_lane_s = base + w; }
+            if (threadIdx.x == 255) { carry_max_s = m; carry_lane_s = base + w; carry_ex_s = ebase + ne; }
             if (in) {
-                const longlong2 exr = make_longlong2(rep_exon_off[r], rep_exon_off[r + 1]);
-                for (int q = 0; q < w; ++q) { lane_ex[base + q] = exr; lane_start[base + q] = first; lane_pmax[base + q] = m; }
+                const int2 lx = make_int2((int)ebase, (int)(ebase + ne));
+                for (int q = 0; q < w; ++q) { lane_ex[base + q] = exr; lane_start[base + q] = first; lane_pmax[base + q] = m; lane_lx[base + q] = lx; }
+                for (int e = 0; e < ne; ++e) lex[ebase + e] = make_int2(ex_ts[exr.x + e], ex_te[exr.x + e]);
             }
             __syncthreads();
         }
@@ -3274,7 +3508,7 @@ __global__ void __launch_bounds__(256) k_lanes(int n_part, const i64 *part_rep_o
 // positions), an exclusive scan of the totals inside each partition (one wave per partition), and the lanes themselves.
 __global__ void __launch_bounds__(256) k_lane_blocks(int n_blocks, const int *rb_part, const int *rb_r0, const i64 *part_rep_off,
                                                      const int *val_sorted, const int *rep_weight, const int *rep_last,
-                                                     i64 *rb_sum, int *rb_max) {
+                                                     i64 *rb_sum, int *rb_max, const i64 *rep_exon_off, i64 *rb_esum) {
     __shared__ int lds[16];
     __shared__ int wmax[4];
     const int lane = lane_id(), wave = threadIdx.x >> 6;
@@ -3288,28 +3522,34 @@ __global__ void __launch_bounds__(256) k_lane_blocks(int n_blocks, const int *rb
         __syncthreads();
         int tot;
         (void)wg_exclusive_scan(w, lds, &tot);
+        int tot_e;
+        (void)wg_exclusive_scan(in ? (int)(rep_exon_off[r + 1] - rep_exon_off[r]) : 0, lds, &tot_e);
         if (lane == 0) wmax[wave] = m;
         __syncthreads();
-        if (threadIdx.x == 0) { rb_sum[blk] = tot; rb_max[blk] = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3])); }
+        if (threadIdx.x == 0) { rb_sum[blk] = tot; rb_esum[blk] = tot_e; rb_max[blk] = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3])); }
     }
 }
 __global__ void __launch_bounds__(256) k_lane_block_scan(int n_part, int n_blocks, const int *rb_part, const i64 *part_lane_off,
-                                                         const i64 *rb_sum, const int *rb_max, i64 *rb_base, int *rb_cmax) {
+                                                         const i64 *rb_sum, const int *rb_max, i64 *rb_base, int *rb_cmax,
+                                                         const i64 *part_rep_off, const i64 *rep_exon_off, const i64 *rb_esum, i64 *rb_ebase) {
     const int lane = lane_id();
     for (int p = blockIdx.x * 4 + (int)(threadIdx.x >> 6); p < n_part; p += gridDim.x * 4) {
         // the partition's blocks are consecutive in the block list: [first block of p, first block of p + 1)
         int b0 = 0, b1 = n_blocks;
         { int lo = 0, hi = n_blocks; while (lo < hi) { const int mid = (lo + hi) >> 1; if (rb_part[mid] < p) lo = mid + 1; else hi = mid; } b0 = lo; }
         { int lo = b0, hi = n_blocks; while (lo < hi) { const int mid = (lo + hi) >> 1; if (rb_part[mid] <= p) lo = mid + 1; else hi = mid; } b1 = lo; }
-        i64 carry = part_lane_off[p];
+        i64 carry = part_lane_off[p], carry_e = rep_exon_off[part_rep_off[p]];
         int carry_max = -0x7fffffff - 1;
         for (int c0 = b0; c0 < b1; c0 += 64) {
             const int b = c0 + lane;
             const bool in = b < b1;
             const i64 v = in ? rb_sum[b] : 0;
             int m = in ? rb_max[b] : -0x7fffffff - 1;
-            i64 tot;
+            i64 tot, tot_e;
             const i64 ex = wave_excl_scan(v, &tot);
+            const i64 ex_e = wave_excl_scan(in ? rb_esum[b] : 0, &tot_e);
+            if (in) rb_ebase[b] = carry_e + ex_e;
+            carry_e += tot_e;
             for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(m, d); if (lane >= d) m = max(m, y); }      // inclusive running maximum
             int before = __shfl_up(m, 1);
             if (lane == 0) before = -0x7fffffff - 1;
@@ -3322,7 +3562,8 @@ __global__ void __launch_bounds__(256) k_lane_block_scan(int n_part, int n_block
 __global__ void __launch_bounds__(256) k_lane_emit(int n_blocks, const int *rb_part, const int *rb_r0, const i64 *part_rep_off,
                                                    const u64 *key_sorted, const int *val_sorted, const int *rep_weight, const int *rep_last,
                                                    const i64 *rep_exon_off, const i64 *rb_base, const int *rb_cmax,
-                                                   longlong2 *lane_ex, int *lane_start, int *lane_pmax) {
+                                                   longlong2 *lane_ex, int *lane_start, int *lane_pmax, const i64 *rb_ebase,
+                                                   const int *ex_ts, const int *ex_te, int2 *lane_lx, int2 *lex) {
     __shared__ int lds[16];
     __shared__ int wmax[4];
     const int lane = lane_id(), wave = threadIdx.x >> 6;
@@ -3342,10 +3583,15 @@ __global__ void __launch_bounds__(256) k_lane_emit(int n_blocks, const int *rb_p
         int run = rb_cmax[blk];
         for (int w2 = 0; w2 < wave; ++w2) run = max(run, wmax[w2]);
         m = max(m, run);
+        const longlong2 exr = in ? make_longlong2(rep_exon_off[r], rep_exon_off[r + 1]) : make_longlong2(0, 0);
+        const int ne = (int)(exr.y - exr.x);
+        int tot_e;
+        const int ex_e = wg_exclusive_scan(ne, lds, &tot_e);
         if (in) {
-            const i64 base = rb_base[blk] + ex;
-            const longlong2 exr = make_longlong2(rep_exon_off[r], rep_exon_off[r + 1]);
-            for (int q = 0; q < w; ++q) { lane_ex[base + q] = exr; lane_start[base + q] = first; lane_pmax[base + q] = m; }
+            const i64 base = rb_base[blk] + ex, ebase = rb_ebase[blk] + ex_e;
+            const int2 lx = make_int2((int)ebase, (int)(ebase + ne));
+            for (int q = 0; q < w; ++q) { lane_ex[base + q] = exr; lane_start[base + q] = first; lane_pmax[base + q] = m; lane_lx[base + q] = lx; }
+            for (int e = 0; e < ne; ++e) lex[ebase + e] = make_int2(ex_ts[exr.x + e], ex_te[exr.x + e]);
         }
     }
 }
@@ -3458,6 +3704,8 @@ struct fseg_ctx {
         d_hc_part, d_hc_p0, d_hc_n, d_hc_glo, d_hc_ghi;
     // slab_in, derived on the device by the upload
     DevBuf d_lane_ex, d_lane_start, d_lane_pmax, d_hc_llo, d_hc_lhi, d_edge, d_key_a, d_key_b, d_val_a, d_val_b, d_rep_last;
+    DevBuf d_lane_lx, d_lex, d_rb_esum, d_rb_ebase;   // the exons again as one (ts, te) stream in lane order, and every lane's range in it
+    i64 max_rep_exons = 0;       // most exons of one rep in the resident batch
     DevBuf d_w_main, d_w_refine, d_h_table, d_thr_tab;     // parameter tables (own allocations)
     // device buffers: position-sized (slab_pos)
     DevBuf d_y_raw, d_y, d_flag, d_cflag, d_v, d_scan_state, d_bsum, d_bsum_side, d_g, d_pk, d_pf, d_kp, d_final_flag;
@@ -3511,6 +3759,7 @@ struct fseg_ctx {
     hipEvent_t fj[kForkEvents] = {};
     bool use_fork = true;
     bool use_tiny = true;       // FSEG_NO_TINY=1: no problem goes to k_tiny
+    bool use_wave = true;       // FSEG_NO_WAVE=1: k_tiny / k_solve<16> instead of the wave kernels (k_wave)
     bool use_fuse = true;       // FSEG_NO_FUSE=1: no problem goes to k_solve (everything that is not tiny takes the arena path)
     bool fuse_on = true;        // this batch's problems go to k_solve: decided per batch -- when its widest problem sees at most
                                 // kFuseLanes reads, i.e. all of them qualify (measured: a batch of 500-read partitions gains 8 %, while
@@ -3655,6 +3904,14 @@ int alloc_arenas(fseg_ctx *c) {
 // look-back state of the three compactions (values, candidates, final positions): nb words each, zeroed per run
 inline i64 scan_blocks(i64 n) { return (n + kScanBlock - 1) / kScanBlock; }
 
+// the wave kernels need the exon stream's pieces to fit their LDS stage (k_wave): a batch with a rep of more exons keeps
+// k_tiny / k_solve for its small problems
+bool wave_on(const fseg_ctx *c) { return c->use_wave && c->max_rep_exons <= kWaveRepExons; }
+ProbSplit split_of(const fseg_ctx *c, bool tiny, bool fuse) {
+    const bool wave = wave_on(c);
+    return ProbSplit{tiny ? kTiny : 0, (c->use_fuse && fuse) ? kFuseLanes : -1, (wave && c->use_fuse) ? kClsSmall : 0, kWaveLanes};
+}
+
 // Enqueue the segments `segs` of one run on the context's stream.
 //   sized: the run is being launched piecewise with the host reading the sizes in between (first run of a batch):
 //          the problem scan always runs as its own kernels (their totals are what the host waits for) and the label
@@ -3675,7 +3932,8 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
     // cross-stream dependencies there (measured: config2 +4 %), so they stay on the one stream.
     const bool forking = c->use_fork && !c->small_batch && !others_in_flight(c) && c->side[0] != nullptr;
     const int tiny_max = c->tiny_on ? kTiny : 0;
-    const ProbSplit split{tiny_max, (c->use_fuse && c->fuse_on) ? kFuseLanes : -1};
+    const bool wave = wave_on(c);
+    const ProbSplit split = split_of(c, c->tiny_on, c->fuse_on);
     // list sizes known (the batch has been sized or has run): launches over an empty list are left out
     const bool known = c->counts_known;
     const bool any_arena = !known || c->n_arena_prob > 0;
@@ -3864,11 +4122,26 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
         // Two ways a problem is scored (prob_kind): the arena path's work items (k_score per size class) and the problems that
         // see few reads (at most 255: 8-bit counters), whole, one workgroup each (k_solve per size class).
         // A batch usually holds only one kind; a class's two launches share a stream.
+        // one wave per problem on the exon stream (k_wave): the small class's solve list and k_tiny's list
+#define FSEG_LAUNCH_WAVE_V(Q, NMV, VT, LIST, N_ITEMS)                                                                        \
+            hipLaunchKernelGGL((k_wave<NMV, VT>), dim3(grid_for((N_ITEMS), 4, FSEG_WG_TINY)), dim3(256), 0, Q, st,           \
+                               c->d_prob_desc.as<ProbDesc>(), c->prob_cap, LIST, pr, c->d_cand_y.as<int>(), c->d_lane_lx.as<int2>(), \
+                               c->d_lex.as<int2>(), c->d_h_table.as<double>(), c->P.h_len, c->P.threshold_rate,               \
+                               c->d_thr_tab.as<int2>(), c->P.min_read_support_outside, c->d_chosen.as<unsigned char>(),        \
+                               c->d_solve_items.as<int>() FSEG_TARG)
+#define FSEG_LAUNCH_WAVE(Q, NMV, LIST, N_ITEMS)                                                                              \
+            do { if (c->LANES < (1LL << 24)) { FSEG_LAUNCH_WAVE_V(Q, NMV, int, LIST, N_ITEMS); }                              \
+                 else { FSEG_LAUNCH_WAVE_V(Q, NMV, i64, LIST, N_ITEMS); } } while (0)
         const bool any_solve = c->use_fuse && c->fuse_on && (!known || c->n_solve[0] + c->n_solve[1] + c->n_solve[2] > 0);
+        const bool wave_solve = c->use_fuse && wave && (!known || c->n_solve[0] > 0);      // list 0 belongs to k_wave<16>
         const i64 cap = c->prob_cap;
         if (c->small_batch) {
             if (any_arena) FSEG_LAUNCH_SCORE(s, kNMax, -1, 512);    // few work items: one launch for every size class
-            if (any_solve) FSEG_LAUNCH_SOLVE_W(s, kNMax, -1, known ? c->n_solve[0] + c->n_solve[1] + c->n_solve[2] : cap, 512);
+            if (wave) {
+                if (wave_solve) FSEG_LAUNCH_WAVE(s, kClsSmall, 0, known ? c->n_solve[0] : cap);
+                if (any_solve && (!known || c->n_solve[1] > 0)) FSEG_LAUNCH_SOLVE_W(s, kNMax, 1, known ? c->n_solve[1] : cap, 512);
+                if (any_solve && (!known || c->n_solve[2] > 0)) FSEG_LAUNCH_SOLVE_W(s, kNMax, 2, known ? c->n_solve[2] : cap, 512);
+            } else if (any_solve) FSEG_LAUNCH_SOLVE_W(s, kNMax, -1, known ? c->n_solve[0] + c->n_solve[1] + c->n_solve[2] : cap, 512);
         } else {                                     // the size classes own disjoint problems: three concurrent chains
             hipStream_t q1 = fork(0), q0 = fork(1);
             if (any_arena && (!known || c->n_cls_work[2] > 0)) FSEG_LAUNCH_SCORE(s, kNMax, 2, 512);     // big problems: they are the long poles
@@ -3876,7 +4149,8 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
             if (any_arena && (!known || c->n_cls_work[1] > 0)) FSEG_LAUNCH_SCORE(q1, kClsMid, 1, 1280);
             if (any_solve && (!known || c->n_solve[1] > 0)) FSEG_LAUNCH_SOLVE_W(q1, kClsMid, 1, known ? c->n_solve[1] : cap, FSEG_WG_MID);
             if (any_arena && (!known || c->n_cls_work[0] > 0)) FSEG_LAUNCH_SCORE(q0, kClsSmall, 0, 2048);
-            if (any_solve && (!known || c->n_solve[0] > 0)) FSEG_LAUNCH_SOLVE_W(q0, kClsSmall, 0, known ? c->n_solve[0] : cap, FSEG_WG_SMALL);
+            if (wave) { if (wave_solve) FSEG_LAUNCH_WAVE(q0, kClsSmall, 0, known ? c->n_solve[0] : cap); }
+            else if (any_solve && (!known || c->n_solve[0] > 0)) FSEG_LAUNCH_SOLVE_W(q0, kClsSmall, 0, known ? c->n_solve[0] : cap, FSEG_WG_SMALL);
         }
 #undef FSEG_LAUNCH_SOLVE_W
 #undef FSEG_LAUNCH_SOLVE
@@ -3885,11 +4159,15 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
             // the problems with a handful of candidates, whole (coverage, labels, counts, DP), beside the others (launched
             // after the classes whose workgroups need half a CU's LDS each); joined at the end of this stage, so the
             // stage's time bracket covers all scoring work
+            if (wave) FSEG_LAUNCH_WAVE(qt, kTiny, 3, known ? c->n_tiny : c->prob_cap);
+            else
             hipLaunchKernelGGL(k_tiny, dim3(grid_for(known ? c->n_tiny : c->prob_cap, 4, FSEG_WG_TINY)), dim3(256), 0, qt, st, c->d_prob_desc.as<ProbDesc>(),
                                c->prob_cap, tiny_max, pr, c->d_cand_y.as<int>(), c->d_lane_ex.as<longlong2>(),
                                c->d_ex_ts.as<int>(), c->d_ex_te.as<int>(), c->d_h_table.as<double>(), c->P.h_len, c->P.threshold_rate,
                                c->d_thr_tab.as<int2>(), c->P.min_read_support_outside, c->d_chosen.as<unsigned char>(), c->d_solve_items.as<int>() FSEG_TARG);
         }
+#undef FSEG_LAUNCH_WAVE
+#undef FSEG_LAUNCH_WAVE_V
         if (!c->small_batch) { join(0); join(1); }
         if (c->have_huge && any_arena)
             hipLaunchKernelGGL(k_score_huge, dim3(256), dim3(512), kHugeScoreLds, s, st, c->d_dp_items.as<int>(), pr,
@@ -4164,7 +4442,7 @@ int run_sized(fseg_ctx *c) {
                 const int pg = grid_for(c->NPOS / 8 / kProbBlock + 1, 1, 1024);
                 Status *st = c->d_status.as<Status>();
                 hipLaunchKernelGGL(k_prob_scan1, dim3(pg), dim3(256), 0, c->stream, st, c->d_cand_pn.as<int>(), c->d_cand_ln.as<int>(),
-                                   c->d_prob_bs.as<i64>(), ProbSplit{tiny ? kTiny : 0, (c->use_fuse && fuse) ? kFuseLanes : -1});
+                                   c->d_prob_bs.as<i64>(), split_of(c, tiny, fuse));
                 hipLaunchKernelGGL(k_prob_scan2, dim3(1), dim3(256), 0, c->stream, st, c->d_prob_bs.as<i64>());
                 HIP_TRY(c, hipMemcpyAsync(c->h_status, st, sizeof(Status), hipMemcpyDeviceToHost, c->stream));
                 HIP_TRY(c, wait_stream(c));
@@ -4299,6 +4577,7 @@ int fseg_create(int device, fseg_ctx **out) {
     if (flag("FSEG_NO_FORK")) c->use_fork = false;
     if (flag("FSEG_NO_TINY")) c->use_tiny = false;
     if (flag("FSEG_NO_FUSE")) c->use_fuse = false;
+    if (flag("FSEG_NO_WAVE")) c->use_wave = false;
     if (flag("FSEG_NO_SIZED")) c->use_sized = false;
     if (flag("FSEG_TRACE")) c->trace = true;
     if (flag("FSEG_DEBUG_RECOPY")) c->debug_recopy = true;
@@ -4391,7 +4670,7 @@ int fseg_upload(fseg_ctx *c, const fseg_batch *b) {
     if (I < 0) return fail(c, FSEG_ERR_ARG, "rep_exon_off not monotone");
     if (I >= 0x7fffffffLL) return fail(c, FSEG_ERR_UNSUPPORTED, "batch has %lld exons; split it (limit 2^31-1 per upload)", (long long)I);
     // ---- host pass 1: the partition / interval level (validation as read_split() asserts it, :138-140) and the counts
-    i64 NPOS = 0, n_tiles = 0, lanes = 0, n_rep_blocks = 0, max_part_reps = 0;
+    i64 NPOS = 0, n_tiles = 0, lanes = 0, n_rep_blocks = 0, max_part_reps = 0, max_rep_exons = 0;
     bool expanded = false;
     for (int p = 0; p < np; ++p) {
         const i64 k0 = b->part_iv_off[p], k1 = b->part_iv_off[p + 1];
@@ -4414,6 +4693,7 @@ int fseg_upload(fseg_ctx *c, const fseg_batch *b) {
         if (w != 1) expanded = true;
         lanes += w;
         if (b->rep_exon_off[r + 1] < b->rep_exon_off[r]) return fail(c, FSEG_ERR_ARG, "rep_exon_off not monotone");
+        if (b->rep_exon_off[r + 1] - b->rep_exon_off[r] > max_rep_exons) max_rep_exons = b->rep_exon_off[r + 1] - b->rep_exon_off[r];
     }
     if (lanes >= 0x7fffffffLL) return fail(c, FSEG_ERR_UNSUPPORTED, "batch has %lld reads; split it (limit 2^31-1 per upload)", (long long)lanes);
     // histogram chunks: consecutive positions of one partition; as large as possible (fewer reads are visited twice)
@@ -4472,6 +4752,10 @@ int fseg_upload(fseg_ctx *c, const fseg_batch *b) {
     in.add(c->d_rb_base, (size_t)n_rep_blocks * 8);
     in.add(c->d_rb_max, (size_t)n_rep_blocks * 4);
     in.add(c->d_rb_cmax, (size_t)n_rep_blocks * 4);
+    in.add(c->d_rb_esum, (size_t)n_rep_blocks * 8);
+    in.add(c->d_rb_ebase, (size_t)n_rep_blocks * 8);
+    in.add(c->d_lane_lx, (size_t)lanes * 8 + 64);
+    in.add(c->d_lex, (size_t)I * 8 + kLexPad);
     TRY(reserve(c, c->slab_in, in.total));
     in.bind(c->slab_in);
     TRY(reserve_host(c, c->h_stage, up_bytes));
@@ -4533,7 +4817,7 @@ int fseg_upload(fseg_ctx *c, const fseg_batch *b) {
     memcpy(host_of(c->d_ex_te), b->ex_te, (size_t)I * 4);
     const double t_copy = tk.ms();
     c->n_part = np; c->K = K; c->R = R; c->I = I; c->NPOS = NPOS; c->LANES = lanes; c->expanded = expanded;
-    c->n_tiles = (int)n_tiles; c->n_hist_chunks = (int)n_chunks; c->n_rep_blocks = (int)n_rep_blocks;
+    c->n_tiles = (int)n_tiles; c->n_hist_chunks = (int)n_chunks; c->n_rep_blocks = (int)n_rep_blocks; c->max_rep_exons = max_rep_exons;
     c->part_iv_off.assign(b->part_iv_off, b->part_iv_off + np + 1);
     c->part_rep_off.assign(b->part_rep_off, b->part_rep_off + np + 1);
     hipStream_t s = c->stream;
@@ -4569,19 +4853,21 @@ int fseg_upload(fseg_ctx *c, const fseg_batch *b) {
             hipLaunchKernelGGL(k_lanes, dim3(grid_for(np, 1, 65536)), dim3(256), 0, s, np, c->d_part_rep_off.as<i64>(), c->d_part_lane_off.as<i64>(),
                                c->d_key_b.as<u64>(), c->d_val_b.as<int>(), c->d_rep_weight.as<int>(), c->d_rep_last.as<int>(),
                                c->d_rep_exon_off.as<i64>(), c->d_lane_ex.as<longlong2>(), c->d_lane_start.as<int>(), c->d_lane_pmax.as<int>(),
-                               1, c->d_key_a.as<u64>());
+                               1, c->d_key_a.as<u64>(), c->d_ex_ts.as<int>(), c->d_ex_te.as<int>(), c->d_lane_lx.as<int2>(), c->d_lex.as<int2>());
         } else {
             const int rbg = grid_for(n_rep_blocks, 1, 65536);
             hipLaunchKernelGGL(k_lane_blocks, dim3(rbg), dim3(256), 0, s, (int)n_rep_blocks, c->d_rb_part.as<int>(), c->d_rb_r0.as<int>(),
                                c->d_part_rep_off.as<i64>(), c->d_val_b.as<int>(), c->d_rep_weight.as<int>(), c->d_rep_last.as<int>(),
-                               c->d_rb_sum.as<i64>(), c->d_rb_max.as<int>());
+                               c->d_rb_sum.as<i64>(), c->d_rb_max.as<int>(), c->d_rep_exon_off.as<i64>(), c->d_rb_esum.as<i64>());
             hipLaunchKernelGGL(k_lane_block_scan, dim3(grid_for(np, 4, 4096)), dim3(256), 0, s, np, (int)n_rep_blocks, c->d_rb_part.as<int>(),
                                c->d_part_lane_off.as<i64>(), c->d_rb_sum.as<i64>(), c->d_rb_max.as<int>(), c->d_rb_base.as<i64>(),
-                               c->d_rb_cmax.as<int>());
+                               c->d_rb_cmax.as<int>(), c->d_part_rep_off.as<i64>(), c->d_rep_exon_off.as<i64>(), c->d_rb_esum.as<i64>(),
+                               c->d_rb_ebase.as<i64>());
             hipLaunchKernelGGL(k_lane_emit, dim3(rbg), dim3(256), 0, s, (int)n_rep_blocks, c->d_rb_part.as<int>(), c->d_rb_r0.as<int>(),
                                c->d_part_rep_off.as<i64>(), c->d_key_b.as<u64>(), c->d_val_b.as<int>(), c->d_rep_weight.as<int>(),
                                c->d_rep_last.as<int>(), c->d_rep_exon_off.as<i64>(), c->d_rb_base.as<i64>(), c->d_rb_cmax.as<int>(),
-                               c->d_lane_ex.as<longlong2>(), c->d_lane_start.as<int>(), c->d_lane_pmax.as<int>());
+                               c->d_lane_ex.as<longlong2>(), c->d_lane_start.as<int>(), c->d_lane_pmax.as<int>(), c->d_rb_ebase.as<i64>(),
+                               c->d_ex_ts.as<int>(), c->d_ex_te.as<int>(), c->d_lane_lx.as<int2>(), c->d_lex.as<int2>());
         }
     }
     hipLaunchKernelGGL(k_hist_ranges, dim3(grid_for(n_chunks, 256, 4096)), dim3(256), 0, s, (int)n_chunks, c->d_hc_part.as<int>(),
@@ -4889,6 +5175,8 @@ int fseg_tap(fseg_ctx *c, int what, void *dst, int64_t cap_bytes, int64_t *n_byt
         case FSEG_TAP_LANE_START: src = c->d_lane_start.p; bytes = c->LANES * 4; break;
         case FSEG_TAP_LANE_PMAX: src = c->d_lane_pmax.p; bytes = c->LANES * 4; break;
         case FSEG_TAP_LANE_EXONS: src = c->d_lane_ex.p; bytes = c->LANES * 16; break;
+        case FSEG_TAP_LANE_STREAM: src = c->d_lane_lx.p; bytes = c->LANES * 8; break;
+        case FSEG_TAP_EXON_STREAM: src = c->d_lex.p; bytes = c->I * 8; break;
         default: return fail(c, FSEG_ERR_ARG, "unknown tap %d", what);
     }
     *n_bytes = bytes;

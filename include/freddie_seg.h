@@ -156,7 +156,9 @@ enum {
      * partition by first position */
     FSEG_TAP_LANE_START = 12, /* int32[lanes]  first position of the lane's rep                                      */
     FSEG_TAP_LANE_PMAX = 13,  /* int32[lanes]  running maximum (inside the partition) of the reps' last positions    */
-    FSEG_TAP_LANE_EXONS = 14  /* int64[lanes][2] exon range (into ex_ts / ex_te) of the lane's rep                   */
+    FSEG_TAP_LANE_EXONS = 14, /* int64[lanes][2] exon range (into ex_ts / ex_te) of the lane's rep                   */
+    FSEG_TAP_LANE_STREAM = 15, /* int32[lanes][2] the lane's exon range in the lane-ordered exon stream                */
+    FSEG_TAP_EXON_STREAM = 16  /* int32[I][2]    (ts, te) of every exon, the reps of a partition in lane order        */
 };
 int fseg_tap(fseg_ctx *ctx, int what, void *dst, int64_t cap_bytes, int64_t *n_bytes);
 

@@ -1,13 +1,15 @@
 """CPU restatement of the reference's partition_reads() (vpc-ccg/freddie py/freddie_cluster.py:196-274) -- TEST
 INFRASTRUCTURE ONLY: imported by tests/ (and tools/cluster_bench.py's cpu_baseline leg), never by the product.
 
-PARITY UNPINNED for this function: the reference module imports networkx and gurobipy at the top (:11-13), neither is
-installed here, and the reference ships no fixtures for this stage, so partition_reads() itself cannot be run.  What
-follows restates its text step by step with a dict-of-sets graph in place of networkx.Graph (the reference uses only
-add_nodes_from / add_edges_from / edges / neighbors / remove_edges_from / has_edge and connected_components, whose
-documented semantics are: undirected simple graph; components yielded in order of their first node in node
-insertion order).  read_segment() and preprocess_ilp() (:119-172, :277-328) ARE pinned: tests/golden/cluster/ holds
-their outputs, produced by executing the reference's own source of those functions (tests/golden/make_cluster_golden.py).
+PINNED: tests/golden/cluster/ holds tint['partitions'] as the reference's own partition_reads() and split_list_evenly()
+(:112-116) left it -- their source executed unmodified, with the module's own networkx imports (networkx 3.4.2 is in this
+image), by tests/golden/make_cluster_golden.py -- for the eleven segment goldens at maximum_ilp_size 7 and 1000 and for
+thirteen seeded random tints; tests/test_cluster_host.py checks this file against all of them.  read_segment() and
+preprocess_ilp() (:119-172, :277-328) are pinned the same way.
+
+What follows restates the function step by step with a list-of-sets graph in place of networkx.Graph (the reference uses only
+add_nodes_from / add_edges_from / edges / neighbors / remove_edges_from / has_edge and connected_components: an undirected
+simple graph; components come out in order of their first node in node insertion order).
 """
 from math import ceil
 

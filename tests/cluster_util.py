@@ -9,8 +9,22 @@ import goldens
 CLUSTER_DIR = os.path.join(goldens.GOLDEN_DIR, "cluster")
 
 
+RANDOM_FIXTURE = "partition_random"
+
+
 def cluster_names():
-    return sorted(f[:-8] for f in os.listdir(CLUSTER_DIR) if f.endswith(".json.gz"))
+    return sorted(f[:-8] for f in os.listdir(CLUSTER_DIR) if f.endswith(".json.gz") and f[:-8] != RANDOM_FIXTURE)
+
+
+def random_partition_cases():
+    """partition_reads() of the reference itself (executed with networkx by tests/golden/make_cluster_golden.py) on seeded
+    random_tint() inputs: [dict(seed, n_reps, n_segs, kw, partitions={maximum_ilp_size: [[rids, incomp], ..]})]."""
+    return json.loads(gzip.open(os.path.join(CLUSTER_DIR, RANDOM_FIXTURE + ".json.gz")).read().decode())
+
+
+def canon_partitions(tint):
+    """tint['partitions'] in the fixtures' JSON shape."""
+    return [[list(rids), [list(pair) for pair in incomp]] for rids, incomp in tint["partitions"]]
 
 
 def load_cluster(name):

@@ -1,6 +1,7 @@
 """Clustering pre-ILP, CPU side: the host mirror of read_segment() / preprocess_ilp() against fixtures produced by the
-reference's own source (tests/golden/make_cluster_golden.py), the oracle's restatement of partition_reads() on
-hand-made graphs, and the C-ABI library's symbols.  No GPU."""
+reference's own source (tests/golden/make_cluster_golden.py), the oracle's restatement of partition_reads() against
+tint['partitions'] written by the reference's own function (same generator) and on hand-made graphs, and the C-ABI
+library's symbols.  No GPU."""
 import copy
 import os
 import re
@@ -36,6 +37,33 @@ def test_read_segment_and_preprocess_match_reference(name, tmp_path):
         assert sorted(map(list, r["softclip"].items())) == [list(x) for x in w["softclip"]]
         assert sorted([k, list(v)] for k, v in r["poly_tail"].items()) == w["poly_tail"]
         assert r["poly_tail_category"] == w["poly_tail_category"]
+
+
+@pytest.mark.parametrize("name", cu.cluster_names())
+def test_oracle_partition_reads_matches_reference_on_segment_tsvs(name, tmp_path):
+    """The oracle's restatement of partition_reads() against tint['partitions'] as the reference's own function (run with
+    networkx at fixture time) left it, for maximum_ilp_size 7 (even split of large components, :259) and 1000."""
+    want = cu.load_cluster(name)
+    tint = list(cluster_prep.read_segment(cu.segment_tsv_file(name, tmp_path)).values())[0]
+    cluster_prep.preprocess_ilp(tint, dict(recycle_model="constant"))
+    for size, parts in want["partitions"].items():
+        t = copy.deepcopy(tint)
+        cluster_oracle.partition_reads(t, int(size))
+        assert cu.canon_partitions(t) == parts, "maximum_ilp_size %s" % size
+
+
+def test_oracle_partition_reads_matches_reference_on_random_tints():
+    cases = cu.random_partition_cases()
+    assert len(cases) >= 10
+    n_multi = 0
+    for case in cases:
+        tint = cu.random_tint(case["seed"], case["n_reps"], case["n_segs"], **case["kw"])
+        for size, parts in case["partitions"].items():
+            t = copy.deepcopy(tint)
+            cluster_oracle.partition_reads(t, int(size))
+            assert cu.canon_partitions(t) == parts, "seed %d, maximum_ilp_size %s" % (case["seed"], size)
+            n_multi += len(parts) > 1
+    assert n_multi >= 10                       # the fixtures do exercise components, pruning and the even split
 
 
 def test_read_segment_error_behaviour(tmp_path):

@@ -1,6 +1,7 @@
 """Clustering pre-ILP on the GPU (row N3): the compatibility graph, its pruning and partition_reads() through the
-C-ABI (include/freddie_cluster.h) against the CPU oracle's restatement of py/freddie_cluster.py:196-274, on the
-reference's own segment TSVs (golden fixtures) and on seeded random tints.  Bit-exact: the graph is integer work."""
+C-ABI (include/freddie_cluster.h) against the CPU oracle's restatement of py/freddie_cluster.py:196-274 and against
+tint['partitions'] as the reference's own partition_reads() wrote it (fixtures), on the reference's own segment TSVs and
+on seeded random tints.  Bit-exact: the graph is integer work."""
 import copy
 
 import numpy as np
@@ -57,12 +58,26 @@ def test_partition_reads_on_reference_segment_tsvs(ctx, name, tmp_path):
     check_graphs(ctx, [tint])
     want = copy.deepcopy(tint)
     cluster_oracle.partition_reads(want, 1000)
-    cluster_prep.partition_reads(tint, 1000, ctx=ctx, verbose=False)
-    assert tint["partitions"] == want["partitions"]
+    ref = cu.load_cluster(name)["partitions"]                     # what the reference's own partition_reads() produced
+    big = copy.deepcopy(tint)
+    cluster_prep.partition_reads(big, 1000, ctx=ctx, verbose=False)
+    assert big["partitions"] == want["partitions"]
+    assert cu.canon_partitions(big) == ref["1000"]
     small = copy.deepcopy(tint); want_small = copy.deepcopy(want)
     cluster_oracle.partition_reads(want_small, 7)                 # forces the even split of large components (:259)
     cluster_prep.partition_reads(small, 7, ctx=ctx, verbose=False)
     assert small["partitions"] == want_small["partitions"]
+    assert cu.canon_partitions(small) == ref["7"]
+
+
+def test_partition_reads_on_random_tints_against_the_reference(ctx):
+    """The GPU path against tint['partitions'] of the reference's own function (networkx) on seeded random tints."""
+    for case in cu.random_partition_cases():
+        tint = cu.random_tint(case["seed"], case["n_reps"], case["n_segs"], **case["kw"])
+        for size, parts in case["partitions"].items():
+            t = copy.deepcopy(tint)
+            cluster_prep.partition_reads(t, int(size), ctx=ctx, verbose=False)
+            assert cu.canon_partitions(t) == parts, "seed %d, maximum_ilp_size %s" % (case["seed"], size)
 
 
 def test_random_tints_batched(ctx):

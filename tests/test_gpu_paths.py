@@ -133,6 +133,7 @@ def test_lane_preparation_on_the_device(big, gpu_ctx):
         assert parts[2].n_reps > 2048
     util.run_gpu(gpu_ctx, parts)
     start, pmax, exons = gpu_ctx.tap("lane_start"), gpu_ctx.tap("lane_pmax"), gpu_ctx.tap("lane_exons")
+    lstream, estream = gpu_ctx.tap("lane_stream"), gpu_ctx.tap("exon_stream")
     l0 = e0 = 0
     for p in parts:
         first = p.ex_ts[p.rep_exon_off[:-1]]
@@ -145,6 +146,16 @@ def test_lane_preparation_on_the_device(big, gpu_ctx):
         assert np.array_equal(pmax[l0:l0 + n], np.maximum.accumulate(last[lanes]))
         assert np.array_equal(exons[l0:l0 + n, 0], p.rep_exon_off[lanes] + e0)
         assert np.array_equal(exons[l0:l0 + n, 1], p.rep_exon_off[lanes + 1] + e0)
+        # the exon stream: the partition's exons once more as (ts, te) pairs, rep after rep in lane order; a lane's range
+        # in it holds exactly its rep's exons (the copies of a weighted rep share one range)
+        n_ex = np.diff(p.rep_exon_off)[order]
+        off = np.concatenate([[0], np.cumsum(n_ex)]) + e0
+        rep_pos = np.repeat(np.arange(p.n_reps), p.rep_weight[order])
+        assert np.array_equal(lstream[l0:l0 + n, 0], off[rep_pos])
+        assert np.array_equal(lstream[l0:l0 + n, 1], off[rep_pos + 1])
+        idx = np.concatenate([np.arange(p.rep_exon_off[r], p.rep_exon_off[r + 1]) for r in order])
+        assert np.array_equal(estream[e0:e0 + len(idx), 0], p.ex_ts[idx])
+        assert np.array_equal(estream[e0:e0 + len(idx), 1], p.ex_te[idx])
         l0 += n; e0 += len(p.ex_ts)
     assert l0 == len(start)
 
