@@ -2302,7 +2302,7 @@ template <int NM> struct WaveCfg {
     static constexpr int kPairs = NM * (NM - 1) / 2, kTri = NM * (NM - 1) * (NM - 2) / 6;
     static constexpr int kPSlots = (kPairs + 63) / 64, kTSlots = (kTri + 63) / 64;
 #ifndef FSEG_WAVE_OCC8
-#define FSEG_WAVE_OCC8 5
+#define FSEG_WAVE_OCC8 7        // (72 registers: all of a 250 k-read batch's ~7 000 tiny problems are resident at once, 30 -> 25 us)
 #endif
 #ifndef FSEG_WAVE_OCC16
 #define FSEG_WAVE_OCC16 4
@@ -2515,7 +2515,10 @@ template <int NM> struct SolveCfg {
 #ifndef FSEG_SOLVE_OCC
 #define FSEG_SOLVE_OCC 1
 #endif
-    static constexpr int kMinBlocks = !FSEG_SOLVE_OCC ? 1 : (NM <= 16 ? 5 : 4);
+#ifndef FSEG_SOLVE_OCC32
+#define FSEG_SOLVE_OCC32 5      // (96 registers, five workgroups of the mid class per CU: 74 -> 70 us on config4; six spill and lose it again)
+#endif
+    static constexpr int kMinBlocks = !FSEG_SOLVE_OCC ? 1 : (NM <= 16 ? 5 : (NM <= 32 ? FSEG_SOLVE_OCC32 : 4));
 };
 inline size_t solve_lds_for(int nm, int cov_stride, int cnt_bytes) {
     const size_t pairs = (size_t)nm * (nm - 1) / 2, tri = (size_t)nm * (nm - 1) * (nm - 2) / 6;
@@ -3728,6 +3731,8 @@ struct fseg_ctx {
     bool counted_in_flight = false, counted_live = false;
     int hsa_agent = -1;         // index into the HSA agent table (-1: not looked up yet, -2: unavailable)
     hsa_signal_t hsa_sig = {0};
+    int hsa_cpu = 0;            // index of the CPU agent that owns the pinned result buffer ...
+    const void *hsa_dst_base = nullptr;   // ... as asked for this allocation of it
     bool profiling = false;
     bool profile_all = true;    // false (fseg_set_profiling(ctx, 2)): only the interval-scoring stage is bracketed by events
     bool have_huge = false;      // the batch has a problem with more than kNMax candidates: launch the huge kernels
@@ -3760,6 +3765,8 @@ struct fseg_ctx {
     bool use_fork = true;
     bool use_tiny = true;       // FSEG_NO_TINY=1: no problem goes to k_tiny
     bool use_wave = true;       // FSEG_NO_WAVE=1: k_tiny / k_solve<16> instead of the wave kernels (k_wave)
+    bool wave_small = false;    // FSEG_WAVE_SMALL=1: the small class (9 .. 16 candidates) goes to k_wave<16> instead of k_solve<16> (one wave
+                                // per problem: a third less wave-time, but 48 instead of 38 us when the kernel has the GPU to itself)
     bool use_fuse = true;       // FSEG_NO_FUSE=1: no problem goes to k_solve (everything that is not tiny takes the arena path)
     bool fuse_on = true;        // this batch's problems go to k_solve: decided per batch -- when its widest problem sees at most
                                 // kFuseLanes reads, i.e. all of them qualify (measured: a batch of 500-read partitions gains 8 %, while
@@ -3783,9 +3790,12 @@ int fail(fseg_ctx *c, int code, const char *fmt, ...) {
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
     if (c) c->err = buf;
+    // A failed HIP call leaves its code as the calling thread's "last error": consumed here, or the next -- successful --
+    // upload or run on this host thread would trip over it at its hipGetLastError() check.
+    if (code == FSEG_ERR_HIP) (void)hipGetLastError();
     return code;
 }
-std::string g_create_error;
+thread_local std::string g_create_error;      // fseg_create has no context to put its message in: the calling thread's own
 
 #define HIP_TRY(c, expr)                                                                         \
     do {                                                                                         \
@@ -3909,7 +3919,7 @@ inline i64 scan_blocks(i64 n) { return (n + kScanBlock - 1) / kScanBlock; }
 bool wave_on(const fseg_ctx *c) { return c->use_wave && c->max_rep_exons <= kWaveRepExons; }
 ProbSplit split_of(const fseg_ctx *c, bool tiny, bool fuse) {
     const bool wave = wave_on(c);
-    return ProbSplit{tiny ? kTiny : 0, (c->use_fuse && fuse) ? kFuseLanes : -1, (wave && c->use_fuse) ? kClsSmall : 0, kWaveLanes};
+    return ProbSplit{tiny ? kTiny : 0, (c->use_fuse && fuse) ? kFuseLanes : -1, (wave && c->use_fuse && c->wave_small) ? kClsSmall : 0, kWaveLanes};
 }
 
 // Enqueue the segments `segs` of one run on the context's stream.
@@ -4133,11 +4143,12 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
             do { if (c->LANES < (1LL << 24)) { FSEG_LAUNCH_WAVE_V(Q, NMV, int, LIST, N_ITEMS); }                              \
                  else { FSEG_LAUNCH_WAVE_V(Q, NMV, i64, LIST, N_ITEMS); } } while (0)
         const bool any_solve = c->use_fuse && c->fuse_on && (!known || c->n_solve[0] + c->n_solve[1] + c->n_solve[2] > 0);
-        const bool wave_solve = c->use_fuse && wave && (!known || c->n_solve[0] > 0);      // list 0 belongs to k_wave<16>
+        const bool wave16 = wave && c->wave_small;                                         // list 0 belongs to k_wave<16>
+        const bool wave_solve = c->use_fuse && wave16 && (!known || c->n_solve[0] > 0);
         const i64 cap = c->prob_cap;
         if (c->small_batch) {
             if (any_arena) FSEG_LAUNCH_SCORE(s, kNMax, -1, 512);    // few work items: one launch for every size class
-            if (wave) {
+            if (wave16) {
                 if (wave_solve) FSEG_LAUNCH_WAVE(s, kClsSmall, 0, known ? c->n_solve[0] : cap);
                 if (any_solve && (!known || c->n_solve[1] > 0)) FSEG_LAUNCH_SOLVE_W(s, kNMax, 1, known ? c->n_solve[1] : cap, 512);
                 if (any_solve && (!known || c->n_solve[2] > 0)) FSEG_LAUNCH_SOLVE_W(s, kNMax, 2, known ? c->n_solve[2] : cap, 512);
@@ -4149,7 +4160,7 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
             if (any_arena && (!known || c->n_cls_work[1] > 0)) FSEG_LAUNCH_SCORE(q1, kClsMid, 1, 1280);
             if (any_solve && (!known || c->n_solve[1] > 0)) FSEG_LAUNCH_SOLVE_W(q1, kClsMid, 1, known ? c->n_solve[1] : cap, FSEG_WG_MID);
             if (any_arena && (!known || c->n_cls_work[0] > 0)) FSEG_LAUNCH_SCORE(q0, kClsSmall, 0, 2048);
-            if (wave) { if (wave_solve) FSEG_LAUNCH_WAVE(q0, kClsSmall, 0, known ? c->n_solve[0] : cap); }
+            if (wave16) { if (wave_solve) FSEG_LAUNCH_WAVE(q0, kClsSmall, 0, known ? c->n_solve[0] : cap); }
             else if (any_solve && (!known || c->n_solve[0] > 0)) FSEG_LAUNCH_SOLVE_W(q0, kClsSmall, 0, known ? c->n_solve[0] : cap, FSEG_WG_SMALL);
         }
 #undef FSEG_LAUNCH_SOLVE_W
@@ -4578,6 +4589,7 @@ int fseg_create(int device, fseg_ctx **out) {
     if (flag("FSEG_NO_TINY")) c->use_tiny = false;
     if (flag("FSEG_NO_FUSE")) c->use_fuse = false;
     if (flag("FSEG_NO_WAVE")) c->use_wave = false;
+    { const char *v = getenv("FSEG_WAVE_SMALL"); if (v && v[0]) c->wave_small = v[0] == '1'; }
     if (flag("FSEG_NO_SIZED")) c->use_sized = false;
     if (flag("FSEG_TRACE")) c->trace = true;
     if (flag("FSEG_DEBUG_RECOPY")) c->debug_recopy = true;
@@ -4650,7 +4662,13 @@ int fseg_set_params(fseg_ctx *c, const fseg_params *p) {
 // of every exon, the per-partition sort of the reps, the lane list, the histogram chunks' lane ranges).  Returns
 // without waiting for the device: what the device-side validation finds is reported by the first call that waits
 // (fseg_run / fseg_sync / fseg_download ...).
+static int upload_impl(fseg_ctx *c, const fseg_batch *b);
 int fseg_upload(fseg_ctx *c, const fseg_batch *b) {
+    const int rc = upload_impl(c, b);
+    if (rc != FSEG_OK && c) set_in_flight(c, false);     // nothing of this batch will run: the device's other contexts may fork again
+    return rc;
+}
+static int upload_impl(fseg_ctx *c, const fseg_batch *b) {
     if (!c || !b) return FSEG_ERR_ARG;
     if (b->n_part <= 0 || !b->part_iv_off || !b->iv_start || !b->iv_end || !b->part_rep_off || !b->rep_weight ||
         !b->rep_exon_off || !b->ex_ts || !b->ex_te)
@@ -4919,7 +4937,13 @@ int fseg_upload(fseg_ctx *c, const fseg_batch *b) {
     return FSEG_OK;
 }
 
+static int run_impl(fseg_ctx *c);
 int fseg_run(fseg_ctx *c) {
+    const int rc = run_impl(c);
+    if (rc != FSEG_OK && c && !c->pending) set_in_flight(c, false);
+    return rc;
+}
+static int run_impl(fseg_ctx *c) {
     if (!c) return FSEG_ERR_ARG;
     if (!c->have_params || !c->have_batch) return fail(c, FSEG_ERR_ARG, "fseg_run: set parameters and upload a batch first");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -5004,13 +5028,13 @@ int fseg_get_sizes(fseg_ctx *c, fseg_sizes *out) {
 }
 
 // Results of the last run in the context's pinned host buffers (one device-to-host copy each, no pageable staging):
-// valid until the next fseg_run / fseg_upload / fseg_results on this context.
+// valid until the next fseg_results / fseg_results_packed on this context (nothing else writes them: see include/freddie_seg.h).
 // Large device-to-host copies go to an SDMA engine through the HSA runtime.  hipMemcpyAsync performs a large copy to pinned
 // host memory with a copy KERNEL (256 workgroups that wait on PCIe): it holds its hardware queue for the 340 us the copy
 // takes, and the kernels of the contexts that share the queue behind it (six contexts taking turns: 253 -> 280 M reads/s
 // with the copy on SDMA).  The HSA agent of a HIP device is found by its PCI address; if anything of this fails the copy
 // falls back to hipMemcpyAsync (FSEG_NO_SDMA_D2H=1 forces that).
-struct HsaAgents { hsa_agent_t gpu[64]; unsigned bdf[64]; unsigned dom[64]; int n_gpu = 0; hsa_agent_t cpu; int n_cpu = 0; bool ok = false; };
+struct HsaAgents { hsa_agent_t gpu[64]; unsigned bdf[64]; unsigned dom[64]; int n_gpu = 0; hsa_agent_t cpu[16]; int n_cpu = 0; bool ok = false; };
 static hsa_status_t hsa_agent_cb(hsa_agent_t a, void *data) {
     HsaAgents *h = static_cast<HsaAgents *>(data);
     hsa_device_type_t t;
@@ -5022,7 +5046,7 @@ static hsa_status_t hsa_agent_cb(hsa_agent_t a, void *data) {
             (void)hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_DOMAIN, &dom);
             h->gpu[h->n_gpu] = a; h->bdf[h->n_gpu] = bdf & 0xffffu; h->dom[h->n_gpu] = dom; ++h->n_gpu;
         }
-    } else if (t == HSA_DEVICE_TYPE_CPU) { if (h->n_cpu++ == 0) h->cpu = a; }
+    } else if (t == HSA_DEVICE_TYPE_CPU) { if (h->n_cpu < 16) h->cpu[h->n_cpu++] = a; }
     return HSA_STATUS_SUCCESS;
 }
 static HsaAgents &hsa_agents() {
@@ -5050,9 +5074,27 @@ static bool sdma_d2h(fseg_ctx *c, void *dst_pinned, const void *src_dev, size_t 
         if (c->hsa_agent >= 0 && hsa_signal_create(1, 0, nullptr, &c->hsa_sig) != HSA_STATUS_SUCCESS) c->hsa_agent = -2;
     }
     if (c->hsa_agent < 0) return false;
+    // the destination's agent: the CPU (NUMA node) that owns the pinned buffer, asked of the runtime whenever the buffer has
+    // been reallocated; the first CPU agent if it will not say
+    if (c->hsa_dst_base != c->h_res.p) {
+        c->hsa_dst_base = c->h_res.p;
+        c->hsa_cpu = 0;
+        hsa_amd_pointer_info_t info;
+        memset(&info, 0, sizeof info);
+        info.size = sizeof info;
+        if (hsa_amd_pointer_info(dst_pinned, &info, nullptr, nullptr, nullptr) == HSA_STATUS_SUCCESS)
+            for (int i = 0; i < h.n_cpu; ++i) if (h.cpu[i].handle == info.agentOwner.handle) c->hsa_cpu = i;
+    }
     hsa_signal_store_relaxed(c->hsa_sig, 1);
-    if (hsa_amd_memory_async_copy(dst_pinned, h.cpu, src_dev, h.gpu[c->hsa_agent], bytes, 0, nullptr, c->hsa_sig) != HSA_STATUS_SUCCESS) return false;
-    hsa_signal_wait_scacquire(c->hsa_sig, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED);
+    if (hsa_amd_memory_async_copy(dst_pinned, h.cpu[c->hsa_cpu], src_dev, h.gpu[c->hsa_agent], bytes, 0, nullptr, c->hsa_sig) != HSA_STATUS_SUCCESS) return false;
+    // a copy that completes takes the signal from 1 to 0; one that FAILS drives it negative, which also ends the wait:
+    // then nothing can be said about the destination -- this context stays off the engine and the caller copies again
+    const hsa_signal_value_t v = hsa_signal_wait_scacquire(c->hsa_sig, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED);
+    if (v != 0) {
+        c->hsa_agent = -2;
+        if (c->trace) fprintf(stderr, "[fseg] SDMA result copy failed (signal %lld): falling back to the runtime's copy\n", (long long)v);
+        return false;
+    }
     return true;
 }
 

@@ -99,46 +99,52 @@ def _parse_cpulist(text):
     return cpus
 
 
-def cpus_near_gpu(ordinal, n_gpus, kfd_root=_KFD_NODES):
-    """Host cores for the worker of GPU ``ordinal`` (of ``n_gpus`` workers): the cores this process may use that belong
-    to the GPU's NUMA node, divided among the GPUs of that node; falls back to an even slice of the allowed cores."""
+def cpus_near_gpu(worker, n_workers, ordinal=None, kfd_root=_KFD_NODES, env=None):
+    """Host cores for worker ``worker`` (of ``n_workers``, one per GPU).  ``ordinal`` is the HIP ordinal of its GPU: when
+    it equals the worker index and no ``*_VISIBLE_DEVICES`` variable remaps the ordinals, ordinal k is the k-th usable GPU of
+    the KFD topology and the worker gets its share of the cores of that GPU's NUMA node; otherwise (``--devices 2,4``, a
+    remapped environment) nothing is known about where the GPU sits and the worker gets an even slice of the allowed
+    cores -- by WORKER index, so that no two workers share cores."""
+    env = os.environ if env is None else env
     try:
         allowed = sorted(os.sched_getaffinity(0))
     except AttributeError:
         return None
-    if n_gpus <= 1 or not allowed:
+    if n_workers <= 1 or not allowed:
         return allowed
-    nodes = _kfd_gpu_nodes(kfd_root) or []
-    usable = [p for _, p in nodes if _usable(p)]
-    numa_of = []
-    for p in usable:
-        node = -1
-        minor = p.get("drm_render_minor", -1)
-        try:
-            with open("/sys/class/drm/renderD%d/device/numa_node" % minor) as f:
-                node = int(f.read().strip())
-        except (OSError, ValueError):
-            pass
-        numa_of.append(node)
-    if ordinal < len(numa_of) and numa_of[ordinal] >= 0:
-        try:
-            with open("/sys/devices/system/node/node%d/cpulist" % numa_of[ordinal]) as f:
-                local = [c for c in _parse_cpulist(f.read()) if c in set(allowed)]
-        except OSError:
-            local = []
-        peers = [i for i, n in enumerate(numa_of[:n_gpus]) if n == numa_of[ordinal]]
-        if local and ordinal in peers:
-            k = peers.index(ordinal)
-            share = len(local) // len(peers)
-            if share > 0:
-                return local[k * share:(k + 1) * share]
-    share = max(1, len(allowed) // n_gpus)
-    return allowed[(ordinal % n_gpus) * share:(ordinal % n_gpus + 1) * share] or allowed
+    ordinal = worker if ordinal is None else ordinal
+    if ordinal == worker and _visible_from_env(env) is None:
+        nodes = _kfd_gpu_nodes(kfd_root) or []
+        usable = [p for _, p in nodes if _usable(p)]
+        numa_of = []
+        for p in usable:
+            node = -1
+            minor = p.get("drm_render_minor", -1)
+            try:
+                with open("/sys/class/drm/renderD%d/device/numa_node" % minor) as f:
+                    node = int(f.read().strip())
+            except (OSError, ValueError):
+                pass
+            numa_of.append(node)
+        if worker < len(numa_of) and numa_of[worker] >= 0:
+            try:
+                with open("/sys/devices/system/node/node%d/cpulist" % numa_of[worker]) as f:
+                    local = [c for c in _parse_cpulist(f.read()) if c in set(allowed)]
+            except OSError:
+                local = []
+            peers = [i for i, n in enumerate(numa_of[:n_workers]) if n == numa_of[worker]]
+            if local and worker in peers:
+                k = peers.index(worker)
+                share = len(local) // len(peers)
+                if share > 0:
+                    return local[k * share:(k + 1) * share]
+    share = max(1, len(allowed) // n_workers)
+    return allowed[(worker % n_workers) * share:(worker % n_workers + 1) * share] or allowed
 
 
-def pin_worker(ordinal, n_gpus):
-    """Bind the calling process to the cores next to its GPU (best effort; returns the core list or None)."""
-    cpus = cpus_near_gpu(ordinal, n_gpus)
+def pin_worker(worker, n_workers, ordinal=None):
+    """Bind the calling process to its share of the host cores (best effort; returns the core list or None)."""
+    cpus = cpus_near_gpu(worker, n_workers, ordinal)
     if cpus:
         try:
             os.sched_setaffinity(0, cpus)

@@ -624,10 +624,11 @@ def open_contexts(device, n=2):
     return ctxs
 
 
-def _gpu_worker(device, n_workers, jobs_with_cost, params, batch_bytes, threads, queue, sidecar="off"):
+def _gpu_worker(device, n_workers, jobs_with_cost, params, batch_bytes, threads, queue, sidecar="off", worker=None):
     from . import devices
     from concurrent.futures import ThreadPoolExecutor
-    devices.pin_worker(device, n_workers)        # host threads of this worker stay on the cores next to its GPU
+    # host threads of this worker stay on its share of the cores (next to its GPU where that is known: devices.py)
+    devices.pin_worker(device if worker is None else worker, n_workers, device)
     with ThreadPoolExecutor(max_workers=1) as boot:
         ctx_future = boot.submit(open_contexts, device)
         try:
@@ -696,7 +697,7 @@ def main(argv=None):
     procs = []
     for w, dev in enumerate(device_list):
         jobs = [((split_dir, args.outdir, parts[i][0], parts[i][1]), parts[i][2]) for i in assign[w]]
-        pr = mp.Process(target=_gpu_worker, args=(dev, n_gpus, jobs, params, batch_bytes, args.threads, queue, args.sidecar))
+        pr = mp.Process(target=_gpu_worker, args=(dev, n_gpus, jobs, params, batch_bytes, args.threads, queue, args.sidecar, w))
         pr.start()
         procs.append(pr)
     import queue as queue_mod

@@ -119,9 +119,12 @@ int fseg_sync(fseg_ctx *ctx);
 int fseg_get_sizes(fseg_ctx *ctx, fseg_sizes *out);
 
 /* Results, zero-copy: pointers into the context's own pinned host buffers, filled by one device-to-host copy per
- * array (layout as for fseg_download below).  They stay valid until the next fseg_run / fseg_upload / fseg_results
- * on this context.  This is what a host pipeline uses (two contexts per GPU: one batch's results are being written
- * out while the next batch runs); fseg_download copies into caller memory instead.  Any pointer may be NULL. */
+ * array (layout as for fseg_download below).  They stay valid until the next fseg_results / fseg_results_packed call
+ * on this context (or fseg_destroy): the pinned result buffers are written by these two calls and by nothing else, so
+ * fseg_upload and fseg_run of the NEXT batch may be issued while a writer thread still reads the previous batch's
+ * results -- which is what the CLI's pipeline does (freddie_amd/segment.py: upload + run of batch i+1, then wait for
+ * the writer of batch i, then fseg_results_packed).  fseg_download copies into caller memory instead.  Any pointer may
+ * be NULL. */
 int fseg_results(fseg_ctx *ctx, const int64_t **part_final_off, const int32_t **final_pos, const int64_t **label_off,
                  const uint8_t **labels);
 

@@ -51,6 +51,10 @@ SWITCHES = [
     {"FSEG_NO_FUSE": "1"},                                  # every non-tiny problem through the arena path (tiles, work items, k_score, k_dp*)
     {"FSEG_NO_FUSE": "1", "FSEG_NO_TINY": "1", "FSEG_NO_SIZED": "1"},
     {"FSEG_NO_TINY": "1"},                                  # ... and the tiny ones through k_solve
+    {"FSEG_NO_WAVE": "1"},                                  # k_tiny instead of k_wave<8> (batches with a rep of > 510 exons take this)
+    {"FSEG_WAVE_SMALL": "1"},                               # the small class through k_wave<16> (one wave per problem)
+    {"FSEG_WAVE_SMALL": "1", "FSEG_TINY_FROM": "0", "FSEG_NO_GRAPH": "1"},
+    {"FSEG_WAVE_SMALL": "1", "FSEG_NO_TINY": "1"},          # ... and the tiny ones with it
     {"FSEG_GLOBAL_SORT": "1"},                              # the batch-wide radix sort of the reps instead of the in-LDS sort per partition
     {"FSEG_PROB_SELF_MAX": "0"},                            # the problem list always through the block-sum scan
     {"FSEG_PROB_SELF_MAX": "100000000"},                    # ... and always through the self-scanning emit kernel
@@ -249,3 +253,25 @@ def test_contexts_taking_turns_on_one_device():
     finally:
         for c in ctxs:
             c.close()
+
+
+def test_results_outlive_the_next_upload_and_run(gpu_ctx):
+    """include/freddie_seg.h: the zero-copy result views stay valid until the next fseg_results*() call on the context --
+    fseg_upload + fseg_run of ANOTHER batch leave them alone (the CLI's pipeline relies on it: its writer thread reads
+    batch i's views while batch i + 1 is uploaded and run on the same context, freddie_amd/segment.py)."""
+    a = [util.make_partition(5100 + i, n_reads=400, n_exons=60, rp=0.05) for i in range(8)]
+    b = [util.make_partition(5200 + i, n_reads=900, n_exons=120, rp=0.1) for i in range(12)]     # larger: every slab is regrown
+    util.run_gpu(gpu_ctx, a)
+    views = gpu_ctx.results(packed=True)
+    kept = [np.array(v, copy=True) for v in views]
+    want_labels = util.pack_labels(gpu_ctx.download()[3])
+    assert np.array_equal(kept[3], want_labels)
+    util.run_gpu(gpu_ctx, b)                                      # upload + run + sync of another batch; no result call
+    for v, k in zip(views, kept):
+        assert np.array_equal(v, k)                               # the retained views still hold batch a's results
+    oracles = [util.run_oracle(p) for p in b]
+    util.compare_partitions(gpu_ctx, b, oracles)                  # (fseg_download copies into caller memory: views untouched)
+    for v, k in zip(views, kept):
+        assert np.array_equal(v, k)
+    fresh = gpu_ctx.results(packed=True)                          # ... and this call is what replaces them
+    assert np.array_equal(fresh[3], util.pack_labels(gpu_ctx.download()[3]))
