@@ -1,31 +1,35 @@
 #!/usr/bin/env python3
 """Benchmark of the segmentation hot path on MI355X.
 
-A *step* is one pass of the hot path over one batch (about 250 k reads) of synthetic partitions, done the way the
-drop-in CLI does it: ``fseg_upload`` (host arrays -> HBM) -> ``fseg_run`` -> ``fseg_results_packed`` (results in host memory:
-final positions, and the label matrix at two bits per label, which is the form the native writer takes).
-Consecutive steps take DISTINCT batches (the default workload, config4, is the whole 2 M-read / 4 000-partition job in 8
-batches) and alternate between the contexts of the GPU (eight by default), so one batch's copies overlap the others' kernels; no step
-replays a resident batch.  ``value`` = reads segmented by all ranks / max-over-ranks wall time of the timed steps
-(host memory to host memory; reference unit of work: run_segment, py/freddie_segment.py:681-735, minus the file I/O
-which the ``e2e`` leg adds).
+The JOB is fixed: BASELINE config 4 = 4 000 synthetic partitions x 500 reads = 2 000 000 reads (``--workload config5``:
+5 000 x 1 000 reads, sigma 3, threshold rate 0.8), statically scattered over the N ranks (LPT on the partitions' reads,
+freddie_amd/scatter.py -- no collective: partitions share nothing).  A STEP is one pass of the hot path over the rank's
+whole share of the job, done the way the drop-in CLI does it: the share is cut into batches of about 250 k reads (N = 1:
+8 batches, N = 8: 1) and every batch goes ``fseg_upload`` (host arrays -> HBM) -> ``fseg_run`` -> ``fseg_results_packed``
+(results in host memory: final positions, and the label matrix at two bits per label, which is the form the native writer
+takes), the batches taking turns on the contexts of the GPU (eight by default) so that one batch's copies overlap the
+others' kernels; nothing is replayed.  ``value`` = 2 000 000 reads x steps / max-over-ranks wall time of the timed steps
+(host memory to host memory; reference unit of work: run_segment, py/freddie_segment.py:681-735, minus the file I/O which
+the ``e2e`` leg adds), ``ms_per_step`` = the time of the whole job, ``scaling`` = "strong".
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload config4|config2|config3|config5|config1]
   python bench.py --workload cluster-many|cluster-big|isoforms      (rows N3 / N4 of SURVEY 8f: their own metrics, 1 GPU)
 
 Prints ONE JSON line (rank 0) with, besides the driver's fields:
-  roofline              interval-scoring stage of the timed steps: algorithmic bytes 4*(N+K)*R + 4*R per partition
-                         over its HIP-event time on the library's streams
-  roofline_config2      the same for one 50 k-read x 2 k-candidate partition (BASELINE configs[1]), measured after the timed region
-  value_resident_replay the old headline: hipGraph replay of one resident batch (no copies, no sizing)
-  value_hbm_resident    every batch uploaded first, then each run once (first-run path, no copies in the timed part)
+  roofline              the interval-scoring stage ALONE on the GPU (one context, one resident batch of the job replayed, HIP
+                        events around the stage on the library's own streams): algorithmic bytes 4*(N+K)*R + 4*R per partition
+                         over that time -- the figure the per-kernel medians of profiles/ reproduce
+  roofline_concurrent   the same bracket inside the timed steps, where the other contexts' kernels run beside the stage
+  roofline_stages       every stage of the path alone on the GPU (first-run path of distinct batches, events around every
+                        stage): SURVEY 8d's algorithmic bytes of the stage over its time
+  roofline_config2      the scoring stage of one 50 k-read x 2 k-candidate partition (BASELINE configs[1])
+  value_resident_replay hipGraph replay of one resident batch (no copies, no sizing)
+  value_hbm_resident    batches uploaded first, then each run once (first-run path, no copies in the timed part)
   cpu_baseline / cpu_baseline_all_cores   the C oracle on this box's host cores (1 thread / every core)
-  e2e                   the drop-in CLI on a split directory of the 2 M-read job in tmpfs: files in -> files out; at --gpus N
-                        the same job through the CLI's N worker processes (strong scaling), run by rank 0 before any rank
-                        touches a GPU
-  valu_util             VALU utilisation of the scoring kernels from the committed SQ counter pass (profiles/)
-At N GPUs every rank owns its own partitions (static scatter, no collectives: partitions share nothing) and runs the same
-number of steps, so the headline's scaling is weak; the e2e leg's is strong.
+  e2e                   the drop-in CLI on a split directory of the same job in tmpfs: files in -> files out, through the CLI's N
+                        worker processes, run by rank 0 before any rank touches a GPU
+  valu_util, roofline.traffic   counter figures of the scoring kernels from the committed rocprofv3 --pmc passes
+                        (profiles/traffic.json) -- null unless that file was made from the very library this run loads
 """
 import argparse
 import json
@@ -63,25 +67,33 @@ class Batch:
         self.alg_bytes = None
 
 
-def plan_batches(workload, n_gpus):
-    """(partitions per batch, batches per rank): batches of about BATCH_READS reads; at N=1 config4 is the whole
-    4 000-partition job (8 batches), otherwise at least 4 distinct batches per rank, at most 8."""
+def plan_job(workload, rank, n_gpus):
+    """(partition indices of this rank, partitions per batch): the workload's partitions are scattered over the ranks by LPT
+    on their reads (freddie_amd/scatter.py; equal partitions end up striped) and a rank's share is cut into batches of about
+    BATCH_READS reads."""
+    from freddie_amd import scatter
     w = synth.WORKLOADS[workload]
-    per = max(1, min(w["n_partitions"], BATCH_READS // w["n_reads"]))
-    total = max(1, w["n_partitions"] // per)
-    n_batches = min(8, max(4, total // max(1, n_gpus)))
-    return per, n_batches
+    n_part = w["n_partitions"]
+    mine = scatter.rank_share([w["n_reads"]] * n_part, rank, n_gpus) if n_gpus > 1 else list(range(n_part))
+    per = max(1, min(len(mine) or 1, BATCH_READS // w["n_reads"]))
+    return mine, per
+
+
+def plan_batches(workload, n_gpus):
+    """(partitions per batch, batches of rank 0) -- what the developer tools under tools/ size their one batch with."""
+    mine, per = plan_job(workload, 0, n_gpus)
+    return per, (len(mine) + per - 1) // per
 
 
 def build_batches(workload, rank, n_gpus):
     w = dict(synth.WORKLOADS[workload])
     w.pop("n_partitions")
-    per, n_batches = plan_batches(workload, n_gpus)
+    mine, per = plan_job(workload, rank, n_gpus)
     batches = []
-    for b in range(n_batches):
+    for b0 in range(0, len(mine), per):
         parts = []
-        for i in range(per):
-            g = synth.generate((rank * n_batches + b) * per + i, with_seq=False, **w)
+        for i in mine[b0:b0 + per]:
+            g = synth.generate(i, with_seq=False, **w)
             parts.append(pack.pack_partition(g.iv_start, g.iv_end, g.read_exon_off, g.ex_ts, g.ex_te, dedupe=True))
         batches.append(Batch(parts))
     return batches
@@ -140,6 +152,8 @@ def cpu_baseline_all_cores(batches, params, tabs, min_s=8.0):
     if len(parts) < 2:
         return None
     cores = min(host_cores(), 64, len(parts))
+    from oracle import oracle
+    oracle.lib()          # built (if stale) and loaded HERE, once: the forked workers inherit it instead of racing to rebuild it
     _POOL_JOB = (parts, params, tabs)
     n_reads = sum(p.n_reads for p in parts)
     with mp.get_context("fork").Pool(cores) as pool:
@@ -261,15 +275,38 @@ def run_next_row(args):
     print(json.dumps(out))
 
 
-def committed_counters(workload):
-    """Counter figures that need their own rocprofv3 --pmc passes (profiles/traffic.json, written by
-    profiles/pmc_summary.py / tools/sq_summary.py from the committed CSVs): HBM bytes per launch and VALU utilisation
-    of the scoring kernel.  Labelled "committed" in the line: they are not measured in this run."""
+def committed_counters(workload, source_hash=None):
+    """Counter figures that need their own rocprofv3 --pmc passes (profiles/traffic.json, written by profiles/make_traffic.py
+    from the passes of tools/profile_round.sh): HBM bytes per launch and VALU utilisation of the scoring kernels.  They are
+    not measured in this run, so they are reported only when the file says it was made from the very library this run has
+    loaded (``source_hash`` = fseg_source_hash()); otherwise None."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            return json.load(f).get(workload)
+            doc = json.load(f)
     except (OSError, ValueError):
         return None
+    if source_hash is not None and doc.get("source_hash") != source_hash:
+        return None
+    return doc.get(workload)
+
+
+def stage_algorithmic_bytes(batch, sizes, part_final_off, scoring_bytes):
+    """SURVEY.md 8(d) / BASELINE.md section 4: algorithmic bytes per stage of one batch, every input read once and every output
+    written once in the reference's own dtypes (P positions, I exons, R read reps, N candidates, K intervals, F final
+    positions; per partition where the formula is a product)."""
+    P, N = sizes["n_positions"], sizes["n_cand"]
+    I = len(batch.arrays["ex_ts"])
+    R = len(batch.arrays["rep_weight"])
+    labels = 0
+    for p, part in enumerate(batch.parts):
+        F, K, Rp = int(part_final_off[p + 1] - part_final_off[p]), len(part.iv_start), part.n_reps
+        labels += 4 * (F + K) * Rp + max(F - 1, 0) * Rp
+    return {"histogram": 8 * I + 4 * R + 8 * P,            # S1  8I + 4R -> 8P                  (:662-673)
+            "smooth": 16 * P,                              # S2  16 B / position                (:755)
+            "threshold": 8 * P,                            # S3a mean + vf * std of Y > 0       (:757-759)
+            "candidates": 8 * P + 4 * N,                   # S3b 8P -> 4N                        (:615-621)
+            "interval_scoring": scoring_bytes,             # S4 + S5  4(N+K)R + 4R per partition (:188-246, :475-568)
+            "labels": labels}                              # S7  4(F+K)R -> (F-1)R               (:808-830)
 
 
 # ---- GPU legs -----------------------------------------------------------------------------------------------------------
@@ -301,8 +338,8 @@ def one_shot_steps(ctxs, batches, order, collect=None):
 
 def scoring_roofline(alg_bytes, score_ms, committed, extra=None):
     achieved = alg_bytes / (score_ms * 1e-3) / 1e9 if score_ms > 0 else 0.0
-    r = {"kernel": "interval-scoring stage: k_solve<16|32|60> + k_tiny where every problem of the batch sees <= 255 reads (they "
-                   "solve a problem whole: coverage, pair labels, in/out counts AND its DP), else k_score<16|32|60> + k_tiny",
+    r = {"kernel": "interval-scoring stage: k_solve<16|32|60> + k_wave<8> (k_tiny) where every problem of the batch sees <= 255 reads "
+                   "(they solve a problem whole: coverage, pair labels, in/out counts AND its DP), else k_score<16|32|60> + k_wave<8>",
          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
          "traffic": (committed or {}).get("traffic_bytes"), "traffic_source": "committed PMC pass (profiles/traffic.json)" if committed else None,
@@ -315,16 +352,15 @@ def scoring_roofline(alg_bytes, score_ms, committed, extra=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=96, help="timed steps (a step is ~1.4 ms: fewer than ~50 and the six-context "
-                    "pipeline's fill and drain show)")
-    ap.add_argument("--warmup", type=int, default=12)
+    ap.add_argument("--steps", type=int, default=20, help="timed steps; a step is the whole job (config4 on one GPU: 8 batches, ~7 ms)")
+    ap.add_argument("--warmup", type=int, default=3, help="untimed steps before them (at least one; more until the GPU has been busy for 0.5 s)")
     ap.add_argument("--workload", default="config4", choices=sorted(synth.WORKLOADS) + list(NEXT_ROW_WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip both CPU-oracle legs")
     ap.add_argument("--no-e2e", action="store_true", help="skip the CLI end-to-end leg")
     ap.add_argument("--no-extras", action="store_true", help="skip config2's roofline, the replay and the HBM-resident legs")
     ap.add_argument("--e2e-reads", type=int, default=2000000, help="reads of the end-to-end job (default: the whole 2 M-read job)")
     ap.add_argument("--contexts", type=int, default=8, help="contexts per GPU the steps alternate between (each on one stream while "
-                    "the others have work in flight: two per hardware queue; 4: -20 %, 16: -30 %)")
+                    "the others have work in flight: two per hardware queue; 4: -20 %%, 16: -30 %%)")
     args = ap.parse_args()
     if args.workload in NEXT_ROW_WORKLOADS:
         return run_next_row(args)
@@ -341,20 +377,22 @@ def main():
                 h_table=np.asarray(tables.smooth_threshold(params["threshold_rate"]), np.float64))
     batches = build_batches(args.workload, rank, args.gpus)
     n_b = len(batches)
+    wl = synth.WORKLOADS[args.workload]
+    job_reads, job_parts = wl["n_partitions"] * wl["n_reads"], wl["n_partitions"]
 
     # everything that forks or starts a process comes before this process initialises the GPU
     cpu_one = cpu_all = e2e = None
     if rank == 0 and not args.no_cpu_baseline:
         cpu_all = cpu_baseline_all_cores(batches, params, tabs)
-    # The end-to-end leg is a strong-scaling run at every --gpus N: the same split directory through the CLI, which scatters
-    # it over N worker processes (one per GPU).  Rank 0 runs it while no rank has touched a GPU yet; the others wait for it.
+    # The end-to-end leg: the same job as files through the CLI, which scatters it over N worker processes (one per GPU).
+    # Rank 0 runs it while no rank has touched a GPU yet; the others wait for it.
     if not args.no_e2e and args.workload != "config2":
         done = os.path.join(tempfile.gettempdir(), "freddie_bench_e2e_%s_%d.done" % (os.environ.get("MASTER_PORT", "0"), os.getppid()))     # (the launcher is every rank's parent)
         if rank == 0:
             try:
                 if os.path.exists(done):
                     os.remove(done)
-                e2e = e2e_leg(args.workload, params, args.e2e_reads, threads=max(1, min(16, host_cores() // world)), gpus=world)
+                e2e = e2e_leg(args.workload, params, min(args.e2e_reads, job_reads), threads=max(1, min(16, host_cores() // world)), gpus=world)
             except Exception as exc:                     # the headline must not depend on this leg (e.g. no room in tmpfs)
                 e2e = dict(error="%s: %s" % (type(exc).__name__, exc))
             finally:
@@ -392,41 +430,27 @@ def main():
     ctxs = [_lib.Context(local_rank) for _ in range(max(1, args.contexts))]
     for ctx in ctxs:
         ctx.set_params(**params, **tabs)
-        ctx.set_profiling(True)
+        ctx.set_profiling(2)                            # two events per run: the bracket around the interval-scoring stage
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # warm-up: every distinct batch passes once (buffers reach their final sizes); its algorithmic bytes are noted here,
-    # outside the timed region (they are a property of the batch)
-    # The per-stage breakdown of the line (stage_ms) is taken here too, with events around every stage; the timed steps
-    # keep only the two events around the interval-scoring stage (the roofline's bracket): 22 event records per run cost
-    # the three-context pipeline about a tenth of a millisecond per step.
-    warm_acc, warm_n = {}, [0]
-    warm_lock = threading.Lock()
-
+    # warm-up: W untimed steps (every batch of the share passes W times: buffers reach their final sizes; a batch's
+    # algorithmic bytes are noted here, outside the timed region: they are a property of the batch) ...
     def note_alg(si, bi, ctx, res):
         if batches[bi].alg_bytes is None:
             batches[bi].alg_bytes = ctx.scoring_algorithmic_bytes()
-        ms = ctx.stage_ms()
-        with warm_lock:
-            warm_n[0] += 1
-            for k, v in ms.items():
-                warm_acc[k] = warm_acc.get(k, 0.0) + v
-    n_warm = max(args.warmup, n_b, 2 * len(ctxs))      # every context has sized its buffers before the timed steps
+    n_warm_steps = max(1, args.warmup)
     t_warm = time.perf_counter()
-    one_shot_steps(ctxs, batches, [i % n_b for i in range(n_warm)], note_alg)
-    # ... and the GPU has been busy for half a second (a fresh box starts its first 100 ms at lower clocks: 1.5 instead of
-    # 1.1 ms per step); more untimed steps, never fewer than --warmup
-    while time.perf_counter() - t_warm < 0.5 and n_warm < 4096:
-        one_shot_steps(ctxs, batches, [(n_warm + i) % n_b for i in range(4 * len(ctxs))], None)
-        n_warm += 4 * len(ctxs)
-    for ctx in ctxs:
-        ctx.set_profiling(2)
+    if n_b:
+        one_shot_steps(ctxs, batches, [i % n_b for i in range(max(n_warm_steps * n_b, 2 * len(ctxs)))], note_alg)
+        # ... and until the GPU has been busy for half a second (a fresh box runs its first 100 ms at lower clocks)
+        while time.perf_counter() - t_warm < 0.5 and n_warm_steps < 4096:
+            one_shot_steps(ctxs, batches, list(range(n_b)), note_alg)
+            n_warm_steps += 1
 
-    stage_acc = {}
     score_ms_total = [0.0]
     alg_total = [0]
     acc_lock = threading.Lock()
@@ -435,18 +459,17 @@ def main():
     def collect(si, bi, ctx, res):
         ms = ctx.stage_ms()
         with acc_lock:
-            for k, v in ms.items():
-                stage_acc[k] = stage_acc.get(k, 0.0) + v
             score_ms_total[0] += ms["interval_scoring"]
             alg_total[0] += batches[bi].alg_bytes
             checksum[0] += int(res[1][-1]) + int(res[3][-1])          # the results are in host memory: touch them
 
-    # (step i goes to context i mod C; the extra term keeps a context from meeting the same batch every time when C divides
-    #  the number of distinct batches)
-    order = [(n_warm + i + i // len(ctxs)) % n_b for i in range(args.steps)]
+    # the timed steps: K passes over the share, batch after batch, as one stream of work for the contexts (step boundaries
+    # are not barriers: the CLI does not stop between batches either); consecutive batch-steps go to consecutive contexts
+    order = [i % n_b for i in range(args.steps * n_b)] if n_b else []
     barrier()
     t0 = time.perf_counter()
-    one_shot_steps(ctxs, batches, order, collect)
+    if order:
+        one_shot_steps(ctxs, batches, order, collect)
     barrier()
     dt = time.perf_counter() - t0
     n_reads = sum(batches[bi].n_reads for bi in order)
@@ -463,10 +486,60 @@ def main():
         dt_max, total_reads = dt, float(n_reads)
 
     if rank == 0:
-        committed = committed_counters(args.workload)
+        lib_hash = _lib.load().fseg_source_hash().decode()
+        committed = committed_counters(args.workload, lib_hash)
         sizes = ctxs[0].sizes()
-        per, _ = plan_batches(args.workload, args.gpus)
-        w = synth.WORKLOADS[args.workload]
+        _, per = plan_job(args.workload, 0, args.gpus)
+        reps = 20
+        ctx = ctxs[0]
+        for c2 in ctxs:
+            c2.sync()
+
+        # ---- the interval-scoring stage alone on the GPU: one context, one resident batch of the job, replayed
+        ctx.set_profiling(2)
+        ctx.upload(**batches[0].arrays)
+        ctx.run(); ctx.sync()
+        for _ in range(3):
+            ctx.run(); ctx.sync()
+        t0 = time.perf_counter()
+        sc = 0.0
+        for _ in range(reps):
+            ctx.run(); ctx.sync()
+            sc += ctx.stage_ms()["interval_scoring"]
+        dt_r = time.perf_counter() - t0
+        roofline = scoring_roofline(batches[0].alg_bytes, sc / reps, committed,
+                                    {"measured": "HIP events around the stage's launches on the library's streams; one context, one resident "
+                                                 "250 k-read batch of the job replayed %d times: the stage alone on the GPU" % reps})
+
+        # ---- every stage alone on the GPU: distinct batches through the first-run path (plain launches, events around every stage)
+        ctx.set_profiling(True)
+        st_acc, st_bytes, n_st = {}, {}, 0
+        for b in batches[:4]:
+            for _ in range(2):                                        # (the second pass of a batch: arenas already sized)
+                ctx.upload(**b.arrays)
+                ctx.run(); ctx.sync()
+            ms = ctx.stage_ms()
+            res = ctx.results(packed=True)
+            by = stage_algorithmic_bytes(b, ctx.sizes(), res[0], ctx.scoring_algorithmic_bytes())
+            n_st += 1
+            for k, v in ms.items():
+                st_acc[k] = st_acc.get(k, 0.0) + v
+            for k, v in by.items():
+                st_bytes[k] = st_bytes.get(k, 0) + v
+        roofline_stages = {}
+        for k, v in st_acc.items():
+            if k.startswith("graph_") or n_st == 0:
+                continue
+            ms_k = v / n_st
+            e = {"ms": ms_k}
+            if k == "interval_scoring":                               # (with its DP: fused batches have none of their own)
+                e["ms"] = ms_k = (v + st_acc.get("dp", 0.0)) / n_st
+            if k in st_bytes and ms_k > 0:
+                gbs = st_bytes[k] / n_st / (ms_k * 1e-3) / 1e9
+                e.update(algorithmic_bytes=st_bytes[k] // n_st, achieved=gbs, unit="GB/s", frac=gbs / HBM_PEAK_GBS)
+            roofline_stages[k] = e
+        ctx.set_profiling(2)
+
         out = {
             "metric": "reads segmented/sec (whole node)",
             "value": total_reads / dt_max,
@@ -474,53 +547,38 @@ def main():
             "n_gpus": args.gpus,
             "steps": args.steps,
             "warmup": args.warmup,
-            "warmup_steps_run": n_warm,
+            "warmup_steps_run": n_warm_steps,
             "ms_per_step": dt_max / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong",
             "vs_baseline": None,
             "dtype": "u32",
             "dtype_detail": "u32 bit-planes + popcount for scoring, int32 (int64 for very large partitions) DP sums, f64 Gaussian smoothing / threshold",
             "data": "synthetic",
-            "value_is": "host memory -> host memory: fseg_upload + fseg_run + fseg_results_packed per step, distinct batches, "
-                        "%d contexts per GPU (no resident replay)" % len(ctxs),
-            "config": {"workload": args.workload, "partitions": per * n_b * args.gpus, "reads": int(sum(b.n_reads for b in batches)) * args.gpus,
-                       "batches_per_gpu": n_b, "partitions_per_batch": per, "reads_per_batch": batches[0].n_reads,
-                       "reads_per_read_partition": w["n_reads"], "contexts_per_gpu": len(ctxs),
+            "value_is": "host memory -> host memory: a step = fseg_upload + fseg_run + fseg_results_packed of every batch of the rank's share of "
+                        "the fixed job, distinct batches, %d contexts per GPU (no resident replay)" % len(ctxs),
+            "timed_s": dt_max,
+            "config": {"workload": args.workload, "partitions": job_parts, "reads": job_reads,
+                       "batches_per_step_rank0": n_b, "partitions_per_batch": per, "reads_per_batch": batches[0].n_reads if n_b else 0,
+                       "reads_per_partition": wl["n_reads"], "contexts_per_gpu": len(ctxs), "scatter": "static LPT over %d rank(s), no collective" % args.gpus,
                        "candidates_last_batch": sizes["n_cand"], "dp_problems_last_batch": sizes["n_problems"],
                        "positions_last_batch": sizes["n_positions"], "params": {k: params[k] for k in ("sigma", "threshold_rate")}},
-            "roofline": scoring_roofline(alg_total[0] / args.steps, score_ms_total[0] / args.steps, committed,
-                                         {"measured": "HIP events around the stage's launches on the library's streams, "
-                                                      "inside the timed steps (the other contexts' kernels run inside the bracket)"}),
+            "roofline": roofline,
+            "roofline_concurrent": scoring_roofline(alg_total[0] / max(1, len(order)), score_ms_total[0] / max(1, len(order)), committed,
+                                                    {"measured": "the same bracket inside the timed steps (the other contexts' kernels run inside it)"}),
+            "roofline_stages": roofline_stages,
+            "roofline_stages_from": "%d distinct batches, one context alone on the GPU, first-run path (plain launches; events around every stage); "
+                                    "interval_scoring includes the DP" % n_st,
             "valu_util": (committed or {}).get("valu_util"),
             "valu_util_source": (committed or {}).get("valu_source"),
-            "stage_ms": {k: v / max(1, warm_n[0]) for k, v in warm_acc.items()},
-            "stage_ms_from": "the warm-up steps (events around every stage; the timed steps bracket the scoring stage only)",
+            "library_source_hash": lib_hash,
             "result_checksum": checksum[0],
         }
+        out["value_resident_replay"] = {"value": batches[0].n_reads * reps / dt_r, "unit": "reads/s", "ms_per_step": dt_r / reps * 1e3,
+                                        "what": "hipGraph replay of one resident 250 k-read batch: no copies, no arena sizing (a batch, not the job)"}
         if not args.no_extras:
-            # (a) the old headline: graph replay of one resident batch
-            ctx = ctxs[0]
-            ctx.upload(**batches[0].arrays)
-            ctx.run(); ctx.sync()
-            for _ in range(3):
-                ctx.run(); ctx.sync()
-            reps = 20
-            t0 = time.perf_counter()
-            sc = 0.0
-            for _ in range(reps):
-                ctx.run(); ctx.sync()
-                sc += ctx.stage_ms()["interval_scoring"]
-            dt_r = time.perf_counter() - t0
-            out["value_resident_replay"] = {"value": batches[0].n_reads * reps / dt_r, "unit": "reads/s", "ms_per_step": dt_r / reps * 1e3,
-                                            "what": "hipGraph replay of one resident batch (round 1's headline): no copies, no arena sizing",
-                                            "roofline": scoring_roofline(batches[0].alg_bytes, sc / reps, committed)}
-            # the same stage with nothing else on the GPU (the timed steps overlap the kernels of several contexts, which
-            # stretches every kernel's event bracket)
-            out["roofline_serial"] = scoring_roofline(batches[0].alg_bytes, sc / reps, committed,
-                                                      {"measured": "one context, one resident batch replayed: the stage alone on the GPU"})
-            # (b) inputs resident in HBM before the timed part, every batch run ONCE on the first-run path: one batch per
-            #     context uploaded, then all of them run (one host thread per context, as in the timed steps), results left in HBM
+            # inputs resident in HBM before the timed part, every batch run ONCE on the first-run path: one batch per
+            # context uploaded, then all of them run (one host thread per context, as in the timed steps), results left in HBM
             n_h = min(len(ctxs), n_b)
             for c2, b in zip(ctxs[:n_h], batches):
                 c2.upload(**b.arrays)
@@ -537,11 +595,11 @@ def main():
             for t_ in th:
                 t_.join()
             dt_h = time.perf_counter() - t0
-            out["value_hbm_resident"] = {"value": sum(b.n_reads for b in batches[:n_h]) / dt_h, "unit": "reads/s", "ms_per_step": dt_h / n_h * 1e3,
+            out["value_hbm_resident"] = {"value": sum(b.n_reads for b in batches[:n_h]) / dt_h, "unit": "reads/s", "ms_per_batch": dt_h / n_h * 1e3,
                                          "what": "%d distinct batches uploaded first (one per context), then each run once, concurrently: "
                                                  "first-run path (sized arenas, plain launches), results left in HBM, no copies in the "
                                                  "timed part" % n_h}
-            # (c) BASELINE configs[1]: one 50 k-read partition
+            # BASELINE configs[1]: one 50 k-read partition
             if config2_batch is not None:
                 ctx.upload(**config2_batch.arrays)
                 ctx.run(); ctx.sync()
@@ -554,7 +612,7 @@ def main():
                     ctx.run(); ctx.sync()
                     sc += ctx.stage_ms()["interval_scoring"]
                 dt_2 = time.perf_counter() - t0
-                r2 = scoring_roofline(alg2, sc / reps, committed_counters("config2"))
+                r2 = scoring_roofline(alg2, sc / reps, committed_counters("config2", lib_hash))
                 r2.update(workload="config2", reads=config2_batch.n_reads, ms_per_step=dt_2 / reps * 1e3,
                           what="one partition, 50 k reads x ~2 k candidates, resident replay")
                 out["roofline_config2"] = r2

@@ -1,7 +1,15 @@
 import sys, json
 for line in sys.stdin:
-    line=line.strip()
-    if not line.startswith("{"): continue
-    d=json.loads(line)
-    print("%s value=%.3gM reads/s ms/step=%.3f frac=%.3f score_ms=%.3f"%(d["config"]["workload"], d["value"]/1e6, d["ms_per_step"], d["roofline"]["frac"], d["roofline"]["launch_ms"]))
-    print("  "+" ".join("%s=%.3f"%(k,v) for k,v in d["stage_ms"].items()))
+    line = line.strip()
+    if not line.startswith("{"):
+        continue
+    d = json.loads(line)
+    r = d["roofline"]
+    print("%s value=%.4gM reads/s ms/step(job)=%.3f timed=%.3fs | scoring stage alone %.3f ms frac=%.3f (concurrent %.3f ms)" % (
+        d["config"]["workload"], d["value"] / 1e6, d["ms_per_step"], d.get("timed_s", 0.0), r["launch_ms"], r["frac"],
+        d.get("roofline_concurrent", {}).get("launch_ms", 0.0)))
+    st = d.get("roofline_stages") or {}
+    print("  " + " ".join("%s=%.3f%s" % (k, v["ms"], ("(%.2f)" % v["frac"]) if "frac" in v else "") for k, v in st.items()))
+    e = d.get("e2e") or {}
+    if "value" in e:
+        print("  e2e %.3gM reads/s (%s s)" % (e["value"] / 1e6, ",".join("%.2f" % x for x in e["wall_s"])))
