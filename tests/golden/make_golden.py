@@ -75,6 +75,16 @@ def edge_cases():
     for i in range(6, 10):
         reads.append((i, "+", [(2010, 2060, 0, 50, "50M"), (2060, 2120, 50, 110, "60M"), (2300, 2380, 110, 190, "80M")], 190 + 30))
     cases["e_plateau_touch"] = (3, [(2000, 2230), (2300, 2400)], reads)
+    # refine_segmentation's find_peaks(distance=20) with an EXACT tie (quirk: the order of equal heights is numpy's argsort):
+    # two families of 30 reads with a one-base gap at 3100|3102 and at 3110|3112.  Every read covers both sides of its gap,
+    # so the DP cuts nowhere and the whole interval reaches refine_segmentation; there the two clusters smooth (radius 5) to
+    # peaks at y = 101 and y = 111 of the same height to the last bit ((30 + 30) * w[1] each), ten positions apart.
+    reads = []
+    for i in range(30):
+        reads.append((i, "+", [(3000, 3100, 0, 100, "100M"), (3102, 3390, 100, 388, "288M")], 388 + 12))
+    for i in range(30, 60):
+        reads.append((i, "-", [(3000, 3110, 0, 110, "110M"), (3112, 3390, 110, 388, "278M")], 388 + 9))
+    cases["e_refine_tie"] = (4, [(3000, 3400)], reads)
     return cases
 
 

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 
 # FREDDIE_FUZZ_SEEDS=20,21,...: a longer sweep by hand after a change to the kernels
-SEEDS = [int(x) for x in os.environ.get("FREDDIE_FUZZ_SEEDS", "7,11").split(",")]
+SEEDS = [int(x) for x in os.environ.get("FREDDIE_FUZZ_SEEDS", "7,11,23,42").split(",")]
 
 
 @pytest.mark.parametrize("seed", SEEDS)

@@ -112,14 +112,15 @@ def test_huge_problems_and_tiny_problems_in_one_batch(monkeypatch):
         ctx.close()
 
 
-@pytest.mark.parametrize("workload,n_part", [("config4", 500), ("config3", 250)])
+@pytest.mark.parametrize("workload,n_part", [("config4", 500), ("config3", 250), ("config5", 250)])
 def test_full_size_bench_batches_against_oracle(workload, n_part, gpu_ctx):
-    """The exact batches bench.py times (config4: one GPU's 500 x 500-read share; config3: 250 x 1000 reads), every
-    tap of every partition against the oracle."""
+    """The exact batches bench.py times (config4: 500 x 500 reads; config3: 250 x 1000 reads; config5: 250 x 1000 reads of the
+    ONT-like error model under sigma = 3, threshold rate 0.8), every tap of every partition against the oracle."""
     kw = dict(synth.WORKLOADS[workload]); kw.pop("n_partitions")
+    params = dict(sigma=3.0, threshold_rate=0.8) if workload == "config5" else None
     parts = [util.make_partition(i, **kw) for i in range(n_part)]
-    oracles = [util.run_oracle(p) for p in parts]
-    util.run_gpu(gpu_ctx, parts)
+    oracles = [util.run_oracle(p, params) for p in parts]
+    util.run_gpu(gpu_ctx, parts, params)
     rep = util.compare_partitions(gpu_ctx, parts, oracles)
     assert rep["y_identical"]
     gpu_ctx.run(); gpu_ctx.sync()
@@ -224,8 +225,10 @@ def test_contexts_taking_turns_on_one_device():
     n_ctx, rounds = 4, 3
     batches = []
     for b in range(n_ctx * rounds):
+        # (the middle round's batches are large enough -- more than 1 MB of packed labels -- to leave through the SDMA engine)
         parts = [util.make_partition(3000 + 17 * b + i, n_reads=150 + 40 * ((b + i) % 5), n_exons=40 + 10 * (i % 4), rp=0.05 * (i % 3))
-                 for i in range(6)]
+                 for i in range(6)] if b // n_ctx != 1 else \
+                [util.make_partition(3400 + 31 * b + i, n_reads=500, n_exons=150, rp=0.05) for i in range(36)]
         batches.append((parts, [util.run_oracle(p) for p in parts]))
     ctxs = [_lib.Context(0) for _ in range(n_ctx)]
     errors = []
