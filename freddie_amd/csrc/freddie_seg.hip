@@ -298,8 +298,11 @@ constexpr int kSmoothStage = (kSmoothTile + 2 * kMaxRadius + kSmoothThreads - 1)
 template <int R>
 __global__ void __launch_bounds__(kSmoothThreads) k_smooth(int n_tiles, const TileDesc *tiles,
                                                 const int *y_raw, const double *__restrict__ w_g, int radius_rt,
-                                                double *y_out, unsigned char *flag_pos, unsigned char *flag_zero, int *cum, int *tile_tot) {
+                                                double *y_out, unsigned char *flag_pos, unsigned char *flag_cand, int *cum, int *tile_tot,
+                                                unsigned char *final_flag, int *tile_defer) {
     __shared__ int xs[kSmoothTile + 2 * kMaxRadius];
+    __shared__ __align__(4) unsigned char cf[kSmoothTile];     // candidate flags of the tile
+    __shared__ int defer_s;
     __shared__ int scan_lds[16];
     __shared__ double ws[kMaxRadius + 1];
     // results go through LDS so that consecutive lanes store consecutive positions (a thread computes 4 in a row)
@@ -345,14 +348,15 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth(int n_tiles, const Ti
             for (int e = 0; e < 4; ++e) cs[o4 + e] = ex + v4[e];
             if (threadIdx.x == 0) tile_tot[t] = tot;
         }
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;    // this thread's four outputs (kept for the candidate test below)
         {   // every thread computes 4 consecutive outputs; the two 4-wide input windows of tap j slide by one
             // position per tap, so each tap costs two LDS reads for four outputs
             const int o4 = threadIdx.x * 4;
             if (y0 + o4 < len) {
                 const int c = o4 + radius;
                 const double w0 = ws[0];
-                double a0 = __dmul_rn((double)(xs[c]), w0), a1 = __dmul_rn((double)(xs[c + 1]), w0);
-                double a2 = __dmul_rn((double)(xs[c + 2]), w0), a3 = __dmul_rn((double)(xs[c + 3]), w0);
+                a0 = __dmul_rn((double)(xs[c]), w0); a1 = __dmul_rn((double)(xs[c + 1]), w0);
+                a2 = __dmul_rn((double)(xs[c + 2]), w0); a3 = __dmul_rn((double)(xs[c + 3]), w0);
                 int l0 = xs[c - radius], l1 = xs[c - radius + 1], l2 = xs[c - radius + 2], l3 = xs[c - radius + 3];
                 int r0 = xs[c + radius], r1 = xs[c + radius + 1], r2 = xs[c + radius + 2], r3 = xs[c + radius + 3];
 #define FSEG_TAP(W)                                                                                        \
@@ -372,13 +376,54 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth(int n_tiles, const Ti
                 ys[o4] = a0; ys[o4 + 1] = a1; ys[o4 + 2] = a2; ys[o4 + 3] = a3;
             }
         }
+        if (threadIdx.x == 0) defer_s = -1;
         lds_barrier();
+        // S3b candidates (candidates_from_peaks :615-621 = scipy's _local_maxima_1d + the interval's first and last position),
+        // decided here while the tile's smoothed values are at hand -- a pass of its own over the signal read all of it back
+        // from HBM.  A strict maximum, or the midpoint of a plateau that rises on its left and falls on its right
+        // ((first + last) / 2), counts.  A thread tests its own four outputs (registers; its two outer neighbours from LDS) and
+        // writes their flags as one word.  What this tile cannot see is left to k_peaks_edges: whether its first and its last
+        // position start a peak (their outer neighbours belong to other tiles) and the one plateau that may run into the
+        // tile's last position (its start goes to tile_defer).
+        int mid0 = -1, mid1 = -1;        // plateau midpoints found by this thread, written after the words (four consecutive
+                                         // positions hold at most two plateau peaks: rise, level, fall, rise, level)
+        {
+            const int o4 = threadIdx.x * 4;
+            const double v[6] = {ys[o4 > 0 ? o4 - 1 : 0], a0, a1, a2, a3, ys[o4 + 4 < kSmoothTile ? o4 + 4 : kSmoothTile - 1]};
+            unsigned word = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = o4 + e;
+                const i64 pos = y0 + i;
+                if (pos >= len) break;
+                if (pos == 0 || pos == len - 1) { word |= 1u << (8 * e); continue; }
+                if (i == 0 || i == kSmoothTile - 1) continue;            // k_peaks_edges
+                const double a = v[e + 1];
+                if (v[e] < a) {
+                    if (v[e + 2] < a) word |= 1u << (8 * e);
+                    else if (v[e + 2] == a) {
+                        int ia = i + 1;                                  // (scipy: extend while ia < len - 1 and y[ia] == y[i])
+                        while (ia < kSmoothTile - 1 && y0 + ia < len - 1 && ys[ia] == a) ++ia;
+                        if (ys[ia] == a && y0 + ia < len - 1) defer_s = i;   // still level at the tile's last position: not decidable here
+                                                                             // (at most one run of equal values reaches the tile's end)
+                        else if (ys[ia] < a) { if (mid0 < 0) mid0 = (i + ia - 1) >> 1; else mid1 = (i + ia - 1) >> 1; }
+                    }
+                }
+            }
+            reinterpret_cast<unsigned *>(cf)[threadIdx.x] = word;
+        }
+        lds_barrier();
+        if (mid0 >= 0) cf[mid0] = 1;
+        if (mid1 >= 0) cf[mid1] = 1;
+        lds_barrier();
+        if (threadIdx.x == 0) tile_defer[t] = defer_s;
         for (int i = threadIdx.x; i < kSmoothTile; i += blockDim.x) {
             if (y0 + i < len) {
                 const double a = ys[i];
                 y_out[base + y0 + i] = a;
                 flag_pos[base + y0 + i] = a > 0.0 ? 1 : 0;
-                flag_zero[base + y0 + i] = 0;                       // candidate flags start cleared (k_peaks sets them)
+                flag_cand[base + y0 + i] = cf[i];
+                final_flag[base + y0 + i] = 0;                       // final-position flags start cleared (k_segments / k_refine set them)
                 cum[base + y0 + i] = cs[i];
             }
         }
@@ -857,46 +902,32 @@ __global__ void k_vsum_part(int n_part, const i64 *voff, const i64 *chunk_off, c
 // strict local maxima with the plateau-midpoint rule, plus the first and last position.
 // ---------------------------------------------------------------------------------------------
 // edge[p]: bit 0 = p is the first position of its interval, bit 1 = the last one.  Built once per uploaded batch.
-__global__ void __launch_bounds__(256) k_edges(i64 K, const i64 *pos_off, unsigned char *edge) {
-    for (i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x; k < K; k += (i64)gridDim.x * blockDim.x) {
-        const i64 a = pos_off[k], b = pos_off[k + 1] - 1;
-        if (a == b) edge[a] = 3;
-        else { edge[a] = 1; edge[b] = 2; }
+// What k_smooth's tiles could not decide about candidates_from_peaks (:615-621): one thread per tile looks, in the finished
+// signal, at the tile's first position, its last position and the plateau start the tile deferred -- as possible STARTS of a
+// peak (a strict maximum, or a plateau whose midpoint counts when it falls on its right; the walk stops at the interval's
+// last position, as scipy's does).  Interval ends were flagged by the tiles.
+__device__ __forceinline__ void peak_from(i64 p, i64 last /* the interval's last position */, const double *x, unsigned char *flag) {
+    const double xi = x[p];
+    if (!(x[p - 1] < xi)) return;
+    if (x[p + 1] < xi) { flag[p] = 1; return; }
+    if (x[p + 1] == xi) {
+        i64 ia = p + 1;
+        while (ia < last && x[ia] == xi) ++ia;
+        if (x[ia] < xi) flag[(p + ia - 1) / 2] = 1;     // plateau midpoint (positions of one interval are consecutive)
     }
 }
-// Flat over all positions of the batch (intervals are contiguous in the position arrays): a thread owns four consecutive
-// positions, the interval structure comes from the edge bytes, every lane is busy whatever the interval lengths are,
-// and the loads are wide and unconditional.  A position that is neither first nor last has both neighbours in its own
-// interval; the plateau walk to the right stops at the interval's last position.
-__global__ void __launch_bounds__(256) k_peaks(i64 n_pos, const unsigned char *edge, const double *x, unsigned char *flag,
-                                               unsigned char *final_zero, int *part_has2, int n_part) {
+__global__ void __launch_bounds__(256) k_peaks_edges(int n_tiles, const TileDesc *tiles, const int *tile_defer, const double *x,
+                                                     unsigned char *flag, int *part_has2, int n_part) {
     // also clears the per-partition 'some default label is not 0' flags that k_label_cols sets much later
     if (blockIdx.x == 0) for (int p = threadIdx.x; p < n_part; p += blockDim.x) part_has2[p] = 0;
-    const i64 n4 = (n_pos + 3) >> 2;
-    for (i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x; g < n4; g += (i64)gridDim.x * blockDim.x) {
-        const i64 p0 = g * 4;
-        // the arrays are padded by 64 elements, so the 4-wide loads of the last group stay inside the allocation
-        const double2 v01 = *reinterpret_cast<const double2 *>(x + p0), v23 = *reinterpret_cast<const double2 *>(x + p0 + 2);
-        const double left = x[p0 > 0 ? p0 - 1 : 0], right = x[p0 + 4 < n_pos ? p0 + 4 : n_pos - 1];
-        const unsigned e4 = *reinterpret_cast<const unsigned *>(edge + p0);
-        *reinterpret_cast<unsigned *>(final_zero + p0) = 0u;    // final-position flags start cleared (k_segments / k_refine set them)
-        const double w[6] = {left, v01.x, v01.y, v23.x, v23.y, right};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const i64 p = p0 + e;
-            if (p >= n_pos) break;
-            const unsigned ed = (e4 >> (8 * e)) & 0xffu;
-            if (ed) { flag[p] = 1; continue; }              // first and last position of an interval are candidates (:618-620)
-            const double xi = w[e + 1];
-            if (w[e] < xi) {
-                if (w[e + 2] < xi) flag[p] = 1;             // strict peak: plateau of one
-                else if (w[e + 2] == xi) {
-                    i64 ia = p + 1;
-                    while (!(edge[ia] & 2) && x[ia] == xi) ++ia;
-                    if (x[ia] < xi) flag[(p + ia - 1) / 2] = 1;   // plateau midpoint (positions of one interval are consecutive)
-                }
-            }
-        }
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n_tiles; t += gridDim.x * blockDim.x) {
+        const TileDesc d = tiles[t];
+        const i64 first = d.base + d.y0, last = d.base + d.len - 1;
+        const i64 tile_last = first + kSmoothTile - 1;
+        if (d.y0 > 0 && first < last) peak_from(first, last, x, flag);              // (an interval's own ends are candidates already)
+        if (tile_last < last && kSmoothTile > 1) peak_from(tile_last, last, x, flag);
+        const int df = tile_defer[t];
+        if (df >= 0) peak_from(first + df, last, x, flag);
     }
 }
 
@@ -3734,7 +3765,7 @@ struct fseg_ctx {
         d_rep_exon_off, d_rep_weight, d_ex_ts, d_ex_te, d_tile_desc, d_iv_tile0, d_blk_iv0, d_rb_part, d_rb_r0, d_rb_sum, d_rb_base, d_rb_max, d_rb_cmax,
         d_hc_part, d_hc_p0, d_hc_n, d_hc_glo, d_hc_ghi;
     // slab_in, derived on the device by the upload
-    DevBuf d_lane_ex, d_lane_start, d_lane_pmax, d_hc_llo, d_hc_lhi, d_edge, d_key_a, d_key_b, d_val_a, d_val_b, d_rep_last;
+    DevBuf d_lane_ex, d_lane_start, d_lane_pmax, d_hc_llo, d_hc_lhi, d_key_a, d_key_b, d_val_a, d_val_b, d_rep_last;
     DevBuf d_lane_lx, d_lex, d_rb_esum, d_rb_ebase;   // the exons again as one (ts, te) stream in lane order, and every lane's range in it
     i64 max_rep_exons = 0;       // most exons of one rep in the resident batch
     DevBuf d_w_main, d_w_refine, d_h_table, d_thr_tab;     // parameter tables (own allocations)
@@ -3746,6 +3777,7 @@ struct fseg_ctx {
     // candidate-sized (slab_pos)
     DevBuf d_cand_off, d_cand_y, d_fixed0, d_added, d_fixed, d_chosen, d_final_off, d_final_y, d_final_pos, d_final_iv, d_col_thr,
         d_col_zero;
+    DevBuf d_tile_defer;        // per smoothing tile: start of the plateau that reaches the tile's end (-1: none)
     DevBuf d_cum, d_tile_tot, d_seg_iv, d_seg_prev, d_rseg_c, d_cand_pn, d_cand_ll, d_cand_ln, d_prob_bs;
     // problems / arenas (slab_arena)
     DevBuf d_prob_iv, d_prob_start, d_prob_n, d_prob_pair_off, d_prob_tri_off, d_prob_flags, d_prob_chain,
@@ -4034,7 +4066,8 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
     hipLaunchKernelGGL(k_smooth<RV>, dim3(tile_grid), dim3(kSmoothThreads), 0, s, c->n_tiles, c->d_tile_desc.as<TileDesc>(),      \
                        c->d_y_raw.as<int>(), c->d_w_main.as<double>(),                                                 \
                        c->P.radius_main, c->d_y.as<double>(), c->d_flag.as<unsigned char>(),                           \
-                       c->d_cflag.as<unsigned char>(), c->d_cum.as<int>(), c->d_tile_tot.as<int>())
+                       c->d_cflag.as<unsigned char>(), c->d_cum.as<int>(), c->d_tile_tot.as<int>(),                    \
+                       c->d_final_flag.as<unsigned char>(), c->d_tile_defer.as<int>())
     // sigma = 5 (default) and sigma = 3 (config 5) have their own unrolled instances; any other radius runs the loop
     if (c->P.radius_main == 20) { FSEG_LAUNCH_SMOOTH(20); }
     else if (c->P.radius_main == 12) { FSEG_LAUNCH_SMOOTH(12); }
@@ -4067,9 +4100,8 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
     }
     begin(ST_CANDIDATES);
     // S3b candidates
-    hipLaunchKernelGGL(k_peaks, dim3(grid_for(NPOS / 4 + 1, 256, 16384)), dim3(256), 0, s, NPOS, c->d_edge.as<unsigned char>(),
-                       c->d_y.as<double>(), c->d_cflag.as<unsigned char>(),
-                       c->d_final_flag.as<unsigned char>(), c->d_part_has2.as<int>(), n_part);
+    hipLaunchKernelGGL(k_peaks_edges, dim3(grid_for(c->n_tiles, 256, 4096)), dim3(256), 0, s, c->n_tiles, c->d_tile_desc.as<TileDesc>(),
+                       c->d_tile_defer.as<int>(), c->d_y.as<double>(), c->d_cflag.as<unsigned char>(), c->d_part_has2.as<int>(), n_part);
     scan_counts(s, bsum, c->d_cflag.as<unsigned char>(), &st->n_cand, c->d_cand_off.as<i64>() + K);
     hipLaunchKernelGGL(k_scan_emit<kEmitPositions>, dim3(scan_grid), dim3(256), 0, s, c->d_cflag.as<unsigned char>(), NPOS,
                        bsum, scan_state + scan_nb, &st->n_cand, c->d_cand_off.as<i64>() + K, &st->err, (const double *)nullptr, (double *)nullptr, K, c->d_pos_off.as<i64>(),
@@ -4788,7 +4820,6 @@ static int upload_impl(fseg_ctx *c, const fseg_batch *b) {
     in.add(c->d_lane_pmax, (size_t)lanes * 4);
     in.add(c->d_hc_llo, (size_t)n_chunks * 8);
     in.add(c->d_hc_lhi, (size_t)n_chunks * 8);
-    in.add(c->d_edge, (size_t)NPOS + 64);
     in.add(c->d_key_a, (size_t)R * 8);
     in.add(c->d_key_b, (size_t)R * 8);
     in.add(c->d_val_a, (size_t)R * 4);
@@ -4919,8 +4950,6 @@ static int upload_impl(fseg_ctx *c, const fseg_batch *b) {
     hipLaunchKernelGGL(k_hist_ranges, dim3(grid_for(n_chunks, 256, 4096)), dim3(256), 0, s, (int)n_chunks, c->d_hc_part.as<int>(),
                        c->d_hc_glo.as<int>(), c->d_hc_ghi.as<int>(), c->d_part_lane_off.as<i64>(), c->d_lane_start.as<int>(),
                        c->d_lane_pmax.as<int>(), c->d_hc_llo.as<i64>(), c->d_hc_lhi.as<i64>());
-    HIP_TRY(c, hipMemsetAsync(c->d_edge.p, 0, (size_t)NPOS + 64, s));
-    hipLaunchKernelGGL(k_edges, dim3(grid_for(K, 256, 4096)), dim3(256), 0, s, K, c->d_pos_off.as<i64>(), c->d_edge.as<unsigned char>());
     HIP_TRY(c, hipMemcpyAsync(c->h_prep, c->d_prep.p, sizeof(PrepStatus), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipGetLastError());
     // ---- position- and candidate-sized work buffers (candidates and finals are distinct positions, so NPOS bounds them)
@@ -4938,6 +4967,7 @@ static int upload_impl(fseg_ctx *c, const fseg_batch *b) {
         cv.add(c->d_final_flag, np8);
         cv.add(c->d_part_has2, ((size_t)np + 1) * 4);
         cv.add(c->d_tile_tot, ((size_t)n_tiles + 1) * 4);
+        cv.add(c->d_tile_defer, ((size_t)n_tiles + 1) * 4);
         cv.add(c->d_voff, ((size_t)np + 2) * 8); cv.add(c->d_chunk_off, ((size_t)np + 2) * 8);
         cv.add(c->d_mean, ((size_t)np + 1) * 8); cv.add(c->d_thr, ((size_t)np + 1) * 8);
         cv.add(c->d_label_off, ((size_t)np + 2) * 8);
