@@ -94,6 +94,7 @@ struct Status {
     u64 cov_queue;
     u64 solve_cls[3];  // problems solved whole by k_solve (n <= 16 / <= 32 / <= kNMax)
     u64 n_tiny;        // problems solved whole by k_tiny (their list follows the three solve lists)
+    unsigned wide_cls[4];   // solve-list problems per size class that see more than kFuseLanes reads (16-bit counters); [3] unused
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -1274,6 +1275,26 @@ __device__ __forceinline__ void prob_block_maxima(Status *st, const int *cand_pn
     for (int d = 32; d >= 1; d >>= 1) { mx = max(mx, __shfl_xor(mx, d)); ml = max(ml, __shfl_xor(ml, d)); }
     if (lane_id() == 0) { l_mx[threadIdx.x >> 6] = mx; l_mx[4 + (threadIdx.x >> 6)] = ml; }
 }
+// solve-list problems of the block that see more than 255 reads, per size class (they need the 16-bit-counter instances of
+// k_solve: the host launches those only for classes that have any)
+__device__ __forceinline__ void prob_block_wide(Status *st, const int *cand_pn, const int *cand_ln, i64 b, i64 n, ProbSplit sp) {
+    unsigned w = 0;                                            // one count per byte: class 0 | class 1 << 8 | class 2 << 16
+    for (int e = 0; e < 4; ++e) {
+        const i64 cc = b * kProbBlock + (i64)threadIdx.x * 4 + e;
+        if (cc < n) {
+            const int pn = cand_pn[cc], ln = pn > 0 ? cand_ln[cc] : 0;
+            if (pn > 0 && ln > 255 && prob_kind(pn, ln, sp) == kKindFused) w += 1u << (8 * size_class(pn));
+        }
+    }
+    if (__ballot(w != 0) == 0) return;
+    unsigned c0 = w & 255u, c1 = (w >> 8) & 255u, c2 = (w >> 16) & 255u;
+    for (int d = 32; d >= 1; d >>= 1) { c0 += __shfl_xor(c0, d); c1 += __shfl_xor(c1, d); c2 += __shfl_xor(c2, d); }
+    if (lane_id() == 0) {
+        if (c0) atomicAdd(&st->wide_cls[0], c0);
+        if (c1) atomicAdd(&st->wide_cls[1], c1);
+        if (c2) atomicAdd(&st->wide_cls[2], c2);
+    }
+}
 __device__ __forceinline__ void prob_publish_maxima(Status *st, const int *l_mx) {
     const int mx = max(max(l_mx[0], l_mx[1]), max(l_mx[2], l_mx[3])), ml = max(max(l_mx[4], l_mx[5]), max(l_mx[6], l_mx[7]));
     if (mx > 0 && (unsigned)mx > __hip_atomic_load(&st->max_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&st->max_n, (unsigned)mx);
@@ -1287,6 +1308,7 @@ __global__ void __launch_bounds__(256) k_prob_scan1(Status *st, const int *cand_
     for (i64 b = blockIdx.x; b < nb; b += gridDim.x) {
         ProbSizes acc = prob_block_sizes(cand_pn, cand_ln, b, n, nullptr, sp), ex, tot;
         prob_block_maxima(st, cand_pn, cand_ln, b, n, l_mx);
+        prob_block_wide(st, cand_pn, cand_ln, b, n, sp);
         wg_scan_cols(acc, ex, tot, lds);
         if (threadIdx.x < kProbCols) bs[b * kProbCols + threadIdx.x] = tot.v[threadIdx.x];
         if (threadIdx.x == 0) prob_publish_maxima(st, l_mx);
@@ -1347,6 +1369,7 @@ __global__ void __launch_bounds__(256) k_prob_emit(Status *st, const int *cand_p
         }
         ProbSizes acc = prob_block_sizes(cand_pn, cand_ln, b, n, sz, sp);
         if (!bs) prob_block_maxima(st, cand_pn, cand_ln, b, n, l_mx);   // (with block sums, k_prob_scan1 has done it; read after the barriers below)
+        if (!bs) prob_block_wide(st, cand_pn, cand_ln, b, n, sp);
         wg_scan_cols(acc, ex, tot, lds);
         if (!bs && threadIdx.x == 0) prob_publish_maxima(st, l_mx);
         for (int q = 0; q < kProbCols; ++q) ex.v[q] += before.v[q];
@@ -2534,8 +2557,10 @@ __global__ void __launch_bounds__(256, WaveCfg<NM>::kOcc) k_wave(Status *st, con
 // threshold / ambiguity / count arenas, no work items, no DP list entry.  (The arena path remains for problems that see
 // thousands of reads, where one problem has to be spread over many workgroups.)
 // ---------------------------------------------------------------------------------------------
-constexpr int kFuseLanes = 255;   // (four 64-read rounds at most: a problem that sees more is quicker spread over work items;
-                                  //  and 8-bit counters always suffice)
+constexpr int kFuseLanes = 255;   // reads a problem may see for 8-bit triple counters (four 64-read rounds at most)
+constexpr int kFuseLanesWide = 1023;   // ... and for the 16-bit instances: partitions of 1 000 reads have problems that see ~300 (one
+                                       // in twenty-five of them more than 255); a problem that sees more than this is quicker spread
+                                       // over the arena path's work items, and so is its whole batch
 template <int NM> struct SolveCfg {
     static constexpr int kThreads = ScoreCfg<NM>::kThreads;
     static constexpr int kSlots = ScoreCfg<NM>::kSlots;
@@ -2567,7 +2592,7 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ int cy_s[NM + 4];
     __shared__ int iend_s[NM + 4];
-    __shared__ int2 act_s[256];                    // reads with coverage in the window: (first exon that meets it, how many do)
+    __shared__ int2 act_s[sizeof(CntT) == 1 ? kFuseLanes + 1 : kFuseLanesWide + 1];   // reads with coverage in the window: (first exon that meets it, how many do)
     __shared__ int act_wave[T / 64];
     const int rt_pairs = nm * (nm - 1) / 2;
     constexpr int rt_stride = NM + 1;             // compile-time row stride (odd: rows do not collide on LDS banks)
@@ -2605,7 +2630,9 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
         __syncthreads();                                             // the previous problem's DP is done with LDS
         FSEG_STICK(0);
         if (n > nm || n > NM) { if (threadIdx.x == 0) atomicOr(&st->err, kErrOverflowNm); continue; }
-        if (sizeof(CntT) == 1 && d.lane_n > 255) { if (threadIdx.x == 0) atomicOr(&st->err, kErrNeedWideDp); continue; }
+        // a list's problems are shared by two launches: the 8-bit counters take those that see at most 255 reads, the 16-bit ones the rest
+        if ((sizeof(CntT) == 1) != (d.lane_n <= kFuseLanes)) continue;
+        if (d.lane_n > kFuseLanesWide) { if (threadIdx.x == 0) atomicOr(&st->err, kErrNeedWideDp); continue; }
         const int npairs = n * (n - 1) / 2, ntri = n * (n - 1) * (n - 2) / 6;
         const int *cy = cand_y + d.c0;
         for (int j = threadIdx.x; j < n; j += T) cy_s[j] = cy[j];
@@ -3828,6 +3855,14 @@ struct fseg_ctx {
     bool wave_small = false;    // FSEG_WAVE_SMALL=1: the small class (9 .. 16 candidates) goes to k_wave<16> instead of k_solve<16> (one wave
                                 // per problem: a third less wave-time, but 48 instead of 38 us when the kernel has the GPU to itself)
     bool use_fuse = true;       // FSEG_NO_FUSE=1: no problem goes to k_solve (everything that is not tiny takes the arena path)
+    // Reads the widest problem of a batch may see for the batch's problems to be solved whole (k_solve / k_wave) instead of going
+    // through the arena path; FSEG_FUSE_LANES=1023 admits batches of 1 000-read partitions (their widest problems see ~300 reads:
+    // the 16-bit-counter instances of k_solve take those).  Measured on 250 x 1 000-read batches (config3 / config5): one batch
+    // alone on the GPU is quicker solved whole (0.82 / 0.76 against 0.85 / 0.82 ms per replayed batch), eight contexts taking
+    // turns are not (config3: 249 against 301 M reads/s; config5: equal) -- the few wide problems are long, thin launches -- so
+    // the default keeps such batches on the arena path.
+    int fuse_lanes = kFuseLanes;
+    bool wide_solve = true;     // some problem of the batch sees more than kFuseLanes reads: the 16-bit-counter instances of k_solve run too
     bool fuse_on = true;        // this batch's problems go to k_solve: decided per batch -- when its widest problem sees at most
                                 // kFuseLanes reads, i.e. all of them qualify (measured: a batch of 500-read partitions gains 8 %, while
                                 // batches whose problems straddle the limit run both paths side by side and lose up to 8 %)
@@ -3835,6 +3870,7 @@ struct fseg_ctx {
     // launches over an empty list are skipped
     bool counts_known = false;
     i64 n_solve[3] = {0, 0, 0}, n_cls_work[4] = {0, 0, 0, 0}, n_dp_cls[3] = {0, 0, 0}, n_arena_prob = 0, n_tiny = 0;
+    i64 n_wide[3] = {0, 0, 0};  // of n_solve: problems that need the 16-bit-counter instances
     i64 tiny_from = 256;        // problems above which k_tiny is used (FSEG_TINY_FROM; tests force 0)
     bool trace = false;         // FSEG_TRACE=1: phase timers of upload / run on stderr
     bool force_global_sort = false;   // FSEG_GLOBAL_SORT=1 (tests): the batch-wide radix sort whatever the partition sizes
@@ -3979,7 +4015,7 @@ inline i64 scan_blocks(i64 n) { return (n + kScanBlock - 1) / kScanBlock; }
 bool wave_on(const fseg_ctx *c) { return c->use_wave && c->max_rep_exons <= kWaveRepExons; }
 ProbSplit split_of(const fseg_ctx *c, bool tiny, bool fuse) {
     const bool wave = wave_on(c);
-    return ProbSplit{tiny ? kTiny : 0, (c->use_fuse && fuse) ? kFuseLanes : -1, (wave && c->use_fuse && c->wave_small) ? kClsSmall : 0, kWaveLanes};
+    return ProbSplit{tiny ? kTiny : 0, (c->use_fuse && fuse) ? c->fuse_lanes : -1, (wave && c->use_fuse && c->wave_small) ? kClsSmall : 0, kWaveLanes};
 }
 
 // Enqueue the segments `segs` of one run on the context's stream.
@@ -4187,8 +4223,11 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
                                c->d_thr_tab.as<int2>(), c->P.min_read_support_outside, c->d_chosen.as<unsigned char>() FSEG_TARG)
         // sums in 32 bits when no chain of a problem can reach 2^30: n <= 64 times the reads of the largest partition
 #define FSEG_LAUNCH_SOLVE_W(Q, NMV, CLS, N_ITEMS, MAXWG)                                                                     \
-            do { if (c->LANES < (1LL << 24)) { FSEG_LAUNCH_SOLVE(Q, NMV, unsigned char, int, CLS, N_ITEMS, MAXWG); }            \
-                 else { FSEG_LAUNCH_SOLVE(Q, NMV, unsigned char, i64, CLS, N_ITEMS, MAXWG); } } while (0)
+            do { if (c->LANES < (1LL << 24)) { FSEG_LAUNCH_SOLVE(Q, NMV, unsigned char, int, CLS, N_ITEMS, MAXWG);              \
+                                               if (FSEG_WIDE_NEEDED(CLS)) FSEG_LAUNCH_SOLVE(Q, NMV, unsigned short, int, CLS, N_ITEMS, MAXWG); } \
+                 else { FSEG_LAUNCH_SOLVE(Q, NMV, unsigned char, i64, CLS, N_ITEMS, MAXWG);                                     \
+                        if (FSEG_WIDE_NEEDED(CLS)) FSEG_LAUNCH_SOLVE(Q, NMV, unsigned short, i64, CLS, N_ITEMS, MAXWG); } } while (0)
+#define FSEG_WIDE_NEEDED(CLS) (!known || (c->wide_solve && ((CLS) < 0 || c->n_wide[(CLS)] > 0)))
         // Two ways a problem is scored (prob_kind): the arena path's work items (k_score per size class) and the problems that
         // see few reads (at most 255: 8-bit counters), whole, one workgroup each (k_solve per size class).
         // A batch usually holds only one kind; a class's two launches share a stream.
@@ -4392,6 +4431,7 @@ int run_input_errors(fseg_ctx *c, const Status &s) {
 void note_counts(fseg_ctx *c, const Status &s) {
     for (int q = 0; q < 3; ++q) { c->n_solve[q] = (i64)s.solve_cls[q]; c->n_dp_cls[q] = (i64)s.dp_cls[q]; }
     c->n_tiny = (i64)s.n_tiny;
+    for (int q = 0; q < 3; ++q) c->n_wide[q] = (i64)s.wide_cls[q];
     for (int q = 0; q < 4; ++q) c->n_cls_work[q] = (i64)s.cls_work[q];
     c->n_arena_prob = (i64)s.dp_cls[0] + (i64)s.dp_cls[1] + (i64)s.dp_cls[2];
     if (!c->counts_known) drop_graph(c);
@@ -4405,7 +4445,8 @@ void adapt_to(fseg_ctx *c, const Status &s) {
     c->small_batch = (i64)s.n_prob <= 256 && (i64)s.n_work <= 1024;
     c->tiny_on = (i64)s.n_prob > c->tiny_from && c->use_tiny;   // depends on the problem count only, which k_tiny does not change
     const bool old_fuse = c->fuse_on;
-    c->fuse_on = (i64)s.max_ln <= kFuseLanes;                   // (the widest problem does not depend on the split either)
+    c->fuse_on = (i64)s.max_ln <= c->fuse_lanes;                 // (the widest problem does not depend on the split either)
+    c->wide_solve = (i64)s.max_ln > kFuseLanes;                  // some problem needs the 16-bit counters
     if (old_fuse != c->fuse_on) { c->counts_known = false; drop_graph(c); }
     c->prob_self_scan = (i64)s.n_cand <= c->prob_self_max;
     {   // the big-problem LDS carve-up: the largest problem (+ headroom, multiple of 4)
@@ -4505,7 +4546,7 @@ int run_sized(fseg_ctx *c) {
         {   // k_tiny's share of the problems was decided from the previous batch: if this batch decides otherwise, the
             // arena sizes change with it -- redo the (cheap) problem scan under the right setting
             const bool tiny = (i64)s.n_prob > c->tiny_from && c->use_tiny;
-            const bool fuse = (i64)s.max_ln <= kFuseLanes;
+            const bool fuse = (i64)s.max_ln <= c->fuse_lanes;
             if (tiny != c->tiny_on || fuse != c->fuse_on) {
                 if (c->trace) fprintf(stderr, "[fseg] problem split changed (tiny %d -> %d, fused %d -> %d; %llu problems, widest sees %u reads): rescan\n",
                                       (int)c->tiny_on, (int)tiny, (int)c->fuse_on, (int)fuse, (unsigned long long)s.n_prob, s.max_ln);
@@ -4634,6 +4675,12 @@ int fseg_create(int device, fseg_ctx **out) {
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve<kNMax, unsigned char, i64>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)solve_lds_for(kNMax, kNMax + 1, 1));
     if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve<kNMax, unsigned short, int>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)solve_lds_for(kNMax, kNMax + 1, 2));
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve<kNMax, unsigned short, i64>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)solve_lds_for(kNMax, kNMax + 1, 2));
+    if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_dp_huge), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)kHugeDpLds);
     if (e != hipSuccess) {
@@ -4650,6 +4697,7 @@ int fseg_create(int device, fseg_ctx **out) {
     if (flag("FSEG_NO_FUSE")) c->use_fuse = false;
     if (flag("FSEG_NO_WAVE")) c->use_wave = false;
     { const char *v = getenv("FSEG_WAVE_SMALL"); if (v && v[0]) c->wave_small = v[0] == '1'; }
+    { const char *v = getenv("FSEG_FUSE_LANES"); if (v && v[0] && atoi(v) > 0 && atoi(v) <= kFuseLanesWide) c->fuse_lanes = atoi(v); }
     if (flag("FSEG_NO_SIZED")) c->use_sized = false;
     if (flag("FSEG_TRACE")) c->trace = true;
     if (flag("FSEG_DEBUG_RECOPY")) c->debug_recopy = true;

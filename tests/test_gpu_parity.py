@@ -57,6 +57,25 @@ def test_config3_slice_against_oracle(gpu_ctx):
     util.compare_partitions(gpu_ctx, parts, oracles)
 
 
+def test_wide_problems_solved_whole_with_sixteen_bit_counters(monkeypatch):
+    """FSEG_FUSE_LANES=1023: a batch of 1 000-read partitions (BASELINE config 3) is solved whole although its widest problems
+    see more than 255 reads -- those go to the 16-bit-counter instances of k_solve, the rest of each list to the 8-bit ones."""
+    from freddie_amd import _lib, synth
+    monkeypatch.setenv("FSEG_FUSE_LANES", "1023")
+    kw = dict(synth.WORKLOADS["config3"]); kw.pop("n_partitions")
+    parts = [util.make_partition(i, **kw) for i in range(24)]
+    oracles = [util.run_oracle(p) for p in parts]
+    ctx = _lib.Context(0)
+    try:
+        util.run_gpu(ctx, parts)
+        assert 255 < ctx.sizes()["max_problem_reads"] <= 1023
+        util.compare_partitions(ctx, parts, oracles)
+        ctx.run(); ctx.sync()                                # the replay: only the classes that have wide problems launch their instance
+        util.compare_partitions(ctx, parts, oracles)
+    finally:
+        ctx.close()
+
+
 def test_config5_slice_against_oracle(gpu_ctx):
     """ONT-like error model with sigma=3.0, threshold_rate=0.80 (BASELINE config 5), 12 partitions x 1000 reads."""
     from freddie_amd import synth
