@@ -3,8 +3,31 @@
 The work is done by freddie_amd (gfx950 HIP library behind a C-ABI); see INTEGRATION.md."""
 import os
 import sys
+import threading
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _preload():
+    # Mapping the native libraries (and the HIP runtime they link) takes as long as importing numpy does: both at once.
+    # Loading is not initialising: no HIP call is made here, so a parent that only scatters work over worker processes
+    # stays clear of the runtime (freddie_amd/devices.py).
+    import ctypes
+    # (the GPU library only when the command line says this process will drive the one GPU itself: --gpus 1 / --devices K)
+    a = sys.argv
+    single = any((x == "--gpus" and a[i + 1:i + 2] == ["1"]) or x == "--gpus=1" or (x == "--devices" and "," not in "".join(a[i + 1:i + 2]))
+                 for i, x in enumerate(a))
+    for name in ("libfreddie_host.so", "libfreddie_seg.so") if single else ("libfreddie_host.so",):
+        try:
+            ctypes.CDLL(os.environ.get("FSEG_LIB") if name == "libfreddie_seg.so" and os.environ.get("FSEG_LIB")
+                        else os.path.join(ROOT, "freddie_amd", name))
+        except OSError:
+            pass            # the loaders in freddie_amd report a missing / stale library with a proper message
+
+
+if __name__ == "__main__":
+    threading.Thread(target=_preload, daemon=True).start()
 
 from freddie_amd.segment import main  # noqa: E402
 

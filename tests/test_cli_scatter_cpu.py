@@ -133,3 +133,32 @@ def test_device_count_without_the_runtime(tmp_path):
     assert cpus and set(cpus) <= set(os.sched_getaffinity(0))
     both = [devices.cpus_near_gpu(k, 2, kfd_root=str(root)) for k in (0, 1)]
     assert not (set(both[0]) & set(both[1])) or len(os.sched_getaffinity(0)) < 2
+
+
+def test_host_ceiling_tool_runs_the_real_main_without_a_device(tmp_path):
+    """tools/host_ceiling.py: main() with a stand-in context that answers at once (both ends of every interval as final
+    positions, a constant label): every partition gets its segment TSV, with one label per segment and read."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("host_ceiling", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "host_ceiling.py"))
+    hc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(hc)
+    split, out = str(tmp_path / "split"), str(tmp_path / "out")
+    for i in range(5):
+        synth.generate(700 + i, n_reads=30 + 10 * i, n_exons=12, rp=0.1, write_dir=split)
+    saved = (segment.open_contexts, segment.WORKER_START_METHOD)
+    try:
+        for label, workers in ((0, 1), (1, 2)):
+            assert hc.run(split, out, workers, 2, label) > 0
+            files = sorted(f for _, _, fs in os.walk(out) for f in fs if f.endswith(".tsv"))
+            assert len(files) == 5
+            for dp, _, fs in os.walk(out):
+                for f in fs:
+                    if not f.endswith(".tsv"):
+                        continue
+                    lines = open(os.path.join(dp, f)).read().split("\n")
+                    n_seg = len(lines[0].split("\t")[2].split(",")) - 1
+                    for ln in lines[1:]:
+                        if ln:
+                            assert ln.split("\t")[5] == str(label) * n_seg
+    finally:
+        segment.open_contexts, segment.WORKER_START_METHOD = saved
