@@ -1,34 +1,38 @@
 #!/bin/bash
 # Round profile: tools/profile_round.sh <tag>   (run on the GPU box from the repo root; writes under gpurun_out/<tag>/;
-# the summaries worth keeping are copied into profiles/ by hand afterwards)
+# tools/collect_profiles.sh copies the summaries worth keeping into profiles/ afterwards -- never the raw counter CSVs)
 T=${1:-round}
 O=gpurun_out/$T
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 mkdir -p $O
 # 1. the driver's command, plain and under the kernel trace (same command: the averages must agree with the line's events)
-python bench.py > $O/bench_default.json 2> $O/bench_default.err; python profiles/benchsum.py < $O/bench_default.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o p -- python3 bench.py --no-cpu-baseline --no-e2e > $O/bench_under_rocprof.json 2> $O/stats.err
+python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err; python profiles/benchsum.py < $O/bench_default.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o p -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-e2e > $O/bench_under_rocprof.json 2> $O/stats.err
 python profiles/benchsum.py < $O/bench_under_rocprof.json | head -1
-python profiles/trace_medians.py $O/stats/p_kernel_trace.csv > $O/config4_kernel_medians_3ctx.txt
-# 2. one context, no side streams: clean per-kernel durations of the one-shot path
-FSEG_NO_FORK=1 rocprofv3 --kernel-trace --output-format csv -d $O/trace1 -o p -- python3 bench.py --contexts 1 --no-cpu-baseline --no-e2e --no-extras --steps 16 > $O/bench_c1.json 2> $O/trace1.err
+python profiles/trace_medians.py $O/stats/p_kernel_trace.csv > $O/config4_kernel_medians_8ctx.txt
+# 2. one context, one stream, one resident batch replayed: per-kernel durations with the GPU to themselves (what `roofline` times)
+FSEG_NO_FORK=1 FSEG_NO_GRAPH=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace1 -o p -- python3 tools/replay_probe.py --workload config4 > $O/replay_config4.txt 2> $O/trace1.err
 python profiles/trace_medians.py $O/trace1/p_kernel_trace.csv > $O/config4_kernel_medians.txt
-# 3. counters, each in its own pass (config4: the k_solve / k_tiny kernels; config2: k_score<60>)
+FSEG_NO_FORK=1 FSEG_NO_GRAPH=1 rocprofv3 --kernel-trace --output-format csv -d $O/trace2 -o p -- python3 tools/replay_probe.py --workload config2 > $O/replay_config2.txt 2> $O/trace2.err
+python profiles/trace_medians.py $O/trace2/p_kernel_trace.csv > $O/config2_kernel_medians.txt
+# 3. counters, each in its own pass
 for w in config4 config2; do
   for pmc in FETCH_SIZE WRITE_SIZE; do
-    FSEG_NO_FORK=1 rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d $O/pmc_${w}_$pmc -o p -- python3 bench.py --workload $w --contexts 1 --no-cpu-baseline --no-e2e --no-extras --steps 8 > /dev/null 2> $O/pmc_${w}_$pmc.err
+    FSEG_NO_FORK=1 rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d $O/pmc_${w}_$pmc -o p -- python3 tools/replay_probe.py --workload $w > /dev/null 2> $O/pmc_${w}_$pmc.err
   done
-  FSEG_NO_FORK=1 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_${w}_sq -o p -- python3 bench.py --workload $w --contexts 1 --no-cpu-baseline --no-e2e --no-extras --steps 8 > /dev/null 2> $O/pmc_${w}_sq.err
+  FSEG_NO_FORK=1 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_${w}_sq -o p -- python3 tools/replay_probe.py --workload $w > /dev/null 2> $O/pmc_${w}_sq.err
   python profiles/pmc_summary.py $O/pmc_${w}_FETCH_SIZE/p_counter_collection.csv $O/pmc_${w}_WRITE_SIZE/p_counter_collection.csv > $O/${w}_pmc_summary.txt
   python tools/sq_summary.py $O/pmc_${w}_sq/p_counter_collection.csv $O/pmc_${w}_sq/p_kernel_trace.csv > $O/${w}_sq_summary.txt
 done
-# 4. the other workloads, rows N3 / N4, end to end
+python profiles/make_traffic.py $O $T > $O/traffic_summary.txt; cp profiles/traffic.json $O/traffic.json
+# 4. the other workloads, rows N3 / N4, end to end, the host alone
 for w in config2 config3 config5; do python bench.py --workload $w --no-cpu-baseline --no-e2e > $O/${w}_bench.json 2>/dev/null; python profiles/benchsum.py < $O/${w}_bench.json | head -1; done
 python bench.py --workload cluster-many > $O/n3_cluster_many_bench.json 2>/dev/null
 python bench.py --workload cluster-big --steps 2 --no-cpu-baseline > $O/n3_cluster_big_bench.json 2>/dev/null
 python bench.py --workload isoforms > $O/n4_isoforms_bench.json 2>/dev/null
-for t in 4 8 16 32; do python tools/e2e_bench.py --partitions 2000 --reads 500 --threads $t --sidecar off --repeat 2 --timing --keep /dev/shm/e2e_$T >> $O/e2e.log 2>&1; done
-python tools/e2e_bench.py --partitions 2000 --reads 500 --threads 16 --sidecar write --repeat 3 --keep /dev/shm/e2e_$T >> $O/e2e.log 2>&1
+python tools/e2e_bench.py --partitions 4000 --reads 500 --generate-only --keep /dev/shm/e2e_$T > /dev/null
+for t in 8 16 32; do python tools/e2e_bench.py --partitions 4000 --reads 500 --threads $t --sidecar off --repeat 2 --timing --keep /dev/shm/e2e_$T >> $O/e2e.log 2>&1; done
+python tools/host_ceiling.py --partitions 4000 --reads 500 --workers 1,2,4,8 --repeat 2 --keep /dev/shm/e2e_$T > $O/host_ceiling.txt 2>&1
 rm -rf /dev/shm/e2e_$T
-python tools/e2e_bench.py --partitions 4000 --reads 500 --threads 16 --sidecar off --repeat 2 >> $O/e2e.log 2>&1
-grep "e2e\[" $O/e2e.log
+grep "e2e\[" $O/e2e.log; cat $O/host_ceiling.txt
+rm -rf $O/stats/*.csv.tmp
