@@ -502,14 +502,16 @@ def main():
         for _ in range(3):
             ctx.run(); ctx.sync()
         t0 = time.perf_counter()
-        sc = 0.0
+        sc_all = []
         for _ in range(reps):
             ctx.run(); ctx.sync()
-            sc += ctx.stage_ms()["interval_scoring"]
+            sc_all.append(ctx.stage_ms()["interval_scoring"])
         dt_r = time.perf_counter() - t0
-        roofline = scoring_roofline(batches[0].alg_bytes, sc / reps, committed,
+        sc_med = float(np.median(sc_all))                      # (the median, like the per-kernel medians of profiles/)
+        roofline = scoring_roofline(batches[0].alg_bytes, sc_med, committed,
                                     {"measured": "HIP events around the stage's launches on the library's streams; one context, one resident "
-                                                 "250 k-read batch of the job replayed %d times: the stage alone on the GPU" % reps})
+                                                 "250 k-read batch of the job replayed %d times: the stage alone on the GPU (median; mean %.4f ms)"
+                                                 % (reps, float(np.mean(sc_all)))})
 
         # ---- every stage alone on the GPU: distinct batches through the first-run path (plain launches, events around every stage)
         ctx.set_profiling(True)
