@@ -674,22 +674,38 @@ __global__ void __launch_bounds__(256) k_scan_emit(const unsigned char *flags, i
             // and the values of eight rows are loaded together from clamped addresses before any of them is used: a
             // load under a condition would be a branch with its own wait, one memory round trip per row.
             i64 k = -1, k_end = 0, k_base = 0;
-            for (int q0 = 0; q0 < 32; q0 += 8) {
+            // the rows that hold a flag at all (bit q of `rows`): the values Y > 0 come in runs of 2 * radius + 1 around the
+            // splice sites, so six rows in ten of a typical batch hold none and their values are not loaded
+            u64 rows = 0;
+            {
+                const u64 lanes_set = __ballot(fm != 0);                 // bit l: lane l's 32 positions hold a flag
+                u64 pairs = (lanes_set | (lanes_set >> 1)) & 0x5555555555555555ULL;     // bit 2q: row q
+                pairs = (pairs | (pairs >> 1)) & 0x3333333333333333ULL;
+                pairs = (pairs | (pairs >> 2)) & 0x0f0f0f0f0f0f0f0fULL;
+                pairs = (pairs | (pairs >> 4)) & 0x00ff00ff00ff00ffULL;
+                pairs = (pairs | (pairs >> 8)) & 0x0000ffff0000ffffULL;
+                rows = (pairs | (pairs >> 16)) & 0x00000000ffffffffULL;
+            }
+            while (rows) {
                 u64 m[8];
                 double yv[8];
+                int qs[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int q = q0 + e;
-                    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)fm, 2 * q);
-                    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)fm, 2 * q + 1);
-                    m[e] = (u64)lo | ((u64)hi << 32);
-                    const i64 i = w0 + q * 64 + lane;
+                for (int e = 0; e < 8; ++e) {                            // the next eight rows that hold flags
+                    const int q = rows ? (int)__builtin_ctzll(rows) : -1;
+                    qs[e] = q;
+                    rows = rows ? rows & (rows - 1) : 0;
+                    const int qq = q < 0 ? 0 : q;
+                    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)fm, 2 * qq);
+                    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)fm, 2 * qq + 1);
+                    m[e] = q < 0 ? 0 : ((u64)lo | ((u64)hi << 32));
+                    const i64 i = w0 + qq * 64 + lane;
                     if (MODE == kEmitValues) yv[e] = y[i < n ? i : n - 1];
                 }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     if (!m[e]) continue;
-                    const i64 i = w0 + (q0 + e) * 64 + lane;
+                    const i64 i = w0 + qs[e] * 64 + lane;
                     if ((m[e] >> lane) & 1ULL) {
                         const int d = ex + __popcll(m[e] & lt_mask);
                         if (MODE == kEmitValues) v[d] = yv[e];
