@@ -94,6 +94,7 @@ struct Status {
     u64 cov_queue;
     u64 solve_cls[3];  // problems solved whole by k_solve (n <= 16 / <= 32 / <= kNMax)
     u64 n_tiny;        // problems solved whole by k_tiny (their list follows the three solve lists)
+    unsigned list_cur[8];   // k_prob_emit's cursors into the four solve lists: [2 * list] from the front (expensive problems), [2 * list + 1] from the back
     unsigned wide_cls[4];   // solve-list problems per size class that see more than kFuseLanes reads (16-bit counters); [3] unused
 };
 
@@ -1363,11 +1364,26 @@ __global__ void __launch_bounds__(256) k_prob_emit(Status *st, const int *cand_p
     __shared__ int l_mx[8];
     __shared__ i64 l_w0[kProbBlock], l_c0[kProbBlock];
     __shared__ int l_n;
+    // The solve lists are filled from BOTH ends: a class's expensive problems (many candidates) from the front, the cheap ones
+    // from the back.  A class's kernel runs one problem per workgroup, what does not fit the chip at once starts when something
+    // else ends, and a 40 us problem that starts late is the kernel's tail: with the expensive half first the dispatcher's
+    // in-order placement is a longest-first schedule (k_solve<32> 69 -> 61 us, <60> 73 -> 68, <16> 38 -> 34 on config4).  A
+    // workgroup reserves its share of each end with one atomic per end; the order inside an end is whatever the atomics make
+    // it -- problems do not depend on one another.
+    __shared__ int l_cnt2[8], l_base2[8], l_cur2[8];
+    auto list_end_of = [&](int nn, int lanes) -> int {            // 2 * list + (cheap ? 1 : 0), or -1: not in a solve list
+        const int kind = prob_kind(nn, lanes, sp);
+        if (kind == kKindTiny) return 6 + (nn >= 5 ? 0 : 1);
+        if (kind != kKindFused) return -1;
+        const int sc = size_class(nn);
+        return 2 * sc + (nn >= (sc == 0 ? 12 : (sc == 1 ? 23 : 42)) ? 0 : 1);
+    };
     i64 n = (i64)st->n_cand;
     i64 nb = (n + kProbBlock - 1) / kProbBlock;
     for (i64 b = blockIdx.x; b < nb; b += gridDim.x) {
         ProbSizes sz[4], ex, tot, before, grand;
         if (threadIdx.x == 0) l_n = 0;
+        if (threadIdx.x < 8) { l_cnt2[threadIdx.x] = 0; l_cur2[threadIdx.x] = 0; }
         if (bs) {
             for (int q = 0; q < kProbCols; ++q) before.v[q] = bs[b * kProbCols + q];
             grand.v[4] = (i64)st->cls_work[0] + ((i64)st->cls_work[1] << 32); grand.v[0] = (i64)st->dp_cls[0] << 32;
@@ -1407,6 +1423,16 @@ __global__ void __launch_bounds__(256) k_prob_emit(Status *st, const int *cand_p
         }
         for (int e = 0; e < 4; ++e) { co4[e] = cand_off[iv4[e]]; is4[e] = iv_start[iv4[e]]; part4[e] = iv_part[iv4[e]]; }
         for (int e = 0; e < 4; ++e) lanes4[e] = (int)(part_lane_off[part4[e] + 1] - part_lane_off[part4[e]]);
+        // this workgroup's share of the two ends of every solve list (the barriers of wg_scan_cols above have published the zeroed counters)
+        int le4[4];
+        for (int e = 0; e < 4; ++e) {
+            le4[e] = (sz[e].v[0] && i0 + e < n) ? list_end_of(pn4[e], ln4[e]) : -1;
+            if (le4[e] >= 0) atomicAdd(&l_cnt2[le4[e]], 1);
+        }
+        __syncthreads();
+        if (threadIdx.x < 8 && l_cnt2[threadIdx.x]) l_base2[threadIdx.x] = (int)atomicAdd(&st->list_cur[threadIdx.x], (unsigned)l_cnt2[threadIdx.x]);
+        __syncthreads();
+        const i64 g_tiny = bs ? (i64)st->n_tiny : col_hi(grand.v[8]);
         for (int e = 0; e < 4; ++e) {
             if (sz[e].v[0]) {
                 i64 c = i0 + e;
@@ -1428,14 +1454,13 @@ __global__ void __launch_bounds__(256) k_prob_emit(Status *st, const int *cand_p
                         desc[slot] = d;
                     }
                     const int kind = prob_kind(nn, ln4[e], sp);
-                    if (kind == kKindFused) {   // solve lists: class 0, then class 1, then class 2
-                        const int sc = size_class(nn);
-                        const i64 si = sc == 0 ? col_lo(ex.v[7]) : (sc == 1 ? g_sol0 + col_hi(ex.v[7]) : g_sol0 + g_sol1 + col_lo(ex.v[8]));
-                        if (si < prob_cap) solve_items[si] = (int)slot;
-                    }
-                    if (kind == kKindTiny) {    // ... then k_tiny's problems (every wave of its workgroups gets one)
-                        const i64 si = g_sol0 + g_sol1 + g_sol2 + col_hi(ex.v[8]);
-                        if (si < prob_cap) solve_items[si] = (int)slot;
+                    if (le4[e] >= 0) {          // solve lists: class 0, then class 1, then class 2, then k_tiny's problems
+                        const int li = le4[e] >> 1;
+                        const i64 lbase = li == 0 ? 0 : (li == 1 ? g_sol0 : (li == 2 ? g_sol0 + g_sol1 : g_sol0 + g_sol1 + g_sol2));
+                        const i64 llen = li == 0 ? g_sol0 : (li == 1 ? g_sol1 : (li == 2 ? g_sol2 : g_tiny));
+                        const i64 off = (i64)l_base2[le4[e]] + atomicAdd(&l_cur2[le4[e]], 1);
+                        const i64 si = (le4[e] & 1) ? lbase + llen - 1 - off : lbase + off;
+                        if (si >= lbase && si < lbase + llen && si < prob_cap) solve_items[si] = (int)slot;
                     }
                     if (kind == kKindArena) {   // DP problem lists: the small problems first, then the big ones
                         // (then the huge ones); k_tiny's and k_solve's problems are in no DP list
@@ -3867,6 +3892,7 @@ struct fseg_ctx {
     hipEvent_t fj[kForkEvents] = {};
     bool use_fork = true;
     bool use_tiny = true;       // FSEG_NO_TINY=1: no problem goes to k_tiny
+    bool score_fork = false;    // FSEG_SCORE_FORK=1: the fused scoring kernels on a stream each
     bool use_wave = true;       // FSEG_NO_WAVE=1: k_tiny / k_solve<16> instead of the wave kernels (k_wave)
     bool wave_small = false;    // FSEG_WAVE_SMALL=1: the small class (9 .. 16 candidates) goes to k_wave<16> instead of k_solve<16> (one wave
                                 // per problem: a third less wave-time, but 48 instead of 38 us when the kernel has the GPU to itself)
@@ -4207,7 +4233,12 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
     }   // do_pre2
     if (do_score) begin(ST_SCORE);
     if (do_score && c->prob_cap > 0) {
-        hipStream_t qt = tiny_max > 0 ? fork(2) : s;     // (forked here: a side stream continues from where it was forked)
+        // The scoring kernels stay on the one stream, largest class first (FSEG_SCORE_FORK=1: a stream each, as until round 3).
+        // On four streams the dispatcher ran them in the reverse of their launch order -- a large-class workgroup needs eight wave
+        // slots and half a CU's LDS at once and got neither until the small classes had drained -- and the lists' longest-first
+        // order was lost in the interleaving: 0.208 against 0.194 ms for the stage.
+        const bool sfork = c->score_fork || any_arena;              // (the arena path's work-item kernels keep their streams)
+        hipStream_t qt = (tiny_max > 0 && sfork) ? fork(2) : s;     // (forked here: a side stream continues from where it was forked)
 #ifdef FSEG_SCORE_TIMING
 #define FSEG_TARG , c->d_tacc.as<unsigned long long>()
 #else
@@ -4269,7 +4300,7 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
                 if (any_solve && (!known || c->n_solve[2] > 0)) FSEG_LAUNCH_SOLVE_W(s, kNMax, 2, known ? c->n_solve[2] : cap, 512);
             } else if (any_solve) FSEG_LAUNCH_SOLVE_W(s, kNMax, -1, known ? c->n_solve[0] + c->n_solve[1] + c->n_solve[2] : cap, 512);
         } else {                                     // the size classes own disjoint problems: three concurrent chains
-            hipStream_t q1 = fork(0), q0 = fork(1);
+            hipStream_t q1 = sfork ? fork(0) : s, q0 = sfork ? fork(1) : s;
             if (any_arena && (!known || c->n_cls_work[2] > 0)) FSEG_LAUNCH_SCORE(s, kNMax, 2, 512);     // big problems: they are the long poles
             if (any_solve && (!known || c->n_solve[2] > 0)) FSEG_LAUNCH_SOLVE_W(s, kNMax, 2, known ? c->n_solve[2] : cap, 512);
             if (any_arena && (!known || c->n_cls_work[1] > 0)) FSEG_LAUNCH_SCORE(q1, kClsMid, 1, 1280);
@@ -4294,13 +4325,13 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
         }
 #undef FSEG_LAUNCH_WAVE
 #undef FSEG_LAUNCH_WAVE_V
-        if (!c->small_batch) { join(0); join(1); }
+        if (!c->small_batch && sfork) { join(0); join(1); }
         if (c->have_huge && any_arena)
             hipLaunchKernelGGL(k_score_huge, dim3(256), dim3(512), kHugeScoreLds, s, st, c->d_dp_items.as<int>(), pr,
                                c->d_prob_desc.as<ProbDesc>(), c->prob_cap, c->work_cap, c->d_cand_y.as<int>(),
                                c->d_cov.as<unsigned>(), c->cov_cap, c->d_pair_thr.as<int2>(), c->pair_cap,
                                c->d_out.as<unsigned>(), c->tri_cap, c->d_amb.as<unsigned>());
-        if (tiny_max > 0) join(2);             // k_tiny is interval scoring too: inside the stage's time bracket
+        if (tiny_max > 0 && sfork) join(2);    // k_tiny is interval scoring too: inside the stage's time bracket
     }
     if (do_score) end(ST_SCORE);
     const i64 labels_n16 = (c->label_cap + 15) / 16;            // the arena is allocated in multiples of 16 bytes
@@ -4712,6 +4743,7 @@ int fseg_create(int device, fseg_ctx **out) {
     if (flag("FSEG_NO_TINY")) c->use_tiny = false;
     if (flag("FSEG_NO_FUSE")) c->use_fuse = false;
     if (flag("FSEG_NO_WAVE")) c->use_wave = false;
+    if (flag("FSEG_SCORE_FORK")) c->score_fork = true;
     { const char *v = getenv("FSEG_WAVE_SMALL"); if (v && v[0]) c->wave_small = v[0] == '1'; }
     { const char *v = getenv("FSEG_FUSE_LANES"); if (v && v[0] && atoi(v) > 0 && atoi(v) <= kFuseLanesWide) c->fuse_lanes = atoi(v); }
     if (flag("FSEG_NO_SIZED")) c->use_sized = false;

@@ -52,6 +52,7 @@ SWITCHES = [
     {"FSEG_NO_FUSE": "1", "FSEG_NO_TINY": "1", "FSEG_NO_SIZED": "1"},
     {"FSEG_NO_TINY": "1"},                                  # ... and the tiny ones through k_solve
     {"FSEG_NO_WAVE": "1"},                                  # k_tiny instead of k_wave<8> (batches with a rep of > 510 exons take this)
+    {"FSEG_SCORE_FORK": "1"},                               # the fused scoring kernels on a stream each
     {"FSEG_WAVE_SMALL": "1"},                               # the small class through k_wave<16> (one wave per problem)
     {"FSEG_WAVE_SMALL": "1", "FSEG_TINY_FROM": "0", "FSEG_NO_GRAPH": "1"},
     {"FSEG_WAVE_SMALL": "1", "FSEG_NO_TINY": "1"},          # ... and the tiny ones with it
