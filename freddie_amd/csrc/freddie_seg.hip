@@ -96,6 +96,8 @@ struct Status {
     u64 n_tiny;        // problems solved whole by k_tiny (their list follows the three solve lists)
     unsigned list_cur[8];   // k_prob_emit's cursors into the four solve lists: [2 * list] from the front (expensive problems), [2 * list + 1] from the back
     unsigned wide_cls[4];   // solve-list problems per size class that see more than kFuseLanes reads (16-bit counters); [3] unused
+    unsigned gate;          // large-class workgroups that have started (k_gate holds the small classes back until they are placed)
+    unsigned gate_mid;      // ... and the mid class's
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -1358,7 +1360,8 @@ __global__ void __launch_bounds__(256) k_prob_emit(Status *st, const int *cand_p
                                                    const int *cand_iv, const i64 *cand_off, const i64 *bs,
                                                    ProblemArrays pr, i64 prob_cap, int2 *work_pc, int4 *cls_items,
                                                    i64 work_cap, int *dp_items, ProbDesc *desc, const int *iv_start,
-                                                   const int *iv_part, const i64 *part_lane_off, ProbSplit sp, int *solve_items) {
+                                                   const int *iv_part, const i64 *part_lane_off, ProbSplit sp, int *solve_items,
+                                                   ProbDesc *solve_desc) {
     __shared__ i64 lds[4 * kProbCols];
     __shared__ int l_slot[kProbBlock], l_cnt[kProbBlock];
     __shared__ int l_mx[8];
@@ -1444,23 +1447,23 @@ __global__ void __launch_bounds__(256) k_prob_emit(Status *st, const int *cand_p
                     pr.pair_off[slot] = ex.v[1]; pr.tri_off[slot] = ex.v[2]; pr.cov_off[slot] = ex.v[3];
                     pr.flags[slot] = 0; pr.chain[slot] = 0;
                     pr.lane_lo[slot] = ll4[e]; pr.lane_n[slot] = ln4[e];
-                    {
-                        ProbDesc d;
-                        d.c0 = c - (nn - 1); d.pair_off = ex.v[1]; d.tri_off = ex.v[2]; d.cov_off = ex.v[3];
-                        d.n = nn; d.lane_lo = ll4[e]; d.lane_n = ln4[e]; d.g0 = is4[e];
-                        d.outside = lanes4[e] - d.lane_n;
-                        d.iv = k; d.w0 = (int)(col_lo(ex.v[4]) + col_hi(ex.v[4]) + col_lo(ex.v[5]) + col_lo(ex.v[6]));
-                        d.kind = prob_kind(nn, ln4[e], sp);
-                        desc[slot] = d;
-                    }
-                    const int kind = prob_kind(nn, ln4[e], sp);
+                    ProbDesc d;
+                    d.c0 = c - (nn - 1); d.pair_off = ex.v[1]; d.tri_off = ex.v[2]; d.cov_off = ex.v[3];
+                    d.n = nn; d.lane_lo = ll4[e]; d.lane_n = ln4[e]; d.g0 = is4[e];
+                    d.outside = lanes4[e] - d.lane_n;
+                    d.iv = k; d.w0 = (int)(col_lo(ex.v[4]) + col_hi(ex.v[4]) + col_lo(ex.v[5]) + col_lo(ex.v[6]));
+                    d.kind = prob_kind(nn, ln4[e], sp);
+                    desc[slot] = d;
+                    const int kind = d.kind;
                     if (le4[e] >= 0) {          // solve lists: class 0, then class 1, then class 2, then k_tiny's problems
                         const int li = le4[e] >> 1;
                         const i64 lbase = li == 0 ? 0 : (li == 1 ? g_sol0 : (li == 2 ? g_sol0 + g_sol1 : g_sol0 + g_sol1 + g_sol2));
                         const i64 llen = li == 0 ? g_sol0 : (li == 1 ? g_sol1 : (li == 2 ? g_sol2 : g_tiny));
                         const i64 off = (i64)l_base2[le4[e]] + atomicAdd(&l_cur2[le4[e]], 1);
                         const i64 si = (le4[e] & 1) ? lbase + llen - 1 - off : lbase + off;
-                        if (si >= lbase && si < lbase + llen && si < prob_cap) solve_items[si] = (int)slot;
+                        // the kernels of the solve lists read the record from the list itself (one load less in every problem's
+                        // chain of dependent loads); w0, the arena path's work item, is the problem's slot there
+                        if (si >= lbase && si < lbase + llen && si < prob_cap) { solve_items[si] = (int)slot; d.w0 = (int)slot; solve_desc[si] = d; }
                     }
                     if (kind == kKindArena) {   // DP problem lists: the small problems first, then the big ones
                         // (then the huge ones); k_tiny's and k_solve's problems are in no DP list
@@ -1693,18 +1696,73 @@ template <typename V> __device__ __forceinline__ constexpr V dp_neg_inf() { retu
 // level (:560-566): M(0,j) = in(0,j) + max_k(out(0,j,k) + M(j,k)), then the first maximiser over j, taken only if it beats
 // "no cut" = in(0,end).  (A gather formulation -- lanes = b, a loop over c2 per lane, blocks of four candidates with a serial
 // in-block fix-up -- took 36 us for n = 49 against 22 us; tools/probes/dp_probe.hip.)
+// A running maximum and its argument are ONE integer, the key  value * 64 + (63 - c2):  the larger value wins, among equal
+// values the smaller c2 (the reference's first maximiser, :526-527), and the update of a pair is one v_max.  A pair's final
+// M(b,c) is stored in the same form with (63 - c) in the low bits -- the tie-break it needs when it is the tail of a push
+// from column c, and at the top level (first maximiser over j) -- or kKeyNone.  With 32-bit keys every |value| must stay
+// below 2^24: k_solve / k_wave take them when the largest partition has fewer than 2^18 reads (a chain has at most 32 links
+// of at most that many reads each), the 64-bit instances otherwise.
+template <typename V> __device__ __forceinline__ constexpr V dp_key_none() { return sizeof(V) == 8 ? (V)(-(1LL << 62)) : (V)(-0x7ff00000); }
+template <typename V> __device__ __forceinline__ constexpr V dp_key_min() { return sizeof(V) == 8 ? (V)(-(1LL << 61)) : (V)(-0x40000000); }   // every key of a value is above it
+// The push of column c2 into the first NS slots of a thread: all the slots' LDS loads first (none of them under a branch),
+// one wait, then four instructions per pair.  Only the last of a wave's live slots can hold pairs at or beyond the column
+// (q >= t2): it is the one that is masked.
+template <int NS, int T, int SLOTS, typename OutT, typename V>
+__device__ __forceinline__ void dp_push_slots(int tid, int t2, int t3, int support, const V *M, const OutT *out_s,
+                                              const int (&pc)[SLOTS], V (&best)[SLOTS]) {
+    constexpr V kNone = dp_key_none<V>();
+    V tail[NS];
+    unsigned o[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int q = s * T + tid;
+        const bool act = s < NS - 1 || q < t2;
+        tail[s] = M[t2 + (act ? pc[s] : 0)];
+        o[s] = (unsigned)out_s[t3 + (act ? q : 0)];
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int q = s * T + tid;
+        const bool act = s < NS - 1 || q < t2;
+        const V key = (V)o[s] * 64 + tail[s];                        // (a tail of kKeyNone stays below every key of a value)
+        const bool ok = act & ((int)o[s] >= support);                // :540
+        const V k2 = ok ? key : kNone;
+        best[s] = k2 > best[s] ? k2 : best[s];
+    }
+}
+// ... for the `ns` (wave-uniform) slots of this wave that still hold pairs below the column
+template <int NS, int T, int SLOTS, typename OutT, typename V>
+__device__ __forceinline__ void dp_push_dispatch(int ns, int tid, int t2, int t3, int support, const V *M, const OutT *out_s,
+                                                 const int (&pc)[SLOTS], V (&best)[SLOTS]) {
+    if (ns >= NS) dp_push_slots<NS, T, SLOTS>(tid, t2, t3, support, M, out_s, pc, best);
+    else if constexpr (NS > 1) dp_push_dispatch<NS - 1, T, SLOTS>(ns, tid, t2, t3, support, M, out_s, pc, best);
+}
+// Pushed, not pulled: every thread OWNS pairs (b,c) -- pair q = s*T + tid, the ownership the scoring phase already uses --
+// and keeps their running maximum in registers:
+//   column c2 final  ->  its owners write M(.,c2)  ->  one barrier  ->  every pair (b,c) with c < c2 takes
+//   out(b,c,c2) + M(c,c2) into its maximum.
+// One barrier per candidate, no reduction over waves, no serial part, and the work of a step is spread over all the
+// threads (out(.,.,c2) is one contiguous run of the count table: lane-consecutive bytes).  The row b = 0 is the top
+// level (:560-566): M(0,j) = in(0,j) + max_k(out(0,j,k) + M(j,k)), then the first maximiser over j, taken only if it beats
+// "no cut" = in(0,end).  A step is a chain -- owners' write, barrier, loads, update -- and the problem's DP is n of them in
+// a row, so what counts is the number of dependent instructions in a step (tools/probes/dp_probe.hip: n = 49 took 19 us with
+// value and argument kept apart and compare / select through the scalar unit; the bare write-barrier-read is 73 ns).
+// (A gather formulation -- lanes = b, a loop over c2 per lane, blocks of four candidates with a serial in-block fix-up --
+// took 36 us for n = 49.)
 template <int T, int NM, typename OutT, typename V>
 __device__ __forceinline__ int dp_solve_push(int n, const OutT *out_s, const int *in_s, V *M, unsigned char *A, const int *cy_s, int support,
                                              unsigned char *chosen /* + first candidate of the problem */ FSEG_DPARAM) {
     constexpr int SLOTS = (NM * (NM - 1) / 2 + T - 1) / T;
-    static_assert(NM <= 64, "the top level is one lane per candidate");
+    constexpr int LOG2T = T == 64 ? 6 : (T == 128 ? 7 : (T == 256 ? 8 : (T == 512 ? 9 : 10)));
+    static_assert((1 << LOG2T) == T, "T is a power of two from 64 to 1024");
+    static_assert(NM <= 64, "the top level is one lane per candidate; an argument is six bits of a key");
     const int lane = lane_id(), wave = T == 64 ? 0 : wave_id();
     const int tid = T == 64 ? lane : (int)threadIdx.x;
     n = uni(n); support = uni(support);
     const int end = n - 1;
     const int npairs = n * (n - 1) / 2;
-    constexpr V kNeg = dp_neg_inf<V>();
-    int pc[SLOTS], arg[SLOTS];
+    constexpr V kNone = dp_key_none<V>(), kMin = dp_key_min<V>();
+    int pc[SLOTS];
     V best[SLOTS], inv[SLOTS];
     bool live[SLOTS];
 #pragma unroll
@@ -1715,55 +1773,62 @@ __device__ __forceinline__ int dp_solve_push(int n, const OutT *out_s, const int
         pc[s] = c;
         live[s] = q < npairs && cy_s[c] - cy_s[b] >= 5;            // "segment too small" (:540)
         inv[s] = (V)in_s[q < npairs ? q : 0];
-        best[s] = kNeg; arg[s] = 255;
+        best[s] = (q < npairs && c == end) ? (V)0 : kNone;         // M(b,end) = in(b,end): the chain's last link (:545-548)
     }
+    int t2 = end * (end - 1) / 2, t3 = end * (end - 1) * (end - 2) / 6;
     for (int c2 = end; c2 >= 1; --c2) {
-        const int t2 = c2 * (c2 - 1) / 2, t3 = c2 * (c2 - 1) * (c2 - 2) / 6;
-        // column c2 is final: its pairs are q in [t2, t2 + c2)
-#pragma unroll
-        for (int s = 0; s < SLOTS; ++s) {
-            const int q = s * T + tid;
-            if (q >= t2 && q < t2 + c2) {
-                const V m = c2 == end ? (live[s] ? inv[s] : kNeg) : ((live[s] && best[s] != kNeg) ? best[s] + inv[s] : kNeg);
-                M[q] = m; A[q] = (unsigned char)arg[s];
+        // column c2 is final: its pairs are q in [t2, t2 + c2), at most one of them this thread's
+        {
+            const int d0 = (tid - t2) & (T - 1);
+            if (d0 < c2) {
+                const int q0 = t2 + d0;
+                auto finish = [&](auto sc) {
+                    constexpr int s = decltype(sc)::value;
+                    const V bb = best[s];
+                    const bool ok = live[s] && bb > kMin;
+                    const V val = (bb >> 6) + inv[s];
+                    M[q0] = ok ? (V)(val * 64 + (V)(63 - c2)) : kNone;
+                    A[q0] = ok ? (unsigned char)(63 - (int)(bb & 63)) : (unsigned char)255;
+                };
+                if constexpr (SLOTS == 1) finish(std::integral_constant<int, 0>{});
+                else if constexpr (T == 64) {                        // (a wave's owners may sit in two slots)
+                    static_for<0, SLOTS>([&](auto sc) { if ((q0 >> LOG2T) == decltype(sc)::value) finish(sc); });
+                } else {                                             // the owners of a wave share the slot
+                    const int so = uni(q0 >> LOG2T);
+                    static_for<0, SLOTS>([&](auto sc) { if (so == decltype(sc)::value) finish(sc); });
+                }
             }
         }
         dp_sync<T>();
         if (c2 == 1) break;
-#pragma unroll
-        for (int s = 0; s < SLOTS; ++s) {
-            const int q = s * T + tid;
-            if (q < t2) {                                            // pairs (b, c) with c < c2
-                const V tail = M[t2 + pc[s]];
-                const unsigned o = (unsigned)out_s[t3 + q];
-                const V cur = (V)o + tail;
-                const bool take = (tail != kNeg) & ((int)o >= support) & (cur >= best[s]);      // :526-527, :540
-                best[s] = take ? cur : best[s]; arg[s] = take ? c2 : arg[s];
-            }
-        }
+        // pairs (b, c) with c < c2: q < t2, a prefix of the pair order -- the slots of this wave that reach below t2 come first
+        const int wave_q0 = T == 64 ? 0 : wave * 64;
+        const int ns = t2 > wave_q0 ? uni((t2 - wave_q0 + T - 1) >> LOG2T) : 0;
+        dp_push_dispatch<SLOTS, T, SLOTS>(ns < SLOTS ? ns : SLOTS, tid, t2, t3, support, M, out_s, pc, best);
+        t2 -= c2 - 1; t3 -= t2;
     }
     FSEG_DTICK(10);
     int chain = 0;
     if (wave == 0) {
-        // first maximiser over j of M(0,j) (larger value, then smaller j), one candidate per lane
+        // first maximiser over j of M(0,j) (larger value, then smaller j): the largest key, one candidate per lane
         const int j0 = lane >= 1 && lane < end ? lane : 1;
-        V bv = (lane >= 1 && lane < end) ? M[j0 * (j0 - 1) / 2] : kNeg;
-        int bj = lane;
+        V kv = (lane >= 1 && lane < end) ? M[j0 * (j0 - 1) / 2] : kNone;
         for (int d = 32; d >= 1; d >>= 1) {
-            const V ov = __shfl_xor(bv, d); const int oj = __shfl_xor(bj, d);
-            if (ov > bv || (ov == bv && oj < bj)) { bv = ov; bj = oj; }
+            const V ov = __shfl_xor(kv, d);
+            kv = ov > kv ? ov : kv;
         }
         FSEG_DTICK(11);
         // the chain is walked by one lane (dependent LDS loads only: the chosen candidates are collected in a mask) and
         // stored by the wave, one candidate per lane
         u64 mask = 0;
-        if (lane == 0 && end >= 2 && bv != kNeg && bv > (V)in_s[end * (end - 1) / 2]) {
+        if (lane == 0 && end >= 2 && kv > kMin && (kv >> 6) > (V)in_s[end * (end - 1) / 2]) {
+            const int bj = 63 - (int)(kv & 63);
             int j = bj, k = A[bj * (bj - 1) / 2];
             mask = 1ULL;
             for (;;) {
                 mask |= (1ULL << j) | (1ULL << k); ++chain;
                 if (k == end) break;
-                const int k2 = A[k * (k - 1) / 2 + j];
+                const int k2 = A[(int)__umul24(k, k - 1) / 2 + j];
                 if (k2 == 255) break;
                 j = k; k = k2;
             }
@@ -2204,7 +2269,7 @@ constexpr int kTinyPairs = kTiny * (kTiny - 1) / 2, kTinyTri = kTiny * (kTiny - 
 __global__ void __launch_bounds__(256, FSEG_TINY_OCC) k_tiny(Status *st, const ProbDesc *desc, i64 prob_cap, int tiny_max, ProblemArrays pr,
                                               const int *cand_y, const longlong2 *lane_ex, const int *ex_ts,
                                               const int *ex_te, const double *h_table, int h_len, double tau, const int2 *thr_tab,
-                                              int support, unsigned char *chosen, const int *solve_items FSEG_TPARAM) {
+                                              int support, unsigned char *chosen, i64 lb_h, i64 ln_h FSEG_TPARAM) {
     __shared__ u64 planes[4][kTinyPairs][2];            // [wave][pair]{yea, nay} of the current 64 reads
     __shared__ i64 M_s[4][kTinyPairs];
     __shared__ int in_s[4][kTinyPairs];
@@ -2223,21 +2288,22 @@ __global__ void __launch_bounds__(256, FSEG_TINY_OCC) k_tiny(Status *st, const P
         tri_ijk[t][0] = (unsigned char)i; tri_ijk[t][1] = (unsigned char)j; tri_ijk[t][2] = (unsigned char)k;
     }
     __syncthreads();
-    const i64 n_prob = (i64)st->n_prob;
-    if (n_prob > prob_cap) return;                      // sizing run: the descriptors are incomplete
+    // (lb_h >= 0: the host knows the lists' sizes -- the batch has been sized --, and the status record is not on the way to the first problem)
+    if (lb_h < 0 && (i64)st->n_prob > prob_cap) return;                      // sizing run: the descriptors are incomplete
 #ifdef FSEG_SCORE_TIMING
     __shared__ unsigned long long tick_sink[16];
     unsigned long long *dp_tacc = tick_sink; unsigned long long dt_prev = 0;
 #endif
     // k_tiny's problems are a list of their own (behind the three solve lists): every wave of a workgroup has one, and a
     // workgroup's four are a grid apart (neighbours in the list are neighbours on the genome and of similar size)
-    const i64 list_base = (i64)st->solve_cls[0] + (i64)st->solve_cls[1] + (i64)st->solve_cls[2], list_n = (i64)st->n_tiny;
+    const i64 list_base = lb_h >= 0 ? lb_h : (i64)st->solve_cls[0] + (i64)st->solve_cls[1] + (i64)st->solve_cls[2];
+    const i64 list_n = lb_h >= 0 ? ln_h : (i64)st->n_tiny;
     for (i64 t = (i64)blockIdx.x + (i64)wave * gridDim.x; t < list_n; t += (i64)gridDim.x * 4) {
 #ifdef FSEG_SCORE_TIMING
         const unsigned long long t_prob0 = wall_clock64();
 #endif
-        const int p = uni(solve_items[list_base + t]);
-        const ProbDesc d = FSEG_LOAD_DESC(desc + p);
+        const ProbDesc d = FSEG_LOAD_DESC(desc + list_base + t);          // (the list's own copy of the record: k_prob_emit)
+        const int p = d.w0;
         const int n = d.n;
         if (n > tiny_max) continue;                     // wave-uniform
         const int npairs = n * (n - 1) / 2, ntri = n * (n - 1) * (n - 2) / 6;
@@ -2417,7 +2483,7 @@ template <int NM, typename V>
 __global__ void __launch_bounds__(256, WaveCfg<NM>::kOcc) k_wave(Status *st, const ProbDesc *desc, i64 prob_cap, int list, ProblemArrays pr,
                                                                  const int *__restrict__ cand_y, const int2 *__restrict__ lane_lx, const int2 *__restrict__ lex,
                                                                  const double *h_table, int h_len, double tau, const int2 *__restrict__ thr_tab,
-                                                                 int support, unsigned char *chosen, const int *__restrict__ solve_items FSEG_TPARAM) {
+                                                                 int support, unsigned char *chosen, i64 lb_h, i64 ln_h FSEG_TPARAM) {
     using C = WaveCfg<NM>;
     __shared__ WaveLds<NM, V> lds4[4];
     __shared__ unsigned short tri_q[C::kTri + 2];      // triple rank t -> (pair (i,j)) | (pair (j,k)) << 8
@@ -2431,20 +2497,20 @@ __global__ void __launch_bounds__(256, WaveCfg<NM>::kOcc) k_wave(Status *st, con
         tri_q[t] = (unsigned short)((j * (j - 1) / 2 + i) | ((k * (k - 1) / 2 + j) << 8));
     }
     __syncthreads();
-    if ((i64)st->n_prob > prob_cap) return;             // sizing run: the descriptors are incomplete
+    if (lb_h < 0 && (i64)st->n_prob > prob_cap) return;             // sizing run: the descriptors are incomplete
 #ifdef FSEG_SCORE_TIMING
     __shared__ unsigned long long tick_sink[16];
     unsigned long long *dp_tacc = tick_sink; unsigned long long dt_prev = 0;
 #endif
-    // list 3: k_tiny's problems (behind the three solve lists); list 0: the small class
-    const i64 list_base = list == 3 ? (i64)st->solve_cls[0] + (i64)st->solve_cls[1] + (i64)st->solve_cls[2] : 0;
-    const i64 list_n = list == 3 ? (i64)st->n_tiny : (i64)st->solve_cls[0];
+    // list 3: k_tiny's problems (behind the three solve lists); list 0: the small class.  lb_h >= 0: bounds from the host (a sized batch)
+    const i64 list_base = lb_h >= 0 ? lb_h : (list == 3 ? (i64)st->solve_cls[0] + (i64)st->solve_cls[1] + (i64)st->solve_cls[2] : 0);
+    const i64 list_n = lb_h >= 0 ? ln_h : (list == 3 ? (i64)st->n_tiny : (i64)st->solve_cls[0]);
     for (i64 t = (i64)blockIdx.x + (i64)wave * gridDim.x; t < list_n; t += (i64)gridDim.x * 4) {
 #ifdef FSEG_SCORE_TIMING
         const unsigned long long t_prob0 = wall_clock64();
 #endif
-        const int p = uni(solve_items[list_base + t]);
-        const ProbDesc d = FSEG_LOAD_DESC(desc + p);
+        const ProbDesc d = FSEG_LOAD_DESC(desc + list_base + t);          // (the list's own copy of the record: k_prob_emit)
+        const int p = d.w0;
         const int n = d.n;
         if (n > NM || n < 3) { if (lane == 0) atomicOr(&st->err, kErrOverflowNm); continue; }       // (wave-uniform)
         const int npairs = n * (n - 1) / 2, ntri = n * (n - 1) * (n - 2) / 6;
@@ -2598,6 +2664,20 @@ __global__ void __launch_bounds__(256, WaveCfg<NM>::kOcc) k_wave(Status *st, con
 // threshold / ambiguity / count arenas, no work items, no DP list entry.  (The arena path remains for problems that see
 // thousands of reads, where one problem has to be spread over many workgroups.)
 // ---------------------------------------------------------------------------------------------
+// A large-class workgroup wants eight wave slots and 57-78 KB of LDS at once.  Beside kernels of small workgroups on other
+// streams it is placed last, whatever the launch order (the dispatcher places what fits), and then the stage ends with the
+// large class running alone on a mostly empty chip.  k_gate is what the side stream runs first: one wave that waits until the
+// large class's workgroups have all started (they all fit the chip at once) or `max_ticks` of the 100 MHz clock have passed --
+// an exit every launch reaches -- so the small classes fill the space the large one leaves instead of taking it first.
+__global__ void __launch_bounds__(64) k_gate(Status *st, int cls, unsigned want_max, unsigned max_ticks) {
+    const u64 n2 = st->solve_cls[cls];
+    const unsigned want = n2 < want_max ? (unsigned)n2 : want_max;
+    const unsigned long long t0 = wall_clock64();
+    const unsigned *ctr = cls == 2 ? &st->gate : &st->gate_mid;
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want && wall_clock64() - t0 < max_ticks)
+        __builtin_amdgcn_s_sleep(16);
+}
+
 constexpr int kFuseLanes = 255;   // reads a problem may see for 8-bit triple counters (four 64-read rounds at most)
 constexpr int kFuseLanesWide = 1023;   // ... and for the 16-bit instances: partitions of 1 000 reads have problems that see ~300 (one
                                        // in twenty-five of them more than 255); a problem that sees more than this is quicker spread
@@ -2622,7 +2702,7 @@ inline size_t solve_lds_for(int nm, int cov_stride, int cnt_bytes) {
     return ((pairs * 16 + (size_t)kSub * cov_stride * 4 + ((tri + 15) & ~(size_t)15) * cnt_bytes) + 15) & ~(size_t)15;
 }
 template <int NM, typename CntT, typename V>
-__global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBlocks) k_solve(Status *st, int cls, int nm, const int *solve_items, ProblemArrays pr,
+__global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBlocks) k_solve(Status *st, int cls, int nm, i64 lb_h, i64 ln_h, ProblemArrays pr,
                                                                   const ProbDesc *desc, i64 prob_cap, const int *cand_y,
                                                                   const longlong2 *lane_ex, const int *ex_ts, const int *ex_te,
                                                                   const double *h_table, int h_len, double tau, const int2 *thr_tab,
@@ -2643,14 +2723,28 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
     V *M = reinterpret_cast<V *>(smem);
     int *in_s = reinterpret_cast<int *>(M + rt_pairs);
     unsigned char *A = reinterpret_cast<unsigned char *>(in_s + rt_pairs);
-    if ((i64)st->n_prob > prob_cap) return;                          // lists incomplete (a run that only sizes the arenas)
+    if (NM == kNMax && sizeof(CntT) == 1 && threadIdx.x == 0) atomicAdd(&st->gate, 1u);     // placed: see k_gate
+    if (NM == kClsMid && sizeof(CntT) == 1 && threadIdx.x == 0) atomicAdd(&st->gate_mid, 1u);
+    // (lb_h >= 0: the host knows the lists' sizes -- the batch has been sized --, and the status record is not on the way to the first problem)
+    if (lb_h < 0 && (i64)st->n_prob > prob_cap) return;              // lists incomplete (a run that only sizes the arenas)
 #ifdef FSEG_SOLVE_PRIO
     __builtin_amdgcn_s_setprio(NM > 32 ? 3 : (NM > 16 ? 2 : 1));
 #endif
     // cls < 0: every solve list (batches of few problems: one launch instead of three)
-    const i64 list_base = cls <= 0 ? 0 : (cls == 1 ? (i64)st->solve_cls[0] : (i64)st->solve_cls[0] + (i64)st->solve_cls[1]);
-    const i64 list_n = cls < 0 ? (i64)st->solve_cls[0] + (i64)st->solve_cls[1] + (i64)st->solve_cls[2] : (i64)st->solve_cls[cls];
+    const i64 list_base = lb_h >= 0 ? lb_h : (cls <= 0 ? 0 : (cls == 1 ? (i64)st->solve_cls[0] : (i64)st->solve_cls[0] + (i64)st->solve_cls[1]));
+    const i64 list_n = lb_h >= 0 ? ln_h : (cls < 0 ? (i64)st->solve_cls[0] + (i64)st->solve_cls[1] + (i64)st->solve_cls[2] : (i64)st->solve_cls[cls]);
     const int r_lane = threadIdx.x & 63, w_rng = wave_id();
+    // A problem is a chain of dependent loads, about a microsecond each, and the chain -- not arithmetic -- is most of what a
+    // problem of the small and mid classes takes.  It is kept to three links: the record (from the list itself), then the
+    // candidates AND the reads' exon ranges, then the pair thresholds AND the reads' first exon blocks.  What needs no link at
+    // all is loaded before the first problem: this thread's pairs (i, j) -- pair q = s * T + tid whatever the problem.
+    int pi[C::kSlots], pj[C::kSlots];
+#pragma unroll
+    for (int s = 0; s < C::kSlots; ++s) {
+        const int q = s * T + threadIdx.x;
+        const unsigned short ij = g_pair_ij[q < kNMax * (kNMax - 1) / 2 ? q : 0];
+        pi[s] = ij & 255; pj[s] = ij >> 8;
+    }
 #ifdef FSEG_SCORE_TIMING
     // diagnostic build: phase clocks of the class given by tacc[15] (slots 0..5 scoring phases, 8..12 the DP's)
     __shared__ unsigned long long tick_sink[16];
@@ -2665,9 +2759,12 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
 #ifdef FSEG_SCORE_TIMING
         const unsigned long long t_prob0 = wall_clock64();
 #endif
-        const int p = uni(solve_items[list_base + t]);
-        const ProbDesc d = FSEG_LOAD_DESC(desc + p);
+        const ProbDesc d = FSEG_LOAD_DESC(desc + list_base + t);    // link 1 (the list's own copy of the record: k_prob_emit)
+        const int p = d.w0;
         const int n = d.n;
+        // link 2: the candidates and the first T reads' exon ranges, side by side (T > NM: a candidate per thread)
+        const int cyv = cand_y[d.c0 + ((int)threadIdx.x < n ? (int)threadIdx.x : 0)];
+        longlong2 ex = lane_ex[d.lane_lo + ((int)threadIdx.x < d.lane_n ? (int)threadIdx.x : 0)];
         __syncthreads();                                             // the previous problem's DP is done with LDS
         FSEG_STICK(0);
         if (n > nm || n > NM) { if (threadIdx.x == 0) atomicOr(&st->err, kErrOverflowNm); continue; }
@@ -2675,26 +2772,29 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
         if ((sizeof(CntT) == 1) != (d.lane_n <= kFuseLanes)) continue;
         if (d.lane_n > kFuseLanesWide) { if (threadIdx.x == 0) atomicOr(&st->err, kErrNeedWideDp); continue; }
         const int npairs = n * (n - 1) / 2, ntri = n * (n - 1) * (n - 2) / 6;
-        const int *cy = cand_y + d.c0;
-        for (int j = threadIdx.x; j < n; j += T) cy_s[j] = cy[j];
+        if ((int)threadIdx.x < n) cy_s[threadIdx.x] = cyv;
+        // link 3, first half: this read's first eight exons (requested before the thresholds below wait for the candidates)
+        int ts8[8], te8[8];
+        load_exons8(ex_ts + ex.x, ts8); load_exons8(ex_te + ex.x, te8);
         {
             uint4 *z = reinterpret_cast<uint4 *>(cnt);
             for (int x = threadIdx.x; x < (ntri * (int)sizeof(CntT) + 15) / 16; x += T) z[x] = make_uint4(0, 0, 0, 0);
         }
         __syncthreads();
-        // this thread's pairs: (i, j), integer label bounds, ambiguity count -- in registers for the whole problem
-        int pi[C::kSlots], pj[C::kSlots], th_hi[C::kSlots], th_lo[C::kSlots];
+        // link 3, second half: integer label bounds of this thread's pairs -- in registers for the whole problem, with the ambiguity counts
+        int th_hi[C::kSlots], th_lo[C::kSlots], seg_len[C::kSlots];
         unsigned amb_acc[C::kSlots];
 #pragma unroll
-        for (int s = 0; s < C::kSlots; ++s) {
+        for (int s = 0; s < C::kSlots; ++s) {                        // (every slot's table load first, none of them under a branch)
             const int q = s * T + threadIdx.x;
-            amb_acc[s] = 0; pi[s] = 0; pj[s] = 1; th_hi[s] = 0x7fffffff; th_lo[s] = -1;
-            if (q < npairs) {
-                const unsigned short ij = g_pair_ij[q];
-                pi[s] = ij & 255; pj[s] = ij >> 8;
-                label_thresholds_tab((i64)cy_s[pj[s]] - cy_s[pi[s]] + 1, thr_tab, h_table, h_len, tau, &th_hi[s], &th_lo[s]);
-            }
+            amb_acc[s] = 0;
+            seg_len[s] = q < npairs ? cy_s[pj[s]] - cy_s[pi[s]] + 1 : 0;
+            const int2 tt = thr_tab[seg_len[s] < kThrTab ? seg_len[s] : 0];        // (entry 0: no label either way)
+            th_hi[s] = tt.x; th_lo[s] = tt.y;
         }
+#pragma unroll
+        for (int s = 0; s < C::kSlots; ++s)
+            if (seg_len[s] >= kThrTab) label_thresholds((i64)seg_len[s], h_table, h_len, tau, &th_hi[s], &th_lo[s]);
         if (threadIdx.x < n) {
             // iend_s[j] = number of i < j with cand_j - cand_i >= 5 (candidates ascending): binary search
             int j = threadIdx.x, lim = cy_s[j] - 5, lo = 0, hi = j;
@@ -2711,12 +2811,11 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
         for (int l0 = 0; l0 < d.lane_n; l0 += T) {
             const int l = l0 + (int)threadIdx.x;
             const bool in = l < d.lane_n;
-            const longlong2 ex = lane_ex[d.lane_lo + (in ? l : 0)];
+            if (l0 > 0) ex = lane_ex[d.lane_lo + (in ? l : 0)];     // (more than T reads: the small class's wider problems, 16-bit counters)
             i64 first = ex.x;
             int cnt = 0;
             for (i64 eb = ex.x; eb < ex.y; eb += 8) {               // eight exons per round from clamped addresses, in flight together
-                int ts8[8], te8[8];
-                load_exons8(ex_ts + eb, ts8); load_exons8(ex_te + eb, te8);
+                if (l0 > 0 || eb > ex.x) { load_exons8(ex_ts + eb, ts8); load_exons8(ex_te + eb, te8); }    // (the first block is on its way)
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const bool hit = eb + u < ex.y && te8[u] >= cp0 && ts8[u] < c_last;
@@ -3815,6 +3914,7 @@ struct fseg_ctx {
     // batch metadata (host)
     int n_part = 0;
     i64 K = 0, R = 0, I = 0, NPOS = 0, LANES = 0;
+    i64 max_part_lanes = 0;    // reads of the batch's largest partition (what bounds a DP sum: 32-bit keys below 2^18)
     int n_tiles = 0;
     bool expanded = false;
     std::vector<i64> part_iv_off, part_rep_off;
@@ -3850,7 +3950,7 @@ struct fseg_ctx {
     // problems / arenas (slab_arena)
     DevBuf d_prob_iv, d_prob_start, d_prob_n, d_prob_pair_off, d_prob_tri_off, d_prob_flags, d_prob_chain,
         d_prob_cov_off, d_prob_lane_lo, d_prob_lane_n;
-    DevBuf d_dp_items, d_solve_items, d_prob_desc, d_work_pc, d_cls_items, d_work_active, d_pair_thr, d_amb, d_out, d_cov;
+    DevBuf d_dp_items, d_solve_items, d_solve_desc, d_prob_desc, d_work_pc, d_cls_items, d_work_active, d_pair_thr, d_amb, d_out, d_cov;
     i64 prob_cap = 0, work_cap = 0, pair_cap = 0, tri_cap = 0, label_cap = 0, chunk_cap = 0, cov_cap = 0;
     DevBuf d_status, d_prep, d_tacc;
     Status *h_status = nullptr;   // pinned
@@ -3892,6 +3992,8 @@ struct fseg_ctx {
     hipEvent_t fj[kForkEvents] = {};
     bool use_fork = true;
     bool use_tiny = true;       // FSEG_NO_TINY=1: no problem goes to k_tiny
+    bool force_key64 = false;
+    char score_plan[32] = "BM|gTS";   // FSEG_SCORE_PLAN (see enqueue_run; anything that does not name each class once = one stream)
     bool score_fork = false;    // FSEG_SCORE_FORK=1: the fused scoring kernels on a stream each
     bool use_wave = true;       // FSEG_NO_WAVE=1: k_tiny / k_solve<16> instead of the wave kernels (k_wave)
     bool wave_small = false;    // FSEG_WAVE_SMALL=1: the small class (9 .. 16 candidates) goes to k_wave<16> instead of k_solve<16> (one wave
@@ -4032,6 +4134,7 @@ int alloc_arenas(fseg_ctx *c) {
     cv.add(c->d_prob_chain, (size_t)c->prob_cap * 4);
     cv.add(c->d_dp_items, (size_t)c->prob_cap * 4);
     cv.add(c->d_solve_items, (size_t)c->prob_cap * 4);
+    cv.add(c->d_solve_desc, (size_t)c->prob_cap * sizeof(ProbDesc));
     cv.add(c->d_prob_cov_off, (size_t)c->prob_cap * 8);
     cv.add(c->d_prob_lane_lo, (size_t)c->prob_cap * 4);
     cv.add(c->d_prob_lane_n, (size_t)c->prob_cap * 4);
@@ -4210,7 +4313,7 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
                        c->d_cand_ln.as<int>(), c->d_seg_iv.as<int>(), c->d_cand_off.as<i64>(), prob_bs,
                        pr, c->prob_cap, c->d_work_pc.as<int2>(), c->d_cls_items.as<int4>(),
                        c->work_cap, c->d_dp_items.as<int>(), c->d_prob_desc.as<ProbDesc>(), c->d_iv_start.as<int>(),
-                       c->d_iv_part.as<int>(), c->d_part_lane_off.as<i64>(), split, c->d_solve_items.as<int>());
+                       c->d_iv_part.as<int>(), c->d_part_lane_off.as<i64>(), split, c->d_solve_items.as<int>(), c->d_solve_desc.as<ProbDesc>());
     // S5
     if (c->prob_cap > 0 && any_arena) {
         const int cov_blocks = work_grid < 2048 ? work_grid : 2048;
@@ -4237,6 +4340,10 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
         // On four streams the dispatcher ran them in the reverse of their launch order -- a large-class workgroup needs eight wave
         // slots and half a CU's LDS at once and got neither until the small classes had drained -- and the lists' longest-first
         // order was lost in the interleaving: 0.208 against 0.194 ms for the stage.
+        // (experiment) FSEG_SCORE_PLAN: streams separated by '|' (the first is the main stream), B M S T = the large / mid / small / tiny
+        // class's kernel, g = k_gate on the large class, h = on the mid class, e = wait for the large class to end
+        const bool any_solve_plan = c->use_fuse && c->fuse_on;
+        const char *plan = (known && !any_arena && !c->small_batch && forking && c->n_solve[2] > 0 && any_solve_plan && wave && !(wave && c->wave_small) && c->score_plan[0]) ? c->score_plan : nullptr;
         const bool sfork = c->score_fork || any_arena;              // (the arena path's work-item kernels keep their streams)
         hipStream_t qt = (tiny_max > 0 && sfork) ? fork(2) : s;     // (forked here: a side stream continues from where it was forked)
 #ifdef FSEG_SCORE_TIMING
@@ -4264,13 +4371,13 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
 #define FSEG_LAUNCH_SOLVE(Q, NMV, CNT, VT, CLS, N_ITEMS, MAXWG)                                                              \
             hipLaunchKernelGGL((k_solve<NMV, CNT, VT>), dim3(grid_for((N_ITEMS), 1, (MAXWG))), dim3(SolveCfg<NMV>::kThreads),       \
                                solve_lds_for((NMV) == kNMax ? c->nm_big : (NMV), (NMV) + 1, (int)sizeof(CNT)), Q, st, CLS,      \
-                               ((NMV) == kNMax ? c->nm_big : (NMV)), c->d_solve_items.as<int>(), pr, c->d_prob_desc.as<ProbDesc>(), \
+                               ((NMV) == kNMax ? c->nm_big : (NMV)), list_lb(CLS), list_ln(CLS), pr, c->d_solve_desc.as<ProbDesc>(), \
                                c->prob_cap, c->d_cand_y.as<int>(), c->d_lane_ex.as<longlong2>(), c->d_ex_ts.as<int>(),         \
                                c->d_ex_te.as<int>(), c->d_h_table.as<double>(), c->P.h_len, c->P.threshold_rate,               \
                                c->d_thr_tab.as<int2>(), c->P.min_read_support_outside, c->d_chosen.as<unsigned char>() FSEG_TARG)
-        // sums in 32 bits when no chain of a problem can reach 2^30: n <= 64 times the reads of the largest partition
+        // 32-bit DP keys (dp_solve_push) when no sum of a chain can reach 2^24: at most 32 links times the reads of the largest partition
 #define FSEG_LAUNCH_SOLVE_W(Q, NMV, CLS, N_ITEMS, MAXWG)                                                                     \
-            do { if (c->LANES < (1LL << 24)) { FSEG_LAUNCH_SOLVE(Q, NMV, unsigned char, int, CLS, N_ITEMS, MAXWG);              \
+            do { if (key32) { FSEG_LAUNCH_SOLVE(Q, NMV, unsigned char, int, CLS, N_ITEMS, MAXWG);              \
                                                if (FSEG_WIDE_NEEDED(CLS)) FSEG_LAUNCH_SOLVE(Q, NMV, unsigned short, int, CLS, N_ITEMS, MAXWG); } \
                  else { FSEG_LAUNCH_SOLVE(Q, NMV, unsigned char, i64, CLS, N_ITEMS, MAXWG);                                     \
                         if (FSEG_WIDE_NEEDED(CLS)) FSEG_LAUNCH_SOLVE(Q, NMV, unsigned short, i64, CLS, N_ITEMS, MAXWG); } } while (0)
@@ -4281,13 +4388,17 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
         // one wave per problem on the exon stream (k_wave): the small class's solve list and k_tiny's list
 #define FSEG_LAUNCH_WAVE_V(Q, NMV, VT, LIST, N_ITEMS)                                                                        \
             hipLaunchKernelGGL((k_wave<NMV, VT>), dim3(grid_for((N_ITEMS), 4, FSEG_WG_TINY)), dim3(256), 0, Q, st,           \
-                               c->d_prob_desc.as<ProbDesc>(), c->prob_cap, LIST, pr, c->d_cand_y.as<int>(), c->d_lane_lx.as<int2>(), \
+                               c->d_solve_desc.as<ProbDesc>(), c->prob_cap, LIST, pr, c->d_cand_y.as<int>(), c->d_lane_lx.as<int2>(), \
                                c->d_lex.as<int2>(), c->d_h_table.as<double>(), c->P.h_len, c->P.threshold_rate,               \
                                c->d_thr_tab.as<int2>(), c->P.min_read_support_outside, c->d_chosen.as<unsigned char>(),        \
-                               c->d_solve_items.as<int>() FSEG_TARG)
+                               list_lb(LIST), list_ln(LIST) FSEG_TARG)
 #define FSEG_LAUNCH_WAVE(Q, NMV, LIST, N_ITEMS)                                                                              \
-            do { if (c->LANES < (1LL << 24)) { FSEG_LAUNCH_WAVE_V(Q, NMV, int, LIST, N_ITEMS); }                              \
+            do { if (key32) { FSEG_LAUNCH_WAVE_V(Q, NMV, int, LIST, N_ITEMS); }                              \
                  else { FSEG_LAUNCH_WAVE_V(Q, NMV, i64, LIST, N_ITEMS); } } while (0)
+        // the bounds of solve list `l` (0..2 the classes, 3 the tiny problems, < 0 the three classes together) when the host knows them
+        const bool key32 = c->max_part_lanes < (1LL << 18) && !c->force_key64;     // (FSEG_FORCE_KEY64=1: the 64-bit instances whatever the batch)
+        auto list_lb = [&](int l) -> i64 { return !known ? -1 : (l <= 0 ? 0 : (l == 1 ? c->n_solve[0] : (l == 2 ? c->n_solve[0] + c->n_solve[1] : c->n_solve[0] + c->n_solve[1] + c->n_solve[2]))); };
+        auto list_ln = [&](int l) -> i64 { return !known ? -1 : (l < 0 ? c->n_solve[0] + c->n_solve[1] + c->n_solve[2] : (l == 3 ? c->n_tiny : c->n_solve[l])); };
         const bool any_solve = c->use_fuse && c->fuse_on && (!known || c->n_solve[0] + c->n_solve[1] + c->n_solve[2] > 0);
         const bool wave16 = wave && c->wave_small;                                         // list 0 belongs to k_wave<16>
         const bool wave_solve = c->use_fuse && wave16 && (!known || c->n_solve[0] > 0);
@@ -4301,6 +4412,30 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
             } else if (any_solve) FSEG_LAUNCH_SOLVE_W(s, kNMax, -1, known ? c->n_solve[0] + c->n_solve[1] + c->n_solve[2] : cap, 512);
         } else {                                     // the size classes own disjoint problems: three concurrent chains
             hipStream_t q1 = sfork ? fork(0) : s, q0 = sfork ? fork(1) : s;
+            if (plan) {
+                int n_seg = 1;
+                for (const char *p = plan; *p; ++p) n_seg += *p == '|';
+                if (n_seg > 4) n_seg = 4;
+                for (int k = 1; k < n_seg; ++k) (void)fork(k - 1);          // every side stream continues from HERE
+                int seg = 0;
+                hipEvent_t ev_big = nullptr;
+                for (const char *p = plan; *p && seg < n_seg; ++p) {
+                    if (*p == '|') { ++seg; continue; }
+                    hipStream_t q = seg == 0 ? s : c->side[seg - 1];
+                    switch (*p) {
+                    case 'B': FSEG_LAUNCH_SOLVE_W(q, kNMax, 2, c->n_solve[2], 512);
+                              ev_big = fj_event(); if (hipEventRecord(ev_big, q) != hipSuccess) fj_err = hipErrorUnknown; break;
+                    case 'M': if (c->n_solve[1] > 0) FSEG_LAUNCH_SOLVE_W(q, kClsMid, 1, c->n_solve[1], FSEG_WG_MID); break;
+                    case 'S': if (c->n_solve[0] > 0) FSEG_LAUNCH_SOLVE_W(q, kClsSmall, 0, c->n_solve[0], FSEG_WG_SMALL); break;
+                    case 'T': if (c->n_tiny > 0) FSEG_LAUNCH_WAVE(q, kTiny, 3, c->n_tiny); break;
+                    case 'g': hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, q, st, 2, (unsigned)(c->n_solve[2] < 512 ? c->n_solve[2] : 512), 3000u); break;
+                    case 'h': hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, q, st, 1, (unsigned)(c->n_solve[1] < FSEG_WG_MID ? c->n_solve[1] : FSEG_WG_MID), 8000u); break;
+                    case 'e': if (ev_big && hipStreamWaitEvent(q, ev_big, 0) != hipSuccess) fj_err = hipErrorUnknown; break;
+                    default: break;
+                    }
+                }
+                for (int k = 1; k < n_seg; ++k) join(k - 1);
+            } else {
             if (any_arena && (!known || c->n_cls_work[2] > 0)) FSEG_LAUNCH_SCORE(s, kNMax, 2, 512);     // big problems: they are the long poles
             if (any_solve && (!known || c->n_solve[2] > 0)) FSEG_LAUNCH_SOLVE_W(s, kNMax, 2, known ? c->n_solve[2] : cap, 512);
             if (any_arena && (!known || c->n_cls_work[1] > 0)) FSEG_LAUNCH_SCORE(q1, kClsMid, 1, 1280);
@@ -4308,20 +4443,21 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
             if (any_arena && (!known || c->n_cls_work[0] > 0)) FSEG_LAUNCH_SCORE(q0, kClsSmall, 0, 2048);
             if (wave16) { if (wave_solve) FSEG_LAUNCH_WAVE(q0, kClsSmall, 0, known ? c->n_solve[0] : cap); }
             else if (any_solve && (!known || c->n_solve[0] > 0)) FSEG_LAUNCH_SOLVE_W(q0, kClsSmall, 0, known ? c->n_solve[0] : cap, FSEG_WG_SMALL);
+            }
         }
 #undef FSEG_LAUNCH_SOLVE_W
 #undef FSEG_LAUNCH_SOLVE
 #undef FSEG_LAUNCH_SCORE
-        if (tiny_max > 0) {
+        if (tiny_max > 0 && !plan) {
             // the problems with a handful of candidates, whole (coverage, labels, counts, DP), beside the others (launched
             // after the classes whose workgroups need half a CU's LDS each); joined at the end of this stage, so the
             // stage's time bracket covers all scoring work
             if (wave) FSEG_LAUNCH_WAVE(qt, kTiny, 3, known ? c->n_tiny : c->prob_cap);
             else
-            hipLaunchKernelGGL(k_tiny, dim3(grid_for(known ? c->n_tiny : c->prob_cap, 4, FSEG_WG_TINY)), dim3(256), 0, qt, st, c->d_prob_desc.as<ProbDesc>(),
+            hipLaunchKernelGGL(k_tiny, dim3(grid_for(known ? c->n_tiny : c->prob_cap, 4, FSEG_WG_TINY)), dim3(256), 0, qt, st, c->d_solve_desc.as<ProbDesc>(),
                                c->prob_cap, tiny_max, pr, c->d_cand_y.as<int>(), c->d_lane_ex.as<longlong2>(),
                                c->d_ex_ts.as<int>(), c->d_ex_te.as<int>(), c->d_h_table.as<double>(), c->P.h_len, c->P.threshold_rate,
-                               c->d_thr_tab.as<int2>(), c->P.min_read_support_outside, c->d_chosen.as<unsigned char>(), c->d_solve_items.as<int>() FSEG_TARG);
+                               c->d_thr_tab.as<int2>(), c->P.min_read_support_outside, c->d_chosen.as<unsigned char>(), list_lb(3), list_ln(3) FSEG_TARG);
         }
 #undef FSEG_LAUNCH_WAVE
 #undef FSEG_LAUNCH_WAVE_V
@@ -4744,6 +4880,14 @@ int fseg_create(int device, fseg_ctx **out) {
     if (flag("FSEG_NO_FUSE")) c->use_fuse = false;
     if (flag("FSEG_NO_WAVE")) c->use_wave = false;
     if (flag("FSEG_SCORE_FORK")) c->score_fork = true;
+    if (flag("FSEG_FORCE_KEY64")) c->force_key64 = true;
+    if (const char *e = getenv("FSEG_SCORE_PLAN")) snprintf(c->score_plan, sizeof c->score_plan, "%s", e);
+    {
+        int seen[4] = {0, 0, 0, 0};
+        static const char kinds[] = "BMST";
+        for (const char *q = c->score_plan; *q; ++q) { const char *at = strchr(kinds, *q); if (at) ++seen[at - kinds]; }
+        if (seen[0] != 1 || seen[1] != 1 || seen[2] != 1 || seen[3] != 1) c->score_plan[0] = 0;
+    }
     { const char *v = getenv("FSEG_WAVE_SMALL"); if (v && v[0]) c->wave_small = v[0] == '1'; }
     { const char *v = getenv("FSEG_FUSE_LANES"); if (v && v[0] && atoi(v) > 0 && atoi(v) <= kFuseLanesWide) c->fuse_lanes = atoi(v); }
     if (flag("FSEG_NO_SIZED")) c->use_sized = false;
@@ -4811,6 +4955,7 @@ int fseg_set_params(fseg_ctx *c, const fseg_params *p) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->have_params = true;
     c->ran = false;          // results of an earlier run belong to other parameters
+    c->counts_known = false; // ... and so do the sizes of its lists
     return FSEG_OK;
 }
 
@@ -4945,7 +5090,7 @@ static int upload_impl(fseg_ctx *c, const fseg_batch *b) {
         int *h_hc_part = reinterpret_cast<int *>(host_of(c->d_hc_part)), *h_hc_n = reinterpret_cast<int *>(host_of(c->d_hc_n));
         int *h_hc_glo = reinterpret_cast<int *>(host_of(c->d_hc_glo)), *h_hc_ghi = reinterpret_cast<int *>(host_of(c->d_hc_ghi));
         i64 *h_hc_p0 = reinterpret_cast<i64 *>(host_of(c->d_hc_p0));
-        h_pos_off[0] = 0; h_lane_off[0] = 0;
+        h_pos_off[0] = 0; h_lane_off[0] = 0; c->max_part_lanes = 0;
         i64 t = 0, rb = 0, ch = 0, l = 0, bq = 0;
         for (int p = 0; p < np; ++p) {
             const i64 k0 = b->part_iv_off[p], k1 = b->part_iv_off[p + 1];
@@ -4961,6 +5106,7 @@ static int upload_impl(fseg_ctx *c, const fseg_batch *b) {
             for (i64 r = b->part_rep_off[p]; r < b->part_rep_off[p + 1]; r += 256) { h_rb_part[rb] = p; h_rb_r0[rb] = (int)r; ++rb; }
             for (i64 r = b->part_rep_off[p]; r < b->part_rep_off[p + 1]; ++r) l += b->rep_weight[r];
             h_lane_off[p + 1] = l;
+            if (l - h_lane_off[p] > c->max_part_lanes) c->max_part_lanes = l - h_lane_off[p];
             // histogram chunks of the partition, with the genomic position of the chunk's first and last position (a
             // chunk may span several intervals of its partition)
             const i64 P0 = h_pos_off[k0], P1 = h_pos_off[k1];
@@ -4990,6 +5136,7 @@ static int upload_impl(fseg_ctx *c, const fseg_batch *b) {
     memcpy(host_of(c->d_ex_te), b->ex_te, (size_t)I * 4);
     const double t_copy = tk.ms();
     c->n_part = np; c->K = K; c->R = R; c->I = I; c->NPOS = NPOS; c->LANES = lanes; c->expanded = expanded;
+    if (c->max_part_lanes > lanes) c->max_part_lanes = lanes;
     c->n_tiles = (int)n_tiles; c->n_hist_chunks = (int)n_chunks; c->n_rep_blocks = (int)n_rep_blocks; c->max_rep_exons = max_rep_exons;
     c->part_iv_off.assign(b->part_iv_off, b->part_iv_off + np + 1);
     c->part_rep_off.assign(b->part_rep_off, b->part_rep_off + np + 1);

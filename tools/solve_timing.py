@@ -13,6 +13,7 @@ params = bench.PARAMS["config5" if wl == "config5" else "default"]
 tabs = dict(w_main=tables.gaussian_half_kernel(params["sigma"], 4.0), w_refine=tables.gaussian_half_kernel(params["sigma"], 1.0),
             h_table=np.asarray(tables.smooth_threshold(params["threshold_rate"]), np.float64))
 per, _ = bench.plan_batches(wl, 1)
+per = int(os.environ.get("PROB_TICKS_PARTS", per))     # a few partitions: every problem alone on a CU (unloaded latency)
 w = dict(bench.synth.WORKLOADS[wl]); w.pop("n_partitions")
 parts = []
 for i in range(per):
