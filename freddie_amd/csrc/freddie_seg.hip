@@ -97,7 +97,7 @@ struct Status {
     unsigned list_cur[8];   // k_prob_emit's cursors into the four solve lists: [2 * list] from the front (expensive problems), [2 * list + 1] from the back
     unsigned wide_cls[4];   // solve-list problems per size class that see more than kFuseLanes reads (16-bit counters); [3] unused
     unsigned gate;          // large-class workgroups that have started (k_gate holds the small classes back until they are placed)
-    unsigned gate_mid;      // ... and the mid class's
+    unsigned pad2;          // (a counter of the mid class's 2 000 workgroups, bumped by each as it started, cost that kernel 10 of its 62 us)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -2669,12 +2669,11 @@ __global__ void __launch_bounds__(256, WaveCfg<NM>::kOcc) k_wave(Status *st, con
 // large class running alone on a mostly empty chip.  k_gate is what the side stream runs first: one wave that waits until the
 // large class's workgroups have all started (they all fit the chip at once) or `max_ticks` of the 100 MHz clock have passed --
 // an exit every launch reaches -- so the small classes fill the space the large one leaves instead of taking it first.
-__global__ void __launch_bounds__(64) k_gate(Status *st, int cls, unsigned want_max, unsigned max_ticks) {
-    const u64 n2 = st->solve_cls[cls];
+__global__ void __launch_bounds__(64) k_gate(Status *st, unsigned want_max, unsigned max_ticks) {
+    const u64 n2 = st->solve_cls[2];
     const unsigned want = n2 < want_max ? (unsigned)n2 : want_max;
     const unsigned long long t0 = wall_clock64();
-    const unsigned *ctr = cls == 2 ? &st->gate : &st->gate_mid;
-    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want && wall_clock64() - t0 < max_ticks)
+    while (__hip_atomic_load(&st->gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want && wall_clock64() - t0 < max_ticks)
         __builtin_amdgcn_s_sleep(16);
 }
 
@@ -2695,7 +2694,10 @@ template <int NM> struct SolveCfg {
 #ifndef FSEG_SOLVE_OCC32
 #define FSEG_SOLVE_OCC32 5      // (96 registers, five workgroups of the mid class per CU: 74 -> 70 us on config4; six spill and lose it again)
 #endif
-    static constexpr int kMinBlocks = !FSEG_SOLVE_OCC ? 1 : (NM <= 16 ? 5 : (NM <= 32 ? FSEG_SOLVE_OCC32 : 4));
+#ifndef FSEG_SOLVE_OCC16
+#define FSEG_SOLVE_OCC16 5
+#endif
+    static constexpr int kMinBlocks = !FSEG_SOLVE_OCC ? 1 : (NM <= 16 ? FSEG_SOLVE_OCC16 : (NM <= 32 ? FSEG_SOLVE_OCC32 : 4));
 };
 inline size_t solve_lds_for(int nm, int cov_stride, int cnt_bytes) {
     const size_t pairs = (size_t)nm * (nm - 1) / 2, tri = (size_t)nm * (nm - 1) * (nm - 2) / 6;
@@ -2724,7 +2726,6 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
     int *in_s = reinterpret_cast<int *>(M + rt_pairs);
     unsigned char *A = reinterpret_cast<unsigned char *>(in_s + rt_pairs);
     if (NM == kNMax && sizeof(CntT) == 1 && threadIdx.x == 0) atomicAdd(&st->gate, 1u);     // placed: see k_gate
-    if (NM == kClsMid && sizeof(CntT) == 1 && threadIdx.x == 0) atomicAdd(&st->gate_mid, 1u);
     // (lb_h >= 0: the host knows the lists' sizes -- the batch has been sized --, and the status record is not on the way to the first problem)
     if (lb_h < 0 && (i64)st->n_prob > prob_cap) return;              // lists incomplete (a run that only sizes the arenas)
 #ifdef FSEG_SOLVE_PRIO
@@ -2734,17 +2735,6 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
     const i64 list_base = lb_h >= 0 ? lb_h : (cls <= 0 ? 0 : (cls == 1 ? (i64)st->solve_cls[0] : (i64)st->solve_cls[0] + (i64)st->solve_cls[1]));
     const i64 list_n = lb_h >= 0 ? ln_h : (cls < 0 ? (i64)st->solve_cls[0] + (i64)st->solve_cls[1] + (i64)st->solve_cls[2] : (i64)st->solve_cls[cls]);
     const int r_lane = threadIdx.x & 63, w_rng = wave_id();
-    // A problem is a chain of dependent loads, about a microsecond each, and the chain -- not arithmetic -- is most of what a
-    // problem of the small and mid classes takes.  It is kept to three links: the record (from the list itself), then the
-    // candidates AND the reads' exon ranges, then the pair thresholds AND the reads' first exon blocks.  What needs no link at
-    // all is loaded before the first problem: this thread's pairs (i, j) -- pair q = s * T + tid whatever the problem.
-    int pi[C::kSlots], pj[C::kSlots];
-#pragma unroll
-    for (int s = 0; s < C::kSlots; ++s) {
-        const int q = s * T + threadIdx.x;
-        const unsigned short ij = g_pair_ij[q < kNMax * (kNMax - 1) / 2 ? q : 0];
-        pi[s] = ij & 255; pj[s] = ij >> 8;
-    }
 #ifdef FSEG_SCORE_TIMING
     // diagnostic build: phase clocks of the class given by tacc[15] (slots 0..5 scoring phases, 8..12 the DP's)
     __shared__ unsigned long long tick_sink[16];
@@ -2759,12 +2749,9 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
 #ifdef FSEG_SCORE_TIMING
         const unsigned long long t_prob0 = wall_clock64();
 #endif
-        const ProbDesc d = FSEG_LOAD_DESC(desc + list_base + t);    // link 1 (the list's own copy of the record: k_prob_emit)
+        const ProbDesc d = FSEG_LOAD_DESC(desc + list_base + t);    // (the list's own copy of the record: k_prob_emit)
         const int p = d.w0;
         const int n = d.n;
-        // link 2: the candidates and the first T reads' exon ranges, side by side (T > NM: a candidate per thread)
-        const int cyv = cand_y[d.c0 + ((int)threadIdx.x < n ? (int)threadIdx.x : 0)];
-        longlong2 ex = lane_ex[d.lane_lo + ((int)threadIdx.x < d.lane_n ? (int)threadIdx.x : 0)];
         __syncthreads();                                             // the previous problem's DP is done with LDS
         FSEG_STICK(0);
         if (n > nm || n > NM) { if (threadIdx.x == 0) atomicOr(&st->err, kErrOverflowNm); continue; }
@@ -2772,29 +2759,30 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
         if ((sizeof(CntT) == 1) != (d.lane_n <= kFuseLanes)) continue;
         if (d.lane_n > kFuseLanesWide) { if (threadIdx.x == 0) atomicOr(&st->err, kErrNeedWideDp); continue; }
         const int npairs = n * (n - 1) / 2, ntri = n * (n - 1) * (n - 2) / 6;
-        if ((int)threadIdx.x < n) cy_s[threadIdx.x] = cyv;
-        // link 3, first half: this read's first eight exons (requested before the thresholds below wait for the candidates)
-        int ts8[8], te8[8];
-        load_exons8(ex_ts + ex.x, ts8); load_exons8(ex_te + ex.x, te8);
+        const int *cy = cand_y + d.c0;
+        for (int j = threadIdx.x; j < n; j += T) cy_s[j] = cy[j];
         {
             uint4 *z = reinterpret_cast<uint4 *>(cnt);
             for (int x = threadIdx.x; x < (ntri * (int)sizeof(CntT) + 15) / 16; x += T) z[x] = make_uint4(0, 0, 0, 0);
         }
         __syncthreads();
-        // link 3, second half: integer label bounds of this thread's pairs -- in registers for the whole problem, with the ambiguity counts
-        int th_hi[C::kSlots], th_lo[C::kSlots], seg_len[C::kSlots];
+        // this thread's pairs: (i, j), integer label bounds, ambiguity count -- in registers for the whole problem
+        // (Tried: the pairs loaded once per workgroup, the reads' exon ranges requested with the candidates and their first exon
+        // blocks with the threshold table -- three dependent loads instead of seven before the first round.  The registers that
+        // keeps alive spill (mid class 61 -> 77 us), and a problem alone on the chip is no faster for it: its time is the LDS
+        // phases and the DP, not these loads.)
+        int pi[C::kSlots], pj[C::kSlots], th_hi[C::kSlots], th_lo[C::kSlots];
         unsigned amb_acc[C::kSlots];
 #pragma unroll
-        for (int s = 0; s < C::kSlots; ++s) {                        // (every slot's table load first, none of them under a branch)
+        for (int s = 0; s < C::kSlots; ++s) {
             const int q = s * T + threadIdx.x;
-            amb_acc[s] = 0;
-            seg_len[s] = q < npairs ? cy_s[pj[s]] - cy_s[pi[s]] + 1 : 0;
-            const int2 tt = thr_tab[seg_len[s] < kThrTab ? seg_len[s] : 0];        // (entry 0: no label either way)
-            th_hi[s] = tt.x; th_lo[s] = tt.y;
+            amb_acc[s] = 0; pi[s] = 0; pj[s] = 1; th_hi[s] = 0x7fffffff; th_lo[s] = -1;
+            if (q < npairs) {
+                const unsigned short ij = g_pair_ij[q];
+                pi[s] = ij & 255; pj[s] = ij >> 8;
+                label_thresholds_tab((i64)cy_s[pj[s]] - cy_s[pi[s]] + 1, thr_tab, h_table, h_len, tau, &th_hi[s], &th_lo[s]);
+            }
         }
-#pragma unroll
-        for (int s = 0; s < C::kSlots; ++s)
-            if (seg_len[s] >= kThrTab) label_thresholds((i64)seg_len[s], h_table, h_len, tau, &th_hi[s], &th_lo[s]);
         if (threadIdx.x < n) {
             // iend_s[j] = number of i < j with cand_j - cand_i >= 5 (candidates ascending): binary search
             int j = threadIdx.x, lim = cy_s[j] - 5, lo = 0, hi = j;
@@ -2811,11 +2799,12 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
         for (int l0 = 0; l0 < d.lane_n; l0 += T) {
             const int l = l0 + (int)threadIdx.x;
             const bool in = l < d.lane_n;
-            if (l0 > 0) ex = lane_ex[d.lane_lo + (in ? l : 0)];     // (more than T reads: the small class's wider problems, 16-bit counters)
+            const longlong2 ex = lane_ex[d.lane_lo + (in ? l : 0)];
             i64 first = ex.x;
             int cnt = 0;
             for (i64 eb = ex.x; eb < ex.y; eb += 8) {               // eight exons per round from clamped addresses, in flight together
-                if (l0 > 0 || eb > ex.x) { load_exons8(ex_ts + eb, ts8); load_exons8(ex_te + eb, te8); }    // (the first block is on its way)
+                int ts8[8], te8[8];
+                load_exons8(ex_ts + eb, ts8); load_exons8(ex_te + eb, te8);
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const bool hit = eb + u < ex.y && te8[u] >= cp0 && ts8[u] < c_last;
@@ -4336,12 +4325,15 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
     }   // do_pre2
     if (do_score) begin(ST_SCORE);
     if (do_score && c->prob_cap > 0) {
-        // The scoring kernels stay on the one stream, largest class first (FSEG_SCORE_FORK=1: a stream each, as until round 3).
-        // On four streams the dispatcher ran them in the reverse of their launch order -- a large-class workgroup needs eight wave
-        // slots and half a CU's LDS at once and got neither until the small classes had drained -- and the lists' longest-first
-        // order was lost in the interleaving: 0.208 against 0.194 ms for the stage.
-        // (experiment) FSEG_SCORE_PLAN: streams separated by '|' (the first is the main stream), B M S T = the large / mid / small / tiny
-        // class's kernel, g = k_gate on the large class, h = on the mid class, e = wait for the large class to end
+        // How the four fused scoring kernels share the chip is a plan (FSEG_SCORE_PLAN, default "BM|gTS"): streams separated by
+        // '|' (the first is the main stream); B M S T = the large / mid / small / tiny class's kernel, g = k_gate (wait until the
+        // large class's workgroups are placed), e = wait for the large class to end.  Measured on config4 (250 k-read batch, stage
+        // alone): all four on the main stream 0.192-0.209 ms; a stream each without a gate 0.208-0.212 (the dispatcher then runs
+        // them in the reverse of their launch order: a large-class workgroup needs eight wave slots and half a CU's LDS at once and
+        // gets neither until the small classes have drained); "BM|gTS" 0.161-0.175: the tiny class runs in the large class's
+        // shadow, which is all that fits there (the large class holds three quarters of the registers), the small class beside the
+        // mid class.  "BM|gS|eT", "BM|gT|eS", "B|gM|gS|gT", "BS|gM|gT": 0.179-0.197.  Anything that does not name each class
+        // once, batches with arena-path problems and small batches: one stream (FSEG_SCORE_FORK=1: a stream each, as until round 3).
         const bool any_solve_plan = c->use_fuse && c->fuse_on;
         const char *plan = (known && !any_arena && !c->small_batch && forking && c->n_solve[2] > 0 && any_solve_plan && wave && !(wave && c->wave_small) && c->score_plan[0]) ? c->score_plan : nullptr;
         const bool sfork = c->score_fork || any_arena;              // (the arena path's work-item kernels keep their streams)
@@ -4428,8 +4420,7 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
                     case 'M': if (c->n_solve[1] > 0) FSEG_LAUNCH_SOLVE_W(q, kClsMid, 1, c->n_solve[1], FSEG_WG_MID); break;
                     case 'S': if (c->n_solve[0] > 0) FSEG_LAUNCH_SOLVE_W(q, kClsSmall, 0, c->n_solve[0], FSEG_WG_SMALL); break;
                     case 'T': if (c->n_tiny > 0) FSEG_LAUNCH_WAVE(q, kTiny, 3, c->n_tiny); break;
-                    case 'g': hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, q, st, 2, (unsigned)(c->n_solve[2] < 512 ? c->n_solve[2] : 512), 3000u); break;
-                    case 'h': hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, q, st, 1, (unsigned)(c->n_solve[1] < FSEG_WG_MID ? c->n_solve[1] : FSEG_WG_MID), 8000u); break;
+                    case 'g': hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, q, st, (unsigned)(c->n_solve[2] < 512 ? c->n_solve[2] : 512), 3000u); break;
                     case 'e': if (ev_big && hipStreamWaitEvent(q, ev_big, 0) != hipSuccess) fj_err = hipErrorUnknown; break;
                     default: break;
                     }
