@@ -2678,6 +2678,7 @@ __global__ void __launch_bounds__(64) k_gate(Status *st, unsigned want_max, unsi
 }
 
 constexpr int kFuseLanes = 255;   // reads a problem may see for 8-bit triple counters (four 64-read rounds at most)
+constexpr int kFuseLanesDefault = 511;  // reads a problem may see for its batch to take the fused kernels (FSEG_FUSE_LANES): eight rounds
 constexpr int kFuseLanesWide = 1023;   // ... and for the 16-bit instances: partitions of 1 000 reads have problems that see ~300 (one
                                        // in twenty-five of them more than 255); a problem that sees more than this is quicker spread
                                        // over the arena path's work items, and so is its whole batch
@@ -3982,7 +3983,7 @@ struct fseg_ctx {
     bool use_fork = true;
     bool use_tiny = true;       // FSEG_NO_TINY=1: no problem goes to k_tiny
     bool force_key64 = false;
-    char score_plan[32] = "BM|gTS";   // FSEG_SCORE_PLAN (see enqueue_run; anything that does not name each class once = one stream)
+    char score_plan[32] = "BM|gTS|b|ms";   // FSEG_SCORE_PLAN (see enqueue_run; anything that does not name each class once = one stream)
     bool score_fork = false;    // FSEG_SCORE_FORK=1: the fused scoring kernels on a stream each
     bool use_wave = true;       // FSEG_NO_WAVE=1: k_tiny / k_solve<16> instead of the wave kernels (k_wave)
     bool wave_small = false;    // FSEG_WAVE_SMALL=1: the small class (9 .. 16 candidates) goes to k_wave<16> instead of k_solve<16> (one wave
@@ -3994,7 +3995,7 @@ struct fseg_ctx {
     // alone on the GPU is quicker solved whole (0.82 / 0.76 against 0.85 / 0.82 ms per replayed batch), eight contexts taking
     // turns are not (config3: 249 against 301 M reads/s; config5: equal) -- the few wide problems are long, thin launches -- so
     // the default keeps such batches on the arena path.
-    int fuse_lanes = kFuseLanes;
+    int fuse_lanes = kFuseLanesDefault;
     bool wide_solve = true;     // some problem of the batch sees more than kFuseLanes reads: the 16-bit-counter instances of k_solve run too
     bool fuse_on = true;        // this batch's problems go to k_solve: decided per batch -- when its widest problem sees at most
                                 // kFuseLanes reads, i.e. all of them qualify (measured: a batch of 500-read partitions gains 8 %, while
@@ -4368,11 +4369,13 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
                                c->d_ex_te.as<int>(), c->d_h_table.as<double>(), c->P.h_len, c->P.threshold_rate,               \
                                c->d_thr_tab.as<int2>(), c->P.min_read_support_outside, c->d_chosen.as<unsigned char>() FSEG_TARG)
         // 32-bit DP keys (dp_solve_push) when no sum of a chain can reach 2^24: at most 32 links times the reads of the largest partition
-#define FSEG_LAUNCH_SOLVE_W(Q, NMV, CLS, N_ITEMS, MAXWG)                                                                     \
-            do { if (key32) { FSEG_LAUNCH_SOLVE(Q, NMV, unsigned char, int, CLS, N_ITEMS, MAXWG);              \
-                                               if (FSEG_WIDE_NEEDED(CLS)) FSEG_LAUNCH_SOLVE(Q, NMV, unsigned short, int, CLS, N_ITEMS, MAXWG); } \
-                 else { FSEG_LAUNCH_SOLVE(Q, NMV, unsigned char, i64, CLS, N_ITEMS, MAXWG);                                     \
-                        if (FSEG_WIDE_NEEDED(CLS)) FSEG_LAUNCH_SOLVE(Q, NMV, unsigned short, i64, CLS, N_ITEMS, MAXWG); } } while (0)
+        // (WHICH: 1 = the instance with 8-bit counters, 2 = the one with 16-bit counters if the class has problems for it, 3 = both)
+#define FSEG_LAUNCH_SOLVE_X(Q, NMV, CLS, N_ITEMS, MAXWG, WHICH)                                                              \
+            do { if (key32) { if ((WHICH) & 1) FSEG_LAUNCH_SOLVE(Q, NMV, unsigned char, int, CLS, N_ITEMS, MAXWG);              \
+                              if (((WHICH) & 2) && FSEG_WIDE_NEEDED(CLS)) FSEG_LAUNCH_SOLVE(Q, NMV, unsigned short, int, CLS, N_ITEMS, MAXWG); } \
+                 else { if ((WHICH) & 1) FSEG_LAUNCH_SOLVE(Q, NMV, unsigned char, i64, CLS, N_ITEMS, MAXWG);                    \
+                        if (((WHICH) & 2) && FSEG_WIDE_NEEDED(CLS)) FSEG_LAUNCH_SOLVE(Q, NMV, unsigned short, i64, CLS, N_ITEMS, MAXWG); } } while (0)
+#define FSEG_LAUNCH_SOLVE_W(Q, NMV, CLS, N_ITEMS, MAXWG) FSEG_LAUNCH_SOLVE_X(Q, NMV, CLS, N_ITEMS, MAXWG, 3)
 #define FSEG_WIDE_NEEDED(CLS) (!known || (c->wide_solve && ((CLS) < 0 || c->n_wide[(CLS)] > 0)))
         // Two ways a problem is scored (prob_kind): the arena path's work items (k_score per size class) and the problems that
         // see few reads (at most 255: 8-bit counters), whole, one workgroup each (k_solve per size class).
@@ -4406,26 +4409,39 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
             hipStream_t q1 = sfork ? fork(0) : s, q0 = sfork ? fork(1) : s;
             if (plan) {
                 int n_seg = 1;
-                for (const char *p = plan; *p; ++p) n_seg += *p == '|';
+                bool used[4] = {true, false, false, false};              // a stream whose kernels have nothing to do is left alone
+                for (const char *p = plan; *p; ++p) {
+                    if (*p == '|') { ++n_seg; continue; }
+                    if (n_seg > 4) continue;
+                    static const char wide_kinds[] = "bms";
+                    const char *at = strchr(wide_kinds, *p);
+                    if (!at || (c->wide_solve && c->n_wide[2 - (int)(at - wide_kinds)] > 0)) used[n_seg - 1] = true;
+                }
                 if (n_seg > 4) n_seg = 4;
-                for (int k = 1; k < n_seg; ++k) (void)fork(k - 1);          // every side stream continues from HERE
+                for (int k = 1; k < n_seg; ++k) if (used[k]) (void)fork(k - 1);          // every side stream continues from HERE
                 int seg = 0;
                 hipEvent_t ev_big = nullptr;
+                // b m s: the class's instance with 16-bit counters on its own (B M S then launch the 8-bit one only)
+                const int wb = strchr(plan, 'b') ? 1 : 3, wm = strchr(plan, 'm') ? 1 : 3, ws = strchr(plan, 's') ? 1 : 3;
                 for (const char *p = plan; *p && seg < n_seg; ++p) {
                     if (*p == '|') { ++seg; continue; }
+                    if (!used[seg]) continue;
                     hipStream_t q = seg == 0 ? s : c->side[seg - 1];
                     switch (*p) {
-                    case 'B': FSEG_LAUNCH_SOLVE_W(q, kNMax, 2, c->n_solve[2], 512);
+                    case 'B': FSEG_LAUNCH_SOLVE_X(q, kNMax, 2, c->n_solve[2], 512, wb);
                               ev_big = fj_event(); if (hipEventRecord(ev_big, q) != hipSuccess) fj_err = hipErrorUnknown; break;
-                    case 'M': if (c->n_solve[1] > 0) FSEG_LAUNCH_SOLVE_W(q, kClsMid, 1, c->n_solve[1], FSEG_WG_MID); break;
-                    case 'S': if (c->n_solve[0] > 0) FSEG_LAUNCH_SOLVE_W(q, kClsSmall, 0, c->n_solve[0], FSEG_WG_SMALL); break;
+                    case 'M': if (c->n_solve[1] > 0) FSEG_LAUNCH_SOLVE_X(q, kClsMid, 1, c->n_solve[1], FSEG_WG_MID, wm); break;
+                    case 'S': if (c->n_solve[0] > 0) FSEG_LAUNCH_SOLVE_X(q, kClsSmall, 0, c->n_solve[0], FSEG_WG_SMALL, ws); break;
+                    case 'b': FSEG_LAUNCH_SOLVE_X(q, kNMax, 2, c->n_solve[2], 512, 2); break;
+                    case 'm': if (c->n_solve[1] > 0) FSEG_LAUNCH_SOLVE_X(q, kClsMid, 1, c->n_solve[1], FSEG_WG_MID, 2); break;
+                    case 's': if (c->n_solve[0] > 0) FSEG_LAUNCH_SOLVE_X(q, kClsSmall, 0, c->n_solve[0], FSEG_WG_SMALL, 2); break;
                     case 'T': if (c->n_tiny > 0) FSEG_LAUNCH_WAVE(q, kTiny, 3, c->n_tiny); break;
                     case 'g': hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, q, st, (unsigned)(c->n_solve[2] < 512 ? c->n_solve[2] : 512), 3000u); break;
                     case 'e': if (ev_big && hipStreamWaitEvent(q, ev_big, 0) != hipSuccess) fj_err = hipErrorUnknown; break;
                     default: break;
                     }
                 }
-                for (int k = 1; k < n_seg; ++k) join(k - 1);
+                for (int k = 1; k < n_seg; ++k) if (used[k]) join(k - 1);
             } else {
             if (any_arena && (!known || c->n_cls_work[2] > 0)) FSEG_LAUNCH_SCORE(s, kNMax, 2, 512);     // big problems: they are the long poles
             if (any_solve && (!known || c->n_solve[2] > 0)) FSEG_LAUNCH_SOLVE_W(s, kNMax, 2, known ? c->n_solve[2] : cap, 512);
@@ -4437,6 +4453,7 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
             }
         }
 #undef FSEG_LAUNCH_SOLVE_W
+#undef FSEG_LAUNCH_SOLVE_X
 #undef FSEG_LAUNCH_SOLVE
 #undef FSEG_LAUNCH_SCORE
         if (tiny_max > 0 && !plan) {

@@ -53,7 +53,10 @@ SWITCHES = [
     {"FSEG_NO_TINY": "1"},                                  # ... and the tiny ones through k_solve
     {"FSEG_NO_WAVE": "1"},                                  # k_tiny instead of k_wave<8> (batches with a rep of > 510 exons take this)
     {"FSEG_SCORE_FORK": "1"},                               # the fused scoring kernels on a stream each
+    {"FSEG_FUSE_LANES": "255"},                             # batches with a problem that sees more than 255 reads: the arena path
+    {"FSEG_FUSE_LANES": "1023"},
     {"FSEG_SCORE_PLAN": "0"},                               # ... all on the main stream (no k_gate)
+    {"FSEG_SCORE_PLAN": "BMbms|gTS"},                       # ... the 16-bit-counter instances behind the others
     {"FSEG_SCORE_PLAN": "B|gM|gS|gT"},                      # ... or each class behind the gate on its own stream
     {"FSEG_FORCE_KEY64": "1"},                              # 64-bit DP keys (batches with a partition of 2^18 reads or more)
     {"FSEG_FORCE_KEY64": "1", "FSEG_NO_WAVE": "1", "FSEG_SCORE_PLAN": "0"},
