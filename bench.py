@@ -338,8 +338,8 @@ def one_shot_steps(ctxs, batches, order, collect=None):
 
 def scoring_roofline(alg_bytes, score_ms, committed, extra=None):
     achieved = alg_bytes / (score_ms * 1e-3) / 1e9 if score_ms > 0 else 0.0
-    r = {"kernel": "interval-scoring stage: k_solve<16|32|60> + k_wave<8> (k_tiny) where every problem of the batch sees <= 255 reads "
-                   "(they solve a problem whole: coverage, pair labels, in/out counts AND its DP), else k_score<16|32|60> + k_wave<8>",
+    r = {"kernel": "interval-scoring stage: k_solve<16|32|60> + k_wave<8> (k_tiny) (+ k_gate, one wave) where every problem of the batch sees "
+                   "<= 511 reads (they solve a problem whole: coverage, pair labels, in/out counts AND its DP), else k_score<16|32|60> + k_wave<8>",
          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
          "traffic": (committed or {}).get("traffic_bytes"), "traffic_source": "committed PMC pass (profiles/traffic.json)" if committed else None,
