@@ -299,6 +299,7 @@ struct __align__(16) TileDesc {
 };
 constexpr int kSmoothStage = (kSmoothTile + 2 * kMaxRadius + kSmoothThreads - 1) / kSmoothThreads;   // staged counts per thread, any radius
 
+typedef int int4u __attribute__((ext_vector_type(4), aligned(4)));      // (16 bytes from a dword-aligned address)
 template <int R>
 __global__ void __launch_bounds__(kSmoothThreads) k_smooth(int n_tiles, const TileDesc *tiles,
                                                 const int *y_raw, const double *__restrict__ w_g, int radius_rt,
@@ -309,9 +310,11 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth(int n_tiles, const Ti
     __shared__ int defer_s;
     __shared__ int scan_lds[16];
     __shared__ double ws[kMaxRadius + 1];
-    // results go through LDS so that consecutive lanes store consecutive positions (a thread computes 4 in a row)
+    // the tile's smoothed values: what the candidate test reads of its neighbours (the results themselves leave from
+    // registers: a thread's four consecutive positions are 32 / 16 / 4 contiguous bytes of the output arrays, a wave's 256
+    // positions one contiguous run per store instruction -- as five arrays of single elements per lane the kernel took
+    // 183 us per 250 k-read batch with or without its arithmetic)
     __shared__ double ys[kSmoothTile];
-    __shared__ int cs[kSmoothTile];
     const int radius = R > 0 ? R : radius_rt;
     const int span = kSmoothTile + 2 * radius;
     constexpr int kStage = R > 0 ? (kSmoothTile + 2 * R + kSmoothThreads - 1) / kSmoothThreads : kSmoothStage;
@@ -343,13 +346,14 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth(int n_tiles, const Ti
         if (t + 2 * G < n_tiles) d_n2 = tiles[t + 2 * G];
         if (t + G < n_tiles) load_counts(d_next, v_cur);             // in flight during this tile's work
         lds_barrier();
+        int c4[4];
         {   // inclusive prefix sums of the histogram inside the tile + the tile total: lets k_segments evaluate
             // refine_segmentation's `sum(i_vals) < 20` test (:258) exactly in O(1) per segment
-            int o4 = threadIdx.x * 4, v4[4], run = 0;
-            for (int e = 0; e < 4; ++e) { run += (y0 + o4 + e < len) ? xs[radius + o4 + e] : 0; v4[e] = run; }
+            int o4 = threadIdx.x * 4, run = 0;
+            for (int e = 0; e < 4; ++e) { run += (y0 + o4 + e < len) ? xs[radius + o4 + e] : 0; c4[e] = run; }
             int tot;
             int ex = wg_exclusive_scan_lds(run, scan_lds, &tot);
-            for (int e = 0; e < 4; ++e) cs[o4 + e] = ex + v4[e];
+            for (int e = 0; e < 4; ++e) c4[e] += ex;
             if (threadIdx.x == 0) tile_tot[t] = tot;
         }
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;    // this thread's four outputs (kept for the candidate test below)
@@ -421,14 +425,34 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth(int n_tiles, const Ti
         if (mid1 >= 0) cf[mid1] = 1;
         lds_barrier();
         if (threadIdx.x == 0) tile_defer[t] = defer_s;
-        for (int i = threadIdx.x; i < kSmoothTile; i += blockDim.x) {
-            if (y0 + i < len) {
-                const double a = ys[i];
-                y_out[base + y0 + i] = a;
-                flag_pos[base + y0 + i] = a > 0.0 ? 1 : 0;
-                flag_cand[base + y0 + i] = cf[i];
-                final_flag[base + y0 + i] = 0;                       // final-position flags start cleared (k_segments / k_refine set them)
-                cum[base + y0 + i] = cs[i];
+        {
+            const int o4 = threadIdx.x * 4;
+            const i64 p = base + y0 + o4;
+            const unsigned cw = reinterpret_cast<const unsigned *>(cf)[threadIdx.x];
+            if (y0 + o4 + 3 < len) {                                 // the thread's four positions lie inside the interval
+                typedef double double2u __attribute__((ext_vector_type(2), aligned(8)));
+                typedef unsigned uint1u __attribute__((ext_vector_type(1), aligned(1)));
+                double2u lo2, hi2; lo2.x = a0; lo2.y = a1; hi2.x = a2; hi2.y = a3;
+                *reinterpret_cast<double2u *>(y_out + p) = lo2;
+                *reinterpret_cast<double2u *>(y_out + p + 2) = hi2;
+                int4u cv; cv.x = c4[0]; cv.y = c4[1]; cv.z = c4[2]; cv.w = c4[3];
+                *reinterpret_cast<int4u *>(cum + p) = cv;
+                uint1u pw; pw.x = (a0 > 0.0 ? 1u : 0u) | (a1 > 0.0 ? 1u << 8 : 0u) | (a2 > 0.0 ? 1u << 16 : 0u) | (a3 > 0.0 ? 1u << 24 : 0u);
+                uint1u cw1; cw1.x = cw;
+                uint1u zero; zero.x = 0;
+                *reinterpret_cast<uint1u *>(flag_pos + p) = pw;
+                *reinterpret_cast<uint1u *>(flag_cand + p) = cw1;
+                *reinterpret_cast<uint1u *>(final_flag + p) = zero;      // final-position flags start cleared (k_segments / k_refine set them)
+            } else {
+                const double av[4] = {a0, a1, a2, a3};
+                for (int e = 0; e < 4; ++e)
+                    if (y0 + o4 + e < len) {
+                        y_out[p + e] = av[e];
+                        flag_pos[p + e] = av[e] > 0.0 ? 1 : 0;
+                        flag_cand[p + e] = (unsigned char)(cw >> (8 * e));
+                        final_flag[p + e] = 0;
+                        cum[p + e] = c4[e];
+                    }
             }
         }
         d_cur = d_next; d_next = d_n2;
