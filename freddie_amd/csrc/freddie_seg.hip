@@ -301,8 +301,8 @@ constexpr int kSmoothStage = (kSmoothTile + 2 * kMaxRadius + kSmoothThreads - 1)
 
 typedef int int4u __attribute__((ext_vector_type(4), aligned(4)));      // (16 bytes from a dword-aligned address)
 template <int R>
-__global__ void __launch_bounds__(kSmoothThreads) k_smooth(int n_tiles, const TileDesc *tiles,
-                                                const int *y_raw, const double *__restrict__ w_g, int radius_rt,
+__global__ void __launch_bounds__(kSmoothThreads) k_smooth(int n_tiles, const TileDesc *__restrict__ tiles,
+                                                const int *__restrict__ y_raw, const double *__restrict__ w_g, int radius_rt,
                                                 double *y_out, unsigned char *flag_pos, unsigned char *flag_cand, int *cum, int *tile_tot,
                                                 unsigned char *final_flag, int *tile_defer) {
     __shared__ int xs[kSmoothTile + 2 * kMaxRadius];
@@ -324,12 +324,16 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth(int n_tiles, const Ti
     // the record one tile further ahead), so its latency hides behind the taps and the stores.
     const int G = gridDim.x;
     auto load_counts = [&](const TileDesc &d, int *v) {
+        // 'reflect': (d c b a | a b c d | d c b a).  One reflection does unless the interval is shorter than the radius;
+        // only then the general index (a 64-bit modulo) is evaluated.
+        const int len_d = d.len, yb = d.y0 - radius + (int)threadIdx.x;
 #pragma unroll
         for (int e = 0; e < kStage; ++e) {
             const int idx = e * kSmoothThreads + threadIdx.x;
-            i64 y = (i64)d.y0 - radius + idx;
-            if (y < 0 || y >= d.len) y = reflect_index(y, d.len);      // only the few halo elements beyond the interval pay the modulo
-            v[e] = idx < span ? y_raw[d.base + y] : 0;
+            const int y = yb + e * kSmoothThreads;
+            int r = y < 0 ? -1 - y : (y >= len_d ? 2 * len_d - 1 - y : y);
+            if ((unsigned)r >= (unsigned)len_d) r = (int)reflect_index((i64)y, (i64)len_d);
+            v[e] = idx < span ? y_raw[d.base + r] : 0;
         }
     };
     int t = blockIdx.x;
@@ -338,7 +342,8 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth(int n_tiles, const Ti
     if (t < n_tiles) { d_cur = tiles[t]; load_counts(d_cur, v_cur); }
     if (t + G < n_tiles) d_next = tiles[t + G];
     for (; t < n_tiles; t += G) {
-        const i64 y0 = d_cur.y0, base = d_cur.base, len = d_cur.len;
+        const int y0 = d_cur.y0, len = d_cur.len;                    // (positions inside one interval: 32 bits)
+        const i64 base = d_cur.base;
         lds_barrier();
 #pragma unroll
         for (int e = 0; e < kStage; ++e) { const int idx = e * kSmoothThreads + threadIdx.x; if (idx < span) xs[idx] = v_cur[e]; }
@@ -402,7 +407,7 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth(int n_tiles, const Ti
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int i = o4 + e;
-                const i64 pos = y0 + i;
+                const int pos = y0 + i;
                 if (pos >= len) break;
                 if (pos == 0 || pos == len - 1) { word |= 1u << (8 * e); continue; }
                 if (i == 0 || i == kSmoothTile - 1) continue;            // k_peaks_edges
