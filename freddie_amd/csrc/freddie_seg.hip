@@ -1272,9 +1272,11 @@ __device__ __forceinline__ void wg_scan_cols(const ProbSizes &v, ProbSizes &ex, 
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     for (int q = 0; q < kProbCols; ++q) {
         i64 x = v.v[q];
-        for (int d = 1; d < 64; d <<= 1) {
-            i64 y = __shfl_up(x, d);
-            if (lane >= d) x += y;
+        if (__ballot(x != 0)) {                          // (a batch fills the arena path's columns or the solve lists', rarely both:
+            for (int d = 1; d < 64; d <<= 1) {           //  the wave skips the columns in which it holds nothing)
+                i64 y = __shfl_up(x, d);
+                if (lane >= d) x += y;
+            }
         }
         ex.v[q] = x - v.v[q];
         if (lane == 63) lds[wave * kProbCols + q] = x;
