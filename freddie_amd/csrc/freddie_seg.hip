@@ -2076,7 +2076,8 @@ __global__ void __launch_bounds__(ScoreCfg<NM>::kThreads) k_score(Status *st, in
                 int tbase = kk * (kk - 1) * (kk - 2) / 6 + j * (j - 1) / 2;
                 int abase = j * (j - 1) / 2;
                 const int i_end = iend_s[j];                          // i with cand_j - cand_i >= 5 (:540), a prefix
-#define FSEG_TRI_CNT(A) (__popc((A).x & B.z) + __popc((A).y & B.w) + __popc((A).z & B.x) + __popc((A).w & B.y))
+        // (a read is never yea AND nay of one pair -- lo < hi --, so the two cross terms of a plane word are disjoint: one popcount of their union)
+#define FSEG_TRI_CNT(A) (__popc(((A).x & B.z) | ((A).z & B.x)) + __popc(((A).y & B.w) | ((A).w & B.y)))
                 unsigned short *o16 = out16 + tbase;
                 int i = 0;
                 if ((tbase & 1) && i_end > 0) {                       // align to a counter pair
@@ -2656,7 +2657,7 @@ __global__ void __launch_bounds__(256, WaveCfg<NM>::kOcc) k_wave(Status *st, con
                 if (tt < ntri) {
                     const unsigned tq = tri_q[tt];
                     const uint4 a = L.planes[tq & 255], b = L.planes[tq >> 8];
-                    outc[s] += (unsigned)(__popc(a.x & b.z) + __popc(a.y & b.w) + __popc(a.z & b.x) + __popc(a.w & b.y));
+                    outc[s] += (unsigned)(__popc((a.x & b.z) | (a.z & b.x)) + __popc((a.y & b.w) | (a.w & b.y)));    // (disjoint: lo < hi)
                 }
             }
             dp_sync<64>();
@@ -2832,19 +2833,20 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
             const int l = l0 + (int)threadIdx.x;
             const bool in = l < d.lane_n;
             const longlong2 ex = lane_ex[d.lane_lo + (in ? l : 0)];
-            i64 first = ex.x;
-            int cnt = 0;
-            for (i64 eb = ex.x; eb < ex.y; eb += 8) {               // eight exons per round from clamped addresses, in flight together
+            const int n_ex = (int)(ex.y - ex.x);                     // (a read's exons: 32-bit counts from here on)
+            int first_rel = 0, cnt = 0;
+            for (int eb = 0; eb < n_ex; eb += 8) {                   // eight exons per round from clamped addresses, in flight together
                 int ts8[8], te8[8];
-                load_exons8(ex_ts + eb, ts8); load_exons8(ex_te + eb, te8);
+                load_exons8(ex_ts + ex.x + eb, ts8); load_exons8(ex_te + ex.x + eb, te8);
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const bool hit = eb + u < ex.y && te8[u] >= cp0 && ts8[u] < c_last;
-                    if (hit && cnt == 0) first = eb + u;
+                    const bool hit = eb + u < n_ex && te8[u] >= cp0 && ts8[u] < c_last;
+                    if (hit && cnt == 0) first_rel = eb + u;
                     cnt += hit;
                 }
-                if (eb + 7 < ex.y && ts8[7] >= c_last) break;        // the rest of the read lies beyond the window
+                if (eb + 7 < n_ex && ts8[7] >= c_last) break;        // the rest of the read lies beyond the window
             }
+            const i64 first = ex.x + first_rel;
             const bool act = in && cnt > 0;
             const u64 m = __ballot(act);
             if ((threadIdx.x & 63) == 0) act_wave[threadIdx.x >> 6] = __popcll(m);
@@ -2935,7 +2937,9 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
                 const int tbase = kk * (kk - 1) * (kk - 2) / 6 + j * (j - 1) / 2;
                 const int abase = j * (j - 1) / 2;
                 const int i_end = iend_s[j];                          // i with cand_j - cand_i >= 5 (:540), a prefix
-#define FSEG_TRI_CNT(Av) (__popc((Av).x & B.z) + __popc((Av).y & B.w) + __popc((Av).z & B.x) + __popc((Av).w & B.y))
+                // (a read is never yea AND nay of one pair -- lo < hi --, so the two cross terms of a plane word are disjoint: one
+                // popcount of their union, six instructions per triple and round instead of eight)
+#define FSEG_TRI_CNT(Av) (__popc(((Av).x & B.z) | ((Av).z & B.x)) + __popc(((Av).y & B.w) | ((Av).w & B.y)))
                 CntT *o = cnt + tbase;
                 int i = 0;
                 for (; i < i_end && ((tbase + i) & (PACK - 1)); ++i) {          // up to a 32-bit boundary of the table
@@ -3052,7 +3056,7 @@ __global__ void __launch_bounds__(512) k_score_huge(Status *st, const int *dp_it
                 const int abase = j * (j - 1) / 2, i_end = iend_s[j];
                 for (int i = 0; i < i_end; ++i) {
                     const uint2 A = planes[abase + i];
-                    const unsigned cnt = __popc(A.x & B.y) + __popc(A.y & B.x);
+                    const unsigned cnt = __popc((A.x & B.y) | (A.y & B.x));          // (disjoint: a read is never yea and nay of one pair)
                     if (cnt) o[i] += cnt;
                 }
             }
