@@ -1851,21 +1851,23 @@ __device__ __forceinline__ int dp_solve_push(int n, const OutT *out_s, const int
         FSEG_DTICK(11);
         // the chain is walked by one lane (dependent LDS loads only: the chosen candidates are collected in a mask) and
         // stored by the wave, one candidate per lane
+        // (every lane holds the same key after the reduction: the walk is the whole wave's, on scalar registers -- a link is one
+        // LDS byte and a few scalar instructions; walked by lane 0 alone under an execution mask it was 113 ns per link)
         u64 mask = 0;
-        if (lane == 0 && end >= 2 && kv > kMin && (kv >> 6) > (V)in_s[end * (end - 1) / 2]) {
-            const int bj = 63 - (int)(kv & 63);
-            int j = bj, k = A[bj * (bj - 1) / 2];
+        const bool cut = end >= 2 && kv > kMin && (kv >> 6) > (V)in_s[end * (end - 1) / 2];
+        if (uni(cut ? 1 : 0)) {
+            const int bj = uni(63 - (int)(kv & 63));
+            int j = bj, k = uni((int)A[bj * (bj - 1) / 2]);
             mask = 1ULL;
             for (;;) {
                 mask |= (1ULL << j) | (1ULL << k); ++chain;
                 if (k == end) break;
-                const int k2 = A[(int)__umul24(k, k - 1) / 2 + j];
+                const int k2 = uni((int)A[k * (k - 1) / 2 + j]);
                 if (k2 == 255) break;
                 j = k; k = k2;
             }
         }
-        const unsigned m_lo = (unsigned)uni((int)(unsigned)mask), m_hi = (unsigned)uni((int)(unsigned)(mask >> 32));
-        if (((((u64)m_hi << 32) | m_lo) >> lane) & 1ULL) chosen[lane] = 1;
+        if ((mask >> lane) & 1ULL) chosen[lane] = 1;
     }
     FSEG_DTICK(12);
     return chain;
@@ -2877,13 +2879,22 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
 #pragma unroll
                 for (int u = 0; u < kCovJ; ++u) acc[u] = 0;
                 const int e_end = valid ? a.y : 0;
-                for (int e = 0; e < e_end; e += 2) {
-                    const int2 ts2 = load_exons2(ex_ts + a.x + e), te2 = load_exons2(ex_te + a.x + e);      // (the second may be the next read's: masked below)
-                    const int tsa = ts2.x, tea = te2.x, tsb = ts2.y, teb = te2.y;
-                    const int a0 = max(tsa, cp0), b0 = tea + 1;                     // closed exon -> half-open end
-                    const int a1 = max(tsb, cp0), b1 = e + 1 < e_end ? teb + 1 : a1;  // (an odd count: the second slot is empty)
+                for (int e = 0; e < e_end; e += 4) {
+                    // four exons per round trip (what lies beyond the read's own exons is masked below; the arrays are padded);
+                    // the second pair is worked on only if some read of the wave has it
+                    const int4u ts4 = *reinterpret_cast<const int4u *>(ex_ts + a.x + e), te4 = *reinterpret_cast<const int4u *>(ex_te + a.x + e);
+                    {
+                        const int a0 = max(ts4.x, cp0), b0 = te4.x + 1;                     // closed exon -> half-open end
+                        const int a1 = max(ts4.y, cp0), b1 = e + 1 < e_end ? te4.y + 1 : a1;  // (an odd count: the second slot is empty)
 #pragma unroll
-                    for (int v = 0; v < kCovJ; ++v) acc[v] += max(0, min(b0, cjv[v]) - a0) + max(0, min(b1, cjv[v]) - a1);
+                        for (int v = 0; v < kCovJ; ++v) acc[v] += max(0, min(b0, cjv[v]) - a0) + max(0, min(b1, cjv[v]) - a1);
+                    }
+                    if (e + 2 < e_end) {
+                        const int a0 = max(ts4.z, cp0), b0 = te4.z + 1;
+                        const int a1 = max(ts4.w, cp0), b1 = e + 3 < e_end ? te4.w + 1 : a1;
+#pragma unroll
+                        for (int v = 0; v < kCovJ; ++v) acc[v] += max(0, min(b0, cjv[v]) - a0) + max(0, min(b1, cjv[v]) - a1);
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < kCovJ; ++u) if (ja + u < jb) cov[r_lane * rt_stride + ja + u] = (unsigned)acc[u];
