@@ -259,7 +259,7 @@ __global__ void __launch_bounds__(512) k_hist(int n_chunks, const int *chunk_par
 // tile plus its halo is staged in LDS as int32 (the histogram holds exact small integers).
 // Also writes the flag Y > 0 used by the threshold stage.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int wg_exclusive_scan(int v, int *lds, int *total);
+template <int NW = 0> __device__ __forceinline__ int wg_exclusive_scan(int v, int *lds, int *total);
 
 // Workgroup barrier that orders LDS traffic only: global loads and stores issued before it (prefetches of the next
 // tile, result stores) stay in flight, which a full __syncthreads() would wait for.
@@ -268,9 +268,12 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
-// wg_exclusive_scan() with LDS-only barriers
+// wg_exclusive_scan() with LDS-only barriers.  NW: the workgroup's waves when the caller knows them (with the count read from
+// blockDim the loop over the waves' totals is a general loop, unrolled sixteen-fold with masks: dozens of instructions for two values)
+template <int NW = 0>
 __device__ __forceinline__ int wg_exclusive_scan_lds(int v, int *lds /* >= 16 ints */, int *total) {
-    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nw = NW > 0 ? NW : (int)((blockDim.x + 63) >> 6);
     int x = v;
     for (int d = 1; d < 64; d <<= 1) {
         int y = __shfl_up(x, d);
@@ -301,7 +304,10 @@ constexpr int kSmoothStage = (kSmoothTile + 2 * kMaxRadius + kSmoothThreads - 1)
 
 typedef int int4u __attribute__((ext_vector_type(4), aligned(4)));      // (16 bytes from a dword-aligned address)
 template <int R>
-__global__ void __launch_bounds__(kSmoothThreads) k_smooth(int n_tiles, const TileDesc *__restrict__ tiles,
+#ifndef FSEG_SMOOTH_OCC
+#define FSEG_SMOOTH_OCC 6
+#endif
+__global__ void __launch_bounds__(kSmoothThreads, FSEG_SMOOTH_OCC) k_smooth(int n_tiles, const TileDesc *__restrict__ tiles,
                                                 const int *__restrict__ y_raw, const double *__restrict__ w_g, int radius_rt,
                                                 double *y_out, unsigned char *flag_pos, unsigned char *flag_cand, int *cum, int *tile_tot,
                                                 unsigned char *final_flag, int *tile_defer) {
@@ -357,7 +363,7 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth(int n_tiles, const Ti
             int o4 = threadIdx.x * 4, run = 0;
             for (int e = 0; e < 4; ++e) { run += (y0 + o4 + e < len) ? xs[radius + o4 + e] : 0; c4[e] = run; }
             int tot;
-            int ex = wg_exclusive_scan_lds(run, scan_lds, &tot);
+            int ex = wg_exclusive_scan_lds<kSmoothThreads / 64>(run, scan_lds, &tot);
             for (int e = 0; e < 4; ++e) c4[e] += ex;
             if (threadIdx.x == 0) tile_tot[t] = tot;
         }
@@ -467,8 +473,10 @@ __global__ void __launch_bounds__(kSmoothThreads) k_smooth(int n_tiles, const Ti
 // ---------------------------------------------------------------------------------------------
 // exclusive prefix sum of byte flags (three small kernels; used for the three compactions)
 // ---------------------------------------------------------------------------------------------
+template <int NW>
 __device__ __forceinline__ int wg_exclusive_scan(int v, int *lds /* >= 16 ints */, int *total) {
-    int lane = lane_id(), wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int nw = NW > 0 ? NW : (int)((blockDim.x + 63) >> 6);
     int x = v;
     for (int d = 1; d < 64; d <<= 1) {
         int y = __shfl_up(x, d);
@@ -519,7 +527,7 @@ __global__ void __launch_bounds__(256) k_scan1(const unsigned char *flags, i64 n
         i64 i0 = b * kScanBlock + (i64)threadIdx.x * 32;
         int s = i0 < n ? count_flags32(load_flags32(flags, i0, n)) : 0;
         int tot;
-        wg_exclusive_scan(s, lds, &tot);
+        wg_exclusive_scan<4>(s, lds, &tot);
         if (threadIdx.x == 0) bsum[b] = tot;
         __syncthreads();
     }
@@ -541,7 +549,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(int *bsum, i64 nb, u64 
 #pragma unroll
         for (int e = 0; e < kScan2Per; ++e) { const int x = v[e]; v[e] = run; run += x; }      // exclusive inside the thread
         int tot;
-        const int ex = wg_exclusive_scan(run, lds, &tot);
+        const int ex = wg_exclusive_scan<kScan2Threads / 64>(run, lds, &tot);
         const int carry = carry_s;
 #pragma unroll
         for (int e = 0; e < kScan2Per; ++e) if (base + e < nb) bsum[base + e] = carry + ex + v[e];
@@ -643,7 +651,7 @@ __global__ void __launch_bounds__(256) k_scan_emit(const unsigned char *flags, i
             int s = 0;
             if (i0 < n) { f = load_flags32(flags, i0, n); s = count_flags32(f); }
             int tot;
-            int ex = wg_exclusive_scan(s, lds, &tot);                // (its barriers also publish the staged table)
+            int ex = wg_exclusive_scan<4>(s, lds, &tot);             // (its barriers also publish the staged table)
             ex += bsum ? bsum[b] : (int)scan_lookback(state, b, nb, tot, &bcast, total_out, off_last, err);
             if (s) {
                 i64 k = -1, k_end = 0, k_base = 0;
