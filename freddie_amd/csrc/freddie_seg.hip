@@ -2798,8 +2798,12 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
         __syncthreads();                                             // the previous problem's DP is done with LDS
         FSEG_STICK(0);
         if (n > nm || n > NM) { if (threadIdx.x == 0) atomicOr(&st->err, kErrOverflowNm); continue; }
-        // a list's problems are shared by two launches: the 8-bit counters take those that see at most 255 reads, the 16-bit ones the rest
-        if ((sizeof(CntT) == 1) != (d.lane_n <= kFuseLanes)) continue;
+        // a list's problems are shared by two launches: the 8-bit counters take those that KEEP at most 255 reads (a counter
+        // counts reads with coverage in the window: about two thirds of those the problem sees), the 16-bit ones the rest.
+        // A problem that sees at most 255 is the 8-bit instance's outright; one that sees more is located by both, and
+        // whoever's counters fit its kept reads goes on with it (below).
+        const bool wide_cand = d.lane_n > kFuseLanes;
+        if (!wide_cand && sizeof(CntT) != 1) continue;
         if (d.lane_n > kFuseLanesWide) { if (threadIdx.x == 0) atomicOr(&st->err, kErrNeedWideDp); continue; }
         const int npairs = n * (n - 1) / 2, ntri = n * (n - 1) * (n - 2) / 6;
         const int *cy = cand_y + d.c0;
@@ -2863,10 +2867,15 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
             __syncthreads();
             int base = n_act, tot = 0;
             for (int w2 = 0; w2 < T / 64; ++w2) { const int v = act_wave[w2]; if (w2 < (int)(threadIdx.x >> 6)) base += v; tot += v; }
-            if (act) act_s[base + __popcll(m & ((1ULL << (threadIdx.x & 63)) - 1ULL))] = make_int2((int)first, cnt);
+            {
+                constexpr int kActCap = sizeof(CntT) == 1 ? kFuseLanes + 1 : kFuseLanesWide + 1;
+                const int slot = base + __popcll(m & ((1ULL << (threadIdx.x & 63)) - 1ULL));
+                if (act && slot < kActCap) act_s[slot] = make_int2((int)first, cnt);      // (beyond it: the other instance's problem)
+            }
             n_act += tot;
             __syncthreads();
         }
+        if (wide_cand && (sizeof(CntT) == 1) != (n_act <= kFuseLanes)) continue;          // (workgroup-uniform)
         FSEG_STICK(1);
         // this thread's share of a round's coverage: read r_lane, candidates [ja, jb) of 1 .. n-1 (at most kCovJ of them)
         constexpr int kCovJ = (NM - 1 + NR - 1) / NR;
