@@ -4957,7 +4957,9 @@ int fseg_create(int device, fseg_ctx **out) {
         int seen[4] = {0, 0, 0, 0};
         static const char kinds[] = "BMST";
         for (const char *q = c->score_plan; *q; ++q) { const char *at = strchr(kinds, *q); if (at) ++seen[at - kinds]; }
-        if (seen[0] != 1 || seen[1] != 1 || seen[2] != 1 || seen[3] != 1) c->score_plan[0] = 0;
+        int bars = 0;
+        for (const char *q = c->score_plan; *q; ++q) bars += *q == '|';
+        if (seen[0] != 1 || seen[1] != 1 || seen[2] != 1 || seen[3] != 1 || bars > fseg_ctx::kSide) c->score_plan[0] = 0;   // (a stream per segment)
     }
     { const char *v = getenv("FSEG_WAVE_SMALL"); if (v && v[0]) c->wave_small = v[0] == '1'; }
     { const char *v = getenv("FSEG_FUSE_LANES"); if (v && v[0] && atoi(v) > 0 && atoi(v) <= kFuseLanesWide) c->fuse_lanes = atoi(v); }
