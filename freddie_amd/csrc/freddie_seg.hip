@@ -2751,7 +2751,7 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
                                                                   const ProbDesc *desc, i64 prob_cap, const int *cand_y,
                                                                   const longlong2 *lane_ex, const int *ex_ts, const int *ex_te,
                                                                   const double *h_table, int h_len, double tau, const int2 *thr_tab,
-                                                                  int support, unsigned char *chosen FSEG_TPARAM) {
+                                                                  int support, unsigned char *chosen, int wide_by_seen FSEG_TPARAM) {
     using C = SolveCfg<NM>;
     constexpr int T = C::kThreads, NR = C::kRanges;
     constexpr int PACK = 4 / (int)sizeof(CntT);                    // counters per 32-bit read-modify-write
@@ -2804,6 +2804,7 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
         // whoever's counters fit its kept reads goes on with it (below).
         const bool wide_cand = d.lane_n > kFuseLanes;
         if (!wide_cand && sizeof(CntT) != 1) continue;
+        if (wide_by_seen && wide_cand && sizeof(CntT) == 1) continue;      // (FSEG_WIDE_BY_SEEN=1, tests: every problem that SEES more than 255 reads to the 16-bit instance)
         if (d.lane_n > kFuseLanesWide) { if (threadIdx.x == 0) atomicOr(&st->err, kErrNeedWideDp); continue; }
         const int npairs = n * (n - 1) / 2, ntri = n * (n - 1) * (n - 2) / 6;
         const int *cy = cand_y + d.c0;
@@ -2875,7 +2876,7 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
             n_act += tot;
             __syncthreads();
         }
-        if (wide_cand && (sizeof(CntT) == 1) != (n_act <= kFuseLanes)) continue;          // (workgroup-uniform)
+        if (wide_cand && !wide_by_seen && (sizeof(CntT) == 1) != (n_act <= kFuseLanes)) continue;      // (workgroup-uniform)
         FSEG_STICK(1);
         // this thread's share of a round's coverage: read r_lane, candidates [ja, jb) of 1 .. n-1 (at most kCovJ of them)
         constexpr int kCovJ = (NM - 1 + NR - 1) / NR;
@@ -4046,6 +4047,7 @@ struct fseg_ctx {
     bool use_fork = true;
     bool use_tiny = true;       // FSEG_NO_TINY=1: no problem goes to k_tiny
     bool force_key64 = false;
+    bool wide_by_seen = false;  // FSEG_WIDE_BY_SEEN=1 (tests)
     char score_plan[32] = "BM|gTS|b|ms";   // FSEG_SCORE_PLAN (see enqueue_run; anything that does not name each class once = one stream)
     bool score_fork = false;    // FSEG_SCORE_FORK=1: the fused scoring kernels on a stream each
     bool use_wave = true;       // FSEG_NO_WAVE=1: k_tiny / k_solve<16> instead of the wave kernels (k_wave)
@@ -4430,7 +4432,8 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
                                ((NMV) == kNMax ? c->nm_big : (NMV)), list_lb(CLS), list_ln(CLS), pr, c->d_solve_desc.as<ProbDesc>(), \
                                c->prob_cap, c->d_cand_y.as<int>(), c->d_lane_ex.as<longlong2>(), c->d_ex_ts.as<int>(),         \
                                c->d_ex_te.as<int>(), c->d_h_table.as<double>(), c->P.h_len, c->P.threshold_rate,               \
-                               c->d_thr_tab.as<int2>(), c->P.min_read_support_outside, c->d_chosen.as<unsigned char>() FSEG_TARG)
+                               c->d_thr_tab.as<int2>(), c->P.min_read_support_outside, c->d_chosen.as<unsigned char>(),       \
+                               (c->wide_by_seen ? 1 : 0) FSEG_TARG)
         // 32-bit DP keys (dp_solve_push) when no sum of a chain can reach 2^24: at most 32 links times the reads of the largest partition
         // (WHICH: 1 = the instance with 8-bit counters, 2 = the one with 16-bit counters if the class has problems for it, 3 = both)
 #define FSEG_LAUNCH_SOLVE_X(Q, NMV, CLS, N_ITEMS, MAXWG, WHICH)                                                              \
@@ -4952,6 +4955,7 @@ int fseg_create(int device, fseg_ctx **out) {
     if (flag("FSEG_NO_WAVE")) c->use_wave = false;
     if (flag("FSEG_SCORE_FORK")) c->score_fork = true;
     if (flag("FSEG_FORCE_KEY64")) c->force_key64 = true;
+    if (flag("FSEG_WIDE_BY_SEEN")) c->wide_by_seen = true;
     if (const char *e = getenv("FSEG_SCORE_PLAN")) snprintf(c->score_plan, sizeof c->score_plan, "%s", e);
     {
         int seen[4] = {0, 0, 0, 0};

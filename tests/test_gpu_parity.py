@@ -57,13 +57,20 @@ def test_config3_slice_against_oracle(gpu_ctx):
     util.compare_partitions(gpu_ctx, parts, oracles)
 
 
-def test_wide_problems_solved_whole_with_sixteen_bit_counters(monkeypatch):
-    """FSEG_FUSE_LANES=1023: a batch of 1 000-read partitions (BASELINE config 3) is solved whole although its widest problems
-    see more than 255 reads -- those go to the 16-bit-counter instances of k_solve, the rest of each list to the 8-bit ones."""
+@pytest.mark.parametrize("by_seen", [False, True], ids=["by-kept-reads", "by-seen-reads"])
+def test_wide_problems_solved_whole_with_sixteen_bit_counters(monkeypatch, by_seen):
+    """FSEG_FUSE_LANES=1023: batches of 1 000- and 1 600-read partitions (BASELINE config 3 and wider) are solved whole although
+    their widest problems see more than 255 reads.  A problem goes to the 16-bit-counter instance of k_solve when it KEEPS more
+    than 255 reads (the 1 600-read partitions have such problems); FSEG_WIDE_BY_SEEN=1 sends every problem that SEES more than
+    255 there, so that the 16-bit instances are compared with the oracle on many problems, not a few."""
     from freddie_amd import _lib, synth
     monkeypatch.setenv("FSEG_FUSE_LANES", "1023")
+    if by_seen:
+        monkeypatch.setenv("FSEG_WIDE_BY_SEEN", "1")
     kw = dict(synth.WORKLOADS["config3"]); kw.pop("n_partitions")
-    parts = [util.make_partition(i, **kw) for i in range(24)]
+    parts = [util.make_partition(i, **kw) for i in range(16)]
+    kw["n_reads"] = 1600
+    parts += [util.make_partition(100 + i, **kw) for i in range(8)]
     oracles = [util.run_oracle(p) for p in parts]
     ctx = _lib.Context(0)
     try:
