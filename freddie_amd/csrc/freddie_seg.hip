@@ -97,7 +97,8 @@ struct Status {
     unsigned list_cur[8];   // k_prob_emit's cursors into the four solve lists: [2 * list] from the front (expensive problems), [2 * list + 1] from the back
     unsigned wide_cls[4];   // solve-list problems per size class that see more than kFuseLanes reads (16-bit counters); [3] unused
     unsigned gate;          // large-class workgroups that have started (k_gate holds the small classes back until they are placed)
-    unsigned pad2;          // (a counter of the mid class's 2 000 workgroups, bumped by each as it started, cost that kernel 10 of its 62 us)
+    unsigned gate_done;     // large-class workgroups that have ended (a counter of the mid class's 2 000 workgroups, bumped by each as it
+                            // started, cost that kernel 10 of its 62 us: these two count a few hundred)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -2711,11 +2712,13 @@ __global__ void __launch_bounds__(256, WaveCfg<NM>::kOcc) k_wave(Status *st, con
 // large class running alone on a mostly empty chip.  k_gate is what the side stream runs first: one wave that waits until the
 // large class's workgroups have all started (they all fit the chip at once) or `max_ticks` of the 100 MHz clock have passed --
 // an exit every launch reaches -- so the small classes fill the space the large one leaves instead of taking it first.
-__global__ void __launch_bounds__(64) k_gate(Status *st, unsigned want_max, unsigned max_ticks) {
+__global__ void __launch_bounds__(64) k_gate(Status *st, int done, unsigned want_max, unsigned pct, unsigned max_ticks) {
     const u64 n2 = st->solve_cls[2];
-    const unsigned want = n2 < want_max ? (unsigned)n2 : want_max;
+    const unsigned grid = n2 < want_max ? (unsigned)n2 : want_max;
+    const unsigned want = done ? (grid * pct + 99) / 100 : grid;     // done: that share of the large class's workgroups has ENDED
+    const unsigned *ctr = done ? &st->gate_done : &st->gate;
     const unsigned long long t0 = wall_clock64();
-    while (__hip_atomic_load(&st->gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want && wall_clock64() - t0 < max_ticks)
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want && wall_clock64() - t0 < max_ticks)
         __builtin_amdgcn_s_sleep(16);
 }
 
@@ -3007,6 +3010,7 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
 #endif
     }
 #undef FSEG_STICK
+    if (NM == kNMax && sizeof(CntT) == 1 && threadIdx.x == 0) atomicAdd(&st->gate_done, 1u);     // ended: see k_gate
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -4048,6 +4052,7 @@ struct fseg_ctx {
     bool use_tiny = true;       // FSEG_NO_TINY=1: no problem goes to k_tiny
     bool force_key64 = false;
     bool wide_by_seen = false;  // FSEG_WIDE_BY_SEEN=1 (tests)
+    int gate_done_pct = 60;     // FSEG_GATE_DONE_PCT: the share of the large class's workgroups that has to have ended for 'd' in the plan
     char score_plan[32] = "BM|gTS|b|ms";   // FSEG_SCORE_PLAN (see enqueue_run; anything that does not name each class once = one stream)
     bool score_fork = false;    // FSEG_SCORE_FORK=1: the fused scoring kernels on a stream each
     bool use_wave = true;       // FSEG_NO_WAVE=1: k_tiny / k_solve<16> instead of the wave kernels (k_wave)
@@ -4391,9 +4396,10 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
     }   // do_pre2
     if (do_score) begin(ST_SCORE);
     if (do_score && c->prob_cap > 0) {
-        // How the four fused scoring kernels share the chip is a plan (FSEG_SCORE_PLAN, default "BM|gTS"): streams separated by
-        // '|' (the first is the main stream); B M S T = the large / mid / small / tiny class's kernel, g = k_gate (wait until the
-        // large class's workgroups are placed), e = wait for the large class to end.  Measured on config4 (250 k-read batch, stage
+        // How the four fused scoring kernels share the chip is a plan (FSEG_SCORE_PLAN, default "BM|gTS|b|ms"): streams separated
+        // by '|' (the first is the main stream); B M S T = the large / mid / small / tiny class's kernel, b m s = their 16-bit
+        // counter instances, g = k_gate (wait until the large class's workgroups are placed), d = k_gate on the share of them
+        // that has ended (FSEG_GATE_DONE_PCT), e = wait for the large class to end.  Measured on config4 (250 k-read batch, stage
         // alone): all four on the main stream 0.192-0.209 ms; a stream each without a gate 0.208-0.212 (the dispatcher then runs
         // them in the reverse of their launch order: a large-class workgroup needs eight wave slots and half a CU's LDS at once and
         // gets neither until the small classes have drained); "BM|gTS" 0.161-0.175: the tiny class runs in the large class's
@@ -4502,7 +4508,8 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
                     case 'm': if (c->n_solve[1] > 0) FSEG_LAUNCH_SOLVE_X(q, kClsMid, 1, c->n_solve[1], FSEG_WG_MID, 2); break;
                     case 's': if (c->n_solve[0] > 0) FSEG_LAUNCH_SOLVE_X(q, kClsSmall, 0, c->n_solve[0], FSEG_WG_SMALL, 2); break;
                     case 'T': if (c->n_tiny > 0) FSEG_LAUNCH_WAVE(q, kTiny, 3, c->n_tiny); break;
-                    case 'g': hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, q, st, (unsigned)(c->n_solve[2] < 512 ? c->n_solve[2] : 512), 3000u); break;
+                    case 'g': hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, q, st, 0, (unsigned)(c->n_solve[2] < 512 ? c->n_solve[2] : 512), 100u, 3000u); break;
+                    case 'd': hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, q, st, 1, (unsigned)(c->n_solve[2] < 512 ? c->n_solve[2] : 512), (unsigned)c->gate_done_pct, 15000u); break;
                     case 'e': if (ev_big && hipStreamWaitEvent(q, ev_big, 0) != hipSuccess) fj_err = hipErrorUnknown; break;
                     default: break;
                     }
@@ -4956,6 +4963,7 @@ int fseg_create(int device, fseg_ctx **out) {
     if (flag("FSEG_SCORE_FORK")) c->score_fork = true;
     if (flag("FSEG_FORCE_KEY64")) c->force_key64 = true;
     if (flag("FSEG_WIDE_BY_SEEN")) c->wide_by_seen = true;
+    { const char *v = getenv("FSEG_GATE_DONE_PCT"); if (v && v[0] && atoi(v) > 0 && atoi(v) <= 100) c->gate_done_pct = atoi(v); }
     if (const char *e = getenv("FSEG_SCORE_PLAN")) snprintf(c->score_plan, sizeof c->score_plan, "%s", e);
     {
         int seen[4] = {0, 0, 0, 0};

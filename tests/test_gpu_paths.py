@@ -57,6 +57,7 @@ SWITCHES = [
     {"FSEG_FUSE_LANES": "1023"},
     {"FSEG_SCORE_PLAN": "0"},                               # ... all on the main stream (no k_gate)
     {"FSEG_SCORE_PLAN": "BMbms|gTS"},                       # ... the 16-bit-counter instances behind the others
+    {"FSEG_SCORE_PLAN": "B|gTS|dM|bms", "FSEG_GATE_DONE_PCT": "50"},   # the mid class once half of the large class's workgroups have ended
     {"FSEG_SCORE_PLAN": "B|M|S|g|T"},                       # more segments than streams: not a plan, one stream
     {"FSEG_SCORE_PLAN": "gBeMTS"},                          # a gate in front of its own kernel: leaves by its time limit
     {"FSEG_SCORE_PLAN": "B|gM|gS|gT"},                      # ... or each class behind the gate on its own stream
