@@ -1742,6 +1742,10 @@ template <typename V> __device__ __forceinline__ constexpr V dp_neg_inf() { retu
 // from column c, and at the top level (first maximiser over j) -- or kKeyNone.  With 32-bit keys every |value| must stay
 // below 2^24: k_solve / k_wave take them when the largest partition has fewer than 2^18 reads (a chain has at most 32 links
 // of at most that many reads each), the 64-bit instances otherwise.
+// f(integral_constant<int, B>) ... f(integral_constant<int, E - 1>): a loop whose index is a compile-time constant in the body
+template <int B, int E, typename F> __device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (B < E) { f(std::integral_constant<int, B>{}); static_for<B + 1, E>(f); }
+}
 template <typename V> __device__ __forceinline__ constexpr V dp_key_none() { return sizeof(V) == 8 ? (V)(-(1LL << 62)) : (V)(-0x7ff00000); }
 template <typename V> __device__ __forceinline__ constexpr V dp_key_min() { return sizeof(V) == 8 ? (V)(-(1LL << 61)) : (V)(-0x40000000); }   // every key of a value is above it
 // The push of column c2 into the first NS slots of a thread: all the slots' LDS loads first (none of them under a branch),
@@ -2495,9 +2499,6 @@ __global__ void __launch_bounds__(256, FSEG_TINY_OCC) k_tiny(Status *st, const P
 // (the lane number has to be an inline constant: a second scalar register would break the one-scalar-operand rule)
 template <int LANE> __device__ __forceinline__ void write_lane(unsigned &acc, unsigned v) {
     asm("v_writelane_b32 %0, %1, %2" : "+v"(acc) : "s"(v), "n"(LANE));
-}
-template <int B, int E, typename F> __device__ __forceinline__ void static_for(F &&f) {
-    if constexpr (B < E) { f(std::integral_constant<int, B>{}); static_for<B + 1, E>(f); }
 }
 constexpr int kWaveLanes = 1023;               // reads up to which a small problem is one wave's (16 rounds); beyond, the arena path
 constexpr int kStageCap = 512;                 // exons of one round's reads staged in LDS (a round takes fewer reads if they own more)
