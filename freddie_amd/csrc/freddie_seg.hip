@@ -2935,19 +2935,37 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
                     const int i = pi[s], j = pj[s], hi = th_hi[s], lo = th_lo[s];
                     unsigned y0 = 0, z0 = 0, y1 = 0, z1 = 0;
 #define FSEG_SHIFT_IN(acc, cmp, a, b) asm("v_cmp_" cmp "_i32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(a), "v"(b) : "vcc")
+                    // (a round's last reads rarely fill a word: a problem keeps ~80 reads, 64 + 16 -- the partly filled word
+                    // costs its reads, not thirty-two; its bits are then moved up to where the full words' are)
+                    if (n_valid >= 32) {
 #pragma unroll
-                    for (int b = 0; b < 32; ++b) {
-                        int dd = (int)(cov[b * rt_stride + j] - cov[b * rt_stride + i]);
-                        FSEG_SHIFT_IN(y0, "ge", dd, hi);
-                        FSEG_SHIFT_IN(z0, "le", dd, lo);
+                        for (int b = 0; b < 32; ++b) {
+                            int dd = (int)(cov[b * rt_stride + j] - cov[b * rt_stride + i]);
+                            FSEG_SHIFT_IN(y0, "ge", dd, hi);
+                            FSEG_SHIFT_IN(z0, "le", dd, lo);
+                        }
+                    } else {
+                        for (int b = 0; b < n_valid; ++b) {
+                            int dd = (int)(cov[b * rt_stride + j] - cov[b * rt_stride + i]);
+                            FSEG_SHIFT_IN(y0, "ge", dd, hi);
+                            FSEG_SHIFT_IN(z0, "le", dd, lo);
+                        }
+                        y0 <<= 32 - n_valid; z0 <<= 32 - n_valid;          // (1 <= n_valid <= 31)
                     }
-                    if (nv1 > 0) {
+                    if (nv1 >= 32) {
 #pragma unroll
                         for (int b = 0; b < 32; ++b) {
                             int dd = (int)(cov[(32 + b) * rt_stride + j] - cov[(32 + b) * rt_stride + i]);
                             FSEG_SHIFT_IN(y1, "ge", dd, hi);
                             FSEG_SHIFT_IN(z1, "le", dd, lo);
                         }
+                    } else if (nv1 > 0) {
+                        for (int b = 0; b < nv1; ++b) {
+                            int dd = (int)(cov[(32 + b) * rt_stride + j] - cov[(32 + b) * rt_stride + i]);
+                            FSEG_SHIFT_IN(y1, "ge", dd, hi);
+                            FSEG_SHIFT_IN(z1, "le", dd, lo);
+                        }
+                        y1 <<= 32 - nv1; z1 <<= 32 - nv1;
                     }
 #undef FSEG_SHIFT_IN
                     y0 &= valid0; z0 &= valid0; y1 &= valid1; z1 &= valid1;     // rows beyond the problem's reads hold nothing
@@ -2972,23 +2990,29 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
                 const int i_end = iend_s[j];                          // i with cand_j - cand_i >= 5 (:540), a prefix
                 // (a read is never yea AND nay of one pair -- lo < hi --, so the two cross terms of a plane word are disjoint: one
                 // popcount of their union, six instructions per triple and round instead of eight)
-#define FSEG_TRI_CNT(Av) (__popc(((Av).x & B.z) | ((Av).z & B.x)) + __popc(((Av).y & B.w) | ((Av).w & B.y)))
+                // (a round of at most 32 reads has nothing in the second words: half the instructions)
+#define FSEG_TRI_CNT(Av) (HALF ? __popc(((Av).x & B.z) | ((Av).z & B.x)) \
+                               : __popc(((Av).x & B.z) | ((Av).z & B.x)) + __popc(((Av).y & B.w) | ((Av).w & B.y)))
                 CntT *o = cnt + tbase;
-                int i = 0;
-                for (; i < i_end && ((tbase + i) & (PACK - 1)); ++i) {          // up to a 32-bit boundary of the table
-                    const uint4 Av = planes[abase + i];
-                    o[i] = (CntT)(o[i] + FSEG_TRI_CNT(Av));
-                }
-                for (; i + PACK <= i_end; i += PACK) {                // PACK counters per 32-bit read-modify-write: a counter
-                    unsigned add = 0;                                 // never exceeds the reads of the problem, so no carry
+                auto row = [&](auto half_c) {
+                    constexpr bool HALF = decltype(half_c)::value;
+                    int i = 0;
+                    for (; i < i_end && ((tbase + i) & (PACK - 1)); ++i) {          // up to a 32-bit boundary of the table
+                        const uint4 Av = planes[abase + i];
+                        o[i] = (CntT)(o[i] + FSEG_TRI_CNT(Av));
+                    }
+                    for (; i + PACK <= i_end; i += PACK) {                // PACK counters per 32-bit read-modify-write: a counter
+                        unsigned add = 0;                                 // never exceeds the reads of the problem, so no carry
 #pragma unroll
-                    for (int u = 0; u < PACK; ++u) { const uint4 Av = planes[abase + i + u]; add |= (unsigned)FSEG_TRI_CNT(Av) << (8 * (int)sizeof(CntT) * u); }
-                    *reinterpret_cast<unsigned *>(o + i) += add;
-                }
-                for (; i < i_end; ++i) {
-                    const uint4 Av = planes[abase + i];
-                    o[i] = (CntT)(o[i] + FSEG_TRI_CNT(Av));
-                }
+                        for (int u = 0; u < PACK; ++u) { const uint4 Av = planes[abase + i + u]; add |= (unsigned)FSEG_TRI_CNT(Av) << (8 * (int)sizeof(CntT) * u); }
+                        *reinterpret_cast<unsigned *>(o + i) += add;
+                    }
+                    for (; i < i_end; ++i) {
+                        const uint4 Av = planes[abase + i];
+                        o[i] = (CntT)(o[i] + FSEG_TRI_CNT(Av));
+                    }
+                };
+                if (n_valid <= 32) row(std::true_type{}); else row(std::false_type{});
 #undef FSEG_TRI_CNT
             }
             lds_barrier();
