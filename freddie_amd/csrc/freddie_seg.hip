@@ -49,6 +49,11 @@ constexpr int kNHuge = 128;            // largest DP problem at all: 60 < n <= 1
 constexpr int kLaneChunk = 256;        // reads ("lanes") per scoring work item (u16 counters: must stay < 65536)
 constexpr int kSub = 64;               // reads per scoring sub-chunk (two 32-bit plane words)
 constexpr i64 kNegInf = (i64)(-0x7fffffffffffffffLL - 1);
+constexpr int kFuseLanes = 255;   // reads a problem may see for 8-bit triple counters (four 64-read rounds at most)
+constexpr int kFuseLanesDefault = 511;  // reads a problem may see for its batch to take the fused kernels (FSEG_FUSE_LANES): eight rounds
+constexpr int kFuseLanesWide = 1023;   // ... and for the 16-bit instances: partitions of 1 000 reads have problems that see ~300 (one
+                                       // in twenty-five of them more than 255); a problem that sees more than this is quicker spread
+                                       // over the arena path's work items, and so is its whole batch
 
 // error bits of Status::err
 enum : unsigned {
@@ -68,7 +73,7 @@ enum : unsigned {
 };
 
 #ifdef FSEG_SCORE_TIMING
-constexpr size_t kTaccProbs = 1u << 17, kTaccBytes = 128 + kTaccProbs * 32;
+constexpr size_t kTaccProbs = 1u << 17, kTaccBytes = 128 + kTaccProbs * 64;     // (a record per problem for k_solve / k_wave, another for k_dpw)
 #else
 constexpr size_t kTaccBytes = 128;
 #endif
@@ -1244,6 +1249,10 @@ __device__ __forceinline__ ProbSizes prob_sizes(int n, int n_lanes, ProbSplit sp
         s.v[0] = 1;
         s.v[7] = c == 0 ? 1 : (c == 1 ? (1LL << 32) : 0);
         s.v[8] = c == 2 ? 1 : 0;
+        // room for k_cover's hand-over to k_solve: the pair thresholds and a coverage row per read the problem sees (an upper
+        // bound of the rows it keeps), in the arenas the arena path uses for the same things
+        s.v[1] = (i64)n * (n - 1) / 2;
+        s.v[3] = ((i64)n_lanes * n + 3) & ~(i64)3;
         return s;
     }
     i64 chunks = (n_lanes + kLaneChunk - 1) / kLaneChunk;
@@ -1746,6 +1755,11 @@ template <typename V> __device__ __forceinline__ constexpr V dp_neg_inf() { retu
 template <int B, int E, typename F> __device__ __forceinline__ void static_for(F &&f) {
     if constexpr (B < E) { f(std::integral_constant<int, B>{}); static_for<B + 1, E>(f); }
 }
+// f(integral_constant<int, I>) ... f(integral_constant<int, 0>)
+template <int I, typename F> __device__ __forceinline__ void static_for_down(F &&f) {
+    f(std::integral_constant<int, I>{});
+    if constexpr (I > 0) static_for_down<I - 1>(f);
+}
 template <typename V> __device__ __forceinline__ constexpr V dp_key_none() { return sizeof(V) == 8 ? (V)(-(1LL << 62)) : (V)(-0x7ff00000); }
 template <typename V> __device__ __forceinline__ constexpr V dp_key_min() { return sizeof(V) == 8 ? (V)(-(1LL << 61)) : (V)(-0x40000000); }   // every key of a value is above it
 // The push of column c2 into the first NS slots of a thread: all the slots' LDS loads first (none of them under a branch),
@@ -1881,6 +1895,123 @@ __device__ __forceinline__ int dp_solve_push(int n, const OutT *out_s, const int
             }
         }
         if ((mask >> lane) & 1ULL) chosen[lane] = 1;
+    }
+    FSEG_DTICK(12);
+    return chain;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same DP by ONE WAVE (k_solve's tail, round 4).  A column of the push DP is a chain -- the owners' write, the
+// loads of the others, a handful of arithmetic -- and with T threads every wave pays the chain's ~50 instructions
+// for a pair or two each, plus a workgroup barrier per column, while seven of the large class's eight waves hold
+// their registers for nothing (the DP was 42-45 % of a problem's time).  One wave holds every pair (slot s = pair
+// s * 64 + lane), needs no barrier (a wave's LDS operations complete in order) and lets the workgroup's other waves
+// END when the scoring rounds are over: their registers and wave slots go to the next workgroup while this one
+// finishes on a sixteenth of what it held.
+//   * The columns are visited in STAGES: stage S = the columns whose first pair lies in slot S (t2 >> 6 == S), S
+//     descending.  Inside a stage the slots that finish (S and S + 1) and the slots that take the push (0 .. S) are
+//     compile-time constants: no dispatch, no register indexing, and a column costs its own pairs only.
+//   * A pair is two registers, its running key and c; the scoring owners of the pairs leave c in A[q] and in(b,c) in
+//     in_s[q] -- kDeadPair where the segment is too small (:540) -- so nothing is decoded here, and in() is read when the
+//     pair's column is finished (asked for a column ahead).
+//   * A[q] becomes the chain's link: the argument, or kLinkNone at the chain's end (c == end).  The walk is one LDS byte
+//     and three integer instructions per link, kept on the vector unit (values the same in every lane); the visited
+//     candidates are collected one per lane and stored by the wave.
+// 32-bit keys only when NM > 32 (64-bit keys would need 112 registers for the large class): k_solve keeps dp_solve_push for
+// that instance.
+// ---------------------------------------------------------------------------------------------
+constexpr int kDeadPair = (int)0x80000000;
+constexpr unsigned char kLinkNone = 255;
+template <int NM, typename OutT, typename V>
+__device__ __forceinline__ int dp_solve_wave(int n, const OutT *out_s, const int *in_s, V *M, unsigned char *A, int support,
+                                             unsigned char *chosen /* + first candidate of the problem */ FSEG_DPARAM) {
+    constexpr int SLOTS = (NM * (NM - 1) / 2 + 63) / 64;
+    static_assert(NM <= 64, "a candidate per lane at the top level; an argument is six bits of a key");
+    const int lane = lane_id();
+    n = uni(n); support = uni(support);
+    const int end = n - 1, npairs = n * (n - 1) / 2;
+    constexpr V kNone = dp_key_none<V>(), kMin = dp_key_min<V>();
+    int pc[SLOTS];                                  // c of pair (b,c)
+    V best[SLOTS];
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        const int q = s * 64 + lane;
+        pc[s] = (int)A[q < npairs ? q : 0];
+        best[s] = (q < npairs && pc[s] == end) ? (V)0 : kNone;       // M(b,end) = in(b,end): the chain's last link (:545-548)
+    }
+    int c2 = end, t2 = end * (end - 1) / 2, t3 = end * (end - 1) * (end - 2) / 6;
+    // the pair this lane finishes in column c2 is q = t2 + ((lane - t2) & 63) if that offset is below c2; its in() is asked for
+    // a column ahead (beside the push's loads), so that a column's chain holds no load of its own before the owners' write
+    int in_nx = in_s[t2 + (((lane - t2) & 63) < c2 ? ((lane - t2) & 63) : 0)];
+    auto stage = [&](auto Sc) {
+        constexpr int S = decltype(Sc)::value;
+        while (c2 >= 1 && (t2 >> 6) == S) {                         // (wave-uniform)
+            const int d0 = (lane - t2) & 63, q0 = t2 + d0;
+            if (d0 < c2) {
+                V bb = best[S];
+                if constexpr (S + 1 < SLOTS) bb = (q0 >> 6) == S ? bb : best[S + 1];
+                const bool ok = in_nx != kDeadPair && bb > kMin;
+                const V val = (bb >> 6) + (V)(ok ? in_nx : 0);
+                M[q0] = ok ? (V)(val * 64 + (V)(63 - c2)) : kNone;
+                A[q0] = (ok && c2 != end) ? (unsigned char)(63 - (int)(bb & 63)) : kLinkNone;
+            }
+            dp_sync<64>();
+            if (c2 == 1) { c2 = 0; break; }
+            const int t2n = t2 - (c2 - 1), d1 = (lane - t2n) & 63;
+            in_nx = in_s[t2n + (d1 < c2 - 1 ? d1 : 0)];
+            // pairs (b, c) with c < c2: q < t2 -- slots 0 .. S, the last one partly
+            // (the loads of up to kBatch slots are in flight together: more would cost the registers the pairs live in)
+            constexpr int kBatch = 8;
+            static_for<0, (S + kBatch) / kBatch>([&](auto gc) {
+                constexpr int s0 = decltype(gc)::value * kBatch, s1 = s0 + kBatch <= S + 1 ? s0 + kBatch : S + 1;
+                V tail[s1 - s0];
+                unsigned o[s1 - s0];
+#pragma unroll
+                for (int s = s0; s < s1; ++s) {
+                    const int q = s * 64 + lane;
+                    const bool act = s < S || q < t2;
+                    tail[s - s0] = M[t2 + (act ? pc[s] : 0)];
+                    o[s - s0] = (unsigned)out_s[t3 + (act ? q : 0)];
+                }
+#pragma unroll
+                for (int s = s0; s < s1; ++s) {
+                    const int q = s * 64 + lane;
+                    const bool act = s < S || q < t2;
+                    const V key = (V)o[s - s0] * 64 + tail[s - s0];          // (a tail of kKeyNone stays below every key of a value)
+                    const bool ok = act & ((int)o[s - s0] >= support);       // :540
+                    const V k2 = ok ? key : kNone;
+                    best[s] = k2 > best[s] ? k2 : best[s];
+                }
+            });
+            t2 = t2n; --c2; t3 -= t2;
+        }
+    };
+    static_for_down<SLOTS - 1>(stage);
+    FSEG_DTICK(10);
+    // first maximiser over j of M(0,j) (larger value, then smaller j): the largest key, one candidate per lane
+    const int j0 = lane >= 1 && lane < end ? lane : 1;
+    V kv = (lane >= 1 && lane < end) ? M[j0 * (j0 - 1) / 2] : kNone;
+    for (int d = 32; d >= 1; d >>= 1) {
+        const V ov = __shfl_xor(kv, d);
+        kv = ov > kv ? ov : kv;
+    }
+    FSEG_DTICK(11);
+    int chain = 0;
+    const bool cut = end >= 2 && kv > kMin && (kv >> 6) > (V)in_s[end * (end - 1) / 2];
+    if (uni(cut ? 1 : 0)) {
+        const int bj = 63 - (int)(kv & 63);
+        int q = bj * (bj - 1) / 2, k = bj, rec = 0;                  // the state (j, k) is reached through pair q = (j, k)'s predecessor
+#pragma nounroll
+        for (; chain < 62; ++chain) {
+            const int e = (int)A[q];
+            if (e == (int)kLinkNone) break;
+            rec = lane == chain ? e : rec;
+            q = e * (e - 1) / 2 + k;                                 // pair (k, e): the next state
+            k = e;
+        }
+        if (lane == 62) rec = 0;
+        if (lane == 63) rec = bj;
+        if (lane < chain || lane >= 62) chosen[rec] = 1;
     }
     FSEG_DTICK(12);
     return chain;
@@ -2708,6 +2839,198 @@ __global__ void __launch_bounds__(256, WaveCfg<NM>::kOcc) k_wave(Status *st, con
 // threshold / ambiguity / count arenas, no work items, no DP list entry.  (The arena path remains for problems that see
 // thousands of reads, where one problem has to be spread over many workgroups.)
 // ---------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------
+// k_cover: everything of a k_solve problem that is a chain of dependent GLOBAL loads, done beforehand by a workgroup that
+// holds next to nothing (round 4).  Under load k_solve spent 44 % (large class) to 76 % (small) of its time before and
+// between its LDS phases -- descriptor -> candidates -> threshold table -> exon ranges -> exon blocks, then the exons again
+// per round -- while holding 25-78 KB of LDS and 96-128 registers per thread (tools/solve_timing.py).  Here: per problem
+//   * the integer label bounds of every pair (:490-495)            -> pair_thr[pair_off + q]
+//   * the reads that have an exon in the window, in lane order, and each one's window coverage
+//     cov[r][j] = positions of its closed exons in [cand_0, cand_j) (get_cumulative_coverage :188-246; a sum of overlaps)
+//                                                                   -> cov_g[cov_off + r * n + j], nact[problem]
+// so that k_solve<.., SPLIT> starts with ONE round of independent loads behind its descriptor and copies a round's rows
+// from memory instead of walking exons.  Lanes are candidates in the coverage pass (a read's exons are wave-uniform):
+// a row leaves as one contiguous store.
+// ---------------------------------------------------------------------------------------------
+constexpr int kCoverStage = 1024;              // exons of one round's reads staged in LDS per wave of k_cover (a round takes fewer reads if they own more)
+// a round of k_cover: the next lanes of the wave's share whose exons fit the stage together -- their piece of the exon stream
+// requested into registers ...
+struct CoverRound { int base, total, m; };
+__device__ __forceinline__ CoverRound cover_round(int2 lx, bool in) {
+    CoverRound r;
+    r.base = uni(lx.x) & ~1;                                                     // (16-byte units)
+    const u64 fm = __ballot(in && lx.y - r.base <= kCoverStage);
+    r.m = ~fm == 0 ? 64 : (int)__builtin_ctzll(~fm);                            // the ranges ascend: a prefix of the lanes
+    r.total = r.m > 0 ? __builtin_amdgcn_readlane(lx.y, r.m - 1) - r.base : 0;
+    return r;
+}
+// (a round's piece waits in eight named registers quadruples: as an array -- handed to a helper or not -- it stayed in scratch
+// memory, a round trip through global memory in the middle of the chain)
+static_assert(kCoverStage == 1024, "CoverPiece holds eight 16-byte loads per lane");
+struct CoverPiece { int4 v0, v1, v2, v3, v4, v5, v6, v7; };
+__device__ __forceinline__ CoverPiece cover_request(const int2 *__restrict__ lex, const CoverRound &r, int lane) {
+    const int last2 = r.total & ~1;
+    auto ld = [&](int u) { const int i = 2 * lane + 128 * u; return *reinterpret_cast<const int4 *>(lex + r.base + (i < last2 ? i : last2)); };
+    CoverPiece pc;
+    pc.v0 = ld(0); pc.v1 = ld(1); pc.v2 = ld(2); pc.v3 = ld(3); pc.v4 = ld(4); pc.v5 = ld(5); pc.v6 = ld(6); pc.v7 = ld(7);
+    return pc;
+}
+__device__ __forceinline__ void cover_store(int2 *stage, int lane, const CoverPiece &pc) {        // (beyond the piece: never read)
+    auto st = [&](int u, const int4 &v) { *reinterpret_cast<int4 *>(&stage[2 * lane + 128 * u]) = v; };
+    st(0, pc.v0); st(1, pc.v1); st(2, pc.v2); st(3, pc.v3); st(4, pc.v4); st(5, pc.v5); st(6, pc.v6); st(7, pc.v7);
+}
+// every lane's exons that meet the window [cp0, c_last): (first, cnt), stage-relative
+__device__ __forceinline__ u64 cover_locate(const int2 *stage, const CoverRound &r, int2 lx, int lane, int cp0, int c_last, int &first, int &cnt) {
+    dp_sync<64>();
+    const bool valid = lane < r.m;
+    const int ea = valid ? lx.x - r.base : 0, eb = valid ? lx.y - r.base : 0;
+    first = ea; cnt = 0;
+    for (int e = ea; e < eb; e += 4) {
+        int2 x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) x[u] = stage[e + u];                          // (beyond the read: masked; the array has room)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool hit = e + u < eb && x[u].y >= cp0 && x[u].x < c_last;
+            if (hit && cnt == 0) first = e + u;
+            cnt += hit;
+        }
+        if (x[3].x >= c_last) break;                                              // the rest of the read lies beyond the window
+    }
+    return __ballot(valid && cnt > 0);
+}
+// NW waves share a problem's lanes; PMAX: the class's most pairs (their thresholds wait in registers while the exons arrive).
+// Under load a dependent global load is 2-5 us, and the first version was a chain of ten of them (50 us for the small class's
+// launch): now everything is requested as early as its address is known -- descriptor -> {candidates, the first round's lane
+// ranges, the pair table} -> {threshold table, the round's piece of the exon stream} -> rows.
+#ifndef FSEG_COVER_OCC
+#define FSEG_COVER_OCC 6
+#endif
+template <int NW, int PMAX>
+__global__ void __launch_bounds__(64 * NW, FSEG_COVER_OCC) k_cover(Status *st, int nm, i64 list_base, i64 list_n, const ProbDesc *desc, const int *__restrict__ cand_y,
+                                                   const int2 *__restrict__ lane_lx, const int2 *__restrict__ lex,
+                                                   const double *h_table, int h_len, double tau, const int2 *__restrict__ thr_tab,
+                                                   int2 *pair_thr, i64 pair_cap, unsigned *cov_g, i64 cov_cap, int *nact FSEG_TPARAM) {
+    constexpr int T = 64 * NW, PS = (PMAX + T - 1) / T;
+#ifdef FSEG_SCORE_TIMING
+    // diagnostic build: phase clocks (slots 6 descriptor + candidates, 7 thresholds, 13 pass 1, 14 pass 2, 5 the rest)
+    unsigned long long ct_prev = wall_clock64();
+#define FSEG_CTICK(i) do { unsigned long long t_now = wall_clock64(); if (threadIdx.x == 0) atomicAdd(&tacc[i], t_now - ct_prev); ct_prev = t_now; } while (0)
+#else
+#define FSEG_CTICK(i)
+#endif
+    __shared__ __align__(16) int2 stage_s[NW][kCoverStage + 4];
+    __shared__ int cy_s[64];
+    __shared__ int wave_n[NW];
+    const i64 t = blockIdx.x;
+    if (t >= list_n) return;
+    unsigned short ij[PS];                                           // (the pair table depends on nothing: asked for first)
+#pragma unroll
+    for (int k = 0; k < PS; ++k) ij[k] = g_pair_ij[k * T + (int)threadIdx.x < PMAX ? k * T + (int)threadIdx.x : 0];
+    const ProbDesc d = FSEG_LOAD_DESC(desc + list_base + t);
+    const int n = d.n, p = d.w0;
+    const int lane = lane_id(), wave = wave_id();
+    if (n > nm || n > kNMax || n < 3 || d.lane_n > kFuseLanesWide) { if (threadIdx.x == 0) nact[p] = 0; return; }   // (k_solve raises the error)
+    const int npairs = n * (n - 1) / 2;
+    // behind the descriptor: the candidates and the first round's lane ranges
+    const int l_begin = (int)((i64)d.lane_n * wave / NW), l_end = (int)((i64)d.lane_n * (wave + 1) / NW);
+    const int cyv = cand_y[d.c0 + (lane < n ? lane : 0)];
+    const int2 lx0 = lane_lx[d.lane_lo + l_begin + (l_begin + lane < l_end ? lane : 0)];
+    if (wave == 0) cy_s[lane] = cyv;
+    if (d.pair_off + npairs > pair_cap) { if (threadIdx.x == 0) { atomicOr(&st->err, kErrOverflowPairs); nact[p] = 0; } return; }
+    FSEG_CTICK(6);
+    // ---- A wave takes a contiguous share of the problem's lanes, in rounds: as many of the next 64 lanes as own at most
+    //      kCoverStage exons together (all 64, usually).  A round's exons are ONE piece of the lane-ordered exon stream, copied
+    //      into LDS with lane-consecutive 16-byte loads; every lane then finds the exons of its read that meet the window there
+    //      (exons are ordered: the first with te >= cand_0 up to the last with ts < cand_{n-1}).  Pass 1 counts the reads that
+    //      have any (about two thirds of the lane range); pass 2, knowing where the wave's rows start, computes a row per kept
+    //      read with lanes = candidates -- the read's first two exons reach the other lanes through v_readlane (most reads meet
+    //      the window with one or two), further ones are uniform LDS reads -- and stores it whole.  A wave whose share is one
+    //      round (the usual case) keeps its staged exons between the passes.
+    const int cp0 = d.g0 + __builtin_amdgcn_readlane(cyv, 0), c_last = d.g0 + __builtin_amdgcn_readlane(cyv, n - 1);
+    int2 *stage = stage_s[wave];
+    const int cj = lane < n ? d.g0 + cyv : cp0;                      // beyond the problem: an empty window
+    unsigned *rows = cov_g + d.cov_off;
+    auto overlap = [&](int ts, int te) { const int a0 = max(ts, cp0), b0 = te + 1; return max(0, min(b0, cj) - a0); };    // closed exon -> half-open end
+    int first = 0, cnt = 0, row = 0, kept = 0;
+    u64 mk = 0;
+    bool bad = false;
+    auto emit = [&]() {                                                       // the rows of the round that `locate` has just worked on
+        const int2 x0 = stage[first], x1 = stage[first + (cnt > 1 ? 1 : 0)];
+        u64 mm = mk;
+        while (mm) {                                                          // (wave-uniform)
+            const int rl = (int)__builtin_ctzll(mm);
+            mm &= mm - 1;
+            const int cu = __builtin_amdgcn_readlane(cnt, rl);
+            int acc = overlap(__builtin_amdgcn_readlane(x0.x, rl), __builtin_amdgcn_readlane(x0.y, rl));
+            if (cu > 1) acc += overlap(__builtin_amdgcn_readlane(x1.x, rl), __builtin_amdgcn_readlane(x1.y, rl));
+            if (cu > 2) {
+                const int fu = __builtin_amdgcn_readlane(first, rl);
+                for (int e = 2; e < cu; ++e) { const int2 xe = stage[fu + e]; acc += overlap(xe.x, xe.y); }
+            }
+            if (lane < n) rows[(i64)row * n + lane] = (unsigned)acc;
+            ++row;
+        }
+    };
+    // the first round's exons are on their way while the thresholds are looked up
+    const bool any_lanes = l_begin < l_end;
+    const CoverRound r0 = cover_round(lx0, l_begin + lane < l_end);
+    const CoverPiece pc0 = cover_request(lex, r0, lane);
+    if (any_lanes && r0.m == 0) bad = true;                          // (a read of more exons than the stage holds: the host keeps such batches away)
+    __syncthreads();                                                 // cy_s
+    {
+        int2 th[PS];
+#pragma unroll
+        for (int k = 0; k < PS; ++k) {
+            const int q = k * T + (int)threadIdx.x;
+            th[k] = make_int2(0x7fffffff, -1);
+            if (q < npairs) label_thresholds_tab((i64)cy_s[ij[k] >> 8] - cy_s[ij[k] & 255] + 1, thr_tab, h_table, h_len, tau, &th[k].x, &th[k].y);   // :490-495 as integer bounds
+        }
+#pragma unroll
+        for (int k = 0; k < PS; ++k) { const int q = k * T + (int)threadIdx.x; if (q < npairs) pair_thr[d.pair_off + q] = th[k]; }
+    }
+    FSEG_CTICK(7);
+    int rounds = 0;
+    if (any_lanes && !bad) {
+        cover_store(stage, lane, pc0);
+        mk = cover_locate(stage, r0, lx0, lane, cp0, c_last, first, cnt);
+        kept = __popcll(mk); rounds = 1;
+        for (int l0 = l_begin + r0.m; l0 < l_end;) {                 // (shares of more than a round: wide problems)
+            const int2 lx = lane_lx[d.lane_lo + l0 + (l0 + lane < l_end ? lane : 0)];
+            dp_sync<64>();
+            const CoverRound r = cover_round(lx, l0 + lane < l_end);
+            if (r.m == 0) { bad = true; break; }
+            cover_store(stage, lane, cover_request(lex, r, lane));
+            int f2, c2;
+            kept += __popcll(cover_locate(stage, r, lx, lane, cp0, c_last, f2, c2));
+            ++rounds; l0 += r.m;
+        }
+    }
+    if (lane == 0) wave_n[wave] = kept;
+    FSEG_CTICK(13);
+    bad = __syncthreads_or(bad ? 1 : 0) != 0;
+    int n_act = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { if (w < wave) row += wave_n[w]; n_act += wave_n[w]; }
+    if (bad) { if (threadIdx.x == 0) { atomicOr(&st->err, kErrOverflowNm); nact[p] = 0; } return; }
+    if (d.cov_off + (i64)n_act * n > cov_cap) { if (threadIdx.x == 0) { atomicOr(&st->err, kErrOverflowCov); nact[p] = 0; } return; }
+    if (threadIdx.x == 0) nact[p] = n_act;
+    FSEG_CTICK(5);
+    if (rounds == 1) emit();
+    else if (rounds > 1)
+        for (int l0 = l_begin; l0 < l_end;) {
+            const int2 lx = lane_lx[d.lane_lo + l0 + (l0 + lane < l_end ? lane : 0)];
+            dp_sync<64>();
+            const CoverRound r = cover_round(lx, l0 + lane < l_end);
+            cover_store(stage, lane, cover_request(lex, r, lane));
+            mk = cover_locate(stage, r, lx, lane, cp0, c_last, first, cnt);
+            emit();
+            l0 += r.m;
+        }
+    FSEG_CTICK(14);
+#undef FSEG_CTICK
+}
+
 // A large-class workgroup wants eight wave slots and 57-78 KB of LDS at once.  Beside kernels of small workgroups on other
 // streams it is placed last, whatever the launch order (the dispatcher places what fits), and then the stage ends with the
 // large class running alone on a mostly empty chip.  k_gate is what the side stream runs first: one wave that waits until the
@@ -2723,11 +3046,6 @@ __global__ void __launch_bounds__(64) k_gate(Status *st, int done, unsigned want
         __builtin_amdgcn_s_sleep(16);
 }
 
-constexpr int kFuseLanes = 255;   // reads a problem may see for 8-bit triple counters (four 64-read rounds at most)
-constexpr int kFuseLanesDefault = 511;  // reads a problem may see for its batch to take the fused kernels (FSEG_FUSE_LANES): eight rounds
-constexpr int kFuseLanesWide = 1023;   // ... and for the 16-bit instances: partitions of 1 000 reads have problems that see ~300 (one
-                                       // in twenty-five of them more than 255); a problem that sees more than this is quicker spread
-                                       // over the arena path's work items, and so is its whole batch
 template <int NM> struct SolveCfg {
     static constexpr int kThreads = ScoreCfg<NM>::kThreads;
     static constexpr int kSlots = ScoreCfg<NM>::kSlots;
@@ -2738,6 +3056,12 @@ template <int NM> struct SolveCfg {
 #ifndef FSEG_SOLVE_OCC
 #define FSEG_SOLVE_OCC 1
 #endif
+#ifndef FSEG_PRECOVER
+#define FSEG_PRECOVER 0         // 1: builds with k_cover's hand-over compiled into k_solve<.., SPLIT> (then FSEG_PRECOVER=1 in the environment turns it on);
+#endif                          // measured slower than k_solve doing its own set-up, so the product build leaves it out
+#ifndef FSEG_WAVE_DP
+#define FSEG_WAVE_DP 1          // k_solve's DP by one wave (dp_solve_wave); 0: by the whole workgroup (dp_solve_push), as until round 4
+#endif
 #ifndef FSEG_SOLVE_OCC32
 #define FSEG_SOLVE_OCC32 5      // (96 registers, five workgroups of the mid class per CU: 74 -> 70 us on config4; six spill and lose it again)
 #endif
@@ -2746,16 +3070,37 @@ template <int NM> struct SolveCfg {
 #endif
     static constexpr int kMinBlocks = !FSEG_SOLVE_OCC ? 1 : (NM <= 16 ? FSEG_SOLVE_OCC16 : (NM <= 32 ? FSEG_SOLVE_OCC32 : 4));
 };
-inline size_t solve_lds_for(int nm, int cov_stride, int cnt_bytes) {
-    const size_t pairs = (size_t)nm * (nm - 1) / 2, tri = (size_t)nm * (nm - 1) * (nm - 2) / 6;
-    return ((pairs * 16 + (size_t)kSub * cov_stride * 4 + ((tri + 15) & ~(size_t)15) * cnt_bytes) + 15) & ~(size_t)15;
+// LDS of a k_solve workgroup: ONE region that is a round's coverage rows, then its pair planes, then (after the rounds) the DP's
+// M | in | A, and the count table behind it.  (Until round 4 planes and coverage lay side by side: 25 KB for the mid class,
+// 57-78 KB for the large one -- and LDS-time, not wave slots, is what the stage runs out of: 3.2 GB us per batch against 41 MB.)
+#ifndef FSEG_LDS_OVERLAY
+#define FSEG_LDS_OVERLAY 0      // 1: the planes of a round take the LDS of its coverage rows (measured slower: the planes wait in registers, which spill)
+#endif
+inline size_t solve_shared_bytes(int nm, int cov_stride) {
+    const size_t planes = (size_t)nm * (nm - 1) / 2 * 16, cov = (size_t)kSub * cov_stride * 4;
+    return ((FSEG_LDS_OVERLAY ? (planes > cov ? planes : cov) : planes + cov) + 15) & ~(size_t)15;
 }
-template <int NM, typename CntT, typename V>
+// a problem's slot of the hand-over arena (k_solve<.., SPLIT> -> k_dpw): in() per pair, the count table
+constexpr int kDpxHeader = 0;
+__host__ __device__ inline size_t dpx_in_bytes(int nm) { return ((size_t)nm * (nm - 1) / 2 * 4 + 15) & ~(size_t)15; }
+inline size_t dpx_slot_bytes(int nm, int cnt_bytes) {
+    const size_t tri = (size_t)nm * (nm - 1) * (nm - 2) / 6;
+    return (kDpxHeader + dpx_in_bytes(nm) + ((tri * cnt_bytes + 15) & ~(size_t)15) + 255) & ~(size_t)255;
+}
+inline size_t solve_lds_for(int nm, int cov_stride, int cnt_bytes) {
+    const size_t tri = (size_t)nm * (nm - 1) * (nm - 2) / 6;
+    return (solve_shared_bytes(nm, cov_stride) + ((tri + 15) & ~(size_t)15) * cnt_bytes + 15) & ~(size_t)15;
+}
+// SPLIT: the workgroup ends when its rounds are over -- the problem's count table and in() go to its slot of the hand-over
+// arena (dpx_slot) and k_dpw, the next launch on the stream, does the DP with one wave and a fraction of the LDS.
+template <int NM, typename CntT, typename V, bool SPLIT>
 __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBlocks) k_solve(Status *st, int cls, int nm, i64 lb_h, i64 ln_h, ProblemArrays pr,
                                                                   const ProbDesc *desc, i64 prob_cap, const int *cand_y,
                                                                   const longlong2 *lane_ex, const int *ex_ts, const int *ex_te,
                                                                   const double *h_table, int h_len, double tau, const int2 *thr_tab,
-                                                                  int support, unsigned char *chosen, int wide_by_seen FSEG_TPARAM) {
+                                                                  int support, unsigned char *chosen, int wide_by_seen,
+                                                                  unsigned char *dpx, i64 dpx_stride, const int2 *__restrict__ pair_thr_g,
+                                                                  const unsigned *__restrict__ cov_g, int *nact_g FSEG_TPARAM) {
     using C = SolveCfg<NM>;
     constexpr int T = C::kThreads, NR = C::kRanges;
     constexpr int PACK = 4 / (int)sizeof(CntT);                    // counters per 32-bit read-modify-write
@@ -2767,11 +3112,15 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
     const int rt_pairs = nm * (nm - 1) / 2;
     constexpr int rt_stride = NM + 1;             // compile-time row stride (odd: rows do not collide on LDS banks)
     uint4 *planes = reinterpret_cast<uint4 *>(smem);                                         // rt_pairs * 16 B; later M | in | A
-    unsigned *cov = reinterpret_cast<unsigned *>(smem + (size_t)rt_pairs * 16);              // kSub * rt_stride * 4 B
-    CntT *cnt = reinterpret_cast<CntT *>(cov + kSub * rt_stride);                            // C(nm,3) counters
+    unsigned *cov = reinterpret_cast<unsigned *>(smem + (FSEG_LDS_OVERLAY ? 0 : (size_t)rt_pairs * 16));   // kSub * rt_stride * 4 B, BEFORE the planes of a round
+    const unsigned shared_b = !FSEG_LDS_OVERLAY ? (unsigned)rt_pairs * 16 + (unsigned)(kSub * rt_stride * 4) :
+                              ((unsigned)rt_pairs * 16 > (unsigned)(kSub * rt_stride * 4) ? (unsigned)rt_pairs * 16 : (unsigned)(kSub * rt_stride * 4));
+    CntT *cnt = reinterpret_cast<CntT *>(smem + ((shared_b + 15) & ~15u));                   // C(nm,3) counters (solve_shared_bytes)
     V *M = reinterpret_cast<V *>(smem);
     int *in_s = reinterpret_cast<int *>(M + rt_pairs);
     unsigned char *A = reinterpret_cast<unsigned char *>(in_s + rt_pairs);
+    // the DP is one wave's (dp_solve_wave) except where its registers would not fit: the large class with 64-bit sums
+    constexpr bool kWaveDp = FSEG_WAVE_DP && (NM <= 32 || sizeof(V) == 4);
     if (NM == kNMax && sizeof(CntT) == 1 && threadIdx.x == 0) atomicAdd(&st->gate, 1u);     // placed: see k_gate
     // (lb_h >= 0: the host knows the lists' sizes -- the batch has been sized --, and the status record is not on the way to the first problem)
     if (lb_h < 0 && (i64)st->n_prob > prob_cap) return;              // lists incomplete (a run that only sizes the arenas)
@@ -2782,6 +3131,7 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
     const i64 list_base = lb_h >= 0 ? lb_h : (cls <= 0 ? 0 : (cls == 1 ? (i64)st->solve_cls[0] : (i64)st->solve_cls[0] + (i64)st->solve_cls[1]));
     const i64 list_n = lb_h >= 0 ? ln_h : (cls < 0 ? (i64)st->solve_cls[0] + (i64)st->solve_cls[1] + (i64)st->solve_cls[2] : (i64)st->solve_cls[cls]);
     const int r_lane = threadIdx.x & 63, w_rng = wave_id();
+    const bool own_wg = (i64)gridDim.x >= list_n;                    // a workgroup per problem (workgroup-uniform)
 #ifdef FSEG_SCORE_TIMING
     // diagnostic build: phase clocks of the class given by tacc[15] (slots 0..5 scoring phases, 8..12 the DP's)
     __shared__ unsigned long long tick_sink[16];
@@ -2801,6 +3151,9 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
         const int n = d.n;
         __syncthreads();                                             // the previous problem's DP is done with LDS
         FSEG_STICK(0);
+        unsigned char *slot = SPLIT ? dpx + t * dpx_stride : nullptr;           // (dpx: the class's first slot)
+        const bool pre = FSEG_PRECOVER && SPLIT && cov_g != nullptr;  // k_cover has run: thresholds, kept reads and coverage rows come from memory
+        const int n_pre = pre ? nact_g[p] : 0;                       // (the reads the problem keeps)
         if (n > nm || n > NM) { if (threadIdx.x == 0) atomicOr(&st->err, kErrOverflowNm); continue; }
         // a list's problems are shared by two launches: the 8-bit counters take those that KEEP at most 255 reads (a counter
         // counts reads with coverage in the window: about two thirds of those the problem sees), the 16-bit ones the rest.
@@ -2810,6 +3163,7 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
         if (!wide_cand && sizeof(CntT) != 1) continue;
         if (wide_by_seen && wide_cand && sizeof(CntT) == 1) continue;      // (FSEG_WIDE_BY_SEEN=1, tests: every problem that SEES more than 255 reads to the 16-bit instance)
         if (d.lane_n > kFuseLanesWide) { if (threadIdx.x == 0) atomicOr(&st->err, kErrNeedWideDp); continue; }
+        if (pre && wide_cand && !wide_by_seen && (sizeof(CntT) == 1) != (n_pre <= kFuseLanes)) continue;       // the other instance's (k_cover has counted)
         const int npairs = n * (n - 1) / 2, ntri = n * (n - 1) * (n - 2) / 6;
         const int *cy = cand_y + d.c0;
         for (int j = threadIdx.x; j < n; j += T) cy_s[j] = cy[j];
@@ -2832,7 +3186,8 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
             if (q < npairs) {
                 const unsigned short ij = g_pair_ij[q];
                 pi[s] = ij & 255; pj[s] = ij >> 8;
-                label_thresholds_tab((i64)cy_s[pj[s]] - cy_s[pi[s]] + 1, thr_tab, h_table, h_len, tau, &th_hi[s], &th_lo[s]);
+                if (pre) { const int2 th = pair_thr_g[d.pair_off + q]; th_hi[s] = th.x; th_lo[s] = th.y; }
+                else label_thresholds_tab((i64)cy_s[pj[s]] - cy_s[pi[s]] + 1, thr_tab, h_table, h_len, tau, &th_hi[s], &th_lo[s]);
             }
         }
         if (threadIdx.x < n) {
@@ -2847,13 +3202,20 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
         //      densely (fewer 64-read rounds), and each of those arrives with the exons that meet the window already located:
         //      exons are ordered, so they are consecutive -- the first with te >= cand_0 up to the last with ts < cand_{n-1}.
         const int cp0 = d.g0 + cy_s[0], c_last = d.g0 + cy_s[n - 1];
-        int n_act = 0;
+        int n_act = n_pre;
+        if (!pre)
         for (int l0 = 0; l0 < d.lane_n; l0 += T) {
             const int l = l0 + (int)threadIdx.x;
             const bool in = l < d.lane_n;
+#ifdef FSEG_ABLATE_COV
+            const longlong2 ex = make_longlong2(0, 0);               // diagnostic (wrong results): no exon access at all, two lanes in three kept
+            const int n_ex = 0;
+            int first_rel = 0, cnt = (l % 3) != 2;
+#else
             const longlong2 ex = lane_ex[d.lane_lo + (in ? l : 0)];
             const int n_ex = (int)(ex.y - ex.x);                     // (a read's exons: 32-bit counts from here on)
             int first_rel = 0, cnt = 0;
+#endif
             for (int eb = 0; eb < n_ex; eb += 8) {                   // eight exons per round from clamped addresses, in flight together
                 int ts8[8], te8[8];
                 load_exons8(ex_ts + ex.x + eb, ts8); load_exons8(ex_te + ex.x + eb, te8);
@@ -2880,6 +3242,7 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
             n_act += tot;
             __syncthreads();
         }
+        if (SPLIT && !pre && wide_cand && threadIdx.x == 0) nact_g[p] = n_act;                       // (k_dpw decides as this kernel does; both instances count the same)
         if (wide_cand && !wide_by_seen && (sizeof(CntT) == 1) != (n_act <= kFuseLanes)) continue;      // (workgroup-uniform)
         FSEG_STICK(1);
         // this thread's share of a round's coverage: read r_lane, candidates [ja, jb) of 1 .. n-1 (at most kCovJ of them)
@@ -2894,13 +3257,36 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
             // ---- A: window coverage cov[r][j] = positions of the read's closed exons in [cand_0, cand_j)
             //      (get_cumulative_coverage :188-246) = sum over its exons of |[ts, te] n [cand_0, cand_j)|, over the few exons that
             //      meet the window (two per step: their loads depend on nothing but the LDS record, so they fly together)
+            if (pre) {
+                // k_cover's rows of this round, a row per wave and step (lanes = candidates); eight loads in flight per thread
+                const unsigned *g_rows = cov_g + d.cov_off + (i64)r0 * n;
+                constexpr int kRows = kSub / NR;                     // rows per wave
+#pragma unroll
+                for (int b0 = 0; b0 < kRows; b0 += 8) {
+                    unsigned v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int rr = (b0 + u) * NR + w_rng;
+                        v[u] = g_rows[(rr < n_valid ? rr : 0) * n + (r_lane < n ? r_lane : 0)];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int rr = (b0 + u) * NR + w_rng;
+                        if (rr < n_valid && r_lane < n) cov[rr * rt_stride + r_lane] = v[u];
+                    }
+                }
+            } else
             {
                 const bool valid = r_lane < n_valid;
                 const int2 a = act_s[r0 + (valid ? r_lane : 0)];
                 int acc[kCovJ];
 #pragma unroll
                 for (int u = 0; u < kCovJ; ++u) acc[u] = 0;
+#ifdef FSEG_ABLATE_COV
+                const int e_end = 0;
+#else
                 const int e_end = valid ? a.y : 0;
+#endif
                 for (int e = 0; e < e_end; e += 4) {
                     // four exons per round trip (what lies beyond the read's own exons is masked below; the arrays are padded);
                     // the second pair is worked on only if some read of the wave has it
@@ -2928,6 +3314,7 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
             const int nv1 = n_valid - 32;
             const unsigned valid0 = n_valid >= 32 ? 0xffffffffu : (n_valid > 0 ? ~(0xffffffffu >> n_valid) : 0u);
             const unsigned valid1 = nv1 >= 32 ? 0xffffffffu : (nv1 > 0 ? ~(0xffffffffu >> nv1) : 0u);
+            uint4 pl[C::kSlots];
 #pragma unroll
             for (int s = 0; s < C::kSlots; ++s) {
                 const int q = s * T + threadIdx.x;
@@ -2969,9 +3356,14 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
                     }
 #undef FSEG_SHIFT_IN
                     y0 &= valid0; z0 &= valid0; y1 &= valid1; z1 &= valid1;     // rows beyond the problem's reads hold nothing
-                    planes[q] = make_uint4(y0, y1, z0, z1);
+                    if (FSEG_LDS_OVERLAY) pl[s] = make_uint4(y0, y1, z0, z1); else planes[q] = make_uint4(y0, y1, z0, z1);
                     amb_acc[s] += __popc(~(y0 | z0) & valid0) + __popc(~(y1 | z1) & valid1);
                 }
+            }
+            if (FSEG_LDS_OVERLAY) {
+                lds_barrier();                                                  // everybody has read the coverage: its LDS becomes the planes
+#pragma unroll
+                for (int s = 0; s < C::kSlots; ++s) { const int q = s * T + threadIdx.x; if (q < npairs) planes[q] = pl[s]; }
             }
             lds_barrier();
             FSEG_STICK(3);
@@ -3024,18 +3416,126 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
 #pragma unroll
         for (int s = 0; s < C::kSlots; ++s) in_val[s] = -(int)((i64)amb_acc[s] + (th_lo[s] < 0 ? (i64)d.outside + (d.lane_n - n_act) : 0));
         __syncthreads();
+        if constexpr (SPLIT) {
+            // hand-over: in() per pair (kDeadPair where the segment is too small, :540; the pair (0, end) keeps its value: it is
+            // "no cut", :560, and never a link) and the count table as it lies (whose counters these are follows from the reads
+            // the problem keeps: k_dpw decides as this kernel did)
+            int *g_in = reinterpret_cast<int *>(slot + kDpxHeader);
+#pragma unroll
+            for (int s = 0; s < C::kSlots; ++s) {
+                const int q = s * T + threadIdx.x;
+                if (q < npairs) {
+                    const bool dead = cy_s[pj[s]] - cy_s[pi[s]] < 5 && !(pi[s] == 0 && pj[s] == n - 1);
+                    g_in[q] = dead ? kDeadPair : in_val[s];
+                }
+            }
+            {
+                uint4 *g_out = reinterpret_cast<uint4 *>(slot + kDpxHeader + dpx_in_bytes(nm));
+                const uint4 *l_out = reinterpret_cast<const uint4 *>(cnt);
+                for (int x = threadIdx.x; x < (ntri * (int)sizeof(CntT) + 15) / 16; x += T) g_out[x] = l_out[x];
+            }
+            FSEG_STICK(9);
+        } else if constexpr (kWaveDp) {
+            // the pairs' owners hand each pair over whole: in(b,c), or kDeadPair where the segment is too small (:540; the pair
+            // (0, end) keeps its value: it is "no cut", :560, and never a link), and c
+#pragma unroll
+            for (int s = 0; s < C::kSlots; ++s) {
+                const int q = s * T + threadIdx.x;
+                if (q < npairs) {
+                    const bool dead = cy_s[pj[s]] - cy_s[pi[s]] < 5 && !(pi[s] == 0 && pj[s] == n - 1);
+                    in_s[q] = dead ? kDeadPair : in_val[s];
+                    A[q] = (unsigned char)pj[s];
+                }
+            }
+            __syncthreads();
+            FSEG_STICK(9);
+            // The other waves are done with this problem.  When every problem of the list has a workgroup of its own (the usual
+            // launch) they END here, and what they held is free for the next workgroup while wave 0 walks the DP's chain; else
+            // they go on to the next problem's descriptor and wait at the barrier at the top of the loop.
+            if (w_rng != 0) { if (own_wg) return; continue; }
+#ifdef FSEG_ABLATE_DP
+            if (own_wg) return;          // diagnostic (wrong results): what the stage takes when a workgroup's LDS is free once its rounds are over
+#endif
+            const int chain = dp_solve_wave<NM>(n, cnt, in_s, M, A, support, chosen + d.c0 FSEG_DARG);
+            if (threadIdx.x == 0) pr.chain[p] = chain;
+        } else {
 #pragma unroll
         for (int s = 0; s < C::kSlots; ++s) { const int q = s * T + threadIdx.x; if (q < npairs) in_s[q] = in_val[s]; }
         __syncthreads();
         FSEG_STICK(9);
         const int chain = dp_solve_push<T, NM>(n, cnt, in_s, M, A, cy_s, support, chosen + d.c0 FSEG_DARG);
         if (threadIdx.x == 0) pr.chain[p] = chain;
+        }
 #ifdef FSEG_SCORE_TIMING
         if (threadIdx.x == 0) FSEG_PROB_TICK(p, t_prob0, d.lane_n, n_act);
 #endif
     }
 #undef FSEG_STICK
     if (NM == kNMax && sizeof(CntT) == 1 && threadIdx.x == 0) atomicAdd(&st->gate_done, 1u);     // ended: see k_gate
+}
+
+// ---------------------------------------------------------------------------------------------
+// The DP of the problems k_solve<.., SPLIT> has handed over: ONE WAVE per problem (a workgroup of one wave), the problem's
+// in() and count table copied from its slot into LDS, then dp_solve_wave.  Why a launch of its own: a k_solve workgroup
+// holds 25 KB (mid class) to 55-78 KB (large) of LDS and its DP needs a third of that and one wave of its four or eight;
+// as the tail of the same workgroup (round 4's first version: the other waves ended early, which frees their registers --
+// tools/probes/exit_probe.hip -- but not the workgroup's LDS) the large class's 385 workgroups sat on half of the chip's
+// LDS for the 20-25 us of their DPs while the mid class waited for room (tools/prob_ticks.py: 250 mid-class problems in
+// flight beside them, 1 250 once they were gone).  OutT says whose problems: the 8-bit instance's or the 16-bit one's.
+// ---------------------------------------------------------------------------------------------
+inline size_t dpw_lds_for(int nm, int key_bytes, int cnt_bytes) {
+    const size_t pairs = (size_t)nm * (nm - 1) / 2, tri = (size_t)nm * (nm - 1) * (nm - 2) / 6;
+    return ((pairs * key_bytes + 15) & ~(size_t)15) + ((pairs * 4 + 15) & ~(size_t)15) + ((pairs + 15) & ~(size_t)15) + ((tri * cnt_bytes + 15) & ~(size_t)15);
+}
+template <int NM, typename OutT, typename V>
+__global__ void __launch_bounds__(64) k_dpw(Status *st, int nm, i64 list_base, i64 list_n, ProblemArrays pr, const ProbDesc *desc,
+                                            const unsigned char *dpx, i64 dpx_stride, const int *__restrict__ nact_g, int wide_by_seen,
+                                            int support, unsigned char *chosen FSEG_TPARAM) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = lane_id();
+    const i64 t = blockIdx.x;
+    if (t >= list_n) return;
+#ifdef FSEG_SCORE_TIMING
+    const unsigned long long t_dp0 = wall_clock64();
+#endif
+    const unsigned char *slot = dpx + t * dpx_stride;
+    const ProbDesc d = FSEG_LOAD_DESC(desc + list_base + t);
+    const int n = d.n;
+    if (n > nm || n > NM || n < 3 || d.lane_n > kFuseLanesWide) return;         // (k_solve has raised the error)
+    {   // whose problem: the 8-bit instance's if it keeps at most kFuseLanes reads (FSEG_WIDE_BY_SEEN: if it sees at most that many)
+        const bool wide = wide_by_seen ? d.lane_n > kFuseLanes : (d.lane_n > kFuseLanes && nact_g[d.w0] > kFuseLanes);
+        if (wide != (sizeof(OutT) != 1)) return;
+    }
+    const int npairs = n * (n - 1) / 2, ntri = n * (n - 1) * (n - 2) / 6;
+    const int rt_pairs = nm * (nm - 1) / 2;
+    V *M = reinterpret_cast<V *>(smem);
+    int *in_s = reinterpret_cast<int *>(smem + (((size_t)rt_pairs * sizeof(V) + 15) & ~(size_t)15));
+    unsigned char *A = reinterpret_cast<unsigned char *>(in_s) + (((size_t)rt_pairs * 4 + 15) & ~(size_t)15);
+    OutT *out_s = reinterpret_cast<OutT *>(A + (((size_t)rt_pairs + 15) & ~(size_t)15));
+    {
+        const int *g_in = reinterpret_cast<const int *>(slot + kDpxHeader);
+        for (int q = lane; q < npairs; q += 64) { in_s[q] = g_in[q]; A[q] = (unsigned char)(g_pair_ij[q] >> 8); }
+        const uint4 *g_out = reinterpret_cast<const uint4 *>(slot + kDpxHeader + dpx_in_bytes(nm));
+        uint4 *l_out = reinterpret_cast<uint4 *>(out_s);
+        const int n16 = (ntri * (int)sizeof(OutT) + 15) / 16;
+        for (int x0 = 0; x0 < n16; x0 += 64 * 8) {                              // eight 16-byte loads per lane in flight
+            uint4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int x = x0 + u * 64 + lane; v[u] = g_out[x < n16 ? x : 0]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int x = x0 + u * 64 + lane; if (x < n16) l_out[x] = v[u]; }
+        }
+    }
+    dp_sync<64>();
+#ifdef FSEG_SCORE_TIMING
+    __shared__ unsigned long long tick_sink[16];
+    unsigned long long *dp_tacc = tick_sink; unsigned long long dt_prev = 0;
+#endif
+    const int chain = dp_solve_wave<NM>(n, out_s, in_s, M, A, support, chosen + d.c0 FSEG_DARG);
+    if (lane == 0) pr.chain[d.w0] = chain;
+#ifdef FSEG_SCORE_TIMING
+    if (lane == 0 && (size_t)d.w0 < kTaccProbs) { unsigned long long *r_ = tacc + 16 + 4 * kTaccProbs + 4 * (size_t)d.w0; r_[0] = wall_clock64() - t_dp0; r_[3] = t_dp0; }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -4034,6 +4534,13 @@ struct fseg_ctx {
     DevBuf d_prob_iv, d_prob_start, d_prob_n, d_prob_pair_off, d_prob_tri_off, d_prob_flags, d_prob_chain,
         d_prob_cov_off, d_prob_lane_lo, d_prob_lane_n;
     DevBuf d_dp_items, d_solve_items, d_solve_desc, d_prob_desc, d_work_pc, d_cls_items, d_work_active, d_pair_thr, d_amb, d_out, d_cov;
+    // hand-over arena between k_solve<.., SPLIT> and k_dpw (dpx_slot_bytes per problem of the three solve lists), laid out by
+    // alloc_arenas() for the counts it knew: a launch takes the split path only for a list that fits what was laid out
+    DevBuf d_dpx, d_prob_nact;   // (d_prob_nact: reads every solve-list problem keeps, counted by k_cover)
+    i64 dpx_base[3] = {0, 0, 0}, dpx_stride[3] = {0, 0, 0}, dpx_n[3] = {0, 0, 0};
+    int dpx_nm = 0, dpx_cnt[3] = {1, 1, 1};
+    bool precover = false;      // FSEG_PRECOVER=1: k_cover computes thresholds, kept reads and coverage rows ahead of k_solve (measured slower: DESIGN section 8)
+    int split_dp = 7;           // FSEG_SPLIT_DP: bit 0 / 1 / 2 = the small / mid / large class hands its DPs to k_dpw (0: the DP stays the tail of k_solve's workgroups)
     i64 prob_cap = 0, work_cap = 0, pair_cap = 0, tri_cap = 0, label_cap = 0, chunk_cap = 0, cov_cap = 0;
     DevBuf d_status, d_prep, d_tacc;
     Status *h_status = nullptr;   // pinned
@@ -4078,7 +4585,7 @@ struct fseg_ctx {
     bool force_key64 = false;
     bool wide_by_seen = false;  // FSEG_WIDE_BY_SEEN=1 (tests)
     int gate_done_pct = 60;     // FSEG_GATE_DONE_PCT: the share of the large class's workgroups that has to have ended for 'd' in the plan
-    char score_plan[32] = "BM|gTS|b|ms";   // FSEG_SCORE_PLAN (see enqueue_run; anything that does not name each class once = one stream)
+    char score_plan[32] = "gM|B|gTS|bms";  // FSEG_SCORE_PLAN (see enqueue_run; anything that does not name each class once = one stream)
     bool score_fork = false;    // FSEG_SCORE_FORK=1: the fused scoring kernels on a stream each
     bool use_wave = true;       // FSEG_NO_WAVE=1: k_tiny / k_solve<16> instead of the wave kernels (k_wave)
     bool wave_small = false;    // FSEG_WAVE_SMALL=1: the small class (9 .. 16 candidates) goes to k_wave<16> instead of k_solve<16> (one wave
@@ -4100,6 +4607,7 @@ struct fseg_ctx {
     bool counts_known = false;
     i64 n_solve[3] = {0, 0, 0}, n_cls_work[4] = {0, 0, 0, 0}, n_dp_cls[3] = {0, 0, 0}, n_arena_prob = 0, n_tiny = 0;
     i64 n_wide[3] = {0, 0, 0};  // of n_solve: problems that need the 16-bit-counter instances
+    i64 max_ln = 0;             // reads the widest problem of the batch sees
     i64 tiny_from = 256;        // problems above which k_tiny is used (FSEG_TINY_FROM; tests force 0)
     bool trace = false;         // FSEG_TRACE=1: phase timers of upload / run on stderr
     bool force_global_sort = false;   // FSEG_GLOBAL_SORT=1 (tests): the batch-wide radix sort whatever the partition sizes
@@ -4217,6 +4725,7 @@ int alloc_arenas(fseg_ctx *c) {
     cv.add(c->d_prob_tri_off, (size_t)c->prob_cap * 8);
     cv.add(c->d_prob_flags, (size_t)c->prob_cap * 4);
     cv.add(c->d_prob_chain, (size_t)c->prob_cap * 4);
+    cv.add(c->d_prob_nact, (size_t)c->prob_cap * 4);
     cv.add(c->d_dp_items, (size_t)c->prob_cap * 4);
     cv.add(c->d_solve_items, (size_t)c->prob_cap * 4);
     cv.add(c->d_solve_desc, (size_t)c->prob_cap * sizeof(ProbDesc));
@@ -4231,6 +4740,20 @@ int alloc_arenas(fseg_ctx *c) {
     cv.add(c->d_pair_thr, (size_t)c->pair_cap * 8);
     cv.add(c->d_amb, (size_t)c->pair_cap * 4);
     cv.add(c->d_out, (size_t)c->tri_cap * 4);
+    {
+        size_t bytes = 0;
+        const int nms[3] = {kClsSmall, kClsMid, c->nm_big};
+        for (int q = 0; q < 3; ++q) {
+            const bool on = ((c->split_dp >> q) & 1) && c->counts_known && c->use_fuse && c->fuse_on && c->n_solve[q] > 0;
+            c->dpx_cnt[q] = (c->wide_solve && c->n_wide[q] > 0) ? 2 : 1;
+            c->dpx_stride[q] = (i64)dpx_slot_bytes(nms[q], c->dpx_cnt[q]);
+            c->dpx_n[q] = on ? c->n_solve[q] : 0;
+            c->dpx_base[q] = (i64)bytes;
+            bytes += (size_t)c->dpx_n[q] * (size_t)c->dpx_stride[q];
+        }
+        c->dpx_nm = c->nm_big;
+        cv.add(c->d_dpx, bytes);
+    }
     TRY(reserve(c, c->slab_arena, cv.total));
     cv.bind(c->slab_arena);
     TRY(ensure(c, c->d_labels, (size_t)c->label_cap + 16));
@@ -4421,16 +4944,21 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
     }   // do_pre2
     if (do_score) begin(ST_SCORE);
     if (do_score && c->prob_cap > 0) {
-        // How the four fused scoring kernels share the chip is a plan (FSEG_SCORE_PLAN, default "BM|gTS|b|ms"): streams separated
-        // by '|' (the first is the main stream); B M S T = the large / mid / small / tiny class's kernel, b m s = their 16-bit
-        // counter instances, g = k_gate (wait until the large class's workgroups are placed), d = k_gate on the share of them
-        // that has ended (FSEG_GATE_DONE_PCT), e = wait for the large class to end.  Measured on config4 (250 k-read batch, stage
-        // alone): all four on the main stream 0.192-0.209 ms; a stream each without a gate 0.208-0.212 (the dispatcher then runs
-        // them in the reverse of their launch order: a large-class workgroup needs eight wave slots and half a CU's LDS at once and
-        // gets neither until the small classes have drained); "BM|gTS" 0.161-0.175: the tiny class runs in the large class's
-        // shadow, which is all that fits there (the large class holds three quarters of the registers), the small class beside the
-        // mid class.  "BM|gS|eT", "BM|gT|eS", "B|gM|gS|gT", "BS|gM|gT": 0.179-0.197.  Anything that does not name each class
-        // once, batches with arena-path problems and small batches: one stream (FSEG_SCORE_FORK=1: a stream each, as until round 3).
+        // How the scoring kernels share the chip is a plan (FSEG_SCORE_PLAN, default "gM|B|gTS|bms"): streams separated by '|'
+        // (the first is the main stream); B M S T = the large / mid / small / tiny class -- a class on the split path is
+        // k_solve (rounds) followed by k_dpw (its DPs), 8-bit then 16-bit instance --, b m s = the 16-bit-counter instances of
+        // classes that are NOT on the split path, g = k_gate (wait until the large class's workgroups are placed), d = k_gate on
+        // the share of them that has ended (FSEG_GATE_DONE_PCT), e = wait for the large class to end.  Measured on config4
+        // (250 k-read batch, stage alone, tools/r4_plans.sh, profiles/r04_config4_plans.txt):
+        //   * everything on the main stream 0.19-0.21 ms; a stream each without a gate 0.21 (the dispatcher runs them in the
+        //     reverse of their launch order: a large-class workgroup needs eight wave slots and half a CU's LDS at once);
+        //   * round 3's "BM|gTS" 0.161-0.165: the tiny class in the large class's shadow, then small beside mid;
+        //   * a cross-stream dependency costs ~9 us (fork or join), so the chain that ends LAST belongs on the main stream,
+        //     where the stage's end needs no join: the mid class (gate, rounds, DPs) on main, the large class on a side stream
+        //     of its own, tiny + small on a third: 0.144-0.149 with the split path ("B|gM|gTS", the same chains with the large
+        //     class on main: 0.154-0.167; per-problem clocks, tools/r4_ticks.sh: 133 us from first start to last end either way).
+        // Anything that does not name each class once, batches with arena-path problems and small batches: one stream
+        // (FSEG_SCORE_FORK=1: a stream each, as until round 3).
         const bool any_solve_plan = c->use_fuse && c->fuse_on;
         const char *plan = (known && !any_arena && !c->small_batch && forking && c->n_solve[2] > 0 && any_solve_plan && wave && !(wave && c->wave_small) && c->score_plan[0]) ? c->score_plan : nullptr;
         const bool sfork = c->score_fork || any_arena;              // (the arena path's work-item kernels keep their streams)
@@ -4457,18 +4985,60 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
                            c->d_cand_y.as<int>(), c->d_work_active.as<unsigned char>(), c->d_cov.as<unsigned>(),        \
                            c->cov_cap, c->d_pair_thr.as<int2>(), c->pair_cap, c->d_out.as<unsigned>(), c->tri_cap,      \
                            c->d_amb.as<unsigned>() FSEG_TARG)
-#define FSEG_LAUNCH_SOLVE(Q, NMV, CNT, VT, CLS, N_ITEMS, MAXWG)                                                              \
-            hipLaunchKernelGGL((k_solve<NMV, CNT, VT>), dim3(grid_for((N_ITEMS), 1, (MAXWG))), dim3(SolveCfg<NMV>::kThreads),       \
-                               solve_lds_for((NMV) == kNMax ? c->nm_big : (NMV), (NMV) + 1, (int)sizeof(CNT)), Q, st, CLS,      \
-                               ((NMV) == kNMax ? c->nm_big : (NMV)), list_lb(CLS), list_ln(CLS), pr, c->d_solve_desc.as<ProbDesc>(), \
+#define FSEG_SOLVE_ARGS(NMV, CLS)                                                                                           \
+                               st, CLS, ((NMV) == kNMax ? c->nm_big : (NMV)), list_lb(CLS), list_ln(CLS), pr, c->d_solve_desc.as<ProbDesc>(), \
                                c->prob_cap, c->d_cand_y.as<int>(), c->d_lane_ex.as<longlong2>(), c->d_ex_ts.as<int>(),         \
                                c->d_ex_te.as<int>(), c->d_h_table.as<double>(), c->P.h_len, c->P.threshold_rate,               \
                                c->d_thr_tab.as<int2>(), c->P.min_read_support_outside, c->d_chosen.as<unsigned char>(),       \
-                               (c->wide_by_seen ? 1 : 0) FSEG_TARG)
+                               (c->wide_by_seen ? 1 : 0)
+        // the split path (k_solve<.., SPLIT> then k_dpw on the same stream) for a list that fits the hand-over arena as laid out
+        const bool pre_on = FSEG_PRECOVER && c->precover && wave;    // (k_cover reads the lane-ordered exon stream)
+        auto split_ok = [&](int cls, int cnt_bytes) {
+            return known && cls >= 0 && cls < 3 && ((c->split_dp >> cls) & 1) && c->dpx_n[cls] > 0 && c->n_solve[cls] <= c->dpx_n[cls] && c->dpx_nm == c->nm_big &&
+                   cnt_bytes <= c->dpx_cnt[cls] && c->d_dpx.p != nullptr;
+        };
+#define FSEG_LAUNCH_SOLVE(Q, NMV, CNT, VT, CLS, N_ITEMS, MAXWG)                                                              \
+            hipLaunchKernelGGL((k_solve<NMV, CNT, VT, false>), dim3(grid_for((N_ITEMS), 1, known ? (1 << 20) : (MAXWG))), dim3(SolveCfg<NMV>::kThreads), \
+                               solve_lds_for((NMV) == kNMax ? c->nm_big : (NMV), (NMV) + 1, (int)sizeof(CNT)), Q,               \
+                               FSEG_SOLVE_ARGS(NMV, CLS), (unsigned char *)nullptr, (i64)0, (const int2 *)nullptr, (const unsigned *)nullptr, \
+                               (int *)nullptr FSEG_TARG)
+        // the split path, one instance: k_solve<.., SPLIT> (rounds only, on k_cover's rows) then k_dpw on the same stream
+#define FSEG_LAUNCH_SPLIT(Q, NMV, CNT, VT, CLS, N_ITEMS)                                                                     \
+        do { const int nm_rt = (NMV) == kNMax ? c->nm_big : (NMV);                                                            \
+            unsigned char *dpx0 = c->d_dpx.as<unsigned char>() + c->dpx_base[(CLS) < 0 ? 0 : (CLS)];                                           \
+            const i64 dstride = c->dpx_stride[(CLS) < 0 ? 0 : (CLS)];                                                                       \
+            hipLaunchKernelGGL((k_solve<NMV, CNT, int, true>), dim3(grid_for((N_ITEMS), 1, 1 << 20)), dim3(SolveCfg<NMV>::kThreads), \
+                               solve_lds_for(nm_rt, (NMV) + 1, (int)sizeof(CNT)), Q, FSEG_SOLVE_ARGS(NMV, CLS), dpx0, dstride,    \
+                               pre_on ? c->d_pair_thr.as<int2>() : (const int2 *)nullptr, pre_on ? c->d_cov.as<unsigned>() : (const unsigned *)nullptr, \
+                               c->d_prob_nact.as<int>() FSEG_TARG);                                                           \
+            hipLaunchKernelGGL((k_dpw<NMV, CNT, VT>), dim3(grid_for((N_ITEMS), 1, 1 << 20)), dim3(64),                         \
+                               dpw_lds_for(nm_rt, (int)sizeof(VT), (int)sizeof(CNT)), Q, st, nm_rt, list_lb(CLS), list_ln(CLS), pr,  \
+                               c->d_solve_desc.as<ProbDesc>(), dpx0, dstride, c->d_prob_nact.as<int>(), (c->wide_by_seen ? 1 : 0), \
+                               c->P.min_read_support_outside, c->d_chosen.as<unsigned char>() FSEG_TARG); } while (0)
+#define FSEG_LAUNCH_COVER(Q, NW, NMV, CLS, N_ITEMS)                                                                          \
+            hipLaunchKernelGGL((k_cover<NW, (NMV) * ((NMV) - 1) / 2>), dim3(grid_for((N_ITEMS), 1, 1 << 20)), dim3(64 * (NW)), 0, Q, st, \
+                               ((NMV) == kNMax ? c->nm_big : (NMV)), list_lb(CLS), list_ln(CLS), c->d_solve_desc.as<ProbDesc>(), \
+                               c->d_cand_y.as<int>(), c->d_lane_lx.as<int2>(), c->d_lex.as<int2>(),                             \
+                               c->d_h_table.as<double>(), c->P.h_len, c->P.threshold_rate, c->d_thr_tab.as<int2>(),             \
+                               c->d_pair_thr.as<int2>(), c->pair_cap, c->d_cov.as<unsigned>(), c->cov_cap, c->d_prob_nact.as<int>() FSEG_TARG)
         // 32-bit DP keys (dp_solve_push) when no sum of a chain can reach 2^24: at most 32 links times the reads of the largest partition
         // (WHICH: 1 = the instance with 8-bit counters, 2 = the one with 16-bit counters if the class has problems for it, 3 = both)
+#define FSEG_LAUNCH_SPLIT_K(Q, NMV, CNT, CLS, N_ITEMS)                                                                        \
+            do { if (key32) FSEG_LAUNCH_SPLIT(Q, NMV, CNT, int, CLS, N_ITEMS); else FSEG_LAUNCH_SPLIT(Q, NMV, CNT, i64, CLS, N_ITEMS); } while (0)
 #define FSEG_LAUNCH_SOLVE_X(Q, NMV, CLS, N_ITEMS, MAXWG, WHICH)                                                              \
-            do { if (key32) { if ((WHICH) & 1) FSEG_LAUNCH_SOLVE(Q, NMV, unsigned char, int, CLS, N_ITEMS, MAXWG);              \
+            do { if (split_ok(CLS, FSEG_WIDE_NEEDED(CLS) ? 2 : 1)) {                                                            \
+                     if (pre_on) {       /* k_cover's rows serve both instances: the class runs whole where its 8-bit instance does */ \
+                         if ((WHICH) & 1) {                                                                                    \
+                             if ((NMV) <= kClsSmall) FSEG_LAUNCH_COVER(Q, 2, NMV, CLS, N_ITEMS);                                 \
+                             else FSEG_LAUNCH_COVER(Q, 4, NMV, CLS, N_ITEMS);                                                   \
+                             FSEG_LAUNCH_SPLIT_K(Q, NMV, unsigned char, CLS, N_ITEMS);                                           \
+                             if (FSEG_WIDE_NEEDED(CLS)) FSEG_LAUNCH_SPLIT_K(Q, NMV, unsigned short, CLS, N_ITEMS);                \
+                         }                                                                                                     \
+                     } else {                                                                                                  \
+                         if ((WHICH) & 1) FSEG_LAUNCH_SPLIT_K(Q, NMV, unsigned char, CLS, N_ITEMS);                              \
+                         if (((WHICH) & 2) && FSEG_WIDE_NEEDED(CLS)) FSEG_LAUNCH_SPLIT_K(Q, NMV, unsigned short, CLS, N_ITEMS);   \
+                     }                                                                                                         \
+                 } else if (key32) { if ((WHICH) & 1) FSEG_LAUNCH_SOLVE(Q, NMV, unsigned char, int, CLS, N_ITEMS, MAXWG);              \
                               if (((WHICH) & 2) && FSEG_WIDE_NEEDED(CLS)) FSEG_LAUNCH_SOLVE(Q, NMV, unsigned short, int, CLS, N_ITEMS, MAXWG); } \
                  else { if ((WHICH) & 1) FSEG_LAUNCH_SOLVE(Q, NMV, unsigned char, i64, CLS, N_ITEMS, MAXWG);                    \
                         if (((WHICH) & 2) && FSEG_WIDE_NEEDED(CLS)) FSEG_LAUNCH_SOLVE(Q, NMV, unsigned short, i64, CLS, N_ITEMS, MAXWG); } } while (0)
@@ -4552,7 +5122,11 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
         }
 #undef FSEG_LAUNCH_SOLVE_W
 #undef FSEG_LAUNCH_SOLVE_X
+#undef FSEG_LAUNCH_SPLIT_K
+#undef FSEG_LAUNCH_SPLIT
+#undef FSEG_LAUNCH_COVER
 #undef FSEG_LAUNCH_SOLVE
+#undef FSEG_SOLVE_ARGS
 #undef FSEG_LAUNCH_SCORE
         if (tiny_max > 0 && !plan) {
             // the problems with a handful of candidates, whole (coverage, labels, counts, DP), beside the others (launched
@@ -4736,6 +5310,7 @@ void adapt_to(fseg_ctx *c, const Status &s) {
     const bool old_fuse = c->fuse_on;
     c->fuse_on = (i64)s.max_ln <= c->fuse_lanes;                 // (the widest problem does not depend on the split either)
     c->wide_solve = (i64)s.max_ln > kFuseLanes;                  // some problem needs the 16-bit counters
+    c->max_ln = (i64)s.max_ln;
     if (old_fuse != c->fuse_on) { c->counts_known = false; drop_graph(c); }
     c->prob_self_scan = (i64)s.n_cand <= c->prob_self_max;
     {   // the big-problem LDS carve-up: the largest problem (+ headroom, multiple of 4)
@@ -4957,18 +5532,19 @@ int fseg_create(int device, fseg_ctx **out) {
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_score_huge), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)kHugeScoreLds);
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve<kNMax, unsigned char, int>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)solve_lds_for(kNMax, kNMax + 1, 1));
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve<kNMax, unsigned char, i64>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)solve_lds_for(kNMax, kNMax + 1, 1));
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve<kNMax, unsigned short, int>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)solve_lds_for(kNMax, kNMax + 1, 2));
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_solve<kNMax, unsigned short, i64>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)solve_lds_for(kNMax, kNMax + 1, 2));
+    {
+        auto lds_attr = [&](const void *f, size_t bytes) { if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes); };
+        lds_attr(reinterpret_cast<const void *>(k_solve<kNMax, unsigned char, int, false>), solve_lds_for(kNMax, kNMax + 1, 1));
+        lds_attr(reinterpret_cast<const void *>(k_solve<kNMax, unsigned char, i64, false>), solve_lds_for(kNMax, kNMax + 1, 1));
+        lds_attr(reinterpret_cast<const void *>(k_solve<kNMax, unsigned short, int, false>), solve_lds_for(kNMax, kNMax + 1, 2));
+        lds_attr(reinterpret_cast<const void *>(k_solve<kNMax, unsigned short, i64, false>), solve_lds_for(kNMax, kNMax + 1, 2));
+        lds_attr(reinterpret_cast<const void *>(k_solve<kNMax, unsigned char, int, true>), solve_lds_for(kNMax, kNMax + 1, 1));
+        lds_attr(reinterpret_cast<const void *>(k_solve<kNMax, unsigned short, int, true>), solve_lds_for(kNMax, kNMax + 1, 2));
+        lds_attr(reinterpret_cast<const void *>(k_dpw<kNMax, unsigned char, int>), dpw_lds_for(kNMax, 4, 1));
+        lds_attr(reinterpret_cast<const void *>(k_dpw<kNMax, unsigned short, int>), dpw_lds_for(kNMax, 4, 2));
+        lds_attr(reinterpret_cast<const void *>(k_dpw<kNMax, unsigned char, i64>), dpw_lds_for(kNMax, 8, 1));
+        lds_attr(reinterpret_cast<const void *>(k_dpw<kNMax, unsigned short, i64>), dpw_lds_for(kNMax, 8, 2));
+    }
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_dp_huge), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)kHugeDpLds);
@@ -4988,6 +5564,8 @@ int fseg_create(int device, fseg_ctx **out) {
     if (flag("FSEG_SCORE_FORK")) c->score_fork = true;
     if (flag("FSEG_FORCE_KEY64")) c->force_key64 = true;
     if (flag("FSEG_WIDE_BY_SEEN")) c->wide_by_seen = true;
+    if (const char *e = getenv("FSEG_SPLIT_DP")) c->split_dp = atoi(e) & 7;
+    if (flag("FSEG_PRECOVER")) c->precover = true;
     { const char *v = getenv("FSEG_GATE_DONE_PCT"); if (v && v[0] && atoi(v) > 0 && atoi(v) <= 100) c->gate_done_pct = atoi(v); }
     if (const char *e = getenv("FSEG_SCORE_PLAN")) snprintf(c->score_plan, sizeof c->score_plan, "%s", e);
     {
@@ -5664,6 +6242,11 @@ int fseg_debug_score_timing(fseg_ctx *c, unsigned long long *out8) {
 int fseg_debug_prob_ticks(fseg_ctx *c, unsigned long long *out4, long long n_prob) {     /* 4 values per problem */
     if (!c || !out4 || n_prob < 0 || (size_t)n_prob > kTaccProbs) return FSEG_ERR_ARG;
     if (hipMemcpy(out4, static_cast<char *>(c->d_tacc.p) + 128, (size_t)n_prob * 32, hipMemcpyDeviceToHost) != hipSuccess) return FSEG_ERR_HIP;
+    return FSEG_OK;
+}
+int fseg_debug_dp_ticks(fseg_ctx *c, unsigned long long *out4, long long n_prob) {       /* k_dpw's records: (ticks, -, -, start tick) */
+    if (!c || !out4 || n_prob < 0 || (size_t)n_prob > kTaccProbs) return FSEG_ERR_ARG;
+    if (hipMemcpy(out4, static_cast<char *>(c->d_tacc.p) + 128 + kTaccProbs * 32, (size_t)n_prob * 32, hipMemcpyDeviceToHost) != hipSuccess) return FSEG_ERR_HIP;
     return FSEG_OK;
 }
 int fseg_debug_timed_class(fseg_ctx *c, int cls) {

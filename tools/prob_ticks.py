@@ -53,4 +53,33 @@ for name, lo, hi in (("tiny (n<=8)", 0, 8), ("n<=16", 9, 16), ("n<=32", 17, 32),
     A = np.stack([np.ones(m.sum()), n[m], ln[m], na[m], n[m].astype(float) ** 2], 1)
     coef, *_ = np.linalg.lstsq(A, d, rcond=None)
     print("             fit us = %.1f + %.2f n + %.3f reads_examined + %.3f reads_kept + %.4f n^2" % tuple(coef))
+# k_dpw's records (the split path: the DP is a launch of its own)
+L.fseg_debug_dp_ticks.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong]
+drec = np.zeros((len(n), 4), np.uint64)
+L.fseg_debug_dp_ticks(ctx._h, drec.ctypes.data, len(n))
+ddur = drec[:, 0].astype(np.float64) / 100.0
+dt0 = drec[:, 3].astype(np.float64) / 100.0 - (rec[:, 3].astype(np.float64) / 100.0)[rec[:, 3] > 0].min()
+dend = dt0 + ddur
+have_dp = ddur > 0
+if have_dp.any():
+    for name, lo, hi in (("n<=16", 9, 16), ("n<=32", 17, 32), ("n<=60", 33, 60)):
+        m = (n >= lo) & (n <= hi) & have_dp
+        if m.any():
+            print("DP %-9s %5d problems: duration us  mean %.1f  p50 %.1f  p99 %.1f  max %.1f | start us p50 %.1f max %.1f | end max %.1f"
+                  % (name, m.sum(), ddur[m].mean(), np.percentile(ddur[m], 50), np.percentile(ddur[m], 99), ddur[m].max(),
+                     np.percentile(dt0[m], 50), dt0[m].max(), dend[m].max()))
+    print("stage span with the DPs: %.1f us" % max(end.max(), dend[have_dp].max()))
+# who is on the chip when: problems in flight per class every 10 us (a workgroup of 1 / 2 / 4 / 8 waves each until its DP)
+cls = (("tiny", 0, 8), ("small", 9, 16), ("mid", 17, 32), ("large", 33, 60))
+print("in flight at t us:   " + " ".join("%6s" % c[0] for c in cls) + "   DP: " + " ".join("%6s" % c[0] for c in cls[1:]))
+last = max(end.max(), dend[have_dp].max() if have_dp.any() else 0.0)
+for t in np.arange(0.0, last + 10.0, 10.0):
+    row, drow = [], []
+    for name, lo, hi in cls:
+        m = (n >= lo) & (n <= hi) & (dur > 0)
+        row.append(int(((t0[m] <= t) & (end[m] > t)).sum()))
+        if lo > 8:
+            md = (n >= lo) & (n <= hi) & have_dp
+            drow.append(int(((dt0[md] <= t) & (dend[md] > t)).sum()))
+    print("            %6.0f   " % t + " ".join("%6d" % v for v in row) + "       " + " ".join("%6d" % v for v in drow))
 ctx.close()

@@ -18,11 +18,26 @@ __global__ void __launch_bounds__(T) k_dp_probe(int n, const OutT *out_g, const 
     for (int i = threadIdx.x; i < n; i += T) cy_s[i] = cy_g[i];
     for (int i = threadIdx.x; i < npairs; i += T) in_s[i] = in_g[i];
     for (int i = threadIdx.x; i < ntri; i += T) out_s[i] = out_g[i];
+    __shared__ unsigned char c_s[NM * (NM - 1) / 2];
+    if constexpr (VARIANT == 2) {
+        __syncthreads();
+        for (int q = threadIdx.x; q < npairs; q += T) {
+            int b, c;
+            pair_decode(q, &b, &c);
+            c_s[q] = (unsigned char)c;
+            in_s[q] = (cy_s[c] - cy_s[b] < 5 && !(b == 0 && c == n - 1)) ? kDeadPair : in_s[q];
+        }
+    }
     __syncthreads();
     long long t0 = wall_clock64();
     unsigned long long dt_prev = t0;
     int chain = 0;
     for (int r = 0; r < reps; ++r) {
+        if constexpr (VARIANT == 2) {                                // k_solve's tail: one wave, the pairs handed over by their scoring owners
+            for (int q = threadIdx.x; q < npairs; q += T) A[q] = c_s[q];
+            __syncthreads();
+            if (threadIdx.x < 64) chain = dp_solve_wave<NM>(n, out_s, in_s, M, A, support, chosen_g + (size_t)blockIdx.x * 64 FSEG_DARG);
+        } else
         chain = dp_solve_push<T, NM>(n, out_s, in_s, M, A, cy_s, support, chosen_g + (size_t)blockIdx.x * 64 FSEG_DARG);
         __syncthreads();
     }
@@ -143,7 +158,7 @@ int main() {
     pingpong<512, 0>("barrier only"); pingpong<512, 1>("LDS write, barrier, LDS read"); pingpong<512, 2>("dependent LDS reads");
     pingpong<128, 0>("barrier only"); pingpong<128, 1>("LDS write, barrier, LDS read"); pingpong<64, 3>("LDS write, wave fence, LDS read");
     pingpong<1024, 1>("LDS write, barrier, LDS read");
-    for (int n : {49, 38, 30, 22, 14, 10, 8, 5, 3}) {
+    for (int n : {59, 49, 38, 32, 30, 22, 16, 14, 10, 8, 5, 3}) {
         std::mt19937 rng(7 + n);
         const int npairs = n * (n - 1) / 2, ntri = n * (n - 1) * (n - 2) / 6;
         std::vector<int> out(ntri), in(npairs), cy(n);
@@ -154,13 +169,18 @@ int main() {
         HostDp ref = host_dp(n, out, in, cy, support);
         printf("host: n=%d chain %d\n", n, ref.chain);
         if (n > 32) {
+            run<64, unsigned char, int, 2, 60>("dp_solve_wave<60,u8,int>", n, out, in, cy, support, ref);
+            run<64, unsigned short, int, 2, 60>("dp_solve_wave<60,u16,int>", n, out, in, cy, support, ref);
             run<512, unsigned char, int, 1, 60>("dp_solve_push<512,60,u8,int>", n, out, in, cy, support, ref);
             run<512, unsigned short, i64, 1, 60>("dp_solve_push<512,60,u16,i64>", n, out, in, cy, support, ref);
             run<1024, unsigned short, i64, 1, 60>("dp_solve_push<1024,60,u16,i64>", n, out, in, cy, support, ref);
         } else if (n > 16) {
+            run<64, unsigned char, int, 2, 32>("dp_solve_wave<32,u8,int>", n, out, in, cy, support, ref);
+            run<64, unsigned char, i64, 2, 32>("dp_solve_wave<32,u8,i64>", n, out, in, cy, support, ref);
             run<256, unsigned char, int, 1, 32>("dp_solve_push<256,32,u8,int>", n, out, in, cy, support, ref);
             run<512, unsigned char, int, 1, 32>("dp_solve_push<512,32,u8,int>", n, out, in, cy, support, ref);
         } else if (n > 8) {
+            run<64, unsigned char, int, 2, 16>("dp_solve_wave<16,u8,int>", n, out, in, cy, support, ref);
             run<128, unsigned char, int, 1, 16>("dp_solve_push<128,16,u8,int>", n, out, in, cy, support, ref);
             run<64, unsigned char, int, 1, 16>("dp_solve_push<64,16,u8,int>", n, out, in, cy, support, ref);
         } else {

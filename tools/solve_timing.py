@@ -24,7 +24,8 @@ ctx = _lib.Context(0); ctx.set_params(**params, **tabs); ctx.set_profiling(True)
 L = _lib.load()
 L.fseg_debug_score_timing.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 L.fseg_debug_timed_class.argtypes = [ctypes.c_void_p, ctypes.c_int]
-names = {0: "wait/next", 1: "setup+thresholds", 2: "coverage", 3: "pairs", 4: "triples", 5: "dp block: slices", 8: "k_dp: wait/next", 9: "in_s", 10: "dp block: fix-up", 11: "dp top level", 12: "dp backtrack"}
+names = {0: "wait/next", 1: "setup+thresholds", 2: "coverage", 3: "pairs", 4: "triples", 8: "k_dp: wait/next", 9: "in_s / hand-over", 10: "dp columns", 11: "dp top level", 12: "dp backtrack",
+         6: "k_cover: descriptor", 7: "k_cover: thresholds", 13: "k_cover: pass 1", 5: "k_cover: prefix", 14: "k_cover: pass 2"}
 buf = np.zeros(16, np.uint64)
 for cls in ((2,) if wl == "config2" else (2, 1, 0)):
     L.fseg_debug_timed_class(ctx._h, cls)
@@ -34,7 +35,7 @@ for cls in ((2,) if wl == "config2" else (2, 1, 0)):
     for _ in range(N):
         ctx.run(); ctx.sync()
     L.fseg_debug_score_timing(ctx._h, buf.ctypes.data)
-    tot = float(buf[:13].sum())
+    tot = float(buf[:15].sum())
     print("class %d: scoring stage %.3f ms; ticks per run %.0f (100 MHz => %.1f us summed over workgroups)" % (cls, ctx.stage_ms()["interval_scoring"], tot / N, tot / N / 100.0))
     for k in sorted(names):
         print("   %-18s %5.1f%%" % (names[k], 100.0 * float(buf[k]) / max(tot, 1.0)))
