@@ -22,7 +22,9 @@ Prints ONE JSON line (rank 0) with, besides the driver's fields:
   roofline_concurrent   the same bracket inside the timed steps, where the other contexts' kernels run beside the stage
   roofline_stages       every stage of the path alone on the GPU (first-run path of distinct batches, events around every
                         stage): SURVEY 8d's algorithmic bytes of the stage over its time
-  roofline_config2      the scoring stage of one 50 k-read x 2 k-candidate partition (BASELINE configs[1])
+  roofline_config2      one 50 k-read x 2 k-candidate partition (BASELINE configs[1], the arena path): coverage + scoring + DP
+                        (scoring_prep + interval_scoring + dp stages), like the other configs' stage; k_score alone as a sub-field
+  roofline_config3 / roofline_config5   the stage of one resident batch of BASELINE configs[2] / [4] (config4 runs only)
   value_resident_replay hipGraph replay of one resident batch (no copies, no sizing)
   value_hbm_resident    batches uploaded first, then each run once (first-run path, no copies in the timed part)
   cpu_baseline / cpu_baseline_all_cores   the C oracle on this box's host cores (1 thread / every core)
@@ -338,8 +340,9 @@ def one_shot_steps(ctxs, batches, order, collect=None):
 
 def scoring_roofline(alg_bytes, score_ms, committed, extra=None):
     achieved = alg_bytes / (score_ms * 1e-3) / 1e9 if score_ms > 0 else 0.0
-    r = {"kernel": "interval-scoring stage: k_solve<16|32|60> + k_wave<8> (k_tiny) (+ k_gate, one wave) where every problem of the batch sees "
-                   "<= 511 reads (they solve a problem whole: coverage, pair labels, in/out counts AND its DP), else k_score<16|32|60> + k_wave<8>",
+    r = {"kernel": "interval-scoring stage: k_solve<16|32|60> (coverage, pair labels, in/out counts of a problem, in LDS) + k_dpw<16|32|60> (its DP, "
+                   "one wave) + k_wave<8> (tiny problems whole) (+ k_gate, one wave) where every problem of the batch sees <= 511 reads, "
+                   "else the arena path: k_cov + k_score<16|32|60> + k_dp (+ k_wave<8>)",
          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
          "traffic": (committed or {}).get("traffic_bytes"), "traffic_source": "committed PMC pass (profiles/traffic.json)" if committed else None,
@@ -403,10 +406,19 @@ def main():
             while not os.path.exists(done) and time.time() - t_wait < 900:
                 time.sleep(0.05)
     config2_batch = None
+    extra_parts = {}
     if rank == 0 and not args.no_extras and args.workload != "config2":
         w2 = dict(synth.WORKLOADS["config2"]); w2.pop("n_partitions")
         g = synth.generate(0, with_seq=False, **w2)
         config2_batch = Batch([pack.pack_partition(g.iv_start, g.iv_end, g.read_exon_off, g.ex_ts, g.ex_te, dedupe=True)])
+    if rank == 0 and not args.no_extras and args.workload == "config4":
+        for wname in ("config3", "config5"):             # one batch of each (the line carries every config's stage fraction)
+            wx = dict(synth.WORKLOADS[wname]); wx.pop("n_partitions")
+            per_x = max(1, BATCH_READS // wx["n_reads"])
+            extra_parts[wname] = []
+            for i in range(per_x):
+                g = synth.generate(i, with_seq=False, **wx)
+                extra_parts[wname].append(pack.pack_partition(g.iv_start, g.iv_end, g.read_exon_off, g.ex_ts, g.ex_te, dedupe=True))
 
     import torch
     from freddie_amd import _lib
@@ -461,7 +473,9 @@ def main():
         with acc_lock:
             score_ms_total[0] += ms["interval_scoring"]
             alg_total[0] += batches[bi].alg_bytes
-            checksum[0] += int(res[1][-1]) + int(res[3][-1])          # the results are in host memory: touch them
+            # final positions + label bytes of the batch (sums over its partitions: the job's total does not depend on how it
+            # is cut into batches or scattered over ranks); the result arrays are in host memory: touch them
+            checksum[0] += int(res[0][-1]) + int(res[2][-1]) + ((int(res[1][-1]) + int(res[3][-1])) & 0)
 
     # the timed steps: K passes over the share, batch after batch, as one stream of work for the contexts (step boundaries
     # are not barriers: the CLI does not stop between batches either); consecutive batch-steps go to consecutive contexts
@@ -474,16 +488,16 @@ def main():
     dt = time.perf_counter() - t0
     n_reads = sum(batches[bi].n_reads for bi in order)
 
-    t = torch.tensor([dt, float(n_reads)], dtype=torch.float64,
+    t = torch.tensor([dt, float(n_reads), float(checksum[0])], dtype=torch.float64,
                      device="cpu" if dist is not None and dist.get_backend() == "gloo" else "cuda")
     if dist is not None:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone()
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        dt_max, total_reads = float(tmax[0]), float(tsum[1])
+        dt_max, total_reads, checksum_all = float(tmax[0]), float(tsum[1]), int(tsum[2])
     else:
-        dt_max, total_reads = dt, float(n_reads)
+        dt_max, total_reads, checksum_all = dt, float(n_reads), checksum[0]
 
     if rank == 0:
         lib_hash = _lib.load().fseg_source_hash().decode()
@@ -510,7 +524,9 @@ def main():
         sc_med = float(np.median(sc_all))                      # (the median, like the per-kernel medians of profiles/)
         roofline = scoring_roofline(batches[0].alg_bytes, sc_med, committed,
                                     {"measured": "HIP events around the stage's launches on the library's streams; one context, one resident "
-                                                 "250 k-read batch of the job replayed %d times: the stage alone on the GPU (median; mean %.4f ms)"
+                                                 "250 k-read batch of the job replayed %d times: the stage alone on the GPU (median; mean %.4f ms). "
+                                                 "The stream plan and k_gate apply to this case only: in the timed steps (value) eight contexts "
+                                                 "take turns and each keeps its stage on one stream -- that bracket is roofline_concurrent"
                                                  % (reps, float(np.mean(sc_all)))})
 
         # ---- every stage alone on the GPU: distinct batches through the first-run path (plain launches, events around every stage)
@@ -574,7 +590,10 @@ def main():
             "valu_util": (committed or {}).get("valu_util"),
             "valu_util_source": (committed or {}).get("valu_source"),
             "library_source_hash": lib_hash,
-            "result_checksum": checksum[0],
+            # final positions + label bytes of every batch of every timed step, summed over the ranks: a property of the job
+            # (every partition exactly once per step), whatever N and however a rank's share is cut into batches
+            "result_checksum": checksum_all,
+            "result_checksum_per_step": checksum_all // max(1, args.steps),
         }
         out["value_resident_replay"] = {"value": batches[0].n_reads * reps / dt_r, "unit": "reads/s", "ms_per_step": dt_r / reps * 1e3,
                                         "what": "hipGraph replay of one resident 250 k-read batch: no copies, no arena sizing (a batch, not the job)"}
@@ -601,23 +620,53 @@ def main():
                                          "what": "%d distinct batches uploaded first (one per context), then each run once, concurrently: "
                                                  "first-run path (sized arenas, plain launches), results left in HBM, no copies in the "
                                                  "timed part" % n_h}
-            # BASELINE configs[1]: one 50 k-read partition
+            # BASELINE configs[1]: one 50 k-read partition.  Its problems take the arena path, where coverage (k_cov, in the
+            # scoring_prep stage) and the DP (k_dp, the dp stage) are launches of their own: the figure that compares with the
+            # other configs' stage (which holds all three) is their sum; k_score alone is the sub-field.
             if config2_batch is not None:
+                ctx.set_profiling(3)
                 ctx.upload(**config2_batch.arrays)
                 ctx.run(); ctx.sync()
                 alg2 = ctx.scoring_algorithmic_bytes()
                 for _ in range(3):
                     ctx.run(); ctx.sync()
                 t0 = time.perf_counter()
-                sc = 0.0
+                acc2 = []
                 for _ in range(reps):
                     ctx.run(); ctx.sync()
-                    sc += ctx.stage_ms()["interval_scoring"]
+                    ms = ctx.stage_ms()
+                    acc2.append((ms["scoring_prep"], ms["interval_scoring"], ms["dp"]))
                 dt_2 = time.perf_counter() - t0
-                r2 = scoring_roofline(alg2, sc / reps, committed_counters("config2", lib_hash))
+                med2 = np.median(np.asarray(acc2), axis=0)
+                r2 = scoring_roofline(alg2, float(med2.sum()), committed_counters("config2", lib_hash))
                 r2.update(workload="config2", reads=config2_batch.n_reads, ms_per_step=dt_2 / reps * 1e3,
-                          what="one partition, 50 k reads x ~2 k candidates, resident replay")
+                          what="one partition, 50 k reads x ~2 k candidates, resident, %d runs with plain launches and events around every stage "
+                               "(median): scoring_prep (problem list, pair thresholds, k_cov) + interval_scoring (k_score) + dp (k_dp)" % reps,
+                          stage_ms={"scoring_prep": float(med2[0]), "interval_scoring": float(med2[1]), "dp": float(med2[2])},
+                          k_score_only=scoring_roofline(alg2, float(med2[1]), None))
                 out["roofline_config2"] = r2
+                ctx.set_profiling(2)
+            # BASELINE configs[2] and [4]: one resident batch each (250 partitions of 1 000 reads; config5 under sigma 3, tau 0.8)
+            for wname, parts_x in extra_parts.items():
+                px = PARAMS["config5" if wname == "config5" else "default"]
+                tx = dict(w_main=tables.gaussian_half_kernel(px["sigma"], 4.0), w_refine=tables.gaussian_half_kernel(px["sigma"], 1.0),
+                          h_table=np.asarray(tables.smooth_threshold(px["threshold_rate"]), np.float64))
+                bx = Batch(parts_x)
+                ctx.set_params(**px, **tx)
+                ctx.upload(**bx.arrays)
+                ctx.run(); ctx.sync()
+                algx = ctx.scoring_algorithmic_bytes()
+                for _ in range(3):
+                    ctx.run(); ctx.sync()
+                scx = []
+                for _ in range(reps):
+                    ctx.run(); ctx.sync()
+                    scx.append(ctx.stage_ms()["interval_scoring"])
+                rx = scoring_roofline(algx, float(np.median(scx)), committed_counters(wname, lib_hash))
+                rx.update(workload=wname, reads=bx.n_reads, params={k: px[k] for k in ("sigma", "threshold_rate")},
+                          what="one resident batch of %d partitions replayed %d times, the stage alone on the GPU (median)" % (len(parts_x), reps))
+                out["roofline_" + wname] = rx
+            ctx.set_params(**params, **tabs)
         if not args.no_cpu_baseline:
             cpu_one = cpu_baseline(batches, params, tabs)
         out["cpu_baseline"] = cpu_one

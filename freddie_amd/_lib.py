@@ -225,8 +225,10 @@ class Context:
         return out.reshape(-1, 4) if name == "problems" else (out.reshape(-1, 2) if name in ("lane_exons", "lane_stream", "exon_stream") else out)
 
     def set_profiling(self, on):
-        """True / 1: HIP events around every stage; 2: around the interval-scoring stage only; False: none."""
-        self._check(self._L.fseg_set_profiling(self._h, 2 if on == 2 else (1 if on else 0)), "fseg_set_profiling")
+        """True / 1: HIP events around every stage (first runs; replays report the scoring stage and the two graphs around it);
+        2: around the interval-scoring stage only; 3: around every stage on replays too (plain launches instead of the graph);
+        False: none."""
+        self._check(self._L.fseg_set_profiling(self._h, on if on in (2, 3) else (1 if on else 0)), "fseg_set_profiling")
 
     def stage_ms(self):
         n = self._L.fseg_n_stages()

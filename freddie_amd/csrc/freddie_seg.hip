@@ -49,6 +49,7 @@ constexpr int kNHuge = 128;            // largest DP problem at all: 60 < n <= 1
 constexpr int kLaneChunk = 256;        // reads ("lanes") per scoring work item (u16 counters: must stay < 65536)
 constexpr int kSub = 64;               // reads per scoring sub-chunk (two 32-bit plane words)
 constexpr i64 kNegInf = (i64)(-0x7fffffffffffffffLL - 1);
+constexpr i64 kKey32Reads = 1LL << 18;   // partitions of fewer reads take the DP's 32-bit keys (dp_solve_push / dp_solve_wave check the margin against NM)
 constexpr int kFuseLanes = 255;   // reads a problem may see for 8-bit triple counters (four 64-read rounds at most)
 constexpr int kFuseLanesDefault = 511;  // reads a problem may see for its batch to take the fused kernels (FSEG_FUSE_LANES): eight rounds
 constexpr int kFuseLanesWide = 1023;   // ... and for the 16-bit instances: partitions of 1 000 reads have problems that see ~300 (one
@@ -68,6 +69,7 @@ enum : unsigned {
     kErrOverflowChunks = 256u,
     kErrOverflowCov = 512u,
     kErrOverflowNm = 1024u,
+    kErrWaveStage = 8192u,     // a wave kernel (k_wave, k_cover) met a read with more exons than its LDS stage holds: rerun without them
     kErrScanStall = 4096u,     // the look-back scan gave up waiting for a predecessor block: rerun with the three-pass scan
     kErrNeedWideDp = 2048u,    // a problem sees >= 65536 reads: its DP needs the 32-bit count table    // a problem is larger than the LDS carve-up this launch was sized for
 };
@@ -1749,8 +1751,8 @@ template <typename V> __device__ __forceinline__ constexpr V dp_neg_inf() { retu
 // values the smaller c2 (the reference's first maximiser, :526-527), and the update of a pair is one v_max.  A pair's final
 // M(b,c) is stored in the same form with (63 - c) in the low bits -- the tie-break it needs when it is the tail of a push
 // from column c, and at the top level (first maximiser over j) -- or kKeyNone.  With 32-bit keys every |value| must stay
-// below 2^24: k_solve / k_wave take them when the largest partition has fewer than 2^18 reads (a chain has at most 32 links
-// of at most that many reads each), the 64-bit instances otherwise.
+// below 2^24: k_solve / k_wave take them when the largest partition has fewer than kKey32Reads = 2^18 reads (a chain has at most
+// NM - 1 <= 63 links of at most that many reads each: 63 * 2^18 < 2^24, checked at compile time), the 64-bit instances otherwise.
 // f(integral_constant<int, B>) ... f(integral_constant<int, E - 1>): a loop whose index is a compile-time constant in the body
 template <int B, int E, typename F> __device__ __forceinline__ void static_for(F &&f) {
     if constexpr (B < E) { f(std::integral_constant<int, B>{}); static_for<B + 1, E>(f); }
@@ -1814,6 +1816,8 @@ __device__ __forceinline__ int dp_solve_push(int n, const OutT *out_s, const int
     constexpr int LOG2T = T == 64 ? 6 : (T == 128 ? 7 : (T == 256 ? 8 : (T == 512 ? 9 : 10)));
     static_assert((1 << LOG2T) == T, "T is a power of two from 64 to 1024");
     static_assert(NM <= 64, "the top level is one lane per candidate; an argument is six bits of a key");
+    // 32-bit keys: value * 64 + argument with |value| < 2^24 -- a chain has at most NM - 1 links of at most kKey32Reads reads each
+    static_assert(sizeof(V) == 8 || (i64)(NM - 1) * kKey32Reads < (1LL << 24), "32-bit DP keys: the longest chain's sum must stay below 2^24");
     const int lane = lane_id(), wave = T == 64 ? 0 : wave_id();
     const int tid = T == 64 ? lane : (int)threadIdx.x;
     n = uni(n); support = uni(support);
@@ -1923,10 +1927,16 @@ __device__ __forceinline__ int dp_solve_push(int n, const OutT *out_s, const int
 constexpr int kDeadPair = (int)0x80000000;
 constexpr unsigned char kLinkNone = 255;
 template <int NM, typename OutT, typename V>
+__device__ __forceinline__ int dp_solve_wave_check() {
+    static_assert(sizeof(V) == 8 || (i64)(NM - 1) * kKey32Reads < (1LL << 24), "32-bit DP keys: the longest chain's sum must stay below 2^24");
+    return 0;
+}
+template <int NM, typename OutT, typename V>
 __device__ __forceinline__ int dp_solve_wave(int n, const OutT *out_s, const int *in_s, V *M, unsigned char *A, int support,
                                              unsigned char *chosen /* + first candidate of the problem */ FSEG_DPARAM) {
     constexpr int SLOTS = (NM * (NM - 1) / 2 + 63) / 64;
     static_assert(NM <= 64, "a candidate per lane at the top level; an argument is six bits of a key");
+    (void)dp_solve_wave_check<NM, OutT, V>();
     const int lane = lane_id();
     n = uni(n); support = uni(support);
     const int end = n - 1, npairs = n * (n - 1) / 2;
@@ -2719,7 +2729,7 @@ __global__ void __launch_bounds__(256, WaveCfg<NM>::kOcc) k_wave(Status *st, con
             const int base = uni(lx.x) & ~1;                                     // (16-byte units)
             const u64 fm = __ballot(in && lx.y - base <= kStageCap);
             const int m = ~fm == 0 ? 64 : (int)__builtin_ctzll(~fm);            // the ranges ascend: a prefix of the lanes
-            if (m == 0) { if (lane == 0) atomicOr(&st->err, kErrOverflowNm); break; }     // (the host keeps such batches away)
+            if (m == 0) { if (lane == 0) atomicOr(&st->err, kErrWaveStage); break; }      // (the host keeps such batches away: wave_on)
             const int total = __builtin_amdgcn_readlane(lx.y, m - 1) - base;
             {
                 const int last2 = total & ~1;
@@ -3012,7 +3022,7 @@ __global__ void __launch_bounds__(64 * NW, FSEG_COVER_OCC) k_cover(Status *st, i
     int n_act = 0;
 #pragma unroll
     for (int w = 0; w < NW; ++w) { if (w < wave) row += wave_n[w]; n_act += wave_n[w]; }
-    if (bad) { if (threadIdx.x == 0) { atomicOr(&st->err, kErrOverflowNm); nact[p] = 0; } return; }
+    if (bad) { if (threadIdx.x == 0) { atomicOr(&st->err, kErrWaveStage); nact[p] = 0; } return; }
     if (d.cov_off + (i64)n_act * n > cov_cap) { if (threadIdx.x == 0) { atomicOr(&st->err, kErrOverflowCov); nact[p] = 0; } return; }
     if (threadIdx.x == 0) nact[p] = n_act;
     FSEG_CTICK(5);
@@ -4567,6 +4577,7 @@ struct fseg_ctx {
     bool force_wide_dp = false;      // FSEG_FORCE_WIDE_DP=1 (tests): 32-bit DP counts whatever the problems need
     hipGraph_t graph[2] = {nullptr, nullptr};            // [0] whole pipeline, or before / after scoring when profiling
     hipGraphExec_t graph_exec[2] = {nullptr, nullptr};
+    bool profile_plain = false;   // fseg_set_profiling(3)
     int n_graphs = 0;
     bool last_sized = false;     // the pending run was launched stage by stage (per-stage events valid)
     hipEvent_t ev_b[ST_COUNT] = {}, ev_e[ST_COUNT] = {};
@@ -4779,7 +4790,7 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
     hipStream_t s = c->stream;
     const bool do_pre1 = segs & SEG_PRE1, do_pre2 = segs & SEG_PRE2, do_score = segs & SEG_SCORE, do_post1 = segs & SEG_POST1,
                do_post2 = segs & SEG_POST2;
-    const bool stage_events = c->profiling && (sized || !c->use_graph);
+    const bool stage_events = c->profiling && (sized || !c->use_graph || c->profile_plain);
     const int n_part = c->n_part;
     const i64 K = c->K, NPOS = c->NPOS;
     Status *st = c->d_status.as<Status>();
@@ -5058,7 +5069,7 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
             do { if (key32) { FSEG_LAUNCH_WAVE_V(Q, NMV, int, LIST, N_ITEMS); }                              \
                  else { FSEG_LAUNCH_WAVE_V(Q, NMV, i64, LIST, N_ITEMS); } } while (0)
         // the bounds of solve list `l` (0..2 the classes, 3 the tiny problems, < 0 the three classes together) when the host knows them
-        const bool key32 = c->max_part_lanes < (1LL << 18) && !c->force_key64;     // (FSEG_FORCE_KEY64=1: the 64-bit instances whatever the batch)
+        const bool key32 = c->max_part_lanes < kKey32Reads && !c->force_key64;     // (FSEG_FORCE_KEY64=1: the 64-bit instances whatever the batch)
         auto list_lb = [&](int l) -> i64 { return !known ? -1 : (l <= 0 ? 0 : (l == 1 ? c->n_solve[0] : (l == 2 ? c->n_solve[0] + c->n_solve[1] : c->n_solve[0] + c->n_solve[1] + c->n_solve[2]))); };
         auto list_ln = [&](int l) -> i64 { return !known ? -1 : (l < 0 ? c->n_solve[0] + c->n_solve[1] + c->n_solve[2] : (l == 3 ? c->n_tiny : c->n_solve[l])); };
         const bool any_solve = c->use_fuse && c->fuse_on && (!known || c->n_solve[0] + c->n_solve[1] + c->n_solve[2] > 0);
@@ -5330,7 +5341,7 @@ void collect_stage_times(fseg_ctx *c, int timed_graphs) {
         (void)hipEventElapsedTime(&c->stage_ms[ST_GRAPH_PRE], c->ev_g[0], c->ev_g[1]);
         (void)hipEventElapsedTime(&c->stage_ms[ST_SCORE], c->ev_g[1], c->ev_g[2]);
         (void)hipEventElapsedTime(&c->stage_ms[ST_GRAPH_POST], c->ev_g[2], c->ev_g[3]);
-    } else if (c->last_sized || !c->use_graph) {
+    } else if (c->last_sized || !c->use_graph || c->profile_plain) {
         for (int i = 0; i < ST_COUNT; ++i) {
             if (!c->profile_all && i != ST_SCORE) continue;
             if (hipEventElapsedTime(&c->stage_ms[i], c->ev_b[i], c->ev_e[i]) != hipSuccess) { c->stage_ms[i] = 0.f; (void)hipGetLastError(); }
@@ -5362,6 +5373,7 @@ static int finish_run_impl(fseg_ctx *c) {
         unsigned ovf = s.err & (kErrOverflowPairs | kErrOverflowTri | kErrOverflowWork | kErrOverflowLabels |
                                 kErrOverflowProblems | kErrOverflowChunks | kErrOverflowCov);
         if (s.err & kErrOverflowNm) { ovf |= kErrOverflowNm; c->nm_big = kNMax; }
+        if (s.err & kErrWaveStage) { ovf |= kErrWaveStage; c->use_wave = false; c->counts_known = false; drop_graph(c); }    // k_tiny / k_solve fetch exons read by read
         if ((i64)s.max_ln >= 65536 && !c->dp_wide_counts) { ovf |= kErrNeedWideDp; c->dp_wide_counts = true; drop_graph(c); }
         if (s.err & kErrScanStall) { ovf |= kErrScanStall; c->scan_single_max = 0; c->force_scan_stall = false; drop_graph(c); }
         if (s.dp_cls[2] > 0 && !c->have_huge) { ovf |= kErrProblemTooLarge << 16; c->have_huge = true; drop_graph(c); }   // rerun with the huge-problem kernels
@@ -5417,6 +5429,8 @@ int run_sized(fseg_ctx *c) {
                 c->tiny_on = tiny; c->fuse_on = fuse;
                 const int pg = grid_for(c->NPOS / 8 / kProbBlock + 1, 1, 1024);
                 Status *st = c->d_status.as<Status>();
+                // (the scan ADDS to the per-class counts of wide problems: the first scan's must not stay in them)
+                HIP_TRY(c, hipMemsetAsync(reinterpret_cast<char *>(st) + offsetof(Status, wide_cls), 0, sizeof(st->wide_cls), c->stream));
                 hipLaunchKernelGGL(k_prob_scan1, dim3(pg), dim3(256), 0, c->stream, st, c->d_cand_pn.as<int>(), c->d_cand_ln.as<int>(),
                                    c->d_prob_bs.as<i64>(), split_of(c, tiny, fuse));
                 hipLaunchKernelGGL(k_prob_scan2, dim3(1), dim3(256), 0, c->stream, st, c->d_prob_bs.as<i64>());
@@ -5953,7 +5967,7 @@ static int run_impl(fseg_ctx *c) {
     // sequence is replayed (as a hipGraph unless disabled)
     if (!c->ran && c->use_sized) return run_sized(c);
     c->last_sized = false;
-    if (c->use_graph) {
+    if (c->use_graph && !c->profile_plain) {
         if (c->n_graphs == 0) {
             const int want = c->profiling ? 2 : 1;
             bool ok = true;
@@ -6218,9 +6232,10 @@ int fseg_tap(fseg_ctx *c, int what, void *dst, int64_t cap_bytes, int64_t *n_byt
 
 int fseg_set_profiling(fseg_ctx *c, int on) {
     if (!c) return FSEG_ERR_ARG;
-    if (c->profiling != (on != 0) || c->profile_all != (on != 2)) drop_graph(c);
+    if (c->profiling != (on != 0) || c->profile_all != (on != 2) || c->profile_plain != (on == 3)) drop_graph(c);
     c->profiling = on != 0;
     c->profile_all = on != 2;
+    c->profile_plain = on == 3;         // every stage bracketed on replays too: plain launches instead of the graph
     return FSEG_OK;
 }
 int fseg_n_stages(void) { return ST_REPORTED; }

@@ -666,11 +666,23 @@ def main(argv=None):
         from concurrent.futures import ThreadPoolExecutor
         boot = ThreadPoolExecutor(max_workers=1)
         ctx_future = boot.submit(open_contexts, device_list[0])
-    parts = discover(split_dir, args.outdir)
-    params = (args.sigma, tables.smooth_threshold(args.threshold_rate), args.threshold_rate, args.variance_factor,
-              args.max_problem_size, args.min_read_support_outside, not args.consider_ends)
-    costs = [c for _, _, c in parts]
-    assign = scatter.lpt_scatter(costs, n_gpus)
+    def close_boot():
+        # whatever stops main() before the batches run (a missing split directory, say): the contexts that are coming up
+        # beside it are closed and the executor ended, so the user sees the error at once and not after HIP's start-up
+        if boot is not None:
+            boot.shutdown(wait=True)
+            if ctx_future is not None and ctx_future.exception() is None:
+                for ctx in ctx_future.result():
+                    ctx.close()
+    try:
+        parts = discover(split_dir, args.outdir)
+        params = (args.sigma, tables.smooth_threshold(args.threshold_rate), args.threshold_rate, args.variance_factor,
+                  args.max_problem_size, args.min_read_support_outside, not args.consider_ends)
+        costs = [c for _, _, c in parts]
+        assign = scatter.lpt_scatter(costs, n_gpus)
+    except BaseException:
+        close_boot()
+        raise
     batch_bytes = max(1, args.batch_reads) * 1400          # ~1.4 KB of split TSV per read
     total = len(parts)
     step = ceil(total / 100) if total else 1

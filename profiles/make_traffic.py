@@ -16,8 +16,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 sys.path.insert(0, ROOT)
 src = sys.argv[1]
-tag = sys.argv[2] if len(sys.argv) > 2 else "r03"
-STAGE = {"config4": ("k_solve<16", "k_solve<32", "k_solve<60", "k_wave<", "k_tiny"), "config2": ("k_score<60>",)}
+tag = sys.argv[2] if len(sys.argv) > 2 else "r04"      # (the prefix the summaries are committed under: tools/collect_profiles.sh)
+STAGE = {"config4": ("k_solve<16", "k_solve<32", "k_solve<60", "k_dpw<", "k_wave<", "k_tiny"),
+         "config2": ("k_cov", "k_score<60>", "k_dp<")}       # (config2: the arena path's coverage + scoring + DP, like config4's stage)
 
 
 def load(path):

@@ -135,6 +135,28 @@ def test_device_count_without_the_runtime(tmp_path):
     assert not (set(both[0]) & set(both[1])) or len(os.sched_getaffinity(0)) < 2
 
 
+def test_eight_workers_get_disjoint_cores(tmp_path, monkeypatch):
+    """devices.cpus_near_gpu() for the 8-GPU node no round has had: eight workers under ``--devices 0,...,7`` (ordinal ==
+    worker, the KFD topology says where each GPU sits) and under a ``HIP_VISIBLE_DEVICES`` remap (nothing is known: even
+    slices by worker index) never share a core, and every worker gets some."""
+    root = tmp_path / "nodes"
+    for i, simd in enumerate([0, 0] + [1024] * 8):
+        d = root / str(i)
+        d.mkdir(parents=True)
+        (d / "properties").write_text("cpu_cores_count %d\nsimd_count %d\ndrm_render_minor %d\n" % (0 if simd else 64, simd, 128 + i))
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(128)))
+    for env in ({}, {"HIP_VISIBLE_DEVICES": "7,6,5,4,3,2,1,0"}):
+        cores = [devices.cpus_near_gpu(k, 8, ordinal=k, kfd_root=str(root), env=env) for k in range(8)]
+        assert all(cores) and all(set(c) <= set(range(128)) for c in cores)
+        for a in range(8):
+            for b in range(a + 1, 8):
+                assert not (set(cores[a]) & set(cores[b])), (env, a, b)
+        assert sum(len(c) for c in cores) <= 128
+    # a worker whose GPU is not "its" ordinal (--devices 2,4): slices by worker index, disjoint as well
+    pair = [devices.cpus_near_gpu(k, 2, ordinal=o, kfd_root=str(root), env={}) for k, o in ((0, 2), (1, 4))]
+    assert pair[0] and pair[1] and not (set(pair[0]) & set(pair[1]))
+
+
 def test_host_ceiling_tool_runs_the_real_main_without_a_device(tmp_path):
     """tools/host_ceiling.py: main() with a stand-in context that answers at once (both ends of every interval as final
     positions, a constant label): every partition gets its segment TSV, with one label per segment and read."""

@@ -10,6 +10,7 @@ cp $O/trace1/p_kernel_stats.csv profiles/${P}_config4_kernel_stats.csv
 cp $O/config4_kernel_medians.txt profiles/${P}_config4_kernel_medians.txt
 cp $O/config4_kernel_medians_8ctx.txt profiles/${P}_config4_kernel_medians_8ctx.txt
 cp $O/config2_kernel_medians.txt profiles/${P}_config2_kernel_medians.txt
+cp $O/config4_stage_span.txt profiles/${P}_config4_stage_span.txt
 for w in config4 config2; do
   cp $O/${w}_pmc_summary.txt profiles/${P}_${w}_pmc_summary.txt
   cp $O/${w}_sq_summary.txt profiles/${P}_${w}_sq_summary.txt

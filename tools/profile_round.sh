@@ -1,7 +1,9 @@
 #!/bin/bash
-# Round profile: tools/profile_round.sh <tag>   (run on the GPU box from the repo root; writes under gpurun_out/<tag>/;
-# tools/collect_profiles.sh copies the summaries worth keeping into profiles/ afterwards -- never the raw counter CSVs)
+# Round profile: tools/profile_round.sh <tag> [prefix]   (run on the GPU box from the repo root; writes under gpurun_out/<tag>/;
+# tools/collect_profiles.sh <tag> <prefix> copies the summaries worth keeping into profiles/<prefix>_* afterwards -- never the raw
+# counter CSVs; prefix = the round, default the tag's first three characters: it is what profiles/traffic.json cites)
 T=${1:-round}
+P=${2:-${T:0:3}}
 O=gpurun_out/$T
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 mkdir -p $O
@@ -15,6 +17,10 @@ FSEG_NO_FORK=1 FSEG_NO_GRAPH=1 rocprofv3 --kernel-trace --stats --output-format 
 python profiles/trace_medians.py $O/trace1/p_kernel_trace.csv > $O/config4_kernel_medians.txt
 FSEG_NO_FORK=1 FSEG_NO_GRAPH=1 rocprofv3 --kernel-trace --output-format csv -d $O/trace2 -o p -- python3 tools/replay_probe.py --workload config2 > $O/replay_config2.txt 2> $O/trace2.err
 python profiles/trace_medians.py $O/trace2/p_kernel_trace.csv > $O/config2_kernel_medians.txt
+# 2b. the same replay with the DEFAULT plan (side streams, gate): what the stage takes from its first kernel's start to its last
+#     kernel's end, and from the end of the kernel before it to the start of the kernel after it (= the event bracket of `roofline`)
+rocprofv3 --kernel-trace --output-format csv -d $O/trace3 -o p -- python3 tools/replay_probe.py --workload config4 > $O/replay_config4_plan.txt 2> $O/trace3.err
+python tools/stage_span.py $O/trace3/p_kernel_trace.csv > $O/config4_stage_span.txt; grep replay $O/replay_config4_plan.txt | cut -c1-120 >> $O/config4_stage_span.txt; cat $O/config4_stage_span.txt
 # 3. counters, each in its own pass
 for w in config4 config2; do
   for pmc in FETCH_SIZE WRITE_SIZE; do
@@ -24,7 +30,7 @@ for w in config4 config2; do
   python profiles/pmc_summary.py $O/pmc_${w}_FETCH_SIZE/p_counter_collection.csv $O/pmc_${w}_WRITE_SIZE/p_counter_collection.csv > $O/${w}_pmc_summary.txt
   python tools/sq_summary.py $O/pmc_${w}_sq/p_counter_collection.csv $O/pmc_${w}_sq/p_kernel_trace.csv > $O/${w}_sq_summary.txt
 done
-python profiles/make_traffic.py $O $T > $O/traffic_summary.txt; cp profiles/traffic.json $O/traffic.json
+python profiles/make_traffic.py $O $P > $O/traffic_summary.txt; cp profiles/traffic.json $O/traffic.json
 # 4. the other workloads, rows N3 / N4, end to end, the host alone
 for w in config2 config3 config5; do python bench.py --workload $w --no-cpu-baseline --no-e2e > $O/${w}_bench.json 2>/dev/null; python profiles/benchsum.py < $O/${w}_bench.json | head -1; done
 python bench.py --workload cluster-many > $O/n3_cluster_many_bench.json 2>/dev/null
