@@ -4550,6 +4550,7 @@ struct fseg_ctx {
     i64 dpx_base[3] = {0, 0, 0}, dpx_stride[3] = {0, 0, 0}, dpx_n[3] = {0, 0, 0};
     int dpx_nm = 0, dpx_cnt[3] = {1, 1, 1};
     bool precover = false;      // FSEG_PRECOVER=1: k_cover computes thresholds, kept reads and coverage rows ahead of k_solve (measured slower: DESIGN section 8)
+    bool split_always = false;  // FSEG_SPLIT_ALWAYS=1 (tests): the split path also where a context keeps to one stream
     int split_dp = 7;           // FSEG_SPLIT_DP: bit 0 / 1 / 2 = the small / mid / large class hands its DPs to k_dpw (0: the DP stays the tail of k_solve's workgroups)
     i64 prob_cap = 0, work_cap = 0, pair_cap = 0, tri_cap = 0, label_cap = 0, chunk_cap = 0, cov_cap = 0;
     DevBuf d_status, d_prep, d_tacc;
@@ -5002,10 +5003,13 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
                                c->d_ex_te.as<int>(), c->d_h_table.as<double>(), c->P.h_len, c->P.threshold_rate,               \
                                c->d_thr_tab.as<int2>(), c->P.min_read_support_outside, c->d_chosen.as<unsigned char>(),       \
                                (c->wide_by_seen ? 1 : 0)
-        // the split path (k_solve<.., SPLIT> then k_dpw on the same stream) for a list that fits the hand-over arena as laid out
+        // the split path (k_solve<.., SPLIT> then k_dpw on the same stream) for a list that fits the hand-over arena as laid out --
+        // when this context has the device to itself (`forking`): with other contexts' batches in flight a context keeps to one
+        // stream, where the extra launches cost more than the early release of LDS gains (the 2 M-read job, eight contexts:
+        // 383 against 388 M reads/s; the stage alone: 0.146 against 0.160 ms)
         const bool pre_on = FSEG_PRECOVER && c->precover && wave;    // (k_cover reads the lane-ordered exon stream)
         auto split_ok = [&](int cls, int cnt_bytes) {
-            return known && cls >= 0 && cls < 3 && ((c->split_dp >> cls) & 1) && c->dpx_n[cls] > 0 && c->n_solve[cls] <= c->dpx_n[cls] && c->dpx_nm == c->nm_big &&
+            return known && (forking || c->split_always) && cls >= 0 && cls < 3 && ((c->split_dp >> cls) & 1) && c->dpx_n[cls] > 0 && c->n_solve[cls] <= c->dpx_n[cls] && c->dpx_nm == c->nm_big &&
                    cnt_bytes <= c->dpx_cnt[cls] && c->d_dpx.p != nullptr;
         };
 #define FSEG_LAUNCH_SOLVE(Q, NMV, CNT, VT, CLS, N_ITEMS, MAXWG)                                                              \
@@ -5580,6 +5584,7 @@ int fseg_create(int device, fseg_ctx **out) {
     if (flag("FSEG_WIDE_BY_SEEN")) c->wide_by_seen = true;
     if (const char *e = getenv("FSEG_SPLIT_DP")) c->split_dp = atoi(e) & 7;
     if (flag("FSEG_PRECOVER")) c->precover = true;
+    if (flag("FSEG_SPLIT_ALWAYS")) c->split_always = true;
     { const char *v = getenv("FSEG_GATE_DONE_PCT"); if (v && v[0] && atoi(v) > 0 && atoi(v) <= 100) c->gate_done_pct = atoi(v); }
     if (const char *e = getenv("FSEG_SCORE_PLAN")) snprintf(c->score_plan, sizeof c->score_plan, "%s", e);
     {

@@ -70,6 +70,12 @@ SWITCHES = [
     {"FSEG_PROB_SELF_MAX": "0"},                            # the problem list always through the block-sum scan
     {"FSEG_PROB_SELF_MAX": "100000000"},                    # ... and always through the self-scanning emit kernel
     {"FSEG_NO_SDMA_D2H": "1"},                              # results through the runtime's copy instead of the SDMA engine
+    {"FSEG_SPLIT_DP": "0"},                                 # the DP as the tail of k_solve's workgroups (one wave: dp_solve_wave), no k_dpw
+    {"FSEG_SPLIT_DP": "0", "FSEG_FORCE_KEY64": "1"},        # ... with 64-bit keys: the large class's DP by the whole workgroup (dp_solve_push)
+    {"FSEG_SPLIT_DP": "5", "FSEG_SCORE_PLAN": "BM|gTS|b|ms"},   # small and large class split, the mid class fused; round 3's plan
+    {"FSEG_SPLIT_ALWAYS": "1", "FSEG_NO_FORK": "1"},        # k_solve + k_dpw on ONE stream
+    {"FSEG_SPLIT_ALWAYS": "1", "FSEG_NO_FORK": "1", "FSEG_FORCE_KEY64": "1", "FSEG_FUSE_LANES": "1023"},   # k_dpw with 64-bit keys, the 16-bit instances behind the 8-bit ones
+    {"FSEG_FUSE_LANES": "1023", "FSEG_WIDE_BY_SEEN": "1"},  # wide problems (16-bit counters) through the split path, chosen by the reads they see
 ]
 
 
