@@ -69,7 +69,7 @@ enum : unsigned {
     kErrOverflowChunks = 256u,
     kErrOverflowCov = 512u,
     kErrOverflowNm = 1024u,
-    kErrWaveStage = 8192u,     // a wave kernel (k_wave, k_cover) met a read with more exons than its LDS stage holds: rerun without them
+    kErrWaveStage = 8192u,     // a wave kernel (k_wave) met a read with more exons than its LDS stage holds: rerun without them
     kErrScanStall = 4096u,     // the look-back scan gave up waiting for a predecessor block: rerun with the three-pass scan
     kErrNeedWideDp = 2048u,    // a problem sees >= 65536 reads: its DP needs the 32-bit count table    // a problem is larger than the LDS carve-up this launch was sized for
 };
@@ -1251,10 +1251,6 @@ __device__ __forceinline__ ProbSizes prob_sizes(int n, int n_lanes, ProbSplit sp
         s.v[0] = 1;
         s.v[7] = c == 0 ? 1 : (c == 1 ? (1LL << 32) : 0);
         s.v[8] = c == 2 ? 1 : 0;
-        // room for k_cover's hand-over to k_solve: the pair thresholds and a coverage row per read the problem sees (an upper
-        // bound of the rows it keeps), in the arenas the arena path uses for the same things
-        s.v[1] = (i64)n * (n - 1) / 2;
-        s.v[3] = ((i64)n_lanes * n + 3) & ~(i64)3;
         return s;
     }
     i64 chunks = (n_lanes + kLaneChunk - 1) / kLaneChunk;
@@ -2849,198 +2845,6 @@ __global__ void __launch_bounds__(256, WaveCfg<NM>::kOcc) k_wave(Status *st, con
 // threshold / ambiguity / count arenas, no work items, no DP list entry.  (The arena path remains for problems that see
 // thousands of reads, where one problem has to be spread over many workgroups.)
 // ---------------------------------------------------------------------------------------------
-// ---------------------------------------------------------------------------------------------
-// k_cover: everything of a k_solve problem that is a chain of dependent GLOBAL loads, done beforehand by a workgroup that
-// holds next to nothing (round 4).  Under load k_solve spent 44 % (large class) to 76 % (small) of its time before and
-// between its LDS phases -- descriptor -> candidates -> threshold table -> exon ranges -> exon blocks, then the exons again
-// per round -- while holding 25-78 KB of LDS and 96-128 registers per thread (tools/solve_timing.py).  Here: per problem
-//   * the integer label bounds of every pair (:490-495)            -> pair_thr[pair_off + q]
-//   * the reads that have an exon in the window, in lane order, and each one's window coverage
-//     cov[r][j] = positions of its closed exons in [cand_0, cand_j) (get_cumulative_coverage :188-246; a sum of overlaps)
-//                                                                   -> cov_g[cov_off + r * n + j], nact[problem]
-// so that k_solve<.., SPLIT> starts with ONE round of independent loads behind its descriptor and copies a round's rows
-// from memory instead of walking exons.  Lanes are candidates in the coverage pass (a read's exons are wave-uniform):
-// a row leaves as one contiguous store.
-// ---------------------------------------------------------------------------------------------
-constexpr int kCoverStage = 1024;              // exons of one round's reads staged in LDS per wave of k_cover (a round takes fewer reads if they own more)
-// a round of k_cover: the next lanes of the wave's share whose exons fit the stage together -- their piece of the exon stream
-// requested into registers ...
-struct CoverRound { int base, total, m; };
-__device__ __forceinline__ CoverRound cover_round(int2 lx, bool in) {
-    CoverRound r;
-    r.base = uni(lx.x) & ~1;                                                     // (16-byte units)
-    const u64 fm = __ballot(in && lx.y - r.base <= kCoverStage);
-    r.m = ~fm == 0 ? 64 : (int)__builtin_ctzll(~fm);                            // the ranges ascend: a prefix of the lanes
-    r.total = r.m > 0 ? __builtin_amdgcn_readlane(lx.y, r.m - 1) - r.base : 0;
-    return r;
-}
-// (a round's piece waits in eight named registers quadruples: as an array -- handed to a helper or not -- it stayed in scratch
-// memory, a round trip through global memory in the middle of the chain)
-static_assert(kCoverStage == 1024, "CoverPiece holds eight 16-byte loads per lane");
-struct CoverPiece { int4 v0, v1, v2, v3, v4, v5, v6, v7; };
-__device__ __forceinline__ CoverPiece cover_request(const int2 *__restrict__ lex, const CoverRound &r, int lane) {
-    const int last2 = r.total & ~1;
-    auto ld = [&](int u) { const int i = 2 * lane + 128 * u; return *reinterpret_cast<const int4 *>(lex + r.base + (i < last2 ? i : last2)); };
-    CoverPiece pc;
-    pc.v0 = ld(0); pc.v1 = ld(1); pc.v2 = ld(2); pc.v3 = ld(3); pc.v4 = ld(4); pc.v5 = ld(5); pc.v6 = ld(6); pc.v7 = ld(7);
-    return pc;
-}
-__device__ __forceinline__ void cover_store(int2 *stage, int lane, const CoverPiece &pc) {        // (beyond the piece: never read)
-    auto st = [&](int u, const int4 &v) { *reinterpret_cast<int4 *>(&stage[2 * lane + 128 * u]) = v; };
-    st(0, pc.v0); st(1, pc.v1); st(2, pc.v2); st(3, pc.v3); st(4, pc.v4); st(5, pc.v5); st(6, pc.v6); st(7, pc.v7);
-}
-// every lane's exons that meet the window [cp0, c_last): (first, cnt), stage-relative
-__device__ __forceinline__ u64 cover_locate(const int2 *stage, const CoverRound &r, int2 lx, int lane, int cp0, int c_last, int &first, int &cnt) {
-    dp_sync<64>();
-    const bool valid = lane < r.m;
-    const int ea = valid ? lx.x - r.base : 0, eb = valid ? lx.y - r.base : 0;
-    first = ea; cnt = 0;
-    for (int e = ea; e < eb; e += 4) {
-        int2 x[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) x[u] = stage[e + u];                          // (beyond the read: masked; the array has room)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const bool hit = e + u < eb && x[u].y >= cp0 && x[u].x < c_last;
-            if (hit && cnt == 0) first = e + u;
-            cnt += hit;
-        }
-        if (x[3].x >= c_last) break;                                              // the rest of the read lies beyond the window
-    }
-    return __ballot(valid && cnt > 0);
-}
-// NW waves share a problem's lanes; PMAX: the class's most pairs (their thresholds wait in registers while the exons arrive).
-// Under load a dependent global load is 2-5 us, and the first version was a chain of ten of them (50 us for the small class's
-// launch): now everything is requested as early as its address is known -- descriptor -> {candidates, the first round's lane
-// ranges, the pair table} -> {threshold table, the round's piece of the exon stream} -> rows.
-#ifndef FSEG_COVER_OCC
-#define FSEG_COVER_OCC 6
-#endif
-template <int NW, int PMAX>
-__global__ void __launch_bounds__(64 * NW, FSEG_COVER_OCC) k_cover(Status *st, int nm, i64 list_base, i64 list_n, const ProbDesc *desc, const int *__restrict__ cand_y,
-                                                   const int2 *__restrict__ lane_lx, const int2 *__restrict__ lex,
-                                                   const double *h_table, int h_len, double tau, const int2 *__restrict__ thr_tab,
-                                                   int2 *pair_thr, i64 pair_cap, unsigned *cov_g, i64 cov_cap, int *nact FSEG_TPARAM) {
-    constexpr int T = 64 * NW, PS = (PMAX + T - 1) / T;
-#ifdef FSEG_SCORE_TIMING
-    // diagnostic build: phase clocks (slots 6 descriptor + candidates, 7 thresholds, 13 pass 1, 14 pass 2, 5 the rest)
-    unsigned long long ct_prev = wall_clock64();
-#define FSEG_CTICK(i) do { unsigned long long t_now = wall_clock64(); if (threadIdx.x == 0) atomicAdd(&tacc[i], t_now - ct_prev); ct_prev = t_now; } while (0)
-#else
-#define FSEG_CTICK(i)
-#endif
-    __shared__ __align__(16) int2 stage_s[NW][kCoverStage + 4];
-    __shared__ int cy_s[64];
-    __shared__ int wave_n[NW];
-    const i64 t = blockIdx.x;
-    if (t >= list_n) return;
-    unsigned short ij[PS];                                           // (the pair table depends on nothing: asked for first)
-#pragma unroll
-    for (int k = 0; k < PS; ++k) ij[k] = g_pair_ij[k * T + (int)threadIdx.x < PMAX ? k * T + (int)threadIdx.x : 0];
-    const ProbDesc d = FSEG_LOAD_DESC(desc + list_base + t);
-    const int n = d.n, p = d.w0;
-    const int lane = lane_id(), wave = wave_id();
-    if (n > nm || n > kNMax || n < 3 || d.lane_n > kFuseLanesWide) { if (threadIdx.x == 0) nact[p] = 0; return; }   // (k_solve raises the error)
-    const int npairs = n * (n - 1) / 2;
-    // behind the descriptor: the candidates and the first round's lane ranges
-    const int l_begin = (int)((i64)d.lane_n * wave / NW), l_end = (int)((i64)d.lane_n * (wave + 1) / NW);
-    const int cyv = cand_y[d.c0 + (lane < n ? lane : 0)];
-    const int2 lx0 = lane_lx[d.lane_lo + l_begin + (l_begin + lane < l_end ? lane : 0)];
-    if (wave == 0) cy_s[lane] = cyv;
-    if (d.pair_off + npairs > pair_cap) { if (threadIdx.x == 0) { atomicOr(&st->err, kErrOverflowPairs); nact[p] = 0; } return; }
-    FSEG_CTICK(6);
-    // ---- A wave takes a contiguous share of the problem's lanes, in rounds: as many of the next 64 lanes as own at most
-    //      kCoverStage exons together (all 64, usually).  A round's exons are ONE piece of the lane-ordered exon stream, copied
-    //      into LDS with lane-consecutive 16-byte loads; every lane then finds the exons of its read that meet the window there
-    //      (exons are ordered: the first with te >= cand_0 up to the last with ts < cand_{n-1}).  Pass 1 counts the reads that
-    //      have any (about two thirds of the lane range); pass 2, knowing where the wave's rows start, computes a row per kept
-    //      read with lanes = candidates -- the read's first two exons reach the other lanes through v_readlane (most reads meet
-    //      the window with one or two), further ones are uniform LDS reads -- and stores it whole.  A wave whose share is one
-    //      round (the usual case) keeps its staged exons between the passes.
-    const int cp0 = d.g0 + __builtin_amdgcn_readlane(cyv, 0), c_last = d.g0 + __builtin_amdgcn_readlane(cyv, n - 1);
-    int2 *stage = stage_s[wave];
-    const int cj = lane < n ? d.g0 + cyv : cp0;                      // beyond the problem: an empty window
-    unsigned *rows = cov_g + d.cov_off;
-    auto overlap = [&](int ts, int te) { const int a0 = max(ts, cp0), b0 = te + 1; return max(0, min(b0, cj) - a0); };    // closed exon -> half-open end
-    int first = 0, cnt = 0, row = 0, kept = 0;
-    u64 mk = 0;
-    bool bad = false;
-    auto emit = [&]() {                                                       // the rows of the round that `locate` has just worked on
-        const int2 x0 = stage[first], x1 = stage[first + (cnt > 1 ? 1 : 0)];
-        u64 mm = mk;
-        while (mm) {                                                          // (wave-uniform)
-            const int rl = (int)__builtin_ctzll(mm);
-            mm &= mm - 1;
-            const int cu = __builtin_amdgcn_readlane(cnt, rl);
-            int acc = overlap(__builtin_amdgcn_readlane(x0.x, rl), __builtin_amdgcn_readlane(x0.y, rl));
-            if (cu > 1) acc += overlap(__builtin_amdgcn_readlane(x1.x, rl), __builtin_amdgcn_readlane(x1.y, rl));
-            if (cu > 2) {
-                const int fu = __builtin_amdgcn_readlane(first, rl);
-                for (int e = 2; e < cu; ++e) { const int2 xe = stage[fu + e]; acc += overlap(xe.x, xe.y); }
-            }
-            if (lane < n) rows[(i64)row * n + lane] = (unsigned)acc;
-            ++row;
-        }
-    };
-    // the first round's exons are on their way while the thresholds are looked up
-    const bool any_lanes = l_begin < l_end;
-    const CoverRound r0 = cover_round(lx0, l_begin + lane < l_end);
-    const CoverPiece pc0 = cover_request(lex, r0, lane);
-    if (any_lanes && r0.m == 0) bad = true;                          // (a read of more exons than the stage holds: the host keeps such batches away)
-    __syncthreads();                                                 // cy_s
-    {
-        int2 th[PS];
-#pragma unroll
-        for (int k = 0; k < PS; ++k) {
-            const int q = k * T + (int)threadIdx.x;
-            th[k] = make_int2(0x7fffffff, -1);
-            if (q < npairs) label_thresholds_tab((i64)cy_s[ij[k] >> 8] - cy_s[ij[k] & 255] + 1, thr_tab, h_table, h_len, tau, &th[k].x, &th[k].y);   // :490-495 as integer bounds
-        }
-#pragma unroll
-        for (int k = 0; k < PS; ++k) { const int q = k * T + (int)threadIdx.x; if (q < npairs) pair_thr[d.pair_off + q] = th[k]; }
-    }
-    FSEG_CTICK(7);
-    int rounds = 0;
-    if (any_lanes && !bad) {
-        cover_store(stage, lane, pc0);
-        mk = cover_locate(stage, r0, lx0, lane, cp0, c_last, first, cnt);
-        kept = __popcll(mk); rounds = 1;
-        for (int l0 = l_begin + r0.m; l0 < l_end;) {                 // (shares of more than a round: wide problems)
-            const int2 lx = lane_lx[d.lane_lo + l0 + (l0 + lane < l_end ? lane : 0)];
-            dp_sync<64>();
-            const CoverRound r = cover_round(lx, l0 + lane < l_end);
-            if (r.m == 0) { bad = true; break; }
-            cover_store(stage, lane, cover_request(lex, r, lane));
-            int f2, c2;
-            kept += __popcll(cover_locate(stage, r, lx, lane, cp0, c_last, f2, c2));
-            ++rounds; l0 += r.m;
-        }
-    }
-    if (lane == 0) wave_n[wave] = kept;
-    FSEG_CTICK(13);
-    bad = __syncthreads_or(bad ? 1 : 0) != 0;
-    int n_act = 0;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) { if (w < wave) row += wave_n[w]; n_act += wave_n[w]; }
-    if (bad) { if (threadIdx.x == 0) { atomicOr(&st->err, kErrWaveStage); nact[p] = 0; } return; }
-    if (d.cov_off + (i64)n_act * n > cov_cap) { if (threadIdx.x == 0) { atomicOr(&st->err, kErrOverflowCov); nact[p] = 0; } return; }
-    if (threadIdx.x == 0) nact[p] = n_act;
-    FSEG_CTICK(5);
-    if (rounds == 1) emit();
-    else if (rounds > 1)
-        for (int l0 = l_begin; l0 < l_end;) {
-            const int2 lx = lane_lx[d.lane_lo + l0 + (l0 + lane < l_end ? lane : 0)];
-            dp_sync<64>();
-            const CoverRound r = cover_round(lx, l0 + lane < l_end);
-            cover_store(stage, lane, cover_request(lex, r, lane));
-            mk = cover_locate(stage, r, lx, lane, cp0, c_last, first, cnt);
-            emit();
-            l0 += r.m;
-        }
-    FSEG_CTICK(14);
-#undef FSEG_CTICK
-}
-
 // A large-class workgroup wants eight wave slots and 57-78 KB of LDS at once.  Beside kernels of small workgroups on other
 // streams it is placed last, whatever the launch order (the dispatcher places what fits), and then the stage ends with the
 // large class running alone on a mostly empty chip.  k_gate is what the side stream runs first: one wave that waits until the
@@ -3066,9 +2870,6 @@ template <int NM> struct SolveCfg {
 #ifndef FSEG_SOLVE_OCC
 #define FSEG_SOLVE_OCC 1
 #endif
-#ifndef FSEG_PRECOVER
-#define FSEG_PRECOVER 0         // 1: builds with k_cover's hand-over compiled into k_solve<.., SPLIT> (then FSEG_PRECOVER=1 in the environment turns it on);
-#endif                          // measured slower than k_solve doing its own set-up, so the product build leaves it out
 #ifndef FSEG_WAVE_DP
 #define FSEG_WAVE_DP 1          // k_solve's DP by one wave (dp_solve_wave); 0: by the whole workgroup (dp_solve_push), as until round 4
 #endif
@@ -3109,8 +2910,7 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
                                                                   const longlong2 *lane_ex, const int *ex_ts, const int *ex_te,
                                                                   const double *h_table, int h_len, double tau, const int2 *thr_tab,
                                                                   int support, unsigned char *chosen, int wide_by_seen,
-                                                                  unsigned char *dpx, i64 dpx_stride, const int2 *__restrict__ pair_thr_g,
-                                                                  const unsigned *__restrict__ cov_g, int *nact_g FSEG_TPARAM) {
+                                                                  unsigned char *dpx, i64 dpx_stride, int *nact_g FSEG_TPARAM) {
     using C = SolveCfg<NM>;
     constexpr int T = C::kThreads, NR = C::kRanges;
     constexpr int PACK = 4 / (int)sizeof(CntT);                    // counters per 32-bit read-modify-write
@@ -3162,8 +2962,6 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
         __syncthreads();                                             // the previous problem's DP is done with LDS
         FSEG_STICK(0);
         unsigned char *slot = SPLIT ? dpx + t * dpx_stride : nullptr;           // (dpx: the class's first slot)
-        const bool pre = FSEG_PRECOVER && SPLIT && cov_g != nullptr;  // k_cover has run: thresholds, kept reads and coverage rows come from memory
-        const int n_pre = pre ? nact_g[p] : 0;                       // (the reads the problem keeps)
         if (n > nm || n > NM) { if (threadIdx.x == 0) atomicOr(&st->err, kErrOverflowNm); continue; }
         // a list's problems are shared by two launches: the 8-bit counters take those that KEEP at most 255 reads (a counter
         // counts reads with coverage in the window: about two thirds of those the problem sees), the 16-bit ones the rest.
@@ -3173,7 +2971,6 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
         if (!wide_cand && sizeof(CntT) != 1) continue;
         if (wide_by_seen && wide_cand && sizeof(CntT) == 1) continue;      // (FSEG_WIDE_BY_SEEN=1, tests: every problem that SEES more than 255 reads to the 16-bit instance)
         if (d.lane_n > kFuseLanesWide) { if (threadIdx.x == 0) atomicOr(&st->err, kErrNeedWideDp); continue; }
-        if (pre && wide_cand && !wide_by_seen && (sizeof(CntT) == 1) != (n_pre <= kFuseLanes)) continue;       // the other instance's (k_cover has counted)
         const int npairs = n * (n - 1) / 2, ntri = n * (n - 1) * (n - 2) / 6;
         const int *cy = cand_y + d.c0;
         for (int j = threadIdx.x; j < n; j += T) cy_s[j] = cy[j];
@@ -3196,8 +2993,7 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
             if (q < npairs) {
                 const unsigned short ij = g_pair_ij[q];
                 pi[s] = ij & 255; pj[s] = ij >> 8;
-                if (pre) { const int2 th = pair_thr_g[d.pair_off + q]; th_hi[s] = th.x; th_lo[s] = th.y; }
-                else label_thresholds_tab((i64)cy_s[pj[s]] - cy_s[pi[s]] + 1, thr_tab, h_table, h_len, tau, &th_hi[s], &th_lo[s]);
+                label_thresholds_tab((i64)cy_s[pj[s]] - cy_s[pi[s]] + 1, thr_tab, h_table, h_len, tau, &th_hi[s], &th_lo[s]);
             }
         }
         if (threadIdx.x < n) {
@@ -3212,8 +3008,7 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
         //      densely (fewer 64-read rounds), and each of those arrives with the exons that meet the window already located:
         //      exons are ordered, so they are consecutive -- the first with te >= cand_0 up to the last with ts < cand_{n-1}.
         const int cp0 = d.g0 + cy_s[0], c_last = d.g0 + cy_s[n - 1];
-        int n_act = n_pre;
-        if (!pre)
+        int n_act = 0;
         for (int l0 = 0; l0 < d.lane_n; l0 += T) {
             const int l = l0 + (int)threadIdx.x;
             const bool in = l < d.lane_n;
@@ -3252,7 +3047,7 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
             n_act += tot;
             __syncthreads();
         }
-        if (SPLIT && !pre && wide_cand && threadIdx.x == 0) nact_g[p] = n_act;                       // (k_dpw decides as this kernel does; both instances count the same)
+        if (SPLIT && wide_cand && threadIdx.x == 0) nact_g[p] = n_act;                               // (k_dpw decides as this kernel does; both instances count the same)
         if (wide_cand && !wide_by_seen && (sizeof(CntT) == 1) != (n_act <= kFuseLanes)) continue;      // (workgroup-uniform)
         FSEG_STICK(1);
         // this thread's share of a round's coverage: read r_lane, candidates [ja, jb) of 1 .. n-1 (at most kCovJ of them)
@@ -3267,25 +3062,6 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
             // ---- A: window coverage cov[r][j] = positions of the read's closed exons in [cand_0, cand_j)
             //      (get_cumulative_coverage :188-246) = sum over its exons of |[ts, te] n [cand_0, cand_j)|, over the few exons that
             //      meet the window (two per step: their loads depend on nothing but the LDS record, so they fly together)
-            if (pre) {
-                // k_cover's rows of this round, a row per wave and step (lanes = candidates); eight loads in flight per thread
-                const unsigned *g_rows = cov_g + d.cov_off + (i64)r0 * n;
-                constexpr int kRows = kSub / NR;                     // rows per wave
-#pragma unroll
-                for (int b0 = 0; b0 < kRows; b0 += 8) {
-                    unsigned v[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int rr = (b0 + u) * NR + w_rng;
-                        v[u] = g_rows[(rr < n_valid ? rr : 0) * n + (r_lane < n ? r_lane : 0)];
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int rr = (b0 + u) * NR + w_rng;
-                        if (rr < n_valid && r_lane < n) cov[rr * rt_stride + r_lane] = v[u];
-                    }
-                }
-            } else
             {
                 const bool valid = r_lane < n_valid;
                 const int2 a = act_s[r0 + (valid ? r_lane : 0)];
@@ -4546,10 +4322,9 @@ struct fseg_ctx {
     DevBuf d_dp_items, d_solve_items, d_solve_desc, d_prob_desc, d_work_pc, d_cls_items, d_work_active, d_pair_thr, d_amb, d_out, d_cov;
     // hand-over arena between k_solve<.., SPLIT> and k_dpw (dpx_slot_bytes per problem of the three solve lists), laid out by
     // alloc_arenas() for the counts it knew: a launch takes the split path only for a list that fits what was laid out
-    DevBuf d_dpx, d_prob_nact;   // (d_prob_nact: reads every solve-list problem keeps, counted by k_cover)
+    DevBuf d_dpx, d_prob_nact;   // (d_prob_nact: the reads a wide solve-list problem keeps: k_solve<.., SPLIT> tells k_dpw whose counters it used)
     i64 dpx_base[3] = {0, 0, 0}, dpx_stride[3] = {0, 0, 0}, dpx_n[3] = {0, 0, 0};
     int dpx_nm = 0, dpx_cnt[3] = {1, 1, 1};
-    bool precover = false;      // FSEG_PRECOVER=1: k_cover computes thresholds, kept reads and coverage rows ahead of k_solve (measured slower: DESIGN section 8)
     bool split_always = false;  // FSEG_SPLIT_ALWAYS=1 (tests): the split path also where a context keeps to one stream
     int split_dp = 7;           // FSEG_SPLIT_DP: bit 0 / 1 / 2 = the small / mid / large class hands its DPs to k_dpw (0: the DP stays the tail of k_solve's workgroups)
     i64 prob_cap = 0, work_cap = 0, pair_cap = 0, tri_cap = 0, label_cap = 0, chunk_cap = 0, cov_cap = 0;
@@ -5007,7 +4782,6 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
         // when this context has the device to itself (`forking`): with other contexts' batches in flight a context keeps to one
         // stream, where the extra launches cost more than the early release of LDS gains (the 2 M-read job, eight contexts:
         // 383 against 388 M reads/s; the stage alone: 0.146 against 0.160 ms)
-        const bool pre_on = FSEG_PRECOVER && c->precover && wave;    // (k_cover reads the lane-ordered exon stream)
         auto split_ok = [&](int cls, int cnt_bytes) {
             return known && (forking || c->split_always) && cls >= 0 && cls < 3 && ((c->split_dp >> cls) & 1) && c->dpx_n[cls] > 0 && c->n_solve[cls] <= c->dpx_n[cls] && c->dpx_nm == c->nm_big &&
                    cnt_bytes <= c->dpx_cnt[cls] && c->d_dpx.p != nullptr;
@@ -5015,44 +4789,27 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
 #define FSEG_LAUNCH_SOLVE(Q, NMV, CNT, VT, CLS, N_ITEMS, MAXWG)                                                              \
             hipLaunchKernelGGL((k_solve<NMV, CNT, VT, false>), dim3(grid_for((N_ITEMS), 1, known ? (1 << 20) : (MAXWG))), dim3(SolveCfg<NMV>::kThreads), \
                                solve_lds_for((NMV) == kNMax ? c->nm_big : (NMV), (NMV) + 1, (int)sizeof(CNT)), Q,               \
-                               FSEG_SOLVE_ARGS(NMV, CLS), (unsigned char *)nullptr, (i64)0, (const int2 *)nullptr, (const unsigned *)nullptr, \
-                               (int *)nullptr FSEG_TARG)
-        // the split path, one instance: k_solve<.., SPLIT> (rounds only, on k_cover's rows) then k_dpw on the same stream
+                               FSEG_SOLVE_ARGS(NMV, CLS), (unsigned char *)nullptr, (i64)0, (int *)nullptr FSEG_TARG)
+        // the split path, one instance: k_solve<.., SPLIT> (set-up and rounds) then k_dpw (the DPs) on the same stream
 #define FSEG_LAUNCH_SPLIT(Q, NMV, CNT, VT, CLS, N_ITEMS)                                                                     \
         do { const int nm_rt = (NMV) == kNMax ? c->nm_big : (NMV);                                                            \
             unsigned char *dpx0 = c->d_dpx.as<unsigned char>() + c->dpx_base[(CLS) < 0 ? 0 : (CLS)];                                           \
             const i64 dstride = c->dpx_stride[(CLS) < 0 ? 0 : (CLS)];                                                                       \
             hipLaunchKernelGGL((k_solve<NMV, CNT, int, true>), dim3(grid_for((N_ITEMS), 1, 1 << 20)), dim3(SolveCfg<NMV>::kThreads), \
                                solve_lds_for(nm_rt, (NMV) + 1, (int)sizeof(CNT)), Q, FSEG_SOLVE_ARGS(NMV, CLS), dpx0, dstride,    \
-                               pre_on ? c->d_pair_thr.as<int2>() : (const int2 *)nullptr, pre_on ? c->d_cov.as<unsigned>() : (const unsigned *)nullptr, \
                                c->d_prob_nact.as<int>() FSEG_TARG);                                                           \
             hipLaunchKernelGGL((k_dpw<NMV, CNT, VT>), dim3(grid_for((N_ITEMS), 1, 1 << 20)), dim3(64),                         \
                                dpw_lds_for(nm_rt, (int)sizeof(VT), (int)sizeof(CNT)), Q, st, nm_rt, list_lb(CLS), list_ln(CLS), pr,  \
                                c->d_solve_desc.as<ProbDesc>(), dpx0, dstride, c->d_prob_nact.as<int>(), (c->wide_by_seen ? 1 : 0), \
                                c->P.min_read_support_outside, c->d_chosen.as<unsigned char>() FSEG_TARG); } while (0)
-#define FSEG_LAUNCH_COVER(Q, NW, NMV, CLS, N_ITEMS)                                                                          \
-            hipLaunchKernelGGL((k_cover<NW, (NMV) * ((NMV) - 1) / 2>), dim3(grid_for((N_ITEMS), 1, 1 << 20)), dim3(64 * (NW)), 0, Q, st, \
-                               ((NMV) == kNMax ? c->nm_big : (NMV)), list_lb(CLS), list_ln(CLS), c->d_solve_desc.as<ProbDesc>(), \
-                               c->d_cand_y.as<int>(), c->d_lane_lx.as<int2>(), c->d_lex.as<int2>(),                             \
-                               c->d_h_table.as<double>(), c->P.h_len, c->P.threshold_rate, c->d_thr_tab.as<int2>(),             \
-                               c->d_pair_thr.as<int2>(), c->pair_cap, c->d_cov.as<unsigned>(), c->cov_cap, c->d_prob_nact.as<int>() FSEG_TARG)
         // 32-bit DP keys (dp_solve_push) when no sum of a chain can reach 2^24: at most 32 links times the reads of the largest partition
         // (WHICH: 1 = the instance with 8-bit counters, 2 = the one with 16-bit counters if the class has problems for it, 3 = both)
 #define FSEG_LAUNCH_SPLIT_K(Q, NMV, CNT, CLS, N_ITEMS)                                                                        \
             do { if (key32) FSEG_LAUNCH_SPLIT(Q, NMV, CNT, int, CLS, N_ITEMS); else FSEG_LAUNCH_SPLIT(Q, NMV, CNT, i64, CLS, N_ITEMS); } while (0)
 #define FSEG_LAUNCH_SOLVE_X(Q, NMV, CLS, N_ITEMS, MAXWG, WHICH)                                                              \
             do { if (split_ok(CLS, FSEG_WIDE_NEEDED(CLS) ? 2 : 1)) {                                                            \
-                     if (pre_on) {       /* k_cover's rows serve both instances: the class runs whole where its 8-bit instance does */ \
-                         if ((WHICH) & 1) {                                                                                    \
-                             if ((NMV) <= kClsSmall) FSEG_LAUNCH_COVER(Q, 2, NMV, CLS, N_ITEMS);                                 \
-                             else FSEG_LAUNCH_COVER(Q, 4, NMV, CLS, N_ITEMS);                                                   \
-                             FSEG_LAUNCH_SPLIT_K(Q, NMV, unsigned char, CLS, N_ITEMS);                                           \
-                             if (FSEG_WIDE_NEEDED(CLS)) FSEG_LAUNCH_SPLIT_K(Q, NMV, unsigned short, CLS, N_ITEMS);                \
-                         }                                                                                                     \
-                     } else {                                                                                                  \
                          if ((WHICH) & 1) FSEG_LAUNCH_SPLIT_K(Q, NMV, unsigned char, CLS, N_ITEMS);                              \
                          if (((WHICH) & 2) && FSEG_WIDE_NEEDED(CLS)) FSEG_LAUNCH_SPLIT_K(Q, NMV, unsigned short, CLS, N_ITEMS);   \
-                     }                                                                                                         \
                  } else if (key32) { if ((WHICH) & 1) FSEG_LAUNCH_SOLVE(Q, NMV, unsigned char, int, CLS, N_ITEMS, MAXWG);              \
                               if (((WHICH) & 2) && FSEG_WIDE_NEEDED(CLS)) FSEG_LAUNCH_SOLVE(Q, NMV, unsigned short, int, CLS, N_ITEMS, MAXWG); } \
                  else { if ((WHICH) & 1) FSEG_LAUNCH_SOLVE(Q, NMV, unsigned char, i64, CLS, N_ITEMS, MAXWG);                    \
@@ -5139,7 +4896,6 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
 #undef FSEG_LAUNCH_SOLVE_X
 #undef FSEG_LAUNCH_SPLIT_K
 #undef FSEG_LAUNCH_SPLIT
-#undef FSEG_LAUNCH_COVER
 #undef FSEG_LAUNCH_SOLVE
 #undef FSEG_SOLVE_ARGS
 #undef FSEG_LAUNCH_SCORE
@@ -5583,7 +5339,6 @@ int fseg_create(int device, fseg_ctx **out) {
     if (flag("FSEG_FORCE_KEY64")) c->force_key64 = true;
     if (flag("FSEG_WIDE_BY_SEEN")) c->wide_by_seen = true;
     if (const char *e = getenv("FSEG_SPLIT_DP")) c->split_dp = atoi(e) & 7;
-    if (flag("FSEG_PRECOVER")) c->precover = true;
     if (flag("FSEG_SPLIT_ALWAYS")) c->split_always = true;
     { const char *v = getenv("FSEG_GATE_DONE_PCT"); if (v && v[0] && atoi(v) > 0 && atoi(v) <= 100) c->gate_done_pct = atoi(v); }
     if (const char *e = getenv("FSEG_SCORE_PLAN")) snprintf(c->score_plan, sizeof c->score_plan, "%s", e);
