@@ -41,6 +41,8 @@ constexpr int kSmoothShift = 9;
 constexpr int kSmoothTile = 1 << kSmoothShift;   // positions per smoothing tile: intervals average ~1.5 K positions in many-partition
                                                  // batches, and a tile never spans two intervals -- 512 keeps the tiles ~95 % full
 constexpr int kSmoothThreads = kSmoothTile / 4;  // a thread computes 4 consecutive outputs
+constexpr int kSumShift = 4, kSumBlock = 1 << kSumShift;     // positions per block of the histogram's in-tile prefix sums (k_smooth -> k_segments)
+static_assert(kSmoothTile / kSumBlock <= 64 && kSumBlock == 16, "a tile's block sums are scanned by one wave; a block is four threads' positions");
 constexpr int kMaxRadius = 200;        // sigma <= 50, truncate 4.0 (py/freddie_segment.py:106,:755)
 constexpr int kScanBlock = 8192;       // elements per scan workgroup (256 threads x 32 flag bytes)
 constexpr int kNMax = 60;              // largest DP problem handled by the LDS-resident scoring kernel
@@ -317,12 +319,12 @@ template <int R>
 #endif
 __global__ void __launch_bounds__(kSmoothThreads, FSEG_SMOOTH_OCC) k_smooth(int n_tiles, const TileDesc *__restrict__ tiles,
                                                 const int *__restrict__ y_raw, const double *__restrict__ w_g, int radius_rt,
-                                                double *y_out, unsigned char *flag_pos, unsigned char *flag_cand, int *cum, int *tile_tot,
+                                                double *y_out, unsigned char *flag_pos, unsigned char *flag_cand, int *blk_pre, int *tile_tot,
                                                 unsigned char *final_flag, int *tile_defer) {
     __shared__ int xs[kSmoothTile + 2 * kMaxRadius];
     __shared__ __align__(4) unsigned char cf[kSmoothTile];     // candidate flags of the tile
     __shared__ int defer_s;
-    __shared__ int scan_lds[16];
+    __shared__ int blk_s[kSmoothTile / kSumBlock];
     __shared__ double ws[kMaxRadius + 1];
     // the tile's smoothed values: what the candidate test reads of its neighbours (the results themselves leave from
     // registers: a thread's four consecutive positions are 32 / 16 / 4 contiguous bytes of the output arrays, a wave's 256
@@ -365,15 +367,18 @@ __global__ void __launch_bounds__(kSmoothThreads, FSEG_SMOOTH_OCC) k_smooth(int 
         if (t + 2 * G < n_tiles) d_n2 = tiles[t + 2 * G];
         if (t + G < n_tiles) load_counts(d_next, v_cur);             // in flight during this tile's work
         lds_barrier();
-        int c4[4];
-        {   // inclusive prefix sums of the histogram inside the tile + the tile total: lets k_segments evaluate
-            // refine_segmentation's `sum(i_vals) < 20` test (:258) exactly in O(1) per segment
-            int o4 = threadIdx.x * 4, run = 0;
-            for (int e = 0; e < 4; ++e) { run += (y0 + o4 + e < len) ? xs[radius + o4 + e] : 0; c4[e] = run; }
-            int tot;
-            int ex = wg_exclusive_scan_lds<kSmoothThreads / 64>(run, scan_lds, &tot);
-            for (int e = 0; e < 4; ++e) c4[e] += ex;
-            if (threadIdx.x == 0) tile_tot[t] = tot;
+        {   // the histogram's sums over blocks of kSumBlock positions of the tile (four threads' positions each; what lies
+            // beyond the interval counts nothing): with their exclusive prefix inside the tile and the tile's total they let
+            // k_segments answer refine_segmentation's `sum(i_vals) < 20` test (:258) exactly with two look-ups and at most
+            // 31 positions of the histogram itself.  (Round 3 kept an inclusive prefix PER POSITION: a workgroup scan per tile
+            // and 114 MB written per batch -- 25 of this kernel's 158 us.)
+            const int o4 = threadIdx.x * 4;
+            int run = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) run += (y0 + o4 + e < len) ? xs[radius + o4 + e] : 0;
+            run += __builtin_amdgcn_update_dpp(0, run, 0xB1, 0xf, 0xf, false);      // quad_perm [1,0,3,2]: + the neighbour's
+            run += __builtin_amdgcn_update_dpp(0, run, 0x4E, 0xf, 0xf, false);      // quad_perm [2,3,0,1]: + the other pair's
+            if ((threadIdx.x & 3) == 0) blk_s[threadIdx.x >> 2] = run;
         }
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;    // this thread's four outputs (kept for the candidate test below)
         {   // every thread computes 4 consecutive outputs; the two 4-wide input windows of tap j slide by one
@@ -405,6 +410,14 @@ __global__ void __launch_bounds__(kSmoothThreads, FSEG_SMOOTH_OCC) k_smooth(int 
         }
         if (threadIdx.x == 0) defer_s = -1;
         lds_barrier();
+        if (threadIdx.x < kSmoothTile / kSumBlock) {                  // (one wave: the tile's block sums -> exclusive prefixes, total)
+            const int v = blk_s[threadIdx.x];
+            int x = v;
+#pragma unroll
+            for (int dd = 1; dd < kSmoothTile / kSumBlock; dd <<= 1) { const int y = __shfl_up(x, dd); if ((int)threadIdx.x >= dd) x += y; }
+            blk_pre[(i64)t * (kSmoothTile / kSumBlock) + threadIdx.x] = x - v;
+            if (threadIdx.x == kSmoothTile / kSumBlock - 1) tile_tot[t] = x;
+        }
         // S3b candidates (candidates_from_peaks :615-621 = scipy's _local_maxima_1d + the interval's first and last position),
         // decided here while the tile's smoothed values are at hand -- a pass of its own over the signal read all of it back
         // from HBM.  A strict maximum, or the midpoint of a plateau that rises on its left and falls on its right
@@ -454,8 +467,6 @@ __global__ void __launch_bounds__(kSmoothThreads, FSEG_SMOOTH_OCC) k_smooth(int 
                 double2u lo2, hi2; lo2.x = a0; lo2.y = a1; hi2.x = a2; hi2.y = a3;
                 *reinterpret_cast<double2u *>(y_out + p) = lo2;
                 *reinterpret_cast<double2u *>(y_out + p + 2) = hi2;
-                int4u cv; cv.x = c4[0]; cv.y = c4[1]; cv.z = c4[2]; cv.w = c4[3];
-                *reinterpret_cast<int4u *>(cum + p) = cv;
                 uint1u pw; pw.x = (a0 > 0.0 ? 1u : 0u) | (a1 > 0.0 ? 1u << 8 : 0u) | (a2 > 0.0 ? 1u << 16 : 0u) | (a3 > 0.0 ? 1u << 24 : 0u);
                 uint1u cw1; cw1.x = cw;
                 uint1u zero; zero.x = 0;
@@ -470,7 +481,6 @@ __global__ void __launch_bounds__(kSmoothThreads, FSEG_SMOOTH_OCC) k_smooth(int 
                         flag_pos[p + e] = av[e] > 0.0 ? 1 : 0;
                         flag_cand[p + e] = (unsigned char)(cw >> (8 * e));
                         final_flag[p + e] = 0;
-                        cum[p + e] = c4[e];
                     }
             }
         }
@@ -3527,8 +3537,8 @@ __global__ void __launch_bounds__(512) k_dp_huge(Status *st, const int *dp_items
 // previous chosen candidate is more than 40 positions away, records that segment; k_refine then
 // visits the recorded segments (one wave each).
 // ---------------------------------------------------------------------------------------------
-__global__ void k_segments(i64 K, const i64 *pos_off, const i64 *cand_off, const int *cand_y, const int *cum,
-                           const int *tile_tot, const int *iv_tile0, const unsigned char *chosen, unsigned char *final_flag, int *rseg_c, int *rseg_prev,
+__global__ void k_segments(i64 K, const i64 *pos_off, const i64 *cand_off, const int *cand_y, const int *__restrict__ y_raw,
+                           const int *__restrict__ blk_pre, const int *tile_tot, const int *iv_tile0, const unsigned char *chosen, unsigned char *final_flag, int *rseg_c, int *rseg_prev,
                            Status *st) {
     __shared__ int lds[16];
     __shared__ int cnt_s[16];
@@ -3552,15 +3562,33 @@ __global__ void k_segments(i64 K, const i64 *pos_off, const i64 *cand_off, const
             }
             bool need = f && py >= 0 && y - py > 40;                  // :252
             if (need) {
-                // refine_segmentation's `sum(i_vals) < 20 -> continue` (:258), exactly, from the per-tile prefix sums
-                // of the histogram: inner positions [py+20, y-21]
-                int a = py + 20, b = y - 21;
-                int ta = a >> kSmoothShift, tb = b >> kSmoothShift;
-                const int *cm = cum + base;
-                const int *tt = tile_tot + iv_tile0[k];
-                i64 tot = (i64)cm[b] - ((a & (kSmoothTile - 1)) ? cm[a - 1] : 0);
-                if (tb > ta && tb - ta <= 64) { for (int q = ta; q < tb; ++q) tot += tt[q]; }
-                if (tb - ta <= 64) need = tot >= 20;                  // very long segments: k_refine sums them itself
+                // refine_segmentation's `sum(i_vals) < 20 -> continue` (:258), exactly, over the inner positions [py+20, y-21]:
+                // k_smooth's prefix of the histogram at the start of a's and of b's block (inside their tiles), the tiles
+                // between them, and the positions of those two blocks up to a (exclusive) / up to b (inclusive)
+                const int a = py + 20, b = y - 21;
+                const int ta = a >> kSmoothShift, tb = b >> kSmoothShift;
+                if (tb - ta <= 64) {                                  // (very long segments: k_refine sums them itself)
+                    constexpr int kBlocks = kSmoothTile / kSumBlock;
+                    const int t0 = iv_tile0[k];
+                    const int *tt = tile_tot + t0;
+                    const int *yr = y_raw + base;
+                    const int a0 = a & ~(kSumBlock - 1), b0 = b & ~(kSumBlock - 1);
+                    i64 tot = (i64)blk_pre[(i64)(t0 + tb) * kBlocks + ((b & (kSmoothTile - 1)) >> kSumShift)]
+                            - (i64)blk_pre[(i64)(t0 + ta) * kBlocks + ((a & (kSmoothTile - 1)) >> kSumShift)];
+                    // (the two blocks as 16-byte loads from dword-aligned addresses; a block of b's may reach beyond the interval's
+                    // last position -- into the next interval's counts or the slab's padding: masked)
+                    int4u va[kSumBlock / 4], vb[kSumBlock / 4];
+#pragma unroll
+                    for (int e = 0; e < kSumBlock / 4; ++e) { va[e] = *reinterpret_cast<const int4u *>(yr + a0 + 4 * e); vb[e] = *reinterpret_cast<const int4u *>(yr + b0 + 4 * e); }
+#pragma unroll
+                    for (int e = 0; e < kSumBlock / 4; ++e) {
+                        const int pa = a0 + 4 * e, pb = b0 + 4 * e;
+                        tot += (pb <= b ? vb[e].x : 0) + (pb + 1 <= b ? vb[e].y : 0) + (pb + 2 <= b ? vb[e].z : 0) + (pb + 3 <= b ? vb[e].w : 0);
+                        tot -= (pa < a ? va[e].x : 0) + (pa + 1 < a ? va[e].y : 0) + (pa + 2 < a ? va[e].z : 0) + (pa + 3 < a ? va[e].w : 0);
+                    }
+                    for (int q = ta; q < tb; ++q) tot += tt[q];
+                    need = tot >= 20;
+                }
             }
             u64 m = __ballot(need);
             if (lane == 0) cnt_s[wave] = __popcll(m);
@@ -4315,7 +4343,7 @@ struct fseg_ctx {
     DevBuf d_cand_off, d_cand_y, d_fixed0, d_added, d_fixed, d_chosen, d_final_off, d_final_y, d_final_pos, d_final_iv, d_col_thr,
         d_col_zero;
     DevBuf d_tile_defer;        // per smoothing tile: start of the plateau that reaches the tile's end (-1: none)
-    DevBuf d_cum, d_tile_tot, d_seg_iv, d_seg_prev, d_rseg_c, d_cand_pn, d_cand_ll, d_cand_ln, d_prob_bs;
+    DevBuf d_blk_pre, d_tile_tot, d_seg_iv, d_seg_prev, d_rseg_c, d_cand_pn, d_cand_ll, d_cand_ln, d_prob_bs;
     // problems / arenas (slab_arena)
     DevBuf d_prob_iv, d_prob_start, d_prob_n, d_prob_pair_off, d_prob_tri_off, d_prob_flags, d_prob_chain,
         d_prob_cov_off, d_prob_lane_lo, d_prob_lane_n;
@@ -4642,7 +4670,7 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
     hipLaunchKernelGGL(k_smooth<RV>, dim3(tile_grid), dim3(kSmoothThreads), 0, s, c->n_tiles, c->d_tile_desc.as<TileDesc>(),      \
                        c->d_y_raw.as<int>(), c->d_w_main.as<double>(),                                                 \
                        c->P.radius_main, c->d_y.as<double>(), c->d_flag.as<unsigned char>(),                           \
-                       c->d_cflag.as<unsigned char>(), c->d_cum.as<int>(), c->d_tile_tot.as<int>(),                    \
+                       c->d_cflag.as<unsigned char>(), c->d_blk_pre.as<int>(), c->d_tile_tot.as<int>(),                \
                        c->d_final_flag.as<unsigned char>(), c->d_tile_defer.as<int>())
     // sigma = 5 (default) and sigma = 3 (config 5) have their own unrolled instances; any other radius runs the loop
     if (c->P.radius_main == 20) { FSEG_LAUNCH_SMOOTH(20); }
@@ -4977,7 +5005,7 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
     end(ST_DP); begin(ST_REFINE);
     // S6
     hipLaunchKernelGGL(k_segments, dim3(grid_for(K, 1, 8192)), dim3(iv_threads), 0, s, K, c->d_pos_off.as<i64>(),
-                       c->d_cand_off.as<i64>(), c->d_cand_y.as<int>(), c->d_cum.as<int>(), c->d_tile_tot.as<int>(), c->d_iv_tile0.as<int>(),
+                       c->d_cand_off.as<i64>(), c->d_cand_y.as<int>(), c->d_y_raw.as<int>(), c->d_blk_pre.as<int>(), c->d_tile_tot.as<int>(), c->d_iv_tile0.as<int>(),
                        c->d_chosen.as<unsigned char>(), c->d_final_flag.as<unsigned char>(), c->d_rseg_c.as<int>(),
                        c->d_seg_prev.as<int>(), st);
     hipLaunchKernelGGL(k_refine, dim3(2048), dim3(64), 0, s, st, c->d_seg_iv.as<int>(), c->d_rseg_c.as<int>(),
@@ -5663,7 +5691,7 @@ static int upload_impl(fseg_ctx *c, const fseg_batch *b) {
         auto atleast = [](i64 &cap, i64 v) { if (cap < v) cap = v; };
         atleast(c->chunk_cap, NPOS / 8192 + np + 8);              // an upper bound, not a guess
         Carve cv;
-        cv.add(c->d_y_raw, np8 * 4); cv.add(c->d_cum, np8 * 4); cv.add(c->d_y, np8 * 8); cv.add(c->d_flag, np8); cv.add(c->d_cflag, np8);
+        cv.add(c->d_y_raw, np8 * 4); cv.add(c->d_y, np8 * 8); cv.add(c->d_flag, np8); cv.add(c->d_cflag, np8);
         cv.add(c->d_v, np8 * 8);
         cv.add(c->d_scan_state, ((size_t)nb * 3 + 1) * 8);
         cv.add(c->d_bsum, ((size_t)nb + 2) * 4);
@@ -5672,6 +5700,7 @@ static int upload_impl(fseg_ctx *c, const fseg_batch *b) {
         cv.add(c->d_final_flag, np8);
         cv.add(c->d_part_has2, ((size_t)np + 1) * 4);
         cv.add(c->d_tile_tot, ((size_t)n_tiles + 1) * 4);
+        cv.add(c->d_blk_pre, ((size_t)n_tiles + 1) * (kSmoothTile / kSumBlock) * 4);
         cv.add(c->d_tile_defer, ((size_t)n_tiles + 1) * 4);
         cv.add(c->d_voff, ((size_t)np + 2) * 8); cv.add(c->d_chunk_off, ((size_t)np + 2) * 8);
         cv.add(c->d_mean, ((size_t)np + 1) * 8); cv.add(c->d_thr, ((size_t)np + 1) * 8);
