@@ -167,8 +167,10 @@ int fseg_tap(fseg_ctx *ctx, int what, void *dst, int64_t cap_bytes, int64_t *n_b
 
 /* Timing support for benchmarks: HIP-event time of the last run in milliseconds, per stage.
  * Stage names are returned by fseg_stage_name(i); n_stages by fseg_n_stages().  Only filled
- * when profiling was enabled with fseg_set_profiling(ctx, 1) (adds event records: two per stage); with 2 only the
- * interval-scoring stage is bracketed (two records per run; the other stages report 0). */
+ * when profiling was enabled with fseg_set_profiling(ctx, 1) (adds event records: two per stage; on replays of a resident
+ * batch only the interval-scoring stage and the two graphs around it are bracketed); with 2 only the interval-scoring
+ * stage is bracketed (two records per run; the other stages report 0); with 3 every stage is bracketed on replays too
+ * (plain launches instead of the graph: what bench.py's config2 leg sums coverage + scoring + DP from). */
 int fseg_set_profiling(fseg_ctx *ctx, int on);
 int fseg_n_stages(void);
 const char *fseg_stage_name(int i);

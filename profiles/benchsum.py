@@ -10,6 +10,11 @@ for line in sys.stdin:
         d.get("roofline_concurrent", {}).get("launch_ms", 0.0)))
     st = d.get("roofline_stages") or {}
     print("  " + " ".join("%s=%.3f%s" % (k, v["ms"], ("(%.2f)" % v["frac"]) if "frac" in v else "") for k, v in st.items()))
+    for w in ("config2", "config3", "config5"):
+        rw = d.get("roofline_" + w)
+        if rw:
+            print("  %s stage alone %.3f ms frac=%.3f%s" % (w, rw["launch_ms"], rw["frac"],
+                  (" (k_score only %.3f)" % rw["k_score_only"]["frac"]) if "k_score_only" in rw else ""))
     e = d.get("e2e") or {}
     if "value" in e:
         print("  e2e %.3gM reads/s (%s s)" % (e["value"] / 1e6, ",".join("%.2f" % x for x in e["wall_s"])))

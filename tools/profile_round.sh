@@ -12,8 +12,9 @@ python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_default.json 2> $O/ben
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o p -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-e2e > $O/bench_under_rocprof.json 2> $O/stats.err
 python profiles/benchsum.py < $O/bench_under_rocprof.json | head -1
 python profiles/trace_medians.py $O/stats/p_kernel_trace.csv > $O/config4_kernel_medians_8ctx.txt
-# 2. one context, one stream, one resident batch replayed: per-kernel durations with the GPU to themselves (what `roofline` times)
-FSEG_NO_FORK=1 FSEG_NO_GRAPH=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace1 -o p -- python3 tools/replay_probe.py --workload config4 > $O/replay_config4.txt 2> $O/trace1.err
+# 2. one context, one stream, one resident batch replayed: per-kernel durations with the GPU to themselves (the kernels `roofline`
+#    times: FSEG_SPLIT_ALWAYS keeps the split path -- k_solve's rounds + k_dpw -- although the streams are not forked)
+FSEG_SPLIT_ALWAYS=1 FSEG_NO_FORK=1 FSEG_NO_GRAPH=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace1 -o p -- python3 tools/replay_probe.py --workload config4 > $O/replay_config4.txt 2> $O/trace1.err
 python profiles/trace_medians.py $O/trace1/p_kernel_trace.csv > $O/config4_kernel_medians.txt
 FSEG_NO_FORK=1 FSEG_NO_GRAPH=1 rocprofv3 --kernel-trace --output-format csv -d $O/trace2 -o p -- python3 tools/replay_probe.py --workload config2 > $O/replay_config2.txt 2> $O/trace2.err
 python profiles/trace_medians.py $O/trace2/p_kernel_trace.csv > $O/config2_kernel_medians.txt
@@ -24,9 +25,9 @@ python tools/stage_span.py $O/trace3/p_kernel_trace.csv > $O/config4_stage_span.
 # 3. counters, each in its own pass
 for w in config4 config2; do
   for pmc in FETCH_SIZE WRITE_SIZE; do
-    FSEG_NO_FORK=1 rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d $O/pmc_${w}_$pmc -o p -- python3 tools/replay_probe.py --workload $w > /dev/null 2> $O/pmc_${w}_$pmc.err
+    FSEG_SPLIT_ALWAYS=1 FSEG_NO_FORK=1 rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d $O/pmc_${w}_$pmc -o p -- python3 tools/replay_probe.py --workload $w > /dev/null 2> $O/pmc_${w}_$pmc.err
   done
-  FSEG_NO_FORK=1 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_${w}_sq -o p -- python3 tools/replay_probe.py --workload $w > /dev/null 2> $O/pmc_${w}_sq.err
+  FSEG_SPLIT_ALWAYS=1 FSEG_NO_FORK=1 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_${w}_sq -o p -- python3 tools/replay_probe.py --workload $w > /dev/null 2> $O/pmc_${w}_sq.err
   python profiles/pmc_summary.py $O/pmc_${w}_FETCH_SIZE/p_counter_collection.csv $O/pmc_${w}_WRITE_SIZE/p_counter_collection.csv > $O/${w}_pmc_summary.txt
   python tools/sq_summary.py $O/pmc_${w}_sq/p_counter_collection.csv $O/pmc_${w}_sq/p_kernel_trace.csv > $O/${w}_sq_summary.txt
 done
