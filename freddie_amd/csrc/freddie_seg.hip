@@ -105,6 +105,8 @@ struct Status {
     u64 n_tiny;        // problems solved whole by k_tiny (their list follows the three solve lists)
     unsigned list_cur[8];   // k_prob_emit's cursors into the four solve lists: [2 * list] from the front (expensive problems), [2 * list + 1] from the back
     unsigned wide_cls[4];   // solve-list problems per size class that see more than kFuseLanes reads (16-bit counters); [3] unused
+    unsigned wide_cur[4];   // k_prob_emit's cursors into the per-class lists of those problems (wide_items)
+    unsigned gate_wide;     // workgroups of the large class's 16-bit instance that have started ('h' in a plan: the 8-bit instance waits for them)
     unsigned gate;          // large-class workgroups that have started (k_gate holds the small classes back until they are placed)
     unsigned gate_done;     // large-class workgroups that have ended (a counter of the mid class's 2 000 workgroups, bumped by each as it
                             // started, cost that kernel 10 of its 62 us: these two count a few hundred)
@@ -1418,7 +1420,7 @@ __global__ void __launch_bounds__(256) k_prob_emit(Status *st, const int *cand_p
                                                    ProblemArrays pr, i64 prob_cap, int2 *work_pc, int4 *cls_items,
                                                    i64 work_cap, int *dp_items, ProbDesc *desc, const int *iv_start,
                                                    const int *iv_part, const i64 *part_lane_off, ProbSplit sp, int *solve_items,
-                                                   ProbDesc *solve_desc) {
+                                                   ProbDesc *solve_desc, int *wide_items) {
     __shared__ i64 lds[4 * kProbCols];
     __shared__ int l_slot[kProbBlock], l_cnt[kProbBlock];
     __shared__ int l_mx[8];
@@ -1520,7 +1522,17 @@ __global__ void __launch_bounds__(256) k_prob_emit(Status *st, const int *cand_p
                         const i64 si = (le4[e] & 1) ? lbase + llen - 1 - off : lbase + off;
                         // the kernels of the solve lists read the record from the list itself (one load less in every problem's
                         // chain of dependent loads); w0, the arena path's work item, is the problem's slot there
-                        if (si >= lbase && si < lbase + llen && si < prob_cap) { solve_items[si] = (int)slot; d.w0 = (int)slot; solve_desc[si] = d; }
+                        if (si >= lbase && si < lbase + llen && si < prob_cap) {
+                            solve_items[si] = (int)slot; d.w0 = (int)slot; solve_desc[si] = d;
+                            // the problems of a solve list that see more than kFuseLanes reads, as list positions: what the
+                            // 16-bit-counter instances are launched over (a class has a handful; as launches over the whole
+                            // list their 90 KB workgroups waited for room behind everything else: config3, one such problem
+                            // started 127 us into the stage)
+                            if (li < 3 && d.lane_n > kFuseLanes) {
+                                const i64 wp = lbase + (i64)atomicAdd(&st->wide_cur[li], 1u);
+                                if (wp < lbase + llen && wp < prob_cap) wide_items[wp] = (int)(si - lbase);
+                            }
+                        }
                     }
                     if (kind == kKindArena) {   // DP problem lists: the small problems first, then the big ones
                         // (then the huge ones); k_tiny's and k_solve's problems are in no DP list
@@ -2860,11 +2872,11 @@ __global__ void __launch_bounds__(256, WaveCfg<NM>::kOcc) k_wave(Status *st, con
 // large class running alone on a mostly empty chip.  k_gate is what the side stream runs first: one wave that waits until the
 // large class's workgroups have all started (they all fit the chip at once) or `max_ticks` of the 100 MHz clock have passed --
 // an exit every launch reaches -- so the small classes fill the space the large one leaves instead of taking it first.
-__global__ void __launch_bounds__(64) k_gate(Status *st, int done, unsigned want_max, unsigned pct, unsigned max_ticks) {
-    const u64 n2 = st->solve_cls[2];
-    const unsigned grid = n2 < want_max ? (unsigned)n2 : want_max;
-    const unsigned want = done ? (grid * pct + 99) / 100 : grid;     // done: that share of the large class's workgroups has ENDED
-    const unsigned *ctr = done ? &st->gate_done : &st->gate;
+__global__ void __launch_bounds__(64) k_gate(Status *st, int done, unsigned grid, unsigned pct, unsigned max_ticks) {
+    // grid: the large class's workgroups the plan has launched (8-bit instance, and for the start gate the 16-bit one's too), at
+    // most as many as fit the chip at once
+    const unsigned want = done == 1 ? (grid * pct + 99) / 100 : grid;     // done == 1: that share of the large class's workgroups has ENDED
+    const unsigned *ctr = done == 1 ? &st->gate_done : (done == 2 ? &st->gate_wide : &st->gate);   // (2: the 16-bit instance's have started)
     const unsigned long long t0 = wall_clock64();
     while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want && wall_clock64() - t0 < max_ticks)
         __builtin_amdgcn_s_sleep(16);
@@ -2920,7 +2932,8 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
                                                                   const longlong2 *lane_ex, const int *ex_ts, const int *ex_te,
                                                                   const double *h_table, int h_len, double tau, const int2 *thr_tab,
                                                                   int support, unsigned char *chosen, int wide_by_seen,
-                                                                  unsigned char *dpx, i64 dpx_stride, int *nact_g FSEG_TPARAM) {
+                                                                  unsigned char *dpx, i64 dpx_stride, int *nact_g,
+                                                                  const int *__restrict__ wide_items FSEG_TPARAM) {
     using C = SolveCfg<NM>;
     constexpr int T = C::kThreads, NR = C::kRanges;
     constexpr int PACK = 4 / (int)sizeof(CntT);                    // counters per 32-bit read-modify-write
@@ -2941,7 +2954,7 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
     unsigned char *A = reinterpret_cast<unsigned char *>(in_s + rt_pairs);
     // the DP is one wave's (dp_solve_wave) except where its registers would not fit: the large class with 64-bit sums
     constexpr bool kWaveDp = FSEG_WAVE_DP && (NM <= 32 || sizeof(V) == 4);
-    if (NM == kNMax && sizeof(CntT) == 1 && threadIdx.x == 0) atomicAdd(&st->gate, 1u);     // placed: see k_gate
+    if (NM == kNMax && threadIdx.x == 0) { atomicAdd(&st->gate, 1u); if (sizeof(CntT) != 1) atomicAdd(&st->gate_wide, 1u); }   // placed: see k_gate
     // (lb_h >= 0: the host knows the lists' sizes -- the batch has been sized --, and the status record is not on the way to the first problem)
     if (lb_h < 0 && (i64)st->n_prob > prob_cap) return;              // lists incomplete (a run that only sizes the arenas)
 #ifdef FSEG_SOLVE_PRIO
@@ -2962,10 +2975,12 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
 #else
 #define FSEG_STICK(i)
 #endif
-    for (i64 t = blockIdx.x; t < list_n; t += gridDim.x) {           // static stride; the lists are in candidate order
+    for (i64 tt = blockIdx.x; tt < list_n; tt += gridDim.x) {         // static stride; the lists are in candidate order
 #ifdef FSEG_SCORE_TIMING
         const unsigned long long t_prob0 = wall_clock64();
 #endif
+        // (wide_items: this launch goes over the list's problems that see more than kFuseLanes reads only -- list_n of them)
+        const i64 t = wide_items ? (i64)uni(wide_items[list_base + tt]) : tt;
         const ProbDesc d = FSEG_LOAD_DESC(desc + list_base + t);    // (the list's own copy of the record: k_prob_emit)
         const int p = d.w0;
         const int n = d.n;
@@ -3286,11 +3301,11 @@ inline size_t dpw_lds_for(int nm, int key_bytes, int cnt_bytes) {
 template <int NM, typename OutT, typename V>
 __global__ void __launch_bounds__(64) k_dpw(Status *st, int nm, i64 list_base, i64 list_n, ProblemArrays pr, const ProbDesc *desc,
                                             const unsigned char *dpx, i64 dpx_stride, const int *__restrict__ nact_g, int wide_by_seen,
-                                            int support, unsigned char *chosen FSEG_TPARAM) {
+                                            int support, unsigned char *chosen, const int *__restrict__ wide_items FSEG_TPARAM) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = lane_id();
-    const i64 t = blockIdx.x;
-    if (t >= list_n) return;
+    if ((i64)blockIdx.x >= list_n) return;
+    const i64 t = wide_items ? (i64)uni(wide_items[list_base + blockIdx.x]) : (i64)blockIdx.x;
 #ifdef FSEG_SCORE_TIMING
     const unsigned long long t_dp0 = wall_clock64();
 #endif
@@ -3327,6 +3342,8 @@ __global__ void __launch_bounds__(64) k_dpw(Status *st, int nm, i64 list_base, i
     __shared__ unsigned long long tick_sink[16];
     unsigned long long *dp_tacc = tick_sink; unsigned long long dt_prev = 0;
 #endif
+    // (s_setprio 3 for this wave -- a chain of dependent instructions that its class's chain ends with -- made the stage slower:
+    // config3 0.210 -> 0.245-0.270 ms, config4 0.147 -> 0.151)
     const int chain = dp_solve_wave<NM>(n, out_s, in_s, M, A, support, chosen + d.c0 FSEG_DARG);
     if (lane == 0) pr.chain[d.w0] = chain;
 #ifdef FSEG_SCORE_TIMING
@@ -4350,6 +4367,7 @@ struct fseg_ctx {
     DevBuf d_dp_items, d_solve_items, d_solve_desc, d_prob_desc, d_work_pc, d_cls_items, d_work_active, d_pair_thr, d_amb, d_out, d_cov;
     // hand-over arena between k_solve<.., SPLIT> and k_dpw (dpx_slot_bytes per problem of the three solve lists), laid out by
     // alloc_arenas() for the counts it knew: a launch takes the split path only for a list that fits what was laid out
+    DevBuf d_wide_items;         // per solve list: the list positions of the problems that see more than kFuseLanes reads (k_prob_emit)
     DevBuf d_dpx, d_prob_nact;   // (d_prob_nact: the reads a wide solve-list problem keeps: k_solve<.., SPLIT> tells k_dpw whose counters it used)
     i64 dpx_base[3] = {0, 0, 0}, dpx_stride[3] = {0, 0, 0}, dpx_n[3] = {0, 0, 0};
     int dpx_nm = 0, dpx_cnt[3] = {1, 1, 1};
@@ -4400,7 +4418,7 @@ struct fseg_ctx {
     bool force_key64 = false;
     bool wide_by_seen = false;  // FSEG_WIDE_BY_SEEN=1 (tests)
     int gate_done_pct = 60;     // FSEG_GATE_DONE_PCT: the share of the large class's workgroups that has to have ended for 'd' in the plan
-    char score_plan[32] = "gM|B|gTS|bms";  // FSEG_SCORE_PLAN (see enqueue_run; anything that does not name each class once = one stream)
+    char score_plan[32] = "gM|hB|msgTS|b"; // FSEG_SCORE_PLAN (see enqueue_run; anything that does not name each class once = one stream)
     bool score_fork = false;    // FSEG_SCORE_FORK=1: the fused scoring kernels on a stream each
     bool use_wave = true;       // FSEG_NO_WAVE=1: k_tiny / k_solve<16> instead of the wave kernels (k_wave)
     bool wave_small = false;    // FSEG_WAVE_SMALL=1: the small class (9 .. 16 candidates) goes to k_wave<16> instead of k_solve<16> (one wave
@@ -4543,6 +4561,7 @@ int alloc_arenas(fseg_ctx *c) {
     cv.add(c->d_prob_nact, (size_t)c->prob_cap * 4);
     cv.add(c->d_dp_items, (size_t)c->prob_cap * 4);
     cv.add(c->d_solve_items, (size_t)c->prob_cap * 4);
+    cv.add(c->d_wide_items, (size_t)c->prob_cap * 4);
     cv.add(c->d_solve_desc, (size_t)c->prob_cap * sizeof(ProbDesc));
     cv.add(c->d_prob_cov_off, (size_t)c->prob_cap * 8);
     cv.add(c->d_prob_lane_lo, (size_t)c->prob_cap * 4);
@@ -4736,7 +4755,8 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
                        c->d_cand_ln.as<int>(), c->d_seg_iv.as<int>(), c->d_cand_off.as<i64>(), prob_bs,
                        pr, c->prob_cap, c->d_work_pc.as<int2>(), c->d_cls_items.as<int4>(),
                        c->work_cap, c->d_dp_items.as<int>(), c->d_prob_desc.as<ProbDesc>(), c->d_iv_start.as<int>(),
-                       c->d_iv_part.as<int>(), c->d_part_lane_off.as<i64>(), split, c->d_solve_items.as<int>(), c->d_solve_desc.as<ProbDesc>());
+                       c->d_iv_part.as<int>(), c->d_part_lane_off.as<i64>(), split, c->d_solve_items.as<int>(), c->d_solve_desc.as<ProbDesc>(),
+                       c->d_wide_items.as<int>());
     // S5
     if (c->prob_cap > 0 && any_arena) {
         const int cov_blocks = work_grid < 2048 ? work_grid : 2048;
@@ -4800,8 +4820,13 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
                            c->d_cand_y.as<int>(), c->d_work_active.as<unsigned char>(), c->d_cov.as<unsigned>(),        \
                            c->cov_cap, c->d_pair_thr.as<int2>(), c->pair_cap, c->d_out.as<unsigned>(), c->tri_cap,      \
                            c->d_amb.as<unsigned>() FSEG_TARG)
-#define FSEG_SOLVE_ARGS(NMV, CLS)                                                                                           \
-                               st, CLS, ((NMV) == kNMax ? c->nm_big : (NMV)), list_lb(CLS), list_ln(CLS), pr, c->d_solve_desc.as<ProbDesc>(), \
+        // (a 16-bit-counter instance of a sized batch goes over its class's WIDE problems only: wide_n of them, through wide_items)
+        auto wide_n = [&](int cls, size_t cnt_bytes) -> i64 { return (known && cls >= 0 && cls < 3 && cnt_bytes == 2) ? c->n_wide[cls] : -1; };
+#define FSEG_SOLVE_N(CNT, CLS, N_ITEMS) (wide_n(CLS, sizeof(CNT)) >= 0 ? wide_n(CLS, sizeof(CNT)) : (i64)(N_ITEMS))
+#define FSEG_SOLVE_WIDE(CNT, CLS) (wide_n(CLS, sizeof(CNT)) >= 0 ? c->d_wide_items.as<int>() : (const int *)nullptr)
+#define FSEG_SOLVE_ARGS(NMV, CNT, CLS)                                                                                      \
+                               st, CLS, ((NMV) == kNMax ? c->nm_big : (NMV)), list_lb(CLS),                                    \
+                               (wide_n(CLS, sizeof(CNT)) >= 0 ? wide_n(CLS, sizeof(CNT)) : list_ln(CLS)), pr, c->d_solve_desc.as<ProbDesc>(), \
                                c->prob_cap, c->d_cand_y.as<int>(), c->d_lane_ex.as<longlong2>(), c->d_ex_ts.as<int>(),         \
                                c->d_ex_te.as<int>(), c->d_h_table.as<double>(), c->P.h_len, c->P.threshold_rate,               \
                                c->d_thr_tab.as<int2>(), c->P.min_read_support_outside, c->d_chosen.as<unsigned char>(),       \
@@ -4815,21 +4840,22 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
                    cnt_bytes <= c->dpx_cnt[cls] && c->d_dpx.p != nullptr;
         };
 #define FSEG_LAUNCH_SOLVE(Q, NMV, CNT, VT, CLS, N_ITEMS, MAXWG)                                                              \
-            hipLaunchKernelGGL((k_solve<NMV, CNT, VT, false>), dim3(grid_for((N_ITEMS), 1, known ? (1 << 20) : (MAXWG))), dim3(SolveCfg<NMV>::kThreads), \
+            hipLaunchKernelGGL((k_solve<NMV, CNT, VT, false>), dim3(grid_for(FSEG_SOLVE_N(CNT, CLS, N_ITEMS), 1, known ? (1 << 20) : (MAXWG))), dim3(SolveCfg<NMV>::kThreads), \
                                solve_lds_for((NMV) == kNMax ? c->nm_big : (NMV), (NMV) + 1, (int)sizeof(CNT)), Q,               \
-                               FSEG_SOLVE_ARGS(NMV, CLS), (unsigned char *)nullptr, (i64)0, (int *)nullptr FSEG_TARG)
+                               FSEG_SOLVE_ARGS(NMV, CNT, CLS), (unsigned char *)nullptr, (i64)0, (int *)nullptr, FSEG_SOLVE_WIDE(CNT, CLS) FSEG_TARG)
         // the split path, one instance: k_solve<.., SPLIT> (set-up and rounds) then k_dpw (the DPs) on the same stream
 #define FSEG_LAUNCH_SPLIT(Q, NMV, CNT, VT, CLS, N_ITEMS)                                                                     \
         do { const int nm_rt = (NMV) == kNMax ? c->nm_big : (NMV);                                                            \
             unsigned char *dpx0 = c->d_dpx.as<unsigned char>() + c->dpx_base[(CLS) < 0 ? 0 : (CLS)];                                           \
             const i64 dstride = c->dpx_stride[(CLS) < 0 ? 0 : (CLS)];                                                                       \
-            hipLaunchKernelGGL((k_solve<NMV, CNT, int, true>), dim3(grid_for((N_ITEMS), 1, 1 << 20)), dim3(SolveCfg<NMV>::kThreads), \
-                               solve_lds_for(nm_rt, (NMV) + 1, (int)sizeof(CNT)), Q, FSEG_SOLVE_ARGS(NMV, CLS), dpx0, dstride,    \
-                               c->d_prob_nact.as<int>() FSEG_TARG);                                                           \
-            hipLaunchKernelGGL((k_dpw<NMV, CNT, VT>), dim3(grid_for((N_ITEMS), 1, 1 << 20)), dim3(64),                         \
-                               dpw_lds_for(nm_rt, (int)sizeof(VT), (int)sizeof(CNT)), Q, st, nm_rt, list_lb(CLS), list_ln(CLS), pr,  \
+            hipLaunchKernelGGL((k_solve<NMV, CNT, int, true>), dim3(grid_for(FSEG_SOLVE_N(CNT, CLS, N_ITEMS), 1, 1 << 20)), dim3(SolveCfg<NMV>::kThreads), \
+                               solve_lds_for(nm_rt, (NMV) + 1, (int)sizeof(CNT)), Q, FSEG_SOLVE_ARGS(NMV, CNT, CLS), dpx0, dstride, \
+                               c->d_prob_nact.as<int>(), FSEG_SOLVE_WIDE(CNT, CLS) FSEG_TARG);                                    \
+            hipLaunchKernelGGL((k_dpw<NMV, CNT, VT>), dim3(grid_for(FSEG_SOLVE_N(CNT, CLS, N_ITEMS), 1, 1 << 20)), dim3(64),      \
+                               dpw_lds_for(nm_rt, (int)sizeof(VT), (int)sizeof(CNT)), Q, st, nm_rt, list_lb(CLS),                \
+                               FSEG_SOLVE_N(CNT, CLS, list_ln(CLS)), pr,                                                        \
                                c->d_solve_desc.as<ProbDesc>(), dpx0, dstride, c->d_prob_nact.as<int>(), (c->wide_by_seen ? 1 : 0), \
-                               c->P.min_read_support_outside, c->d_chosen.as<unsigned char>() FSEG_TARG); } while (0)
+                               c->P.min_read_support_outside, c->d_chosen.as<unsigned char>(), FSEG_SOLVE_WIDE(CNT, CLS) FSEG_TARG); } while (0)
         // 32-bit DP keys (dp_solve_push) when no sum of a chain can reach 2^24: at most 32 links times the reads of the largest partition
         // (WHICH: 1 = the instance with 8-bit counters, 2 = the one with 16-bit counters if the class has problems for it, 3 = both)
 #define FSEG_LAUNCH_SPLIT_K(Q, NMV, CNT, CLS, N_ITEMS)                                                                        \
@@ -4890,9 +4916,24 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
                 hipEvent_t ev_big = nullptr;
                 // b m s: the class's instance with 16-bit counters on its own (B M S then launch the 8-bit one only)
                 const int wb = strchr(plan, 'b') ? 1 : 3, wm = strchr(plan, 'm') ? 1 : 3, ws = strchr(plan, 's') ? 1 : 3;
+                // the large class's workgroups a start gate waits for: the 8-bit instance's and the 16-bit instance's (one per wide
+                // problem) -- the latter need 90 KB of LDS each and find no room once the other classes are in
+                const i64 big_wgs = c->n_solve[2] + (FSEG_WIDE_NEEDED(2) ? c->n_wide[2] : 0);
+                // Three passes over the plan: the large class's launches that open their stream go out FIRST -- the 16-bit instance
+                // (b), then the 8-bit one (B, behind `h` = a gate on b's workgroups having started) --, everything else follows in
+                // plan order (a stream's own order is kept).  Why: a workgroup of the 16-bit instance holds up to 120 KB of LDS (n
+                // <= 60: planes 28 + coverage 16 + 16-bit counters 68 KB) and fits no CU that has one of the 8-bit instance's
+                // (81 KB); enqueued behind it, config3's one real wide problem was placed 135-150 us into the stage, when the 8-bit
+                // instance and the classes behind the gate had drained, and the stage took 0.29 ms (tools/stage_timeline.py).  A
+                // class has a handful of wide problems: placed first they take a few CUs and the 8-bit instance the rest.
+                for (int pass = 0; pass < 3; ++pass) {                       // 0: b   1: h, B   2: the rest
+                seg = 0;
+                bool opens = true;
                 for (const char *p = plan; *p && seg < n_seg; ++p) {
-                    if (*p == '|') { ++seg; continue; }
-                    if (!used[seg]) continue;
+                    if (*p == '|') { ++seg; opens = true; continue; }
+                    const int when = !opens ? 2 : (*p == 'b' ? 0 : ((*p == 'B' || *p == 'h') ? 1 : 2));
+                    if (*p != 'h') opens = false;
+                    if (!used[seg] || when != pass) continue;
                     hipStream_t q = seg == 0 ? s : c->side[seg - 1];
                     switch (*p) {
                     case 'B': FSEG_LAUNCH_SOLVE_X(q, kNMax, 2, c->n_solve[2], 512, wb);
@@ -4903,11 +4944,15 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
                     case 'm': if (c->n_solve[1] > 0) FSEG_LAUNCH_SOLVE_X(q, kClsMid, 1, c->n_solve[1], FSEG_WG_MID, 2); break;
                     case 's': if (c->n_solve[0] > 0) FSEG_LAUNCH_SOLVE_X(q, kClsSmall, 0, c->n_solve[0], FSEG_WG_SMALL, 2); break;
                     case 'T': if (c->n_tiny > 0) FSEG_LAUNCH_WAVE(q, kTiny, 3, c->n_tiny); break;
-                    case 'g': hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, q, st, 0, (unsigned)(c->n_solve[2] < 512 ? c->n_solve[2] : 512), 100u, 3000u); break;
+                    case 'g': hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, q, st, 0, (unsigned)(big_wgs < 512 ? big_wgs : 512), 100u, 3000u); break;
+                    case 'h': if (FSEG_WIDE_NEEDED(2) && c->n_wide[2] > 0)       // the 16-bit instance's workgroups (up to 120 KB of LDS each) take their CUs first
+                                  hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, q, st, 2, (unsigned)(c->n_wide[2] < 256 ? c->n_wide[2] : 256), 100u, 1500u);
+                              break;
                     case 'd': hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, q, st, 1, (unsigned)(c->n_solve[2] < 512 ? c->n_solve[2] : 512), (unsigned)c->gate_done_pct, 15000u); break;
                     case 'e': if (ev_big && hipStreamWaitEvent(q, ev_big, 0) != hipSuccess) fj_err = hipErrorUnknown; break;
                     default: break;
                     }
+                }
                 }
                 for (int k = 1; k < n_seg; ++k) if (used[k]) join(k - 1);
             } else {
@@ -4926,6 +4971,8 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
 #undef FSEG_LAUNCH_SPLIT
 #undef FSEG_LAUNCH_SOLVE
 #undef FSEG_SOLVE_ARGS
+#undef FSEG_SOLVE_WIDE
+#undef FSEG_SOLVE_N
 #undef FSEG_LAUNCH_SCORE
         if (tiny_max > 0 && !plan) {
             // the problems with a handful of candidates, whole (coverage, labels, counts, DP), beside the others (launched

@@ -76,6 +76,8 @@ SWITCHES = [
     {"FSEG_SPLIT_ALWAYS": "1", "FSEG_NO_FORK": "1"},        # k_solve + k_dpw on ONE stream
     {"FSEG_SPLIT_ALWAYS": "1", "FSEG_NO_FORK": "1", "FSEG_FORCE_KEY64": "1", "FSEG_FUSE_LANES": "1023"},   # k_dpw with 64-bit keys, the 16-bit instances behind the 8-bit ones
     {"FSEG_FUSE_LANES": "1023", "FSEG_WIDE_BY_SEEN": "1"},  # wide problems (16-bit counters) through the split path, chosen by the reads they see
+    {"FSEG_FUSE_LANES": "1023", "FSEG_WIDE_BY_SEEN": "1", "FSEG_SPLIT_DP": "0"},   # ... and fused: the 16-bit instances go over their classes' wide lists either way
+    {"FSEG_FUSE_LANES": "1023", "FSEG_SCORE_PLAN": "gM|B|gTS|bms"},    # no `h` gate, the 16-bit instances one after the other on a stream
 ]
 
 
