@@ -108,8 +108,8 @@ struct Status {
     unsigned wide_cur[4];   // k_prob_emit's cursors into the per-class lists of those problems (wide_items)
     unsigned gate_wide;     // workgroups of the large class's 16-bit instance that have started ('h' in a plan: the 8-bit instance waits for them)
     unsigned gate;          // large-class workgroups that have started (k_gate holds the small classes back until they are placed)
-    unsigned gate_done;     // large-class workgroups that have ended (a counter of the mid class's 2 000 workgroups, bumped by each as it
-                            // started, cost that kernel 10 of its 62 us: these two count a few hundred)
+                            // (a counter of the mid class's 2 000 workgroups, bumped by each as it started, cost that kernel 10 of
+                            // its 62 us: these two count a few hundred)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -1245,11 +1245,10 @@ __device__ __forceinline__ int size_class(int n) { return n <= kClsSmall ? 0 : (
 //     (problems that see many reads need many workgroups to score them).
 //   with the wave kernels (k_wave: the batch has its exon stream) the small class -- n <= wave_n -- is solved whole, one wave
 //     per problem, whenever the problem sees at most wave_lanes reads, whatever the rest of the batch looks like.
-struct ProbSplit { int tiny_max, fuse_lanes, wave_n, wave_lanes; };
+struct ProbSplit { int tiny_max, fuse_lanes; };
 enum { kKindArena = 0, kKindTiny = 1, kKindFused = 2 };
 __device__ __forceinline__ int prob_kind(int n, int n_lanes, ProbSplit sp) {
     if (n <= sp.tiny_max) return kKindTiny;
-    if (n <= sp.wave_n && n_lanes <= sp.wave_lanes) return kKindFused;
     return (n_lanes <= sp.fuse_lanes && n <= kNMax) ? kKindFused : kKindArena;
 }
 __device__ __forceinline__ ProbSizes prob_sizes(int n, int n_lanes, ProbSplit sp) {
@@ -2872,11 +2871,11 @@ __global__ void __launch_bounds__(256, WaveCfg<NM>::kOcc) k_wave(Status *st, con
 // large class running alone on a mostly empty chip.  k_gate is what the side stream runs first: one wave that waits until the
 // large class's workgroups have all started (they all fit the chip at once) or `max_ticks` of the 100 MHz clock have passed --
 // an exit every launch reaches -- so the small classes fill the space the large one leaves instead of taking it first.
-__global__ void __launch_bounds__(64) k_gate(Status *st, int done, unsigned grid, unsigned pct, unsigned max_ticks) {
+__global__ void __launch_bounds__(64) k_gate(Status *st, int which, unsigned grid, unsigned max_ticks) {
     // grid: the large class's workgroups the plan has launched (8-bit instance, and for the start gate the 16-bit one's too), at
     // most as many as fit the chip at once
-    const unsigned want = done == 1 ? (grid * pct + 99) / 100 : grid;     // done == 1: that share of the large class's workgroups has ENDED
-    const unsigned *ctr = done == 1 ? &st->gate_done : (done == 2 ? &st->gate_wide : &st->gate);   // (2: the 16-bit instance's have started)
+    const unsigned want = grid;
+    const unsigned *ctr = which == 2 ? &st->gate_wide : &st->gate;      // (2: the 16-bit instance's workgroups)
     const unsigned long long t0 = wall_clock64();
     while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want && wall_clock64() - t0 < max_ticks)
         __builtin_amdgcn_s_sleep(16);
@@ -2892,9 +2891,6 @@ template <int NM> struct SolveCfg {
 #ifndef FSEG_SOLVE_OCC
 #define FSEG_SOLVE_OCC 1
 #endif
-#ifndef FSEG_WAVE_DP
-#define FSEG_WAVE_DP 1          // k_solve's DP by one wave (dp_solve_wave); 0: by the whole workgroup (dp_solve_push), as until round 4
-#endif
 #ifndef FSEG_SOLVE_OCC32
 #define FSEG_SOLVE_OCC32 5      // (96 registers, five workgroups of the mid class per CU: 74 -> 70 us on config4; six spill and lose it again)
 #endif
@@ -2903,15 +2899,12 @@ template <int NM> struct SolveCfg {
 #endif
     static constexpr int kMinBlocks = !FSEG_SOLVE_OCC ? 1 : (NM <= 16 ? FSEG_SOLVE_OCC16 : (NM <= 32 ? FSEG_SOLVE_OCC32 : 4));
 };
-// LDS of a k_solve workgroup: ONE region that is a round's coverage rows, then its pair planes, then (after the rounds) the DP's
-// M | in | A, and the count table behind it.  (Until round 4 planes and coverage lay side by side: 25 KB for the mid class,
-// 57-78 KB for the large one -- and LDS-time, not wave slots, is what the stage runs out of: 3.2 GB us per batch against 41 MB.)
-#ifndef FSEG_LDS_OVERLAY
-#define FSEG_LDS_OVERLAY 0      // 1: the planes of a round take the LDS of its coverage rows (measured slower: the planes wait in registers, which spill)
-#endif
+// LDS of a k_solve workgroup: the pair planes (later the DP's M | in | A), a round's coverage rows, the count table.  (Round 4
+// tried the planes IN the coverage rows' LDS -- 25 -> 16 KB for the mid class, 55 -> 39 KB for the large one: the planes then wait
+// in registers across a barrier, the kernels sit at their register caps, and the spills cost 12-17 % per problem: DESIGN section 8.)
 inline size_t solve_shared_bytes(int nm, int cov_stride) {
     const size_t planes = (size_t)nm * (nm - 1) / 2 * 16, cov = (size_t)kSub * cov_stride * 4;
-    return ((FSEG_LDS_OVERLAY ? (planes > cov ? planes : cov) : planes + cov) + 15) & ~(size_t)15;
+    return (planes + cov + 15) & ~(size_t)15;
 }
 // a problem's slot of the hand-over arena (k_solve<.., SPLIT> -> k_dpw): in() per pair, the count table
 constexpr int kDpxHeader = 0;
@@ -2945,21 +2938,17 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
     const int rt_pairs = nm * (nm - 1) / 2;
     constexpr int rt_stride = NM + 1;             // compile-time row stride (odd: rows do not collide on LDS banks)
     uint4 *planes = reinterpret_cast<uint4 *>(smem);                                         // rt_pairs * 16 B; later M | in | A
-    unsigned *cov = reinterpret_cast<unsigned *>(smem + (FSEG_LDS_OVERLAY ? 0 : (size_t)rt_pairs * 16));   // kSub * rt_stride * 4 B, BEFORE the planes of a round
-    const unsigned shared_b = !FSEG_LDS_OVERLAY ? (unsigned)rt_pairs * 16 + (unsigned)(kSub * rt_stride * 4) :
-                              ((unsigned)rt_pairs * 16 > (unsigned)(kSub * rt_stride * 4) ? (unsigned)rt_pairs * 16 : (unsigned)(kSub * rt_stride * 4));
+    unsigned *cov = reinterpret_cast<unsigned *>(smem + (size_t)rt_pairs * 16);              // kSub * rt_stride * 4 B
+    const unsigned shared_b = (unsigned)rt_pairs * 16 + (unsigned)(kSub * rt_stride * 4);
     CntT *cnt = reinterpret_cast<CntT *>(smem + ((shared_b + 15) & ~15u));                   // C(nm,3) counters (solve_shared_bytes)
     V *M = reinterpret_cast<V *>(smem);
     int *in_s = reinterpret_cast<int *>(M + rt_pairs);
     unsigned char *A = reinterpret_cast<unsigned char *>(in_s + rt_pairs);
     // the DP is one wave's (dp_solve_wave) except where its registers would not fit: the large class with 64-bit sums
-    constexpr bool kWaveDp = FSEG_WAVE_DP && (NM <= 32 || sizeof(V) == 4);
+    constexpr bool kWaveDp = NM <= 32 || sizeof(V) == 4;
     if (NM == kNMax && threadIdx.x == 0) { atomicAdd(&st->gate, 1u); if (sizeof(CntT) != 1) atomicAdd(&st->gate_wide, 1u); }   // placed: see k_gate
     // (lb_h >= 0: the host knows the lists' sizes -- the batch has been sized --, and the status record is not on the way to the first problem)
     if (lb_h < 0 && (i64)st->n_prob > prob_cap) return;              // lists incomplete (a run that only sizes the arenas)
-#ifdef FSEG_SOLVE_PRIO
-    __builtin_amdgcn_s_setprio(NM > 32 ? 3 : (NM > 16 ? 2 : 1));
-#endif
     // cls < 0: every solve list (batches of few problems: one launch instead of three)
     const i64 list_base = lb_h >= 0 ? lb_h : (cls <= 0 ? 0 : (cls == 1 ? (i64)st->solve_cls[0] : (i64)st->solve_cls[0] + (i64)st->solve_cls[1]));
     const i64 list_n = lb_h >= 0 ? ln_h : (cls < 0 ? (i64)st->solve_cls[0] + (i64)st->solve_cls[1] + (i64)st->solve_cls[2] : (i64)st->solve_cls[cls]);
@@ -3125,7 +3114,6 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
             const int nv1 = n_valid - 32;
             const unsigned valid0 = n_valid >= 32 ? 0xffffffffu : (n_valid > 0 ? ~(0xffffffffu >> n_valid) : 0u);
             const unsigned valid1 = nv1 >= 32 ? 0xffffffffu : (nv1 > 0 ? ~(0xffffffffu >> nv1) : 0u);
-            uint4 pl[C::kSlots];
 #pragma unroll
             for (int s = 0; s < C::kSlots; ++s) {
                 const int q = s * T + threadIdx.x;
@@ -3167,14 +3155,9 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
                     }
 #undef FSEG_SHIFT_IN
                     y0 &= valid0; z0 &= valid0; y1 &= valid1; z1 &= valid1;     // rows beyond the problem's reads hold nothing
-                    if (FSEG_LDS_OVERLAY) pl[s] = make_uint4(y0, y1, z0, z1); else planes[q] = make_uint4(y0, y1, z0, z1);
+                    planes[q] = make_uint4(y0, y1, z0, z1);
                     amb_acc[s] += __popc(~(y0 | z0) & valid0) + __popc(~(y1 | z1) & valid1);
                 }
-            }
-            if (FSEG_LDS_OVERLAY) {
-                lds_barrier();                                                  // everybody has read the coverage: its LDS becomes the planes
-#pragma unroll
-                for (int s = 0; s < C::kSlots; ++s) { const int q = s * T + threadIdx.x; if (q < npairs) planes[q] = pl[s]; }
             }
             lds_barrier();
             FSEG_STICK(3);
@@ -3282,7 +3265,6 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
 #endif
     }
 #undef FSEG_STICK
-    if (NM == kNMax && sizeof(CntT) == 1 && threadIdx.x == 0) atomicAdd(&st->gate_done, 1u);     // ended: see k_gate
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -4417,12 +4399,8 @@ struct fseg_ctx {
     bool use_tiny = true;       // FSEG_NO_TINY=1: no problem goes to k_tiny
     bool force_key64 = false;
     bool wide_by_seen = false;  // FSEG_WIDE_BY_SEEN=1 (tests)
-    int gate_done_pct = 60;     // FSEG_GATE_DONE_PCT: the share of the large class's workgroups that has to have ended for 'd' in the plan
     char score_plan[32] = "gM|hB|msgTS|b"; // FSEG_SCORE_PLAN (see enqueue_run; anything that does not name each class once = one stream)
-    bool score_fork = false;    // FSEG_SCORE_FORK=1: the fused scoring kernels on a stream each
     bool use_wave = true;       // FSEG_NO_WAVE=1: k_tiny / k_solve<16> instead of the wave kernels (k_wave)
-    bool wave_small = false;    // FSEG_WAVE_SMALL=1: the small class (9 .. 16 candidates) goes to k_wave<16> instead of k_solve<16> (one wave
-                                // per problem: a third less wave-time, but 48 instead of 38 us when the kernel has the GPU to itself)
     bool use_fuse = true;       // FSEG_NO_FUSE=1: no problem goes to k_solve (everything that is not tiny takes the arena path)
     // Reads the widest problem of a batch may see for the batch's problems to be solved whole (k_solve / k_wave) instead of going
     // through the arena path; FSEG_FUSE_LANES=1023 admits batches of 1 000-read partitions (their widest problems see ~300 reads:
@@ -4602,7 +4580,8 @@ inline i64 scan_blocks(i64 n) { return (n + kScanBlock - 1) / kScanBlock; }
 bool wave_on(const fseg_ctx *c) { return c->use_wave && c->max_rep_exons <= kWaveRepExons; }
 ProbSplit split_of(const fseg_ctx *c, bool tiny, bool fuse) {
     const bool wave = wave_on(c);
-    return ProbSplit{tiny ? kTiny : 0, (c->use_fuse && fuse) ? c->fuse_lanes : -1, (wave && c->use_fuse && c->wave_small) ? kClsSmall : 0, kWaveLanes};
+    (void)wave;
+    return ProbSplit{tiny ? kTiny : 0, (c->use_fuse && fuse) ? c->fuse_lanes : -1};
 }
 
 // Enqueue the segments `segs` of one run on the context's stream.
@@ -4795,8 +4774,8 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
         // Anything that does not name each class once, batches with arena-path problems and small batches: one stream
         // (FSEG_SCORE_FORK=1: a stream each, as until round 3).
         const bool any_solve_plan = c->use_fuse && c->fuse_on;
-        const char *plan = (known && !any_arena && !c->small_batch && forking && c->n_solve[2] > 0 && any_solve_plan && wave && !(wave && c->wave_small) && c->score_plan[0]) ? c->score_plan : nullptr;
-        const bool sfork = c->score_fork || any_arena;              // (the arena path's work-item kernels keep their streams)
+        const char *plan = (known && !any_arena && !c->small_batch && forking && c->n_solve[2] > 0 && any_solve_plan && wave && c->score_plan[0]) ? c->score_plan : nullptr;
+        const bool sfork = any_arena;                               // (the arena path's work-item kernels keep their streams)
         hipStream_t qt = (tiny_max > 0 && sfork) ? fork(2) : s;     // (forked here: a side stream continues from where it was forked)
 #ifdef FSEG_SCORE_TIMING
 #define FSEG_TARG , c->d_tacc.as<unsigned long long>()
@@ -4888,16 +4867,10 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
         auto list_lb = [&](int l) -> i64 { return !known ? -1 : (l <= 0 ? 0 : (l == 1 ? c->n_solve[0] : (l == 2 ? c->n_solve[0] + c->n_solve[1] : c->n_solve[0] + c->n_solve[1] + c->n_solve[2]))); };
         auto list_ln = [&](int l) -> i64 { return !known ? -1 : (l < 0 ? c->n_solve[0] + c->n_solve[1] + c->n_solve[2] : (l == 3 ? c->n_tiny : c->n_solve[l])); };
         const bool any_solve = c->use_fuse && c->fuse_on && (!known || c->n_solve[0] + c->n_solve[1] + c->n_solve[2] > 0);
-        const bool wave16 = wave && c->wave_small;                                         // list 0 belongs to k_wave<16>
-        const bool wave_solve = c->use_fuse && wave16 && (!known || c->n_solve[0] > 0);
         const i64 cap = c->prob_cap;
         if (c->small_batch) {
             if (any_arena) FSEG_LAUNCH_SCORE(s, kNMax, -1, 512);    // few work items: one launch for every size class
-            if (wave16) {
-                if (wave_solve) FSEG_LAUNCH_WAVE(s, kClsSmall, 0, known ? c->n_solve[0] : cap);
-                if (any_solve && (!known || c->n_solve[1] > 0)) FSEG_LAUNCH_SOLVE_W(s, kNMax, 1, known ? c->n_solve[1] : cap, 512);
-                if (any_solve && (!known || c->n_solve[2] > 0)) FSEG_LAUNCH_SOLVE_W(s, kNMax, 2, known ? c->n_solve[2] : cap, 512);
-            } else if (any_solve) FSEG_LAUNCH_SOLVE_W(s, kNMax, -1, known ? c->n_solve[0] + c->n_solve[1] + c->n_solve[2] : cap, 512);
+            if (any_solve) FSEG_LAUNCH_SOLVE_W(s, kNMax, -1, known ? c->n_solve[0] + c->n_solve[1] + c->n_solve[2] : cap, 512);
         } else {                                     // the size classes own disjoint problems: three concurrent chains
             hipStream_t q1 = sfork ? fork(0) : s, q0 = sfork ? fork(1) : s;
             if (plan) {
@@ -4911,7 +4884,10 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
                     if (!at || (c->wide_solve && c->n_wide[2 - (int)(at - wide_kinds)] > 0)) used[n_seg - 1] = true;
                 }
                 if (n_seg > 4) n_seg = 4;
-                for (int k = 1; k < n_seg; ++k) if (used[k]) (void)fork(k - 1);          // every side stream continues from HERE
+                // (the segments that have something to launch take the side streams in order: the first ones start first)
+                int side_of[4] = {-1, -1, -1, -1};
+                for (int k = 1, nx = 0; k < n_seg; ++k) if (used[k]) side_of[k] = nx++;
+                for (int k = 1; k < n_seg; ++k) if (used[k]) (void)fork(side_of[k]);     // every side stream continues from HERE
                 int seg = 0;
                 hipEvent_t ev_big = nullptr;
                 // b m s: the class's instance with 16-bit counters on its own (B M S then launch the 8-bit one only)
@@ -4934,7 +4910,7 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
                     const int when = !opens ? 2 : (*p == 'b' ? 0 : ((*p == 'B' || *p == 'h') ? 1 : 2));
                     if (*p != 'h') opens = false;
                     if (!used[seg] || when != pass) continue;
-                    hipStream_t q = seg == 0 ? s : c->side[seg - 1];
+                    hipStream_t q = seg == 0 ? s : c->side[side_of[seg]];
                     switch (*p) {
                     case 'B': FSEG_LAUNCH_SOLVE_X(q, kNMax, 2, c->n_solve[2], 512, wb);
                               ev_big = fj_event(); if (hipEventRecord(ev_big, q) != hipSuccess) fj_err = hipErrorUnknown; break;
@@ -4944,25 +4920,23 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
                     case 'm': if (c->n_solve[1] > 0) FSEG_LAUNCH_SOLVE_X(q, kClsMid, 1, c->n_solve[1], FSEG_WG_MID, 2); break;
                     case 's': if (c->n_solve[0] > 0) FSEG_LAUNCH_SOLVE_X(q, kClsSmall, 0, c->n_solve[0], FSEG_WG_SMALL, 2); break;
                     case 'T': if (c->n_tiny > 0) FSEG_LAUNCH_WAVE(q, kTiny, 3, c->n_tiny); break;
-                    case 'g': hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, q, st, 0, (unsigned)(big_wgs < 512 ? big_wgs : 512), 100u, 3000u); break;
+                    case 'g': hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, q, st, 0, (unsigned)(big_wgs < 512 ? big_wgs : 512), 3000u); break;
                     case 'h': if (FSEG_WIDE_NEEDED(2) && c->n_wide[2] > 0)       // the 16-bit instance's workgroups (up to 120 KB of LDS each) take their CUs first
-                                  hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, q, st, 2, (unsigned)(c->n_wide[2] < 256 ? c->n_wide[2] : 256), 100u, 1500u);
+                                  hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, q, st, 2, (unsigned)(c->n_wide[2] < 256 ? c->n_wide[2] : 256), 1500u);
                               break;
-                    case 'd': hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, q, st, 1, (unsigned)(c->n_solve[2] < 512 ? c->n_solve[2] : 512), (unsigned)c->gate_done_pct, 15000u); break;
                     case 'e': if (ev_big && hipStreamWaitEvent(q, ev_big, 0) != hipSuccess) fj_err = hipErrorUnknown; break;
                     default: break;
                     }
                 }
                 }
-                for (int k = 1; k < n_seg; ++k) if (used[k]) join(k - 1);
+                for (int k = 1; k < n_seg; ++k) if (used[k]) join(side_of[k]);
             } else {
             if (any_arena && (!known || c->n_cls_work[2] > 0)) FSEG_LAUNCH_SCORE(s, kNMax, 2, 512);     // big problems: they are the long poles
             if (any_solve && (!known || c->n_solve[2] > 0)) FSEG_LAUNCH_SOLVE_W(s, kNMax, 2, known ? c->n_solve[2] : cap, 512);
             if (any_arena && (!known || c->n_cls_work[1] > 0)) FSEG_LAUNCH_SCORE(q1, kClsMid, 1, 1280);
             if (any_solve && (!known || c->n_solve[1] > 0)) FSEG_LAUNCH_SOLVE_W(q1, kClsMid, 1, known ? c->n_solve[1] : cap, FSEG_WG_MID);
             if (any_arena && (!known || c->n_cls_work[0] > 0)) FSEG_LAUNCH_SCORE(q0, kClsSmall, 0, 2048);
-            if (wave16) { if (wave_solve) FSEG_LAUNCH_WAVE(q0, kClsSmall, 0, known ? c->n_solve[0] : cap); }
-            else if (any_solve && (!known || c->n_solve[0] > 0)) FSEG_LAUNCH_SOLVE_W(q0, kClsSmall, 0, known ? c->n_solve[0] : cap, FSEG_WG_SMALL);
+            if (any_solve && (!known || c->n_solve[0] > 0)) FSEG_LAUNCH_SOLVE_W(q0, kClsSmall, 0, known ? c->n_solve[0] : cap, FSEG_WG_SMALL);
             }
         }
 #undef FSEG_LAUNCH_SOLVE_W
@@ -5410,12 +5384,10 @@ int fseg_create(int device, fseg_ctx **out) {
     if (flag("FSEG_NO_TINY")) c->use_tiny = false;
     if (flag("FSEG_NO_FUSE")) c->use_fuse = false;
     if (flag("FSEG_NO_WAVE")) c->use_wave = false;
-    if (flag("FSEG_SCORE_FORK")) c->score_fork = true;
     if (flag("FSEG_FORCE_KEY64")) c->force_key64 = true;
     if (flag("FSEG_WIDE_BY_SEEN")) c->wide_by_seen = true;
     if (const char *e = getenv("FSEG_SPLIT_DP")) c->split_dp = atoi(e) & 7;
     if (flag("FSEG_SPLIT_ALWAYS")) c->split_always = true;
-    { const char *v = getenv("FSEG_GATE_DONE_PCT"); if (v && v[0] && atoi(v) > 0 && atoi(v) <= 100) c->gate_done_pct = atoi(v); }
     if (const char *e = getenv("FSEG_SCORE_PLAN")) snprintf(c->score_plan, sizeof c->score_plan, "%s", e);
     {
         int seen[4] = {0, 0, 0, 0};
@@ -5425,7 +5397,6 @@ int fseg_create(int device, fseg_ctx **out) {
         for (const char *q = c->score_plan; *q; ++q) bars += *q == '|';
         if (seen[0] != 1 || seen[1] != 1 || seen[2] != 1 || seen[3] != 1 || bars > fseg_ctx::kSide) c->score_plan[0] = 0;   // (a stream per segment)
     }
-    { const char *v = getenv("FSEG_WAVE_SMALL"); if (v && v[0]) c->wave_small = v[0] == '1'; }
     { const char *v = getenv("FSEG_FUSE_LANES"); if (v && v[0] && atoi(v) > 0 && atoi(v) <= kFuseLanesWide) c->fuse_lanes = atoi(v); }
     if (flag("FSEG_NO_SIZED")) c->use_sized = false;
     if (flag("FSEG_TRACE")) c->trace = true;

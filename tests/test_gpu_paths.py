@@ -52,20 +52,16 @@ SWITCHES = [
     {"FSEG_NO_FUSE": "1", "FSEG_NO_TINY": "1", "FSEG_NO_SIZED": "1"},
     {"FSEG_NO_TINY": "1"},                                  # ... and the tiny ones through k_solve
     {"FSEG_NO_WAVE": "1"},                                  # k_tiny instead of k_wave<8> (batches with a rep of > 510 exons take this)
-    {"FSEG_SCORE_FORK": "1"},                               # the fused scoring kernels on a stream each
     {"FSEG_FUSE_LANES": "255"},                             # batches with a problem that sees more than 255 reads: the arena path
     {"FSEG_FUSE_LANES": "1023"},
     {"FSEG_SCORE_PLAN": "0"},                               # ... all on the main stream (no k_gate)
     {"FSEG_SCORE_PLAN": "BMbms|gTS"},                       # ... the 16-bit-counter instances behind the others
-    {"FSEG_SCORE_PLAN": "B|gTS|dM|bms", "FSEG_GATE_DONE_PCT": "50"},   # the mid class once half of the large class's workgroups have ended
     {"FSEG_SCORE_PLAN": "B|M|S|g|T"},                       # more segments than streams: not a plan, one stream
+    {"FSEG_SCORE_PLAN": "B|geM|TS", "FSEG_SPLIT_DP": "0"},    # the mid class behind the END of the large one ('e': an event across streams)
     {"FSEG_SCORE_PLAN": "gBeMTS"},                          # a gate in front of its own kernel: leaves by its time limit
     {"FSEG_SCORE_PLAN": "B|gM|gS|gT"},                      # ... or each class behind the gate on its own stream
     {"FSEG_FORCE_KEY64": "1"},                              # 64-bit DP keys (batches with a partition of 2^18 reads or more)
     {"FSEG_FORCE_KEY64": "1", "FSEG_NO_WAVE": "1", "FSEG_SCORE_PLAN": "0"},
-    {"FSEG_WAVE_SMALL": "1"},                               # the small class through k_wave<16> (one wave per problem)
-    {"FSEG_WAVE_SMALL": "1", "FSEG_TINY_FROM": "0", "FSEG_NO_GRAPH": "1"},
-    {"FSEG_WAVE_SMALL": "1", "FSEG_NO_TINY": "1"},          # ... and the tiny ones with it
     {"FSEG_GLOBAL_SORT": "1"},                              # the batch-wide radix sort of the reps instead of the in-LDS sort per partition
     {"FSEG_PROB_SELF_MAX": "0"},                            # the problem list always through the block-sum scan
     {"FSEG_PROB_SELF_MAX": "100000000"},                    # ... and always through the self-scanning emit kernel
