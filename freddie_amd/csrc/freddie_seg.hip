@@ -4758,21 +4758,21 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
     }   // do_pre2
     if (do_score) begin(ST_SCORE);
     if (do_score && c->prob_cap > 0) {
-        // How the scoring kernels share the chip is a plan (FSEG_SCORE_PLAN, default "gM|B|gTS|bms"): streams separated by '|'
-        // (the first is the main stream); B M S T = the large / mid / small / tiny class -- a class on the split path is
-        // k_solve (rounds) followed by k_dpw (its DPs), 8-bit then 16-bit instance --, b m s = the 16-bit-counter instances of
-        // classes that are NOT on the split path, g = k_gate (wait until the large class's workgroups are placed), d = k_gate on
-        // the share of them that has ended (FSEG_GATE_DONE_PCT), e = wait for the large class to end.  Measured on config4
-        // (250 k-read batch, stage alone, tools/r4_plans.sh, profiles/r04_config4_plans.txt):
+        // How the scoring kernels share the chip is a plan (FSEG_SCORE_PLAN, default "gM|hB|msgTS|b"): streams separated by '|'
+        // (the first is the main stream; the segments that have something to launch take the side streams in order); B M S T =
+        // the large / mid / small / tiny class -- a class on the split path is k_solve (rounds) followed by k_dpw (its DPs) --,
+        // b m s = the classes' 16-bit-counter instances (launched over their classes' wide problems), g = k_gate (wait until the
+        // large class's workgroups, both instances', are placed), h = wait until the 16-bit instance's are, e = wait for the large
+        // class to end.  Measured on config4 (250 k-read batch, stage alone, tools/r4_plans.sh):
         //   * everything on the main stream 0.19-0.21 ms; a stream each without a gate 0.21 (the dispatcher runs them in the
         //     reverse of their launch order: a large-class workgroup needs eight wave slots and half a CU's LDS at once);
         //   * round 3's "BM|gTS" 0.161-0.165: the tiny class in the large class's shadow, then small beside mid;
         //   * a cross-stream dependency costs ~9 us (fork or join), so the chain that ends LAST belongs on the main stream,
         //     where the stage's end needs no join: the mid class (gate, rounds, DPs) on main, the large class on a side stream
         //     of its own, tiny + small on a third: 0.144-0.149 with the split path ("B|gM|gTS", the same chains with the large
-        //     class on main: 0.154-0.167; per-problem clocks, tools/r4_ticks.sh: 133 us from first start to last end either way).
-        // Anything that does not name each class once, batches with arena-path problems and small batches: one stream
-        // (FSEG_SCORE_FORK=1: a stream each, as until round 3).
+        //     class on main: 0.154-0.167; per-problem clocks, tools/r4_ticks.sh: 133 us from first start to last end either way);
+        //   * the 16-bit instances first (batches of 1 000-read partitions): see the passes below.
+        // Anything that does not name each class once, batches with arena-path problems and small batches: one stream.
         const bool any_solve_plan = c->use_fuse && c->fuse_on;
         const char *plan = (known && !any_arena && !c->small_batch && forking && c->n_solve[2] > 0 && any_solve_plan && wave && c->score_plan[0]) ? c->score_plan : nullptr;
         const bool sfork = any_arena;                               // (the arena path's work-item kernels keep their streams)
