@@ -44,7 +44,8 @@ constexpr int kSmoothThreads = kSmoothTile / 4;  // a thread computes 4 consecut
 constexpr int kSumShift = 4, kSumBlock = 1 << kSumShift;     // positions per block of the histogram's in-tile prefix sums (k_smooth -> k_segments)
 static_assert(kSmoothTile / kSumBlock <= 64 && kSumBlock == 16, "a tile's block sums are scanned by one wave; a block is four threads' positions");
 constexpr int kMaxRadius = 200;        // sigma <= 50, truncate 4.0 (py/freddie_segment.py:106,:755)
-constexpr int kScanBlock = 8192;       // elements per scan workgroup (256 threads x 32 flag bytes)
+constexpr int kScanBlock = 8192;       // elements per scan workgroup (256 threads x one 32-bit word of flags)
+inline size_t flag_words(i64 n_pos) { return ((size_t)n_pos + 31) / 32 + 64; }      // words of one flag mask (+ room for a tile's last word and the scans' last block)
 constexpr int kNMax = 60;              // largest DP problem handled by the LDS-resident scoring kernel
 constexpr int kNHuge = 128;            // largest DP problem at all: 60 < n <= 128 (max_problem_size up to ~115) takes the
                                        // global-table kernels k_score_huge / k_dp_huge
@@ -321,10 +322,11 @@ template <int R>
 #endif
 __global__ void __launch_bounds__(kSmoothThreads, FSEG_SMOOTH_OCC) k_smooth(int n_tiles, const TileDesc *__restrict__ tiles,
                                                 const int *__restrict__ y_raw, const double *__restrict__ w_g, int radius_rt,
-                                                double *y_out, unsigned char *flag_pos, unsigned char *flag_cand, int *blk_pre, int *tile_tot,
-                                                unsigned char *final_flag, int *tile_defer) {
+                                                double *y_out, unsigned *flag_pos, unsigned *flag_cand, int *blk_pre, int *tile_tot,
+                                                int *tile_defer) {
     __shared__ int xs[kSmoothTile + 2 * kMaxRadius];
     __shared__ __align__(4) unsigned char cf[kSmoothTile];     // candidate flags of the tile
+    __shared__ unsigned pf[kSmoothTile / 4];                   // Y > 0 flags of the tile, a byte per position like cf
     __shared__ int defer_s;
     __shared__ int blk_s[kSmoothTile / kSumBlock];
     __shared__ double ws[kMaxRadius + 1];
@@ -457,34 +459,48 @@ __global__ void __launch_bounds__(kSmoothThreads, FSEG_SMOOTH_OCC) k_smooth(int 
         lds_barrier();
         if (mid0 >= 0) cf[mid0] = 1;
         if (mid1 >= 0) cf[mid1] = 1;
+        {   // this thread's four Y > 0 flags, a byte each like the candidate flags (what lies beyond the interval flags nothing)
+            const int o4 = threadIdx.x * 4, left = len - (y0 + o4);
+            pf[threadIdx.x] = (left > 0 && a0 > 0.0 ? 1u : 0u) | (left > 1 && a1 > 0.0 ? 1u << 8 : 0u) |
+                              (left > 2 && a2 > 0.0 ? 1u << 16 : 0u) | (left > 3 && a3 > 0.0 ? 1u << 24 : 0u);
+        }
         lds_barrier();
         if (threadIdx.x == 0) tile_defer[t] = defer_s;
         {
             const int o4 = threadIdx.x * 4;
             const i64 p = base + y0 + o4;
-            const unsigned cw = reinterpret_cast<const unsigned *>(cf)[threadIdx.x];
             if (y0 + o4 + 3 < len) {                                 // the thread's four positions lie inside the interval
                 typedef double double2u __attribute__((ext_vector_type(2), aligned(8)));
-                typedef unsigned uint1u __attribute__((ext_vector_type(1), aligned(1)));
                 double2u lo2, hi2; lo2.x = a0; lo2.y = a1; hi2.x = a2; hi2.y = a3;
                 *reinterpret_cast<double2u *>(y_out + p) = lo2;
                 *reinterpret_cast<double2u *>(y_out + p + 2) = hi2;
-                uint1u pw; pw.x = (a0 > 0.0 ? 1u : 0u) | (a1 > 0.0 ? 1u << 8 : 0u) | (a2 > 0.0 ? 1u << 16 : 0u) | (a3 > 0.0 ? 1u << 24 : 0u);
-                uint1u cw1; cw1.x = cw;
-                uint1u zero; zero.x = 0;
-                *reinterpret_cast<uint1u *>(flag_pos + p) = pw;
-                *reinterpret_cast<uint1u *>(flag_cand + p) = cw1;
-                *reinterpret_cast<uint1u *>(final_flag + p) = zero;      // final-position flags start cleared (k_segments / k_refine set them)
             } else {
                 const double av[4] = {a0, a1, a2, a3};
                 for (int e = 0; e < 4; ++e)
-                    if (y0 + o4 + e < len) {
-                        y_out[p + e] = av[e];
-                        flag_pos[p + e] = av[e] > 0.0 ? 1 : 0;
-                        flag_cand[p + e] = (unsigned char)(cw >> (8 * e));
-                        final_flag[p + e] = 0;
-                    }
+                    if (y0 + o4 + e < len) y_out[p + e] = av[e];
             }
+        }
+        if (threadIdx.x <= kSmoothTile / 32) {
+            // The tile's flags leave as bits of the batch-wide masks: lane j < 16 packs the 32 flag bytes of the tile's j-th
+            // group into a word (four bytes at a time: (w * 0x00204081) >> 21 gathers their low bits), and since the tile starts
+            // at an arbitrary position of the batch -- bit s = (base + y0) & 31 of its first word -- word j of the masks is
+            // T[j] << s | T[j-1] >> (32 - s), seventeen of them, OR-ed in (the first and the last are shared with the
+            // neighbouring tiles; the masks are cleared before this kernel).
+            const int j = threadIdx.x;
+            auto pack = [&](const unsigned *bytes_w) {
+                unsigned tw = 0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) tw |= ((((bytes_w[8 * (j & 15) + q] & 0x01010101u) * 0x00204081u) >> 21) & 15u) << (4 * q);
+                return j < kSmoothTile / 32 ? tw : 0u;
+            };
+            const unsigned tc = pack(reinterpret_cast<const unsigned *>(cf)), tp = pack(pf);
+            const unsigned pc = __shfl_up(tc, 1), pp = __shfl_up(tp, 1);
+            const i64 p0 = base + y0;
+            const int sh = (int)(p0 & 31);
+            const unsigned gc = sh ? (tc << sh) | (j > 0 ? pc >> (32 - sh) : 0u) : tc;
+            const unsigned gp = sh ? (tp << sh) | (j > 0 ? pp >> (32 - sh) : 0u) : tp;
+            if (gc) atomicOr(&flag_cand[(p0 >> 5) + j], gc);
+            if (gp) atomicOr(&flag_pos[(p0 >> 5) + j], gp);
         }
         d_cur = d_next; d_next = d_n2;
     }
@@ -515,32 +531,20 @@ __device__ __forceinline__ int wg_exclusive_scan(int v, int *lds /* >= 16 ints *
     return off + x - v;
 }
 
-// each thread owns 32 consecutive flag bytes (two 16-byte loads)
-struct Flags32 { unsigned w[8]; };
-__device__ __forceinline__ Flags32 load_flags32(const unsigned char *flags, i64 i0, i64 n) {
-    Flags32 f;
-    if (i0 + 32 <= n) {
-        const uint4 *src = reinterpret_cast<const uint4 *>(flags + i0);
-        uint4 a = src[0], b = src[1];
-        f.w[0] = a.x; f.w[1] = a.y; f.w[2] = a.z; f.w[3] = a.w; f.w[4] = b.x; f.w[5] = b.y; f.w[6] = b.z; f.w[7] = b.w;
-    } else {
-        for (int q = 0; q < 8; ++q) {
-            unsigned w = 0;
-            for (int e = 0; e < 4; ++e) { i64 i = i0 + q * 4 + e; if (i < n) w |= (unsigned)(flags[i] & 1) << (8 * e); }
-            f.w[q] = w;
-        }
-    }
-    for (int q = 0; q < 8; ++q) f.w[q] &= 0x01010101u;
-    return f;
+// The three flag sets of a run (Y > 0, candidate, final position) are BIT masks over the batch's positions: bit (p & 31) of word
+// p >> 5 (round 4; a byte per position until then: 85 MB written by k_smooth per 250 k-read batch and read again by five scan
+// launches).  Every thread of a scan owns the 32 positions of one word; i0 is a multiple of 32, positions at or beyond n count nothing.
+typedef unsigned Flags32;
+__device__ __forceinline__ Flags32 load_flags32(const unsigned *flags, i64 i0, i64 n) {
+    unsigned w = flags[i0 >> 5];
+    if (i0 + 32 > n) w &= n > i0 ? ((1u << (int)(n - i0)) - 1u) : 0u;
+    return w;
 }
-__device__ __forceinline__ int count_flags32(const Flags32 &f) {
-    int s = 0;
-    for (int q = 0; q < 8; ++q) s += __popc(f.w[q]);
-    return s;
-}
+__device__ __forceinline__ int count_flags32(Flags32 f) { return __popc(f); }
+__device__ __forceinline__ void set_flag(unsigned *flags, i64 p) { atomicOr(&flags[p >> 5], 1u << (int)(p & 31)); }
 
 // many blocks: three passes (block sums, their scan by one workgroup, emission)
-__global__ void __launch_bounds__(256) k_scan1(const unsigned char *flags, i64 n, int *bsum) {
+__global__ void __launch_bounds__(256) k_scan1(const unsigned *flags, i64 n, int *bsum) {
     __shared__ int lds[16];
     i64 nb = (n + kScanBlock - 1) / kScanBlock;
     for (i64 b = blockIdx.x; b < nb; b += gridDim.x) {
@@ -633,7 +637,7 @@ __device__ __forceinline__ i64 scan_lookback(u64 *state, i64 b, i64 nb, i64 agg,
 //                   out_off[k] = rank of the interval's first position (always flagged)
 enum { kEmitValues = 0, kEmitPositions = 1 };
 template <int MODE>
-__global__ void __launch_bounds__(256) k_scan_emit(const unsigned char *flags, i64 n, const int *bsum /* or null */,
+__global__ void __launch_bounds__(256) k_scan_emit(const unsigned *flags, i64 n, const int *bsum /* or null */,
                                                    u64 *state, u64 *total_out, i64 *off_last /* may be null */,
                                                    unsigned *err, const double *y,
                                                    double *v, i64 K, const i64 *pos_off, const int *iv_start,
@@ -667,7 +671,7 @@ __global__ void __launch_bounds__(256) k_scan_emit(const unsigned char *flags, i
                 for (int x = threadIdx.x; x < niv; x += blockDim.x) is_s[x] = iv_start[ka0 + x];
             }
             i64 i0 = b * kScanBlock + (i64)threadIdx.x * 32;
-            Flags32 f;
+            Flags32 f = 0;
             int s = 0;
             if (i0 < n) { f = load_flags32(flags, i0, n); s = count_flags32(f); }
             int tot;
@@ -676,12 +680,12 @@ __global__ void __launch_bounds__(256) k_scan_emit(const unsigned char *flags, i
             if (s) {
                 i64 k = -1, k_end = 0, k_base = 0;
                 int k_start = 0;
-                for (int q = 0; q < 8; ++q) {
-                    unsigned w = f.w[q];
+                {
+                    unsigned w = f;
                     while (w) {
-                        int e = (__ffs(w) - 1) >> 3;
+                        int e = __ffs(w) - 1;
                         w &= w - 1;
-                        i64 i = i0 + q * 4 + e;
+                        i64 i = i0 + e;
                         if (k < 0 || i >= k_end) {
                             // the interval of position i lies between the first intervals of this and the next block
                             const i64 ka = k < 0 ? ka0 : k + 1;
@@ -714,12 +718,8 @@ __global__ void __launch_bounds__(256) k_scan_emit(const unsigned char *flags, i
         {
             i64 i0 = w0 + (i64)lane * 32;
             if (i0 < n) {
-                const Flags32 f = load_flags32(flags, i0, n);
-                s = count_flags32(f);
-                for (int q = 0; q < 8; ++q) {
-                    const unsigned w = f.w[q];                       // four 0/1 bytes -> four bits
-                    fm |= ((w & 1u) | ((w >> 7) & 2u) | ((w >> 14) & 4u) | ((w >> 21) & 8u)) << (4 * q);
-                }
+                fm = load_flags32(flags, i0, n);
+                s = count_flags32(fm);
             }
         }
         for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
@@ -791,14 +791,14 @@ __global__ void __launch_bounds__(256) k_scan_emit(const unsigned char *flags, i
 }
 // rank of the first position of every partition in the compaction of the Y > 0 flags
 __global__ void __launch_bounds__(64) k_voff(int n_part, const i64 *part_iv_off, const i64 *pos_off, i64 n_pos,
-                                             const unsigned char *flags, const int *bsum /* or null */, const u64 *state, const u64 *total, i64 *voff) {
+                                             const unsigned *flags, const int *bsum /* or null */, const u64 *state, const u64 *total, i64 *voff) {
     for (int p = blockIdx.x; p <= n_part; p += gridDim.x) {
         if (p == n_part) { if (threadIdx.x == 0) voff[p] = (i64)*total; continue; }
         i64 pos = pos_off[part_iv_off[p]];
         i64 b = pos / kScanBlock, start = b * kScanBlock;
         int cnt = 0;
         for (i64 i0 = start + (i64)threadIdx.x * 32; i0 < pos; i0 += 64 * 32) {
-            Flags32 f = load_flags32(flags, i0, pos);      // bytes at or after pos are masked out by the bound
+            Flags32 f = load_flags32(flags, i0, pos);      // positions at or after pos are masked out by the bound
             cnt += count_flags32(f);
         }
         for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
@@ -983,18 +983,18 @@ __global__ void k_vsum_part(int n_part, const i64 *voff, const i64 *chunk_off, c
 // signal, at the tile's first position, its last position and the plateau start the tile deferred -- as possible STARTS of a
 // peak (a strict maximum, or a plateau whose midpoint counts when it falls on its right; the walk stops at the interval's
 // last position, as scipy's does).  Interval ends were flagged by the tiles.
-__device__ __forceinline__ void peak_from(i64 p, i64 last /* the interval's last position */, const double *x, unsigned char *flag) {
+__device__ __forceinline__ void peak_from(i64 p, i64 last /* the interval's last position */, const double *x, unsigned *flag) {
     const double xi = x[p];
     if (!(x[p - 1] < xi)) return;
-    if (x[p + 1] < xi) { flag[p] = 1; return; }
+    if (x[p + 1] < xi) { set_flag(flag, p); return; }
     if (x[p + 1] == xi) {
         i64 ia = p + 1;
         while (ia < last && x[ia] == xi) ++ia;
-        if (x[ia] < xi) flag[(p + ia - 1) / 2] = 1;     // plateau midpoint (positions of one interval are consecutive)
+        if (x[ia] < xi) set_flag(flag, (p + ia - 1) / 2);     // plateau midpoint (positions of one interval are consecutive)
     }
 }
 __global__ void __launch_bounds__(256) k_peaks_edges(int n_tiles, const TileDesc *tiles, const int *tile_defer, const double *x,
-                                                     unsigned char *flag, int *part_has2, int n_part) {
+                                                     unsigned *flag, int *part_has2, int n_part) {
     // also clears the per-partition 'some default label is not 0' flags that k_label_cols sets much later
     if (blockIdx.x == 0) for (int p = threadIdx.x; p < n_part; p += blockDim.x) part_has2[p] = 0;
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n_tiles; t += gridDim.x * blockDim.x) {
@@ -3537,7 +3537,7 @@ __global__ void __launch_bounds__(512) k_dp_huge(Status *st, const int *dp_items
 // visits the recorded segments (one wave each).
 // ---------------------------------------------------------------------------------------------
 __global__ void k_segments(i64 K, const i64 *pos_off, const i64 *cand_off, const int *cand_y, const int *__restrict__ y_raw,
-                           const int *__restrict__ blk_pre, const int *tile_tot, const int *iv_tile0, const unsigned char *chosen, unsigned char *final_flag, int *rseg_c, int *rseg_prev,
+                           const int *__restrict__ blk_pre, const int *tile_tot, const int *iv_tile0, const unsigned char *chosen, unsigned *final_flag, int *rseg_c, int *rseg_prev,
                            Status *st) {
     __shared__ int lds[16];
     __shared__ int cnt_s[16];
@@ -3556,7 +3556,7 @@ __global__ void k_segments(i64 K, const i64 *pos_off, const i64 *cand_off, const
             int y = 0, py = -1;
             if (f) {
                 y = cand_y[c0 + c];
-                final_flag[base + y] = 1;
+                set_flag(final_flag, base + y);
                 if (prev >= 0) py = cand_y[c0 + prev];
             }
             bool need = f && py >= 0 && y - py > 40;                  // :252
@@ -3612,7 +3612,7 @@ __global__ void __launch_bounds__(64) k_refine(const Status *st, const int *cand
                                                const int *rseg_prev, const int *cand_y, const i64 *pos_off,
                                                const int *y_raw, const double *w_g, int radius, double sigma,
                                                double *g_scr, int *pk_scr, unsigned char *flag_scr,
-                                               unsigned char *keep_scr, unsigned char *final_flag) {
+                                               unsigned char *keep_scr, unsigned *final_flag) {
     __shared__ double ws[kMaxRadius + 1];
     __shared__ int xl[kRefCap], pkl[kRefCap];
     __shared__ double gl[kRefCap];
@@ -3702,7 +3702,7 @@ __global__ void __launch_bounds__(64) k_refine(const Status *st, const int *cand
                 if (b < 0) { b += len; if (b < 0) b = 0; } else if (b > len) b = len;
                 double sm = 0.0;
                 for (i64 x = a; x < b; ++x) sm = __dadd_rn(sm, gl[x]);
-                if (!(sm < 20.0)) final_flag[base + i] = 1;
+                if (!(sm < 20.0)) set_flag(final_flag, base + i);
             }
             __syncthreads();
             continue;
@@ -3775,7 +3775,7 @@ __global__ void __launch_bounds__(64) k_refine(const Status *st, const int *cand
             if (b < 0) { b += len; if (b < 0) b = 0; } else if (b > len) b = len;
             double sm = 0.0;
             for (i64 x = a; x < b; ++x) sm = __dadd_rn(sm, g[x]);
-            if (!(sm < 20.0)) final_flag[base + i] = 1;
+            if (!(sm < 20.0)) set_flag(final_flag, base + i);
         }
         __syncthreads();
       }
@@ -4334,7 +4334,8 @@ struct fseg_ctx {
     i64 max_rep_exons = 0;       // most exons of one rep in the resident batch
     DevBuf d_w_main, d_w_refine, d_h_table, d_thr_tab;     // parameter tables (own allocations)
     // device buffers: position-sized (slab_pos)
-    DevBuf d_y_raw, d_y, d_flag, d_cflag, d_v, d_scan_state, d_bsum, d_bsum_side, d_g, d_pk, d_pf, d_kp, d_final_flag;
+    DevBuf d_bits;               // the three flag masks (Y > 0, candidate, final position), a bit per position each, cleared per run
+    DevBuf d_y_raw, d_y, d_v, d_scan_state, d_bsum, d_bsum_side, d_g, d_pk, d_pf, d_kp;
     int n_hist_chunks = 0;
     DevBuf d_voff, d_chunk_off, d_csum, d_mean, d_thr, d_label_off, d_part_has2;
     int n_rep_blocks = 0;
@@ -4596,6 +4597,8 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
     const int n_part = c->n_part;
     const i64 K = c->K, NPOS = c->NPOS;
     Status *st = c->d_status.as<Status>();
+    // the flag masks: Y > 0 | candidate | final position, flag_words(NPOS) words each
+    unsigned *flag_pos_bits = c->d_bits.as<unsigned>(), *flag_cand_bits = flag_pos_bits + flag_words(NPOS), *flag_final_bits = flag_cand_bits + flag_words(NPOS);
     auto begin = [&](int i) { if (stage_events && (c->profile_all || i == ST_SCORE)) (void)hipEventRecord(c->ev_b[i], s); };
     auto end = [&](int i) { if (stage_events && (c->profile_all || i == ST_SCORE)) (void)hipEventRecord(c->ev_e[i], s); };
     // fork(k): side stream k continues from here; join(k): the main stream waits for it.  Every fork is joined before
@@ -4637,7 +4640,7 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
     const bool scan_single = scan_nb <= c->scan_single_max;
     int *bsum = scan_single ? nullptr : c->d_bsum.as<int>();
     int *bsum_side = scan_single ? nullptr : c->d_bsum_side.as<int>();     // block sums of the scan that runs on a side stream
-    auto scan_counts = [&](hipStream_t q, int *bs, const unsigned char *flags, u64 *total_dev, i64 *off_last) {
+    auto scan_counts = [&](hipStream_t q, int *bs, const unsigned *flags, u64 *total_dev, i64 *off_last) {
         if (scan_single) return;
         hipLaunchKernelGGL(k_scan1, dim3(grid_for(scan_nb, 1, 4096)), dim3(256), 0, q, flags, NPOS, bs);
         hipLaunchKernelGGL(k_scan2, dim3(1), dim3(kScan2Threads), 0, q, bs, scan_nb, total_dev, off_last);
@@ -4653,6 +4656,7 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
     i64 *prob_bs = (c->prob_self_scan && !sized) ? nullptr : c->d_prob_bs.as<i64>();
     if (do_pre1) {
     HIP_TRY(c, hipMemsetAsync(st, 0, sizeof(Status), s));
+    HIP_TRY(c, hipMemsetAsync(c->d_bits.p, 0, 3 * flag_words(NPOS) * 4, s));        // (the flags are OR-ed in: k_smooth, k_peaks_edges, k_segments, k_refine)
     begin(ST_HIST);
     // S1
     hipLaunchKernelGGL(k_hist, dim3(grid_for(c->n_hist_chunks, 1, 16384)), dim3(512), 0, s, c->n_hist_chunks,
@@ -4667,9 +4671,8 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
 #define FSEG_LAUNCH_SMOOTH(RV)                                                                                         \
     hipLaunchKernelGGL(k_smooth<RV>, dim3(tile_grid), dim3(kSmoothThreads), 0, s, c->n_tiles, c->d_tile_desc.as<TileDesc>(),      \
                        c->d_y_raw.as<int>(), c->d_w_main.as<double>(),                                                 \
-                       c->P.radius_main, c->d_y.as<double>(), c->d_flag.as<unsigned char>(),                           \
-                       c->d_cflag.as<unsigned char>(), c->d_blk_pre.as<int>(), c->d_tile_tot.as<int>(),                \
-                       c->d_final_flag.as<unsigned char>(), c->d_tile_defer.as<int>())
+                       c->P.radius_main, c->d_y.as<double>(), flag_pos_bits,                           \
+                       flag_cand_bits, c->d_blk_pre.as<int>(), c->d_tile_tot.as<int>(), c->d_tile_defer.as<int>())
     // sigma = 5 (default) and sigma = 3 (config 5) have their own unrolled instances; any other radius runs the loop
     if (c->P.radius_main == 20) { FSEG_LAUNCH_SMOOTH(20); }
     else if (c->P.radius_main == 12) { FSEG_LAUNCH_SMOOTH(12); }
@@ -4680,13 +4683,13 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
     {
     hipStream_t q = fork(0);
     if (stage_events && c->profile_all) (void)hipEventRecord(c->ev_b[ST_THRESHOLD], q);
-    scan_counts(q, bsum_side, c->d_flag.as<unsigned char>(), &st->n_vals, nullptr);
-    hipLaunchKernelGGL(k_scan_emit<kEmitValues>, dim3(scan_grid), dim3(256), 0, q, c->d_flag.as<unsigned char>(), NPOS,
+    scan_counts(q, bsum_side, flag_pos_bits, &st->n_vals, nullptr);
+    hipLaunchKernelGGL(k_scan_emit<kEmitValues>, dim3(scan_grid), dim3(256), 0, q, flag_pos_bits, NPOS,
                        bsum_side, scan_state, &st->n_vals, (i64 *)nullptr, &st->err, c->d_y.as<double>(), c->d_v.as<double>(), K, c->d_pos_off.as<i64>(),
                        c->d_iv_start.as<int>(), c->d_blk_iv0.as<int>(), (int *)nullptr, (int *)nullptr, (i64 *)nullptr,
                        c->force_scan_stall ? 1 : 0, (int *)nullptr);
     hipLaunchKernelGGL(k_voff, dim3(grid_for(n_part + 1, 1, 2048)), dim3(64), 0, q, n_part, c->d_part_iv_off.as<i64>(),
-                       c->d_pos_off.as<i64>(), NPOS, c->d_flag.as<unsigned char>(), bsum_side, scan_state, &st->n_vals,
+                       c->d_pos_off.as<i64>(), NPOS, flag_pos_bits, bsum_side, scan_state, &st->n_vals,
                        c->d_voff.as<i64>());
     hipLaunchKernelGGL(k_vplan, dim3(1), dim3(256), 0, q, n_part, c->d_part_iv_off.as<i64>(), c->d_pos_off.as<i64>(), NPOS,
                        c->d_voff.as<i64>(), c->d_chunk_off.as<i64>(), st, c->chunk_cap);
@@ -4703,9 +4706,9 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
     begin(ST_CANDIDATES);
     // S3b candidates
     hipLaunchKernelGGL(k_peaks_edges, dim3(grid_for(c->n_tiles, 256, 4096)), dim3(256), 0, s, c->n_tiles, c->d_tile_desc.as<TileDesc>(),
-                       c->d_tile_defer.as<int>(), c->d_y.as<double>(), c->d_cflag.as<unsigned char>(), c->d_part_has2.as<int>(), n_part);
-    scan_counts(s, bsum, c->d_cflag.as<unsigned char>(), &st->n_cand, c->d_cand_off.as<i64>() + K);
-    hipLaunchKernelGGL(k_scan_emit<kEmitPositions>, dim3(scan_grid), dim3(256), 0, s, c->d_cflag.as<unsigned char>(), NPOS,
+                       c->d_tile_defer.as<int>(), c->d_y.as<double>(), flag_cand_bits, c->d_part_has2.as<int>(), n_part);
+    scan_counts(s, bsum, flag_cand_bits, &st->n_cand, c->d_cand_off.as<i64>() + K);
+    hipLaunchKernelGGL(k_scan_emit<kEmitPositions>, dim3(scan_grid), dim3(256), 0, s, flag_cand_bits, NPOS,
                        bsum, scan_state + scan_nb, &st->n_cand, c->d_cand_off.as<i64>() + K, &st->err, (const double *)nullptr, (double *)nullptr, K, c->d_pos_off.as<i64>(),
                        c->d_iv_start.as<int>(), c->d_blk_iv0.as<int>(), c->d_cand_y.as<int>(), (int *)nullptr,
                        c->d_cand_off.as<i64>(), 0, (int *)nullptr);
@@ -5027,15 +5030,15 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
     // S6
     hipLaunchKernelGGL(k_segments, dim3(grid_for(K, 1, 8192)), dim3(iv_threads), 0, s, K, c->d_pos_off.as<i64>(),
                        c->d_cand_off.as<i64>(), c->d_cand_y.as<int>(), c->d_y_raw.as<int>(), c->d_blk_pre.as<int>(), c->d_tile_tot.as<int>(), c->d_iv_tile0.as<int>(),
-                       c->d_chosen.as<unsigned char>(), c->d_final_flag.as<unsigned char>(), c->d_rseg_c.as<int>(),
+                       c->d_chosen.as<unsigned char>(), flag_final_bits, c->d_rseg_c.as<int>(),
                        c->d_seg_prev.as<int>(), st);
     hipLaunchKernelGGL(k_refine, dim3(2048), dim3(64), 0, s, st, c->d_seg_iv.as<int>(), c->d_rseg_c.as<int>(),
                        c->d_seg_prev.as<int>(), c->d_cand_y.as<int>(), c->d_pos_off.as<i64>(), c->d_y_raw.as<int>(),
                        c->d_w_refine.as<double>(), c->P.radius_refine, c->P.sigma, c->d_g.as<double>(), c->d_pk.as<int>(),
-                       c->d_pf.as<unsigned char>(), c->d_kp.as<unsigned char>(), c->d_final_flag.as<unsigned char>());
+                       c->d_pf.as<unsigned char>(), c->d_kp.as<unsigned char>(), flag_final_bits);
     end(ST_REFINE); begin(ST_FINAL);
-    scan_counts(s, bsum, c->d_final_flag.as<unsigned char>(), &st->n_final, c->d_final_off.as<i64>() + K);
-    hipLaunchKernelGGL(k_scan_emit<kEmitPositions>, dim3(scan_grid), dim3(256), 0, s, c->d_final_flag.as<unsigned char>(),
+    scan_counts(s, bsum, flag_final_bits, &st->n_final, c->d_final_off.as<i64>() + K);
+    hipLaunchKernelGGL(k_scan_emit<kEmitPositions>, dim3(scan_grid), dim3(256), 0, s, flag_final_bits,
                        NPOS, bsum, scan_state + 2 * scan_nb, &st->n_final, c->d_final_off.as<i64>() + K, &st->err, (const double *)nullptr, (double *)nullptr, K, c->d_pos_off.as<i64>(),
                        c->d_iv_start.as<int>(), c->d_blk_iv0.as<int>(), c->d_final_y.as<int>(), c->d_final_pos.as<int>(),
                        c->d_final_off.as<i64>(), 0, c->d_final_iv.as<int>());
@@ -5709,13 +5712,12 @@ static int upload_impl(fseg_ctx *c, const fseg_batch *b) {
         auto atleast = [](i64 &cap, i64 v) { if (cap < v) cap = v; };
         atleast(c->chunk_cap, NPOS / 8192 + np + 8);              // an upper bound, not a guess
         Carve cv;
-        cv.add(c->d_y_raw, np8 * 4); cv.add(c->d_y, np8 * 8); cv.add(c->d_flag, np8); cv.add(c->d_cflag, np8);
+        cv.add(c->d_y_raw, np8 * 4); cv.add(c->d_y, np8 * 8); cv.add(c->d_bits, 3 * flag_words(np8) * 4);
         cv.add(c->d_v, np8 * 8);
         cv.add(c->d_scan_state, ((size_t)nb * 3 + 1) * 8);
         cv.add(c->d_bsum, ((size_t)nb + 2) * 4);
         cv.add(c->d_bsum_side, ((size_t)nb + 2) * 4);
         cv.add(c->d_g, np8 * 8); cv.add(c->d_pk, np8 * 4); cv.add(c->d_pf, np8); cv.add(c->d_kp, np8);
-        cv.add(c->d_final_flag, np8);
         cv.add(c->d_part_has2, ((size_t)np + 1) * 4);
         cv.add(c->d_tile_tot, ((size_t)n_tiles + 1) * 4);
         cv.add(c->d_blk_pre, ((size_t)n_tiles + 1) * (kSmoothTile / kSumBlock) * 4);
