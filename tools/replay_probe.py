@@ -17,6 +17,7 @@ from freddie_amd import _lib, tables  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--workload", default="config4")
 ap.add_argument("--reps", type=int, default=20)
+ap.add_argument("--profiling", type=int, default=1, help="0: no stage events (the product's single graph), 1: scoring stage bracketed, 3: every stage")
 args = ap.parse_args()
 params = bench.PARAMS["config5" if args.workload == "config5" else "default"]
 tabs = dict(w_main=tables.gaussian_half_kernel(params["sigma"], 4.0), w_refine=tables.gaussian_half_kernel(params["sigma"], 1.0),
@@ -30,7 +31,7 @@ for i in range(per):
 b = bench.Batch(parts)
 ctx = _lib.Context(0)
 ctx.set_params(**params, **tabs)
-ctx.set_profiling(True)
+ctx.set_profiling(args.profiling)
 for rnd in range(2):
     ctx.upload(**b.arrays)
     t0 = time.perf_counter(); ctx.run(); ctx.sync(); t1 = time.perf_counter()
@@ -44,7 +45,7 @@ for _ in range(args.reps):
     for k, v in ctx.stage_ms().items():
         acc[k] = acc.get(k, 0.0) + v
 dt = (time.perf_counter() - t0) / args.reps * 1e3
-sc = acc["interval_scoring"] / args.reps
+sc = acc.get("interval_scoring", 0.0) / args.reps or float("nan")
 print("replay: %.3f ms/step, %.1f M reads/s; scoring %.3f ms = %.0f GB/s credited (frac %.3f); sizes %s" % (
     dt, b.n_reads / dt / 1e3, sc, alg / sc / 1e6, alg / sc / 1e6 / 8000.0, ctx.sizes()))
 print("  " + " ".join("%s=%.3f" % (k, v / args.reps) for k, v in acc.items() if v > 0))
