@@ -25,7 +25,8 @@ Prints ONE JSON line (rank 0) with, besides the driver's fields:
   roofline_config2      one 50 k-read x 2 k-candidate partition (BASELINE configs[1], the arena path): coverage + scoring + DP
                         (scoring_prep + interval_scoring + dp stages), like the other configs' stage; k_score alone as a sub-field
   roofline_config3 / roofline_config5   the stage of one resident batch of BASELINE configs[2] / [4] (config4 runs only)
-  value_resident_replay hipGraph replay of one resident batch (no copies, no sizing)
+  value_resident_replay replay of one resident batch (no copies, no sizing; plain launches on the library's streams -- a run
+                        that forks is not replayed as a hipGraph: DESIGN.md section 3)
   value_hbm_resident    batches uploaded first, then each run once (first-run path, no copies in the timed part)
   cpu_baseline / cpu_baseline_all_cores   the C oracle on this box's host cores (1 thread / every core)
   e2e                   the drop-in CLI on a split directory of the same job in tmpfs: files in -> files out, through the CLI's N
@@ -596,7 +597,7 @@ def main():
             "result_checksum_per_step": checksum_all // max(1, args.steps),
         }
         out["value_resident_replay"] = {"value": batches[0].n_reads * reps / dt_r, "unit": "reads/s", "ms_per_step": dt_r / reps * 1e3,
-                                        "what": "hipGraph replay of one resident 250 k-read batch: no copies, no arena sizing (a batch, not the job)"}
+                                        "what": "replay of one resident 250 k-read batch: no copies, no arena sizing (a batch, not the job)"}
         if not args.no_extras:
             # inputs resident in HBM before the timed part, every batch run ONCE on the first-run path: one batch per
             # context uploaded, then all of them run (one host thread per context, as in the timed steps), results left in HBM

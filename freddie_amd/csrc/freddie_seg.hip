@@ -106,7 +106,7 @@ struct Status {
     u64 n_tiny;        // problems solved whole by k_tiny (their list follows the three solve lists)
     unsigned list_cur[8];   // k_prob_emit's cursors into the four solve lists: [2 * list] from the front (expensive problems), [2 * list + 1] from the back
     unsigned wide_cls[4];   // solve-list problems per size class that see more than kFuseLanes reads (16-bit counters); [3] unused
-    unsigned wide_cur[4];   // k_prob_emit's cursors into the per-class lists of those problems (wide_items)
+    unsigned wide_cur[4];   // k_prob_emit's cursors into the per-class lists of those problems (wide_items); [3]: into the list of all of them (wide_all)
     unsigned gate_wide;     // workgroups of the large class's 16-bit instance that have started ('h' in a plan: the 8-bit instance waits for them)
     unsigned gate;          // large-class workgroups that have started (k_gate holds the small classes back until they are placed)
                             // (a counter of the mid class's 2 000 workgroups, bumped by each as it started, cost that kernel 10 of
@@ -1419,7 +1419,7 @@ __global__ void __launch_bounds__(256) k_prob_emit(Status *st, const int *cand_p
                                                    ProblemArrays pr, i64 prob_cap, int2 *work_pc, int4 *cls_items,
                                                    i64 work_cap, int *dp_items, ProbDesc *desc, const int *iv_start,
                                                    const int *iv_part, const i64 *part_lane_off, ProbSplit sp, int *solve_items,
-                                                   ProbDesc *solve_desc, int *wide_items) {
+                                                   ProbDesc *solve_desc, int *wide_items, int *wide_all) {
     __shared__ i64 lds[4 * kProbCols];
     __shared__ int l_slot[kProbBlock], l_cnt[kProbBlock];
     __shared__ int l_mx[8];
@@ -1530,6 +1530,10 @@ __global__ void __launch_bounds__(256) k_prob_emit(Status *st, const int *cand_p
                             if (li < 3 && d.lane_n > kFuseLanes) {
                                 const i64 wp = lbase + (i64)atomicAdd(&st->wide_cur[li], 1u);
                                 if (wp < lbase + llen && wp < prob_cap) wide_items[wp] = (int)(si - lbase);
+                                // ... and of the three lists together, as positions from the first list's start: a batch with a
+                                // handful of them has one launch for them all (plan 'W')
+                                const i64 wa = (i64)atomicAdd(&st->wide_cur[3], 1u);
+                                if (wa < prob_cap) wide_all[wa] = (int)si;
                             }
                         }
                     }
@@ -4351,10 +4355,12 @@ struct fseg_ctx {
     // hand-over arena between k_solve<.., SPLIT> and k_dpw (dpx_slot_bytes per problem of the three solve lists), laid out by
     // alloc_arenas() for the counts it knew: a launch takes the split path only for a list that fits what was laid out
     DevBuf d_wide_items;         // per solve list: the list positions of the problems that see more than kFuseLanes reads (k_prob_emit)
+    DevBuf d_wide_all;           // ... of the three lists together (positions from the first list's start)
     DevBuf d_dpx, d_prob_nact;   // (d_prob_nact: the reads a wide solve-list problem keeps: k_solve<.., SPLIT> tells k_dpw whose counters it used)
     i64 dpx_base[3] = {0, 0, 0}, dpx_stride[3] = {0, 0, 0}, dpx_n[3] = {0, 0, 0};
     int dpx_nm = 0, dpx_cnt[3] = {1, 1, 1};
     bool split_always = false;  // FSEG_SPLIT_ALWAYS=1 (tests): the split path also where a context keeps to one stream
+    i64 wide_one_max = 256;     // FSEG_WIDE_ONE_MAX: plan 'W' takes a batch's wide problems in one launch when there are at most this many (0: never)
     int split_dp = 7;           // FSEG_SPLIT_DP: bit 0 / 1 / 2 = the small / mid / large class hands its DPs to k_dpw (0: the DP stays the tail of k_solve's workgroups)
     i64 prob_cap = 0, work_cap = 0, pair_cap = 0, tri_cap = 0, label_cap = 0, chunk_cap = 0, cov_cap = 0;
     DevBuf d_status, d_prep, d_tacc;
@@ -4374,6 +4380,14 @@ struct fseg_ctx {
     bool small_batch = false;
     bool tiny_on = false;       // many problems (> tiny_from): problems with <= kTiny candidates go to k_tiny
     bool use_graph = true;      // replay the launch sequence as hipGraphs from the second run of a batch on (FSEG_NO_GRAPH=1 disables)
+    // ... when the run keeps to ONE stream (other contexts' batches in flight, small batches, FSEG_NO_FORK=1).  A run that
+    // forks is replayed as plain launches: launching a graph with cross-stream edges costs the host 0.5-0.6 ms (ROCm 7.2,
+    // the 250 k-read batch: 0.51 ms against 0.17 ms for the ~60 plain launches and 0.03 ms for the one-stream graph), more than
+    // the GPU needs for the stages before the scoring stage -- the side streams' packets arrive late and the replay takes
+    // 1.13 ms instead of 0.71 (tools/replay_probe.py --profiling 0; FSEG_GRAPH_FORK=1 brings the forked graph back).
+    bool graph_fork = false;
+    bool run_plain = false;     // this run: plain launches (set by fseg_run)
+    bool run_linear = false;    // this run: one stream whatever else holds (a graph is being captured)
     bool use_sized = true;      // the first run of a batch stops twice to size its arenas exactly (FSEG_NO_SIZED=1: guess, and re-run on overflow)
     i64 prob_self_max = 4 * kProbBlock;   // candidates up to which it does (FSEG_PROB_SELF_MAX)
     bool prob_self_scan = false; // k_prob_emit adds up the candidate blocks itself (few candidates)
@@ -4400,7 +4414,7 @@ struct fseg_ctx {
     bool use_tiny = true;       // FSEG_NO_TINY=1: no problem goes to k_tiny
     bool force_key64 = false;
     bool wide_by_seen = false;  // FSEG_WIDE_BY_SEEN=1 (tests)
-    char score_plan[32] = "gM|hB|msgTS|b"; // FSEG_SCORE_PLAN (see enqueue_run; anything that does not name each class once = one stream)
+    char score_plan[32] = "gM|hB|gTS|W";   // FSEG_SCORE_PLAN (see enqueue_run; anything that does not name each class once = one stream)
     bool use_wave = true;       // FSEG_NO_WAVE=1: k_tiny / k_solve<16> instead of the wave kernels (k_wave)
     bool use_fuse = true;       // FSEG_NO_FUSE=1: no problem goes to k_solve (everything that is not tiny takes the arena path)
     // Reads the widest problem of a batch may see for the batch's problems to be solved whole (k_solve / k_wave) instead of going
@@ -4457,6 +4471,7 @@ static std::atomic<int> g_in_flight[64];
 static std::atomic<int> g_live[64];
 static void set_in_flight(fseg_ctx *c, bool on);
 static bool others_in_flight(const fseg_ctx *c);
+static bool would_fork(const fseg_ctx *c);
 
 struct Tick {
     std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
@@ -4541,6 +4556,7 @@ int alloc_arenas(fseg_ctx *c) {
     cv.add(c->d_dp_items, (size_t)c->prob_cap * 4);
     cv.add(c->d_solve_items, (size_t)c->prob_cap * 4);
     cv.add(c->d_wide_items, (size_t)c->prob_cap * 4);
+    cv.add(c->d_wide_all, (size_t)c->prob_cap * 4);
     cv.add(c->d_solve_desc, (size_t)c->prob_cap * sizeof(ProbDesc));
     cv.add(c->d_prob_cov_off, (size_t)c->prob_cap * 8);
     cv.add(c->d_prob_lane_lo, (size_t)c->prob_cap * 4);
@@ -4593,7 +4609,7 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
     hipStream_t s = c->stream;
     const bool do_pre1 = segs & SEG_PRE1, do_pre2 = segs & SEG_PRE2, do_score = segs & SEG_SCORE, do_post1 = segs & SEG_POST1,
                do_post2 = segs & SEG_POST2;
-    const bool stage_events = c->profiling && (sized || !c->use_graph || c->profile_plain);
+    const bool stage_events = c->profiling && (sized || c->run_plain);
     const int n_part = c->n_part;
     const i64 K = c->K, NPOS = c->NPOS;
     Status *st = c->d_status.as<Status>();
@@ -4605,7 +4621,7 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
     // the function returns, so a capture of the main stream ends with all branches merged.
     // Small batches (one partition, few problems) are chains of launch-latency-sized kernels: branches only add
     // cross-stream dependencies there (measured: config2 +4 %), so they stay on the one stream.
-    const bool forking = c->use_fork && !c->small_batch && !others_in_flight(c) && c->side[0] != nullptr;
+    const bool forking = would_fork(c) && !c->run_linear;
     const int tiny_max = c->tiny_on ? kTiny : 0;
     const bool wave = wave_on(c);
     const ProbSplit split = split_of(c, c->tiny_on, c->fuse_on);
@@ -4738,7 +4754,7 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
                        pr, c->prob_cap, c->d_work_pc.as<int2>(), c->d_cls_items.as<int4>(),
                        c->work_cap, c->d_dp_items.as<int>(), c->d_prob_desc.as<ProbDesc>(), c->d_iv_start.as<int>(),
                        c->d_iv_part.as<int>(), c->d_part_lane_off.as<i64>(), split, c->d_solve_items.as<int>(), c->d_solve_desc.as<ProbDesc>(),
-                       c->d_wide_items.as<int>());
+                       c->d_wide_items.as<int>(), c->d_wide_all.as<int>());
     // S5
     if (c->prob_cap > 0 && any_arena) {
         const int cov_blocks = work_grid < 2048 ? work_grid : 2048;
@@ -4825,6 +4841,14 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
             hipLaunchKernelGGL((k_solve<NMV, CNT, VT, false>), dim3(grid_for(FSEG_SOLVE_N(CNT, CLS, N_ITEMS), 1, known ? (1 << 20) : (MAXWG))), dim3(SolveCfg<NMV>::kThreads), \
                                solve_lds_for((NMV) == kNMax ? c->nm_big : (NMV), (NMV) + 1, (int)sizeof(CNT)), Q,               \
                                FSEG_SOLVE_ARGS(NMV, CNT, CLS), (unsigned char *)nullptr, (i64)0, (int *)nullptr, FSEG_SOLVE_WIDE(CNT, CLS) FSEG_TARG)
+        // every list's problems that see more than kFuseLanes reads, through wide_all: the large class's 16-bit instance, a workgroup each
+#define FSEG_LAUNCH_WIDE_ALL(Q, VT)                                                                                          \
+            hipLaunchKernelGGL((k_solve<kNMax, unsigned short, VT, false>), dim3((unsigned)n_wide_all), dim3(SolveCfg<kNMax>::kThreads), \
+                               solve_lds_for(c->nm_big, kNMax + 1, 2), Q, st, -1, c->nm_big, (i64)0, n_wide_all, pr, c->d_solve_desc.as<ProbDesc>(), \
+                               c->prob_cap, c->d_cand_y.as<int>(), c->d_lane_ex.as<longlong2>(), c->d_ex_ts.as<int>(),         \
+                               c->d_ex_te.as<int>(), c->d_h_table.as<double>(), c->P.h_len, c->P.threshold_rate,               \
+                               c->d_thr_tab.as<int2>(), c->P.min_read_support_outside, c->d_chosen.as<unsigned char>(),       \
+                               (c->wide_by_seen ? 1 : 0), (unsigned char *)nullptr, (i64)0, (int *)nullptr, c->d_wide_all.as<int>() FSEG_TARG)
         // the split path, one instance: k_solve<.., SPLIT> (set-up and rounds) then k_dpw (the DPs) on the same stream
 #define FSEG_LAUNCH_SPLIT(Q, NMV, CNT, VT, CLS, N_ITEMS)                                                                     \
         do { const int nm_rt = (NMV) == kNMax ? c->nm_big : (NMV);                                                            \
@@ -4879,12 +4903,19 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
             if (plan) {
                 int n_seg = 1;
                 bool used[4] = {true, false, false, false};              // a stream whose kernels have nothing to do is left alone
+                // W: the problems of every class that see more than kFuseLanes reads -- a handful per batch, most of which keep fewer
+                // and are only looked at -- in ONE launch of the large class's 16-bit instance, a workgroup each (as a launch per
+                // class on the tiny class's stream they held it back 46-60 us on config3 / config5: tools/run_gaps.py); batches
+                // with many such problems keep the per-class instances (b, m, s in a row)
+                const i64 n_wide_all = c->n_wide[0] + c->n_wide[1] + c->n_wide[2];
+                const bool wide_one = c->wide_one_max > 0 && n_wide_all <= c->wide_one_max && strchr(plan, 'W') != nullptr;
                 for (const char *p = plan; *p; ++p) {
                     if (*p == '|') { ++n_seg; continue; }
                     if (n_seg > 4) continue;
                     static const char wide_kinds[] = "bms";
                     const char *at = strchr(wide_kinds, *p);
-                    if (!at || (c->wide_solve && c->n_wide[2 - (int)(at - wide_kinds)] > 0)) used[n_seg - 1] = true;
+                    if (*p == 'W') { if (c->wide_solve && n_wide_all > 0) used[n_seg - 1] = true; }
+                    else if (!at || (c->wide_solve && c->n_wide[2 - (int)(at - wide_kinds)] > 0)) used[n_seg - 1] = true;
                 }
                 if (n_seg > 4) n_seg = 4;
                 // (the segments that have something to launch take the side streams in order: the first ones start first)
@@ -4894,10 +4925,12 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
                 int seg = 0;
                 hipEvent_t ev_big = nullptr;
                 // b m s: the class's instance with 16-bit counters on its own (B M S then launch the 8-bit one only)
-                const int wb = strchr(plan, 'b') ? 1 : 3, wm = strchr(plan, 'm') ? 1 : 3, ws = strchr(plan, 's') ? 1 : 3;
+                const bool pw = strchr(plan, 'W') != nullptr;
+                const int wb = (pw || strchr(plan, 'b')) ? 1 : 3, wm = (pw || strchr(plan, 'm')) ? 1 : 3, ws = (pw || strchr(plan, 's')) ? 1 : 3;
                 // the large class's workgroups a start gate waits for: the 8-bit instance's and the 16-bit instance's (one per wide
                 // problem) -- the latter need 90 KB of LDS each and find no room once the other classes are in
-                const i64 big_wgs = c->n_solve[2] + (FSEG_WIDE_NEEDED(2) ? c->n_wide[2] : 0);
+                const i64 wide_wgs = wide_one ? (c->wide_solve ? n_wide_all : 0) : (FSEG_WIDE_NEEDED(2) ? c->n_wide[2] : 0);
+                const i64 big_wgs = c->n_solve[2] + wide_wgs;
                 // Three passes over the plan: the large class's launches that open their stream go out FIRST -- the 16-bit instance
                 // (b), then the 8-bit one (B, behind `h` = a gate on b's workgroups having started) --, everything else follows in
                 // plan order (a stream's own order is kept).  Why: a workgroup of the 16-bit instance holds up to 120 KB of LDS (n
@@ -4910,7 +4943,7 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
                 bool opens = true;
                 for (const char *p = plan; *p && seg < n_seg; ++p) {
                     if (*p == '|') { ++seg; opens = true; continue; }
-                    const int when = !opens ? 2 : (*p == 'b' ? 0 : ((*p == 'B' || *p == 'h') ? 1 : 2));
+                    const int when = !opens ? 2 : ((*p == 'b' || *p == 'W') ? 0 : ((*p == 'B' || *p == 'h') ? 1 : 2));
                     if (*p != 'h') opens = false;
                     if (!used[seg] || when != pass) continue;
                     hipStream_t q = seg == 0 ? s : c->side[side_of[seg]];
@@ -4920,12 +4953,22 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
                     case 'M': if (c->n_solve[1] > 0) FSEG_LAUNCH_SOLVE_X(q, kClsMid, 1, c->n_solve[1], FSEG_WG_MID, wm); break;
                     case 'S': if (c->n_solve[0] > 0) FSEG_LAUNCH_SOLVE_X(q, kClsSmall, 0, c->n_solve[0], FSEG_WG_SMALL, ws); break;
                     case 'b': FSEG_LAUNCH_SOLVE_X(q, kNMax, 2, c->n_solve[2], 512, 2); break;
+                    case 'W':
+                        if (!c->wide_solve || n_wide_all == 0) break;
+                        if (wide_one) {                          // (the DP stays the workgroup's tail: nothing to hand over, no second placement)
+                            if (key32) FSEG_LAUNCH_WIDE_ALL(q, int); else FSEG_LAUNCH_WIDE_ALL(q, i64);
+                        } else {
+                            FSEG_LAUNCH_SOLVE_X(q, kNMax, 2, c->n_solve[2], 512, 2);
+                            if (c->n_solve[1] > 0) FSEG_LAUNCH_SOLVE_X(q, kClsMid, 1, c->n_solve[1], FSEG_WG_MID, 2);
+                            if (c->n_solve[0] > 0) FSEG_LAUNCH_SOLVE_X(q, kClsSmall, 0, c->n_solve[0], FSEG_WG_SMALL, 2);
+                        }
+                        break;
                     case 'm': if (c->n_solve[1] > 0) FSEG_LAUNCH_SOLVE_X(q, kClsMid, 1, c->n_solve[1], FSEG_WG_MID, 2); break;
                     case 's': if (c->n_solve[0] > 0) FSEG_LAUNCH_SOLVE_X(q, kClsSmall, 0, c->n_solve[0], FSEG_WG_SMALL, 2); break;
                     case 'T': if (c->n_tiny > 0) FSEG_LAUNCH_WAVE(q, kTiny, 3, c->n_tiny); break;
                     case 'g': hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, q, st, 0, (unsigned)(big_wgs < 512 ? big_wgs : 512), 3000u); break;
-                    case 'h': if (FSEG_WIDE_NEEDED(2) && c->n_wide[2] > 0)       // the 16-bit instance's workgroups (up to 120 KB of LDS each) take their CUs first
-                                  hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, q, st, 2, (unsigned)(c->n_wide[2] < 256 ? c->n_wide[2] : 256), 1500u);
+                    case 'h': if (wide_wgs > 0)       // the 16-bit instance's workgroups (up to 120 KB of LDS each) take their CUs first
+                                  hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, q, st, 2, (unsigned)(wide_wgs < 256 ? wide_wgs : 256), 1500u);
                               break;
                     case 'e': if (ev_big && hipStreamWaitEvent(q, ev_big, 0) != hipSuccess) fj_err = hipErrorUnknown; break;
                     default: break;
@@ -4945,6 +4988,7 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
 #undef FSEG_LAUNCH_SOLVE_W
 #undef FSEG_LAUNCH_SOLVE_X
 #undef FSEG_LAUNCH_SPLIT_K
+#undef FSEG_LAUNCH_WIDE_ALL
 #undef FSEG_LAUNCH_SPLIT
 #undef FSEG_LAUNCH_SOLVE
 #undef FSEG_SOLVE_ARGS
@@ -5153,7 +5197,7 @@ void collect_stage_times(fseg_ctx *c, int timed_graphs) {
         (void)hipEventElapsedTime(&c->stage_ms[ST_GRAPH_PRE], c->ev_g[0], c->ev_g[1]);
         (void)hipEventElapsedTime(&c->stage_ms[ST_SCORE], c->ev_g[1], c->ev_g[2]);
         (void)hipEventElapsedTime(&c->stage_ms[ST_GRAPH_POST], c->ev_g[2], c->ev_g[3]);
-    } else if (c->last_sized || !c->use_graph || c->profile_plain) {
+    } else if (c->last_sized || c->run_plain) {
         for (int i = 0; i < ST_COUNT; ++i) {
             if (!c->profile_all && i != ST_SCORE) continue;
             if (hipEventElapsedTime(&c->stage_ms[i], c->ev_b[i], c->ev_e[i]) != hipSuccess) { c->stage_ms[i] = 0.f; (void)hipGetLastError(); }
@@ -5171,6 +5215,8 @@ static bool others_in_flight(const fseg_ctx *c) {
     if (c->device < 0 || c->device >= 64) return false;
     return g_in_flight[c->device].load(std::memory_order_relaxed) - (c->counted_in_flight ? 1 : 0) > 0;
 }
+// the run has the device to itself and is worth branching (see enqueue_run)
+static bool would_fork(const fseg_ctx *c) { return c->use_fork && !c->small_batch && !others_in_flight(c) && c->side[0] != nullptr; }
 static int finish_run_impl(fseg_ctx *c);
 int finish_run(fseg_ctx *c) {
     const int rc = finish_run_impl(c);
@@ -5195,7 +5241,7 @@ static int finish_run_impl(fseg_ctx *c) {
         if (!need) {
             c->pending = false;
             c->ran = true;
-            const int timed_graphs = c->n_graphs;
+            const int timed_graphs = c->run_plain ? 0 : c->n_graphs;
             collect_stage_times(c, timed_graphs);
             note_counts(c, s);
             adapt_to(c, s);
@@ -5383,6 +5429,7 @@ int fseg_create(int device, fseg_ctx **out) {
     c->d_status.cap = sizeof(Status); c->d_prep.cap = sizeof(PrepStatus); c->d_tacc.cap = kTaccBytes;
     auto flag = [](const char *name) { const char *v = getenv(name); return v && v[0] == '1'; };
     if (flag("FSEG_NO_GRAPH")) c->use_graph = false;
+    if (flag("FSEG_GRAPH_FORK")) c->graph_fork = true;
     if (flag("FSEG_NO_FORK")) c->use_fork = false;
     if (flag("FSEG_NO_TINY")) c->use_tiny = false;
     if (flag("FSEG_NO_FUSE")) c->use_fuse = false;
@@ -5391,6 +5438,7 @@ int fseg_create(int device, fseg_ctx **out) {
     if (flag("FSEG_WIDE_BY_SEEN")) c->wide_by_seen = true;
     if (const char *e = getenv("FSEG_SPLIT_DP")) c->split_dp = atoi(e) & 7;
     if (flag("FSEG_SPLIT_ALWAYS")) c->split_always = true;
+    if (const char *e = getenv("FSEG_WIDE_ONE_MAX")) c->wide_one_max = atoll(e) < 0 ? 0 : atoll(e);
     if (const char *e = getenv("FSEG_SCORE_PLAN")) snprintf(c->score_plan, sizeof c->score_plan, "%s", e);
     {
         int seen[4] = {0, 0, 0, 0};
@@ -5776,7 +5824,10 @@ static int run_impl(fseg_ctx *c) {
     // sequence is replayed (as a hipGraph unless disabled)
     if (!c->ran && c->use_sized) return run_sized(c);
     c->last_sized = false;
-    if (c->use_graph && !c->profile_plain) {
+    c->run_plain = !c->use_graph || c->profile_plain || (would_fork(c) && !c->graph_fork);
+    if (!c->run_plain) {
+        c->run_linear = !c->graph_fork;
+        struct Unset { fseg_ctx *c; ~Unset() { c->run_linear = false; } } unset{c};
         if (c->n_graphs == 0) {
             const int want = c->profiling ? 2 : 1;
             bool ok = true;
@@ -5792,6 +5843,7 @@ static int run_impl(fseg_ctx *c) {
                 (void)hipGetLastError();
                 drop_graph(c);
                 c->use_graph = false;
+                c->run_plain = true;
             }
         }
         if (c->n_graphs == 1) {

@@ -74,6 +74,11 @@ SWITCHES = [
     {"FSEG_FUSE_LANES": "1023", "FSEG_WIDE_BY_SEEN": "1"},  # wide problems (16-bit counters) through the split path, chosen by the reads they see
     {"FSEG_FUSE_LANES": "1023", "FSEG_WIDE_BY_SEEN": "1", "FSEG_SPLIT_DP": "0"},   # ... and fused: the 16-bit instances go over their classes' wide lists either way
     {"FSEG_FUSE_LANES": "1023", "FSEG_SCORE_PLAN": "gM|B|gTS|bms"},    # no `h` gate, the 16-bit instances one after the other on a stream
+    {"FSEG_SCORE_PLAN": "gM|hB|msgTS|b"},                   # the 16-bit instances per class (round 4's earlier default)
+    {"FSEG_WIDE_ONE_MAX": "0"},                             # plan 'W' with too many wide problems for one launch: an instance per class
+    {"FSEG_FUSE_LANES": "1023", "FSEG_WIDE_BY_SEEN": "1", "FSEG_WIDE_ONE_MAX": "100000"},   # every wide problem, whatever its class, by the large class's 16-bit instance
+    {"FSEG_FUSE_LANES": "1023", "FSEG_WIDE_BY_SEEN": "1", "FSEG_WIDE_ONE_MAX": "100000", "FSEG_FORCE_KEY64": "1"},
+    {"FSEG_GRAPH_FORK": "1"},                               # the forked run replayed as a hipGraph with cross-stream edges (slower to launch: DESIGN section 3)
 ]
 
 

@@ -40,8 +40,10 @@ for rnd in range(2):
 alg = ctx.scoring_algorithmic_bytes()
 acc = {}
 t0 = time.perf_counter()
+t_run = 0.0
 for _ in range(args.reps):
-    ctx.run(); ctx.sync()
+    h0 = time.perf_counter(); ctx.run(); t_run += time.perf_counter() - h0
+    ctx.sync()
     for k, v in ctx.stage_ms().items():
         acc[k] = acc.get(k, 0.0) + v
 dt = (time.perf_counter() - t0) / args.reps * 1e3
@@ -49,4 +51,5 @@ sc = acc.get("interval_scoring", 0.0) / args.reps or float("nan")
 print("replay: %.3f ms/step, %.1f M reads/s; scoring %.3f ms = %.0f GB/s credited (frac %.3f); sizes %s" % (
     dt, b.n_reads / dt / 1e3, sc, alg / sc / 1e6, alg / sc / 1e6 / 8000.0, ctx.sizes()))
 print("  " + " ".join("%s=%.3f" % (k, v / args.reps) for k, v in acc.items() if v > 0))
+print("  host time of fseg_run (enqueue only): %.3f ms" % (t_run / args.reps * 1e3))
 ctx.close()
