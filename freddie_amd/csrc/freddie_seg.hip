@@ -72,6 +72,7 @@ enum : unsigned {
     kErrOverflowChunks = 256u,
     kErrOverflowCov = 512u,
     kErrOverflowNm = 1024u,
+    kErrWideMissed = 16384u,   // internal: a problem keeps more reads than k_prob_range counted for it (the 8-bit instance met it)
     kErrWaveStage = 8192u,     // a wave kernel (k_wave) met a read with more exons than its LDS stage holds: rerun without them
     kErrScanStall = 4096u,     // the look-back scan gave up waiting for a predecessor block: rerun with the three-pass scan
     kErrNeedWideDp = 2048u,    // a problem sees >= 65536 reads: its DP needs the 32-bit count table    // a problem is larger than the LDS carve-up this launch was sized for
@@ -1198,27 +1199,87 @@ __global__ void k_fix(i64 K, const i64 *pos_off, const int *iv_part, const i64 *
     }
 }
 
+// The exons of one read (ex = its range in the exon arrays) that meet the window [cp0, c_last): exons are ordered, so they
+// are consecutive -- `cnt` of them from the read's `first_rel`-th.  k_solve keeps the reads with cnt > 0 (its rounds run over
+// those only) and k_prob_range counts them ahead of it: the one definition of "keeps".
+__device__ __forceinline__ void window_exons(const int *__restrict__ ex_ts, const int *__restrict__ ex_te, longlong2 ex, int cp0, int c_last,
+                                             int *first_rel, int *cnt_out) {
+    const int n_ex = (int)(ex.y - ex.x);                     // (a read's exons: 32-bit counts from here on)
+    int fr = 0, cnt = 0;
+    for (int eb = 0; eb < n_ex; eb += 8) {                   // eight exons per round from clamped addresses, in flight together
+        int ts8[8], te8[8];
+        load_exons8(ex_ts + ex.x + eb, ts8); load_exons8(ex_te + ex.x + eb, te8);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool hit = eb + u < n_ex && te8[u] >= cp0 && ts8[u] < c_last;
+            if (hit && cnt == 0) fr = eb + u;
+            cnt += hit;
+        }
+        if (eb + 7 < n_ex && ts8[7] >= c_last) break;        // the rest of the read lies beyond the window
+    }
+    *first_rel = fr; *cnt_out = cnt;
+}
+
 // For the right end of every problem: the range of position-sorted reads that can overlap the problem's window
 // [g0, g1): reads are sorted by first position, lane_pmax is the running maximum of their last position.
-__global__ void k_prob_range(const Status *st, const int *cand_pn, const int *cand_iv, const int *cand_y,
+// ... and, for a problem that sees more than kFuseLanes reads (8-bit counters hold 255), whether it KEEPS more than that
+// many -- reads with an exon in the window, about two thirds of those it sees: cand_wide[c] = 1 sends it to the 16-bit
+// instances of k_solve (kKindFusedWide in its record).  Such candidates are rare and expensive (up to kFuseLanesWide reads
+// each): the workgroup collects its own in LDS and goes over them together, a read per thread.  (Round 4 until here: both
+// instances located every such problem and counted its kept reads, the 16-bit ones to drop nearly all of them again --
+// launches of 12-70 us in front of the classes behind them on config3 / config5.)
+constexpr int kRangeThreads = 256;
+__global__ void __launch_bounds__(kRangeThreads) k_prob_range(const Status *st, const int *cand_pn, const int *cand_iv, const int *cand_y,
                              const int *iv_part, const int *iv_start, const i64 *part_lane_off, const int *lane_start,
-                             const int *lane_pmax, int *cand_ll, int *cand_ln) {
-    i64 n_cand = (i64)st->n_cand;
-    for (i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x; c < n_cand; c += (i64)gridDim.x * blockDim.x) {
-        int n = cand_pn[c];
-        int lo_lane = 0, n_lanes = 0;
-        if (n > 0) {
-            int k = cand_iv[c];
-            int part = iv_part[k];
-            int g0 = iv_start[k] + cand_y[c - (n - 1)], g1 = iv_start[k] + cand_y[c];
-            i64 a = part_lane_off[part], L1 = part_lane_off[part + 1], b = L1;
-            while (a < b) { i64 m = (a + b) >> 1; if (lane_pmax[m] < g0) a = m + 1; else b = m; }
-            i64 lo = a;
-            b = L1;
-            while (a < b) { i64 m = (a + b) >> 1; if (lane_start[m] < g1) a = m + 1; else b = m; }
-            lo_lane = (int)lo; n_lanes = (int)(a - lo);
+                             const int *lane_pmax, int *cand_ll, int *cand_ln, unsigned char *cand_wide,
+                             const longlong2 *__restrict__ lane_ex, const int *__restrict__ ex_ts, const int *__restrict__ ex_te, int wide_by_seen) {
+    __shared__ int l_wide[kRangeThreads], l_n, l_red[kRangeThreads / 64];
+    const i64 n_cand = (i64)st->n_cand;
+    for (i64 c0 = (i64)blockIdx.x * blockDim.x; c0 < n_cand; c0 += (i64)gridDim.x * blockDim.x) {    // (workgroup-uniform)
+        const i64 c = c0 + threadIdx.x;
+        if (threadIdx.x == 0) l_n = 0;
+        __syncthreads();
+        if (c < n_cand) {
+            int n = cand_pn[c];
+            int lo_lane = 0, n_lanes = 0;
+            if (n > 0) {
+                int k = cand_iv[c];
+                int part = iv_part[k];
+                int g0 = iv_start[k] + cand_y[c - (n - 1)], g1 = iv_start[k] + cand_y[c];
+                i64 a = part_lane_off[part], L1 = part_lane_off[part + 1], b = L1;
+                while (a < b) { i64 m = (a + b) >> 1; if (lane_pmax[m] < g0) a = m + 1; else b = m; }
+                i64 lo = a;
+                b = L1;
+                while (a < b) { i64 m = (a + b) >> 1; if (lane_start[m] < g1) a = m + 1; else b = m; }
+                lo_lane = (int)lo; n_lanes = (int)(a - lo);
+            }
+            cand_ll[c] = lo_lane; cand_ln[c] = n_lanes;
+            const bool cand = n > 0 && n <= kNMax && n_lanes > kFuseLanes && n_lanes <= kFuseLanesWide;
+            cand_wide[c] = (unsigned char)((cand && wide_by_seen) ? 1 : 0);     // (FSEG_WIDE_BY_SEEN=1, tests: whatever SEES more than kFuseLanes reads)
+            if (cand && !wide_by_seen) l_wide[atomicAdd(&l_n, 1)] = (int)threadIdx.x;
         }
-        cand_ll[c] = lo_lane; cand_ln[c] = n_lanes;
+        __syncthreads();
+        const int nw = l_n;
+        for (int w = 0; w < nw; ++w) {
+            const i64 cw = c0 + l_wide[w];
+            const int n = cand_pn[cw], k = cand_iv[cw], ll = cand_ll[cw], ln = cand_ln[cw];
+            const int cp0 = iv_start[k] + cand_y[cw - (n - 1)], c_last = iv_start[k] + cand_y[cw];
+            int kept = 0;
+            for (int l = threadIdx.x; l < ln; l += kRangeThreads) {
+                int first_rel, cnt;
+                window_exons(ex_ts, ex_te, lane_ex[ll + l], cp0, c_last, &first_rel, &cnt);
+                kept += cnt > 0;
+            }
+            for (int d = 32; d >= 1; d >>= 1) kept += __shfl_xor(kept, d);
+            if (lane_id() == 0) l_red[threadIdx.x >> 6] = kept;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                int tot = 0;
+                for (int q = 0; q < kRangeThreads / 64; ++q) tot += l_red[q];
+                if (tot > kFuseLanes) cand_wide[cw] = 1;
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -1246,7 +1307,7 @@ __device__ __forceinline__ int size_class(int n) { return n <= kClsSmall ? 0 : (
 //   with the wave kernels (k_wave: the batch has its exon stream) the small class -- n <= wave_n -- is solved whole, one wave
 //     per problem, whenever the problem sees at most wave_lanes reads, whatever the rest of the batch looks like.
 struct ProbSplit { int tiny_max, fuse_lanes; };
-enum { kKindArena = 0, kKindTiny = 1, kKindFused = 2 };
+enum { kKindArena = 0, kKindTiny = 1, kKindFused = 2, kKindFusedWide = 3 };   // (kKindFusedWide: a record's kind only -- a fused problem that KEEPS more than kFuseLanes reads, k_prob_range)
 __device__ __forceinline__ int prob_kind(int n, int n_lanes, ProbSplit sp) {
     if (n <= sp.tiny_max) return kKindTiny;
     return (n_lanes <= sp.fuse_lanes && n <= kNMax) ? kKindFused : kKindArena;
@@ -1352,15 +1413,15 @@ __device__ __forceinline__ void prob_block_maxima(Status *st, const int *cand_pn
     for (int d = 32; d >= 1; d >>= 1) { mx = max(mx, __shfl_xor(mx, d)); ml = max(ml, __shfl_xor(ml, d)); }
     if (lane_id() == 0) { l_mx[threadIdx.x >> 6] = mx; l_mx[4 + (threadIdx.x >> 6)] = ml; }
 }
-// solve-list problems of the block that see more than 255 reads, per size class (they need the 16-bit-counter instances of
-// k_solve: the host launches those only for classes that have any)
-__device__ __forceinline__ void prob_block_wide(Status *st, const int *cand_pn, const int *cand_ln, i64 b, i64 n, ProbSplit sp) {
+// solve-list problems of the block that keep more than 255 reads (k_prob_range), per size class (they need the 16-bit-counter
+// instances of k_solve: the host launches those only for classes that have any)
+__device__ __forceinline__ void prob_block_wide(Status *st, const int *cand_pn, const int *cand_ln, const unsigned char *cand_wide, i64 b, i64 n, ProbSplit sp) {
     unsigned w = 0;                                            // one count per byte: class 0 | class 1 << 8 | class 2 << 16
     for (int e = 0; e < 4; ++e) {
         const i64 cc = b * kProbBlock + (i64)threadIdx.x * 4 + e;
         if (cc < n) {
             const int pn = cand_pn[cc], ln = pn > 0 ? cand_ln[cc] : 0;
-            if (pn > 0 && ln > 255 && prob_kind(pn, ln, sp) == kKindFused) w += 1u << (8 * size_class(pn));
+            if (pn > 0 && cand_wide[cc] && prob_kind(pn, ln, sp) == kKindFused) w += 1u << (8 * size_class(pn));
         }
     }
     if (__ballot(w != 0) == 0) return;
@@ -1377,7 +1438,7 @@ __device__ __forceinline__ void prob_publish_maxima(Status *st, const int *l_mx)
     if (mx > 0 && (unsigned)mx > __hip_atomic_load(&st->max_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&st->max_n, (unsigned)mx);
     if (ml > 0 && (unsigned)ml > __hip_atomic_load(&st->max_ln, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&st->max_ln, (unsigned)ml);
 }
-__global__ void __launch_bounds__(256) k_prob_scan1(Status *st, const int *cand_pn, const int *cand_ln, i64 *bs, ProbSplit sp) {
+__global__ void __launch_bounds__(256) k_prob_scan1(Status *st, const int *cand_pn, const int *cand_ln, const unsigned char *cand_wide, i64 *bs, ProbSplit sp) {
     __shared__ i64 lds[4 * kProbCols];
     __shared__ int l_mx[8];
     i64 n = (i64)st->n_cand;
@@ -1385,7 +1446,7 @@ __global__ void __launch_bounds__(256) k_prob_scan1(Status *st, const int *cand_
     for (i64 b = blockIdx.x; b < nb; b += gridDim.x) {
         ProbSizes acc = prob_block_sizes(cand_pn, cand_ln, b, n, nullptr, sp), ex, tot;
         prob_block_maxima(st, cand_pn, cand_ln, b, n, l_mx);
-        prob_block_wide(st, cand_pn, cand_ln, b, n, sp);
+        prob_block_wide(st, cand_pn, cand_ln, cand_wide, b, n, sp);
         wg_scan_cols(acc, ex, tot, lds);
         if (threadIdx.x < kProbCols) bs[b * kProbCols + threadIdx.x] = tot.v[threadIdx.x];
         if (threadIdx.x == 0) prob_publish_maxima(st, l_mx);
@@ -1419,7 +1480,7 @@ __global__ void __launch_bounds__(256) k_prob_emit(Status *st, const int *cand_p
                                                    ProblemArrays pr, i64 prob_cap, int2 *work_pc, int4 *cls_items,
                                                    i64 work_cap, int *dp_items, ProbDesc *desc, const int *iv_start,
                                                    const int *iv_part, const i64 *part_lane_off, ProbSplit sp, int *solve_items,
-                                                   ProbDesc *solve_desc, int *wide_items, int *wide_all) {
+                                                   ProbDesc *solve_desc, int *wide_items, int *wide_all, const unsigned char *cand_wide) {
     __shared__ i64 lds[4 * kProbCols];
     __shared__ int l_slot[kProbBlock], l_cnt[kProbBlock];
     __shared__ int l_mx[8];
@@ -1462,7 +1523,7 @@ __global__ void __launch_bounds__(256) k_prob_emit(Status *st, const int *cand_p
         }
         ProbSizes acc = prob_block_sizes(cand_pn, cand_ln, b, n, sz, sp);
         if (!bs) prob_block_maxima(st, cand_pn, cand_ln, b, n, l_mx);   // (with block sums, k_prob_scan1 has done it; read after the barriers below)
-        if (!bs) prob_block_wide(st, cand_pn, cand_ln, b, n, sp);
+        if (!bs) prob_block_wide(st, cand_pn, cand_ln, cand_wide, b, n, sp);
         wg_scan_cols(acc, ex, tot, lds);
         if (!bs && threadIdx.x == 0) prob_publish_maxima(st, l_mx);
         for (int q = 0; q < kProbCols; ++q) ex.v[q] += before.v[q];
@@ -1510,9 +1571,10 @@ __global__ void __launch_bounds__(256) k_prob_emit(Status *st, const int *cand_p
                     d.n = nn; d.lane_lo = ll4[e]; d.lane_n = ln4[e]; d.g0 = is4[e];
                     d.outside = lanes4[e] - d.lane_n;
                     d.iv = k; d.w0 = (int)(col_lo(ex.v[4]) + col_hi(ex.v[4]) + col_lo(ex.v[5]) + col_lo(ex.v[6]));
-                    d.kind = prob_kind(nn, ln4[e], sp);
+                    const int kind = prob_kind(nn, ln4[e], sp);
+                    const bool keeps_wide = kind == kKindFused && cand_wide[c] != 0;
+                    d.kind = keeps_wide ? kKindFusedWide : kind;
                     desc[slot] = d;
-                    const int kind = d.kind;
                     if (le4[e] >= 0) {          // solve lists: class 0, then class 1, then class 2, then k_tiny's problems
                         const int li = le4[e] >> 1;
                         const i64 lbase = li == 0 ? 0 : (li == 1 ? g_sol0 : (li == 2 ? g_sol0 + g_sol1 : g_sol0 + g_sol1 + g_sol2));
@@ -1523,11 +1585,11 @@ __global__ void __launch_bounds__(256) k_prob_emit(Status *st, const int *cand_p
                         // chain of dependent loads); w0, the arena path's work item, is the problem's slot there
                         if (si >= lbase && si < lbase + llen && si < prob_cap) {
                             solve_items[si] = (int)slot; d.w0 = (int)slot; solve_desc[si] = d;
-                            // the problems of a solve list that see more than kFuseLanes reads, as list positions: what the
+                            // the problems of a solve list that keep more than kFuseLanes reads, as list positions: what the
                             // 16-bit-counter instances are launched over (a class has a handful; as launches over the whole
                             // list their 90 KB workgroups waited for room behind everything else: config3, one such problem
                             // started 127 us into the stage)
-                            if (li < 3 && d.lane_n > kFuseLanes) {
+                            if (li < 3 && keeps_wide) {
                                 const i64 wp = lbase + (i64)atomicAdd(&st->wide_cur[li], 1u);
                                 if (wp < lbase + llen && wp < prob_cap) wide_items[wp] = (int)(si - lbase);
                                 // ... and of the three lists together, as positions from the first list's start: a batch with a
@@ -2928,8 +2990,8 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
                                                                   const ProbDesc *desc, i64 prob_cap, const int *cand_y,
                                                                   const longlong2 *lane_ex, const int *ex_ts, const int *ex_te,
                                                                   const double *h_table, int h_len, double tau, const int2 *thr_tab,
-                                                                  int support, unsigned char *chosen, int wide_by_seen,
-                                                                  unsigned char *dpx, i64 dpx_stride, int *nact_g,
+                                                                  int support, unsigned char *chosen,
+                                                                  unsigned char *dpx, i64 dpx_stride,
                                                                   const int *__restrict__ wide_items FSEG_TPARAM) {
     using C = SolveCfg<NM>;
     constexpr int T = C::kThreads, NR = C::kRanges;
@@ -2982,12 +3044,9 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
         unsigned char *slot = SPLIT ? dpx + t * dpx_stride : nullptr;           // (dpx: the class's first slot)
         if (n > nm || n > NM) { if (threadIdx.x == 0) atomicOr(&st->err, kErrOverflowNm); continue; }
         // a list's problems are shared by two launches: the 8-bit counters take those that KEEP at most 255 reads (a counter
-        // counts reads with coverage in the window: about two thirds of those the problem sees), the 16-bit ones the rest.
-        // A problem that sees at most 255 is the 8-bit instance's outright; one that sees more is located by both, and
-        // whoever's counters fit its kept reads goes on with it (below).
-        const bool wide_cand = d.lane_n > kFuseLanes;
-        if (!wide_cand && sizeof(CntT) != 1) continue;
-        if (wide_by_seen && wide_cand && sizeof(CntT) == 1) continue;      // (FSEG_WIDE_BY_SEEN=1, tests: every problem that SEES more than 255 reads to the 16-bit instance)
+        // counts reads with coverage in the window: about two thirds of those the problem sees), the 16-bit ones the rest --
+        // k_prob_range has counted, the record says whose the problem is.
+        if ((d.kind == kKindFusedWide) != (sizeof(CntT) != 1)) continue;
         if (d.lane_n > kFuseLanesWide) { if (threadIdx.x == 0) atomicOr(&st->err, kErrNeedWideDp); continue; }
         const int npairs = n * (n - 1) / 2, ntri = n * (n - 1) * (n - 2) / 6;
         const int *cy = cand_y + d.c0;
@@ -3032,24 +3091,12 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
             const bool in = l < d.lane_n;
 #ifdef FSEG_ABLATE_COV
             const longlong2 ex = make_longlong2(0, 0);               // diagnostic (wrong results): no exon access at all, two lanes in three kept
-            const int n_ex = 0;
             int first_rel = 0, cnt = (l % 3) != 2;
 #else
             const longlong2 ex = lane_ex[d.lane_lo + (in ? l : 0)];
-            const int n_ex = (int)(ex.y - ex.x);                     // (a read's exons: 32-bit counts from here on)
-            int first_rel = 0, cnt = 0;
+            int first_rel, cnt;
+            window_exons(ex_ts, ex_te, ex, cp0, c_last, &first_rel, &cnt);
 #endif
-            for (int eb = 0; eb < n_ex; eb += 8) {                   // eight exons per round from clamped addresses, in flight together
-                int ts8[8], te8[8];
-                load_exons8(ex_ts + ex.x + eb, ts8); load_exons8(ex_te + ex.x + eb, te8);
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const bool hit = eb + u < n_ex && te8[u] >= cp0 && ts8[u] < c_last;
-                    if (hit && cnt == 0) first_rel = eb + u;
-                    cnt += hit;
-                }
-                if (eb + 7 < n_ex && ts8[7] >= c_last) break;        // the rest of the read lies beyond the window
-            }
             const i64 first = ex.x + first_rel;
             const bool act = in && cnt > 0;
             const u64 m = __ballot(act);
@@ -3065,8 +3112,8 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
             n_act += tot;
             __syncthreads();
         }
-        if (SPLIT && wide_cand && threadIdx.x == 0) nact_g[p] = n_act;                               // (k_dpw decides as this kernel does; both instances count the same)
-        if (wide_cand && !wide_by_seen && (sizeof(CntT) == 1) != (n_act <= kFuseLanes)) continue;      // (workgroup-uniform)
+        // (k_prob_range has counted the same reads by the same test: an 8-bit instance never meets more than its counters hold)
+        if (sizeof(CntT) == 1 && n_act > kFuseLanes) { if (threadIdx.x == 0) atomicOr(&st->err, kErrWideMissed); continue; }      // (workgroup-uniform)
         FSEG_STICK(1);
         // this thread's share of a round's coverage: read r_lane, candidates [ja, jb) of 1 .. n-1 (at most kCovJ of them)
         constexpr int kCovJ = (NM - 1 + NR - 1) / NR;
@@ -3286,7 +3333,7 @@ inline size_t dpw_lds_for(int nm, int key_bytes, int cnt_bytes) {
 }
 template <int NM, typename OutT, typename V>
 __global__ void __launch_bounds__(64) k_dpw(Status *st, int nm, i64 list_base, i64 list_n, ProblemArrays pr, const ProbDesc *desc,
-                                            const unsigned char *dpx, i64 dpx_stride, const int *__restrict__ nact_g, int wide_by_seen,
+                                            const unsigned char *dpx, i64 dpx_stride,
                                             int support, unsigned char *chosen, const int *__restrict__ wide_items FSEG_TPARAM) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = lane_id();
@@ -3299,10 +3346,7 @@ __global__ void __launch_bounds__(64) k_dpw(Status *st, int nm, i64 list_base, i
     const ProbDesc d = FSEG_LOAD_DESC(desc + list_base + t);
     const int n = d.n;
     if (n > nm || n > NM || n < 3 || d.lane_n > kFuseLanesWide) return;         // (k_solve has raised the error)
-    {   // whose problem: the 8-bit instance's if it keeps at most kFuseLanes reads (FSEG_WIDE_BY_SEEN: if it sees at most that many)
-        const bool wide = wide_by_seen ? d.lane_n > kFuseLanes : (d.lane_n > kFuseLanes && nact_g[d.w0] > kFuseLanes);
-        if (wide != (sizeof(OutT) != 1)) return;
-    }
+    if ((d.kind == kKindFusedWide) != (sizeof(OutT) != 1)) return;               // whose problem (k_prob_range)
     const int npairs = n * (n - 1) / 2, ntri = n * (n - 1) * (n - 2) / 6;
     const int rt_pairs = nm * (nm - 1) / 2;
     V *M = reinterpret_cast<V *>(smem);
@@ -4347,7 +4391,7 @@ struct fseg_ctx {
     DevBuf d_cand_off, d_cand_y, d_fixed0, d_added, d_fixed, d_chosen, d_final_off, d_final_y, d_final_pos, d_final_iv, d_col_thr,
         d_col_zero;
     DevBuf d_tile_defer;        // per smoothing tile: start of the plateau that reaches the tile's end (-1: none)
-    DevBuf d_blk_pre, d_tile_tot, d_seg_iv, d_seg_prev, d_rseg_c, d_cand_pn, d_cand_ll, d_cand_ln, d_prob_bs;
+    DevBuf d_blk_pre, d_tile_tot, d_seg_iv, d_seg_prev, d_rseg_c, d_cand_pn, d_cand_ll, d_cand_ln, d_cand_wide, d_prob_bs;
     // problems / arenas (slab_arena)
     DevBuf d_prob_iv, d_prob_start, d_prob_n, d_prob_pair_off, d_prob_tri_off, d_prob_flags, d_prob_chain,
         d_prob_cov_off, d_prob_lane_lo, d_prob_lane_n;
@@ -4356,7 +4400,7 @@ struct fseg_ctx {
     // alloc_arenas() for the counts it knew: a launch takes the split path only for a list that fits what was laid out
     DevBuf d_wide_items;         // per solve list: the list positions of the problems that see more than kFuseLanes reads (k_prob_emit)
     DevBuf d_wide_all;           // ... of the three lists together (positions from the first list's start)
-    DevBuf d_dpx, d_prob_nact;   // (d_prob_nact: the reads a wide solve-list problem keeps: k_solve<.., SPLIT> tells k_dpw whose counters it used)
+    DevBuf d_dpx;
     i64 dpx_base[3] = {0, 0, 0}, dpx_stride[3] = {0, 0, 0}, dpx_n[3] = {0, 0, 0};
     int dpx_nm = 0, dpx_cnt[3] = {1, 1, 1};
     bool split_always = false;  // FSEG_SPLIT_ALWAYS=1 (tests): the split path also where a context keeps to one stream
@@ -4414,7 +4458,7 @@ struct fseg_ctx {
     bool use_tiny = true;       // FSEG_NO_TINY=1: no problem goes to k_tiny
     bool force_key64 = false;
     bool wide_by_seen = false;  // FSEG_WIDE_BY_SEEN=1 (tests)
-    char score_plan[32] = "gM|hB|gTS|W";   // FSEG_SCORE_PLAN (see enqueue_run; anything that does not name each class once = one stream)
+    char score_plan[32] = "gM|W|hB|gTS";   // FSEG_SCORE_PLAN (see enqueue_run; anything that does not name each class once = one stream)
     bool use_wave = true;       // FSEG_NO_WAVE=1: k_tiny / k_solve<16> instead of the wave kernels (k_wave)
     bool use_fuse = true;       // FSEG_NO_FUSE=1: no problem goes to k_solve (everything that is not tiny takes the arena path)
     // Reads the widest problem of a batch may see for the batch's problems to be solved whole (k_solve / k_wave) instead of going
@@ -4552,7 +4596,6 @@ int alloc_arenas(fseg_ctx *c) {
     cv.add(c->d_prob_tri_off, (size_t)c->prob_cap * 8);
     cv.add(c->d_prob_flags, (size_t)c->prob_cap * 4);
     cv.add(c->d_prob_chain, (size_t)c->prob_cap * 4);
-    cv.add(c->d_prob_nact, (size_t)c->prob_cap * 4);
     cv.add(c->d_dp_items, (size_t)c->prob_cap * 4);
     cv.add(c->d_solve_items, (size_t)c->prob_cap * 4);
     cv.add(c->d_wide_items, (size_t)c->prob_cap * 4);
@@ -4740,9 +4783,10 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
     hipLaunchKernelGGL(k_prob_range, dim3(grid_for(NPOS / 64 + 1, 256, 1024)), dim3(256), 0, s, st, c->d_cand_pn.as<int>(),
                        c->d_seg_iv.as<int>(), c->d_cand_y.as<int>(), c->d_iv_part.as<int>(), c->d_iv_start.as<int>(),
                        c->d_part_lane_off.as<i64>(), c->d_lane_start.as<int>(), c->d_lane_pmax.as<int>(),
-                       c->d_cand_ll.as<int>(), c->d_cand_ln.as<int>());
+                       c->d_cand_ll.as<int>(), c->d_cand_ln.as<int>(), c->d_cand_wide.as<unsigned char>(), c->d_lane_ex.as<longlong2>(),
+                       c->d_ex_ts.as<int>(), c->d_ex_te.as<int>(), c->wide_by_seen ? 1 : 0);
     if (prob_bs) {
-        hipLaunchKernelGGL(k_prob_scan1, dim3(pg), dim3(256), 0, s, st, c->d_cand_pn.as<int>(), c->d_cand_ln.as<int>(), prob_bs, split);
+        hipLaunchKernelGGL(k_prob_scan1, dim3(pg), dim3(256), 0, s, st, c->d_cand_pn.as<int>(), c->d_cand_ln.as<int>(), c->d_cand_wide.as<unsigned char>(), prob_bs, split);
         hipLaunchKernelGGL(k_prob_scan2, dim3(1), dim3(256), 0, s, st, prob_bs);
     }
     end(ST_FIX);
@@ -4754,7 +4798,7 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
                        pr, c->prob_cap, c->d_work_pc.as<int2>(), c->d_cls_items.as<int4>(),
                        c->work_cap, c->d_dp_items.as<int>(), c->d_prob_desc.as<ProbDesc>(), c->d_iv_start.as<int>(),
                        c->d_iv_part.as<int>(), c->d_part_lane_off.as<i64>(), split, c->d_solve_items.as<int>(), c->d_solve_desc.as<ProbDesc>(),
-                       c->d_wide_items.as<int>(), c->d_wide_all.as<int>());
+                       c->d_wide_items.as<int>(), c->d_wide_all.as<int>(), c->d_cand_wide.as<unsigned char>());
     // S5
     if (c->prob_cap > 0 && any_arena) {
         const int cov_blocks = work_grid < 2048 ? work_grid : 2048;
@@ -4777,7 +4821,7 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
     }   // do_pre2
     if (do_score) begin(ST_SCORE);
     if (do_score && c->prob_cap > 0) {
-        // How the scoring kernels share the chip is a plan (FSEG_SCORE_PLAN, default "gM|hB|msgTS|b"): streams separated by '|'
+        // How the scoring kernels share the chip is a plan (FSEG_SCORE_PLAN, default "gM|W|hB|gTS"): streams separated by '|'
         // (the first is the main stream; the segments that have something to launch take the side streams in order); B M S T =
         // the large / mid / small / tiny class -- a class on the split path is k_solve (rounds) followed by k_dpw (its DPs) --,
         // b m s = the classes' 16-bit-counter instances (launched over their classes' wide problems), g = k_gate (wait until the
@@ -4827,8 +4871,7 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
                                (wide_n(CLS, sizeof(CNT)) >= 0 ? wide_n(CLS, sizeof(CNT)) : list_ln(CLS)), pr, c->d_solve_desc.as<ProbDesc>(), \
                                c->prob_cap, c->d_cand_y.as<int>(), c->d_lane_ex.as<longlong2>(), c->d_ex_ts.as<int>(),         \
                                c->d_ex_te.as<int>(), c->d_h_table.as<double>(), c->P.h_len, c->P.threshold_rate,               \
-                               c->d_thr_tab.as<int2>(), c->P.min_read_support_outside, c->d_chosen.as<unsigned char>(),       \
-                               (c->wide_by_seen ? 1 : 0)
+                               c->d_thr_tab.as<int2>(), c->P.min_read_support_outside, c->d_chosen.as<unsigned char>()
         // the split path (k_solve<.., SPLIT> then k_dpw on the same stream) for a list that fits the hand-over arena as laid out --
         // when this context has the device to itself (`forking`): with other contexts' batches in flight a context keeps to one
         // stream, where the extra launches cost more than the early release of LDS gains (the 2 M-read job, eight contexts:
@@ -4840,7 +4883,7 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
 #define FSEG_LAUNCH_SOLVE(Q, NMV, CNT, VT, CLS, N_ITEMS, MAXWG)                                                              \
             hipLaunchKernelGGL((k_solve<NMV, CNT, VT, false>), dim3(grid_for(FSEG_SOLVE_N(CNT, CLS, N_ITEMS), 1, known ? (1 << 20) : (MAXWG))), dim3(SolveCfg<NMV>::kThreads), \
                                solve_lds_for((NMV) == kNMax ? c->nm_big : (NMV), (NMV) + 1, (int)sizeof(CNT)), Q,               \
-                               FSEG_SOLVE_ARGS(NMV, CNT, CLS), (unsigned char *)nullptr, (i64)0, (int *)nullptr, FSEG_SOLVE_WIDE(CNT, CLS) FSEG_TARG)
+                               FSEG_SOLVE_ARGS(NMV, CNT, CLS), (unsigned char *)nullptr, (i64)0, FSEG_SOLVE_WIDE(CNT, CLS) FSEG_TARG)
         // every list's problems that see more than kFuseLanes reads, through wide_all: the large class's 16-bit instance, a workgroup each
 #define FSEG_LAUNCH_WIDE_ALL(Q, VT)                                                                                          \
             hipLaunchKernelGGL((k_solve<kNMax, unsigned short, VT, false>), dim3((unsigned)n_wide_all), dim3(SolveCfg<kNMax>::kThreads), \
@@ -4848,7 +4891,7 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
                                c->prob_cap, c->d_cand_y.as<int>(), c->d_lane_ex.as<longlong2>(), c->d_ex_ts.as<int>(),         \
                                c->d_ex_te.as<int>(), c->d_h_table.as<double>(), c->P.h_len, c->P.threshold_rate,               \
                                c->d_thr_tab.as<int2>(), c->P.min_read_support_outside, c->d_chosen.as<unsigned char>(),       \
-                               (c->wide_by_seen ? 1 : 0), (unsigned char *)nullptr, (i64)0, (int *)nullptr, c->d_wide_all.as<int>() FSEG_TARG)
+                               (unsigned char *)nullptr, (i64)0, c->d_wide_all.as<int>() FSEG_TARG)
         // the split path, one instance: k_solve<.., SPLIT> (set-up and rounds) then k_dpw (the DPs) on the same stream
 #define FSEG_LAUNCH_SPLIT(Q, NMV, CNT, VT, CLS, N_ITEMS)                                                                     \
         do { const int nm_rt = (NMV) == kNMax ? c->nm_big : (NMV);                                                            \
@@ -4856,11 +4899,11 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
             const i64 dstride = c->dpx_stride[(CLS) < 0 ? 0 : (CLS)];                                                                       \
             hipLaunchKernelGGL((k_solve<NMV, CNT, int, true>), dim3(grid_for(FSEG_SOLVE_N(CNT, CLS, N_ITEMS), 1, 1 << 20)), dim3(SolveCfg<NMV>::kThreads), \
                                solve_lds_for(nm_rt, (NMV) + 1, (int)sizeof(CNT)), Q, FSEG_SOLVE_ARGS(NMV, CNT, CLS), dpx0, dstride, \
-                               c->d_prob_nact.as<int>(), FSEG_SOLVE_WIDE(CNT, CLS) FSEG_TARG);                                    \
+                               FSEG_SOLVE_WIDE(CNT, CLS) FSEG_TARG);                                    \
             hipLaunchKernelGGL((k_dpw<NMV, CNT, VT>), dim3(grid_for(FSEG_SOLVE_N(CNT, CLS, N_ITEMS), 1, 1 << 20)), dim3(64),      \
                                dpw_lds_for(nm_rt, (int)sizeof(VT), (int)sizeof(CNT)), Q, st, nm_rt, list_lb(CLS),                \
                                FSEG_SOLVE_N(CNT, CLS, list_ln(CLS)), pr,                                                        \
-                               c->d_solve_desc.as<ProbDesc>(), dpx0, dstride, c->d_prob_nact.as<int>(), (c->wide_by_seen ? 1 : 0), \
+                               c->d_solve_desc.as<ProbDesc>(), dpx0, dstride, \
                                c->P.min_read_support_outside, c->d_chosen.as<unsigned char>(), FSEG_SOLVE_WIDE(CNT, CLS) FSEG_TARG); } while (0)
         // 32-bit DP keys (dp_solve_push) when no sum of a chain can reach 2^24: at most 32 links times the reads of the largest partition
         // (WHICH: 1 = the instance with 8-bit counters, 2 = the one with 16-bit counters if the class has problems for it, 3 = both)
@@ -5153,6 +5196,7 @@ int check_prep(fseg_ctx *c) {
 int run_input_errors(fseg_ctx *c, const Status &s) {
     if (s.err & kErrExonInterval) return fail(c, FSEG_ERR_INPUT, "an exon does not lie inside one tint interval (py/freddie_segment.py:668)");
     if (s.err & kErrBreakAssert) return fail(c, FSEG_ERR_INPUT, "break_large_problems: candidate window out of range or no positive signal (py/freddie_segment.py:640-643)");
+    if (s.err & kErrWideMissed) return fail(c, FSEG_ERR_HIP, "internal: a problem keeps more reads than were counted for it (kErrWideMissed)");
     if (s.err & kErrProblemTooLarge) return fail(c, FSEG_ERR_UNSUPPORTED, "a DP problem has more than %d candidates (max_problem_size too large for this build)", kNHuge);
     return FSEG_OK;
 }
@@ -5289,7 +5333,7 @@ int run_sized(fseg_ctx *c) {
                 Status *st = c->d_status.as<Status>();
                 // (the scan ADDS to the per-class counts of wide problems: the first scan's must not stay in them)
                 HIP_TRY(c, hipMemsetAsync(reinterpret_cast<char *>(st) + offsetof(Status, wide_cls), 0, sizeof(st->wide_cls), c->stream));
-                hipLaunchKernelGGL(k_prob_scan1, dim3(pg), dim3(256), 0, c->stream, st, c->d_cand_pn.as<int>(), c->d_cand_ln.as<int>(),
+                hipLaunchKernelGGL(k_prob_scan1, dim3(pg), dim3(256), 0, c->stream, st, c->d_cand_pn.as<int>(), c->d_cand_ln.as<int>(), c->d_cand_wide.as<unsigned char>(),
                                    c->d_prob_bs.as<i64>(), split_of(c, tiny, fuse));
                 hipLaunchKernelGGL(k_prob_scan2, dim3(1), dim3(256), 0, c->stream, st, c->d_prob_bs.as<i64>());
                 HIP_TRY(c, hipMemcpyAsync(c->h_status, st, sizeof(Status), hipMemcpyDeviceToHost, c->stream));
@@ -5779,7 +5823,7 @@ static int upload_impl(fseg_ctx *c, const fseg_batch *b) {
         cv.add(c->d_fixed, np8); cv.add(c->d_chosen, np8);
         cv.add(c->d_final_y, np8 * 4); cv.add(c->d_final_pos, np8 * 4); cv.add(c->d_final_iv, np8 * 4); cv.add(c->d_col_thr, np8 * 8); cv.add(c->d_col_zero, np8);
         cv.add(c->d_seg_iv, np8 * 4); cv.add(c->d_seg_prev, np8 * 4); cv.add(c->d_rseg_c, np8 * 4);
-        cv.add(c->d_cand_pn, np8 * 4); cv.add(c->d_cand_ll, np8 * 4); cv.add(c->d_cand_ln, np8 * 4);
+        cv.add(c->d_cand_pn, np8 * 4); cv.add(c->d_cand_ll, np8 * 4); cv.add(c->d_cand_ln, np8 * 4); cv.add(c->d_cand_wide, np8);
         cv.add(c->d_prob_bs, ((size_t)NPOS / kProbBlock + 2) * kProbCols * 8);
         TRY(reserve(c, c->slab_pos, cv.total));
         cv.bind(c->slab_pos);
