@@ -4458,7 +4458,7 @@ struct fseg_ctx {
     bool use_tiny = true;       // FSEG_NO_TINY=1: no problem goes to k_tiny
     bool force_key64 = false;
     bool wide_by_seen = false;  // FSEG_WIDE_BY_SEEN=1 (tests)
-    char score_plan[32] = "gM|W|hB|gTS";   // FSEG_SCORE_PLAN (see enqueue_run; anything that does not name each class once = one stream)
+    char score_plan[32] = "gM|W|hB|gST";   // FSEG_SCORE_PLAN (see enqueue_run; anything that does not name each class once = one stream)
     bool use_wave = true;       // FSEG_NO_WAVE=1: k_tiny / k_solve<16> instead of the wave kernels (k_wave)
     bool use_fuse = true;       // FSEG_NO_FUSE=1: no problem goes to k_solve (everything that is not tiny takes the arena path)
     // Reads the widest problem of a batch may see for the batch's problems to be solved whole (k_solve / k_wave) instead of going
@@ -4821,7 +4821,7 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
     }   // do_pre2
     if (do_score) begin(ST_SCORE);
     if (do_score && c->prob_cap > 0) {
-        // How the scoring kernels share the chip is a plan (FSEG_SCORE_PLAN, default "gM|W|hB|gTS"): streams separated by '|'
+        // How the scoring kernels share the chip is a plan (FSEG_SCORE_PLAN, default "gM|W|hB|gST"): streams separated by '|'
         // (the first is the main stream; the segments that have something to launch take the side streams in order); B M S T =
         // the large / mid / small / tiny class -- a class on the split path is k_solve (rounds) followed by k_dpw (its DPs) --,
         // b m s = the classes' 16-bit-counter instances (launched over their classes' wide problems), g = k_gate (wait until the
