@@ -126,12 +126,14 @@ def load():
 class Context:
     """One GPU context (one per device; not shared between threads)."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, handle=None):
+        """``handle``: a context fseg_create() has already made for this device (freddie_amd/_early.py)."""
         self._L = load()
-        h = ctypes.c_void_p()
-        rc = self._L.fseg_create(int(device), ctypes.byref(h))
-        if rc != 0:
-            raise SegError("fseg_create(device=%d) failed: %s" % (device, self._L.fseg_last_error(None).decode()))
+        h = handle if handle is not None else ctypes.c_void_p()
+        if handle is None:
+            rc = self._L.fseg_create(int(device), ctypes.byref(h))
+            if rc != 0:
+                raise SegError("fseg_create(device=%d) failed: %s" % (device, self._L.fseg_last_error(None).decode()))
         self._h = h
         self._keep = []
         self.n_part = 0

@@ -502,7 +502,7 @@ def run_batches(batches, params, ctxs, threads, on_done, sidecar="off"):
 
         def prefetch():
             nonlocal nxt
-            while nxt < len(batches) and len(loads) < 2:
+            while nxt < len(batches) and len(loads) < 3:        # (two being parsed, one waiting: the first ones while the contexts come up)
                 loads.append(load_pool.submit(load, batches[nxt]))
                 nxt += 1
 
@@ -612,15 +612,21 @@ WORKER_START_METHOD = "spawn"
 
 def open_contexts(device, n=2):
     """The contexts one GPU worker drives: two per device, so that copies and kernels of consecutive batches overlap."""
-    from . import _lib
+    from . import _early, _lib
+    early = _early.take(device)              # what the drop-in script started before the imports, if it did
     ctxs = []
     try:
-        for _ in range(n):
+        while early and len(ctxs) < n:
+            ctxs.append(_lib.Context(device, handle=early[0]))      # (a stale library is refused here: _lib.load())
+            early.pop(0)
+        while len(ctxs) < n:
             ctxs.append(_lib.Context(device))
     except BaseException:
         for c in ctxs:
             c.close()
+        _early.discard(early)
         raise
+    _early.discard(early)
     return ctxs
 
 

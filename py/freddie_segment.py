@@ -26,8 +26,28 @@ def _preload():
             pass            # the loaders in freddie_amd report a missing / stale library with a proper message
 
 
+def _one_device():
+    """The device this process will drive itself, or None: --gpus 1 / --devices K on the command line (anything else is
+    decided by main(), which may have to start worker processes and must then not have touched the HIP runtime)."""
+    a = sys.argv
+    for i, x in enumerate(a):
+        if x == "--devices" and i + 1 < len(a) and a[i + 1].isdigit():
+            return int(a[i + 1])
+        if x.startswith("--devices=") and x[10:].isdigit():
+            return int(x[10:])
+    if any((x == "--gpus" and a[i + 1:i + 2] == ["1"]) or x == "--gpus=1" for i, x in enumerate(a)) and not any(
+            x == "--devices" or x.startswith("--devices=") for x in a):
+        return 0
+    return None
+
+
 if __name__ == "__main__":
     threading.Thread(target=_preload, daemon=True).start()
+    _dev = _one_device()
+    if _dev is not None:
+        # the GPU's contexts come up (0.3 s) beside the imports, the directory scan and the first parse
+        from freddie_amd import _early
+        _early.start(_dev)
 
 from freddie_amd.segment import main  # noqa: E402
 
