@@ -22,6 +22,13 @@ python profiles/trace_medians.py $O/trace2/p_kernel_trace.csv > $O/config2_kerne
 #     kernel's end, and from the end of the kernel before it to the start of the kernel after it (= the event bracket of `roofline`)
 rocprofv3 --kernel-trace --output-format csv -d $O/trace3 -o p -- python3 tools/replay_probe.py --workload config4 > $O/replay_config4_plan.txt 2> $O/trace3.err
 python tools/stage_span.py $O/trace3/p_kernel_trace.csv > $O/config4_stage_span.txt; grep replay $O/replay_config4_plan.txt | cut -c1-120 >> $O/config4_stage_span.txt; cat $O/config4_stage_span.txt
+# 2c. how a resident batch is replayed: plain launches on the forked streams (default), the same as one hipGraph with cross-stream
+#     edges (FSEG_GRAPH_FORK=1), one stream as a hipGraph (FSEG_NO_FORK=1), one stream as plain launches -- ms per replay and the
+#     host's time inside fseg_run
+for e in "-" "FSEG_GRAPH_FORK=1" "FSEG_NO_FORK=1" "FSEG_NO_FORK=1 FSEG_NO_GRAPH=1"; do
+  if [ "$e" = "-" ]; then v=""; else v="$e"; fi
+  echo "== ${v:-default}"; env $v python tools/replay_probe.py --workload config4 --profiling 0 | grep "replay\|host time" | cut -c1-70
+done > $O/replay_modes.txt 2>&1; cat $O/replay_modes.txt
 # 3. counters, each in its own pass
 for w in config4 config2; do
   for pmc in FETCH_SIZE WRITE_SIZE; do
