@@ -48,8 +48,11 @@ for _ in range(args.reps):
         acc[k] = acc.get(k, 0.0) + v
 dt = (time.perf_counter() - t0) / args.reps * 1e3
 sc = acc.get("interval_scoring", 0.0) / args.reps or float("nan")
-print("replay: %.3f ms/step, %.1f M reads/s; scoring %.3f ms = %.0f GB/s credited (frac %.3f); sizes %s" % (
-    dt, b.n_reads / dt / 1e3, sc, alg / sc / 1e6, alg / sc / 1e6 / 8000.0, ctx.sizes()))
+if args.profiling:
+    print("replay: %.3f ms/step, %.1f M reads/s; scoring %.3f ms = %.0f GB/s credited (frac %.3f); sizes %s" % (
+        dt, b.n_reads / dt / 1e3, sc, alg / sc / 1e6, alg / sc / 1e6 / 8000.0, ctx.sizes()))
+else:
+    print("replay: %.3f ms/step, %.1f M reads/s (no stage events)" % (dt, b.n_reads / dt / 1e3))
 print("  " + " ".join("%s=%.3f" % (k, v / args.reps) for k, v in acc.items() if v > 0))
 print("  host time of fseg_run (enqueue only): %.3f ms" % (t_run / args.reps * 1e3))
 ctx.close()
