@@ -4964,7 +4964,16 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
                 // (the segments that have something to launch take the side streams in order: the first ones start first)
                 int side_of[4] = {-1, -1, -1, -1};
                 for (int k = 1, nx = 0; k < n_seg; ++k) if (used[k]) side_of[k] = nx++;
-                for (int k = 1; k < n_seg; ++k) if (used[k]) (void)fork(side_of[k]);     // every side stream continues from HERE
+                // every side stream continues from HERE (the stage's begin event, when it is being recorded, is the first side
+                // stream's fork: one marker packet less in front of everything -- each is ~5 us on its queue)
+                // (every side stream on that one event: 0.135 -> 0.137-0.149 ms -- the records stagger the streams' starts)
+                bool shared = !(stage_events && forking);
+                for (int k = 1; k < n_seg; ++k) if (used[k]) {
+                    if (!shared) {
+                        shared = true;
+                        if (hipError_t r = hipStreamWaitEvent(c->side[side_of[k]], c->ev_b[ST_SCORE], 0); r != hipSuccess) fj_err = r;
+                    } else (void)fork(side_of[k]);
+                }
                 int seg = 0;
                 hipEvent_t ev_big = nullptr;
                 // b m s: the class's instance with 16-bit counters on its own (B M S then launch the 8-bit one only)

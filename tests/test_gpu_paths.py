@@ -96,6 +96,29 @@ def test_diagnostic_switches_keep_parity(env, monkeypatch):
         ctx.close()
 
 
+@pytest.mark.parametrize("mode,env", [(1, {}), (2, {}), (3, {}), (1, {"FSEG_NO_FORK": "1"}), (2, {"FSEG_GRAPH_FORK": "1"})],
+                         ids=["all-stages", "scoring-only", "plain-replays", "one-stream-graphs", "forked-graphs"])
+def test_stage_events_keep_parity(mode, env, monkeypatch):
+    """fseg_set_profiling: events around the stages (the scoring stage's begin event doubles as its first fork) change no
+    result, and the stage times they give are there on the first run and on replays."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    parts, oracles = mixed_batch()
+    ctx = _lib.Context(0)
+    try:
+        ctx.set_profiling(mode)
+        check_twice(ctx, parts, oracles)
+        ms = ctx.stage_ms()
+        assert ms["interval_scoring"] > 0.0 and all(v >= 0.0 for v in ms.values())
+        ctx.run(); ctx.sync()                               # a second replay with the events in place
+        assert util.compare_partitions(ctx, parts, oracles)["y_identical"]
+        assert ctx.stage_ms()["interval_scoring"] > 0.0
+        ctx.set_profiling(0)
+        check_twice(ctx, parts, oracles)
+    finally:
+        ctx.close()
+
+
 def test_wide_count_dp_for_real():
     """One partition whose DP windows see more than 65 535 reads: the 16-bit count tables cannot hold out(i,j,k), the
     library must pick the 32-bit DP by itself."""
