@@ -52,6 +52,17 @@ def take(device):
     return hs
 
 
+def finish():
+    """End of the process that called start(): contexts nobody took over (main() stopped before its batches) are destroyed --
+    after the thread that makes them has ended, so the interpreter never exits with a thread inside the runtime's start-up."""
+    st = _state
+    if st is None:
+        return
+    st["thread"].join()
+    hs, st["handles"] = st["handles"], []
+    discard(hs, st["lib"])
+
+
 def discard(handles, lib=None):
     lib = lib or (_state or {}).get("lib")
     if lib is None:

@@ -52,4 +52,8 @@ if __name__ == "__main__":
 from freddie_amd.segment import main  # noqa: E402
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    finally:
+        if _dev is not None:
+            _early.finish()
