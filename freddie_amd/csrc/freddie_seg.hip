@@ -4791,6 +4791,7 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
     }
     end(ST_FIX);
     }   // do_pre1
+    bool score_begun = false;
     if (do_pre2) {
     begin(ST_SCORE_PREP);
     hipLaunchKernelGGL(k_prob_emit, dim3(pg), dim3(256), 0, s, st, c->d_cand_pn.as<int>(), c->d_cand_ll.as<int>(),
@@ -4799,8 +4800,11 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
                        c->work_cap, c->d_dp_items.as<int>(), c->d_prob_desc.as<ProbDesc>(), c->d_iv_start.as<int>(),
                        c->d_iv_part.as<int>(), c->d_part_lane_off.as<i64>(), split, c->d_solve_items.as<int>(), c->d_solve_desc.as<ProbDesc>(),
                        c->d_wide_items.as<int>(), c->d_wide_all.as<int>(), c->d_cand_wide.as<unsigned char>());
-    // S5
+    // S5.  The arena path's window coverage (and pair thresholds) are launches of their own in front of k_score: they are
+    // interval scoring (get_cumulative_coverage :188-246 -- the solve-list kernels do the same inside their workgroups), so
+    // where the stages are bracketed by events the scoring stage's bracket opens here
     if (c->prob_cap > 0 && any_arena) {
+        if (stage_events && do_score) { end(ST_SCORE_PREP); begin(ST_SCORE); score_begun = true; }
         const int cov_blocks = work_grid < 2048 ? work_grid : 2048;
         const int pt_blocks = c->small_batch ? grid_for(c->prob_cap, 1, 512) : 0;       // fused only for small batches
         if (!pt_blocks)
@@ -4817,9 +4821,9 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
                            cov_blocks, pr, c->d_h_table.as<double>(), c->P.h_len, c->P.threshold_rate, c->d_pair_thr.as<int2>(),
                            c->pair_cap, c->d_amb.as<unsigned>(), c->d_out.as<unsigned>(), c->tri_cap);
     }
-    end(ST_SCORE_PREP);
+    if (!score_begun) end(ST_SCORE_PREP);
     }   // do_pre2
-    if (do_score) begin(ST_SCORE);
+    if (do_score && !score_begun) begin(ST_SCORE);
     if (do_score && c->prob_cap > 0) {
         // How the scoring kernels share the chip is a plan (FSEG_SCORE_PLAN, default "gM|W|hB|gST"): streams separated by '|'
         // (the first is the main stream; the segments that have something to launch take the side streams in order); B M S T =
