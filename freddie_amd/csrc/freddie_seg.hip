@@ -5076,7 +5076,8 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
     const i64 labels_n16 = (c->label_cap + 15) / 16;            // the arena is allocated in multiples of 16 bytes
     // the label arena's '0' fill rides the big-problem DP launch as extra workgroups -- unless the run is being sized
     // (the arena's size is not known yet) or there is no DP launch
-    const bool ride_fill = !sized && c->prob_cap > 0 && c->label_cap > 0 && any_arena;
+    // (not where the stages are bracketed by events: the fill is the labels stage's work, and a DP bracket that holds it says nothing about the DP)
+    const bool ride_fill = !sized && c->prob_cap > 0 && c->label_cap > 0 && any_arena && !stage_events;
     if (do_post1) {
     begin(ST_DP);
     if (c->prob_cap > 0 && any_arena) {
