@@ -51,4 +51,6 @@ for t in 8 16 32; do python tools/e2e_bench.py --partitions 4000 --reads 500 --t
 python tools/host_ceiling.py --partitions 4000 --reads 500 --workers 1,2,4,8 --repeat 2 --keep /dev/shm/e2e_$T > $O/host_ceiling.txt 2>&1
 rm -rf /dev/shm/e2e_$T
 grep "e2e\[" $O/e2e.log; cat $O/host_ceiling.txt
+# the driver's command once more, now that profiles/traffic.json carries this library's hash: bench_default.json (again) holds roofline.traffic / valu_util
+python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err; python profiles/benchsum.py < $O/bench_default.json
 rm -rf $O/stats/*.csv.tmp
