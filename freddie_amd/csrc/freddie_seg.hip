@@ -1202,20 +1202,26 @@ __global__ void k_fix(i64 K, const i64 *pos_off, const int *iv_part, const i64 *
 // The exons of one read (ex = its range in the exon arrays) that meet the window [cp0, c_last): exons are ordered, so they
 // are consecutive -- `cnt` of them from the read's `first_rel`-th.  k_solve keeps the reads with cnt > 0 (its rounds run over
 // those only) and k_prob_range counts them ahead of it: the one definition of "keeps".
-__device__ __forceinline__ void window_exons(const int *__restrict__ ex_ts, const int *__restrict__ ex_te, longlong2 ex, int cp0, int c_last,
-                                             int *first_rel, int *cnt_out) {
-    const int n_ex = (int)(ex.y - ex.x);                     // (a read's exons: 32-bit counts from here on)
+__device__ __forceinline__ void window_exons(const int2 *__restrict__ lex, int2 lx, int cp0, int c_last, int *first_rel, int *cnt_out) {
+    // (the exons come from the lane-ordered (ts, te) stream: a read's exons are one contiguous piece of it and consecutive
+    // lanes' pieces follow each other, so the lanes of a wave walk neighbouring cache lines -- from the rep-ordered ex_ts / ex_te
+    // every lane's eight exons were two lines of their own, 128 line accesses per load instruction of a wave)
+    const int n_ex = lx.y - lx.x;
     int fr = 0, cnt = 0;
-    for (int eb = 0; eb < n_ex; eb += 8) {                   // eight exons per round from clamped addresses, in flight together
-        int ts8[8], te8[8];
-        load_exons8(ex_ts + ex.x + eb, ts8); load_exons8(ex_te + ex.x + eb, te8);
+    for (int eb = 0; eb < n_ex; eb += 8) {                   // eight exons per round (what lies beyond the read's own is masked; the stream is padded)
+        int4u x[4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const bool hit = eb + u < n_ex && te8[u] >= cp0 && ts8[u] < c_last;
-            if (hit && cnt == 0) fr = eb + u;
-            cnt += hit;
+        for (int u = 0; u < 4; ++u) x[u] = *reinterpret_cast<const int4u *>(lex + lx.x + eb + 2 * u);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool hit0 = eb + 2 * u < n_ex && x[u].y >= cp0 && x[u].x < c_last;
+            if (hit0 && cnt == 0) fr = eb + 2 * u;
+            cnt += hit0;
+            const bool hit1 = eb + 2 * u + 1 < n_ex && x[u].w >= cp0 && x[u].z < c_last;
+            if (hit1 && cnt == 0) fr = eb + 2 * u + 1;
+            cnt += hit1;
         }
-        if (eb + 7 < n_ex && ts8[7] >= c_last) break;        // the rest of the read lies beyond the window
+        if (eb + 7 < n_ex && x[3].z >= c_last) break;        // the rest of the read lies beyond the window
     }
     *first_rel = fr; *cnt_out = cnt;
 }
@@ -1232,7 +1238,7 @@ constexpr int kRangeThreads = 256;
 __global__ void __launch_bounds__(kRangeThreads) k_prob_range(const Status *st, const int *cand_pn, const int *cand_iv, const int *cand_y,
                              const int *iv_part, const int *iv_start, const i64 *part_lane_off, const int *lane_start,
                              const int *lane_pmax, int *cand_ll, int *cand_ln, unsigned char *cand_wide,
-                             const longlong2 *__restrict__ lane_ex, const int *__restrict__ ex_ts, const int *__restrict__ ex_te, int wide_by_seen) {
+                             const int2 *__restrict__ lane_lx, const int2 *__restrict__ lex, int wide_by_seen) {
     __shared__ int l_wide[kRangeThreads], l_n, l_red[kRangeThreads / 64];
     const i64 n_cand = (i64)st->n_cand;
     for (i64 c0 = (i64)blockIdx.x * blockDim.x; c0 < n_cand; c0 += (i64)gridDim.x * blockDim.x) {    // (workgroup-uniform)
@@ -1267,7 +1273,7 @@ __global__ void __launch_bounds__(kRangeThreads) k_prob_range(const Status *st, 
             int kept = 0;
             for (int l = threadIdx.x; l < ln; l += kRangeThreads) {
                 int first_rel, cnt;
-                window_exons(ex_ts, ex_te, lane_ex[ll + l], cp0, c_last, &first_rel, &cnt);
+                window_exons(lex, lane_lx[ll + l], cp0, c_last, &first_rel, &cnt);
                 kept += cnt > 0;
             }
             for (int d = 32; d >= 1; d >>= 1) kept += __shfl_xor(kept, d);
@@ -2988,7 +2994,7 @@ inline size_t solve_lds_for(int nm, int cov_stride, int cnt_bytes) {
 template <int NM, typename CntT, typename V, bool SPLIT>
 __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBlocks) k_solve(Status *st, int cls, int nm, i64 lb_h, i64 ln_h, ProblemArrays pr,
                                                                   const ProbDesc *desc, i64 prob_cap, const int *cand_y,
-                                                                  const longlong2 *lane_ex, const int *ex_ts, const int *ex_te,
+                                                                  const int2 *__restrict__ lane_lx, const int2 *__restrict__ lex,
                                                                   const double *h_table, int h_len, double tau, const int2 *thr_tab,
                                                                   int support, unsigned char *chosen,
                                                                   unsigned char *dpx, i64 dpx_stride,
@@ -3090,14 +3096,14 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
             const int l = l0 + (int)threadIdx.x;
             const bool in = l < d.lane_n;
 #ifdef FSEG_ABLATE_COV
-            const longlong2 ex = make_longlong2(0, 0);               // diagnostic (wrong results): no exon access at all, two lanes in three kept
+            const int2 ex = make_int2(0, 0);                         // diagnostic (wrong results): no exon access at all, two lanes in three kept
             int first_rel = 0, cnt = (l % 3) != 2;
 #else
-            const longlong2 ex = lane_ex[d.lane_lo + (in ? l : 0)];
+            const int2 ex = lane_lx[d.lane_lo + (in ? l : 0)];
             int first_rel, cnt;
-            window_exons(ex_ts, ex_te, ex, cp0, c_last, &first_rel, &cnt);
+            window_exons(lex, ex, cp0, c_last, &first_rel, &cnt);
 #endif
-            const i64 first = ex.x + first_rel;
+            const int first = ex.x + first_rel;
             const bool act = in && cnt > 0;
             const u64 m = __ballot(act);
             if ((threadIdx.x & 63) == 0) act_wave[threadIdx.x >> 6] = __popcll(m);
@@ -3107,7 +3113,7 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
             {
                 constexpr int kActCap = sizeof(CntT) == 1 ? kFuseLanes + 1 : kFuseLanesWide + 1;
                 const int slot = base + __popcll(m & ((1ULL << (threadIdx.x & 63)) - 1ULL));
-                if (act && slot < kActCap) act_s[slot] = make_int2((int)first, cnt);      // (beyond it: the other instance's problem)
+                if (act && slot < kActCap) act_s[slot] = make_int2(first, cnt);      // (beyond it: the other instance's problem)
             }
             n_act += tot;
             __syncthreads();
@@ -3141,16 +3147,16 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
                 for (int e = 0; e < e_end; e += 4) {
                     // four exons per round trip (what lies beyond the read's own exons is masked below; the arrays are padded);
                     // the second pair is worked on only if some read of the wave has it
-                    const int4u ts4 = *reinterpret_cast<const int4u *>(ex_ts + a.x + e), te4 = *reinterpret_cast<const int4u *>(ex_te + a.x + e);
+                    const int4u x01 = *reinterpret_cast<const int4u *>(lex + a.x + e), x23 = *reinterpret_cast<const int4u *>(lex + a.x + e + 2);
                     {
-                        const int a0 = max(ts4.x, cp0), b0 = te4.x + 1;                     // closed exon -> half-open end
-                        const int a1 = max(ts4.y, cp0), b1 = e + 1 < e_end ? te4.y + 1 : a1;  // (an odd count: the second slot is empty)
+                        const int a0 = max(x01.x, cp0), b0 = x01.y + 1;                     // closed exon -> half-open end
+                        const int a1 = max(x01.z, cp0), b1 = e + 1 < e_end ? x01.w + 1 : a1;  // (an odd count: the second slot is empty)
 #pragma unroll
                         for (int v = 0; v < kCovJ; ++v) acc[v] += max(0, min(b0, cjv[v]) - a0) + max(0, min(b1, cjv[v]) - a1);
                     }
                     if (e + 2 < e_end) {
-                        const int a0 = max(ts4.z, cp0), b0 = te4.z + 1;
-                        const int a1 = max(ts4.w, cp0), b1 = e + 3 < e_end ? te4.w + 1 : a1;
+                        const int a0 = max(x23.x, cp0), b0 = x23.y + 1;
+                        const int a1 = max(x23.z, cp0), b1 = e + 3 < e_end ? x23.w + 1 : a1;
 #pragma unroll
                         for (int v = 0; v < kCovJ; ++v) acc[v] += max(0, min(b0, cjv[v]) - a0) + max(0, min(b1, cjv[v]) - a1);
                     }
@@ -4783,8 +4789,8 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
     hipLaunchKernelGGL(k_prob_range, dim3(grid_for(NPOS / 64 + 1, 256, 1024)), dim3(256), 0, s, st, c->d_cand_pn.as<int>(),
                        c->d_seg_iv.as<int>(), c->d_cand_y.as<int>(), c->d_iv_part.as<int>(), c->d_iv_start.as<int>(),
                        c->d_part_lane_off.as<i64>(), c->d_lane_start.as<int>(), c->d_lane_pmax.as<int>(),
-                       c->d_cand_ll.as<int>(), c->d_cand_ln.as<int>(), c->d_cand_wide.as<unsigned char>(), c->d_lane_ex.as<longlong2>(),
-                       c->d_ex_ts.as<int>(), c->d_ex_te.as<int>(), c->wide_by_seen ? 1 : 0);
+                       c->d_cand_ll.as<int>(), c->d_cand_ln.as<int>(), c->d_cand_wide.as<unsigned char>(), c->d_lane_lx.as<int2>(),
+                       c->d_lex.as<int2>(), c->wide_by_seen ? 1 : 0);
     if (prob_bs) {
         hipLaunchKernelGGL(k_prob_scan1, dim3(pg), dim3(256), 0, s, st, c->d_cand_pn.as<int>(), c->d_cand_ln.as<int>(), c->d_cand_wide.as<unsigned char>(), prob_bs, split);
         hipLaunchKernelGGL(k_prob_scan2, dim3(1), dim3(256), 0, s, st, prob_bs);
@@ -4873,8 +4879,8 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
 #define FSEG_SOLVE_ARGS(NMV, CNT, CLS)                                                                                      \
                                st, CLS, ((NMV) == kNMax ? c->nm_big : (NMV)), list_lb(CLS),                                    \
                                (wide_n(CLS, sizeof(CNT)) >= 0 ? wide_n(CLS, sizeof(CNT)) : list_ln(CLS)), pr, c->d_solve_desc.as<ProbDesc>(), \
-                               c->prob_cap, c->d_cand_y.as<int>(), c->d_lane_ex.as<longlong2>(), c->d_ex_ts.as<int>(),         \
-                               c->d_ex_te.as<int>(), c->d_h_table.as<double>(), c->P.h_len, c->P.threshold_rate,               \
+                               c->prob_cap, c->d_cand_y.as<int>(), c->d_lane_lx.as<int2>(), c->d_lex.as<int2>(),               \
+                               c->d_h_table.as<double>(), c->P.h_len, c->P.threshold_rate,               \
                                c->d_thr_tab.as<int2>(), c->P.min_read_support_outside, c->d_chosen.as<unsigned char>()
         // the split path (k_solve<.., SPLIT> then k_dpw on the same stream) for a list that fits the hand-over arena as laid out --
         // when this context has the device to itself (`forking`): with other contexts' batches in flight a context keeps to one
@@ -4892,8 +4898,8 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
 #define FSEG_LAUNCH_WIDE_ALL(Q, VT)                                                                                          \
             hipLaunchKernelGGL((k_solve<kNMax, unsigned short, VT, false>), dim3((unsigned)n_wide_all), dim3(SolveCfg<kNMax>::kThreads), \
                                solve_lds_for(c->nm_big, kNMax + 1, 2), Q, st, -1, c->nm_big, (i64)0, n_wide_all, pr, c->d_solve_desc.as<ProbDesc>(), \
-                               c->prob_cap, c->d_cand_y.as<int>(), c->d_lane_ex.as<longlong2>(), c->d_ex_ts.as<int>(),         \
-                               c->d_ex_te.as<int>(), c->d_h_table.as<double>(), c->P.h_len, c->P.threshold_rate,               \
+                               c->prob_cap, c->d_cand_y.as<int>(), c->d_lane_lx.as<int2>(), c->d_lex.as<int2>(),               \
+                               c->d_h_table.as<double>(), c->P.h_len, c->P.threshold_rate,               \
                                c->d_thr_tab.as<int2>(), c->P.min_read_support_outside, c->d_chosen.as<unsigned char>(),       \
                                (unsigned char *)nullptr, (i64)0, c->d_wide_all.as<int>() FSEG_TARG)
         // the split path, one instance: k_solve<.., SPLIT> (set-up and rounds) then k_dpw (the DPs) on the same stream
