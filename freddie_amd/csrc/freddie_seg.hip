@@ -189,9 +189,9 @@ __global__ void __launch_bounds__(512) k_hist(int n_chunks, const int *chunk_par
                                               const int *chunk_glo, const int *chunk_ghi, const i64 *chunk_lane_lo,
                                               const i64 *chunk_lane_hi, const i64 *part_iv_off,
                                               const int *iv_start, const int *iv_end, const i64 *pos_off,
-                                              const i64 *part_lane_off, const longlong2 *lane_ex, const int *lane_start,
-                                              const int *lane_pmax, const int *ex_ts,
-                                              const int *ex_te, int ignore_ends, int *y_raw, Status *st, u64 *zero_ptr, i64 zero_n) {
+                                              const i64 *part_lane_off, const int2 *__restrict__ lane_lx, const int *lane_start,
+                                              const int *lane_pmax, const int2 *__restrict__ lex,
+                                              int ignore_ends, int *y_raw, Status *st, u64 *zero_ptr, i64 zero_n) {
     __shared__ int hist[kHistChunk];
     __shared__ int ivs_s[kHistIv], ive_s[kHistIv], base_s[kHistIv];
     // first kernel of the run: also clears the look-back words of the three compactions (saves a memset node)
@@ -218,7 +218,9 @@ __global__ void __launch_bounds__(512) k_hist(int n_chunks, const int *chunk_par
         __syncthreads();
         // 8 threads share a read: thread q of the group takes the read's exons q, q+8, ...  The walk is a chain of
         // dependent loads (lane -> exon range -> exon), so four reads per group are in flight: their exon ranges, then
-        // their first exons, are loaded together from clamped addresses before any of them is used.
+        // their first exons, are loaded together from clamped addresses before any of them is used.  The exons come from
+        // the lane-ordered (ts, te) stream: a group's eight threads read 64 consecutive bytes, consecutive groups consecutive
+        // lanes' pieces (from the rep-ordered ex_ts / ex_te: two lines per read, anywhere)
         const int sub = threadIdx.x & 7;
         const int G8 = blockDim.x >> 3;
         auto count_exon = [&](i64 e, i64 e0, i64 e1, int ts, int te) {
@@ -244,21 +246,20 @@ __global__ void __launch_bounds__(512) k_hist(int n_chunks, const int *chunk_par
             if (!(ignore_ends && e == e1 - 1) && te >= g_lo && te <= g_hi) atomicAdd(&hist[base + te], 1);   // :672-673
         };
         for (i64 l0 = lo + (threadIdx.x >> 3); l0 < hi; l0 += 4 * (i64)G8) {
-            longlong2 ex[4];
-            int ts0[4], te0[4];
+            int2 ex[4], x0[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const i64 l = l0 + (i64)u * G8; ex[u] = lane_ex[l < hi ? l : l0]; }
+            for (int u = 0; u < 4; ++u) { const i64 l = l0 + (i64)u * G8; ex[u] = lane_lx[l < hi ? l : l0]; }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const i64 e = ex[u].x + sub < ex[u].y ? ex[u].x + sub : ex[u].x;       // a valid exon of the read (a read has at least one)
-                ts0[u] = ex_ts[e]; te0[u] = ex_te[e];
+                const int e = ex[u].x + sub < ex[u].y ? ex[u].x + sub : ex[u].x;       // a valid exon of the read (a read has at least one)
+                x0[u] = lex[e];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 if (l0 + (i64)u * G8 >= hi) break;
                 const i64 e0 = ex[u].x, e1 = ex[u].y;
-                if (e0 + sub < e1) count_exon(e0 + sub, e0, e1, ts0[u], te0[u]);
-                for (i64 e = e0 + sub + 8; e < e1; e += 8) count_exon(e, e0, e1, ex_ts[e], ex_te[e]);
+                if (e0 + sub < e1) count_exon(e0 + sub, e0, e1, x0[u].x, x0[u].y);
+                for (i64 e = e0 + sub + 8; e < e1; e += 8) { const int2 x = lex[e]; count_exon(e, e0, e1, x.x, x.y); }
             }
         }
         __syncthreads();
@@ -4727,9 +4728,9 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
     hipLaunchKernelGGL(k_hist, dim3(grid_for(c->n_hist_chunks, 1, 16384)), dim3(512), 0, s, c->n_hist_chunks,
                        c->d_hc_part.as<int>(), c->d_hc_p0.as<i64>(), c->d_hc_n.as<int>(), c->d_hc_glo.as<int>(),
                        c->d_hc_ghi.as<int>(), c->d_hc_llo.as<i64>(), c->d_hc_lhi.as<i64>(), c->d_part_iv_off.as<i64>(), c->d_iv_start.as<int>(), c->d_iv_end.as<int>(),
-                       c->d_pos_off.as<i64>(), c->d_part_lane_off.as<i64>(), c->d_lane_ex.as<longlong2>(),
+                       c->d_pos_off.as<i64>(), c->d_part_lane_off.as<i64>(), c->d_lane_lx.as<int2>(),
                        c->d_lane_start.as<int>(), c->d_lane_pmax.as<int>(),
-                       c->d_ex_ts.as<int>(), c->d_ex_te.as<int>(), c->P.ignore_ends, c->d_y_raw.as<int>(), st,
+                       c->d_lex.as<int2>(), c->P.ignore_ends, c->d_y_raw.as<int>(), st,
                        scan_state, scan_single ? scan_nb * 3 : 0);
     end(ST_HIST); begin(ST_SMOOTH);
     // S2
