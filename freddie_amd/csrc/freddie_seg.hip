@@ -1703,8 +1703,8 @@ __global__ void __launch_bounds__(256) k_pair_thresholds(const Status *st, Probl
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kLaneChunk) k_cov(Status *st, const ProbDesc *desc, i64 prob_cap, const int2 *work_pc,
                                                     i64 work_cap, const i64 *cand_off,
-                                                    const int *cand_y, const int *iv_start, const longlong2 *lane_ex,
-                                                    const int *ex_ts, const int *ex_te,
+                                                    const int *cand_y, const int *iv_start, const int2 *__restrict__ lane_lx,
+                                                    const int2 *__restrict__ lex,
                                                     unsigned *cov_g, i64 cov_cap, unsigned char *work_active,
                                                     int cov_blocks, ProblemArrays pr, const double *h_table, int h_len, double tau,
                                                     int2 *pair_thr, i64 pair_cap, unsigned *amb_g, unsigned *out_g, i64 tri_cap) {
@@ -1736,7 +1736,7 @@ __global__ void __launch_bounds__(kLaneChunk) k_cov(Status *st, const ProbDesc *
         int t = threadIdx.x;
         int li = chunk * kLaneChunk + t;
         // the read's exon range needs only the descriptor: in flight together with the candidate positions
-        const longlong2 ex = lane_ex[d.lane_lo + (li < d.lane_n ? li : 0)];
+        const int2 ex = lane_lx[d.lane_lo + (li < d.lane_n ? li : 0)];      // (its piece of the lane-ordered (ts, te) stream)
         for (int j = threadIdx.x; j < n; j += blockDim.x) cp[j] = g0 + cy[j];
         __syncthreads();
         const int cp0 = cp[0];
@@ -1746,19 +1746,19 @@ __global__ void __launch_bounds__(kLaneChunk) k_cov(Status *st, const ProbDesc *
             i64 e = ex.x, e1 = ex.y;
             {   // first exon whose closed interval reaches cand_0 (exons of a read are ordered, :158)
                 i64 lo = e, hi = e1;
-                while (lo < hi) { i64 mid = (lo + hi) >> 1; if (ex_te[mid] < cp0) lo = mid + 1; else hi = mid; }
+                while (lo < hi) { i64 mid = (lo + hi) >> 1; if (lex[mid].y < cp0) lo = mid + 1; else hi = mid; }
                 e = lo;
             }
             unsigned acc = 0;
             int ts = 0, te = -1;
-            if (e < e1) { ts = ex_ts[e]; te = ex_te[e]; }
+            if (e < e1) { const int2 x = lex[e]; ts = x.x; te = x.y; }
             dst[0] = 0;
             for (int j = 1; j < n; ++j) {
                 int cj = cp[j];
                 while (e < e1 && te < cj) {
                     acc += (unsigned)(te + 1 - (ts > cp0 ? ts : cp0));
                     ++e;
-                    if (e < e1) { ts = ex_ts[e]; te = ex_te[e]; }
+                    if (e < e1) { const int2 x = lex[e]; ts = x.x; te = x.y; }
                 }
                 unsigned part_cov = 0;
                 if (e < e1 && ts < cj) part_cov = (unsigned)(cj - (ts > cp0 ? ts : cp0));
@@ -4822,8 +4822,8 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
                                c->d_out.as<unsigned>(), c->tri_cap);
         hipLaunchKernelGGL(k_cov, dim3(cov_blocks + pt_blocks), dim3(kLaneChunk), 0, s, st,
                            c->d_prob_desc.as<ProbDesc>(), c->prob_cap, c->d_work_pc.as<int2>(), c->work_cap, c->d_cand_off.as<i64>(),
-                           c->d_cand_y.as<int>(), c->d_iv_start.as<int>(), c->d_lane_ex.as<longlong2>(),
-                           c->d_ex_ts.as<int>(), c->d_ex_te.as<int>(),
+                           c->d_cand_y.as<int>(), c->d_iv_start.as<int>(), c->d_lane_lx.as<int2>(),
+                           c->d_lex.as<int2>(),
                            c->d_cov.as<unsigned>(), c->cov_cap, c->d_work_active.as<unsigned char>(),
                            cov_blocks, pr, c->d_h_table.as<double>(), c->P.h_len, c->P.threshold_rate, c->d_pair_thr.as<int2>(),
                            c->pair_cap, c->d_amb.as<unsigned>(), c->d_out.as<unsigned>(), c->tri_cap);
