@@ -476,10 +476,16 @@ def run_batches(batches, params, ctxs, threads, on_done, sidecar="off"):
     timing = os.environ.get("FREDDIE_TIMING") == "1"
     done_lock = threading.Lock()
 
+    t_pipe = time.perf_counter()
+    marks = []                                   # FREDDIE_TIMING=1: (what, batch, start, end) relative to the pipeline's start
+
     def load(jobs):
         t0 = time.perf_counter()
         hb = load_batch_native(jobs, threads, sidecar)
-        return hb, time.perf_counter() - t0
+        t1 = time.perf_counter()
+        if timing:
+            marks.append(("load", len(marks), t0 - t_pipe, t1 - t_pipe))
+        return hb, t1 - t0
 
     def write(hb, res, jobs, t_load, t_dev, i):
         t0 = time.perf_counter()
@@ -489,6 +495,7 @@ def run_batches(batches, params, ctxs, threads, on_done, sidecar="off"):
             n_sc, n_reads = hb.n_from_sidecar, hb.n_reads
             hb.close()
         if timing:
+            marks.append(("write", i, t0 - t_pipe, time.perf_counter() - t_pipe))
             print("[freddie_segment] batch %d: %d partitions (%d from side-cars), %d reads: load %.3f s, device %.3f s, "
                   "write %.3f s" % (i, len(jobs), n_sc, n_reads, t_load, t_dev, time.perf_counter() - t0), file=sys.stderr)
         with done_lock:
@@ -509,6 +516,8 @@ def run_batches(batches, params, ctxs, threads, on_done, sidecar="off"):
         prefetch()                           # the first batches are being parsed while the contexts come up
         if hasattr(ctxs, "result"):
             ctxs = ctxs.result()             # a future of open_contexts()
+            if timing:
+                marks.append(("contexts-up", 0, 0.0, time.perf_counter() - t_pipe))
         if not isinstance(ctxs, (list, tuple)):
             ctxs = [ctxs]
         for ctx in ctxs:
@@ -539,6 +548,8 @@ def run_batches(batches, params, ctxs, threads, on_done, sidecar="off"):
                     return
                 raise
             t_dev = (t1 - t0) + (time.perf_counter() - t2)       # without the wait for the writer
+            if timing:
+                marks.append(("device", i, t0 - t_pipe, time.perf_counter() - t_pipe))
             last_write[k] = write_pool.submit(write, hb, res, jobs, t_load, t_dev, i)
 
         dev_futs = [None] * n_ctx
@@ -556,6 +567,9 @@ def run_batches(batches, params, ctxs, threads, on_done, sidecar="off"):
             for f in last_write:
                 if f is not None:
                     f.result()
+            if timing:
+                print("[freddie_segment] pipeline (s from its start): " + "; ".join(
+                    "%s %d %.3f-%.3f" % m for m in sorted(marks, key=lambda m: m[2])), file=sys.stderr)
         finally:
             for f in loads:                  # an error above: do not leak the batches that were already parsed
                 try:
