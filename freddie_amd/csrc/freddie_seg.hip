@@ -1239,7 +1239,7 @@ constexpr int kRangeThreads = 256;
 __global__ void __launch_bounds__(kRangeThreads) k_prob_range(const Status *st, const int *cand_pn, const int *cand_iv, const int *cand_y,
                              const int *iv_part, const int *iv_start, const i64 *part_lane_off, const int *lane_start,
                              const int *lane_pmax, int *cand_ll, int *cand_ln, unsigned char *cand_wide,
-                             const int2 *__restrict__ lane_lx, const int2 *__restrict__ lex, int wide_by_seen) {
+                             const int2 *__restrict__ lane_lx, const int2 *__restrict__ lex, int wide_by_seen, int fuse_lanes) {
     __shared__ int l_wide[kRangeThreads], l_n, l_red[kRangeThreads / 64];
     const i64 n_cand = (i64)st->n_cand;
     for (i64 c0 = (i64)blockIdx.x * blockDim.x; c0 < n_cand; c0 += (i64)gridDim.x * blockDim.x) {    // (workgroup-uniform)
@@ -1261,7 +1261,9 @@ __global__ void __launch_bounds__(kRangeThreads) k_prob_range(const Status *st, 
                 lo_lane = (int)lo; n_lanes = (int)(a - lo);
             }
             cand_ll[c] = lo_lane; cand_ln[c] = n_lanes;
-            const bool cand = n > 0 && n <= kNMax && n_lanes > kFuseLanes && n_lanes <= kFuseLanesWide;
+            // (fuse_lanes: what a problem may see to be solved whole, -1 in a batch that is not -- there nobody asks, and a
+            // batch of deep problems would pay a workgroup's walk over up to 1 023 reads for every one of them)
+            const bool cand = n > 0 && n <= kNMax && n_lanes > kFuseLanes && n_lanes <= kFuseLanesWide && n_lanes <= fuse_lanes;
             cand_wide[c] = (unsigned char)((cand && wide_by_seen) ? 1 : 0);     // (FSEG_WIDE_BY_SEEN=1, tests: whatever SEES more than kFuseLanes reads)
             if (cand && !wide_by_seen) l_wide[atomicAdd(&l_n, 1)] = (int)threadIdx.x;
         }
@@ -2713,9 +2715,10 @@ __global__ void __launch_bounds__(256, FSEG_TINY_OCC) k_tiny(Status *st, const P
 
 // ---------------------------------------------------------------------------------------------
 // S5 whole by ONE WAVE per problem, for problems of at most NM candidates (NM = 8: the tiny list, NM = 16: solve list 0) --
-// k_tiny's plan with the loads made cheap.  k_tiny and k_solve fetch a read's exons with one gather per lane (64 cache lines
-// per load instruction, and the texture path takes them one by one: that rate, not HBM or the ALUs, is what they run at) and
-// every problem is a chain of such gathers.  Here the exons come from the lane-ordered stream `lex` (k_lanes): the reads a
+// k_tiny's plan with the loads made cheap.  k_tiny fetches a read's exons with one gather per lane from the rep-ordered arrays (64
+// cache lines per load instruction, and the texture path takes them one by one: that rate, not HBM or the ALUs, is what it runs
+// at; k_solve gathers too, but since round 4 from the lane-ordered stream, where neighbouring lanes share lines) and every
+// problem is a chain of such gathers.  Here the exons come from the lane-ordered stream `lex` (k_lanes): the reads a
 // round examines -- up to 64 consecutive lanes -- own ONE contiguous piece of it, which the wave copies into LDS with
 // lane-consecutive 16-byte loads; everything after that is LDS and registers:
 //   per round: every lane finds the exons of its read that meet the window (ordered, so they are consecutive) and sums
@@ -4791,7 +4794,7 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
                        c->d_seg_iv.as<int>(), c->d_cand_y.as<int>(), c->d_iv_part.as<int>(), c->d_iv_start.as<int>(),
                        c->d_part_lane_off.as<i64>(), c->d_lane_start.as<int>(), c->d_lane_pmax.as<int>(),
                        c->d_cand_ll.as<int>(), c->d_cand_ln.as<int>(), c->d_cand_wide.as<unsigned char>(), c->d_lane_lx.as<int2>(),
-                       c->d_lex.as<int2>(), c->wide_by_seen ? 1 : 0);
+                       c->d_lex.as<int2>(), c->wide_by_seen ? 1 : 0, split.fuse_lanes);
     if (prob_bs) {
         hipLaunchKernelGGL(k_prob_scan1, dim3(pg), dim3(256), 0, s, st, c->d_cand_pn.as<int>(), c->d_cand_ln.as<int>(), c->d_cand_wide.as<unsigned char>(), prob_bs, split);
         hipLaunchKernelGGL(k_prob_scan2, dim3(1), dim3(256), 0, s, st, prob_bs);
@@ -5349,9 +5352,16 @@ int run_sized(fseg_ctx *c) {
             if (tiny != c->tiny_on || fuse != c->fuse_on) {
                 if (c->trace) fprintf(stderr, "[fseg] problem split changed (tiny %d -> %d, fused %d -> %d; %llu problems, widest sees %u reads): rescan\n",
                                       (int)c->tiny_on, (int)tiny, (int)c->fuse_on, (int)fuse, (unsigned long long)s.n_prob, s.max_ln);
+                const bool fuse_turned_on = fuse && !c->fuse_on;
                 c->tiny_on = tiny; c->fuse_on = fuse;
                 const int pg = grid_for(c->NPOS / 8 / kProbBlock + 1, 1, 1024);
                 Status *st = c->d_status.as<Status>();
+                if (fuse_turned_on)     // the first pass did not count the reads the wide problems keep: nobody was going to ask
+                    hipLaunchKernelGGL(k_prob_range, dim3(grid_for(c->NPOS / 64 + 1, 256, 1024)), dim3(256), 0, c->stream, st, c->d_cand_pn.as<int>(),
+                                       c->d_seg_iv.as<int>(), c->d_cand_y.as<int>(), c->d_iv_part.as<int>(), c->d_iv_start.as<int>(),
+                                       c->d_part_lane_off.as<i64>(), c->d_lane_start.as<int>(), c->d_lane_pmax.as<int>(),
+                                       c->d_cand_ll.as<int>(), c->d_cand_ln.as<int>(), c->d_cand_wide.as<unsigned char>(), c->d_lane_lx.as<int2>(),
+                                       c->d_lex.as<int2>(), c->wide_by_seen ? 1 : 0, split_of(c, tiny, fuse).fuse_lanes);
                 // (the scan ADDS to the per-class counts of wide problems: the first scan's must not stay in them)
                 HIP_TRY(c, hipMemsetAsync(reinterpret_cast<char *>(st) + offsetof(Status, wide_cls), 0, sizeof(st->wide_cls), c->stream));
                 hipLaunchKernelGGL(k_prob_scan1, dim3(pg), dim3(256), 0, c->stream, st, c->d_cand_pn.as<int>(), c->d_cand_ln.as<int>(), c->d_cand_wide.as<unsigned char>(),

@@ -119,6 +119,26 @@ def test_stage_events_keep_parity(mode, env, monkeypatch):
         ctx.close()
 
 
+def test_fuse_turning_on_recounts_the_reads_wide_problems_keep(monkeypatch):
+    """A batch that is not solved whole (its widest problem sees too many reads) leaves the kept-read counts of k_prob_range
+    out; the next batch on the same context, solved whole with 16-bit counters for some problems, must get them (the sized
+    run's rescan redoes k_prob_range) -- and the other way round."""
+    monkeypatch.setenv("FSEG_FUSE_LANES", "1023")
+    deep = [util.make_partition(4242, n_reads=4000, n_exons=14, rp=0.02, max_span=0)]
+    deep_oracle = [util.run_oracle(p) for p in deep]
+    parts, oracles = mixed_batch()
+    ctx = _lib.Context(0)
+    try:
+        for rnd in range(2):
+            util.run_gpu(ctx, deep, None)
+            assert ctx.sizes()["max_problem_reads"] > 1023              # the arena path: nothing is solved whole
+            assert util.compare_partitions(ctx, deep, deep_oracle)["y_identical"]
+            check_twice(ctx, parts, oracles)
+            assert 255 < ctx.sizes()["max_problem_reads"] <= 1023      # solved whole, some problems by the 16-bit instances
+    finally:
+        ctx.close()
+
+
 def test_wide_count_dp_for_real():
     """One partition whose DP windows see more than 65 535 reads: the 16-bit count tables cannot hold out(i,j,k), the
     library must pick the 32-bit DP by itself."""
