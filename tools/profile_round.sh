@@ -23,7 +23,7 @@ python profiles/trace_medians.py $O/trace2/p_kernel_trace.csv > $O/config2_kerne
 #     (--profiling 2: events around the scoring stage only, as in bench.py's roofline leg -- every other stage's pair of events is two more
 #     marker packets between the stage's kernels and its neighbours)
 rocprofv3 --kernel-trace --output-format csv -d $O/trace3 -o p -- python3 tools/replay_probe.py --workload config4 --profiling 2 > $O/replay_config4_plan.txt 2> $O/trace3.err
-python tools/stage_span.py $O/trace3/p_kernel_trace.csv > $O/config4_stage_span.txt; grep replay $O/replay_config4_plan.txt | cut -c1-120 >> $O/config4_stage_span.txt; cat $O/config4_stage_span.txt
+python tools/stage_timeline.py $O/trace3/p_kernel_trace.csv > $O/config4_stage_timeline.txt; python tools/stage_span.py $O/trace3/p_kernel_trace.csv > $O/config4_stage_span.txt; grep replay $O/replay_config4_plan.txt | cut -c1-120 >> $O/config4_stage_span.txt; cat $O/config4_stage_span.txt
 # 2c. how a resident batch is replayed: plain launches on the forked streams (default), the same as one hipGraph with cross-stream
 #     edges (FSEG_GRAPH_FORK=1), one stream as a hipGraph (FSEG_NO_FORK=1), one stream as plain launches -- ms per replay and the
 #     host's time inside fseg_run
