@@ -68,6 +68,7 @@ class Batch:
         self.arrays = pack.concat_batch(parts)
         self.n_reads = sum(p.n_reads for p in parts)
         self.alg_bytes = None
+        self.label_popcount = None
 
 
 def plan_job(workload, rank, n_gpus):
@@ -455,6 +456,10 @@ def main():
     def note_alg(si, bi, ctx, res):
         if batches[bi].alg_bytes is None:
             batches[bi].alg_bytes = ctx.scoring_algorithmic_bytes()
+        if batches[bi].label_popcount is None:
+            # the labels' CONTENT, out here where it costs nothing timed: set bits of the two-bit labels = labels that are '1' or
+            # '2' (padding is zero), a property of the batch's partitions however they are batched
+            batches[bi].label_popcount = int(np.bitwise_count(res[3]).sum(dtype=np.int64))
     n_warm_steps = max(1, args.warmup)
     t_warm = time.perf_counter()
     if n_b:
@@ -474,9 +479,11 @@ def main():
         with acc_lock:
             score_ms_total[0] += ms["interval_scoring"]
             alg_total[0] += batches[bi].alg_bytes
-            # final positions + label bytes of the batch (sums over its partitions: the job's total does not depend on how it
-            # is cut into batches or scattered over ranks); the result arrays are in host memory: touch them
-            checksum[0] += int(res[0][-1]) + int(res[2][-1]) + ((int(res[1][-1]) + int(res[3][-1])) & 0)
+            # the batch's results, read where they lie in host memory: the number of final positions, the number of label bytes
+            # and the SUM of the final positions (content; ~150 k integers per batch) -- sums over partitions, so the job's total
+            # does not depend on how it is cut into batches or scattered over ranks.  The labels' content (19 MB per batch at
+            # two bits per label) is summed in the warm-up pass instead: label_popcount below
+            checksum[0] += int(res[0][-1]) + int(res[2][-1]) + int(res[1].sum(dtype=np.int64))
 
     # the timed steps: K passes over the share, batch after batch, as one stream of work for the contexts (step boundaries
     # are not barriers: the CLI does not stop between batches either); consecutive batch-steps go to consecutive contexts
@@ -489,16 +496,17 @@ def main():
     dt = time.perf_counter() - t0
     n_reads = sum(batches[bi].n_reads for bi in order)
 
-    t = torch.tensor([dt, float(n_reads), float(checksum[0])], dtype=torch.float64,
+    label_pop = sum(b.label_popcount or 0 for b in batches)
+    t = torch.tensor([dt, float(n_reads), float(checksum[0]), float(label_pop)], dtype=torch.float64,
                      device="cpu" if dist is not None and dist.get_backend() == "gloo" else "cuda")
     if dist is not None:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone()
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        dt_max, total_reads, checksum_all = float(tmax[0]), float(tsum[1]), int(tsum[2])
+        dt_max, total_reads, checksum_all, label_pop_all = float(tmax[0]), float(tsum[1]), int(tsum[2]), int(tsum[3])
     else:
-        dt_max, total_reads, checksum_all = dt, float(n_reads), checksum[0]
+        dt_max, total_reads, checksum_all, label_pop_all = dt, float(n_reads), checksum[0], label_pop
 
     if rank == 0:
         lib_hash = _lib.load().fseg_source_hash().decode()
@@ -591,10 +599,13 @@ def main():
             "valu_util": (committed or {}).get("valu_util"),
             "valu_util_source": (committed or {}).get("valu_source"),
             "library_source_hash": lib_hash,
-            # final positions + label bytes of every batch of every timed step, summed over the ranks: a property of the job
-            # (every partition exactly once per step), whatever N and however a rank's share is cut into batches
+            # counts of final positions and label bytes + the sum of the final positions, of every batch of every timed step,
+            # summed over the ranks: a property of the job (every partition exactly once per step), whatever N and however a
+            # rank's share is cut into batches; result_label_popcount: the labels that are '1' or '2' in one pass over the job
+            # (counted in the warm-up pass, outside the timed region)
             "result_checksum": checksum_all,
             "result_checksum_per_step": checksum_all // max(1, args.steps),
+            "result_label_popcount": label_pop_all,
         }
         out["value_resident_replay"] = {"value": batches[0].n_reads * reps / dt_r, "unit": "reads/s", "ms_per_step": dt_r / reps * 1e3,
                                         "what": "replay of one resident 250 k-read batch: no copies, no arena sizing (a batch, not the job)"}

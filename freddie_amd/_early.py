@@ -39,6 +39,11 @@ def start(device, n=2):
     _state = st
 
 
+def started():
+    """True once start() has been called in this process (HIP's start-up is under way or done)."""
+    return _state is not None
+
+
 def take(device):
     """The context handles start() has created for ``device`` (waits for it), or [] -- each handle is handed out once."""
     st = _state

@@ -39,7 +39,9 @@ def str_to_bool(value):
 
 
 def parse_args(argv=None):
-    ap = argparse.ArgumentParser(description="Cluster aligned reads into isoforms")
+    # (allow_abbrev=False: py/freddie_segment.py reads --gpus / --devices off the command line before this parser runs, to
+    # start the one GPU's contexts early; an abbreviated "--dev 0,1" would be accepted here and missed there)
+    ap = argparse.ArgumentParser(description="Cluster aligned reads into isoforms", allow_abbrev=False)
     ap.add_argument("-s", "--split-dir", type=str, required=True, help="Path to Freddie split directory of the reads")
     ap.add_argument("--consider-ends", type=str_to_bool, nargs="?", const=True, default=False,
                     help="Consider the start and end splice sites in segmentation")
@@ -479,12 +481,12 @@ def run_batches(batches, params, ctxs, threads, on_done, sidecar="off"):
     t_pipe = time.perf_counter()
     marks = []                                   # FREDDIE_TIMING=1: (what, batch, start, end) relative to the pipeline's start
 
-    def load(jobs):
+    def load(jobs, i=-1):
         t0 = time.perf_counter()
         hb = load_batch_native(jobs, threads, sidecar)
         t1 = time.perf_counter()
         if timing:
-            marks.append(("load", len(marks), t0 - t_pipe, t1 - t_pipe))
+            marks.append(("load", i, t0 - t_pipe, t1 - t_pipe))      # (i = the batch's index; -1: a half of a batch that was too large)
         return hb, t1 - t0
 
     def write(hb, res, jobs, t_load, t_dev, i):
@@ -509,8 +511,11 @@ def run_batches(batches, params, ctxs, threads, on_done, sidecar="off"):
 
         def prefetch():
             nonlocal nxt
-            while nxt < len(batches) and len(loads) < 3:        # (two being parsed, one waiting: the first ones while the contexts come up)
-                loads.append(load_pool.submit(load, batches[nxt]))
+            # (two being parsed, one waiting: the first ones while the contexts come up.  Host memory: a parsed batch is its
+            # mapped TSVs plus ~100 B per read of arrays -- with --batch-reads 250 000 about 25 MB each, three of them held here,
+            # two more on the contexts and up to two with the writers: ~0.2 GB at the default, in proportion to --batch-reads)
+            while nxt < len(batches) and len(loads) < 3:
+                loads.append(load_pool.submit(load, batches[nxt], nxt))
                 nxt += 1
 
         prefetch()                           # the first batches are being parsed while the contexts come up
@@ -679,6 +684,12 @@ def main(argv=None):
     n_gpus = len(device_list)
     if n_gpus <= 0:
         raise SystemExit("freddie_segment: no GPU visible (this implementation has no CPU path)")
+    from . import _early
+    if n_gpus != 1 and _early.started():
+        # the CLI shim took the command line for a one-GPU run and this process has begun HIP's start-up: it must not start
+        # worker processes now (a spawn is an exec, and a process that has initialised the GPU must not exec: devices.py)
+        raise SystemExit("freddie_segment: --gpus / --devices name %d GPUs but were first read as one (repeated or "
+                         "contradictory options?): give each once, in full" % n_gpus)
     # One GPU: this process drives it itself, and bringing its contexts up (library load, HIP start-up, streams: a few tenths
     # of a second, a third of the wall time of a 2 M-read job) starts NOW, beside the directory scan and the first parse.
     boot = ctx_future = None

@@ -49,11 +49,13 @@ if __name__ == "__main__":
         from freddie_amd import _early
         _early.start(_dev)
 
-from freddie_amd.segment import main  # noqa: E402
-
 if __name__ == "__main__":
     try:
+        # (inside the try: an import error must not end the interpreter while the start-up thread is inside the HIP runtime)
+        from freddie_amd.segment import main
         main()
     finally:
         if _dev is not None:
             _early.finish()
+else:
+    from freddie_amd.segment import main  # noqa: E402,F401

@@ -45,6 +45,27 @@ SYNTH_CASES = {
     "g_sigma12": (dict(index=17, n_reads=400, n_exons=80, rp=0.3, jp=0.5, jsd=4.0, max_span=0),
                   dict(sigma=12.0, min_read_support_outside=0)),
     "g_tiny": (dict(index=18, n_reads=6, n_exons=3, rp=0.0, jp=0.5, jsd=2.0), {}),
+    # the CLI's parameter bounds (parse_args :104-109: 0 < sigma <= 50, 0.5 <= threshold_rate <= 1, 0 < variance_factor < 10,
+    # max_problem_size > 3): sigma = 50 is radius 200 in the main filter (intervals shorter than the radius: repeated
+    # reflection) and radius 50 in refine_segmentation; sigma = 0.1 is radius 0 in both (the filters are the identity);
+    # threshold_rate = 0.5 makes smooth_threshold() six entries of 0.5 (h = l = 0.5: nothing is ambiguous but an exact half)
+    "b_sigma50": (dict(index=21, n_reads=300, n_exons=40, rp=0.1), dict(sigma=50.0)),
+    "b_sigma50_dense": (dict(index=22, n_reads=200, n_exons=60, rp=0.0), dict(sigma=50.0)),
+    "b_sigma50_refine": (dict(index=29, n_reads=600, n_exons=60, rp=0.2, max_span=0), dict(sigma=50.0, min_read_support_outside=1000)),
+    "b_sigma01": (dict(index=23, n_reads=300, n_exons=60, rp=0.1, jp=0.5), dict(sigma=0.1)),
+    "b_sigma01_refine": (dict(index=30, n_reads=600, n_exons=60, rp=0.2, max_span=0), dict(sigma=0.1, min_read_support_outside=1000)),
+    "b_tau05": (dict(index=24, n_reads=300, n_exons=60, rp=0.1), dict(threshold_rate=0.5)),
+    "b_tau051": (dict(index=31, n_reads=300, n_exons=60, rp=0.1), dict(threshold_rate=0.51)),
+    "b_vf001": (dict(index=25, n_reads=300, n_exons=60, rp=0.1), dict(variance_factor=0.01)),
+    "b_vf999": (dict(index=26, n_reads=300, n_exons=60, rp=0.1), dict(variance_factor=9.99)),
+    "b_mps5": (dict(index=28, n_reads=300, n_exons=60, rp=0.3, max_span=0), dict(max_problem_size=5)),
+}
+
+# Inputs on which the REFERENCE ITSELF raises (break_large_problems :636-643: with max_problem_size = 4 an anchor's window of
+# ten candidates runs past the candidate list -> IndexError at :640).  The fixture holds the inputs and the exception's text;
+# oracle and library must refuse the partition (x_*.npz: not in goldens.names()).
+RAISE_CASES = {
+    "x_mps4": (dict(index=27, n_reads=300, n_exons=60, rp=0.3, max_span=0), dict(max_problem_size=4)),
 }
 
 
@@ -180,25 +201,53 @@ def record_case(name, split_dir, contig, tint_id, run_kw, out_dir, manifest, sto
         len(refine), len(probs), max([p[2] - p[1] + 1 for p in probs] + [0])))
 
 
+def record_raise_case(name, split_dir, contig, tint_id, run_kw, out_dir, manifest):
+    kw = dict(RUN_DEFAULTS, **run_kw)
+    tmp_out = tempfile.mkdtemp(prefix="gold_out_")
+    try:
+        tint, rec = refrun.run_recorded(split_dir, tmp_out, contig, tint_id, allow_raise=True, **kw)
+    finally:
+        shutil.rmtree(tmp_out, ignore_errors=True)
+    assert "raised" in rec, "%s: the reference did not raise" % name
+    out = dict(pack_tint(tint))
+    out.update(sigma=kw["sigma"], threshold_rate=kw["threshold_rate"], variance_factor=kw["variance_factor"],
+               max_problem_size=kw["max_problem_size"], min_read_support_outside=kw["min_read_support_outside"],
+               ignore_ends=int(not kw["consider_ends"]),
+               w_main=tables.gaussian_half_kernel(kw["sigma"], 4.0), w_refine=tables.gaussian_half_kernel(kw["sigma"], 1.0),
+               h_table=np.array(rec["h_table"], np.float64), raised=np.array(rec["raised"]))
+    np.savez_compressed(os.path.join(out_dir, name + ".npz"), **out)
+    manifest["cases"][name] = dict(run=kw, contig=contig, tint_id=tint_id, n_reads=len(tint["reads"]),
+                                   n_reps=len(tint["read_reps"]), raised=rec["raised"])
+    print("%-18s reads=%d reps=%d the reference raises %s" % (name, len(tint["reads"]), len(tint["read_reps"]), rec["raised"]))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--big", action="store_true", help="also mint the config-2-scale hash fixture (minutes, GBs)")
+    ap.add_argument("--only", default="", help="mint only the synthetic cases whose name starts with this prefix (e.g. b_, x_) "
+                    "and merge them into the manifest: the other fixtures' files stay as they are")
     args = ap.parse_args()
     manifest = dict(numpy=np.__version__, scipy=scipy.__version__, python=sys.version.split()[0],
                     reference="vpc-ccg/freddie py/freddie_segment.py (imported from /root/reference)", cases={})
     work = tempfile.mkdtemp(prefix="gold_in_")
     try:
-        for name, (gen_kw, run_kw) in SYNTH_CASES.items():
+        for name, (gen_kw, run_kw) in list(SYNTH_CASES.items()) + list(RAISE_CASES.items()):
+            if args.only and not name.startswith(args.only):
+                continue
             d = os.path.join(work, name)
             gkw = dict(gen_kw); idx = gkw.pop("index")
             synth.generate(idx, write_dir=d, contig="chrS", **gkw)
-            record_case(name, d, "chrS", idx, run_kw, HERE, manifest)
+            if name in RAISE_CASES:
+                record_raise_case(name, d, "chrS", idx, run_kw, HERE, manifest)
+            else:
+                record_case(name, d, "chrS", idx, run_kw, HERE, manifest)
             manifest["cases"][name]["generator"] = gen_kw
             manifest["cases"][name]["split_sha256"] = sha256_file(os.path.join(d, "chrS", "split_chrS_%d.tsv" % idx))
             manifest["cases"][name]["reads_sha256"] = sha256_file(os.path.join(d, "chrS", "reads_chrS_%d.tsv" % idx))
         edge_root = os.path.join(HERE, "edge")
-        shutil.rmtree(edge_root, ignore_errors=True)
-        for name, (tint_id, intervals, reads) in edge_cases().items():
+        if not args.only:
+            shutil.rmtree(edge_root, ignore_errors=True)
+        for name, (tint_id, intervals, reads) in ({} if args.only else edge_cases()).items():
             d = os.path.join(edge_root, name)
             write_edge(d, "chrE", tint_id, intervals, reads, seed=tint_id)
             record_case(name, d, "chrE", tint_id, {}, HERE, manifest)
@@ -211,10 +260,11 @@ def main():
         shutil.rmtree(work, ignore_errors=True)
     old = {}
     mp = os.path.join(HERE, "MANIFEST.json")
-    if os.path.exists(mp) and not args.big:
+    if os.path.exists(mp) and (not args.big or args.only):
         old = json.load(open(mp)).get("cases", {})
-        if "g4_config2" in old:
-            manifest["cases"]["g4_config2"] = old["g4_config2"]
+        for k, v in old.items():
+            if k == "g4_config2" or args.only:
+                manifest["cases"].setdefault(k, v)
     json.dump(manifest, open(mp, "w"), indent=1, sort_keys=True)
 
 

@@ -32,10 +32,12 @@ def ref():
 
 
 def run_recorded(split_dir, outdir, contig, tint_id, sigma=5.0, threshold_rate=0.9, variance_factor=3.0,
-                 max_problem_size=50, min_read_support_outside=3, consider_ends=False):
+                 max_problem_size=50, min_read_support_outside=3, consider_ends=False, allow_raise=False):
     """Runs the reference's own run_segment() (py/freddie_segment.py:681-735) on one partition,
     writing ``<outdir>/<contig>/segment_<contig>_<tint>.tsv`` with the reference's writer.
-    Returns (tint, rec): the mutated tint dict and a dict of recorded intermediates."""
+    Returns (tint, rec): the mutated tint dict and a dict of recorded intermediates.
+    ``allow_raise``: an exception of the reference (its own assertions, an IndexError of ``break_large_problems`` :640) is
+    recorded as ``rec["raised"]`` (type name and message) instead of propagating; the tint is the parsed input then."""
     R = ref()
     rec = dict(Y_raw=None, Y=[], cands=[], fixed=[], final_c=[], refine=[], problems=[], tint=None)
     names = ["gaussian_filter1d", "candidates_from_peaks", "break_large_problems", "run_optimize",
@@ -102,8 +104,13 @@ def run_recorded(split_dir, outdir, contig, tint_id, sigma=5.0, threshold_rate=0
         os.makedirs(os.path.join(outdir, contig), exist_ok=True)
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            R.run_segment((split_dir, outdir, contig, tint_id, sigma, table, threshold_rate, variance_factor,
-                           max_problem_size, min_read_support_outside, not consider_ends))
+            try:
+                R.run_segment((split_dir, outdir, contig, tint_id, sigma, table, threshold_rate, variance_factor,
+                               max_problem_size, min_read_support_outside, not consider_ends))
+            except (AssertionError, IndexError) as e:
+                if not allow_raise:
+                    raise
+                rec["raised"] = "%s: %s" % (type(e).__name__, e)
             vals = np.array([v for y in rec["Y"] for v in y if v > 0])
             rec["threshold"] = float(vals.mean() + variance_factor * vals.std())
         rec["h_table"] = [float(v) for v in table]

@@ -11,7 +11,12 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def names():
-    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+    return sorted(n for n in (os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))) if not n.startswith("x_"))
+
+
+def raising_names():
+    """Fixtures of inputs on which the reference itself raises (x_*.npz: inputs + the exception's text)."""
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "x_*.npz")))
 
 
 def manifest():

@@ -18,6 +18,17 @@ CASES = [
     ("mps100", dict(n_reads=300, n_exons=150, rp=0.3, max_span=0), dict(max_problem_size=100)),
     ("mps100_vf9", dict(n_reads=300, n_exons=150, rp=0.3, max_span=0), dict(max_problem_size=100, variance_factor=9.0)),
     ("sigma12", dict(n_reads=400, n_exons=80, rp=0.3, jp=0.5, jsd=4, max_span=0), dict(sigma=12.0, min_read_support_outside=0)),
+    # the CLI's parameter bounds (parse_args :104-109)
+    ("sigma50", dict(n_reads=300, n_exons=40, rp=0.1), dict(sigma=50.0)),
+    ("sigma50_dense", dict(n_reads=200, n_exons=60, rp=0.0), dict(sigma=50.0)),
+    ("sigma50_refine", dict(n_reads=600, n_exons=60, rp=0.2, max_span=0), dict(sigma=50.0, min_read_support_outside=1000)),
+    ("sigma01", dict(n_reads=300, n_exons=60, rp=0.1, jp=0.5), dict(sigma=0.1)),
+    ("sigma01_refine", dict(n_reads=600, n_exons=60, rp=0.2, max_span=0), dict(sigma=0.1, min_read_support_outside=1000)),
+    ("tau05", dict(n_reads=300, n_exons=60, rp=0.1), dict(threshold_rate=0.5)),
+    ("tau051", dict(n_reads=300, n_exons=60, rp=0.1), dict(threshold_rate=0.51)),
+    ("vf001", dict(n_reads=300, n_exons=60, rp=0.1), dict(variance_factor=0.01)),
+    ("vf999", dict(n_reads=300, n_exons=60, rp=0.1), dict(variance_factor=9.99)),
+    ("mps5", dict(n_reads=300, n_exons=60, rp=0.3, max_span=0), dict(max_problem_size=5)),
 ]
 
 

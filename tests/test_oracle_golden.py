@@ -46,3 +46,24 @@ def test_tables_match_reference_constants():
         g = goldens.load(name)
         assert np.array_equal(g["w_main"], tables.gaussian_half_kernel(float(g["sigma"]), 4.0))
         assert np.array_equal(g["h_table"], np.array(tables.smooth_threshold(float(g["threshold_rate"]))))
+
+
+@pytest.mark.parametrize("name", goldens.raising_names())
+def test_oracle_refuses_what_the_reference_raises_on(name):
+    """x_*.npz: inputs on which the reference itself raises (break_large_problems :640 with max_problem_size = 4)."""
+    g = goldens.load(name)
+    assert str(g["raised"]).split(":")[0] in ("IndexError", "AssertionError")
+    o = util.run_oracle(goldens.partition_of(g), goldens.params_of(g), goldens.tables_of(g))
+    assert o["error"] != 0 and "break_large_problems" in o["errmsg"]
+
+
+def test_goldens_reach_the_cli_parameter_bounds():
+    """parse_args :104-109: 0 < sigma <= 50, 0.5 <= threshold_rate <= 1, 0 < variance_factor < 10, max_problem_size > 3."""
+    runs = [c["run"] for c in goldens.manifest()["cases"].values()]
+    assert {50.0, 0.1} <= {r["sigma"] for r in runs}
+    assert {0.5, 0.51} <= {r["threshold_rate"] for r in runs}
+    assert {0.01, 9.99} <= {r["variance_factor"] for r in runs}
+    assert {4, 5} <= {r["max_problem_size"] for r in runs}
+    g = goldens.load("b_sigma50_dense")
+    assert len(g["w_main"]) == 201 and (g["iv_end"] - g["iv_start"] + 1).min() < 200     # intervals shorter than the radius
+    assert len(goldens.load("b_sigma01")["w_main"]) == 1                                  # radius 0
