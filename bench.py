@@ -294,6 +294,43 @@ def committed_counters(workload, source_hash=None):
     return doc.get(workload)
 
 
+def reference_cpu(workload, value, cpu_one, e2e=None):
+    """The REFERENCE's own CPU figure for this workload, as recorded by tools/ref_cpu.py in the BUILD CONTAINER (the reference
+    never travels to the GPU box): the unmodified reference CLI on the first partitions of the very split directories this
+    benchmark's generator writes, `-t 1` and `-t <cores>`.  Quoted here next to cpu_baseline (the C port timed on this box),
+    with the ratios a reader wants: this run's value over the reference at one core and at all of the container's cores, and
+    the port's one-core rate over the reference's (what "kind: port" hides).  Different machines: the ratios are reported,
+    not claimed as a same-box speed-up."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "reference_cpu.json")) as f:
+            doc = json.load(f)
+    except (OSError, ValueError):
+        return None
+    run = (doc.get("runs") or {}).get(workload)
+    if not run:
+        return None
+    by = {int(t): r for t, r in run["by_threads"].items()}
+    t1, tn = by.get(1), by.get(max(by))
+    out = {"kind": "reference", "where": "%s, %d vCPU (%s)" % (doc.get("where", "build container"), doc.get("cores", 0), doc.get("cpu", "?")),
+           "versions": "python %s, numpy %s, scipy %s" % (doc.get("python"), doc.get("numpy"), doc.get("scipy")),
+           "sample": "%d partitions (%d reads) of %s, indices 0.., params %s; input sha256 %s" % (
+               run["partitions"], run["reads"], workload, run["params"], run["input_sha256"][:16]),
+           "unit": "reads/s", "by_threads": {str(t): r["reads_per_s"] for t, r in sorted(by.items())},
+           "outputs_identical_across_threads": all(r.get("same_bytes_as_first") for r in by.values()),
+           "source": "profiles/reference_cpu.json (tools/ref_cpu.py, %s)" % doc.get("date")}
+    if t1:
+        out["value"] = t1["reads_per_s"]; out["cores"] = 1
+        out["this_run_over_reference_1_core"] = value / t1["reads_per_s"]
+        if cpu_one and cpu_one.get("value"):
+            out["port_over_reference_per_core"] = cpu_one["value"] / t1["reads_per_s"]
+    if tn and max(by) > 1:
+        out["this_run_over_reference_%d_cores" % max(by)] = value / tn["reads_per_s"]
+        # like for like with the reference's CLI (files in, files out, process start-up included): the drop-in CLI's e2e leg
+        if e2e and e2e.get("value"):
+            out["e2e_cli_over_reference_%d_cores" % max(by)] = e2e["value"] / tn["reads_per_s"]
+    return out
+
+
 def stage_algorithmic_bytes(batch, sizes, part_final_off, scoring_bytes):
     """SURVEY.md 8(d) / BASELINE.md section 4: algorithmic bytes per stage of one batch, every input read once and every output
     written once in the reference's own dtypes (P positions, I exons, R read reps, N candidates, K intervals, F final
@@ -692,6 +729,7 @@ def main():
             cpu_one = cpu_baseline(batches, params, tabs)
         out["cpu_baseline"] = cpu_one
         out["cpu_baseline_all_cores"] = cpu_all
+        out["reference_cpu"] = reference_cpu(args.workload, out["value"], cpu_one, e2e)
         out["e2e"] = e2e
         print(json.dumps(out))
     for ctx in ctxs:

@@ -58,7 +58,7 @@ TAPS = dict(pos_off=(1, np.int64), y_raw=(2, np.int32), y=(3, np.float64), thres
             cand_off=(5, np.int64), cand_y=(6, np.int32), fixed=(7, np.uint8), chosen=(8, np.uint8),
             final_off=(9, np.int64), final_y=(10, np.int32), problems=(11, np.int32),
             lane_start=(12, np.int32), lane_pmax=(13, np.int32), lane_exons=(14, np.int64),
-            lane_stream=(15, np.int32), exon_stream=(16, np.int32))
+            lane_stream=(15, np.int32), exon_stream=(16, np.int32), sync=(17, np.int32))
 
 
 def lib_path():

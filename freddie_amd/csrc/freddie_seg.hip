@@ -75,6 +75,7 @@ enum : unsigned {
     kErrWideMissed = 16384u,   // internal: a problem keeps more reads than k_prob_range counted for it (the 8-bit instance met it)
     kErrWaveStage = 8192u,     // a wave kernel (k_wave) met a read with more exons than its LDS stage holds: rerun without them
     kErrScanStall = 4096u,     // the look-back scan gave up waiting for a predecessor block: rerun with the three-pass scan
+    kErrSyncTimeout = 32768u,  // a device-side waiter of the scoring stage (k_wait_word) gave up: the stage was skipped, rerun with events
     kErrNeedWideDp = 2048u,    // a problem sees >= 65536 reads: its DP needs the 32-bit count table    // a problem is larger than the LDS carve-up this launch was sized for
 };
 
@@ -112,12 +113,42 @@ struct Status {
     unsigned gate;          // large-class workgroups that have started (k_gate holds the small classes back until they are placed)
                             // (a counter of the mid class's 2 000 workgroups, bumped by each as it started, cost that kernel 10 of
                             // its 62 us: these two count a few hundred)
+    unsigned sync_abort;    // a device-side waiter timed out: the scoring kernels behind it end at once (their input may not exist yet)
+    unsigned pad2;
+};
+// Words of the device-side fork / join of the scoring stage (own allocation, zeroed once; generations only grow): see k_wait_word.
+struct SyncWords {
+    unsigned emit_gen;      // generation of the last scoring stage whose problem list is complete (published by the first launch behind
+                            // k_prob_emit on the main stream): the side streams' waiters spin on it
+    unsigned side_gen[4];   // generation of the last scoring stage whose chain on side stream k has ended (k_signal)
+    unsigned emit_ctr;      // FSEG_EMIT_SIGNAL=1: workgroups of k_prob_emit that have finished (the last one publishes emit_gen and resets this)
+    unsigned pad[2];
 };
 
 // ---------------------------------------------------------------------------------------------
 // small device helpers
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// k_prob_emit's LAST workgroup publishes the stage's generation itself (FSEG_EMIT_SIGNAL=0: left to the first launch behind it on
+// the main stream) -- the side streams start ~6 us earlier: config4 0.130 -> 0.123 ms, config3 0.148 -> 0.144, k_prob_emit as long as before.  Every workgroup pays one release to the device (its stores have reached L2: s_waitcnt +
+// barrier; thread 0's release writes the XCD's dirty L2 lines back).  As __threadfence() in every wave it took the kernel from 17
+// to 106 us (four write-backs AND four L2 invalidations per workgroup, in a kernel that lives on L2 hits).
+__device__ __forceinline__ void emit_done(SyncWords *sw, unsigned gen) {
+    if (!sw) return;
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned done = __hip_atomic_fetch_add(&sw->emit_ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == gridDim.x - 1) {
+            __hip_atomic_store(&sw->emit_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&sw->emit_gen, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+// (asked beside the first descriptor load and tested behind it: no dependent load of its own in a problem's chain)
+__device__ __forceinline__ unsigned stage_aborted(const Status *st) { return __hip_atomic_load(&st->sync_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 
 // index of the last element of a[0..n) that is <= x  (a ascending, a[0] <= x)
 template <typename T, typename X>
@@ -846,14 +877,108 @@ __global__ void __launch_bounds__(256) k_vplan(int n_part, const i64 *part_iv_of
 // a[16+q] + ... in that order; the 8 accumulators are combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) by
 // three xor-shuffles (IEEE addition is commutative, so both partners get identical bits), the tail (len%8)
 // is added left to right, and the leaves are combined in recursion order.
-__global__ void __launch_bounds__(512) k_vsum_chunks(int n_part, const i64 *voff, const i64 *chunk_off, const double *v,
-                                                     const double *csum0, int pass, double *csum, i64 chunk_cap) {
+struct VsumLds {
     // leaves of the pairwise recursion, left to right; a partial chunk's tree is kept in heap order (root 1,
     // children 2i / 2i+1; depth <= 7): node_kind 1 = leaf, 2 = inner node
-    __shared__ int leaf_off[128], leaf_len[128], leaf_heap[128];
-    __shared__ double node_val[256];
-    __shared__ unsigned char node_kind[256];
-    __shared__ int n_leaf_s, wave0_leaves;
+    int leaf_off[128], leaf_len[128], leaf_heap[128];
+    double node_val[256];
+    unsigned char node_kind[256];
+    int n_leaf_s, wave0_leaves;
+};
+// numpy's pairwise sum of ONE chunk (m <= 8192 values at a; pass 1: of (v - mu)^2) by a 512-thread workgroup; the result is
+// valid in thread 0.  Starts with a barrier (the previous chunk is done with L).
+__device__ __forceinline__ double vsum_chunk(const double *a, int m, int pass, double mu, VsumLds &L) {
+    __syncthreads();
+    if (m == 8192) {
+        // perfect tree: 64 leaves of 128
+        for (int t = threadIdx.x; t < 64; t += blockDim.x) { L.leaf_off[t] = t * 128; L.leaf_len[t] = 128; L.leaf_heap[t] = 64 + t; }
+        if (threadIdx.x == 0) L.n_leaf_s = 64;
+    } else {
+        // every leaf but a lone one has at least 64 elements, so it holds exactly one x = 64 t with x - off < 64:
+        // thread t walks the recursion (n2 = len/2 rounded down to a multiple of 8) down to the leaf of x
+        if (threadIdx.x < 256) L.node_kind[threadIdx.x] = 0;
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            const int x = threadIdx.x * 64;
+            int off = 0, len = m, h = 1;
+            bool own = false;
+            if (x < m) {
+                while (len > 128) {
+                    int n2 = len / 2; n2 -= n2 % 8;
+                    if (x < off + n2) { len = n2; h = 2 * h; } else { off += n2; len -= n2; h = 2 * h + 1; }
+                }
+                own = x - off < 64;
+            }
+            const u64 mk = __ballot(own);
+            if (threadIdx.x == 0) L.wave0_leaves = __popcll(mk);
+            __syncthreads();
+            if (own) {
+                const int rank = __popcll(mk & ((1ULL << lane_id()) - 1ULL)) + (threadIdx.x >= 64 ? L.wave0_leaves : 0);
+                L.leaf_off[rank] = off; L.leaf_len[rank] = len; L.leaf_heap[rank] = h;
+                L.node_kind[h] = 1;
+                for (int anc = h >> 1; anc >= 1; anc >>= 1) L.node_kind[anc] = 2;
+            }
+            if (threadIdx.x == 64) L.n_leaf_s = L.wave0_leaves + __popcll(mk);
+        } else __syncthreads();
+    }
+    __syncthreads();
+    int nl = L.n_leaf_s;
+    const int q = threadIdx.x & 7;
+#define FSEG_VAL(x) (pass ? __dmul_rn(__dsub_rn((x), mu), __dsub_rn((x), mu)) : (x))
+    for (int t0 = 0; t0 < nl; t0 += 64) {
+        int t = t0 + (threadIdx.x >> 3);
+        double res = 0.0;
+        if (t < nl) {
+            const double *b = a + L.leaf_off[t];
+            int len = L.leaf_len[t];
+            if (len < 8) {
+                for (int i = 0; i < len; ++i) res = __dadd_rn(res, FSEG_VAL(b[i]));      // from 0.0, left to right
+            } else {
+                int body = len - (len % 8);
+                double x[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) x[i] = (8 * i + q < body) ? b[8 * i + q] : 0.0;
+                double r = FSEG_VAL(x[0]);
+#pragma unroll
+                for (int i = 1; i < 16; ++i) if (8 * i + q < body) r = __dadd_rn(r, FSEG_VAL(x[i]));
+                r = __dadd_rn(r, __shfl_xor(r, 1));
+                r = __dadd_rn(r, __shfl_xor(r, 2));
+                r = __dadd_rn(r, __shfl_xor(r, 4));
+                res = r;
+                for (int i = body; i < len; ++i) res = __dadd_rn(res, FSEG_VAL(b[i]));
+            }
+        }
+        if (t < nl && q == 0) L.node_val[L.leaf_heap[t]] = res;
+    }
+#undef FSEG_VAL
+    __syncthreads();
+    double out = 0.0;
+    if (m == 8192) {
+        // perfect tree over 64 leaves: adjacent pairs level by level = xor butterfly on one wave
+        if (threadIdx.x < 64) {
+            double x = L.node_val[64 + threadIdx.x];
+            for (int d = 1; d < 64; d <<= 1) x = __dadd_rn(x, __shfl_xor(x, d));
+            out = x;
+        }
+    } else {
+        // inner nodes bottom-up, one tree level per step: sum(left) + sum(right)
+        for (int lvl = 6; lvl >= 0; --lvl) {
+            const int i = (1 << lvl) + threadIdx.x;
+            if ((int)threadIdx.x < (1 << lvl) && L.node_kind[i] == 2) L.node_val[i] = __dadd_rn(L.node_val[2 * i], L.node_val[2 * i + 1]);
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) out = L.node_val[1];
+    }
+    return out;
+}
+// one 512-thread workgroup per chunk; pass 0 sums v, pass 1 sums (v-mean)^2.
+// Thread (leaf, q) owns accumulator q of the 8-lane leaf of the pairwise recursion: r[q] = a[q] + a[8+q] +
+// a[16+q] + ... in that order; the 8 accumulators are combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) by
+// three xor-shuffles (IEEE addition is commutative, so both partners get identical bits), the tail (len%8)
+// is added left to right, and the leaves are combined in recursion order.
+__global__ void __launch_bounds__(512) k_vsum_chunks(int n_part, const i64 *voff, const i64 *chunk_off, const double *v,
+                                                     const double *csum0, int pass, double *csum, i64 chunk_cap) {
+    __shared__ VsumLds L;
     __shared__ double mu_s;
     i64 n_chunks = chunk_off[n_part];
     if (n_chunks > chunk_cap) n_chunks = chunk_cap;
@@ -878,85 +1003,113 @@ __global__ void __launch_bounds__(512) k_vsum_chunks(int n_part, const i64 *voff
             __syncthreads();
             mu = mu_s;
         }
-        if (m == 8192) {
-            // perfect tree: 64 leaves of 128
-            for (int t = threadIdx.x; t < 64; t += blockDim.x) { leaf_off[t] = t * 128; leaf_len[t] = 128; leaf_heap[t] = 64 + t; }
-            if (threadIdx.x == 0) n_leaf_s = 64;
-        } else {
-            // every leaf but a lone one has at least 64 elements, so it holds exactly one x = 64 t with x - off < 64:
-            // thread t walks the recursion (n2 = len/2 rounded down to a multiple of 8) down to the leaf of x
-            if (threadIdx.x < 256) node_kind[threadIdx.x] = 0;
+        const double x = vsum_chunk(a, m, pass, mu, L);
+        if (threadIdx.x == 0) csum[c] = x;
+    }
+}
+// The whole threshold of a partition by ONE 512-thread workgroup (round 5; batches of many partitions of moderate size): the
+// partition's Y > 0 values are compacted into its own piece of v (it starts where the partition's positions start: no batch-wide
+// scan, no offsets), summed chunk by chunk in numpy's order (vsum_chunk, the same function the chunk kernel uses), the mean,
+// the squared deviations likewise, the threshold.  One launch instead of seven to nine (k_scan1 / k_scan2 / k_scan_emit<values>,
+// k_voff, k_vplan, k_vsum_chunks twice, k_vsum_part): 0.106 ms of launch-latency-sized pieces per 250 k-read batch.
+constexpr int kThrPartMaxChunks = 128;     // chunk sums a workgroup keeps in LDS: partitions of up to 2^20 positions
+// A wave compacts the flagged values of its 2048 positions w0 .. w0 + 2047 (fm: the flag word of lane l's 32 positions, w0 + 32 l ..)
+// into v[ex ..) and returns their number.  Rows of 64 positions (lane = column), so the loads of y and the stores are coalesced;
+// a row's 64 flags are the words of lanes 2q and 2q + 1 (two readlanes); rows without a flag are skipped (the values Y > 0 come
+// in runs of 2 * radius + 1 around the splice sites) and the values of eight rows are loaded together from clamped addresses.
+__device__ __forceinline__ int wave_emit_values(i64 w0, i64 n_pos, unsigned fm, i64 ex, const double *__restrict__ y, double *v) {
+    const int lane = lane_id();
+    const u64 lt_mask = (1ULL << lane) - 1ULL;
+    u64 rows;
+    {
+        const u64 lanes_set = __ballot(fm != 0);                 // bit l: lane l's 32 positions hold a flag
+        u64 pairs = (lanes_set | (lanes_set >> 1)) & 0x5555555555555555ULL;     // bit 2q: row q
+        pairs = (pairs | (pairs >> 1)) & 0x3333333333333333ULL;
+        pairs = (pairs | (pairs >> 2)) & 0x0f0f0f0f0f0f0f0fULL;
+        pairs = (pairs | (pairs >> 4)) & 0x00ff00ff00ff00ffULL;
+        pairs = (pairs | (pairs >> 8)) & 0x0000ffff0000ffffULL;
+        rows = (pairs | (pairs >> 16)) & 0x00000000ffffffffULL;
+    }
+    int cnt = 0;
+    while (rows) {
+        u64 m[8];
+        double yv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {                            // the next eight rows that hold flags
+            const int q = rows ? (int)__builtin_ctzll(rows) : -1;
+            rows = rows ? rows & (rows - 1) : 0;
+            const int qq = q < 0 ? 0 : q;
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)fm, 2 * qq);
+            const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)fm, 2 * qq + 1);
+            m[e] = q < 0 ? 0 : ((u64)lo | ((u64)hi << 32));
+            const i64 i = w0 + qq * 64 + lane;
+            yv[e] = y[i < n_pos ? i : n_pos - 1];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (!m[e]) continue;
+            if ((m[e] >> lane) & 1ULL) v[ex + cnt + __popcll(m[e] & lt_mask)] = yv[e];
+            cnt += __popcll(m[e]);
+        }
+    }
+    return cnt;
+}
+__global__ void __launch_bounds__(512) k_thr_part(int n_part, const i64 *part_iv_off, const i64 *pos_off, i64 n_pos, const unsigned *flags,
+                                                  const double *__restrict__ y, double *v, double vf, double *mean, double *thr) {
+    __shared__ VsumLds L;
+    __shared__ int wave_cnt[8];
+    __shared__ double cs[kThrPartMaxChunks];
+    __shared__ double mu_s;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    for (int p = blockIdx.x; p < n_part; p += gridDim.x) {
+        const i64 pos0 = pos_off[part_iv_off[p]], pos1 = pos_off[part_iv_off[p + 1]];
+        double *vp = v + pos0;
+        // compaction: the partition's flag words in groups of 64 (2048 positions), every wave an eighth of the groups
+        const i64 wbeg = pos0 >> 5, wend = (pos1 + 31) >> 5;
+        const i64 groups = (wend - wbeg + 63) / 64, gpw = (groups + 7) / 8;
+        const i64 g0 = (i64)wave * gpw, g1 = g0 + gpw < groups ? g0 + gpw : groups;
+        auto flag_word = [&](i64 wd) -> unsigned {
+            if (wd >= wend) return 0u;
+            unsigned f = flags[wd];
+            const i64 i0 = wd << 5;
+            if (i0 < pos0) f &= ~0u << (int)(pos0 - i0);
+            if (i0 + 32 > pos1) f &= (1u << (int)(pos1 - i0)) - 1u;
+            return f;
+        };
+        int cnt = 0;
+        for (i64 g = g0; g < g1; ++g) cnt += __popc(flag_word(wbeg + g * 64 + lane));
+        for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
+        if (lane == 0) wave_cnt[wave] = cnt;
+        __syncthreads();
+        i64 ex = 0;
+        int nv = 0;
+        for (int w = 0; w < 8; ++w) { if (w < wave) ex += wave_cnt[w]; nv += wave_cnt[w]; }
+        for (i64 g = g0; g < g1; ++g) ex += wave_emit_values((wbeg + g * 64) << 5, n_pos, flag_word(wbeg + g * 64 + lane), ex, y, vp);
+        __builtin_amdgcn_s_waitcnt(0);                  // the values are read back by other waves of this workgroup
+        __syncthreads();
+        const int nch = (nv + 8191) / 8192;
+        double s_acc[2] = {0.0, 0.0};
+        for (int pass = 0; pass < 2; ++pass) {
+            const double mu = pass ? mu_s : 0.0;
+            for (int c = 0; c < nch; ++c) {
+                const int m = nv - c * 8192 < 8192 ? nv - c * 8192 : 8192;
+                const double x = vsum_chunk(vp + (i64)c * 8192, m, pass, mu, L);
+                if (threadIdx.x == 0) cs[c] = x;
+            }
+            if (threadIdx.x == 0) {
+                double sacc = 0.0;
+                for (int c = 0; c < nch; ++c) sacc = c == 0 ? cs[0] : __dadd_rn(sacc, cs[c]);     // numpy adds its chunks left to right
+                s_acc[pass] = sacc;
+                if (pass == 0) mu_s = sacc / (double)nv;                                         // empty -> 0/0 = NaN like numpy
+            }
             __syncthreads();
-            if (threadIdx.x < 128) {
-                const int x = threadIdx.x * 64;
-                int off = 0, len = m, h = 1;
-                bool own = false;
-                if (x < m) {
-                    while (len > 128) {
-                        int n2 = len / 2; n2 -= n2 % 8;
-                        if (x < off + n2) { len = n2; h = 2 * h; } else { off += n2; len -= n2; h = 2 * h + 1; }
-                    }
-                    own = x - off < 64;
-                }
-                const u64 mk = __ballot(own);
-                if (threadIdx.x == 0) wave0_leaves = __popcll(mk);
-                __syncthreads();
-                if (own) {
-                    const int rank = __popcll(mk & ((1ULL << lane_id()) - 1ULL)) + (threadIdx.x >= 64 ? wave0_leaves : 0);
-                    leaf_off[rank] = off; leaf_len[rank] = len; leaf_heap[rank] = h;
-                    node_kind[h] = 1;
-                    for (int anc = h >> 1; anc >= 1; anc >>= 1) node_kind[anc] = 2;
-                }
-                if (threadIdx.x == 64) n_leaf_s = wave0_leaves + __popcll(mk);
-            } else __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            const double mu = mu_s;
+            mean[p] = mu;
+            thr[p] = __dadd_rn(mu, __dmul_rn(vf, __dsqrt_rn(s_acc[1] / (double)nv)));             // :758-759
         }
         __syncthreads();
-        int nl = n_leaf_s;
-        const int q = threadIdx.x & 7;
-#define FSEG_VAL(x) (pass ? __dmul_rn(__dsub_rn((x), mu), __dsub_rn((x), mu)) : (x))
-        for (int t0 = 0; t0 < nl; t0 += 64) {
-            int t = t0 + (threadIdx.x >> 3);
-            double res = 0.0;
-            if (t < nl) {
-                const double *b = a + leaf_off[t];
-                int len = leaf_len[t];
-                if (len < 8) {
-                    for (int i = 0; i < len; ++i) res = __dadd_rn(res, FSEG_VAL(b[i]));      // from 0.0, left to right
-                } else {
-                    int body = len - (len % 8);
-                    double x[16];
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) x[i] = (8 * i + q < body) ? b[8 * i + q] : 0.0;
-                    double r = FSEG_VAL(x[0]);
-#pragma unroll
-                    for (int i = 1; i < 16; ++i) if (8 * i + q < body) r = __dadd_rn(r, FSEG_VAL(x[i]));
-                    r = __dadd_rn(r, __shfl_xor(r, 1));
-                    r = __dadd_rn(r, __shfl_xor(r, 2));
-                    r = __dadd_rn(r, __shfl_xor(r, 4));
-                    res = r;
-                    for (int i = body; i < len; ++i) res = __dadd_rn(res, FSEG_VAL(b[i]));
-                }
-            }
-            if (t < nl && q == 0) node_val[leaf_heap[t]] = res;
-        }
-#undef FSEG_VAL
-        __syncthreads();
-        if (m == 8192) {
-            // perfect tree over 64 leaves: adjacent pairs level by level = xor butterfly on one wave
-            if (threadIdx.x < 64) {
-                double x = node_val[64 + threadIdx.x];
-                for (int d = 1; d < 64; d <<= 1) x = __dadd_rn(x, __shfl_xor(x, d));
-                if (threadIdx.x == 0) csum[c] = x;
-            }
-        } else {
-            // inner nodes bottom-up, one tree level per step: sum(left) + sum(right)
-            for (int lvl = 6; lvl >= 0; --lvl) {
-                const int i = (1 << lvl) + threadIdx.x;
-                if ((int)threadIdx.x < (1 << lvl) && node_kind[i] == 2) node_val[i] = __dadd_rn(node_val[2 * i], node_val[2 * i + 1]);
-                __syncthreads();
-            }
-            if (threadIdx.x == 0) csum[c] = node_val[1];
-        }
     }
 }
 __global__ void k_vsum_part(int n_part, const i64 *voff, const i64 *chunk_off, const double *csum0, const double *csum1,
@@ -1489,7 +1642,8 @@ __global__ void __launch_bounds__(256) k_prob_emit(Status *st, const int *cand_p
                                                    ProblemArrays pr, i64 prob_cap, int2 *work_pc, int4 *cls_items,
                                                    i64 work_cap, int *dp_items, ProbDesc *desc, const int *iv_start,
                                                    const int *iv_part, const i64 *part_lane_off, ProbSplit sp, int *solve_items,
-                                                   ProbDesc *solve_desc, int *wide_items, int *wide_all, const unsigned char *cand_wide) {
+                                                   ProbDesc *solve_desc, int *wide_items, int *wide_all, const unsigned char *cand_wide,
+                                                   SyncWords *sw, unsigned sync_gen) {
     __shared__ i64 lds[4 * kProbCols];
     __shared__ int l_slot[kProbBlock], l_cnt[kProbBlock];
     __shared__ int l_mx[8];
@@ -1645,6 +1799,7 @@ __global__ void __launch_bounds__(256) k_prob_emit(Status *st, const int *cand_p
         }
         __syncthreads();
     }
+    emit_done(sw, sync_gen);
 }
 
 // pair index q = j*(j-1)/2 + i (i < j);  triple rank = k*(k-1)*(k-2)/6 + j*(j-1)/2 + i (i < j < k)
@@ -2783,11 +2938,13 @@ __global__ void __launch_bounds__(256, WaveCfg<NM>::kOcc) k_wave(Status *st, con
     // list 3: k_tiny's problems (behind the three solve lists); list 0: the small class.  lb_h >= 0: bounds from the host (a sized batch)
     const i64 list_base = lb_h >= 0 ? lb_h : (list == 3 ? (i64)st->solve_cls[0] + (i64)st->solve_cls[1] + (i64)st->solve_cls[2] : 0);
     const i64 list_n = lb_h >= 0 ? ln_h : (list == 3 ? (i64)st->n_tiny : (i64)st->solve_cls[0]);
+    const unsigned aborted = stage_aborted(st);                     // (a waiter in front of this launch gave up: the lists may not exist)
     for (i64 t = (i64)blockIdx.x + (i64)wave * gridDim.x; t < list_n; t += (i64)gridDim.x * 4) {
 #ifdef FSEG_SCORE_TIMING
         const unsigned long long t_prob0 = wall_clock64();
 #endif
         const ProbDesc d = FSEG_LOAD_DESC(desc + list_base + t);          // (the list's own copy of the record: k_prob_emit)
+        if (aborted) return;
         const int p = d.w0;
         const int n = d.n;
         if (n > NM || n < 3) { if (lane == 0) atomicOr(&st->err, kErrOverflowNm); continue; }       // (wave-uniform)
@@ -2947,16 +3104,56 @@ __global__ void __launch_bounds__(256, WaveCfg<NM>::kOcc) k_wave(Status *st, con
 // large class running alone on a mostly empty chip.  k_gate is what the side stream runs first: one wave that waits until the
 // large class's workgroups have all started (they all fit the chip at once) or `max_ticks` of the 100 MHz clock have passed --
 // an exit every launch reaches -- so the small classes fill the space the large one leaves instead of taking it first.
-__global__ void __launch_bounds__(64) k_gate(Status *st, int which, unsigned grid, unsigned max_ticks) {
+__global__ void __launch_bounds__(64) k_gate(Status *st, int which, unsigned grid, unsigned max_ticks, unsigned *signal_word, unsigned signal_gen) {
+    // signal_word: this is the first launch behind k_prob_emit on the main stream -- the problem list is complete and released
+    // (the kernel boundary): tell the side streams' waiters (k_wait_word)
+    if (signal_word && threadIdx.x == 0) __hip_atomic_store(signal_word, signal_gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     // grid: the large class's workgroups the plan has launched (8-bit instance, and for the start gate the 16-bit one's too), at
     // most as many as fit the chip at once
     const unsigned want = grid;
     const unsigned *ctr = which == 2 ? &st->gate_wide : &st->gate;      // (2: the 16-bit instance's workgroups)
     const unsigned long long t0 = wall_clock64();
-    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want && wall_clock64() - t0 < max_ticks)
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want && wall_clock64() - t0 < max_ticks && !stage_aborted(st))
         __builtin_amdgcn_s_sleep(16);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Device-side fork and join of the scoring stage (round 5).  A dependency between two streams made of hipEventRecord +
+// hipStreamWaitEvent costs 10-15 us on this runtime (a marker packet on one queue, a barrier packet on the other): with the
+// stage's chains on three streams that was 31 of the 145 us between k_prob_emit's end and k_segments' start
+// (profiles/r04_config4_stage_timeline.txt).  Instead:
+//   fork: the side streams are forked EARLY by an event (before k_fix, or at the start of the piece that holds k_prob_emit: the
+//         event's latency hides behind the kernels in front of the stage) and then run k_wait_word: one wave that sleeps until
+//         the FIRST launch behind k_prob_emit on the main stream -- the plan's k_gate, else a k_signal -- has published this run's
+//         generation.  (Published by k_prob_emit's own last workgroup the side streams started 5 us earlier, but a release
+//         fence per workgroup -- buffer_wbl2 sc1: the XCD's whole L2 is searched for dirty lines, by 600 waves -- took the kernel
+//         from 17 to 106 us: the release that costs nothing is the one at a kernel's end.)
+//   join: the last launch of a side chain is k_signal (the chain's generation, stored with release order once the kernels in
+//         front of it on that stream have ended), and the main stream runs k_wait_word on those words in front of k_segments.
+// Every waiter has an exit every launch reaches: after `max_ticks` of the 100 MHz clock it raises kErrSyncTimeout and
+// Status::sync_abort -- the scoring kernels behind it end at once (their lists may not exist yet) and the host reruns the batch
+// with events (FSEG_DEV_SYNC=0).  A waiter must never sit on the hardware queue of the stream it waits for: the process's
+// fourth stream shares a queue with the first, so only side streams 0 and 1 take waiters; a third keeps events.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool gen_reached(unsigned have, unsigned want) { return (int)(have - want) >= 0; }
+__global__ void __launch_bounds__(64) k_wait_word(Status *st, const unsigned *words, int n_words, unsigned gen, unsigned max_ticks) {
+    const int lane = lane_id();
+    const unsigned *w = words + (lane < n_words ? lane : 0);
+    const unsigned long long t0 = wall_clock64();
+    bool ok = false;
+    for (;;) {
+        ok = gen_reached(__hip_atomic_load(w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT), gen);
+        if (__all(ok) || wall_clock64() - t0 >= max_ticks) break;
+        __builtin_amdgcn_s_sleep(8);
+    }
+    if (!__all(ok) && lane == 0) {
+        __hip_atomic_store(&st->sync_abort, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        atomicOr(&st->err, kErrSyncTimeout);
+    }
+}
+__global__ void __launch_bounds__(64) k_signal(unsigned *word, unsigned gen) {
+    if (threadIdx.x == 0) __hip_atomic_store(word, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
 template <int NM> struct SolveCfg {
     static constexpr int kThreads = ScoreCfg<NM>::kThreads;
     static constexpr int kSlots = ScoreCfg<NM>::kSlots;
@@ -3030,6 +3227,7 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
     const i64 list_n = lb_h >= 0 ? ln_h : (cls < 0 ? (i64)st->solve_cls[0] + (i64)st->solve_cls[1] + (i64)st->solve_cls[2] : (i64)st->solve_cls[cls]);
     const int r_lane = threadIdx.x & 63, w_rng = wave_id();
     const bool own_wg = (i64)gridDim.x >= list_n;                    // a workgroup per problem (workgroup-uniform)
+    const unsigned aborted = stage_aborted(st);                      // (a waiter in front of this launch gave up: the lists may not exist)
 #ifdef FSEG_SCORE_TIMING
     // diagnostic build: phase clocks of the class given by tacc[15] (slots 0..5 scoring phases, 8..12 the DP's)
     __shared__ unsigned long long tick_sink[16];
@@ -3045,8 +3243,10 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
         const unsigned long long t_prob0 = wall_clock64();
 #endif
         // (wide_items: this launch goes over the list's problems that see more than kFuseLanes reads only -- list_n of them)
+        if (wide_items && aborted) return;                           // (the list of wide problems is an index into the records: not followed blindly)
         const i64 t = wide_items ? (i64)uni(wide_items[list_base + tt]) : tt;
         const ProbDesc d = FSEG_LOAD_DESC(desc + list_base + t);    // (the list's own copy of the record: k_prob_emit)
+        if (aborted) return;                                         // (workgroup-uniform)
         const int p = d.w0;
         const int n = d.n;
         __syncthreads();                                             // the previous problem's DP is done with LDS
@@ -3337,6 +3537,7 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
 // LDS for the 20-25 us of their DPs while the mid class waited for room (tools/prob_ticks.py: 250 mid-class problems in
 // flight beside them, 1 250 once they were gone).  OutT says whose problems: the 8-bit instance's or the 16-bit one's.
 // ---------------------------------------------------------------------------------------------
+constexpr i64 kSplitGridCap = 1 << 20;      // workgroups of a split-path launch: k_dpw's workgroup b does problem b of its list, so lists beyond this are not split
 inline size_t dpw_lds_for(int nm, int key_bytes, int cnt_bytes) {
     const size_t pairs = (size_t)nm * (nm - 1) / 2, tri = (size_t)nm * (nm - 1) * (nm - 2) / 6;
     return ((pairs * key_bytes + 15) & ~(size_t)15) + ((pairs * 4 + 15) & ~(size_t)15) + ((pairs + 15) & ~(size_t)15) + ((tri * cnt_bytes + 15) & ~(size_t)15);
@@ -3348,6 +3549,8 @@ __global__ void __launch_bounds__(64) k_dpw(Status *st, int nm, i64 list_base, i
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = lane_id();
     if ((i64)blockIdx.x >= list_n) return;
+    const unsigned aborted = stage_aborted(st);
+    if (wide_items && aborted) return;                  // (the list of wide problems is an index into the records: not followed blindly)
     const i64 t = wide_items ? (i64)uni(wide_items[list_base + blockIdx.x]) : (i64)blockIdx.x;
 #ifdef FSEG_SCORE_TIMING
     const unsigned long long t_dp0 = wall_clock64();
@@ -3355,6 +3558,7 @@ __global__ void __launch_bounds__(64) k_dpw(Status *st, int nm, i64 list_base, i
     const unsigned char *slot = dpx + t * dpx_stride;
     const ProbDesc d = FSEG_LOAD_DESC(desc + list_base + t);
     const int n = d.n;
+    if (aborted) return;
     if (n > nm || n > NM || n < 3 || d.lane_n > kFuseLanesWide) return;         // (k_solve has raised the error)
     if ((d.kind == kKindFusedWide) != (sizeof(OutT) != 1)) return;               // whose problem (k_prob_range)
     const int npairs = n * (n - 1) / 2, ntri = n * (n - 1) * (n - 2) / 6;
@@ -4368,6 +4572,8 @@ struct fseg_ctx {
     // batch metadata (host)
     int n_part = 0;
     i64 K = 0, R = 0, I = 0, NPOS = 0, LANES = 0;
+    i64 max_part_pos = 0;      // positions of the batch's largest partition (k_thr_part takes partitions of up to kThrPartMaxChunks * 8192)
+    int thr_part = -1;         // FSEG_THR_PART=0 / 1: the threshold per partition by one workgroup (k_thr_part) never / whenever possible; -1: batches of many partitions
     i64 max_part_lanes = 0;    // reads of the batch's largest partition (what bounds a DP sum: 32-bit keys below 2^18)
     int n_tiles = 0;
     bool expanded = false;
@@ -4418,6 +4624,11 @@ struct fseg_ctx {
     int split_dp = 7;           // FSEG_SPLIT_DP: bit 0 / 1 / 2 = the small / mid / large class hands its DPs to k_dpw (0: the DP stays the tail of k_solve's workgroups)
     i64 prob_cap = 0, work_cap = 0, pair_cap = 0, tri_cap = 0, label_cap = 0, chunk_cap = 0, cov_cap = 0;
     DevBuf d_status, d_prep, d_tacc;
+    DevBuf d_sync;               // SyncWords: the scoring stage's device-side fork / join (k_wait_word)
+    unsigned sync_gen = 0;       // generation of the last stage enqueued with device-side waiters
+    unsigned sync_ticks = 2000000u;   // what a waiter waits at most: 20 ms of the 100 MHz clock (FSEG_SYNC_TICKS; tests force a timeout with 1)
+    bool emit_signal = true;     // FSEG_EMIT_SIGNAL=0: only the first launch behind k_prob_emit tells the side streams' waiters, not k_prob_emit's last workgroup (see emit_done)
+    bool dev_sync = true;        // FSEG_DEV_SYNC=0: the stage's side streams are forked and joined with events only (also after a waiter timed out)
     Status *h_status = nullptr;   // pinned
     PrepStatus *h_prep = nullptr; // pinned
     bool prep_checked = false;   // the upload's device-side validation has been read back
@@ -4699,6 +4910,46 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
         if (r == hipSuccess) r = hipStreamWaitEvent(s, e, 0);
         if (r != hipSuccess) fj_err = r;
     };
+    // The scoring plan of this enqueue (FSEG_SCORE_PLAN, see the scoring stage below) is decided HERE: with the device-side
+    // fork (k_wait_word) its side streams are forked in front of the stage's predecessors, so that the events' latency
+    // (10-15 us each) is over when k_prob_emit ends.
+    const bool any_solve_plan = c->use_fuse && c->fuse_on;
+    const char *plan = (do_score && c->prob_cap > 0 && known && !any_arena && !c->small_batch && forking && c->n_solve[2] > 0 && any_solve_plan && wave && c->score_plan[0]) ? c->score_plan : nullptr;
+    struct PlanSegs { int n_seg = 1; bool used[4] = {true, false, false, false}; int side_of[4] = {-1, -1, -1, -1}; i64 n_wide_all = 0; bool wide_one = false; } ps;
+    if (plan) {
+        // W: the problems of every class that see more than kFuseLanes reads -- a handful per batch, most of which keep fewer
+        // and are only looked at -- in ONE launch of the large class's 16-bit instance, a workgroup each (as a launch per
+        // class on the tiny class's stream they held it back 46-60 us on config3 / config5: tools/run_gaps.py); batches
+        // with many such problems keep the per-class instances (b, m, s in a row)
+        ps.n_wide_all = c->n_wide[0] + c->n_wide[1] + c->n_wide[2];
+        ps.wide_one = c->wide_one_max > 0 && ps.n_wide_all <= c->wide_one_max && strchr(plan, 'W') != nullptr;
+        for (const char *p = plan; *p; ++p) {
+            if (*p == '|') { ++ps.n_seg; continue; }
+            if (ps.n_seg > 4) continue;
+            static const char wide_kinds[] = "bms";
+            const char *at = strchr(wide_kinds, *p);
+            if (*p == 'W') { if (c->wide_solve && ps.n_wide_all > 0) ps.used[ps.n_seg - 1] = true; }
+            else if (!at || (c->wide_solve && c->n_wide[2 - (int)(at - wide_kinds)] > 0)) ps.used[ps.n_seg - 1] = true;
+        }
+        if (ps.n_seg > 4) ps.n_seg = 4;
+        // (the segments that have something to launch take the side streams in order: the first ones start first)
+        for (int k = 1, nx = 0; k < ps.n_seg; ++k) if (ps.used[k]) ps.side_of[k] = nx++;
+    }
+    // device-side fork / join (k_wait_word): plain launches only (never inside a capture), and only when this enqueue holds
+    // k_prob_emit, whose last workgroup is what the side streams wait for; side streams 0 and 1 only (the process's fourth
+    // stream shares a hardware queue with the first: a waiter there would sit in front of the kernel it waits for)
+    const bool dev_sync = plan && c->dev_sync && do_pre2 && (sized || c->run_plain) && c->d_sync.p != nullptr;
+    SyncWords *sw = c->d_sync.as<SyncWords>();
+    const unsigned sync_gen = dev_sync ? ++c->sync_gen : 0;
+    const unsigned kSyncTicks = c->sync_ticks;
+    auto dev_side = [&](int k) { return dev_sync && k >= 1 && k < ps.n_seg && ps.used[k] && ps.side_of[k] >= 0 && ps.side_of[k] < 2; };
+    auto early_fork = [&]() {
+        if (!dev_sync) return;
+        for (int k = 1; k < ps.n_seg; ++k) if (dev_side(k)) {
+            hipStream_t q = fork(ps.side_of[k]);
+            hipLaunchKernelGGL(k_wait_word, dim3(1), dim3(64), 0, q, st, &sw->emit_gen, 1, sync_gen, kSyncTicks);
+        }
+    };
     const i64 avg_len = NPOS / (K > 0 ? K : 1);
     const int iv_threads = avg_len > 65536 ? 1024 : (avg_len > 16384 ? 256 : 64);
     int tile_grid = grid_for(c->n_tiles, 1, 16384);
@@ -4752,6 +5003,14 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
     {
     hipStream_t q = fork(0);
     if (stage_events && c->profile_all) (void)hipEventRecord(c->ev_b[ST_THRESHOLD], q);
+    // batches of many partitions of moderate size: a workgroup per partition does the whole threshold (k_thr_part); a batch of a
+    // few large partitions (config 2: one) keeps the batch-wide compaction and a workgroup per 8192-value chunk
+    const bool thr_part_fits = c->max_part_pos <= (i64)kThrPartMaxChunks * 8192;
+    const bool thr_part = thr_part_fits && (c->thr_part == 1 || (c->thr_part < 0 && n_part >= 64));
+    if (thr_part) {
+        hipLaunchKernelGGL(k_thr_part, dim3(grid_for(n_part, 1, 4096)), dim3(512), 0, q, n_part, c->d_part_iv_off.as<i64>(), c->d_pos_off.as<i64>(), NPOS,
+                           flag_pos_bits, c->d_y.as<double>(), c->d_v.as<double>(), c->P.variance_factor, c->d_mean.as<double>(), c->d_thr.as<double>());
+    } else {
     scan_counts(q, bsum_side, flag_pos_bits, &st->n_vals, nullptr);
     hipLaunchKernelGGL(k_scan_emit<kEmitValues>, dim3(scan_grid), dim3(256), 0, q, flag_pos_bits, NPOS,
                        bsum_side, scan_state, &st->n_vals, (i64 *)nullptr, &st->err, c->d_y.as<double>(), c->d_v.as<double>(), K, c->d_pos_off.as<i64>(),
@@ -4770,6 +5029,7 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
     hipLaunchKernelGGL(k_vsum_part, dim3(grid_for(n_part, 64, 1024)), dim3(64), 0, q, n_part, c->d_voff.as<i64>(),
                        c->d_chunk_off.as<i64>(), csum0, csum1, c->P.variance_factor, c->d_mean.as<double>(),
                        c->d_thr.as<double>(), c->chunk_cap);
+    }
     if (stage_events && c->profile_all) (void)hipEventRecord(c->ev_e[ST_THRESHOLD], q);
     }
     begin(ST_CANDIDATES);
@@ -4783,6 +5043,7 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
                        c->d_cand_off.as<i64>(), 0, (int *)nullptr);
     end(ST_CANDIDATES);
     join(0);
+    early_fork();
     begin(ST_FIX);
     // S4
     hipLaunchKernelGGL(k_fix, dim3(grid_for(K, 1, 8192)), dim3(iv_threads), 0, s, K, c->d_pos_off.as<i64>(),
@@ -4803,13 +5064,15 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
     }   // do_pre1
     bool score_begun = false;
     if (do_pre2) {
+    if (!do_pre1) early_fork();
     begin(ST_SCORE_PREP);
     hipLaunchKernelGGL(k_prob_emit, dim3(pg), dim3(256), 0, s, st, c->d_cand_pn.as<int>(), c->d_cand_ll.as<int>(),
                        c->d_cand_ln.as<int>(), c->d_seg_iv.as<int>(), c->d_cand_off.as<i64>(), prob_bs,
                        pr, c->prob_cap, c->d_work_pc.as<int2>(), c->d_cls_items.as<int4>(),
                        c->work_cap, c->d_dp_items.as<int>(), c->d_prob_desc.as<ProbDesc>(), c->d_iv_start.as<int>(),
                        c->d_iv_part.as<int>(), c->d_part_lane_off.as<i64>(), split, c->d_solve_items.as<int>(), c->d_solve_desc.as<ProbDesc>(),
-                       c->d_wide_items.as<int>(), c->d_wide_all.as<int>(), c->d_cand_wide.as<unsigned char>());
+                       c->d_wide_items.as<int>(), c->d_wide_all.as<int>(), c->d_cand_wide.as<unsigned char>(),
+                       (dev_sync && c->emit_signal) ? sw : (SyncWords *)nullptr, sync_gen);
     // S5.  The arena path's window coverage (and pair thresholds) are launches of their own in front of k_score: they are
     // interval scoring (get_cumulative_coverage :188-246 -- the solve-list kernels do the same inside their workgroups), so
     // where the stages are bracketed by events the scoring stage's bracket opens here
@@ -4850,8 +5113,6 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
         //     class on main: 0.154-0.167; per-problem clocks, tools/r4_ticks.sh: 133 us from first start to last end either way);
         //   * the 16-bit instances first (batches of 1 000-read partitions): see the passes below.
         // Anything that does not name each class once, batches with arena-path problems and small batches: one stream.
-        const bool any_solve_plan = c->use_fuse && c->fuse_on;
-        const char *plan = (known && !any_arena && !c->small_batch && forking && c->n_solve[2] > 0 && any_solve_plan && wave && c->score_plan[0]) ? c->score_plan : nullptr;
         const bool sfork = any_arena;                               // (the arena path's work-item kernels keep their streams)
         hipStream_t qt = (tiny_max > 0 && sfork) ? fork(2) : s;     // (forked here: a side stream continues from where it was forked)
 #ifdef FSEG_SCORE_TIMING
@@ -4891,8 +5152,10 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
         // stream, where the extra launches cost more than the early release of LDS gains (the 2 M-read job, eight contexts:
         // 383 against 388 M reads/s; the stage alone: 0.146 against 0.160 ms)
         auto split_ok = [&](int cls, int cnt_bytes) {
+            // (k_dpw takes the problem its workgroup index names -- no grid stride --, so a list longer than the grid cap of the
+            // two launches keeps the DP as k_solve's tail)
             return known && (forking || c->split_always) && cls >= 0 && cls < 3 && ((c->split_dp >> cls) & 1) && c->dpx_n[cls] > 0 && c->n_solve[cls] <= c->dpx_n[cls] && c->dpx_nm == c->nm_big &&
-                   cnt_bytes <= c->dpx_cnt[cls] && c->d_dpx.p != nullptr;
+                   c->n_solve[cls] <= kSplitGridCap && cnt_bytes <= c->dpx_cnt[cls] && c->d_dpx.p != nullptr;
         };
 #define FSEG_LAUNCH_SOLVE(Q, NMV, CNT, VT, CLS, N_ITEMS, MAXWG)                                                              \
             hipLaunchKernelGGL((k_solve<NMV, CNT, VT, false>), dim3(grid_for(FSEG_SOLVE_N(CNT, CLS, N_ITEMS), 1, known ? (1 << 20) : (MAXWG))), dim3(SolveCfg<NMV>::kThreads), \
@@ -4911,10 +5174,10 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
         do { const int nm_rt = (NMV) == kNMax ? c->nm_big : (NMV);                                                            \
             unsigned char *dpx0 = c->d_dpx.as<unsigned char>() + c->dpx_base[(CLS) < 0 ? 0 : (CLS)];                                           \
             const i64 dstride = c->dpx_stride[(CLS) < 0 ? 0 : (CLS)];                                                                       \
-            hipLaunchKernelGGL((k_solve<NMV, CNT, int, true>), dim3(grid_for(FSEG_SOLVE_N(CNT, CLS, N_ITEMS), 1, 1 << 20)), dim3(SolveCfg<NMV>::kThreads), \
+            hipLaunchKernelGGL((k_solve<NMV, CNT, int, true>), dim3(grid_for(FSEG_SOLVE_N(CNT, CLS, N_ITEMS), 1, (int)kSplitGridCap)), dim3(SolveCfg<NMV>::kThreads), \
                                solve_lds_for(nm_rt, (NMV) + 1, (int)sizeof(CNT)), Q, FSEG_SOLVE_ARGS(NMV, CNT, CLS), dpx0, dstride, \
                                FSEG_SOLVE_WIDE(CNT, CLS) FSEG_TARG);                                    \
-            hipLaunchKernelGGL((k_dpw<NMV, CNT, VT>), dim3(grid_for(FSEG_SOLVE_N(CNT, CLS, N_ITEMS), 1, 1 << 20)), dim3(64),      \
+            hipLaunchKernelGGL((k_dpw<NMV, CNT, VT>), dim3(grid_for(FSEG_SOLVE_N(CNT, CLS, N_ITEMS), 1, (int)kSplitGridCap)), dim3(64),      \
                                dpw_lds_for(nm_rt, (int)sizeof(VT), (int)sizeof(CNT)), Q, st, nm_rt, list_lb(CLS),                \
                                FSEG_SOLVE_N(CNT, CLS, list_ln(CLS)), pr,                                                        \
                                c->d_solve_desc.as<ProbDesc>(), dpx0, dstride, \
@@ -4958,31 +5221,18 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
         } else {                                     // the size classes own disjoint problems: three concurrent chains
             hipStream_t q1 = sfork ? fork(0) : s, q0 = sfork ? fork(1) : s;
             if (plan) {
-                int n_seg = 1;
-                bool used[4] = {true, false, false, false};              // a stream whose kernels have nothing to do is left alone
-                // W: the problems of every class that see more than kFuseLanes reads -- a handful per batch, most of which keep fewer
-                // and are only looked at -- in ONE launch of the large class's 16-bit instance, a workgroup each (as a launch per
-                // class on the tiny class's stream they held it back 46-60 us on config3 / config5: tools/run_gaps.py); batches
-                // with many such problems keep the per-class instances (b, m, s in a row)
-                const i64 n_wide_all = c->n_wide[0] + c->n_wide[1] + c->n_wide[2];
-                const bool wide_one = c->wide_one_max > 0 && n_wide_all <= c->wide_one_max && strchr(plan, 'W') != nullptr;
-                for (const char *p = plan; *p; ++p) {
-                    if (*p == '|') { ++n_seg; continue; }
-                    if (n_seg > 4) continue;
-                    static const char wide_kinds[] = "bms";
-                    const char *at = strchr(wide_kinds, *p);
-                    if (*p == 'W') { if (c->wide_solve && n_wide_all > 0) used[n_seg - 1] = true; }
-                    else if (!at || (c->wide_solve && c->n_wide[2 - (int)(at - wide_kinds)] > 0)) used[n_seg - 1] = true;
-                }
-                if (n_seg > 4) n_seg = 4;
-                // (the segments that have something to launch take the side streams in order: the first ones start first)
-                int side_of[4] = {-1, -1, -1, -1};
-                for (int k = 1, nx = 0; k < n_seg; ++k) if (used[k]) side_of[k] = nx++;
+                // (which segments have something to launch and the side streams they take: decided at the top, `ps`)
+                const int n_seg = ps.n_seg;
+                const bool *used = ps.used;              // a stream whose kernels have nothing to do is left alone
+                const int *side_of = ps.side_of;
+                const i64 n_wide_all = ps.n_wide_all;
+                const bool wide_one = ps.wide_one;
                 // every side stream continues from HERE (the stage's begin event, when it is being recorded, is the first side
                 // stream's fork: one marker packet less in front of everything -- each is ~5 us on its queue)
                 // (every side stream on that one event: 0.135 -> 0.137-0.149 ms -- the records stagger the streams' starts)
                 bool shared = !(stage_events && forking);
                 for (int k = 1; k < n_seg; ++k) if (used[k]) {
+                    if (dev_side(k)) continue;           // forked early; its waiter (k_wait_word) is what the stream runs first
                     if (!shared) {
                         shared = true;
                         if (hipError_t r = hipStreamWaitEvent(c->side[side_of[k]], c->ev_b[ST_SCORE], 0); r != hipSuccess) fj_err = r;
@@ -5004,6 +5254,7 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
                 // (81 KB); enqueued behind it, config3's one real wide problem was placed 135-150 us into the stage, when the 8-bit
                 // instance and the classes behind the gate had drained, and the stage took 0.29 ms (tools/stage_timeline.py).  A
                 // class has a handful of wide problems: placed first they take a few CUs and the 8-bit instance the rest.
+                bool signalled = false;
                 for (int pass = 0; pass < 3; ++pass) {                       // 0: b   1: h, B   2: the rest
                 seg = 0;
                 bool opens = true;
@@ -5013,6 +5264,14 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
                     if (*p != 'h') opens = false;
                     if (!used[seg] || when != pass) continue;
                     hipStream_t q = seg == 0 ? s : c->side[side_of[seg]];
+                    // the first launch behind k_prob_emit on the main stream tells the side streams' waiters that the problem list
+                    // is complete: the plan's own gate when that is what comes first, else a k_signal
+                    unsigned *sig_word = nullptr;
+                    if (dev_sync && seg == 0 && !signalled) {
+                        signalled = true;
+                        if (*p == 'g' || (*p == 'h' && wide_wgs > 0)) sig_word = &sw->emit_gen;
+                        else hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, s, &sw->emit_gen, sync_gen);
+                    }
                     switch (*p) {
                     case 'B': FSEG_LAUNCH_SOLVE_X(q, kNMax, 2, c->n_solve[2], 512, wb);
                               ev_big = fj_event(); if (hipEventRecord(ev_big, q) != hipSuccess) fj_err = hipErrorUnknown; break;
@@ -5032,16 +5291,24 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
                     case 'm': if (c->n_solve[1] > 0) FSEG_LAUNCH_SOLVE_X(q, kClsMid, 1, c->n_solve[1], FSEG_WG_MID, 2); break;
                     case 's': if (c->n_solve[0] > 0) FSEG_LAUNCH_SOLVE_X(q, kClsSmall, 0, c->n_solve[0], FSEG_WG_SMALL, 2); break;
                     case 'T': if (c->n_tiny > 0) FSEG_LAUNCH_WAVE(q, kTiny, 3, c->n_tiny); break;
-                    case 'g': hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, q, st, 0, (unsigned)(big_wgs < 512 ? big_wgs : 512), 3000u); break;
+                    case 'g': hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, q, st, 0, (unsigned)(big_wgs < 512 ? big_wgs : 512), 3000u, sig_word, sync_gen); break;
                     case 'h': if (wide_wgs > 0)       // the 16-bit instance's workgroups (up to 120 KB of LDS each) take their CUs first
-                                  hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, q, st, 2, (unsigned)(wide_wgs < 256 ? wide_wgs : 256), 1500u);
+                                  hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, q, st, 2, (unsigned)(wide_wgs < 256 ? wide_wgs : 256), 1500u, sig_word, sync_gen);
                               break;
                     case 'e': if (ev_big && hipStreamWaitEvent(q, ev_big, 0) != hipSuccess) fj_err = hipErrorUnknown; break;
                     default: break;
                     }
                 }
                 }
-                for (int k = 1; k < n_seg; ++k) if (used[k]) join(side_of[k]);
+                // join: a side chain with a device-side fork ends with k_signal and the main stream waits for the words (one wave in
+                // front of k_segments) instead of two marker + barrier packets per side stream
+                if (dev_sync && !signalled) hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, s, &sw->emit_gen, sync_gen);    // (a plan with nothing on the main stream)
+                int n_dev = 0;
+                for (int k = 1; k < n_seg; ++k) if (used[k]) {
+                    if (dev_side(k)) { hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, c->side[side_of[k]], &sw->side_gen[side_of[k]], sync_gen); ++n_dev; }
+                    else join(side_of[k]);
+                }
+                if (n_dev) hipLaunchKernelGGL(k_wait_word, dim3(1), dim3(64), 0, s, st, sw->side_gen, n_dev, sync_gen, kSyncTicks);
             } else {
             if (any_arena && (!known || c->n_cls_work[2] > 0)) FSEG_LAUNCH_SCORE(s, kNMax, 2, 512);     // big problems: they are the long poles
             if (any_solve && (!known || c->n_solve[2] > 0)) FSEG_LAUNCH_SOLVE_W(s, kNMax, 2, known ? c->n_solve[2] : cap, 512);
@@ -5246,7 +5513,10 @@ void adapt_to(fseg_ctx *c, const Status &s) {
     c->fuse_on = (i64)s.max_ln <= c->fuse_lanes;                 // (the widest problem does not depend on the split either)
     c->wide_solve = (i64)s.max_ln > kFuseLanes;                  // some problem needs the 16-bit counters
     c->max_ln = (i64)s.max_ln;
-    if (old_fuse != c->fuse_on) { c->counts_known = false; drop_graph(c); }
+    // (the lists' sizes were counted under the old division of the problems: a run under the new one must not take them from the host --
+    // an unsized first run of a batch with more than tiny_from problems turns k_tiny's share on for the replay, whose list bounds then
+    // came from the run without it: kErrOverflowNm on every attempt, "arena sizing did not converge"; found in round 5)
+    if (old_fuse != c->fuse_on || old_tiny != c->tiny_on) { c->counts_known = false; drop_graph(c); }
     c->prob_self_scan = (i64)s.n_cand <= c->prob_self_max;
     {   // the big-problem LDS carve-up: the largest problem (+ headroom, multiple of 4)
         int want = (int)s.max_n + 3;
@@ -5300,6 +5570,7 @@ static int finish_run_impl(fseg_ctx *c) {
                                 kErrOverflowProblems | kErrOverflowChunks | kErrOverflowCov);
         if (s.err & kErrOverflowNm) { ovf |= kErrOverflowNm; c->nm_big = kNMax; }
         if (s.err & kErrWaveStage) { ovf |= kErrWaveStage; c->use_wave = false; c->counts_known = false; drop_graph(c); }    // k_tiny / k_solve fetch exons read by read
+        if (s.err & kErrSyncTimeout) { ovf |= kErrSyncTimeout; c->dev_sync = false; }     // a device-side waiter gave up (the stage was skipped): events from now on
         if ((i64)s.max_ln >= 65536 && !c->dp_wide_counts) { ovf |= kErrNeedWideDp; c->dp_wide_counts = true; drop_graph(c); }
         if (s.err & kErrScanStall) { ovf |= kErrScanStall; c->scan_single_max = 0; c->force_scan_stall = false; drop_graph(c); }
         if (s.dp_cls[2] > 0 && !c->have_huge) { ovf |= kErrProblemTooLarge << 16; c->have_huge = true; drop_graph(c); }   // rerun with the huge-problem kernels
@@ -5326,7 +5597,14 @@ static int finish_run_impl(fseg_ctx *c) {
         c->last_sized = false;
         TRY(enqueue_run(c, SEG_ALL));
     }
-    return fail(c, FSEG_ERR_HIP, "arena sizing did not converge");
+    {
+        const Status &s = *c->h_status;
+        return fail(c, FSEG_ERR_HIP, "arena sizing did not converge (status %#x; %llu problems / cap %lld, %llu work items / %lld, pairs %llu / %lld, triples %llu / %lld, "
+                    "coverage %llu / %lld, label bytes %llu / %lld, chunks %llu / %lld, widest problem sees %u reads)", s.err,
+                    (unsigned long long)s.n_prob, (long long)c->prob_cap, (unsigned long long)s.n_work, (long long)c->work_cap, (unsigned long long)s.pair_used, (long long)c->pair_cap,
+                    (unsigned long long)s.tri_used, (long long)c->tri_cap, (unsigned long long)s.cov_used, (long long)c->cov_cap, (unsigned long long)s.label_bytes, (long long)c->label_cap,
+                    (unsigned long long)s.n_vchunks, (long long)c->chunk_cap, s.max_ln);
+    }
 }
 
 // First run of a batch: launched in three pieces with the host reading the status record in between, so every arena is
@@ -5394,6 +5672,11 @@ int run_sized(fseg_ctx *c) {
         const unsigned bad = s.err & (kErrOverflowPairs | kErrOverflowTri | kErrOverflowWork | kErrOverflowProblems | kErrOverflowChunks |
                                       kErrOverflowCov | kErrOverflowNm | kErrNeedWideDp);
         if (bad) return fail(c, FSEG_ERR_HIP, "internal: a sized run overflowed an arena (status %#x)", s.err);
+        // (what B's scoring kernels can raise besides: a result that is garbage fails HERE, not after the label stage; a wave kernel
+        // that met a read it cannot stage turns the wave kernels off and the sized attempt starts over)
+        if (s.err & kErrSyncTimeout) { c->dev_sync = false; continue; }     // a device-side waiter gave up (the stage was skipped): once more, with events
+        if (s.err & kErrWideMissed) { c->pending = false; c->ran = false; return run_input_errors(c, s); }
+        if (s.err & kErrWaveStage) { c->use_wave = false; c->counts_known = false; drop_graph(c); continue; }
         if ((s.err & (kErrExonInterval | kErrBreakAssert | kErrProblemTooLarge))) {
             c->pending = false; c->ran = false;
             return run_input_errors(c, s);
@@ -5450,6 +5733,8 @@ int fseg_create(int device, fseg_ctx **out) {
     if (e == hipSuccess) e = hipMalloc(&c->d_prep.p, sizeof(PrepStatus));
     if (e == hipSuccess) e = hipMalloc(&c->d_tacc.p, kTaccBytes);
     if (e == hipSuccess) e = hipMemsetAsync(c->d_tacc.p, 0, kTaccBytes, c->stream);
+    if (e == hipSuccess) e = hipMalloc(&c->d_sync.p, sizeof(SyncWords));
+    if (e == hipSuccess) e = hipMemsetAsync(c->d_sync.p, 0, sizeof(SyncWords), c->stream);
     for (int i = 0; e == hipSuccess && i < ST_COUNT; ++i) { e = hipEventCreate(&c->ev_b[i]); if (e == hipSuccess) e = hipEventCreate(&c->ev_e[i]); }
     for (int i = 0; e == hipSuccess && i < 4; ++i) e = hipEventCreate(&c->ev_g[i]);
     // The side streams: at once for the first context of a device (the usual single-context user gets its four streams on
@@ -5501,8 +5786,12 @@ int fseg_create(int device, fseg_ctx **out) {
         delete c;
         return FSEG_ERR_HIP;
     }
-    c->d_status.cap = sizeof(Status); c->d_prep.cap = sizeof(PrepStatus); c->d_tacc.cap = kTaccBytes;
+    c->d_status.cap = sizeof(Status); c->d_prep.cap = sizeof(PrepStatus); c->d_tacc.cap = kTaccBytes; c->d_sync.cap = sizeof(SyncWords);
     auto flag = [](const char *name) { const char *v = getenv(name); return v && v[0] == '1'; };
+    { const char *v = getenv("FSEG_DEV_SYNC"); if (v && v[0] == '0') c->dev_sync = false; }
+    { const char *v = getenv("FSEG_EMIT_SIGNAL"); if (v && v[0] == '0') c->emit_signal = false; }
+    { const char *v = getenv("FSEG_THR_PART"); if (v && (v[0] == '0' || v[0] == '1')) c->thr_part = v[0] - '0'; }
+    { const char *v = getenv("FSEG_SYNC_TICKS"); if (v && v[0] && atoll(v) > 0) c->sync_ticks = (unsigned)atoll(v); }
     if (flag("FSEG_NO_GRAPH")) c->use_graph = false;
     if (flag("FSEG_GRAPH_FORK")) c->graph_fork = true;
     if (flag("FSEG_NO_FORK")) c->use_fork = false;
@@ -5547,7 +5836,7 @@ void fseg_destroy(fseg_ctx *c) {
     drop_graph(c);
     Slab *slabs[] = {&c->slab_in, &c->slab_pos, &c->slab_arena};
     for (Slab *s : slabs) if (s->p) (void)hipFree(s->p);
-    DevBuf *bufs[] = {&c->d_labels, &c->d_packed, &c->d_sort_tmp, &c->d_w_main, &c->d_w_refine, &c->d_h_table, &c->d_thr_tab, &c->d_status, &c->d_prep, &c->d_tacc};
+    DevBuf *bufs[] = {&c->d_labels, &c->d_packed, &c->d_sort_tmp, &c->d_w_main, &c->d_w_refine, &c->d_h_table, &c->d_thr_tab, &c->d_status, &c->d_prep, &c->d_tacc, &c->d_sync};
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
     if (c->h_stage.p) (void)hipHostFree(c->h_stage.p);
     if (c->h_res.p) (void)hipHostFree(c->h_res.p);
@@ -5724,7 +6013,7 @@ static int upload_impl(fseg_ctx *c, const fseg_batch *b) {
         int *h_hc_part = reinterpret_cast<int *>(host_of(c->d_hc_part)), *h_hc_n = reinterpret_cast<int *>(host_of(c->d_hc_n));
         int *h_hc_glo = reinterpret_cast<int *>(host_of(c->d_hc_glo)), *h_hc_ghi = reinterpret_cast<int *>(host_of(c->d_hc_ghi));
         i64 *h_hc_p0 = reinterpret_cast<i64 *>(host_of(c->d_hc_p0));
-        h_pos_off[0] = 0; h_lane_off[0] = 0; c->max_part_lanes = 0;
+        h_pos_off[0] = 0; h_lane_off[0] = 0; c->max_part_lanes = 0; c->max_part_pos = 0;
         i64 t = 0, rb = 0, ch = 0, l = 0, bq = 0;
         for (int p = 0; p < np; ++p) {
             const i64 k0 = b->part_iv_off[p], k1 = b->part_iv_off[p + 1];
@@ -5744,6 +6033,7 @@ static int upload_impl(fseg_ctx *c, const fseg_batch *b) {
             // histogram chunks of the partition, with the genomic position of the chunk's first and last position (a
             // chunk may span several intervals of its partition)
             const i64 P0 = h_pos_off[k0], P1 = h_pos_off[k1];
+            if (P1 - P0 > c->max_part_pos) c->max_part_pos = P1 - P0;
             i64 k = k0;
             for (i64 q0 = P0; q0 < P1; q0 += hist_chunk) {
                 const i64 q1 = std::min<i64>(q0 + hist_chunk, P1) - 1;
@@ -6158,6 +6448,15 @@ int fseg_tap(fseg_ctx *c, int what, void *dst, int64_t cap_bytes, int64_t *n_byt
         case FSEG_TAP_LANE_EXONS: src = c->d_lane_ex.p; bytes = c->LANES * 16; break;
         case FSEG_TAP_LANE_STREAM: src = c->d_lane_lx.p; bytes = c->LANES * 8; break;
         case FSEG_TAP_EXON_STREAM: src = c->d_lex.p; bytes = c->I * 8; break;
+        case FSEG_TAP_SYNC: {
+            SyncWords w{};
+            HIP_TRY(c, hipMemcpy(&w, c->d_sync.p, sizeof w, hipMemcpyDeviceToHost));
+            packed = {(int)c->sync_gen, c->dev_sync ? 1 : 0, (int)w.emit_gen, (int)w.side_gen[0], (int)w.side_gen[1], (int)w.emit_ctr};
+            bytes = (i64)packed.size() * 4;
+            *n_bytes = bytes;
+            if (dst && cap_bytes > 0) memcpy(dst, packed.data(), (size_t)(bytes < cap_bytes ? bytes : cap_bytes));
+            return FSEG_OK;
+        }
         default: return fail(c, FSEG_ERR_ARG, "unknown tap %d", what);
     }
     *n_bytes = bytes;

@@ -161,7 +161,11 @@ enum {
     FSEG_TAP_LANE_PMAX = 13,  /* int32[lanes]  running maximum (inside the partition) of the reps' last positions    */
     FSEG_TAP_LANE_EXONS = 14, /* int64[lanes][2] exon range (into ex_ts / ex_te) of the lane's rep                   */
     FSEG_TAP_LANE_STREAM = 15, /* int32[lanes][2] the lane's exon range in the lane-ordered exon stream                */
-    FSEG_TAP_EXON_STREAM = 16  /* int32[I][2]    (ts, te) of every exon, the reps of a partition in lane order        */
+    FSEG_TAP_EXON_STREAM = 16, /* int32[I][2]    (ts, te) of every exon, the reps of a partition in lane order        */
+    /* the scoring stage's device-side fork / join: stages enqueued with waiters so far, whether waiters are still in use
+     * (0 after one timed out: events from then on), and the device's words (last problem-list generation, last generation of
+     * side streams 0 / 1, workgroup counter) */
+    FSEG_TAP_SYNC = 17         /* int32[6]                                                                             */
 };
 int fseg_tap(fseg_ctx *ctx, int what, void *dst, int64_t cap_bytes, int64_t *n_bytes);
 

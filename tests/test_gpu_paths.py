@@ -79,6 +79,10 @@ SWITCHES = [
     {"FSEG_FUSE_LANES": "1023", "FSEG_WIDE_BY_SEEN": "1", "FSEG_WIDE_ONE_MAX": "100000"},   # every wide problem, whatever its class, by the large class's 16-bit instance
     {"FSEG_FUSE_LANES": "1023", "FSEG_WIDE_BY_SEEN": "1", "FSEG_WIDE_ONE_MAX": "100000", "FSEG_FORCE_KEY64": "1"},
     {"FSEG_GRAPH_FORK": "1"},                               # the forked run replayed as a hipGraph with cross-stream edges (slower to launch: DESIGN section 3)
+    {"FSEG_THR_PART": "1"},                                 # the variance threshold of a partition by one workgroup (k_thr_part), whatever the batch's size
+    {"FSEG_THR_PART": "0"},                                 # ... and never: the batch-wide compaction + a workgroup per 8192-value chunk
+    {"FSEG_THR_PART": "1", "FSEG_NO_FORK": "1", "FSEG_NO_GRAPH": "1"},
+    {"FSEG_EMIT_SIGNAL": "0"},                              # the side streams' waiters released by the first launch behind k_prob_emit only, not by its last workgroup
 ]
 
 
@@ -188,6 +192,65 @@ def test_full_size_bench_batches_against_oracle(workload, n_part, gpu_ctx):
     assert rep["y_identical"]
     gpu_ctx.run(); gpu_ctx.sync()
     util.compare_partitions(gpu_ctx, parts, oracles)
+
+
+@pytest.mark.parametrize("env,waiters,still_on", [({}, True, True), ({"FSEG_DEV_SYNC": "0"}, False, False), ({"FSEG_SYNC_TICKS": "1"}, True, False),
+                                                  ({"FSEG_SCORE_PLAN": "gM|hB|gS|T"}, True, True), ({"FSEG_NO_SIZED": "1"}, True, True), ({"FSEG_NO_SIZED": "1", "FSEG_DEV_SYNC": "0"}, False, False),
+                                                  ({"FSEG_EMIT_SIGNAL": "0"}, True, True)],
+                         ids=["device-side", "events", "waiter-times-out", "three-side-streams", "unsized-first-run", "unsized-first-run-events",
+                              "signal-from-the-gate"])
+def test_scoring_stage_fork_and_join(env, waiters, still_on, monkeypatch):
+    """The scoring stage's side streams (FSEG_SCORE_PLAN) are forked and joined on the device (k_wait_word / k_signal behind
+    k_prob_emit's last workgroup) or with events (FSEG_DEV_SYNC=0); a waiter that gives up (forced: one tick) must end the
+    stage unharmed -- the kernels behind it do nothing -- and the batch is rerun with events.  Either way: the oracle's results,
+    first run and replays.  (A batch large enough for a plan: many problems in every size class, one context alone.)"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    kw = dict(synth.WORKLOADS["config4"]); kw.pop("n_partitions")
+    parts = [util.make_partition(7000 + i, **kw) for i in range(48)]
+    oracles = [util.run_oracle(p) for p in parts]
+    ctx = _lib.Context(0)
+    try:
+        check_twice(ctx, parts, oracles)
+        for _ in range(3):
+            ctx.run(); ctx.sync()
+        util.compare_partitions(ctx, parts, oracles)
+        sy = ctx.tap("sync")
+        assert (sy[0] > 0) == waiters, sy                      # stages enqueued with device-side waiters
+        assert bool(sy[1]) == still_on, sy
+        if waiters and still_on:
+            assert sy[2] == sy[0] and sy[3] == sy[0] and sy[5] == 0, sy     # the words carry the last generation; the counter is back at 0
+        more = [util.make_partition(7100 + i, **kw) for i in range(40)]    # another batch on the same context
+        check_twice(ctx, more, [util.run_oracle(p) for p in more])
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("mode", ["0", "1"], ids=["chunk-kernels", "workgroup-per-partition"])
+def test_threshold_paths_on_the_goldens_and_big_partitions(mode, monkeypatch):
+    """The variance threshold (:757-759, numpy's summation order) both ways -- a workgroup per partition (k_thr_part) and the
+    batch-wide compaction with a workgroup per chunk -- on every golden of the reference (NaN threshold, sigma 50, ...), on a
+    partition with dozens of 8192-value chunks, and on a many-partition batch; bit-identical thresholds either way."""
+    import goldens
+    monkeypatch.setenv("FSEG_THR_PART", mode)
+    ctx = _lib.Context(0)
+    try:
+        for name in goldens.names():
+            if name == "g4_config2":
+                continue
+            g = goldens.load(name)
+            part = goldens.partition_of(g)
+            util.run_gpu(ctx, [part], goldens.params_of(g), goldens.tables_of(g))
+            util.compare_partitions(ctx, [part], [goldens.as_oracle_result(g)])
+        big = [util.make_partition(8100, n_reads=20000, n_exons=400, rp=0.05), util.make_partition(8101, n_reads=300, n_exons=30)]
+        oracles = [util.run_oracle(p) for p in big]
+        assert int((oracles[0]["Y"] > 0).sum()) > 4 * 8192                       # several chunks, the last one partial
+        check_twice(ctx, big, oracles)
+        kw = dict(synth.WORKLOADS["config4"]); kw.pop("n_partitions")
+        parts = [util.make_partition(8200 + i, **kw) for i in range(70)]          # (64 partitions and more: the default takes k_thr_part)
+        check_twice(ctx, parts, [util.run_oracle(p) for p in parts])
+    finally:
+        ctx.close()
 
 
 @pytest.mark.parametrize("big", [False, True], ids=["sorted-in-LDS", "batch-wide-sort"])

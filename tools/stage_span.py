@@ -12,6 +12,7 @@ import sys
 import numpy as np
 
 STAGE = ("k_solve", "k_dpw", "k_wave", "k_tiny", "k_gate", "k_cover", "k_score")
+SYNC = ("k_wait_word", "k_signal")
 rows = []
 for r in csv.DictReader(open(sys.argv[1])):
     name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
@@ -30,8 +31,15 @@ for run in runs:
     if not st:
         continue
     first, last = min(s for s, _, _ in st), max(e for _, e, _ in st)
-    before = [e for s, e, n in run if e <= first and not n.startswith(STAGE)]
-    after = [s for s, e, n in run if s >= last and not n.startswith(STAGE)]
+    # (round 5: the side streams' waiters, k_wait_word, start long before the stage and k_signal / the join's waiter are not
+    # stage work: the bracket is named -- k_prob_emit's end to k_segments' start -- where the run has both)
+    emit = [e for s, e, n in run if n.startswith("k_prob_emit")]
+    segs = [s for s, e, n in run if n.startswith("k_segments")]
+    if emit and segs:
+        before, after = [max(emit)], [min(x for x in segs if x >= max(emit))] if any(x >= max(emit) for x in segs) else []
+    else:
+        before = [e for s, e, n in run if e <= first and not n.startswith(STAGE + SYNC)]
+        after = [s for s, e, n in run if s >= last and not n.startswith(STAGE + SYNC)]
     ker.append((last - first) / 1e3)
     if before and after:
         brk.append((min(after) - max(before)) / 1e3)
