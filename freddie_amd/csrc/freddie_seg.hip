@@ -3798,6 +3798,7 @@ __global__ void __launch_bounds__(512) k_dp_huge(Status *st, const int *dp_items
 // previous chosen candidate is more than 40 positions away, records that segment; k_refine then
 // visits the recorded segments (one wave each).
 // ---------------------------------------------------------------------------------------------
+constexpr int kSegChunks = 4;      // 64-candidate chunks of an interval that k_segments' one-wave path takes at once
 __global__ void k_segments(i64 K, const i64 *pos_off, const i64 *cand_off, const int *cand_y, const int *__restrict__ y_raw,
                            const int *__restrict__ blk_pre, const int *tile_tot, const int *iv_tile0, const unsigned char *chosen, unsigned *final_flag, int *rseg_c, int *rseg_prev,
                            Status *st) {
@@ -3806,10 +3807,87 @@ __global__ void k_segments(i64 K, const i64 *pos_off, const i64 *cand_off, const
     __shared__ u64 base_s;
     const int T = blockDim.x;
     int lane = lane_id(), wave = threadIdx.x >> 6, nw = (T + 63) >> 6;
+    // the inner-positions test of refine_segmentation (:258) for the segment (py, y] of interval k, whose first tile is tile0
+    auto inner_sum_ok = [&](i64 base, int tile0, int py, int y) -> bool {
+        // refine_segmentation's `sum(i_vals) < 20 -> continue` (:258), exactly, over the inner positions [py+20, y-21]:
+        // k_smooth's prefix of the histogram at the start of a's and of b's block (inside their tiles), the tiles
+        // between them, and the positions of those two blocks up to a (exclusive) / up to b (inclusive)
+        const int a = py + 20, b = y - 21;
+        const int ta = a >> kSmoothShift, tb = b >> kSmoothShift;
+        if (tb - ta > 64) return true;                            // (very long segments: k_refine sums them itself)
+        constexpr int kBlocks = kSmoothTile / kSumBlock;
+        const int *tt = tile_tot + tile0;
+        const int *yr = y_raw + base;
+        const int a0 = a & ~(kSumBlock - 1), b0 = b & ~(kSumBlock - 1);
+        i64 tot = (i64)blk_pre[(i64)(tile0 + tb) * kBlocks + ((b & (kSmoothTile - 1)) >> kSumShift)]
+                - (i64)blk_pre[(i64)(tile0 + ta) * kBlocks + ((a & (kSmoothTile - 1)) >> kSumShift)];
+        // (the two blocks as 16-byte loads from dword-aligned addresses; a block of b's may reach beyond the interval's
+        // last position -- into the next interval's counts or the slab's padding: masked)
+        int4u va[kSumBlock / 4], vb[kSumBlock / 4];
+#pragma unroll
+        for (int e = 0; e < kSumBlock / 4; ++e) { va[e] = *reinterpret_cast<const int4u *>(yr + a0 + 4 * e); vb[e] = *reinterpret_cast<const int4u *>(yr + b0 + 4 * e); }
+#pragma unroll
+        for (int e = 0; e < kSumBlock / 4; ++e) {
+            const int pa = a0 + 4 * e, pb = b0 + 4 * e;
+            tot += (pb <= b ? vb[e].x : 0) + (pb + 1 <= b ? vb[e].y : 0) + (pb + 2 <= b ? vb[e].z : 0) + (pb + 3 <= b ? vb[e].w : 0);
+            tot -= (pa < a ? va[e].x : 0) + (pa + 1 < a ? va[e].y : 0) + (pa + 2 < a ? va[e].z : 0) + (pa + 3 < a ? va[e].w : 0);
+        }
+        for (int q = ta; q < tb; ++q) tot += tt[q];
+        return tot >= 20;
+    };
     for (i64 k = blockIdx.x; k < K; k += gridDim.x) {
         i64 c0 = cand_off[k];
         int N = (int)(cand_off[k + 1] - c0);
         i64 base = pos_off[k];
+        if (T == 64 && N <= 64 * kSegChunks) {
+            // an interval of at most 256 candidates, one wave (round 5): the chosen flags and the candidates' positions of all its
+            // 64-candidate chunks are asked for together, the previous chosen candidate's position comes from its lane (or the
+            // chunk before), and the chunks' inner-sum tests are in flight together -- three rounds of loads per interval whatever
+            // its length and no barrier.  (The kernel is a chain of dependent loads per interval; with six rounds per 64
+            // candidates the few long intervals of a batch -- 100 to 300 candidates -- were what it took: 26 us.)
+            const int tile0 = iv_tile0[k];
+            unsigned char ch[kSegChunks];
+            int yv[kSegChunks];
+#pragma unroll
+            for (int u = 0; u < kSegChunks; ++u) {
+                const int c = u * 64 + lane;
+                ch[u] = chosen[c0 + (c < N ? c : 0)];
+                yv[u] = cand_y[c0 + (c < N ? c : 0)];
+            }
+            int pyv[kSegChunks];
+            bool need[kSegChunks];
+            int carry_y = -1;                                          // position of the last chosen candidate of the chunks before (wave-uniform)
+#pragma unroll
+            for (int u = 0; u < kSegChunks; ++u) {
+                const int c = u * 64 + lane;
+                const bool f = c < N && ch[u];
+                const u64 mask = __ballot(f);
+                const u64 below = mask & ((1ULL << lane) - 1ULL);
+                const int prev = below ? 63 - __clzll((long long)below) : -1;
+                const int py_in = __shfl(yv[u], prev >= 0 ? prev : 0);
+                const int py = prev >= 0 ? py_in : carry_y;
+                if (f) set_flag(final_flag, base + yv[u]);
+                pyv[u] = py;
+                need[u] = f && py >= 0 && yv[u] - py > 40;              // :252
+                if (mask) carry_y = __shfl(yv[u], 63 - __clzll((long long)mask));
+            }
+#pragma unroll
+            for (int u = 0; u < kSegChunks; ++u) if (need[u]) need[u] = inner_sum_ok(base, tile0, pyv[u], yv[u]);
+#pragma unroll
+            for (int u = 0; u < kSegChunks; ++u) {
+                const u64 m = __ballot(need[u]);
+                if (m) {                                               // (wave-uniform)
+                    u64 slot0 = 0;
+                    if (lane == 0) slot0 = atomicAdd(&st->n_rseg, (u64)__popcll(m));
+                    slot0 = __shfl(slot0, 0);
+                    if (need[u]) {
+                        const u64 slot = slot0 + __popcll(m & ((1ULL << lane) - 1ULL));
+                        rseg_c[slot] = (int)(c0 + u * 64 + lane); rseg_prev[slot] = pyv[u];
+                    }
+                }
+            }
+            continue;
+        }
         int carry = -1;
         for (int t0 = 0; t0 < N; t0 += T) {
             int c = t0 + threadIdx.x;
@@ -3822,35 +3900,7 @@ __global__ void k_segments(i64 K, const i64 *pos_off, const i64 *cand_off, const
                 if (prev >= 0) py = cand_y[c0 + prev];
             }
             bool need = f && py >= 0 && y - py > 40;                  // :252
-            if (need) {
-                // refine_segmentation's `sum(i_vals) < 20 -> continue` (:258), exactly, over the inner positions [py+20, y-21]:
-                // k_smooth's prefix of the histogram at the start of a's and of b's block (inside their tiles), the tiles
-                // between them, and the positions of those two blocks up to a (exclusive) / up to b (inclusive)
-                const int a = py + 20, b = y - 21;
-                const int ta = a >> kSmoothShift, tb = b >> kSmoothShift;
-                if (tb - ta <= 64) {                                  // (very long segments: k_refine sums them itself)
-                    constexpr int kBlocks = kSmoothTile / kSumBlock;
-                    const int t0 = iv_tile0[k];
-                    const int *tt = tile_tot + t0;
-                    const int *yr = y_raw + base;
-                    const int a0 = a & ~(kSumBlock - 1), b0 = b & ~(kSumBlock - 1);
-                    i64 tot = (i64)blk_pre[(i64)(t0 + tb) * kBlocks + ((b & (kSmoothTile - 1)) >> kSumShift)]
-                            - (i64)blk_pre[(i64)(t0 + ta) * kBlocks + ((a & (kSmoothTile - 1)) >> kSumShift)];
-                    // (the two blocks as 16-byte loads from dword-aligned addresses; a block of b's may reach beyond the interval's
-                    // last position -- into the next interval's counts or the slab's padding: masked)
-                    int4u va[kSumBlock / 4], vb[kSumBlock / 4];
-#pragma unroll
-                    for (int e = 0; e < kSumBlock / 4; ++e) { va[e] = *reinterpret_cast<const int4u *>(yr + a0 + 4 * e); vb[e] = *reinterpret_cast<const int4u *>(yr + b0 + 4 * e); }
-#pragma unroll
-                    for (int e = 0; e < kSumBlock / 4; ++e) {
-                        const int pa = a0 + 4 * e, pb = b0 + 4 * e;
-                        tot += (pb <= b ? vb[e].x : 0) + (pb + 1 <= b ? vb[e].y : 0) + (pb + 2 <= b ? vb[e].z : 0) + (pb + 3 <= b ? vb[e].w : 0);
-                        tot -= (pa < a ? va[e].x : 0) + (pa + 1 < a ? va[e].y : 0) + (pa + 2 < a ? va[e].z : 0) + (pa + 3 < a ? va[e].w : 0);
-                    }
-                    for (int q = ta; q < tb; ++q) tot += tt[q];
-                    need = tot >= 20;
-                }
-            }
+            if (need) need = inner_sum_ok(base, iv_tile0[k], py, y);
             u64 m = __ballot(need);
             if (lane == 0) cnt_s[wave] = __popcll(m);
             __syncthreads();
@@ -4054,8 +4104,10 @@ __global__ void __launch_bounds__(64) k_refine(const Status *st, const int *cand
 // label arena offsets of the partitions (one workgroup of 256 threads; part of k_label_cols)
 __device__ void label_plan(int n_part, const i64 *part_iv_off, const i64 *part_rep_off,
                            const i64 *final_off, i64 *label_off, Status *st, i64 label_cap) {
+    // (a workgroup scan per 256 partitions; until round 5 thread 0 added the 256 sizes up one by one -- a chain of 256 LDS round
+    // trips, 12 us per 256 partitions: it was what k_label_cols took, 23 us for the 500 partitions of a config4 batch)
     __shared__ i64 carry_s;
-    __shared__ i64 tmp[256];
+    __shared__ i64 scan_lds[16];
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
     for (int p0 = 0; p0 < n_part; p0 += blockDim.x) {
@@ -4065,15 +4117,12 @@ __device__ void label_plan(int n_part, const i64 *part_iv_off, const i64 *part_r
             i64 F = final_off[part_iv_off[p + 1]] - final_off[part_iv_off[p]];
             bytes = (part_rep_off[p + 1] - part_rep_off[p]) * (F > 0 ? F - 1 : 0);
         }
-        tmp[threadIdx.x] = bytes;
+        i64 tot;
+        const i64 ex = wg_exclusive_scan64(bytes, scan_lds, &tot);
+        const i64 carry = carry_s;
+        if (p < n_part) label_off[p] = carry + ex;
         __syncthreads();
-        if (threadIdx.x == 0) {
-            i64 c = carry_s;
-            for (int q = 0; q < (int)blockDim.x && p0 + q < n_part; ++q) { i64 b = tmp[q]; tmp[q] = c; c += b; }
-            carry_s = c;
-        }
-        __syncthreads();
-        if (p < n_part) label_off[p] = tmp[threadIdx.x];
+        if (threadIdx.x == 0) carry_s = carry + tot;
         __syncthreads();
     }
     if (threadIdx.x == 0) {
@@ -5005,8 +5054,12 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
     if (stage_events && c->profile_all) (void)hipEventRecord(c->ev_b[ST_THRESHOLD], q);
     // batches of many partitions of moderate size: a workgroup per partition does the whole threshold (k_thr_part); a batch of a
     // few large partitions (config 2: one) keeps the batch-wide compaction and a workgroup per 8192-value chunk
+    // ... and so does a context that shares the device: k_thr_part is the LATENCY-optimised form (one launch, a partition's phases in a
+    // row by eight waves that mostly wait: 0.106 -> 0.070 ms for a context alone, the replay of a 250 k-read batch 0.742 -> 0.683 ms),
+    // the chunk kernels are the throughput-friendly one -- with eight contexts taking turns the job ran at 368 M reads/s with
+    // k_thr_part against 381 M without (tools/r5_value.sh, three rounds each in one call)
     const bool thr_part_fits = c->max_part_pos <= (i64)kThrPartMaxChunks * 8192;
-    const bool thr_part = thr_part_fits && (c->thr_part == 1 || (c->thr_part < 0 && n_part >= 64));
+    const bool thr_part = thr_part_fits && (c->thr_part == 1 || (c->thr_part < 0 && n_part >= 64 && forking));
     if (thr_part) {
         hipLaunchKernelGGL(k_thr_part, dim3(grid_for(n_part, 1, 4096)), dim3(512), 0, q, n_part, c->d_part_iv_off.as<i64>(), c->d_pos_off.as<i64>(), NPOS,
                            flag_pos_bits, c->d_y.as<double>(), c->d_v.as<double>(), c->P.variance_factor, c->d_mean.as<double>(), c->d_thr.as<double>());
