@@ -47,8 +47,11 @@ constexpr int kMaxRadius = 200;        // sigma <= 50, truncate 4.0 (py/freddie_
 constexpr int kScanBlock = 8192;       // elements per scan workgroup (256 threads x one 32-bit word of flags)
 inline size_t flag_words(i64 n_pos) { return ((size_t)n_pos + 31) / 32 + 64; }      // words of one flag mask (+ room for a tile's last word and the scans' last block)
 constexpr int kNMax = 60;              // largest DP problem handled by the LDS-resident scoring kernel
-constexpr int kNHuge = 128;            // largest DP problem at all: 60 < n <= 128 (max_problem_size up to ~115) takes the
-                                       // global-table kernels k_score_huge / k_dp_huge
+constexpr int kNHuge = 128;            // 60 < n <= 128 (max_problem_size up to ~115): the global-count-table kernels k_score_huge / k_dp_huge
+                                       // (pair planes and the DP's tables in LDS)
+constexpr int kNGiant = 1024;          // 128 < n <= 1024 (max_problem_size up to 1 000: what the CLI accepts): k_score_giant / k_dp_giant,
+                                       // every per-pair table in global scratch -- slow, complete (the reference's own optimize() is
+                                       // O(n^3 R) Python there: nobody runs it for long)
 constexpr int kLaneChunk = 256;        // reads ("lanes") per scoring work item (u16 counters: must stay < 65536)
 constexpr int kSub = 64;               // reads per scoring sub-chunk (two 32-bit plane words)
 constexpr i64 kNegInf = (i64)(-0x7fffffffffffffffLL - 1);
@@ -63,7 +66,7 @@ constexpr int kFuseLanesWide = 1023;   // ... and for the 16-bit instances: part
 enum : unsigned {
     kErrExonInterval = 1u,     // an exon is not inside one tint interval (py/freddie_segment.py:668)
     kErrBreakAssert = 2u,      // break_large_problems: assert max_c_idx_y_v > 0 / index out of range (:640-643)
-    kErrProblemTooLarge = 4u,  // a DP problem has more than kNHuge candidates
+    kErrProblemTooLarge = 4u,  // a DP problem has more than kNGiant candidates
     kErrOverflowPairs = 8u,
     kErrOverflowTri = 16u,
     kErrOverflowWork = 32u,
@@ -1345,7 +1348,7 @@ __global__ void k_fix(i64 K, const i64 *pos_off, const int *iv_part, const i64 *
             if (c < N) {
                 fixed[c0 + c] = f; chosen[c0 + c] = f;
                 int n = (f && prev >= 0 && c - prev + 1 >= 3) ? c - prev + 1 : 0;
-                if (n > kNHuge) atomicOr(&st->err, kErrProblemTooLarge);
+                if (n > kNGiant) atomicOr(&st->err, kErrProblemTooLarge);
                 cand_pn[c0 + c] = n;
             }
         }
@@ -1873,7 +1876,7 @@ __global__ void __launch_bounds__(kLaneChunk) k_cov(Status *st, const ProbDesc *
                                pair_thr, pair_cap, amb_g, out_g, tri_cap);
         return;
     }
-    __shared__ int cp[kNHuge + 4];
+    __shared__ int cp[kNGiant + 4];
     __shared__ u64 work_s;
     __shared__ unsigned active_s;
     i64 n_work = (i64)st->n_work;
@@ -1887,7 +1890,7 @@ __global__ void __launch_bounds__(kLaneChunk) k_cov(Status *st, const ProbDesc *
         const ProbDesc d = load_desc(desc + pc.x);
         const int n = d.n;
         i64 coff = d.cov_off + (i64)chunk * kLaneChunk * n;
-        if (n > kNHuge || coff + (i64)kLaneChunk * n > cov_cap) { if (threadIdx.x == 0) work_active[w] = 0; continue; }
+        if (n > kNGiant || coff + (i64)kLaneChunk * n > cov_cap) { if (threadIdx.x == 0) work_active[w] = 0; continue; }
         const int *cy = cand_y + d.c0;
         const int g0 = d.g0;
         int t = threadIdx.x;
@@ -3793,6 +3796,202 @@ __global__ void __launch_bounds__(512) k_dp_huge(Status *st, const int *dp_items
 }
 
 // ---------------------------------------------------------------------------------------------
+// Problems with kNHuge < n <= kNGiant candidates (round 5: max_problem_size beyond ~115 used to be refused, although the CLI
+// -- like the reference's parse_args :108 -- accepts any value > 3 and optimize :475-568 has no size limit).  The same two
+// kernels as the huge class with every per-pair table in GLOBAL scratch (a piece per workgroup, sized for the run's largest
+// problem): the pair planes of the scoring kernel; M, in() and the argument (16 bits) of the DP.  Only the 32 reads' coverage
+// rows and the candidates' positions stay in LDS (dynamic: (32 + 2) * (n + 1) words).  One workgroup owns a problem; values
+// written by one wave and read by another are ordered by the workgroup's barriers (one CU, one L1).  Slow -- a thread walks its
+// pairs' c2 loop from global memory -- and complete; checked against the oracle at max_problem_size 150 and 300.
+// ---------------------------------------------------------------------------------------------
+constexpr int kGiantWgs = 64;              // workgroups (and scratch pieces) of a giant-kernel launch
+inline size_t giant_score_lds(int nm) { return (size_t)(2 * nm + kHugeSub * (nm + 1)) * 4; }
+inline size_t giant_dp_lds(int nm) { return (size_t)nm * 4; }
+inline size_t giant_scratch_bytes(int nm) {                 // per workgroup: max(planes, M + in + A)
+    const size_t pairs = (size_t)nm * (nm - 1) / 2;
+    return ((pairs * (8 + 4 + 2) + 255) & ~(size_t)255);
+}
+__global__ void __launch_bounds__(512) k_score_giant(Status *st, const int *dp_items, ProblemArrays pr, const ProbDesc *desc,
+                                                     i64 prob_cap, i64 work_cap, const int *cand_y, const unsigned *cov_g,
+                                                     i64 cov_cap, const int2 *pair_thr, i64 pair_cap, unsigned *out_g,
+                                                     i64 tri_cap, unsigned *amb_g, int nm, unsigned char *scratch, i64 scratch_stride) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    int *cy_s = reinterpret_cast<int *>(smem);
+    int *iend_s = cy_s + nm;
+    unsigned *cov = reinterpret_cast<unsigned *>(iend_s + nm);                 // [read][j], stride nm + 1
+    uint2 *planes = reinterpret_cast<uint2 *>(scratch + (i64)blockIdx.x * scratch_stride);   // {yea, nay} per pair
+    constexpr int T = 512;
+    const int stride = nm + 1;
+    if ((i64)st->n_work > work_cap || (i64)st->n_prob > prob_cap) return;              // sizing run
+    const i64 list_base = (i64)st->dp_cls[0] + (i64)st->dp_cls[1], list_n = (i64)st->dp_cls[2];
+    for (i64 t = blockIdx.x; t < list_n; t += gridDim.x) {
+        __syncthreads();
+        const int p = dp_items[list_base + t];
+        const ProbDesc d = load_desc(desc + p);
+        const int n = d.n;
+        if (n <= kNHuge || n > nm) continue;                                          // (the huge kernels' problems; nm covers the run's largest)
+        const int npairs = n * (n - 1) / 2;
+        const i64 ntri = (i64)n * (n - 1) * (n - 2) / 6;
+        const i64 poff = d.pair_off, toff = d.tri_off;
+        const int n_chunks = (d.lane_n + kLaneChunk - 1) / kLaneChunk;
+        if (poff + npairs > pair_cap || toff + ntri > tri_cap || d.cov_off + (i64)n_chunks * kLaneChunk * n > cov_cap) continue;
+        for (int j = threadIdx.x; j < n; j += T) cy_s[j] = cand_y[d.c0 + j];
+        __syncthreads();
+        for (int j = threadIdx.x; j < n; j += T) {
+            int lim = cy_s[j] - 5, lo = 0, hi = j;
+            while (lo < hi) { int mid = (lo + hi) >> 1; if (cy_s[mid] <= lim) lo = mid + 1; else hi = mid; }
+            iend_s[j] = lo;                                        // number of i < j with cand_j - cand_i >= 5 (:540)
+        }
+        for (int r0 = 0; r0 < d.lane_n; r0 += kHugeSub) {
+            const int nr = d.lane_n - r0 < kHugeSub ? d.lane_n - r0 : kHugeSub;
+            const int chunk = r0 / kLaneChunk, in_chunk = r0 % kLaneChunk;
+            const unsigned *src = cov_g + d.cov_off + (i64)chunk * kLaneChunk * n + in_chunk;   // [j][256 reads]
+            __syncthreads();
+            for (int x = threadIdx.x; x < n * kHugeSub; x += T) {
+                const int j = x / kHugeSub, b = x % kHugeSub;
+                cov[b * stride + j] = b < nr ? src[(i64)j * kLaneChunk + b] : 0u;
+            }
+            __syncthreads();
+            const unsigned valid = nr >= 32 ? 0xffffffffu : ((1u << nr) - 1u);
+            for (int q = threadIdx.x; q < npairs; q += T) {
+                int i, j;
+                pair_decode(q, &i, &j);
+                const int2 th = pair_thr[poff + q];
+                unsigned y = 0, z = 0;
+                for (int b = 0; b < kHugeSub; ++b) {
+                    const int dd = (int)(cov[b * stride + j] - cov[b * stride + i]);
+                    y |= (unsigned)(dd >= th.x) << b;              // yea: covered fraction above the high threshold
+                    z |= (unsigned)(dd <= th.y) << b;              // nay: below the low threshold
+                }
+                y &= valid; z &= valid;
+                planes[q] = make_uint2(y, z);
+                const unsigned amb = __popc(~(y | z) & valid);
+                if (amb) amb_g[poff + q] += amb;                    // this workgroup owns the problem: plain update
+            }
+            __syncthreads();
+            // triples: thread = (j,k), loop over the i with cand_j - cand_i >= 5; counters of a (j,k) are contiguous
+            for (int r = threadIdx.x; r < npairs; r += T) {
+                int j, kk;
+                pair_decode(r, &j, &kk);
+                if (j == 0 || cy_s[kk] - cy_s[j] < 5) continue;
+                const uint2 B = planes[r];
+                if ((B.x | B.y) == 0) continue;
+                unsigned *o = out_g + toff + (i64)kk * (kk - 1) * (kk - 2) / 6 + j * (j - 1) / 2;
+                const int abase = j * (j - 1) / 2, i_end = iend_s[j];
+                for (int i = 0; i < i_end; ++i) {
+                    const uint2 A = planes[abase + i];
+                    const unsigned cnt = __popc((A.x & B.y) | (A.y & B.x));          // (disjoint: a read is never yea and nay of one pair)
+                    if (cnt) o[i] += cnt;
+                }
+            }
+        }
+    }
+}
+__global__ void __launch_bounds__(512) k_dp_giant(Status *st, const int *dp_items, ProblemArrays pr, const ProbDesc *desc,
+                                                  i64 prob_cap, const int *cand_y, const unsigned *out_g, i64 tri_cap,
+                                                  const unsigned *amb_g, const int2 *pair_thr, i64 pair_cap, int support,
+                                                  unsigned char *chosen, int nm, unsigned char *scratch, i64 scratch_stride) {
+    constexpr int T = 512;
+    constexpr unsigned short kNoArg = 0xffffu;
+    extern __shared__ __align__(16) unsigned char smem[];
+    int *cy_s = reinterpret_cast<int *>(smem);
+    __shared__ i64 top_v[T / 64];
+    __shared__ i64 top_key[T / 64];
+    const i64 rt_pairs = (i64)nm * (nm - 1) / 2;
+    i64 *M = reinterpret_cast<i64 *>(scratch + (i64)blockIdx.x * scratch_stride);
+    int *in_s = reinterpret_cast<int *>(M + rt_pairs);
+    unsigned short *A = reinterpret_cast<unsigned short *>(in_s + rt_pairs);
+    if ((i64)st->n_prob > prob_cap) return;
+    const i64 list_base = (i64)st->dp_cls[0] + (i64)st->dp_cls[1], list_n = (i64)st->dp_cls[2];
+    for (i64 t = blockIdx.x; t < list_n; t += gridDim.x) {
+        __syncthreads();
+        const int p = dp_items[list_base + t];
+        const ProbDesc d = load_desc(desc + p);
+        const int n = d.n;
+        if (n <= kNHuge || n > nm) continue;
+        const int npairs = n * (n - 1) / 2, end = n - 1;
+        const i64 ntri = (i64)n * (n - 1) * (n - 2) / 6;
+        const i64 poff = d.pair_off, toff = d.tri_off;
+        if (poff + npairs > pair_cap || toff + ntri > tri_cap) continue;
+        const unsigned *out_p = out_g + toff;
+        const i64 outside = d.outside;
+        const bool zamb = (pr.flags[p] & 1) != 0;
+        for (int j = threadIdx.x; j < n; j += T) cy_s[j] = cand_y[d.c0 + j];
+        for (int q = threadIdx.x; q < npairs; q += T)
+            in_s[q] = -(int)((i64)amb_g[poff + q] + ((zamb && pair_thr[poff + q].y < 0) ? outside : 0));
+        __syncthreads();
+#define FSEG_IN(a, bb) ((i64)in_s[(bb) * ((bb) - 1) / 2 + (a)])
+#define FSEG_M(a, bb) M[(bb) * ((bb) - 1) / 2 + (a)]
+        for (int x = threadIdx.x; x < end; x += T) {
+            FSEG_M(x, end) = cy_s[end] - cy_s[x] >= 5 ? FSEG_IN(x, end) : kNegInf;
+            A[end * (end - 1) / 2 + x] = kNoArg;
+        }
+        __syncthreads();
+        for (int c = end - 1; c >= 2; --c) {
+            // M(b,c) = in(b,c) + max over c2 > c of out(b,c,c2) + M(c,c2), first maximiser (:550-555); a thread per b
+            for (int b = 1 + threadIdx.x; b < c; b += T) {
+                i64 best = kNegInf; int arg = kNoArg;
+                const bool live = cy_s[c] - cy_s[b] >= 5;
+                if (live) {
+                    const int base = c * (c - 1) / 2 + b;
+                    for (int c2 = c + 1; c2 <= end; ++c2) {
+                        const i64 tail = FSEG_M(c, c2);
+                        const unsigned o = out_p[(i64)c2 * (c2 - 1) * (c2 - 2) / 6 + base];
+                        const bool ok = (tail != kNegInf) & ((i64)o >= (i64)support);
+                        const i64 cur = ok ? (i64)o + tail : kNegInf;
+                        const bool take = cur > best;
+                        best = take ? cur : best; arg = take ? c2 : arg;
+                    }
+                }
+                FSEG_M(b, c) = (live && best != kNegInf) ? best + FSEG_IN(b, c) : kNegInf;
+                A[c * (c - 1) / 2 + b] = (unsigned short)arg;
+            }
+            __syncthreads();
+        }
+        // top level (:560-566): first maximiser in (j, k) order, taken only if strictly better than no cut
+        i64 bv = kNegInf, bkey = 0x7fffffffffffffffLL;
+        for (int q = threadIdx.x; q < npairs; q += T) {
+            int j, kx;
+            pair_decode(q, &j, &kx);
+            if (j < 1) continue;
+            if (cy_s[j] - cy_s[0] < 5 || cy_s[kx] - cy_s[j] < 5) continue;
+            const i64 tail = FSEG_M(j, kx);
+            const unsigned o = out_p[(i64)kx * (kx - 1) * (kx - 2) / 6 + j * (j - 1) / 2];
+            if (tail == kNegInf || (i64)o < (i64)support) continue;
+            const i64 cur = FSEG_IN(0, j) + (i64)o + tail;
+            const i64 key = ((i64)j << 20) | (i64)kx;
+            if (cur > bv || (cur == bv && key < bkey)) { bv = cur; bkey = key; }
+        }
+        for (int dd = 32; dd >= 1; dd >>= 1) {
+            i64 ov = __shfl_xor(bv, dd); i64 ok2 = __shfl_xor(bkey, dd);
+            if (ov > bv || (ov == bv && ok2 < bkey)) { bv = ov; bkey = ok2; }
+        }
+        if (lane_id() == 0) { top_v[threadIdx.x >> 6] = bv; top_key[threadIdx.x >> 6] = bkey; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < T / 64; ++w)
+                if (top_v[w] > bv || (top_v[w] == bv && top_key[w] < bkey)) { bv = top_v[w]; bkey = top_key[w]; }
+            int chain = 0;
+            if (bv != kNegInf && bv > FSEG_IN(0, end)) {
+                int j = (int)(bkey >> 20), k = (int)(bkey & 0xfffff);
+                unsigned char *ch = chosen + d.c0;
+                ch[0] = 1;
+                for (;;) {
+                    ch[j] = 1; ch[k] = 1; ++chain;
+                    if (k == end) break;
+                    const int k2 = A[k * (k - 1) / 2 + j];
+                    if (k2 == kNoArg) break;
+                    j = k; k = k2;
+                }
+            }
+            pr.chain[p] = chain;
+        }
+#undef FSEG_IN
+#undef FSEG_M
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // S6  refinement   (refine_segmentation :249-266) and final positions (:802-807)
 // k_segments marks the chosen candidates as final positions and, for every chosen candidate whose
 // previous chosen candidate is more than 40 positions away, records that segment; k_refine then
@@ -4689,6 +4888,8 @@ struct fseg_ctx {
     bool profiling = false;
     bool profile_all = true;    // false (fseg_set_profiling(ctx, 2)): only the interval-scoring stage is bracketed by events
     bool have_huge = false;      // the batch has a problem with more than kNMax candidates: launch the huge kernels
+    int nm_giant = 0;            // ... with more than kNHuge: its size (rounded up: the LDS carve-up and scratch piece of the giant kernels); 0: none
+    DevBuf d_giant;              // their scratch: kGiantWgs pieces of giant_scratch_bytes(nm_giant) (own allocation)
     bool dp_wide_counts = false; // some problem sees >= 65536 reads: DP stages 32-bit counts
     int nm_big = kNMax;         // LDS carve-up of the big-problem kernels: largest problem of the batch, rounded up
     bool small_batch = false;
@@ -5400,6 +5601,12 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
                                c->d_prob_desc.as<ProbDesc>(), c->prob_cap, c->work_cap, c->d_cand_y.as<int>(),
                                c->d_cov.as<unsigned>(), c->cov_cap, c->d_pair_thr.as<int2>(), c->pair_cap,
                                c->d_out.as<unsigned>(), c->tri_cap, c->d_amb.as<unsigned>());
+        if (c->have_huge && c->nm_giant > 0 && any_arena && c->d_giant.p)
+            hipLaunchKernelGGL(k_score_giant, dim3(kGiantWgs), dim3(512), giant_score_lds(c->nm_giant), s, st, c->d_dp_items.as<int>(), pr,
+                               c->d_prob_desc.as<ProbDesc>(), c->prob_cap, c->work_cap, c->d_cand_y.as<int>(),
+                               c->d_cov.as<unsigned>(), c->cov_cap, c->d_pair_thr.as<int2>(), c->pair_cap,
+                               c->d_out.as<unsigned>(), c->tri_cap, c->d_amb.as<unsigned>(), c->nm_giant,
+                               c->d_giant.as<unsigned char>(), (i64)giant_scratch_bytes(c->nm_giant));
         if (tiny_max > 0 && sfork) join(2);    // k_tiny is interval scoring too: inside the stage's time bracket
     }
     if (do_score) end(ST_SCORE);
@@ -5456,6 +5663,12 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
                                pr, c->d_prob_desc.as<ProbDesc>(), c->prob_cap, c->d_cand_y.as<int>(), c->d_out.as<unsigned>(),
                                c->tri_cap, c->d_amb.as<unsigned>(), c->d_pair_thr.as<int2>(), c->pair_cap,
                                c->P.min_read_support_outside, c->d_chosen.as<unsigned char>());
+        if (c->have_huge && c->nm_giant > 0 && c->d_giant.p)
+            hipLaunchKernelGGL(k_dp_giant, dim3(kGiantWgs), dim3(512), giant_dp_lds(c->nm_giant), s, st, c->d_dp_items.as<int>(),
+                               pr, c->d_prob_desc.as<ProbDesc>(), c->prob_cap, c->d_cand_y.as<int>(), c->d_out.as<unsigned>(),
+                               c->tri_cap, c->d_amb.as<unsigned>(), c->d_pair_thr.as<int2>(), c->pair_cap,
+                               c->P.min_read_support_outside, c->d_chosen.as<unsigned char>(), c->nm_giant,
+                               c->d_giant.as<unsigned char>(), (i64)giant_scratch_bytes(c->nm_giant));
     }
     end(ST_DP); begin(ST_REFINE);
     // S6
@@ -5541,7 +5754,19 @@ int run_input_errors(fseg_ctx *c, const Status &s) {
     if (s.err & kErrExonInterval) return fail(c, FSEG_ERR_INPUT, "an exon does not lie inside one tint interval (py/freddie_segment.py:668)");
     if (s.err & kErrBreakAssert) return fail(c, FSEG_ERR_INPUT, "break_large_problems: candidate window out of range or no positive signal (py/freddie_segment.py:640-643)");
     if (s.err & kErrWideMissed) return fail(c, FSEG_ERR_HIP, "internal: a problem keeps more reads than were counted for it (kErrWideMissed)");
-    if (s.err & kErrProblemTooLarge) return fail(c, FSEG_ERR_UNSUPPORTED, "a DP problem has more than %d candidates (max_problem_size too large for this build)", kNHuge);
+    if (s.err & kErrProblemTooLarge) return fail(c, FSEG_ERR_UNSUPPORTED, "a DP problem has more than %d candidates (max_problem_size beyond 1000 is not supported)", kNGiant);
+    return FSEG_OK;
+}
+
+// the giant-problem kernels' LDS carve-up and scratch for a run whose largest problem has max_n candidates
+int prepare_giant(fseg_ctx *c, int max_n) {
+    if (max_n <= kNHuge || max_n > kNGiant) { if (max_n <= kNHuge) c->nm_giant = 0; return FSEG_OK; }
+    int want = (max_n + 7) & ~7;
+    if (want > kNGiant) want = kNGiant;
+    if (want > c->nm_giant || c->nm_giant == 0) { c->nm_giant = want; drop_graph(c); }
+    TRY(ensure(c, c->d_giant, (size_t)kGiantWgs * giant_scratch_bytes(c->nm_giant)));
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_score_giant), hipFuncAttributeMaxDynamicSharedMemorySize, (int)giant_score_lds(kNGiant));
+    if (e != hipSuccess) return fail(c, FSEG_ERR_HIP, "hipFuncSetAttribute(k_score_giant): %s", hipGetErrorString(e));
     return FSEG_OK;
 }
 
@@ -5627,6 +5852,10 @@ static int finish_run_impl(fseg_ctx *c) {
         if ((i64)s.max_ln >= 65536 && !c->dp_wide_counts) { ovf |= kErrNeedWideDp; c->dp_wide_counts = true; drop_graph(c); }
         if (s.err & kErrScanStall) { ovf |= kErrScanStall; c->scan_single_max = 0; c->force_scan_stall = false; drop_graph(c); }
         if (s.dp_cls[2] > 0 && !c->have_huge) { ovf |= kErrProblemTooLarge << 16; c->have_huge = true; drop_graph(c); }   // rerun with the huge-problem kernels
+        if ((int)s.max_n > kNHuge && (int)s.max_n <= kNGiant && (int)s.max_n > c->nm_giant) {                             // ... and the giant ones, sized for this run's largest problem
+            ovf |= kErrProblemTooLarge << 17; drop_graph(c);
+            TRY(prepare_giant(c, (int)s.max_n));
+        }
         bool need = ovf != 0 || (i64)s.n_prob > c->prob_cap || (i64)s.n_work > c->work_cap ||
                     (i64)s.pair_used > c->pair_cap || (i64)s.tri_used > c->tri_cap || (i64)s.label_bytes > c->label_cap ||
                     (i64)s.n_vchunks > c->chunk_cap || (i64)s.cov_used > c->cov_cap;
@@ -5712,6 +5941,7 @@ int run_sized(fseg_ctx *c) {
         atleast(c->prob_cap, (i64)s.n_prob); atleast(c->work_cap, (i64)s.n_work); atleast(c->pair_cap, (i64)s.pair_used);
         atleast(c->tri_cap, (i64)s.tri_used); atleast(c->cov_cap, (i64)s.cov_used);
         c->have_huge = s.dp_cls[2] > 0;
+        TRY(prepare_giant(c, (int)s.max_n));
         c->dp_wide_counts = c->force_wide_dp || (i64)s.max_ln >= 65536;
         note_counts(c, s);
         adapt_to(c, s);
@@ -5889,7 +6119,7 @@ void fseg_destroy(fseg_ctx *c) {
     drop_graph(c);
     Slab *slabs[] = {&c->slab_in, &c->slab_pos, &c->slab_arena};
     for (Slab *s : slabs) if (s->p) (void)hipFree(s->p);
-    DevBuf *bufs[] = {&c->d_labels, &c->d_packed, &c->d_sort_tmp, &c->d_w_main, &c->d_w_refine, &c->d_h_table, &c->d_thr_tab, &c->d_status, &c->d_prep, &c->d_tacc, &c->d_sync};
+    DevBuf *bufs[] = {&c->d_labels, &c->d_packed, &c->d_sort_tmp, &c->d_w_main, &c->d_w_refine, &c->d_h_table, &c->d_thr_tab, &c->d_status, &c->d_prep, &c->d_tacc, &c->d_sync, &c->d_giant};
     for (DevBuf *b : bufs) if (b->p) (void)hipFree(b->p);
     if (c->h_stage.p) (void)hipHostFree(c->h_stage.p);
     if (c->h_res.p) (void)hipHostFree(c->h_res.p);

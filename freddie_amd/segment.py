@@ -27,6 +27,9 @@ CIGAR_OPS = "MIDNSHPX="
 # --------------------------------------------------------------------------------------------------
 # arguments (same flags, defaults and range checks as the reference; --gpus / --batch-reads are additions)
 # --------------------------------------------------------------------------------------------------
+MAX_PROBLEM_SIZE = 1000      # -mps: the library's largest DP problem is 1 024 candidates (kNGiant, freddie_amd/csrc/freddie_seg.hip)
+
+
 def str_to_bool(value):
     if isinstance(value, bool):
         return value
@@ -70,6 +73,10 @@ def parse_args(argv=None):
     assert 10 > args.variance_factor > 0
     assert 50 >= args.sigma > 0
     assert args.max_problem_size > 3
+    # (the reference has no upper bound -- its optimize() is O(n^3 R) Python --; this library's DP kernels take problems of up to
+    # 1 024 candidates, and break_large_problems leaves problems a little larger than the limit it is given)
+    if args.max_problem_size > MAX_PROBLEM_SIZE:
+        ap.error("--max-problem-size %d is beyond what this implementation runs (at most %d)" % (args.max_problem_size, MAX_PROBLEM_SIZE))
     assert args.min_read_support_outside >= 0
     assert args.threads > 0
     return args

@@ -179,6 +179,42 @@ def test_huge_problems_and_tiny_problems_in_one_batch(monkeypatch):
         ctx.close()
 
 
+@pytest.mark.parametrize("mps", [150, 300])
+def test_giant_problems_beyond_the_lds_kernels(mps, monkeypatch):
+    """max_problem_size 150 / 300 (the CLI, like the reference's parse_args :108, accepts any value > 3; optimize :475-568 has no
+    size limit): DP problems of 130 .. 300 candidates go through k_score_giant / k_dp_giant (every per-pair table in global
+    scratch), next to ordinary partitions in the same batch, sized first run and replay, and with guessed arenas."""
+    params = dict(max_problem_size=mps, variance_factor=9.99)
+    parts = [util.make_partition(77, n_reads=300, n_exons=400, rp=0.3, max_span=0), util.make_partition(78, n_reads=200, n_exons=600, rp=0.5, max_span=0)]
+    parts += [util.make_partition(600 + i, n_reads=150, n_exons=60, rp=0.05) for i in range(4)]
+    oracles = [util.run_oracle(p, params) for p in parts]
+    sizes = np.concatenate([o["prob_end"] - o["prob_start"] + 1 for o in oracles])
+    assert sizes.max() > 128 and (mps == 150 or sizes.max() > 256), sizes.max()
+    for env in ({}, {"FSEG_NO_SIZED": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ctx = _lib.Context(0)
+        try:
+            check_twice(ctx, parts, oracles, params)
+            assert ctx.sizes()["max_problem_size"] == sizes.max()
+            small = parts[2:]                                     # the next batch has no such problem
+            check_twice(ctx, small, oracles[2:], params)
+        finally:
+            ctx.close()
+
+
+def test_problems_beyond_the_largest_kernel_are_refused(gpu_ctx):
+    """More than 1 024 candidates in one problem (max_problem_size beyond what the CLI lets through): FSEG_ERR_UNSUPPORTED, no labels."""
+    params = dict(max_problem_size=5000, variance_factor=9.99)
+    part = util.make_partition(79, n_reads=100, n_exons=1500, rp=0.6, max_span=0)
+    with pytest.raises(_lib.SegError, match="more than 1024 candidates"):
+        util.run_gpu(gpu_ctx, [part], params)
+        gpu_ctx.download()
+    good = util.make_partition(5, n_reads=100, n_exons=20)
+    util.run_gpu(gpu_ctx, [good])                                 # the context is still usable
+    util.compare_partitions(gpu_ctx, [good], [util.run_oracle(good)])
+
+
 @pytest.mark.parametrize("workload,n_part", [("config4", 500), ("config3", 250), ("config5", 250)])
 def test_full_size_bench_batches_against_oracle(workload, n_part, gpu_ctx):
     """The exact batches bench.py times (config4: 500 x 500 reads; config3: 250 x 1000 reads; config5: 250 x 1000 reads of the

@@ -68,6 +68,12 @@ def test_cli_arguments_match_reference_defaults():
     for bad in (["-tp", "0.4"], ["-vf", "10"], ["-sd", "51"], ["-mps", "3"], ["-lo", "-1"], ["-t", "0"]):
         with pytest.raises(AssertionError):
             segment.parse_args(["-s", "x"] + bad)
+    # what the library cannot run is refused at the door (the reference has no upper bound on -mps; the DP kernels stop at 1 024
+    # candidates per problem), and abbreviated options are not guessed (py/freddie_segment.py reads --gpus / --devices itself)
+    assert segment.parse_args(["-s", "x", "-mps", "1000"]).max_problem_size == 1000
+    for bad in (["-mps", "1001"], ["--dev", "0,1"], ["--gpu", "2"]):
+        with pytest.raises(SystemExit):
+            segment.parse_args(["-s", "x"] + bad)
 
 
 def test_parser_rejects_malformed_lines(tmp_path):
