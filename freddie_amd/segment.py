@@ -601,14 +601,20 @@ def run_segment(segment_args, ctx=None):
 
 def discover(split_dir, outdir):
     """(contig, tint_id, cost) of every partition, creating the output directories (:852-857)."""
+    # (one scandir pass per contig directory: name, type and size of an entry come from the same directory read -- listdir +
+    # glob + getsize was three passes and a stat per file, 40 ms for the 8 000 files of the 2 M-read job)
     found = []
-    for contig in os.listdir(split_dir):
-        if not os.path.isdir("{}/{}".format(split_dir, contig)):
-            continue
-        os.makedirs("{}/{}".format(outdir, contig), exist_ok=True)
-        for path in glob.iglob("{}/{}/split_*.tsv".format(split_dir, contig)):
-            tint_id = int(path[:-4].split("/")[-1].split("_")[-1])
-            found.append((contig, tint_id, os.path.getsize(path)))
+    with os.scandir(split_dir) as contigs:
+        for centry in contigs:
+            if not centry.is_dir():
+                continue
+            contig = centry.name
+            os.makedirs("{}/{}".format(outdir, contig), exist_ok=True)
+            with os.scandir(centry.path) as files:
+                for f in files:
+                    name = f.name
+                    if name.startswith("split_") and name.endswith(".tsv"):
+                        found.append((contig, int(name[:-4].split("_")[-1]), f.stat().st_size))
     return found
 
 
@@ -657,6 +663,9 @@ def open_contexts(device, n=2):
 
 
 def _gpu_worker(device, n_workers, jobs_with_cost, params, batch_bytes, threads, queue, sidecar="off", worker=None):
+    """jobs_with_cost: the worker's jobs, or the receiving end of a pipe they arrive through (main() starts its workers before
+    it has looked at the split directory: interpreter start-up, imports and the GPU's contexts -- 0.3-0.5 s -- run beside the
+    parent's discovery and scatter instead of behind them)."""
     from . import devices
     from concurrent.futures import ThreadPoolExecutor
     # host threads of this worker stay on its share of the cores (next to its GPU where that is known: devices.py)
@@ -664,6 +673,12 @@ def _gpu_worker(device, n_workers, jobs_with_cost, params, batch_bytes, threads,
     with ThreadPoolExecutor(max_workers=1) as boot:
         ctx_future = boot.submit(open_contexts, device)
         try:
+            if hasattr(jobs_with_cost, "recv"):
+                conn = jobs_with_cost
+                try:
+                    jobs_with_cost = _expand_jobs(conn.recv())
+                finally:
+                    conn.close()
             run_batches(make_batches(jobs_with_cost, batch_bytes), params, ctx_future, threads, queue.put, sidecar)
         finally:
             try:
@@ -671,6 +686,15 @@ def _gpu_worker(device, n_workers, jobs_with_cost, params, batch_bytes, threads,
                     ctx.close()
             finally:
                 queue.put(None)
+
+
+def _expand_jobs(msg):
+    """(split_dir, outdir, [(contig, tint_id, cost), ...]) -> [((split_dir, outdir, contig, tint_id), cost), ...]; None: no work
+    (the parent stopped before it had a job list: an error it reports itself)."""
+    if msg is None:
+        return []
+    split_dir, outdir, items = msg
+    return [((split_dir, outdir, contig, tint_id), cost) for contig, tint_id, cost in items]
 
 
 def main(argv=None):
@@ -712,16 +736,39 @@ def main(argv=None):
             if ctx_future is not None and ctx_future.exception() is None:
                 for ctx in ctx_future.result():
                     ctx.close()
+    params = (args.sigma, tables.smooth_threshold(args.threshold_rate), args.threshold_rate, args.variance_factor,
+              args.max_problem_size, args.min_read_support_outside, not args.consider_ends)
+    batch_bytes = max(1, args.batch_reads) * 1400          # ~1.4 KB of split TSV per read
+    # Several GPUs: one worker process each, started NOW -- before this process has looked at the split directory -- with the
+    # sending end of a pipe kept here: a worker's interpreter, imports and GPU contexts (0.3-0.5 s) come up beside the
+    # discovery and the scatter, and its job list follows through the pipe.  (Until round 5 the workers were started one after
+    # the other once the scatter was known, each with its job list pickled into the start-up message.)
+    procs, conns, queue = [], [], None
+    if n_gpus > 1:
+        mp = multiprocessing.get_context(WORKER_START_METHOD)
+        queue = mp.Queue()
+        for w, dev in enumerate(device_list):
+            recv_end, send_end = mp.Pipe(duplex=False)
+            pr = mp.Process(target=_gpu_worker, args=(dev, n_gpus, recv_end, params, batch_bytes, args.threads, queue, args.sidecar, w))
+            pr.start()
+            recv_end.close()
+            procs.append(pr)
+            conns.append(send_end)
+    t_started = time.perf_counter()
     try:
         parts = discover(split_dir, args.outdir)
-        params = (args.sigma, tables.smooth_threshold(args.threshold_rate), args.threshold_rate, args.variance_factor,
-                  args.max_problem_size, args.min_read_support_outside, not args.consider_ends)
         costs = [c for _, _, c in parts]
         assign = scatter.lpt_scatter(costs, n_gpus)
     except BaseException:
         close_boot()
+        for conn in conns:                       # the workers end at once (nothing to do) and the error is this process's to report
+            try:
+                conn.send(None); conn.close()
+            except OSError:
+                pass
+        for pr in procs:
+            pr.join()
         raise
-    batch_bytes = max(1, args.batch_reads) * 1400          # ~1.4 KB of split TSV per read
     total = len(parts)
     step = ceil(total / 100) if total else 1
     done_count = 0
@@ -747,14 +794,12 @@ def main(argv=None):
             print("[freddie_segment] discover %.3f s, batches (incl. context start-up) %.3f s, close %.3f s" % (
                 t_disc - t_start, t_run - t_disc, time.perf_counter() - t_run), file=sys.stderr)
         return
-    mp = multiprocessing.get_context(WORKER_START_METHOD)
-    queue = mp.Queue()
-    procs = []
-    for w, dev in enumerate(device_list):
-        jobs = [((split_dir, args.outdir, parts[i][0], parts[i][1]), parts[i][2]) for i in assign[w]]
-        pr = mp.Process(target=_gpu_worker, args=(dev, n_gpus, jobs, params, batch_bytes, args.threads, queue, args.sidecar, w))
-        pr.start()
-        procs.append(pr)
+    t_disc = time.perf_counter()
+    for w, conn in enumerate(conns):
+        conn.send((split_dir, args.outdir, [parts[i] for i in assign[w]]))
+        conn.close()
+    t_sent = time.perf_counter()
+    t_first = None
     import queue as queue_mod
     alive = n_gpus
     while alive:
@@ -771,11 +816,19 @@ def main(argv=None):
         if item is None:
             alive -= 1
         else:
+            if t_first is None:
+                t_first = time.perf_counter()
             report()
+    t_done = time.perf_counter()
     for pr in procs:
         pr.join()
         if pr.exitcode != 0:
             raise SystemExit("a GPU worker failed with exit code %s" % pr.exitcode)
+    if timing:
+        print("[freddie_segment] %d workers started %.3f s after main() began; discovery + scatter of %d partitions until %.3f s; job lists sent "
+              "%.3f s; first partition done %.3f s; last %.3f s; workers joined %.3f s" % (
+                  n_gpus, t_started - t_start, total, t_disc - t_start, t_sent - t_start, (t_first or t_done) - t_start, t_done - t_start,
+                  time.perf_counter() - t_start), file=sys.stderr)
 
 
 if __name__ == "__main__":

@@ -65,15 +65,18 @@ def null_contexts(device, n=2):
     return [NullContext(device) for _ in range(n)]
 
 
-def generate(split, n_part, n_reads):
+def generate(split, n_part, n_reads, n_contigs=1):
+    """Partitions 0 .. n_part - 1, spread over n_contigs contig directories (chr1 .. chrN; one: chrS, as the bench's e2e leg) --
+    a genome's split directory has a directory per contig (reference main() :852-857), and a directory is also what the
+    output files of many partitions contend for."""
     import multiprocessing as mp
-    with mp.get_context("fork").Pool(min(os.cpu_count() or 1, 32)) as pool:
-        pool.map(_gen, [(i, n_reads, split) for i in range(n_part)], chunksize=8)
+    with mp.get_context("fork").Pool(min(len(os.sched_getaffinity(0)), 32)) as pool:
+        pool.map(_gen, [(i, n_reads, split, "chrS" if n_contigs <= 1 else "chr%d" % (1 + i % n_contigs)) for i in range(n_part)], chunksize=8)
 
 
 def _gen(job):
-    i, n_reads, split = job
-    synth.generate(i, n_reads=n_reads, n_exons=150, rp=0.05, write_dir=split)
+    i, n_reads, split, contig = job
+    synth.generate(i, n_reads=n_reads, n_exons=150, rp=0.05, write_dir=split, contig=contig)
 
 
 def run(split, out, workers, threads, label):
@@ -101,6 +104,7 @@ def main():
     ap.add_argument("--label", default="0,1")
     ap.add_argument("--keep", default=None)
     ap.add_argument("--repeat", type=int, default=2)
+    ap.add_argument("--contigs", type=int, default=1, help="contig directories the partitions are spread over (a genome: 24 and more)")
     args = ap.parse_args()
     base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
     work = args.keep or tempfile.mkdtemp(prefix="host_ceiling_", dir=base)
@@ -108,8 +112,9 @@ def main():
     try:
         if not os.path.isdir(split):
             t0 = time.perf_counter()
-            generate(split, args.partitions, args.reads)
-            print("generated %d partitions x %d reads in %.1f s under %s" % (args.partitions, args.reads, time.perf_counter() - t0, work))
+            generate(split, args.partitions, args.reads, args.contigs)
+            print("generated %d partitions x %d reads in %d contig directories in %.1f s under %s" % (
+                args.partitions, args.reads, max(1, args.contigs), time.perf_counter() - t0, work))
         n = args.partitions * args.reads
         cores = len(os.sched_getaffinity(0))
         print("host cores available: %d" % cores)
