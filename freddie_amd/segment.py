@@ -508,8 +508,7 @@ def run_batches(batches, params, ctxs, threads, on_done, sidecar="off"):
             print("[freddie_segment] batch %d: %d partitions (%d from side-cars), %d reads: load %.3f s, device %.3f s, "
                   "write %.3f s" % (i, len(jobs), n_sc, n_reads, t_load, t_dev, time.perf_counter() - t0), file=sys.stderr)
         with done_lock:
-            for j in jobs:
-                on_done((j[2], j[3]))
+            on_done(len(jobs))               # (a count per batch, not a message per partition: see main())
 
     with ThreadPoolExecutor(max_workers=2) as load_pool, ThreadPoolExecutor(max_workers=2) as dev_pool, \
             ThreadPoolExecutor(max_workers=2) as write_pool:
@@ -624,9 +623,14 @@ def make_batches(jobs_with_cost, bytes_per_batch):
     one's write) stay short; a batch costs the device a few milliseconds, so small batches are cheap."""
     total = sum(c for _, c in jobs_with_cost)
     bytes_per_batch = min(bytes_per_batch, max(total // 8, 8 << 20))
+    # ... and the first batches are cut smaller (a quarter, a quarter, a half, a half of the size): the device and the writers have
+    # nothing to do until the first load is through, and the first load is what the pipeline's start costs (0.10-0.13 s of the
+    # 0.55 s the 2 M-read job spends in its batches, FREDDIE_TIMING=1)
+    ramp = [4, 4, 2, 2] if total > 4 * bytes_per_batch else []
     batches, cur, size = [], [], 0
     for job, cost in jobs_with_cost:
-        if cur and size + cost > bytes_per_batch:
+        limit = bytes_per_batch // ramp[len(batches)] if len(batches) < len(ramp) else bytes_per_batch
+        if cur and size + cost > limit:
             batches.append(cur)
             cur, size = [], 0
         cur.append(job)
@@ -773,11 +777,16 @@ def main(argv=None):
     step = ceil(total / 100) if total else 1
     done_count = 0
 
-    def report():
+    def report(n=1):
+        # (the reference prints as its pool hands partitions back, one line per hundredth of them, :877; here partitions come
+        # back a batch at a time.  Workers send ONE message per batch: with a message per partition the parent's queue loop --
+        # 30-50 us per item -- was what an eight-worker run waited for: 8 M reads took 1.06 s with eight workers and 0.91 s
+        # with one, tools/host_ceiling.py)
         nonlocal done_count
-        if done_count % step == 0:
-            print("[freddie_segment] Done with {}/{} tints ({:.1%})".format(done_count, total, done_count / total))
-        done_count += 1
+        for _ in range(n):
+            if done_count % step == 0:
+                print("[freddie_segment] Done with {}/{} tints ({:.1%})".format(done_count, total, done_count / total))
+            done_count += 1
 
     timing = os.environ.get("FREDDIE_TIMING") == "1"
     if n_gpus == 1:
@@ -785,7 +794,7 @@ def main(argv=None):
         jobs = [((split_dir, args.outdir, parts[i][0], parts[i][1]), parts[i][2]) for i in assign[0]]
         with boot:
             try:
-                run_batches(make_batches(jobs, batch_bytes), params, ctx_future, args.threads, lambda _done: report(), args.sidecar)
+                run_batches(make_batches(jobs, batch_bytes), params, ctx_future, args.threads, report, args.sidecar)
             finally:
                 t_run = time.perf_counter()
                 for ctx in ctx_future.result():
@@ -818,7 +827,7 @@ def main(argv=None):
         else:
             if t_first is None:
                 t_first = time.perf_counter()
-            report()
+            report(item)
     t_done = time.perf_counter()
     for pr in procs:
         pr.join()

@@ -4,7 +4,9 @@ The work is done by freddie_amd (gfx950 HIP library behind a C-ABI); see INTEGRA
 import os
 import sys
 import threading
+import time
 
+_T0 = time.perf_counter()
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
@@ -53,9 +55,13 @@ if __name__ == "__main__":
     try:
         # (inside the try: an import error must not end the interpreter while the start-up thread is inside the HIP runtime)
         from freddie_amd.segment import main
+        _t_import = time.perf_counter()
         main()
     finally:
         if _dev is not None:
             _early.finish()
+    if os.environ.get("FREDDIE_TIMING") == "1":
+        print("[freddie_segment] script: imports done %.3f s after its first line, main() returned at %.3f s (interpreter start-up and exit "
+              "come on top)" % (_t_import - _T0, time.perf_counter() - _T0), file=sys.stderr)
 else:
     from freddie_amd.segment import main  # noqa: E402,F401
