@@ -674,6 +674,7 @@ def _gpu_worker(device, n_workers, jobs_with_cost, params, batch_bytes, threads,
     from concurrent.futures import ThreadPoolExecutor
     # host threads of this worker stay on its share of the cores (next to its GPU where that is known: devices.py)
     devices.pin_worker(device if worker is None else worker, n_workers, device)
+    ok = False
     with ThreadPoolExecutor(max_workers=1) as boot:
         ctx_future = boot.submit(open_contexts, device)
         try:
@@ -684,12 +685,21 @@ def _gpu_worker(device, n_workers, jobs_with_cost, params, batch_bytes, threads,
                 finally:
                     conn.close()
             run_batches(make_batches(jobs_with_cost, batch_bytes), params, ctx_future, threads, queue.put, sidecar)
+            ok = True
         finally:
             try:
                 for ctx in ctx_future.result():
                     ctx.close()
             finally:
                 queue.put(None)
+    if ok and WORKER_START_METHOD == "spawn" and os.environ.get("FREDDIE_CLEAN_EXIT") != "1":
+        # (a spawned worker that has finished its share leaves without the interpreter's and the HIP runtime's tear-down, like the
+        # drop-in script: py/freddie_segment.py -- once its last messages are on their way to the parent)
+        queue.close()
+        queue.join_thread()
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 def _expand_jobs(msg):

@@ -63,5 +63,12 @@ if __name__ == "__main__":
     if os.environ.get("FREDDIE_TIMING") == "1":
         print("[freddie_segment] script: imports done %.3f s after its first line, main() returned at %.3f s (interpreter start-up and exit "
               "come on top)" % (_t_import - _T0, time.perf_counter() - _T0), file=sys.stderr)
+    # The work is done and every output file is closed: leave without the interpreter's and the HIP runtime's tear-down (module
+    # clean-up, the runtime's static destructors, unmapping the code objects: 0.15 s of a 2 M-read job's 0.84 s wall).  Only on
+    # success -- an exception takes the ordinary way out above --; FREDDIE_CLEAN_EXIT=1 keeps the ordinary exit.
+    if os.environ.get("FREDDIE_CLEAN_EXIT") != "1":
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 else:
     from freddie_amd.segment import main  # noqa: E402,F401
