@@ -114,7 +114,7 @@ def load():
         raise SegError("libfreddie_seg.so ABI version mismatch")
     if not os.environ.get("FSEG_LIB"):
         # the built library is git-ignored and travels with the tree: refuse one that was built from other sources
-        want = _build.source_hash(_build.SEG_SRC + [os.path.join(_build.INCLUDE, "freddie_seg.h")], _build.seg_command())
+        want = _build.seg_hash()
         have = L.fseg_source_hash().decode()
         if have != want:
             raise SegError("%s is stale (built from sources %s, the tree is %s): rebuild with "

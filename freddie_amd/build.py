@@ -1,6 +1,7 @@
 """In-tree build of the native pieces.
 
-* ``libfreddie_seg.so``  -- the product: gfx950 HIP kernels + C-ABI (hipcc, cross-compiles without a GPU)
+* ``libfreddie_seg.so``  -- the product: gfx950 HIP kernels + C-ABI (hipcc, cross-compiles without a GPU; a translation unit per
+  stage family under csrc/, compiled side by side: build_seg())
 * ``libfreddie_host.so`` -- the product's native host I/O: TSV parser, gaps/poly-A, writer (g++)
 * ``libfreddie_cluster.so`` -- gfx950 kernels + C-ABI of the clustering stage's pre-ILP graph work (hipcc; built by
   ``freddie_amd.cluster_prep.build``)
@@ -18,7 +19,15 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 SEG_SO = os.path.join(_HERE, "libfreddie_seg.so")
-SEG_SRC = [os.path.join(_HERE, "csrc", "freddie_seg.hip"), os.path.join(_HERE, "csrc", "freddie_seg_sort.hip")]
+CSRC = os.path.join(_HERE, "csrc")
+# libfreddie_seg.so: one translation unit per stage family (kernels), the host side (freddie_seg.hip: contexts, launches, C-ABI)
+# and the radix-sort unit; what they share is in two headers of csrc/ plus the ABI header.  The units are compiled side by side
+# (k_solve's three size classes are a unit each: the kernel is most of the build time -- 71 s as one file, ~25 s now on 8 cores).
+SEG_UNITS = ["freddie_seg", "seg_front", "seg_problems", "seg_score_arena", "seg_score_fused", "seg_solve16", "seg_solve32", "seg_solve60",
+             "seg_tail", "seg_upload", "freddie_seg_sort"]
+SEG_HEADERS = [os.path.join(CSRC, "seg_common.h"), os.path.join(CSRC, "seg_kernels.h"), os.path.join(CSRC, "seg_solve.h")]
+SEG_SRC = [os.path.join(CSRC, u + ".hip") for u in SEG_UNITS] + SEG_HEADERS
+SEG_OBJ_DIR = os.path.join(CSRC, ".obj")
 HOST_SO = os.path.join(_HERE, "libfreddie_host.so")
 HOST_SRC = [os.path.join(_HERE, "csrc", "freddie_host.cpp")]
 INCLUDE = os.path.join(ROOT, "include")
@@ -69,14 +78,68 @@ def is_current(target, cmd, sources):
     return embedded_hash(target) == source_hash(sources, cmd)
 
 
-def seg_command():
-    return ["hipcc", "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-shared", "-fPIC", "-I", INCLUDE,
-            "-o", SEG_SO] + SEG_SRC + ["-lhsa-runtime64"]
+SEG_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC"]
 
 
-def build_seg(force=False, verbose=False):
-    build_stamped(SEG_SO, seg_command(), SEG_SRC + [os.path.join(INCLUDE, "freddie_seg.h")], force, verbose)
-    return SEG_SO
+def seg_command(extra=()):
+    """What the library is built from, as ONE command line (it is what the source hash covers, and it builds the library as it
+    stands -- one unit after the other; build_seg() runs the same compilations side by side)."""
+    return (["hipcc"] + SEG_FLAGS + list(extra) + ["-shared", "-I", INCLUDE, "-o", SEG_SO] +
+            [os.path.join(CSRC, u + ".hip") for u in SEG_UNITS] + ["-lhsa-runtime64"])
+
+
+def seg_hash(extra=()):
+    """The hash a current libfreddie_seg.so carries (fseg_source_hash()): sources, headers and the build command."""
+    return source_hash(SEG_SRC + [os.path.join(INCLUDE, "freddie_seg.h")], seg_command(extra))
+
+
+def build_seg(force=False, verbose=False, extra=(), target=None):
+    """Compile the units that changed (an object per unit under csrc/.obj/, each with the hash of what it was compiled from),
+    side by side, and link.  ``extra``: more compiler flags (diagnostic builds: tools/build_variant.sh); ``target``: the library
+    to write (default: the product, libfreddie_seg.so)."""
+    import time
+    from concurrent.futures import ThreadPoolExecutor
+    target = target or SEG_SO
+    want = seg_hash(extra)
+    if not force and embedded_hash(target) == want:
+        return target
+    t0 = time.perf_counter()
+    tag = hashlib.sha256((" ".join(extra) + "|" + os.path.basename(target)).encode()).hexdigest()[:8] if (extra or target != SEG_SO) else "main"
+    objdir = os.path.join(SEG_OBJ_DIR, tag)
+    os.makedirs(objdir, exist_ok=True)
+    shared = SEG_HEADERS + [os.path.join(INCLUDE, "freddie_seg.h")]
+
+    def compile_unit(u):
+        src, obj = os.path.join(CSRC, u + ".hip"), os.path.join(objdir, u + ".o")
+        cmd = ["hipcc"] + SEG_FLAGS + list(extra) + ["-I", INCLUDE, "-c", src, "-o", obj]
+        if u == "freddie_seg":
+            cmd.append('-DFREDDIE_SOURCE_HASH="%s"' % want)         # (the stamp lives in the host unit: it is recompiled whenever anything changed)
+        h = source_hash([src] + shared, cmd)
+        try:
+            with open(obj + ".hash") as f:
+                if not force and f.read().strip() == h and os.path.exists(obj):
+                    return u, 0.0
+        except OSError:
+            pass
+        t = time.perf_counter()
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        with open(obj + ".hash", "w") as f:
+            f.write(h)
+        return u, time.perf_counter() - t
+
+    with ThreadPoolExecutor(max_workers=max(1, min(len(SEG_UNITS), os.cpu_count() or 1))) as pool:
+        times = list(pool.map(compile_unit, SEG_UNITS))
+    link = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", target] + [os.path.join(objdir, u + ".o") for u in SEG_UNITS] + ["-lhsa-runtime64"]
+    if verbose:
+        print(" ".join(link))
+    subprocess.check_call(link)
+    if embedded_hash(target) != want:
+        raise RuntimeError("%s was built but does not carry its source hash" % target)
+    if verbose:
+        print("libfreddie_seg: %.1f s (units: %s)" % (time.perf_counter() - t0, ", ".join("%s %.1f" % (u, t) for u, t in times if t > 0)))
+    return target
 
 
 def host_command():
@@ -97,3 +160,17 @@ def build_all(force=False, verbose=False):
     isoforms.build(force, verbose)
     synth.build(force)
     return SEG_SO
+
+
+if __name__ == "__main__":
+    # python -m freddie_amd.build [--variant NAME] [-DFOO=1 ...]: the product, or the same library under other switches as
+    # freddie_amd/libfreddie_seg_<NAME>.so (FSEG_LIB=... selects it)
+    import sys
+    argv = sys.argv[1:]
+    name = None
+    if argv[:1] == ["--variant"]:
+        name, argv = argv[1], argv[2:]
+    if name:
+        print(build_seg(force=False, verbose=True, extra=tuple(argv), target=os.path.join(_HERE, "libfreddie_seg_%s.so" % name)))
+    else:
+        build_all(force=False, verbose=True)

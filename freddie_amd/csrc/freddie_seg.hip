@@ -13,4739 +13,11 @@
 //     in LDS, and counts out(i,j,k) with AND + popcount into an LDS-resident table.
 //
 // No CPU fallback exists in this library: without a GPU fseg_create() fails.
-#include <hip/hip_runtime.h>
-#include <type_traits>
-#include <hsa/hsa.h>
-#include <hsa/hsa_ext_amd.h>
-#include <chrono>
+#include "seg_kernels.h"
 
-#include <algorithm>
-#include <atomic>
-#include <mutex>
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <string>
-#include <vector>
-
-#include "freddie_seg.h"
+using namespace fseg;
 
 namespace {
-
-typedef long long i64;
-typedef unsigned long long u64;
-
-constexpr int kSmoothShift = 9;
-constexpr int kSmoothTile = 1 << kSmoothShift;   // positions per smoothing tile: intervals average ~1.5 K positions in many-partition
-                                                 // batches, and a tile never spans two intervals -- 512 keeps the tiles ~95 % full
-constexpr int kSmoothThreads = kSmoothTile / 4;  // a thread computes 4 consecutive outputs
-constexpr int kSumShift = 4, kSumBlock = 1 << kSumShift;     // positions per block of the histogram's in-tile prefix sums (k_smooth -> k_segments)
-static_assert(kSmoothTile / kSumBlock <= 64 && kSumBlock == 16, "a tile's block sums are scanned by one wave; a block is four threads' positions");
-constexpr int kMaxRadius = 200;        // sigma <= 50, truncate 4.0 (py/freddie_segment.py:106,:755)
-constexpr int kScanBlock = 8192;       // elements per scan workgroup (256 threads x one 32-bit word of flags)
-inline size_t flag_words(i64 n_pos) { return ((size_t)n_pos + 31) / 32 + 64; }      // words of one flag mask (+ room for a tile's last word and the scans' last block)
-constexpr int kNMax = 60;              // largest DP problem handled by the LDS-resident scoring kernel
-constexpr int kNHuge = 128;            // 60 < n <= 128 (max_problem_size up to ~115): the global-count-table kernels k_score_huge / k_dp_huge
-                                       // (pair planes and the DP's tables in LDS)
-constexpr int kNGiant = 1024;          // 128 < n <= 1024 (max_problem_size up to 1 000: what the CLI accepts): k_score_giant / k_dp_giant,
-                                       // every per-pair table in global scratch -- slow, complete (the reference's own optimize() is
-                                       // O(n^3 R) Python there: nobody runs it for long)
-constexpr int kLaneChunk = 256;        // reads ("lanes") per scoring work item (u16 counters: must stay < 65536)
-constexpr int kSub = 64;               // reads per scoring sub-chunk (two 32-bit plane words)
-constexpr i64 kNegInf = (i64)(-0x7fffffffffffffffLL - 1);
-constexpr i64 kKey32Reads = 1LL << 18;   // partitions of fewer reads take the DP's 32-bit keys (dp_solve_push / dp_solve_wave check the margin against NM)
-constexpr int kFuseLanes = 255;   // reads a problem may see for 8-bit triple counters (four 64-read rounds at most)
-constexpr int kFuseLanesDefault = 511;  // reads a problem may see for its batch to take the fused kernels (FSEG_FUSE_LANES): eight rounds
-constexpr int kFuseLanesWide = 1023;   // ... and for the 16-bit instances: partitions of 1 000 reads have problems that see ~300 (one
-                                       // in twenty-five of them more than 255); a problem that sees more than this is quicker spread
-                                       // over the arena path's work items, and so is its whole batch
-
-// error bits of Status::err
-enum : unsigned {
-    kErrExonInterval = 1u,     // an exon is not inside one tint interval (py/freddie_segment.py:668)
-    kErrBreakAssert = 2u,      // break_large_problems: assert max_c_idx_y_v > 0 / index out of range (:640-643)
-    kErrProblemTooLarge = 4u,  // a DP problem has more than kNGiant candidates
-    kErrOverflowPairs = 8u,
-    kErrOverflowTri = 16u,
-    kErrOverflowWork = 32u,
-    kErrOverflowLabels = 64u,
-    kErrOverflowProblems = 128u,
-    kErrOverflowChunks = 256u,
-    kErrOverflowCov = 512u,
-    kErrOverflowNm = 1024u,
-    kErrWideMissed = 16384u,   // internal: a problem keeps more reads than k_prob_range counted for it (the 8-bit instance met it)
-    kErrWaveStage = 8192u,     // a wave kernel (k_wave) met a read with more exons than its LDS stage holds: rerun without them
-    kErrScanStall = 4096u,     // the look-back scan gave up waiting for a predecessor block: rerun with the three-pass scan
-    kErrSyncTimeout = 32768u,  // a device-side waiter of the scoring stage (k_wait_word) gave up: the stage was skipped, rerun with events
-    kErrNeedWideDp = 2048u,    // a problem sees >= 65536 reads: its DP needs the 32-bit count table    // a problem is larger than the LDS carve-up this launch was sized for
-};
-
-#ifdef FSEG_SCORE_TIMING
-constexpr size_t kTaccProbs = 1u << 17, kTaccBytes = 128 + kTaccProbs * 64;     // (a record per problem for k_solve / k_wave, another for k_dpw)
-#else
-constexpr size_t kTaccBytes = 128;
-#endif
-struct Status {
-    unsigned err;
-    unsigned pad;
-    u64 n_vals;        // number of Y > 0 values (all partitions)
-    u64 n_vchunks;     // 8192-element chunks of the threshold reduction
-    u64 n_cand;
-    u64 n_prob;
-    u64 n_work;
-    u64 pair_used;
-    u64 tri_used;
-    u64 n_rseg;
-    u64 n_final;
-    u64 label_bytes;
-    u64 cov_used;      // elements of the coverage arena
-    unsigned max_n;    // largest DP problem of this run
-    unsigned max_ln;   // most reads any DP problem of this run examines (>= 65536: the DP needs 32-bit counts)
-    u64 cls_work[4];   // work items per problem-size class (n <= 16, <= 32, <= kNMax, <= kNHuge)
-    u64 cls_queue[3];  // dynamic work counters of the scoring kernels
-    u64 dp_cls[3];     // DP problems with n <= kDpSmall / <= kNMax / larger
-    u64 cov_queue;
-    u64 solve_cls[3];  // problems solved whole by k_solve (n <= 16 / <= 32 / <= kNMax)
-    u64 n_tiny;        // problems solved whole by k_tiny (their list follows the three solve lists)
-    unsigned list_cur[8];   // k_prob_emit's cursors into the four solve lists: [2 * list] from the front (expensive problems), [2 * list + 1] from the back
-    unsigned wide_cls[4];   // solve-list problems per size class that see more than kFuseLanes reads (16-bit counters); [3] unused
-    unsigned wide_cur[4];   // k_prob_emit's cursors into the per-class lists of those problems (wide_items); [3]: into the list of all of them (wide_all)
-    unsigned gate_wide;     // workgroups of the large class's 16-bit instance that have started ('h' in a plan: the 8-bit instance waits for them)
-    unsigned gate;          // large-class workgroups that have started (k_gate holds the small classes back until they are placed)
-                            // (a counter of the mid class's 2 000 workgroups, bumped by each as it started, cost that kernel 10 of
-                            // its 62 us: these two count a few hundred)
-    unsigned sync_abort;    // a device-side waiter timed out: the scoring kernels behind it end at once (their input may not exist yet)
-    unsigned pad2;
-};
-// Words of the device-side fork / join of the scoring stage (own allocation, zeroed once; generations only grow): see k_wait_word.
-struct SyncWords {
-    unsigned emit_gen;      // generation of the last scoring stage whose problem list is complete (published by the first launch behind
-                            // k_prob_emit on the main stream): the side streams' waiters spin on it
-    unsigned side_gen[4];   // generation of the last scoring stage whose chain on side stream k has ended (k_signal)
-    unsigned emit_ctr;      // FSEG_EMIT_SIGNAL=1: workgroups of k_prob_emit that have finished (the last one publishes emit_gen and resets this)
-    unsigned pad[2];
-};
-
-// ---------------------------------------------------------------------------------------------
-// small device helpers
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
-
-// k_prob_emit's LAST workgroup publishes the stage's generation itself (FSEG_EMIT_SIGNAL=0: left to the first launch behind it on
-// the main stream) -- the side streams start ~6 us earlier: config4 0.130 -> 0.123 ms, config3 0.148 -> 0.144, k_prob_emit as long as before.  Every workgroup pays one release to the device (its stores have reached L2: s_waitcnt +
-// barrier; thread 0's release writes the XCD's dirty L2 lines back).  As __threadfence() in every wave it took the kernel from 17
-// to 106 us (four write-backs AND four L2 invalidations per workgroup, in a kernel that lives on L2 hits).
-__device__ __forceinline__ void emit_done(SyncWords *sw, unsigned gen) {
-    if (!sw) return;
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned done = __hip_atomic_fetch_add(&sw->emit_ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        if (done == gridDim.x - 1) {
-            __hip_atomic_store(&sw->emit_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&sw->emit_gen, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-}
-// (asked beside the first descriptor load and tested behind it: no dependent load of its own in a problem's chain)
-__device__ __forceinline__ unsigned stage_aborted(const Status *st) { return __hip_atomic_load(&st->sync_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-
-// index of the last element of a[0..n) that is <= x  (a ascending, a[0] <= x)
-template <typename T, typename X>
-__device__ __forceinline__ i64 last_le(const T *a, i64 n, X x) {
-    i64 lo = 0, hi = n;   // invariant: a[lo] <= x (if any), answer in [lo, hi)
-    while (hi - lo > 1) {
-        i64 mid = (lo + hi) >> 1;
-        if ((X)a[mid] <= x) lo = mid; else hi = mid;
-    }
-    return lo;
-}
-
-__device__ __forceinline__ i64 reflect_index(i64 i, i64 n) {
-    if (n == 1) return 0;
-    i64 p = 2 * n;
-    i %= p;
-    if (i < 0) i += p;
-    return i < n ? i : p - 1 - i;
-}
-
-// Integer forms of the reference's floating-point label tests (py/freddie_segment.py:490-495,
-// :816-828): with c = cov/L in IEEE double, `c > h`  <=>  cov >= hi  and  `c < 1-h`  <=>  cov <= lo,
-// where hi = min{v : fl(v/L) > h}, lo = max{v : fl(v/L) < fl(1-h)} (fl(v/L) is monotone in v).
-__device__ __forceinline__ void label_thresholds(i64 L, const double *h_table, int h_len, double tau, int *hi_out,
-                                                 int *lo_out) {
-    double h = L < (i64)h_len ? h_table[L] : tau;   // get_high_threshold :269-274
-    double l = 1.0 - h;
-    double dL = (double)L;
-    i64 v = (i64)floor(h * dL);
-    if (v < 0) v = 0;
-    while (v > 0 && (double)(v - 1) / dL > h) --v;
-    while (!((double)v / dL > h) && v <= L + 1) ++v;
-    *hi_out = (int)v;
-    i64 u = (i64)ceil(l * dL);
-    if (u > L) u = L;
-    while (u >= 0 && !((double)u / dL < l)) --u;
-    while ((double)(u + 1) / dL < l && u < L) ++u;
-    *lo_out = (int)u;
-}
-
-// The bounds depend only on L (and the run's parameters): a table for the short segments, built once per parameter set,
-// replaces the fp64 divisions in the kernels that evaluate them per problem (a DP window's pairs are mostly a few
-// hundred positions apart).
-constexpr int kThrTab = 8192;
-__global__ void __launch_bounds__(256) k_thr_table(const double *h_table, int h_len, double tau, int2 *tab) {
-    for (int L = blockIdx.x * blockDim.x + threadIdx.x; L < kThrTab; L += gridDim.x * blockDim.x) {
-        int hi = 0x7fffffff, lo = -1;
-        if (L >= 1) label_thresholds((i64)L, h_table, h_len, tau, &hi, &lo);
-        tab[L] = make_int2(hi, lo);
-    }
-}
-__device__ __forceinline__ void label_thresholds_tab(i64 L, const int2 *tab, const double *h_table, int h_len, double tau,
-                                                     int *hi_out, int *lo_out) {
-    if (L < (i64)kThrTab) { const int2 t = tab[L]; *hi_out = t.x; *lo_out = t.y; }
-    else label_thresholds(L, h_table, h_len, tau, hi_out, lo_out);
-}
-
-// ---------------------------------------------------------------------------------------------
-// S1  splice histogram   (process_splicing_data, py/freddie_segment.py:648-678)
-// One workgroup per chunk of kHistChunk consecutive positions of one partition.  The reads that can touch the
-// chunk are a contiguous range of the position-sorted lane list (same two binary searches as k_prob_range); their
-// exon ends falling into the chunk are counted in an LDS histogram (integer counts, so LDS atomics are
-// order-free) which is then written out whole -- no global atomics and no memset of the histogram.
-// A lane is one read (reps are repeated rep_weight times in the lane list), so every hit adds 1.
-// ---------------------------------------------------------------------------------------------
-constexpr int kHistChunk = 8192;
-constexpr int kHistIv = 1024;      // intervals of a partition cached in LDS by k_hist
-__global__ void __launch_bounds__(512) k_hist(int n_chunks, const int *chunk_part, const i64 *chunk_p0, const int *chunk_n,
-                                              const int *chunk_glo, const int *chunk_ghi, const i64 *chunk_lane_lo,
-                                              const i64 *chunk_lane_hi, const i64 *part_iv_off,
-                                              const int *iv_start, const int *iv_end, const i64 *pos_off,
-                                              const i64 *part_lane_off, const int2 *__restrict__ lane_lx, const int *lane_start,
-                                              const int *lane_pmax, const int2 *__restrict__ lex,
-                                              int ignore_ends, int *y_raw, Status *st, u64 *zero_ptr, i64 zero_n) {
-    __shared__ int hist[kHistChunk];
-    __shared__ int ivs_s[kHistIv], ive_s[kHistIv], base_s[kHistIv];
-    // first kernel of the run: also clears the look-back words of the three compactions (saves a memset node)
-    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < zero_n; i += (i64)gridDim.x * blockDim.x) zero_ptr[i] = 0;
-    for (int ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
-        const int part = chunk_part[ch];
-        const i64 p0 = chunk_p0[ch];
-        const int np = chunk_n[ch];
-        const int g_lo = chunk_glo[ch], g_hi = chunk_ghi[ch];          // genomic position of the first / last position
-        const i64 k0 = part_iv_off[part], k1 = part_iv_off[part + 1];
-        __syncthreads();
-        for (int i = threadIdx.x; i < np; i += blockDim.x) hist[i] = 0;
-        // lanes whose [first, last] position range meets [g_lo, g_hi]: found on upload (the chunks and the sorted
-        // lanes are both fixed then), two dependent 16-step searches less per workgroup
-        const i64 lo = chunk_lane_lo[ch], hi = chunk_lane_hi[ch];
-        // the partition's interval table in LDS when it fits (the per-exon interval search then stays on chip)
-        const int nk = (int)(k1 - k0);
-        const bool cached = nk <= kHistIv;
-        if (cached)
-            for (int i = threadIdx.x; i < nk; i += blockDim.x) {
-                ivs_s[i] = iv_start[k0 + i]; ive_s[i] = iv_end[k0 + i];
-                base_s[i] = (int)(pos_off[k0 + i] - p0) - iv_start[k0 + i];   // chunk-local index = base + genomic position
-            }
-        __syncthreads();
-        // 8 threads share a read: thread q of the group takes the read's exons q, q+8, ...  The walk is a chain of
-        // dependent loads (lane -> exon range -> exon), so four reads per group are in flight: their exon ranges, then
-        // their first exons, are loaded together from clamped addresses before any of them is used.  The exons come from
-        // the lane-ordered (ts, te) stream: a group's eight threads read 64 consecutive bytes, consecutive groups consecutive
-        // lanes' pieces (from the rep-ordered ex_ts / ex_te: two lines per read, anywhere)
-        const int sub = threadIdx.x & 7;
-        const int G8 = blockDim.x >> 3;
-        auto count_exon = [&](i64 e, i64 e0, i64 e1, int ts, int te) {
-            if (te < g_lo || ts > g_hi) return;
-            // the interval that holds ts must hold te as well (:666-668; also validated on upload)
-            int kl = 0;
-            bool ok;
-            int base;
-            if (cached) {
-                int a2 = 0, b2 = nk;
-                while (b2 - a2 > 1) { int m = (a2 + b2) >> 1; if (ivs_s[m] <= ts) a2 = m; else b2 = m; }
-                kl = a2;
-                ok = ts >= ivs_s[kl] && ts <= ive_s[kl] && te <= ive_s[kl];
-                base = base_s[kl];
-            } else {
-                ok = ts >= iv_start[k0];
-                i64 k = k0;
-                if (ok) { k = k0 + last_le(iv_start + k0, k1 - k0, ts); ok = ts <= iv_end[k] && te <= iv_end[k]; }
-                base = (int)(pos_off[k] - p0) - iv_start[k];
-            }
-            if (!ok) { atomicOr(&st->err, kErrExonInterval); return; }
-            if (!(ignore_ends && e == e0) && ts >= g_lo && ts <= g_hi) atomicAdd(&hist[base + ts], 1);       // :670-671
-            if (!(ignore_ends && e == e1 - 1) && te >= g_lo && te <= g_hi) atomicAdd(&hist[base + te], 1);   // :672-673
-        };
-        for (i64 l0 = lo + (threadIdx.x >> 3); l0 < hi; l0 += 4 * (i64)G8) {
-            int2 ex[4], x0[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { const i64 l = l0 + (i64)u * G8; ex[u] = lane_lx[l < hi ? l : l0]; }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = ex[u].x + sub < ex[u].y ? ex[u].x + sub : ex[u].x;       // a valid exon of the read (a read has at least one)
-                x0[u] = lex[e];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (l0 + (i64)u * G8 >= hi) break;
-                const i64 e0 = ex[u].x, e1 = ex[u].y;
-                if (e0 + sub < e1) count_exon(e0 + sub, e0, e1, x0[u].x, x0[u].y);
-                for (i64 e = e0 + sub + 8; e < e1; e += 8) { const int2 x = lex[e]; count_exon(e, e0, e1, x.x, x.y); }
-            }
-        }
-        __syncthreads();
-        for (int i = threadIdx.x; i < np; i += blockDim.x) y_raw[p0 + i] = hist[i];
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// S2  Gaussian smoothing, fp64   (gaussian_filter1d(y, sigma, truncate=4.0), :755)
-// out[l] = x[l]*w[0]; for j = radius..1: out += (x[l-j] + x[l+j]) * w[j]   -- farthest pair first,
-// separate multiply and add (no FMA), 'reflect' boundary.  One workgroup per tile of positions; the
-// tile plus its halo is staged in LDS as int32 (the histogram holds exact small integers).
-// Also writes the flag Y > 0 used by the threshold stage.
-// ---------------------------------------------------------------------------------------------
-template <int NW = 0> __device__ __forceinline__ int wg_exclusive_scan(int v, int *lds, int *total);
-
-// Workgroup barrier that orders LDS traffic only: global loads and stores issued before it (prefetches of the next
-// tile, result stores) stay in flight, which a full __syncthreads() would wait for.
-__device__ __forceinline__ void lds_barrier() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
-// wg_exclusive_scan() with LDS-only barriers.  NW: the workgroup's waves when the caller knows them (with the count read from
-// blockDim the loop over the waves' totals is a general loop, unrolled sixteen-fold with masks: dozens of instructions for two values)
-template <int NW = 0>
-__device__ __forceinline__ int wg_exclusive_scan_lds(int v, int *lds /* >= 16 ints */, int *total) {
-    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nw = NW > 0 ? NW : (int)((blockDim.x + 63) >> 6);
-    int x = v;
-    for (int d = 1; d < 64; d <<= 1) {
-        int y = __shfl_up(x, d);
-        if (lane >= d) x += y;
-    }
-    lds_barrier();
-    if (lane == 63) lds[wave] = x;
-    lds_barrier();
-    int off = 0, tot = 0;
-    for (int w = 0; w < nw; ++w) {
-        int sv = lds[w];
-        if (w < wave) off += sv;
-        tot += sv;
-    }
-    *total = tot;
-    return off + x - v;
-}
-
-// R > 0: radius known at compile time (the tap loop is fully unrolled: no window moves, no loop control, weights
-// in scalar registers); R == 0: any radius <= kMaxRadius.
-// One 16-byte record per tile (built on upload) instead of tile -> interval -> offsets: the per-tile set-up is one load.
-struct __align__(16) TileDesc {
-    i64 base;       // position of the interval's first element (pos_off[interval])
-    int y0;         // first position of the tile inside the interval
-    int len;        // interval length
-};
-constexpr int kSmoothStage = (kSmoothTile + 2 * kMaxRadius + kSmoothThreads - 1) / kSmoothThreads;   // staged counts per thread, any radius
-
-typedef int int4u __attribute__((ext_vector_type(4), aligned(4)));      // (16 bytes from a dword-aligned address)
-template <int R>
-#ifndef FSEG_SMOOTH_OCC
-#define FSEG_SMOOTH_OCC 6
-#endif
-__global__ void __launch_bounds__(kSmoothThreads, FSEG_SMOOTH_OCC) k_smooth(int n_tiles, const TileDesc *__restrict__ tiles,
-                                                const int *__restrict__ y_raw, const double *__restrict__ w_g, int radius_rt,
-                                                double *y_out, unsigned *flag_pos, unsigned *flag_cand, int *blk_pre, int *tile_tot,
-                                                int *tile_defer) {
-    __shared__ int xs[kSmoothTile + 2 * kMaxRadius];
-    __shared__ __align__(4) unsigned char cf[kSmoothTile];     // candidate flags of the tile
-    __shared__ unsigned pf[kSmoothTile / 4];                   // Y > 0 flags of the tile, a byte per position like cf
-    __shared__ int defer_s;
-    __shared__ int blk_s[kSmoothTile / kSumBlock];
-    __shared__ double ws[kMaxRadius + 1];
-    // the tile's smoothed values: what the candidate test reads of its neighbours (the results themselves leave from
-    // registers: a thread's four consecutive positions are 32 / 16 / 4 contiguous bytes of the output arrays, a wave's 256
-    // positions one contiguous run per store instruction -- as five arrays of single elements per lane the kernel took
-    // 183 us per 250 k-read batch with or without its arithmetic)
-    __shared__ double ys[kSmoothTile];
-    const int radius = R > 0 ? R : radius_rt;
-    const int span = kSmoothTile + 2 * radius;
-    constexpr int kStage = R > 0 ? (kSmoothTile + 2 * R + kSmoothThreads - 1) / kSmoothThreads : kSmoothStage;
-    for (int j = threadIdx.x; j <= radius; j += blockDim.x) ws[j] = w_g[j];
-    // A tile is a short chain of dependent loads (record -> counts) followed by barriers, and a workgroup walks several
-    // tiles: the chain of the NEXT tile is issued before the arithmetic of the current one (counts into registers,
-    // the record one tile further ahead), so its latency hides behind the taps and the stores.
-    const int G = gridDim.x;
-    auto load_counts = [&](const TileDesc &d, int *v) {
-        // 'reflect': (d c b a | a b c d | d c b a).  One reflection does unless the interval is shorter than the radius;
-        // only then the general index (a 64-bit modulo) is evaluated.
-        const int len_d = d.len, yb = d.y0 - radius + (int)threadIdx.x;
-#pragma unroll
-        for (int e = 0; e < kStage; ++e) {
-            const int idx = e * kSmoothThreads + threadIdx.x;
-            const int y = yb + e * kSmoothThreads;
-            int r = y < 0 ? -1 - y : (y >= len_d ? 2 * len_d - 1 - y : y);
-            if ((unsigned)r >= (unsigned)len_d) r = (int)reflect_index((i64)y, (i64)len_d);
-            v[e] = idx < span ? y_raw[d.base + r] : 0;
-        }
-    };
-    int t = blockIdx.x;
-    TileDesc d_cur = {0, 0, 1}, d_next = {0, 0, 1};
-    int v_cur[kStage];
-    if (t < n_tiles) { d_cur = tiles[t]; load_counts(d_cur, v_cur); }
-    if (t + G < n_tiles) d_next = tiles[t + G];
-    for (; t < n_tiles; t += G) {
-        const int y0 = d_cur.y0, len = d_cur.len;                    // (positions inside one interval: 32 bits)
-        const i64 base = d_cur.base;
-        lds_barrier();
-#pragma unroll
-        for (int e = 0; e < kStage; ++e) { const int idx = e * kSmoothThreads + threadIdx.x; if (idx < span) xs[idx] = v_cur[e]; }
-        TileDesc d_n2 = {0, 0, 1};
-        if (t + 2 * G < n_tiles) d_n2 = tiles[t + 2 * G];
-        if (t + G < n_tiles) load_counts(d_next, v_cur);             // in flight during this tile's work
-        lds_barrier();
-        {   // the histogram's sums over blocks of kSumBlock positions of the tile (four threads' positions each; what lies
-            // beyond the interval counts nothing): with their exclusive prefix inside the tile and the tile's total they let
-            // k_segments answer refine_segmentation's `sum(i_vals) < 20` test (:258) exactly with two look-ups and at most
-            // 31 positions of the histogram itself.  (Round 3 kept an inclusive prefix PER POSITION: a workgroup scan per tile
-            // and 114 MB written per batch -- 25 of this kernel's 158 us.)
-            const int o4 = threadIdx.x * 4;
-            int run = 0;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) run += (y0 + o4 + e < len) ? xs[radius + o4 + e] : 0;
-            run += __builtin_amdgcn_update_dpp(0, run, 0xB1, 0xf, 0xf, false);      // quad_perm [1,0,3,2]: + the neighbour's
-            run += __builtin_amdgcn_update_dpp(0, run, 0x4E, 0xf, 0xf, false);      // quad_perm [2,3,0,1]: + the other pair's
-            if ((threadIdx.x & 3) == 0) blk_s[threadIdx.x >> 2] = run;
-        }
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;    // this thread's four outputs (kept for the candidate test below)
-        {   // every thread computes 4 consecutive outputs; the two 4-wide input windows of tap j slide by one
-            // position per tap, so each tap costs two LDS reads for four outputs
-            const int o4 = threadIdx.x * 4;
-            if (y0 + o4 < len) {
-                const int c = o4 + radius;
-                const double w0 = ws[0];
-                a0 = __dmul_rn((double)(xs[c]), w0); a1 = __dmul_rn((double)(xs[c + 1]), w0);
-                a2 = __dmul_rn((double)(xs[c + 2]), w0); a3 = __dmul_rn((double)(xs[c + 3]), w0);
-                int l0 = xs[c - radius], l1 = xs[c - radius + 1], l2 = xs[c - radius + 2], l3 = xs[c - radius + 3];
-                int r0 = xs[c + radius], r1 = xs[c + radius + 1], r2 = xs[c + radius + 2], r3 = xs[c + radius + 3];
-#define FSEG_TAP(W)                                                                                        \
-                    a0 = __dadd_rn(a0, __dmul_rn((double)(l0 + r0), (W)));                                         \
-                    a1 = __dadd_rn(a1, __dmul_rn((double)(l1 + r1), (W)));                                         \
-                    a2 = __dadd_rn(a2, __dmul_rn((double)(l2 + r2), (W)));                                         \
-                    a3 = __dadd_rn(a3, __dmul_rn((double)(l3 + r3), (W)));                                         \
-                    l0 = l1; l1 = l2; l2 = l3; l3 = xs[c - j + 4];          /* left window moves right */          \
-                    r3 = r2; r2 = r1; r1 = r0; r0 = xs[c + j - 1];          /* right window moves left */
-                if (R > 0) {
-#pragma unroll
-                    for (int j = R; j >= 1; --j) { FSEG_TAP(w_g[j]) }
-                } else {
-                    for (int j = radius; j >= 1; --j) { FSEG_TAP(ws[j]) }
-                }
-#undef FSEG_TAP
-                ys[o4] = a0; ys[o4 + 1] = a1; ys[o4 + 2] = a2; ys[o4 + 3] = a3;
-            }
-        }
-        if (threadIdx.x == 0) defer_s = -1;
-        lds_barrier();
-        if (threadIdx.x < kSmoothTile / kSumBlock) {                  // (one wave: the tile's block sums -> exclusive prefixes, total)
-            const int v = blk_s[threadIdx.x];
-            int x = v;
-#pragma unroll
-            for (int dd = 1; dd < kSmoothTile / kSumBlock; dd <<= 1) { const int y = __shfl_up(x, dd); if ((int)threadIdx.x >= dd) x += y; }
-            blk_pre[(i64)t * (kSmoothTile / kSumBlock) + threadIdx.x] = x - v;
-            if (threadIdx.x == kSmoothTile / kSumBlock - 1) tile_tot[t] = x;
-        }
-        // S3b candidates (candidates_from_peaks :615-621 = scipy's _local_maxima_1d + the interval's first and last position),
-        // decided here while the tile's smoothed values are at hand -- a pass of its own over the signal read all of it back
-        // from HBM.  A strict maximum, or the midpoint of a plateau that rises on its left and falls on its right
-        // ((first + last) / 2), counts.  A thread tests its own four outputs (registers; its two outer neighbours from LDS) and
-        // writes their flags as one word.  What this tile cannot see is left to k_peaks_edges: whether its first and its last
-        // position start a peak (their outer neighbours belong to other tiles) and the one plateau that may run into the
-        // tile's last position (its start goes to tile_defer).
-        int mid0 = -1, mid1 = -1;        // plateau midpoints found by this thread, written after the words (four consecutive
-                                         // positions hold at most two plateau peaks: rise, level, fall, rise, level)
-        {
-            const int o4 = threadIdx.x * 4;
-            const double v[6] = {ys[o4 > 0 ? o4 - 1 : 0], a0, a1, a2, a3, ys[o4 + 4 < kSmoothTile ? o4 + 4 : kSmoothTile - 1]};
-            unsigned word = 0;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int i = o4 + e;
-                const int pos = y0 + i;
-                if (pos >= len) break;
-                if (pos == 0 || pos == len - 1) { word |= 1u << (8 * e); continue; }
-                if (i == 0 || i == kSmoothTile - 1) continue;            // k_peaks_edges
-                const double a = v[e + 1];
-                if (v[e] < a) {
-                    if (v[e + 2] < a) word |= 1u << (8 * e);
-                    else if (v[e + 2] == a) {
-                        int ia = i + 1;                                  // (scipy: extend while ia < len - 1 and y[ia] == y[i])
-                        while (ia < kSmoothTile - 1 && y0 + ia < len - 1 && ys[ia] == a) ++ia;
-                        if (ys[ia] == a && y0 + ia < len - 1) defer_s = i;   // still level at the tile's last position: not decidable here
-                                                                             // (at most one run of equal values reaches the tile's end)
-                        else if (ys[ia] < a) { if (mid0 < 0) mid0 = (i + ia - 1) >> 1; else mid1 = (i + ia - 1) >> 1; }
-                    }
-                }
-            }
-            reinterpret_cast<unsigned *>(cf)[threadIdx.x] = word;
-        }
-        lds_barrier();
-        if (mid0 >= 0) cf[mid0] = 1;
-        if (mid1 >= 0) cf[mid1] = 1;
-        {   // this thread's four Y > 0 flags, a byte each like the candidate flags (what lies beyond the interval flags nothing)
-            const int o4 = threadIdx.x * 4, left = len - (y0 + o4);
-            pf[threadIdx.x] = (left > 0 && a0 > 0.0 ? 1u : 0u) | (left > 1 && a1 > 0.0 ? 1u << 8 : 0u) |
-                              (left > 2 && a2 > 0.0 ? 1u << 16 : 0u) | (left > 3 && a3 > 0.0 ? 1u << 24 : 0u);
-        }
-        lds_barrier();
-        if (threadIdx.x == 0) tile_defer[t] = defer_s;
-        {
-            const int o4 = threadIdx.x * 4;
-            const i64 p = base + y0 + o4;
-            if (y0 + o4 + 3 < len) {                                 // the thread's four positions lie inside the interval
-                typedef double double2u __attribute__((ext_vector_type(2), aligned(8)));
-                double2u lo2, hi2; lo2.x = a0; lo2.y = a1; hi2.x = a2; hi2.y = a3;
-                *reinterpret_cast<double2u *>(y_out + p) = lo2;
-                *reinterpret_cast<double2u *>(y_out + p + 2) = hi2;
-            } else {
-                const double av[4] = {a0, a1, a2, a3};
-                for (int e = 0; e < 4; ++e)
-                    if (y0 + o4 + e < len) y_out[p + e] = av[e];
-            }
-        }
-        if (threadIdx.x <= kSmoothTile / 32) {
-            // The tile's flags leave as bits of the batch-wide masks: lane j < 16 packs the 32 flag bytes of the tile's j-th
-            // group into a word (four bytes at a time: (w * 0x00204081) >> 21 gathers their low bits), and since the tile starts
-            // at an arbitrary position of the batch -- bit s = (base + y0) & 31 of its first word -- word j of the masks is
-            // T[j] << s | T[j-1] >> (32 - s), seventeen of them, OR-ed in (the first and the last are shared with the
-            // neighbouring tiles; the masks are cleared before this kernel).
-            const int j = threadIdx.x;
-            auto pack = [&](const unsigned *bytes_w) {
-                unsigned tw = 0;
-#pragma unroll
-                for (int q = 0; q < 8; ++q) tw |= ((((bytes_w[8 * (j & 15) + q] & 0x01010101u) * 0x00204081u) >> 21) & 15u) << (4 * q);
-                return j < kSmoothTile / 32 ? tw : 0u;
-            };
-            const unsigned tc = pack(reinterpret_cast<const unsigned *>(cf)), tp = pack(pf);
-            const unsigned pc = __shfl_up(tc, 1), pp = __shfl_up(tp, 1);
-            const i64 p0 = base + y0;
-            const int sh = (int)(p0 & 31);
-            const unsigned gc = sh ? (tc << sh) | (j > 0 ? pc >> (32 - sh) : 0u) : tc;
-            const unsigned gp = sh ? (tp << sh) | (j > 0 ? pp >> (32 - sh) : 0u) : tp;
-            if (gc) atomicOr(&flag_cand[(p0 >> 5) + j], gc);
-            if (gp) atomicOr(&flag_pos[(p0 >> 5) + j], gp);
-        }
-        d_cur = d_next; d_next = d_n2;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// exclusive prefix sum of byte flags (three small kernels; used for the three compactions)
-// ---------------------------------------------------------------------------------------------
-template <int NW>
-__device__ __forceinline__ int wg_exclusive_scan(int v, int *lds /* >= 16 ints */, int *total) {
-    int lane = lane_id(), wave = threadIdx.x >> 6;
-    const int nw = NW > 0 ? NW : (int)((blockDim.x + 63) >> 6);
-    int x = v;
-    for (int d = 1; d < 64; d <<= 1) {
-        int y = __shfl_up(x, d);
-        if (lane >= d) x += y;
-    }
-    __syncthreads();
-    if (lane == 63) lds[wave] = x;
-    __syncthreads();
-    int off = 0, tot = 0;
-    for (int w = 0; w < nw; ++w) {
-        int s = lds[w];
-        if (w < wave) off += s;
-        tot += s;
-    }
-    *total = tot;
-    return off + x - v;
-}
-
-// The three flag sets of a run (Y > 0, candidate, final position) are BIT masks over the batch's positions: bit (p & 31) of word
-// p >> 5 (round 4; a byte per position until then: 85 MB written by k_smooth per 250 k-read batch and read again by five scan
-// launches).  Every thread of a scan owns the 32 positions of one word; i0 is a multiple of 32, positions at or beyond n count nothing.
-typedef unsigned Flags32;
-__device__ __forceinline__ Flags32 load_flags32(const unsigned *flags, i64 i0, i64 n) {
-    unsigned w = flags[i0 >> 5];
-    if (i0 + 32 > n) w &= n > i0 ? ((1u << (int)(n - i0)) - 1u) : 0u;
-    return w;
-}
-__device__ __forceinline__ int count_flags32(Flags32 f) { return __popc(f); }
-__device__ __forceinline__ void set_flag(unsigned *flags, i64 p) { atomicOr(&flags[p >> 5], 1u << (int)(p & 31)); }
-
-// many blocks: three passes (block sums, their scan by one workgroup, emission)
-__global__ void __launch_bounds__(256) k_scan1(const unsigned *flags, i64 n, int *bsum) {
-    __shared__ int lds[16];
-    i64 nb = (n + kScanBlock - 1) / kScanBlock;
-    for (i64 b = blockIdx.x; b < nb; b += gridDim.x) {
-        i64 i0 = b * kScanBlock + (i64)threadIdx.x * 32;
-        int s = i0 < n ? count_flags32(load_flags32(flags, i0, n)) : 0;
-        int tot;
-        wg_exclusive_scan<4>(s, lds, &tot);
-        if (threadIdx.x == 0) bsum[b] = tot;
-        __syncthreads();
-    }
-}
-// One workgroup of 1024 threads, eight block sums per thread per round (registers), so a batch's few thousand block sums are
-// scanned in one round of one load, one workgroup scan and one store per thread (it was 256 threads x one element: a dozen
-// latency-bound rounds, 12 us three times per run).
-constexpr int kScan2Threads = 1024, kScan2Per = 8;
-__global__ void __launch_bounds__(kScan2Threads) k_scan2(int *bsum, i64 nb, u64 *total_out, i64 *off_last /* may be null */) {
-    __shared__ int lds[16];
-    __shared__ int carry_s;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    for (i64 b0 = 0; b0 < nb; b0 += (i64)kScan2Threads * kScan2Per) {
-        const i64 base = b0 + (i64)threadIdx.x * kScan2Per;
-        int v[kScan2Per], run = 0;
-#pragma unroll
-        for (int e = 0; e < kScan2Per; ++e) { v[e] = base + e < nb ? bsum[base + e] : 0; }
-#pragma unroll
-        for (int e = 0; e < kScan2Per; ++e) { const int x = v[e]; v[e] = run; run += x; }      // exclusive inside the thread
-        int tot;
-        const int ex = wg_exclusive_scan<kScan2Threads / 64>(run, lds, &tot);
-        const int carry = carry_s;
-#pragma unroll
-        for (int e = 0; e < kScan2Per; ++e) if (base + e < nb) bsum[base + e] = carry + ex + v[e];
-        __syncthreads();
-        if (threadIdx.x == 0) carry_s = carry + tot;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) { *total_out = (u64)carry_s; if (off_last) *off_last = (i64)carry_s; }
-}
-// few blocks: single-pass chained scan (decoupled look-back): block b publishes its flag count in state[b] as soon as it is
-// known, then adds up its predecessors' words until it meets one that already holds an inclusive prefix.
-// state word = (tag << 62) | value, tag 0 = empty (zeroed at the start of the run), 1 = block aggregate,
-// 2 = inclusive prefix.  One workgroup per block: a block only ever waits for blocks with a smaller index, which
-// the dispatcher started earlier.  Returns the exclusive prefix of the block (all threads); the last block also
-// writes the grand total.
-constexpr u64 kScanValueMask = (1ULL << 62) - 1ULL;
-__device__ __forceinline__ i64 scan_lookback(u64 *state, i64 b, i64 nb, i64 agg, i64 *bcast /* LDS */, u64 *total_out,
-                                             i64 *off_last, unsigned *err) {
-    const int lane = lane_id();
-    if (threadIdx.x < 64) {
-        if (lane == 0)
-            __hip_atomic_store(&state[b], ((b == 0 ? 2ULL : 1ULL) << 62) | (u64)agg, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        i64 excl = 0;
-        if (b > 0) {
-            i64 base = b - 1;                                        // lane l looks at block base - l
-            // every spin is bounded: the chain is short (the host only picks this scan then) and all its blocks are
-            // resident together, but nothing about dispatch order is guaranteed -- a stall is reported, not waited out
-            for (int spins = 0;; ++spins) {
-                if (spins > (1 << 20)) { if (lane == 0) atomicOr(err, kErrScanStall); break; }
-                const i64 idx = base - lane;
-                u64 sv = 2ULL << 62;                                 // before block 0: prefix 0
-                if (idx >= 0) sv = __hip_atomic_load(&state[idx], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned tag = (unsigned)(sv >> 62);
-                const u64 m_pref = __ballot(tag == 2), m_empty = __ballot(tag == 0);
-                u64 use;                                             // lanes whose value is added
-                if (m_pref) {
-                    const int first = __ffsll((long long)m_pref) - 1;
-                    use = first == 63 ? ~0ULL : ((2ULL << first) - 1ULL);
-                } else use = ~0ULL;
-                if (m_empty & use) { __builtin_amdgcn_s_sleep(1); continue; }   // a predecessor has not published yet
-                i64 v = ((use >> lane) & 1ULL) ? (i64)(sv & kScanValueMask) : 0;
-                for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
-                excl += v;
-                if (m_pref) break;
-                base -= 64;
-            }
-            if (lane == 0)
-                __hip_atomic_store(&state[b], (2ULL << 62) | (u64)(excl + agg), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (lane == 0) {
-            *bcast = excl;
-            if (b == nb - 1) { *total_out = (u64)(excl + agg); if (off_last) *off_last = excl + agg; }
-        }
-    }
-    __syncthreads();
-    return *bcast;
-}
-// third pass fused with the consumer of the compaction:
-//   kEmitValues:    v[rank] = y[i]                                   (threshold stage)
-//   kEmitPositions: out_y[rank] = y index inside its interval, out_pos[rank] = genomic position,
-//                   out_off[k] = rank of the interval's first position (always flagged)
-enum { kEmitValues = 0, kEmitPositions = 1 };
-template <int MODE>
-__global__ void __launch_bounds__(256) k_scan_emit(const unsigned *flags, i64 n, const int *bsum /* or null */,
-                                                   u64 *state, u64 *total_out, i64 *off_last /* may be null */,
-                                                   unsigned *err, const double *y,
-                                                   double *v, i64 K, const i64 *pos_off, const int *iv_start,
-                                                   const int *blk_iv0, int *out_y, int *out_pos, i64 *out_off,
-                                                   int force_stall /* tests: report a look-back stall */, int *out_iv /* may be null */) {
-    if (force_stall && !bsum && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(err, kErrScanStall);
-    // A block is 4 waves x 2048 consecutive positions.  Each wave first counts its flags (16-byte loads), the wave
-    // offsets come from LDS, then the wave walks its positions in rows of 64: ballot -> rank, so the loads of y and
-    // the stores of the compacted output are coalesced.
-    __shared__ int wave_cnt[4];
-    __shared__ int lds[16];
-    __shared__ i64 bcast;
-    const int lane = lane_id(), wave = threadIdx.x >> 6;
-    const u64 lt_mask = (1ULL << lane) - 1ULL;
-    i64 nb = (n + kScanBlock - 1) / kScanBlock;
-    if (MODE == kEmitPositions) {
-        // sparse flags (about one position in a hundred): every thread owns 32 consecutive positions and only the
-        // threads that hold a flag do any work.  The intervals the block's positions lie in (first interval of this block ..
-        // first interval of the next) are staged in LDS with one coalesced load: a flagged thread's interval search and its
-        // three look-ups would otherwise be a chain of five or six dependent global loads, which is what this kernel ran at.
-        constexpr int kIvStage = 768;
-        __shared__ i64 po_s[kIvStage + 1];
-        __shared__ int is_s[kIvStage];
-        {
-            const i64 b = blockIdx.x;                                // grid == nb
-            const i64 ka0 = blk_iv0[b], kb0 = (i64)blk_iv0[b + 1] + 1;      // intervals [ka0, kb0) (kb0 <= K)
-            const int niv = (int)(kb0 - ka0);
-            const bool staged = niv <= kIvStage;
-            if (staged) {
-                for (int x = threadIdx.x; x <= niv; x += blockDim.x) po_s[x] = pos_off[ka0 + x];
-                for (int x = threadIdx.x; x < niv; x += blockDim.x) is_s[x] = iv_start[ka0 + x];
-            }
-            i64 i0 = b * kScanBlock + (i64)threadIdx.x * 32;
-            Flags32 f = 0;
-            int s = 0;
-            if (i0 < n) { f = load_flags32(flags, i0, n); s = count_flags32(f); }
-            int tot;
-            int ex = wg_exclusive_scan<4>(s, lds, &tot);             // (its barriers also publish the staged table)
-            ex += bsum ? bsum[b] : (int)scan_lookback(state, b, nb, tot, &bcast, total_out, off_last, err);
-            if (s) {
-                i64 k = -1, k_end = 0, k_base = 0;
-                int k_start = 0;
-                {
-                    unsigned w = f;
-                    while (w) {
-                        int e = __ffs(w) - 1;
-                        w &= w - 1;
-                        i64 i = i0 + e;
-                        if (k < 0 || i >= k_end) {
-                            // the interval of position i lies between the first intervals of this and the next block
-                            const i64 ka = k < 0 ? ka0 : k + 1;
-                            if (staged) {
-                                const int a = (int)(ka - ka0);
-                                const int kk = a + (int)last_le(po_s + a, (i64)(niv - a), i);
-                                k = ka0 + kk; k_base = po_s[kk]; k_end = po_s[kk + 1]; k_start = is_s[kk];
-                            } else {
-                                k = ka + last_le(pos_off + ka, kb0 - ka, i);
-                                k_base = pos_off[k]; k_end = pos_off[k + 1]; k_start = iv_start[k];
-                            }
-                        }
-                        int yy = (int)(i - k_base);
-                        out_y[ex] = yy;
-                        if (out_pos) out_pos[ex] = k_start + yy;
-                        if (out_iv) out_iv[ex] = (int)k;
-                        if (yy == 0) out_off[k] = ex;
-                        ++ex;
-                    }
-                }
-            }
-        }
-        return;
-    }
-    {
-        const i64 b = blockIdx.x;                                    // grid == nb
-        const i64 w0 = b * kScanBlock + (i64)wave * 2048;            // first position of this wave
-        int s = 0;
-        unsigned fm = 0;                                             // bit j = flag of position w0 + lane * 32 + j
-        {
-            i64 i0 = w0 + (i64)lane * 32;
-            if (i0 < n) {
-                fm = load_flags32(flags, i0, n);
-                s = count_flags32(fm);
-            }
-        }
-        for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
-        if (lane == 0) wave_cnt[wave] = s;
-        __syncthreads();
-        const int tot = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-        int ex = bsum ? bsum[b] : (int)scan_lookback(state, b, nb, tot, &bcast, total_out, off_last, err);
-        for (int w = 0; w < wave; ++w) ex += wave_cnt[w];
-        if (s) {
-            // The wave walks its 2048 positions in rows of 64 (lane = column), so the loads of y and the compacted
-            // stores are coalesced.  Row q's 64 flags are the masks of lanes 2q and 2q+1 (two readlanes, no memory),
-            // and the values of eight rows are loaded together from clamped addresses before any of them is used: a
-            // load under a condition would be a branch with its own wait, one memory round trip per row.
-            i64 k = -1, k_end = 0, k_base = 0;
-            // the rows that hold a flag at all (bit q of `rows`): the values Y > 0 come in runs of 2 * radius + 1 around the
-            // splice sites, so six rows in ten of a typical batch hold none and their values are not loaded
-            u64 rows = 0;
-            {
-                const u64 lanes_set = __ballot(fm != 0);                 // bit l: lane l's 32 positions hold a flag
-                u64 pairs = (lanes_set | (lanes_set >> 1)) & 0x5555555555555555ULL;     // bit 2q: row q
-                pairs = (pairs | (pairs >> 1)) & 0x3333333333333333ULL;
-                pairs = (pairs | (pairs >> 2)) & 0x0f0f0f0f0f0f0f0fULL;
-                pairs = (pairs | (pairs >> 4)) & 0x00ff00ff00ff00ffULL;
-                pairs = (pairs | (pairs >> 8)) & 0x0000ffff0000ffffULL;
-                rows = (pairs | (pairs >> 16)) & 0x00000000ffffffffULL;
-            }
-            while (rows) {
-                u64 m[8];
-                double yv[8];
-                int qs[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {                            // the next eight rows that hold flags
-                    const int q = rows ? (int)__builtin_ctzll(rows) : -1;
-                    qs[e] = q;
-                    rows = rows ? rows & (rows - 1) : 0;
-                    const int qq = q < 0 ? 0 : q;
-                    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)fm, 2 * qq);
-                    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)fm, 2 * qq + 1);
-                    m[e] = q < 0 ? 0 : ((u64)lo | ((u64)hi << 32));
-                    const i64 i = w0 + qq * 64 + lane;
-                    if (MODE == kEmitValues) yv[e] = y[i < n ? i : n - 1];
-                }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    if (!m[e]) continue;
-                    const i64 i = w0 + qs[e] * 64 + lane;
-                    if ((m[e] >> lane) & 1ULL) {
-                        const int d = ex + __popcll(m[e] & lt_mask);
-                        if (MODE == kEmitValues) v[d] = yv[e];
-                        else {
-                            if (k < 0 || i >= k_end) {
-                                // the interval of position i lies between the first intervals of this and the next block
-                                const i64 ka = k < 0 ? blk_iv0[b] : k, kb = (i64)blk_iv0[b + 1] + 1;
-                                k = ka + last_le(pos_off + ka, kb - ka, i);
-                                k_base = pos_off[k]; k_end = pos_off[k + 1];
-                            }
-                            int yy = (int)(i - k_base);
-                            out_y[d] = yy;
-                            if (out_pos) out_pos[d] = iv_start[k] + yy;
-                            if (out_iv) out_iv[d] = (int)k;
-                            if (yy == 0) out_off[k] = d;
-                        }
-                    }
-                    ex += __popcll(m[e]);
-                }
-            }
-        }
-    }
-}
-// rank of the first position of every partition in the compaction of the Y > 0 flags
-__global__ void __launch_bounds__(64) k_voff(int n_part, const i64 *part_iv_off, const i64 *pos_off, i64 n_pos,
-                                             const unsigned *flags, const int *bsum /* or null */, const u64 *state, const u64 *total, i64 *voff) {
-    for (int p = blockIdx.x; p <= n_part; p += gridDim.x) {
-        if (p == n_part) { if (threadIdx.x == 0) voff[p] = (i64)*total; continue; }
-        i64 pos = pos_off[part_iv_off[p]];
-        i64 b = pos / kScanBlock, start = b * kScanBlock;
-        int cnt = 0;
-        for (i64 i0 = start + (i64)threadIdx.x * 32; i0 < pos; i0 += 64 * 32) {
-            Flags32 f = load_flags32(flags, i0, pos);      // positions at or after pos are masked out by the bound
-            cnt += count_flags32(f);
-        }
-        for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
-        if (threadIdx.x == 0)                                       // look-back state: inclusive prefix of block b-1
-            voff[p] = (bsum ? (i64)bsum[b] : (b ? (i64)(state[b - 1] & kScanValueMask) : 0)) + cnt;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// S3a  variance threshold   (py/freddie_segment.py:757-759)
-// V = the Y > 0 values in (interval, position) order; thr = mean(V) + vf * std(V) with numpy's
-// summation order: consecutive 8192-element chunks, each summed pairwise (8 strided accumulators
-// below 129 elements, halves rounded down to a multiple of 8 above), chunk results added left to
-// right.  Empty V gives NaN, which fixes nothing.
-// ---------------------------------------------------------------------------------------------
-// one workgroup: per-partition V ranges and chunk offsets
-__global__ void __launch_bounds__(256) k_vplan(int n_part, const i64 *part_iv_off, const i64 *pos_off, i64 n_pos,
-                                               i64 *voff, i64 *chunk_off, Status *st, i64 chunk_cap) {
-    __shared__ int lds[16];
-    __shared__ i64 carry_s;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    for (int p0 = 0; p0 < n_part; p0 += blockDim.x) {
-        int p = p0 + threadIdx.x;
-        int nch = 0;
-        if (p < n_part) nch = (int)((voff[p + 1] - voff[p] + 8191) / 8192);
-        int tot;
-        int ex = wg_exclusive_scan(nch, lds, &tot);
-        i64 carry = carry_s;
-        if (p < n_part) chunk_off[p] = carry + ex;
-        __syncthreads();
-        if (threadIdx.x == 0) carry_s = carry + tot;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        chunk_off[n_part] = carry_s;
-        st->n_vchunks = (u64)carry_s;
-        if (carry_s > chunk_cap) atomicOr(&st->err, kErrOverflowChunks);
-    }
-}
-// one 512-thread workgroup per chunk; pass 0 sums v, pass 1 sums (v-mean)^2.
-// Thread (leaf, q) owns accumulator q of the 8-lane leaf of the pairwise recursion: r[q] = a[q] + a[8+q] +
-// a[16+q] + ... in that order; the 8 accumulators are combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) by
-// three xor-shuffles (IEEE addition is commutative, so both partners get identical bits), the tail (len%8)
-// is added left to right, and the leaves are combined in recursion order.
-struct VsumLds {
-    // leaves of the pairwise recursion, left to right; a partial chunk's tree is kept in heap order (root 1,
-    // children 2i / 2i+1; depth <= 7): node_kind 1 = leaf, 2 = inner node
-    int leaf_off[128], leaf_len[128], leaf_heap[128];
-    double node_val[256];
-    unsigned char node_kind[256];
-    int n_leaf_s, wave0_leaves;
-};
-// numpy's pairwise sum of ONE chunk (m <= 8192 values at a; pass 1: of (v - mu)^2) by a 512-thread workgroup; the result is
-// valid in thread 0.  Starts with a barrier (the previous chunk is done with L).
-__device__ __forceinline__ double vsum_chunk(const double *a, int m, int pass, double mu, VsumLds &L) {
-    __syncthreads();
-    if (m == 8192) {
-        // perfect tree: 64 leaves of 128
-        for (int t = threadIdx.x; t < 64; t += blockDim.x) { L.leaf_off[t] = t * 128; L.leaf_len[t] = 128; L.leaf_heap[t] = 64 + t; }
-        if (threadIdx.x == 0) L.n_leaf_s = 64;
-    } else {
-        // every leaf but a lone one has at least 64 elements, so it holds exactly one x = 64 t with x - off < 64:
-        // thread t walks the recursion (n2 = len/2 rounded down to a multiple of 8) down to the leaf of x
-        if (threadIdx.x < 256) L.node_kind[threadIdx.x] = 0;
-        __syncthreads();
-        if (threadIdx.x < 128) {
-            const int x = threadIdx.x * 64;
-            int off = 0, len = m, h = 1;
-            bool own = false;
-            if (x < m) {
-                while (len > 128) {
-                    int n2 = len / 2; n2 -= n2 % 8;
-                    if (x < off + n2) { len = n2; h = 2 * h; } else { off += n2; len -= n2; h = 2 * h + 1; }
-                }
-                own = x - off < 64;
-            }
-            const u64 mk = __ballot(own);
-            if (threadIdx.x == 0) L.wave0_leaves = __popcll(mk);
-            __syncthreads();
-            if (own) {
-                const int rank = __popcll(mk & ((1ULL << lane_id()) - 1ULL)) + (threadIdx.x >= 64 ? L.wave0_leaves : 0);
-                L.leaf_off[rank] = off; L.leaf_len[rank] = len; L.leaf_heap[rank] = h;
-                L.node_kind[h] = 1;
-                for (int anc = h >> 1; anc >= 1; anc >>= 1) L.node_kind[anc] = 2;
-            }
-            if (threadIdx.x == 64) L.n_leaf_s = L.wave0_leaves + __popcll(mk);
-        } else __syncthreads();
-    }
-    __syncthreads();
-    int nl = L.n_leaf_s;
-    const int q = threadIdx.x & 7;
-#define FSEG_VAL(x) (pass ? __dmul_rn(__dsub_rn((x), mu), __dsub_rn((x), mu)) : (x))
-    for (int t0 = 0; t0 < nl; t0 += 64) {
-        int t = t0 + (threadIdx.x >> 3);
-        double res = 0.0;
-        if (t < nl) {
-            const double *b = a + L.leaf_off[t];
-            int len = L.leaf_len[t];
-            if (len < 8) {
-                for (int i = 0; i < len; ++i) res = __dadd_rn(res, FSEG_VAL(b[i]));      // from 0.0, left to right
-            } else {
-                int body = len - (len % 8);
-                double x[16];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) x[i] = (8 * i + q < body) ? b[8 * i + q] : 0.0;
-                double r = FSEG_VAL(x[0]);
-#pragma unroll
-                for (int i = 1; i < 16; ++i) if (8 * i + q < body) r = __dadd_rn(r, FSEG_VAL(x[i]));
-                r = __dadd_rn(r, __shfl_xor(r, 1));
-                r = __dadd_rn(r, __shfl_xor(r, 2));
-                r = __dadd_rn(r, __shfl_xor(r, 4));
-                res = r;
-                for (int i = body; i < len; ++i) res = __dadd_rn(res, FSEG_VAL(b[i]));
-            }
-        }
-        if (t < nl && q == 0) L.node_val[L.leaf_heap[t]] = res;
-    }
-#undef FSEG_VAL
-    __syncthreads();
-    double out = 0.0;
-    if (m == 8192) {
-        // perfect tree over 64 leaves: adjacent pairs level by level = xor butterfly on one wave
-        if (threadIdx.x < 64) {
-            double x = L.node_val[64 + threadIdx.x];
-            for (int d = 1; d < 64; d <<= 1) x = __dadd_rn(x, __shfl_xor(x, d));
-            out = x;
-        }
-    } else {
-        // inner nodes bottom-up, one tree level per step: sum(left) + sum(right)
-        for (int lvl = 6; lvl >= 0; --lvl) {
-            const int i = (1 << lvl) + threadIdx.x;
-            if ((int)threadIdx.x < (1 << lvl) && L.node_kind[i] == 2) L.node_val[i] = __dadd_rn(L.node_val[2 * i], L.node_val[2 * i + 1]);
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) out = L.node_val[1];
-    }
-    return out;
-}
-// one 512-thread workgroup per chunk; pass 0 sums v, pass 1 sums (v-mean)^2.
-// Thread (leaf, q) owns accumulator q of the 8-lane leaf of the pairwise recursion: r[q] = a[q] + a[8+q] +
-// a[16+q] + ... in that order; the 8 accumulators are combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) by
-// three xor-shuffles (IEEE addition is commutative, so both partners get identical bits), the tail (len%8)
-// is added left to right, and the leaves are combined in recursion order.
-__global__ void __launch_bounds__(512) k_vsum_chunks(int n_part, const i64 *voff, const i64 *chunk_off, const double *v,
-                                                     const double *csum0, int pass, double *csum, i64 chunk_cap) {
-    __shared__ VsumLds L;
-    __shared__ double mu_s;
-    i64 n_chunks = chunk_off[n_part];
-    if (n_chunks > chunk_cap) n_chunks = chunk_cap;
-    for (i64 c = blockIdx.x; c < n_chunks; c += gridDim.x) {
-        int p = (int)last_le(chunk_off, (i64)n_part + 1, c);
-        i64 nv = voff[p + 1] - voff[p];
-        i64 o0 = (c - chunk_off[p]) * 8192;
-        int m = (int)((nv - o0) < 8192 ? (nv - o0) : 8192);
-        const double *a = v + voff[p] + o0;
-        __syncthreads();
-        double mu = 0.0;
-        if (pass) {
-            // mean of the partition from the first pass' chunk sums, added left to right (numpy adds its 8192-element
-            // blocks in order); every chunk of the partition repeats these few additions instead of a separate launch
-            if (threadIdx.x == 0) {
-                i64 c0 = chunk_off[p], c1 = chunk_off[p + 1];
-                if (c1 > chunk_cap) c1 = chunk_cap;
-                double sacc = 0.0;
-                for (i64 cc = c0; cc < c1; ++cc) sacc = (cc == c0) ? csum0[cc] : __dadd_rn(sacc, csum0[cc]);
-                mu_s = sacc / (double)nv;
-            }
-            __syncthreads();
-            mu = mu_s;
-        }
-        const double x = vsum_chunk(a, m, pass, mu, L);
-        if (threadIdx.x == 0) csum[c] = x;
-    }
-}
-// The whole threshold of a partition by ONE 512-thread workgroup (round 5; batches of many partitions of moderate size): the
-// partition's Y > 0 values are compacted into its own piece of v (it starts where the partition's positions start: no batch-wide
-// scan, no offsets), summed chunk by chunk in numpy's order (vsum_chunk, the same function the chunk kernel uses), the mean,
-// the squared deviations likewise, the threshold.  One launch instead of seven to nine (k_scan1 / k_scan2 / k_scan_emit<values>,
-// k_voff, k_vplan, k_vsum_chunks twice, k_vsum_part): 0.106 ms of launch-latency-sized pieces per 250 k-read batch.
-constexpr int kThrPartMaxChunks = 128;     // chunk sums a workgroup keeps in LDS: partitions of up to 2^20 positions
-// A wave compacts the flagged values of its 2048 positions w0 .. w0 + 2047 (fm: the flag word of lane l's 32 positions, w0 + 32 l ..)
-// into v[ex ..) and returns their number.  Rows of 64 positions (lane = column), so the loads of y and the stores are coalesced;
-// a row's 64 flags are the words of lanes 2q and 2q + 1 (two readlanes); rows without a flag are skipped (the values Y > 0 come
-// in runs of 2 * radius + 1 around the splice sites) and the values of eight rows are loaded together from clamped addresses.
-__device__ __forceinline__ int wave_emit_values(i64 w0, i64 n_pos, unsigned fm, i64 ex, const double *__restrict__ y, double *v) {
-    const int lane = lane_id();
-    const u64 lt_mask = (1ULL << lane) - 1ULL;
-    u64 rows;
-    {
-        const u64 lanes_set = __ballot(fm != 0);                 // bit l: lane l's 32 positions hold a flag
-        u64 pairs = (lanes_set | (lanes_set >> 1)) & 0x5555555555555555ULL;     // bit 2q: row q
-        pairs = (pairs | (pairs >> 1)) & 0x3333333333333333ULL;
-        pairs = (pairs | (pairs >> 2)) & 0x0f0f0f0f0f0f0f0fULL;
-        pairs = (pairs | (pairs >> 4)) & 0x00ff00ff00ff00ffULL;
-        pairs = (pairs | (pairs >> 8)) & 0x0000ffff0000ffffULL;
-        rows = (pairs | (pairs >> 16)) & 0x00000000ffffffffULL;
-    }
-    int cnt = 0;
-    while (rows) {
-        u64 m[8];
-        double yv[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {                            // the next eight rows that hold flags
-            const int q = rows ? (int)__builtin_ctzll(rows) : -1;
-            rows = rows ? rows & (rows - 1) : 0;
-            const int qq = q < 0 ? 0 : q;
-            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)fm, 2 * qq);
-            const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)fm, 2 * qq + 1);
-            m[e] = q < 0 ? 0 : ((u64)lo | ((u64)hi << 32));
-            const i64 i = w0 + qq * 64 + lane;
-            yv[e] = y[i < n_pos ? i : n_pos - 1];
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            if (!m[e]) continue;
-            if ((m[e] >> lane) & 1ULL) v[ex + cnt + __popcll(m[e] & lt_mask)] = yv[e];
-            cnt += __popcll(m[e]);
-        }
-    }
-    return cnt;
-}
-__global__ void __launch_bounds__(512) k_thr_part(int n_part, const i64 *part_iv_off, const i64 *pos_off, i64 n_pos, const unsigned *flags,
-                                                  const double *__restrict__ y, double *v, double vf, double *mean, double *thr) {
-    __shared__ VsumLds L;
-    __shared__ int wave_cnt[8];
-    __shared__ double cs[kThrPartMaxChunks];
-    __shared__ double mu_s;
-    const int lane = lane_id(), wave = threadIdx.x >> 6;
-    for (int p = blockIdx.x; p < n_part; p += gridDim.x) {
-        const i64 pos0 = pos_off[part_iv_off[p]], pos1 = pos_off[part_iv_off[p + 1]];
-        double *vp = v + pos0;
-        // compaction: the partition's flag words in groups of 64 (2048 positions), every wave an eighth of the groups
-        const i64 wbeg = pos0 >> 5, wend = (pos1 + 31) >> 5;
-        const i64 groups = (wend - wbeg + 63) / 64, gpw = (groups + 7) / 8;
-        const i64 g0 = (i64)wave * gpw, g1 = g0 + gpw < groups ? g0 + gpw : groups;
-        auto flag_word = [&](i64 wd) -> unsigned {
-            if (wd >= wend) return 0u;
-            unsigned f = flags[wd];
-            const i64 i0 = wd << 5;
-            if (i0 < pos0) f &= ~0u << (int)(pos0 - i0);
-            if (i0 + 32 > pos1) f &= (1u << (int)(pos1 - i0)) - 1u;
-            return f;
-        };
-        int cnt = 0;
-        for (i64 g = g0; g < g1; ++g) cnt += __popc(flag_word(wbeg + g * 64 + lane));
-        for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
-        if (lane == 0) wave_cnt[wave] = cnt;
-        __syncthreads();
-        i64 ex = 0;
-        int nv = 0;
-        for (int w = 0; w < 8; ++w) { if (w < wave) ex += wave_cnt[w]; nv += wave_cnt[w]; }
-        for (i64 g = g0; g < g1; ++g) ex += wave_emit_values((wbeg + g * 64) << 5, n_pos, flag_word(wbeg + g * 64 + lane), ex, y, vp);
-        __builtin_amdgcn_s_waitcnt(0);                  // the values are read back by other waves of this workgroup
-        __syncthreads();
-        const int nch = (nv + 8191) / 8192;
-        double s_acc[2] = {0.0, 0.0};
-        for (int pass = 0; pass < 2; ++pass) {
-            const double mu = pass ? mu_s : 0.0;
-            for (int c = 0; c < nch; ++c) {
-                const int m = nv - c * 8192 < 8192 ? nv - c * 8192 : 8192;
-                const double x = vsum_chunk(vp + (i64)c * 8192, m, pass, mu, L);
-                if (threadIdx.x == 0) cs[c] = x;
-            }
-            if (threadIdx.x == 0) {
-                double sacc = 0.0;
-                for (int c = 0; c < nch; ++c) sacc = c == 0 ? cs[0] : __dadd_rn(sacc, cs[c]);     // numpy adds its chunks left to right
-                s_acc[pass] = sacc;
-                if (pass == 0) mu_s = sacc / (double)nv;                                         // empty -> 0/0 = NaN like numpy
-            }
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) {
-            const double mu = mu_s;
-            mean[p] = mu;
-            thr[p] = __dadd_rn(mu, __dmul_rn(vf, __dsqrt_rn(s_acc[1] / (double)nv)));             // :758-759
-        }
-        __syncthreads();
-    }
-}
-__global__ void k_vsum_part(int n_part, const i64 *voff, const i64 *chunk_off, const double *csum0, const double *csum1,
-                            double vf, double *mean, double *thr, i64 chunk_cap) {
-    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n_part; p += gridDim.x * blockDim.x) {
-        i64 c0 = chunk_off[p], c1 = chunk_off[p + 1];
-        if (c1 > chunk_cap) c1 = chunk_cap;
-        double n = (double)(voff[p + 1] - voff[p]);
-        double s0 = 0.0, s1 = 0.0;
-        for (i64 c = c0; c < c1; ++c) {
-            s0 = (c == c0) ? csum0[c] : __dadd_rn(s0, csum0[c]);
-            s1 = (c == c0) ? csum1[c] : __dadd_rn(s1, csum1[c]);
-        }
-        const double mu = s0 / n;                                       // empty -> 0/0 = NaN like numpy
-        mean[p] = mu;
-        thr[p] = __dadd_rn(mu, __dmul_rn(vf, __dsqrt_rn(s1 / n)));      // :758-759
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// S3b  candidates   (candidates_from_peaks :615-621; scipy _local_maxima_1d)
-// strict local maxima with the plateau-midpoint rule, plus the first and last position.
-// ---------------------------------------------------------------------------------------------
-// edge[p]: bit 0 = p is the first position of its interval, bit 1 = the last one.  Built once per uploaded batch.
-// What k_smooth's tiles could not decide about candidates_from_peaks (:615-621): one thread per tile looks, in the finished
-// signal, at the tile's first position, its last position and the plateau start the tile deferred -- as possible STARTS of a
-// peak (a strict maximum, or a plateau whose midpoint counts when it falls on its right; the walk stops at the interval's
-// last position, as scipy's does).  Interval ends were flagged by the tiles.
-__device__ __forceinline__ void peak_from(i64 p, i64 last /* the interval's last position */, const double *x, unsigned *flag) {
-    const double xi = x[p];
-    if (!(x[p - 1] < xi)) return;
-    if (x[p + 1] < xi) { set_flag(flag, p); return; }
-    if (x[p + 1] == xi) {
-        i64 ia = p + 1;
-        while (ia < last && x[ia] == xi) ++ia;
-        if (x[ia] < xi) set_flag(flag, (p + ia - 1) / 2);     // plateau midpoint (positions of one interval are consecutive)
-    }
-}
-__global__ void __launch_bounds__(256) k_peaks_edges(int n_tiles, const TileDesc *tiles, const int *tile_defer, const double *x,
-                                                     unsigned *flag, int *part_has2, int n_part) {
-    // also clears the per-partition 'some default label is not 0' flags that k_label_cols sets much later
-    if (blockIdx.x == 0) for (int p = threadIdx.x; p < n_part; p += blockDim.x) part_has2[p] = 0;
-    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n_tiles; t += gridDim.x * blockDim.x) {
-        const TileDesc d = tiles[t];
-        const i64 first = d.base + d.y0, last = d.base + d.len - 1;
-        const i64 tile_last = first + kSmoothTile - 1;
-        if (d.y0 > 0 && first < last) peak_from(first, last, x, flag);              // (an interval's own ends are candidates already)
-        if (tile_last < last && kSmoothTile > 1) peak_from(tile_last, last, x, flag);
-        const int df = tile_defer[t];
-        if (df >= 0) peak_from(first + df, last, x, flag);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// S4  fixing, problem splitting, problem list
-//   fixed = {0, N-1} U {c : Y[cand_c] > thr}                      py/freddie_segment.py:776-783
-//   break_large_problems                                           :623-645 (pairs taken before insertion)
-//   problems = consecutive fixed pairs                             :581
-// One wave per tint interval, lane = candidate inside a 64-candidate tile; the "previous fixed
-// candidate" of a lane comes from the tile's ballot mask or from the carry of earlier tiles.
-// Problems with n == 2 have no (i,j,k) and can never add a breakpoint, so only n >= 3 are emitted.
-// For each problem the kernel also finds the range of position-sorted reads that can overlap its
-// window and carves its share of the arenas (one wave-aggregated atomic per arena and tile).
-// ---------------------------------------------------------------------------------------------
-struct ProblemArrays {
-    int *iv;        // interval
-    int *start;     // first candidate (index inside the interval)
-    int *n;         // number of candidates
-    i64 *pair_off;  // offset into the pair arenas (thresholds, ambiguity counts)
-    i64 *tri_off;   // offset into the out-count arena
-    int *flags;     // bit0: some pair has lo < 0 (a read with zero coverage is ambiguous there)
-    int *chain;     // number of backtracked triples (debug)
-    i64 *cov_off;   // offset into the coverage arena
-    int *lane_lo;   // first lane (position-sorted read) that can overlap the problem's window
-    int *lane_n;    // number of lanes examined: [lane_lo, lane_lo + lane_n)
-};
-// Everything the coverage / scoring / DP kernels need to know about a problem, in one 64-byte record: their
-// per-item set-up is a chain of dependent loads, and one record load replaces three levels of it.
-struct __align__(16) ProbDesc {
-    i64 c0;         // global index of the problem's first candidate (cand_off[iv] + start)
-    i64 pair_off, tri_off, cov_off;
-    int n, lane_lo, lane_n;
-    int g0;         // genomic start of the interval (iv_start[iv])
-    int outside;    // lanes of the partition outside [lane_lo, lane_lo + lane_n)
-    int iv;
-    int w0;         // first work item (= chunk 0) of the problem
-    int kind;       // kKindArena / kKindTiny / kKindFused: which kernels solve it
-};
-static_assert(sizeof(ProbDesc) == 64, "ProbDesc is one 64-byte record");
-__device__ __forceinline__ ProbDesc load_desc(const ProbDesc *d) {
-    const uint4 *q = reinterpret_cast<const uint4 *>(d);
-    union { uint4 v[4]; ProbDesc p; } u;
-    u.v[0] = q[0]; u.v[1] = q[1]; u.v[2] = q[2]; u.v[3] = q[3];
-    return u.p;
-}
-
-// Eight (two) consecutive exon coordinates from a dword-aligned address as two 16-byte loads (one 8-byte load).  A lane that
-// walks its own read's exons touches one or two cache lines per block whichever way it loads them, but the texture path works
-// per instruction and lane: eight dword loads of 64 lanes are 512 line accesses, two 16-byte loads 128 -- and that rate, not
-// HBM or the ALUs, is what the small problems' kernels run at.  The exon arrays are padded so that a block which starts at
-// the batch's last exons stays inside them; elements beyond a read's own exons are masked by the callers.
-typedef int int4u __attribute__((ext_vector_type(4), aligned(4)));
-typedef int int2u __attribute__((ext_vector_type(2), aligned(4)));
-__device__ __forceinline__ void load_exons8(const int *p, int (&v)[8]) {
-    const int4u a = *reinterpret_cast<const int4u *>(p), b = *reinterpret_cast<const int4u *>(p + 4);
-    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-}
-__device__ __forceinline__ int2 load_exons2(const int *p) {
-    const int2u a = *reinterpret_cast<const int2u *>(p);
-    return make_int2(a.x, a.y);
-}
-constexpr size_t kExonPad = 32;        // bytes behind ex_ts / ex_te
-constexpr size_t kLexPad = 64;         // bytes behind the lane-ordered exon stream (it is read in aligned 16-byte units)
-
-// A value every lane of the wave holds identically, moved to a scalar register: what is computed from it (triangular
-// table offsets, loop bounds, LDS base addresses) then runs on the scalar unit instead of costing every lane a multiply.
-__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ int wave_id() { return uni((int)(threadIdx.x >> 6)); }
-__device__ __forceinline__ ProbDesc load_desc_uniform(const ProbDesc *d) {      // the whole wave loads the same record
-    const uint4 *q = reinterpret_cast<const uint4 *>(d);
-    union { uint4 v[4]; int w[16]; ProbDesc p; } u;
-    u.v[0] = q[0]; u.v[1] = q[1]; u.v[2] = q[2]; u.v[3] = q[3];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) u.w[i] = uni(u.w[i]);
-    return u.p;
-}
-
-#ifdef FSEG_DESC_VECTOR
-#define FSEG_LOAD_DESC load_desc
-#else
-#define FSEG_LOAD_DESC load_desc_uniform
-#endif
-
-__device__ __forceinline__ i64 wave_excl_scan(i64 v, i64 *total) {
-    int lane = lane_id();
-    i64 x = v;
-    for (int d = 1; d < 64; d <<= 1) {
-        i64 y = __shfl_up(x, d);
-        if (lane >= d) x += y;
-    }
-    *total = __shfl(x, 63);
-    return x - v;
-}
-
-// Workgroup-wide "previous flagged element": every thread holds one element (index idx, flag f) of a tile of
-// blockDim.x consecutive elements; returns the index of the nearest flagged element before it (from this tile,
-// else `carry`), and advances carry to the tile's last flagged element.  lds: >= 16 ints.
-__device__ __forceinline__ int wg_prev_flagged(bool f, int idx, int &carry, int *lds) {
-    int lane = lane_id(), wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
-    u64 mask = __ballot(f);
-    __syncthreads();
-    if (lane == 0) lds[wave] = mask ? idx + 63 - __clzll((long long)mask) : -1;
-    __syncthreads();
-    u64 below = mask & ((1ULL << lane) - 1ULL);
-    int prev = carry;
-    if (below) prev = idx - lane + 63 - __clzll((long long)below);
-    else for (int w = wave - 1; w >= 0; --w) if (lds[w] >= 0) { prev = lds[w]; break; }
-    for (int w = nw - 1; w >= 0; --w) if (lds[w] >= 0) { carry = lds[w]; break; }
-    return prev;
-}
-
-__global__ void k_fix(i64 K, const i64 *pos_off, const int *iv_part, const i64 *cand_off, const int *cand_y,
-                      const double *yv, const double *thr_part, int mps, unsigned char *fixed0, unsigned char *added,
-                      unsigned char *fixed, unsigned char *chosen, int *cand_pn, int *cand_iv, Status *st) {
-    __shared__ int lds[16];
-    const int T = blockDim.x;
-    for (i64 k = blockIdx.x; k < K; k += gridDim.x) {
-        i64 c0 = cand_off[k];
-        int N = (int)(cand_off[k + 1] - c0);
-        const double *y = yv + pos_off[k];
-        const int *cy = cand_y + c0;
-        double thr = thr_part[iv_part[k]];
-        if (T == 64 && N <= 64 && N <= mps) {
-            // short interval, one wave: no gap can exceed max_problem_size, so the fixed set is final at once and the
-            // previous fixed candidate comes from the ballot -- three dependent load rounds, no barrier
-            const int c = threadIdx.x;
-            const bool in = c < N;
-            const bool f = in && (c == 0 || c == N - 1 || y[cy[c]] > thr);
-            const u64 mask = __ballot(f);
-            int n = 0;
-            if (in) {
-                const u64 below = mask & ((1ULL << c) - 1ULL);
-                const int prev = below ? 63 - __clzll((long long)below) : -1;
-                n = (f && prev >= 0 && c - prev + 1 >= 3) ? c - prev + 1 : 0;
-                fixed0[c0 + c] = f; added[c0 + c] = 0; cand_iv[c0 + c] = (int)k;
-                fixed[c0 + c] = f; chosen[c0 + c] = f;
-                cand_pn[c0 + c] = n;
-            }
-            continue;
-        }
-        for (int c = threadIdx.x; c < N; c += T) {
-            fixed0[c0 + c] = (c == 0 || c == N - 1 || y[cy[c]] > thr) ? 1 : 0;
-            added[c0 + c] = 0;
-            cand_iv[c0 + c] = (int)k;
-        }
-        __syncthreads();
-        // break_large_problems over the original consecutive fixed pairs; the thread that owns the
-        // right end of an oversized gap places its anchors
-        int carry = -1;
-        for (int t0 = 0; t0 < N; t0 += T) {
-            int c = t0 + threadIdx.x;
-            bool f = c < N && fixed0[c0 + c];
-            int prev = wg_prev_flagged(f, c, carry, lds);
-            if (f && prev >= 0) {
-                int size = c - prev + 1;
-                if (size > mps) {
-                    int cnt = (int)ceil((double)size / (double)mps);
-                    double step = (double)size / (double)cnt;
-                    for (int i = 1; i < cnt; ++i) {
-                        int anchor = (int)((double)prev + __dmul_rn((double)i, step));
-                        double best = -INFINITY;
-                        int best_c = -1;
-                        bool bad = false;
-                        for (int cc = anchor - 5; cc < anchor + 5; ++cc) {
-                            int ci = cc < 0 ? cc + N : cc;          // Python negative-index wraparound
-                            if (ci < 0 || ci >= N) { bad = true; continue; }
-                            double val = y[cy[ci]];
-                            if (val > best) { best = val; best_c = cc; }
-                        }
-                        if (bad || !(best > 0.0) || best_c < 0) atomicOr(&st->err, kErrBreakAssert);
-                        else added[c0 + best_c] = 1;
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        // final fixed set; the right end of every problem records the problem's size
-        carry = -1;
-        for (int t0 = 0; t0 < N; t0 += T) {
-            int c = t0 + threadIdx.x;
-            bool f = c < N && (fixed0[c0 + c] | added[c0 + c]);
-            int prev = wg_prev_flagged(f, c, carry, lds);
-            if (c < N) {
-                fixed[c0 + c] = f; chosen[c0 + c] = f;
-                int n = (f && prev >= 0 && c - prev + 1 >= 3) ? c - prev + 1 : 0;
-                if (n > kNGiant) atomicOr(&st->err, kErrProblemTooLarge);
-                cand_pn[c0 + c] = n;
-            }
-        }
-        __syncthreads();
-    }
-}
-
-// The exons of one read (ex = its range in the exon arrays) that meet the window [cp0, c_last): exons are ordered, so they
-// are consecutive -- `cnt` of them from the read's `first_rel`-th.  k_solve keeps the reads with cnt > 0 (its rounds run over
-// those only) and k_prob_range counts them ahead of it: the one definition of "keeps".
-__device__ __forceinline__ void window_exons(const int2 *__restrict__ lex, int2 lx, int cp0, int c_last, int *first_rel, int *cnt_out) {
-    // (the exons come from the lane-ordered (ts, te) stream: a read's exons are one contiguous piece of it and consecutive
-    // lanes' pieces follow each other, so the lanes of a wave walk neighbouring cache lines -- from the rep-ordered ex_ts / ex_te
-    // every lane's eight exons were two lines of their own, 128 line accesses per load instruction of a wave)
-    const int n_ex = lx.y - lx.x;
-    int fr = 0, cnt = 0;
-    for (int eb = 0; eb < n_ex; eb += 8) {                   // eight exons per round (what lies beyond the read's own is masked; the stream is padded)
-        int4u x[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) x[u] = *reinterpret_cast<const int4u *>(lex + lx.x + eb + 2 * u);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const bool hit0 = eb + 2 * u < n_ex && x[u].y >= cp0 && x[u].x < c_last;
-            if (hit0 && cnt == 0) fr = eb + 2 * u;
-            cnt += hit0;
-            const bool hit1 = eb + 2 * u + 1 < n_ex && x[u].w >= cp0 && x[u].z < c_last;
-            if (hit1 && cnt == 0) fr = eb + 2 * u + 1;
-            cnt += hit1;
-        }
-        if (eb + 7 < n_ex && x[3].z >= c_last) break;        // the rest of the read lies beyond the window
-    }
-    *first_rel = fr; *cnt_out = cnt;
-}
-
-// For the right end of every problem: the range of position-sorted reads that can overlap the problem's window
-// [g0, g1): reads are sorted by first position, lane_pmax is the running maximum of their last position.
-// ... and, for a problem that sees more than kFuseLanes reads (8-bit counters hold 255), whether it KEEPS more than that
-// many -- reads with an exon in the window, about two thirds of those it sees: cand_wide[c] = 1 sends it to the 16-bit
-// instances of k_solve (kKindFusedWide in its record).  Such candidates are rare and expensive (up to kFuseLanesWide reads
-// each): the workgroup collects its own in LDS and goes over them together, a read per thread.  (Round 4 until here: both
-// instances located every such problem and counted its kept reads, the 16-bit ones to drop nearly all of them again --
-// launches of 12-70 us in front of the classes behind them on config3 / config5.)
-constexpr int kRangeThreads = 256;
-__global__ void __launch_bounds__(kRangeThreads) k_prob_range(const Status *st, const int *cand_pn, const int *cand_iv, const int *cand_y,
-                             const int *iv_part, const int *iv_start, const i64 *part_lane_off, const int *lane_start,
-                             const int *lane_pmax, int *cand_ll, int *cand_ln, unsigned char *cand_wide,
-                             const int2 *__restrict__ lane_lx, const int2 *__restrict__ lex, int wide_by_seen, int fuse_lanes) {
-    __shared__ int l_wide[kRangeThreads], l_n, l_red[kRangeThreads / 64];
-    const i64 n_cand = (i64)st->n_cand;
-    for (i64 c0 = (i64)blockIdx.x * blockDim.x; c0 < n_cand; c0 += (i64)gridDim.x * blockDim.x) {    // (workgroup-uniform)
-        const i64 c = c0 + threadIdx.x;
-        if (threadIdx.x == 0) l_n = 0;
-        __syncthreads();
-        if (c < n_cand) {
-            int n = cand_pn[c];
-            int lo_lane = 0, n_lanes = 0;
-            if (n > 0) {
-                int k = cand_iv[c];
-                int part = iv_part[k];
-                int g0 = iv_start[k] + cand_y[c - (n - 1)], g1 = iv_start[k] + cand_y[c];
-                i64 a = part_lane_off[part], L1 = part_lane_off[part + 1], b = L1;
-                while (a < b) { i64 m = (a + b) >> 1; if (lane_pmax[m] < g0) a = m + 1; else b = m; }
-                i64 lo = a;
-                b = L1;
-                while (a < b) { i64 m = (a + b) >> 1; if (lane_start[m] < g1) a = m + 1; else b = m; }
-                lo_lane = (int)lo; n_lanes = (int)(a - lo);
-            }
-            cand_ll[c] = lo_lane; cand_ln[c] = n_lanes;
-            // (fuse_lanes: what a problem may see to be solved whole, -1 in a batch that is not -- there nobody asks, and a
-            // batch of deep problems would pay a workgroup's walk over up to 1 023 reads for every one of them)
-            const bool cand = n > 0 && n <= kNMax && n_lanes > kFuseLanes && n_lanes <= kFuseLanesWide && n_lanes <= fuse_lanes;
-            cand_wide[c] = (unsigned char)((cand && wide_by_seen) ? 1 : 0);     // (FSEG_WIDE_BY_SEEN=1, tests: whatever SEES more than kFuseLanes reads)
-            if (cand && !wide_by_seen) l_wide[atomicAdd(&l_n, 1)] = (int)threadIdx.x;
-        }
-        __syncthreads();
-        const int nw = l_n;
-        for (int w = 0; w < nw; ++w) {
-            const i64 cw = c0 + l_wide[w];
-            const int n = cand_pn[cw], k = cand_iv[cw], ll = cand_ll[cw], ln = cand_ln[cw];
-            const int cp0 = iv_start[k] + cand_y[cw - (n - 1)], c_last = iv_start[k] + cand_y[cw];
-            int kept = 0;
-            for (int l = threadIdx.x; l < ln; l += kRangeThreads) {
-                int first_rel, cnt;
-                window_exons(lex, lane_lx[ll + l], cp0, c_last, &first_rel, &cnt);
-                kept += cnt > 0;
-            }
-            for (int d = 32; d >= 1; d >>= 1) kept += __shfl_xor(kept, d);
-            if (lane_id() == 0) l_red[threadIdx.x >> 6] = kept;
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                int tot = 0;
-                for (int q = 0; q < kRangeThreads / 64; ++q) tot += l_red[q];
-                if (tot > kFuseLanes) cand_wide[cw] = 1;
-            }
-            __syncthreads();
-        }
-    }
-}
-
-// Problem list by a prefix sum over the candidates: problem slot, pair / triple / coverage arena offsets and
-// work items come out in candidate order, so the arena layout is deterministic.
-// Scanned columns.  Counters that stay below 2^32 over a whole batch share a 64-bit column (low | high << 32):
-//   0: problem slot | DP problems of the small class     1: pairs     2: triples     3: coverage elements
-//   4: work items of class 0 | class 1                   5: work items of class 2 | DP problems of the big class
-//   6: work items of class 3 (huge) | DP problems of the huge class
-//   7: fused problems of class 0 | class 1                   8: fused problems of class 2 | k_tiny's problems
-// (work items overall = the four class counts)
-constexpr int kProbCols = 9;
-__device__ __forceinline__ i64 col_lo(i64 x) { return x & 0xffffffffLL; }
-__device__ __forceinline__ i64 col_hi(i64 x) { return (i64)((u64)x >> 32); }
-constexpr int kDpSmall = 32;
-constexpr int kClsSmall = 16, kClsMid = 32;
-struct ProbSizes { i64 v[kProbCols]; };
-__device__ __forceinline__ int size_class(int n) { return n <= kClsSmall ? 0 : (n <= kClsMid ? 1 : (n <= kNMax ? 2 : 3)); }
-// How the problems of a run are divided among the three ways of solving them:
-//   n <= tiny_max (> 0 in batches of many problems): whole by k_tiny, one wave each; a problem slot and nothing else;
-//   otherwise, lanes <= fuse_lanes and n <= kNMax: whole by k_solve, one workgroup each (coverage, pair labels, counts and
-//     DP without leaving LDS); a problem slot and an entry in its size class's solve list;
-//   otherwise: the arena path -- coverage tiles, one scoring work item per 256 reads, global count tables, DP kernels
-//     (problems that see many reads need many workgroups to score them).
-//   with the wave kernels (k_wave: the batch has its exon stream) the small class -- n <= wave_n -- is solved whole, one wave
-//     per problem, whenever the problem sees at most wave_lanes reads, whatever the rest of the batch looks like.
-struct ProbSplit { int tiny_max, fuse_lanes; };
-enum { kKindArena = 0, kKindTiny = 1, kKindFused = 2, kKindFusedWide = 3 };   // (kKindFusedWide: a record's kind only -- a fused problem that KEEPS more than kFuseLanes reads, k_prob_range)
-__device__ __forceinline__ int prob_kind(int n, int n_lanes, ProbSplit sp) {
-    if (n <= sp.tiny_max) return kKindTiny;
-    return (n_lanes <= sp.fuse_lanes && n <= kNMax) ? kKindFused : kKindArena;
-}
-__device__ __forceinline__ ProbSizes prob_sizes(int n, int n_lanes, ProbSplit sp) {
-    ProbSizes s;
-    for (int q = 0; q < kProbCols; ++q) s.v[q] = 0;
-    if (n <= 0) return s;
-    const int kind = prob_kind(n, n_lanes, sp);
-    if (kind == kKindTiny) { s.v[0] = 1; s.v[8] = 1LL << 32; return s; }
-    if (kind == kKindFused) {
-        const int c = size_class(n);
-        s.v[0] = 1;
-        s.v[7] = c == 0 ? 1 : (c == 1 ? (1LL << 32) : 0);
-        s.v[8] = c == 2 ? 1 : 0;
-        return s;
-    }
-    i64 chunks = (n_lanes + kLaneChunk - 1) / kLaneChunk;
-    const int cls = size_class(n);
-    s.v[0] = 1 + (n <= kDpSmall ? (1LL << 32) : 0);
-    s.v[1] = (i64)n * (n - 1) / 2; s.v[2] = (i64)n * (n - 1) * (n - 2) / 6;
-    s.v[3] = chunks * kLaneChunk * n;
-    s.v[4] = cls == 0 ? chunks : (cls == 1 ? chunks << 32 : 0);
-    s.v[5] = (cls == 2 ? chunks : 0) + ((n > kDpSmall && n <= kNMax) ? (1LL << 32) : 0);
-    s.v[6] = (cls == 3 ? chunks : 0) + (n > kNMax ? (1LL << 32) : 0);
-    return s;
-}
-__device__ __forceinline__ i64 wg_exclusive_scan64(i64 v, i64 *lds /* >= 16 */, i64 *total) {
-    int lane = lane_id(), wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
-    i64 x = v;
-    for (int d = 1; d < 64; d <<= 1) {
-        i64 y = __shfl_up(x, d);
-        if (lane >= d) x += y;
-    }
-    __syncthreads();
-    if (lane == 63) lds[wave] = x;
-    __syncthreads();
-    i64 off = 0, tot = 0;
-    for (int w = 0; w < nw; ++w) {
-        i64 sv = lds[w];
-        if (w < wave) off += sv;
-        tot += sv;
-    }
-    *total = tot;
-    return off + x - v;
-}
-constexpr int kProbBlock = 1024;   // candidates per workgroup of the problem scan (256 threads x 4)
-// exclusive scan of kProbCols columns over the 256 threads of a workgroup (two barriers for all columns)
-__device__ __forceinline__ void wg_scan_cols(const ProbSizes &v, ProbSizes &ex, ProbSizes &tot, i64 *lds /* 4 * kProbCols */) {
-    const int lane = lane_id(), wave = threadIdx.x >> 6;
-    for (int q = 0; q < kProbCols; ++q) {
-        i64 x = v.v[q];
-        if (__ballot(x != 0)) {                          // (a batch fills the arena path's columns or the solve lists', rarely both:
-            for (int d = 1; d < 64; d <<= 1) {           //  the wave skips the columns in which it holds nothing)
-                i64 y = __shfl_up(x, d);
-                if (lane >= d) x += y;
-            }
-        }
-        ex.v[q] = x - v.v[q];
-        if (lane == 63) lds[wave * kProbCols + q] = x;
-    }
-    __syncthreads();
-    for (int q = 0; q < kProbCols; ++q) {
-        i64 off = 0, t = 0;
-        for (int w = 0; w < 4; ++w) {
-            i64 sv = lds[w * kProbCols + q];
-            if (w < wave) off += sv;
-            t += sv;
-        }
-        ex.v[q] += off; tot.v[q] = t;
-    }
-    __syncthreads();
-}
-__device__ __forceinline__ ProbSizes prob_block_sizes(const int *cand_pn, const int *cand_ln, i64 b, i64 n, ProbSizes *per_elem /* 4, may be null */, ProbSplit sp) {
-    ProbSizes acc;
-    for (int q = 0; q < kProbCols; ++q) acc.v[q] = 0;
-    const i64 i0 = b * kProbBlock + (i64)threadIdx.x * 4;
-    for (int e = 0; e < 4; ++e) {
-        ProbSizes sz = i0 + e < n ? prob_sizes(cand_pn[i0 + e], cand_ln[i0 + e], sp) : prob_sizes(0, 0, sp);
-        if (per_elem) per_elem[e] = sz;
-        for (int q = 0; q < kProbCols; ++q) acc.v[q] += sz.v[q];
-    }
-    return acc;
-}
-__device__ __forceinline__ void prob_store_totals(Status *st, const ProbSizes &t) {
-    st->n_prob = (u64)col_lo(t.v[0]); st->pair_used = (u64)t.v[1]; st->tri_used = (u64)t.v[2];
-    st->n_work = (u64)(col_lo(t.v[4]) + col_hi(t.v[4]) + col_lo(t.v[5]) + col_lo(t.v[6])); st->cov_used = (u64)t.v[3];
-    st->cls_work[0] = (u64)col_lo(t.v[4]); st->cls_work[1] = (u64)col_hi(t.v[4]); st->cls_work[2] = (u64)col_lo(t.v[5]);
-    st->cls_work[3] = (u64)col_lo(t.v[6]);
-    st->dp_cls[0] = (u64)col_hi(t.v[0]); st->dp_cls[1] = (u64)col_hi(t.v[5]); st->dp_cls[2] = (u64)col_hi(t.v[6]);
-    st->solve_cls[0] = (u64)col_lo(t.v[7]); st->solve_cls[1] = (u64)col_hi(t.v[7]); st->solve_cls[2] = (u64)col_lo(t.v[8]);
-    st->n_tiny = (u64)col_hi(t.v[8]);
-}
-// Largest problem (candidates) and widest problem (reads examined) of the run: they size the big-problem kernels' LDS
-// and pick the DP's count width.  One atomic per block of 1024 candidates -- per-problem atomics on the one address
-// serialise (~90 per us).  l_mx: 8 ints of LDS; the caller's next barrier orders them.
-__device__ __forceinline__ void prob_block_maxima(Status *st, const int *cand_pn, const int *cand_ln, i64 b, i64 n, int *l_mx) {
-    int mx = 0, ml = 0;
-    for (int e = 0; e < 4; ++e) {
-        const i64 cc = b * kProbBlock + (i64)threadIdx.x * 4 + e;
-        if (cc < n) { const int pn = cand_pn[cc]; mx = max(mx, pn); if (pn > 0) ml = max(ml, cand_ln[cc]); }
-    }
-    for (int d = 32; d >= 1; d >>= 1) { mx = max(mx, __shfl_xor(mx, d)); ml = max(ml, __shfl_xor(ml, d)); }
-    if (lane_id() == 0) { l_mx[threadIdx.x >> 6] = mx; l_mx[4 + (threadIdx.x >> 6)] = ml; }
-}
-// solve-list problems of the block that keep more than 255 reads (k_prob_range), per size class (they need the 16-bit-counter
-// instances of k_solve: the host launches those only for classes that have any)
-__device__ __forceinline__ void prob_block_wide(Status *st, const int *cand_pn, const int *cand_ln, const unsigned char *cand_wide, i64 b, i64 n, ProbSplit sp) {
-    unsigned w = 0;                                            // one count per byte: class 0 | class 1 << 8 | class 2 << 16
-    for (int e = 0; e < 4; ++e) {
-        const i64 cc = b * kProbBlock + (i64)threadIdx.x * 4 + e;
-        if (cc < n) {
-            const int pn = cand_pn[cc], ln = pn > 0 ? cand_ln[cc] : 0;
-            if (pn > 0 && cand_wide[cc] && prob_kind(pn, ln, sp) == kKindFused) w += 1u << (8 * size_class(pn));
-        }
-    }
-    if (__ballot(w != 0) == 0) return;
-    unsigned c0 = w & 255u, c1 = (w >> 8) & 255u, c2 = (w >> 16) & 255u;
-    for (int d = 32; d >= 1; d >>= 1) { c0 += __shfl_xor(c0, d); c1 += __shfl_xor(c1, d); c2 += __shfl_xor(c2, d); }
-    if (lane_id() == 0) {
-        if (c0) atomicAdd(&st->wide_cls[0], c0);
-        if (c1) atomicAdd(&st->wide_cls[1], c1);
-        if (c2) atomicAdd(&st->wide_cls[2], c2);
-    }
-}
-__device__ __forceinline__ void prob_publish_maxima(Status *st, const int *l_mx) {
-    const int mx = max(max(l_mx[0], l_mx[1]), max(l_mx[2], l_mx[3])), ml = max(max(l_mx[4], l_mx[5]), max(l_mx[6], l_mx[7]));
-    if (mx > 0 && (unsigned)mx > __hip_atomic_load(&st->max_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&st->max_n, (unsigned)mx);
-    if (ml > 0 && (unsigned)ml > __hip_atomic_load(&st->max_ln, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&st->max_ln, (unsigned)ml);
-}
-__global__ void __launch_bounds__(256) k_prob_scan1(Status *st, const int *cand_pn, const int *cand_ln, const unsigned char *cand_wide, i64 *bs, ProbSplit sp) {
-    __shared__ i64 lds[4 * kProbCols];
-    __shared__ int l_mx[8];
-    i64 n = (i64)st->n_cand;
-    i64 nb = (n + kProbBlock - 1) / kProbBlock;
-    for (i64 b = blockIdx.x; b < nb; b += gridDim.x) {
-        ProbSizes acc = prob_block_sizes(cand_pn, cand_ln, b, n, nullptr, sp), ex, tot;
-        prob_block_maxima(st, cand_pn, cand_ln, b, n, l_mx);
-        prob_block_wide(st, cand_pn, cand_ln, cand_wide, b, n, sp);
-        wg_scan_cols(acc, ex, tot, lds);
-        if (threadIdx.x < kProbCols) bs[b * kProbCols + threadIdx.x] = tot.v[threadIdx.x];
-        if (threadIdx.x == 0) prob_publish_maxima(st, l_mx);
-        __syncthreads();
-    }
-}
-__global__ void __launch_bounds__(256) k_prob_scan2(Status *st, i64 *bs) {
-    __shared__ i64 lds[4 * kProbCols];
-    i64 n = (i64)st->n_cand;
-    i64 nb = (n + kProbBlock - 1) / kProbBlock;
-    ProbSizes carry;
-    for (int q = 0; q < kProbCols; ++q) carry.v[q] = 0;
-    for (i64 b0 = 0; b0 < nb; b0 += blockDim.x) {
-        i64 b = b0 + threadIdx.x;
-        ProbSizes v, ex, tot;
-        for (int q = 0; q < kProbCols; ++q) v.v[q] = b < nb ? bs[b * kProbCols + q] : 0;
-        wg_scan_cols(v, ex, tot, lds);
-        for (int q = 0; q < kProbCols; ++q) {
-            if (b < nb) bs[b * kProbCols + q] = carry.v[q] + ex.v[q];
-            carry.v[q] += tot.v[q];
-        }
-    }
-    if (threadIdx.x == 0) prob_store_totals(st, carry);
-}
-// bs == nullptr: every workgroup adds up the blocks before it itself (and all of them for the class bases) -- one
-// launch instead of three while the candidate list is a handful of blocks (the host picks the mode from the
-// previous run; either is correct for any size).
-constexpr int kProbDirect = 4;     // work items a problem's own thread writes itself; longer lists are written by the workgroup
-__global__ void __launch_bounds__(256) k_prob_emit(Status *st, const int *cand_pn, const int *cand_ll, const int *cand_ln,
-                                                   const int *cand_iv, const i64 *cand_off, const i64 *bs,
-                                                   ProblemArrays pr, i64 prob_cap, int2 *work_pc, int4 *cls_items,
-                                                   i64 work_cap, int *dp_items, ProbDesc *desc, const int *iv_start,
-                                                   const int *iv_part, const i64 *part_lane_off, ProbSplit sp, int *solve_items,
-                                                   ProbDesc *solve_desc, int *wide_items, int *wide_all, const unsigned char *cand_wide,
-                                                   SyncWords *sw, unsigned sync_gen) {
-    __shared__ i64 lds[4 * kProbCols];
-    __shared__ int l_slot[kProbBlock], l_cnt[kProbBlock];
-    __shared__ int l_mx[8];
-    __shared__ i64 l_w0[kProbBlock], l_c0[kProbBlock];
-    __shared__ int l_n;
-    // The solve lists are filled from BOTH ends: a class's expensive problems (many candidates) from the front, the cheap ones
-    // from the back.  A class's kernel runs one problem per workgroup, what does not fit the chip at once starts when something
-    // else ends, and a 40 us problem that starts late is the kernel's tail: with the expensive half first the dispatcher's
-    // in-order placement is a longest-first schedule (k_solve<32> 69 -> 61 us, <60> 73 -> 68, <16> 38 -> 34 on config4).  A
-    // workgroup reserves its share of each end with one atomic per end; the order inside an end is whatever the atomics make
-    // it -- problems do not depend on one another.
-    __shared__ int l_cnt2[8], l_base2[8], l_cur2[8];
-    auto list_end_of = [&](int nn, int lanes) -> int {            // 2 * list + (cheap ? 1 : 0), or -1: not in a solve list
-        const int kind = prob_kind(nn, lanes, sp);
-        if (kind == kKindTiny) return 6 + (nn >= 5 ? 0 : 1);
-        if (kind != kKindFused) return -1;
-        const int sc = size_class(nn);
-        return 2 * sc + (nn >= (sc == 0 ? 12 : (sc == 1 ? 23 : 42)) ? 0 : 1);
-    };
-    i64 n = (i64)st->n_cand;
-    i64 nb = (n + kProbBlock - 1) / kProbBlock;
-    for (i64 b = blockIdx.x; b < nb; b += gridDim.x) {
-        ProbSizes sz[4], ex, tot, before, grand;
-        if (threadIdx.x == 0) l_n = 0;
-        if (threadIdx.x < 8) { l_cnt2[threadIdx.x] = 0; l_cur2[threadIdx.x] = 0; }
-        if (bs) {
-            for (int q = 0; q < kProbCols; ++q) before.v[q] = bs[b * kProbCols + q];
-            grand.v[4] = (i64)st->cls_work[0] + ((i64)st->cls_work[1] << 32); grand.v[0] = (i64)st->dp_cls[0] << 32;
-            grand.v[5] = (i64)st->cls_work[2] + ((i64)st->dp_cls[1] << 32);
-            grand.v[7] = (i64)st->solve_cls[0] + ((i64)st->solve_cls[1] << 32);
-            grand.v[8] = (i64)st->solve_cls[2];
-        } else {
-            for (int q = 0; q < kProbCols; ++q) { before.v[q] = 0; grand.v[q] = 0; }
-            for (i64 bb = 0; bb < nb; ++bb) {
-                if (bb == b) continue;
-                ProbSizes acc = prob_block_sizes(cand_pn, cand_ln, bb, n, nullptr, sp), e2, t2;
-                wg_scan_cols(acc, e2, t2, lds);
-                for (int q = 0; q < kProbCols; ++q) { if (bb < b) before.v[q] += t2.v[q]; grand.v[q] += t2.v[q]; }
-            }
-        }
-        ProbSizes acc = prob_block_sizes(cand_pn, cand_ln, b, n, sz, sp);
-        if (!bs) prob_block_maxima(st, cand_pn, cand_ln, b, n, l_mx);   // (with block sums, k_prob_scan1 has done it; read after the barriers below)
-        if (!bs) prob_block_wide(st, cand_pn, cand_ln, cand_wide, b, n, sp);
-        wg_scan_cols(acc, ex, tot, lds);
-        if (!bs && threadIdx.x == 0) prob_publish_maxima(st, l_mx);
-        for (int q = 0; q < kProbCols; ++q) ex.v[q] += before.v[q];
-        if (!bs) {
-            for (int q = 0; q < kProbCols; ++q) grand.v[q] += tot.v[q];
-            if (b == nb - 1 && threadIdx.x == 0) prob_store_totals(st, grand);
-        }
-        const i64 i0 = b * kProbBlock + (i64)threadIdx.x * 4;
-        const i64 g_cls0 = col_lo(grand.v[4]), g_cls1 = col_hi(grand.v[4]), g_cls2 = col_lo(grand.v[5]);
-        const i64 g_dp0 = col_hi(grand.v[0]), g_dp1 = col_hi(grand.v[5]);
-        const i64 g_sol0 = col_lo(grand.v[7]), g_sol1 = col_hi(grand.v[7]), g_sol2 = col_lo(grand.v[8]);
-        // what a problem's records need, for this thread's four candidates, in three rounds of loads instead of one
-        // chain per candidate (a load under `if (problem)` is a branch with its own wait): candidate -> interval -> partition
-        int pn4[4], iv4[4], ll4[4], ln4[4], is4[4], part4[4], lanes4[4];
-        i64 co4[4];
-        for (int e = 0; e < 4; ++e) {
-            const i64 cc = i0 + e < n ? i0 + e : n - 1;
-            pn4[e] = cand_pn[cc]; iv4[e] = cand_iv[cc]; ll4[e] = cand_ll[cc]; ln4[e] = cand_ln[cc];
-        }
-        for (int e = 0; e < 4; ++e) { co4[e] = cand_off[iv4[e]]; is4[e] = iv_start[iv4[e]]; part4[e] = iv_part[iv4[e]]; }
-        for (int e = 0; e < 4; ++e) lanes4[e] = (int)(part_lane_off[part4[e] + 1] - part_lane_off[part4[e]]);
-        // this workgroup's share of the two ends of every solve list (the barriers of wg_scan_cols above have published the zeroed counters)
-        int le4[4];
-        for (int e = 0; e < 4; ++e) {
-            le4[e] = (sz[e].v[0] && i0 + e < n) ? list_end_of(pn4[e], ln4[e]) : -1;
-            if (le4[e] >= 0) atomicAdd(&l_cnt2[le4[e]], 1);
-        }
-        __syncthreads();
-        if (threadIdx.x < 8 && l_cnt2[threadIdx.x]) l_base2[threadIdx.x] = (int)atomicAdd(&st->list_cur[threadIdx.x], (unsigned)l_cnt2[threadIdx.x]);
-        __syncthreads();
-        const i64 g_tiny = bs ? (i64)st->n_tiny : col_hi(grand.v[8]);
-        for (int e = 0; e < 4; ++e) {
-            if (sz[e].v[0]) {
-                i64 c = i0 + e;
-                i64 slot = col_lo(ex.v[0]);
-                int nn = pn4[e];
-                if (slot < prob_cap) {
-                    int k = iv4[e];
-                    pr.iv[slot] = k; pr.start[slot] = (int)(c - co4[e]) - (nn - 1); pr.n[slot] = nn;
-                    pr.pair_off[slot] = ex.v[1]; pr.tri_off[slot] = ex.v[2]; pr.cov_off[slot] = ex.v[3];
-                    pr.flags[slot] = 0; pr.chain[slot] = 0;
-                    pr.lane_lo[slot] = ll4[e]; pr.lane_n[slot] = ln4[e];
-                    ProbDesc d;
-                    d.c0 = c - (nn - 1); d.pair_off = ex.v[1]; d.tri_off = ex.v[2]; d.cov_off = ex.v[3];
-                    d.n = nn; d.lane_lo = ll4[e]; d.lane_n = ln4[e]; d.g0 = is4[e];
-                    d.outside = lanes4[e] - d.lane_n;
-                    d.iv = k; d.w0 = (int)(col_lo(ex.v[4]) + col_hi(ex.v[4]) + col_lo(ex.v[5]) + col_lo(ex.v[6]));
-                    const int kind = prob_kind(nn, ln4[e], sp);
-                    const bool keeps_wide = kind == kKindFused && cand_wide[c] != 0;
-                    d.kind = keeps_wide ? kKindFusedWide : kind;
-                    desc[slot] = d;
-                    if (le4[e] >= 0) {          // solve lists: class 0, then class 1, then class 2, then k_tiny's problems
-                        const int li = le4[e] >> 1;
-                        const i64 lbase = li == 0 ? 0 : (li == 1 ? g_sol0 : (li == 2 ? g_sol0 + g_sol1 : g_sol0 + g_sol1 + g_sol2));
-                        const i64 llen = li == 0 ? g_sol0 : (li == 1 ? g_sol1 : (li == 2 ? g_sol2 : g_tiny));
-                        const i64 off = (i64)l_base2[le4[e]] + atomicAdd(&l_cur2[le4[e]], 1);
-                        const i64 si = (le4[e] & 1) ? lbase + llen - 1 - off : lbase + off;
-                        // the kernels of the solve lists read the record from the list itself (one load less in every problem's
-                        // chain of dependent loads); w0, the arena path's work item, is the problem's slot there
-                        if (si >= lbase && si < lbase + llen && si < prob_cap) {
-                            solve_items[si] = (int)slot; d.w0 = (int)slot; solve_desc[si] = d;
-                            // the problems of a solve list that keep more than kFuseLanes reads, as list positions: what the
-                            // 16-bit-counter instances are launched over (a class has a handful; as launches over the whole
-                            // list their 90 KB workgroups waited for room behind everything else: config3, one such problem
-                            // started 127 us into the stage)
-                            if (li < 3 && keeps_wide) {
-                                const i64 wp = lbase + (i64)atomicAdd(&st->wide_cur[li], 1u);
-                                if (wp < lbase + llen && wp < prob_cap) wide_items[wp] = (int)(si - lbase);
-                                // ... and of the three lists together, as positions from the first list's start: a batch with a
-                                // handful of them has one launch for them all (plan 'W')
-                                const i64 wa = (i64)atomicAdd(&st->wide_cur[3], 1u);
-                                if (wa < prob_cap) wide_all[wa] = (int)si;
-                            }
-                        }
-                    }
-                    if (kind == kKindArena) {   // DP problem lists: the small problems first, then the big ones
-                        // (then the huge ones); k_tiny's and k_solve's problems are in no DP list
-                        i64 di = nn <= kDpSmall ? col_hi(ex.v[0]) : (nn <= kNMax ? g_dp0 + col_hi(ex.v[5]) : g_dp0 + g_dp1 + col_hi(ex.v[6]));
-                        if (di < prob_cap) dp_items[di] = (int)slot;
-                    }
-                    int cls = size_class(nn);
-                    const i64 e_cls0 = col_lo(ex.v[4]), e_cls1 = col_hi(ex.v[4]), e_cls2 = col_lo(ex.v[5]), e_cls3 = col_lo(ex.v[6]);
-                    const i64 w0 = e_cls0 + e_cls1 + e_cls2 + e_cls3;   // work items before this problem
-                    i64 cbase = cls == 0 ? e_cls0 : (cls == 1 ? g_cls0 + e_cls1 : (cls == 2 ? g_cls0 + g_cls1 + e_cls2
-                                                                                    : g_cls0 + g_cls1 + g_cls2 + e_cls3));
-                    const i64 cnt = col_lo(sz[e].v[4]) + col_hi(sz[e].v[4]) + col_lo(sz[e].v[5]) + col_lo(sz[e].v[6]);
-                    if (w0 + cnt > work_cap || cbase + cnt > work_cap) atomicOr(&st->err, kErrOverflowWork);
-                    else if (cnt <= kProbDirect) {
-                        for (i64 q = 0; q < cnt; ++q) {
-                            work_pc[w0 + q] = make_int2((int)slot, (int)q);
-                            cls_items[cbase + q] = make_int4((int)(w0 + q), (int)slot, (int)q, 0);
-                        }
-                    } else {
-                        int li = atomicAdd(&l_n, 1);
-                        l_slot[li] = (int)slot; l_cnt[li] = (int)cnt; l_w0[li] = w0; l_c0[li] = cbase;
-                    }
-                } else atomicOr(&st->err, kErrOverflowProblems);
-            }
-            for (int q = 0; q < kProbCols; ++q) ex.v[q] += sz[e].v[q];
-        }
-        __syncthreads();
-        const int ln = l_n;
-        for (int li = threadIdx.x >> 6; li < ln; li += 4) {        // one wave per long list
-            const int slot = l_slot[li], cnt = l_cnt[li];
-            const i64 w0 = l_w0[li], c0 = l_c0[li];
-            for (int q = lane_id(); q < cnt; q += 64) {
-                work_pc[w0 + q] = make_int2(slot, q);
-                cls_items[c0 + q] = make_int4((int)(w0 + q), slot, q, 0);
-            }
-        }
-        __syncthreads();
-    }
-    emit_done(sw, sync_gen);
-}
-
-// pair index q = j*(j-1)/2 + i (i < j);  triple rank = k*(k-1)*(k-2)/6 + j*(j-1)/2 + i (i < j < k)
-__device__ __forceinline__ void pair_decode(int q, int *i, int *j) {
-    int jj = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)q)) * 0.5f);
-    while (jj * (jj - 1) / 2 > q) --jj;
-    while ((jj + 1) * jj / 2 <= q) ++jj;
-    *j = jj;
-    *i = q - jj * (jj - 1) / 2;
-}
-
-// S5a  integer label thresholds of every candidate pair of every problem (:490-495)
-__device__ __forceinline__ void pair_thresholds_blocks(i64 first, i64 stride, const Status *st, ProblemArrays pr, const ProbDesc *desc,
-                                                       i64 prob_cap, const int *cand_y, const double *h_table, int h_len, double tau,
-                                                       int2 *pair_thr, i64 pair_cap, unsigned *amb_g, unsigned *out_g, i64 tri_cap) {
-    i64 n_prob = (i64)st->n_prob < prob_cap ? (i64)st->n_prob : prob_cap;
-    for (i64 p = first; p < n_prob; p += stride) {
-        const ProbDesc d = load_desc(desc + p);
-        int n = d.n;
-        if (d.kind != kKindArena) continue;                 // solved whole by k_tiny / k_solve: owns nothing in the arenas
-        i64 poff = d.pair_off;
-        int npairs = n * (n - 1) / 2;
-        if (poff + npairs > pair_cap) continue;
-        const int *cy = cand_y + d.c0;
-        int any_neg = 0;
-        for (int q = threadIdx.x; q < npairs; q += blockDim.x) {
-            int i, j;
-            pair_decode(q, &i, &j);
-            i64 L = (i64)cy[j] - cy[i] + 1;
-            int hi, lo;
-            label_thresholds(L, h_table, h_len, tau, &hi, &lo);
-            pair_thr[poff + q] = make_int2(hi, lo);
-            amb_g[poff + q] = 0;
-            if (lo < 0) any_neg = 1;
-        }
-        i64 toff = d.tri_off;
-        int ntri = n * (n - 1) * (n - 2) / 6;
-        if (toff + ntri <= tri_cap) for (int x = threadIdx.x; x < ntri; x += blockDim.x) out_g[toff + x] = 0;
-        if (any_neg) atomicOr(&pr.flags[p], 1);
-    }
-}
-__global__ void __launch_bounds__(256) k_pair_thresholds(const Status *st, ProblemArrays pr, const ProbDesc *desc, i64 prob_cap,
-                                                         const i64 *cand_off, const int *cand_y, const double *h_table,
-                                                         int h_len, double tau, int2 *pair_thr, i64 pair_cap,
-                                                         unsigned *amb_g, unsigned *out_g, i64 tri_cap) {
-    pair_thresholds_blocks(blockIdx.x, gridDim.x, st, pr, desc, prob_cap, cand_y, h_table, h_len, tau, pair_thr, pair_cap, amb_g, out_g,
-                           tri_cap);
-}
-
-
-// ---------------------------------------------------------------------------------------------
-// S5b  window coverage of every (problem, read)      get_cumulative_coverage (:188-246)
-// cov[j] = #positions of the read's closed exons in [cand_0, cand_j) = C[start+j] - C[start].
-// One thread per read of the problem's read range; the read's (ordered) exon list is merged
-// against the problem's n candidates.  Layout of a work item's block: [j][kLaneChunk reads], so
-// both this kernel's stores and the scoring kernel's loads are coalesced.  Also records, per work
-// item, which 64-read sub-chunks contain a read with any coverage in the window.
-// ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kLaneChunk) k_cov(Status *st, const ProbDesc *desc, i64 prob_cap, const int2 *work_pc,
-                                                    i64 work_cap, const i64 *cand_off,
-                                                    const int *cand_y, const int *iv_start, const int2 *__restrict__ lane_lx,
-                                                    const int2 *__restrict__ lex,
-                                                    unsigned *cov_g, i64 cov_cap, unsigned char *work_active,
-                                                    int cov_blocks, ProblemArrays pr, const double *h_table, int h_len, double tau,
-                                                    int2 *pair_thr, i64 pair_cap, unsigned *amb_g, unsigned *out_g, i64 tri_cap) {
-    // One-partition batches are chains of launch-latency-sized kernels: there the pair thresholds (which, like the
-    // coverage, need only the problem list) ride along as the workgroups behind the coverage ones -- one graph node less,
-    // and the two overlap (cov_blocks == gridDim.x: no such workgroups, k_pair_thresholds was launched on its own).
-    if ((int)blockIdx.x >= cov_blocks) {
-        pair_thresholds_blocks(blockIdx.x - cov_blocks, gridDim.x - cov_blocks, st, pr, desc, prob_cap, cand_y, h_table, h_len, tau,
-                               pair_thr, pair_cap, amb_g, out_g, tri_cap);
-        return;
-    }
-    __shared__ int cp[kNGiant + 4];
-    __shared__ u64 work_s;
-    __shared__ unsigned active_s;
-    i64 n_work = (i64)st->n_work;
-    if (n_work > work_cap || (i64)st->n_prob > prob_cap) return;   // lists incomplete: this run only sizes the arenas
-    for (i64 w = blockIdx.x; w < n_work; w += cov_blocks) {     // static stride: a shared work counter saturates near 90 pops/us
-        __syncthreads();
-        if (threadIdx.x == 0) active_s = 0;
-        __syncthreads();
-        const int2 pc = work_pc[w];
-        const int chunk = pc.y;
-        const ProbDesc d = load_desc(desc + pc.x);
-        const int n = d.n;
-        i64 coff = d.cov_off + (i64)chunk * kLaneChunk * n;
-        if (n > kNGiant || coff + (i64)kLaneChunk * n > cov_cap) { if (threadIdx.x == 0) work_active[w] = 0; continue; }
-        const int *cy = cand_y + d.c0;
-        const int g0 = d.g0;
-        int t = threadIdx.x;
-        int li = chunk * kLaneChunk + t;
-        // the read's exon range needs only the descriptor: in flight together with the candidate positions
-        const int2 ex = lane_lx[d.lane_lo + (li < d.lane_n ? li : 0)];      // (its piece of the lane-ordered (ts, te) stream)
-        for (int j = threadIdx.x; j < n; j += blockDim.x) cp[j] = g0 + cy[j];
-        __syncthreads();
-        const int cp0 = cp[0];
-        unsigned *dst = cov_g + coff + t;
-        unsigned last = 0;
-        if (li < d.lane_n) {
-            i64 e = ex.x, e1 = ex.y;
-            {   // first exon whose closed interval reaches cand_0 (exons of a read are ordered, :158)
-                i64 lo = e, hi = e1;
-                while (lo < hi) { i64 mid = (lo + hi) >> 1; if (lex[mid].y < cp0) lo = mid + 1; else hi = mid; }
-                e = lo;
-            }
-            unsigned acc = 0;
-            int ts = 0, te = -1;
-            if (e < e1) { const int2 x = lex[e]; ts = x.x; te = x.y; }
-            dst[0] = 0;
-            for (int j = 1; j < n; ++j) {
-                int cj = cp[j];
-                while (e < e1 && te < cj) {
-                    acc += (unsigned)(te + 1 - (ts > cp0 ? ts : cp0));
-                    ++e;
-                    if (e < e1) { const int2 x = lex[e]; ts = x.x; te = x.y; }
-                }
-                unsigned part_cov = 0;
-                if (e < e1 && ts < cj) part_cov = (unsigned)(cj - (ts > cp0 ? ts : cp0));
-                last = acc + part_cov;
-                dst[(i64)j * kLaneChunk] = last;
-            }
-        } else {
-            for (int j = 0; j < n; ++j) dst[(i64)j * kLaneChunk] = 0;
-        }
-        u64 any = __ballot(last > 0);
-        if (lane_id() == 0 && any) atomicOr(&active_s, 1u << (threadIdx.x >> 6));
-        __syncthreads();
-        if (threadIdx.x == 0) work_active[w] = (unsigned char)active_s;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// S5  interval scoring   (optimize(): pair labels :488-497, inside :500-506, outside :509-528)
-//
-// Work item = (problem, chunk of <= kLaneChunk reads of the problem's read range).  For 64 reads at a
-// time the workgroup
-//   A. stages the coverage prefixes cov[r][j] of the 64 reads in LDS;
-//   B. evaluates every pair (i,j): yea = cov_j-cov_i >= hi_ij, nay = cov_j-cov_i <= lo_ij, shifting the
-//      64 results into two 32-bit plane words per label, kept in LDS as {yea0,yea1,nay0,nay1};
-//      ambiguous reads (neither) are counted per pair for inside(i,j) = -sum(W*amb);
-//   C. for every triple i<j<k that the DP can use adds
-//      popc(yea_ij & nay_jk) + popc(nay_ij & yea_jk)  (the two conjunctions are disjoint, :515-523)
-//      into a u16 counter table in LDS.
-// At the end of the work item the non-zero counters go to the global table with one atomic each.
-// Reads with multiplicity W are expanded into W lanes on upload, so every lane has weight 1.
-// ---------------------------------------------------------------------------------------------
-// ---------------------------------------------------------------------------------------------
-// S5c  DP over one problem   (dp() :532-558, top level :560-566, backtrack :592-594)
-// D(a,b,c) = in_ab + out_abc + M(b,c),  M(b,c) = max_{c2>c} D(b,c,c2) (first maximiser, strict >),
-// M(b,end) := in_b,end closes the chain (base case :545-548).  The inner maximum depends only on (b,c), so
-// filling M for c descending is O(n^3) and gives the reference's O(n^4) recursion's result
-// (SURVEY.md App. A.7).  All tables live in LDS:
-//   out_s[rank(a,b,c)] counts, in_s[pair] = -(ambiguous reads), M / A (argmax) per pair, cy_s = candidate y.
-// Every thread of the workgroup must call it; returns the number of backtracked triples (valid on thread 0)
-// and marks the chosen candidates.
-// ---------------------------------------------------------------------------------------------
-#ifdef FSEG_SCORE_TIMING
-#define FSEG_DTICK(i) do { unsigned long long t_now = wall_clock64(); if (threadIdx.x == 0) atomicAdd(&dp_tacc[i], t_now - dt_prev); dt_prev = t_now; } while (0)
-#define FSEG_DPARAM , unsigned long long *dp_tacc, unsigned long long &dt_prev
-#define FSEG_DARG , dp_tacc, dt_prev
-#else
-#define FSEG_DTICK(i)
-#define FSEG_DPARAM
-#define FSEG_DARG
-#endif
-// T == 64: the caller is ONE WAVE working on its own problem with wave-private tables (other waves of the workgroup
-// may be inside their own dp_solve_push<64>), so synchronisation is wave-level and thread indices are lane indices.
-// Either way only LDS traffic is ordered (the tables are in LDS): global loads issued before it -- the next phase's
-// prefetches -- stay in flight, which a full fence would wait for.
-template <int T>
-__device__ __forceinline__ void dp_sync() {
-    if (T == 64) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
-    } else {
-        lds_barrier();
-    }
-}
-// V: the type the sums are kept in.  i64 in general; int where the caller knows that n * (reads of the partition) stays
-// below 2^30 (k_solve's launches: every sum is a chain of at most n/2 counts and ambiguity terms, each bounded by the
-// partition's reads) -- half the registers, LDS traffic and instructions of the chain.
-template <typename V> __device__ __forceinline__ constexpr V dp_neg_inf() { return sizeof(V) == 8 ? (V)kNegInf : (V)(-0x40000000); }
-// Pushed, not pulled: every thread OWNS pairs (b,c) -- pair q = s*T + tid, the ownership the scoring phase already uses --
-// and keeps their running maximum in registers:
-//   column c2 final  ->  its owners write M(.,c2)  ->  one barrier  ->  every pair (b,c) with c < c2 takes
-//   out(b,c,c2) + M(c,c2) into its maximum.
-// One barrier per candidate, no reduction over waves, no serial part, and the work of a step is spread over all the
-// threads (out(.,.,c2) is one contiguous run of the count table: lane-consecutive bytes).  Pushes arrive with c2
-// descending, so "first maximiser" (the smallest c2 among equals) is "the later push wins ties".  The row b = 0 is the top
-// level (:560-566): M(0,j) = in(0,j) + max_k(out(0,j,k) + M(j,k)), then the first maximiser over j, taken only if it beats
-// "no cut" = in(0,end).  (A gather formulation -- lanes = b, a loop over c2 per lane, blocks of four candidates with a serial
-// in-block fix-up -- took 36 us for n = 49 against 22 us; tools/probes/dp_probe.hip.)
-// A running maximum and its argument are ONE integer, the key  value * 64 + (63 - c2):  the larger value wins, among equal
-// values the smaller c2 (the reference's first maximiser, :526-527), and the update of a pair is one v_max.  A pair's final
-// M(b,c) is stored in the same form with (63 - c) in the low bits -- the tie-break it needs when it is the tail of a push
-// from column c, and at the top level (first maximiser over j) -- or kKeyNone.  With 32-bit keys every |value| must stay
-// below 2^24: k_solve / k_wave take them when the largest partition has fewer than kKey32Reads = 2^18 reads (a chain has at most
-// NM - 1 <= 63 links of at most that many reads each: 63 * 2^18 < 2^24, checked at compile time), the 64-bit instances otherwise.
-// f(integral_constant<int, B>) ... f(integral_constant<int, E - 1>): a loop whose index is a compile-time constant in the body
-template <int B, int E, typename F> __device__ __forceinline__ void static_for(F &&f) {
-    if constexpr (B < E) { f(std::integral_constant<int, B>{}); static_for<B + 1, E>(f); }
-}
-// f(integral_constant<int, I>) ... f(integral_constant<int, 0>)
-template <int I, typename F> __device__ __forceinline__ void static_for_down(F &&f) {
-    f(std::integral_constant<int, I>{});
-    if constexpr (I > 0) static_for_down<I - 1>(f);
-}
-template <typename V> __device__ __forceinline__ constexpr V dp_key_none() { return sizeof(V) == 8 ? (V)(-(1LL << 62)) : (V)(-0x7ff00000); }
-template <typename V> __device__ __forceinline__ constexpr V dp_key_min() { return sizeof(V) == 8 ? (V)(-(1LL << 61)) : (V)(-0x40000000); }   // every key of a value is above it
-// The push of column c2 into the first NS slots of a thread: all the slots' LDS loads first (none of them under a branch),
-// one wait, then four instructions per pair.  Only the last of a wave's live slots can hold pairs at or beyond the column
-// (q >= t2): it is the one that is masked.
-template <int NS, int T, int SLOTS, typename OutT, typename V>
-__device__ __forceinline__ void dp_push_slots(int tid, int t2, int t3, int support, const V *M, const OutT *out_s,
-                                              const int (&pc)[SLOTS], V (&best)[SLOTS]) {
-    constexpr V kNone = dp_key_none<V>();
-    V tail[NS];
-    unsigned o[NS];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        const int q = s * T + tid;
-        const bool act = s < NS - 1 || q < t2;
-        tail[s] = M[t2 + (act ? pc[s] : 0)];
-        o[s] = (unsigned)out_s[t3 + (act ? q : 0)];
-    }
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        const int q = s * T + tid;
-        const bool act = s < NS - 1 || q < t2;
-        const V key = (V)o[s] * 64 + tail[s];                        // (a tail of kKeyNone stays below every key of a value)
-        const bool ok = act & ((int)o[s] >= support);                // :540
-        const V k2 = ok ? key : kNone;
-        best[s] = k2 > best[s] ? k2 : best[s];
-    }
-}
-// ... for the `ns` (wave-uniform) slots of this wave that still hold pairs below the column
-template <int NS, int T, int SLOTS, typename OutT, typename V>
-__device__ __forceinline__ void dp_push_dispatch(int ns, int tid, int t2, int t3, int support, const V *M, const OutT *out_s,
-                                                 const int (&pc)[SLOTS], V (&best)[SLOTS]) {
-    if (ns >= NS) dp_push_slots<NS, T, SLOTS>(tid, t2, t3, support, M, out_s, pc, best);
-    else if constexpr (NS > 1) dp_push_dispatch<NS - 1, T, SLOTS>(ns, tid, t2, t3, support, M, out_s, pc, best);
-}
-// Pushed, not pulled: every thread OWNS pairs (b,c) -- pair q = s*T + tid, the ownership the scoring phase already uses --
-// and keeps their running maximum in registers:
-//   column c2 final  ->  its owners write M(.,c2)  ->  one barrier  ->  every pair (b,c) with c < c2 takes
-//   out(b,c,c2) + M(c,c2) into its maximum.
-// One barrier per candidate, no reduction over waves, no serial part, and the work of a step is spread over all the
-// threads (out(.,.,c2) is one contiguous run of the count table: lane-consecutive bytes).  The row b = 0 is the top
-// level (:560-566): M(0,j) = in(0,j) + max_k(out(0,j,k) + M(j,k)), then the first maximiser over j, taken only if it beats
-// "no cut" = in(0,end).  A step is a chain -- owners' write, barrier, loads, update -- and the problem's DP is n of them in
-// a row, so what counts is the number of dependent instructions in a step (tools/probes/dp_probe.hip: n = 49 took 19 us with
-// value and argument kept apart and compare / select through the scalar unit; the bare write-barrier-read is 73 ns).
-// (A gather formulation -- lanes = b, a loop over c2 per lane, blocks of four candidates with a serial in-block fix-up --
-// took 36 us for n = 49.)
-template <int T, int NM, typename OutT, typename V>
-__device__ __forceinline__ int dp_solve_push(int n, const OutT *out_s, const int *in_s, V *M, unsigned char *A, const int *cy_s, int support,
-                                             unsigned char *chosen /* + first candidate of the problem */ FSEG_DPARAM) {
-    constexpr int SLOTS = (NM * (NM - 1) / 2 + T - 1) / T;
-    constexpr int LOG2T = T == 64 ? 6 : (T == 128 ? 7 : (T == 256 ? 8 : (T == 512 ? 9 : 10)));
-    static_assert((1 << LOG2T) == T, "T is a power of two from 64 to 1024");
-    static_assert(NM <= 64, "the top level is one lane per candidate; an argument is six bits of a key");
-    // 32-bit keys: value * 64 + argument with |value| < 2^24 -- a chain has at most NM - 1 links of at most kKey32Reads reads each
-    static_assert(sizeof(V) == 8 || (i64)(NM - 1) * kKey32Reads < (1LL << 24), "32-bit DP keys: the longest chain's sum must stay below 2^24");
-    const int lane = lane_id(), wave = T == 64 ? 0 : wave_id();
-    const int tid = T == 64 ? lane : (int)threadIdx.x;
-    n = uni(n); support = uni(support);
-    const int end = n - 1;
-    const int npairs = n * (n - 1) / 2;
-    constexpr V kNone = dp_key_none<V>(), kMin = dp_key_min<V>();
-    int pc[SLOTS];
-    V best[SLOTS], inv[SLOTS];
-    bool live[SLOTS];
-#pragma unroll
-    for (int s = 0; s < SLOTS; ++s) {
-        const int q = s * T + tid;
-        int b, c;
-        pair_decode(q < npairs ? q : 0, &b, &c);
-        pc[s] = c;
-        live[s] = q < npairs && cy_s[c] - cy_s[b] >= 5;            // "segment too small" (:540)
-        inv[s] = (V)in_s[q < npairs ? q : 0];
-        best[s] = (q < npairs && c == end) ? (V)0 : kNone;         // M(b,end) = in(b,end): the chain's last link (:545-548)
-    }
-    int t2 = end * (end - 1) / 2, t3 = end * (end - 1) * (end - 2) / 6;
-    for (int c2 = end; c2 >= 1; --c2) {
-        // column c2 is final: its pairs are q in [t2, t2 + c2), at most one of them this thread's
-        {
-            const int d0 = (tid - t2) & (T - 1);
-            if (d0 < c2) {
-                const int q0 = t2 + d0;
-                auto finish = [&](auto sc) {
-                    constexpr int s = decltype(sc)::value;
-                    const V bb = best[s];
-                    const bool ok = live[s] && bb > kMin;
-                    const V val = (bb >> 6) + inv[s];
-                    M[q0] = ok ? (V)(val * 64 + (V)(63 - c2)) : kNone;
-                    A[q0] = ok ? (unsigned char)(63 - (int)(bb & 63)) : (unsigned char)255;
-                };
-                if constexpr (SLOTS == 1) finish(std::integral_constant<int, 0>{});
-                else if constexpr (T == 64) {                        // (a wave's owners may sit in two slots)
-                    static_for<0, SLOTS>([&](auto sc) { if ((q0 >> LOG2T) == decltype(sc)::value) finish(sc); });
-                } else {                                             // the owners of a wave share the slot
-                    const int so = uni(q0 >> LOG2T);
-                    static_for<0, SLOTS>([&](auto sc) { if (so == decltype(sc)::value) finish(sc); });
-                }
-            }
-        }
-        dp_sync<T>();
-        if (c2 == 1) break;
-        // pairs (b, c) with c < c2: q < t2, a prefix of the pair order -- the slots of this wave that reach below t2 come first
-        const int wave_q0 = T == 64 ? 0 : wave * 64;
-        const int ns = t2 > wave_q0 ? uni((t2 - wave_q0 + T - 1) >> LOG2T) : 0;
-        dp_push_dispatch<SLOTS, T, SLOTS>(ns < SLOTS ? ns : SLOTS, tid, t2, t3, support, M, out_s, pc, best);
-        t2 -= c2 - 1; t3 -= t2;
-    }
-    FSEG_DTICK(10);
-    int chain = 0;
-    if (wave == 0) {
-        // first maximiser over j of M(0,j) (larger value, then smaller j): the largest key, one candidate per lane
-        const int j0 = lane >= 1 && lane < end ? lane : 1;
-        V kv = (lane >= 1 && lane < end) ? M[j0 * (j0 - 1) / 2] : kNone;
-        for (int d = 32; d >= 1; d >>= 1) {
-            const V ov = __shfl_xor(kv, d);
-            kv = ov > kv ? ov : kv;
-        }
-        FSEG_DTICK(11);
-        // the chain is walked by one lane (dependent LDS loads only: the chosen candidates are collected in a mask) and
-        // stored by the wave, one candidate per lane
-        // (every lane holds the same key after the reduction: the walk is the whole wave's, on scalar registers -- a link is one
-        // LDS byte and a few scalar instructions; walked by lane 0 alone under an execution mask it was 113 ns per link)
-        u64 mask = 0;
-        const bool cut = end >= 2 && kv > kMin && (kv >> 6) > (V)in_s[end * (end - 1) / 2];
-        if (uni(cut ? 1 : 0)) {
-            const int bj = uni(63 - (int)(kv & 63));
-            int j = bj, k = uni((int)A[bj * (bj - 1) / 2]);
-            mask = 1ULL;
-            for (;;) {
-                mask |= (1ULL << j) | (1ULL << k); ++chain;
-                if (k == end) break;
-                const int k2 = uni((int)A[k * (k - 1) / 2 + j]);
-                if (k2 == 255) break;
-                j = k; k = k2;
-            }
-        }
-        if ((mask >> lane) & 1ULL) chosen[lane] = 1;
-    }
-    FSEG_DTICK(12);
-    return chain;
-}
-
-// ---------------------------------------------------------------------------------------------
-// The same DP by ONE WAVE (k_solve's tail, round 4).  A column of the push DP is a chain -- the owners' write, the
-// loads of the others, a handful of arithmetic -- and with T threads every wave pays the chain's ~50 instructions
-// for a pair or two each, plus a workgroup barrier per column, while seven of the large class's eight waves hold
-// their registers for nothing (the DP was 42-45 % of a problem's time).  One wave holds every pair (slot s = pair
-// s * 64 + lane), needs no barrier (a wave's LDS operations complete in order) and lets the workgroup's other waves
-// END when the scoring rounds are over: their registers and wave slots go to the next workgroup while this one
-// finishes on a sixteenth of what it held.
-//   * The columns are visited in STAGES: stage S = the columns whose first pair lies in slot S (t2 >> 6 == S), S
-//     descending.  Inside a stage the slots that finish (S and S + 1) and the slots that take the push (0 .. S) are
-//     compile-time constants: no dispatch, no register indexing, and a column costs its own pairs only.
-//   * A pair is two registers, its running key and c; the scoring owners of the pairs leave c in A[q] and in(b,c) in
-//     in_s[q] -- kDeadPair where the segment is too small (:540) -- so nothing is decoded here, and in() is read when the
-//     pair's column is finished (asked for a column ahead).
-//   * A[q] becomes the chain's link: the argument, or kLinkNone at the chain's end (c == end).  The walk is one LDS byte
-//     and three integer instructions per link, kept on the vector unit (values the same in every lane); the visited
-//     candidates are collected one per lane and stored by the wave.
-// 32-bit keys only when NM > 32 (64-bit keys would need 112 registers for the large class): k_solve keeps dp_solve_push for
-// that instance.
-// ---------------------------------------------------------------------------------------------
-constexpr int kDeadPair = (int)0x80000000;
-constexpr unsigned char kLinkNone = 255;
-template <int NM, typename OutT, typename V>
-__device__ __forceinline__ int dp_solve_wave_check() {
-    static_assert(sizeof(V) == 8 || (i64)(NM - 1) * kKey32Reads < (1LL << 24), "32-bit DP keys: the longest chain's sum must stay below 2^24");
-    return 0;
-}
-template <int NM, typename OutT, typename V>
-__device__ __forceinline__ int dp_solve_wave(int n, const OutT *out_s, const int *in_s, V *M, unsigned char *A, int support,
-                                             unsigned char *chosen /* + first candidate of the problem */ FSEG_DPARAM) {
-    constexpr int SLOTS = (NM * (NM - 1) / 2 + 63) / 64;
-    static_assert(NM <= 64, "a candidate per lane at the top level; an argument is six bits of a key");
-    (void)dp_solve_wave_check<NM, OutT, V>();
-    const int lane = lane_id();
-    n = uni(n); support = uni(support);
-    const int end = n - 1, npairs = n * (n - 1) / 2;
-    constexpr V kNone = dp_key_none<V>(), kMin = dp_key_min<V>();
-    int pc[SLOTS];                                  // c of pair (b,c)
-    V best[SLOTS];
-#pragma unroll
-    for (int s = 0; s < SLOTS; ++s) {
-        const int q = s * 64 + lane;
-        pc[s] = (int)A[q < npairs ? q : 0];
-        best[s] = (q < npairs && pc[s] == end) ? (V)0 : kNone;       // M(b,end) = in(b,end): the chain's last link (:545-548)
-    }
-    int c2 = end, t2 = end * (end - 1) / 2, t3 = end * (end - 1) * (end - 2) / 6;
-    // the pair this lane finishes in column c2 is q = t2 + ((lane - t2) & 63) if that offset is below c2; its in() is asked for
-    // a column ahead (beside the push's loads), so that a column's chain holds no load of its own before the owners' write
-    int in_nx = in_s[t2 + (((lane - t2) & 63) < c2 ? ((lane - t2) & 63) : 0)];
-    auto stage = [&](auto Sc) {
-        constexpr int S = decltype(Sc)::value;
-        while (c2 >= 1 && (t2 >> 6) == S) {                         // (wave-uniform)
-            const int d0 = (lane - t2) & 63, q0 = t2 + d0;
-            if (d0 < c2) {
-                V bb = best[S];
-                if constexpr (S + 1 < SLOTS) bb = (q0 >> 6) == S ? bb : best[S + 1];
-                const bool ok = in_nx != kDeadPair && bb > kMin;
-                const V val = (bb >> 6) + (V)(ok ? in_nx : 0);
-                M[q0] = ok ? (V)(val * 64 + (V)(63 - c2)) : kNone;
-                A[q0] = (ok && c2 != end) ? (unsigned char)(63 - (int)(bb & 63)) : kLinkNone;
-            }
-            dp_sync<64>();
-            if (c2 == 1) { c2 = 0; break; }
-            const int t2n = t2 - (c2 - 1), d1 = (lane - t2n) & 63;
-            in_nx = in_s[t2n + (d1 < c2 - 1 ? d1 : 0)];
-            // pairs (b, c) with c < c2: q < t2 -- slots 0 .. S, the last one partly
-            // (the loads of up to kBatch slots are in flight together: more would cost the registers the pairs live in)
-            constexpr int kBatch = 8;
-            static_for<0, (S + kBatch) / kBatch>([&](auto gc) {
-                constexpr int s0 = decltype(gc)::value * kBatch, s1 = s0 + kBatch <= S + 1 ? s0 + kBatch : S + 1;
-                V tail[s1 - s0];
-                unsigned o[s1 - s0];
-#pragma unroll
-                for (int s = s0; s < s1; ++s) {
-                    const int q = s * 64 + lane;
-                    const bool act = s < S || q < t2;
-                    tail[s - s0] = M[t2 + (act ? pc[s] : 0)];
-                    o[s - s0] = (unsigned)out_s[t3 + (act ? q : 0)];
-                }
-#pragma unroll
-                for (int s = s0; s < s1; ++s) {
-                    const int q = s * 64 + lane;
-                    const bool act = s < S || q < t2;
-                    const V key = (V)o[s - s0] * 64 + tail[s - s0];          // (a tail of kKeyNone stays below every key of a value)
-                    const bool ok = act & ((int)o[s - s0] >= support);       // :540
-                    const V k2 = ok ? key : kNone;
-                    best[s] = k2 > best[s] ? k2 : best[s];
-                }
-            });
-            t2 = t2n; --c2; t3 -= t2;
-        }
-    };
-    static_for_down<SLOTS - 1>(stage);
-    FSEG_DTICK(10);
-    // first maximiser over j of M(0,j) (larger value, then smaller j): the largest key, one candidate per lane
-    const int j0 = lane >= 1 && lane < end ? lane : 1;
-    V kv = (lane >= 1 && lane < end) ? M[j0 * (j0 - 1) / 2] : kNone;
-    for (int d = 32; d >= 1; d >>= 1) {
-        const V ov = __shfl_xor(kv, d);
-        kv = ov > kv ? ov : kv;
-    }
-    FSEG_DTICK(11);
-    int chain = 0;
-    const bool cut = end >= 2 && kv > kMin && (kv >> 6) > (V)in_s[end * (end - 1) / 2];
-    if (uni(cut ? 1 : 0)) {
-        const int bj = 63 - (int)(kv & 63);
-        int q = bj * (bj - 1) / 2, k = bj, rec = 0;                  // the state (j, k) is reached through pair q = (j, k)'s predecessor
-#pragma nounroll
-        for (; chain < 62; ++chain) {
-            const int e = (int)A[q];
-            if (e == (int)kLinkNone) break;
-            rec = lane == chain ? e : rec;
-            q = e * (e - 1) / 2 + k;                                 // pair (k, e): the next state
-            k = e;
-        }
-        if (lane == 62) rec = 0;
-        if (lane == 63) rec = bj;
-        if (lane < chain || lane >= 62) chosen[rec] = 1;
-    }
-    FSEG_DTICK(12);
-    return chain;
-}
-
-// pair q = j*(j-1)/2 + i  <->  (i, j); independent of the problem size, built once per context
-__device__ unsigned short g_pair_ij[kNMax * (kNMax - 1) / 2];
-__global__ void k_init_pair_table() {
-    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < kNMax * (kNMax - 1) / 2; q += gridDim.x * blockDim.x) {
-        int i, j;
-        pair_decode(q, &i, &j);
-        g_pair_ij[q] = (unsigned short)(i | (j << 8));
-    }
-}
-
-
-template <int NM> struct ScoreCfg {
-    static constexpr int kPairs = NM * (NM - 1) / 2;
-    static constexpr int kTri = NM * (NM - 1) * (NM - 2) / 6;
-    static constexpr int kThreads = NM <= 16 ? 128 : (NM <= 32 ? 256 : 512);
-    static constexpr int kSlots = (kPairs + kThreads - 1) / kThreads;
-    static constexpr int kCovStride = NM + 1;      // odd: read-major rows do not collide on LDS banks
-    static constexpr int kStage = (NM * kSub + kThreads - 1) / kThreads;   // coverage words per thread and tile
-    static constexpr size_t kLds = (size_t)kPairs * 16 + (size_t)kSub * kCovStride * 4 + (size_t)((kPairs + 7) & ~7) * 2 +
-                                   (size_t)((kTri + 7) & ~7) * 2;
-};
-inline size_t score_lds_for(int nm, int cov_stride) {
-    size_t pairs = (size_t)nm * (nm - 1) / 2, tri = (size_t)nm * (nm - 1) * (nm - 2) / 6;
-    return ((pairs * 16 + (size_t)kSub * cov_stride * 4 + ((pairs + 7) & ~(size_t)7) * 2 + ((tri + 7) & ~(size_t)7) * 2) + 15) & ~(size_t)15;
-}
-
-#ifdef FSEG_SCORE_TIMING
-#define FSEG_TPARAM , unsigned long long *tacc
-// diagnostic build: per-problem records behind the 16 phase slots -- (ticks, reads examined, reads with coverage, start tick)
-#define FSEG_PROB_TICK(P, T0, LN, NA) do { if ((P) < kTaccProbs) { unsigned long long *r_ = tacc + 16 + 4 * (size_t)(P); \
-        r_[0] = wall_clock64() - (T0); r_[1] = (unsigned long long)(LN); r_[2] = (unsigned long long)(NA); r_[3] = (T0); } } while (0)
-#define FSEG_T0 unsigned long long t_prev = wall_clock64()
-#define FSEG_TICK(i) do { unsigned long long t_now = wall_clock64(); if (threadIdx.x == 0) atomicAdd(&tacc[i], t_now - t_prev); t_prev = t_now; } while (0)
-#else
-#define FSEG_TPARAM
-#define FSEG_T0
-#define FSEG_TICK(i)
-#endif
-template <int NM>
-__global__ void __launch_bounds__(ScoreCfg<NM>::kThreads) k_score(Status *st, int cls, int nm, ProblemArrays pr, i64 prob_cap,
-                                                                  const int4 *cls_items, const ProbDesc *desc,
-                                                                  i64 work_cap, const i64 *cand_off,
-                                                                  const int *cand_y, const unsigned char *work_active,
-                                                                  const unsigned *cov_g, i64 cov_cap, const int2 *pair_thr,
-                                                                  i64 pair_cap, unsigned *out_g, i64 tri_cap,
-                                                                  unsigned *amb_g FSEG_TPARAM) {
-    using C = ScoreCfg<NM>;
-    constexpr int T = C::kThreads;
-    extern __shared__ __align__(16) unsigned char smem[];
-    __shared__ int cy_s[NM + 4];
-    __shared__ int iend_s[NM + 4];
-    __shared__ u64 work_s;
-    // LDS carve-up for problems of at most nm candidates (nm <= NM is chosen by the host from the previous run's
-    // largest problem, so that a batch of moderately sized problems gets more workgroups per CU)
-    const int rt_pairs = nm * (nm - 1) / 2;
-    constexpr int rt_stride = C::kCovStride;      // compile-time row stride: LDS addresses fold into instruction offsets
-    uint4 *planes = reinterpret_cast<uint4 *>(smem);                                         // rt_pairs * 16 B
-    unsigned *cov = reinterpret_cast<unsigned *>(smem + (size_t)rt_pairs * 16);              // kSub * rt_stride * 4 B
-    unsigned short *pair_ij = reinterpret_cast<unsigned short *>(cov + kSub * rt_stride);    // rt_pairs * 2 B
-    unsigned short *out16 = pair_ij + ((rt_pairs + 7) & ~7);                                 // C(nm,3) * 2 B
-    for (int q = threadIdx.x; q < rt_pairs; q += T) pair_ij[q] = g_pair_ij[q];
-    // cls < 0: this launch takes the work items of every size class (small batches: one launch instead of three)
-    i64 cls_base = cls < 0 ? 0 : (cls >= 1 ? (i64)st->cls_work[0] : 0) + (cls >= 2 ? (i64)st->cls_work[1] : 0);
-    i64 n_items = cls < 0 ? (i64)st->n_work - (i64)st->cls_work[3] : (i64)st->cls_work[cls];   // never the huge class
-    u64 *queue = &st->cls_queue[cls < 0 ? 0 : cls];
-    if ((i64)st->n_work > work_cap || (i64)st->n_prob > prob_cap) n_items = 0;   // lists incomplete: sizing run
-    FSEG_T0;
-    // a shared work counter saturates near 90 pops/us, so the small classes claim several items per pop
-    constexpr int kPop = NM <= 16 ? 8 : (NM <= 32 ? 4 : 1);
-#ifndef FSEG_SCORE_STATIC
-#define FSEG_SCORE_STATIC 1
-#endif
-    // The small classes hold tens of thousands of short items: even batched pops serialise on the one counter, so
-    // they take a static stride (neighbouring items are of similar size); the big class keeps the counter.
-    constexpr bool kStatic = FSEG_SCORE_STATIC && NM <= 32;
-    i64 wi_base = 0;
-    int wi_left = 0;
-    i64 wi_static = blockIdx.x;
-    for (;;) {
-        i64 wi;
-        if (kStatic) {
-            wi = cls < 0 ? -1 : wi_static;
-            wi_static += gridDim.x;
-        }
-        if (!kStatic || wi < 0) {
-            if (wi_left == 0) {
-                __syncthreads();
-                if (threadIdx.x == 0) work_s = atomicAdd(queue, (u64)kPop);
-                __syncthreads();
-                wi_base = (i64)work_s;
-                wi_left = kPop;
-            }
-            wi = wi_base + (kPop - wi_left);
-            --wi_left;
-        }
-        __syncthreads();
-        FSEG_TICK(0);
-        if (wi >= n_items) break;
-        const int4 item = cls_items[cls_base + wi];
-        const i64 w = item.x;
-        const int p = item.y, chunk = item.z;
-        const ProbDesc d = load_desc(desc + p);
-        const int n = d.n;
-        i64 poff = d.pair_off, toff = d.tri_off;
-        i64 coff = d.cov_off + (i64)chunk * kLaneChunk * n;
-        int npairs = n * (n - 1) / 2, ntri = n * (n - 1) * (n - 2) / 6;
-        if (n > nm) { if (threadIdx.x == 0) atomicOr(&st->err, kErrOverflowNm); continue; }
-        if (poff + npairs > pair_cap || toff + ntri > tri_cap || coff + (i64)kLaneChunk * n > cov_cap) continue;
-        bool zero_ambiguous = (pr.flags[p] & 1) != 0;
-        unsigned active = zero_ambiguous ? 0xfu : work_active[w];
-        int lanes_here = d.lane_n - chunk * kLaneChunk;
-        if (lanes_here > kLaneChunk) lanes_here = kLaneChunk;
-        if (lanes_here < kLaneChunk) active &= (1u << ((lanes_here + kSub - 1) / kSub)) - 1u;
-        if (active == 0) continue;                       // no read of this chunk touches the window
-        const int *cy = cand_y + d.c0;
-        for (int j = threadIdx.x; j < n; j += T) cy_s[j] = cy[j];
-        {
-            uint4 *z = reinterpret_cast<uint4 *>(out16);              // 8 counters per store
-            for (int x = threadIdx.x; x < (ntri + 7) / 8; x += T) z[x] = make_uint4(0, 0, 0, 0);
-        }
-        unsigned amb_acc[C::kSlots];
-#pragma unroll
-        for (int s = 0; s < C::kSlots; ++s) amb_acc[s] = 0;
-        // coverage tile of the first active sub-chunk into registers (global layout is [j][reads])
-        unsigned stage[C::kStage];
-        int sub = __ffs(active) - 1;
-        const int tile_words = n * kSub;
-#pragma unroll
-        for (int e = 0; e < C::kStage; ++e) {
-            int x = e * T + threadIdx.x;
-            stage[e] = x < tile_words ? cov_g[coff + (i64)(x >> 6) * kLaneChunk + sub * kSub + (x & 63)] : 0;
-        }
-        __syncthreads();
-        if (threadIdx.x < n) {
-            // iend_s[j] = number of i < j with cand_j - cand_i >= 5 (candidates ascending): binary search
-            int j = threadIdx.x, lim = cy_s[j] - 5, lo = 0, hi = j;
-            while (lo < hi) { int mid = (lo + hi) >> 1; if (cy_s[mid] <= lim) lo = mid + 1; else hi = mid; }
-            iend_s[j] = lo;
-        }
-        __syncthreads();
-        FSEG_TICK(1);
-        while (sub >= 0) {
-            int n_valid = lanes_here - sub * kSub;
-            if (n_valid > kSub) n_valid = kSub;
-            // ---- A: registers -> LDS cov[r][j]; start fetching the next active tile ---------------------
-#pragma unroll
-            for (int e = 0; e < C::kStage; ++e) {
-                int x = e * T + threadIdx.x;
-                if (x < tile_words) cov[(x & 63) * rt_stride + (x >> 6)] = stage[e];
-            }
-            unsigned rest = active & ~((2u << sub) - 1u);
-            int next_sub = rest ? __ffs(rest) - 1 : -1;
-            if (next_sub >= 0) {
-#pragma unroll
-                for (int e = 0; e < C::kStage; ++e) {
-                    int x = e * T + threadIdx.x;
-                    stage[e] = x < tile_words ? cov_g[coff + (i64)(x >> 6) * kLaneChunk + next_sub * kSub + (x & 63)] : 0;
-                }
-            }
-            lds_barrier();
-            FSEG_TICK(2);
-            // ---- B: pair planes ---------------------------------------------------------------------
-            const int nv1 = n_valid - 32;
-            unsigned valid0 = n_valid >= 32 ? 0xffffffffu : (n_valid > 0 ? ~(0xffffffffu >> n_valid) : 0u);
-            unsigned valid1 = nv1 >= 32 ? 0xffffffffu : (nv1 > 0 ? ~(0xffffffffu >> nv1) : 0u);
-#pragma unroll
-            for (int s = 0; s < C::kSlots; ++s) {
-                int q = s * T + threadIdx.x;
-                if (q < npairs) {
-                    int i = pair_ij[q] & 255, j = pair_ij[q] >> 8;
-                    int2 th = pair_thr[poff + q];
-                    // shift the compare result into the plane word through the carry: acc = 2*acc + (d >= hi).
-                    // Read b of a word therefore lands on bit 31-b (the valid masks below use the same order).
-                    unsigned y0 = 0, z0 = 0, y1 = 0, z1 = 0;
-#define FSEG_SHIFT_IN(acc, cmp, a, b) asm("v_cmp_" cmp "_i32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(a), "v"(b) : "vcc")
-#pragma unroll
-                    for (int b = 0; b < 32; ++b) {
-                        int d = (int)(cov[b * rt_stride + j] - cov[b * rt_stride + i]);
-                        FSEG_SHIFT_IN(y0, "ge", d, th.x);
-                        FSEG_SHIFT_IN(z0, "le", d, th.y);
-                    }
-#pragma unroll
-                    for (int b = 0; b < 32; ++b) {
-                        int d = (int)(cov[(32 + b) * rt_stride + j] - cov[(32 + b) * rt_stride + i]);
-                        FSEG_SHIFT_IN(y1, "ge", d, th.x);
-                        FSEG_SHIFT_IN(z1, "le", d, th.y);
-                    }
-#undef FSEG_SHIFT_IN
-                    planes[q] = make_uint4(y0, y1, z0, z1);
-                    amb_acc[s] += __popc(~(y0 | z0) & valid0) + __popc(~(y1 | z1) & valid1);
-                }
-            }
-            lds_barrier();
-            FSEG_TICK(3);
-            // ---- C: triples.  B pairs (j,k) are enumerated with j descending so that the 64 lanes of a wave
-            // have (nearly) the same trip count j and mostly share the (i,j) plane they read --------------
-            for (int r = threadIdx.x; r < npairs; r += T) {
-                int m = pair_ij[r] >> 8, x = pair_ij[r] & 255;        // m = n-1-j in [1, n-1], x = k-j-1 in [0, m)
-                int j = n - 1 - m, kk = j + 1 + x;
-                if (j == 0 || cy_s[kk] - cy_s[j] < 5) continue;       // dp(): segment too small (:540)
-                uint4 B = planes[kk * (kk - 1) / 2 + j];
-                if ((B.x | B.y | B.z | B.w) == 0) continue;
-                int tbase = kk * (kk - 1) * (kk - 2) / 6 + j * (j - 1) / 2;
-                int abase = j * (j - 1) / 2;
-                const int i_end = iend_s[j];                          // i with cand_j - cand_i >= 5 (:540), a prefix
-        // (a read is never yea AND nay of one pair -- lo < hi --, so the two cross terms of a plane word are disjoint: one popcount of their union)
-#define FSEG_TRI_CNT(A) (__popc(((A).x & B.z) | ((A).z & B.x)) + __popc(((A).y & B.w) | ((A).w & B.y)))
-                unsigned short *o16 = out16 + tbase;
-                int i = 0;
-                if ((tbase & 1) && i_end > 0) {                       // align to a counter pair
-                    uint4 A = planes[abase];
-                    o16[0] += (unsigned short)FSEG_TRI_CNT(A);
-                    i = 1;
-                }
-                for (; i + 1 < i_end; i += 2) {                       // two u16 counters per 32-bit read-modify-write
-                    uint4 A0 = planes[abase + i], A1 = planes[abase + i + 1];
-                    unsigned add = FSEG_TRI_CNT(A0) | (FSEG_TRI_CNT(A1) << 16);
-                    *reinterpret_cast<unsigned *>(o16 + i) += add;    // a counter never exceeds the reads of a work item (< 65536)
-                }
-                if (i < i_end) {
-                    uint4 A = planes[abase + i];
-                    o16[i] += (unsigned short)FSEG_TRI_CNT(A);
-                }
-#undef FSEG_TRI_CNT
-            }
-            lds_barrier();
-            FSEG_TICK(4);
-            sub = next_sub;
-        }
-        // ---- flush ---------------------------------------------------------------------------------
-        for (int x = threadIdx.x; x < ntri; x += T) {
-            unsigned v = out16[x];
-            if (v) atomicAdd(&out_g[toff + x], v);
-        }
-#pragma unroll
-        for (int s = 0; s < C::kSlots; ++s) {
-            int q = s * T + threadIdx.x;
-            if (q < npairs && amb_acc[s]) atomicAdd(&amb_g[poff + q], amb_acc[s]);
-        }
-        FSEG_TICK(5);
-    }
-}
-
-// The label arena starts every run filled with '0' (the label of a read without coverage, S7).  The fill depends on
-// nothing but the arena's capacity, and the big-problem DP occupies a fraction of the GPU with latency-bound
-// workgroups -- so the fill rides along as extra workgroups of that launch (k_label_zero when there is no DP launch).
-__device__ __forceinline__ void fill_labels(uint4 *labels16, i64 n16, i64 first, i64 stride) {
-    const uint4 z = make_uint4(0x30303030u, 0x30303030u, 0x30303030u, 0x30303030u);
-    for (i64 i = first; i < n16; i += stride) labels16[i] = z;
-}
-
-template <int NM, int T, typename OutT>
-__global__ void __launch_bounds__(T) k_dp(Status *st, int dp_class, int nm, const int *dp_items, ProblemArrays pr, const ProbDesc *desc, i64 prob_cap,
-                                            const i64 *cand_off, const int *cand_y, const int *iv_part,
-                                            const i64 *part_lane_off, const unsigned *out_g, i64 tri_cap,
-                                            const unsigned *amb_g, const int2 *pair_thr, i64 pair_cap, int support,
-                                            unsigned char *chosen, int n_lo, int dp_blocks, uint4 *labels16, i64 labels_n16 FSEG_TPARAM) {
-    if ((int)blockIdx.x >= dp_blocks) {                 // the workgroups behind the DP ones: label arena fill
-        fill_labels(labels16, labels_n16, (i64)(blockIdx.x - dp_blocks) * T + threadIdx.x, (i64)(gridDim.x - dp_blocks) * T);
-        return;
-    }
-    // handles problems with n_lo < n <= NM that the scoring kernel did not finish itself (more than one
-    // work item); the out table of the problem is staged in LDS first
-    // LDS carve-up for problems of at most nm <= NM candidates (nm from the previous run's largest problem)
-    const int kTri = nm * (nm - 1) * (nm - 2) / 6, kPairs = nm * (nm - 1) / 2;
-    extern __shared__ __align__(16) unsigned char smem[];
-    i64 *M = reinterpret_cast<i64 *>(smem);                          // M(b,c), b < c, at c*(c-1)/2 + b
-    int *in_s = reinterpret_cast<int *>(M + kPairs);
-    OutT *out_s = reinterpret_cast<OutT *>(in_s + kPairs);            // counts: 16 bit when every problem sees < 65536 reads
-    unsigned char *A = reinterpret_cast<unsigned char *>(out_s + ((kTri + 3) & ~3));
-    __shared__ int cy_s[NM];
-    i64 n_prob = (i64)st->n_prob;
-    if (n_prob > prob_cap) return;                                  // sizing run
-    // dp_class 0 / 1: the small / big problems of the per-class list; -1: every problem
-    const i64 list_base = dp_class == 1 ? (i64)st->dp_cls[0] : 0;
-    const i64 list_n = dp_class < 0 ? n_prob : (i64)st->dp_cls[dp_class];
-#ifdef FSEG_SCORE_TIMING
-    unsigned long long *dp_tacc = tacc; unsigned long long dt_prev = wall_clock64();
-#endif
-    for (i64 t = blockIdx.x; t < list_n; t += dp_blocks) {          // static stride (no shared work counter)
-        __syncthreads();
-        FSEG_DTICK(8);
-        const i64 p = dp_class < 0 ? t : (i64)dp_items[list_base + t];
-        const ProbDesc d = load_desc(desc + p);
-        int n = d.n;
-        if (n > NM || n <= n_lo || d.kind != kKindArena) continue;   // (when this launch walks every problem: k_tiny's and k_solve's are not its own)
-        if (n > nm) { if (threadIdx.x == 0) atomicOr(&st->err, kErrOverflowNm); continue; }
-        if (sizeof(OutT) == 2 && d.lane_n >= 65536) { if (threadIdx.x == 0) atomicOr(&st->err, kErrNeedWideDp); continue; }
-        i64 poff = d.pair_off, toff = d.tri_off;
-        int npairs = n * (n - 1) / 2, ntri = n * (n - 1) * (n - 2) / 6;
-        if (poff + npairs > pair_cap || toff + ntri > tri_cap) continue;
-        const i64 c0 = d.c0;
-        const i64 outside = d.outside;
-        const bool zamb = (pr.flags[p] & 1) != 0;
-        for (int j = threadIdx.x; j < n; j += blockDim.x) cy_s[j] = cand_y[c0 + j];
-        for (int x0 = threadIdx.x; x0 < ntri; x0 += T * 8) {       // 8 loads in flight per thread
-            unsigned v[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { int x = x0 + e * T; v[e] = x < ntri ? out_g[toff + x] : 0u; }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { int x = x0 + e * T; if (x < ntri) out_s[x] = (OutT)v[e]; }
-        }
-        for (int q = threadIdx.x; q < npairs; q += blockDim.x)
-            in_s[q] = -(int)((i64)amb_g[poff + q] + ((zamb && pair_thr[poff + q].y < 0) ? outside : 0));
-        __syncthreads();
-        FSEG_DTICK(9);
-        int chain = dp_solve_push<T, NM>(n, out_s, in_s, M, A, cy_s, support, chosen + c0 FSEG_DARG);
-        if (threadIdx.x == 0) pr.chain[p] = chain;
-    }
-}
-
-// DP of the small class (n <= kDpSmall) for batches of many partitions, where most problems have a handful of
-// candidates: a workgroup takes four list entries at a time; every wave solves its own entry alone when it has at most
-// kDpWave candidates (wave-private tables, wave-level synchronisation, no workgroup barrier on that path), and the
-// entries above that are then solved one after the other by the whole workgroup as in k_dp.
-constexpr int kDpWave = 16;
-constexpr int kDpWavePairs = kDpWave * (kDpWave - 1) / 2, kDpWaveTri = kDpWave * (kDpWave - 1) * (kDpWave - 2) / 6;
-template <typename OutT>
-__host__ __device__ constexpr size_t dp_wave_bytes() {          // tables of one wave-private problem, 16-byte multiple
-    return (((size_t)kDpWavePairs * (8 + 4 + 1) + (size_t)(kDpWaveTri + 4) * sizeof(OutT)) + 15) & ~(size_t)15;
-}
-template <typename OutT>
-__global__ void __launch_bounds__(256, 6) k_dp_waves(Status *st, const int *dp_items, ProblemArrays pr, const ProbDesc *desc, i64 prob_cap,
-                                                  const int *cand_y, const unsigned *out_g, i64 tri_cap, const unsigned *amb_g,
-                                                  const int2 *pair_thr, i64 pair_cap, int support, unsigned char *chosen, int coop) {
-    constexpr int T = 256, NM = kDpSmall;
-    constexpr int kTri = NM * (NM - 1) * (NM - 2) / 6, kPairs = NM * (NM - 1) / 2;
-    extern __shared__ __align__(16) unsigned char smem[];
-    __shared__ int cy_s[NM];
-    __shared__ int cy_w[4][kDpWave];
-    __shared__ int big_s[4];
-    const i64 n_prob = (i64)st->n_prob;
-    if (n_prob > prob_cap) return;                                  // sizing run
-    const i64 list_n = (i64)st->dp_cls[0];
-    const int lane = lane_id(), wave = threadIdx.x >> 6;
-#ifdef FSEG_SCORE_TIMING
-    __shared__ unsigned long long tick_sink[16];                    // the diagnostic build's ticks of this kernel are dropped
-    unsigned long long *dp_tacc = tick_sink; unsigned long long dt_prev = 0;
-#endif
-    // a workgroup's four entries are a grid apart, not neighbours: the list is in candidate order, neighbouring problems
-    // come from the same gene and are of similar size, and four large ones in one workgroup would be solved one after
-    // the other while the rest of the GPU is already idle
-    for (i64 g = (i64)blockIdx.x; g < list_n; g += (i64)gridDim.x * 4) {
-        __syncthreads();
-        {   // ---- every wave: its own entry ------------------------------------------------------------------
-            const i64 t = g + (i64)wave * gridDim.x;
-            int big = -1;
-            if (t < list_n) {
-                const i64 p = dp_items[t];
-                const ProbDesc d = load_desc(desc + p);
-                const int n = d.n;
-                const i64 poff = d.pair_off, toff = d.tri_off;
-                const int npairs = n * (n - 1) / 2, ntri = n * (n - 1) * (n - 2) / 6;
-                const bool usable = n <= NM && poff + npairs <= pair_cap && toff + ntri <= tri_cap;
-                if (sizeof(OutT) == 2 && d.lane_n >= 65536) { if (lane == 0) atomicOr(&st->err, kErrNeedWideDp); }
-                else if (usable && n > kDpWave) big = coop ? (int)p : -1;   // coop == 0: a k_dp launch of its own takes these
-                else if (usable) {
-                    unsigned char *w_mem = smem + (size_t)wave * dp_wave_bytes<OutT>();
-                    i64 *M = reinterpret_cast<i64 *>(w_mem);
-                    int *in_s = reinterpret_cast<int *>(M + kDpWavePairs);
-                    OutT *out_s = reinterpret_cast<OutT *>(in_s + kDpWavePairs);
-                    unsigned char *A = reinterpret_cast<unsigned char *>(out_s + ((kDpWaveTri + 3) & ~3));
-                    const bool zamb = (pr.flags[p] & 1) != 0;
-                    if (lane < n) cy_w[wave][lane] = cand_y[d.c0 + lane];
-                    for (int x0 = lane; x0 < ntri; x0 += 64 * 4) {
-                        unsigned v[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { int x = x0 + e * 64; v[e] = x < ntri ? out_g[toff + x] : 0u; }
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { int x = x0 + e * 64; if (x < ntri) out_s[x] = (OutT)v[e]; }
-                    }
-                    for (int q = lane; q < npairs; q += 64)
-                        in_s[q] = -(int)((i64)amb_g[poff + q] + ((zamb && pair_thr[poff + q].y < 0) ? (i64)d.outside : 0));
-                    dp_sync<64>();
-                    int chain = dp_solve_push<64, kDpWave>(n, out_s, in_s, M, A, cy_w[wave], support, chosen + d.c0 FSEG_DARG);
-                    if (lane == 0) pr.chain[p] = chain;
-                }
-            }
-            if (lane == 0) big_s[wave] = big;
-        }
-        __syncthreads();
-        // ---- the workgroup: entries with more than kDpWave candidates, one after the other ----------------------
-        for (int w = 0; w < 4; ++w) {
-            const int pb = big_s[w];
-            if (pb < 0) continue;                                       // uniform: big_s is shared
-            i64 *M = reinterpret_cast<i64 *>(smem);
-            int *in_s = reinterpret_cast<int *>(M + kPairs);
-            OutT *out_s = reinterpret_cast<OutT *>(in_s + kPairs);
-            unsigned char *A = reinterpret_cast<unsigned char *>(out_s + ((kTri + 3) & ~3));
-            const ProbDesc d = load_desc(desc + pb);
-            const int n = d.n;
-            const i64 poff = d.pair_off, toff = d.tri_off;
-            const int npairs = n * (n - 1) / 2, ntri = n * (n - 1) * (n - 2) / 6;
-            const bool zamb = (pr.flags[pb] & 1) != 0;
-            __syncthreads();
-            for (int j = threadIdx.x; j < n; j += T) cy_s[j] = cand_y[d.c0 + j];
-            for (int x0 = threadIdx.x; x0 < ntri; x0 += T * 8) {
-                unsigned v[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { int x = x0 + e * T; v[e] = x < ntri ? out_g[toff + x] : 0u; }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { int x = x0 + e * T; if (x < ntri) out_s[x] = (OutT)v[e]; }
-            }
-            for (int q = threadIdx.x; q < npairs; q += T)
-                in_s[q] = -(int)((i64)amb_g[poff + q] + ((zamb && pair_thr[poff + q].y < 0) ? (i64)d.outside : 0));
-            __syncthreads();
-            int chain = dp_solve_push<T, NM>(n, out_s, in_s, M, A, cy_s, support, chosen + d.c0 FSEG_DARG);
-            if (threadIdx.x == 0) pr.chain[pb] = chain;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Problems with at most kTiny candidates -- in batches of many partitions that is most of them (half have n = 3) -- are
-// solved whole by ONE WAVE each: window coverage (get_cumulative_coverage :188-246), pair labels (:488-497), in / out
-// counts (:500-528) and the DP (:532-566), without a work item, a coverage tile or an arena entry.  Lanes are the reads
-// of the problem's lane range, 64 at a time: a pair's yea / nay plane for those reads is the result of one v_cmp (a
-// ballot), lane q keeps pair q's planes and ambiguity count, lane t the count of triple t; the DP is dp_solve_push<64> on
-// wave-private tables.  Four waves = four problems per workgroup, no workgroup barrier anywhere.
-// ---------------------------------------------------------------------------------------------
-constexpr int kTiny = 8;
-constexpr int kTinyPairs = kTiny * (kTiny - 1) / 2, kTinyTri = kTiny * (kTiny - 1) * (kTiny - 2) / 6;
-// (6 workgroups = 24 waves per CU asked of the register allocator: the kernel is a chain of dependent loads, and at the
-// 120 registers it would otherwise take only 16 waves fit; measured 56 -> 47 us on config4, 8 spills and is slower)
-#ifndef FSEG_TINY_OCC
-#define FSEG_TINY_OCC 5
-#endif
-__global__ void __launch_bounds__(256, FSEG_TINY_OCC) k_tiny(Status *st, const ProbDesc *desc, i64 prob_cap, int tiny_max, ProblemArrays pr,
-                                              const int *cand_y, const longlong2 *lane_ex, const int *ex_ts,
-                                              const int *ex_te, const double *h_table, int h_len, double tau, const int2 *thr_tab,
-                                              int support, unsigned char *chosen, i64 lb_h, i64 ln_h FSEG_TPARAM) {
-    __shared__ u64 planes[4][kTinyPairs][2];            // [wave][pair]{yea, nay} of the current 64 reads
-    __shared__ i64 M_s[4][kTinyPairs];
-    __shared__ int in_s[4][kTinyPairs];
-    __shared__ unsigned out_s[4][kTinyTri + 4];
-    __shared__ unsigned char A_s[4][kTinyPairs + 4];
-    __shared__ int cy_s[4][kTiny];
-    __shared__ unsigned char tri_ijk[kTinyTri][4];
-    __shared__ int2 act_w[4][128];                      // [wave] reads with coverage in the window, waiting for a round: (first exon, count)
-    const int lane = lane_id(), wave = wave_id();
-    const u64 lt_mask = (1ULL << lane) - 1ULL;
-    if (threadIdx.x < kTinyTri) {                       // rank t = k(k-1)(k-2)/6 + j(j-1)/2 + i  ->  (i, j, k)
-        int t = threadIdx.x, k = 2;
-        while ((k + 1) * k * (k - 1) / 6 <= t) ++k;
-        int i, j;
-        pair_decode(t - k * (k - 1) * (k - 2) / 6, &i, &j);
-        tri_ijk[t][0] = (unsigned char)i; tri_ijk[t][1] = (unsigned char)j; tri_ijk[t][2] = (unsigned char)k;
-    }
-    __syncthreads();
-    // (lb_h >= 0: the host knows the lists' sizes -- the batch has been sized --, and the status record is not on the way to the first problem)
-    if (lb_h < 0 && (i64)st->n_prob > prob_cap) return;                      // sizing run: the descriptors are incomplete
-#ifdef FSEG_SCORE_TIMING
-    __shared__ unsigned long long tick_sink[16];
-    unsigned long long *dp_tacc = tick_sink; unsigned long long dt_prev = 0;
-#endif
-    // k_tiny's problems are a list of their own (behind the three solve lists): every wave of a workgroup has one, and a
-    // workgroup's four are a grid apart (neighbours in the list are neighbours on the genome and of similar size)
-    const i64 list_base = lb_h >= 0 ? lb_h : (i64)st->solve_cls[0] + (i64)st->solve_cls[1] + (i64)st->solve_cls[2];
-    const i64 list_n = lb_h >= 0 ? ln_h : (i64)st->n_tiny;
-    for (i64 t = (i64)blockIdx.x + (i64)wave * gridDim.x; t < list_n; t += (i64)gridDim.x * 4) {
-#ifdef FSEG_SCORE_TIMING
-        const unsigned long long t_prob0 = wall_clock64();
-#endif
-        const ProbDesc d = FSEG_LOAD_DESC(desc + list_base + t);          // (the list's own copy of the record: k_prob_emit)
-        const int p = d.w0;
-        const int n = d.n;
-        if (n > tiny_max) continue;                     // wave-uniform
-        const int npairs = n * (n - 1) / 2, ntri = n * (n - 1) * (n - 2) / 6;
-        // The problem is a chain of dependent loads (descriptor -> candidates -> thresholds; descriptor -> exon ranges -> exons):
-        // the second branch needs nothing of the first, so the first 64 reads' exon ranges and first exon blocks are requested
-        // now and arrive while the candidates and thresholds are being fetched.
-        longlong2 pf_ex = make_longlong2(0, 0);
-        int pf_ts[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pf_te[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (d.lane_n > 0) {                             // (wave-uniform)
-            pf_ex = lane_ex[d.lane_lo + (lane < d.lane_n ? lane : 0)];
-            load_exons8(ex_ts + pf_ex.x, pf_ts); load_exons8(ex_te + pf_ex.x, pf_te);
-        }
-        dp_sync<64>();                                  // the previous problem's readers of the wave-private tables are done
-        if (lane < n) cy_s[wave][lane] = cand_y[d.c0 + lane];
-        dp_sync<64>();
-        int hi_q = 0x7fffffff, lo_q = -1, pi = 0, pj = 1;
-        if (lane < npairs) {
-            pair_decode(lane, &pi, &pj);
-            label_thresholds_tab((i64)cy_s[wave][pj] - cy_s[wave][pi] + 1, thr_tab, h_table, h_len, tau, &hi_q, &lo_q);   // :490-495 as integer bounds
-        }
-        int ti = 0, tj = 1, tk = 2;
-        if (lane < ntri) { ti = tri_ijk[lane][0]; tj = tri_ijk[lane][1]; tk = tri_ijk[lane][2]; }
-        const int cp0 = d.g0 + cy_s[wave][0], c_last = d.g0 + cy_s[wave][n - 1];
-        int cj[kTiny];
-#pragma unroll
-        for (int j = 0; j < kTiny; ++j) cj[j] = j < n ? d.g0 + cy_s[wave][j] : cp0;      // beyond the problem: an empty window
-        unsigned amb = 0, out = 0;
-        // As in k_solve: only the reads with an exon in the window are scored (about 60 % of the lane range), packed into
-        // full rounds of 64, each with its window exons located (they are consecutive: first with te >= cand_0 .. last with
-        // ts < cand_{n-1}), so the coverage below is a sum of overlaps over two or three exons instead of a search and a walk.
-        int raw = 0, fill = 0, n_act = 0;               // wave-uniform: lanes examined, records waiting, reads kept
-        while (raw < d.lane_n || fill > 0) {
-            while (fill < 64 && raw < d.lane_n) {
-                const int li = raw + lane;
-                const bool in = li < d.lane_n;
-                longlong2 ex;
-                int ts8[8], te8[8];
-                if (raw == 0) {                                               // (wave-uniform) the block requested above
-                    ex = pf_ex;
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) { ts8[u] = pf_ts[u]; te8[u] = pf_te[u]; }
-                } else {
-                    ex = lane_ex[d.lane_lo + (in ? li : 0)];                  // unconditional: no branch around the load
-                    load_exons8(ex_ts + ex.x, ts8); load_exons8(ex_te + ex.x, te8);
-                }
-                i64 first = ex.x;
-                int cnt = 0;
-                for (i64 eb = ex.x;;) {                                       // eight exons per round from clamped addresses
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const bool hit = eb + u < ex.y && te8[u] >= cp0 && ts8[u] < c_last;
-                        if (hit && cnt == 0) first = eb + u;
-                        cnt += hit;
-                    }
-                    if (ts8[7] >= c_last) break;
-                    eb += 8;
-                    if (eb >= ex.y) break;
-                    load_exons8(ex_ts + eb, ts8); load_exons8(ex_te + eb, te8);
-                }
-                const bool act = in && cnt > 0;
-                const u64 m = __ballot(act);
-                if (act) act_w[wave][fill + __popcll(m & lt_mask)] = make_int2((int)first, cnt);
-                fill += __popcll(m); n_act += __popcll(m);
-                raw += 64;
-            }
-            dp_sync<64>();
-            const int nv = fill < 64 ? fill : 64;
-            const bool valid = lane < nv;
-            // window coverage of this lane's read: cov[j] = positions of its closed exons in [cand_0, cand_j)
-            int cov[kTiny];
-#pragma unroll
-            for (int j = 0; j < kTiny; ++j) cov[j] = 0;
-            {
-                const int2 a = act_w[wave][valid ? lane : 0];
-                const int e_end = valid ? a.y : 0;
-                for (int e = 0; e < e_end; e += 2) {
-                    const int2 ts2 = load_exons2(ex_ts + a.x + e), te2 = load_exons2(ex_te + a.x + e);      // (the second may be the next read's: masked below)
-                    const int tsa = ts2.x, tea = te2.x, tsb = ts2.y, teb = te2.y;
-                    const int a0 = max(tsa, cp0), b0 = tea + 1;
-                    const int a1 = max(tsb, cp0), b1 = e + 1 < e_end ? teb + 1 : a1;
-#pragma unroll
-                    for (int j = 1; j < kTiny; ++j) cov[j] += max(0, min(b0, cj[j]) - a0) + max(0, min(b1, cj[j]) - a1);
-                }
-            }
-            const u64 vmask = __ballot(valid);
-            // pair labels: one compare per plane, the 64 reads' bits arrive as the ballot; lane q keeps pair q's planes
-            u64 my_yea = 0, my_nay = 0;
-#pragma unroll
-            for (int j = 1; j < kTiny; ++j) {
-#pragma unroll
-                for (int i = 0; i < j; ++i) {
-                    const int q = j * (j - 1) / 2 + i;
-                    if (q < npairs) {                   // wave-uniform
-                        const int dd = cov[j] - cov[i];
-                        const int hi = __builtin_amdgcn_readlane(hi_q, q), lo = __builtin_amdgcn_readlane(lo_q, q);
-                        const u64 y = __ballot(valid && dd >= hi), z = __ballot(valid && dd <= lo);
-                        if (lane == q) { my_yea = y; my_nay = z; }
-                    }
-                }
-            }
-            if (lane < npairs) {
-                amb += (unsigned)__popcll(~(my_yea | my_nay) & vmask);       // neither label: ambiguous (:500-506)
-                planes[wave][lane][0] = my_yea; planes[wave][lane][1] = my_nay;
-            }
-            // the records beyond this round move to the front of the list
-            int2 keep = make_int2(0, 0);
-            if (lane < fill - nv) keep = act_w[wave][64 + lane];
-            dp_sync<64>();
-            if (lane < fill - nv) act_w[wave][lane] = keep;
-            fill -= nv;
-            if (lane < ntri) {                          // out(i,j,k) (:509-528): the two labels exclude each other
-                const int qa = tj * (tj - 1) / 2 + ti, qb = tk * (tk - 1) / 2 + tj;
-                out += (unsigned)(__popcll(planes[wave][qa][0] & planes[wave][qb][1]) + __popcll(planes[wave][qa][1] & planes[wave][qb][0]));
-            }
-            dp_sync<64>();
-        }
-        const int dropped = d.lane_n - n_act;           // reads of the lane range without coverage: treated like those outside it
-        // a read outside the lane range has no coverage in the window: ambiguous exactly where lo < 0 (only tau = 1)
-        if (lane < npairs) in_s[wave][lane] = -(int)((i64)amb + (lo_q < 0 ? (i64)d.outside + dropped : 0));
-        if (lane < ntri) out_s[wave][lane] = out;
-        dp_sync<64>();
-        const int chain = dp_solve_push<64, kTiny>(n, out_s[wave], in_s[wave], M_s[wave], A_s[wave], cy_s[wave], support, chosen + d.c0 FSEG_DARG);
-        if (lane == 0) pr.chain[p] = chain;
-#ifdef FSEG_SCORE_TIMING
-        if (lane == 0) FSEG_PROB_TICK(p, t_prob0, d.lane_n, n_act);
-#endif
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// S5 whole by ONE WAVE per problem, for problems of at most NM candidates (NM = 8: the tiny list, NM = 16: solve list 0) --
-// k_tiny's plan with the loads made cheap.  k_tiny fetches a read's exons with one gather per lane from the rep-ordered arrays (64
-// cache lines per load instruction, and the texture path takes them one by one: that rate, not HBM or the ALUs, is what it runs
-// at; k_solve gathers too, but since round 4 from the lane-ordered stream, where neighbouring lanes share lines) and every
-// problem is a chain of such gathers.  Here the exons come from the lane-ordered stream `lex` (k_lanes): the reads a
-// round examines -- up to 64 consecutive lanes -- own ONE contiguous piece of it, which the wave copies into LDS with
-// lane-consecutive 16-byte loads; everything after that is LDS and registers:
-//   per round: every lane finds the exons of its read that meet the window (ordered, so they are consecutive) and sums
-//     their overlaps with [cand_0, cand_j) -- window coverage (get_cumulative_coverage :188-246) in registers, lane = read;
-//     pair labels (:488-497): the 64 reads' bits of a pair's plane are one v_cmp, kept by lane q for pair q; in / out counts
-//     (:500-528) with lane t owning triples t, t + 64, ..;
-//   then dp_solve_push<64> (:532-566, :592-594) on wave-private tables.
-// A read of the lane range without coverage in the window is scored like any other (all `nay`; ambiguous where lo < 0).
-// No workgroup barrier anywhere; four waves = four problems per workgroup.
-// ---------------------------------------------------------------------------------------------
-// acc's lane `lane` := the wave-uniform value v (v_writelane_b32; this compiler has no builtin for it)
-// (the lane number has to be an inline constant: a second scalar register would break the one-scalar-operand rule)
-template <int LANE> __device__ __forceinline__ void write_lane(unsigned &acc, unsigned v) {
-    asm("v_writelane_b32 %0, %1, %2" : "+v"(acc) : "s"(v), "n"(LANE));
-}
-constexpr int kWaveLanes = 1023;               // reads up to which a small problem is one wave's (16 rounds); beyond, the arena path
-constexpr int kStageCap = 512;                 // exons of one round's reads staged in LDS (a round takes fewer reads if they own more)
-constexpr int kWaveRepExons = kStageCap - 2;   // a batch with a rep of more exons than this keeps k_tiny / k_solve
-template <int NM> struct WaveCfg {
-    static constexpr int kPairs = NM * (NM - 1) / 2, kTri = NM * (NM - 1) * (NM - 2) / 6;
-    static constexpr int kPSlots = (kPairs + 63) / 64, kTSlots = (kTri + 63) / 64;
-#ifndef FSEG_WAVE_OCC8
-#define FSEG_WAVE_OCC8 7        // (72 registers: all of a 250 k-read batch's ~7 000 tiny problems are resident at once, 30 -> 25 us)
-#endif
-#ifndef FSEG_WAVE_OCC16
-#define FSEG_WAVE_OCC16 4
-#endif
-    static constexpr int kOcc = NM <= 8 ? FSEG_WAVE_OCC8 : FSEG_WAVE_OCC16;
-};
-template <int NM, typename V> struct __align__(16) WaveLds {
-    int2 stage[kStageCap + 4];
-    uint4 planes[WaveCfg<NM>::kPairs];             // {yea lo, yea hi, nay lo, nay hi} of the current round's reads
-    V M[WaveCfg<NM>::kPairs];
-    int in[WaveCfg<NM>::kPairs];
-    unsigned out[WaveCfg<NM>::kTri + 4];
-    unsigned char A[WaveCfg<NM>::kPairs + 8];
-    int cy[NM];
-};
-template <int NM, typename V>
-__global__ void __launch_bounds__(256, WaveCfg<NM>::kOcc) k_wave(Status *st, const ProbDesc *desc, i64 prob_cap, int list, ProblemArrays pr,
-                                                                 const int *__restrict__ cand_y, const int2 *__restrict__ lane_lx, const int2 *__restrict__ lex,
-                                                                 const double *h_table, int h_len, double tau, const int2 *__restrict__ thr_tab,
-                                                                 int support, unsigned char *chosen, i64 lb_h, i64 ln_h FSEG_TPARAM) {
-    using C = WaveCfg<NM>;
-    __shared__ WaveLds<NM, V> lds4[4];
-    __shared__ unsigned short tri_q[C::kTri + 2];      // triple rank t -> (pair (i,j)) | (pair (j,k)) << 8
-    const int lane = lane_id(), wave = wave_id();
-    WaveLds<NM, V> &L = lds4[wave];
-    for (int t = threadIdx.x; t < C::kTri; t += 256) {
-        int k = 2;
-        while ((k + 1) * k * (k - 1) / 6 <= t) ++k;
-        int i, j;
-        pair_decode(t - k * (k - 1) * (k - 2) / 6, &i, &j);
-        tri_q[t] = (unsigned short)((j * (j - 1) / 2 + i) | ((k * (k - 1) / 2 + j) << 8));
-    }
-    __syncthreads();
-    if (lb_h < 0 && (i64)st->n_prob > prob_cap) return;             // sizing run: the descriptors are incomplete
-#ifdef FSEG_SCORE_TIMING
-    __shared__ unsigned long long tick_sink[16];
-    unsigned long long *dp_tacc = tick_sink; unsigned long long dt_prev = 0;
-#endif
-    // list 3: k_tiny's problems (behind the three solve lists); list 0: the small class.  lb_h >= 0: bounds from the host (a sized batch)
-    const i64 list_base = lb_h >= 0 ? lb_h : (list == 3 ? (i64)st->solve_cls[0] + (i64)st->solve_cls[1] + (i64)st->solve_cls[2] : 0);
-    const i64 list_n = lb_h >= 0 ? ln_h : (list == 3 ? (i64)st->n_tiny : (i64)st->solve_cls[0]);
-    const unsigned aborted = stage_aborted(st);                     // (a waiter in front of this launch gave up: the lists may not exist)
-    for (i64 t = (i64)blockIdx.x + (i64)wave * gridDim.x; t < list_n; t += (i64)gridDim.x * 4) {
-#ifdef FSEG_SCORE_TIMING
-        const unsigned long long t_prob0 = wall_clock64();
-#endif
-        const ProbDesc d = FSEG_LOAD_DESC(desc + list_base + t);          // (the list's own copy of the record: k_prob_emit)
-        if (aborted) return;
-        const int p = d.w0;
-        const int n = d.n;
-        if (n > NM || n < 3) { if (lane == 0) atomicOr(&st->err, kErrOverflowNm); continue; }       // (wave-uniform)
-        const int npairs = n * (n - 1) / 2, ntri = n * (n - 1) * (n - 2) / 6;
-        // two independent loads behind the descriptor: the first round's lane ranges and the candidates
-        int2 lx = lane_lx[d.lane_lo + (lane < d.lane_n ? lane : 0)];
-        const int cyv = cand_y[d.c0 + (lane < n ? lane : 0)];
-        dp_sync<64>();                                  // the previous problem's DP is done with the wave's tables
-        if (lane < n) L.cy[lane] = cyv;
-        int hi_q[C::kPSlots], lo_q[C::kPSlots];
-        unsigned amb[C::kPSlots], outc[C::kTSlots];
-#pragma unroll
-        for (int s = 0; s < C::kPSlots; ++s) {
-            const int q = s * 64 + lane;
-            hi_q[s] = 0x7fffffff; lo_q[s] = -1; amb[s] = 0;
-            const unsigned short ij = g_pair_ij[q < npairs ? q : 0];
-            const int ci = __shfl(cyv, ij & 255), cjv = __shfl(cyv, ij >> 8);
-            if (q < npairs) label_thresholds_tab((i64)cjv - ci + 1, thr_tab, h_table, h_len, tau, &hi_q[s], &lo_q[s]);   // :490-495 as integer bounds
-        }
-#pragma unroll
-        for (int s = 0; s < C::kTSlots; ++s) outc[s] = 0;
-        // the candidates' genomic positions, wave-uniform
-        const int cp0 = d.g0 + __builtin_amdgcn_readlane(cyv, 0), c_last = d.g0 + __builtin_amdgcn_readlane(cyv, n - 1);
-        int cj[NM];
-#pragma unroll
-        for (int j = 0; j < NM; ++j) cj[j] = j < n ? d.g0 + __builtin_amdgcn_readlane(cyv, j) : cp0;      // beyond the problem: an empty window
-        for (int l0 = 0; l0 < d.lane_n;) {
-            const bool in = l0 + lane < d.lane_n;
-            if (l0 > 0) lx = lane_lx[d.lane_lo + l0 + (in ? lane : 0)];
-            // ---- the round's reads: as many of the next 64 lanes as own at most kStageCap exons together (all 64, usually);
-            //      their exons are the stream's piece [base, end of the last one's)
-            const int base = uni(lx.x) & ~1;                                     // (16-byte units)
-            const u64 fm = __ballot(in && lx.y - base <= kStageCap);
-            const int m = ~fm == 0 ? 64 : (int)__builtin_ctzll(~fm);            // the ranges ascend: a prefix of the lanes
-            if (m == 0) { if (lane == 0) atomicOr(&st->err, kErrWaveStage); break; }      // (the host keeps such batches away: wave_on)
-            const int total = __builtin_amdgcn_readlane(lx.y, m - 1) - base;
-            {
-                const int last2 = total & ~1;
-                int4 sv[kStageCap / 128];
-#pragma unroll
-                for (int u = 0; u < kStageCap / 128; ++u) {
-                    const int i = 2 * lane + 128 * u;
-                    sv[u] = *reinterpret_cast<const int4 *>(lex + base + (i < last2 ? i : last2));
-                }
-#pragma unroll
-                for (int u = 0; u < kStageCap / 128; ++u) {
-                    const int i = 2 * lane + 128 * u;
-                    if (i < total) *reinterpret_cast<int4 *>(&L.stage[i]) = sv[u];
-                }
-            }
-            dp_sync<64>();
-            const bool valid = lane < m;
-            const u64 vmask = m == 64 ? ~0ULL : ((1ULL << m) - 1ULL);
-            // ---- this lane's read: its exons that meet the window (consecutive: the first with te >= cand_0 up to the last with
-            //      ts < cand_{n-1}), then its window coverage cov[j] = positions of its closed exons in [cand_0, cand_j)
-            //      = sum over those exons of |[ts, te] n [cand_0, cand_j)|
-            const int ea = valid ? lx.x - base : 0, eb = valid ? lx.y - base : 0;
-            int first = ea, cnt = 0;
-            for (int e = ea; e < eb; e += 4) {
-                int2 x[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) x[u] = L.stage[e + u];                 // (beyond the read: masked; the array has room)
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const bool hit = e + u < eb && x[u].y >= cp0 && x[u].x < c_last;
-                    if (hit && cnt == 0) first = e + u;
-                    cnt += hit;
-                }
-                if (x[3].x >= c_last) break;                                       // the rest of the read lies beyond the window
-            }
-            int cov[NM];
-#pragma unroll
-            for (int j = 0; j < NM; ++j) cov[j] = 0;
-            for (int e = 0; e < cnt; e += 2) {
-                const int2 xa = L.stage[first + e], xb = L.stage[first + e + 1];
-                const int a0 = max(xa.x, cp0), b0 = xa.y + 1;                      // closed exon -> half-open end
-                const int a1 = max(xb.x, cp0), b1 = e + 1 < cnt ? xb.y + 1 : a1;   // (an odd count: the second slot is empty)
-#pragma unroll
-                for (int j = 1; j < NM; ++j)
-                    if (j < n) cov[j] += max(0, min(b0, cj[j]) - a0) + max(0, min(b1, cj[j]) - a1);
-            }
-            // ---- pair labels: one compare per plane, the reads' bits arrive as the ballot; lane q keeps pair q's planes
-            unsigned yl[C::kPSlots], yh[C::kPSlots], zl[C::kPSlots], zh[C::kPSlots];
-#pragma unroll
-            for (int s = 0; s < C::kPSlots; ++s) { yl[s] = 0; yh[s] = 0; zl[s] = 0; zh[s] = 0; }
-            static_for<1, NM>([&](auto jc) {
-                constexpr int j = decltype(jc)::value;
-                if (j < n) {                                                       // (wave-uniform)
-                    static_for<0, j>([&](auto ic) {
-                        constexpr int i = decltype(ic)::value;
-                        constexpr int q = j * (j - 1) / 2 + i, s = q >> 6, ql = q & 63;
-                        const int dd = cov[j] - cov[i];
-                        const int hi = __builtin_amdgcn_readlane(hi_q[s], ql), lo = __builtin_amdgcn_readlane(lo_q[s], ql);
-                        const u64 y = __ballot(dd >= hi) & vmask, z = __ballot(dd <= lo) & vmask;
-                        write_lane<ql>(yl[s], (unsigned)y); write_lane<ql>(yh[s], (unsigned)(y >> 32));
-                        write_lane<ql>(zl[s], (unsigned)z); write_lane<ql>(zh[s], (unsigned)(z >> 32));
-                    });
-                }
-            });
-#pragma unroll
-            for (int s = 0; s < C::kPSlots; ++s) {
-                const int q = s * 64 + lane;
-                if (q < npairs) {
-                    amb[s] += (unsigned)(__popc(~(yl[s] | zl[s]) & (unsigned)vmask) + __popc(~(yh[s] | zh[s]) & (unsigned)(vmask >> 32)));   // neither label (:500-506)
-                    L.planes[q] = make_uint4(yl[s], yh[s], zl[s], zh[s]);
-                }
-            }
-            dp_sync<64>();
-            // ---- out(i,j,k) (:509-528): the two labels exclude each other
-#pragma unroll
-            for (int s = 0; s < C::kTSlots; ++s) {
-                const int tt = s * 64 + lane;
-                if (tt < ntri) {
-                    const unsigned tq = tri_q[tt];
-                    const uint4 a = L.planes[tq & 255], b = L.planes[tq >> 8];
-                    outc[s] += (unsigned)(__popc((a.x & b.z) | (a.z & b.x)) + __popc((a.y & b.w) | (a.w & b.y)));    // (disjoint: lo < hi)
-                }
-            }
-            dp_sync<64>();
-            l0 += m;
-        }
-        // a read outside the lane range has no coverage in the window: ambiguous exactly where lo < 0 (only tau = 1)
-#pragma unroll
-        for (int s = 0; s < C::kPSlots; ++s) {
-            const int q = s * 64 + lane;
-            if (q < npairs) L.in[q] = -(int)((i64)amb[s] + (lo_q[s] < 0 ? (i64)d.outside : 0));
-        }
-#pragma unroll
-        for (int s = 0; s < C::kTSlots; ++s) {
-            const int tt = s * 64 + lane;
-            if (tt < ntri) L.out[tt] = outc[s];
-        }
-        dp_sync<64>();
-        const int chain = dp_solve_push<64, NM>(n, L.out, L.in, L.M, L.A, L.cy, support, chosen + d.c0 FSEG_DARG);
-        if (lane == 0) pr.chain[p] = chain;
-#ifdef FSEG_SCORE_TIMING
-        if (lane == 0) FSEG_PROB_TICK(p, t_prob0, d.lane_n, d.lane_n);
-#endif
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// S5 whole, for problems that see few reads (at most kFuseLanes -- in batches of many partitions that is every problem: a
-// DP window of a 500-read partition overlaps some 40 .. 130 of them): ONE WORKGROUP takes a problem from its candidates to
-// its chosen breakpoints without leaving LDS --
-//   pair thresholds (:490-495 as integer bounds) into registers, a thread keeps the pairs q = tid, tid + T, ..;
-//   per 64 reads: window coverage (get_cumulative_coverage :188-246) by (read, candidate range) threads -- every read's
-//     exon walk is cut into T/64 pieces that run side by side --, pair planes and ambiguity counts (:488-506), triple
-//     counts (:509-528) into a table of CntT counters (8 bit when no problem of the launch sees more than 255 reads);
-//   then the planes' LDS becomes M / in / A and dp_solve_push (:532-566, :592-594) runs on the count table where it lies.
-// Nothing of such a problem exists in global memory between its descriptor and its chosen flags: no coverage tiles, no
-// threshold / ambiguity / count arenas, no work items, no DP list entry.  (The arena path remains for problems that see
-// thousands of reads, where one problem has to be spread over many workgroups.)
-// ---------------------------------------------------------------------------------------------
-// A large-class workgroup wants eight wave slots and 57-78 KB of LDS at once.  Beside kernels of small workgroups on other
-// streams it is placed last, whatever the launch order (the dispatcher places what fits), and then the stage ends with the
-// large class running alone on a mostly empty chip.  k_gate is what the side stream runs first: one wave that waits until the
-// large class's workgroups have all started (they all fit the chip at once) or `max_ticks` of the 100 MHz clock have passed --
-// an exit every launch reaches -- so the small classes fill the space the large one leaves instead of taking it first.
-__global__ void __launch_bounds__(64) k_gate(Status *st, int which, unsigned grid, unsigned max_ticks, unsigned *signal_word, unsigned signal_gen) {
-    // signal_word: this is the first launch behind k_prob_emit on the main stream -- the problem list is complete and released
-    // (the kernel boundary): tell the side streams' waiters (k_wait_word)
-    if (signal_word && threadIdx.x == 0) __hip_atomic_store(signal_word, signal_gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    // grid: the large class's workgroups the plan has launched (8-bit instance, and for the start gate the 16-bit one's too), at
-    // most as many as fit the chip at once
-    const unsigned want = grid;
-    const unsigned *ctr = which == 2 ? &st->gate_wide : &st->gate;      // (2: the 16-bit instance's workgroups)
-    const unsigned long long t0 = wall_clock64();
-    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want && wall_clock64() - t0 < max_ticks && !stage_aborted(st))
-        __builtin_amdgcn_s_sleep(16);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Device-side fork and join of the scoring stage (round 5).  A dependency between two streams made of hipEventRecord +
-// hipStreamWaitEvent costs 10-15 us on this runtime (a marker packet on one queue, a barrier packet on the other): with the
-// stage's chains on three streams that was 31 of the 145 us between k_prob_emit's end and k_segments' start
-// (profiles/r04_config4_stage_timeline.txt).  Instead:
-//   fork: the side streams are forked EARLY by an event (before k_fix, or at the start of the piece that holds k_prob_emit: the
-//         event's latency hides behind the kernels in front of the stage) and then run k_wait_word: one wave that sleeps until
-//         the FIRST launch behind k_prob_emit on the main stream -- the plan's k_gate, else a k_signal -- has published this run's
-//         generation.  (Published by k_prob_emit's own last workgroup the side streams started 5 us earlier, but a release
-//         fence per workgroup -- buffer_wbl2 sc1: the XCD's whole L2 is searched for dirty lines, by 600 waves -- took the kernel
-//         from 17 to 106 us: the release that costs nothing is the one at a kernel's end.)
-//   join: the last launch of a side chain is k_signal (the chain's generation, stored with release order once the kernels in
-//         front of it on that stream have ended), and the main stream runs k_wait_word on those words in front of k_segments.
-// Every waiter has an exit every launch reaches: after `max_ticks` of the 100 MHz clock it raises kErrSyncTimeout and
-// Status::sync_abort -- the scoring kernels behind it end at once (their lists may not exist yet) and the host reruns the batch
-// with events (FSEG_DEV_SYNC=0).  A waiter must never sit on the hardware queue of the stream it waits for: the process's
-// fourth stream shares a queue with the first, so only side streams 0 and 1 take waiters; a third keeps events.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool gen_reached(unsigned have, unsigned want) { return (int)(have - want) >= 0; }
-__global__ void __launch_bounds__(64) k_wait_word(Status *st, const unsigned *words, int n_words, unsigned gen, unsigned max_ticks) {
-    const int lane = lane_id();
-    const unsigned *w = words + (lane < n_words ? lane : 0);
-    const unsigned long long t0 = wall_clock64();
-    bool ok = false;
-    for (;;) {
-        ok = gen_reached(__hip_atomic_load(w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT), gen);
-        if (__all(ok) || wall_clock64() - t0 >= max_ticks) break;
-        __builtin_amdgcn_s_sleep(8);
-    }
-    if (!__all(ok) && lane == 0) {
-        __hip_atomic_store(&st->sync_abort, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        atomicOr(&st->err, kErrSyncTimeout);
-    }
-}
-__global__ void __launch_bounds__(64) k_signal(unsigned *word, unsigned gen) {
-    if (threadIdx.x == 0) __hip_atomic_store(word, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-}
-template <int NM> struct SolveCfg {
-    static constexpr int kThreads = ScoreCfg<NM>::kThreads;
-    static constexpr int kSlots = ScoreCfg<NM>::kSlots;
-    static constexpr int kRanges = kThreads / 64;                 // candidate ranges a read's coverage walk is cut into
-    // waves per SIMD asked of the register allocator (HIP's second launch bound): the kernel is mostly waiting (descriptor
-    // -> candidates -> exon block -> LDS phases -> DP chain), so what it needs is many problems in flight, not many
-    // registers per thread; the big class must fit two 8-wave workgroups per CU
-#ifndef FSEG_SOLVE_OCC
-#define FSEG_SOLVE_OCC 1
-#endif
-#ifndef FSEG_SOLVE_OCC32
-#define FSEG_SOLVE_OCC32 5      // (96 registers, five workgroups of the mid class per CU: 74 -> 70 us on config4; six spill and lose it again)
-#endif
-#ifndef FSEG_SOLVE_OCC16
-#define FSEG_SOLVE_OCC16 5
-#endif
-    static constexpr int kMinBlocks = !FSEG_SOLVE_OCC ? 1 : (NM <= 16 ? FSEG_SOLVE_OCC16 : (NM <= 32 ? FSEG_SOLVE_OCC32 : 4));
-};
-// LDS of a k_solve workgroup: the pair planes (later the DP's M | in | A), a round's coverage rows, the count table.  (Round 4
-// tried the planes IN the coverage rows' LDS -- 25 -> 16 KB for the mid class, 55 -> 39 KB for the large one: the planes then wait
-// in registers across a barrier, the kernels sit at their register caps, and the spills cost 12-17 % per problem: DESIGN section 8.)
-inline size_t solve_shared_bytes(int nm, int cov_stride) {
-    const size_t planes = (size_t)nm * (nm - 1) / 2 * 16, cov = (size_t)kSub * cov_stride * 4;
-    return (planes + cov + 15) & ~(size_t)15;
-}
-// a problem's slot of the hand-over arena (k_solve<.., SPLIT> -> k_dpw): in() per pair, the count table
-constexpr int kDpxHeader = 0;
-__host__ __device__ inline size_t dpx_in_bytes(int nm) { return ((size_t)nm * (nm - 1) / 2 * 4 + 15) & ~(size_t)15; }
-inline size_t dpx_slot_bytes(int nm, int cnt_bytes) {
-    const size_t tri = (size_t)nm * (nm - 1) * (nm - 2) / 6;
-    return (kDpxHeader + dpx_in_bytes(nm) + ((tri * cnt_bytes + 15) & ~(size_t)15) + 255) & ~(size_t)255;
-}
-inline size_t solve_lds_for(int nm, int cov_stride, int cnt_bytes) {
-    const size_t tri = (size_t)nm * (nm - 1) * (nm - 2) / 6;
-    return (solve_shared_bytes(nm, cov_stride) + ((tri + 15) & ~(size_t)15) * cnt_bytes + 15) & ~(size_t)15;
-}
-// SPLIT: the workgroup ends when its rounds are over -- the problem's count table and in() go to its slot of the hand-over
-// arena (dpx_slot) and k_dpw, the next launch on the stream, does the DP with one wave and a fraction of the LDS.
-template <int NM, typename CntT, typename V, bool SPLIT>
-__global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBlocks) k_solve(Status *st, int cls, int nm, i64 lb_h, i64 ln_h, ProblemArrays pr,
-                                                                  const ProbDesc *desc, i64 prob_cap, const int *cand_y,
-                                                                  const int2 *__restrict__ lane_lx, const int2 *__restrict__ lex,
-                                                                  const double *h_table, int h_len, double tau, const int2 *thr_tab,
-                                                                  int support, unsigned char *chosen,
-                                                                  unsigned char *dpx, i64 dpx_stride,
-                                                                  const int *__restrict__ wide_items FSEG_TPARAM) {
-    using C = SolveCfg<NM>;
-    constexpr int T = C::kThreads, NR = C::kRanges;
-    constexpr int PACK = 4 / (int)sizeof(CntT);                    // counters per 32-bit read-modify-write
-    extern __shared__ __align__(16) unsigned char smem[];
-    __shared__ int cy_s[NM + 4];
-    __shared__ int iend_s[NM + 4];
-    __shared__ int2 act_s[sizeof(CntT) == 1 ? kFuseLanes + 1 : kFuseLanesWide + 1];   // reads with coverage in the window: (first exon that meets it, how many do)
-    __shared__ int act_wave[T / 64];
-    const int rt_pairs = nm * (nm - 1) / 2;
-    constexpr int rt_stride = NM + 1;             // compile-time row stride (odd: rows do not collide on LDS banks)
-    uint4 *planes = reinterpret_cast<uint4 *>(smem);                                         // rt_pairs * 16 B; later M | in | A
-    unsigned *cov = reinterpret_cast<unsigned *>(smem + (size_t)rt_pairs * 16);              // kSub * rt_stride * 4 B
-    const unsigned shared_b = (unsigned)rt_pairs * 16 + (unsigned)(kSub * rt_stride * 4);
-    CntT *cnt = reinterpret_cast<CntT *>(smem + ((shared_b + 15) & ~15u));                   // C(nm,3) counters (solve_shared_bytes)
-    V *M = reinterpret_cast<V *>(smem);
-    int *in_s = reinterpret_cast<int *>(M + rt_pairs);
-    unsigned char *A = reinterpret_cast<unsigned char *>(in_s + rt_pairs);
-    // the DP is one wave's (dp_solve_wave) except where its registers would not fit: the large class with 64-bit sums
-    constexpr bool kWaveDp = NM <= 32 || sizeof(V) == 4;
-    if (NM == kNMax && threadIdx.x == 0) { atomicAdd(&st->gate, 1u); if (sizeof(CntT) != 1) atomicAdd(&st->gate_wide, 1u); }   // placed: see k_gate
-    // (lb_h >= 0: the host knows the lists' sizes -- the batch has been sized --, and the status record is not on the way to the first problem)
-    if (lb_h < 0 && (i64)st->n_prob > prob_cap) return;              // lists incomplete (a run that only sizes the arenas)
-    // cls < 0: every solve list (batches of few problems: one launch instead of three)
-    const i64 list_base = lb_h >= 0 ? lb_h : (cls <= 0 ? 0 : (cls == 1 ? (i64)st->solve_cls[0] : (i64)st->solve_cls[0] + (i64)st->solve_cls[1]));
-    const i64 list_n = lb_h >= 0 ? ln_h : (cls < 0 ? (i64)st->solve_cls[0] + (i64)st->solve_cls[1] + (i64)st->solve_cls[2] : (i64)st->solve_cls[cls]);
-    const int r_lane = threadIdx.x & 63, w_rng = wave_id();
-    const bool own_wg = (i64)gridDim.x >= list_n;                    // a workgroup per problem (workgroup-uniform)
-    const unsigned aborted = stage_aborted(st);                      // (a waiter in front of this launch gave up: the lists may not exist)
-#ifdef FSEG_SCORE_TIMING
-    // diagnostic build: phase clocks of the class given by tacc[15] (slots 0..5 scoring phases, 8..12 the DP's)
-    __shared__ unsigned long long tick_sink[16];
-    const bool timed = (int)tacc[15] == cls;
-    unsigned long long *tk = timed ? tacc : tick_sink;
-    unsigned long long *dp_tacc = tk; unsigned long long dt_prev = wall_clock64();
-#define FSEG_STICK(i) FSEG_DTICK(i)
-#else
-#define FSEG_STICK(i)
-#endif
-    for (i64 tt = blockIdx.x; tt < list_n; tt += gridDim.x) {         // static stride; the lists are in candidate order
-#ifdef FSEG_SCORE_TIMING
-        const unsigned long long t_prob0 = wall_clock64();
-#endif
-        // (wide_items: this launch goes over the list's problems that see more than kFuseLanes reads only -- list_n of them)
-        if (wide_items && aborted) return;                           // (the list of wide problems is an index into the records: not followed blindly)
-        const i64 t = wide_items ? (i64)uni(wide_items[list_base + tt]) : tt;
-        const ProbDesc d = FSEG_LOAD_DESC(desc + list_base + t);    // (the list's own copy of the record: k_prob_emit)
-        if (aborted) return;                                         // (workgroup-uniform)
-        const int p = d.w0;
-        const int n = d.n;
-        __syncthreads();                                             // the previous problem's DP is done with LDS
-        FSEG_STICK(0);
-        unsigned char *slot = SPLIT ? dpx + t * dpx_stride : nullptr;           // (dpx: the class's first slot)
-        if (n > nm || n > NM) { if (threadIdx.x == 0) atomicOr(&st->err, kErrOverflowNm); continue; }
-        // a list's problems are shared by two launches: the 8-bit counters take those that KEEP at most 255 reads (a counter
-        // counts reads with coverage in the window: about two thirds of those the problem sees), the 16-bit ones the rest --
-        // k_prob_range has counted, the record says whose the problem is.
-        if ((d.kind == kKindFusedWide) != (sizeof(CntT) != 1)) continue;
-        if (d.lane_n > kFuseLanesWide) { if (threadIdx.x == 0) atomicOr(&st->err, kErrNeedWideDp); continue; }
-        const int npairs = n * (n - 1) / 2, ntri = n * (n - 1) * (n - 2) / 6;
-        const int *cy = cand_y + d.c0;
-        for (int j = threadIdx.x; j < n; j += T) cy_s[j] = cy[j];
-        {
-            uint4 *z = reinterpret_cast<uint4 *>(cnt);
-            for (int x = threadIdx.x; x < (ntri * (int)sizeof(CntT) + 15) / 16; x += T) z[x] = make_uint4(0, 0, 0, 0);
-        }
-        __syncthreads();
-        // this thread's pairs: (i, j), integer label bounds, ambiguity count -- in registers for the whole problem
-        // (Tried: the pairs loaded once per workgroup, the reads' exon ranges requested with the candidates and their first exon
-        // blocks with the threshold table -- three dependent loads instead of seven before the first round.  The registers that
-        // keeps alive spill (mid class 61 -> 77 us), and a problem alone on the chip is no faster for it: its time is the LDS
-        // phases and the DP, not these loads.)
-        int pi[C::kSlots], pj[C::kSlots], th_hi[C::kSlots], th_lo[C::kSlots];
-        unsigned amb_acc[C::kSlots];
-#pragma unroll
-        for (int s = 0; s < C::kSlots; ++s) {
-            const int q = s * T + threadIdx.x;
-            amb_acc[s] = 0; pi[s] = 0; pj[s] = 1; th_hi[s] = 0x7fffffff; th_lo[s] = -1;
-            if (q < npairs) {
-                const unsigned short ij = g_pair_ij[q];
-                pi[s] = ij & 255; pj[s] = ij >> 8;
-                label_thresholds_tab((i64)cy_s[pj[s]] - cy_s[pi[s]] + 1, thr_tab, h_table, h_len, tau, &th_hi[s], &th_lo[s]);
-            }
-        }
-        if (threadIdx.x < n) {
-            // iend_s[j] = number of i < j with cand_j - cand_i >= 5 (candidates ascending): binary search
-            int j = threadIdx.x, lim = cy_s[j] - 5, lo = 0, hi = j;
-            while (lo < hi) { int mid = (lo + hi) >> 1; if (cy_s[mid] <= lim) lo = mid + 1; else hi = mid; }
-            iend_s[j] = lo;
-        }
-        // ---- the reads that matter.  The lane range is a superset (reads sorted by first position, cut by a running maximum of
-        //      last positions): about a third of its reads have no exon in the window at all.  Such a read is `nay` for every pair
-        //      -- it adds nothing to out(), and to in() only where lo < 0 -- so the scoring rounds run over the others only, packed
-        //      densely (fewer 64-read rounds), and each of those arrives with the exons that meet the window already located:
-        //      exons are ordered, so they are consecutive -- the first with te >= cand_0 up to the last with ts < cand_{n-1}.
-        const int cp0 = d.g0 + cy_s[0], c_last = d.g0 + cy_s[n - 1];
-        int n_act = 0;
-        for (int l0 = 0; l0 < d.lane_n; l0 += T) {
-            const int l = l0 + (int)threadIdx.x;
-            const bool in = l < d.lane_n;
-#ifdef FSEG_ABLATE_COV
-            const int2 ex = make_int2(0, 0);                         // diagnostic (wrong results): no exon access at all, two lanes in three kept
-            int first_rel = 0, cnt = (l % 3) != 2;
-#else
-            const int2 ex = lane_lx[d.lane_lo + (in ? l : 0)];
-            int first_rel, cnt;
-            window_exons(lex, ex, cp0, c_last, &first_rel, &cnt);
-#endif
-            const int first = ex.x + first_rel;
-            const bool act = in && cnt > 0;
-            const u64 m = __ballot(act);
-            if ((threadIdx.x & 63) == 0) act_wave[threadIdx.x >> 6] = __popcll(m);
-            __syncthreads();
-            int base = n_act, tot = 0;
-            for (int w2 = 0; w2 < T / 64; ++w2) { const int v = act_wave[w2]; if (w2 < (int)(threadIdx.x >> 6)) base += v; tot += v; }
-            {
-                constexpr int kActCap = sizeof(CntT) == 1 ? kFuseLanes + 1 : kFuseLanesWide + 1;
-                const int slot = base + __popcll(m & ((1ULL << (threadIdx.x & 63)) - 1ULL));
-                if (act && slot < kActCap) act_s[slot] = make_int2(first, cnt);      // (beyond it: the other instance's problem)
-            }
-            n_act += tot;
-            __syncthreads();
-        }
-        // (k_prob_range has counted the same reads by the same test: an 8-bit instance never meets more than its counters hold)
-        if (sizeof(CntT) == 1 && n_act > kFuseLanes) { if (threadIdx.x == 0) atomicOr(&st->err, kErrWideMissed); continue; }      // (workgroup-uniform)
-        FSEG_STICK(1);
-        // this thread's share of a round's coverage: read r_lane, candidates [ja, jb) of 1 .. n-1 (at most kCovJ of them)
-        constexpr int kCovJ = (NM - 1 + NR - 1) / NR;
-        const int ja = 1 + (int)((i64)(n - 1) * w_rng / NR), jb = 1 + (int)((i64)(n - 1) * (w_rng + 1) / NR);
-        int cjv[kCovJ];
-#pragma unroll
-        for (int u = 0; u < kCovJ; ++u) cjv[u] = ja + u < jb ? d.g0 + cy_s[ja + u] : cp0;     // beyond the share: an empty window
-        for (int r0 = 0; r0 < n_act; r0 += kSub) {
-            int n_valid = n_act - r0;
-            if (n_valid > kSub) n_valid = kSub;
-            // ---- A: window coverage cov[r][j] = positions of the read's closed exons in [cand_0, cand_j)
-            //      (get_cumulative_coverage :188-246) = sum over its exons of |[ts, te] n [cand_0, cand_j)|, over the few exons that
-            //      meet the window (two per step: their loads depend on nothing but the LDS record, so they fly together)
-            {
-                const bool valid = r_lane < n_valid;
-                const int2 a = act_s[r0 + (valid ? r_lane : 0)];
-                int acc[kCovJ];
-#pragma unroll
-                for (int u = 0; u < kCovJ; ++u) acc[u] = 0;
-#ifdef FSEG_ABLATE_COV
-                const int e_end = 0;
-#else
-                const int e_end = valid ? a.y : 0;
-#endif
-                for (int e = 0; e < e_end; e += 4) {
-                    // four exons per round trip (what lies beyond the read's own exons is masked below; the arrays are padded);
-                    // the second pair is worked on only if some read of the wave has it
-                    const int4u x01 = *reinterpret_cast<const int4u *>(lex + a.x + e), x23 = *reinterpret_cast<const int4u *>(lex + a.x + e + 2);
-                    {
-                        const int a0 = max(x01.x, cp0), b0 = x01.y + 1;                     // closed exon -> half-open end
-                        const int a1 = max(x01.z, cp0), b1 = e + 1 < e_end ? x01.w + 1 : a1;  // (an odd count: the second slot is empty)
-#pragma unroll
-                        for (int v = 0; v < kCovJ; ++v) acc[v] += max(0, min(b0, cjv[v]) - a0) + max(0, min(b1, cjv[v]) - a1);
-                    }
-                    if (e + 2 < e_end) {
-                        const int a0 = max(x23.x, cp0), b0 = x23.y + 1;
-                        const int a1 = max(x23.z, cp0), b1 = e + 3 < e_end ? x23.w + 1 : a1;
-#pragma unroll
-                        for (int v = 0; v < kCovJ; ++v) acc[v] += max(0, min(b0, cjv[v]) - a0) + max(0, min(b1, cjv[v]) - a1);
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < kCovJ; ++u) if (ja + u < jb) cov[r_lane * rt_stride + ja + u] = (unsigned)acc[u];
-                if (w_rng == 0) cov[r_lane * rt_stride] = 0;
-            }
-            lds_barrier();
-            FSEG_STICK(2);
-            // ---- B: pair planes (read b of a plane word lands on bit 31-b, as in k_score) -----------------------------
-            const int nv1 = n_valid - 32;
-            const unsigned valid0 = n_valid >= 32 ? 0xffffffffu : (n_valid > 0 ? ~(0xffffffffu >> n_valid) : 0u);
-            const unsigned valid1 = nv1 >= 32 ? 0xffffffffu : (nv1 > 0 ? ~(0xffffffffu >> nv1) : 0u);
-#pragma unroll
-            for (int s = 0; s < C::kSlots; ++s) {
-                const int q = s * T + threadIdx.x;
-                if (q < npairs) {
-                    const int i = pi[s], j = pj[s], hi = th_hi[s], lo = th_lo[s];
-                    unsigned y0 = 0, z0 = 0, y1 = 0, z1 = 0;
-#define FSEG_SHIFT_IN(acc, cmp, a, b) asm("v_cmp_" cmp "_i32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(a), "v"(b) : "vcc")
-                    // (a round's last reads rarely fill a word: a problem keeps ~80 reads, 64 + 16 -- the partly filled word
-                    // costs its reads, not thirty-two; its bits are then moved up to where the full words' are)
-                    if (n_valid >= 32) {
-#pragma unroll
-                        for (int b = 0; b < 32; ++b) {
-                            int dd = (int)(cov[b * rt_stride + j] - cov[b * rt_stride + i]);
-                            FSEG_SHIFT_IN(y0, "ge", dd, hi);
-                            FSEG_SHIFT_IN(z0, "le", dd, lo);
-                        }
-                    } else {
-                        for (int b = 0; b < n_valid; ++b) {
-                            int dd = (int)(cov[b * rt_stride + j] - cov[b * rt_stride + i]);
-                            FSEG_SHIFT_IN(y0, "ge", dd, hi);
-                            FSEG_SHIFT_IN(z0, "le", dd, lo);
-                        }
-                        y0 <<= 32 - n_valid; z0 <<= 32 - n_valid;          // (1 <= n_valid <= 31)
-                    }
-                    if (nv1 >= 32) {
-#pragma unroll
-                        for (int b = 0; b < 32; ++b) {
-                            int dd = (int)(cov[(32 + b) * rt_stride + j] - cov[(32 + b) * rt_stride + i]);
-                            FSEG_SHIFT_IN(y1, "ge", dd, hi);
-                            FSEG_SHIFT_IN(z1, "le", dd, lo);
-                        }
-                    } else if (nv1 > 0) {
-                        for (int b = 0; b < nv1; ++b) {
-                            int dd = (int)(cov[(32 + b) * rt_stride + j] - cov[(32 + b) * rt_stride + i]);
-                            FSEG_SHIFT_IN(y1, "ge", dd, hi);
-                            FSEG_SHIFT_IN(z1, "le", dd, lo);
-                        }
-                        y1 <<= 32 - nv1; z1 <<= 32 - nv1;
-                    }
-#undef FSEG_SHIFT_IN
-                    y0 &= valid0; z0 &= valid0; y1 &= valid1; z1 &= valid1;     // rows beyond the problem's reads hold nothing
-                    planes[q] = make_uint4(y0, y1, z0, z1);
-                    amb_acc[s] += __popc(~(y0 | z0) & valid0) + __popc(~(y1 | z1) & valid1);
-                }
-            }
-            lds_barrier();
-            FSEG_STICK(3);
-            // ---- C: triples; the (j,k) pairs are enumerated with j descending (lanes of a wave share the trip count) ---
-#pragma unroll
-            for (int s = 0; s < C::kSlots; ++s) {
-                const int r = s * T + threadIdx.x;
-                if (r >= npairs) continue;
-                const int m = pj[s], x = pi[s];                       // pair r = (x, m): m = n-1-j in [1, n-1], x = k-j-1 in [0, m)
-                const int j = n - 1 - m, kk = j + 1 + x;
-                if (j == 0 || cy_s[kk] - cy_s[j] < 5) continue;       // dp(): segment too small (:540)
-                const uint4 B = planes[kk * (kk - 1) / 2 + j];
-                if ((B.x | B.y | B.z | B.w) == 0) continue;
-                const int tbase = kk * (kk - 1) * (kk - 2) / 6 + j * (j - 1) / 2;
-                const int abase = j * (j - 1) / 2;
-                const int i_end = iend_s[j];                          // i with cand_j - cand_i >= 5 (:540), a prefix
-                // (a read is never yea AND nay of one pair -- lo < hi --, so the two cross terms of a plane word are disjoint: one
-                // popcount of their union, six instructions per triple and round instead of eight)
-                // (a round of at most 32 reads has nothing in the second words: half the instructions)
-#define FSEG_TRI_CNT(Av) (HALF ? __popc(((Av).x & B.z) | ((Av).z & B.x)) \
-                               : __popc(((Av).x & B.z) | ((Av).z & B.x)) + __popc(((Av).y & B.w) | ((Av).w & B.y)))
-                CntT *o = cnt + tbase;
-                auto row = [&](auto half_c) {
-                    constexpr bool HALF = decltype(half_c)::value;
-                    int i = 0;
-                    for (; i < i_end && ((tbase + i) & (PACK - 1)); ++i) {          // up to a 32-bit boundary of the table
-                        const uint4 Av = planes[abase + i];
-                        o[i] = (CntT)(o[i] + FSEG_TRI_CNT(Av));
-                    }
-                    for (; i + PACK <= i_end; i += PACK) {                // PACK counters per 32-bit read-modify-write: a counter
-                        unsigned add = 0;                                 // never exceeds the reads of the problem, so no carry
-#pragma unroll
-                        for (int u = 0; u < PACK; ++u) { const uint4 Av = planes[abase + i + u]; add |= (unsigned)FSEG_TRI_CNT(Av) << (8 * (int)sizeof(CntT) * u); }
-                        *reinterpret_cast<unsigned *>(o + i) += add;
-                    }
-                    for (; i < i_end; ++i) {
-                        const uint4 Av = planes[abase + i];
-                        o[i] = (CntT)(o[i] + FSEG_TRI_CNT(Av));
-                    }
-                };
-                if (n_valid <= 32) row(std::true_type{}); else row(std::false_type{});
-#undef FSEG_TRI_CNT
-            }
-            lds_barrier();
-            FSEG_STICK(4);
-        }
-        // ---- DP on the tables where they lie: the planes' LDS becomes M | in | A ---------------------------------------
-        // a read outside the lane range, or dropped above, has no coverage in the window: ambiguous exactly where lo < 0 (only tau = 1)
-        int in_val[C::kSlots];
-#pragma unroll
-        for (int s = 0; s < C::kSlots; ++s) in_val[s] = -(int)((i64)amb_acc[s] + (th_lo[s] < 0 ? (i64)d.outside + (d.lane_n - n_act) : 0));
-        __syncthreads();
-        if constexpr (SPLIT) {
-            // hand-over: in() per pair (kDeadPair where the segment is too small, :540; the pair (0, end) keeps its value: it is
-            // "no cut", :560, and never a link) and the count table as it lies (whose counters these are follows from the reads
-            // the problem keeps: k_dpw decides as this kernel did)
-            int *g_in = reinterpret_cast<int *>(slot + kDpxHeader);
-#pragma unroll
-            for (int s = 0; s < C::kSlots; ++s) {
-                const int q = s * T + threadIdx.x;
-                if (q < npairs) {
-                    const bool dead = cy_s[pj[s]] - cy_s[pi[s]] < 5 && !(pi[s] == 0 && pj[s] == n - 1);
-                    g_in[q] = dead ? kDeadPair : in_val[s];
-                }
-            }
-            {
-                uint4 *g_out = reinterpret_cast<uint4 *>(slot + kDpxHeader + dpx_in_bytes(nm));
-                const uint4 *l_out = reinterpret_cast<const uint4 *>(cnt);
-                for (int x = threadIdx.x; x < (ntri * (int)sizeof(CntT) + 15) / 16; x += T) g_out[x] = l_out[x];
-            }
-            FSEG_STICK(9);
-        } else if constexpr (kWaveDp) {
-            // the pairs' owners hand each pair over whole: in(b,c), or kDeadPair where the segment is too small (:540; the pair
-            // (0, end) keeps its value: it is "no cut", :560, and never a link), and c
-#pragma unroll
-            for (int s = 0; s < C::kSlots; ++s) {
-                const int q = s * T + threadIdx.x;
-                if (q < npairs) {
-                    const bool dead = cy_s[pj[s]] - cy_s[pi[s]] < 5 && !(pi[s] == 0 && pj[s] == n - 1);
-                    in_s[q] = dead ? kDeadPair : in_val[s];
-                    A[q] = (unsigned char)pj[s];
-                }
-            }
-            __syncthreads();
-            FSEG_STICK(9);
-            // The other waves are done with this problem.  When every problem of the list has a workgroup of its own (the usual
-            // launch) they END here, and what they held is free for the next workgroup while wave 0 walks the DP's chain; else
-            // they go on to the next problem's descriptor and wait at the barrier at the top of the loop.
-            if (w_rng != 0) { if (own_wg) return; continue; }
-#ifdef FSEG_ABLATE_DP
-            if (own_wg) return;          // diagnostic (wrong results): what the stage takes when a workgroup's LDS is free once its rounds are over
-#endif
-            const int chain = dp_solve_wave<NM>(n, cnt, in_s, M, A, support, chosen + d.c0 FSEG_DARG);
-            if (threadIdx.x == 0) pr.chain[p] = chain;
-        } else {
-#pragma unroll
-        for (int s = 0; s < C::kSlots; ++s) { const int q = s * T + threadIdx.x; if (q < npairs) in_s[q] = in_val[s]; }
-        __syncthreads();
-        FSEG_STICK(9);
-        const int chain = dp_solve_push<T, NM>(n, cnt, in_s, M, A, cy_s, support, chosen + d.c0 FSEG_DARG);
-        if (threadIdx.x == 0) pr.chain[p] = chain;
-        }
-#ifdef FSEG_SCORE_TIMING
-        if (threadIdx.x == 0) FSEG_PROB_TICK(p, t_prob0, d.lane_n, n_act);
-#endif
-    }
-#undef FSEG_STICK
-}
-
-// ---------------------------------------------------------------------------------------------
-// The DP of the problems k_solve<.., SPLIT> has handed over: ONE WAVE per problem (a workgroup of one wave), the problem's
-// in() and count table copied from its slot into LDS, then dp_solve_wave.  Why a launch of its own: a k_solve workgroup
-// holds 25 KB (mid class) to 55-78 KB (large) of LDS and its DP needs a third of that and one wave of its four or eight;
-// as the tail of the same workgroup (round 4's first version: the other waves ended early, which frees their registers --
-// tools/probes/exit_probe.hip -- but not the workgroup's LDS) the large class's 385 workgroups sat on half of the chip's
-// LDS for the 20-25 us of their DPs while the mid class waited for room (tools/prob_ticks.py: 250 mid-class problems in
-// flight beside them, 1 250 once they were gone).  OutT says whose problems: the 8-bit instance's or the 16-bit one's.
-// ---------------------------------------------------------------------------------------------
-constexpr i64 kSplitGridCap = 1 << 20;      // workgroups of a split-path launch: k_dpw's workgroup b does problem b of its list, so lists beyond this are not split
-inline size_t dpw_lds_for(int nm, int key_bytes, int cnt_bytes) {
-    const size_t pairs = (size_t)nm * (nm - 1) / 2, tri = (size_t)nm * (nm - 1) * (nm - 2) / 6;
-    return ((pairs * key_bytes + 15) & ~(size_t)15) + ((pairs * 4 + 15) & ~(size_t)15) + ((pairs + 15) & ~(size_t)15) + ((tri * cnt_bytes + 15) & ~(size_t)15);
-}
-template <int NM, typename OutT, typename V>
-__global__ void __launch_bounds__(64) k_dpw(Status *st, int nm, i64 list_base, i64 list_n, ProblemArrays pr, const ProbDesc *desc,
-                                            const unsigned char *dpx, i64 dpx_stride,
-                                            int support, unsigned char *chosen, const int *__restrict__ wide_items FSEG_TPARAM) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int lane = lane_id();
-    if ((i64)blockIdx.x >= list_n) return;
-    const unsigned aborted = stage_aborted(st);
-    if (wide_items && aborted) return;                  // (the list of wide problems is an index into the records: not followed blindly)
-    const i64 t = wide_items ? (i64)uni(wide_items[list_base + blockIdx.x]) : (i64)blockIdx.x;
-#ifdef FSEG_SCORE_TIMING
-    const unsigned long long t_dp0 = wall_clock64();
-#endif
-    const unsigned char *slot = dpx + t * dpx_stride;
-    const ProbDesc d = FSEG_LOAD_DESC(desc + list_base + t);
-    const int n = d.n;
-    if (aborted) return;
-    if (n > nm || n > NM || n < 3 || d.lane_n > kFuseLanesWide) return;         // (k_solve has raised the error)
-    if ((d.kind == kKindFusedWide) != (sizeof(OutT) != 1)) return;               // whose problem (k_prob_range)
-    const int npairs = n * (n - 1) / 2, ntri = n * (n - 1) * (n - 2) / 6;
-    const int rt_pairs = nm * (nm - 1) / 2;
-    V *M = reinterpret_cast<V *>(smem);
-    int *in_s = reinterpret_cast<int *>(smem + (((size_t)rt_pairs * sizeof(V) + 15) & ~(size_t)15));
-    unsigned char *A = reinterpret_cast<unsigned char *>(in_s) + (((size_t)rt_pairs * 4 + 15) & ~(size_t)15);
-    OutT *out_s = reinterpret_cast<OutT *>(A + (((size_t)rt_pairs + 15) & ~(size_t)15));
-    {
-        const int *g_in = reinterpret_cast<const int *>(slot + kDpxHeader);
-        for (int q = lane; q < npairs; q += 64) { in_s[q] = g_in[q]; A[q] = (unsigned char)(g_pair_ij[q] >> 8); }
-        const uint4 *g_out = reinterpret_cast<const uint4 *>(slot + kDpxHeader + dpx_in_bytes(nm));
-        uint4 *l_out = reinterpret_cast<uint4 *>(out_s);
-        const int n16 = (ntri * (int)sizeof(OutT) + 15) / 16;
-        for (int x0 = 0; x0 < n16; x0 += 64 * 8) {                              // eight 16-byte loads per lane in flight
-            uint4 v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { const int x = x0 + u * 64 + lane; v[u] = g_out[x < n16 ? x : 0]; }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { const int x = x0 + u * 64 + lane; if (x < n16) l_out[x] = v[u]; }
-        }
-    }
-    dp_sync<64>();
-#ifdef FSEG_SCORE_TIMING
-    __shared__ unsigned long long tick_sink[16];
-    unsigned long long *dp_tacc = tick_sink; unsigned long long dt_prev = 0;
-#endif
-    // (s_setprio 3 for this wave -- a chain of dependent instructions that its class's chain ends with -- made the stage slower:
-    // config3 0.210 -> 0.245-0.270 ms, config4 0.147 -> 0.151)
-    const int chain = dp_solve_wave<NM>(n, out_s, in_s, M, A, support, chosen + d.c0 FSEG_DARG);
-    if (lane == 0) pr.chain[d.w0] = chain;
-#ifdef FSEG_SCORE_TIMING
-    if (lane == 0 && (size_t)d.w0 < kTaccProbs) { unsigned long long *r_ = tacc + 16 + 4 * kTaccProbs + 4 * (size_t)d.w0; r_[0] = wall_clock64() - t_dp0; r_[3] = t_dp0; }
-#endif
-}
-
-// ---------------------------------------------------------------------------------------------
-// Problems with kNMax < n <= kNHuge candidates (max_problem_size well above the default 50): the same scoring and
-// DP with the triple counters left in the global arena.  One workgroup owns a problem outright and walks all of its
-// coverage chunks itself, 32 reads at a time, so the counters are plain read-modify-writes (no atomics).  These are
-// the slow-but-complete kernels; they are only launched when a previous run of the batch met such a problem.
-// ---------------------------------------------------------------------------------------------
-constexpr int kHugeSub = 32;           // reads per step of the huge-problem scoring kernel (one plane word per label)
-constexpr size_t kHugeScoreLds = (size_t)(kNHuge * (kNHuge - 1) / 2) * 8 + (size_t)kHugeSub * (kNHuge + 1) * 4;
-__global__ void __launch_bounds__(512) k_score_huge(Status *st, const int *dp_items, ProblemArrays pr, const ProbDesc *desc,
-                                                    i64 prob_cap, i64 work_cap, const int *cand_y, const unsigned *cov_g,
-                                                    i64 cov_cap, const int2 *pair_thr, i64 pair_cap, unsigned *out_g,
-                                                    i64 tri_cap, unsigned *amb_g) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    uint2 *planes = reinterpret_cast<uint2 *>(smem);                                   // {yea, nay} per pair
-    unsigned *cov = reinterpret_cast<unsigned *>(smem + (size_t)(kNHuge * (kNHuge - 1) / 2) * 8);   // [read][j], stride kNHuge + 1
-    __shared__ int cy_s[kNHuge];
-    __shared__ int iend_s[kNHuge];
-    constexpr int T = 512, stride = kNHuge + 1;
-    if ((i64)st->n_work > work_cap || (i64)st->n_prob > prob_cap) return;              // sizing run
-    const i64 list_base = (i64)st->dp_cls[0] + (i64)st->dp_cls[1], list_n = (i64)st->dp_cls[2];
-    for (i64 t = blockIdx.x; t < list_n; t += gridDim.x) {
-        __syncthreads();
-        const int p = dp_items[list_base + t];
-        const ProbDesc d = load_desc(desc + p);
-        const int n = d.n;
-        if (n > kNHuge) continue;
-        const int npairs = n * (n - 1) / 2, ntri = n * (n - 1) * (n - 2) / 6;
-        const i64 poff = d.pair_off, toff = d.tri_off;
-        const int n_chunks = (d.lane_n + kLaneChunk - 1) / kLaneChunk;
-        if (poff + npairs > pair_cap || toff + ntri > tri_cap || d.cov_off + (i64)n_chunks * kLaneChunk * n > cov_cap) continue;
-        for (int j = threadIdx.x; j < n; j += T) cy_s[j] = cand_y[d.c0 + j];
-        __syncthreads();
-        if (threadIdx.x < n) {
-            int j = threadIdx.x, lim = cy_s[j] - 5, lo = 0, hi = j;
-            while (lo < hi) { int mid = (lo + hi) >> 1; if (cy_s[mid] <= lim) lo = mid + 1; else hi = mid; }
-            iend_s[j] = lo;                                        // number of i < j with cand_j - cand_i >= 5 (:540)
-        }
-        const bool zero_ambiguous = (pr.flags[p] & 1) != 0;
-        for (int r0 = 0; r0 < d.lane_n; r0 += kHugeSub) {
-            const int nr = d.lane_n - r0 < kHugeSub ? d.lane_n - r0 : kHugeSub;
-            const int chunk = r0 / kLaneChunk, in_chunk = r0 % kLaneChunk;
-            const unsigned *src = cov_g + d.cov_off + (i64)chunk * kLaneChunk * n + in_chunk;   // [j][256 reads]
-            __syncthreads();
-            for (int x = threadIdx.x; x < n * kHugeSub; x += T) {
-                const int j = x / kHugeSub, b = x % kHugeSub;
-                cov[b * stride + j] = b < nr ? src[(i64)j * kLaneChunk + b] : 0u;
-            }
-            __syncthreads();
-            const unsigned valid = nr >= 32 ? 0xffffffffu : ((1u << nr) - 1u);
-            for (int q = threadIdx.x; q < npairs; q += T) {
-                int i, j;
-                pair_decode(q, &i, &j);
-                const int2 th = pair_thr[poff + q];
-                unsigned y = 0, z = 0;
-                for (int b = 0; b < kHugeSub; ++b) {
-                    const int dd = (int)(cov[b * stride + j] - cov[b * stride + i]);
-                    y |= (unsigned)(dd >= th.x) << b;              // yea: covered fraction above the high threshold
-                    z |= (unsigned)(dd <= th.y) << b;              // nay: below the low threshold
-                }
-                y &= valid; z &= valid;
-                planes[q] = make_uint2(y, z);
-                const unsigned amb = __popc(~(y | z) & valid);
-                if (amb) amb_g[poff + q] += amb;                    // this workgroup owns the problem: plain update
-            }
-            __syncthreads();
-            // triples: thread = (j,k), loop over the i with cand_j - cand_i >= 5; counters of a (j,k) are contiguous
-            for (int r = threadIdx.x; r < npairs; r += T) {
-                int j, kk;
-                pair_decode(r, &j, &kk);
-                if (j == 0 || cy_s[kk] - cy_s[j] < 5) continue;
-                const uint2 B = planes[r];
-                if ((B.x | B.y) == 0) continue;
-                unsigned *o = out_g + toff + (i64)kk * (kk - 1) * (kk - 2) / 6 + j * (j - 1) / 2;
-                const int abase = j * (j - 1) / 2, i_end = iend_s[j];
-                for (int i = 0; i < i_end; ++i) {
-                    const uint2 A = planes[abase + i];
-                    const unsigned cnt = __popc((A.x & B.y) | (A.y & B.x));          // (disjoint: a read is never yea and nay of one pair)
-                    if (cnt) o[i] += cnt;
-                }
-            }
-        }
-        (void)zero_ambiguous;                                       // zero-coverage reads outside the lane range: added in the DP
-    }
-}
-
-constexpr size_t kHugeDpLds = (size_t)(kNHuge * (kNHuge - 1) / 2) * (8 + 4 + 1) + 16;
-__global__ void __launch_bounds__(512) k_dp_huge(Status *st, const int *dp_items, ProblemArrays pr, const ProbDesc *desc,
-                                                 i64 prob_cap, const int *cand_y, const unsigned *out_g, i64 tri_cap,
-                                                 const unsigned *amb_g, const int2 *pair_thr, i64 pair_cap, int support,
-                                                 unsigned char *chosen) {
-    constexpr int T = 512, kSlices = 4, kB = T / kSlices;          // thread = (b, c2 slice); kB == kNHuge
-    constexpr int kPairs = kNHuge * (kNHuge - 1) / 2;
-    extern __shared__ __align__(16) unsigned char smem[];
-    i64 *M = reinterpret_cast<i64 *>(smem);
-    int *in_s = reinterpret_cast<int *>(M + kPairs);
-    unsigned char *A = reinterpret_cast<unsigned char *>(in_s + kPairs);
-    __shared__ int cy_s[kNHuge];
-    __shared__ i64 part_v[T];
-    __shared__ unsigned char part_a[T];
-    __shared__ i64 top_v[T / 64];
-    __shared__ int top_key[T / 64];
-    if ((i64)st->n_prob > prob_cap) return;
-    const i64 list_base = (i64)st->dp_cls[0] + (i64)st->dp_cls[1], list_n = (i64)st->dp_cls[2];
-    const int b = 1 + threadIdx.x % kB, slice = threadIdx.x / kB;
-    for (i64 t = blockIdx.x; t < list_n; t += gridDim.x) {
-        __syncthreads();
-        const int p = dp_items[list_base + t];
-        const ProbDesc d = load_desc(desc + p);
-        const int n = d.n;
-        if (n > kNHuge) continue;
-        const int npairs = n * (n - 1) / 2, ntri = n * (n - 1) * (n - 2) / 6, end = n - 1;
-        const i64 poff = d.pair_off, toff = d.tri_off;
-        if (poff + npairs > pair_cap || toff + ntri > tri_cap) continue;
-        const unsigned *out_p = out_g + toff;
-        const i64 outside = d.outside;
-        const bool zamb = (pr.flags[p] & 1) != 0;
-        for (int j = threadIdx.x; j < n; j += T) cy_s[j] = cand_y[d.c0 + j];
-        for (int q = threadIdx.x; q < npairs; q += T)
-            in_s[q] = -(int)((i64)amb_g[poff + q] + ((zamb && pair_thr[poff + q].y < 0) ? outside : 0));
-        __syncthreads();
-#define FSEG_IN(a, bb) ((i64)in_s[(bb) * ((bb) - 1) / 2 + (a)])
-#define FSEG_M(a, bb) M[(bb) * ((bb) - 1) / 2 + (a)]
-        for (int x = threadIdx.x; x < end; x += T) {
-            FSEG_M(x, end) = cy_s[end] - cy_s[x] >= 5 ? FSEG_IN(x, end) : kNegInf;
-            A[end * (end - 1) / 2 + x] = 255;
-        }
-        __syncthreads();
-        for (int c = end - 1; c >= 2; --c) {
-            i64 best = kNegInf; int arg = 255;
-            const bool live = b < c && cy_s[c] - cy_s[b] >= 5;
-            if (live) {
-                const int base = c * (c - 1) / 2 + b;
-                for (int c2 = c + 1 + slice; c2 <= end; c2 += kSlices) {
-                    const i64 tail = FSEG_M(c, c2);
-                    const unsigned o = out_p[(i64)c2 * (c2 - 1) * (c2 - 2) / 6 + base];
-                    const bool ok = (tail != kNegInf) & ((i64)o >= (i64)support);
-                    const i64 cur = ok ? (i64)o + tail : kNegInf;
-                    const bool take = cur > best;
-                    best = take ? cur : best; arg = take ? c2 : arg;
-                }
-            }
-            part_v[threadIdx.x] = best; part_a[threadIdx.x] = (unsigned char)arg;
-            __syncthreads();
-            if (slice == 0 && b < c) {
-                i64 bv = best; int ba = arg;
-                for (int s2 = 1; s2 < kSlices; ++s2) {
-                    const i64 v = part_v[s2 * kB + b - 1]; const int a2 = part_a[s2 * kB + b - 1];
-                    if (v > bv || (v == bv && v != kNegInf && a2 < ba)) { bv = v; ba = a2; }
-                }
-                FSEG_M(b, c) = (live && bv != kNegInf) ? bv + FSEG_IN(b, c) : kNegInf;
-                A[c * (c - 1) / 2 + b] = (unsigned char)ba;
-            }
-            __syncthreads();
-        }
-        // top level (:560-566): first maximiser in (j, k) order, taken only if strictly better than no cut
-        i64 bv = kNegInf; int bkey = 0x7fffffff;
-        for (int q = threadIdx.x; q < npairs; q += T) {
-            int j, kx;
-            pair_decode(q, &j, &kx);
-            if (j < 1) continue;
-            if (cy_s[j] - cy_s[0] < 5 || cy_s[kx] - cy_s[j] < 5) continue;
-            const i64 tail = FSEG_M(j, kx);
-            const unsigned o = out_p[(i64)kx * (kx - 1) * (kx - 2) / 6 + j * (j - 1) / 2];
-            if (tail == kNegInf || (i64)o < (i64)support) continue;
-            const i64 cur = FSEG_IN(0, j) + (i64)o + tail;
-            const int key = j * 256 + kx;
-            if (cur > bv || (cur == bv && key < bkey)) { bv = cur; bkey = key; }
-        }
-        for (int dd = 32; dd >= 1; dd >>= 1) {
-            i64 ov = __shfl_xor(bv, dd); int ok2 = __shfl_xor(bkey, dd);
-            if (ov > bv || (ov == bv && ok2 < bkey)) { bv = ov; bkey = ok2; }
-        }
-        if (lane_id() == 0) { top_v[threadIdx.x >> 6] = bv; top_key[threadIdx.x >> 6] = bkey; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            for (int w = 1; w < T / 64; ++w)
-                if (top_v[w] > bv || (top_v[w] == bv && top_key[w] < bkey)) { bv = top_v[w]; bkey = top_key[w]; }
-            int chain = 0;
-            if (bv != kNegInf && bv > FSEG_IN(0, end)) {
-                int j = bkey >> 8, k = bkey & 255;
-                unsigned char *ch = chosen + d.c0;
-                ch[0] = 1;
-                for (;;) {
-                    ch[j] = 1; ch[k] = 1; ++chain;
-                    if (k == end) break;
-                    int k2 = A[k * (k - 1) / 2 + j];
-                    if (k2 == 255) break;
-                    j = k; k = k2;
-                }
-            }
-            pr.chain[p] = chain;
-        }
-#undef FSEG_IN
-#undef FSEG_M
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Problems with kNHuge < n <= kNGiant candidates (round 5: max_problem_size beyond ~115 used to be refused, although the CLI
-// -- like the reference's parse_args :108 -- accepts any value > 3 and optimize :475-568 has no size limit).  The same two
-// kernels as the huge class with every per-pair table in GLOBAL scratch (a piece per workgroup, sized for the run's largest
-// problem): the pair planes of the scoring kernel; M, in() and the argument (16 bits) of the DP.  Only the 32 reads' coverage
-// rows and the candidates' positions stay in LDS (dynamic: (32 + 2) * (n + 1) words).  One workgroup owns a problem; values
-// written by one wave and read by another are ordered by the workgroup's barriers (one CU, one L1).  Slow -- a thread walks its
-// pairs' c2 loop from global memory -- and complete; checked against the oracle at max_problem_size 150 and 300.
-// ---------------------------------------------------------------------------------------------
-constexpr int kGiantWgs = 64;              // workgroups (and scratch pieces) of a giant-kernel launch
-inline size_t giant_score_lds(int nm) { return (size_t)(2 * nm + kHugeSub * (nm + 1)) * 4; }
-inline size_t giant_dp_lds(int nm) { return (size_t)nm * 4; }
-inline size_t giant_scratch_bytes(int nm) {                 // per workgroup: max(planes, M + in + A)
-    const size_t pairs = (size_t)nm * (nm - 1) / 2;
-    return ((pairs * (8 + 4 + 2) + 255) & ~(size_t)255);
-}
-__global__ void __launch_bounds__(512) k_score_giant(Status *st, const int *dp_items, ProblemArrays pr, const ProbDesc *desc,
-                                                     i64 prob_cap, i64 work_cap, const int *cand_y, const unsigned *cov_g,
-                                                     i64 cov_cap, const int2 *pair_thr, i64 pair_cap, unsigned *out_g,
-                                                     i64 tri_cap, unsigned *amb_g, int nm, unsigned char *scratch, i64 scratch_stride) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    int *cy_s = reinterpret_cast<int *>(smem);
-    int *iend_s = cy_s + nm;
-    unsigned *cov = reinterpret_cast<unsigned *>(iend_s + nm);                 // [read][j], stride nm + 1
-    uint2 *planes = reinterpret_cast<uint2 *>(scratch + (i64)blockIdx.x * scratch_stride);   // {yea, nay} per pair
-    constexpr int T = 512;
-    const int stride = nm + 1;
-    if ((i64)st->n_work > work_cap || (i64)st->n_prob > prob_cap) return;              // sizing run
-    const i64 list_base = (i64)st->dp_cls[0] + (i64)st->dp_cls[1], list_n = (i64)st->dp_cls[2];
-    for (i64 t = blockIdx.x; t < list_n; t += gridDim.x) {
-        __syncthreads();
-        const int p = dp_items[list_base + t];
-        const ProbDesc d = load_desc(desc + p);
-        const int n = d.n;
-        if (n <= kNHuge || n > nm) continue;                                          // (the huge kernels' problems; nm covers the run's largest)
-        const int npairs = n * (n - 1) / 2;
-        const i64 ntri = (i64)n * (n - 1) * (n - 2) / 6;
-        const i64 poff = d.pair_off, toff = d.tri_off;
-        const int n_chunks = (d.lane_n + kLaneChunk - 1) / kLaneChunk;
-        if (poff + npairs > pair_cap || toff + ntri > tri_cap || d.cov_off + (i64)n_chunks * kLaneChunk * n > cov_cap) continue;
-        for (int j = threadIdx.x; j < n; j += T) cy_s[j] = cand_y[d.c0 + j];
-        __syncthreads();
-        for (int j = threadIdx.x; j < n; j += T) {
-            int lim = cy_s[j] - 5, lo = 0, hi = j;
-            while (lo < hi) { int mid = (lo + hi) >> 1; if (cy_s[mid] <= lim) lo = mid + 1; else hi = mid; }
-            iend_s[j] = lo;                                        // number of i < j with cand_j - cand_i >= 5 (:540)
-        }
-        for (int r0 = 0; r0 < d.lane_n; r0 += kHugeSub) {
-            const int nr = d.lane_n - r0 < kHugeSub ? d.lane_n - r0 : kHugeSub;
-            const int chunk = r0 / kLaneChunk, in_chunk = r0 % kLaneChunk;
-            const unsigned *src = cov_g + d.cov_off + (i64)chunk * kLaneChunk * n + in_chunk;   // [j][256 reads]
-            __syncthreads();
-            for (int x = threadIdx.x; x < n * kHugeSub; x += T) {
-                const int j = x / kHugeSub, b = x % kHugeSub;
-                cov[b * stride + j] = b < nr ? src[(i64)j * kLaneChunk + b] : 0u;
-            }
-            __syncthreads();
-            const unsigned valid = nr >= 32 ? 0xffffffffu : ((1u << nr) - 1u);
-            for (int q = threadIdx.x; q < npairs; q += T) {
-                int i, j;
-                pair_decode(q, &i, &j);
-                const int2 th = pair_thr[poff + q];
-                unsigned y = 0, z = 0;
-                for (int b = 0; b < kHugeSub; ++b) {
-                    const int dd = (int)(cov[b * stride + j] - cov[b * stride + i]);
-                    y |= (unsigned)(dd >= th.x) << b;              // yea: covered fraction above the high threshold
-                    z |= (unsigned)(dd <= th.y) << b;              // nay: below the low threshold
-                }
-                y &= valid; z &= valid;
-                planes[q] = make_uint2(y, z);
-                const unsigned amb = __popc(~(y | z) & valid);
-                if (amb) amb_g[poff + q] += amb;                    // this workgroup owns the problem: plain update
-            }
-            __syncthreads();
-            // triples: thread = (j,k), loop over the i with cand_j - cand_i >= 5; counters of a (j,k) are contiguous
-            for (int r = threadIdx.x; r < npairs; r += T) {
-                int j, kk;
-                pair_decode(r, &j, &kk);
-                if (j == 0 || cy_s[kk] - cy_s[j] < 5) continue;
-                const uint2 B = planes[r];
-                if ((B.x | B.y) == 0) continue;
-                unsigned *o = out_g + toff + (i64)kk * (kk - 1) * (kk - 2) / 6 + j * (j - 1) / 2;
-                const int abase = j * (j - 1) / 2, i_end = iend_s[j];
-                for (int i = 0; i < i_end; ++i) {
-                    const uint2 A = planes[abase + i];
-                    const unsigned cnt = __popc((A.x & B.y) | (A.y & B.x));          // (disjoint: a read is never yea and nay of one pair)
-                    if (cnt) o[i] += cnt;
-                }
-            }
-        }
-    }
-}
-__global__ void __launch_bounds__(512) k_dp_giant(Status *st, const int *dp_items, ProblemArrays pr, const ProbDesc *desc,
-                                                  i64 prob_cap, const int *cand_y, const unsigned *out_g, i64 tri_cap,
-                                                  const unsigned *amb_g, const int2 *pair_thr, i64 pair_cap, int support,
-                                                  unsigned char *chosen, int nm, unsigned char *scratch, i64 scratch_stride) {
-    constexpr int T = 512;
-    constexpr unsigned short kNoArg = 0xffffu;
-    extern __shared__ __align__(16) unsigned char smem[];
-    int *cy_s = reinterpret_cast<int *>(smem);
-    __shared__ i64 top_v[T / 64];
-    __shared__ i64 top_key[T / 64];
-    const i64 rt_pairs = (i64)nm * (nm - 1) / 2;
-    i64 *M = reinterpret_cast<i64 *>(scratch + (i64)blockIdx.x * scratch_stride);
-    int *in_s = reinterpret_cast<int *>(M + rt_pairs);
-    unsigned short *A = reinterpret_cast<unsigned short *>(in_s + rt_pairs);
-    if ((i64)st->n_prob > prob_cap) return;
-    const i64 list_base = (i64)st->dp_cls[0] + (i64)st->dp_cls[1], list_n = (i64)st->dp_cls[2];
-    for (i64 t = blockIdx.x; t < list_n; t += gridDim.x) {
-        __syncthreads();
-        const int p = dp_items[list_base + t];
-        const ProbDesc d = load_desc(desc + p);
-        const int n = d.n;
-        if (n <= kNHuge || n > nm) continue;
-        const int npairs = n * (n - 1) / 2, end = n - 1;
-        const i64 ntri = (i64)n * (n - 1) * (n - 2) / 6;
-        const i64 poff = d.pair_off, toff = d.tri_off;
-        if (poff + npairs > pair_cap || toff + ntri > tri_cap) continue;
-        const unsigned *out_p = out_g + toff;
-        const i64 outside = d.outside;
-        const bool zamb = (pr.flags[p] & 1) != 0;
-        for (int j = threadIdx.x; j < n; j += T) cy_s[j] = cand_y[d.c0 + j];
-        for (int q = threadIdx.x; q < npairs; q += T)
-            in_s[q] = -(int)((i64)amb_g[poff + q] + ((zamb && pair_thr[poff + q].y < 0) ? outside : 0));
-        __syncthreads();
-#define FSEG_IN(a, bb) ((i64)in_s[(bb) * ((bb) - 1) / 2 + (a)])
-#define FSEG_M(a, bb) M[(bb) * ((bb) - 1) / 2 + (a)]
-        for (int x = threadIdx.x; x < end; x += T) {
-            FSEG_M(x, end) = cy_s[end] - cy_s[x] >= 5 ? FSEG_IN(x, end) : kNegInf;
-            A[end * (end - 1) / 2 + x] = kNoArg;
-        }
-        __syncthreads();
-        for (int c = end - 1; c >= 2; --c) {
-            // M(b,c) = in(b,c) + max over c2 > c of out(b,c,c2) + M(c,c2), first maximiser (:550-555); a thread per b
-            for (int b = 1 + threadIdx.x; b < c; b += T) {
-                i64 best = kNegInf; int arg = kNoArg;
-                const bool live = cy_s[c] - cy_s[b] >= 5;
-                if (live) {
-                    const int base = c * (c - 1) / 2 + b;
-                    for (int c2 = c + 1; c2 <= end; ++c2) {
-                        const i64 tail = FSEG_M(c, c2);
-                        const unsigned o = out_p[(i64)c2 * (c2 - 1) * (c2 - 2) / 6 + base];
-                        const bool ok = (tail != kNegInf) & ((i64)o >= (i64)support);
-                        const i64 cur = ok ? (i64)o + tail : kNegInf;
-                        const bool take = cur > best;
-                        best = take ? cur : best; arg = take ? c2 : arg;
-                    }
-                }
-                FSEG_M(b, c) = (live && best != kNegInf) ? best + FSEG_IN(b, c) : kNegInf;
-                A[c * (c - 1) / 2 + b] = (unsigned short)arg;
-            }
-            __syncthreads();
-        }
-        // top level (:560-566): first maximiser in (j, k) order, taken only if strictly better than no cut
-        i64 bv = kNegInf, bkey = 0x7fffffffffffffffLL;
-        for (int q = threadIdx.x; q < npairs; q += T) {
-            int j, kx;
-            pair_decode(q, &j, &kx);
-            if (j < 1) continue;
-            if (cy_s[j] - cy_s[0] < 5 || cy_s[kx] - cy_s[j] < 5) continue;
-            const i64 tail = FSEG_M(j, kx);
-            const unsigned o = out_p[(i64)kx * (kx - 1) * (kx - 2) / 6 + j * (j - 1) / 2];
-            if (tail == kNegInf || (i64)o < (i64)support) continue;
-            const i64 cur = FSEG_IN(0, j) + (i64)o + tail;
-            const i64 key = ((i64)j << 20) | (i64)kx;
-            if (cur > bv || (cur == bv && key < bkey)) { bv = cur; bkey = key; }
-        }
-        for (int dd = 32; dd >= 1; dd >>= 1) {
-            i64 ov = __shfl_xor(bv, dd); i64 ok2 = __shfl_xor(bkey, dd);
-            if (ov > bv || (ov == bv && ok2 < bkey)) { bv = ov; bkey = ok2; }
-        }
-        if (lane_id() == 0) { top_v[threadIdx.x >> 6] = bv; top_key[threadIdx.x >> 6] = bkey; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            for (int w = 1; w < T / 64; ++w)
-                if (top_v[w] > bv || (top_v[w] == bv && top_key[w] < bkey)) { bv = top_v[w]; bkey = top_key[w]; }
-            int chain = 0;
-            if (bv != kNegInf && bv > FSEG_IN(0, end)) {
-                int j = (int)(bkey >> 20), k = (int)(bkey & 0xfffff);
-                unsigned char *ch = chosen + d.c0;
-                ch[0] = 1;
-                for (;;) {
-                    ch[j] = 1; ch[k] = 1; ++chain;
-                    if (k == end) break;
-                    const int k2 = A[k * (k - 1) / 2 + j];
-                    if (k2 == kNoArg) break;
-                    j = k; k = k2;
-                }
-            }
-            pr.chain[p] = chain;
-        }
-#undef FSEG_IN
-#undef FSEG_M
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// S6  refinement   (refine_segmentation :249-266) and final positions (:802-807)
-// k_segments marks the chosen candidates as final positions and, for every chosen candidate whose
-// previous chosen candidate is more than 40 positions away, records that segment; k_refine then
-// visits the recorded segments (one wave each).
-// ---------------------------------------------------------------------------------------------
-constexpr int kSegChunks = 4;      // 64-candidate chunks of an interval that k_segments' one-wave path takes at once
-__global__ void k_segments(i64 K, const i64 *pos_off, const i64 *cand_off, const int *cand_y, const int *__restrict__ y_raw,
-                           const int *__restrict__ blk_pre, const int *tile_tot, const int *iv_tile0, const unsigned char *chosen, unsigned *final_flag, int *rseg_c, int *rseg_prev,
-                           Status *st) {
-    __shared__ int lds[16];
-    __shared__ int cnt_s[16];
-    __shared__ u64 base_s;
-    const int T = blockDim.x;
-    int lane = lane_id(), wave = threadIdx.x >> 6, nw = (T + 63) >> 6;
-    // the inner-positions test of refine_segmentation (:258) for the segment (py, y] of interval k, whose first tile is tile0
-    auto inner_sum_ok = [&](i64 base, int tile0, int py, int y) -> bool {
-        // refine_segmentation's `sum(i_vals) < 20 -> continue` (:258), exactly, over the inner positions [py+20, y-21]:
-        // k_smooth's prefix of the histogram at the start of a's and of b's block (inside their tiles), the tiles
-        // between them, and the positions of those two blocks up to a (exclusive) / up to b (inclusive)
-        const int a = py + 20, b = y - 21;
-        const int ta = a >> kSmoothShift, tb = b >> kSmoothShift;
-        if (tb - ta > 64) return true;                            // (very long segments: k_refine sums them itself)
-        constexpr int kBlocks = kSmoothTile / kSumBlock;
-        const int *tt = tile_tot + tile0;
-        const int *yr = y_raw + base;
-        const int a0 = a & ~(kSumBlock - 1), b0 = b & ~(kSumBlock - 1);
-        i64 tot = (i64)blk_pre[(i64)(tile0 + tb) * kBlocks + ((b & (kSmoothTile - 1)) >> kSumShift)]
-                - (i64)blk_pre[(i64)(tile0 + ta) * kBlocks + ((a & (kSmoothTile - 1)) >> kSumShift)];
-        // (the two blocks as 16-byte loads from dword-aligned addresses; a block of b's may reach beyond the interval's
-        // last position -- into the next interval's counts or the slab's padding: masked)
-        int4u va[kSumBlock / 4], vb[kSumBlock / 4];
-#pragma unroll
-        for (int e = 0; e < kSumBlock / 4; ++e) { va[e] = *reinterpret_cast<const int4u *>(yr + a0 + 4 * e); vb[e] = *reinterpret_cast<const int4u *>(yr + b0 + 4 * e); }
-#pragma unroll
-        for (int e = 0; e < kSumBlock / 4; ++e) {
-            const int pa = a0 + 4 * e, pb = b0 + 4 * e;
-            tot += (pb <= b ? vb[e].x : 0) + (pb + 1 <= b ? vb[e].y : 0) + (pb + 2 <= b ? vb[e].z : 0) + (pb + 3 <= b ? vb[e].w : 0);
-            tot -= (pa < a ? va[e].x : 0) + (pa + 1 < a ? va[e].y : 0) + (pa + 2 < a ? va[e].z : 0) + (pa + 3 < a ? va[e].w : 0);
-        }
-        for (int q = ta; q < tb; ++q) tot += tt[q];
-        return tot >= 20;
-    };
-    for (i64 k = blockIdx.x; k < K; k += gridDim.x) {
-        i64 c0 = cand_off[k];
-        int N = (int)(cand_off[k + 1] - c0);
-        i64 base = pos_off[k];
-        if (T == 64 && N <= 64 * kSegChunks) {
-            // an interval of at most 256 candidates, one wave (round 5): the chosen flags and the candidates' positions of all its
-            // 64-candidate chunks are asked for together, the previous chosen candidate's position comes from its lane (or the
-            // chunk before), and the chunks' inner-sum tests are in flight together -- three rounds of loads per interval whatever
-            // its length and no barrier.  (The kernel is a chain of dependent loads per interval; with six rounds per 64
-            // candidates the few long intervals of a batch -- 100 to 300 candidates -- were what it took: 26 us.)
-            const int tile0 = iv_tile0[k];
-            unsigned char ch[kSegChunks];
-            int yv[kSegChunks];
-#pragma unroll
-            for (int u = 0; u < kSegChunks; ++u) {
-                const int c = u * 64 + lane;
-                ch[u] = chosen[c0 + (c < N ? c : 0)];
-                yv[u] = cand_y[c0 + (c < N ? c : 0)];
-            }
-            int pyv[kSegChunks];
-            bool need[kSegChunks];
-            int carry_y = -1;                                          // position of the last chosen candidate of the chunks before (wave-uniform)
-#pragma unroll
-            for (int u = 0; u < kSegChunks; ++u) {
-                const int c = u * 64 + lane;
-                const bool f = c < N && ch[u];
-                const u64 mask = __ballot(f);
-                const u64 below = mask & ((1ULL << lane) - 1ULL);
-                const int prev = below ? 63 - __clzll((long long)below) : -1;
-                const int py_in = __shfl(yv[u], prev >= 0 ? prev : 0);
-                const int py = prev >= 0 ? py_in : carry_y;
-                if (f) set_flag(final_flag, base + yv[u]);
-                pyv[u] = py;
-                need[u] = f && py >= 0 && yv[u] - py > 40;              // :252
-                if (mask) carry_y = __shfl(yv[u], 63 - __clzll((long long)mask));
-            }
-#pragma unroll
-            for (int u = 0; u < kSegChunks; ++u) if (need[u]) need[u] = inner_sum_ok(base, tile0, pyv[u], yv[u]);
-#pragma unroll
-            for (int u = 0; u < kSegChunks; ++u) {
-                const u64 m = __ballot(need[u]);
-                if (m) {                                               // (wave-uniform)
-                    u64 slot0 = 0;
-                    if (lane == 0) slot0 = atomicAdd(&st->n_rseg, (u64)__popcll(m));
-                    slot0 = __shfl(slot0, 0);
-                    if (need[u]) {
-                        const u64 slot = slot0 + __popcll(m & ((1ULL << lane) - 1ULL));
-                        rseg_c[slot] = (int)(c0 + u * 64 + lane); rseg_prev[slot] = pyv[u];
-                    }
-                }
-            }
-            continue;
-        }
-        int carry = -1;
-        for (int t0 = 0; t0 < N; t0 += T) {
-            int c = t0 + threadIdx.x;
-            bool f = c < N && chosen[c0 + c];
-            int prev = wg_prev_flagged(f, c, carry, lds);
-            int y = 0, py = -1;
-            if (f) {
-                y = cand_y[c0 + c];
-                set_flag(final_flag, base + y);
-                if (prev >= 0) py = cand_y[c0 + prev];
-            }
-            bool need = f && py >= 0 && y - py > 40;                  // :252
-            if (need) need = inner_sum_ok(base, iv_tile0[k], py, y);
-            u64 m = __ballot(need);
-            if (lane == 0) cnt_s[wave] = __popcll(m);
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                int tot = 0;
-                for (int w = 0; w < nw; ++w) { int v = cnt_s[w]; cnt_s[w] = tot; tot += v; }
-                base_s = tot ? atomicAdd(&st->n_rseg, (u64)tot) : 0;
-            }
-            __syncthreads();
-            if (need) {
-                u64 slot = base_s + cnt_s[wave] + __popcll(m & ((1ULL << lane) - 1ULL));
-                rseg_c[slot] = (int)(c0 + c); rseg_prev[slot] = py;
-            }
-            __syncthreads();
-        }
-    }
-}
-
-constexpr int kRefCap = 1024;       // segment length up to which k_refine works out of LDS
-__global__ void __launch_bounds__(64) k_refine(const Status *st, const int *cand_iv, const int *rseg_c,
-                                               const int *rseg_prev, const int *cand_y, const i64 *pos_off,
-                                               const int *y_raw, const double *w_g, int radius, double sigma,
-                                               double *g_scr, int *pk_scr, unsigned char *flag_scr,
-                                               unsigned char *keep_scr, unsigned *final_flag) {
-    __shared__ double ws[kMaxRadius + 1];
-    __shared__ int xl[kRefCap], pkl[kRefCap];
-    __shared__ double gl[kRefCap];
-    __shared__ unsigned char pfl[kRefCap], kpl[kRefCap];
-    const int skip = 20;
-    int lane = lane_id();
-    for (int j = lane; j <= radius; j += 64) ws[j] = w_g[j];
-    __syncthreads();
-    i64 n_seg = (i64)st->n_rseg;
-    for (i64 si = blockIdx.x; si < n_seg; si += gridDim.x) {
-      {
-        i64 sg = rseg_c[si];
-        int s = rseg_prev[si];
-        int e = cand_y[sg];
-        int len = e - s;
-        i64 base = pos_off[cand_iv[sg]] + s;
-        const int *xr = y_raw + base;
-        if (len <= kRefCap) {
-            // ---- the segment fits in LDS (nearly all do): its counts are fetched once, four coalesced rows at a time
-            // from clamped addresses (a load under a condition is a branch with its own wait -- and the filter below
-            // would do 2 * radius of them per position), then everything runs out of LDS --------------------------------
-            i64 tot_l = 0;
-            for (int i0 = 0; i0 < len; i0 += 256) {
-                int v[4];
-#pragma unroll
-                for (int e4 = 0; e4 < 4; ++e4) { const int t = i0 + e4 * 64 + lane; v[e4] = xr[t < len ? t : len - 1]; }
-#pragma unroll
-                for (int e4 = 0; e4 < 4; ++e4) {
-                    const int t = i0 + e4 * 64 + lane;
-                    if (t < len) { const int m = (t < skip || t >= len - skip) ? 0 : v[e4]; xl[t] = m; tot_l += m; }   // zeroed ends (:256-257)
-                }
-            }
-            for (int d = 32; d >= 1; d >>= 1) tot_l += __shfl_xor(tot_l, d);
-            if (tot_l < 20) continue;                                     // sum(i_vals) < 20 -> skip (:258)
-            __syncthreads();
-            for (int i = lane; i < len; i += 64) {                         // gaussian_filter1d(..., mode='constant', truncate=1.0) (:260-261)
-                double acc = __dmul_rn((double)xl[i], ws[0]);
-                for (int j = radius; j >= 1; --j) {
-                    const int a = i - j, b = i + j;
-                    const int sv = (a >= 0 ? xl[a] : 0) + (b < len ? xl[b] : 0);
-                    acc = __dadd_rn(acc, __dmul_rn((double)sv, ws[j]));
-                }
-                gl[i] = acc;
-                pfl[i] = 0;
-            }
-            __syncthreads();
-            for (int i = 1 + lane; i < len - 1; i += 64) {                 // scipy _local_maxima_1d
-                const double gi = gl[i];
-                if (gl[i - 1] < gi) {
-                    int ia = i + 1;
-                    while (ia < len - 1 && gl[ia] == gi) ++ia;
-                    if (gl[ia] < gi) pfl[(i + ia - 1) / 2] = 1;
-                }
-            }
-            __syncthreads();
-            int m = 0;
-            for (int t0 = 0; t0 < len; t0 += 64) {
-                const int i = t0 + lane;
-                const bool f = i < len && pfl[i];
-                const u64 mask = __ballot(f);
-                if (f) { const int rank = __popcll(mask & ((1ULL << lane) - 1ULL)); pkl[m + rank] = i; kpl[m + rank] = 1; }
-                m += __popcll(mask);
-            }
-            __syncthreads();
-            for (;;) {                                                     // find_peaks(distance=20), as in the general path below
-                double bv = -INFINITY; int bq = -1;
-                for (int q = lane; q < m; q += 64)
-                    if (kpl[q] == 1) { const double v = gl[pkl[q]]; if (v > bv || (v == bv && q > bq)) { bv = v; bq = q; } }
-                for (int d = 32; d >= 1; d >>= 1) {
-                    const double ov = __shfl_xor(bv, d); const int oq = __shfl_xor(bq, d);
-                    if (oq >= 0 && (bq < 0 || ov > bv || (ov == bv && oq > bq))) { bv = ov; bq = oq; }
-                }
-                if (bq < 0) break;
-                if (lane == 0) {
-                    kpl[bq] = 2;
-                    const int pj = pkl[bq];
-                    for (int q = bq - 1; q >= 0 && pj - pkl[q] < skip; --q) kpl[q] = 0;
-                    for (int q = bq + 1; q < m && pkl[q] - pj < skip; ++q) kpl[q] = 0;
-                }
-                __syncthreads();
-            }
-            for (int q = lane; q < m; q += 64) {
-                if (kpl[q] != 2) continue;
-                const int i = pkl[q];
-                i64 a = (i64)rint((double)i - sigma), b = (i64)rint((double)i + sigma + 1.0);   // Python round(): half even
-                if (a < 0) { a += len; if (a < 0) a = 0; } else if (a > len) a = len;           // slice semantics (:263)
-                if (b < 0) { b += len; if (b < 0) b = 0; } else if (b > len) b = len;
-                double sm = 0.0;
-                for (i64 x = a; x < b; ++x) sm = __dadd_rn(sm, gl[x]);
-                if (!(sm < 20.0)) set_flag(final_flag, base + i);
-            }
-            __syncthreads();
-            continue;
-        }
-        // ---- general path (segments longer than kRefCap): scratch in global memory -------------------------------
-        // sum(i_vals) < 20 -> skip (:258); values are exact integers
-        i64 tot = 0;
-        for (int i = skip + lane; i < len - skip; i += 64) tot += xr[i];
-        for (int d = 32; d >= 1; d >>= 1) tot += __shfl_xor(tot, d);
-        if (tot < 20) continue;
-        double *g = g_scr + base;
-        int *pk = pk_scr + base;
-        unsigned char *pf = flag_scr + base, *kp = keep_scr + base;
-        // gaussian_filter1d(i_vals, sigma, mode='constant', cval=0, truncate=1.0)  (:260-261)
-        for (int i = lane; i < len; i += 64) {
-#define FSEG_V(t) (((t) < skip || (t) >= len - skip) ? 0 : xr[t])
-            double acc = __dmul_rn((double)FSEG_V(i), ws[0]);
-            for (int j = radius; j >= 1; --j) {
-                int a = i - j, b = i + j;
-                int sv = (a >= 0 ? FSEG_V(a) : 0) + (b < len ? FSEG_V(b) : 0);
-                acc = __dadd_rn(acc, __dmul_rn((double)sv, ws[j]));
-            }
-#undef FSEG_V
-            g[i] = acc;
-            pf[i] = 0;
-        }
-        __syncthreads();
-        for (int i = 1 + lane; i < len - 1; i += 64) {
-            double gi = g[i];
-            if (g[i - 1] < gi) {
-                int ia = i + 1;
-                while (ia < len - 1 && g[ia] == gi) ++ia;
-                if (g[ia] < gi) pf[(i + ia - 1) / 2] = 1;
-            }
-        }
-        __syncthreads();
-        int m = 0;
-        for (int t0 = 0; t0 < len; t0 += 64) {
-            int i = t0 + lane;
-            bool f = i < len && pf[i];
-            u64 mask = __ballot(f);
-            if (f) { int rank = __popcll(mask & ((1ULL << lane) - 1ULL)); pk[m + rank] = i; kp[m + rank] = 1; }
-            m += __popcll(mask);
-        }
-        __syncthreads();
-        // find_peaks(distance=20): highest peak first, ties -> later peak first; state 1 = kept and
-        // unprocessed, 2 = kept and processed, 0 = removed
-        for (;;) {
-            double bv = -INFINITY; int bq = -1;
-            for (int q = lane; q < m; q += 64)
-                if (kp[q] == 1) { double v = g[pk[q]]; if (v > bv || (v == bv && q > bq)) { bv = v; bq = q; } }
-            for (int d = 32; d >= 1; d >>= 1) {
-                double ov = __shfl_xor(bv, d); int oq = __shfl_xor(bq, d);
-                if (oq >= 0 && (bq < 0 || ov > bv || (ov == bv && oq > bq))) { bv = ov; bq = oq; }
-            }
-            if (bq < 0) break;
-            if (lane == 0) {
-                kp[bq] = 2;
-                int pj = pk[bq];
-                for (int q = bq - 1; q >= 0 && pj - pk[q] < skip; --q) kp[q] = 0;
-                for (int q = bq + 1; q < m && pk[q] - pj < skip; ++q) kp[q] = 0;
-            }
-            __syncthreads();
-        }
-        for (int q = lane; q < m; q += 64) {
-            if (kp[q] != 2) continue;
-            int i = pk[q];
-            i64 a = (i64)rint((double)i - sigma), b = (i64)rint((double)i + sigma + 1.0);   // Python round(): half even
-            if (a < 0) { a += len; if (a < 0) a = 0; } else if (a > len) a = len;           // slice semantics (:263)
-            if (b < 0) { b += len; if (b < 0) b = 0; } else if (b > len) b = len;
-            double sm = 0.0;
-            for (i64 x = a; x < b; ++x) sm = __dadd_rn(sm, g[x]);
-            if (!(sm < 20.0)) set_flag(final_flag, base + i);
-        }
-        __syncthreads();
-      }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// S7  labels   (py/freddie_segment.py:808-830, sentinel :829-830, pop :840)
-// The label matrix of a partition is R x (F-1) bytes ('0','1','2').  A read overlaps only a few of
-// the F-1 segments, so the matrix is first filled with each column's zero-coverage label (k_label_fill,
-// a pure streaming store) and then every read rewrites just the columns its exons can reach
-// (k_label_reads).
-// ---------------------------------------------------------------------------------------------
-// label arena offsets of the partitions (one workgroup of 256 threads; part of k_label_cols)
-__device__ void label_plan(int n_part, const i64 *part_iv_off, const i64 *part_rep_off,
-                           const i64 *final_off, i64 *label_off, Status *st, i64 label_cap) {
-    // (a workgroup scan per 256 partitions; until round 5 thread 0 added the 256 sizes up one by one -- a chain of 256 LDS round
-    // trips, 12 us per 256 partitions: it was what k_label_cols took, 23 us for the 500 partitions of a config4 batch)
-    __shared__ i64 carry_s;
-    __shared__ i64 scan_lds[16];
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    for (int p0 = 0; p0 < n_part; p0 += blockDim.x) {
-        int p = p0 + threadIdx.x;
-        i64 bytes = 0;
-        if (p < n_part) {
-            i64 F = final_off[part_iv_off[p + 1]] - final_off[part_iv_off[p]];
-            bytes = (part_rep_off[p + 1] - part_rep_off[p]) * (F > 0 ? F - 1 : 0);
-        }
-        i64 tot;
-        const i64 ex = wg_exclusive_scan64(bytes, scan_lds, &tot);
-        const i64 carry = carry_s;
-        if (p < n_part) label_off[p] = carry + ex;
-        __syncthreads();
-        if (threadIdx.x == 0) carry_s = carry + tot;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        label_off[n_part] = carry_s;
-        st->label_bytes = (u64)carry_s;
-        if (carry_s > label_cap) atomicOr(&st->err, kErrOverflowLabels);
-    }
-}
-// per final index f (= column): integer thresholds of the segment [final_f, final_f+1) and the label of
-// a read without coverage there; the last index of an interval is the sentinel column (hi = INT_MAX)
-__global__ void __launch_bounds__(256) k_label_cols(i64 K, const i64 *final_off, const int *final_y, const int *final_iv, const int *iv_part,
-                                                    const double *h_table, int h_len, double tau, const int2 *thr_tab, int2 *col_thr,
-                                                    unsigned char *col_zero, int *part_has2, int n_part,
-                                                    const i64 *part_iv_off, const i64 *part_rep_off, i64 *label_off,
-                                                    Status *st, i64 label_cap) {
-    if (blockIdx.x == 0) label_plan(n_part, part_iv_off, part_rep_off, final_off, label_off, st, label_cap);
-    i64 F = final_off[K];
-    for (i64 f = (i64)blockIdx.x * blockDim.x + threadIdx.x; f < F; f += (i64)gridDim.x * blockDim.x) {
-        const i64 k = final_iv[f];                           // the interval of every final position, noted by the compaction that emitted it
-        if (f + 1 == final_off[k + 1]) { col_thr[f] = make_int2(0x7fffffff, 0x7fffffff); col_zero[f] = '0'; continue; }
-        int hi, lo;
-        label_thresholds_tab((i64)final_y[f + 1] - final_y[f] + 1, thr_tab, h_table, h_len, tau, &hi, &lo);
-        col_thr[f] = make_int2(hi, lo);
-        col_zero[f] = lo >= 0 ? '0' : '2';
-        if (lo < 0) atomicOr(&part_has2[iv_part[k]], 1);
-    }
-}
-// The label arena is pre-filled with '0' (the label of a read without coverage) by one streaming kernel; in
-// partitions in which a zero-coverage read is ambiguous for some segment (lo < 0, i.e. threshold_rate == 1) every rep
-// first rewrites its row with the columns' defaults (k_label_reads).
-__global__ void __launch_bounds__(256) k_label_zero(uint4 *labels16, i64 n16) {
-    fill_labels(labels16, n16, (i64)blockIdx.x * blockDim.x + threadIdx.x, (i64)gridDim.x * blockDim.x);
-}
-// One workgroup per 64 read reps of one partition (a quarter of a 256-rep block).  The partition's column table
-// (segment boundaries and integer thresholds) is staged in LDS when it fits; kLabelSplit threads share a rep: each
-// merges the rep's exon list against a quarter of the columns the exons can reach (the walk is a chain of dependent
-// loads, so shorter chains and more of them is what makes it faster).
-constexpr int kLabelCols = 1024;
-#ifndef FSEG_LABEL_STAGE
-#define FSEG_LABEL_STAGE 1024
-#endif
-constexpr int kLabelStage = FSEG_LABEL_STAGE;
-constexpr int kLabelSplit = 4;
-__global__ void __launch_bounds__(256) k_label_reads(int n_blocks, const int *rb_part, const int *rb_r0,
-                                                     const i64 *label_off, i64 label_cap, int n_part,
-                                                     const i64 *part_iv_off, const i64 *part_rep_off,
-                                                     const i64 *final_off, const int *final_pos, const int2 *col_thr,
-                                                     const i64 *rep_exon_off, const int *ex_ts, const int *ex_te,
-                                                     const unsigned char *col_zero, const int *part_has2,
-                                                     unsigned char *labels) {
-    __shared__ int fp_s[kLabelCols + 1];
-    __shared__ int2 th_s[kLabelCols];
-    if (label_off[n_part] > label_cap) return;
-    for (i64 unit = blockIdx.x; unit < (i64)n_blocks * kLabelSplit; unit += gridDim.x) {
-        const int blk = (int)(unit / kLabelSplit), sub = (int)(unit % kLabelSplit);
-        int p = rb_part[blk];
-        i64 f0 = final_off[part_iv_off[p]];
-        i64 F = final_off[part_iv_off[p + 1]] - f0;
-        i64 S = F - 1;
-        if (S <= 0) continue;
-        if ((i64)rb_r0[blk] + sub * (256 / kLabelSplit) >= part_rep_off[p + 1]) continue;
-        const int *fp = final_pos + f0;                      // ascending over the whole partition
-        const int2 *th = col_thr + f0;
-        __syncthreads();
-        // short column tables are staged in LDS; a long table stays in global memory (a read only visits the few
-        // columns around its exons, and staging the whole table per workgroup would cost more than it saves)
-        if (S <= kLabelStage) {
-            for (int x = threadIdx.x; x <= S; x += blockDim.x) fp_s[x] = fp[x];
-            for (int x = threadIdx.x; x < S; x += blockDim.x) th_s[x] = th[x];
-            fp = fp_s; th = th_s;
-        }
-        __syncthreads();
-        i64 r = (i64)rb_r0[blk] + sub * (256 / kLabelSplit) + (threadIdx.x / kLabelSplit);
-        const int q = threadIdx.x % kLabelSplit;
-        if (part_has2[p]) {                                  // uniform over the workgroup: the rows' defaults are not all '0'
-            if (r < part_rep_off[p + 1]) {
-                unsigned char *row0 = labels + label_off[p] + (r - part_rep_off[p]) * S;
-                const unsigned char *cz = col_zero + f0;
-                for (i64 x = S * q / kLabelSplit; x < S * (q + 1) / kLabelSplit; ++x) row0[x] = cz[x];
-            }
-            __threadfence_block();
-            __syncthreads();                                 // the label stores below may hit bytes another thread just wrote
-        }
-        if (r >= part_rep_off[p + 1]) continue;
-        unsigned char *row = labels + label_off[p] + (r - part_rep_off[p]) * S;
-        i64 e = rep_exon_off[r], e1 = rep_exon_off[r + 1];
-        if (e >= e1) continue;
-        int first_ts = ex_ts[e], last_te = ex_te[e1 - 1];
-        // first column whose segment [fp[c], fp[c+1]) ends after first_ts
-        int lo = 0, hi = (int)S;
-        while (lo < hi) { int mid = (lo + hi) >> 1; if (fp[mid + 1] <= first_ts) lo = mid + 1; else hi = mid; }
-        // first column that starts after last_te
-        int c_hi = lo; hi = (int)S;
-        while (c_hi < hi) { int mid = (c_hi + hi) >> 1; if (fp[mid] <= last_te) c_hi = mid + 1; else hi = mid; }
-        // this thread's share of [lo, c_hi)
-        const int span = c_hi - lo;
-        const int c_a = lo + (int)((i64)span * q / kLabelSplit), c_b = lo + (int)((i64)span * (q + 1) / kLabelSplit);
-        if (c_a >= c_b) continue;
-        if (q) {                                             // first exon that reaches the first column of the share
-            const int g = fp[c_a];
-            i64 a = e, b = e1;
-            while (a < b) { i64 mid = (a + b) >> 1; if (ex_te[mid] < g) a = mid + 1; else b = mid; }
-            e = a;
-        }
-        int ts = 0, te = 0;
-        if (e < e1) { ts = ex_ts[e]; te = ex_te[e]; }
-        for (int c = c_a; c < c_b; ++c) {
-            int2 t2 = th[c];
-            if (t2.x == 0x7fffffff) continue;                 // sentinel column between two intervals
-            int g0 = fp[c], g1 = fp[c + 1];
-            while (e < e1 && te < g0) { ++e; if (e < e1) { ts = ex_ts[e]; te = ex_te[e]; } }   // exons before the segment
-            int cov = 0;
-            if (e < e1 && ts < g1) {
-                int a = ts > g0 ? ts : g0, b2 = te + 1 < g1 ? te + 1 : g1;
-                if (b2 > a) cov += b2 - a;
-                for (i64 x = e + 1; x < e1 && ex_ts[x] < g1; ++x) {
-                    int a3 = ex_ts[x] > g0 ? ex_ts[x] : g0;
-                    int b3 = ex_te[x] + 1 < g1 ? ex_te[x] + 1 : g1;
-                    if (b3 > a3) cov += b3 - a3;
-                }
-            }
-            // the arena already holds the zero-coverage label of the column ('0', or '2' when lo < 0): store only what differs
-            const unsigned char lab = cov >= t2.x ? '1' : (cov <= t2.y ? '0' : '2');
-            if (lab != (t2.y < 0 ? '2' : '0')) row[c] = lab;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Results to the host.  The label matrix is by far the largest thing that crosses PCIe (about 300 bytes per read, 75 MB per
-// 250 k-read batch, 1.4 ms at 55 GB/s -- more than the whole device pipeline), and a label has three values: the arena is
-// packed to two bits per label before it leaves (k_pack_labels; label byte g of the arena = bits 2(g & 3) .. of packed byte
-// g >> 2) and the host writer unpacks rows straight into the TSV it is assembling (fhost_write_packed).
-// (A copy kernel of our own that streams to pinned memory with a small grid was tried instead of the runtime's copy: it
-// slows kernels of the other contexts of the pipeline 3x while it runs.  The runtime's own large copies are kernels too --
-// see sdma_d2h() for what replaces them.)
-// ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_pack_labels(const uint4 *__restrict__ labels16, unsigned *__restrict__ packed, i64 n16) {
-    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (i64)gridDim.x * blockDim.x) {
-        const uint4 v = labels16[i];                    // 16 ASCII labels ('0' + 0 .. 2) -> 32 bits
-        const unsigned w[4] = {v.x, v.y, v.z, v.w};
-        unsigned out = 0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const unsigned x = w[q] & 0x03030303u;      // the two low bits of each byte are the label
-            out |= ((x & 3u) | ((x >> 6) & 0xcu) | ((x >> 12) & 0x30u) | ((x >> 18) & 0xc0u)) << (8 * q);
-        }
-        packed[i] = out;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// upload-time preparation, once per batch, on the device (the inputs arrive in one copy; what used to be a host pass
-// over every exon and a host sort now runs behind that copy on the context's stream)
-//   k_prep_reps   the per-read assertions of read_split() (py/freddie_segment.py:158-161) and of process_splicing_data
-//                 (:666-668: both ends of an exon are positions of one tint interval), and the sort key of every rep
-//   (radix sort)  reps of a partition by first position (freddie_seg_sort.hip)
-//   k_lanes       the lane list: every rep repeated rep_weight times, with the running maximum of the last position
-//   k_hist_ranges the lanes that can reach each histogram chunk
-// ---------------------------------------------------------------------------------------------
-enum : unsigned { kPrepExonEnds = 1u, kPrepExonOrder = 2u, kPrepExonInterval = 4u, kPrepNoExons = 8u };
-struct PrepStatus {
-    unsigned err;
-    unsigned pad;
-    i64 bad_rep[4];    // smallest rep with error bit q
-};
-
-__global__ void __launch_bounds__(256) k_prep_reps(int n_blocks, const int *rb_part, const int *rb_r0, const i64 *part_rep_off,
-                                                   const i64 *part_iv_off, const int *iv_start, const int *iv_end,
-                                                   const i64 *rep_exon_off, const int *ex_ts, const int *ex_te, u64 *key,
-                                                   int *val, int *rep_last, PrepStatus *ps) {
-    for (int blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
-        const int p = rb_part[blk];
-        const i64 r = (i64)rb_r0[blk] + threadIdx.x;
-        if (r >= part_rep_off[p + 1]) continue;
-        const i64 e0 = rep_exon_off[r], e1 = rep_exon_off[r + 1];
-        unsigned bad = 0;
-        int first = 0, last = 0;
-        if (e1 <= e0) bad = kPrepNoExons;
-        else {
-            const i64 k0 = part_iv_off[p], k1 = part_iv_off[p + 1];
-            first = ex_ts[e0]; last = ex_te[e1 - 1];
-            i64 kk = k0;
-            {   // first interval that ends at or after the read's first position; exons and intervals are both ordered
-                i64 lo = k0, hi = k1;
-                while (lo < hi) { const i64 mid = (lo + hi) >> 1; if (iv_end[mid] < first) lo = mid + 1; else hi = mid; }
-                kk = lo;
-            }
-            int prev_te = 0;
-            for (i64 e = e0; e < e1; ++e) {
-                const int ts = ex_ts[e], te = ex_te[e];
-                if (!(ts < te)) bad |= kPrepExonEnds;                                   // :160
-                if (e > e0 && !(prev_te <= ts)) bad |= kPrepExonOrder;                  // :158
-                while (kk < k1 && iv_end[kk] < ts) ++kk;
-                if (kk >= k1 || ts < iv_start[kk] || te > iv_end[kk]) bad |= kPrepExonInterval;   // :666-668
-                prev_te = te;
-            }
-        }
-        key[r] = ((u64)(unsigned)p << 32) | (u64)((unsigned)first ^ 0x80000000u);   // signed order of the position
-        val[r] = (int)r;
-        rep_last[r] = last;
-        if (bad) {
-            atomicOr(&ps->err, bad);
-            for (int q = 0; q < 4; ++q) if ((bad >> q) & 1u) atomicMin((unsigned long long *)&ps->bad_rep[q], (unsigned long long)r);
-        }
-    }
-}
-
-// One workgroup per partition walks the partition's reps in sorted order, 256 at a time: exclusive scan of the weights
-// (lane offsets) and inclusive running maximum of the last positions, both with a carry from tile to tile.
-// sort_here: no batch-wide sort ran (every partition has at most kLaneSortMax reps, the usual case): the workgroup sorts
-// its partition's (first position, rep) keys itself, bitonic in LDS -- one launch instead of the radix sort's sixteen.
-constexpr int kLaneSortMax = 2048;
-// The exon stream of a tile of 256 sorted reps: thread u's rep owns [eb, eb + ne) of the tile's piece, which starts at
-// lex[tile_e0]; its exons are exr.x .. in the caller's arrays.  Every thread marks its own range in an owner table (a
-// byte per exon, kLexChunk exons at a time), then the workgroup copies the piece with lane-consecutive stores -- a thread
-// copying its own rep's exons writes eight bytes every ~60 (the lane kernel: 17 -> 36 us per 250 k-read batch that way).
-constexpr int kLexChunk = 4096;
-__device__ __forceinline__ void lex_copy_tile(int eb, int ne, i64 src0, int tot_e, i64 tile_e0, const int *__restrict__ ex_ts,
-                                              const int *__restrict__ ex_te, int2 *__restrict__ lex, unsigned char *owner_s /* kLexChunk */,
-                                              int *eb_s /* 256 */, i64 *src_s /* 256 */) {
-    eb_s[threadIdx.x] = eb; src_s[threadIdx.x] = src0;
-    for (int c0 = 0; c0 < tot_e; c0 += kLexChunk) {
-        __syncthreads();
-        const int lo = max(eb, c0), hi = min(eb + ne, c0 + kLexChunk);
-        for (int o = lo; o < hi; ++o) owner_s[o - c0] = (unsigned char)threadIdx.x;
-        __syncthreads();
-        const int end = min(tot_e, c0 + kLexChunk);
-        for (int o = c0 + (int)threadIdx.x; o < end; o += 256) {
-            const int u = owner_s[o - c0];
-            const i64 src = src_s[u] + (o - eb_s[u]);
-            lex[tile_e0 + o] = make_int2(ex_ts[src], ex_te[src]);
-        }
-    }
-    __syncthreads();
-}
-__global__ void __launch_bounds__(256) k_lanes(int n_part, const i64 *part_rep_off, const i64 *part_lane_off, const u64 *key_sorted,
-                                               const int *val_sorted, const int *rep_weight, const int *rep_last,
-                                               const i64 *rep_exon_off, longlong2 *lane_ex, int *lane_start, int *lane_pmax,
-                                               int sort_here, const u64 *key_unsorted, const int *ex_ts, const int *ex_te,
-                                               int2 *lane_lx, int2 *lex) {
-    __shared__ int lds[16];
-    __shared__ int wmax[4];
-    __shared__ int carry_max_s;
-    __shared__ i64 carry_lane_s;
-    __shared__ i64 carry_ex_s;
-    __shared__ unsigned char owner_s[kLexChunk];
-    __shared__ int eb_s[256];
-    __shared__ i64 src_s[256];
-    __shared__ u64 skey[kLaneSortMax];             // (biased first position << 32 | rep index inside the partition): unique, so
-                                                   // the order is the stable order by position
-    const int lane = lane_id(), wave = threadIdx.x >> 6;
-    for (int p = blockIdx.x; p < n_part; p += gridDim.x) {
-        const i64 r0 = part_rep_off[p], r1 = part_rep_off[p + 1];
-        __syncthreads();
-        if (threadIdx.x == 0) { carry_max_s = -0x7fffffff - 1; carry_lane_s = part_lane_off[p]; carry_ex_s = rep_exon_off[r0]; }
-        if (sort_here) {
-            const int nr = (int)(r1 - r0);
-            int N = 1;
-            while (N < nr) N <<= 1;
-            for (int i = threadIdx.x; i < N; i += 256)
-                skey[i] = i < nr ? ((key_unsorted[r0 + i] & 0xffffffffULL) << 32) | (u64)(unsigned)i : ~0ULL;     // padding sorts last
-            __syncthreads();
-            for (int k = 2; k <= N; k <<= 1)
-                for (int j = k >> 1; j > 0; j >>= 1) {
-                    for (int t = threadIdx.x; t < N / 2; t += 256) {
-                        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), ixj = i | j;      // the pair (i, i ^ j) with bit j clear in i
-                        const u64 a = skey[i], b = skey[ixj];
-                        const bool up = (i & k) == 0;
-                        if ((a > b) == up) { skey[i] = b; skey[ixj] = a; }
-                    }
-                    __syncthreads();
-                }
-        }
-        __syncthreads();
-        for (i64 t0 = r0; t0 < r1; t0 += 256) {
-            const i64 i = t0 + threadIdx.x;
-            const bool in = i < r1;
-            int r = 0, first = 0;
-            if (in) {
-                if (sort_here) { const u64 k2 = skey[i - r0]; r = (int)(r0 + (i64)(k2 & 0xffffffffULL)); first = (int)((unsigned)(k2 >> 32) ^ 0x80000000u); }
-                else { r = val_sorted[i]; first = (int)((unsigned)(key_sorted[i] & 0xffffffffULL) ^ 0x80000000u); }
-            }
-            const int w = in ? rep_weight[r] : 0;
-            int m = in ? rep_last[r] : -0x7fffffff - 1;
-            for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(m, d); if (lane >= d) m = max(m, y); }
-            int tot;
-            const int ex = wg_exclusive_scan(w, lds, &tot);
-            if (lane == 63) wmax[wave] = m;
-            __syncthreads();
-            int run = carry_max_s;
-            for (int w2 = 0; w2 < wave; ++w2) run = max(run, wmax[w2]);
-            m = max(m, run);
-            const i64 base = carry_lane_s + ex;
-            // the partition's exons again, in lane order (the exon stream `lex`): a rep's exons start where the exons of
-            // the reps sorted before it end, inside the partition's own exon range
-            const longlong2 exr = in ? make_longlong2(rep_exon_off[r], rep_exon_off[r + 1]) : make_longlong2(0, 0);
-            const int ne = (int)(exr.y - exr.x);
-            int tot_e;
-            const int ex_e = wg_exclusive_scan(ne, lds, &tot_e);
-            const i64 ebase = carry_ex_s + ex_e;
-            __syncthreads();
-            if (threadIdx.x == 255) { carry_max_s = m; carry_lane_s = base + w; carry_ex_s = ebase + ne; }
-            if (in) {
-                const int2 lx = make_int2((int)ebase, (int)(ebase + ne));
-                for (int q = 0; q < w; ++q) { lane_ex[base + q] = exr; lane_start[base + q] = first; lane_pmax[base + q] = m; lane_lx[base + q] = lx; }
-            }
-            lex_copy_tile(ex_e, ne, exr.x, tot_e, ebase - ex_e, ex_ts, ex_te, lex, owner_s, eb_s, src_s);
-        }
-    }
-}
-
-// The same for a batch that went through the batch-wide sort (it holds a partition of more than kLaneSortMax reps, e.g. one
-// 50 000-read partition): a workgroup per partition would walk such a partition 256 reps at a time, alone (330 us for 50 k
-// reps).  Instead every block of 256 sorted reps is a workgroup of its own, in three launches: block totals (weights, last
-// positions), an exclusive scan of the totals inside each partition (one wave per partition), and the lanes themselves.
-__global__ void __launch_bounds__(256) k_lane_blocks(int n_blocks, const int *rb_part, const int *rb_r0, const i64 *part_rep_off,
-                                                     const int *val_sorted, const int *rep_weight, const int *rep_last,
-                                                     i64 *rb_sum, int *rb_max, const i64 *rep_exon_off, i64 *rb_esum) {
-    __shared__ int lds[16];
-    __shared__ int wmax[4];
-    const int lane = lane_id(), wave = threadIdx.x >> 6;
-    for (int blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
-        const i64 i = (i64)rb_r0[blk] + threadIdx.x;
-        const bool in = i < part_rep_off[rb_part[blk] + 1];
-        const int r = in ? val_sorted[i] : 0;
-        const int w = in ? rep_weight[r] : 0;
-        int m = in ? rep_last[r] : -0x7fffffff - 1;
-        for (int d = 32; d >= 1; d >>= 1) m = max(m, __shfl_xor(m, d));
-        __syncthreads();
-        int tot;
-        (void)wg_exclusive_scan(w, lds, &tot);
-        int tot_e;
-        (void)wg_exclusive_scan(in ? (int)(rep_exon_off[r + 1] - rep_exon_off[r]) : 0, lds, &tot_e);
-        if (lane == 0) wmax[wave] = m;
-        __syncthreads();
-        if (threadIdx.x == 0) { rb_sum[blk] = tot; rb_esum[blk] = tot_e; rb_max[blk] = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3])); }
-    }
-}
-__global__ void __launch_bounds__(256) k_lane_block_scan(int n_part, int n_blocks, const int *rb_part, const i64 *part_lane_off,
-                                                         const i64 *rb_sum, const int *rb_max, i64 *rb_base, int *rb_cmax,
-                                                         const i64 *part_rep_off, const i64 *rep_exon_off, const i64 *rb_esum, i64 *rb_ebase) {
-    const int lane = lane_id();
-    for (int p = blockIdx.x * 4 + (int)(threadIdx.x >> 6); p < n_part; p += gridDim.x * 4) {
-        // the partition's blocks are consecutive in the block list: [first block of p, first block of p + 1)
-        int b0 = 0, b1 = n_blocks;
-        { int lo = 0, hi = n_blocks; while (lo < hi) { const int mid = (lo + hi) >> 1; if (rb_part[mid] < p) lo = mid + 1; else hi = mid; } b0 = lo; }
-        { int lo = b0, hi = n_blocks; while (lo < hi) { const int mid = (lo + hi) >> 1; if (rb_part[mid] <= p) lo = mid + 1; else hi = mid; } b1 = lo; }
-        i64 carry = part_lane_off[p], carry_e = rep_exon_off[part_rep_off[p]];
-        int carry_max = -0x7fffffff - 1;
-        for (int c0 = b0; c0 < b1; c0 += 64) {
-            const int b = c0 + lane;
-            const bool in = b < b1;
-            const i64 v = in ? rb_sum[b] : 0;
-            int m = in ? rb_max[b] : -0x7fffffff - 1;
-            i64 tot, tot_e;
-            const i64 ex = wave_excl_scan(v, &tot);
-            const i64 ex_e = wave_excl_scan(in ? rb_esum[b] : 0, &tot_e);
-            if (in) rb_ebase[b] = carry_e + ex_e;
-            carry_e += tot_e;
-            for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(m, d); if (lane >= d) m = max(m, y); }      // inclusive running maximum
-            int before = __shfl_up(m, 1);
-            if (lane == 0) before = -0x7fffffff - 1;
-            if (in) { rb_base[b] = carry + ex; rb_cmax[b] = max(carry_max, before); }
-            carry += tot;
-            carry_max = max(carry_max, __shfl(m, 63));
-        }
-    }
-}
-__global__ void __launch_bounds__(256) k_lane_emit(int n_blocks, const int *rb_part, const int *rb_r0, const i64 *part_rep_off,
-                                                   const u64 *key_sorted, const int *val_sorted, const int *rep_weight, const int *rep_last,
-                                                   const i64 *rep_exon_off, const i64 *rb_base, const int *rb_cmax,
-                                                   longlong2 *lane_ex, int *lane_start, int *lane_pmax, const i64 *rb_ebase,
-                                                   const int *ex_ts, const int *ex_te, int2 *lane_lx, int2 *lex) {
-    __shared__ int lds[16];
-    __shared__ int wmax[4];
-    __shared__ unsigned char owner_s[kLexChunk];
-    __shared__ int eb_s[256];
-    __shared__ i64 src_s[256];
-    const int lane = lane_id(), wave = threadIdx.x >> 6;
-    for (int blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
-        const i64 i = (i64)rb_r0[blk] + threadIdx.x;
-        const bool in = i < part_rep_off[rb_part[blk] + 1];
-        const int r = in ? val_sorted[i] : 0;
-        const int first = in ? (int)((unsigned)(key_sorted[i] & 0xffffffffULL) ^ 0x80000000u) : 0;
-        const int w = in ? rep_weight[r] : 0;
-        int m = in ? rep_last[r] : -0x7fffffff - 1;
-        for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(m, d); if (lane >= d) m = max(m, y); }
-        __syncthreads();
-        int tot;
-        const int ex = wg_exclusive_scan(w, lds, &tot);
-        if (lane == 63) wmax[wave] = m;
-        __syncthreads();
-        int run = rb_cmax[blk];
-        for (int w2 = 0; w2 < wave; ++w2) run = max(run, wmax[w2]);
-        m = max(m, run);
-        const longlong2 exr = in ? make_longlong2(rep_exon_off[r], rep_exon_off[r + 1]) : make_longlong2(0, 0);
-        const int ne = (int)(exr.y - exr.x);
-        int tot_e;
-        const int ex_e = wg_exclusive_scan(ne, lds, &tot_e);
-        if (in) {
-            const i64 base = rb_base[blk] + ex, ebase = rb_ebase[blk] + ex_e;
-            const int2 lx = make_int2((int)ebase, (int)(ebase + ne));
-            for (int q = 0; q < w; ++q) { lane_ex[base + q] = exr; lane_start[base + q] = first; lane_pmax[base + q] = m; lane_lx[base + q] = lx; }
-        }
-        lex_copy_tile(ex_e, ne, exr.x, tot_e, rb_ebase[blk], ex_ts, ex_te, lex, owner_s, eb_s, src_s);
-    }
-}
-
-// lanes of the chunk's partition whose [first, last] position range meets the chunk's genomic range [glo, ghi]
-__global__ void __launch_bounds__(256) k_hist_ranges(int n_chunks, const int *hc_part, const int *hc_glo, const int *hc_ghi,
-                                                     const i64 *part_lane_off, const int *lane_start, const int *lane_pmax,
-                                                     i64 *hc_llo, i64 *hc_lhi) {
-    for (int ch = blockIdx.x * blockDim.x + threadIdx.x; ch < n_chunks; ch += gridDim.x * blockDim.x) {
-        const int p = hc_part[ch], glo = hc_glo[ch], ghi = hc_ghi[ch];
-        const i64 L0 = part_lane_off[p], L1 = part_lane_off[p + 1];
-        i64 a = L0, b = L1;
-        while (a < b) { const i64 m = (a + b) >> 1; if (lane_pmax[m] < glo) a = m + 1; else b = m; }
-        const i64 llo = a;
-        b = L1;
-        while (a < b) { const i64 m = (a + b) >> 1; if (lane_start[m] <= ghi) a = m + 1; else b = m; }
-        hc_llo[ch] = llo; hc_lhi[ch] = a;
-    }
-}
 
 // ---------------------------------------------------------------------------------------------
 // host side
@@ -5258,7 +530,7 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
     // ... and so does a context that shares the device: k_thr_part is the LATENCY-optimised form (one launch, a partition's phases in a
     // row by eight waves that mostly wait: 0.106 -> 0.070 ms for a context alone, the replay of a 250 k-read batch 0.742 -> 0.683 ms),
     // the chunk kernels are the throughput-friendly one -- with eight contexts taking turns the job ran at 368 M reads/s with
-    // k_thr_part against 381 M without (tools/r5_value.sh, three rounds each in one call)
+    // k_thr_part against 381 M without (tools/value_ab.sh, three rounds each in one call)
     const bool thr_part_fits = c->max_part_pos <= (i64)kThrPartMaxChunks * 8192;
     const bool thr_part = thr_part_fits && (c->thr_part == 1 || (c->thr_part < 0 && n_part >= 64 && forking));
     if (thr_part) {
@@ -6031,10 +1303,6 @@ int fseg_create(int device, fseg_ctx **out) {
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_score<kNMax>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)ScoreCfg<kNMax>::kLds);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_init_pair_table, dim3(8), dim3(256), 0, c->stream);
-        e = hipStreamSynchronize(c->stream);
-    }
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_dp<kNMax, 256, unsigned>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)dp_lds_for(kNMax, 4));
@@ -6805,3 +2073,4 @@ int64_t fseg_scoring_algorithmic_bytes(fseg_ctx *c) {
 }
 
 }  // extern "C"
+

@@ -24,7 +24,7 @@ STAGE = {"config4": ("k_solve<16", "k_solve<32", "k_solve<60", "k_dpw<", "k_wave
 def load(path):
     out = defaultdict(lambda: defaultdict(list))
     for r in csv.DictReader(open(path)):
-        name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+        name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("fseg::", "").replace("void ", "").split("(")[0]
         out[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return out
 
@@ -38,7 +38,7 @@ from freddie_amd import build  # noqa: E402
 doc = {"_comment": "HBM traffic and VALU utilisation of the interval-scoring stage per launch, from rocprofv3 --pmc passes "
        "(FETCH_SIZE, WRITE_SIZE and the SQ counters each in their own run: tools/profile_round.sh).  bench.py copies these figures "
        "into its line only when source_hash is the hash of the library it has loaded: they are not measured in the benchmark run.",
-       "source_hash": build.source_hash(build.SEG_SRC + [os.path.join(build.INCLUDE, "freddie_seg.h")], build.seg_command()),
+       "source_hash": build.seg_hash(),
        "round": tag}
 for w, kernels in STAGE.items():
     f = load(os.path.join(src, "pmc_%s_FETCH_SIZE" % w, "p_counter_collection.csv"))

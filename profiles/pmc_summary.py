@@ -12,7 +12,7 @@ def load(path, counter):
     out = defaultdict(list)
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == counter:
-            name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
+            name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("fseg::", "").split("(")[0]
             out[name].append(float(r["Counter_Value"]))
     return out
 

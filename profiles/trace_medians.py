@@ -8,7 +8,7 @@ import sys
 
 d = collections.defaultdict(list)
 for r in csv.DictReader(open(sys.argv[1])):
-    name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+    name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("fseg::", "").replace("void ", "").split("(")[0]
     d[name].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 print("%-28s %5s %10s %10s %10s" % ("kernel", "calls", "median_us", "min_us", "max_us"))
 for k, v in sorted(d.items(), key=lambda kv: -sorted(kv[1])[len(kv[1]) // 2] * len(kv[1])):

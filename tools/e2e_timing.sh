@@ -1,5 +1,5 @@
 #!/bin/bash
-# the CLI on a 2 M-read split directory in tmpfs, with the library's trace and the CLI's timing:  tools/r4_e2e.sh <tag> [runs]
+# the CLI on a 2 M-read split directory in tmpfs, with the library's trace and the CLI's timing:  tools/e2e_timing.sh <tag> [runs]
 T=$1; N=${2:-3}; shift; shift; EXTRA="$@"
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/$T
 python - <<'P' > gpurun_out/$T/gen.txt 2>&1

@@ -6,7 +6,7 @@ import csv
 import sys
 rows = []
 for r in csv.DictReader(open(sys.argv[1])):
-    name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+    name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("fseg::", "").replace("void ", "").split("(")[0]
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name, r.get("Queue_Id")))
 rows.sort()
 idx = [i for i, r in enumerate(rows) if r[2].startswith("k_hist") and not r[2].startswith("k_hist_ranges")]

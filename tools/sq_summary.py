@@ -8,7 +8,7 @@ import csv, sys
 from collections import defaultdict
 vals = defaultdict(lambda: defaultdict(list))
 for r in csv.DictReader(open(sys.argv[1])):
-    name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
+    name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("fseg::", "").split("(")[0].replace("void ", "")
     vals[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 args = [a for a in sys.argv[2:]]
 pat = ""

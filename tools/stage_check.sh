@@ -2,7 +2,7 @@
 # Round-5 GPU check of a scoring-stage change: parity tests of the stage's paths, then the stage's bracket (HIP events, one
 # resident batch replayed) for the three many-partition workloads with the device-side fork / join and with events, and the
 # stage's kernels one by one from a kernel trace.
-#   tools/r5_stage.sh <tag> [tests...]          (NO_TESTS=1 skips the tests; ENVS="A=1;B=2 C=3" adds environment variants; NO_TRACE=1)
+#   tools/stage_check.sh <tag> [tests...]          (NO_TESTS=1 skips the tests; ENVS="A=1;B=2 C=3" adds environment variants; NO_TRACE=1)
 T=${1:-r5s}; shift
 O=gpurun_out/$T
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT

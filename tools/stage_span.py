@@ -15,7 +15,7 @@ STAGE = ("k_solve", "k_dpw", "k_wave", "k_tiny", "k_gate", "k_cover", "k_score")
 SYNC = ("k_wait_word", "k_signal")
 rows = []
 for r in csv.DictReader(open(sys.argv[1])):
-    name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+    name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("fseg::", "").replace("void ", "").split("(")[0]
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name))
 rows.sort()
 runs, cur = [], []

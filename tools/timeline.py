@@ -5,7 +5,7 @@ the chosen step (default: the last but one), so that what really overlaps on the
 import csv, sys
 rows = []
 for r in csv.DictReader(open(sys.argv[1])):
-    name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+    name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("fseg::", "").replace("void ", "").split("(")[0]
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name, int(r["Queue_Id"]), int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"])), int(r["LDS_Block_Size"]), int(r["VGPR_Count"])))
 rows.sort()
 anchor = sys.argv[2] if len(sys.argv) > 2 else "k_hist"

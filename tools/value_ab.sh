@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-5 A/B of the headline figure (the 2 M-read job, host to host, eight contexts) under environment variants, in ONE call
-# (box-to-box differences are larger than most changes):  tools/r5_value.sh <tag> "A=1;B=2 C=3"   (REPS=3 rounds of every variant)
+# (box-to-box differences are larger than most changes):  tools/value_ab.sh <tag> "A=1;B=2 C=3"   (REPS=3 rounds of every variant)
 T=${1:-r5v}; ENVS=$2
 O=gpurun_out/$T
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
