@@ -107,6 +107,13 @@ struct fseg_ctx {
     DevBuf d_labels;             // label arena (sized after the final positions are known)
     DevBuf d_packed;             // the same at two bits per label, for the trip to the host
     int fetched_packed = -1;     // what the pinned result buffer holds: -1 nothing, 0 label bytes, 1 packed labels
+    // Round 5: the labels are WRITTEN at two bits each (k_label_reads ORs the codes of a rep's non-'0' labels into d_packed, a word
+    // at a time) whenever no column's default can be '2' (threshold_rate < 1: a read without coverage is never ambiguous) -- the
+    // 75 MB byte arena of a 250 k-read batch is then neither filled (15 us) nor packed (25 us); fseg_results / fseg_download unpack
+    // it on demand.  FSEG_LABEL_BYTES=1 keeps the byte arena as the primary form (and threshold_rate = 1 always does).
+    bool label_packed_ok = true;
+    bool run_label_packed = false;   // the resident run's labels live in d_packed
+    bool labels_unpacked = false;    // ... and d_labels holds their byte form (made on demand)
     DevBuf d_sort_tmp;
     // device buffers: inputs (slab_in, uploaded)
     DevBuf d_part_iv_off, d_part_rep_off, d_part_lane_off, d_iv_start, d_iv_end, d_pos_off, d_iv_part,
@@ -329,6 +336,12 @@ void drop_graph(fseg_ctx *c) {
 
 // (re)bind the data-dependent arenas for the current capacities; the label arena is its own allocation because it is
 // sized after everything else of a run has been written
+// the label arena for label_cap labels: two bits each (d_packed) when this context's parameters allow it, else bytes (d_labels)
+bool labels_packed(const fseg_ctx *c) { return c->label_packed_ok && c->have_params && c->P.threshold_rate < 1.0; }
+int ensure_label_arena(fseg_ctx *c) {
+    if (labels_packed(c)) return ensure(c, c->d_packed, (size_t)((c->label_cap + 15) / 16) * 4 + 16);
+    return ensure(c, c->d_labels, (size_t)c->label_cap + 16);
+}
 int alloc_arenas(fseg_ctx *c) {
     drop_graph(c);
     Carve cv;
@@ -371,7 +384,7 @@ int alloc_arenas(fseg_ctx *c) {
     }
     TRY(reserve(c, c->slab_arena, cv.total));
     cv.bind(c->slab_arena);
-    TRY(ensure(c, c->d_labels, (size_t)c->label_cap + 16));
+    TRY(ensure_label_arena(c));
     return FSEG_OK;
 }
 
@@ -886,7 +899,8 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
     // the label arena's '0' fill rides the big-problem DP launch as extra workgroups -- unless the run is being sized
     // (the arena's size is not known yet) or there is no DP launch
     // (not where the stages are bracketed by events: the fill is the labels stage's work, and a DP bracket that holds it says nothing about the DP)
-    const bool ride_fill = !sized && c->prob_cap > 0 && c->label_cap > 0 && any_arena && !stage_events;
+    const bool lab_packed = labels_packed(c);                   // (two-bit labels: the arena is cleared by a memset, nothing rides)
+    const bool ride_fill = !sized && c->prob_cap > 0 && c->label_cap > 0 && any_arena && !stage_events && !lab_packed;
     if (do_post1) {
     begin(ST_DP);
     if (c->prob_cap > 0 && any_arena) {
@@ -969,7 +983,11 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
     if (do_post2) {
     begin(ST_LABEL);
     if (c->label_cap > 0) {
-        if (!ride_fill) {                                           // no DP launch carried the fill
+        c->run_label_packed = lab_packed; c->labels_unpacked = false;
+        if (lab_packed) {
+            const i64 n16 = sized ? (label_fill_bytes + 15) / 16 : labels_n16;
+            if (n16 > 0) HIP_TRY(c, hipMemsetAsync(c->d_packed.p, 0, (size_t)n16 * 4, s));
+        } else if (!ride_fill) {                                    // no DP launch carried the fill
             const i64 n16 = sized ? (label_fill_bytes + 15) / 16 : labels_n16;
             if (n16 > 0)
                 hipLaunchKernelGGL(k_label_zero, dim3(grid_for(n16 / 8 + 1, 256, 4096)), dim3(256), 0, s, c->d_labels.as<uint4>(), n16);
@@ -979,7 +997,7 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
                            c->d_part_iv_off.as<i64>(), c->d_part_rep_off.as<i64>(), c->d_final_off.as<i64>(),
                            c->d_final_pos.as<int>(), c->d_col_thr.as<int2>(), c->d_rep_exon_off.as<i64>(),
                            c->d_ex_ts.as<int>(), c->d_ex_te.as<int>(), c->d_col_zero.as<unsigned char>(),
-                           c->d_part_has2.as<int>(), c->d_labels.as<unsigned char>());
+                           c->d_part_has2.as<int>(), c->d_labels.as<unsigned char>(), lab_packed ? c->d_packed.as<unsigned>() : (unsigned *)nullptr);
     }
     end(ST_LABEL);
     }   // do_post2
@@ -1237,7 +1255,11 @@ int run_sized(fseg_ctx *c) {
             return run_input_errors(c, s);
         }
         // C
-        if ((i64)s.label_bytes > c->label_cap) { c->label_cap = (i64)s.label_bytes; TRY(ensure(c, c->d_labels, (size_t)c->label_cap + 16)); c->label_cap = (i64)c->d_labels.cap - 16; }
+        if ((i64)s.label_bytes > c->label_cap) {
+            c->label_cap = (i64)s.label_bytes;
+            TRY(ensure_label_arena(c));
+            if (!labels_packed(c)) c->label_cap = (i64)c->d_labels.cap - 16;
+        }
         TRY(enqueue_run(c, SEG_POST2, true, (i64)s.label_bytes));
         c->h_status->err &= ~kErrOverflowLabels;       // the plan was made against the old capacity; the arena has been grown since
         c->pending = true;
@@ -1341,6 +1363,7 @@ int fseg_create(int device, fseg_ctx **out) {
     auto flag = [](const char *name) { const char *v = getenv(name); return v && v[0] == '1'; };
     { const char *v = getenv("FSEG_DEV_SYNC"); if (v && v[0] == '0') c->dev_sync = false; }
     { const char *v = getenv("FSEG_EMIT_SIGNAL"); if (v && v[0] == '0') c->emit_signal = false; }
+    if (flag("FSEG_LABEL_BYTES")) c->label_packed_ok = false;
     { const char *v = getenv("FSEG_THR_PART"); if (v && (v[0] == '0' || v[0] == '1')) c->thr_part = v[0] - '0'; }
     { const char *v = getenv("FSEG_SYNC_TICKS"); if (v && v[0] && atoll(v) > 0) c->sync_ticks = (unsigned)atoll(v); }
     if (flag("FSEG_NO_GRAPH")) c->use_graph = false;
@@ -1878,6 +1901,16 @@ static bool sdma_d2h(fseg_ctx *c, void *dst_pinned, const void *src_dev, size_t 
     return true;
 }
 
+// the byte form of labels that the run wrote at two bits each (fseg_results / fseg_download; once per run)
+static int unpack_labels(fseg_ctx *c, size_t lb) {
+    if (!c->run_label_packed || c->labels_unpacked || lb == 0) return FSEG_OK;
+    TRY(ensure(c, c->d_labels, lb + 32));
+    const i64 n16 = (i64)((lb + 15) / 16);
+    hipLaunchKernelGGL(k_unpack_labels, dim3(grid_for(n16, 256 * 4, 2048)), dim3(256), 0, c->stream, c->d_packed.as<unsigned>(), c->d_labels.as<uint4>(), n16);
+    c->labels_unpacked = true;
+    return FSEG_OK;
+}
+
 static int results_impl(fseg_ctx *c, const int64_t **part_final_off, const int32_t **final_pos, const int64_t **label_off,
                         const uint8_t **labels, bool packed) {
     if (!c) return FSEG_ERR_ARG;
@@ -1899,13 +1932,15 @@ static int results_impl(fseg_ctx *c, const int64_t **part_final_off, const int32
         HIP_TRY(c, hipMemcpyAsync(h + c->res_off[2], c->d_label_off.p, ((size_t)c->n_part + 1) * 8, hipMemcpyDeviceToHost, s));
         const void *big_src = nullptr;                       // the label matrix: on SDMA when it is large (see sdma_d2h)
         size_t big_bytes = 0;
-        if (lb && !packed) { big_src = c->d_labels.p; big_bytes = lb; }
+        if (lb && !packed) { TRY(unpack_labels(c, lb)); big_src = c->d_labels.p; big_bytes = lb; }
         if (lb && packed) {
             // (the label arena is allocated with 16 spare bytes: the last, partial group of 16 labels is read whole)
             const i64 n16 = (i64)((lb + 15) / 16);
-            TRY(ensure(c, c->d_packed, (size_t)n16 * 4));
-            hipLaunchKernelGGL(k_pack_labels, dim3(grid_for(n16, 256 * 4, 2048)), dim3(256), 0, s, c->d_labels.as<uint4>(),
-                               c->d_packed.as<unsigned>(), n16);
+            if (!c->run_label_packed) {                      // the run wrote bytes (threshold_rate = 1, FSEG_LABEL_BYTES=1): pack them
+                TRY(ensure(c, c->d_packed, (size_t)n16 * 4));
+                hipLaunchKernelGGL(k_pack_labels, dim3(grid_for(n16, 256 * 4, 2048)), dim3(256), 0, s, c->d_labels.as<uint4>(),
+                                   c->d_packed.as<unsigned>(), n16);
+            }
             big_src = c->d_packed.p; big_bytes = (size_t)n16 * 4;
         }
         if (big_bytes >= (1u << 20) && hsa_agents().ok && c->hsa_agent != -2) {
@@ -1954,7 +1989,10 @@ int fseg_download(fseg_ctx *c, int64_t *part_final_off, int32_t *final_pos, int6
     }
     if (final_pos) HIP_TRY(c, hipMemcpyAsync(final_pos, c->d_final_pos.p, (size_t)c->h_status->n_final * 4, hipMemcpyDeviceToHost, s));
     if (label_off) HIP_TRY(c, hipMemcpyAsync(label_off, c->d_label_off.p, ((size_t)c->n_part + 1) * 8, hipMemcpyDeviceToHost, s));
-    if (labels && c->h_status->label_bytes) HIP_TRY(c, hipMemcpyAsync(labels, c->d_labels.p, (size_t)c->h_status->label_bytes, hipMemcpyDeviceToHost, s));
+    if (labels && c->h_status->label_bytes) {
+        TRY(unpack_labels(c, (size_t)c->h_status->label_bytes));
+        HIP_TRY(c, hipMemcpyAsync(labels, c->d_labels.p, (size_t)c->h_status->label_bytes, hipMemcpyDeviceToHost, s));
+    }
     HIP_TRY(c, hipStreamSynchronize(s));
     return FSEG_OK;
 }

@@ -225,7 +225,8 @@ __global__ void __launch_bounds__(256) k_label_reads(int n_blocks, const int *rb
                                                      const i64 *final_off, const int *final_pos, const int2 *col_thr,
                                                      const i64 *rep_exon_off, const int *ex_ts, const int *ex_te,
                                                      const unsigned char *col_zero, const int *part_has2,
-                                                     unsigned char *labels);
+                                                     unsigned char *labels, unsigned *packed);
+__global__ void __launch_bounds__(256) k_unpack_labels(const unsigned *__restrict__ packed, uint4 *__restrict__ labels16, i64 n16);
 
 // seg_tail.hip
 __global__ void __launch_bounds__(256) k_pack_labels(const uint4 *__restrict__ labels16, unsigned *__restrict__ packed, i64 n16);

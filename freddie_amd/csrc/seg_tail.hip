@@ -370,7 +370,10 @@ __global__ void __launch_bounds__(256) k_label_reads(int n_blocks, const int *rb
                                                      const i64 *final_off, const int *final_pos, const int2 *col_thr,
                                                      const i64 *rep_exon_off, const int *ex_ts, const int *ex_te,
                                                      const unsigned char *col_zero, const int *part_has2,
-                                                     unsigned char *labels) {
+                                                     unsigned char *labels, unsigned *packed) {
+    // packed != nullptr: the labels are written at two bits each into a cleared arena (label g at bits 2 (g & 15) .. of word g >> 4,
+    // the layout fseg_results_packed delivers): a thread walks consecutive columns of its rep's row, collects the codes of a word
+    // in a register and ORs the word in when it moves on.  Only where no column's default is '2' (the host: threshold_rate < 1).
     __shared__ int fp_s[kLabelCols + 1];
     __shared__ int2 th_s[kLabelCols];
     if (label_off[n_part] > label_cap) return;
@@ -395,7 +398,7 @@ __global__ void __launch_bounds__(256) k_label_reads(int n_blocks, const int *rb
         __syncthreads();
         i64 r = (i64)rb_r0[blk] + sub * (256 / kLabelSplit) + (threadIdx.x / kLabelSplit);
         const int q = threadIdx.x % kLabelSplit;
-        if (part_has2[p]) {                                  // uniform over the workgroup: the rows' defaults are not all '0'
+        if (!packed && part_has2[p]) {                       // uniform over the workgroup: the rows' defaults are not all '0'
             if (r < part_rep_off[p + 1]) {
                 unsigned char *row0 = labels + label_off[p] + (r - part_rep_off[p]) * S;
                 const unsigned char *cz = col_zero + f0;
@@ -405,7 +408,10 @@ __global__ void __launch_bounds__(256) k_label_reads(int n_blocks, const int *rb
             __syncthreads();                                 // the label stores below may hit bytes another thread just wrote
         }
         if (r >= part_rep_off[p + 1]) continue;
-        unsigned char *row = labels + label_off[p] + (r - part_rep_off[p]) * S;
+        const i64 row_g0 = label_off[p] + (r - part_rep_off[p]) * S;
+        unsigned char *row = labels + row_g0;
+        unsigned acc = 0;
+        i64 acc_w = -1;
         i64 e = rep_exon_off[r], e1 = rep_exon_off[r + 1];
         if (e >= e1) continue;
         int first_ts = ex_ts[e], last_te = ex_te[e1 - 1];
@@ -444,8 +450,15 @@ __global__ void __launch_bounds__(256) k_label_reads(int n_blocks, const int *rb
             }
             // the arena already holds the zero-coverage label of the column ('0', or '2' when lo < 0): store only what differs
             const unsigned char lab = cov >= t2.x ? '1' : (cov <= t2.y ? '0' : '2');
-            if (lab != (t2.y < 0 ? '2' : '0')) row[c] = lab;
+            if (lab != (t2.y < 0 ? '2' : '0')) {
+                if (packed) {
+                    const i64 g = row_g0 + c, w = g >> 4;
+                    if (w != acc_w) { if (acc) atomicOr(&packed[acc_w], acc); acc_w = w; acc = 0; }
+                    acc |= (unsigned)(lab - '0') << (2 * (int)(g & 15));
+                } else row[c] = lab;
+            }
         }
+        if (acc) atomicOr(&packed[acc_w], acc);
     }
 }
 
@@ -459,6 +472,19 @@ __global__ void __launch_bounds__(256) k_label_reads(int n_blocks, const int *rb
 // slows kernels of the other contexts of the pipeline 3x while it runs.  The runtime's own large copies are kernels too --
 // see sdma_d2h() for what replaces them.)
 // ---------------------------------------------------------------------------------------------
+// ... and back: 32 bits -> 16 ASCII labels (fseg_results / fseg_download of a run that wrote its labels packed)
+__global__ void __launch_bounds__(256) k_unpack_labels(const unsigned *__restrict__ packed, uint4 *__restrict__ labels16, i64 n16) {
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (i64)gridDim.x * blockDim.x) {
+        const unsigned v = packed[i];
+        unsigned w[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned b = (v >> (8 * q)) & 0xffu;      // four labels
+            w[q] = 0x30303030u | (b & 3u) | ((b & 0xcu) << 6) | ((b & 0x30u) << 12) | ((b & 0xc0u) << 18);
+        }
+        labels16[i] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
 __global__ void __launch_bounds__(256) k_pack_labels(const uint4 *__restrict__ labels16, unsigned *__restrict__ packed, i64 n16) {
     for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (i64)gridDim.x * blockDim.x) {
         const uint4 v = labels16[i];                    // 16 ASCII labels ('0' + 0 .. 2) -> 32 bits

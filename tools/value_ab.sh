@@ -9,9 +9,9 @@ IFS=';' read -ra EV <<< "-${ENVS:+;$ENVS}"
 for r in $(seq 1 ${REPS:-3}); do
   for e in "${EV[@]}"; do
     if [ "$e" = "-" ]; then v=""; else v="$e"; fi
-    env $v timeout -k 10 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-e2e --no-extras 2>/dev/null | python -c "
+    env $v timeout -k 10 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-e2e --no-extras $BENCH_ARGS 2>/dev/null | python -c "
 import json,sys
 d=json.loads([l for l in sys.stdin if l.startswith('{')][-1])
-print('%-40s value %.1f M reads/s  %.3f ms/job  concurrent stage %.3f ms' % ('${v:-default}', d['value']/1e6, d['ms_per_step'], d['roofline_concurrent']['launch_ms']))"
+print('%-40s %s value %.1f M reads/s  %.3f ms/job  concurrent stage %.3f ms' % ('${v:-default}', '$BENCH_ARGS', d['value']/1e6, d['ms_per_step'], d['roofline_concurrent']['launch_ms']))"
   done
 done | tee $O/value_ab.txt
