@@ -1,4 +1,8 @@
-// freddie_seg.hip -- gfx950 (MI355X) kernels and C-ABI of the canonical-segmentation path.
+// freddie_seg.hip -- the HOST side of libfreddie_seg.so, the gfx950 (MI355X) library of the canonical-segmentation path: contexts,
+// slabs and arenas, the launch sequence of a run (enqueue_run), the sized first run, uploads, results, and the C-ABI of
+// include/freddie_seg.h.  The kernels live in the stage families' translation units (seg_front / seg_problems /
+// seg_score_arena / seg_score_fused + seg_solve16|32|60 / seg_tail / seg_upload .hip; shared definitions seg_common.h,
+// declarations seg_kernels.h); freddie_amd/build.py compiles the units side by side.
 //
 // What each kernel computes is defined by the reference's py/freddie_segment.py (cited per
 // kernel as file:line); how it computes it is specific to this implementation:

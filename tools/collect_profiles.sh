@@ -12,6 +12,8 @@ cp $O/config4_kernel_medians_8ctx.txt profiles/${P}_config4_kernel_medians_8ctx.
 cp $O/config2_kernel_medians.txt profiles/${P}_config2_kernel_medians.txt
 cp $O/config4_stage_span.txt profiles/${P}_config4_stage_span.txt
 [ -f $O/config4_stage_timeline.txt ] && cp $O/config4_stage_timeline.txt profiles/${P}_config4_stage_timeline.txt
+[ -f $O/config3_stage_timeline.txt ] && cp $O/config3_stage_timeline.txt profiles/${P}_config3_stage_timeline.txt
+[ -f $O/config3_stage_span.txt ] && cp $O/config3_stage_span.txt profiles/${P}_config3_stage_span.txt
 cp $O/replay_modes.txt profiles/${P}_replay_modes.txt
 for w in config4 config2; do
   cp $O/${w}_pmc_summary.txt profiles/${P}_${w}_pmc_summary.txt

@@ -7,6 +7,9 @@ P=${2:-${T:0:3}}
 O=gpurun_out/$T
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 mkdir -p $O
+# PART=1: bench + traces + counters; PART=2: the other workloads, rows N3 / N4, end to end, the host alone (a call each: gpurun's
+# limit is 20 minutes); default: everything
+if [[ "${PART:-all}" =~ ^(all|1)$ ]]; then
 # 1. the driver's command, plain and under the kernel trace (same command: the averages must agree with the line's events)
 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err; python profiles/benchsum.py < $O/bench_default.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o p -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-e2e > $O/bench_under_rocprof.json 2> $O/stats.err
@@ -41,6 +44,12 @@ for w in config4 config2; do
   python tools/sq_summary.py $O/pmc_${w}_sq/p_counter_collection.csv $O/pmc_${w}_sq/p_kernel_trace.csv > $O/${w}_sq_summary.txt
 done
 python profiles/make_traffic.py $O $P > $O/traffic_summary.txt; cp profiles/traffic.json $O/traffic.json
+fi
+if [[ "${PART:-all}" =~ ^(all|2)$ ]]; then
+# 2d. the stage's timeline on config3 (its chains end with the large class's DPs and the mid class's)
+rocprofv3 --kernel-trace --output-format csv -d $O/trace3c -o p -- python3 tools/replay_probe.py --workload config3 --profiling 2 > $O/replay_config3_plan.txt 2> $O/trace3c.err
+python tools/stage_timeline.py $O/trace3c/p_kernel_trace.csv > $O/config3_stage_timeline.txt; python tools/stage_span.py $O/trace3c/p_kernel_trace.csv > $O/config3_stage_span.txt; grep replay $O/replay_config3_plan.txt | cut -c1-120 >> $O/config3_stage_span.txt; cat $O/config3_stage_span.txt
+rm -rf $O/trace3c
 # 4. the other workloads, rows N3 / N4, end to end, the host alone
 for w in config2 config3 config5; do python bench.py --workload $w --no-cpu-baseline --no-e2e > $O/${w}_bench.json 2>/dev/null; python profiles/benchsum.py < $O/${w}_bench.json | head -1; done
 python bench.py --workload cluster-many > $O/n3_cluster_many_bench.json 2>/dev/null
@@ -48,9 +57,19 @@ python bench.py --workload cluster-big --steps 2 --no-cpu-baseline > $O/n3_clust
 python bench.py --workload isoforms > $O/n4_isoforms_bench.json 2>/dev/null
 python tools/e2e_bench.py --partitions 4000 --reads 500 --generate-only --keep /dev/shm/e2e_$T > /dev/null
 for t in 8 16 32; do python tools/e2e_bench.py --partitions 4000 --reads 500 --threads $t --sidecar off --repeat 2 --timing --keep /dev/shm/e2e_$T >> $O/e2e.log 2>&1; done
-python tools/host_ceiling.py --partitions 4000 --reads 500 --workers 1,2,4,8 --repeat 2 --keep /dev/shm/e2e_$T > $O/host_ceiling.txt 2>&1
 rm -rf /dev/shm/e2e_$T
+# the host alone (no GPU): the CPU share of this lease, the real main() against a stand-in device on a genome-like split
+# directory (24 contig directories), the native parser / writer under P processes x T threads
+{ echo "cgroup cpu.max: $(cat /sys/fs/cgroup/cpu.max 2>/dev/null)   visible CPUs: $(nproc)"; } > $O/host_ceiling.txt
+python tools/host_ceiling.py --partitions 16000 --reads 500 --contigs 24 --workers 1,2,4,8 --label 0,1 --repeat 2 --keep /dev/shm/hc_$T >> $O/host_ceiling.txt 2>/dev/null
+python tools/host_scaling_probe.py /dev/shm/hc_$T --procs 1,2,4,8,16,32 --threads 1,4,16 >> $O/host_ceiling.txt 2>&1
+python tools/host_scaling_probe.py /dev/shm/hc_$T --procs 8,16 --threads 1,4 --write >> $O/host_ceiling.txt 2>&1
+grep -h "nr_throttled\|throttled_usec" /sys/fs/cgroup/cpu.stat >> $O/host_ceiling.txt
+rm -rf /dev/shm/hc_$T
 grep "e2e\[" $O/e2e.log; cat $O/host_ceiling.txt
+fi
+if [[ "${PART:-all}" =~ ^(all|1)$ ]]; then
 # the driver's command once more, now that profiles/traffic.json carries this library's hash: bench_default.json (again) holds roofline.traffic / valu_util
 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err; python profiles/benchsum.py < $O/bench_default.json
 rm -rf $O/stats/*.csv.tmp
+fi
