@@ -1569,7 +1569,6 @@ constexpr int kLabelCols = 1024;
 constexpr int kLabelStage = FSEG_LABEL_STAGE;
 
 constexpr int kLabelSplit = 4;
-constexpr int kLabelExStage = 2048;    // exons of a unit's 64 reps that k_label_reads stages in LDS (a unit with more reads them from global memory)
 
 
 // ---------------------------------------------------------------------------------------------

@@ -376,9 +376,6 @@ __global__ void __launch_bounds__(256) k_label_reads(int n_blocks, const int *rb
     // in a register and ORs the word in when it moves on.  Only where no column's default is '2' (the host: threshold_rate < 1).
     __shared__ int fp_s[kLabelCols + 1];
     __shared__ int2 th_s[kLabelCols];
-    // the exons of the unit's 64 reps, staged (round 5): they are ONE contiguous piece of ex_ts / ex_te (consecutive reps), copied
-    // with coalesced loads; a thread's walk over its rep's exons -- a chain of dependent loads, two arrays -- then runs out of LDS
-    __shared__ int ets_s[kLabelExStage], ete_s[kLabelExStage];
     if (label_off[n_part] > label_cap) return;
     for (i64 unit = blockIdx.x; unit < (i64)n_blocks * kLabelSplit; unit += gridDim.x) {
         const int blk = (int)(unit / kLabelSplit), sub = (int)(unit % kLabelSplit);
@@ -397,16 +394,6 @@ __global__ void __launch_bounds__(256) k_label_reads(int n_blocks, const int *rb
             for (int x = threadIdx.x; x <= S; x += blockDim.x) fp_s[x] = fp[x];
             for (int x = threadIdx.x; x < S; x += blockDim.x) th_s[x] = th[x];
             fp = fp_s; th = th_s;
-        }
-        const int *xts = ex_ts, *xte = ex_te;                // (indexed by exon number: the staged copies are biased by the piece's start)
-        {
-            const i64 rA = (i64)rb_r0[blk] + sub * (256 / kLabelSplit);
-            const i64 rB = rA + 256 / kLabelSplit < part_rep_off[p + 1] ? rA + 256 / kLabelSplit : part_rep_off[p + 1];
-            const i64 eA = rep_exon_off[rA], eB = rep_exon_off[rB];
-            if (eB - eA <= kLabelExStage) {                   // (workgroup-uniform)
-                for (int x = threadIdx.x; x < (int)(eB - eA); x += blockDim.x) { ets_s[x] = ex_ts[eA + x]; ete_s[x] = ex_te[eA + x]; }
-                xts = ets_s - eA; xte = ete_s - eA;
-            }
         }
         __syncthreads();
         i64 r = (i64)rb_r0[blk] + sub * (256 / kLabelSplit) + (threadIdx.x / kLabelSplit);
@@ -427,7 +414,7 @@ __global__ void __launch_bounds__(256) k_label_reads(int n_blocks, const int *rb
         i64 acc_w = -1;
         i64 e = rep_exon_off[r], e1 = rep_exon_off[r + 1];
         if (e >= e1) continue;
-        int first_ts = xts[e], last_te = xte[e1 - 1];
+        int first_ts = ex_ts[e], last_te = ex_te[e1 - 1];
         // first column whose segment [fp[c], fp[c+1]) ends after first_ts
         int lo = 0, hi = (int)S;
         while (lo < hi) { int mid = (lo + hi) >> 1; if (fp[mid + 1] <= first_ts) lo = mid + 1; else hi = mid; }
@@ -441,23 +428,23 @@ __global__ void __launch_bounds__(256) k_label_reads(int n_blocks, const int *rb
         if (q) {                                             // first exon that reaches the first column of the share
             const int g = fp[c_a];
             i64 a = e, b = e1;
-            while (a < b) { i64 mid = (a + b) >> 1; if (xte[mid] < g) a = mid + 1; else b = mid; }
+            while (a < b) { i64 mid = (a + b) >> 1; if (ex_te[mid] < g) a = mid + 1; else b = mid; }
             e = a;
         }
         int ts = 0, te = 0;
-        if (e < e1) { ts = xts[e]; te = xte[e]; }
+        if (e < e1) { ts = ex_ts[e]; te = ex_te[e]; }
         for (int c = c_a; c < c_b; ++c) {
             int2 t2 = th[c];
             if (t2.x == 0x7fffffff) continue;                 // sentinel column between two intervals
             int g0 = fp[c], g1 = fp[c + 1];
-            while (e < e1 && te < g0) { ++e; if (e < e1) { ts = xts[e]; te = xte[e]; } }   // exons before the segment
+            while (e < e1 && te < g0) { ++e; if (e < e1) { ts = ex_ts[e]; te = ex_te[e]; } }   // exons before the segment
             int cov = 0;
             if (e < e1 && ts < g1) {
                 int a = ts > g0 ? ts : g0, b2 = te + 1 < g1 ? te + 1 : g1;
                 if (b2 > a) cov += b2 - a;
-                for (i64 x = e + 1; x < e1 && xts[x] < g1; ++x) {
-                    int a3 = xts[x] > g0 ? xts[x] : g0;
-                    int b3 = xte[x] + 1 < g1 ? xte[x] + 1 : g1;
+                for (i64 x = e + 1; x < e1 && ex_ts[x] < g1; ++x) {
+                    int a3 = ex_ts[x] > g0 ? ex_ts[x] : g0;
+                    int b3 = ex_te[x] + 1 < g1 ? ex_te[x] + 1 : g1;
                     if (b3 > a3) cov += b3 - a3;
                 }
             }

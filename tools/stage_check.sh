@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 mkdir -p $O
 TESTS=${@:-tests/test_gpu_paths.py tests/test_gpu_parity.py}
 if [ -z "$NO_TESTS" ]; then
-  timeout -k 10 1000 python -m pytest $TESTS -x -q -m gpu > $O/tests.txt 2>&1; rc=$?; tail -5 $O/tests.txt
+  timeout -k 10 ${TEST_TMO:-400} python -m pytest $TESTS -x -q -m gpu > $O/tests.txt 2>&1; rc=$?; tail -5 $O/tests.txt
   if [ $rc -ne 0 ]; then echo "TESTS FAILED rc=$rc"; exit $rc; fi
 fi
 IFS=';' read -ra EV <<< "-;FSEG_DEV_SYNC=0${ENVS:+;$ENVS}"
