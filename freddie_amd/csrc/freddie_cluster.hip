@@ -47,6 +47,7 @@ __device__ __forceinline__ unsigned range_mask(int f, int l, int w) {
 __global__ void __launch_bounds__(256) k_compat(int n_tiles, const int4 *tiles, const TintDesc *tints, const unsigned *bits,
                                                 const int *first, const int *last, const unsigned char *tail, u64 *adj) {
     extern __shared__ unsigned lds[];
+    __shared__ int row_f[kTile], row_l[kTile], row_t[kTile];
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     for (int ti = blockIdx.x; ti < n_tiles; ti += gridDim.x) {
         const int4 tile = tiles[ti];
@@ -61,6 +62,15 @@ __global__ void __launch_bounds__(256) k_compat(int n_tiles, const int4 *tiles, 
             rows[q * Wp + w] = r0 + q < d.n ? B[(i64)(r0 + q) * W + w] : 0u;
             cols[q * Wp + w] = c0 + q < d.n ? B[(i64)(c0 + q) * W + w] : 0u;
         }
+        // the tile's rows' first / last covered segment and tail, staged with the bit rows (round 5): the row loop below read them
+        // from global memory, three wave-uniform loads in front of every row's 64 pairs -- a microsecond of latency per row
+        if (threadIdx.x < kTile) {
+            const int row = r0 + threadIdx.x;
+            const bool ok = row < d.n;
+            row_f[threadIdx.x] = ok ? first[d.row0 + row] : 0;
+            row_l[threadIdx.x] = ok ? last[d.row0 + row] : -1;
+            row_t[threadIdx.x] = ok ? tail[d.row0 + row] : 0;
+        }
         __syncthreads();
         const int col = c0 + lane;
         const bool col_ok = col < d.n;
@@ -70,7 +80,7 @@ __global__ void __launch_bounds__(256) k_compat(int n_tiles, const int4 *tiles, 
         for (int rr = wave; rr < kTile; rr += 4) {
             const int row = r0 + rr;
             if (row >= d.n) break;
-            const int f1 = first[d.row0 + row], l1 = last[d.row0 + row], t1 = tail[d.row0 + row];
+            const int f1 = row_f[rr], l1 = row_l[rr], t1 = row_t[rr];
             bool edge = false;
             // poly-A tails on different ends: incompatible (:222-223)
             if (col_ok && col != row && !(t1 != 0 && t2 != 0 && t1 != t2)) {

@@ -1766,6 +1766,13 @@ static int run_impl(fseg_ctx *c) {
     // first run of a batch: piecewise with exact arena sizes; afterwards the sizes are known and the same launch
     // sequence is replayed (as a hipGraph unless disabled)
     if (!c->ran && c->use_sized) return run_sized(c);
+    if (c->label_cap > 0) {
+        // (the label arena of THIS run's form: a context whose parameters moved between threshold_rate < 1 -- two bits per label --
+        // and threshold_rate = 1 -- bytes -- has so far only the other one; nothing to do otherwise)
+        void *before[2] = {c->d_labels.p, c->d_packed.p};
+        TRY(ensure_label_arena(c));
+        if (before[0] != c->d_labels.p || before[1] != c->d_packed.p) drop_graph(c);
+    }
     c->last_sized = false;
     c->run_plain = !c->use_graph || c->profile_plain || (would_fork(c) && !c->graph_fork);
     if (!c->run_plain) {

@@ -180,6 +180,24 @@ def test_huge_problems_and_tiny_problems_in_one_batch(monkeypatch):
         ctx.close()
 
 
+@pytest.mark.parametrize("env", [{}, {"FSEG_NO_SIZED": "1"}], ids=["sized", "guessed-arenas"])
+def test_label_arena_follows_the_parameters(env, monkeypatch):
+    """threshold_rate < 1 writes the labels at two bits each, threshold_rate = 1 as bytes (a column's default can be '2'): one
+    context going back and forth between the two -- first runs and replays, sized and with guessed arenas -- always has the arena
+    its run needs."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    parts = [util.make_partition(9100 + i, n_reads=200 + 30 * i, n_exons=50, rp=0.1) for i in range(5)]
+    ctx = _lib.Context(0)
+    try:
+        for tau in (1.0, 0.9, 1.0, 0.8, 0.9, 1.0):
+            params = dict(threshold_rate=tau)
+            oracles = [util.run_oracle(p, params) for p in parts]
+            check_twice(ctx, parts, oracles, params)
+    finally:
+        ctx.close()
+
+
 @pytest.mark.parametrize("mps", [150, 300])
 def test_giant_problems_beyond_the_lds_kernels(mps, monkeypatch):
     """max_problem_size 150 / 300 (the CLI, like the reference's parse_args :108, accepts any value > 3; optimize :475-568 has no
