@@ -8,7 +8,9 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 namespace {
@@ -18,7 +20,8 @@ typedef unsigned long long u64;
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
-// One workgroup per isoform, its reads in chunks of kSpanCap.  Phase 1: the four waves split the chunk's reads and
+// k_consensus: rows of any length (the launch takes it when an isoform of the call has more than kRowMax segments; FISO_ROWS=0
+// forces it).  One workgroup per isoform, its reads in chunks of kSpanCap.  Phase 1: the four waves split the chunk's reads and
 // find every read's span = first / last segment holding '1' (ballot over 256 label bytes at a time), widened by the
 // tail rule of :217-224, into LDS.  Phase 2: lanes = 4 consecutive segments each, the waves split the reads again and count
 // coverage / consensus, partial sums meet in LDS.  The chunk's label bytes (tens of KB) are read from HBM once: the
@@ -151,6 +154,173 @@ __global__ void __launch_bounds__(256) k_consensus(int n_iso, const i64 *iso_rea
     }
 }
 
+// ---- rows of at most kRowMax segments (every tint seen so far): one pass, a read's whole row in one load instruction ----------
+// A read's M labels are a group of G = ceil(M / 16) consecutive lanes, 16 labels (one 16-byte load; 32 bits when PACKED) per
+// lane, and a wave-wide load instruction carries 64 / G reads; kRowE of them are in flight per wave.  With the row in
+// registers the span (first / last '1': one ballot, the group's bits of it, two lane reads) comes from the same bytes: no
+// second pass, no spans in LDS.  What is counted:
+//   consensus  a '1' always lies inside its read's span (the span IS first '1' .. last '1', and the tail rule only widens it),
+//              so cons[j] = the reads that hold '1' at j: the flag bytes themselves (bit 0 of a label's byte), added four
+//              segments to a register as BYTE counters, which go to the isoform's sums in LDS before a byte could overflow
+//              (every kRowFlush row loads) and at the end;
+//   coverage   cov[j] = reads with first <= j <= last = the running sum of (+1 at first, -1 at last + 1): two LDS atomics per
+//              read by its first lane and one scan per isoform instead of a span mask per lane and load.
+constexpr int kRowMax = 1024;        // 64 lanes x 16 labels
+#ifndef FISO_ROW_E
+#define FISO_ROW_E 2
+#endif
+#ifndef FISO_ROW_OCC
+#define FISO_ROW_OCC 8
+#endif
+constexpr int kRowE = FISO_ROW_E;    // row loads a wave keeps in flight
+constexpr int kRowFlush = 255 / kRowE * kRowE;   // row loads between flushes of the byte counters (a byte holds 255; a multiple of kRowE)
+// (24-bit multiplies and dot products: full rate, where a 32-bit multiply takes four issue slots)
+__device__ __forceinline__ unsigned spread4(unsigned nib) { return __umul24(nib, 0x00204081u) & 0x01010101u; }     // bit k -> bit 8k (k < 4)
+
+template <bool PACKED>
+__global__ void __launch_bounds__(256, FISO_ROW_OCC) k_consensus_rows(int n_iso, const i64 *iso_read_off, const int *n_seg, const i64 *iso_seg_off,
+                                                        const i64 *__restrict__ read_lab_off, const unsigned char *__restrict__ labels,
+                                                        const unsigned char *__restrict__ tail, int *cons, int *cov, int *tails) {
+    __shared__ int cons_s[kRowMax], diff_s[kRowMax + 4];
+    __shared__ int t_s[4], wtot_s[4];
+    const int lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int i = blockIdx.x; i < n_iso; i += gridDim.x) {
+        const i64 r0 = iso_read_off[i], r1 = iso_read_off[i + 1];
+        const int M = n_seg[i];
+        __syncthreads();                                                  // (the previous isoform's sums have left)
+        for (int j = threadIdx.x; j <= M && j <= kRowMax; j += blockDim.x) { if (j < kRowMax) cons_s[j] = 0; diff_s[j] = 0; }
+        if (threadIdx.x < 4) t_s[threadIdx.x] = 0;
+        __syncthreads();
+        if (M > 0 && M <= kRowMax && r0 < r1) {
+            const int G = (M + 15) >> 4, rpw = 64 / G;                    // lanes per read, reads per row load
+            const int g = lane / G, lp = lane - g * G;                    // this lane's read of the load, its 16 labels of the row
+            const bool lane_on = g < rpw;
+            const int seg0 = 16 * lp;
+            // labels of the sixteen inside the row (lp < G: M > seg0), as byte masks of the four words; nothing for an idle lane
+            const unsigned row16 = !lane_on ? 0u : (M - seg0 >= 16 ? 0xffffu : (1u << (M - seg0)) - 1u);
+            const unsigned rowm[4] = {spread4(row16 & 15u), spread4((row16 >> 4) & 15u), spread4((row16 >> 8) & 15u), spread4(row16 >> 12)};
+            const int gsh = g * G;                                        // the group's first lane
+            const u64 gmask = lane_on ? (G == 64 ? ~0ULL : (1ULL << G) - 1ULL) << gsh : 0ULL;     // the group's lanes, where they are in the wave
+            unsigned x[4] = {0, 0, 0, 0}, tc = 0;                         // byte counters: consensus; tails (a byte per tail value)
+            auto flush = [&]() {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const int xv = (int)((x[k] >> (8 * b)) & 255u);
+                        if (xv) atomicAdd(&cons_s[seg0 + 4 * k + b], xv);      // (xv > 0 only inside the row)
+                    }
+                    x[k] = 0;
+                }
+#pragma unroll
+                for (int t = 0; t < 3; ++t) { const int v = (int)((tc >> (8 * t)) & 255u); if (v) atomicAdd(&t_s[t], v); }
+                tc = 0;
+            };
+            const i64 stride = (i64)4 * rpw * kRowE;                      // reads a workgroup takes per step
+            i64 off[kRowE]; unsigned tl[kRowE];
+            const unsigned n_reads = (unsigned)(r1 - r0 < 0x10000000 ? r1 - r0 : 0x10000000);     // (an isoform of more reads than this: the two-pass kernel, see the launch)
+            const unsigned lane_r = lane_on ? (unsigned)(wave * rpw + g) : 0u;
+            const i64 *off_p = read_lab_off + r0;
+            const unsigned char *tail_p = tail + r0;
+            auto fetch_meta = [&](unsigned rel) {                        // rel: the step's first read, counted from the isoform's
+#pragma unroll
+                for (int e = 0; e < kRowE; ++e) {
+                    unsigned rc = rel + (unsigned)(e * 4 * rpw) + lane_r;
+                    rc = rc < n_reads ? rc : n_reads - 1u;                // (a valid read: loads are unconditional, the predicate comes after)
+                    off[e] = off_p[rc]; tl[e] = tail_p[rc];
+                }
+            };
+            // one step: kRowE row loads of this wave.  FULL: every read of the step exists (all but the isoform's last step).
+            // (Tried: the next step's rows requested before this step's are worked on -- 101 registers, 0.103 against 0.093 ms;
+            // with the arithmetic taken out the kernel takes 0.088 ms at rows of 150 labels and 0.070 at 148: a row that starts
+            // off a 4-byte boundary costs the load path what the arithmetic costs the ALUs.)
+            auto step = [&](auto full_c, i64 base, bool more) {
+                constexpr bool FULL = decltype(full_c)::value;
+                unsigned fb[kRowE][4];                                    // a lane's sixteen labels: a flag byte where the label is '1'
+                unsigned tle[kRowE];
+#pragma unroll
+                for (int e = 0; e < kRowE; ++e) {
+                    tle[e] = tl[e];
+                    const i64 first_label = off[e] + seg0;
+                    if (!PACKED) {
+                        // (a row starts anywhere.  Five words from the 4-byte boundary below, shifted into place with v_alignbyte,
+                        // instead of this unaligned 16-byte load: no faster at rows of 150 labels, slower at 144)
+                        uint4 v; __builtin_memcpy(&v, labels + first_label, 16);
+                        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const unsigned t = w[k] ^ 0x31313131u;                                        // a zero byte where the label is '1'
+                            fb[e][k] = (~(((t & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t) >> 7) & rowm[k];          // (exact: no carry crosses a byte)
+                        }
+                    } else {
+                        u64 q; __builtin_memcpy(&q, labels + (first_label >> 2), 8);
+                        const unsigned codes = (unsigned)(q >> (2 * (unsigned)(first_label & 3)));         // sixteen 2-bit codes
+                        const unsigned one = codes & ~(codes >> 1) & 0x55555555u;                          // code 1: bit 2s
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) fb[e][k] = __umul24((one >> (8 * k)) & 0x55u, 0x00041041u) & rowm[k];   // bit 2s -> bit 8s
+                    }
+                }
+                if (more) fetch_meta((unsigned)(base - r0 + stride));     // the next step's offsets fly during this step's arithmetic
+#pragma unroll
+                for (int e = 0; e < kRowE; ++e) {
+                    if (!FULL) {
+                        if (base + (i64)(e * 4 + wave) * rpw >= r1) break;                                 // (wave-uniform: none of this load's reads exists)
+                        const bool valid = base + (i64)(e * 4 + wave) * rpw + g < r1;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) fb[e][k] = valid ? fb[e][k] : 0u;
+                    }
+                    // flag bytes -> bits: a dot product with the bits' weights gathers a word's four flags
+                    const unsigned o16 = __builtin_amdgcn_udot4(fb[e][1], 0x80402010u, __builtin_amdgcn_udot4(fb[e][0], 0x08040201u, 0u, false), false) |
+                                         (__builtin_amdgcn_udot4(fb[e][3], 0x80402010u, __builtin_amdgcn_udot4(fb[e][2], 0x08040201u, 0u, false), false) << 8);
+                    const u64 m = __ballot(o16 != 0);
+                    const u64 gm = m & gmask;                                                              // this read's lanes that hold a '1'
+                    const bool has = gm != 0;                                                              // reads without a '1' are not counted (:215-216)
+                    const int lf = __ffsll((long long)gm) - 1, ll = 63 - __clzll((long long)gm);           // (lanes of the wave)
+                    const int myf = __ffs(o16) - 1 - 16 * gsh, myl = 31 - __clz(o16) - 16 * gsh;           // (the group's first lane taken off here: one subtraction)
+                    int first = 16 * lf + __shfl(myf, lf & 63), last = 16 * ll + __shfl(myl, ll & 63);
+                    if (tle[e] == 1) { first = 0; last = M - 1; }                                          // 'S': the whole tint (:217-224)
+                    if (has && lp == 0) {
+                        atomicAdd(&diff_s[first], 1); atomicAdd(&diff_s[last + 1], -1);
+                        tc += 1u << (8 * tle[e]);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) x[k] += fb[e][k];
+                }
+            };
+            fetch_meta(0u);
+            int since = 0;
+            i64 base = r0;
+            for (; base + stride <= r1; base += stride) {                 // steps whose reads all exist
+                step(std::true_type{}, base, base + stride < r1);
+                since += kRowE;
+                if (since >= kRowFlush) { flush(); since = 0; }
+            }
+            if (base < r1) step(std::false_type{}, base, false);
+            flush();
+        }
+        __syncthreads();
+        {   // coverage = the running sum of diff_s (four segments per thread, the waves' totals through LDS); results out
+            const int j4 = 4 * threadIdx.x;
+            int v[4], run = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { run += j4 + k < M && j4 + k < kRowMax ? diff_s[j4 + k] : 0; v[k] = run; }
+            int inc = run;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(inc, d); if (lane >= d) inc += y; }
+            if (lane == 63) wtot_s[wave] = inc;
+            __syncthreads();
+            int before = inc - run;
+            for (int w = 0; w < wave; ++w) before += wtot_s[w];
+            if (M <= kRowMax) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (j4 + k < M) { const i64 o = iso_seg_off[i] + j4 + k; cons[o] = cons_s[j4 + k]; cov[o] = before + v[k]; }
+            }
+        }
+        if (threadIdx.x < 3) tails[3 * (i64)i + threadIdx.x] = t_s[threadIdx.x];
+    }
+}
+
 // one workgroup per isoform: threads = the member reads' boundaries; every boundary votes for the isoform boundaries
 // within the window (they are ascending: lower bound, then walk)
 __global__ void __launch_bounds__(256) k_votes(int n_iso, const i64 *iso_read_off, const i64 *iso_b_off, const int *iso_bound,
@@ -209,7 +379,7 @@ struct Dev {
 
 template <typename T>
 int to_device(fiso_ctx *c, Dev &d, const T *src, size_t n) {
-    HIP_TRY(c, hipMalloc(&d.p, n * sizeof(T) + 16));
+    HIP_TRY(c, hipMalloc(&d.p, n * sizeof(T) + 32));      // (the kernels' vector loads reach up to 19 bytes past a row's end)
     if (n) HIP_TRY(c, hipMemcpyAsync(d.p, src, n * sizeof(T), hipMemcpyHostToDevice, c->stream));
     return FISO_OK;
 }
@@ -282,7 +452,11 @@ static int consensus_impl(fiso_ctx *c, int32_t n_iso, const int64_t *iso_read_of
     TRY(check_offsets(c, "iso_seg_off", iso_seg_off, n_iso));
     const i64 R = iso_read_off[n_iso], S = iso_seg_off[n_iso];
     i64 lab_bytes = 0;
+    int max_seg = 0;
+    i64 max_reads = 0;
     for (int i = 0; i < n_iso; ++i) {
+        if (n_seg[i] > max_seg) max_seg = n_seg[i];
+        if (iso_read_off[i + 1] - iso_read_off[i] > max_reads) max_reads = iso_read_off[i + 1] - iso_read_off[i];
         if (n_seg[i] < 0 || iso_seg_off[i + 1] - iso_seg_off[i] != n_seg[i]) return fail(c, FISO_ERR_ARG, "isoform %d: iso_seg_off does not match n_seg", i);
         for (i64 r = iso_read_off[i]; r < iso_read_off[i + 1]; ++r) {
             if (read_lab_off[r] < 0 || tail[r] > 2) return fail(c, FISO_ERR_ARG, "read %lld: bad label offset or tail", r);
@@ -302,7 +476,19 @@ static int consensus_impl(fiso_ctx *c, int32_t n_iso, const int64_t *iso_read_of
     HIP_TRY(c, hipMalloc(&d_tails.p, (size_t)n_iso * 12 + 16));
     hipStream_t s = c->stream;
     HIP_TRY(c, hipEventRecord(c->ev[0], s));
-    if (packed)
+    // rows of at most kRowMax labels (every isoform of the call): the one-pass kernel; FISO_ROWS=0 keeps the two-pass one (tests)
+    const char *rows_env = getenv("FISO_ROWS");
+    const bool rows = max_seg <= kRowMax && max_reads < 0x10000000 && !(rows_env && rows_env[0] == '0');
+    const dim3 grid(n_iso < 8192 ? n_iso : 8192);
+    if (rows && packed)
+        hipLaunchKernelGGL(k_consensus_rows<true>, grid, dim3(256), 0, s, n_iso, d_iro.as<i64>(), d_ns.as<int>(),
+                           d_iso.as<i64>(), d_rlo.as<i64>(), d_lab.as<unsigned char>(), d_tail.as<unsigned char>(),
+                           d_cons.as<int>(), d_cov.as<int>(), d_tails.as<int>());
+    else if (rows)
+        hipLaunchKernelGGL(k_consensus_rows<false>, grid, dim3(256), 0, s, n_iso, d_iro.as<i64>(), d_ns.as<int>(),
+                           d_iso.as<i64>(), d_rlo.as<i64>(), d_lab.as<unsigned char>(), d_tail.as<unsigned char>(),
+                           d_cons.as<int>(), d_cov.as<int>(), d_tails.as<int>());
+    else if (packed)
         hipLaunchKernelGGL(k_consensus<true>, dim3(n_iso < 8192 ? n_iso : 8192), dim3(256), 0, s, n_iso, d_iro.as<i64>(), d_ns.as<int>(),
                            d_iso.as<i64>(), d_rlo.as<i64>(), d_lab.as<unsigned char>(), d_tail.as<unsigned char>(),
                            d_cons.as<int>(), d_cov.as<int>(), d_tails.as<int>());

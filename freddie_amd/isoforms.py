@@ -44,9 +44,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(ISO_SO):
-        raise IsoformsError("%s not found: build it first (freddie_amd.isoforms.build()); there is no CPU fallback" % ISO_SO)
-    L = ctypes.CDLL(ISO_SO)
+    so = os.environ.get("FISO_LIB") or ISO_SO          # (FISO_LIB: a variant build, tools/ only)
+    if not os.path.exists(so):
+        raise IsoformsError("%s not found: build it first (freddie_amd.isoforms.build()); there is no CPU fallback" % so)
+    L = ctypes.CDLL(so)
     vp = ctypes.c_void_p
     L.fiso_abi_version.restype = ctypes.c_int
     L.fiso_create.restype = ctypes.c_int

@@ -134,3 +134,56 @@ def test_counts_are_plain_sums(ctx):
     d = rb[i * per:(i + 1) * per].reshape(-1)[None, :] - iso_b[i][:, None]
     want = np.stack([(d == x).sum(1) for x in range(-w, w + 1)], axis=1)
     assert np.array_equal(votes[i * nb:(i + 1) * nb], want)
+
+
+def _plain_counts(iro, n_seg, off, lab, tail):
+    """cons / cov / tails of isoforms_cons (:203-232) with numpy, an isoform at a time."""
+    cons, cov, tails = [], [], []
+    for i in range(len(n_seg)):
+        M, r0, r1 = int(n_seg[i]), int(iro[i]), int(iro[i + 1])
+        rows = np.stack([lab[int(off[r]):int(off[r]) + M] for r in range(r0, r1)]) if r1 > r0 and M else np.zeros((r1 - r0, M), np.uint8)
+        one = rows == ord("1")
+        has = one.any(1) if M else np.zeros(r1 - r0, bool)
+        first = np.where(has, one.argmax(1), M) if M else np.zeros(r1 - r0, int)
+        last = np.where(has, M - 1 - one[:, ::-1].argmax(1), -1) if M else np.zeros(r1 - r0, int) - 1
+        tl = tail[r0:r1]
+        first = np.where(has & (tl == 1), 0, first); last = np.where(has & (tl == 1), M - 1, last)
+        j = np.arange(M)[None, :]
+        inside = (j >= first[:, None]) & (j <= last[:, None])
+        cons.append((inside & one).sum(0)); cov.append(inside.sum(0))
+        tails.append([int((has & (tl == k)).sum()) for k in range(3)])
+    return np.concatenate(cons).astype(np.int32), np.concatenate(cov).astype(np.int32), np.asarray(tails, np.int32)
+
+
+@pytest.mark.parametrize("rows_switch", ["1", "0"])
+def test_row_lengths_and_read_counts_of_every_shape(ctx, rows_switch, monkeypatch):
+    """The one-pass kernel (rows of at most 1 024 labels: a read's row is one load instruction of a group of lanes) and the
+    two-pass one (FISO_ROWS=0; any row length) against plain numpy: row lengths around the 16-label lane and the group sizes,
+    the longest row, isoforms without reads, reads without a '1', enough reads to flush the byte counters mid-way, raw and
+    two-bit labels; a call with a longer row than 1 024 goes to the two-pass kernel whole."""
+    monkeypatch.setenv("FISO_ROWS", rows_switch)
+    rng = np.random.default_rng(21)
+    shapes = [(1, 70), (15, 33), (16, 200), (17, 64), (31, 5), (32, 129), (33, 1), (150, 500), (160, 77), (161, 300), (255, 40), (256, 9),
+              (511, 21), (513, 30), (1000, 1100), (1024, 300), (20, 33000), (48, 0), (100, 3), (0, 4)]
+    for longer in (False, True):
+        sh = shapes + ([(1025, 7), (3000, 12)] if longer else [])
+        n_seg = np.asarray([m for m, _ in sh]); per = np.asarray([n for _, n in sh])
+        iro = np.concatenate([[0], np.cumsum(per)])
+        R = int(iro[-1])
+        rows = []
+        for m, n in sh:
+            blk = rng.choice(np.frombuffer(b"0012", np.uint8), size=(n, m), p=[0.45, 0.25, 0.25, 0.05])
+            if m:
+                blk[rng.random(n) < 0.1] = ord("0")                       # reads without a '1'
+                blk[rng.random(n) < 0.1, : m // 2] = ord("2")             # spans that start late
+            rows.append(blk.reshape(-1))
+        lab = np.concatenate(rows)
+        off = np.concatenate([[0], np.cumsum(np.repeat(n_seg, per))])[:-1]
+        tail = rng.integers(0, 3, R).astype(np.uint8)
+        want = _plain_counts(iro, n_seg, off, lab, tail)
+        for packed in (False, True):
+            _, cons, cov, tails = ctx.consensus(iro, n_seg, off, isoforms.pack_labels(lab) if packed else lab, tail, packed=packed)
+            assert np.array_equal(cons, want[0]), (longer, packed)
+            assert np.array_equal(cov, want[1]), (longer, packed)
+            assert np.array_equal(tails, want[2]), (longer, packed)
+        assert want[0].sum() > 0

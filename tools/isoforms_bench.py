@@ -67,7 +67,7 @@ def run(n_iso=4000, per=500, M=150, steps=5, cpu_baseline=None):
            "n_gpus": 1, "steps": steps, "higher_is_better": True, "dtype": "u8/int32", "data": "synthetic",
            "config": {"workload": "isoforms", "isoforms": n_iso, "reads": R, "segments": M, "window": w},
            "kernel_ms": {"consensus": c_ms, "votes": v_ms}, "call_wall_ms": wall_ms,
-           "roofline": {"kernel": "k_consensus", "bound": "hbm", "achieved": alg / (c_ms * 1e-3) / 1e9, "peak": 8000.0,
+           "roofline": {"kernel": "k_consensus_rows (rows of at most 1 024 labels: one pass; longer rows: the two-pass k_consensus)", "bound": "hbm", "achieved": alg / (c_ms * 1e-3) / 1e9, "peak": 8000.0,
                         "unit": "GB/s", "frac": alg / (c_ms * 1e-3) / 1e9 / 8000.0, "traffic": None, "algorithmic_bytes_per_launch": alg}}
     p_ms = float(np.mean(pk_ms))
     out["consensus_packed_labels"] = {"kernel_ms": p_ms, "call_wall_ms": float(np.median(pk_wall)) * 1e3,
