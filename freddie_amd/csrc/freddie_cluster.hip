@@ -15,6 +15,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -44,23 +45,44 @@ __device__ __forceinline__ unsigned range_mask(int f, int l, int w) {
 }
 
 // ---- pairwise compatibility (py/freddie_cluster.py:217-234) ------------------------------------------------------
+// The relation is symmetric, so only the tiles on and above the diagonal are computed: a workgroup writes its tile's rows (a
+// row's 64 edge bits are one ballot) AND the transposed tile (lane = column keeps its own bit of every row; the waves' sixteen
+// rows each meet in LDS).
+// RANK (rows of at most kRankWords words): besides the bit rows, the number of a row's bits in front of each of its words is
+// staged (16 bits each; as 8-byte entries {word, rank} the big tint ran at two workgroups per CU instead of three and
+// took 3.0 instead of 2.0 ms).  A read's bits lie inside [first, last] (checked on the host), so over the pair's overlap [f, l]
+//   same = popcount(a & b) over the overlap's words, no mask (a & b has no bit outside [f, l]);
+//   diff = bits of a in [f, l] + bits of b in [f, l] - 2 same, and "bits of a in [f, l]" is the ranks of the overlap's first and
+//          last word and two masked popcounts of those words -- which the sum over the overlap reads anyway.
+// Most overlaps lie in one or two words: the first and the last word are taken outside the loop (four LDS reads a pair), the
+// loop runs over what lies between (its trip count is the longest overlap of the wave's 64 pairs).
+// !RANK: longer rows (up to kMaxWords): both sums with a range mask per word.
+constexpr int kRankWords = 207;     // (64 + 64) rows x (4 + 2) bytes x 207 words + the static arrays <= 160 KB of LDS
+
+template <bool RANK>
 __global__ void __launch_bounds__(256) k_compat(int n_tiles, const int4 *tiles, const TintDesc *tints, const unsigned *bits,
                                                 const int *first, const int *last, const unsigned char *tail, u64 *adj) {
     extern __shared__ unsigned lds[];
     __shared__ int row_f[kTile], row_l[kTile], row_t[kTile];
-    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    __shared__ unsigned col_part[4][kTile];
+    const int lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (int ti = blockIdx.x; ti < n_tiles; ti += gridDim.x) {
         const int4 tile = tiles[ti];
         const TintDesc d = tints[tile.x];
-        const int W = d.w, Wp = W | 1;                  // odd row stride: lanes reading the same word of 64 rows hit 64 banks
+        const int W = d.w, Wp = W | 1;                  // odd row stride: lanes reading the same word of 64 rows spread over the banks
         unsigned *rows = lds, *cols = lds + kTile * Wp;
+        unsigned short *rrank = reinterpret_cast<unsigned short *>(cols + kTile * Wp), *crank = rrank + kTile * Wp;
         const unsigned *B = bits + d.bits_off;
         const int r0 = tile.y * kTile, c0 = tile.z * kTile;
         __syncthreads();
-        for (int x = threadIdx.x; x < kTile * W; x += blockDim.x) {
-            const int q = x / W, w = x - q * W;
-            rows[q * Wp + w] = r0 + q < d.n ? B[(i64)(r0 + q) * W + w] : 0u;
-            cols[q * Wp + w] = c0 + q < d.n ? B[(i64)(c0 + q) * W + w] : 0u;
+        {
+            const float inv_w = 1.0f / (float)W;        // x / W for x < 64 * kMaxWords: a float quotient and one correction
+            for (int x = threadIdx.x; x < kTile * W; x += blockDim.x) {
+                int q = (int)((float)x * inv_w), w = x - q * W;
+                if (w >= W) { ++q; w -= W; } else if (w < 0) { --q; w += W; }
+                rows[q * Wp + w] = r0 + q < d.n ? B[(i64)(r0 + q) * W + w] : 0u;
+                cols[q * Wp + w] = c0 + q < d.n ? B[(i64)(c0 + q) * W + w] : 0u;
+            }
         }
         // the tile's rows' first / last covered segment and tail, staged with the bit rows (round 5): the row loop below read them
         // from global memory, three wave-uniform loads in front of every row's 64 pairs -- a microsecond of latency per row
@@ -72,34 +94,67 @@ __global__ void __launch_bounds__(256) k_compat(int n_tiles, const int4 *tiles, 
             row_t[threadIdx.x] = ok ? tail[d.row0 + row] : 0;
         }
         __syncthreads();
+        if (RANK) {
+            if (threadIdx.x < 2 * kTile) {              // a thread per staged row: the bits in front of each of its words
+                const unsigned *src = (threadIdx.x < kTile ? rows : cols) + (threadIdx.x & (kTile - 1)) * Wp;
+                unsigned short *dst = (threadIdx.x < kTile ? rrank : crank) + (threadIdx.x & (kTile - 1)) * Wp;
+                unsigned run = 0;
+                for (int w = 0; w < W; ++w) { dst[w] = (unsigned short)run; run += __popc(src[w]); }
+            }
+            __syncthreads();
+        }
         const int col = c0 + lane;
         const bool col_ok = col < d.n;
         int f2 = 0, l2 = -1, t2 = 0;
         if (col_ok) { f2 = first[d.row0 + col]; l2 = last[d.row0 + col]; t2 = tail[d.row0 + col]; }
         const unsigned *b = cols + lane * Wp;
-        for (int rr = wave; rr < kTile; rr += 4) {
-            const int row = r0 + rr;
+        const unsigned short *rb = crank + lane * Wp;
+        unsigned mine = 0;                               // this column's edge bits of the wave's sixteen rows
+        for (int k = 0; k < kTile / 4; ++k) {
+            const int rr = wave * (kTile / 4) + k, row = r0 + rr;
             if (row >= d.n) break;
             const int f1 = row_f[rr], l1 = row_l[rr], t1 = row_t[rr];
+            const int f = f1 > f2 ? f1 : f2, l = l1 < l2 ? l1 : l2;         // overlap of the two reads (:224-226)
+            const int o = l - f + 1;
             bool edge = false;
-            // poly-A tails on different ends: incompatible (:222-223)
-            if (col_ok && col != row && !(t1 != 0 && t2 != 0 && t1 != t2)) {
-                const int f = f1 > f2 ? f1 : f2, l = l1 < l2 ? l1 : l2;     // overlap of the two reads (:224-226)
-                const int o = l - f + 1;
-                // f < 0 only when neither read covers any segment: then no common segment either (:228-230)
-                if (o >= 1 && f >= 0) {
-                    const unsigned *a = rows + rr * Wp;
-                    int same = 0, diff = 0;
+            // poly-A tails on different ends: incompatible (:222-223); f < 0 only when neither read covers any segment: then no
+            // common segment either (:228-230).  (Straight-line code that computes every pair and drops the untested ones at the
+            // end was slower: whole waves skip here -- 0.168 against 0.151 ms on 400 tints of 500 reads.)
+            if (col_ok && col != row && !(t1 != 0 && t2 != 0 && t1 != t2) && o >= 1 && f >= 0) {
+                const unsigned *a = rows + rr * Wp;
+                int same = 0, diff = 0;
+                if (RANK) {
+                    const unsigned short *ra = rrank + rr * Wp;
+                    const int wf = f >> 5, wl = l >> 5;
+                    const unsigned a0 = a[wf], a1 = a[wl], b0 = b[wf], b1 = b[wl];
+                    same = __popc(a0 & b0);                                             // segments both reads cover (:229)
+                    if (wl > wf) {
+                        same += __popc(a1 & b1);
+                        for (int w = wf + 1; w < wl; ++w) same += __popc(a[w] & b[w]);
+                    }
+                    const unsigned below_f = (1u << (f & 31)) - 1u, upto_l = 0xffffffffu >> (31 - (l & 31));
+                    const int in_a = (int)ra[wl] + __popc(a1 & upto_l) - (int)ra[wf] - __popc(a0 & below_f);
+                    const int in_b = (int)rb[wl] + __popc(b1 & upto_l) - (int)rb[wf] - __popc(b0 & below_f);
+                    diff = in_a + in_b - 2 * same;                                      // segments where they differ (:232)
+                } else {
                     for (int w = f >> 5; w <= (l >> 5); ++w) {
                         const unsigned m = range_mask(f, l, w), x = a[w], y = b[w];
                         same += __popc(x & y & m);           // segments both reads cover (:229)
                         diff += __popc((x ^ y) & m);         // segments where they differ (:232)
                     }
-                    edge = same >= 1 && ((o > 3 && diff < 3) || (o <= 3 && diff == 0));   // :230, :234
                 }
+                edge = same >= 1 && ((o > 3 && diff < 3) || (o <= 3 && diff == 0));   // :230, :234
             }
             const u64 word = __ballot(edge);
             if (lane == 0) adj[d.adj_off + (i64)row * d.aw + tile.z] = word;
+            mine |= (unsigned)edge << k;
+        }
+        if (tile.y != tile.z) {                          // (workgroup-uniform) the tile below the diagonal: this one transposed
+            col_part[wave][lane] = mine;
+            __syncthreads();
+            if (threadIdx.x < kTile && col_ok)
+                adj[d.adj_off + (i64)col * d.aw + tile.y] = (u64)col_part[0][lane] | ((u64)col_part[1][lane] << 16) |
+                                                            ((u64)col_part[2][lane] << 32) | ((u64)col_part[3][lane] << 48);
         }
     }
 }
@@ -251,8 +306,11 @@ int fclu_create(int device, fclu_ctx **out) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     for (int i = 0; e == hipSuccess && i < 3; ++i) e = hipEventCreate(&c->ev[i]);
     if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_compat), hipFuncAttributeMaxDynamicSharedMemorySize,
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_compat<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 2 * kTile * (kMaxWords | 1) * 4);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_compat<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                2 * kTile * (kRankWords | 1) * 6);
     if (e != hipSuccess) {
         fail(nullptr, FCLU_ERR_HIP, "context creation failed: %s", hipGetErrorString(e));
         delete c;
@@ -306,8 +364,19 @@ int fclu_compat_graph(fclu_ctx *c, const fclu_batch *b, int32_t prune, uint64_t 
             row_tint[(size_t)(d.row0 + r)] = t;
             const int f = b->first[d.row0 + r], l = b->last[d.row0 + r];
             if (f < -1 || l >= (d.n_seg > 0 ? d.n_seg : 1) || b->tail[d.row0 + r] > 2) return fail(c, FCLU_ERR_ARG, "tint %d read %lld: first/last/tail out of range", t, r);
+            // a read's bits lie inside [first, last] (first / last ARE its first and last covered segment, :175-183): k_compat counts on it
+            const uint32_t *rw = b->bits + d.bits_off + r * d.w;
+            for (int w = 0; w < d.w; ++w) {
+                uint32_t allowed = 0;
+                if (f >= 0 && l >= f && w >= (f >> 5) && w <= (l >> 5)) {
+                    allowed = 0xffffffffu;
+                    if (w == (f >> 5)) allowed &= 0xffffffffu << (f & 31);
+                    if (w == (l >> 5)) allowed &= 0xffffffffu >> (31 - (l & 31));
+                }
+                if (rw[w] & ~allowed) return fail(c, FCLU_ERR_ARG, "tint %d read %lld: a covered segment outside [first, last]", t, r);
+            }
         }
-        for (int ti = 0; ti < d.aw; ++ti) for (int tj = 0; tj < d.aw; ++tj) tiles.push_back(make_int4(t, ti, tj, 0));
+        for (int ti = 0; ti < d.aw; ++ti) for (int tj = ti; tj < d.aw; ++tj) tiles.push_back(make_int4(t, ti, tj, 0));   // (on and above the diagonal)
         for (int z = 0; z < d.aw; ++z) word_tint.push_back(make_int2(t, z));
         tint_word0[(size_t)t + 1] = (i64)word_tint.size();
     }
@@ -357,10 +426,17 @@ int fclu_compat_graph(fclu_ctx *c, const fclu_batch *b, int32_t prune, uint64_t 
     HIP_TRY(c, hipMemcpyAsync(d_tail.p, b->tail, (size_t)R, hipMemcpyHostToDevice, s));
 
     const int grid = n_tiles < 8192 ? n_tiles : 8192;
-    const size_t lds = (size_t)2 * kTile * (max_w | 1) * 4;
+    // rows of at most kRankWords words: the rank tables ride along (FCLU_RANK=0 keeps the masked sums: tests)
+    const char *rank_env = getenv("FCLU_RANK");
+    const bool rank = max_w <= kRankWords && !(rank_env && rank_env[0] == '0');
+    const size_t lds = (size_t)2 * kTile * (max_w | 1) * (rank ? 6 : 4);
     HIP_TRY(c, hipEventRecord(c->ev[0], s));
-    hipLaunchKernelGGL(k_compat, dim3(grid), dim3(256), lds, s, n_tiles, d_tiles.as<int4>(), d_tints.as<TintDesc>(),
-                       d_bits.as<unsigned>(), d_first.as<int>(), d_last.as<int>(), d_tail.as<unsigned char>(), d_adj[0].as<u64>());
+    if (rank)
+        hipLaunchKernelGGL(k_compat<true>, dim3(grid), dim3(256), lds, s, n_tiles, d_tiles.as<int4>(), d_tints.as<TintDesc>(),
+                           d_bits.as<unsigned>(), d_first.as<int>(), d_last.as<int>(), d_tail.as<unsigned char>(), d_adj[0].as<u64>());
+    else
+        hipLaunchKernelGGL(k_compat<false>, dim3(grid), dim3(256), lds, s, n_tiles, d_tiles.as<int4>(), d_tints.as<TintDesc>(),
+                           d_bits.as<unsigned>(), d_first.as<int>(), d_last.as<int>(), d_tail.as<unsigned char>(), d_adj[0].as<u64>());
     HIP_TRY(c, hipEventRecord(c->ev[1], s));
     int cur = 0;
     if (prune) {

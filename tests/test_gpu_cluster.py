@@ -80,8 +80,12 @@ def test_partition_reads_on_random_tints_against_the_reference(ctx):
             assert cu.canon_partitions(t) == parts, "seed %d, maximum_ilp_size %s" % (case["seed"], size)
 
 
-def test_random_tints_batched(ctx):
-    """Shapes that cross every tile edge: N around 64 / 128, M around 32 / 64, one-row and empty-ish tints, in one batch."""
+@pytest.mark.parametrize("rank_switch", ["1", "0"])
+def test_random_tints_batched(ctx, rank_switch, monkeypatch):
+    """Shapes that cross every tile edge: N around 64 / 128, M around 32 / 64, one-row and empty-ish tints, in one batch.
+    Both forms of k_compat (FCLU_RANK=0: a range mask per word; default: rank tables), whose tiles lie on and above the
+    diagonal only -- the graphs are compared whole, both triangles."""
+    monkeypatch.setenv("FCLU_RANK", rank_switch)
     shapes = [(1, 5), (2, 1), (63, 31), (64, 32), (65, 33), (130, 64), (200, 65), (257, 100), (40, 300)]
     tints = [cu.random_tint(100 + k, n, m) for k, (n, m) in enumerate(shapes)]
     tints.append(cu.random_tint(200, 150, 20, n_isoforms=2, noise=0.0, tail_p=0.0))      # dense graph: heavy pruning input
@@ -126,11 +130,23 @@ def test_partitions_are_a_cover_and_incompatible_pairs_are_non_edges(ctx):
             assert a in s and b in s and not A[rep_row[a], rep_row[b]]
 
 
+def test_rows_longer_than_the_rank_tables_hold(ctx):
+    """A tint of 7 000 segments (219 words a row: beyond kRankWords = 207) takes the masked form whatever the switch says; a batch
+    that mixes it with short rows does so whole."""
+    tints = [cu.random_tint(300, 90, 7000, n_isoforms=5), cu.random_tint(301, 70, 40)]
+    check_graphs(ctx, tints)
+
+
 def test_rejects_bad_shapes(ctx):
     uniq = cluster_prep.unique_structures(cu.random_tint(5, 10, 12))
     packed = cluster_prep.pack_structures([uniq])
     bad = dict(packed); bad["last"] = packed["last"].copy(); bad["last"][0] = 12          # beyond the last segment
     with pytest.raises(cluster_prep.ClusterError, match="out of range"):
+        ctx.compat_graph(bad)
+    bad = dict(packed); bad["first"] = packed["first"].copy()
+    k = int(np.argmax(packed["last"] > packed["first"]))
+    bad["first"][k] += 1                                                                  # the read's first covered segment now lies in front of `first`
+    with pytest.raises(cluster_prep.ClusterError, match="outside"):
         ctx.compat_graph(bad)
     bad = dict(packed); bad["adj_off"] = packed["adj_off"].copy(); bad["adj_off"][1] += 1
     with pytest.raises(cluster_prep.ClusterError, match="adj_off"):
