@@ -3,6 +3,8 @@
 // Part of libfreddie_seg.so (gfx950); shared definitions: seg_common.h, declarations: seg_kernels.h, launches: freddie_seg.hip.
 #include "seg_kernels.h"
 
+#include <type_traits>
+
 namespace fseg {
 
 __global__ void __launch_bounds__(256) k_thr_table(const double *h_table, int h_len, double tau, int2 *tab) {
@@ -104,8 +106,7 @@ __global__ void __launch_bounds__(kSmoothThreads, FSEG_SMOOTH_OCC) k_smooth(int 
                                                 double *y_out, unsigned *flag_pos, unsigned *flag_cand, int *blk_pre, int *tile_tot,
                                                 int *tile_defer) {
     __shared__ int xs[kSmoothTile + 2 * kMaxRadius];
-    __shared__ __align__(4) unsigned char cf[kSmoothTile];     // candidate flags of the tile
-    __shared__ unsigned pf[kSmoothTile / 4];                   // Y > 0 flags of the tile, a byte per position like cf
+    __shared__ unsigned tw_c[kSmoothTile / 32 + 1], tw_p[kSmoothTile / 32 + 1];   // the tile's candidate / Y > 0 flags, a bit per position
     __shared__ int defer_s;
     __shared__ int blk_s[kSmoothTile / kSumBlock];
     __shared__ double ws[kMaxRadius + 1];
@@ -125,14 +126,30 @@ __global__ void __launch_bounds__(kSmoothThreads, FSEG_SMOOTH_OCC) k_smooth(int 
     auto load_counts = [&](const TileDesc &d, int *v) {
         // 'reflect': (d c b a | a b c d | d c b a).  One reflection does unless the interval is shorter than the radius;
         // only then the general index (a 64-bit modulo) is evaluated.
-        const int len_d = d.len, yb = d.y0 - radius + (int)threadIdx.x;
+        // (the record is the same in every lane: in scalar registers the tests below are branches of the whole wave)
+        const int len_d = __builtin_amdgcn_readfirstlane(d.len), y0_d = __builtin_amdgcn_readfirstlane(d.y0);
+        const int yb = y0_d - radius + (int)threadIdx.x;
+        const int *src = y_raw + (((i64)__builtin_amdgcn_readfirstlane((int)(d.base >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)d.base));
+        if (R > 0 && y0_d + kSmoothTile + radius <= len_d) {
+            // nothing of the window lies beyond the interval's end (two tiles in three): only the first radius positions of the
+            // interval's first tile reflect, and they are all in the first staged element (R <= kSmoothThreads)
+            static_assert(R <= kSmoothThreads, "a tile's left halo lies in the first staged element of each thread");
+#pragma unroll
+            for (int e = 0; e < kStage; ++e) {
+                const int idx = e * kSmoothThreads + threadIdx.x;
+                const int y = yb + e * kSmoothThreads;
+                const int r = e == 0 && y < 0 ? -1 - y : y;
+                v[e] = (e + 1) * kSmoothThreads <= kSmoothTile + 2 * R || idx < span ? src[r] : 0;
+            }
+            return;
+        }
 #pragma unroll
         for (int e = 0; e < kStage; ++e) {
             const int idx = e * kSmoothThreads + threadIdx.x;
             const int y = yb + e * kSmoothThreads;
             int r = y < 0 ? -1 - y : (y >= len_d ? 2 * len_d - 1 - y : y);
             if ((unsigned)r >= (unsigned)len_d) r = (int)reflect_index((i64)y, (i64)len_d);
-            v[e] = idx < span ? y_raw[d.base + r] : 0;
+            v[e] = idx < span ? src[r] : 0;
         }
     };
     int t = blockIdx.x;
@@ -172,15 +189,20 @@ __global__ void __launch_bounds__(kSmoothThreads, FSEG_SMOOTH_OCC) k_smooth(int 
                 const double w0 = ws[0];
                 a0 = __dmul_rn((double)(xs[c]), w0); a1 = __dmul_rn((double)(xs[c + 1]), w0);
                 a2 = __dmul_rn((double)(xs[c + 2]), w0); a3 = __dmul_rn((double)(xs[c + 3]), w0);
-                int l0 = xs[c - radius], l1 = xs[c - radius + 1], l2 = xs[c - radius + 2], l3 = xs[c - radius + 3];
-                int r0 = xs[c + radius], r1 = xs[c + radius + 1], r2 = xs[c + radius + 2], r3 = xs[c + radius + 3];
+                // R > 0: the windows hold the counts as doubles: a count is converted once, when it enters a window, and a pair's sum is
+                // an fp64 addition of two integers (exact: the same value as the sum converted) -- 3.5 instead of 4 instructions
+                // per output and tap.  (Any radius: integer windows, the sum converted: the doubles would spill there.)
+                typedef typename std::conditional<(R > 0), double, int>::type Win;
+                auto pair_sum = [](Win l, Win r) -> double { if constexpr (R > 0) return __dadd_rn(l, r); else return (double)(l + r); };
+                Win l0 = (Win)xs[c - radius], l1 = (Win)xs[c - radius + 1], l2 = (Win)xs[c - radius + 2], l3 = (Win)xs[c - radius + 3];
+                Win r0 = (Win)xs[c + radius], r1 = (Win)xs[c + radius + 1], r2 = (Win)xs[c + radius + 2], r3 = (Win)xs[c + radius + 3];
 #define FSEG_TAP(W)                                                                                        \
-                    a0 = __dadd_rn(a0, __dmul_rn((double)(l0 + r0), (W)));                                         \
-                    a1 = __dadd_rn(a1, __dmul_rn((double)(l1 + r1), (W)));                                         \
-                    a2 = __dadd_rn(a2, __dmul_rn((double)(l2 + r2), (W)));                                         \
-                    a3 = __dadd_rn(a3, __dmul_rn((double)(l3 + r3), (W)));                                         \
-                    l0 = l1; l1 = l2; l2 = l3; l3 = xs[c - j + 4];          /* left window moves right */          \
-                    r3 = r2; r2 = r1; r1 = r0; r0 = xs[c + j - 1];          /* right window moves left */
+                    a0 = __dadd_rn(a0, __dmul_rn(pair_sum(l0, r0), (W)));                                          \
+                    a1 = __dadd_rn(a1, __dmul_rn(pair_sum(l1, r1), (W)));                                          \
+                    a2 = __dadd_rn(a2, __dmul_rn(pair_sum(l2, r2), (W)));                                          \
+                    a3 = __dadd_rn(a3, __dmul_rn(pair_sum(l3, r3), (W)));                                          \
+                    l0 = l1; l1 = l2; l2 = l3; l3 = (Win)xs[c - j + 4];     /* left window moves right */          \
+                    r3 = r2; r2 = r1; r1 = r0; r0 = (Win)xs[c + j - 1];     /* right window moves left */
                 if (R > 0) {
 #pragma unroll
                     for (int j = R; j >= 1; --j) { FSEG_TAP(w_g[j]) }
@@ -208,41 +230,75 @@ __global__ void __launch_bounds__(kSmoothThreads, FSEG_SMOOTH_OCC) k_smooth(int 
         // writes their flags as one word.  What this tile cannot see is left to k_peaks_edges: whether its first and its last
         // position start a peak (their outer neighbours belong to other tiles) and the one plateau that may run into the
         // tile's last position (its start goes to tile_defer).
-        int mid0 = -1, mid1 = -1;        // plateau midpoints found by this thread, written after the words (four consecutive
-                                         // positions hold at most two plateau peaks: rise, level, fall, rise, level)
+        int mid0 = -1, mid1 = -1;        // plateau midpoints found by this thread (four consecutive positions hold at most two
+                                         // plateau peaks: rise, level, fall, rise, level)
+        unsigned word = 0;               // this thread's four candidate flags, a byte each
+#ifndef FSEG_SM_NOCAND
         {
             const int o4 = threadIdx.x * 4;
             const double v[6] = {ys[o4 > 0 ? o4 - 1 : 0], a0, a1, a2, a3, ys[o4 + 4 < kSmoothTile ? o4 + 4 : kSmoothTile - 1]};
-            unsigned word = 0;
+            auto plateau = [&](int i, double a) {                        // position i rises to a and the next one is level with it
+                int ia = i + 1;                                          // (scipy: extend while ia < len - 1 and y[ia] == y[i])
+                while (ia < kSmoothTile - 1 && y0 + ia < len - 1 && ys[ia] == a) ++ia;
+                if (ys[ia] == a && y0 + ia < len - 1) defer_s = i;       // still level at the tile's last position: not decidable here
+                                                                         // (at most one run of equal values reaches the tile's end)
+                else if (ys[ia] < a) { if (mid0 < 0) mid0 = (i + ia - 1) >> 1; else mid1 = (i + ia - 1) >> 1; }
+            };
+            // the wave's 256 positions lie strictly inside the interval (four waves in six of an average interval): no position is an
+            // end of the interval or beyond it, and the tile's own first / last position need no test -- the first sees itself as its
+            // left neighbour (no rise), the last itself as its right one (level: excluded below)
+            const int w0 = __builtin_amdgcn_readfirstlane(y0) + (int)(threadIdx.x & ~63u) * 4;
+            if (w0 >= 1 && w0 + 255 <= __builtin_amdgcn_readfirstlane(len) - 2) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int i = o4 + e;
-                const int pos = y0 + i;
-                if (pos >= len) break;
-                if (pos == 0 || pos == len - 1) { word |= 1u << (8 * e); continue; }
-                if (i == 0 || i == kSmoothTile - 1) continue;            // k_peaks_edges
-                const double a = v[e + 1];
-                if (v[e] < a) {
-                    if (v[e + 2] < a) word |= 1u << (8 * e);
-                    else if (v[e + 2] == a) {
-                        int ia = i + 1;                                  // (scipy: extend while ia < len - 1 and y[ia] == y[i])
-                        while (ia < kSmoothTile - 1 && y0 + ia < len - 1 && ys[ia] == a) ++ia;
-                        if (ys[ia] == a && y0 + ia < len - 1) defer_s = i;   // still level at the tile's last position: not decidable here
-                                                                             // (at most one run of equal values reaches the tile's end)
-                        else if (ys[ia] < a) { if (mid0 < 0) mid0 = (i + ia - 1) >> 1; else mid1 = (i + ia - 1) >> 1; }
+                for (int e = 0; e < 4; ++e) {
+                    const double a = v[e + 1];
+                    if (v[e] < a) {
+                        if (v[e + 2] < a) word |= 1u << (8 * e);
+                        else if (v[e + 2] == a && o4 + e != kSmoothTile - 1) plateau(o4 + e, a);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = o4 + e;
+                    const int pos = y0 + i;
+                    if (pos >= len) break;
+                    if (pos == 0 || pos == len - 1) { word |= 1u << (8 * e); continue; }
+                    if (i == 0 || i == kSmoothTile - 1) continue;        // k_peaks_edges
+                    const double a = v[e + 1];
+                    if (v[e] < a) {
+                        if (v[e + 2] < a) word |= 1u << (8 * e);
+                        else if (v[e + 2] == a) plateau(i, a);
                     }
                 }
             }
-            reinterpret_cast<unsigned *>(cf)[threadIdx.x] = word;
         }
-        lds_barrier();
-        if (mid0 >= 0) cf[mid0] = 1;
-        if (mid1 >= 0) cf[mid1] = 1;
-        {   // this thread's four Y > 0 flags, a byte each like the candidate flags (what lies beyond the interval flags nothing)
+#else
+        word = a1 > a2 ? 1u : 0u;      // diagnostic build (wrong results): no candidate test
+#endif
+#ifndef FSEG_SM_NOPACK
+        // The tile's flags leave as bits of the batch-wide masks (cleared before this kernel).  A thread's four candidate flags and
+        // its four Y > 0 flags are a nibble each; eight neighbouring lanes OR their nibbles into the word of their 32 positions
+        // (three DPP steps) and its first lane leaves it in LDS -- sixteen words a tile and mask -- where seventeen lanes shift them to
+        // where the tile starts in the batch, below.  (Round 4 kept a flag byte per position in LDS and had those seventeen lanes
+        // gather thirty-two bytes each: 11 of the kernel's 128 us, with the other threads waiting at the barrier.)  A plateau's
+        // midpoint is another thread's position: its bit goes to the mask directly.
+        {
             const int o4 = threadIdx.x * 4, left = len - (y0 + o4);
-            pf[threadIdx.x] = (left > 0 && a0 > 0.0 ? 1u : 0u) | (left > 1 && a1 > 0.0 ? 1u << 8 : 0u) |
-                              (left > 2 && a2 > 0.0 ? 1u << 16 : 0u) | (left > 3 && a3 > 0.0 ? 1u << 24 : 0u);
+            const unsigned nib_c = __builtin_amdgcn_udot4(word, 0x08040201u, 0u, false);
+            const unsigned nib_p = (left > 0 && a0 > 0.0 ? 1u : 0u) | (left > 1 && a1 > 0.0 ? 2u : 0u) |
+                                   (left > 2 && a2 > 0.0 ? 4u : 0u) | (left > 3 && a3 > 0.0 ? 8u : 0u);     // (what lies beyond the interval flags nothing)
+            const int sh4 = 4 * (threadIdx.x & 7);
+            unsigned vc = nib_c << sh4, vp = nib_p << sh4;
+            vc |= __builtin_amdgcn_update_dpp(0, vc, 0xB1, 0xf, 0xf, false);  vp |= __builtin_amdgcn_update_dpp(0, vp, 0xB1, 0xf, 0xf, false);    // quad_perm [1,0,3,2]
+            vc |= __builtin_amdgcn_update_dpp(0, vc, 0x4E, 0xf, 0xf, false);  vp |= __builtin_amdgcn_update_dpp(0, vp, 0x4E, 0xf, 0xf, false);    // quad_perm [2,3,0,1]
+            vc |= __builtin_amdgcn_update_dpp(0, vc, 0x141, 0xf, 0xf, false); vp |= __builtin_amdgcn_update_dpp(0, vp, 0x141, 0xf, 0xf, false);   // row_half_mirror: the other quad of the eight
+            if ((threadIdx.x & 7) == 0) { tw_c[threadIdx.x >> 3] = vc; tw_p[threadIdx.x >> 3] = vp; }
+            const i64 p0 = base + y0;
+            if (mid0 >= 0) atomicOr(&flag_cand[(p0 + mid0) >> 5], 1u << (int)((p0 + mid0) & 31));
+            if (mid1 >= 0) atomicOr(&flag_cand[(p0 + mid1) >> 5], 1u << (int)((p0 + mid1) & 31));
         }
+#endif
         lds_barrier();
         if (threadIdx.x == 0) tile_defer[t] = defer_s;
         {
@@ -259,28 +315,22 @@ __global__ void __launch_bounds__(kSmoothThreads, FSEG_SMOOTH_OCC) k_smooth(int 
                     if (y0 + o4 + e < len) y_out[p + e] = av[e];
             }
         }
+#ifndef FSEG_SM_NOPACK
         if (threadIdx.x <= kSmoothTile / 32) {
-            // The tile's flags leave as bits of the batch-wide masks: lane j < 16 packs the 32 flag bytes of the tile's j-th
-            // group into a word (four bytes at a time: (w * 0x00204081) >> 21 gathers their low bits), and since the tile starts
-            // at an arbitrary position of the batch -- bit s = (base + y0) & 31 of its first word -- word j of the masks is
-            // T[j] << s | T[j-1] >> (32 - s), seventeen of them, OR-ed in (the first and the last are shared with the
-            // neighbouring tiles; the masks are cleared before this kernel).
+            // the tile starts at an arbitrary position of the batch -- bit s = (base + y0) & 31 of its first word --, so word j of the
+            // masks is T[j] << s | T[j-1] >> (32 - s), seventeen of them, OR-ed in (the first and the last are shared with the
+            // neighbouring tiles)
             const int j = threadIdx.x;
-            auto pack = [&](const unsigned *bytes_w) {
-                unsigned tw = 0;
-#pragma unroll
-                for (int q = 0; q < 8; ++q) tw |= ((((bytes_w[8 * (j & 15) + q] & 0x01010101u) * 0x00204081u) >> 21) & 15u) << (4 * q);
-                return j < kSmoothTile / 32 ? tw : 0u;
-            };
-            const unsigned tc = pack(reinterpret_cast<const unsigned *>(cf)), tp = pack(pf);
-            const unsigned pc = __shfl_up(tc, 1), pp = __shfl_up(tp, 1);
+            const unsigned tc = j < kSmoothTile / 32 ? tw_c[j] : 0u, tp = j < kSmoothTile / 32 ? tw_p[j] : 0u;
+            const unsigned pc = j > 0 ? tw_c[j - 1] : 0u, pp = j > 0 ? tw_p[j - 1] : 0u;
             const i64 p0 = base + y0;
             const int sh = (int)(p0 & 31);
-            const unsigned gc = sh ? (tc << sh) | (j > 0 ? pc >> (32 - sh) : 0u) : tc;
-            const unsigned gp = sh ? (tp << sh) | (j > 0 ? pp >> (32 - sh) : 0u) : tp;
+            const unsigned gc = sh ? (tc << sh) | (pc >> (32 - sh)) : tc;
+            const unsigned gp = sh ? (tp << sh) | (pp >> (32 - sh)) : tp;
             if (gc) atomicOr(&flag_cand[(p0 >> 5) + j], gc);
             if (gp) atomicOr(&flag_pos[(p0 >> 5) + j], gp);
         }
+#endif
         d_cur = d_next; d_next = d_n2;
     }
 }
