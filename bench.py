@@ -52,7 +52,7 @@ sys.path.insert(0, ROOT)
 from freddie_amd import pack, synth, tables  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-BATCH_READS = 250000
+BATCH_READS = int(os.environ.get("FREDDIE_BENCH_BATCH_READS", "250000"))      # (the override: tuning runs only)
 
 PARAMS = {
     "default": dict(sigma=5.0, threshold_rate=0.9, variance_factor=3.0, max_problem_size=50,

@@ -233,6 +233,7 @@ struct fseg_ctx {
     i64 n_wide[3] = {0, 0, 0};  // of n_solve: problems that need the 16-bit-counter instances
     i64 max_ln = 0;             // reads the widest problem of the batch sees
     i64 tiny_from = 256;        // problems above which k_tiny is used (FSEG_TINY_FROM; tests force 0)
+    bool range_sums = true;     // FSEG_RANGE_SUMS=0: the problem scan's block sums by k_prob_scan1 instead of k_prob_range
     bool trace = false;         // FSEG_TRACE=1: phase timers of upload / run on stderr
     bool force_global_sort = false;   // FSEG_GLOBAL_SORT=1 (tests): the batch-wide radix sort whatever the partition sizes
     bool debug_recopy = false;  // FSEG_DEBUG_RECOPY=1 (probes): fseg_results copies again on every call
@@ -594,13 +595,16 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
                        c->d_thr.as<double>(), c->P.max_problem_size, c->d_fixed0.as<unsigned char>(),
                        c->d_added.as<unsigned char>(), c->d_fixed.as<unsigned char>(), c->d_chosen.as<unsigned char>(),
                        c->d_cand_pn.as<int>(), c->d_seg_iv.as<int>(), st);
-    hipLaunchKernelGGL(k_prob_range, dim3(grid_for(NPOS / 64 + 1, 256, 1024)), dim3(256), 0, s, st, c->d_cand_pn.as<int>(),
+    // (with the block sums of the problem scan when the scan is a launch of its own: k_prob_scan1 is the rescan's only; FSEG_RANGE_SUMS=0: tests)
+    i64 *range_bs = c->range_sums ? prob_bs : nullptr;
+    hipLaunchKernelGGL(k_prob_range, dim3(pg), dim3(kRangeThreads), 0, s, st, c->d_cand_pn.as<int>(),
                        c->d_seg_iv.as<int>(), c->d_cand_y.as<int>(), c->d_iv_part.as<int>(), c->d_iv_start.as<int>(),
                        c->d_part_lane_off.as<i64>(), c->d_lane_start.as<int>(), c->d_lane_pmax.as<int>(),
                        c->d_cand_ll.as<int>(), c->d_cand_ln.as<int>(), c->d_cand_wide.as<unsigned char>(), c->d_lane_lx.as<int2>(),
-                       c->d_lex.as<int2>(), c->wide_by_seen ? 1 : 0, split.fuse_lanes);
+                       c->d_lex.as<int2>(), c->wide_by_seen ? 1 : 0, split.fuse_lanes, range_bs, split);
     if (prob_bs) {
-        hipLaunchKernelGGL(k_prob_scan1, dim3(pg), dim3(256), 0, s, st, c->d_cand_pn.as<int>(), c->d_cand_ln.as<int>(), c->d_cand_wide.as<unsigned char>(), prob_bs, split);
+        if (!range_bs)
+            hipLaunchKernelGGL(k_prob_scan1, dim3(pg), dim3(256), 0, s, st, c->d_cand_pn.as<int>(), c->d_cand_ln.as<int>(), c->d_cand_wide.as<unsigned char>(), prob_bs, split);
         hipLaunchKernelGGL(k_prob_scan2, dim3(1), dim3(256), 0, s, st, prob_bs);
     }
     end(ST_FIX);
@@ -1211,11 +1215,11 @@ int run_sized(fseg_ctx *c) {
                 const int pg = grid_for(c->NPOS / 8 / kProbBlock + 1, 1, 1024);
                 Status *st = c->d_status.as<Status>();
                 if (fuse_turned_on)     // the first pass did not count the reads the wide problems keep: nobody was going to ask
-                    hipLaunchKernelGGL(k_prob_range, dim3(grid_for(c->NPOS / 64 + 1, 256, 1024)), dim3(256), 0, c->stream, st, c->d_cand_pn.as<int>(),
+                    hipLaunchKernelGGL(k_prob_range, dim3(pg), dim3(kRangeThreads), 0, c->stream, st, c->d_cand_pn.as<int>(),
                                        c->d_seg_iv.as<int>(), c->d_cand_y.as<int>(), c->d_iv_part.as<int>(), c->d_iv_start.as<int>(),
                                        c->d_part_lane_off.as<i64>(), c->d_lane_start.as<int>(), c->d_lane_pmax.as<int>(),
                                        c->d_cand_ll.as<int>(), c->d_cand_ln.as<int>(), c->d_cand_wide.as<unsigned char>(), c->d_lane_lx.as<int2>(),
-                                       c->d_lex.as<int2>(), c->wide_by_seen ? 1 : 0, split_of(c, tiny, fuse).fuse_lanes);
+                                       c->d_lex.as<int2>(), c->wide_by_seen ? 1 : 0, split_of(c, tiny, fuse).fuse_lanes, (i64 *)nullptr, split_of(c, tiny, fuse));
                 // (the scan ADDS to the per-class counts of wide problems: the first scan's must not stay in them)
                 HIP_TRY(c, hipMemsetAsync(reinterpret_cast<char *>(st) + offsetof(Status, wide_cls), 0, sizeof(st->wide_cls), c->stream));
                 hipLaunchKernelGGL(k_prob_scan1, dim3(pg), dim3(256), 0, c->stream, st, c->d_cand_pn.as<int>(), c->d_cand_ln.as<int>(), c->d_cand_wide.as<unsigned char>(),
@@ -1393,6 +1397,7 @@ int fseg_create(int device, fseg_ctx **out) {
     { const char *v = getenv("FSEG_FUSE_LANES"); if (v && v[0] && atoi(v) > 0 && atoi(v) <= kFuseLanesWide) c->fuse_lanes = atoi(v); }
     if (flag("FSEG_NO_SIZED")) c->use_sized = false;
     if (flag("FSEG_TRACE")) c->trace = true;
+    if (const char *e = getenv("FSEG_RANGE_SUMS")) c->range_sums = e[0] != '0';
     if (flag("FSEG_DEBUG_RECOPY")) c->debug_recopy = true;
     if (flag("FSEG_GLOBAL_SORT")) c->force_global_sort = true;
     if (flag("FSEG_FORCE_SCAN_STALL")) c->force_scan_stall = true;

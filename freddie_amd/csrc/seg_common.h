@@ -731,7 +731,7 @@ __device__ __forceinline__ void window_exons(const int2 *__restrict__ lex, int2 
 // each): the workgroup collects its own in LDS and goes over them together, a read per thread.  (Round 4 until here: both
 // instances located every such problem and counted its kept reads, the 16-bit ones to drop nearly all of them again --
 // launches of 12-70 us in front of the classes behind them on config3 / config5.)
-constexpr int kRangeThreads = 256;
+constexpr int kRangeThreads = 1024;    // = kProbBlock: a workgroup of k_prob_range is a block of the problem scan
 
 
 // Problem list by a prefix sum over the candidates: problem slot, pair / triple / coverage arena offsets and

@@ -72,10 +72,11 @@ __global__ void k_fix(i64 K, const i64 *pos_off, const int *iv_part, const i64 *
                       unsigned char *fixed, unsigned char *chosen, int *cand_pn, int *cand_iv, Status *st);
 
 // seg_problems.hip
-__global__ void __launch_bounds__(kRangeThreads) k_prob_range(const Status *st, const int *cand_pn, const int *cand_iv, const int *cand_y,
+__global__ void __launch_bounds__(kRangeThreads) k_prob_range(Status *st, const int *cand_pn, const int *cand_iv, const int *cand_y,
                              const int *iv_part, const int *iv_start, const i64 *part_lane_off, const int *lane_start,
                              const int *lane_pmax, int *cand_ll, int *cand_ln, unsigned char *cand_wide,
-                             const int2 *__restrict__ lane_lx, const int2 *__restrict__ lex, int wide_by_seen, int fuse_lanes);
+                             const int2 *__restrict__ lane_lx, const int2 *__restrict__ lex, int wide_by_seen, int fuse_lanes,
+                             i64 *bs, ProbSplit sp);
 
 // seg_problems.hip
 __global__ void __launch_bounds__(256) k_prob_scan1(Status *st, const int *cand_pn, const int *cand_ln, const unsigned char *cand_wide, i64 *bs, ProbSplit sp);

@@ -10,6 +10,9 @@ __global__ void k_fix(i64 K, const i64 *pos_off, const int *iv_part, const i64 *
                       unsigned char *fixed, unsigned char *chosen, int *cand_pn, int *cand_iv, Status *st) {
     __shared__ int lds[16];
     const int T = blockDim.x;
+    // (Round 5, measured and not kept: eight intervals per wave -- lanes 8g .. 8g+7 the candidates of interval kb + g -- while an interval
+    // holds at most eight candidates (most hold two or three) and the longer ones one by one behind them: 17 us against 14, the longer
+    // intervals of a group then run one after the other in ONE wave instead of side by side in their own.)
     for (i64 k = blockIdx.x; k < K; k += gridDim.x) {
         i64 c0 = cand_off[k];
         int N = (int)(cand_off[k + 1] - c0);
@@ -87,11 +90,18 @@ __global__ void k_fix(i64 K, const i64 *pos_off, const int *iv_part, const i64 *
     }
 }
 
-__global__ void __launch_bounds__(kRangeThreads) k_prob_range(const Status *st, const int *cand_pn, const int *cand_iv, const int *cand_y,
+// bs != nullptr: the workgroup's 1 024 candidates are a block of the problem scan, and it adds up the block's sizes itself when its
+// ranges are known -- what k_prob_scan1 (25 us of a config4 batch, most of it 147 workgroups starting, loading and ending) then
+// need not do.
+__global__ void __launch_bounds__(kRangeThreads) k_prob_range(Status *st, const int *cand_pn, const int *cand_iv, const int *cand_y,
                              const int *iv_part, const int *iv_start, const i64 *part_lane_off, const int *lane_start,
                              const int *lane_pmax, int *cand_ll, int *cand_ln, unsigned char *cand_wide,
-                             const int2 *__restrict__ lane_lx, const int2 *__restrict__ lex, int wide_by_seen, int fuse_lanes) {
+                             const int2 *__restrict__ lane_lx, const int2 *__restrict__ lex, int wide_by_seen, int fuse_lanes,
+                             i64 *bs, ProbSplit sp) {
+    static_assert(kRangeThreads == kProbBlock, "a workgroup of k_prob_range is a block of the problem scan");
     __shared__ int l_wide[kRangeThreads], l_n, l_red[kRangeThreads / 64];
+    __shared__ i64 scan_lds[4 * kProbCols];
+    __shared__ int l_mx[8];
     const i64 n_cand = (i64)st->n_cand;
     for (i64 c0 = (i64)blockIdx.x * blockDim.x; c0 < n_cand; c0 += (i64)gridDim.x * blockDim.x) {    // (workgroup-uniform)
         const i64 c = c0 + threadIdx.x;
@@ -138,6 +148,30 @@ __global__ void __launch_bounds__(kRangeThreads) k_prob_range(const Status *st, 
                 for (int q = 0; q < kRangeThreads / 64; ++q) tot += l_red[q];
                 if (tot > kFuseLanes) cand_wide[cw] = 1;
             }
+            __syncthreads();
+        }
+        if (bs) {                                            // (workgroup-uniform) the block's sums, as k_prob_scan1 makes them
+            __syncthreads();                                 // (the block's ranges and wide marks are written)
+            const i64 b = c0 / kProbBlock;
+            // (the scan's own shape: the first four waves, four candidates a thread; the other waves only meet the barriers)
+            const bool scan_t = threadIdx.x < 256;
+            const int lane = lane_id(), wave = threadIdx.x >> 6;
+            ProbSizes acc;
+            if (scan_t) {
+                acc = prob_block_sizes(cand_pn, cand_ln, b, n_cand, nullptr, sp);
+                prob_block_maxima(st, cand_pn, cand_ln, b, n_cand, l_mx);
+                prob_block_wide(st, cand_pn, cand_ln, cand_wide, b, n_cand, sp);
+                for (int q = 0; q < kProbCols; ++q) {
+                    i64 x = acc.v[q];
+                    for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d);
+                    if (lane == 0) scan_lds[wave * kProbCols + q] = x;
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x < kProbCols)
+                bs[b * kProbCols + threadIdx.x] = scan_lds[threadIdx.x] + scan_lds[kProbCols + threadIdx.x] + scan_lds[2 * kProbCols + threadIdx.x] +
+                                                  scan_lds[3 * kProbCols + threadIdx.x];
+            if (threadIdx.x == 0) prob_publish_maxima(st, l_mx);
             __syncthreads();
         }
     }

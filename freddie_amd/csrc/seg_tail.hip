@@ -398,6 +398,9 @@ __global__ void __launch_bounds__(256) k_label_reads(int n_blocks, const int *rb
         __syncthreads();
         i64 r = (i64)rb_r0[blk] + sub * (256 / kLabelSplit) + (threadIdx.x / kLabelSplit);
         const int q = threadIdx.x % kLabelSplit;
+#ifdef FSEG_LAB_NOSEARCH
+        if (fp[0] != -12345) continue;                       // diagnostic build (wrong results): the workgroup's staging only
+#endif
         if (!packed && part_has2[p]) {                       // uniform over the workgroup: the rows' defaults are not all '0'
             if (r < part_rep_off[p + 1]) {
                 unsigned char *row0 = labels + label_off[p] + (r - part_rep_off[p]) * S;
@@ -425,6 +428,9 @@ __global__ void __launch_bounds__(256) k_label_reads(int n_blocks, const int *rb
         const int span = c_hi - lo;
         const int c_a = lo + (int)((i64)span * q / kLabelSplit), c_b = lo + (int)((i64)span * (q + 1) / kLabelSplit);
         if (c_a >= c_b) continue;
+#ifdef FSEG_LAB_NOLOOP
+        if (c_a != -12345) { if (c_b == 0x7ffffff0) atomicOr(&packed[0], 1u); continue; }    // diagnostic build (wrong results): no column loop
+#endif
         if (q) {                                             // first exon that reaches the first column of the share
             const int g = fp[c_a];
             i64 a = e, b = e1;
@@ -453,7 +459,11 @@ __global__ void __launch_bounds__(256) k_label_reads(int n_blocks, const int *rb
             if (lab != (t2.y < 0 ? '2' : '0')) {
                 if (packed) {
                     const i64 g = row_g0 + c, w = g >> 4;
+#ifdef FSEG_LAB_NOSTORE
+                    if (w != acc_w) { acc_w = w; }           // diagnostic build (wrong results): one store per thread
+#else
                     if (w != acc_w) { if (acc) atomicOr(&packed[acc_w], acc); acc_w = w; acc = 0; }
+#endif
                     acc |= (unsigned)(lab - '0') << (2 * (int)(g & 15));
                 } else row[c] = lab;
             }
@@ -461,6 +471,13 @@ __global__ void __launch_bounds__(256) k_label_reads(int n_blocks, const int *rb
         if (acc) atomicOr(&packed[acc_w], acc);
     }
 }
+
+
+// (Round 5, measured and not kept: the (rep, column) pairs of a workgroup's 64 reps as ONE list walked by its 256 threads -- every
+// thread the same number of pairs, the reps' exons in LDS, a word's codes OR-ed across lanes before one atomic -- parity-green,
+// 78 us against 73: finding a pair's rep, walking its exons from the first and the cross-lane OR cost more per pair than the
+// balance saves.  Of k_label_reads' 73 us 41 are the column loop, 13 its stores, 9 the bisections, 10 the workgroup's staging
+// (tools/probes/label_ablate.sh with the FSEG_LAB_NO* builds).)
 
 
 // ---------------------------------------------------------------------------------------------

@@ -83,6 +83,7 @@ SWITCHES = [
     {"FSEG_THR_PART": "0"},                                 # ... and never: the batch-wide compaction + a workgroup per 8192-value chunk
     {"FSEG_THR_PART": "1", "FSEG_NO_FORK": "1", "FSEG_NO_GRAPH": "1"},
     {"FSEG_LABEL_BYTES": "1"},                              # the label arena as bytes (the default writes two bits per label; threshold_rate = 1 always takes bytes)
+    {"FSEG_RANGE_SUMS": "0"},                               # the problem scan's block sums by k_prob_scan1 (the rescan's kernel) instead of k_prob_range
     {"FSEG_EMIT_SIGNAL": "0"},                              # the side streams' waiters released by the first launch behind k_prob_emit only, not by its last workgroup
 ]
 
