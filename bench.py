@@ -28,6 +28,7 @@ Prints ONE JSON line (rank 0) with, besides the driver's fields:
   value_resident_replay replay of one resident batch (no copies, no sizing; plain launches on the library's streams -- a run
                         that forks is not replayed as a hipGraph: DESIGN.md section 3)
   value_hbm_resident    batches uploaded first, then each run once (first-run path, no copies in the timed part)
+  value_inputs_resident the same batches left resident, K passes by the eight contexts (no copies in the timed part)
   cpu_baseline / cpu_baseline_all_cores   the C oracle on this box's host cores (1 thread / every core)
   e2e                   the drop-in CLI on a split directory of the same job in tmpfs: files in -> files out, through the CLI's N
                         worker processes, run by rank 0 before any rank touches a GPU
@@ -669,6 +670,29 @@ def main():
                                          "what": "%d distinct batches uploaded first (one per context), then each run once, concurrently: "
                                                  "first-run path (sized arenas, plain launches), results left in HBM, no copies in the "
                                                  "timed part" % n_h}
+            # the same with the batches left where they are: K passes, every context over its own resident batch (inputs in HBM
+            # before the timed part, results left in HBM, everything recomputed from the inputs each pass; a pass after the first
+            # finds its arenas sized).  `value` itself stays host memory -> host memory, the stricter figure.
+            for c2 in ctxs[:n_h]:
+                c2.sync()
+
+            def run_many(c2):
+                for _ in range(args.steps):
+                    c2.run()
+                    c2.sync()
+            th = [threading.Thread(target=run_many, args=(c2,)) for c2 in ctxs[:n_h]]
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for t_ in th:
+                t_.start()
+            for t_ in th:
+                t_.join()
+            torch.cuda.synchronize()
+            dt_i = time.perf_counter() - t0
+            out["value_inputs_resident"] = {"value": sum(b.n_reads for b in batches[:n_h]) * args.steps / dt_i, "unit": "reads/s",
+                                            "ms_per_batch": dt_i / (n_h * args.steps) * 1e3, "steps": args.steps,
+                                            "what": "%d contexts, each over its own resident batch (%d distinct batches of the job), %d passes: inputs in HBM "
+                                                    "when the timed part starts, no copies in it, results left in HBM; rank 0's GPU" % (n_h, n_h, args.steps)}
             # BASELINE configs[1]: one 50 k-read partition.  Its problems take the arena path, where coverage (k_cov: inside the
             # interval_scoring bracket when the stages are bracketed on plain launches) and the DP (k_dp, the dp stage) are launches
             # of their own: the figure that compares with the other configs' stage (which holds all three) is interval_scoring + dp;
