@@ -4,13 +4,18 @@
 The JOB is fixed: BASELINE config 4 = 4 000 synthetic partitions x 500 reads = 2 000 000 reads (``--workload config5``:
 5 000 x 1 000 reads, sigma 3, threshold rate 0.8), statically scattered over the N ranks (LPT on the partitions' reads,
 freddie_amd/scatter.py -- no collective: partitions share nothing).  A STEP is one pass of the hot path over the rank's
-whole share of the job, done the way the drop-in CLI does it: the share is cut into batches of about 250 k reads (N = 1:
-8 batches, N = 8: 1) and every batch goes ``fseg_upload`` (host arrays -> HBM) -> ``fseg_run`` -> ``fseg_results_packed``
-(results in host memory: final positions, and the label matrix at two bits per label, which is the form the native writer
-takes), the batches taking turns on the contexts of the GPU (eight by default) so that one batch's copies overlap the
-others' kernels; nothing is replayed.  ``value`` = 2 000 000 reads x steps / max-over-ranks wall time of the timed steps
-(host memory to host memory; reference unit of work: run_segment, py/freddie_segment.py:681-735, minus the file I/O which
-the ``e2e`` leg adds), ``ms_per_step`` = the time of the whole job, ``scaling`` = "strong".
+whole share of the job, cut into batches of about 250 k reads (N = 1: 8 batches, N = 8: 1) that take turns on the contexts of the
+GPU (eight by default).  It is timed twice, K steps each, between barriers:
+  value               with the inputs RESIDENT IN HBM when the timed part starts (every context holds a batch of the share;
+                      a pass = ``fseg_run`` of every batch: histogram .. labels recomputed from the inputs, results left in HBM
+                      and checked from one fetch per context afterwards) -- the contract's reading of ``value``;
+  value_host_to_host  the way the drop-in CLI does it, PCIe inside: every batch ``fseg_upload`` (host arrays -> HBM) ->
+                      ``fseg_run`` -> ``fseg_results_packed`` (final positions and the label matrix at two bits per label in host
+                      memory), one batch's copies overlapping the others' kernels; nothing is replayed.  Rounds 1-4 reported this
+                      rate as ``value``; it depends on the box's host as much as on the GPU (300-409 M reads/s box to box).
+``value`` = 2 000 000 reads x steps / max-over-ranks wall time (reference unit of work: run_segment,
+py/freddie_segment.py:681-735, minus the file I/O which the ``e2e`` leg adds), ``ms_per_step`` = the time of the whole job,
+``scaling`` = "strong".
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload config4|config2|config3|config5|config1]
   python bench.py --workload cluster-many|cluster-big|isoforms      (rows N3 / N4 of SURVEY 8f: their own metrics, 1 GPU)
@@ -28,7 +33,6 @@ Prints ONE JSON line (rank 0) with, besides the driver's fields:
   value_resident_replay replay of one resident batch (no copies, no sizing; plain launches on the library's streams -- a run
                         that forks is not replayed as a hipGraph: DESIGN.md section 3)
   value_hbm_resident    batches uploaded first, then each run once (first-run path, no copies in the timed part)
-  value_inputs_resident the same batches left resident, K passes by the eight contexts (no copies in the timed part)
   cpu_baseline / cpu_baseline_all_cores   the C oracle on this box's host cores (1 thread / every core)
   e2e                   the drop-in CLI on a split directory of the same job in tmpfs: files in -> files out, through the CLI's N
                         worker processes, run by rank 0 before any rank touches a GPU
@@ -534,17 +538,64 @@ def main():
     dt = time.perf_counter() - t0
     n_reads = sum(batches[bi].n_reads for bi in order)
 
+    # ---- `value`: the same K passes with the inputs RESIDENT IN HBM when the timed part starts (the contract's reading: a rate that
+    # carries the host buffers across PCIe is reported beside it -- the region above, `value_host_to_host` -- and is never `value`).
+    # Every context holds a batch of the rank's share (context k: batch k mod n_b, so a rank with fewer batches than contexts --
+    # N GPUs share the eight batches -- still keeps all its contexts busy); a pass = every batch of the share run once, everything
+    # recomputed from the inputs (histogram .. labels), results left in HBM; K passes dealt out over the contexts that hold each
+    # batch, one host thread per context.  Shares of more batches than contexts go group by group, the uploads between the timed
+    # parts.  The checksum is taken from one fetch per context after the timed part.
+    n_ctx = len(ctxs)
+    dev_t = "cpu" if dist is not None and dist.get_backend() == "gloo" else "cuda"
+    n_groups = (n_b + n_ctx - 1) // n_ctx
+    if dist is not None:
+        tg = torch.tensor([float(n_groups)], dtype=torch.float64, device=dev_t)
+        dist.all_reduce(tg, op=dist.ReduceOp.MAX)             # (every rank meets the same barriers)
+        n_groups = int(tg[0])
+    dt_res, reads_res, chk_res = 0.0, 0, 0
+    for gi in range(n_groups):
+        grp = list(range(gi * n_ctx, min(n_b, (gi + 1) * n_ctx)))
+        runs = [0] * n_ctx
+        if grp:
+            for k, c2 in enumerate(ctxs):
+                c2.upload(**batches[grp[k % len(grp)]].arrays)
+                c2.run(); c2.sync()                               # (arenas sized, the replay set up: outside the timed part)
+            for i in range(len(grp)):
+                holders = [k for k in range(n_ctx) if k % len(grp) == i]
+                for pos, k in enumerate(holders):
+                    runs[k] = args.steps // len(holders) + (1 if pos < args.steps % len(holders) else 0)
+
+        def run_many(k):
+            for _ in range(runs[k]):
+                ctxs[k].run()
+                ctxs[k].sync()
+        th = [threading.Thread(target=run_many, args=(k,)) for k in range(n_ctx) if runs[k]]
+        barrier()
+        t0 = time.perf_counter()
+        for t_ in th:
+            t_.start()
+        for t_ in th:
+            t_.join()
+        barrier()
+        dt_res += time.perf_counter() - t0
+        for k in range(n_ctx):
+            if runs[k]:
+                res = ctxs[k].results(packed=True)
+                reads_res += runs[k] * batches[grp[k % len(grp)]].n_reads
+                chk_res += runs[k] * (int(res[0][-1]) + int(res[2][-1]) + int(res[1].sum(dtype=np.int64)))
+
     label_pop = sum(b.label_popcount or 0 for b in batches)
-    t = torch.tensor([dt, float(n_reads), float(checksum[0]), float(label_pop)], dtype=torch.float64,
-                     device="cpu" if dist is not None and dist.get_backend() == "gloo" else "cuda")
+    t = torch.tensor([dt, float(n_reads), float(checksum[0]), float(label_pop), dt_res, float(reads_res), float(chk_res)], dtype=torch.float64, device=dev_t)
     if dist is not None:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone()
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        dt_max, total_reads, checksum_all, label_pop_all = float(tmax[0]), float(tsum[1]), int(tsum[2]), int(tsum[3])
+        dt_h2h, reads_h2h, checksum_h2h, label_pop_all = float(tmax[0]), float(tsum[1]), int(tsum[2]), int(tsum[3])
+        dt_max, total_reads, checksum_all = float(tmax[4]), float(tsum[5]), int(tsum[6])
     else:
-        dt_max, total_reads, checksum_all, label_pop_all = dt, float(n_reads), checksum[0], label_pop
+        dt_h2h, reads_h2h, checksum_h2h, label_pop_all = dt, float(n_reads), checksum[0], label_pop
+        dt_max, total_reads, checksum_all = dt_res, float(reads_res), chk_res
 
     if rank == 0:
         lib_hash = _lib.load().fseg_source_hash().decode()
@@ -620,9 +671,15 @@ def main():
             "dtype": "u32",
             "dtype_detail": "u32 bit-planes + popcount for scoring, int32 (int64 for very large partitions) DP sums, f64 Gaussian smoothing / threshold",
             "data": "synthetic",
-            "value_is": "host memory -> host memory: a step = fseg_upload + fseg_run + fseg_results_packed of every batch of the rank's share of "
-                        "the fixed job, distinct batches, %d contexts per GPU (no resident replay)" % len(ctxs),
+            "value_is": "inputs resident in HBM when the timed part starts (the contract's reading; rounds 1-4 reported the host memory -> host "
+                        "memory rate here, now `value_host_to_host`): a step = fseg_run of every batch of the rank's share of the fixed job, distinct "
+                        "batches, %d contexts per GPU each holding a batch of the share, everything recomputed from the inputs each pass, results "
+                        "left in HBM (checked: one fetch per context after the timed part)" % len(ctxs),
             "timed_s": dt_max,
+            "value_host_to_host": {"value": reads_h2h / dt_h2h if dt_h2h > 0 else 0.0, "unit": "reads/s", "ms_per_step": dt_h2h / args.steps * 1e3,
+                                   "timed_s": dt_h2h, "result_checksum": checksum_h2h,
+                                   "what": "the same K passes host memory -> host memory: a step = fseg_upload + fseg_run + fseg_results_packed of every "
+                                           "batch of the share, %d contexts per GPU taking turns (PCIe-inclusive; what the CLI's workers do per batch)" % len(ctxs)},
             "config": {"workload": args.workload, "partitions": job_parts, "reads": job_reads,
                        "batches_per_step_rank0": n_b, "partitions_per_batch": per, "reads_per_batch": batches[0].n_reads if n_b else 0,
                        "reads_per_partition": wl["n_reads"], "contexts_per_gpu": len(ctxs), "scatter": "static LPT over %d rank(s), no collective" % args.gpus,
@@ -670,29 +727,6 @@ def main():
                                          "what": "%d distinct batches uploaded first (one per context), then each run once, concurrently: "
                                                  "first-run path (sized arenas, plain launches), results left in HBM, no copies in the "
                                                  "timed part" % n_h}
-            # the same with the batches left where they are: K passes, every context over its own resident batch (inputs in HBM
-            # before the timed part, results left in HBM, everything recomputed from the inputs each pass; a pass after the first
-            # finds its arenas sized).  `value` itself stays host memory -> host memory, the stricter figure.
-            for c2 in ctxs[:n_h]:
-                c2.sync()
-
-            def run_many(c2):
-                for _ in range(args.steps):
-                    c2.run()
-                    c2.sync()
-            th = [threading.Thread(target=run_many, args=(c2,)) for c2 in ctxs[:n_h]]
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for t_ in th:
-                t_.start()
-            for t_ in th:
-                t_.join()
-            torch.cuda.synchronize()
-            dt_i = time.perf_counter() - t0
-            out["value_inputs_resident"] = {"value": sum(b.n_reads for b in batches[:n_h]) * args.steps / dt_i, "unit": "reads/s",
-                                            "ms_per_batch": dt_i / (n_h * args.steps) * 1e3, "steps": args.steps,
-                                            "what": "%d contexts, each over its own resident batch (%d distinct batches of the job), %d passes: inputs in HBM "
-                                                    "when the timed part starts, no copies in it, results left in HBM; rank 0's GPU" % (n_h, n_h, args.steps)}
             # BASELINE configs[1]: one 50 k-read partition.  Its problems take the arena path, where coverage (k_cov: inside the
             # interval_scoring bracket when the stages are bracketed on plain launches) and the DP (k_dp, the dp stage) are launches
             # of their own: the figure that compares with the other configs' stage (which holds all three) is interval_scoring + dp;

@@ -46,5 +46,8 @@ def test_two_ranks_on_one_gpu_report_the_same_job():
         assert r["steps"] == 2 and r["value"] > 0
     assert r2["config"]["batches_per_step_rank0"] == 4 and r1["config"]["batches_per_step_rank0"] == 8
     assert r2["result_checksum"] == r1["result_checksum"] and r1["result_checksum"] > 0
+    # (both timed regions pass over the same job K times: resident inputs -- `value` -- and host memory -> host memory)
+    for r in (r1, r2):
+        assert r["value_host_to_host"]["result_checksum"] == r1["result_checksum"] and r["value_host_to_host"]["value"] > 0
     # (the checksum holds the SUM of the final positions, and the labels' content is compared too: '1' / '2' labels of the job)
     assert r2["result_label_popcount"] == r1["result_label_popcount"] and r1["result_label_popcount"] > 0
