@@ -150,7 +150,8 @@ struct fseg_ctx {
     DevBuf d_dpx;
     i64 dpx_base[3] = {0, 0, 0}, dpx_stride[3] = {0, 0, 0}, dpx_n[3] = {0, 0, 0};
     int dpx_nm = 0, dpx_cnt[3] = {1, 1, 1};
-    bool split_always = false;  // FSEG_SPLIT_ALWAYS=1 (tests): the split path also where a context keeps to one stream
+    bool split_always = true;   // FSEG_SPLIT_ALWAYS=0: the split path only where a context has the device to itself (round 5: also on one stream, eight
+                                // contexts over resident batches do 528 against 519 M reads/s with it, three pairs of runs in one call)
     i64 wide_one_max = 256;     // FSEG_WIDE_ONE_MAX: plan 'W' takes a batch's wide problems in one launch when there are at most this many (0: never)
     int split_dp = 7;           // FSEG_SPLIT_DP: bit 0 / 1 / 2 = the small / mid / large class hands its DPs to k_dpw (0: the DP stays the tail of k_solve's workgroups)
     i64 prob_cap = 0, work_cap = 0, pair_cap = 0, tri_cap = 0, label_cap = 0, chunk_cap = 0, cov_cap = 0;
@@ -694,10 +695,9 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
                                c->prob_cap, c->d_cand_y.as<int>(), c->d_lane_lx.as<int2>(), c->d_lex.as<int2>(),               \
                                c->d_h_table.as<double>(), c->P.h_len, c->P.threshold_rate,               \
                                c->d_thr_tab.as<int2>(), c->P.min_read_support_outside, c->d_chosen.as<unsigned char>()
-        // the split path (k_solve<.., SPLIT> then k_dpw on the same stream) for a list that fits the hand-over arena as laid out --
-        // when this context has the device to itself (`forking`): with other contexts' batches in flight a context keeps to one
-        // stream, where the extra launches cost more than the early release of LDS gains (the 2 M-read job, eight contexts:
-        // 383 against 388 M reads/s; the stage alone: 0.146 against 0.160 ms)
+        // the split path (k_solve<.., SPLIT> then k_dpw on the same stream) for a list that fits the hand-over arena as laid out.
+        // (Until round 5 only where the context has the device to itself: host memory -> host memory, eight contexts, the two were
+        // within the noise -- 383 against 388 M reads/s; over resident batches the split is 1.8 % faster; FSEG_SPLIT_ALWAYS=0.)
         auto split_ok = [&](int cls, int cnt_bytes) {
             // (k_dpw takes the problem its workgroup index names -- no grid stride --, so a list longer than the grid cap of the
             // two launches keeps the DP as k_solve's tail)
@@ -1383,7 +1383,7 @@ int fseg_create(int device, fseg_ctx **out) {
     if (flag("FSEG_FORCE_KEY64")) c->force_key64 = true;
     if (flag("FSEG_WIDE_BY_SEEN")) c->wide_by_seen = true;
     if (const char *e = getenv("FSEG_SPLIT_DP")) c->split_dp = atoi(e) & 7;
-    if (flag("FSEG_SPLIT_ALWAYS")) c->split_always = true;
+    if (const char *e = getenv("FSEG_SPLIT_ALWAYS")) c->split_always = e[0] != '0';
     if (const char *e = getenv("FSEG_WIDE_ONE_MAX")) c->wide_one_max = atoll(e) < 0 ? 0 : atoll(e);
     if (const char *e = getenv("FSEG_SCORE_PLAN")) snprintf(c->score_plan, sizeof c->score_plan, "%s", e);
     {
