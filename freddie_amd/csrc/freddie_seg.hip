@@ -546,12 +546,12 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
     if (stage_events && c->profile_all) (void)hipEventRecord(c->ev_b[ST_THRESHOLD], q);
     // batches of many partitions of moderate size: a workgroup per partition does the whole threshold (k_thr_part); a batch of a
     // few large partitions (config 2: one) keeps the batch-wide compaction and a workgroup per 8192-value chunk
-    // ... and so does a context that shares the device: k_thr_part is the LATENCY-optimised form (one launch, a partition's phases in a
-    // row by eight waves that mostly wait: 0.106 -> 0.070 ms for a context alone, the replay of a 250 k-read batch 0.742 -> 0.683 ms),
-    // the chunk kernels are the throughput-friendly one -- with eight contexts taking turns the job ran at 368 M reads/s with
-    // k_thr_part against 381 M without (tools/value_ab.sh, three rounds each in one call)
+    // (Until the end of round 5 a context that shares the device kept the chunk kernels: host memory -> host memory, eight contexts, the job
+    // ran at 368 M reads/s with k_thr_part against 381 M without -- a difference inside that figure's box noise, as it turned out.
+    // Over resident batches, three pairs of runs in one call: 527.6 / 530.8 / 531.5 with it, 524.1 / 524.4 / 503.7 without: one launch
+    // of 47 us instead of seven that hold a hardware queue for 84.)
     const bool thr_part_fits = c->max_part_pos <= (i64)kThrPartMaxChunks * 8192;
-    const bool thr_part = thr_part_fits && (c->thr_part == 1 || (c->thr_part < 0 && n_part >= 64 && forking));
+    const bool thr_part = thr_part_fits && (c->thr_part == 1 || (c->thr_part < 0 && n_part >= 64));
     if (thr_part) {
         hipLaunchKernelGGL(k_thr_part, dim3(grid_for(n_part, 1, 4096)), dim3(512), 0, q, n_part, c->d_part_iv_off.as<i64>(), c->d_pos_off.as<i64>(), NPOS,
                            flag_pos_bits, c->d_y.as<double>(), c->d_v.as<double>(), c->P.variance_factor, c->d_mean.as<double>(), c->d_thr.as<double>());
