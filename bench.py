@@ -5,11 +5,12 @@ The JOB is fixed: BASELINE config 4 = 4 000 synthetic partitions x 500 reads = 2
 5 000 x 1 000 reads, sigma 3, threshold rate 0.8), statically scattered over the N ranks (LPT on the partitions' reads,
 freddie_amd/scatter.py -- no collective: partitions share nothing).  A STEP is one pass of the hot path over the rank's
 whole share of the job, cut into batches of about 250 k reads (N = 1: 8 batches, N = 8: 1) that take turns on the contexts of the
-GPU (eight by default).  It is timed twice, K steps each, between barriers:
+GPU (eight by default); since round 6 a step is PASSES_PER_STEP = 16 such passes (a timed region of 20 steps is then 1.2 s instead of
+0.076 s; reads are counted per pass, so `value` is unchanged by it).  It is timed twice, K steps each, between barriers:
   value               with the inputs RESIDENT IN HBM when the timed part starts (every context holds a batch of the share;
                       a pass = ``fseg_run`` of every batch: histogram .. labels recomputed from the inputs, results left in HBM
                       and checked from one fetch per context afterwards) -- the contract's reading of ``value``;
-  value_host_to_host  the way the drop-in CLI does it, PCIe inside: every batch ``fseg_upload`` (host arrays -> HBM) ->
+  value_h2h           the way the drop-in CLI does it, PCIe inside: every batch ``fseg_upload`` (host arrays -> HBM) ->
                       ``fseg_run`` -> ``fseg_results_packed`` (final positions and the label matrix at two bits per label in host
                       memory), one batch's copies overlapping the others' kernels; nothing is replayed.  Rounds 1-4 reported this
                       rate as ``value``; it depends on the box's host as much as on the GPU (300-409 M reads/s box to box).
@@ -25,6 +26,9 @@ Prints ONE JSON line (rank 0) with, besides the driver's fields:
                         events around the stage on the library's own streams): algorithmic bytes 4*(N+K)*R + 4*R per partition
                          over that time -- the figure the per-kernel medians of profiles/ reproduce
   roofline_concurrent   the same bracket inside the timed steps, where the other contexts' kernels run beside the stage
+  roofline_path         the fraction that belongs to `value` (and `value_h2h`): the algorithmic bytes of EVERY stage of one pass over
+                        the job over the time of a pass, against 8 TB/s per GPU
+  sync_timeouts         device-side waiters of the scoring stage that reached their time limit (must be 0)
   roofline_stages       every stage of the path alone on the GPU (first-run path of distinct batches, events around every
                         stage): SURVEY 8d's algorithmic bytes of the stage over its time
   roofline_config2      one 50 k-read x 2 k-candidate partition (BASELINE configs[1], the arena path): coverage + scoring + DP
@@ -58,6 +62,19 @@ from freddie_amd import pack, synth, tables  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BATCH_READS = int(os.environ.get("FREDDIE_BENCH_BATCH_READS", "250000"))      # (the override: tuning runs only)
+# A STEP is this many passes over the job (round 6; until round 5: one).  One pass of the 2 M-read job takes 3.8 ms on one GPU, so the
+# driver's 20 steps were a timed region of 0.076 s -- too short for anything that samples the GPU from outside.  Reads are counted
+# per pass: `value` does not depend on this number, `ms_per_step` is the time of PASSES_PER_STEP passes.
+PASSES_PER_STEP = int(os.environ.get("FREDDIE_BENCH_PASSES", "16"))
+
+
+def popcount_bytes(a):
+    """Set bits of a uint8 array (numpy >= 2 has bitwise_count; a table look-up otherwise)."""
+    a = np.asarray(a, np.uint8)
+    if hasattr(np, "bitwise_count"):
+        return int(np.bitwise_count(a).sum(dtype=np.int64))
+    lut = np.array([bin(i).count("1") for i in range(256)], np.uint8)
+    return int(lut[a].sum(dtype=np.int64))
 
 PARAMS = {
     "default": dict(sigma=5.0, threshold_rate=0.9, variance_factor=3.0, max_problem_size=50,
@@ -74,6 +91,7 @@ class Batch:
         self.n_reads = sum(p.n_reads for p in parts)
         self.alg_bytes = None
         self.label_popcount = None
+        self.path_bytes = None          # SURVEY 8(d)'s algorithmic bytes of every stage of the path, summed (noted in the warm-up)
 
 
 def plan_job(workload, rank, n_gpus):
@@ -501,11 +519,13 @@ def main():
         if batches[bi].label_popcount is None:
             # the labels' CONTENT, out here where it costs nothing timed: set bits of the two-bit labels = labels that are '1' or
             # '2' (padding is zero), a property of the batch's partitions however they are batched
-            batches[bi].label_popcount = int(np.bitwise_count(res[3]).sum(dtype=np.int64))
+            batches[bi].label_popcount = popcount_bytes(res[3])
+        if batches[bi].path_bytes is None:
+            batches[bi].path_bytes = sum(stage_algorithmic_bytes(batches[bi], ctx.sizes(), res[0], batches[bi].alg_bytes).values())
     n_warm_steps = max(1, args.warmup)
     t_warm = time.perf_counter()
     if n_b:
-        one_shot_steps(ctxs, batches, [i % n_b for i in range(max(n_warm_steps * n_b, 2 * len(ctxs)))], note_alg)
+        one_shot_steps(ctxs, batches, [i % n_b for i in range(max(n_warm_steps * PASSES_PER_STEP * n_b, 2 * len(ctxs)))], note_alg)
         # ... and until the GPU has been busy for half a second (a fresh box runs its first 100 ms at lower clocks)
         while time.perf_counter() - t_warm < 0.5 and n_warm_steps < 4096:
             one_shot_steps(ctxs, batches, list(range(n_b)), note_alg)
@@ -529,7 +549,8 @@ def main():
 
     # the timed steps: K passes over the share, batch after batch, as one stream of work for the contexts (step boundaries
     # are not barriers: the CLI does not stop between batches either); consecutive batch-steps go to consecutive contexts
-    order = [i % n_b for i in range(args.steps * n_b)] if n_b else []
+    n_passes = args.steps * PASSES_PER_STEP
+    order = [i % n_b for i in range(n_passes * n_b)] if n_b else []
     barrier()
     t0 = time.perf_counter()
     if order:
@@ -539,7 +560,7 @@ def main():
     n_reads = sum(batches[bi].n_reads for bi in order)
 
     # ---- `value`: the same K passes with the inputs RESIDENT IN HBM when the timed part starts (the contract's reading: a rate that
-    # carries the host buffers across PCIe is reported beside it -- the region above, `value_host_to_host` -- and is never `value`).
+    # carries the host buffers across PCIe is reported beside it -- the region above, `value_h2h` -- and is never `value`).
     # Every context holds a batch of the rank's share (context k: batch k mod n_b, so a rank with fewer batches than contexts --
     # N GPUs share the eight batches -- still keeps all its contexts busy); a pass = every batch of the share run once, everything
     # recomputed from the inputs (histogram .. labels), results left in HBM; K passes dealt out over the contexts that hold each
@@ -552,7 +573,7 @@ def main():
         tg = torch.tensor([float(n_groups)], dtype=torch.float64, device=dev_t)
         dist.all_reduce(tg, op=dist.ReduceOp.MAX)             # (every rank meets the same barriers)
         n_groups = int(tg[0])
-    dt_res, reads_res, chk_res = 0.0, 0, 0
+    dt_res, reads_res, chk_res, pop_res, sync_timeouts, forked_runs = 0.0, 0, 0, 0, 0, 0
     for gi in range(n_groups):
         grp = list(range(gi * n_ctx, min(n_b, (gi + 1) * n_ctx)))
         runs = [0] * n_ctx
@@ -563,7 +584,7 @@ def main():
             for i in range(len(grp)):
                 holders = [k for k in range(n_ctx) if k % len(grp) == i]
                 for pos, k in enumerate(holders):
-                    runs[k] = args.steps // len(holders) + (1 if pos < args.steps % len(holders) else 0)
+                    runs[k] = n_passes // len(holders) + (1 if pos < n_passes % len(holders) else 0)
 
         def run_many(k):
             for _ in range(runs[k]):
@@ -581,11 +602,23 @@ def main():
         for k in range(n_ctx):
             if runs[k]:
                 res = ctxs[k].results(packed=True)
-                reads_res += runs[k] * batches[grp[k % len(grp)]].n_reads
+                bk = batches[grp[k % len(grp)]]
+                reads_res += runs[k] * bk.n_reads
                 chk_res += runs[k] * (int(res[0][-1]) + int(res[2][-1]) + int(res[1].sum(dtype=np.int64)))
+                # the labels the LAST pass of the region left in HBM, by content: their popcount must be the batch's (warm-up pass,
+                # host memory -> host memory on another context)
+                pop = popcount_bytes(res[3])
+                if pop != bk.label_popcount:
+                    raise SystemExit("resident region: context %d left labels with popcount %d, the batch's is %d" % (k, pop, bk.label_popcount))
+                pop_res += pop
+            sy = ctxs[k].tap("sync")
+            if len(sy) > 7:                                    # (a library of an earlier round under FSEG_LIB has no such counters)
+                sync_timeouts += int(sy[6]); forked_runs += int(sy[7])
 
     label_pop = sum(b.label_popcount or 0 for b in batches)
-    t = torch.tensor([dt, float(n_reads), float(checksum[0]), float(label_pop), dt_res, float(reads_res), float(chk_res)], dtype=torch.float64, device=dev_t)
+    path_bytes = sum(b.path_bytes or 0 for b in batches)                 # one pass over this rank's share
+    t = torch.tensor([dt, float(n_reads), float(checksum[0]), float(label_pop), dt_res, float(reads_res), float(chk_res), float(path_bytes),
+                      float(pop_res), float(sync_timeouts), float(forked_runs)], dtype=torch.float64, device=dev_t)
     if dist is not None:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -593,9 +626,11 @@ def main():
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         dt_h2h, reads_h2h, checksum_h2h, label_pop_all = float(tmax[0]), float(tsum[1]), int(tsum[2]), int(tsum[3])
         dt_max, total_reads, checksum_all = float(tmax[4]), float(tsum[5]), int(tsum[6])
+        path_bytes_all, pop_res_all, sync_timeouts_all, forked_runs_all = float(tsum[7]), int(tsum[8]), int(tsum[9]), int(tsum[10])
     else:
         dt_h2h, reads_h2h, checksum_h2h, label_pop_all = dt, float(n_reads), checksum[0], label_pop
         dt_max, total_reads, checksum_all = dt_res, float(reads_res), chk_res
+        path_bytes_all, pop_res_all, sync_timeouts_all, forked_runs_all = float(path_bytes), pop_res, sync_timeouts, forked_runs
 
     if rank == 0:
         lib_hash = _lib.load().fseg_source_hash().decode()
@@ -665,6 +700,8 @@ def main():
             "warmup": args.warmup,
             "warmup_steps_run": n_warm_steps,
             "ms_per_step": dt_max / args.steps * 1e3,
+            "passes_per_step": PASSES_PER_STEP,
+            "ms_per_pass": dt_max / max(1, n_passes) * 1e3,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -672,14 +709,33 @@ def main():
             "dtype_detail": "u32 bit-planes + popcount for scoring, int32 (int64 for very large partitions) DP sums, f64 Gaussian smoothing / threshold",
             "data": "synthetic",
             "value_is": "inputs resident in HBM when the timed part starts (the contract's reading; rounds 1-4 reported the host memory -> host "
-                        "memory rate here, now `value_host_to_host`): a step = fseg_run of every batch of the rank's share of the fixed job, distinct "
+                        "memory rate here, now `value_h2h`): a step = fseg_run of every batch of the rank's share of the fixed job, distinct "
                         "batches, %d contexts per GPU each holding a batch of the share, everything recomputed from the inputs each pass, results "
                         "left in HBM (checked: one fetch per context after the timed part)" % len(ctxs),
             "timed_s": dt_max,
-            "value_host_to_host": {"value": reads_h2h / dt_h2h if dt_h2h > 0 else 0.0, "unit": "reads/s", "ms_per_step": dt_h2h / args.steps * 1e3,
-                                   "timed_s": dt_h2h, "result_checksum": checksum_h2h,
-                                   "what": "the same K passes host memory -> host memory: a step = fseg_upload + fseg_run + fseg_results_packed of every "
-                                           "batch of the share, %d contexts per GPU taking turns (PCIe-inclusive; what the CLI's workers do per batch)" % len(ctxs)},
+            # rounds 1-4's `value` (pinned host memory -> results in host memory) continues HERE, at the top level
+            "value_h2h": reads_h2h / dt_h2h if dt_h2h > 0 else 0.0,
+            "ms_per_step_h2h": dt_h2h / args.steps * 1e3,
+            "ms_per_pass_h2h": dt_h2h / max(1, n_passes) * 1e3,
+            "timed_s_h2h": dt_h2h,
+            "value_h2h_is": "the same passes host memory -> host memory: fseg_upload + fseg_run + fseg_results_packed of every batch of the share, "
+                            "%d contexts per GPU taking turns (PCIe-inclusive; what the CLI's workers do per batch); the figure BENCH_r01..r04 "
+                            "report as `value`" % len(ctxs),
+            "result_checksum_h2h": checksum_h2h,
+            # the fraction of the HBM roofline that belongs to `value` / `value_h2h`: SURVEY 8(d)'s algorithmic bytes of EVERY stage of the
+            # path (histogram, smoothing, threshold, candidates, interval scoring, labels) of one pass over the job, over the time of a pass
+            "roofline_path": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS * args.gpus, "algorithmic_bytes_per_pass": path_bytes_all,
+                              "achieved": path_bytes_all * n_passes / dt_max / 1e9 if dt_max > 0 else 0.0,
+                              "frac": path_bytes_all * n_passes / dt_max / 1e9 / (HBM_PEAK_GBS * args.gpus) if dt_max > 0 else 0.0,
+                              "achieved_h2h": path_bytes_all * n_passes / dt_h2h / 1e9 if dt_h2h > 0 else 0.0,
+                              "frac_h2h": path_bytes_all * n_passes / dt_h2h / 1e9 / (HBM_PEAK_GBS * args.gpus) if dt_h2h > 0 else 0.0,
+                              "what": "sum of the stages' algorithmic bytes (SURVEY 8d, every input once, every output once, reference dtypes) of one pass "
+                                      "over the job / time of a pass / (8 TB/s x GPUs): `frac` for `value` (inputs resident), `frac_h2h` for `value_h2h`"},
+            # device-side waiters (k_wait_word) of the scoring stage that reached their time limit in this process's contexts (each costs the
+            # limit + a rerun of its batch): must be 0; forked_runs = runs that owned the device (side streams in use)
+            "sync_timeouts": sync_timeouts_all,
+            "forked_runs": forked_runs_all,
+            "result_label_popcount_resident": pop_res_all,
             "config": {"workload": args.workload, "partitions": job_parts, "reads": job_reads,
                        "batches_per_step_rank0": n_b, "partitions_per_batch": per, "reads_per_batch": batches[0].n_reads if n_b else 0,
                        "reads_per_partition": wl["n_reads"], "contexts_per_gpu": len(ctxs), "scatter": "static LPT over %d rank(s), no collective" % args.gpus,
@@ -699,7 +755,7 @@ def main():
             # rank's share is cut into batches; result_label_popcount: the labels that are '1' or '2' in one pass over the job
             # (counted in the warm-up pass, outside the timed region)
             "result_checksum": checksum_all,
-            "result_checksum_per_step": checksum_all // max(1, args.steps),
+            "result_checksum_per_pass": checksum_all // max(1, n_passes),
             "result_label_popcount": label_pop_all,
         }
         out["value_resident_replay"] = {"value": batches[0].n_reads * reps / dt_r, "unit": "reads/s", "ms_per_step": dt_r / reps * 1e3,
@@ -787,7 +843,10 @@ def main():
             cpu_one = cpu_baseline(batches, params, tabs)
         out["cpu_baseline"] = cpu_one
         out["cpu_baseline_all_cores"] = cpu_all
-        out["reference_cpu"] = reference_cpu(args.workload, out["value"], cpu_one, e2e)
+        # (the ratios against the reference's CLI use the PCIe-inclusive rate: the reference's figure includes its I/O)
+        out["reference_cpu"] = reference_cpu(args.workload, out["value_h2h"], cpu_one, e2e)
+        if out["reference_cpu"]:
+            out["reference_cpu"]["ratios_use"] = "value_h2h (host memory -> host memory)"
         out["e2e"] = e2e
         print(json.dumps(out))
     for ctx in ctxs:

@@ -115,7 +115,11 @@ struct fseg_ctx {
     // at a time) whenever no column's default can be '2' (threshold_rate < 1: a read without coverage is never ambiguous) -- the
     // 75 MB byte arena of a 250 k-read batch is then neither filled (15 us) nor packed (25 us); fseg_results / fseg_download unpack
     // it on demand.  FSEG_LABEL_BYTES=1 keeps the byte arena as the primary form (and threshold_rate = 1 always does).
+    // "No column's default can be '2'" is a property of the TABLE, not of the rate: smooth_threshold() rounds to two decimals, so a rate
+    // in about (0.99972, 1) has a last entry of 1.0 (0.9999: segments of exactly 107 positions have h = 1, l = 0, lo = -1 and every
+    // read is '2' there -- golden e_tau9999_len107).  label_has2 is computed from the table by fseg_set_params.
     bool label_packed_ok = true;
+    bool label_has2 = false;         // some segment length has h >= 1 (lo < 0): a read without coverage is '2' there -> byte arena
     bool run_label_packed = false;   // the resident run's labels live in d_packed
     bool labels_unpacked = false;    // ... and d_labels holds their byte form (made on demand)
     DevBuf d_sort_tmp;
@@ -158,13 +162,33 @@ struct fseg_ctx {
     DevBuf d_status, d_prep, d_tacc;
     DevBuf d_sync;               // SyncWords: the scoring stage's device-side fork / join (k_wait_word)
     unsigned sync_gen = 0;       // generation of the last stage enqueued with device-side waiters
-    unsigned sync_ticks = 2000000u;   // what a waiter waits at most: 20 ms of the 100 MHz clock (FSEG_SYNC_TICKS; tests force a timeout with 1)
+    // What a waiter waits at most, in ticks of the 100 MHz clock, per 2^18 reads of the batch: 2 ms (FSEG_SYNC_TICKS; tests force a
+    // time-out with 1).  Round 5's limit was 20 ms and it DID run out, four times in one 8-context trace -- for two reasons, both removed
+    // in round 6: a later context's side stream could share its own main stream's hardware queue (probe_side_queues), and two contexts
+    // that started together could both fork (claim_device).  What is left is honest waiting: the fork waiters sleep through k_fix ..
+    // k_prob_emit (median 60 us on a 250 k-read batch), the join waiter through what the side chains need beyond the main stream's
+    // (a few us) -- and, with seven other contexts' kernels ahead of the owner's in its hardware queue, up to 168 us in the traced
+    // 8-context run (profiles/r06_config4_waiters_8ctx.txt).  200 us, the figure first tried, turned four to six such waits per
+    // bench run into time-outs (each a stage skipped and the batch run again): the limit is a bound on a stall, not a schedule.
+    unsigned sync_ticks = 200000u;
+    unsigned sync_timeouts = 0;  // runs of this context that a waiter gave up on (each was redone with events); FSEG_TAP_SYNC[6]
+    unsigned forked_runs = 0;    // runs of this context that owned the device (side streams in use); FSEG_TAP_SYNC[7]
+    bool run_events_only = false;   // this run: no device-side waiters (it is the rerun after a timeout)
     bool emit_signal = true;     // FSEG_EMIT_SIGNAL=0: only the first launch behind k_prob_emit tells the side streams' waiters, not k_prob_emit's last workgroup (see emit_done)
     bool dev_sync = true;        // FSEG_DEV_SYNC=0: the stage's side streams are forked and joined with events only (also after a waiter timed out)
     Status *h_status = nullptr;   // pinned
     PrepStatus *h_prep = nullptr; // pinned
     bool prep_checked = false;   // the upload's device-side validation has been read back
     bool counted_in_flight = false, counted_live = false;
+    // Which side streams may carry a device-side waiter: those whose hardware queue is NOT the main stream's (probe_side_queues).
+    // The runtime multiplexes a process's streams onto four hardware queues as they are created: the first context of a device makes
+    // its four streams back to back (queues 1 2 3 4: the third side stream shares the main stream's), a later context makes its side
+    // streams when it first forks and they land wherever the count of streams then points -- round 5's 8-context trace had four
+    // k_wait_word of 20 ms during which NOTHING else ran on the GPU: a waiter in front of its own main stream.
+    bool side_probed = false;
+    bool side_ok[3] = {false, false, false};
+    unsigned probe_gen = 0;
+    bool owns_device = false;    // this context holds the device's owner word: the only one that may fork over side streams (claim_device)
     int hsa_agent = -1;         // index into the HSA agent table (-1: not looked up yet, -2: unavailable)
     hsa_signal_t hsa_sig = {0};
     int hsa_cpu = 0;            // index of the CPU agent that owns the pinned result buffer ...
@@ -267,11 +291,20 @@ thread_local std::string g_create_error;      // fseg_create has no context to p
 // run over side streams only when it is alone on the device: with several contexts taking turns (the CLI, the benchmark's
 // timed steps) the other contexts' kernels already fill what one stream leaves idle, and the extra streams only crowd the
 // hardware queues (three contexts: 1.44 -> 1.28 ms per 250 k-read batch without them).
+// Forking (and with it the device-side waiters of the scoring stage) needs more than that count: two contexts that start together
+// could both read "alone", and then each parks one-wave spinners on side streams that share hardware queues with the other's
+// main stream -- a cycle that only the waiters' time limit broke (round 5's 8-context trace: four 20 ms k_wait_word).  So a run
+// forks only after it has CLAIMED the device: one compare-and-swap on the device's owner word, taken by fseg_run when nobody
+// else is in flight, given back when the run has completed (finish_run).  Losers, and whoever arrives while the word is held,
+// keep to one stream.  With one forking context per device a waiter can only sit in front of kernels that do not feed it.
 static std::atomic<int> g_in_flight[64];
 static std::atomic<int> g_live[64];
+static std::atomic<const fseg_ctx *> g_owner[64];
 static void set_in_flight(fseg_ctx *c, bool on);
 static bool others_in_flight(const fseg_ctx *c);
 static bool would_fork(const fseg_ctx *c);
+static void claim_device(fseg_ctx *c);
+static void release_device(fseg_ctx *c);
 
 struct Tick {
     std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
@@ -343,7 +376,7 @@ void drop_graph(fseg_ctx *c) {
 // (re)bind the data-dependent arenas for the current capacities; the label arena is its own allocation because it is
 // sized after everything else of a run has been written
 // the label arena for label_cap labels: two bits each (d_packed) when this context's parameters allow it, else bytes (d_labels)
-bool labels_packed(const fseg_ctx *c) { return c->label_packed_ok && c->have_params && c->P.threshold_rate < 1.0; }
+bool labels_packed(const fseg_ctx *c) { return c->label_packed_ok && c->have_params && !c->label_has2; }
 int ensure_label_arena(fseg_ctx *c) {
     if (labels_packed(c)) return ensure(c, c->d_packed, (size_t)((c->label_cap + 15) / 16) * 4 + 16);
     return ensure(c, c->d_labels, (size_t)c->label_cap + 16);
@@ -477,18 +510,22 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
         for (int k = 1, nx = 0; k < ps.n_seg; ++k) if (ps.used[k]) ps.side_of[k] = nx++;
     }
     // device-side fork / join (k_wait_word): plain launches only (never inside a capture), and only when this enqueue holds
-    // k_prob_emit, whose last workgroup is what the side streams wait for; side streams 0 and 1 only (the process's fourth
-    // stream shares a hardware queue with the first: a waiter there would sit in front of the kernel it waits for)
-    const bool dev_sync = plan && c->dev_sync && do_pre2 && (sized || c->run_plain) && c->d_sync.p != nullptr;
+    // k_prob_emit, whose last workgroup is what the side streams wait for; only on side streams whose hardware queue is not the
+    // main stream's (side_ok, probed once: a waiter there would sit in front of the kernel it waits for)
+    const bool dev_sync = plan && c->dev_sync && !c->run_events_only && do_pre2 && (sized || c->run_plain) && c->d_sync.p != nullptr;
     SyncWords *sw = c->d_sync.as<SyncWords>();
     const unsigned sync_gen = dev_sync ? ++c->sync_gen : 0;
-    const unsigned kSyncTicks = c->sync_ticks;
-    auto dev_side = [&](int k) { return dev_sync && k >= 1 && k < ps.n_seg && ps.used[k] && ps.side_of[k] >= 0 && ps.side_of[k] < 2; };
+    // (a context's first two stages with waiters get ten times the limit: the first launches of the stage's kernels load their
+    // code objects and make the runtime allocate scratch for the side streams' queues -- hundreds of microseconds, once.  Measured:
+    // tools/waiter_probe.py, a context alone: the first sized run lost a waiter at 200 us, later runs sleep 49 us in the median, 134 at most.)
+    const i64 sync_scale = std::max<i64>(1, c->LANES >> 18) * (c->sync_gen <= 2 && c->sync_ticks > 1 ? 10 : 1);
+    const unsigned kSyncTicks = (unsigned)std::min<i64>((i64)c->sync_ticks * sync_scale, 2000000);
+    auto dev_side = [&](int k) { return dev_sync && k >= 1 && k < ps.n_seg && ps.used[k] && ps.side_of[k] >= 0 && ps.side_of[k] < fseg_ctx::kSide && c->side_ok[ps.side_of[k]]; };
     auto early_fork = [&]() {
         if (!dev_sync) return;
         for (int k = 1; k < ps.n_seg; ++k) if (dev_side(k)) {
             hipStream_t q = fork(ps.side_of[k]);
-            hipLaunchKernelGGL(k_wait_word, dim3(1), dim3(64), 0, q, st, &sw->emit_gen, 1, sync_gen, kSyncTicks);
+            hipLaunchKernelGGL(k_wait_word, dim3(1), dim3(64), 0, q, st, &sw->emit_gen, 1u, sync_gen, kSyncTicks);
         }
     };
     const i64 avg_len = NPOS / (K > 0 ? K : 1);
@@ -850,12 +887,12 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
                 // join: a side chain with a device-side fork ends with k_signal and the main stream waits for the words (one wave in
                 // front of k_segments) instead of two marker + barrier packets per side stream
                 if (dev_sync && !signalled) hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, s, &sw->emit_gen, sync_gen);    // (a plan with nothing on the main stream)
-                int n_dev = 0;
+                unsigned dev_mask = 0;
                 for (int k = 1; k < n_seg; ++k) if (used[k]) {
-                    if (dev_side(k)) { hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, c->side[side_of[k]], &sw->side_gen[side_of[k]], sync_gen); ++n_dev; }
+                    if (dev_side(k)) { hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, c->side[side_of[k]], &sw->side_gen[side_of[k]], sync_gen); dev_mask |= 1u << side_of[k]; }
                     else join(side_of[k]);
                 }
-                if (n_dev) hipLaunchKernelGGL(k_wait_word, dim3(1), dim3(64), 0, s, st, sw->side_gen, n_dev, sync_gen, kSyncTicks);
+                if (dev_mask) hipLaunchKernelGGL(k_wait_word, dim3(1), dim3(64), 0, s, st, sw->side_gen, dev_mask, sync_gen, kSyncTicks);
             } else {
             if (any_arena && (!known || c->n_cls_work[2] > 0)) FSEG_LAUNCH_SCORE(s, kNMax, 2, 512);     // big problems: they are the long poles
             if (any_solve && (!known || c->n_solve[2] > 0)) FSEG_LAUNCH_SOLVE_W(s, kNMax, 2, known ? c->n_solve[2] : cap, 512);
@@ -1119,18 +1156,40 @@ void collect_stage_times(fseg_ctx *c, int timed_graphs) {
     }
 }
 
+// A device-side waiter gave up: the run is redone with events (run_events_only), the context keeps its waiters for later runs
+// unless it keeps happening (three times: events for good).  Counted and exposed (FSEG_TAP_SYNC): a time-out is a stall of the
+// waiter's limit plus a rerun, and nothing else would show it.
+static void note_sync_timeout(fseg_ctx *c) {
+    c->run_events_only = true;
+    if (++c->sync_timeouts >= 3 && c->dev_sync) {
+        c->dev_sync = false;
+        if (c->trace) fprintf(stderr, "[fseg] %u runs lost a device-side waiter to its time limit: this context forks and joins with events from now on\n", c->sync_timeouts);
+    } else if (c->trace) fprintf(stderr, "[fseg] a device-side waiter reached its time limit: the run is redone with events\n");
+}
+
 // wait for the run; grow arenas and re-run if a capacity was exceeded (never after a sized run: its capacities are exact)
 static void set_in_flight(fseg_ctx *c, bool on) {
+    if (!on) release_device(c);
     if (c->counted_in_flight == on || c->device < 0 || c->device >= 64) return;
     c->counted_in_flight = on;
-    g_in_flight[c->device].fetch_add(on ? 1 : -1, std::memory_order_relaxed);
+    g_in_flight[c->device].fetch_add(on ? 1 : -1, std::memory_order_acq_rel);
+}
+static void claim_device(fseg_ctx *c) {
+    if (c->owns_device || c->device < 0 || c->device >= 64 || !c->use_fork || others_in_flight(c)) return;
+    const fseg_ctx *nobody = nullptr;
+    if (g_owner[c->device].compare_exchange_strong(nobody, c, std::memory_order_acq_rel)) c->owns_device = true;
+}
+static void release_device(fseg_ctx *c) {
+    if (!c->owns_device) return;
+    c->owns_device = false;
+    g_owner[c->device].store(nullptr, std::memory_order_release);
 }
 static bool others_in_flight(const fseg_ctx *c) {
     if (c->device < 0 || c->device >= 64) return false;
-    return g_in_flight[c->device].load(std::memory_order_relaxed) - (c->counted_in_flight ? 1 : 0) > 0;
+    return g_in_flight[c->device].load(std::memory_order_acquire) - (c->counted_in_flight ? 1 : 0) > 0;
 }
-// the run has the device to itself and is worth branching (see enqueue_run)
-static bool would_fork(const fseg_ctx *c) { return c->use_fork && !c->small_batch && !others_in_flight(c) && c->side[0] != nullptr; }
+// the run owns the device and is worth branching (see enqueue_run)
+static bool would_fork(const fseg_ctx *c) { return c->use_fork && !c->small_batch && c->owns_device && c->side[0] != nullptr; }
 static int finish_run_impl(fseg_ctx *c);
 int finish_run(fseg_ctx *c) {
     const int rc = finish_run_impl(c);
@@ -1146,7 +1205,7 @@ static int finish_run_impl(fseg_ctx *c) {
                                 kErrOverflowProblems | kErrOverflowChunks | kErrOverflowCov);
         if (s.err & kErrOverflowNm) { ovf |= kErrOverflowNm; c->nm_big = kNMax; }
         if (s.err & kErrWaveStage) { ovf |= kErrWaveStage; c->use_wave = false; c->counts_known = false; drop_graph(c); }    // k_tiny / k_solve fetch exons read by read
-        if (s.err & kErrSyncTimeout) { ovf |= kErrSyncTimeout; c->dev_sync = false; }     // a device-side waiter gave up (the stage was skipped): events from now on
+        if (s.err & kErrSyncTimeout) { ovf |= kErrSyncTimeout; note_sync_timeout(c); }   // a device-side waiter gave up (the stage was skipped): this run again, with events
         if ((i64)s.max_ln >= 65536 && !c->dp_wide_counts) { ovf |= kErrNeedWideDp; c->dp_wide_counts = true; drop_graph(c); }
         if (s.err & kErrScanStall) { ovf |= kErrScanStall; c->scan_single_max = 0; c->force_scan_stall = false; drop_graph(c); }
         if (s.dp_cls[2] > 0 && !c->have_huge) { ovf |= kErrProblemTooLarge << 16; c->have_huge = true; drop_graph(c); }   // rerun with the huge-problem kernels
@@ -1187,6 +1246,30 @@ static int finish_run_impl(fseg_ctx *c) {
     }
 }
 
+// Which of the context's side streams run BESIDE its main stream (see side_ok).  Once per context, by the first run that owns the
+// device: per side stream a k_probe_wait on it, then a k_signal on the (drained) main stream.  The limit is generous (2 ms: kernels of
+// other contexts may be ahead of the signal in the main stream's hardware queue); a probe that runs out only costs that stream its
+// waiters (events instead), never correctness.
+int probe_side_queues(fseg_ctx *c) {
+    if (c->side_probed || !c->side[0] || !c->d_sync.p) return FSEG_OK;
+    c->side_probed = true;
+    SyncWords *sw = c->d_sync.as<SyncWords>();
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int k = 0; k < fseg_ctx::kSide; ++k) {
+        const unsigned gen = ++c->probe_gen;
+        unsigned res = 0;
+        HIP_TRY(c, hipMemsetAsync(&sw->probe_result, 0, sizeof(unsigned), c->side[k]));
+        hipLaunchKernelGGL(k_probe_wait, dim3(1), dim3(64), 0, c->side[k], &sw->probe_word, gen, &sw->probe_result, 200000u);
+        hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, c->stream, &sw->probe_word, gen);
+        HIP_TRY(c, hipStreamSynchronize(c->side[k]));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipMemcpy(&res, &sw->probe_result, sizeof res, hipMemcpyDeviceToHost));
+        c->side_ok[k] = res == 1u;
+    }
+    if (c->trace) fprintf(stderr, "[fseg] side streams beside the main stream (device-side waiters allowed): %d %d %d\n", (int)c->side_ok[0], (int)c->side_ok[1], (int)c->side_ok[2]);
+    return FSEG_OK;
+}
+
 // First run of a batch: launched in three pieces with the host reading the status record in between, so every arena is
 // sized exactly before anything is written into it -- no guessed capacities, no overflow re-run.
 //   A  histogram .. problem scan   -> problems, work items, pairs, triples, coverage elements, largest / widest problem
@@ -1196,7 +1279,7 @@ static int finish_run_impl(fseg_ctx *c) {
 int run_sized(fseg_ctx *c) {
     Tick tk;
     double t_a = 0, t_b = 0;
-    for (int attempt = 0; attempt < 3; ++attempt) {
+    for (int attempt = 0; attempt < 3; ++attempt) {          // (attempts = redone scans; a waiter's time-out has a retry of its own, once per run)
         // A
         TRY(enqueue_run(c, SEG_PRE1 | SEG_STATUS, true));
         HIP_TRY(c, wait_stream(c));
@@ -1255,7 +1338,10 @@ int run_sized(fseg_ctx *c) {
         if (bad) return fail(c, FSEG_ERR_HIP, "internal: a sized run overflowed an arena (status %#x)", s.err);
         // (what B's scoring kernels can raise besides: a result that is garbage fails HERE, not after the label stage; a wave kernel
         // that met a read it cannot stage turns the wave kernels off and the sized attempt starts over)
-        if (s.err & kErrSyncTimeout) { c->dev_sync = false; continue; }     // a device-side waiter gave up (the stage was skipped): once more, with events
+        if (s.err & kErrSyncTimeout) {                       // a device-side waiter gave up (the stage was skipped): once more, with events
+            if (c->run_events_only) return fail(c, FSEG_ERR_HIP, "internal: a waiter timed out in a run without waiters (status %#x)", s.err);
+            note_sync_timeout(c); --attempt; continue;
+        }
         if (s.err & kErrWideMissed) { c->pending = false; c->ran = false; return run_input_errors(c, s); }
         if (s.err & kErrWaveStage) { c->use_wave = false; c->counts_known = false; drop_graph(c); continue; }
         if ((s.err & (kErrExonInterval | kErrBreakAssert | kErrProblemTooLarge))) {
@@ -1412,6 +1498,7 @@ int fseg_create(int device, fseg_ctx **out) {
 void fseg_destroy(fseg_ctx *c) {
     if (!c) return;
     set_in_flight(c, false);
+    release_device(c);
     if (c->counted_live) { g_live[c->device].fetch_sub(1); c->counted_live = false; }
     if (c->hsa_agent >= 0) { (void)hsa_signal_destroy(c->hsa_sig); c->hsa_agent = -2; }
     (void)hipSetDevice(c->device);
@@ -1459,6 +1546,10 @@ int fseg_set_params(fseg_ctx *c, const fseg_params *p) {
     hipLaunchKernelGGL(k_thr_table, dim3(kThrTab / 256), dim3(256), 0, c->stream, c->d_h_table.as<double>(), c->P.h_len,
                        c->P.threshold_rate, c->d_thr_tab.as<int2>());
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // lo < 0 (label_thresholds: no v >= 0 with v / L < 1 - h) exactly where h >= 1: the rate itself, or an entry of the table that
+    // round(y, 2) took to 1.0 (segment lengths start at 1)
+    c->label_has2 = !(p->threshold_rate < 1.0);
+    for (int L = 1; L < p->h_len; ++L) if (!(c->h_table[(size_t)L] < 1.0)) c->label_has2 = true;
     c->have_params = true;
     c->ran = false;          // results of an earlier run belong to other parameters
     c->counts_known = false; // ... and so do the sizes of its lists
@@ -1757,8 +1848,11 @@ static int run_impl(fseg_ctx *c) {
     HIP_TRY(c, hipSetDevice(c->device));
     if (c->pending) TRY(finish_run(c));
     c->fetched = false;
+    c->run_events_only = false;
     set_in_flight(c, true);
-    if (c->use_fork && !c->side[0] && !others_in_flight(c)) {
+    claim_device(c);
+    if (c->owns_device) ++c->forked_runs;
+    if (c->use_fork && !c->side[0] && c->owns_device) {
         hipStream_t made[fseg_ctx::kSide] = {};
         hipError_t e = hipSuccess;
         for (int i = 0; e == hipSuccess && i < fseg_ctx::kSide; ++i) e = hipStreamCreateWithFlags(&made[i], hipStreamNonBlocking);
@@ -1768,6 +1862,7 @@ static int run_impl(fseg_ctx *c) {
         }
         for (int i = 0; i < fseg_ctx::kSide; ++i) c->side[i] = made[i];
     }
+    if (c->owns_device && c->dev_sync && !c->side_probed) TRY(probe_side_queues(c));
     // first run of a batch: piecewise with exact arena sizes; afterwards the sizes are known and the same launch
     // sequence is replayed (as a hipGraph unless disabled)
     if (!c->ran && c->use_sized) return run_sized(c);
@@ -2056,7 +2151,8 @@ int fseg_tap(fseg_ctx *c, int what, void *dst, int64_t cap_bytes, int64_t *n_byt
         case FSEG_TAP_SYNC: {
             SyncWords w{};
             HIP_TRY(c, hipMemcpy(&w, c->d_sync.p, sizeof w, hipMemcpyDeviceToHost));
-            packed = {(int)c->sync_gen, c->dev_sync ? 1 : 0, (int)w.emit_gen, (int)w.side_gen[0], (int)w.side_gen[1], (int)w.emit_ctr};
+            packed = {(int)c->sync_gen, c->dev_sync ? 1 : 0, (int)w.emit_gen, (int)w.side_gen[0], (int)w.side_gen[1], (int)w.emit_ctr,
+                      (int)c->sync_timeouts, (int)c->forked_runs, (c->side_probed ? 8 : 0) | (c->side_ok[0] ? 1 : 0) | (c->side_ok[1] ? 2 : 0) | (c->side_ok[2] ? 4 : 0)};
             bytes = (i64)packed.size() * 4;
             *n_bytes = bytes;
             if (dst && cap_bytes > 0) memcpy(dst, packed.data(), (size_t)(bytes < cap_bytes ? bytes : cap_bytes));

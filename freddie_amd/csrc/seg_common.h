@@ -141,7 +141,8 @@ struct SyncWords {
                             // k_prob_emit on the main stream): the side streams' waiters spin on it
     unsigned side_gen[4];   // generation of the last scoring stage whose chain on side stream k has ended (k_signal)
     unsigned emit_ctr;      // FSEG_EMIT_SIGNAL=1: workgroups of k_prob_emit that have finished (the last one publishes emit_gen and resets this)
-    unsigned pad[2];
+    unsigned probe_word;    // probe_side_queues: generation published by a k_signal on the main stream ...
+    unsigned probe_result;  // ... and what the side stream's k_probe_wait saw (1: the word, 2: its time limit)
 };
 
 
@@ -160,7 +161,7 @@ __device__ __forceinline__ void emit_done(SyncWords *sw, unsigned gen) {
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned done = __hip_atomic_fetch_add(&sw->emit_ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned done = __hip_atomic_fetch_add(&sw->emit_ctr, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);   // (acquire: the last workgroup's release of emit_gen then carries every workgroup's stores, not only its own)
         if (done == gridDim.x - 1) {
             __hip_atomic_store(&sw->emit_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&sw->emit_gen, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);

@@ -152,10 +152,11 @@ __global__ void __launch_bounds__(256, WaveCfg<NM>::kOcc) k_wave(Status *st, con
 __global__ void __launch_bounds__(64) k_gate(Status *st, int which, unsigned grid, unsigned max_ticks, unsigned *signal_word, unsigned signal_gen);
 
 // seg_score_fused.hip
-__global__ void __launch_bounds__(64) k_wait_word(Status *st, const unsigned *words, int n_words, unsigned gen, unsigned max_ticks);
+__global__ void __launch_bounds__(64) k_wait_word(Status *st, const unsigned *words, unsigned mask, unsigned gen, unsigned max_ticks);
 
 // seg_score_fused.hip
 __global__ void __launch_bounds__(64) k_signal(unsigned *word, unsigned gen);
+__global__ void __launch_bounds__(64) k_probe_wait(const unsigned *word, unsigned gen, unsigned *result, unsigned max_ticks);
 
 // seg_score_fused.hip
 template <int NM, typename CntT, typename V, bool SPLIT>

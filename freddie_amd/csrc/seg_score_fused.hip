@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(256, FSEG_TINY_OCC) k_tiny(Status *st, const P
             dp_sync<64>();
         }
         const int dropped = d.lane_n - n_act;           // reads of the lane range without coverage: treated like those outside it
-        // a read outside the lane range has no coverage in the window: ambiguous exactly where lo < 0 (only tau = 1)
+        // a read outside the lane range has no coverage in the window: ambiguous exactly where lo < 0 (h >= 1)
         if (lane < npairs) in_s[wave][lane] = -(int)((i64)amb + (lo_q < 0 ? (i64)d.outside + dropped : 0));
         if (lane < ntri) out_s[wave][lane] = out;
         dp_sync<64>();
@@ -332,7 +332,7 @@ __global__ void __launch_bounds__(256, WaveCfg<NM>::kOcc) k_wave(Status *st, con
             dp_sync<64>();
             l0 += m;
         }
-        // a read outside the lane range has no coverage in the window: ambiguous exactly where lo < 0 (only tau = 1)
+        // a read outside the lane range has no coverage in the window: ambiguous exactly where lo < 0 (h >= 1)
 #pragma unroll
         for (int s = 0; s < C::kPSlots; ++s) {
             const int q = s * 64 + lane;
@@ -384,13 +384,15 @@ __global__ void __launch_bounds__(64) k_gate(Status *st, int which, unsigned gri
         __builtin_amdgcn_s_sleep(16);
 }
 
-__global__ void __launch_bounds__(64) k_wait_word(Status *st, const unsigned *words, int n_words, unsigned gen, unsigned max_ticks) {
+__global__ void __launch_bounds__(64) k_wait_word(Status *st, const unsigned *words, unsigned mask, unsigned gen, unsigned max_ticks) {
+    // mask: which of words[0..31] must have reached the generation (lane i looks at word i)
     const int lane = lane_id();
-    const unsigned *w = words + (lane < n_words ? lane : 0);
+    const bool mine = lane < 32 && ((mask >> lane) & 1u);
+    const unsigned *w = words + (mine ? lane : 0);
     const unsigned long long t0 = wall_clock64();
     bool ok = false;
     for (;;) {
-        ok = gen_reached(__hip_atomic_load(w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT), gen);
+        ok = !mine || gen_reached(__hip_atomic_load(w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT), gen);
         if (__all(ok) || wall_clock64() - t0 >= max_ticks) break;
         __builtin_amdgcn_s_sleep(8);
     }
@@ -402,6 +404,21 @@ __global__ void __launch_bounds__(64) k_wait_word(Status *st, const unsigned *wo
 
 __global__ void __launch_bounds__(64) k_signal(unsigned *word, unsigned gen) {
     if (threadIdx.x == 0) __hip_atomic_store(word, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The probe of a side stream's hardware queue (probe_side_queues, freddie_seg.hip): one wave that waits for a word a k_signal on the
+// MAIN stream publishes behind it.  If it sees the word, the main stream runs beside this stream (result 1); if its time runs
+// out, the main stream's packets sit BEHIND this wave in the same hardware queue (result 2) -- a k_wait_word here would wait for
+// its own limit every time.
+__global__ void __launch_bounds__(64) k_probe_wait(const unsigned *word, unsigned gen, unsigned *result, unsigned max_ticks) {
+    const unsigned long long t0 = wall_clock64();
+    bool ok = false;
+    for (;;) {
+        ok = gen_reached(__hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT), gen);
+        if (ok || wall_clock64() - t0 >= max_ticks) break;
+        __builtin_amdgcn_s_sleep(8);
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(result, ok ? 1u : 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // (k_solve: seg_solve.h, instantiated by seg_solve16 / 32 / 60 .hip)

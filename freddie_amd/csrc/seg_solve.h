@@ -282,7 +282,7 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
             FSEG_STICK(4);
         }
         // ---- DP on the tables where they lie: the planes' LDS becomes M | in | A ---------------------------------------
-        // a read outside the lane range, or dropped above, has no coverage in the window: ambiguous exactly where lo < 0 (only tau = 1)
+        // a read outside the lane range, or dropped above, has no coverage in the window: ambiguous exactly where lo < 0 (h >= 1)
         int in_val[C::kSlots];
 #pragma unroll
         for (int s = 0; s < C::kSlots; ++s) in_val[s] = -(int)((i64)amb_acc[s] + (th_lo[s] < 0 ? (i64)d.outside + (d.lane_n - n_act) : 0));

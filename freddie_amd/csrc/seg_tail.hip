@@ -362,7 +362,7 @@ __global__ void __launch_bounds__(256) k_label_cols(i64 K, const i64 *final_off,
 }
 
 // The label arena is pre-filled with '0' (the label of a read without coverage) by one streaming kernel; in
-// partitions in which a zero-coverage read is ambiguous for some segment (lo < 0, i.e. threshold_rate == 1) every rep
+// partitions in which a zero-coverage read is ambiguous for some segment (lo < 0: h >= 1 -- threshold_rate = 1, or a table entry rounded to 1.0) every rep
 // first rewrites its row with the columns' defaults (k_label_reads).
 __global__ void __launch_bounds__(256) k_label_zero(uint4 *labels16, i64 n16) {
     fill_labels(labels16, n16, (i64)blockIdx.x * blockDim.x + threadIdx.x, (i64)gridDim.x * blockDim.x);
@@ -377,7 +377,7 @@ __global__ void __launch_bounds__(256) k_label_reads(int n_blocks, const int *rb
                                                      unsigned char *labels, unsigned *packed) {
     // packed != nullptr: the labels are written at two bits each into a cleared arena (label g at bits 2 (g & 15) .. of word g >> 4,
     // the layout fseg_results_packed delivers): a thread walks consecutive columns of its rep's row, collects the codes of a word
-    // in a register and ORs the word in when it moves on.  Only where no column's default is '2' (the host: threshold_rate < 1).
+    // in a register and ORs the word in when it moves on.  Only where no column's default is '2' (the host: no table entry and no rate >= 1, label_has2).
     __shared__ int fp_s[kLabelCols + 1];
     __shared__ int2 th_s[kLabelCols];
     if (label_off[n_part] > label_cap) return;

@@ -5,9 +5,10 @@ for line in sys.stdin:
         continue
     d = json.loads(line)
     r = d["roofline"]
-    print("%s value=%.4gM reads/s ms/step(job)=%.3f timed=%.3fs | scoring stage alone %.3f ms frac=%.3f (concurrent %.3f ms)" % (
-        d["config"]["workload"], d["value"] / 1e6, d["ms_per_step"], d.get("timed_s", 0.0), r["launch_ms"], r["frac"],
-        d.get("roofline_concurrent", {}).get("launch_ms", 0.0)))
+    print("%s value=%.4gM reads/s ms/pass(job)=%.3f timed=%.3fs | h2h %.4gM (%.3f ms/pass) | path frac %.3f / %.3f | scoring stage alone %.3f ms frac=%.3f (concurrent %.3f ms) | waiter time-outs %s" % (
+        d["config"]["workload"], d["value"] / 1e6, d.get("ms_per_pass", d["ms_per_step"]), d.get("timed_s", 0.0),
+        d.get("value_h2h", 0.0) / 1e6, d.get("ms_per_pass_h2h", 0.0), (d.get("roofline_path") or {}).get("frac", 0.0), (d.get("roofline_path") or {}).get("frac_h2h", 0.0),
+        r["launch_ms"], r["frac"], d.get("roofline_concurrent", {}).get("launch_ms", 0.0), d.get("sync_timeouts")))
     st = d.get("roofline_stages") or {}
     print("  " + " ".join("%s=%.3f%s" % (k, v["ms"], ("(%.2f)" % v["frac"]) if "frac" in v else "") for k, v in st.items()))
     for w in ("config2", "config3", "config5"):

@@ -106,6 +106,19 @@ def edge_cases():
     for i in range(30, 60):
         reads.append((i, "-", [(3000, 3110, 0, 110, "110M"), (3112, 3390, 110, 388, "278M")], 388 + 9))
     cases["e_refine_tie"] = (4, [(3000, 3400)], reads)
+    # threshold_rate = 0.9999: smooth_threshold() rounds its last entry (segment length 107) to 1.0 while the rate itself stays
+    # below 1 -- for a segment of exactly 107 positions h = 1, l = 0, so nothing is ever "not covered" (c < 0 is false) and a read
+    # WITHOUT coverage there is labelled '2' (:816-828); every other length has l > 0 and such a read gets '0'.  First interval:
+    # 107 positions without an inner candidate (one segment of length 107); second interval: ordinary splicing.  Reads of
+    # the second family never touch the first interval.
+    reads = []
+    for i in range(12):
+        reads.append((i, "+", [(5000, 5106, 0, 106, "106M"), (5300, 5380, 106, 186, "80M"), (5420, 5600, 186, 366, "180M")], 366 + 10))
+    for i in range(12, 20):
+        reads.append((i, "-", [(5300, 5380, 4, 84, "80M"), (5420, 5500, 84, 164, "80M"), (5530, 5600, 164, 234, "70M")], 234 + 8))
+    for i in range(20, 24):
+        reads.append((i, "+", [(5040, 5106, 0, 66, "66M"), (5300, 5360, 66, 126, "60M")], 126 + 8))
+    cases["e_tau9999_len107"] = (5, [(5000, 5106), (5300, 5600)], reads, dict(threshold_rate=0.9999))
     return cases
 
 
@@ -224,7 +237,7 @@ def record_raise_case(name, split_dir, contig, tint_id, run_kw, out_dir, manifes
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--big", action="store_true", help="also mint the config-2-scale hash fixture (minutes, GBs)")
-    ap.add_argument("--only", default="", help="mint only the synthetic cases whose name starts with this prefix (e.g. b_, x_) "
+    ap.add_argument("--only", default="", help="mint only the cases whose name starts with this prefix (e.g. b_, x_, e_tau) "
                     "and merge them into the manifest: the other fixtures' files stay as they are")
     args = ap.parse_args()
     manifest = dict(numpy=np.__version__, scipy=scipy.__version__, python=sys.version.split()[0],
@@ -247,10 +260,14 @@ def main():
         edge_root = os.path.join(HERE, "edge")
         if not args.only:
             shutil.rmtree(edge_root, ignore_errors=True)
-        for name, (tint_id, intervals, reads) in ({} if args.only else edge_cases()).items():
+        for name, case in edge_cases().items():
+            if args.only and not name.startswith(args.only):
+                continue
+            tint_id, intervals, reads = case[:3]
             d = os.path.join(edge_root, name)
+            shutil.rmtree(d, ignore_errors=True)
             write_edge(d, "chrE", tint_id, intervals, reads, seed=tint_id)
-            record_case(name, d, "chrE", tint_id, {}, HERE, manifest)
+            record_case(name, d, "chrE", tint_id, case[3] if len(case) > 3 else {}, HERE, manifest)
         if args.big:
             d = os.path.join(work, "g4_config2")
             gkw = dict(synth.WORKLOADS["config2"]); gkw.pop("n_partitions")

@@ -200,6 +200,32 @@ def test_label_arena_follows_the_parameters(env, monkeypatch):
         ctx.close()
 
 
+def test_rate_just_below_one_whose_table_ends_at_one():
+    """threshold_rate = 0.9999 (parse_args :105 accepts it): smooth_threshold() (:277-286) rounds its entry for segments of 107
+    positions to 1.0, so in THAT column every read -- covered or not -- is '2' (:816-828 with h = 1, l = 0) although the rate is
+    below 1.  The two-bit label arena assumes no column's default is '2': the library must decide from the table.
+    The reference-minted golden e_tau9999_len107 (one segment of exactly 107 positions) inside a batch of ordinary
+    partitions, labels as bytes, packed, first run and replay; then the same context back at an ordinary rate."""
+    import goldens
+    g = goldens.load("e_tau9999_len107")
+    params, tabs = goldens.params_of(g), goldens.tables_of(g)
+    assert params["threshold_rate"] < 1.0 and tabs["h_table"][107] == 1.0
+    gold_part, gold_res = goldens.partition_of(g), goldens.as_oracle_result(g)
+    assert (gold_res["labels"][:, 0] == 2).all()                            # the column of length 107: '2' for every rep
+    others = [util.make_partition(9300 + i, n_reads=150 + 25 * i, n_exons=40, rp=0.1) for i in range(6)]
+    parts = others[:3] + [gold_part] + others[3:]
+    oracles = [util.run_oracle(p, params, tabs) for p in others]
+    oracles = oracles[:3] + [gold_res] + oracles[3:]
+    ctx = _lib.Context(0)
+    try:
+        check_twice(ctx, parts, oracles, params)
+        check_twice(ctx, [gold_part], [gold_res], params)                   # alone (a small batch)
+        check_twice(ctx, others, [util.run_oracle(p) for p in others])      # the packed arena again
+        check_twice(ctx, parts, oracles, params)
+    finally:
+        ctx.close()
+
+
 @pytest.mark.parametrize("mps", [150, 300])
 def test_giant_problems_beyond_the_lds_kernels(mps, monkeypatch):
     """max_problem_size 150 / 300 (the CLI, like the reference's parse_args :108, accepts any value > 3; optimize :475-568 has no
@@ -277,6 +303,10 @@ def test_scoring_stage_fork_and_join(env, waiters, still_on, monkeypatch):
         assert bool(sy[1]) == still_on, sy
         if waiters and still_on:
             assert sy[2] == sy[0] and sy[3] == sy[0] and sy[5] == 0, sy     # the words carry the last generation; the counter is back at 0
+            assert sy[6] == 0, sy                                          # no waiter reached its limit (2 ms per 2^18 reads)
+        if waiters and not still_on:
+            assert sy[6] >= 3, sy                                          # every forked run lost its waiter, was redone with events; after three: events for good
+        assert sy[7] >= 5, sy                                              # every run of a context alone owns the device
         more = [util.make_partition(7100 + i, **kw) for i in range(40)]    # another batch on the same context
         check_twice(ctx, more, [util.run_oracle(p) for p in more])
     finally:
@@ -436,6 +466,63 @@ def test_contexts_taking_turns_on_one_device():
             t.join()
         if errors:
             raise errors[0]
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+def test_eight_contexts_replaying_resident_batches():
+    """The configuration bench.py's `value` runs (the pool map :871-876 as contexts of one device): eight contexts, each with its own
+    RESIDENT batch of config4-shaped partitions (64 and more each: k_thr_part and the split DP are on), uploaded and run once, then
+    replayed twenty times by eight host threads at once -- everything recomputed per pass, results left in HBM.  Afterwards every tap
+    of every context against the oracle.  Only the context that claimed the device may fork (side streams, device-side waiters);
+    no waiter may reach its time limit (round 5: four 20 ms time-outs in one such run, two contexts' waiters in front of each other)."""
+    import threading
+    n_ctx, passes = 8, 20
+    kw = dict(synth.WORKLOADS["config4"]); kw.pop("n_partitions")
+    batches = []
+    for k in range(n_ctx):
+        parts = [util.make_partition(61000 + 100 * k + i, **kw) for i in range(64 + 2 * k)]
+        batches.append((parts, [util.run_oracle(p) for p in parts]))
+    ctxs = [_lib.Context(0) for _ in range(n_ctx)]
+    errors = []
+    start = threading.Barrier(n_ctx)
+
+    def worker(k):
+        try:
+            util.run_gpu(ctxs[k], batches[k][0])              # upload + first (sized) run
+            start.wait()
+            for _ in range(passes):
+                ctxs[k].run(); ctxs[k].sync()
+        except BaseException as exc:                          # noqa: BLE001
+            errors.append(exc)
+            start.abort()
+
+    try:
+        th = [threading.Thread(target=worker, args=(k,)) for k in range(n_ctx)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        if errors:
+            raise errors[0]
+        forked = 0
+        for k in range(n_ctx):
+            rep = util.compare_partitions(ctxs[k], *batches[k])
+            assert rep["y_identical"]
+            packed = ctxs[k].results(packed=True)
+            assert np.array_equal(packed[3], util.pack_labels(ctxs[k].download()[3]))
+            sy = ctxs[k].tap("sync")
+            assert sy[6] == 0, "context %d: %d runs lost a waiter to its time limit (%r)" % (k, sy[6], sy)
+            forked += int(sy[7])
+        assert forked <= n_ctx * (passes + 1)
+        # ... and once more one after the other, each context alone on the device (it owns it: forked run, device-side waiters)
+        for k in range(n_ctx):
+            before = ctxs[k].tap("sync")
+            ctxs[k].run(); ctxs[k].sync()
+            after = ctxs[k].tap("sync")
+            assert after[7] == before[7] + 1 and after[6] == 0, (before, after)
+            assert util.compare_partitions(ctxs[k], *batches[k])["y_identical"]
     finally:
         for c in ctxs:
             c.close()

@@ -9,6 +9,7 @@ cp $O/stats/p_kernel_stats.csv profiles/${P}_config4_kernel_stats_8ctx.csv
 cp $O/trace1/p_kernel_stats.csv profiles/${P}_config4_kernel_stats.csv
 cp $O/config4_kernel_medians.txt profiles/${P}_config4_kernel_medians.txt
 cp $O/config4_kernel_medians_8ctx.txt profiles/${P}_config4_kernel_medians_8ctx.txt
+[ -f $O/config4_waiters_8ctx.txt ] && cp $O/config4_waiters_8ctx.txt profiles/${P}_config4_waiters_8ctx.txt
 cp $O/config2_kernel_medians.txt profiles/${P}_config2_kernel_medians.txt
 cp $O/config4_stage_span.txt profiles/${P}_config4_stage_span.txt
 [ -f $O/config4_stage_timeline.txt ] && cp $O/config4_stage_timeline.txt profiles/${P}_config4_stage_timeline.txt

@@ -12,9 +12,13 @@ mkdir -p $O
 if [[ "${PART:-all}" =~ ^(all|1)$ ]]; then
 # 1. the driver's command, plain and under the kernel trace (same command: the averages must agree with the line's events)
 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err; python profiles/benchsum.py < $O/bench_default.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o p -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-e2e > $O/bench_under_rocprof.json 2> $O/stats.err
+# (FREDDIE_BENCH_PASSES=1: a step = ONE pass over the job, as until round 5.  With the default 16 passes a step -- 330 k dispatches in
+# the process -- rocprofv3 7.2 dies of a SIGSEGV inside its own queue interception a few seconds in, whichever library is loaded,
+# round 5's too; one stream per context (FSEG_NO_FORK=1) survives.  Kernel durations do not depend on the number of passes.)
+FREDDIE_BENCH_PASSES=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o p -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-e2e > $O/bench_under_rocprof.json 2> $O/stats.err
 python profiles/benchsum.py < $O/bench_under_rocprof.json | head -1
 python profiles/trace_medians.py $O/stats/p_kernel_trace.csv > $O/config4_kernel_medians_8ctx.txt
+python tools/waiter_trace.py $O/stats/p_kernel_trace.csv 3 > $O/config4_waiters_8ctx.txt
 # 2. one context, one stream, one resident batch replayed: per-kernel durations with the GPU to themselves (the kernels `roofline`
 #    times: FSEG_SPLIT_ALWAYS keeps the split path -- k_solve's rounds + k_dpw -- although the streams are not forked)
 FSEG_SPLIT_ALWAYS=1 FSEG_NO_FORK=1 FSEG_NO_GRAPH=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace1 -o p -- python3 tools/replay_probe.py --workload config4 > $O/replay_config4.txt 2> $O/trace1.err
