@@ -228,21 +228,54 @@ def e2e_leg(workload, params, n_reads_target, threads, gpus=1):
             pool.map(_gen_split, [(i, w, split) for i in range(n_part)], chunksize=8)
         t_gen = time.perf_counter() - t0
         size = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(split) for f in fs)
-        cmd = [sys.executable, os.path.join(ROOT, "py", "freddie_segment.py"), "-s", split, "-o", out, "-t", str(threads),
-               "--gpus", str(gpus), "--sidecar", "off", "-sd", str(params["sigma"]), "-tp", str(params["threshold_rate"])]
+        def cli(sidecar):
+            return [sys.executable, os.path.join(ROOT, "py", "freddie_segment.py"), "-s", split, "-o", out, "-t", str(threads),
+                    "--gpus", str(gpus), "--sidecar", sidecar, "-sd", str(params["sigma"]), "-tp", str(params["threshold_rate"])]
         walls = []
         for _ in range(2):
             shutil.rmtree(out, ignore_errors=True)
             t0 = time.perf_counter()
-            subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL)
+            subprocess.run(cli("off"), check=True, stdout=subprocess.DEVNULL)
             walls.append(time.perf_counter() - t0)
         n_out = sum(len(fs) for _, _, fs in os.walk(out))
         reads = n_part * w["n_reads"]
-        return dict(value=reads / walls[-1], unit="reads/s", reads=reads, partitions=n_part, wall_s=walls, threads=threads,
-                    n_gpus=gpus, scaling="strong", input_mb=size / 1e6, output_files=n_out, tmp=base or tempfile.gettempdir(),
-                    generate_s=t_gen,
-                    what="py/freddie_segment.py -s <split> -o <out> -t %d --gpus %d --sidecar off (-t is per GPU worker): whole "
-                         "process wall time, second of two runs" % (threads, gpus))
+        res = dict(value=reads / walls[-1], unit="reads/s", reads=reads, partitions=n_part, wall_s=walls, threads=threads,
+                   n_gpus=gpus, scaling="strong", input_mb=size / 1e6, output_files=n_out, tmp=base or tempfile.gettempdir(),
+                   generate_s=t_gen,
+                   what="py/freddie_segment.py -s <split> -o <out> -t %d --gpus %d --sidecar off (-t is per GPU worker): whole "
+                        "process wall time, second of two runs" % (threads, gpus))
+        # row N2: the same job with binary side-cars beside the TSVs (what a second pass over a split directory meets: a parameter
+        # sweep, a re-run).  One untimed run writes them (--sidecar write), two timed runs load them (--sidecar auto); the output
+        # files must be byte-identical to the side-car-free run's.
+        try:
+            import hashlib
+
+            def digest():
+                h = hashlib.sha256()
+                for dp, _, fs in sorted(os.walk(out)):
+                    for f in sorted(fs):
+                        with open(os.path.join(dp, f), "rb") as fh:
+                            h.update(f.encode()); h.update(fh.read())
+                return h.hexdigest()
+            plain = digest()
+            shutil.rmtree(out, ignore_errors=True)
+            t0 = time.perf_counter()
+            subprocess.run(cli("write"), check=True, stdout=subprocess.DEVNULL)
+            t_write = time.perf_counter() - t0
+            sc_walls = []
+            for _ in range(2):
+                shutil.rmtree(out, ignore_errors=True)
+                t0 = time.perf_counter()
+                subprocess.run(cli("auto"), check=True, stdout=subprocess.DEVNULL)
+                sc_walls.append(time.perf_counter() - t0)
+            sc_mb = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(split) for f in fs if f.endswith(".fsc")) / 1e6
+            res["sidecar"] = dict(value=reads / sc_walls[-1], unit="reads/s", wall_s=sc_walls, write_pass_s=t_write, sidecar_mb=sc_mb,
+                                  same_bytes_as_plain=digest() == plain,
+                                  what="the same command with --sidecar auto on a split directory whose .fsc side-cars exist (written by an "
+                                       "untimed --sidecar write run): second of two runs")
+        except Exception as exc:                          # (the plain figure must not depend on this leg)
+            res["sidecar"] = dict(error="%s: %s" % (type(exc).__name__, exc))
+        return res
     finally:
         shutil.rmtree(work, ignore_errors=True)
 
@@ -848,6 +881,7 @@ def main():
         if out["reference_cpu"]:
             out["reference_cpu"]["ratios_use"] = "value_h2h (host memory -> host memory)"
         out["e2e"] = e2e
+        out["e2e_sidecar"] = (e2e or {}).get("sidecar")
         print(json.dumps(out))
     for ctx in ctxs:
         ctx.close()

@@ -365,9 +365,12 @@ i64 thread_cigar(const Partition &P, int ex, i64 t_goal, i64 t_pos, i64 q_pos) {
     }
     return q_pos;
 }
-void query_at_or_after(const Partition &P, const Read &r, i64 start, i64 &q, i64 &slack) {    // get_interval_start :307-326
-    for (int x = r.ex0; x < r.ex1; ++x) {
+// (`from`: where the scan starts -- the queries of one read come with ascending positions, so each starts where the last one ended
+// instead of at the read's first / last exon; the exon found is the same)
+void query_at_or_after(const Partition &P, const Read &r, i64 start, i64 &q, i64 &slack, int *from = nullptr) {    // get_interval_start :307-326
+    for (int x = from ? *from : r.ex0; x < r.ex1; ++x) {
         if (P.te[x] < start) continue;
+        if (from) *from = x;
         if (start < P.ts[x]) { q = P.qs[x]; slack = start - P.ts[x]; }
         else { q = thread_cigar(P, x, start, P.ts[x], P.qs[x]); slack = 0; }
         if (!(slack <= 0 && P.qs[x] <= q && q <= P.qe[x])) throw Fail{"get_interval_start: slack / query position out of range (:323-324)"};
@@ -375,15 +378,16 @@ void query_at_or_after(const Partition &P, const Read &r, i64 start, i64 &q, i64
     }
     throw Fail{"get_interval_start: no exon at or after the position (:326)"};
 }
-void query_at_or_before(const Partition &P, const Read &r, i64 end, i64 &q, i64 &slack) {     // get_interval_end :329-349
-    for (int x = r.ex1 - 1; x >= r.ex0; --x) {
-        if (P.ts[x] > end) continue;
-        if (P.te[x] < end) { q = P.qe[x]; slack = P.te[x] - end; }
-        else { q = thread_cigar(P, x, end, P.ts[x], P.qs[x]); slack = 0; }
-        if (!(slack <= 0 && 0 <= q && q <= P.qe[x])) throw Fail{"get_interval_end: slack / query position out of range (:346-347)"};
-        return;
-    }
-    throw Fail{"get_interval_end: no exon at or before the position (:349)"};
+void query_at_or_before(const Partition &P, const Read &r, i64 end, i64 &q, i64 &slack, int *from = nullptr) {     // get_interval_end :329-349
+    // the LAST exon with ts <= end: scanned backwards from the read's end (the reference's order), or forwards from `from` -- the
+    // last exon known to start at or before an earlier, smaller position
+    int x = r.ex1 - 1;
+    if (from) { x = *from; while (x + 1 < r.ex1 && P.ts[x + 1] <= end) ++x; if (x < r.ex0 || P.ts[x] > end) x = r.ex0 - 1; else *from = x; }
+    else while (x >= r.ex0 && P.ts[x] > end) --x;
+    if (x < r.ex0) throw Fail{"get_interval_end: no exon at or before the position (:349)"};
+    if (P.te[x] < end) { q = P.qe[x]; slack = P.te[x] - end; }
+    else { q = thread_cigar(P, x, end, P.ts[x], P.qs[x]); slack = 0; }
+    if (!(slack <= 0 && 0 <= q && q <= P.qe[x])) throw Fail{"get_interval_end: slack / query position out of range (:346-347)"};
 }
 
 struct PolyRun { i64 first, len; double purity; char ch; };
@@ -404,36 +408,44 @@ bool best_poly(const Str &seq, bool minus, i64 s0, i64 e0, PolyRun &best) {
     }
     if (!minus && s0 + count > n) count = n - s0;
     if (minus && n - 1 - s0 - (count - 1) < 0) count = n - s0;
-    bool have = false;
-    const char *base = seq.p;
-    for (int pass = 0; pass < 2; ++pass) {
-        const char ch = pass ? 'T' : 'A';
-        const char target = minus ? (ch == 'A' ? 'T' : 'A') : ch;
-        int prev = 0, best_s = 0;
-        bool in_run = false;
-        i64 run_i = 0, best_i = 0, hits_run = 0, hits_best = 0;
-        auto emit = [&]() {
-            const i64 len = best_i + 1 - run_i;
-            if (len < 20) return;
-            const double purity = (double)hits_best / (double)len;
-            if (purity < 0.85) return;
-            if (!have || purity > best.purity) { best = PolyRun{run_i, len, purity, ch}; have = true; }
-        };
-        const char *q = minus ? base + (n - 1 - s0) : base + s0;
-        const i64 step = minus ? -1 : 1;
-        for (i64 t = 0; t < count; ++t, q += step) {
-            const int m = *q == target;
-            const int s = std::max(0, prev + (m ? 1 : -2));
-            if (s > 0) {
-                if (!in_run) { in_run = true; run_i = t; best_s = 0; hits_run = 0; }
-                hits_run += m;
-                if (s >= best_s) { best_s = s; best_i = t; hits_best = hits_run; }     // max over (score, index): the last maximum
-            } else if (in_run) { emit(); in_run = false; }
-            prev = s;
+    // a run shorter than 20 is never reported (:399, :429), so a window of fewer than 20 letters has none
+    if (count < 20) return false;
+    // both letters in ONE pass over the window; "A runs before T runs, the first of the purest wins" = the best A run unless a T run
+    // is strictly purer
+    struct Scan { int prev = 0, best_s = 0; bool in_run = false, have = false; i64 run_i = 0, best_i = 0, hits_run = 0, hits_best = 0; PolyRun best{}; };
+    Scan sc[2];
+    const char tgt[2] = {minus ? 'T' : 'A', minus ? 'A' : 'T'};          // (a '-' read is scanned backwards for the complement letter)
+    auto emit = [](Scan &z, char ch) {
+        const i64 len = z.best_i + 1 - z.run_i;
+        if (len < 20) return;
+        const double purity = (double)z.hits_best / (double)len;
+        if (purity < 0.85) return;
+        if (!z.have || purity > z.best.purity) { z.best = PolyRun{z.run_i, len, purity, ch}; z.have = true; }
+    };
+    const char *q = minus ? seq.p + (n - 1 - s0) : seq.p + s0;
+    const i64 step = minus ? -1 : 1;
+    for (i64 t = 0; t < count; ++t, q += step) {
+        const char c = *q;
+#define FHOST_POLY_STEP(Z, CH, TARGET)                                                                          \
+        {                                                                                                       \
+            const int m = c == (TARGET);                                                                        \
+            const int s = std::max(0, (Z).prev + (m ? 1 : -2));                                                 \
+            if (s > 0) {                                                                                        \
+                if (!(Z).in_run) { (Z).in_run = true; (Z).run_i = t; (Z).best_s = 0; (Z).hits_run = 0; }        \
+                (Z).hits_run += m;                                                                              \
+                if (s >= (Z).best_s) { (Z).best_s = s; (Z).best_i = t; (Z).hits_best = (Z).hits_run; }   /* max over (score, index): the last maximum */ \
+            } else if ((Z).in_run) { emit((Z), (CH)); (Z).in_run = false; }                                     \
+            (Z).prev = s;                                                                                       \
         }
-        if (in_run) emit();
+        FHOST_POLY_STEP(sc[0], 'A', tgt[0])
+        FHOST_POLY_STEP(sc[1], 'T', tgt[1])
+#undef FHOST_POLY_STEP
     }
-    return have;
+    if (sc[0].in_run) emit(sc[0], 'A');
+    if (sc[1].in_run) emit(sc[1], 'T');
+    if (sc[0].have && (!sc[1].have || !(sc[1].best.purity > sc[0].best.purity))) { best = sc[0].best; return true; }
+    if (sc[1].have) { best = sc[1].best; return true; }
+    return false;
 }
 
 struct Tok { char s[48]; };
@@ -457,7 +469,11 @@ void annotate_read(const Partition &P, const Read &r, const unsigned char *data,
     toks.clear();
     runs.clear();
     for (i64 i = 0; i < S;) {
-        if (data[i] != '1') { ++i; continue; }
+        if (data[i] != '1') {                                   // (rows are mostly '0': skip to the next '1' a word at a time)
+            const void *nx = memchr(data + i, '1', (size_t)(S - i));
+            if (!nx) break;
+            i = (i64)(static_cast<const unsigned char *>(nx) - data);
+        }
         i64 j = i;
         while (j + 1 < S && data[j + 1] == '1') ++j;
         runs.emplace_back(i, j);
@@ -483,17 +499,30 @@ void annotate_read(const Partition &P, const Read &r, const unsigned char *data,
         char *t = tok(); *t++ = 'E'; *t++ = b.ch; *t++ = '_'; t = put_i(t, b.len); *t++ = ':'; t = put_i(t, b.first); *t = 0;
         t = tok(); t = put_s(t, "ESC:"); t = put_i(t, length - q_esc - b.first); *t = 0;
     } else { char *t = tok(); t = put_s(t, "ESC:"); t = put_i(t, length - q_esc); *t = 0; }
+    const size_t n_ends = toks.size();                      // the soft-clip / poly tokens: "E.." and "S.."
+    int xa = r.ex0, xb = r.ex0;
     for (size_t k = 0; k + 1 < runs.size(); ++k) {
         i64 last1 = runs[k].second, first2 = runs[k + 1].first, q_a, slack_a, q_b, slack_b;
-        query_at_or_before(P, r, fp[last1 + 1], q_a, slack_a);
-        query_at_or_after(P, r, fp[first2], q_b, slack_b);
+        query_at_or_before(P, r, fp[last1 + 1], q_a, slack_a, &xb);
+        query_at_or_after(P, r, fp[first2], q_b, slack_b, &xa);
         if (!(0 < q_a && q_a <= q_b && q_b < length)) throw Fail{"unaligned gap positions out of order (:462)"};
         i64 size = std::max<i64>(0, q_b - q_a + slack_a + slack_b);
         if (!(0 <= size && size < length && last1 < first2)) throw Fail{"unaligned gap size out of range (:466-468)"};
         char *t = tok(); t = put_i(t, last1); *t++ = '-'; t = put_i(t, first2); *t++ = ':'; t = put_i(t, size); *t = 0;
     }
-    std::sort(toks.begin(), toks.end(), [](const Tok &a, const Tok &b2) { return strcmp(a.s, b2.s) < 0; });   // sorted(set(...)) on strings (:472)
-    toks.erase(std::unique(toks.begin(), toks.end(), [](const Tok &a, const Tok &b2) { return strcmp(a.s, b2.s) == 0; }), toks.end());
+    // read['gaps'] = sorted(set(...)) on strings (:472).  No two tokens are equal (the gap tokens differ in their first number, the
+    // others in their first letters), and a digit sorts before 'E' before 'S': the gap tokens, sorted among themselves, go first,
+    // then the (at most three each) E and S tokens -- a rotation and two short sorts instead of one sort of 48-byte records.
+    std::rotate(toks.begin(), toks.begin() + (std::ptrdiff_t)n_ends, toks.end());
+    const auto less = [](const Tok &a, const Tok &b2) { return strcmp(a.s, b2.s) < 0; };
+    const size_t n_gaps = toks.size() - n_ends;
+    if (n_gaps > 1) {
+        // "last1-first2:size" with last1 ascending: already sorted unless the first numbers differ in their digit counts
+        bool sorted = true;
+        for (size_t k = 1; k < n_gaps && sorted; ++k) sorted = less(toks[k - 1], toks[k]);
+        if (!sorted) std::sort(toks.begin(), toks.begin() + (std::ptrdiff_t)n_gaps, less);
+    }
+    std::sort(toks.begin() + (std::ptrdiff_t)n_gaps, toks.end(), less);
 }
 
 // ---- binary side-car of a partition ------------------------------------------

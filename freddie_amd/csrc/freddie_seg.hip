@@ -297,6 +297,7 @@ thread_local std::string g_create_error;      // fseg_create has no context to p
 // forks only after it has CLAIMED the device: one compare-and-swap on the device's owner word, taken by fseg_run when nobody
 // else is in flight, given back when the run has completed (finish_run).  Losers, and whoever arrives while the word is held,
 // keep to one stream.  With one forking context per device a waiter can only sit in front of kernels that do not feed it.
+static bool g_ablate_dp = false;     // (diagnostic build FSEG_ABLATE_STAGE only: the k_dpw launches are left out)
 static std::atomic<int> g_in_flight[64];
 static std::atomic<int> g_live[64];
 static std::atomic<const fseg_ctx *> g_owner[64];
@@ -761,7 +762,7 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
             hipLaunchKernelGGL((k_solve<NMV, CNT, int, true>), dim3(grid_for(FSEG_SOLVE_N(CNT, CLS, N_ITEMS), 1, (int)kSplitGridCap)), dim3(SolveCfg<NMV>::kThreads), \
                                solve_lds_for(nm_rt, (NMV) + 1, (int)sizeof(CNT)), Q, FSEG_SOLVE_ARGS(NMV, CNT, CLS), dpx0, dstride, \
                                FSEG_SOLVE_WIDE(CNT, CLS) FSEG_TARG);                                    \
-            hipLaunchKernelGGL((k_dpw<NMV, CNT, VT>), dim3(grid_for(FSEG_SOLVE_N(CNT, CLS, N_ITEMS), 1, (int)kSplitGridCap)), dim3(64),      \
+            if (!g_ablate_dp) hipLaunchKernelGGL((k_dpw<NMV, CNT, VT>), dim3(grid_for(FSEG_SOLVE_N(CNT, CLS, N_ITEMS), 1, (int)kSplitGridCap)), dim3(64),      \
                                dpw_lds_for(nm_rt, (int)sizeof(VT), (int)sizeof(CNT)), Q, st, nm_rt, list_lb(CLS),                \
                                FSEG_SOLVE_N(CNT, CLS, list_ln(CLS)), pr,                                                        \
                                c->d_solve_desc.as<ProbDesc>(), dpx0, dstride, \
@@ -856,6 +857,19 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
                         if (*p == 'g' || (*p == 'h' && wide_wgs > 0)) sig_word = &sw->emit_gen;
                         else hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, s, &sw->emit_gen, sync_gen);
                     }
+#ifdef FSEG_ABLATE_STAGE
+                    // diagnostic build (wrong results, honest timing): FSEG_ABLATE = bit mask of what the stage leaves out --
+                    // 1 the DP launches (k_dpw), 2 the large class, 4 the gates, 8 the mid class, 16 the small class, 32 the tiny class
+                    {
+                        static const int abl = getenv("FSEG_ABLATE") ? atoi(getenv("FSEG_ABLATE")) : 0;
+                        g_ablate_dp = (abl & 1) != 0;
+                        if (((abl & 2) && (*p == 'B' || *p == 'W' || *p == 'b')) || ((abl & 4) && (*p == 'g' || *p == 'h')) || ((abl & 8) && (*p == 'M' || *p == 'm')) ||
+                            ((abl & 16) && (*p == 'S' || *p == 's')) || ((abl & 32) && *p == 'T')) {
+                            if (sig_word) hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, s, &sw->emit_gen, sync_gen);
+                            continue;
+                        }
+                    }
+#endif
                     switch (*p) {
                     case 'B': FSEG_LAUNCH_SOLVE_X(q, kNMax, 2, c->n_solve[2], 512, wb);
                               ev_big = fj_event(); if (hipEventRecord(ev_big, q) != hipSuccess) fj_err = hipErrorUnknown; break;

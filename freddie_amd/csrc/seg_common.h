@@ -133,6 +133,9 @@ struct Status {
                             // its 62 us: these two count a few hundred)
     unsigned sync_abort;    // a device-side waiter timed out: the scoring kernels behind it end at once (their input may not exist yet)
     unsigned pad2;
+    // (Round 6 tried a start counter for the mid class here -- a gate 'i' that holds the small class back until the mid class's first
+    // workgroups are placed.  Beside sync_abort, which every workgroup of the stage reads, eight counters took the stage from 0.125 to
+    // 0.151 ms; on 128-byte lines of their own they cost nothing, and the gate gained nothing: 0.120-0.127 ms.  Removed.)
 };
 
 // Words of the device-side fork / join of the scoring stage (own allocation, zeroed once; generations only grow): see k_wait_word.

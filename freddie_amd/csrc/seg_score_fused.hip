@@ -378,8 +378,8 @@ __global__ void __launch_bounds__(64) k_gate(Status *st, int which, unsigned gri
     // grid: the large class's workgroups the plan has launched (8-bit instance, and for the start gate the 16-bit one's too), at
     // most as many as fit the chip at once
     const unsigned want = grid;
-    const unsigned *ctr = which == 2 ? &st->gate_wide : &st->gate;      // (2: the 16-bit instance's workgroups)
     const unsigned long long t0 = wall_clock64();
+    const unsigned *ctr = which == 2 ? &st->gate_wide : &st->gate;      // (2: the 16-bit instance's workgroups)
     while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want && wall_clock64() - t0 < max_ticks && !stage_aborted(st))
         __builtin_amdgcn_s_sleep(16);
 }

@@ -413,6 +413,11 @@ def set_context_params(ctx, params):
                    np.asarray(smoothed_threshold, np.float64))
 
 
+def _early_mod():
+    from . import _early
+    return _early
+
+
 def sidecar_path(split_tsv):
     """split_<contig>_<tint>.tsv -> split_<contig>_<tint>.fsc (binary side-car, include/freddie_host.h)."""
     return split_tsv[:-4] + ".fsc"
@@ -517,10 +522,11 @@ def run_batches(batches, params, ctxs, threads, on_done, sidecar="off"):
 
         def prefetch():
             nonlocal nxt
-            # (two being parsed, one waiting: the first ones while the contexts come up.  Host memory: a parsed batch is its
-            # mapped TSVs plus ~100 B per read of arrays -- with --batch-reads 250 000 about 25 MB each, three of them held here,
-            # two more on the contexts and up to two with the writers: ~0.2 GB at the default, in proportion to --batch-reads)
-            while nxt < len(batches) and len(loads) < 3:
+            # (two being parsed, three waiting or done: while the contexts come up -- 0.08-0.15 s -- nobody takes a parsed batch
+            # away, and with three in all the loaders sat idle for the second half of that time (FREDDIE_TIMING=1, round 6).  Host
+            # memory: a parsed batch is its mapped TSVs plus ~100 B per read of arrays -- with --batch-reads 250 000 about 25 MB
+            # each, five of them held here, two more on the contexts and up to two with the writers: ~0.25 GB at the default)
+            while nxt < len(batches) and len(loads) < 5:
                 loads.append(load_pool.submit(load, batches[nxt], nxt))
                 nxt += 1
 
@@ -600,8 +606,9 @@ def run_segment(segment_args, ctx=None):
 
 def discover(split_dir, outdir):
     """(contig, tint_id, cost) of every partition, creating the output directories (:852-857)."""
-    # (one scandir pass per contig directory: name, type and size of an entry come from the same directory read -- listdir +
-    # glob + getsize was three passes and a stat per file, 40 ms for the 8 000 files of the 2 M-read job)
+    # (one scandir pass per contig directory for the names -- listdir + glob + getsize was three passes and a stat per file --, then
+    # the sizes: a stat per file, the system call outside the GIL, so a big directory's files are stat-ed by a few threads at once:
+    # 0.09 -> 0.03 s of the 2 M-read job's 0.8 s for its 8 000 files)
     found = []
     with os.scandir(split_dir) as contigs:
         for centry in contigs:
@@ -613,8 +620,19 @@ def discover(split_dir, outdir):
                 for f in files:
                     name = f.name
                     if name.startswith("split_") and name.endswith(".tsv"):
-                        found.append((contig, int(name[:-4].split("_")[-1]), f.stat().st_size))
-    return found
+                        found.append((contig, int(name[:-4].split("_")[-1]), f.path))
+
+    def sizes(chunk):
+        return [os.stat(p).st_size for _, _, p in chunk]
+    if len(found) >= 1024:
+        from concurrent.futures import ThreadPoolExecutor
+        n_thr = 8
+        step = (len(found) + n_thr - 1) // n_thr
+        with ThreadPoolExecutor(max_workers=n_thr) as pool:
+            got = [x for part in pool.map(sizes, [found[i:i + step] for i in range(0, len(found), step)]) for x in part]
+    else:
+        got = sizes(found)
+    return [(c, t, sz) for (c, t, _), sz in zip(found, got)]
 
 
 def make_batches(jobs_with_cost, bytes_per_batch):
@@ -692,7 +710,7 @@ def _gpu_worker(device, n_workers, jobs_with_cost, params, batch_bytes, threads,
                     ctx.close()
             finally:
                 queue.put(None)
-    if ok and WORKER_START_METHOD == "spawn" and os.environ.get("FREDDIE_CLEAN_EXIT") != "1":
+    if ok and WORKER_START_METHOD == "spawn" and _early_mod().fast_exit_allowed():
         # (a spawned worker that has finished its share leaves without the interpreter's and the HIP runtime's tear-down, like the
         # drop-in script: py/freddie_segment.py -- once its last messages are on their way to the parent)
         queue.close()
@@ -711,7 +729,9 @@ def _expand_jobs(msg):
     return [((split_dir, outdir, contig, tint_id), cost) for contig, tint_id, cost in items]
 
 
-def main(argv=None):
+def main(argv=None, leave_contexts=False):
+    """leave_contexts: the caller ends the process right after main() (the drop-in script's fast exit): a successful one-GPU run then
+    leaves its contexts to the process's end instead of closing them one by one (streams, events, slabs: 0.03-0.06 s)."""
     import time
     t_start = time.perf_counter()
     from . import devices, scatter
@@ -803,12 +823,18 @@ def main(argv=None):
         t_disc = time.perf_counter()
         jobs = [((split_dir, args.outdir, parts[i][0], parts[i][1]), parts[i][2]) for i in assign[0]]
         with boot:
+            ok = False
             try:
                 run_batches(make_batches(jobs, batch_bytes), params, ctx_future, args.threads, report, args.sidecar)
+                ok = True
             finally:
                 t_run = time.perf_counter()
-                for ctx in ctx_future.result():
-                    ctx.close()
+                if not (ok and leave_contexts):
+                    for ctx in ctx_future.result():
+                        ctx.close()
+                else:
+                    for ctx in ctx_future.result():
+                        ctx.sync()                   # (every batch's results have been written: nothing is in flight)
         if timing:
             print("[freddie_segment] discover %.3f s, batches (incl. context start-up) %.3f s, close %.3f s" % (
                 t_disc - t_start, t_run - t_disc, time.perf_counter() - t_run), file=sys.stderr)

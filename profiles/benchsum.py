@@ -19,3 +19,6 @@ for line in sys.stdin:
     e = d.get("e2e") or {}
     if "value" in e:
         print("  e2e %.3gM reads/s (%s s)" % (e["value"] / 1e6, ",".join("%.2f" % x for x in e["wall_s"])))
+    sc = d.get("e2e_sidecar") or {}
+    if "value" in sc:
+        print("  e2e with side-cars %.3gM reads/s (%s s; same bytes: %s)" % (sc["value"] / 1e6, ",".join("%.2f" % x for x in sc["wall_s"]), sc.get("same_bytes_as_plain")))

@@ -55,8 +55,9 @@ if __name__ == "__main__":
     try:
         # (inside the try: an import error must not end the interpreter while the start-up thread is inside the HIP runtime)
         from freddie_amd.segment import main
+        from freddie_amd._early import fast_exit_allowed
         _t_import = time.perf_counter()
-        main()
+        main(leave_contexts=fast_exit_allowed())
     finally:
         if _dev is not None:
             _early.finish()
@@ -65,8 +66,9 @@ if __name__ == "__main__":
               "come on top)" % (_t_import - _T0, time.perf_counter() - _T0), file=sys.stderr)
     # The work is done and every output file is closed: leave without the interpreter's and the HIP runtime's tear-down (module
     # clean-up, the runtime's static destructors, unmapping the code objects: 0.15 s of a 2 M-read job's 0.84 s wall).  Only on
-    # success -- an exception takes the ordinary way out above --; FREDDIE_CLEAN_EXIT=1 keeps the ordinary exit.
-    if os.environ.get("FREDDIE_CLEAN_EXIT") != "1":
+    # success -- an exception takes the ordinary way out above --, and never under a profiler, tracer or coverage run, whose output is
+    # written by exit hooks (freddie_amd/_early.py: fast_exit_allowed); FREDDIE_CLEAN_EXIT=1 keeps the ordinary exit.
+    if fast_exit_allowed():
         sys.stdout.flush()
         sys.stderr.flush()
         os._exit(0)

@@ -213,3 +213,72 @@ def test_sidecar_tool_covers_a_split_directory(tmp_path):
     for k, v in a.arrays().items():
         assert np.array_equal(v, b.arrays()[k]), k
     a.close(); b.close()
+
+
+def craft_poly_clips(src_dir, contig, tid, seed):
+    """Rewrites the soft clips of a synthetic partition's reads with poly-A / poly-T runs that compete: both letters in one clip, equal
+    purities (the 'A' run must win a tie), runs of 19 and of exactly 20, impure runs around the 0.85 limit, runs cut by a mismatch
+    burst, clips shorter than 20 -- on both strands (a '-' read is scanned backwards for the complement letter)."""
+    sp, rp = paths(src_dir, contig, tid)
+    rng = np.random.default_rng(seed)
+    clips = {}
+    for line in open(sp):
+        if line.startswith("#"):
+            continue
+        f = line.rstrip("\n").split("\t")
+        ivs = [x for x in f[5:] if x]
+        q0 = int(ivs[0].split(":")[1].split("-")[0]); q1 = int(ivs[-1].split(":")[1].split("-")[1])
+        clips[f[0]] = (q0, q1)
+    blocks = ["A" * 25, "T" * 25, "A" * 19, "T" * 20, "A" * 20, "A" * 17 + "C" + "A" * 6, "T" * 10 + "G" + "T" * 12 + "C" + "T" * 9,
+              "A" * 22 + "CC" + "A" * 30, "T" * 30 + "G" + "A" * 30, "A" * 20 + "G" + "T" * 20, "AAAC" * 8, "T" * 6 + "CCCC" + "T" * 24]
+
+    def fill(n):
+        out = ""
+        while len(out) < n:
+            out += blocks[int(rng.integers(len(blocks)))] if rng.random() < 0.8 else "".join("ACGT"[i] for i in rng.integers(0, 4, int(rng.integers(1, 9))))
+        return out[:n]
+    lines = []
+    for line in open(rp):
+        f = line.rstrip("\n").split("\t")
+        q0, q1 = clips[f[0]]
+        seq = f[3]
+        seq = fill(q0) + seq[q0:q1] + fill(len(seq) - q1)
+        lines.append("\t".join(f[:3] + [seq]) + "\n")
+    open(rp, "w").writelines(lines)
+
+
+@pytest.mark.parametrize("seed", [31, 32])
+def test_native_poly_tails_match_the_python_mirror(seed, tmp_path):
+    """The writer's poly-A / poly-T choice (one pass for both letters, :352-367 + :397-408 / :427-439) on crafted soft clips against the
+    Python mirror of the reference (itself pinned by the goldens' TSV bytes); tests/test_live_reference.py runs the same input through
+    the reference where it is present."""
+    from freddie_amd import segment, synth
+    import util
+    d = str(tmp_path / "in")
+    synth.generate(seed, write_dir=d, n_reads=240, n_exons=30, rp=0.1)
+    craft_poly_clips(d, "chrS", seed, seed)
+    tint = segment._load_partition(d, "chrS", seed)
+    part = segment.pack_tint(tint)
+    o = util.run_oracle(part)
+    assert o["error"] == 0
+    tint["final_positions"] = o["final_pos"].tolist()
+    tint["segs"] = list(zip(tint["final_positions"][:-1], tint["final_positions"][1:]))
+    for ri, (_, ridxs) in enumerate(tint["read_reps"]):
+        for ridx in ridxs:
+            tint["reads"][ridx]["data"] = o["labels"][ri].tolist()
+    for read in tint["reads"]:
+        segment.unaligned_gaps_and_polyA(read, tint["segs"])
+    want = tmp_path / "want.tsv"
+    segment.write_segment_tsv(tint, str(want))
+    text = want.read_text()
+    counts = {k: text.count(k) for k in ("SA_", "ST_", "EA_", "ET_")}
+    assert min(counts.values()) >= 3 and sum(counts.values()) >= 25, counts   # the crafted clips do produce poly tokens of both letters at both ends
+    sp, rp = paths(d, "chrS", seed)
+    hb = _host.HostBatch([sp], [rp], n_threads=1)
+    try:
+        F = len(o["final_pos"])
+        out = str(tmp_path / "got.tsv")
+        hb.write(np.array([0, F]), o["final_pos"], np.array([0, o["labels"].size]), (o["labels"] + 48).astype(np.uint8).ravel(), [out])
+        assert open(out, "rb").read() == want.read_bytes()
+    finally:
+        hb.close()

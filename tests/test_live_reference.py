@@ -69,3 +69,28 @@ def test_oracle_vs_live_reference_large_problems(tmp_path):
     assert np.array_equal(np.array(tint["final_positions"], np.int32), o["final_pos"])
     for ri, (_, ridxs) in enumerate(tint["read_reps"]):
         assert list(o["labels"][ri]) == tint["reads"][ridxs[0]]["data"]
+
+
+@pytest.mark.parametrize("seed", [31, 33])
+def test_native_writer_vs_live_reference_on_crafted_poly_clips(tmp_path, seed):
+    """The native writer's gaps / poly-A annotation (:370-472; one pass for both letters since round 6) against the reference's own
+    run_segment() output bytes on soft clips crafted to hold competing poly-A / poly-T runs (ties, lengths 19 / 20, impurities, both
+    strands).  Labels and final positions are the reference's."""
+    from freddie_amd import _host
+    from test_host_native import craft_poly_clips, paths
+    d = str(tmp_path / "in")
+    synth.generate(seed, write_dir=d, n_reads=240, n_exons=30, rp=0.1)
+    craft_poly_clips(d, "chrS", seed, seed)
+    tint, rec = refrun.run_recorded(d, str(tmp_path / "out"), "chrS", seed)
+    want = open(os.path.join(str(tmp_path / "out"), "chrS", "segment_chrS_%d.tsv" % seed), "rb").read()
+    assert sum(want.count(k) for k in (b"SA_", b"ST_", b"EA_", b"ET_")) >= 25
+    labels = np.array([tint["reads"][ridxs[0]]["data"] for _, ridxs in tint["read_reps"]], np.uint8)
+    fp = np.array(tint["final_positions"], np.int32)
+    sp, rp = paths(d, "chrS", seed)
+    hb = _host.HostBatch([sp], [rp], n_threads=2)
+    try:
+        out = str(tmp_path / "got.tsv")
+        hb.write(np.array([0, len(fp)]), fp, np.array([0, labels.size]), (labels + 48).astype(np.uint8).ravel(), [out], n_threads=2)
+        assert open(out, "rb").read() == want
+    finally:
+        hb.close()
