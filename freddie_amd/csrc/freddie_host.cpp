@@ -5,7 +5,7 @@
 // annotation (:289-472) and the segment TSV writer (:703-732).  What each function must produce is defined by
 // those reference lines; the implementation is this project's own and is built around not allocating per read:
 //   * the two TSVs of a partition are mapped, not copied; read names, contigs and sequences are views into the
-//     mappings for as long as the batch lives (a partition loaded from a side-car keeps them in one arena instead);
+//     mappings for as long as the batch lives (a partition loaded from a side-car: views into the mapped side-car, sequences packed);
 //   * one pass over the bytes of a line, integers parsed in place; the rep grouping is an open-addressing table over
 //     the exon tuples; sequences are matched to reads by position when the two files list the reads in the same
 //     order (the split stage writes them that way), by a hash of the read id otherwise;
@@ -33,14 +33,15 @@ namespace {
 
 typedef long long i64;
 
-struct Str {                   // a view into a mapped file or into the partition's arena
+struct Str {                   // a view into a mapped file (a TSV, or the partition's side-car)
     const char *p = nullptr;
     uint32_t n = 0;
 };
 
 struct Read {
     i64 id = 0, tint = 0;
-    Str name, chr, seq;
+    Str name, chr, seq;          // seq.p == nullptr: the sequence lives two bits a base in the partition's side-car (seq_g0 = its first base there)
+    uint64_t seq_g0 = 0;
     int ex0 = 0, ex1 = 0;     // exon range of this read inside the partition's exon arrays
     int rep = 0;
     char strand = '+';
@@ -86,7 +87,16 @@ struct Partition {
     // read reps in first-occurrence order (:165-170)
     std::vector<int> rep_first_read, rep_weight;
     Mapping map_split, map_reads;           // the TSVs stay mapped while the partition lives
-    std::vector<char> arena;                // side-car path: names, contigs and unpacked sequences
+    // side-car path: the .fsc stays mapped instead; names and contigs are views into it and the sequences stay PACKED (two bits a
+    // base + an exception list) -- the writer unpacks the soft-clipped ends it looks at (seq_window), a few dozen bases of a read's
+    // ~1 500.  (Until round 6 every sequence was unpacked into an arena when the side-car was loaded: 1.5 KB of stores and page
+    // faults per read, which made a side-car load SLOWER than parsing the TSVs: 0.15 against 0.08 s per 250 k reads.)
+    Mapping map_fsc;
+    const uint8_t *packed = nullptr;
+    const uint64_t *exc_pos = nullptr;
+    const uint8_t *exc_ch = nullptr;
+    size_t n_exc = 0;
+    bool from_sidecar = false;
     // the TSVs as they were when this partition was read (what a side-car written from it is bound to)
     uint64_t split_size = 0, reads_size = 0;
     int64_t split_mtime_ns = 0, reads_mtime_ns = 0;
@@ -96,12 +106,13 @@ struct Partition {
     Partition() = default;
     Partition(const Partition &) = delete;
     Partition &operator=(const Partition &) = delete;
-    ~Partition() { map_split.close(); map_reads.close(); }
+    ~Partition() { map_split.close(); map_reads.close(); map_fsc.close(); }
     void reset() {
         chr.clear(); id = read_count = 0;
         iv_s.clear(); iv_e.clear(); reads.clear(); ts.clear(); te.clear(); qs.clear(); qe.clear();
         cig_off.clear(); cig_len.clear(); cig_op.clear(); rep_first_read.clear(); rep_weight.clear();
-        map_split.close(); map_reads.close(); arena.clear(); have_stat = false; err.clear();
+        map_split.close(); map_reads.close(); map_fsc.close(); packed = nullptr; exc_pos = nullptr; exc_ch = nullptr; n_exc = 0; from_sidecar = false;
+        have_stat = false; err.clear();
     }
 };
 
@@ -392,13 +403,29 @@ void query_at_or_before(const Partition &P, const Read &r, i64 end, i64 &q, i64 
 
 struct PolyRun { i64 first, len; double purity; char ch; };
 
+// the stored letters [lo, hi) of a read: where they lie (TSV path), or unpacked into `scratch` (side-car path)
+const char *seq_window(const Partition &P, const Read &r, i64 lo, i64 hi, std::vector<char> &scratch) {
+    if (r.seq.p) return r.seq.p + lo;
+    static const char LUT[4] = {'A', 'C', 'G', 'T'};
+    const size_t m = (size_t)(hi - lo);
+    if (scratch.size() < m + 8) scratch.resize(m + 64);
+    char *dst = scratch.data();
+    const uint64_t g0 = r.seq_g0 + (uint64_t)lo;
+    for (size_t t = 0; t < m; ++t) { const uint64_t g = g0 + t; dst[t] = LUT[(P.packed[(size_t)(g >> 2)] >> ((g & 3) * 2)) & 3]; }
+    if (P.n_exc) {                                            // bytes other than upper-case ACGT (rare): the exception list, ascending
+        const uint64_t *e = std::lower_bound(P.exc_pos, P.exc_pos + P.n_exc, g0);
+        for (; e < P.exc_pos + P.n_exc && *e < g0 + m; ++e) dst[*e - g0] = (char)P.exc_ch[e - P.exc_pos];
+    }
+    return dst;
+}
+
 // find_longest_poly (:352-367) over the window [s0, e0) of the read in alignment orientation (for '-' reads the window
 // is taken from the end of the stored sequence backwards and the complement letter is searched), fused with the
 // caller's choice (:397-408, :427-439): runs of positive local score (+1 match, -2 mismatch, floored at 0), each cut at
 // its LAST maximum; of those with length >= 20 and purity >= 0.85 the purest wins, the first one on ties, 'A' runs
 // before 'T' runs.  Streaming: no score array.
-bool best_poly(const Str &seq, bool minus, i64 s0, i64 e0, PolyRun &best) {
-    const i64 n = (i64)seq.n;
+bool best_poly(const Partition &P, const Read &r, bool minus, i64 s0, i64 e0, PolyRun &best, std::vector<char> &scratch) {
+    const i64 n = (i64)r.seq.n;
     if (e0 - s0 == 0) return false;
     i64 count = e0 - s0;
     if (count < 0) count = 0;
@@ -422,7 +449,10 @@ bool best_poly(const Str &seq, bool minus, i64 s0, i64 e0, PolyRun &best) {
         if (purity < 0.85) return;
         if (!z.have || purity > z.best.purity) { z.best = PolyRun{z.run_i, len, purity, ch}; z.have = true; }
     };
-    const char *q = minus ? seq.p + (n - 1 - s0) : seq.p + s0;
+    // the window in stored coordinates: [s0, s0 + count) of a '+' read, [n - s0 - count, n - s0) of a '-' read (walked backwards)
+    const i64 lo = minus ? n - s0 - count : s0;
+    const char *win = seq_window(P, r, lo, lo + count, scratch);
+    const char *q = minus ? win + (count - 1) : win;
     const i64 step = minus ? -1 : 1;
     for (i64 t = 0; t < count; ++t, q += step) {
         const char c = *q;
@@ -465,7 +495,7 @@ inline char *put_s(char *p, const char *s) { while (*s) *p++ = *s++; return p; }
 
 // gaps: the tokens of read['gaps'] = sorted(set(...)) (:472), in `toks` (sorted, unique); empty when the read has no '1'
 void annotate_read(const Partition &P, const Read &r, const unsigned char *data, i64 S, const int *fp,
-                   std::vector<Tok> &toks, std::vector<std::pair<i64, i64>> &runs) {
+                   std::vector<Tok> &toks, std::vector<std::pair<i64, i64>> &runs, std::vector<char> &scratch) {
     toks.clear();
     runs.clear();
     for (i64 i = 0; i < S;) {
@@ -488,13 +518,13 @@ void annotate_read(const Partition &P, const Read &r, const unsigned char *data,
     if (!(0 <= q_ssc && q_ssc <= q_esc && q_esc <= length)) throw Fail{"soft-clip positions out of order (:389)"};
     auto tok = [&]() -> char * { toks.emplace_back(); return toks.back().s; };
     PolyRun b;
-    if (best_poly(r.seq, minus, 0, q_ssc, b)) {
+    if (best_poly(P, r, minus, 0, q_ssc, b, scratch)) {
         i64 gap = q_ssc - b.first - b.len;
         if (!(0 <= b.first && b.first < q_ssc && 0 <= gap && gap < q_ssc)) throw Fail{"start poly tail out of range (:405,:410)"};
         char *t = tok(); *t++ = 'S'; *t++ = b.ch; *t++ = '_'; t = put_i(t, b.len); *t++ = ':'; t = put_i(t, gap); *t = 0;
         t = tok(); t = put_s(t, "SSC:"); t = put_i(t, b.first); *t = 0;
     } else { char *t = tok(); t = put_s(t, "SSC:"); t = put_i(t, q_ssc); *t = 0; }
-    if (best_poly(r.seq, minus, q_esc, length, b)) {
+    if (best_poly(P, r, minus, q_esc, length, b, scratch)) {
         if (!(0 <= b.first && b.first < length - q_esc && length - q_esc - b.first > 0)) throw Fail{"end poly tail out of range (:435,:441,:450)"};
         char *t = tok(); *t++ = 'E'; *t++ = b.ch; *t++ = '_'; t = put_i(t, b.len); *t++ = ':'; t = put_i(t, b.first); *t = 0;
         t = tok(); t = put_s(t, "ESC:"); t = put_i(t, length - q_esc - b.first); *t = 0;
@@ -530,7 +560,7 @@ void annotate_read(const Partition &P, const Read &r, const unsigned char *data,
 // the read_reps grouping and the sequences packed two bits per base (bytes other than upper-case ACGT are kept in
 // an exception list, so the round trip is exact).  It is bound to its TSVs by their sizes and mtimes and is only an
 // accelerator: the TSVs stay the stage's contract (py/freddie_split.py:445-481 writes them, :121-185 reads them).
-const char FSC_MAGIC[8] = {'F', 'S', 'C', '2', 0, 0, 0, 0};
+const char FSC_MAGIC[8] = {'F', 'S', 'C', '3', 0, 0, 0, 0};     // ('2': the checksum was one FNV lane)
 
 struct FscHeader {
     char magic[8];
@@ -548,10 +578,23 @@ bool stat_file(const char *path, uint64_t &size, int64_t &mtime_ns) {
     return true;
 }
 
-uint64_t fsc_checksum(const unsigned char *p, size_t n, uint64_t h = 1469598103934665603ull) {   // FNV-1a over 8-byte words (sections are 8-aligned)
-    size_t w = n / 8;
-    for (size_t i = 0; i < w; ++i) { uint64_t v; memcpy(&v, p + i * 8, 8); h = (h ^ v) * 1099511628211ull; }
-    for (size_t i = w * 8; i < n; ++i) h = (h ^ p[i]) * 1099511628211ull;
+// FNV-1a over 8-byte words (sections are 8-aligned), in FOUR interleaved lanes (word i goes to lane i mod 4) that are folded at the
+// end: one lane is a chain of dependent multiplies -- 1.4 GB/s, as much as the rest of a side-car load -- four run side by side
+// (format "FSC3"; "FSC2" had one lane)
+uint64_t fsc_checksum(const unsigned char *p, size_t n, uint64_t h = 1469598103934665603ull) {
+    const uint64_t K = 1099511628211ull;
+    uint64_t a = h, b = h ^ 0x9e3779b97f4a7c15ull, c = h ^ 0xc2b2ae3d27d4eb4full, d = h ^ 0x165667b19e3779f9ull;
+    const size_t w = n / 8;
+    size_t i = 0;
+    for (; i + 4 <= w; i += 4) {
+        uint64_t v[4];
+        memcpy(v, p + i * 8, 32);
+        a = (a ^ v[0]) * K; b = (b ^ v[1]) * K; c = (c ^ v[2]) * K; d = (d ^ v[3]) * K;
+    }
+    for (; i < w; ++i) { uint64_t v; memcpy(&v, p + i * 8, 8); a = (a ^ v) * K; }
+    for (size_t j = w * 8; j < n; ++j) a = (a ^ p[j]) * K;
+    h = a;
+    h = (h ^ b) * K; h = (h ^ c) * K; h = (h ^ d) * K;
     return h;
 }
 
@@ -631,12 +674,14 @@ bool write_sidecar(const Partition &P, const char *split_path, const char *reads
     read_ex_off[n] = (int32_t)P.ts.size(); name_off[n] = (uint32_t)names.size(); seq_off[n] = bases;
     if (chr_differs) chr_off.push_back((uint32_t)read_chrs.size());
     std::vector<uint8_t> packed((size_t)((bases + 3) / 4), 0);
+    std::vector<char> unpacked;
     for (size_t i = 0; i < n; ++i) {
         const Str &q = P.reads[i].seq;
+        const char *qp = seq_window(P, P.reads[i], 0, (i64)q.n, unpacked);     // (a partition that itself came from a side-car)
         uint64_t g = seq_off[i];
         for (size_t t = 0; t < q.n; ++t, ++g) {
-            int c = base_code((unsigned char)q.p[t]);
-            if (c < 0) { exc_pos.push_back(g); exc_ch.push_back((uint8_t)q.p[t]); c = 0; }
+            int c = base_code((unsigned char)qp[t]);
+            if (c < 0) { exc_pos.push_back(g); exc_ch.push_back((uint8_t)qp[t]); c = 0; }
             packed[(size_t)(g >> 2)] |= (uint8_t)(c << ((g & 3) * 2));
         }
     }
@@ -670,8 +715,8 @@ bool write_sidecar(const Partition &P, const char *split_path, const char *reads
 // Returns true when the side-car exists, belongs to exactly these TSVs and is intact; P is then what
 // parse_partition() would have produced.  Any mismatch returns false (the caller parses the TSVs instead).
 bool load_sidecar(const char *sidecar_path, const char *split_path, const char *reads_path, Partition &P, bool verify) {
-    Mapping blob;                                          // unmapped when the function returns: everything is copied out
-    struct Closer { Mapping &m; ~Closer() { m.close(); } } closer{blob};
+    Mapping &blob = P.map_fsc;                             // stays mapped on success: names, contigs and the packed sequences are views into it
+    struct Closer { Mapping &m; bool keep = false; ~Closer() { if (!keep) m.close(); } } closer{blob};
     if (!blob.open(sidecar_path, nullptr, nullptr) || blob.n < sizeof(FscHeader)) return false;
     FscHeader h;
     memcpy(&h, blob.p, sizeof h);
@@ -721,32 +766,18 @@ bool load_sidecar(const char *sidecar_path, const char *split_path, const char *
     P.id = h.id; P.read_count = h.read_count;
     P.split_size = h.split_size; P.split_mtime_ns = h.split_mtime_ns; P.reads_size = h.reads_size; P.reads_mtime_ns = h.reads_mtime_ns;
     P.have_stat = true;
-    static const char LUT[4] = {'A', 'C', 'G', 'T'};
-    static char QUAD[256][4];
-    static std::once_flag quad_once;
-    std::call_once(quad_once, []() { for (int b = 0; b < 256; ++b) for (int k = 0; k < 4; ++k) QUAD[b][k] = LUT[(b >> (2 * k)) & 3]; });
-    // one arena for the strings of the partition: names | per-read contigs | sequences
-    P.arena.resize((size_t)h.name_bytes + read_chr_len + (size_t)h.seq_bases);
-    char *a_names = P.arena.data(), *a_chrs = a_names + h.name_bytes, *a_seq = a_chrs + read_chr_len;
-    if (h.name_bytes) memcpy(a_names, names, (size_t)h.name_bytes);
-    if (read_chr_len) memcpy(a_chrs, read_chrs, read_chr_len);
+    P.packed = packed; P.exc_pos = exc_pos; P.exc_ch = exc_ch; P.n_exc = (size_t)h.n_exc;
     P.reads.resize(n);
-    size_t e = 0;
     for (size_t i = 0; i < n; ++i) {
         Read &r = P.reads[i];
         r.id = read_id[i]; r.tint = h.id; r.strand = (char)strand[i]; r.ex0 = read_ex_off[i]; r.ex1 = read_ex_off[i + 1]; r.rep = read_rep[i];
-        r.name.p = a_names + name_off[i]; r.name.n = name_off[i + 1] - name_off[i];
-        if (h.read_chr_bytes) { r.chr.p = a_chrs + chr_off[i]; r.chr.n = chr_off[i + 1] - chr_off[i]; }
+        r.name.p = names + name_off[i]; r.name.n = name_off[i + 1] - name_off[i];
+        if (h.read_chr_bytes) { r.chr.p = read_chrs + chr_off[i]; r.chr.n = chr_off[i + 1] - chr_off[i]; }
         else { r.chr.p = P.chr.data(); r.chr.n = (uint32_t)P.chr.size(); }
-        const uint64_t g0 = seq_off[i], len = seq_off[i + 1] - g0;
-        char *dst = a_seq + g0;
-        r.seq.p = dst; r.seq.n = (uint32_t)len;
-        uint64_t t = 0;
-        for (; t < len && ((g0 + t) & 3); ++t) { uint64_t g = g0 + t; dst[t] = LUT[(packed[(size_t)(g >> 2)] >> ((g & 3) * 2)) & 3]; }
-        for (; t + 4 <= len; t += 4) memcpy(dst + t, QUAD[packed[(size_t)((g0 + t) >> 2)]], 4);      // one packed byte = 4 bases
-        for (; t < len; ++t) { uint64_t g = g0 + t; dst[t] = LUT[(packed[(size_t)(g >> 2)] >> ((g & 3) * 2)) & 3]; }
-        while (e < (size_t)h.n_exc && exc_pos[e] < g0 + len) { dst[exc_pos[e] - g0] = (char)exc_ch[e]; ++e; }
+        r.seq.p = nullptr; r.seq.n = (uint32_t)(seq_off[i + 1] - seq_off[i]); r.seq_g0 = seq_off[i];
     }
+    P.from_sidecar = true;
+    closer.keep = true;
     return true;
 }
 
@@ -860,6 +891,7 @@ int32_t fhost_sidecar_write(fhost_batch *b, const char *const *split_paths, cons
     parallel_for((int)b->parts.size(), n_threads, [&](int p) {
         std::string err;
         bool ok = false;
+        if (b->parts[(size_t)p].from_sidecar) return;        // loaded from this very side-car, which was found fresh: nothing to write
         try { ok = write_sidecar(b->parts[(size_t)p], split_paths[p], reads_paths[p], sidecar_paths[p], err); }
         catch (const std::exception &e) { err = std::string(sidecar_paths[p]) + ": " + e.what(); }
         catch (...) { err = std::string(sidecar_paths[p]) + ": internal error"; }
@@ -900,6 +932,7 @@ static int32_t write_impl(fhost_batch *b, const int64_t *part_final_off, const i
         static thread_local std::vector<char> out;
         static thread_local std::vector<Tok> toks;
         static thread_local std::vector<std::pair<i64, i64>> runs;
+        static thread_local std::vector<char> scratch;
         try {
             const Partition &P = b->parts[(size_t)p];
             const int *fp = final_pos + part_final_off[p];
@@ -934,7 +967,7 @@ static int32_t write_impl(fhost_batch *b, const int64_t *part_final_off, const i
                     for (; i < Sc; ++i, ++g) row[i] = (char)('0' + ((labels[g >> 2] >> ((g & 3) * 2)) & 3));
                 }
                 w += Sc;
-                annotate_read(P, r, reinterpret_cast<const unsigned char *>(row), S, fp, toks, runs);
+                annotate_read(P, r, reinterpret_cast<const unsigned char *>(row), S, fp, toks, runs, scratch);
                 {   // a read with many label runs has many gap tokens: make room before writing them
                     const size_t used = (size_t)(w - out.data()), rest_max = 8 + toks.size() * 48;
                     if (used + rest_max > out.size()) { out.resize((used + rest_max) * 2); w = out.data() + used; }
