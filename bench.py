@@ -335,6 +335,27 @@ def run_next_row(args):
     print(json.dumps(out))
 
 
+def next_rows_summary():
+    """Short runs of the N3 / N4 measurements (tools/cluster_bench.py, tools/isoforms_bench.py; no CPU legs): value, unit, kernel times and
+    the roofline fraction of each row's hot kernel."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    rows = {}
+    try:
+        import cluster_bench
+        import isoforms_bench
+        for name, fn in (("cluster-many", lambda: cluster_bench.run("many", steps=3)), ("cluster-big", lambda: cluster_bench.run("big", steps=2)),
+                         ("isoforms", lambda: isoforms_bench.run(steps=3))):
+            t0 = time.perf_counter()
+            r = fn()
+            rows[name] = {"metric": r.get("metric"), "value": r.get("value"), "unit": r.get("unit"), "config": r.get("config"),
+                          "call_wall_ms": r.get("call_wall_ms"), "kernel_ms": r.get("kernel_ms"),
+                          "roofline": {k: (r.get("roofline") or {}).get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac")},
+                          "leg_s": time.perf_counter() - t0}
+    except Exception as exc:                              # the headline must not depend on these
+        rows["error"] = "%s: %s" % (type(exc).__name__, exc)
+    return rows
+
+
 def committed_counters(workload, source_hash=None):
     """Counter figures that need their own rocprofv3 --pmc passes (profiles/traffic.json, written by profiles/make_traffic.py
     from the passes of tools/profile_round.sh): HBM bytes per launch and VALU utilisation of the scoring kernels.  They are
@@ -456,6 +477,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip both CPU-oracle legs")
     ap.add_argument("--no-e2e", action="store_true", help="skip the CLI end-to-end leg")
     ap.add_argument("--no-extras", action="store_true", help="skip config2's roofline, the replay and the HBM-resident legs")
+    ap.add_argument("--no-next-rows", action="store_true", help="skip the short runs of rows N3 / N4 (cluster-many, cluster-big, isoforms) in `next_rows`")
     ap.add_argument("--e2e-reads", type=int, default=2000000, help="reads of the end-to-end job (default: the whole 2 M-read job)")
     ap.add_argument("--contexts", type=int, default=8, help="contexts per GPU the steps alternate between (each on one stream while "
                     "the others have work in flight: two per hardware queue; 4: -20 %%, 16: -30 %%)")
@@ -882,6 +904,13 @@ def main():
             out["reference_cpu"]["ratios_use"] = "value_h2h (host memory -> host memory)"
         out["e2e"] = e2e
         out["e2e_sidecar"] = (e2e or {}).get("sidecar")
+        if not args.no_next_rows and not args.no_extras and args.gpus == 1:
+            # rows N3 / N4 of SURVEY 8(f), their own metrics, a few steps each on this GPU (the full runs: --workload cluster-many | cluster-big |
+            # isoforms): the line that is recorded carries them, not only profiles/
+            for ctx in ctxs:
+                ctx.close()
+            ctxs = []
+            out["next_rows"] = next_rows_summary()
         print(json.dumps(out))
     for ctx in ctxs:
         ctx.close()

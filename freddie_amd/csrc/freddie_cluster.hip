@@ -13,6 +13,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -31,6 +32,7 @@ constexpr int kMaxWords = 300;      // uint32 words per read row the LDS staging
 struct TintDesc {
     i64 row0, bits_off, adj_off;
     int n, n_seg, w, aw;            // rows, segments, uint32 words per read row, uint64 words per adjacency row
+    int in_lds, pad;                // the tint's pruning runs whole in one workgroup's LDS (k_prune_lds): the per-pass kernels skip its rows
 };
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
@@ -170,6 +172,7 @@ __global__ void __launch_bounds__(256) k_degree(i64 n_rows_total, const int *row
     const i64 wave_g = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((i64)gridDim.x * blockDim.x) >> 6;
     for (i64 r = wave_g; r < n_rows_total; r += n_waves) {
         const TintDesc d = tints[row_tint[r]];
+        if (d.in_lds) continue;
         const u64 *a = adj + d.adj_off + (r - d.row0) * d.aw;
         int c = 0;
         for (int w = lane; w < d.aw; w += 64) c += __popcll(a[w]);
@@ -193,11 +196,72 @@ __global__ void __launch_bounds__(256) k_deg1(int n_words_total, const int2 *wor
     for (i64 x = wave_g; x < n_words_total; x += n_waves) {
         const int2 wt = word_tint[x];                    // (tint, word index inside the tint)
         const TintDesc d = tints[wt.x];
+        if (d.in_lds) continue;
         const int col = wt.y * 64 + lane;
         const u64 m = __ballot(col < d.n && deg[d.row0 + col] == 1);
         if (lane == 0) deg1[x] = m;
     }
 }
+// The same pass, edge by edge (round 6; rows of at most kEdgeChunks x 64 words = 32 768 reads): only the columns c that ARE neighbours
+// of r need an answer, and "r and c share a neighbour" is "row r AND row c is not empty" (the matrix is symmetric).  A wave takes a row,
+// keeps it in registers (lane = word, kEdgeChunks words a lane), walks its set bits in order and for each neighbour c reads row c 64 words
+// at a time until a word of the AND is not zero -- in these graphs (reads of one gene: triangles everywhere) the first 512 bytes nearly
+// always answer, where the OR of all of N(r)'s rows (k_prune below) reads every row whole, once per 64-word chunk of the output:
+// 19 539 reads, mean degree 239: 8.7 -> ~2 ms a pass.  Removed bits are cleared in the lane that holds their word.
+constexpr int kEdgeChunks = 8;
+
+__global__ void __launch_bounds__(256) k_prune_edges(i64 n_rows_total, const int *row_tint, const TintDesc *tints, const u64 *old_adj, const int *deg,
+                                                     u64 *new_adj, int *changed /* per tint */, int *pass_any, const int *gate) {
+    if (gate && *gate == 0) return;
+    const int lane = lane_id();
+    const i64 wave_g = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((i64)gridDim.x * blockDim.x) >> 6;
+    for (i64 r = wave_g; r < n_rows_total; r += n_waves) {
+        const int t = row_tint[r];
+        const TintDesc d = tints[t];
+        if (d.in_lds) continue;
+        const u64 *A = old_adj + d.adj_off;
+        const i64 rl = r - d.row0;
+        const int aw = d.aw, n_chunks = (aw + 63) >> 6;
+        u64 mine[kEdgeChunks], keep[kEdgeChunks];
+#pragma unroll
+        for (int q = 0; q < kEdgeChunks; ++q) { const int z = q * 64 + lane; mine[q] = (q < n_chunks && z < aw) ? A[rl * aw + z] : 0ull; keep[q] = mine[q]; }
+        const int deg_r = deg[r];
+        bool any_change = false;
+        if (deg_r > 1) {                                       // (deg 1: the edge stays; deg 0: nothing to do)
+#pragma unroll
+            for (int q = 0; q < kEdgeChunks; ++q) {
+                if (q >= n_chunks) break;
+                u64 have = __ballot(mine[q] != 0ull);          // the lanes whose word of this chunk holds a neighbour
+                while (have) {
+                    const int L = __builtin_amdgcn_readfirstlane(__ffsll((long long)have) - 1);     // (wave-uniform: a scalar for readlane)
+                    have &= have - 1;
+                    u64 word = ((u64)(unsigned)__builtin_amdgcn_readlane((int)(mine[q] >> 32), L) << 32) | (u64)(unsigned)__builtin_amdgcn_readlane((int)mine[q], L);
+                    while (word) {
+                        const int b = __builtin_amdgcn_readfirstlane(__ffsll((long long)word) - 1);
+                        word &= word - 1;
+                        const i64 c = ((i64)q * 64 + L) * 64 + b;                   // the neighbour (wave-uniform)
+                        bool stays = deg[d.row0 + c] == 1;
+                        if (!stays) {
+                            const u64 *C = A + c * aw;
+#pragma unroll
+                            for (int q2 = 0; q2 < kEdgeChunks; ++q2) {
+                                if (q2 >= n_chunks) break;
+                                const int z = q2 * 64 + lane;
+                                const u64 cw = z < aw ? C[z] : 0ull;
+                                if (__ballot((cw & mine[q2]) != 0ull)) { stays = true; break; }
+                            }
+                        }
+                        if (!stays) { if (lane == L) keep[q] &= ~(1ull << b); any_change = true; }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < kEdgeChunks; ++q) { const int z = q * 64 + lane; if (q < n_chunks && z < aw) new_adj[d.adj_off + rl * aw + z] = keep[q]; }
+        if (any_change && lane == 0) { changed[t] = 1; *pass_any = 1; }
+    }
+}
+
 __global__ void __launch_bounds__(256) k_prune(i64 n_rows_total, const int *row_tint, const TintDesc *tints, const i64 *tint_word0,
                                                const u64 *old_adj, const int *deg, const u64 *deg1, u64 *new_adj,
                                                int *changed /* per tint */, int *pass_any, const int *gate) {
@@ -207,6 +271,7 @@ __global__ void __launch_bounds__(256) k_prune(i64 n_rows_total, const int *row_
     for (i64 r = wave_g; r < n_rows_total; r += n_waves) {
         const int t = row_tint[r];
         const TintDesc d = tints[t];
+        if (d.in_lds) continue;
         const u64 *A = old_adj + d.adj_off;
         const i64 rl = r - d.row0;
         const int deg_r = deg[r];
@@ -237,6 +302,77 @@ __global__ void __launch_bounds__(256) k_prune(i64 n_rows_total, const int *row_
     }
 }
 
+// ---- the whole pruning of a small tint by ONE workgroup, in LDS (round 6) ------------------------------------------
+// A tint whose bit matrix fits LDS twice (rows x words <= kPruneLdsWords: 500 reads are 32 KB a copy) is pruned to its fixed point
+// without leaving the workgroup: degrees, the "exactly one neighbour" column mask, one pass into the other copy, again until a pass
+// removes nothing (:240-255) -- no launch per pass, no flags to the host, no pass over tints that are already done.  The per-pass
+// kernels above are what tints too large for this use (and they skip the rows of the tints that are not theirs).
+// A thread owns (row r, word z) pairs: new = old & (deg r == 1 ? all : H(r)[z] | deg1[z]) with H(r) = OR of the rows of r's
+// neighbours; only the bits of old[r][z] that are not excused by deg1 need a common neighbour, and the walk over r's neighbours
+// ends as soon as they all have one (in these graphs -- reads of one gene -- after a handful of neighbours).
+constexpr int kPruneLdsWords = 7808;       // u64 words of one copy: 2 x 61 KB, two such workgroups share a CU's LDS with room for the rest
+
+__global__ void __launch_bounds__(256) k_prune_lds(const int *small_tints, const TintDesc *tints, u64 *adj0, u64 *adj1, int *rounds) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    __shared__ int s_changed;
+    const int t = small_tints[blockIdx.x];
+    const TintDesc d = tints[t];
+    const int n = d.n, aw = d.aw, nw = n * aw;
+    u64 *buf[2] = {reinterpret_cast<u64 *>(lds_raw), reinterpret_cast<u64 *>(lds_raw) + nw};
+    u64 *d1 = buf[1] + nw;
+    unsigned short *deg = reinterpret_cast<unsigned short *>(d1 + aw);
+    for (int x = threadIdx.x; x < nw; x += blockDim.x) buf[0][x] = adj0[d.adj_off + x];
+    __syncthreads();
+    int cur = 0, n_rounds = 0;
+    for (;;) {
+        const u64 *old = buf[cur];
+        u64 *nxt = buf[cur ^ 1];
+        for (int r = threadIdx.x; r < n; r += blockDim.x) {
+            int c = 0;
+            for (int z = 0; z < aw; ++z) c += __popcll(old[r * aw + z]);
+            deg[r] = (unsigned short)c;
+        }
+        if (threadIdx.x == 0) s_changed = 0;
+        __syncthreads();
+        for (int z = threadIdx.x; z < aw; z += blockDim.x) {
+            u64 m = 0;
+            for (int b = 0; b < 64; ++b) { const int col = z * 64 + b; if (col < n && deg[col] == 1) m |= 1ull << b; }
+            d1[z] = m;
+        }
+        __syncthreads();
+        bool ch = false;
+        for (int x = threadIdx.x; x < nw; x += blockDim.x) {
+            const int r = x / aw, z = x - r * aw;
+            const u64 oldw = old[x];
+            u64 neww = oldw;
+            if (oldw && deg[r] != 1) {
+                const u64 need = oldw & ~d1[z];                 // these bits stay only with a common neighbour
+                u64 acc = 0;
+                for (int wi = 0; wi < aw && (need & ~acc); ++wi) {
+                    u64 word = old[r * aw + wi];
+                    while (word && (need & ~acc)) {
+                        const int k = wi * 64 + __ffsll((long long)word) - 1;
+                        word &= word - 1;
+                        acc |= old[k * aw + z];
+                    }
+                }
+                neww = oldw & (acc | d1[z]);
+            }
+            nxt[x] = neww;
+            ch |= neww != oldw;
+        }
+        if (ch) s_changed = 1;
+        __syncthreads();
+        const int any = s_changed;
+        __syncthreads();                                        // (everybody has read the flag before the next pass clears it)
+        cur ^= 1;
+        if (!any) break;
+        ++n_rounds;
+    }
+    for (int x = threadIdx.x; x < nw; x += blockDim.x) { const u64 v = buf[cur][x]; adj0[d.adj_off + x] = v; adj1[d.adj_off + x] = v; }
+    if (threadIdx.x == 0) rounds[t] = n_rounds;
+}
+
 }  // namespace
 
 struct GrowBuf {              // device buffer that lives with the context and only ever grows
@@ -250,7 +386,7 @@ struct fclu_ctx {
     hipEvent_t ev[3] = {};
     std::string err;
     float compat_ms = 0.f, prune_ms = 0.f;
-    GrowBuf tints, tiles, row_tint, bits, first, last, tail, adj[2], deg, changed, word_tint, tint_word0, deg1, pass_any;
+    GrowBuf tints, tiles, row_tint, bits, first, last, tail, adj[2], deg, changed, word_tint, tint_word0, deg1, pass_any, small_tints, small_rounds;
     int *h_flags = nullptr;   // pinned: per-pass flags of a burst + per-tint flags
     size_t h_flags_cap = 0;
 };
@@ -311,6 +447,8 @@ int fclu_create(int device, fclu_ctx **out) {
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_compat<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 2 * kTile * (kRankWords | 1) * 6);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_prune_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     if (e != hipSuccess) {
         fail(nullptr, FCLU_ERR_HIP, "context creation failed: %s", hipGetErrorString(e));
         delete c;
@@ -326,7 +464,7 @@ void fclu_destroy(fclu_ctx *c) {
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     for (int i = 0; i < 3; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     GrowBuf *bufs[] = {&c->tints, &c->tiles, &c->row_tint, &c->bits, &c->first, &c->last, &c->tail, &c->adj[0], &c->adj[1], &c->deg,
-                       &c->changed, &c->word_tint, &c->tint_word0, &c->deg1, &c->pass_any};
+                       &c->changed, &c->word_tint, &c->tint_word0, &c->deg1, &c->pass_any, &c->small_tints, &c->small_rounds};
     for (GrowBuf *b : bufs) if (b->p) (void)hipFree(b->p);
     if (c->h_flags) (void)hipHostFree(c->h_flags);
     delete c;
@@ -346,7 +484,14 @@ int fclu_compat_graph(fclu_ctx *c, const fclu_batch *b, int32_t prune, uint64_t 
     std::vector<int> row_tint((size_t)R);
     std::vector<int2> word_tint;                         // every adjacency word column of every tint: (tint, word)
     std::vector<i64> tint_word0((size_t)T + 1, 0);
-    int max_w = 1;
+    std::vector<int> small_tints;                        // pruned whole in LDS (k_prune_lds); FCLU_PRUNE_LDS=0: none (tests)
+    const char *lds_env = getenv("FCLU_PRUNE_LDS");
+    const bool lds_ok = !(lds_env && lds_env[0] == '0');
+    const char *ldsw_env = getenv("FCLU_PRUNE_LDS_WORDS");                // (tests: a lower limit, so that small tints take both ways in one batch)
+    const i64 lds_words = (ldsw_env && atoll(ldsw_env) > 0 && atoll(ldsw_env) < kPruneLdsWords) ? atoll(ldsw_env) : kPruneLdsWords;
+    size_t small_lds = 0;
+    bool any_large = false;
+    int max_w = 1, max_aw_large = 0;
     for (int t = 0; t < T; ++t) {
         TintDesc &d = tints[(size_t)t];
         d.row0 = b->row_off[t];
@@ -356,6 +501,9 @@ int fclu_compat_graph(fclu_ctx *c, const fclu_batch *b, int32_t prune, uint64_t 
         d.w = (d.n_seg + 31) / 32; if (d.w < 1) d.w = 1;
         d.aw = (d.n + 63) / 64;
         d.bits_off = b->bits_off[t]; d.adj_off = b->adj_off[t];
+        d.in_lds = (prune && lds_ok && d.n > 0 && d.n <= 65535 && (i64)d.n * d.aw <= lds_words) ? 1 : 0; d.pad = 0;
+        if (d.in_lds) { small_tints.push_back(t); small_lds = std::max(small_lds, ((size_t)2 * d.n * d.aw + d.aw) * 8 + (size_t)d.n * 2 + 16); }
+        else if (d.n > 0) { any_large = true; max_aw_large = std::max(max_aw_large, d.aw); }
         if (b->bits_off[t + 1] - d.bits_off != (i64)d.n * d.w) return fail(c, FCLU_ERR_ARG, "tint %d: bits_off does not match rows x words", t);
         if (b->adj_off[t + 1] - d.adj_off != (i64)d.n * d.aw) return fail(c, FCLU_ERR_ARG, "tint %d: adj_off does not match rows x words", t);
         if (d.w > kMaxWords) return fail(c, FCLU_ERR_UNSUPPORTED, "tint %d has %d segments; this build stages at most %d", t, d.n_seg, kMaxWords * 32);
@@ -405,6 +553,8 @@ int fclu_compat_graph(fclu_ctx *c, const fclu_batch *b, int32_t prune, uint64_t 
     HIP_TRY(c, grow(d_tint_word0, tint_word0.size() * 8));
     HIP_TRY(c, grow(d_deg1, word_tint.size() * 8));
     HIP_TRY(c, grow(d_pass_any, (size_t)kBurst * 4));
+    HIP_TRY(c, grow(c->small_tints, small_tints.size() * 4 + 4));
+    HIP_TRY(c, grow(c->small_rounds, (size_t)T * 4));
     {
         const size_t need = ((size_t)kBurst * T + kBurst) * 4;
         if (need > c->h_flags_cap) {
@@ -439,10 +589,20 @@ int fclu_compat_graph(fclu_ctx *c, const fclu_batch *b, int32_t prune, uint64_t 
                            d_bits.as<unsigned>(), d_first.as<int>(), d_last.as<int>(), d_tail.as<unsigned char>(), d_adj[0].as<u64>());
     HIP_TRY(c, hipEventRecord(c->ev[1], s));
     int cur = 0;
-    if (prune) {
+    if (prune && !small_tints.empty()) {
+        // (the final matrix of such a tint goes into BOTH copies: whichever the per-pass kernels of the large tints end on holds it)
+        HIP_TRY(c, hipMemcpyAsync(c->small_tints.p, small_tints.data(), small_tints.size() * 4, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_prune_lds, dim3((unsigned)small_tints.size()), dim3(256), small_lds, s, c->small_tints.as<int>(), d_tints.as<TintDesc>(),
+                           d_adj[0].as<u64>(), d_adj[1].as<u64>(), c->small_rounds.as<int>());
+    }
+    if (prune && any_large) {
         // Passes are enqueued kBurst at a time; pass q of a burst is gated on pass q-1's "removed something" word, so the host
         // reads the flags once per burst instead of once per pass (the loop of :240-255 usually ends after two or three).
         const int deg_grid = (int)((R + 3) / 4 < 4096 ? (R + 3) / 4 : 4096);
+        // the pass edge by edge (k_prune_edges) when every tint of the per-pass kernels has rows of at most kEdgeChunks x 64 words;
+        // FCLU_PRUNE_EDGES=0: the OR-of-rows form whatever the shapes (tests)
+        const char *edge_env = getenv("FCLU_PRUNE_EDGES");
+        const bool edge_walk = max_aw_large <= kEdgeChunks * 64 && !(edge_env && edge_env[0] == '0');
         const int n_words = (int)word_tint.size();
         int *h_any = c->h_flags, *h_changed = c->h_flags + kBurst;
         bool done = false;
@@ -454,11 +614,17 @@ int fclu_compat_graph(fclu_ctx *c, const fclu_batch *b, int32_t prune, uint64_t 
                 const int from = cur ^ (q & 1), to = from ^ 1;
                 hipLaunchKernelGGL(k_degree, dim3(deg_grid), dim3(256), 0, s, R, d_row_tint.as<int>(), d_tints.as<TintDesc>(),
                                    d_adj[from].as<u64>(), d_deg.as<int>(), gate);
+                if (edge_walk)
+                    hipLaunchKernelGGL(k_prune_edges, dim3((int)((R + 3) / 4 < 16384 ? (R + 3) / 4 : 16384)), dim3(256), 0, s, R, d_row_tint.as<int>(),
+                                       d_tints.as<TintDesc>(), d_adj[from].as<u64>(), d_deg.as<int>(), d_adj[to].as<u64>(),
+                                       d_changed.as<int>() + (size_t)q * T, d_pass_any.as<int>() + q, gate);
+                else {
                 hipLaunchKernelGGL(k_deg1, dim3((n_words + 3) / 4 < 4096 ? (n_words + 3) / 4 : 4096), dim3(256), 0, s, n_words,
                                    d_word_tint.as<int2>(), d_tints.as<TintDesc>(), d_deg.as<int>(), d_deg1.as<u64>(), gate);
                 hipLaunchKernelGGL(k_prune, dim3((int)((R + 3) / 4 < 16384 ? (R + 3) / 4 : 16384)), dim3(256), 0, s, R, d_row_tint.as<int>(),
                                    d_tints.as<TintDesc>(), d_tint_word0.as<i64>(), d_adj[from].as<u64>(), d_deg.as<int>(),
                                    d_deg1.as<u64>(), d_adj[to].as<u64>(), d_changed.as<int>() + (size_t)q * T, d_pass_any.as<int>() + q, gate);
+                }
             }
             HIP_TRY(c, hipMemcpyAsync(h_any, d_pass_any.p, (size_t)kBurst * 4, hipMemcpyDeviceToHost, s));
             HIP_TRY(c, hipMemcpyAsync(h_changed, d_changed.p, (size_t)kBurst * T * 4, hipMemcpyDeviceToHost, s));
@@ -473,7 +639,13 @@ int fclu_compat_graph(fclu_ctx *c, const fclu_batch *b, int32_t prune, uint64_t 
     }
     HIP_TRY(c, hipEventRecord(c->ev[2], s));
     HIP_TRY(c, hipMemcpyAsync(adj_out, d_adj[cur].p, (size_t)n_adj * 8, hipMemcpyDeviceToHost, s));
+    std::vector<int> small_rounds;
+    if (prune && rounds_out && !small_tints.empty()) {
+        small_rounds.resize((size_t)T);
+        HIP_TRY(c, hipMemcpyAsync(small_rounds.data(), c->small_rounds.p, (size_t)T * 4, hipMemcpyDeviceToHost, s));
+    }
     HIP_TRY(c, hipStreamSynchronize(s));
+    if (!small_rounds.empty()) for (int t : small_tints) rounds_out[t] = small_rounds[(size_t)t];
     HIP_TRY(c, hipGetLastError());
     (void)hipEventElapsedTime(&c->compat_ms, c->ev[0], c->ev[1]);
     (void)hipEventElapsedTime(&c->prune_ms, c->ev[1], c->ev[2]);

@@ -154,9 +154,7 @@ struct fseg_ctx {
     DevBuf d_dpx;
     i64 dpx_base[3] = {0, 0, 0}, dpx_stride[3] = {0, 0, 0}, dpx_n[3] = {0, 0, 0};
     int dpx_nm = 0, dpx_cnt[3] = {1, 1, 1};
-    bool split_always = true;   // FSEG_SPLIT_ALWAYS=0: the split path only where a context has the device to itself (round 5: also on one stream, eight
-                                // contexts over resident batches do 528 against 519 M reads/s with it, three pairs of runs in one call)
-    i64 wide_one_max = 256;     // FSEG_WIDE_ONE_MAX: plan 'W' takes a batch's wide problems in one launch when there are at most this many (0: never)
+    static constexpr i64 kWideOneMax = 256;   // plan 'W' takes a batch's wide problems in one launch when there are at most this many
     int split_dp = 7;           // FSEG_SPLIT_DP: bit 0 / 1 / 2 = the small / mid / large class hands its DPs to k_dpw (0: the DP stays the tail of k_solve's workgroups)
     i64 prob_cap = 0, work_cap = 0, pair_cap = 0, tri_cap = 0, label_cap = 0, chunk_cap = 0, cov_cap = 0;
     DevBuf d_status, d_prep, d_tacc;
@@ -174,7 +172,6 @@ struct fseg_ctx {
     unsigned sync_timeouts = 0;  // runs of this context that a waiter gave up on (each was redone with events); FSEG_TAP_SYNC[6]
     unsigned forked_runs = 0;    // runs of this context that owned the device (side streams in use); FSEG_TAP_SYNC[7]
     bool run_events_only = false;   // this run: no device-side waiters (it is the rerun after a timeout)
-    bool emit_signal = true;     // FSEG_EMIT_SIGNAL=0: only the first launch behind k_prob_emit tells the side streams' waiters, not k_prob_emit's last workgroup (see emit_done)
     bool dev_sync = true;        // FSEG_DEV_SYNC=0: the stage's side streams are forked and joined with events only (also after a waiter timed out)
     Status *h_status = nullptr;   // pinned
     PrepStatus *h_prep = nullptr; // pinned
@@ -207,16 +204,14 @@ struct fseg_ctx {
     // forks is replayed as plain launches: launching a graph with cross-stream edges costs the host 0.5-0.6 ms (ROCm 7.2,
     // the 250 k-read batch: 0.51 ms against 0.17 ms for the ~60 plain launches and 0.03 ms for the one-stream graph), more than
     // the GPU needs for the stages before the scoring stage -- the side streams' packets arrive late and the replay takes
-    // 1.13 ms instead of 0.71 (tools/replay_probe.py --profiling 0; FSEG_GRAPH_FORK=1 brings the forked graph back).
-    bool graph_fork = false;
+    // 1.13 ms instead of 0.71 (profiles/r04_replay_modes.txt; the forked graph was a switch, FSEG_GRAPH_FORK, until round 6).
     bool run_plain = false;     // this run: plain launches (set by fseg_run)
     bool run_linear = false;    // this run: one stream whatever else holds (a graph is being captured)
     bool use_sized = true;      // the first run of a batch stops twice to size its arenas exactly (FSEG_NO_SIZED=1: guess, and re-run on overflow)
-    i64 prob_self_max = 4 * kProbBlock;   // candidates up to which it does (FSEG_PROB_SELF_MAX)
+    static constexpr i64 kProbSelfMax = 4 * kProbBlock;   // candidates up to which it does
     bool prob_self_scan = false; // k_prob_emit adds up the candidate blocks itself (few candidates)
     i64 scan_single_max = 512;  // scan blocks up to which the compactions use the single-pass look-back scan (FSEG_SCAN_SINGLE_MAX)
     bool force_scan_stall = false;   // FSEG_FORCE_SCAN_STALL=1 (tests): the first look-back run reports a stall
-    bool force_wide_dp = false;      // FSEG_FORCE_WIDE_DP=1 (tests): 32-bit DP counts whatever the problems need
     hipGraph_t graph[2] = {nullptr, nullptr};            // [0] whole pipeline, or before / after scoring when profiling
     hipGraphExec_t graph_exec[2] = {nullptr, nullptr};
     bool profile_plain = false;   // fseg_set_profiling(3)
@@ -234,7 +229,6 @@ struct fseg_ctx {
     hipStream_t side[kSide] = {};
     hipEvent_t fj[kForkEvents] = {};
     bool use_fork = true;
-    bool use_tiny = true;       // FSEG_NO_TINY=1: no problem goes to k_tiny
     bool force_key64 = false;
     bool wide_by_seen = false;  // FSEG_WIDE_BY_SEEN=1 (tests)
     char score_plan[32] = "gM|W|hB|gST";   // FSEG_SCORE_PLAN (see enqueue_run; anything that does not name each class once = one stream)
@@ -258,10 +252,8 @@ struct fseg_ctx {
     i64 n_wide[3] = {0, 0, 0};  // of n_solve: problems that need the 16-bit-counter instances
     i64 max_ln = 0;             // reads the widest problem of the batch sees
     i64 tiny_from = 256;        // problems above which k_tiny is used (FSEG_TINY_FROM; tests force 0)
-    bool range_sums = true;     // FSEG_RANGE_SUMS=0: the problem scan's block sums by k_prob_scan1 instead of k_prob_range
     bool trace = false;         // FSEG_TRACE=1: phase timers of upload / run on stderr
     bool force_global_sort = false;   // FSEG_GLOBAL_SORT=1 (tests): the batch-wide radix sort whatever the partition sizes
-    bool debug_recopy = false;  // FSEG_DEBUG_RECOPY=1 (probes): fseg_results copies again on every call
 };
 
 namespace {
@@ -495,16 +487,14 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
         // W: the problems of every class that see more than kFuseLanes reads -- a handful per batch, most of which keep fewer
         // and are only looked at -- in ONE launch of the large class's 16-bit instance, a workgroup each (as a launch per
         // class on the tiny class's stream they held it back 46-60 us on config3 / config5: tools/run_gaps.py); batches
-        // with many such problems keep the per-class instances (b, m, s in a row)
+        // with many such problems keep the per-class instances (in a row on W's stream)
         ps.n_wide_all = c->n_wide[0] + c->n_wide[1] + c->n_wide[2];
-        ps.wide_one = c->wide_one_max > 0 && ps.n_wide_all <= c->wide_one_max && strchr(plan, 'W') != nullptr;
+        ps.wide_one = ps.n_wide_all <= fseg_ctx::kWideOneMax && strchr(plan, 'W') != nullptr;
         for (const char *p = plan; *p; ++p) {
             if (*p == '|') { ++ps.n_seg; continue; }
             if (ps.n_seg > 4) continue;
-            static const char wide_kinds[] = "bms";
-            const char *at = strchr(wide_kinds, *p);
             if (*p == 'W') { if (c->wide_solve && ps.n_wide_all > 0) ps.used[ps.n_seg - 1] = true; }
-            else if (!at || (c->wide_solve && c->n_wide[2 - (int)(at - wide_kinds)] > 0)) ps.used[ps.n_seg - 1] = true;
+            else ps.used[ps.n_seg - 1] = true;
         }
         if (ps.n_seg > 4) ps.n_seg = 4;
         // (the segments that have something to launch take the side streams in order: the first ones start first)
@@ -634,8 +624,8 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
                        c->d_thr.as<double>(), c->P.max_problem_size, c->d_fixed0.as<unsigned char>(),
                        c->d_added.as<unsigned char>(), c->d_fixed.as<unsigned char>(), c->d_chosen.as<unsigned char>(),
                        c->d_cand_pn.as<int>(), c->d_seg_iv.as<int>(), st);
-    // (with the block sums of the problem scan when the scan is a launch of its own: k_prob_scan1 is the rescan's only; FSEG_RANGE_SUMS=0: tests)
-    i64 *range_bs = c->range_sums ? prob_bs : nullptr;
+    // (with the block sums of the problem scan when the scan is a launch of its own: k_prob_scan1 is the rescan's only)
+    i64 *range_bs = prob_bs;
     hipLaunchKernelGGL(k_prob_range, dim3(pg), dim3(kRangeThreads), 0, s, st, c->d_cand_pn.as<int>(),
                        c->d_seg_iv.as<int>(), c->d_cand_y.as<int>(), c->d_iv_part.as<int>(), c->d_iv_start.as<int>(),
                        c->d_part_lane_off.as<i64>(), c->d_lane_start.as<int>(), c->d_lane_pmax.as<int>(),
@@ -658,7 +648,7 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
                        c->work_cap, c->d_dp_items.as<int>(), c->d_prob_desc.as<ProbDesc>(), c->d_iv_start.as<int>(),
                        c->d_iv_part.as<int>(), c->d_part_lane_off.as<i64>(), split, c->d_solve_items.as<int>(), c->d_solve_desc.as<ProbDesc>(),
                        c->d_wide_items.as<int>(), c->d_wide_all.as<int>(), c->d_cand_wide.as<unsigned char>(),
-                       (dev_sync && c->emit_signal) ? sw : (SyncWords *)nullptr, sync_gen);
+                       dev_sync ? sw : (SyncWords *)nullptr, sync_gen);
     // S5.  The arena path's window coverage (and pair thresholds) are launches of their own in front of k_score: they are
     // interval scoring (get_cumulative_coverage :188-246 -- the solve-list kernels do the same inside their workgroups), so
     // where the stages are bracketed by events the scoring stage's bracket opens here
@@ -739,7 +729,7 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
         auto split_ok = [&](int cls, int cnt_bytes) {
             // (k_dpw takes the problem its workgroup index names -- no grid stride --, so a list longer than the grid cap of the
             // two launches keeps the DP as k_solve's tail)
-            return known && (forking || c->split_always) && cls >= 0 && cls < 3 && ((c->split_dp >> cls) & 1) && c->dpx_n[cls] > 0 && c->n_solve[cls] <= c->dpx_n[cls] && c->dpx_nm == c->nm_big &&
+            return known && cls >= 0 && cls < 3 && ((c->split_dp >> cls) & 1) && c->dpx_n[cls] > 0 && c->n_solve[cls] <= c->dpx_n[cls] && c->dpx_nm == c->nm_big &&
                    c->n_solve[cls] <= kSplitGridCap && cnt_bytes <= c->dpx_cnt[cls] && c->d_dpx.p != nullptr;
         };
 #define FSEG_LAUNCH_SOLVE(Q, NMV, CNT, VT, CLS, N_ITEMS, MAXWG)                                                              \
@@ -824,58 +814,43 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
                     } else (void)fork(side_of[k]);
                 }
                 int seg = 0;
-                hipEvent_t ev_big = nullptr;
-                // b m s: the class's instance with 16-bit counters on its own (B M S then launch the 8-bit one only)
-                const bool pw = strchr(plan, 'W') != nullptr;
-                const int wb = (pw || strchr(plan, 'b')) ? 1 : 3, wm = (pw || strchr(plan, 'm')) ? 1 : 3, ws = (pw || strchr(plan, 's')) ? 1 : 3;
+                // (a plan with W: B M S launch their 8-bit instances only; without: both instances, one after the other)
+                const int wb = strchr(plan, 'W') ? 1 : 3, wm = wb, ws = wb;
                 // the large class's workgroups a start gate waits for: the 8-bit instance's and the 16-bit instance's (one per wide
                 // problem) -- the latter need 90 KB of LDS each and find no room once the other classes are in
                 const i64 wide_wgs = wide_one ? (c->wide_solve ? n_wide_all : 0) : (FSEG_WIDE_NEEDED(2) ? c->n_wide[2] : 0);
                 const i64 big_wgs = c->n_solve[2] + wide_wgs;
                 // Three passes over the plan: the large class's launches that open their stream go out FIRST -- the 16-bit instance
-                // (b), then the 8-bit one (B, behind `h` = a gate on b's workgroups having started) --, everything else follows in
+                // (W), then the 8-bit one (B, behind `h` = a gate on W's workgroups having started) --, everything else follows in
                 // plan order (a stream's own order is kept).  Why: a workgroup of the 16-bit instance holds up to 120 KB of LDS (n
                 // <= 60: planes 28 + coverage 16 + 16-bit counters 68 KB) and fits no CU that has one of the 8-bit instance's
                 // (81 KB); enqueued behind it, config3's one real wide problem was placed 135-150 us into the stage, when the 8-bit
                 // instance and the classes behind the gate had drained, and the stage took 0.29 ms (tools/stage_timeline.py).  A
                 // class has a handful of wide problems: placed first they take a few CUs and the 8-bit instance the rest.
-                bool signalled = false;
-                for (int pass = 0; pass < 3; ++pass) {                       // 0: b   1: h, B   2: the rest
+                for (int pass = 0; pass < 3; ++pass) {                       // 0: W   1: h, B   2: the rest
                 seg = 0;
                 bool opens = true;
                 for (const char *p = plan; *p && seg < n_seg; ++p) {
                     if (*p == '|') { ++seg; opens = true; continue; }
-                    const int when = !opens ? 2 : ((*p == 'b' || *p == 'W') ? 0 : ((*p == 'B' || *p == 'h') ? 1 : 2));
+                    const int when = !opens ? 2 : (*p == 'W' ? 0 : ((*p == 'B' || *p == 'h') ? 1 : 2));
                     if (*p != 'h') opens = false;
                     if (!used[seg] || when != pass) continue;
                     hipStream_t q = seg == 0 ? s : c->side[side_of[seg]];
-                    // the first launch behind k_prob_emit on the main stream tells the side streams' waiters that the problem list
-                    // is complete: the plan's own gate when that is what comes first, else a k_signal
-                    unsigned *sig_word = nullptr;
-                    if (dev_sync && seg == 0 && !signalled) {
-                        signalled = true;
-                        if (*p == 'g' || (*p == 'h' && wide_wgs > 0)) sig_word = &sw->emit_gen;
-                        else hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, s, &sw->emit_gen, sync_gen);
-                    }
+                    // (the side streams' waiters are released by k_prob_emit's last workgroup: emit_done)
 #ifdef FSEG_ABLATE_STAGE
                     // diagnostic build (wrong results, honest timing): FSEG_ABLATE = bit mask of what the stage leaves out --
                     // 1 the DP launches (k_dpw), 2 the large class, 4 the gates, 8 the mid class, 16 the small class, 32 the tiny class
                     {
                         static const int abl = getenv("FSEG_ABLATE") ? atoi(getenv("FSEG_ABLATE")) : 0;
                         g_ablate_dp = (abl & 1) != 0;
-                        if (((abl & 2) && (*p == 'B' || *p == 'W' || *p == 'b')) || ((abl & 4) && (*p == 'g' || *p == 'h')) || ((abl & 8) && (*p == 'M' || *p == 'm')) ||
-                            ((abl & 16) && (*p == 'S' || *p == 's')) || ((abl & 32) && *p == 'T')) {
-                            if (sig_word) hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, s, &sw->emit_gen, sync_gen);
-                            continue;
-                        }
+                        if (((abl & 2) && (*p == 'B' || *p == 'W')) || ((abl & 4) && (*p == 'g' || *p == 'h')) || ((abl & 8) && *p == 'M') ||
+                            ((abl & 16) && *p == 'S') || ((abl & 32) && *p == 'T')) continue;
                     }
 #endif
                     switch (*p) {
-                    case 'B': FSEG_LAUNCH_SOLVE_X(q, kNMax, 2, c->n_solve[2], 512, wb);
-                              ev_big = fj_event(); if (hipEventRecord(ev_big, q) != hipSuccess) fj_err = hipErrorUnknown; break;
+                    case 'B': FSEG_LAUNCH_SOLVE_X(q, kNMax, 2, c->n_solve[2], 512, wb); break;
                     case 'M': if (c->n_solve[1] > 0) FSEG_LAUNCH_SOLVE_X(q, kClsMid, 1, c->n_solve[1], FSEG_WG_MID, wm); break;
                     case 'S': if (c->n_solve[0] > 0) FSEG_LAUNCH_SOLVE_X(q, kClsSmall, 0, c->n_solve[0], FSEG_WG_SMALL, ws); break;
-                    case 'b': FSEG_LAUNCH_SOLVE_X(q, kNMax, 2, c->n_solve[2], 512, 2); break;
                     case 'W':
                         if (!c->wide_solve || n_wide_all == 0) break;
                         if (wide_one) {                          // (the DP stays the workgroup's tail: nothing to hand over, no second placement)
@@ -886,21 +861,17 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
                             if (c->n_solve[0] > 0) FSEG_LAUNCH_SOLVE_X(q, kClsSmall, 0, c->n_solve[0], FSEG_WG_SMALL, 2);
                         }
                         break;
-                    case 'm': if (c->n_solve[1] > 0) FSEG_LAUNCH_SOLVE_X(q, kClsMid, 1, c->n_solve[1], FSEG_WG_MID, 2); break;
-                    case 's': if (c->n_solve[0] > 0) FSEG_LAUNCH_SOLVE_X(q, kClsSmall, 0, c->n_solve[0], FSEG_WG_SMALL, 2); break;
                     case 'T': if (c->n_tiny > 0) FSEG_LAUNCH_WAVE(q, kTiny, 3, c->n_tiny); break;
-                    case 'g': hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, q, st, 0, (unsigned)(big_wgs < 512 ? big_wgs : 512), 3000u, sig_word, sync_gen); break;
+                    case 'g': hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, q, st, 0, (unsigned)(big_wgs < 512 ? big_wgs : 512), 3000u); break;
                     case 'h': if (wide_wgs > 0)       // the 16-bit instance's workgroups (up to 120 KB of LDS each) take their CUs first
-                                  hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, q, st, 2, (unsigned)(wide_wgs < 256 ? wide_wgs : 256), 1500u, sig_word, sync_gen);
+                                  hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, q, st, 2, (unsigned)(wide_wgs < 256 ? wide_wgs : 256), 1500u);
                               break;
-                    case 'e': if (ev_big && hipStreamWaitEvent(q, ev_big, 0) != hipSuccess) fj_err = hipErrorUnknown; break;
                     default: break;
                     }
                 }
                 }
                 // join: a side chain with a device-side fork ends with k_signal and the main stream waits for the words (one wave in
                 // front of k_segments) instead of two marker + barrier packets per side stream
-                if (dev_sync && !signalled) hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, s, &sw->emit_gen, sync_gen);    // (a plan with nothing on the main stream)
                 unsigned dev_mask = 0;
                 for (int k = 1; k < n_seg; ++k) if (used[k]) {
                     if (dev_side(k)) { hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, c->side[side_of[k]], &sw->side_gen[side_of[k]], sync_gen); dev_mask |= 1u << side_of[k]; }
@@ -1135,7 +1106,7 @@ void adapt_to(fseg_ctx *c, const Status &s) {
     const bool old_small = c->small_batch, old_self = c->prob_self_scan, old_tiny = c->tiny_on;
     const int old_nm = c->nm_big;
     c->small_batch = (i64)s.n_prob <= 256 && (i64)s.n_work <= 1024;
-    c->tiny_on = (i64)s.n_prob > c->tiny_from && c->use_tiny;   // depends on the problem count only, which k_tiny does not change
+    c->tiny_on = (i64)s.n_prob > c->tiny_from;                  // depends on the problem count only, which k_tiny does not change
     const bool old_fuse = c->fuse_on;
     c->fuse_on = (i64)s.max_ln <= c->fuse_lanes;                 // (the widest problem does not depend on the split either)
     c->wide_solve = (i64)s.max_ln > kFuseLanes;                  // some problem needs the 16-bit counters
@@ -1144,7 +1115,7 @@ void adapt_to(fseg_ctx *c, const Status &s) {
     // an unsized first run of a batch with more than tiny_from problems turns k_tiny's share on for the replay, whose list bounds then
     // came from the run without it: kErrOverflowNm on every attempt, "arena sizing did not converge"; found in round 5)
     if (old_fuse != c->fuse_on || old_tiny != c->tiny_on) { c->counts_known = false; drop_graph(c); }
-    c->prob_self_scan = (i64)s.n_cand <= c->prob_self_max;
+    c->prob_self_scan = (i64)s.n_cand <= fseg_ctx::kProbSelfMax;
     {   // the big-problem LDS carve-up: the largest problem (+ headroom, multiple of 4)
         int want = (int)s.max_n + 3;
         want = (want + 3) & ~3;
@@ -1302,7 +1273,7 @@ int run_sized(fseg_ctx *c) {
         if (s.err & kErrScanStall) { c->scan_single_max = 0; c->force_scan_stall = false; continue; }     // redo with the three-pass scan
         {   // k_tiny's share of the problems was decided from the previous batch: if this batch decides otherwise, the
             // arena sizes change with it -- redo the (cheap) problem scan under the right setting
-            const bool tiny = (i64)s.n_prob > c->tiny_from && c->use_tiny;
+            const bool tiny = (i64)s.n_prob > c->tiny_from;
             const bool fuse = (i64)s.max_ln <= c->fuse_lanes;
             if (tiny != c->tiny_on || fuse != c->fuse_on) {
                 if (c->trace) fprintf(stderr, "[fseg] problem split changed (tiny %d -> %d, fused %d -> %d; %llu problems, widest sees %u reads): rescan\n",
@@ -1337,7 +1308,7 @@ int run_sized(fseg_ctx *c) {
         atleast(c->tri_cap, (i64)s.tri_used); atleast(c->cov_cap, (i64)s.cov_used);
         c->have_huge = s.dp_cls[2] > 0;
         TRY(prepare_giant(c, (int)s.max_n));
-        c->dp_wide_counts = c->force_wide_dp || (i64)s.max_ln >= 65536;
+        c->dp_wide_counts = (i64)s.max_ln >= 65536;
         note_counts(c, s);
         adapt_to(c, s);
         TRY(alloc_arenas(c));
@@ -1470,21 +1441,16 @@ int fseg_create(int device, fseg_ctx **out) {
     c->d_status.cap = sizeof(Status); c->d_prep.cap = sizeof(PrepStatus); c->d_tacc.cap = kTaccBytes; c->d_sync.cap = sizeof(SyncWords);
     auto flag = [](const char *name) { const char *v = getenv(name); return v && v[0] == '1'; };
     { const char *v = getenv("FSEG_DEV_SYNC"); if (v && v[0] == '0') c->dev_sync = false; }
-    { const char *v = getenv("FSEG_EMIT_SIGNAL"); if (v && v[0] == '0') c->emit_signal = false; }
     if (flag("FSEG_LABEL_BYTES")) c->label_packed_ok = false;
     { const char *v = getenv("FSEG_THR_PART"); if (v && (v[0] == '0' || v[0] == '1')) c->thr_part = v[0] - '0'; }
     { const char *v = getenv("FSEG_SYNC_TICKS"); if (v && v[0] && atoll(v) > 0) c->sync_ticks = (unsigned)atoll(v); }
     if (flag("FSEG_NO_GRAPH")) c->use_graph = false;
-    if (flag("FSEG_GRAPH_FORK")) c->graph_fork = true;
     if (flag("FSEG_NO_FORK")) c->use_fork = false;
-    if (flag("FSEG_NO_TINY")) c->use_tiny = false;
     if (flag("FSEG_NO_FUSE")) c->use_fuse = false;
     if (flag("FSEG_NO_WAVE")) c->use_wave = false;
     if (flag("FSEG_FORCE_KEY64")) c->force_key64 = true;
     if (flag("FSEG_WIDE_BY_SEEN")) c->wide_by_seen = true;
     if (const char *e = getenv("FSEG_SPLIT_DP")) c->split_dp = atoi(e) & 7;
-    if (const char *e = getenv("FSEG_SPLIT_ALWAYS")) c->split_always = e[0] != '0';
-    if (const char *e = getenv("FSEG_WIDE_ONE_MAX")) c->wide_one_max = atoll(e) < 0 ? 0 : atoll(e);
     if (const char *e = getenv("FSEG_SCORE_PLAN")) snprintf(c->score_plan, sizeof c->score_plan, "%s", e);
     {
         int seen[4] = {0, 0, 0, 0};
@@ -1497,14 +1463,10 @@ int fseg_create(int device, fseg_ctx **out) {
     { const char *v = getenv("FSEG_FUSE_LANES"); if (v && v[0] && atoi(v) > 0 && atoi(v) <= kFuseLanesWide) c->fuse_lanes = atoi(v); }
     if (flag("FSEG_NO_SIZED")) c->use_sized = false;
     if (flag("FSEG_TRACE")) c->trace = true;
-    if (const char *e = getenv("FSEG_RANGE_SUMS")) c->range_sums = e[0] != '0';
-    if (flag("FSEG_DEBUG_RECOPY")) c->debug_recopy = true;
     if (flag("FSEG_GLOBAL_SORT")) c->force_global_sort = true;
     if (flag("FSEG_FORCE_SCAN_STALL")) c->force_scan_stall = true;
-    if (flag("FSEG_FORCE_WIDE_DP")) { c->force_wide_dp = true; c->dp_wide_counts = true; }
     { const char *tf = getenv("FSEG_TINY_FROM"); if (tf && tf[0]) c->tiny_from = atoll(tf); }
     { const char *sm = getenv("FSEG_SCAN_SINGLE_MAX"); if (sm && sm[0]) c->scan_single_max = atoll(sm); }
-    { const char *sm = getenv("FSEG_PROB_SELF_MAX"); if (sm && sm[0]) c->prob_self_max = atoll(sm); }
     *out = c;
     return FSEG_OK;
 }
@@ -1888,9 +1850,9 @@ static int run_impl(fseg_ctx *c) {
         if (before[0] != c->d_labels.p || before[1] != c->d_packed.p) drop_graph(c);
     }
     c->last_sized = false;
-    c->run_plain = !c->use_graph || c->profile_plain || (would_fork(c) && !c->graph_fork);
+    c->run_plain = !c->use_graph || c->profile_plain || would_fork(c);
     if (!c->run_plain) {
-        c->run_linear = !c->graph_fork;
+        c->run_linear = true;
         struct Unset { fseg_ctx *c; ~Unset() { c->run_linear = false; } } unset{c};
         if (c->n_graphs == 0) {
             const int want = c->profiling ? 2 : 1;
@@ -2042,7 +2004,7 @@ static int results_impl(fseg_ctx *c, const int64_t **part_final_off, const int32
     HIP_TRY(c, hipSetDevice(c->device));
     if (!c->pending && !c->ran) return fail(c, FSEG_ERR_ARG, "no completed run");
     hipStream_t s = c->stream;
-    if (!c->fetched || c->debug_recopy || c->fetched_packed != (packed ? 1 : 0)) {
+    if (!c->fetched || c->fetched_packed != (packed ? 1 : 0)) {
         // a sized run knows its result sizes before its last kernels have finished: the copies queue up right behind them
         if (!(c->pending && c->last_sized)) TRY(fseg_sync(c));
         if (!c->pending && !c->ran) return fail(c, FSEG_ERR_ARG, "no completed run");

@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(256, WaveCfg<NM>::kOcc) k_wave(Status *st, con
                                                                  int support, unsigned char *chosen, i64 lb_h, i64 ln_h FSEG_TPARAM);
 
 // seg_score_fused.hip
-__global__ void __launch_bounds__(64) k_gate(Status *st, int which, unsigned grid, unsigned max_ticks, unsigned *signal_word, unsigned signal_gen);
+__global__ void __launch_bounds__(64) k_gate(Status *st, int which, unsigned grid, unsigned max_ticks);
 
 // seg_score_fused.hip
 __global__ void __launch_bounds__(64) k_wait_word(Status *st, const unsigned *words, unsigned mask, unsigned gen, unsigned max_ticks);

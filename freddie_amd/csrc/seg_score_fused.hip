@@ -371,10 +371,7 @@ __global__ void __launch_bounds__(256, WaveCfg<NM>::kOcc) k_wave(Status *st, con
 // large class running alone on a mostly empty chip.  k_gate is what the side stream runs first: one wave that waits until the
 // large class's workgroups have all started (they all fit the chip at once) or `max_ticks` of the 100 MHz clock have passed --
 // an exit every launch reaches -- so the small classes fill the space the large one leaves instead of taking it first.
-__global__ void __launch_bounds__(64) k_gate(Status *st, int which, unsigned grid, unsigned max_ticks, unsigned *signal_word, unsigned signal_gen) {
-    // signal_word: this is the first launch behind k_prob_emit on the main stream -- the problem list is complete and released
-    // (the kernel boundary): tell the side streams' waiters (k_wait_word)
-    if (signal_word && threadIdx.x == 0) __hip_atomic_store(signal_word, signal_gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+__global__ void __launch_bounds__(64) k_gate(Status *st, int which, unsigned grid, unsigned max_ticks) {
     // grid: the large class's workgroups the plan has launched (8-bit instance, and for the start gate the 16-bit one's too), at
     // most as many as fit the chip at once
     const unsigned want = grid;

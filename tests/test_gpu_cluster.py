@@ -80,12 +80,20 @@ def test_partition_reads_on_random_tints_against_the_reference(ctx):
             assert cu.canon_partitions(t) == parts, "seed %d, maximum_ilp_size %s" % (case["seed"], size)
 
 
-@pytest.mark.parametrize("rank_switch", ["1", "0"])
-def test_random_tints_batched(ctx, rank_switch, monkeypatch):
+@pytest.mark.parametrize("rank_switch,prune_lds", [("1", "1"), ("0", "1"), ("1", "0"), ("1", "0,edges=0"), ("1", "words=300")],
+                         ids=["rank-tables", "masked-sums", "per-pass-edge-walk", "per-pass-or-of-rows", "both-prunings-in-one-batch"])
+def test_random_tints_batched(ctx, rank_switch, prune_lds, monkeypatch):
     """Shapes that cross every tile edge: N around 64 / 128, M around 32 / 64, one-row and empty-ish tints, in one batch.
     Both forms of k_compat (FCLU_RANK=0: a range mask per word; default: rank tables), whose tiles lie on and above the
-    diagonal only -- the graphs are compared whole, both triangles."""
+    diagonal only -- the graphs are compared whole, both triangles.  Both prunings (:240-255): a small tint whole in one workgroup's LDS
+    (k_prune_lds, the default), the per-pass kernels (FCLU_PRUNE_LDS=0), and a batch whose tints are divided between them."""
     monkeypatch.setenv("FCLU_RANK", rank_switch)
+    if prune_lds.startswith("words="):
+        monkeypatch.setenv("FCLU_PRUNE_LDS_WORDS", prune_lds[6:])
+    else:
+        monkeypatch.setenv("FCLU_PRUNE_LDS", prune_lds[0])
+        if prune_lds.endswith("edges=0"):
+            monkeypatch.setenv("FCLU_PRUNE_EDGES", "0")             # the per-pass kernels' older form: OR of the neighbours' rows
     shapes = [(1, 5), (2, 1), (63, 31), (64, 32), (65, 33), (130, 64), (200, 65), (257, 100), (40, 300)]
     tints = [cu.random_tint(100 + k, n, m) for k, (n, m) in enumerate(shapes)]
     tints.append(cu.random_tint(200, 150, 20, n_isoforms=2, noise=0.0, tail_p=0.0))      # dense graph: heavy pruning input

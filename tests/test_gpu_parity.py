@@ -148,13 +148,13 @@ def test_tiny_problem_path_forced(monkeypatch):
 
 def test_tiny_path_switches_on_by_itself_and_changes_nothing(monkeypatch):
     """A many-partition batch: the first run sizes the arenas without k_tiny, later runs use it (more than 256 problems);
-    a context with FSEG_NO_TINY=1 must download the same bytes."""
+    a context that never uses it (FSEG_TINY_FROM beyond any problem count) must download the same bytes."""
     from freddie_amd import _lib, synth
     kw = dict(synth.WORKLOADS["config4"]); kw.pop("n_partitions")
     parts = [util.make_partition(100 + i, **kw) for i in range(40)]
     outs = []
-    for no_tiny in ("0", "1"):
-        monkeypatch.setenv("FSEG_NO_TINY", no_tiny)
+    for tiny_from in ("256", "1000000000"):
+        monkeypatch.setenv("FSEG_TINY_FROM", tiny_from)
         ctx = _lib.Context(0)
         try:
             util.run_gpu(ctx, parts)

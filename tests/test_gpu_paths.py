@@ -46,46 +46,35 @@ SWITCHES = [
     {"FSEG_NO_GRAPH": "1", "FSEG_NO_FORK": "1"},            # how the per-kernel profiles are taken
     {"FSEG_NO_SIZED": "1"},                                 # guessed arenas, overflow -> grow -> re-run (the fallback path)
     {"FSEG_NO_SIZED": "1", "FSEG_FORCE_SCAN_STALL": "1"},
-    {"FSEG_FORCE_WIDE_DP": "1"},                            # 32-bit DP count tables on every problem
-    {"FSEG_FORCE_WIDE_DP": "1", "FSEG_TINY_FROM": "0"},
+    {"FSEG_TINY_FROM": "0"},                                # k_wave / k_tiny take the small problems of a batch of few
     {"FSEG_NO_FUSE": "1"},                                  # every non-tiny problem through the arena path (tiles, work items, k_score, k_dp*)
-    {"FSEG_NO_FUSE": "1", "FSEG_NO_TINY": "1", "FSEG_NO_SIZED": "1"},
-    {"FSEG_NO_TINY": "1"},                                  # ... and the tiny ones through k_solve
+    {"FSEG_NO_FUSE": "1", "FSEG_TINY_FROM": "1000000000", "FSEG_NO_SIZED": "1"},
+    {"FSEG_TINY_FROM": "1000000000"},                       # ... and the tiny ones through k_solve (no problem count reaches the limit)
     {"FSEG_NO_WAVE": "1"},                                  # k_tiny instead of k_wave<8> (batches with a rep of > 510 exons take this)
     {"FSEG_FUSE_LANES": "255"},                             # batches with a problem that sees more than 255 reads: the arena path
     {"FSEG_FUSE_LANES": "1023"},
     {"FSEG_SCORE_PLAN": "0"},                               # ... all on the main stream (no k_gate)
-    {"FSEG_SCORE_PLAN": "BMbms|gTS"},                       # ... the 16-bit-counter instances behind the others
+    {"FSEG_SCORE_PLAN": "BM|gTS"},                          # ... no W: the 16-bit-counter instances behind their classes' 8-bit ones
     {"FSEG_SCORE_PLAN": "B|M|S|g|T"},                       # more segments than streams: not a plan, one stream
-    {"FSEG_SCORE_PLAN": "B|geM|TS", "FSEG_SPLIT_DP": "0"},    # the mid class behind the END of the large one ('e': an event across streams)
-    {"FSEG_SCORE_PLAN": "gBeMTS"},                          # a gate in front of its own kernel: leaves by its time limit
+    {"FSEG_SCORE_PLAN": "gBMTS"},                           # a gate in front of its own kernel: leaves by its time limit
     {"FSEG_SCORE_PLAN": "B|gM|gS|gT"},                      # ... or each class behind the gate on its own stream
     {"FSEG_FORCE_KEY64": "1"},                              # 64-bit DP keys (batches with a partition of 2^18 reads or more)
     {"FSEG_FORCE_KEY64": "1", "FSEG_NO_WAVE": "1", "FSEG_SCORE_PLAN": "0"},
     {"FSEG_GLOBAL_SORT": "1"},                              # the batch-wide radix sort of the reps instead of the in-LDS sort per partition
-    {"FSEG_PROB_SELF_MAX": "0"},                            # the problem list always through the block-sum scan
-    {"FSEG_PROB_SELF_MAX": "100000000"},                    # ... and always through the self-scanning emit kernel
     {"FSEG_NO_SDMA_D2H": "1"},                              # results through the runtime's copy instead of the SDMA engine
     {"FSEG_SPLIT_DP": "0"},                                 # the DP as the tail of k_solve's workgroups (one wave: dp_solve_wave), no k_dpw
     {"FSEG_SPLIT_DP": "0", "FSEG_FORCE_KEY64": "1"},        # ... with 64-bit keys: the large class's DP by the whole workgroup (dp_solve_push)
-    {"FSEG_SPLIT_DP": "5", "FSEG_SCORE_PLAN": "BM|gTS|b|ms"},   # small and large class split, the mid class fused; round 3's plan
-    {"FSEG_SPLIT_ALWAYS": "1", "FSEG_NO_FORK": "1"},        # k_solve + k_dpw on ONE stream (the default since round 5)
-    {"FSEG_SPLIT_ALWAYS": "0", "FSEG_NO_FORK": "1"},        # on one stream the DP stays the tail of k_solve's workgroups
-    {"FSEG_SPLIT_ALWAYS": "1", "FSEG_NO_FORK": "1", "FSEG_FORCE_KEY64": "1", "FSEG_FUSE_LANES": "1023"},   # k_dpw with 64-bit keys, the 16-bit instances behind the 8-bit ones
+    {"FSEG_SPLIT_DP": "5", "FSEG_SCORE_PLAN": "BM|gTS"},    # small and large class split, the mid class fused; round 3's plan
+    {"FSEG_NO_FORK": "1", "FSEG_FORCE_KEY64": "1", "FSEG_FUSE_LANES": "1023"},   # k_dpw with 64-bit keys on one stream, the 16-bit instances behind the 8-bit ones
     {"FSEG_FUSE_LANES": "1023", "FSEG_WIDE_BY_SEEN": "1"},  # wide problems (16-bit counters) through the split path, chosen by the reads they see
     {"FSEG_FUSE_LANES": "1023", "FSEG_WIDE_BY_SEEN": "1", "FSEG_SPLIT_DP": "0"},   # ... and fused: the 16-bit instances go over their classes' wide lists either way
-    {"FSEG_FUSE_LANES": "1023", "FSEG_SCORE_PLAN": "gM|B|gTS|bms"},    # no `h` gate, the 16-bit instances one after the other on a stream
-    {"FSEG_SCORE_PLAN": "gM|hB|msgTS|b"},                   # the 16-bit instances per class (round 4's earlier default)
-    {"FSEG_WIDE_ONE_MAX": "0"},                             # plan 'W' with too many wide problems for one launch: an instance per class
-    {"FSEG_FUSE_LANES": "1023", "FSEG_WIDE_BY_SEEN": "1", "FSEG_WIDE_ONE_MAX": "100000"},   # every wide problem, whatever its class, by the large class's 16-bit instance
-    {"FSEG_FUSE_LANES": "1023", "FSEG_WIDE_BY_SEEN": "1", "FSEG_WIDE_ONE_MAX": "100000", "FSEG_FORCE_KEY64": "1"},
-    {"FSEG_GRAPH_FORK": "1"},                               # the forked run replayed as a hipGraph with cross-stream edges (slower to launch: DESIGN section 3)
+    {"FSEG_FUSE_LANES": "1023", "FSEG_WIDE_BY_SEEN": "1", "FSEG_FORCE_KEY64": "1"},
+    {"FSEG_FUSE_LANES": "1023", "FSEG_SCORE_PLAN": "gM|B|gTS"},    # no `h` gate, no W
     {"FSEG_THR_PART": "1"},                                 # the variance threshold of a partition by one workgroup (k_thr_part), whatever the batch's size
     {"FSEG_THR_PART": "0"},                                 # ... and never: the batch-wide compaction + a workgroup per 8192-value chunk
     {"FSEG_THR_PART": "1", "FSEG_NO_FORK": "1", "FSEG_NO_GRAPH": "1"},
-    {"FSEG_LABEL_BYTES": "1"},                              # the label arena as bytes (the default writes two bits per label; threshold_rate = 1 always takes bytes)
-    {"FSEG_RANGE_SUMS": "0"},                               # the problem scan's block sums by k_prob_scan1 (the rescan's kernel) instead of k_prob_range
-    {"FSEG_EMIT_SIGNAL": "0"},                              # the side streams' waiters released by the first launch behind k_prob_emit only, not by its last workgroup
+    {"FSEG_LABEL_BYTES": "1"},                              # the label arena as bytes (the default writes two bits per label unless the threshold table holds a 1.0)
+    {"FSEG_DEV_SYNC": "0"},                                 # the scoring stage's side streams forked and joined with events
 ]
 
 
@@ -103,8 +92,8 @@ def test_diagnostic_switches_keep_parity(env, monkeypatch):
         ctx.close()
 
 
-@pytest.mark.parametrize("mode,env", [(1, {}), (2, {}), (3, {}), (1, {"FSEG_NO_FORK": "1"}), (2, {"FSEG_GRAPH_FORK": "1"})],
-                         ids=["all-stages", "scoring-only", "plain-replays", "one-stream-graphs", "forked-graphs"])
+@pytest.mark.parametrize("mode,env", [(1, {}), (2, {}), (3, {}), (1, {"FSEG_NO_FORK": "1"}), (2, {"FSEG_DEV_SYNC": "0"})],
+                         ids=["all-stages", "scoring-only", "plain-replays", "one-stream-graphs", "scoring-only-event-joins"])
 def test_stage_events_keep_parity(mode, env, monkeypatch):
     """fseg_set_profiling: events around the stages (the scoring stage's begin event doubles as its first fork) change no
     result, and the stage times they give are there on the first run and on replays."""
@@ -278,10 +267,8 @@ def test_full_size_bench_batches_against_oracle(workload, n_part, gpu_ctx):
 
 
 @pytest.mark.parametrize("env,waiters,still_on", [({}, True, True), ({"FSEG_DEV_SYNC": "0"}, False, False), ({"FSEG_SYNC_TICKS": "1"}, True, False),
-                                                  ({"FSEG_SCORE_PLAN": "gM|hB|gS|T"}, True, True), ({"FSEG_NO_SIZED": "1"}, True, True), ({"FSEG_NO_SIZED": "1", "FSEG_DEV_SYNC": "0"}, False, False),
-                                                  ({"FSEG_EMIT_SIGNAL": "0"}, True, True)],
-                         ids=["device-side", "events", "waiter-times-out", "three-side-streams", "unsized-first-run", "unsized-first-run-events",
-                              "signal-from-the-gate"])
+                                                  ({"FSEG_SCORE_PLAN": "gM|hB|gS|T"}, True, True), ({"FSEG_NO_SIZED": "1"}, True, True), ({"FSEG_NO_SIZED": "1", "FSEG_DEV_SYNC": "0"}, False, False)],
+                         ids=["device-side", "events", "waiter-times-out", "three-side-streams", "unsized-first-run", "unsized-first-run-events"])
 def test_scoring_stage_fork_and_join(env, waiters, still_on, monkeypatch):
     """The scoring stage's side streams (FSEG_SCORE_PLAN) are forked and joined on the device (k_wait_word / k_signal behind
     k_prob_emit's last workgroup) or with events (FSEG_DEV_SYNC=0); a waiter that gives up (forced: one tick) must end the
@@ -406,7 +393,7 @@ def test_upload_rejects_what_read_split_asserts(gpu_ctx):
     util.compare_partitions(gpu_ctx, [good], [util.run_oracle(good)])
 
 
-@pytest.mark.parametrize("env", [{}, {"FSEG_NO_TINY": "1"}, {"FSEG_TINY_FROM": "0"}], ids=["default", "no-k_tiny", "k_tiny"])
+@pytest.mark.parametrize("env", [{}, {"FSEG_TINY_FROM": "1000000000"}, {"FSEG_TINY_FROM": "0"}], ids=["default", "no-k_tiny", "k_tiny"])
 def test_windows_wider_than_sixteen_bits(env, monkeypatch):
     """Problems whose window spans more than 65 535 positions (a long unspliced interval): coverage and thresholds beyond
     16 bits, in every size class, alone and inside a larger batch.  (16-bit coverage rows in the fused solver were tried for

@@ -20,8 +20,8 @@ python profiles/benchsum.py < $O/bench_under_rocprof.json | head -1
 python profiles/trace_medians.py $O/stats/p_kernel_trace.csv > $O/config4_kernel_medians_8ctx.txt
 python tools/waiter_trace.py $O/stats/p_kernel_trace.csv 3 > $O/config4_waiters_8ctx.txt
 # 2. one context, one stream, one resident batch replayed: per-kernel durations with the GPU to themselves (the kernels `roofline`
-#    times: FSEG_SPLIT_ALWAYS keeps the split path -- k_solve's rounds + k_dpw -- although the streams are not forked)
-FSEG_SPLIT_ALWAYS=1 FSEG_NO_FORK=1 FSEG_NO_GRAPH=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace1 -o p -- python3 tools/replay_probe.py --workload config4 > $O/replay_config4.txt 2> $O/trace1.err
+#    times: the split path -- k_solve's rounds + k_dpw -- on one stream)
+FSEG_NO_FORK=1 FSEG_NO_GRAPH=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace1 -o p -- python3 tools/replay_probe.py --workload config4 > $O/replay_config4.txt 2> $O/trace1.err
 python profiles/trace_medians.py $O/trace1/p_kernel_trace.csv > $O/config4_kernel_medians.txt
 FSEG_NO_FORK=1 FSEG_NO_GRAPH=1 rocprofv3 --kernel-trace --output-format csv -d $O/trace2 -o p -- python3 tools/replay_probe.py --workload config2 > $O/replay_config2.txt 2> $O/trace2.err
 python profiles/trace_medians.py $O/trace2/p_kernel_trace.csv > $O/config2_kernel_medians.txt
@@ -32,18 +32,18 @@ python profiles/trace_medians.py $O/trace2/p_kernel_trace.csv > $O/config2_kerne
 rocprofv3 --kernel-trace --output-format csv -d $O/trace3 -o p -- python3 tools/replay_probe.py --workload config4 --profiling 2 > $O/replay_config4_plan.txt 2> $O/trace3.err
 python tools/stage_timeline.py $O/trace3/p_kernel_trace.csv > $O/config4_stage_timeline.txt; python tools/stage_span.py $O/trace3/p_kernel_trace.csv > $O/config4_stage_span.txt; grep replay $O/replay_config4_plan.txt | cut -c1-120 >> $O/config4_stage_span.txt; cat $O/config4_stage_span.txt
 # 2c. how a resident batch is replayed: plain launches on the forked streams (default), the same as one hipGraph with cross-stream
-#     edges (FSEG_GRAPH_FORK=1), one stream as a hipGraph (FSEG_NO_FORK=1), one stream as plain launches -- ms per replay and the
+#     edges (retired in round 6: profiles/r04_replay_modes.txt), one stream as a hipGraph (FSEG_NO_FORK=1), one stream as plain launches -- ms per replay and the
 #     host's time inside fseg_run
-for e in "-" "FSEG_GRAPH_FORK=1" "FSEG_NO_FORK=1" "FSEG_NO_FORK=1 FSEG_NO_GRAPH=1"; do
+for e in "-" "FSEG_NO_FORK=1" "FSEG_NO_FORK=1 FSEG_NO_GRAPH=1"; do
   if [ "$e" = "-" ]; then v=""; else v="$e"; fi
   echo "== ${v:-default}"; env $v python tools/replay_probe.py --workload config4 --profiling 0 | grep "replay\|host time" | cut -c1-70
 done > $O/replay_modes.txt 2>&1; cat $O/replay_modes.txt
 # 3. counters, each in its own pass
 for w in config4 config2; do
   for pmc in FETCH_SIZE WRITE_SIZE; do
-    FSEG_SPLIT_ALWAYS=1 FSEG_NO_FORK=1 rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d $O/pmc_${w}_$pmc -o p -- python3 tools/replay_probe.py --workload $w > /dev/null 2> $O/pmc_${w}_$pmc.err
+    FSEG_NO_FORK=1 rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d $O/pmc_${w}_$pmc -o p -- python3 tools/replay_probe.py --workload $w > /dev/null 2> $O/pmc_${w}_$pmc.err
   done
-  FSEG_SPLIT_ALWAYS=1 FSEG_NO_FORK=1 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_${w}_sq -o p -- python3 tools/replay_probe.py --workload $w > /dev/null 2> $O/pmc_${w}_sq.err
+  FSEG_NO_FORK=1 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_${w}_sq -o p -- python3 tools/replay_probe.py --workload $w > /dev/null 2> $O/pmc_${w}_sq.err
   python profiles/pmc_summary.py $O/pmc_${w}_FETCH_SIZE/p_counter_collection.csv $O/pmc_${w}_WRITE_SIZE/p_counter_collection.csv > $O/${w}_pmc_summary.txt
   python tools/sq_summary.py $O/pmc_${w}_sq/p_counter_collection.csv $O/pmc_${w}_sq/p_kernel_trace.csv > $O/${w}_sq_summary.txt
 done

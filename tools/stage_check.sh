@@ -23,7 +23,7 @@ done 2>&1 | tee $O/stage_ms.txt
 # TRACE1=1: per-kernel medians of the one-stream replay (what every kernel takes with the GPU to itself)
 if [ -n "$TRACE1" ]; then
   for wl in ${TRACE1_WLS:-config4}; do
-    FSEG_SPLIT_ALWAYS=1 FSEG_NO_FORK=1 FSEG_NO_GRAPH=1 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/trace1_$wl -o p -- python3 tools/replay_probe.py --workload $wl > /dev/null 2> $O/trace1_$wl.err
+    FSEG_NO_FORK=1 FSEG_NO_GRAPH=1 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/trace1_$wl -o p -- python3 tools/replay_probe.py --workload $wl > /dev/null 2> $O/trace1_$wl.err
     python profiles/trace_medians.py $O/trace1_$wl/p_kernel_trace.csv > $O/${wl}_kernel_medians.txt; cat $O/${wl}_kernel_medians.txt
     rm -rf $O/trace1_$wl
   done
