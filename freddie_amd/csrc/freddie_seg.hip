@@ -345,6 +345,17 @@ int upload_vec(fseg_ctx *c, DevBuf &b, const T *src, size_t n) {
     return FSEG_OK;
 }
 
+// A blocking copy on the context's OWN stream.  (Never hipMemcpy: it runs on the legacy stream, which must not be touched while another
+// thread of the process -- another context -- is capturing a graph: "operation would make the legacy stream depend on a capturing blocking
+// stream".  Found by tests/test_gpu_contexts_stress.py in round 6: taps, and the side-stream probe of a context that forks for the first
+// time while another replays on one stream.)
+hipError_t copy_sync(fseg_ctx *c, void *dst, const void *src, size_t bytes, hipMemcpyKind kind, hipStream_t q = nullptr) {
+    if (!q) q = c->stream;
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, q);
+    if (e == hipSuccess) e = hipStreamSynchronize(q);
+    return e;
+}
+
 int grid_for(i64 items, int per_block, int max_blocks) {
     i64 g = (items + per_block - 1) / per_block;
     if (g < 1) g = 1;
@@ -1248,7 +1259,7 @@ int probe_side_queues(fseg_ctx *c) {
         hipLaunchKernelGGL(k_signal, dim3(1), dim3(64), 0, c->stream, &sw->probe_word, gen);
         HIP_TRY(c, hipStreamSynchronize(c->side[k]));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
-        HIP_TRY(c, hipMemcpy(&res, &sw->probe_result, sizeof res, hipMemcpyDeviceToHost));
+        HIP_TRY(c, copy_sync(c, &res, &sw->probe_result, sizeof res, hipMemcpyDeviceToHost, c->side[k]));
         c->side_ok[k] = res == 1u;
     }
     if (c->trace) fprintf(stderr, "[fseg] side streams beside the main stream (device-side waiters allowed): %d %d %d\n", (int)c->side_ok[0], (int)c->side_ok[1], (int)c->side_ok[2]);
@@ -2107,10 +2118,10 @@ int fseg_tap(fseg_ctx *c, int what, void *dst, int64_t cap_bytes, int64_t *n_byt
             size_t n = (size_t)st.n_prob;
             std::vector<int> iv(n), sa(n), nn(n), ch(n);
             if (n) {
-                HIP_TRY(c, hipMemcpy(iv.data(), c->d_prob_iv.p, n * 4, hipMemcpyDeviceToHost));
-                HIP_TRY(c, hipMemcpy(sa.data(), c->d_prob_start.p, n * 4, hipMemcpyDeviceToHost));
-                HIP_TRY(c, hipMemcpy(nn.data(), c->d_prob_n.p, n * 4, hipMemcpyDeviceToHost));
-                HIP_TRY(c, hipMemcpy(ch.data(), c->d_prob_chain.p, n * 4, hipMemcpyDeviceToHost));
+                HIP_TRY(c, copy_sync(c, iv.data(), c->d_prob_iv.p, n * 4, hipMemcpyDeviceToHost));
+                HIP_TRY(c, copy_sync(c, sa.data(), c->d_prob_start.p, n * 4, hipMemcpyDeviceToHost));
+                HIP_TRY(c, copy_sync(c, nn.data(), c->d_prob_n.p, n * 4, hipMemcpyDeviceToHost));
+                HIP_TRY(c, copy_sync(c, ch.data(), c->d_prob_chain.p, n * 4, hipMemcpyDeviceToHost));
             }
             packed.resize(n * 4);
             for (size_t i = 0; i < n; ++i) { packed[4 * i] = iv[i]; packed[4 * i + 1] = sa[i]; packed[4 * i + 2] = nn[i]; packed[4 * i + 3] = ch[i]; }
@@ -2126,7 +2137,7 @@ int fseg_tap(fseg_ctx *c, int what, void *dst, int64_t cap_bytes, int64_t *n_byt
         case FSEG_TAP_EXON_STREAM: src = c->d_lex.p; bytes = c->I * 8; break;
         case FSEG_TAP_SYNC: {
             SyncWords w{};
-            HIP_TRY(c, hipMemcpy(&w, c->d_sync.p, sizeof w, hipMemcpyDeviceToHost));
+            HIP_TRY(c, copy_sync(c, &w, c->d_sync.p, sizeof w, hipMemcpyDeviceToHost));
             packed = {(int)c->sync_gen, c->dev_sync ? 1 : 0, (int)w.emit_gen, (int)w.side_gen[0], (int)w.side_gen[1], (int)w.emit_ctr,
                       (int)c->sync_timeouts, (int)c->forked_runs, (c->side_probed ? 8 : 0) | (c->side_ok[0] ? 1 : 0) | (c->side_ok[1] ? 2 : 0) | (c->side_ok[2] ? 4 : 0)};
             bytes = (i64)packed.size() * 4;
@@ -2138,7 +2149,7 @@ int fseg_tap(fseg_ctx *c, int what, void *dst, int64_t cap_bytes, int64_t *n_byt
     }
     *n_bytes = bytes;
     if (dst && cap_bytes > 0 && bytes > 0)
-        HIP_TRY(c, hipMemcpy(dst, src, (size_t)(bytes < cap_bytes ? bytes : cap_bytes), hipMemcpyDeviceToHost));
+        HIP_TRY(c, copy_sync(c, dst, src, (size_t)(bytes < cap_bytes ? bytes : cap_bytes), hipMemcpyDeviceToHost));
     return FSEG_OK;
 }
 
@@ -2162,23 +2173,23 @@ int fseg_stage_ms(fseg_ctx *c, float *ms) {
 #ifdef FSEG_SCORE_TIMING
 int fseg_debug_score_timing(fseg_ctx *c, unsigned long long *out8) {
     if (!c || !out8 || !c->d_tacc.p) return FSEG_ERR_ARG;
-    if (hipMemcpy(out8, c->d_tacc.p, 128, hipMemcpyDeviceToHost) != hipSuccess) return FSEG_ERR_HIP;   /* 16 slots */
-    (void)hipMemset(c->d_tacc.p, 0, 120);               /* slot 15 = the k_solve class being timed: kept */
+    if (copy_sync(c, out8, c->d_tacc.p, 128, hipMemcpyDeviceToHost) != hipSuccess) return FSEG_ERR_HIP;   /* 16 slots */
+    (void)hipMemsetAsync(c->d_tacc.p, 0, 120, c->stream); (void)hipStreamSynchronize(c->stream);   /* slot 15 = the k_solve class being timed: kept */
     return FSEG_OK;
 }
 int fseg_debug_prob_ticks(fseg_ctx *c, unsigned long long *out4, long long n_prob) {     /* 4 values per problem */
     if (!c || !out4 || n_prob < 0 || (size_t)n_prob > kTaccProbs) return FSEG_ERR_ARG;
-    if (hipMemcpy(out4, static_cast<char *>(c->d_tacc.p) + 128, (size_t)n_prob * 32, hipMemcpyDeviceToHost) != hipSuccess) return FSEG_ERR_HIP;
+    if (copy_sync(c, out4, static_cast<char *>(c->d_tacc.p) + 128, (size_t)n_prob * 32, hipMemcpyDeviceToHost) != hipSuccess) return FSEG_ERR_HIP;
     return FSEG_OK;
 }
 int fseg_debug_dp_ticks(fseg_ctx *c, unsigned long long *out4, long long n_prob) {       /* k_dpw's records: (ticks, -, -, start tick) */
     if (!c || !out4 || n_prob < 0 || (size_t)n_prob > kTaccProbs) return FSEG_ERR_ARG;
-    if (hipMemcpy(out4, static_cast<char *>(c->d_tacc.p) + 128 + kTaccProbs * 32, (size_t)n_prob * 32, hipMemcpyDeviceToHost) != hipSuccess) return FSEG_ERR_HIP;
+    if (copy_sync(c, out4, static_cast<char *>(c->d_tacc.p) + 128 + kTaccProbs * 32, (size_t)n_prob * 32, hipMemcpyDeviceToHost) != hipSuccess) return FSEG_ERR_HIP;
     return FSEG_OK;
 }
 int fseg_debug_timed_class(fseg_ctx *c, int cls) {
     unsigned long long v = (unsigned long long)(long long)cls;
-    if (!c || hipMemcpy(static_cast<char *>(c->d_tacc.p) + 120, &v, 8, hipMemcpyHostToDevice) != hipSuccess) return FSEG_ERR_HIP;
+    if (!c || copy_sync(c, static_cast<char *>(c->d_tacc.p) + 120, &v, 8, hipMemcpyHostToDevice) != hipSuccess) return FSEG_ERR_HIP;
     return FSEG_OK;
 }
 #endif
@@ -2187,7 +2198,7 @@ int64_t fseg_scoring_algorithmic_bytes(fseg_ctx *c) {
     if (!c || !c->ran) return -1;
     // per partition 4*(N_p + K_p)*R_p + 4*R_p, R_p = read reps
     std::vector<i64> co((size_t)c->K + 1);
-    if (hipMemcpy(co.data(), c->d_cand_off.p, co.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (copy_sync(c, co.data(), c->d_cand_off.p, co.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
     i64 total = 0;
     for (int p = 0; p < c->n_part; ++p) {
         i64 Np = co[(size_t)c->part_iv_off[p + 1]] - co[(size_t)c->part_iv_off[p]];

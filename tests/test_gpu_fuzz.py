@@ -26,7 +26,7 @@ def test_random_inputs_and_parameters(seed, monkeypatch):
         try:
             # (the choices reach the CLI's bounds, parse_args :104-109; the first four of each list are the pre-round-5 sweep)
             params = dict(sigma=rng.choice([2.0, 3.0, 5.0, 8.0, 0.1, 0.4, 20.0, 50.0]),
-                          threshold_rate=rng.choice([0.8, 0.9, 0.95, 1.0, 0.5, 0.51, 0.6]),
+                          threshold_rate=rng.choice([0.8, 0.9, 0.95, 1.0, 0.5, 0.51, 0.6, 0.9999, 0.999]),
                           variance_factor=rng.choice([1.0, 3.0, 6.0, 0.01, 9.99]), max_problem_size=rng.choice([6, 10, 30, 50, 90, 4, 5]),
                           min_read_support_outside=rng.choice([0, 1, 3, 10]), ignore_ends=rng.random() < 0.7)
             parts = []
