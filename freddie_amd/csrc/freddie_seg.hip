@@ -160,15 +160,17 @@ struct fseg_ctx {
     DevBuf d_status, d_prep, d_tacc;
     DevBuf d_sync;               // SyncWords: the scoring stage's device-side fork / join (k_wait_word)
     unsigned sync_gen = 0;       // generation of the last stage enqueued with device-side waiters
-    // What a waiter waits at most, in ticks of the 100 MHz clock, per 2^18 reads of the batch: 2 ms (FSEG_SYNC_TICKS; tests force a
-    // time-out with 1).  Round 5's limit was 20 ms and it DID run out, four times in one 8-context trace -- for two reasons, both removed
-    // in round 6: a later context's side stream could share its own main stream's hardware queue (probe_side_queues), and two contexts
-    // that started together could both fork (claim_device).  What is left is honest waiting: the fork waiters sleep through k_fix ..
-    // k_prob_emit (median 60 us on a 250 k-read batch), the join waiter through what the side chains need beyond the main stream's
-    // (a few us) -- and, with seven other contexts' kernels ahead of the owner's in its hardware queue, up to 168 us in the traced
-    // 8-context run (profiles/r06_config4_waiters_8ctx.txt).  200 us, the figure first tried, turned four to six such waits per
-    // bench run into time-outs (each a stage skipped and the batch run again): the limit is a bound on a stall, not a schedule.
-    unsigned sync_ticks = 200000u;
+    // What a waiter waits at most, in ticks of the 100 MHz clock, per 2^18 reads of the batch: 10 ms, at most 20 (FSEG_SYNC_TICKS; tests
+    // force a time-out with 1).  Round 5's 20 ms DID run out, four times in one 8-context trace -- for two reasons, both removed in
+    // round 6: a later context's side stream could share its own main stream's hardware queue (probe_side_queues), and two contexts that
+    // started together could both fork (claim_device).  What is left is honest waiting: the fork waiters sleep through k_fix ..
+    // k_prob_emit (median 49-68 us), the join waiter through what the side chains need beyond the main stream's -- plus whatever is in
+    // front of the owner's kernels in its hardware queue: other contexts' kernels (168 and 235 us in two traced 8-context runs) or a
+    // large copy to pageable memory (40 MB of a test's taps hold a queue for milliseconds: one time-out at 2 ms in 1 600 forked runs of
+    // tests/test_gpu_contexts_stress.py; 200 us, the figure first tried, lost four to six waits per bench run).  A time-out costs the
+    // limit AND a rerun of the batch, and with the two causes above gone a waiter only ever waits for work that completes: the limit
+    // is the exit every launch must have, not a schedule.
+    unsigned sync_ticks = 1000000u;
     unsigned sync_timeouts = 0;  // runs of this context that a waiter gave up on (each was redone with events); FSEG_TAP_SYNC[6]
     unsigned forked_runs = 0;    // runs of this context that owned the device (side streams in use); FSEG_TAP_SYNC[7]
     bool run_events_only = false;   // this run: no device-side waiters (it is the rerun after a timeout)
@@ -517,18 +519,24 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
     const bool dev_sync = plan && c->dev_sync && !c->run_events_only && do_pre2 && (sized || c->run_plain) && c->d_sync.p != nullptr;
     SyncWords *sw = c->d_sync.as<SyncWords>();
     const unsigned sync_gen = dev_sync ? ++c->sync_gen : 0;
-    // (a context's first two stages with waiters get ten times the limit: the first launches of the stage's kernels load their
-    // code objects and make the runtime allocate scratch for the side streams' queues -- hundreds of microseconds, once.  Measured:
-    // tools/waiter_probe.py, a context alone: the first sized run lost a waiter at 200 us, later runs sleep 49 us in the median, 134 at most.)
-    const i64 sync_scale = std::max<i64>(1, c->LANES >> 18) * (c->sync_gen <= 2 && c->sync_ticks > 1 ? 10 : 1);
+    // (a context's first stages with waiters also load the stage's code objects and make the runtime allocate scratch for the side
+    // streams' queues -- hundreds of microseconds, once: tools/waiter_probe.py)
+    const i64 sync_scale = std::max<i64>(1, c->LANES >> 18);
     const unsigned kSyncTicks = (unsigned)std::min<i64>((i64)c->sync_ticks * sync_scale, 2000000);
     auto dev_side = [&](int k) { return dev_sync && k >= 1 && k < ps.n_seg && ps.used[k] && ps.side_of[k] >= 0 && ps.side_of[k] < fseg_ctx::kSide && c->side_ok[ps.side_of[k]]; };
+    // The fork is EARLY (the event in front of k_fix: its latency hides behind the stage's predecessors), the waiters' launches come
+    // LATE on the host -- behind k_prob_emit's --: a waiter then never spins on the device while the host has not yet enqueued the
+    // kernel it waits for (a host thread that is descheduled, or held up in the runtime beside another context's large pageable copy,
+    // between the two was one way to a time-out: tests/test_gpu_contexts_stress.py); on the device nothing moves -- the host is four
+    // launches (~20 us) ahead of the event either way.
     auto early_fork = [&]() {
         if (!dev_sync) return;
-        for (int k = 1; k < ps.n_seg; ++k) if (dev_side(k)) {
-            hipStream_t q = fork(ps.side_of[k]);
-            hipLaunchKernelGGL(k_wait_word, dim3(1), dim3(64), 0, q, st, &sw->emit_gen, 1u, sync_gen, kSyncTicks);
-        }
+        for (int k = 1; k < ps.n_seg; ++k) if (dev_side(k)) (void)fork(ps.side_of[k]);
+    };
+    auto launch_fork_waiters = [&]() {
+        if (!dev_sync) return;
+        for (int k = 1; k < ps.n_seg; ++k) if (dev_side(k))
+            hipLaunchKernelGGL(k_wait_word, dim3(1), dim3(64), 0, c->side[ps.side_of[k]], st, &sw->emit_gen, 1u, sync_gen, kSyncTicks);
     };
     const i64 avg_len = NPOS / (K > 0 ? K : 1);
     const int iv_threads = avg_len > 65536 ? 1024 : (avg_len > 16384 ? 256 : 64);
@@ -660,6 +668,7 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
                        c->d_iv_part.as<int>(), c->d_part_lane_off.as<i64>(), split, c->d_solve_items.as<int>(), c->d_solve_desc.as<ProbDesc>(),
                        c->d_wide_items.as<int>(), c->d_wide_all.as<int>(), c->d_cand_wide.as<unsigned char>(),
                        dev_sync ? sw : (SyncWords *)nullptr, sync_gen);
+    launch_fork_waiters();
     // S5.  The arena path's window coverage (and pair thresholds) are launches of their own in front of k_score: they are
     // interval scoring (get_cumulative_coverage :188-246 -- the solve-list kernels do the same inside their workgroups), so
     // where the stages are bracketed by events the scoring stage's bracket opens here

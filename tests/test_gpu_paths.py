@@ -290,7 +290,7 @@ def test_scoring_stage_fork_and_join(env, waiters, still_on, monkeypatch):
         assert bool(sy[1]) == still_on, sy
         if waiters and still_on:
             assert sy[2] == sy[0] and sy[3] == sy[0] and sy[5] == 0, sy     # the words carry the last generation; the counter is back at 0
-            assert sy[6] == 0, sy                                          # no waiter reached its limit (2 ms per 2^18 reads)
+            assert sy[6] == 0, sy                                          # no waiter reached its limit (10 ms per 2^18 reads)
         if waiters and not still_on:
             assert sy[6] >= 3, sy                                          # every forked run lost its waiter, was redone with events; after three: events for good
         assert sy[7] >= 5, sy                                              # every run of a context alone owns the device
