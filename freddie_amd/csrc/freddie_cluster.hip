@@ -210,54 +210,81 @@ __global__ void __launch_bounds__(256) k_deg1(int n_words_total, const int2 *wor
 // 19 539 reads, mean degree 239: 8.7 -> ~2 ms a pass.  Removed bits are cleared in the lane that holds their word.
 constexpr int kEdgeChunks = 8;
 
-__global__ void __launch_bounds__(256) k_prune_edges(i64 n_rows_total, const int *row_tint, const TintDesc *tints, const u64 *old_adj, const int *deg,
+__global__ void __launch_bounds__(256) k_prune_edges(i64 n_rows_total, int max_chunks, const int *row_tint, const TintDesc *tints, const u64 *old_adj, const int *deg,
                                                      u64 *new_adj, int *changed /* per tint */, int *pass_any, const int *gate) {
     if (gate && *gate == 0) return;
     const int lane = lane_id();
     const i64 wave_g = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((i64)gridDim.x * blockDim.x) >> 6;
-    for (i64 r = wave_g; r < n_rows_total; r += n_waves) {
+    // a work item = (row r, 64-word chunk qc of it): the wave tests the neighbours whose bits lie in that chunk and writes that chunk of
+    // the new row.  (A wave per ROW ended with its longest rows: degrees reach 7 000 where the mean is 239.)
+    for (i64 item = wave_g; item < n_rows_total * max_chunks; item += n_waves) {
+        const i64 r = item / max_chunks;
+        const int qc = (int)(item - r * max_chunks);
         const int t = row_tint[r];
         const TintDesc d = tints[t];
         if (d.in_lds) continue;
         const u64 *A = old_adj + d.adj_off;
         const i64 rl = r - d.row0;
         const int aw = d.aw, n_chunks = (aw + 63) >> 6;
-        u64 mine[kEdgeChunks], keep[kEdgeChunks];
+        if (qc >= n_chunks) continue;
+        u64 mine[kEdgeChunks];
 #pragma unroll
-        for (int q = 0; q < kEdgeChunks; ++q) { const int z = q * 64 + lane; mine[q] = (q < n_chunks && z < aw) ? A[rl * aw + z] : 0ull; keep[q] = mine[q]; }
+        for (int q = 0; q < kEdgeChunks; ++q) { const int z = q * 64 + lane; mine[q] = (q < n_chunks && z < aw) ? A[rl * aw + z] : 0ull; }
+        u64 own = 0;                                          // this item's chunk of the row
+#pragma unroll
+        for (int q = 0; q < kEdgeChunks; ++q) if (q == qc) own = mine[q];
+        u64 keep = own;
         const int deg_r = deg[r];
         bool any_change = false;
         if (deg_r > 1) {                                       // (deg 1: the edge stays; deg 0: nothing to do)
+            // Neighbours are taken FOUR at a time: their degrees and the first 64 words of their rows are asked for together and
+            // looked at afterwards -- one neighbour at a time the walk was a chain of two dependent loads (~1 us) per neighbour.
+            i64 bc[4] = {0, 0, 0, 0}; int bl[4] = {0, 0, 0, 0}, bb[4] = {0, 0, 0, 0};
+            int cnt = 0;
+            auto flush = [&]() {
+                int dg[4]; u64 cw[4];
 #pragma unroll
-            for (int q = 0; q < kEdgeChunks; ++q) {
-                if (q >= n_chunks) break;
-                u64 have = __ballot(mine[q] != 0ull);          // the lanes whose word of this chunk holds a neighbour
-                while (have) {
-                    const int L = __builtin_amdgcn_readfirstlane(__ffsll((long long)have) - 1);     // (wave-uniform: a scalar for readlane)
-                    have &= have - 1;
-                    u64 word = ((u64)(unsigned)__builtin_amdgcn_readlane((int)(mine[q] >> 32), L) << 32) | (u64)(unsigned)__builtin_amdgcn_readlane((int)mine[q], L);
-                    while (word) {
-                        const int b = __builtin_amdgcn_readfirstlane(__ffsll((long long)word) - 1);
-                        word &= word - 1;
-                        const i64 c = ((i64)q * 64 + L) * 64 + b;                   // the neighbour (wave-uniform)
-                        bool stays = deg[d.row0 + c] == 1;
-                        if (!stays) {
-                            const u64 *C = A + c * aw;
+                for (int u = 0; u < 4; ++u) dg[u] = deg[d.row0 + bc[u < cnt ? u : 0]];
 #pragma unroll
-                            for (int q2 = 0; q2 < kEdgeChunks; ++q2) {
-                                if (q2 >= n_chunks) break;
-                                const int z = q2 * 64 + lane;
-                                const u64 cw = z < aw ? C[z] : 0ull;
-                                if (__ballot((cw & mine[q2]) != 0ull)) { stays = true; break; }
-                            }
+                for (int u = 0; u < 4; ++u) cw[u] = lane < aw ? A[bc[u < cnt ? u : 0] * aw + lane] : 0ull;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (u >= cnt) break;
+                    bool stays = dg[u] == 1;
+                    if (!stays) stays = __ballot((cw[u] & mine[0]) != 0ull) != 0ull;
+                    if (!stays) {
+                        const u64 *C = A + bc[u] * aw;
+#pragma unroll
+                        for (int q2 = 1; q2 < kEdgeChunks; ++q2) {
+                            if (q2 >= n_chunks) break;
+                            const int z = q2 * 64 + lane;
+                            const u64 w2 = z < aw ? C[z] : 0ull;
+                            if (__ballot((w2 & mine[q2]) != 0ull)) { stays = true; break; }
                         }
-                        if (!stays) { if (lane == L) keep[q] &= ~(1ull << b); any_change = true; }
                     }
+                    if (!stays) { if (lane == bl[u]) keep &= ~(1ull << bb[u]); any_change = true; }
+                }
+                cnt = 0;
+            };
+            u64 have = __ballot(own != 0ull);                  // the lanes whose word of this chunk holds a neighbour
+            while (have) {
+                const int L = __builtin_amdgcn_readfirstlane(__ffsll((long long)have) - 1);     // (wave-uniform: a scalar for readlane)
+                have &= have - 1;
+                u64 word = ((u64)(unsigned)__builtin_amdgcn_readlane((int)(own >> 32), L) << 32) | (u64)(unsigned)__builtin_amdgcn_readlane((int)own, L);
+                while (word) {
+                    const int b = __builtin_amdgcn_readfirstlane(__ffsll((long long)word) - 1);
+                    word &= word - 1;
+                    // (the newest neighbour enters at slot 0 and the others move up: static register indices, no scratch; the order
+                    // inside a batch does not matter)
+#pragma unroll
+                    for (int u = 3; u > 0; --u) { bc[u] = bc[u - 1]; bl[u] = bl[u - 1]; bb[u] = bb[u - 1]; }
+                    bc[0] = ((i64)qc * 64 + L) * 64 + b; bl[0] = L; bb[0] = b;                 // the neighbour (wave-uniform)
+                    if (++cnt == 4) flush();
                 }
             }
+            if (cnt) flush();
         }
-#pragma unroll
-        for (int q = 0; q < kEdgeChunks; ++q) { const int z = q * 64 + lane; if (q < n_chunks && z < aw) new_adj[d.adj_off + rl * aw + z] = keep[q]; }
+        { const int z = qc * 64 + lane; if (z < aw) new_adj[d.adj_off + rl * aw + z] = keep; }
         if (any_change && lane == 0) { changed[t] = 1; *pass_any = 1; }
     }
 }
@@ -603,6 +630,7 @@ int fclu_compat_graph(fclu_ctx *c, const fclu_batch *b, int32_t prune, uint64_t 
         // FCLU_PRUNE_EDGES=0: the OR-of-rows form whatever the shapes (tests)
         const char *edge_env = getenv("FCLU_PRUNE_EDGES");
         const bool edge_walk = max_aw_large <= kEdgeChunks * 64 && !(edge_env && edge_env[0] == '0');
+        const int edge_chunks = (max_aw_large + 63) / 64 > 0 ? (max_aw_large + 63) / 64 : 1;
         const int n_words = (int)word_tint.size();
         int *h_any = c->h_flags, *h_changed = c->h_flags + kBurst;
         bool done = false;
@@ -615,8 +643,8 @@ int fclu_compat_graph(fclu_ctx *c, const fclu_batch *b, int32_t prune, uint64_t 
                 hipLaunchKernelGGL(k_degree, dim3(deg_grid), dim3(256), 0, s, R, d_row_tint.as<int>(), d_tints.as<TintDesc>(),
                                    d_adj[from].as<u64>(), d_deg.as<int>(), gate);
                 if (edge_walk)
-                    hipLaunchKernelGGL(k_prune_edges, dim3((int)((R + 3) / 4 < 16384 ? (R + 3) / 4 : 16384)), dim3(256), 0, s, R, d_row_tint.as<int>(),
-                                       d_tints.as<TintDesc>(), d_adj[from].as<u64>(), d_deg.as<int>(), d_adj[to].as<u64>(),
+                    hipLaunchKernelGGL(k_prune_edges, dim3((int)((R * edge_chunks + 3) / 4 < 65536 ? (R * edge_chunks + 3) / 4 : 65536)), dim3(256), 0, s, R, edge_chunks,
+                                       d_row_tint.as<int>(), d_tints.as<TintDesc>(), d_adj[from].as<u64>(), d_deg.as<int>(), d_adj[to].as<u64>(),
                                        d_changed.as<int>() + (size_t)q * T, d_pass_any.as<int>() + q, gate);
                 else {
                 hipLaunchKernelGGL(k_deg1, dim3((n_words + 3) / 4 < 4096 ? (n_words + 3) / 4 : 4096), dim3(256), 0, s, n_words,
