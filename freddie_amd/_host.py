@@ -47,8 +47,54 @@ def load():
     for name in ("fhost_write", "fhost_write_packed"):
         getattr(L, name).restype = ctypes.c_int32
         getattr(L, name).argtypes = [vp, vp, vp, vp, vp, cpp, ctypes.c_int32]
+    L.fhost_discover.restype = vp
+    L.fhost_discover.argtypes = [ctypes.c_char_p, ctypes.c_int32]
+    L.fhost_listing_free.restype = None
+    L.fhost_listing_free.argtypes = [vp]
+    L.fhost_listing_error.restype = ctypes.c_char_p
+    L.fhost_listing_error.argtypes = [vp]
+    L.fhost_listing_n.restype = ctypes.c_int64
+    L.fhost_listing_n.argtypes = [vp]
+    L.fhost_listing_n_contigs.restype = ctypes.c_int32
+    L.fhost_listing_n_contigs.argtypes = [vp]
+    L.fhost_listing_contig.restype = ctypes.c_char_p
+    L.fhost_listing_contig.argtypes = [vp, ctypes.c_int32]
+    for name in ("fhost_listing_contig_of", "fhost_listing_tint", "fhost_listing_size"):
+        getattr(L, name).restype = vp
+        getattr(L, name).argtypes = [vp]
+    L.fhost_touch.restype = ctypes.c_int32
+    L.fhost_touch.argtypes = [cpp, ctypes.c_int32, ctypes.c_int32]
     _lib = L
     return L
+
+
+def discover(split_dir, n_threads=8):
+    """[(contig, tint_id, bytes of split_<contig>_<tint>.tsv)] of every partition under split_dir, in directory order (the native
+    form of the listing loop of the reference's main(), py/freddie_segment.py:852-857)."""
+    L = load()
+    h = L.fhost_discover(split_dir.encode(), int(n_threads))
+    if not h:
+        raise HostError("fhost_discover: out of memory")
+    try:
+        err = L.fhost_listing_error(h).decode()
+        if err:
+            raise HostError(err)
+        n = L.fhost_listing_n(h)
+        contigs = [L.fhost_listing_contig(h, k).decode() for k in range(L.fhost_listing_n_contigs(h))]
+        ci = _view(L.fhost_listing_contig_of(h), n, np.int32).tolist()
+        tint = _view(L.fhost_listing_tint(h), n, np.int64).tolist()
+        size = _view(L.fhost_listing_size(h), n, np.int64).tolist()
+        return contigs, [(contigs[c], t, s) for c, t, s in zip(ci, tint, size)]
+    finally:
+        L.fhost_listing_free(h)
+
+
+def touch(paths, n_threads=4):
+    """Create (or truncate) the given files: the empty segment_*.log the reference leaves per partition (:695), a batch at a time."""
+    if not paths:
+        return
+    if load().fhost_touch(_c_strings(paths), len(paths), int(n_threads)) != 0:
+        raise HostError("cannot create %s ..." % paths[0])
 
 
 def _c_strings(items):

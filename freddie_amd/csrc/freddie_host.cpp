@@ -28,6 +28,7 @@
 #include <unistd.h>
 #include <unordered_map>
 #include <vector>
+#include <dirent.h>
 
 namespace {
 
@@ -904,6 +905,87 @@ int32_t fhost_sidecar_write(fhost_batch *b, const char *const *split_paths, cons
 }
 
 void fhost_free(fhost_batch *b) { delete b; }
+
+// ---- the split directory's listing and the empty .log files: two loops of system calls the Python driver used to make one by one ----
+struct fhost_listing {
+    std::string err;
+    std::vector<std::string> contigs;
+    std::vector<int32_t> contig_of;
+    std::vector<int64_t> tint, size;
+};
+
+fhost_listing *fhost_discover(const char *split_dir, int32_t n_threads) {
+    fhost_listing *l = new (std::nothrow) fhost_listing();
+    if (!l) return nullptr;
+    try {
+        std::vector<std::string> paths;
+        DIR *top = opendir(split_dir);
+        if (!top) { l->err = std::string("cannot list ") + split_dir; return l; }
+        std::vector<std::string> dirs;
+        while (struct dirent *e = readdir(top)) {
+            if (e->d_name[0] == '.' && (e->d_name[1] == 0 || (e->d_name[1] == '.' && e->d_name[2] == 0))) continue;
+            bool is_dir = e->d_type == DT_DIR;
+            if (e->d_type == DT_UNKNOWN || e->d_type == DT_LNK) {           // file systems that do not say: ask (os.DirEntry.is_dir follows links too)
+                struct stat st;
+                is_dir = stat((std::string(split_dir) + "/" + e->d_name).c_str(), &st) == 0 && S_ISDIR(st.st_mode);
+            }
+            if (is_dir) dirs.push_back(e->d_name);
+        }
+        closedir(top);
+        for (const std::string &c : dirs) {
+            const std::string dpath = std::string(split_dir) + "/" + c;
+            DIR *d = opendir(dpath.c_str());
+            if (!d) { l->err = "cannot list " + dpath; return l; }
+            const int32_t ci = (int32_t)l->contigs.size();
+            l->contigs.push_back(c);
+            while (struct dirent *e = readdir(d)) {
+                const char *nm = e->d_name;
+                const size_t n = strlen(nm);
+                if (n < 11 || strncmp(nm, "split_", 6) != 0 || strcmp(nm + n - 4, ".tsv") != 0) continue;      // split_*.tsv (:853)
+                const char *us = nm + n - 4;
+                while (us > nm && us[-1] != '_') --us;                     // int(name[:-4].split("_")[-1])
+                i64 id = 0;
+                if (!parse_uint(us, nm + n - 4, id)) {          // (the message first: the entry's name lives in the directory stream)
+                    l->err = dpath + "/" + nm + ": the tint id in the file name is not a number";
+                    closedir(d);
+                    return l;
+                }
+                l->contig_of.push_back(ci); l->tint.push_back(id);
+                paths.push_back(dpath + "/" + nm);
+            }
+            closedir(d);
+        }
+        l->size.assign(paths.size(), 0);
+        std::atomic<bool> bad(false);
+        parallel_for((int)paths.size(), n_threads, [&](int i) {
+            struct stat st;
+            if (stat(paths[(size_t)i].c_str(), &st) != 0) bad.store(true); else l->size[(size_t)i] = (int64_t)st.st_size;
+        });
+        if (bad.load()) l->err = std::string("cannot stat a split file under ") + split_dir;
+    } catch (const std::exception &e) { l->err = std::string("fhost_discover: ") + e.what(); }
+    catch (...) { l->err = "fhost_discover: internal error"; }
+    return l;
+}
+void fhost_listing_free(fhost_listing *l) { delete l; }
+const char *fhost_listing_error(const fhost_listing *l) { return l ? l->err.c_str() : "null listing"; }
+int64_t fhost_listing_n(const fhost_listing *l) { return (int64_t)l->tint.size(); }
+int32_t fhost_listing_n_contigs(const fhost_listing *l) { return (int32_t)l->contigs.size(); }
+const char *fhost_listing_contig(const fhost_listing *l, int32_t k) { return (k >= 0 && (size_t)k < l->contigs.size()) ? l->contigs[(size_t)k].c_str() : ""; }
+const int32_t *fhost_listing_contig_of(const fhost_listing *l) { return l->contig_of.data(); }
+const int64_t *fhost_listing_tint(const fhost_listing *l) { return l->tint.data(); }
+const int64_t *fhost_listing_size(const fhost_listing *l) { return l->size.data(); }
+
+int32_t fhost_touch(const char *const *paths, int32_t n, int32_t n_threads) {
+    if (n <= 0) return 0;
+    std::atomic<int> failed(0);
+    try {
+        parallel_for(n, n_threads, [&](int i) {
+            const int fd = ::open(paths[i], O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
+            if (fd < 0 || ::close(fd) != 0) failed.fetch_add(1);
+        });
+    } catch (...) { return 1; }
+    return failed.load() ? 2 : 0;
+}
 const char *fhost_error(const fhost_batch *b) { return b ? b->err.c_str() : "null batch"; }
 int32_t fhost_n_part(const fhost_batch *b) { return (int32_t)b->parts.size(); }
 int64_t fhost_n_reads(const fhost_batch *b) { return b->n_reads; }

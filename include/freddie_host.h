@@ -70,6 +70,23 @@ int32_t fhost_n_from_sidecar(const fhost_batch *b);   /* partitions of the batch
 int32_t fhost_sidecar_write(fhost_batch *b, const char *const *split_paths, const char *const *reads_paths,
                             const char *const *sidecar_paths, int32_t n_threads);
 
+/* ---- the split directory's listing and the empty .log files (round 6) ---------------------------------------------------
+ * What main() does before and around the batches as loops of system calls (py/freddie_segment.py:852-857: one directory per
+ * contig, one split_<contig>_<tint>.tsv per partition; :695: an empty segment_*.log per partition), natively and on n_threads:
+ * fhost_discover lists every split_*.tsv of every contig directory with its size (what the scatter and the batching weigh a
+ * partition by); fhost_touch creates (or truncates) the given files. */
+typedef struct fhost_listing fhost_listing;
+fhost_listing *fhost_discover(const char *split_dir, int32_t n_threads);   /* NULL: out of memory; else check fhost_listing_error() */
+void fhost_listing_free(fhost_listing *l);
+const char *fhost_listing_error(const fhost_listing *l);                   /* "" when the listing is usable */
+int64_t fhost_listing_n(const fhost_listing *l);                           /* partitions found */
+int32_t fhost_listing_n_contigs(const fhost_listing *l);
+const char *fhost_listing_contig(const fhost_listing *l, int32_t k);       /* name of contig directory k */
+const int32_t *fhost_listing_contig_of(const fhost_listing *l);            /* per partition: index of its contig directory */
+const int64_t *fhost_listing_tint(const fhost_listing *l);                 /* per partition: the tint id from the file name */
+const int64_t *fhost_listing_size(const fhost_listing *l);                 /* per partition: bytes of its split TSV */
+int32_t fhost_touch(const char *const *paths, int32_t n, int32_t n_threads);   /* 0 on success */
+
 #ifdef __cplusplus
 }
 #endif

@@ -282,3 +282,34 @@ def test_native_poly_tails_match_the_python_mirror(seed, tmp_path):
         assert open(out, "rb").read() == want.read_bytes()
     finally:
         hb.close()
+
+
+def test_native_listing_and_touch(tmp_path):
+    """fhost_discover / fhost_touch (include/freddie_host.h): the split directory's listing as the reference's main() builds it
+    (:852-857: one directory per contig, split_<contig>_<tint>.tsv per partition, the tint id = the text behind the last '_') with the
+    files' sizes, and the empty .log files of a batch (:695)."""
+    split = tmp_path / "split"
+    want = set()
+    for contig, ids in (("chr1", [0, 7, 12345]), ("chr_2_x", [3]), ("empty", [])):
+        (split / contig).mkdir(parents=True)
+        for t in ids:
+            body = b"x" * (10 + 3 * t % 97)
+            (split / contig / ("split_%s_%d.tsv" % (contig, t))).write_bytes(body)
+            (split / contig / ("reads_%s_%d.tsv" % (contig, t))).write_bytes(b"r")          # not a split file
+            (split / contig / ("split_%s_%d.fsc" % (contig, t))).write_bytes(b"s")          # a side-car: not listed
+            want.add((contig, t, len(body)))
+    (split / "stray_file.tsv").write_bytes(b"")                                            # a file beside the contig directories
+    contigs, found = _host.discover(str(split))
+    assert sorted(contigs) == ["chr1", "chr_2_x", "empty"]
+    assert set(found) == want and len(found) == len(want)
+    (split / "chr1" / "split_chr1_abc.tsv").write_bytes(b"")                                # int("abc") raises in the reference's main()
+    with pytest.raises(_host.HostError, match="not a number"):
+        _host.discover(str(split))
+    with pytest.raises(_host.HostError):
+        _host.discover(str(tmp_path / "absent"))
+    logs = [str(tmp_path / ("l%d.log" % i)) for i in range(40)]
+    open(logs[3], "w").write("old")
+    _host.touch(logs, n_threads=4)
+    assert all(os.path.getsize(p) == 0 for p in logs)
+    with pytest.raises(_host.HostError):
+        _host.touch([str(tmp_path / "no_such_dir" / "x.log")])
