@@ -1337,8 +1337,16 @@ inline size_t score_lds_for(int nm, int cov_stride) {
 #ifdef FSEG_SCORE_TIMING
 #define FSEG_TPARAM , unsigned long long *tacc
 // diagnostic build: per-problem records behind the 16 phase slots -- (ticks, reads examined, reads with coverage, start tick)
+// where the wave runs: HW_ID's low 16 bits (wave 3:0, SIMD 5:4, pipe 7:6, CU 11:8, SH 12, SE 15:13) | XCC_ID << 16 -- kept in the upper
+// half of the record's second word (tools/prob_ticks.py: who is on which CU when)
+__device__ __forceinline__ unsigned hw_where() {
+    unsigned a, b;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(a));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(b));
+    return (a & 0xffffu) | ((b & 0xfu) << 16);
+}
 #define FSEG_PROB_TICK(P, T0, LN, NA) do { if ((P) < kTaccProbs) { unsigned long long *r_ = tacc + 16 + 4 * (size_t)(P); \
-        r_[0] = wall_clock64() - (T0); r_[1] = (unsigned long long)(LN); r_[2] = (unsigned long long)(NA); r_[3] = (T0); } } while (0)
+        r_[0] = wall_clock64() - (T0); r_[1] = (unsigned long long)(LN) | ((unsigned long long)hw_where() << 32); r_[2] = (unsigned long long)(NA); r_[3] = (T0); } } while (0)
 #define FSEG_T0 unsigned long long t_prev = wall_clock64()
 #define FSEG_TICK(i) do { unsigned long long t_now = wall_clock64(); if (threadIdx.x == 0) atomicAdd(&tacc[i], t_now - t_prev); t_prev = t_now; } while (0)
 #else

@@ -469,7 +469,7 @@ __global__ void __launch_bounds__(64) k_dpw(Status *st, int nm, i64 list_base, i
     const int chain = dp_solve_wave<NM>(n, out_s, in_s, M, A, support, chosen + d.c0 FSEG_DARG);
     if (lane == 0) pr.chain[d.w0] = chain;
 #ifdef FSEG_SCORE_TIMING
-    if (lane == 0 && (size_t)d.w0 < kTaccProbs) { unsigned long long *r_ = tacc + 16 + 4 * kTaccProbs + 4 * (size_t)d.w0; r_[0] = wall_clock64() - t_dp0; r_[3] = t_dp0; }
+    if (lane == 0 && (size_t)d.w0 < kTaccProbs) { unsigned long long *r_ = tacc + 16 + 4 * kTaccProbs + 4 * (size_t)d.w0; r_[0] = wall_clock64() - t_dp0; r_[1] = (unsigned long long)hw_where() << 32; r_[3] = t_dp0; }
 #endif
 }
 
