@@ -540,19 +540,39 @@ def main():
     import torch
     from freddie_amd import _lib
     dist = None
-    if world > 1:
+    coll = None                                         # the group the barriers and the reductions of (time, reads, checksums) use
+    coll_note = None
+    # (FREDDIE_BENCH_FORCE_DIST=1: the process group also for one rank -- how the RCCL branch is rehearsed on a one-GPU box)
+    if world > 1 or os.environ.get("FREDDIE_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # FREDDIE_BENCH_BACKEND=gloo: rehearsal of the multi-rank flow on a box with fewer GPUs than ranks (the ranks share
-        # the GPUs there are); the driver's runs use RCCL, one GPU per rank
+        # The job has no data-path collective: the process group carries the barriers around the timed regions and
+        # one reduction of eleven numbers.  The default group is gloo (host tensors; it comes up wherever TCP to 127.0.0.1 does), and
+        # the barriers and reductions go over RCCL, one GPU per rank, when every rank has seen an RCCL all-reduce of its own work:
+        # a rank whose RCCL does not come up must not cost the node its whole run.  FREDDIE_BENCH_BACKEND=gloo: no RCCL at all -- the
+        # rehearsal of the multi-rank flow on a box with fewer GPUs than ranks (the ranks share the GPUs there are).
         backend = os.environ.get("FREDDIE_BENCH_BACKEND", "nccl")
         if backend == "gloo":
             local_rank = local_rank % max(1, torch.cuda.device_count())
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("gloo")
-        else:
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("gloo")
+        if backend != "gloo":
+            ok, why = 1.0, ""
+            try:
+                coll = dist.new_group(backend="nccl")
+                probe = torch.ones(1, dtype=torch.float64, device="cuda")
+                dist.all_reduce(probe, op=dist.ReduceOp.SUM, group=coll)
+                torch.cuda.synchronize()
+                if int(probe[0].item()) != dist.get_world_size():
+                    ok, why = 0.0, "RCCL all-reduce returned %r on rank %d" % (probe[0].item(), rank)
+            except Exception as exc:                     # noqa: BLE001  (whatever RCCL raises here, the run goes on over gloo)
+                ok, why = 0.0, "%s: %s" % (type(exc).__name__, str(exc)[:200])
+            agreed = torch.tensor([ok], dtype=torch.float64)
+            dist.all_reduce(agreed, op=dist.ReduceOp.MIN)            # (over gloo: every rank takes the same branch)
+            if agreed[0] < 1.0:
+                coll = None
+                coll_note = "gloo (RCCL did not come up on every rank%s)" % ((": " + why) if why else "")
+                print("bench.py rank %d: %s" % (rank, coll_note), file=sys.stderr)
     else:
         torch.cuda.set_device(local_rank)
 
@@ -563,7 +583,7 @@ def main():
 
     def barrier():
         if dist is not None:
-            dist.barrier()
+            dist.barrier(group=coll)
         torch.cuda.synchronize()
 
     # warm-up: W untimed steps (every batch of the share passes W times: buffers reach their final sizes; a batch's
@@ -622,11 +642,11 @@ def main():
     # batch, one host thread per context.  Shares of more batches than contexts go group by group, the uploads between the timed
     # parts.  The checksum is taken from one fetch per context after the timed part.
     n_ctx = len(ctxs)
-    dev_t = "cpu" if dist is not None and dist.get_backend() == "gloo" else "cuda"
+    dev_t = "cuda" if coll is not None else "cpu"
     n_groups = (n_b + n_ctx - 1) // n_ctx
     if dist is not None:
         tg = torch.tensor([float(n_groups)], dtype=torch.float64, device=dev_t)
-        dist.all_reduce(tg, op=dist.ReduceOp.MAX)             # (every rank meets the same barriers)
+        dist.all_reduce(tg, op=dist.ReduceOp.MAX, group=coll)  # (every rank meets the same barriers)
         n_groups = int(tg[0])
     dt_res, reads_res, chk_res, pop_res, sync_timeouts, forked_runs = 0.0, 0, 0, 0, 0, 0
     for gi in range(n_groups):
@@ -676,9 +696,9 @@ def main():
                       float(pop_res), float(sync_timeouts), float(forked_runs)], dtype=torch.float64, device=dev_t)
     if dist is not None:
         tmax = t.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=coll)
         tsum = t.clone()
-        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM, group=coll)
         dt_h2h, reads_h2h, checksum_h2h, label_pop_all = float(tmax[0]), float(tsum[1]), int(tsum[2]), int(tsum[3])
         dt_max, total_reads, checksum_all = float(tmax[4]), float(tsum[5]), int(tsum[6])
         path_bytes_all, pop_res_all, sync_timeouts_all, forked_runs_all = float(tsum[7]), int(tsum[8]), int(tsum[9]), int(tsum[10])
@@ -790,6 +810,8 @@ def main():
             # limit + a rerun of its batch): must be 0; forked_runs = runs that owned the device (side streams in use)
             "sync_timeouts": sync_timeouts_all,
             "forked_runs": forked_runs_all,
+            # what carried the barriers and the reduction of the ranks' (time, reads, checksums): RCCL one GPU per rank, or gloo
+            "rank_sync": None if dist is None else (coll_note or ("rccl" if coll is not None else "gloo")),
             "result_label_popcount_resident": pop_res_all,
             "config": {"workload": args.workload, "partitions": job_parts, "reads": job_reads,
                        "batches_per_step_rank0": n_b, "partitions_per_batch": per, "reads_per_batch": batches[0].n_reads if n_b else 0,

@@ -40,6 +40,7 @@ def test_two_ranks_on_one_gpu_report_the_same_job():
     assert one.returncode == 0, one.stderr[-3000:]
     r1 = _last_json(one.stdout)
     assert r2["n_gpus"] == 2 and r1["n_gpus"] == 1
+    assert r2["rank_sync"] == "gloo" and r1["rank_sync"] is None
     for r in (r1, r2):
         assert r["metric"] == "reads segmented/sec (whole node)" and r["unit"] == "reads/s"
         assert r["scaling"] == "strong" and r["config"]["workload"] == "config4" and r["config"]["reads"] == 2000000
@@ -91,3 +92,21 @@ def test_the_shape_an_eight_gpu_run_has_per_rank(workload, batch_reads, batches_
     assert rn["result_label_popcount"] == r1["result_label_popcount"] > 0
     # (the resident region's label popcounts are compared with the warm-up's per batch INSIDE bench.py; here: every context fetched one)
     assert rn["result_label_popcount_resident"] > 0 and r1["result_label_popcount_resident"] > 0
+
+
+@pytest.mark.gpu
+def test_the_rccl_branch_with_the_one_rank_a_one_gpu_box_allows():
+    """The driver's N > 1 runs carry their barriers and the reduction of (time, reads, checksums) over RCCL, one GPU per rank; two ranks
+    cannot share a card over RCCL, so what can be executed here is that branch with ONE rank (FREDDIE_BENCH_FORCE_DIST=1 under
+    torch.distributed.run): the gloo default group, the RCCL group made beside it, its probe all-reduce, `barrier(group=...)`, the MAX /
+    SUM reductions on device tensors.  The line must say the ranks were synchronised over RCCL and report the job as the plain run does."""
+    env = dict(os.environ, FREDDIE_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", FREDDIE_BENCH_PASSES="2")
+    env.pop("FREDDIE_BENCH_BACKEND", None)
+    run = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                          "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1"] + COMMON,
+                         cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert run.returncode == 0, run.stderr[-3000:]
+    r = _last_json(run.stdout)
+    assert r["rank_sync"] == "rccl", (r["rank_sync"], run.stderr[-2000:])
+    assert r["n_gpus"] == 1 and r["value"] > 0 and r["value_h2h"] > 0 and r["sync_timeouts"] == 0
+    assert r["result_checksum"] == r["result_checksum_h2h"] > 0
