@@ -563,8 +563,10 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
     // host reads the scan's totals before the emit kernel is launched)
     i64 *prob_bs = (c->prob_self_scan && !sized) ? nullptr : c->d_prob_bs.as<i64>();
     if (do_pre1) {
-    HIP_TRY(c, hipMemsetAsync(st, 0, sizeof(Status), s));
-    HIP_TRY(c, hipMemsetAsync(c->d_bits.p, 0, 3 * flag_words(NPOS) * 4, s));        // (the flags are OR-ed in: k_smooth, k_peaks_edges, k_segments, k_refine)
+    {   // Status and the flag planes (OR-ed into: k_smooth, k_peaks_edges, k_segments, k_refine) by one launch (two memsets were three fill kernels)
+        const i64 nw = 3 * (i64)flag_words(NPOS);
+        hipLaunchKernelGGL(k_clear, dim3(grid_for(nw / 4 + 1, 256, 2048)), dim3(256), 0, s, st, c->d_bits.as<unsigned>(), nw);
+    }
     begin(ST_HIST);
     // S1
     hipLaunchKernelGGL(k_hist, dim3(grid_for(c->n_hist_chunks, 1, 16384)), dim3(512), 0, s, c->n_hist_chunks,
@@ -1036,7 +1038,8 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
         c->run_label_packed = lab_packed; c->labels_unpacked = false;
         if (lab_packed) {
             const i64 n16 = sized ? (label_fill_bytes + 15) / 16 : labels_n16;
-            if (n16 > 0) HIP_TRY(c, hipMemsetAsync(c->d_packed.p, 0, (size_t)n16 * 4, s));
+            if (n16 > 0)                                            // (one launch: a hipMemsetAsync of 19 MB is two fill kernels here)
+                hipLaunchKernelGGL(k_clear, dim3(grid_for(n16 / 4 + 1, 256, 4096)), dim3(256), 0, s, (Status *)nullptr, c->d_packed.as<unsigned>(), n16);
         } else if (!ride_fill) {                                    // no DP launch carried the fill
             const i64 n16 = sized ? (label_fill_bytes + 15) / 16 : labels_n16;
             if (n16 > 0)

@@ -336,6 +336,22 @@ __global__ void __launch_bounds__(kSmoothThreads, FSEG_SMOOTH_OCC) k_smooth(int 
 }
 
 
+// The start of a run: Status and the three flag planes (OR-ed into by k_smooth, k_peaks_edges, k_segments, k_refine) zeroed by ONE
+// launch of 4 us (round 6; two hipMemsetAsync until then, which this runtime turns into three fill kernels of ~4 us each in front of
+// k_hist: tools/probes/kernel_ab.sh).
+static_assert(sizeof(Status) % 4 == 0, "k_clear zeroes Status word by word");
+__global__ void __launch_bounds__(256) k_clear(Status *st, unsigned *bits, i64 n_words) {
+    const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x, stride = (i64)gridDim.x * blockDim.x;
+    uint4 *b4 = reinterpret_cast<uint4 *>(bits);                     // (the planes start an allocation: 256-byte aligned)
+    const i64 n4 = n_words >> 2;
+    for (i64 i = t; i < n4; i += stride) b4[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (i64 i = (n4 << 2) + t; i < n_words; i += stride) bits[i] = 0u;
+    if (blockIdx.x == 0 && st) {                                     // (null: the two-bit label arena's clear, labels stage)
+        unsigned *s32 = reinterpret_cast<unsigned *>(st);
+        for (int i = threadIdx.x; i < (int)(sizeof(Status) / 4); i += blockDim.x) s32[i] = 0u;
+    }
+}
+
 // many blocks: three passes (block sums, their scan by one workgroup, emission)
 __global__ void __launch_bounds__(256) k_scan1(const unsigned *flags, i64 n, int *bsum) {
     __shared__ int lds[16];

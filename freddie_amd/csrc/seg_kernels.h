@@ -28,6 +28,9 @@ __global__ void __launch_bounds__(kSmoothThreads, FSEG_SMOOTH_OCC) k_smooth(int 
                                                 int *tile_defer);
 
 // seg_front.hip
+__global__ void __launch_bounds__(256) k_clear(Status *st, unsigned *bits, i64 n_words);
+
+// seg_front.hip
 __global__ void __launch_bounds__(256) k_scan1(const unsigned *flags, i64 n, int *bsum);
 
 // seg_front.hip
