@@ -155,7 +155,8 @@ struct fseg_ctx {
     i64 dpx_base[3] = {0, 0, 0}, dpx_stride[3] = {0, 0, 0}, dpx_n[3] = {0, 0, 0};
     int dpx_nm = 0, dpx_cnt[3] = {1, 1, 1};
     static constexpr i64 kWideOneMax = 256;   // plan 'W' takes a batch's wide problems in one launch when there are at most this many
-    int split_dp = 7;           // FSEG_SPLIT_DP: bit 0 / 1 / 2 = the small / mid / large class hands its DPs to k_dpw (0: the DP stays the tail of k_solve's workgroups)
+    int split_dp = 7;           // FSEG_SPLIT_DP: bit 0 / 1 / 2 = the small / mid / large class hands its DPs to k_dpw (0: the DP stays the tail of k_solve's workgroups);
+                                // bit 3 = the large class's k_dpw by one wave a problem (as the other classes') instead of eight
     i64 prob_cap = 0, work_cap = 0, pair_cap = 0, tri_cap = 0, label_cap = 0, chunk_cap = 0, cov_cap = 0;
     DevBuf d_status, d_prep, d_tacc;
     DevBuf d_sync;               // SyncWords: the scoring stage's device-side fork / join (k_wait_word)
@@ -766,6 +767,12 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
                                c->d_h_table.as<double>(), c->P.h_len, c->P.threshold_rate,               \
                                c->d_thr_tab.as<int2>(), c->P.min_read_support_outside, c->d_chosen.as<unsigned char>(),       \
                                (unsigned char *)nullptr, (i64)0, c->d_wide_all.as<int>() FSEG_TARG)
+#define FSEG_LAUNCH_DPW(Q, NMV, CNT, VT, CLS, N_ITEMS, TT)                                                                   \
+            hipLaunchKernelGGL((k_dpw<NMV, CNT, VT, TT>), dim3(grid_for(FSEG_SOLVE_N(CNT, CLS, N_ITEMS), 1, (int)kSplitGridCap)), dim3(TT),      \
+                               dpw_lds_for(nm_rt, (int)sizeof(VT), (int)sizeof(CNT)), Q, st, nm_rt, list_lb(CLS),                \
+                               FSEG_SOLVE_N(CNT, CLS, list_ln(CLS)), pr,                                                        \
+                               c->d_solve_desc.as<ProbDesc>(), dpx0, dstride, \
+                               c->P.min_read_support_outside, c->d_chosen.as<unsigned char>(), FSEG_SOLVE_WIDE(CNT, CLS) FSEG_TARG)
         // the split path, one instance: k_solve<.., SPLIT> (set-up and rounds) then k_dpw (the DPs) on the same stream
 #define FSEG_LAUNCH_SPLIT(Q, NMV, CNT, VT, CLS, N_ITEMS)                                                                     \
         do { const int nm_rt = (NMV) == kNMax ? c->nm_big : (NMV);                                                            \
@@ -774,11 +781,10 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
             hipLaunchKernelGGL((k_solve<NMV, CNT, int, true>), dim3(grid_for(FSEG_SOLVE_N(CNT, CLS, N_ITEMS), 1, (int)kSplitGridCap)), dim3(SolveCfg<NMV>::kThreads), \
                                solve_lds_for(nm_rt, (NMV) + 1, (int)sizeof(CNT)), Q, FSEG_SOLVE_ARGS(NMV, CNT, CLS), dpx0, dstride, \
                                FSEG_SOLVE_WIDE(CNT, CLS) FSEG_TARG);                                    \
-            if (!g_ablate_dp) hipLaunchKernelGGL((k_dpw<NMV, CNT, VT>), dim3(grid_for(FSEG_SOLVE_N(CNT, CLS, N_ITEMS), 1, (int)kSplitGridCap)), dim3(64),      \
-                               dpw_lds_for(nm_rt, (int)sizeof(VT), (int)sizeof(CNT)), Q, st, nm_rt, list_lb(CLS),                \
-                               FSEG_SOLVE_N(CNT, CLS, list_ln(CLS)), pr,                                                        \
-                               c->d_solve_desc.as<ProbDesc>(), dpx0, dstride, \
-                               c->P.min_read_support_outside, c->d_chosen.as<unsigned char>(), FSEG_SOLVE_WIDE(CNT, CLS) FSEG_TARG); } while (0)
+            if (g_ablate_dp) break;                                                                                               \
+            /* the large class's DPs by workgroups of eight waves (k_dpw<.., 512>: 27 us alone instead of 38; FSEG_SPLIT_DP bit 3: by one) */ \
+            if constexpr ((NMV) == kNMax) { if (!(c->split_dp & 8)) { FSEG_LAUNCH_DPW(Q, NMV, CNT, VT, CLS, N_ITEMS, 512); break; } }      \
+            FSEG_LAUNCH_DPW(Q, NMV, CNT, VT, CLS, N_ITEMS, 64); } while (0)
         // 32-bit DP keys (dp_solve_push) when no sum of a chain can reach 2^24: at most 32 links times the reads of the largest partition
         // (WHICH: 1 = the instance with 8-bit counters, 2 = the one with 16-bit counters if the class has problems for it, 3 = both)
 #define FSEG_LAUNCH_SPLIT_K(Q, NMV, CNT, CLS, N_ITEMS)                                                                        \
@@ -912,6 +918,7 @@ int enqueue_run(fseg_ctx *c, unsigned segs, bool sized = false, i64 label_fill_b
 #undef FSEG_LAUNCH_SOLVE_W
 #undef FSEG_LAUNCH_SOLVE_X
 #undef FSEG_LAUNCH_SPLIT_K
+#undef FSEG_LAUNCH_DPW
 #undef FSEG_LAUNCH_WIDE_ALL
 #undef FSEG_LAUNCH_SPLIT
 #undef FSEG_LAUNCH_SOLVE
@@ -1447,10 +1454,14 @@ int fseg_create(int device, fseg_ctx **out) {
         lds_attr(reinterpret_cast<const void *>(k_solve<kNMax, unsigned short, i64, false>), solve_lds_for(kNMax, kNMax + 1, 2));
         lds_attr(reinterpret_cast<const void *>(k_solve<kNMax, unsigned char, int, true>), solve_lds_for(kNMax, kNMax + 1, 1));
         lds_attr(reinterpret_cast<const void *>(k_solve<kNMax, unsigned short, int, true>), solve_lds_for(kNMax, kNMax + 1, 2));
-        lds_attr(reinterpret_cast<const void *>(k_dpw<kNMax, unsigned char, int>), dpw_lds_for(kNMax, 4, 1));
-        lds_attr(reinterpret_cast<const void *>(k_dpw<kNMax, unsigned short, int>), dpw_lds_for(kNMax, 4, 2));
-        lds_attr(reinterpret_cast<const void *>(k_dpw<kNMax, unsigned char, i64>), dpw_lds_for(kNMax, 8, 1));
-        lds_attr(reinterpret_cast<const void *>(k_dpw<kNMax, unsigned short, i64>), dpw_lds_for(kNMax, 8, 2));
+        lds_attr(reinterpret_cast<const void *>(k_dpw<kNMax, unsigned char, int, 64>), dpw_lds_for(kNMax, 4, 1));
+        lds_attr(reinterpret_cast<const void *>(k_dpw<kNMax, unsigned short, int, 64>), dpw_lds_for(kNMax, 4, 2));
+        lds_attr(reinterpret_cast<const void *>(k_dpw<kNMax, unsigned char, i64, 64>), dpw_lds_for(kNMax, 8, 1));
+        lds_attr(reinterpret_cast<const void *>(k_dpw<kNMax, unsigned short, i64, 64>), dpw_lds_for(kNMax, 8, 2));
+        lds_attr(reinterpret_cast<const void *>(k_dpw<kNMax, unsigned char, int, 512>), dpw_lds_for(kNMax, 4, 1));
+        lds_attr(reinterpret_cast<const void *>(k_dpw<kNMax, unsigned short, int, 512>), dpw_lds_for(kNMax, 4, 2));
+        lds_attr(reinterpret_cast<const void *>(k_dpw<kNMax, unsigned char, i64, 512>), dpw_lds_for(kNMax, 8, 1));
+        lds_attr(reinterpret_cast<const void *>(k_dpw<kNMax, unsigned short, i64, 512>), dpw_lds_for(kNMax, 8, 2));
     }
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_dp_huge), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1473,7 +1484,7 @@ int fseg_create(int device, fseg_ctx **out) {
     if (flag("FSEG_NO_WAVE")) c->use_wave = false;
     if (flag("FSEG_FORCE_KEY64")) c->force_key64 = true;
     if (flag("FSEG_WIDE_BY_SEEN")) c->wide_by_seen = true;
-    if (const char *e = getenv("FSEG_SPLIT_DP")) c->split_dp = atoi(e) & 7;
+    if (const char *e = getenv("FSEG_SPLIT_DP")) c->split_dp = atoi(e) & 15;
     if (const char *e = getenv("FSEG_SCORE_PLAN")) snprintf(c->score_plan, sizeof c->score_plan, "%s", e);
     {
         int seen[4] = {0, 0, 0, 0};

@@ -1093,7 +1093,9 @@ __device__ __forceinline__ void dp_push_dispatch(int ns, int tid, int t2, int t3
 // value and argument kept apart and compare / select through the scalar unit; the bare write-barrier-read is 73 ns).
 // (A gather formulation -- lanes = b, a loop over c2 per lane, blocks of four candidates with a serial in-block fix-up --
 // took 36 us for n = 49.)
-template <int T, int NM, typename OutT, typename V>
+// IN_DEAD: in_s[] is a hand-over of k_solve<.., SPLIT> -- kDeadPair marks the pairs whose segment is too small (:540) and cy_s is not
+// looked at (k_dpw: the candidates' positions are not among what a problem hands over).
+template <int T, int NM, typename OutT, typename V, bool IN_DEAD = false>
 __device__ __forceinline__ int dp_solve_push(int n, const OutT *out_s, const int *in_s, V *M, unsigned char *A, const int *cy_s, int support,
                                              unsigned char *chosen /* + first candidate of the problem */ FSEG_DPARAM) {
     constexpr int SLOTS = (NM * (NM - 1) / 2 + T - 1) / T;
@@ -1117,8 +1119,10 @@ __device__ __forceinline__ int dp_solve_push(int n, const OutT *out_s, const int
         int b, c;
         pair_decode(q < npairs ? q : 0, &b, &c);
         pc[s] = c;
-        live[s] = q < npairs && cy_s[c] - cy_s[b] >= 5;            // "segment too small" (:540)
-        inv[s] = (V)in_s[q < npairs ? q : 0];
+        const int in_q = in_s[q < npairs ? q : 0];
+        if constexpr (IN_DEAD) live[s] = q < npairs && in_q != (int)0x80000000;    // (kDeadPair)
+        else live[s] = q < npairs && cy_s[c] - cy_s[b] >= 5;       // "segment too small" (:540)
+        inv[s] = (V)in_q;
         best[s] = (q < npairs && c == end) ? (V)0 : kNone;         // M(b,end) = in(b,end): the chain's last link (:545-548)
     }
     int t2 = end * (end - 1) / 2, t3 = end * (end - 1) * (end - 2) / 6;

@@ -172,8 +172,8 @@ __global__ void __launch_bounds__(SolveCfg<NM>::kThreads, SolveCfg<NM>::kMinBloc
                                                                   const int *__restrict__ wide_items FSEG_TPARAM);
 
 // seg_score_fused.hip
-template <int NM, typename OutT, typename V>
-__global__ void __launch_bounds__(64) k_dpw(Status *st, int nm, i64 list_base, i64 list_n, ProblemArrays pr, const ProbDesc *desc,
+template <int NM, typename OutT, typename V, int T>
+__global__ void __launch_bounds__(T) k_dpw(Status *st, int nm, i64 list_base, i64 list_n, ProblemArrays pr, const ProbDesc *desc,
                                             const unsigned char *dpx, i64 dpx_stride,
                                             int support, unsigned char *chosen, const int *__restrict__ wide_items FSEG_TPARAM);
 

@@ -420,12 +420,17 @@ __global__ void __launch_bounds__(64) k_probe_wait(const unsigned *word, unsigne
 
 // (k_solve: seg_solve.h, instantiated by seg_solve16 / 32 / 60 .hip)
 
-template <int NM, typename OutT, typename V>
-__global__ void __launch_bounds__(64) k_dpw(Status *st, int nm, i64 list_base, i64 list_n, ProblemArrays pr, const ProbDesc *desc,
+// T > 64 (round 6): the same DP by T threads (dp_solve_push: a column is owners' write, workgroup barrier, a pair or two per thread).
+// The large class's launch takes T = 512: its problems' columns are up to 28 slots of a single wave, and eight waves bring the launch
+// from 38 to 27 us alone, the stage from 0.136 to 0.133 ms on config3 and 0.121 to 0.118 on config5, whose closing chain it is (config4:
+// 0.123 to 0.122).  The mid class stays with one wave: four take its launch from 20.4 to 17.8 us alone and the stage nowhere
+// (tools/probes/dp_waves.sh; two and four waves for the large class: 0.125 / 0.122 against 0.122 / 0.122 with one / eight on config4).
+template <int NM, typename OutT, typename V, int T>
+__global__ void __launch_bounds__(T) k_dpw(Status *st, int nm, i64 list_base, i64 list_n, ProblemArrays pr, const ProbDesc *desc,
                                             const unsigned char *dpx, i64 dpx_stride,
                                             int support, unsigned char *chosen, const int *__restrict__ wide_items FSEG_TPARAM) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int lane = lane_id();
+    const int lane = T == 64 ? lane_id() : (int)threadIdx.x;
     if ((i64)blockIdx.x >= list_n) return;
     const unsigned aborted = stage_aborted(st);
     if (wide_items && aborted) return;                  // (the list of wide problems is an index into the records: not followed blindly)
@@ -447,26 +452,29 @@ __global__ void __launch_bounds__(64) k_dpw(Status *st, int nm, i64 list_base, i
     OutT *out_s = reinterpret_cast<OutT *>(A + (((size_t)rt_pairs + 15) & ~(size_t)15));
     {
         const int *g_in = reinterpret_cast<const int *>(slot + kDpxHeader);
-        for (int q = lane; q < npairs; q += 64) { in_s[q] = g_in[q]; A[q] = (unsigned char)(g_pair_ij[q] >> 8); }
+        for (int q = lane; q < npairs; q += T) { in_s[q] = g_in[q]; A[q] = (unsigned char)(g_pair_ij[q] >> 8); }
         const uint4 *g_out = reinterpret_cast<const uint4 *>(slot + kDpxHeader + dpx_in_bytes(nm));
         uint4 *l_out = reinterpret_cast<uint4 *>(out_s);
         const int n16 = (ntri * (int)sizeof(OutT) + 15) / 16;
-        for (int x0 = 0; x0 < n16; x0 += 64 * 8) {                              // eight 16-byte loads per lane in flight
-            uint4 v[8];
+        constexpr int kInFlight = T == 64 ? 8 : 2;                               // 16-byte loads per thread in flight
+        for (int x0 = 0; x0 < n16; x0 += T * kInFlight) {
+            uint4 v[kInFlight];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const int x = x0 + u * 64 + lane; v[u] = g_out[x < n16 ? x : 0]; }
+            for (int u = 0; u < kInFlight; ++u) { const int x = x0 + u * T + lane; v[u] = g_out[x < n16 ? x : 0]; }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const int x = x0 + u * 64 + lane; if (x < n16) l_out[x] = v[u]; }
+            for (int u = 0; u < kInFlight; ++u) { const int x = x0 + u * T + lane; if (x < n16) l_out[x] = v[u]; }
         }
     }
-    dp_sync<64>();
+    dp_sync<T>();
 #ifdef FSEG_SCORE_TIMING
     __shared__ unsigned long long tick_sink[16];
     unsigned long long *dp_tacc = tick_sink; unsigned long long dt_prev = 0;
 #endif
     // (s_setprio 3 for this wave -- a chain of dependent instructions that its class's chain ends with -- made the stage slower:
     // config3 0.210 -> 0.245-0.270 ms, config4 0.147 -> 0.151)
-    const int chain = dp_solve_wave<NM>(n, out_s, in_s, M, A, support, chosen + d.c0 FSEG_DARG);
+    int chain;
+    if constexpr (T == 64) chain = dp_solve_wave<NM>(n, out_s, in_s, M, A, support, chosen + d.c0 FSEG_DARG);
+    else chain = dp_solve_push<T, NM, OutT, V, true>(n, out_s, in_s, M, A, nullptr, support, chosen + d.c0 FSEG_DARG);
     if (lane == 0) pr.chain[d.w0] = chain;
 #ifdef FSEG_SCORE_TIMING
     if (lane == 0 && (size_t)d.w0 < kTaccProbs) { unsigned long long *r_ = tacc + 16 + 4 * kTaccProbs + 4 * (size_t)d.w0; r_[0] = wall_clock64() - t_dp0; r_[1] = (unsigned long long)hw_where() << 32; r_[3] = t_dp0; }
@@ -479,18 +487,22 @@ __global__ void __launch_bounds__(64) k_dpw(Status *st, int nm, i64 list_base, i
 __attribute__((used)) static const void *const kInstances[] = {
     reinterpret_cast<const void *>(&k_wave<kTiny, int>),
     reinterpret_cast<const void *>(&k_wave<kTiny, i64>),
-    reinterpret_cast<const void *>(&k_dpw<kClsSmall, unsigned char, int>),
-    reinterpret_cast<const void *>(&k_dpw<kClsSmall, unsigned char, i64>),
-    reinterpret_cast<const void *>(&k_dpw<kClsSmall, unsigned short, int>),
-    reinterpret_cast<const void *>(&k_dpw<kClsSmall, unsigned short, i64>),
-    reinterpret_cast<const void *>(&k_dpw<kClsMid, unsigned char, int>),
-    reinterpret_cast<const void *>(&k_dpw<kClsMid, unsigned char, i64>),
-    reinterpret_cast<const void *>(&k_dpw<kClsMid, unsigned short, int>),
-    reinterpret_cast<const void *>(&k_dpw<kClsMid, unsigned short, i64>),
-    reinterpret_cast<const void *>(&k_dpw<kNMax, unsigned char, int>),
-    reinterpret_cast<const void *>(&k_dpw<kNMax, unsigned char, i64>),
-    reinterpret_cast<const void *>(&k_dpw<kNMax, unsigned short, int>),
-    reinterpret_cast<const void *>(&k_dpw<kNMax, unsigned short, i64>),
+    reinterpret_cast<const void *>(&k_dpw<kClsSmall, unsigned char, int, 64>),
+    reinterpret_cast<const void *>(&k_dpw<kClsSmall, unsigned char, i64, 64>),
+    reinterpret_cast<const void *>(&k_dpw<kClsSmall, unsigned short, int, 64>),
+    reinterpret_cast<const void *>(&k_dpw<kClsSmall, unsigned short, i64, 64>),
+    reinterpret_cast<const void *>(&k_dpw<kClsMid, unsigned char, int, 64>),
+    reinterpret_cast<const void *>(&k_dpw<kClsMid, unsigned char, i64, 64>),
+    reinterpret_cast<const void *>(&k_dpw<kClsMid, unsigned short, int, 64>),
+    reinterpret_cast<const void *>(&k_dpw<kClsMid, unsigned short, i64, 64>),
+    reinterpret_cast<const void *>(&k_dpw<kNMax, unsigned char, int, 64>),
+    reinterpret_cast<const void *>(&k_dpw<kNMax, unsigned char, i64, 64>),
+    reinterpret_cast<const void *>(&k_dpw<kNMax, unsigned short, int, 64>),
+    reinterpret_cast<const void *>(&k_dpw<kNMax, unsigned short, i64, 64>),
+    reinterpret_cast<const void *>(&k_dpw<kNMax, unsigned char, int, 512>),
+    reinterpret_cast<const void *>(&k_dpw<kNMax, unsigned char, i64, 512>),
+    reinterpret_cast<const void *>(&k_dpw<kNMax, unsigned short, int, 512>),
+    reinterpret_cast<const void *>(&k_dpw<kNMax, unsigned short, i64, 512>),
 };
 
 }  // namespace fseg

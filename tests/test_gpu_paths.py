@@ -65,6 +65,8 @@ SWITCHES = [
     {"FSEG_SPLIT_DP": "0"},                                 # the DP as the tail of k_solve's workgroups (one wave: dp_solve_wave), no k_dpw
     {"FSEG_SPLIT_DP": "0", "FSEG_FORCE_KEY64": "1"},        # ... with 64-bit keys: the large class's DP by the whole workgroup (dp_solve_push)
     {"FSEG_SPLIT_DP": "5", "FSEG_SCORE_PLAN": "BM|gTS"},    # small and large class split, the mid class fused; round 3's plan
+    {"FSEG_SPLIT_DP": "15"},                                # the large class's k_dpw by one wave a problem (default: eight, dp_solve_push on the handed-over tables)
+    {"FSEG_SPLIT_DP": "7", "FSEG_FORCE_KEY64": "1", "FSEG_FUSE_LANES": "1023", "FSEG_WIDE_BY_SEEN": "1"},   # eight-wave k_dpw: 64-bit keys, 16-bit counters
     {"FSEG_NO_FORK": "1", "FSEG_FORCE_KEY64": "1", "FSEG_FUSE_LANES": "1023"},   # k_dpw with 64-bit keys on one stream, the 16-bit instances behind the 8-bit ones
     {"FSEG_FUSE_LANES": "1023", "FSEG_WIDE_BY_SEEN": "1"},  # wide problems (16-bit counters) through the split path, chosen by the reads they see
     {"FSEG_FUSE_LANES": "1023", "FSEG_WIDE_BY_SEEN": "1", "FSEG_SPLIT_DP": "0"},   # ... and fused: the 16-bit instances go over their classes' wide lists either way
