@@ -546,6 +546,9 @@ def main():
     if world > 1 or os.environ.get("FREDDIE_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:                                   # (FREDDIE_BENCH_FORCE_DIST without a launcher: a group of one)
+            for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_PORT", "29511")):
+                os.environ.setdefault(k, v)
         # The job has no data-path collective: the process group carries the barriers around the timed regions and
         # one reduction of eleven numbers.  The default group is gloo (host tensors; it comes up wherever TCP to 127.0.0.1 does), and
         # the barriers and reductions go over RCCL, one GPU per rank, when every rank has seen an RCCL all-reduce of its own work:
