@@ -34,6 +34,8 @@ Prints ONE JSON line (rank 0) with, besides the driver's fields:
   roofline_config2      one 50 k-read x 2 k-candidate partition (BASELINE configs[1], the arena path): coverage + scoring + DP
                         (interval_scoring = k_cov + k_score, + the dp stage), like the other configs' stage; k_score alone as a sub-field
   roofline_config3 / roofline_config5   the stage of one resident batch of BASELINE configs[2] / [4] (config4 runs only)
+  roofline_whole_job    the stage with the whole job as ONE resident batch (config4: 2 M reads, one launch): what the stage does when the
+                        fork / join and its tail are paid once (config4 runs only)
   value_resident_replay replay of one resident batch (no copies, no sizing; plain launches on the library's streams -- a run
                         that forks is not replayed as a hipGraph: DESIGN.md section 3)
   value_hbm_resident    batches uploaded first, then each run once (first-run path, no copies in the timed part)
@@ -919,6 +921,28 @@ def main():
                           what="one resident batch of %d partitions replayed %d times, the stage alone on the GPU (median)" % (len(parts_x), reps))
                 out["roofline_" + wname] = rx
             ctx.set_params(**params, **tabs)
+            # The same stage with the rank's WHOLE share as one launch (config4 on one GPU: the 2 M-read job, 4 000 partitions, one batch):
+            # the fork / join and the tail of the stage are paid once per launch, and the 250 k-read batches `value` prefers (eight contexts
+            # fill each other's gaps: 540 M reads/s against 504 for the job as one batch on one context) pay them eight times a pass.
+            if args.workload == "config4" and n_b > 1:
+                bw = Batch([p_ for b_ in batches for p_ in b_.parts])
+                ctx.upload(**bw.arrays)
+                ctx.run(); ctx.sync()
+                algw = ctx.scoring_algorithmic_bytes()
+                for _ in range(2):
+                    ctx.run(); ctx.sync()
+                scw, t0 = [], time.perf_counter()
+                for _ in range(10):
+                    ctx.run(); ctx.sync()
+                    scw.append(ctx.stage_ms()["interval_scoring"])
+                dt_w = (time.perf_counter() - t0) / 10
+                rw = scoring_roofline(algw, float(np.median(scw)), None)
+                rw.update(workload=args.workload, reads=bw.n_reads, partitions=len(bw.parts), ms_per_replay=dt_w * 1e3,
+                          reads_per_s_one_context=bw.n_reads / dt_w if dt_w > 0 else 0.0,
+                          what="the rank's whole share as ONE resident batch, one context, replayed 10 times: the stage alone on the GPU (median); "
+                               "`roofline` is the same stage on one of the job's 250 k-read batches")
+                out["roofline_whole_job"] = rw
+                del bw
         if not args.no_cpu_baseline:
             cpu_one = cpu_baseline(batches, params, tabs)
         out["cpu_baseline"] = cpu_one

@@ -16,6 +16,10 @@ for line in sys.stdin:
         if rw:
             print("  %s stage alone %.3f ms frac=%.3f%s" % (w, rw["launch_ms"], rw["frac"],
                   (" (k_score only %.3f)" % rw["k_score_only"]["frac"]) if "k_score_only" in rw else ""))
+    rw = d.get("roofline_whole_job")
+    if rw:
+        print("  the job as ONE batch (%d reads): stage alone %.3f ms frac=%.3f; %.3f ms a replay = %.4gM reads/s on one context" % (
+            rw["reads"], rw["launch_ms"], rw["frac"], rw["ms_per_replay"], rw["reads_per_s_one_context"] / 1e6))
     e = d.get("e2e") or {}
     if "value" in e:
         print("  e2e %.3gM reads/s (%s s)" % (e["value"] / 1e6, ",".join("%.2f" % x for x in e["wall_s"])))
