@@ -4,7 +4,7 @@
 The JOB is fixed: BASELINE config 4 = 4 000 synthetic partitions x 500 reads = 2 000 000 reads (``--workload config5``:
 5 000 x 1 000 reads, sigma 3, threshold rate 0.8), statically scattered over the N ranks (LPT on the partitions' reads,
 freddie_amd/scatter.py -- no collective: partitions share nothing).  A STEP is one pass of the hot path over the rank's
-whole share of the job, cut into batches of about 250 k reads (N = 1: 8 batches, N = 8: 1) that take turns on the contexts of the
+whole share of the job, cut into batches of about 1 M reads (N = 1: 2 batches, N >= 2: 1) that take turns on the contexts of the
 GPU (eight by default); since round 6 a step is PASSES_PER_STEP = 16 such passes (a timed region of 20 steps is then 1.2 s instead of
 0.076 s; reads are counted per pass, so `value` is unchanged by it).  It is timed twice, K steps each, between barriers:
   value               with the inputs RESIDENT IN HBM when the timed part starts (every context holds a batch of the share;
@@ -63,7 +63,9 @@ sys.path.insert(0, ROOT)
 from freddie_amd import pack, synth, tables  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-BATCH_READS = int(os.environ.get("FREDDIE_BENCH_BATCH_READS", "250000"))      # (the override: tuning runs only)
+# (1 M reads since the end of round 6, 250 k until then: with eight contexts the job in two batches runs at 576 M reads/s resident and 413 M host
+# memory -> host memory against 539 / 368 in eight -- every launch pays its stage tails and its fork / join once; the override: tuning runs)
+BATCH_READS = int(os.environ.get("FREDDIE_BENCH_BATCH_READS", "1000000"))
 # A STEP is this many passes over the job (round 6; until round 5: one).  One pass of the 2 M-read job takes 3.8 ms on one GPU, so the
 # driver's 20 steps were a timed region of 0.076 s -- too short for anything that samples the GPU from outside.  Reads are counted
 # per pass: `value` does not depend on this number, `ms_per_step` is the time of PASSES_PER_STEP passes.
@@ -533,7 +535,7 @@ def main():
     if rank == 0 and not args.no_extras and args.workload == "config4":
         for wname in ("config3", "config5"):             # one batch of each (the line carries every config's stage fraction)
             wx = dict(synth.WORKLOADS[wname]); wx.pop("n_partitions")
-            per_x = max(1, BATCH_READS // wx["n_reads"])
+            per_x = max(1, min(synth.WORKLOADS[wname]["n_partitions"], BATCH_READS // wx["n_reads"]))     # (config3's whole job is 500 partitions)
             extra_parts[wname] = []
             for i in range(per_x):
                 g = synth.generate(i, with_seq=False, **wx)
@@ -737,10 +739,10 @@ def main():
         sc_med = float(np.median(sc_all))                      # (the median, like the per-kernel medians of profiles/)
         roofline = scoring_roofline(batches[0].alg_bytes, sc_med, committed,
                                     {"measured": "HIP events around the stage's launches on the library's streams; one context, one resident "
-                                                 "250 k-read batch of the job replayed %d times: the stage alone on the GPU (median; mean %.4f ms). "
+                                                 "batch of the job (%d reads) replayed %d times: the stage alone on the GPU (median; mean %.4f ms). "
                                                  "The stream plan and k_gate apply to this case only: in the timed steps (value) eight contexts "
                                                  "take turns and each keeps its stage on one stream -- that bracket is roofline_concurrent"
-                                                 % (reps, float(np.mean(sc_all)))})
+                                                 % (batches[0].n_reads, reps, float(np.mean(sc_all)))})
 
         # ---- every stage alone on the GPU: distinct batches through the first-run path (plain launches, events around every stage)
         ctx.set_profiling(True)
@@ -841,7 +843,7 @@ def main():
             "result_label_popcount": label_pop_all,
         }
         out["value_resident_replay"] = {"value": batches[0].n_reads * reps / dt_r, "unit": "reads/s", "ms_per_step": dt_r / reps * 1e3,
-                                        "what": "replay of one resident 250 k-read batch: no copies, no arena sizing (a batch, not the job)"}
+                                        "what": "replay of one resident batch of the job (%d reads): no copies, no arena sizing (a batch, not the job)" % batches[0].n_reads}
         if not args.no_extras:
             # inputs resident in HBM before the timed part, every batch run ONCE on the first-run path: one batch per
             # context uploaded, then all of them run (one host thread per context, as in the timed steps), results left in HBM
@@ -922,8 +924,8 @@ def main():
                 out["roofline_" + wname] = rx
             ctx.set_params(**params, **tabs)
             # The same stage with the rank's WHOLE share as one launch (config4 on one GPU: the 2 M-read job, 4 000 partitions, one batch):
-            # the fork / join and the tail of the stage are paid once per launch, and the 250 k-read batches `value` prefers (eight contexts
-            # fill each other's gaps: 540 M reads/s against 504 for the job as one batch on one context) pay them eight times a pass.
+            # the fork / join and the tail of the stage are paid once per launch (250 k-read batches: 0.34-0.35 of the roofline, 1 M: 0.354,
+            # the job: 0.38; `value` itself wants eight contexts that fill each other's gaps, and 8 x 2 M reads would be 190 GB of HBM).
             if args.workload == "config4" and n_b > 1:
                 bw = Batch([p_ for b_ in batches for p_ in b_.parts])
                 ctx.upload(**bw.arrays)
@@ -940,7 +942,7 @@ def main():
                 rw.update(workload=args.workload, reads=bw.n_reads, partitions=len(bw.parts), ms_per_replay=dt_w * 1e3,
                           reads_per_s_one_context=bw.n_reads / dt_w if dt_w > 0 else 0.0,
                           what="the rank's whole share as ONE resident batch, one context, replayed 10 times: the stage alone on the GPU (median); "
-                               "`roofline` is the same stage on one of the job's 250 k-read batches")
+                               "`roofline` is the same stage on one of the job's batches")
                 out["roofline_whole_job"] = rw
                 del bw
         if not args.no_cpu_baseline:

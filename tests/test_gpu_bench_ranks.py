@@ -45,7 +45,7 @@ def test_two_ranks_on_one_gpu_report_the_same_job():
         assert r["metric"] == "reads segmented/sec (whole node)" and r["unit"] == "reads/s"
         assert r["scaling"] == "strong" and r["config"]["workload"] == "config4" and r["config"]["reads"] == 2000000
         assert r["steps"] == 2 and r["value"] > 0
-    assert r2["config"]["batches_per_step_rank0"] == 4 and r1["config"]["batches_per_step_rank0"] == 8
+    assert r2["config"]["batches_per_step_rank0"] == 1 and r1["config"]["batches_per_step_rank0"] == 2     # (batches of 1 M reads; two contexts)
     assert r2["result_checksum"] == r1["result_checksum"] and r1["result_checksum"] > 0
     # (both timed regions pass over the same job K times: resident inputs -- `value` -- and host memory -> host memory)
     for r in (r1, r2):
@@ -78,7 +78,7 @@ def _ranks(n, workload, env_extra):
 def test_the_shape_an_eight_gpu_run_has_per_rank(workload, batch_reads, batches_rank0):
     """What the driver's N = 8 run will be the first to execute on hardware, rehearsed within this pool's limit of six processes on
     a card: FOUR gloo ranks on the one GPU, eight contexts each.  (a) config4 with batches of 500 k reads: every rank's share is
-    ONE batch and its eight contexts all hold it -- at N = 8 with the default 250 k-read batches every rank is in exactly this
+    ONE batch and its eight contexts all hold it -- with the default batches of 1 M reads every rank of an N >= 2 run is in exactly this
     position (bench.py: `n_b < n_ctx`, context k holds batch k mod n_b, a pass's runs dealt out over a batch's holders);
     (b) config5: five batches on eight contexts, three of them held twice.  The job is fixed: checksum of final positions and the
     labels' popcount must be the one-rank run's, no waiter may time out, the line says strong scaling over 4 GPUs."""
