@@ -4,7 +4,7 @@
 The JOB is fixed: BASELINE config 4 = 4 000 synthetic partitions x 500 reads = 2 000 000 reads (``--workload config5``:
 5 000 x 1 000 reads, sigma 3, threshold rate 0.8), statically scattered over the N ranks (LPT on the partitions' reads,
 freddie_amd/scatter.py -- no collective: partitions share nothing).  A STEP is one pass of the hot path over the rank's
-whole share of the job, cut into batches of about 1 M reads (N = 1: 2 batches, N >= 2: 1) that take turns on the contexts of the
+whole share of the job as ONE batch of up to 2 M reads (where HBM allows eight contexts to hold it: BATCH_READS) that takes turns on the contexts of the
 GPU (eight by default); since round 6 a step is PASSES_PER_STEP = 16 such passes (a timed region of 20 steps is then 1.2 s instead of
 0.076 s; reads are counted per pass, so `value` is unchanged by it).  It is timed twice, K steps each, between barriers:
   value               with the inputs RESIDENT IN HBM when the timed part starts (every context holds a batch of the share;
@@ -63,9 +63,55 @@ sys.path.insert(0, ROOT)
 from freddie_amd import pack, synth, tables  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-# (1 M reads since the end of round 6, 250 k until then: with eight contexts the job in two batches runs at 576 M reads/s resident and 413 M host
-# memory -> host memory against 539 / 368 in eight -- every launch pays its stage tails and its fork / join once; the override: tuning runs)
-BATCH_READS = int(os.environ.get("FREDDIE_BENCH_BATCH_READS", "1000000"))
+# Reads of a batch.  With eight contexts (one box, reads/s resident / host memory -> host memory, the stage alone as a fraction of the HBM roofline):
+# 250 k (rounds 2-6): 539 M / 368 M, 0.345;  500 k: 560 / 394;  1 M: 576 / 381-413, 0.354;  2 M = the whole job as ONE batch that all eight
+# contexts hold: 578 / 398-415, 0.383 -- every launch pays its stages' tails and the scoring stage's fork / join once.  A context that holds the
+# 2 M-read job takes 26.4 GB of HBM (13.2 KB a read: 116 B a position), eight of them 211 of the card's 309 GB: the default is the whole job
+# where the cards' free memory (sysfs, no HIP call: this is decided before anything forks) allows it, half of it and so on otherwise.
+HBM_BYTES_PER_READ = 14000          # (config4, rounded up; the 1 000-read partitions of config3 / config5 take half of it)
+
+
+def hbm_free_bytes():
+    """The least free VRAM over the GPUs this process could use, without a HIP call in this process: the KFD topology's GPU nodes whose
+    render node is accessible (freddie_amd/devices.py: on a shared host sysfs shows every tenant's card), amdgpu's mem_info_vram_* of
+    each; a child process that asks the runtime where sysfs does not say; None where neither does."""
+    from freddie_amd import devices
+    free = []
+    for _, props in (devices._kfd_gpu_nodes() or []):
+        minor = props.get("drm_render_minor", -1)
+        if minor < 0 or not devices._usable(props):
+            continue
+        try:
+            base = "/sys/class/drm/renderD%d/device/mem_info_vram_" % minor
+            free.append(int(open(base + "total").read()) - int(open(base + "used").read()))
+        except (OSError, ValueError):
+            pass
+    if free:
+        return min(free)
+    code = ("import ctypes\n"
+            "L=ctypes.CDLL('libamdhip64.so'); n=ctypes.c_int(0); out=[]\n"
+            "if L.hipGetDeviceCount(ctypes.byref(n))==0:\n"
+            "    for d in range(n.value):\n"
+            "        f=ctypes.c_size_t(0); t=ctypes.c_size_t(0)\n"
+            "        if L.hipSetDevice(d)==0 and L.hipMemGetInfo(ctypes.byref(f),ctypes.byref(t))==0: out.append(f.value)\n"
+            "print(min(out) if out else -1)\n")
+    try:
+        v = int(subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120).stdout.strip() or -1)
+        return v if v > 0 else None
+    except (OSError, ValueError, subprocess.TimeoutExpired):
+        return None
+
+
+def default_batch_reads(contexts=8, want=2000000):
+    free = hbm_free_bytes()
+    if free is None:
+        return 1000000                                   # (nothing known about the card: what 96 GB hold)
+    while want > 250000 and want * HBM_BYTES_PER_READ * contexts > 0.8 * free:
+        want //= 2
+    return want
+
+
+BATCH_READS = int(os.environ.get("FREDDIE_BENCH_BATCH_READS", "0")) or default_batch_reads()      # (the override: tuning runs and tests)
 # A STEP is this many passes over the job (round 6; until round 5: one).  One pass of the 2 M-read job takes 3.8 ms on one GPU, so the
 # driver's 20 steps were a timed region of 0.076 s -- too short for anything that samples the GPU from outside.  Reads are counted
 # per pass: `value` does not depend on this number, `ms_per_step` is the time of PASSES_PER_STEP passes.

@@ -29,14 +29,15 @@ def _last_json(out):
 
 @pytest.mark.gpu
 def test_two_ranks_on_one_gpu_report_the_same_job():
-    env = dict(os.environ, FREDDIE_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # (batches of 1 M reads: by default a batch is the whole job where the card has the memory for eight contexts that hold it)
+    env = dict(os.environ, FREDDIE_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", FREDDIE_BENCH_BATCH_READS="1000000")
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + COMMON,
                          cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert two.returncode == 0, two.stderr[-3000:]
     r2 = _last_json(two.stdout)
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + COMMON,
-                         cwd=ROOT, env=os.environ.copy(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+                         cwd=ROOT, env=dict(os.environ, FREDDIE_BENCH_BATCH_READS="1000000"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert one.returncode == 0, one.stderr[-3000:]
     r1 = _last_json(one.stdout)
     assert r2["n_gpus"] == 2 and r1["n_gpus"] == 1
